@@ -1,0 +1,141 @@
+/*
+ * qt_hip.h — C-ABI of libqt_hip.so, the MI355X (gfx950) backend for the QuantTorch
+ * quantised-operator hot path:  sign / ternarize / k-bit quantize  ->  bit-pack  ->
+ * XNOR-popcount GEMM (BinaryNet / XNOR-Net), two-plane ternary GEMM, packed low-bit GEMM.
+ *
+ * This header is the drop-in boundary.  Everything above it (the autograd.Function /
+ * nn.Module mirror of QuantTorch.functions / QuantTorch.layers) is host plumbing.
+ *
+ * Conventions (all entry points):
+ *   - plain `extern "C"`, raw DEVICE pointers + explicit sizes/strides, no torch types;
+ *   - stateless and re-entrant: no allocation, no ownership transfer, no global state;
+ *   - work is enqueued on `stream` (a hipStream_t, passed as an opaque pointer; NULL = the
+ *     default stream) and the call returns without synchronising;
+ *   - the caller has already made the right device current (hipSetDevice);
+ *   - return value: QT_OK (0) or a negative qt_status; qt_strerror() names it.
+ *   - "ld*" arguments are leading dimensions IN ELEMENTS of that buffer's type.
+ *
+ * Packed formats (defined by this library, see DESIGN.md "Data layout in HBM"):
+ *   bit plane  : uint32 words along K, bit j of word w <-> element k = 32*w + j.
+ *                sign plane bit = 1  <=>  value < 0   (so +0.0, -0.0, NaN -> bit 0 -> +1,
+ *                exactly the reference's safeSign, QuantTorch/functions/common.py:4-7).
+ *                mask plane bit = 1  <=>  ternary value != 0.
+ *                Row stride ("ldp", in words) must be a multiple of 4 (16-byte rows);
+ *                every bit/word between K and 32*ldp is ZERO in every plane.
+ *   nib plane  : FP4-E2M1 nibbles (two per byte, element 2i in the low nibble), value set
+ *                {+1 = 0x2, -1 = 0xA, 0 = 0x0}; 8 elements per uint32 word.  Row stride in
+ *                words must be a multiple of 8 (K padded to 64 with zero nibbles).  This is
+ *                the MFMA operand format (v_mfma_scale_f32_32x32x64_f8f6f4, exact for +-1/0).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo root):
+ *   the reference has NO native code; the functions below replace the ATen calls made from
+ *   QuantTorch/functions and QuantTorch/layers (all .py files) that are cited per entry point.
+ */
+#ifndef QT_HIP_H
+#define QT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* qt_stream_t; /* hipStream_t */
+
+typedef enum qt_status {
+    QT_OK = 0,
+    QT_ERR_INVALID_ARG = -1,  /* null pointer, negative size, inconsistent shape            */
+    QT_ERR_ALIGNMENT = -2,    /* pointer / leading dimension violates the packed-format rule */
+    QT_ERR_LAUNCH = -3,       /* hipLaunchKernel / hipGetLastError reported a failure        */
+    QT_ERR_UNSUPPORTED = -4,  /* argument combination not implemented                        */
+    QT_ERR_NO_DEVICE = -5     /* no gfx950 device / wrong architecture                        */
+} qt_status;
+
+/* Library identification. qt_version() = major*10000 + minor*100 + patch. */
+int qt_version(void);
+const char* qt_strerror(int status);
+/* Name of the gfx arch the code objects were built for ("gfx950"). */
+const char* qt_target_arch(void);
+/* Fills name[cap] with the current device's gcnArchName, returns CU count (<0 on error). */
+int qt_device_info(char* name, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise quantisers (fp32 -> fp32), forward and STE backward.
+ * ---------------------------------------------------------------------------------------- */
+
+/* y[i] = x[i] < 0 ? -1 : +1.            safeSign, QuantTorch/functions/common.py:4-7;
+ * forward of BinaryConnectDeterministic, functions/binary_connect.py:22-28. */
+int qt_binarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream);
+
+/* y[i] = z[i] < (clamp(x[i],-1,1)+1)/2 ? +1 : -1 with caller-supplied uniforms z in [0,1).
+ * forward of BinaryConnectStochastic, functions/binary_connect.py:52-61 (the RNG draw
+ * `torch.rand_like` stays on the torch side so the stream of randoms is torch's). */
+int qt_binarize_stochastic_f32(const float* x, const float* z, float* y, int64_t n,
+                               qt_stream_t stream);
+
+/* y[i] = x >= 0.5 ? +1 : (x < -0.5 ? -1 : 0)   (NaN -> +1, as the reference's double safeSign)
+ * forward of TernaryConnectDeterministic, functions/terner_connect.py:24-27. */
+int qt_ternarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream);
+
+/* y[i] = s - s*(z[i] > |x[i]|),  s = safeSign(x[i]).
+ * forward of TernaryConnectStochastic, functions/terner_connect.py:52-56. */
+int qt_ternarize_stochastic_f32(const float* x, const float* z, float* y, int64_t n,
+                                qt_stream_t stream);
+
+/* gin[i] = |x[i]| > thr ? 0 : gout[i]     (thr = 1.001f in every reference caller)
+ * backward of Binary/TernaryConnect{Deterministic,Stochastic},
+ * functions/binary_connect.py:31-38,64-71; functions/terner_connect.py:29-34,58-63. */
+int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, float thr,
+                    qt_stream_t stream);
+
+/* DoReFa k-bit quantiser: k==1 -> safeSign; k==32 -> copy; else
+ * y = fl(fl(1/n) * rint(n*x)), n = 2^k - 1, round-half-even, NO clamp.
+ * _quantize, functions/dorefa_connect.py:11-25. */
+int qt_dorefa_quantize_f32(const float* x, float* y, int64_t n, int bit_width,
+                           qt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bit-pack kernels (fp32 -> packed planes).  rows x K fp32 (row stride ldx) ->
+ * rows x ldp uint32 (only the first ceil(K/32) words of a row carry data, the rest are 0).
+ * ---------------------------------------------------------------------------------------- */
+
+/* sign plane of safeSign(x): bit = (x < 0).  If y_f32 != NULL the +-1 fp32 image is written too
+ * (row stride ldy) — one pass for BinaryConnectDeterministic.forward + the pack that feeds the
+ * next layer (functions/binary_connect.py:22-28 followed by layers/binary_layers.py:44). */
+int qt_sign_pack_f32(const float* x, int64_t ldx, uint32_t* sign_plane, int64_t ldp,
+                     float* y_f32, int64_t ldy, int64_t rows, int64_t K, qt_stream_t stream);
+
+/* ternary planes of TernaryConnectDeterministic(x): mask = (x>=0.5 || x<-0.5 || isnan),
+ * sign = (x < -0.5).  functions/terner_connect.py:24-27 + layers/terner_layers.py:49. */
+int qt_ternary_pack_f32(const float* x, int64_t ldx, uint32_t* mask_plane, uint32_t* sign_plane,
+                        int64_t ldp, int64_t rows, int64_t K, qt_stream_t stream);
+
+/* Device-side check used when a layer receives an un-tagged activation tensor:
+ * *flag (int32, device) is OR-ed with 1 if any element of x is not exactly +1.0f or -1.0f.
+ * The caller zeroes *flag beforehand. */
+int qt_check_pm1_f32(const float* x, int64_t n, int32_t* flag, qt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Packed GEMMs.  Y[M,N] (fp32, row stride ldy) = dot over K of the +-1 / {-1,0,+1} values the
+ * planes encode, + bias[n] (bias may be NULL).  Replaces torch.nn.functional.linear on
+ * quantised operands: layers/binary_layers.py:44,46; layers/terner_layers.py:49,51;
+ * functions/binary_connect.py:93-98 (BinaryDense); functions/terner_connect.py:92-94.
+ * Integer part is exact (int32 accumulate), converted to fp32 once, bias added once.
+ * ---------------------------------------------------------------------------------------- */
+
+/* XNOR-popcount GEMM (VALU path: v_xor_b32 + v_bcnt_u32_b32, LDS-staged tiles).
+ * Xs: M x ldxp sign plane of the activations, Ws: N x ldwp sign plane of the weights.
+ * y = K - 2*popcount(x ^ w). */
+int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
+                 const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                 qt_stream_t stream);
+
+/* Binary activations x ternary weights (two planes): y = popc(m) - 2*popc((x ^ s) & m). */
+int qt_tern_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
+                 int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
+                 int64_t K, qt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QT_HIP_H */

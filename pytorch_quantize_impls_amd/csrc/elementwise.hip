@@ -1,0 +1,152 @@
+// Elementwise quantisers and STE masks (fp32 -> fp32).  All HBM-bound: 16-byte loads/stores per
+// lane, grid-stride, scalar head/tail so any pointer alignment and any n is accepted.
+#include "qt_common.h"
+
+namespace {
+
+struct OpBinarize {
+    __device__ __forceinline__ float operator()(float x) const { return qt_safe_sign(x); }
+};
+struct OpTernarize {
+    __device__ __forceinline__ float operator()(float x) const { return qt_ternarize(x); }
+};
+// _quantize, functions/dorefa_connect.py:24-25:  (1/(2^k-1)) * round((2^k-1) * x).
+// torch.round is round-half-even -> rintf under the default rounding mode.  The reciprocal is
+// computed in fp32 first (fl(1/n)), then multiplied: NOT r/n (differs in the last ulp).
+struct OpDorefa {
+    float n, inv_n;
+    __device__ __forceinline__ float operator()(float x) const { return inv_n * rintf(n * x); }
+};
+struct OpCopy {
+    __device__ __forceinline__ float operator()(float x) const { return x; }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x,
+                                                    float* __restrict__ y, int64_t n, int64_t head,
+                                                    Op op) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    // scalar head up to the first 16-byte boundary of x (y shares x's misalignment or we were
+    // launched with head = n, i.e. fully scalar)
+    for (int64_t i = tid; i < head; i += nthreads) y[i] = op(x[i]);
+    const int64_t n4 = (n - head) / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x + head);
+    float4* y4 = reinterpret_cast<float4*>(y + head);
+    for (int64_t i = tid; i < n4; i += nthreads) {
+        float4 v = x4[i];
+        float4 r;
+        r.x = op(v.x); r.y = op(v.y); r.z = op(v.z); r.w = op(v.w);
+        y4[i] = r;
+    }
+    for (int64_t i = head + n4 * 4 + tid; i < n; i += nthreads) y[i] = op(x[i]);
+}
+
+struct Op2BinStoch {  // -1 + 2*[z < (clamp(x,-1,1)+1)/2]   binary_connect.py:57-61
+    __device__ __forceinline__ float operator()(float x, float z) const {
+        const float c = fminf(fmaxf(x, -1.0f), 1.0f);
+        // NaN: torch.clamp propagates NaN -> p = NaN -> (z < p) false -> -1.  fmaxf/fminf drop the
+        // NaN, so restore it explicitly.
+        const float p = (x != x) ? x : (c + 1.0f) / 2.0f;
+        return (z < p) ? 1.0f : -1.0f;
+    }
+};
+struct Op2TerStoch {  // s - s*[z > |x|]   terner_connect.py:54-56
+    __device__ __forceinline__ float operator()(float x, float z) const {
+        const float s = qt_safe_sign(x);
+        return s - s * ((z > fabsf(x)) ? 1.0f : 0.0f);
+    }
+};
+struct Op2SteMask {  // g * [|x| <= thr]  (NaN input keeps g: |NaN| > thr is false)
+    float thr;
+    __device__ __forceinline__ float operator()(float g, float x) const {
+        return (fabsf(x) > thr) ? 0.0f : g;
+    }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a,
+                                                     const float* __restrict__ b,
+                                                     float* __restrict__ y, int64_t n, int vec,
+                                                     Op op) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (int64_t i = tid; i < n4; i += nthreads) {
+        float4 u = a4[i], v = b4[i], r;
+        r.x = op(u.x, v.x); r.y = op(u.y, v.y); r.z = op(u.z, v.z); r.w = op(u.w, v.w);
+        y4[i] = r;
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += nthreads) y[i] = op(a[i], b[i]);
+}
+
+template <class Op>
+int launch_unary(const float* x, float* y, int64_t n, qt_stream_t stream, Op op) {
+    if (n < 0 || (n > 0 && (!x || !y))) return QT_ERR_INVALID_ARG;
+    if (n == 0) return QT_OK;
+    // vector body needs x and y to share their offset from a 16-byte boundary
+    const uintptr_t ax = reinterpret_cast<uintptr_t>(x) & 15u, ay = reinterpret_cast<uintptr_t>(y) & 15u;
+    int64_t head = n;
+    if (ax == ay && (ax & 3u) == 0) head = ax ? (int64_t)((16 - ax) / 4) : 0;
+    if (head > n) head = n;
+    const int grid = qt_stream_grid((n + 1023) / 1024);
+    hipLaunchKernelGGL(unary_kernel<Op>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n,
+                       head, op);
+    return qt_check_launch();
+}
+
+template <class Op>
+int launch_binary(const float* a, const float* b, float* y, int64_t n, qt_stream_t stream, Op op) {
+    if (n < 0 || (n > 0 && (!a || !b || !y))) return QT_ERR_INVALID_ARG;
+    if (n == 0) return QT_OK;
+    const int vec = qt_aligned16(a) && qt_aligned16(b) && qt_aligned16(y);
+    const int grid = qt_stream_grid((n + 1023) / 1024);
+    hipLaunchKernelGGL(binary_kernel<Op>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                       n, vec, op);
+    return qt_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_binarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream) {
+    return launch_unary(x, y, n, stream, OpBinarize{});
+}
+
+int qt_ternarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream) {
+    return launch_unary(x, y, n, stream, OpTernarize{});
+}
+
+int qt_dorefa_quantize_f32(const float* x, float* y, int64_t n, int bit_width,
+                           qt_stream_t stream) {
+    if (bit_width < 1 || bit_width > 32) return QT_ERR_INVALID_ARG;
+    if (bit_width == 1) return launch_unary(x, y, n, stream, OpBinarize{});
+    if (bit_width == 32) return launch_unary(x, y, n, stream, OpCopy{});
+    // the reference builds 2^k with torch.pow on fp32 tensors: exact for k <= 24, and for
+    // 25..31 the fp32 value of 2^k - 1 rounds to 2^k; mirror that by forming it in fp32.
+    const float two_k = (float)(1ull << bit_width);
+    const float nf = two_k - 1.0f;
+    OpDorefa op{nf, 1.0f / nf};
+    return launch_unary(x, y, n, stream, op);
+}
+
+int qt_binarize_stochastic_f32(const float* x, const float* z, float* y, int64_t n,
+                               qt_stream_t stream) {
+    return launch_binary(x, z, y, n, stream, Op2BinStoch{});
+}
+
+int qt_ternarize_stochastic_f32(const float* x, const float* z, float* y, int64_t n,
+                                qt_stream_t stream) {
+    return launch_binary(x, z, y, n, stream, Op2TerStoch{});
+}
+
+int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, float thr,
+                    qt_stream_t stream) {
+    return launch_binary(gout, x, gin, n, stream, Op2SteMask{thr});
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""Forward dispatch shared by the quantised Linear / Conv2d layers and the fused Function forms.
+
+Reference call sites this replaces (all ``torch.nn.functional.linear / conv2d`` on a quantised
+weight): layers/binary_layers.py:44,46,105,106; layers/terner_layers.py:49,51,91,92;
+functions/binary_connect.py:93-98,128-131; functions/terner_connect.py:92-94.
+
+Device tensors:
+  * activation known to be +-1 (bit planes attached by the quantiser, or verified on device)
+        -> bit-pack the weight, XNOR-popcount / ternary GEMM in libqt_hip.so;
+  * arbitrary fp32 activation (first layer of every model)
+        -> weight quantised by the HIP elementwise kernel, contraction by the dense fp32 GEMM
+           library (the values are exact +-1/0, so this is the reference computation itself).
+CPU tensors: the same expression in torch (host logic; never used for a device tensor).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops, packed
+
+#: When True (default) an un-tagged device activation is checked on the device for being exactly
+#: +-1 before the packed path is taken (costs one read of the activation and one host sync).
+#: A layer can override per instance with its ``binary_input`` attribute (True / False / None).
+DETECT_BINARY_INPUT = True
+
+
+def _safe_sign_t(w: torch.Tensor) -> torch.Tensor:
+    one = torch.ones((), dtype=w.dtype, device=w.device)
+    return torch.where(w < 0, -one, one)
+
+
+def quantize_weight_f32(weight: torch.Tensor, kind: str) -> torch.Tensor:
+    """fp32 image of the deterministic weight quantiser of a layer family."""
+    if kind == "binary":  # safeSign, functions/common.py:4-7
+        return ops.binarize(weight) if weight.is_cuda else _safe_sign_t(weight)
+    if kind == "ternary":  # functions/terner_connect.py:26-27
+        if weight.is_cuda:
+            return ops.ternarize(weight)
+        s = _safe_sign_t(weight)
+        return (s + _safe_sign_t(weight - 0.5 * s)) / 2
+    raise ValueError(f"unknown quantiser kind {kind!r}")
+
+
+def pack_weight(weight_2d: torch.Tensor, kind: str) -> ops.BitPlanes:
+    """Bit planes of the deterministic quantiser applied to a [N, K] device weight.  Both
+    quantisers are idempotent, so this is also right for an already-quantised (eval / stochastic)
+    weight image."""
+    if kind == "binary":
+        return ops.sign_pack(weight_2d)[0]
+    if kind == "ternary":
+        return ops.ternary_pack(weight_2d)
+    raise ValueError(f"unknown quantiser kind {kind!r}")
+
+
+def activation_planes(input: torch.Tensor, binary_input: Optional[bool]) -> Optional[ops.BitPlanes]:
+    """Sign planes of a device activation if it is (known to be) exactly +-1, else None."""
+    if input.dtype != torch.float32 or input.numel() == 0:
+        return None
+    tagged = packed.lookup(input, packed.ROWS_LAST)
+    if tagged is not None:
+        return tagged
+    if binary_input is False:
+        return None
+    if binary_input is None:
+        if not DETECT_BINARY_INPUT:
+            return None
+        if int(ops.check_pm1(input).item()) != 0:  # host sync: only for un-tagged inputs
+            return None
+    return ops.sign_pack(input)[0]
+
+
+def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                         kind: str, weight_q: Optional[torch.Tensor] = None,
+                         weight_planes: Optional[ops.BitPlanes] = None,
+                         binary_input: Optional[bool] = None) -> torch.Tensor:
+    """y = input . Q(weight)^T + bias.
+
+    ``weight_q``: explicit fp32 quantised weight (stochastic draw, or eval-mode pre-quantised
+    weight); ``weight_planes``: cached planes of that same quantised weight.
+    """
+    if not input.is_cuda:
+        wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+        return F.linear(input, wq, bias)
+
+    xp = activation_planes(input, binary_input)
+    if xp is not None:
+        K = input.shape[-1]
+        if xp.K != K or xp.rows * K != input.numel():
+            xp = ops.sign_pack(input)[0]
+        wp = weight_planes
+        if wp is None:
+            wp = pack_weight(weight_q if weight_q is not None else weight, kind)
+        y = ops.xnor_gemm(xp, wp, bias) if kind == "binary" else ops.tern_gemm(xp, wp, bias)
+        return y.view(*input.shape[:-1], wp.rows)
+
+    wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+    return F.linear(input, wq, bias)
+
+
+def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
+                         weight_q: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv2d(input, Q(weight), bias, ...).  Weight quantisation runs in the HIP elementwise
+    kernel; the contraction of a device tensor currently goes to the dense conv library on the
+    exact +-1/0 weight image (bit-packed conv: DESIGN.md 'next')."""
+    wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+    return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
+
+
+class QuantLinearFn(torch.autograd.Function):
+    """Autograd node of LinearBin / LinearTer in training mode.
+
+    forward : F.linear(x, Q(W), b)                         layers/binary_layers.py:44
+    backward: grad_x = g . Q(W) ; grad_W = (g^T . x) * 1[|W| <= 1.001] ; grad_b = sum g
+              (what autograd derives from F.linear + the STE backward of the quantiser,
+              functions/binary_connect.py:31-38 / terner_connect.py:29-34)
+    """
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, kind, weight_q, binary_input):
+        ctx.kind = kind
+        ctx.has_bias = bias is not None
+        # a stochastic draw must be kept; the deterministic image is recomputed in backward
+        ctx.save_for_backward(input, weight, weight_q)
+        return quant_linear_forward(input, weight, bias, kind, weight_q=weight_q,
+                                    binary_input=binary_input)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from .common import ste_mask
+        input, weight, weight_q = ctx.saved_tensors
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
+            grad_input = g2.mm(wq).view(input.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = input.reshape(-1, input.shape[-1])
+            grad_weight = ste_mask(g2.t().mm(x2), weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = g2.sum(0)
+        return grad_input, grad_weight, grad_bias, None, None, None

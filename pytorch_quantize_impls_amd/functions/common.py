@@ -1,0 +1,46 @@
+"""Shared pieces of the STE function family (reference: QuantTorch/functions/common.py)."""
+import torch
+
+from .. import ops
+
+
+def safeSign(tensor: torch.Tensor) -> torch.Tensor:
+    """-1 where tensor < 0, +1 everywhere else (+0.0, -0.0 and NaN map to +1).
+
+    Reference: QuantTorch/functions/common.py:4-7 (torch.sign followed by a masked write of the
+    zeros).  HIP device tensors go through qt_binarize_f32; CPU tensors use the same predicate in
+    torch.
+    """
+    if tensor.is_cuda and tensor.dtype == torch.float32:
+        return ops.binarize(tensor)
+    one = torch.ones((), dtype=tensor.dtype, device=tensor.device)
+    return torch.where(tensor < 0, -one, one)
+
+
+class _FunctionModule(torch.nn.Module):
+    """nn.Module that applies an autograd.Function class (what front()/front2() hand out)."""
+
+    def __init__(self, fn_class):
+        super().__init__()
+        self.core = fn_class
+
+    def forward(self, x):
+        return self.core.apply(x)
+
+
+def front(claaz):
+    """Module proxy of an autograd.Function class (reference: functions/common.py:10-20)."""
+    return _FunctionModule(claaz)
+
+
+def front2(claaz):
+    """Same proxy, keeping the Function on ``.core`` (reference: functions/common.py:23-31)."""
+    return _FunctionModule(claaz)
+
+
+def ste_mask(grad_output: torch.Tensor, saved_input: torch.Tensor, thr: float = ops.STE_THRESHOLD):
+    """grad * 1[|x| <= thr]: the straight-through mask every Binary/Ternary op shares
+    (functions/binary_connect.py:31-38, terner_connect.py:29-34)."""
+    if grad_output.is_cuda and grad_output.dtype == torch.float32 and saved_input.dtype == torch.float32:
+        return ops.ste_mask(grad_output, saved_input, thr)
+    return torch.where(saved_input.abs() > thr, torch.zeros_like(grad_output), grad_output)

@@ -1,0 +1,162 @@
+"""DoReFa-Net ops (reference: QuantTorch/functions/dorefa_connect.py)."""
+import warnings
+
+import torch
+
+from .. import ops
+from .common import front, safeSign
+
+warnings.simplefilter("always", DeprecationWarning)
+
+
+def _quantize(x, bit_width=3):
+    """k-bit quantiser: k=1 safeSign, k=32 identity, else (1/(2^k-1)) * round((2^k-1) x) with
+    round-half-even and NO clamp (dorefa_connect.py:11-25).  The scale is formed in fp32 and the
+    reciprocal is multiplied (not divided) so the last ulp matches the reference."""
+    if bit_width == 1:
+        return safeSign(x)
+    if bit_width == 32:
+        return x
+    if x.is_cuda and x.dtype == torch.float32:
+        return ops.dorefa_quantize(x, bit_width)
+    n = torch.pow(torch.full_like(x, 2.0), bit_width) - 1
+    return (1 / n) * torch.round(n * x)
+
+
+def _make_quant_function(bit_width):
+    class _Quant(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input):
+            return _quantize(input, bit_width=bit_width)
+
+        @staticmethod
+        def backward(ctx, grad_ouput):  # identity STE (dorefa_connect.py:43-44, 61-62)
+            return grad_ouput.clone()
+
+    return _Quant
+
+
+def nnDorefaQuant(bit_width=3):
+    """nn.Module applying the k-bit quantiser with identity gradient (dorefa_connect.py:28-45)."""
+    return front(_make_quant_function(bit_width))
+
+
+def DorefaQuant(x, bit_width=3):
+    """Functional form of the k-bit quantiser (dorefa_connect.py:49-63)."""
+    return _make_quant_function(bit_width).apply(x)
+
+
+class _ignore_factor_op(torch.autograd.Function):
+    """forward x*c ; backward passes the gradient through UNscaled (dorefa_connect.py:66-79)."""
+
+    @staticmethod
+    def forward(ctx, input, const):
+        return input * const
+
+    @staticmethod
+    def backward(ctx, grad_ouput):
+        var_grad = grad_ouput.clone() if ctx.needs_input_grad[0] else None
+        return var_grad, None
+
+
+class _QuantWeight(torch.nn.Module):
+    def __init__(self, bit_width):
+        super().__init__()
+        self.bit_width = bit_width
+        self.quant_op = nnDorefaQuant(bit_width)
+
+    def forward(self, x):
+        if self.bit_width == 1:
+            # sign(W) * mean|W| with the scalar detached (dorefa_connect.py:99-102)
+            E = torch.mean(torch.abs(x)).detach()
+            return _ignore_factor_op.apply(self.quant_op(x), E)
+        if self.bit_width == 32:
+            return x
+        if torch.max(torch.abs(x)) == 0.0:  # all-zero guard (dorefa_connect.py:106-107)
+            return torch.zeros_like(x)
+        weight = torch.tanh(x)
+        weight = weight / (2 * torch.max(torch.abs(weight))) + 0.5
+        return 2 * self.quant_op(weight) - 1
+
+
+def nnQuantWeight(bit_width=3):
+    """Weight quantiser module: 2*quantize_k(tanh W / (2 max|tanh W|) + 1/2) - 1
+    (dorefa_connect.py:82-113)."""
+    return _QuantWeight(bit_width)
+
+
+def QuantDense(bit_width=3):
+    """DEPRECATED functional dense op with explicit tanh-derivative backward
+    (dorefa_connect.py:116-155)."""
+
+    class _QuantDense(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input, weight, bias=None):
+            max_abs = torch.max(torch.abs(torch.tanh(weight)))
+            if bit_width == 1:
+                weight_q = safeSign(weight) * torch.mean(torch.abs(weight)).detach()
+            elif bit_width == 32:
+                weight_q = weight
+            else:
+                weight_q = 2 * _quantize(0.5 + torch.tanh(weight) / (2 * max_abs), bit_width=bit_width) - 1
+            output = torch.nn.functional.linear(input, weight_q, bias)
+            ctx.save_for_backward(input, weight, weight_q, max_abs, bias)
+            return output
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            input, weight, weight_q, max_abs, bias = ctx.saved_tensors
+            grad_input = grad_weight = grad_bias = None
+            if ctx.needs_input_grad[0]:
+                grad_input = grad_output.mm(weight_q)
+            if ctx.needs_input_grad[1]:
+                grad_weight = grad_output.t().mm(input)
+                if 1 < bit_width < 32:
+                    grad_weight = grad_weight * (1 - torch.pow(torch.tanh(weight), 2)) / max_abs
+            if bias is not None and ctx.needs_input_grad[2]:
+                grad_bias = grad_output.sum(0)
+            return grad_input, grad_weight, grad_bias
+
+    return _QuantDense
+
+
+def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
+    """DEPRECATED functional conv op; normalises by tanh(max|W|) (dorefa_connect.py:158-199)."""
+    warnings.warn("Deprecated conv op ! Use layers.DorefaConv2d.", DeprecationWarning, stacklevel=2)
+
+    class _QuantConv2d(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input, weight, bias=None):
+            max_weight = torch.max(torch.abs(weight))
+            if bit_width == 1:
+                weight_q = safeSign(weight) * torch.mean(torch.abs(weight)).detach()
+            elif bit_width == 32:
+                weight_q = weight
+            else:
+                weight_q = 2 * _quantize(0.5 + torch.tanh(weight) / (2 * torch.tanh(max_weight)),
+                                         bit_width=bit_width) - 1
+            ctx.save_for_backward(input, weight, weight_q, max_weight, bias)
+            return torch.nn.functional.conv2d(input, weight_q, bias=bias, stride=stride,
+                                              padding=padding, dilation=dilation, groups=groups)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            input, weight, weight_q, max_weight, bias = ctx.saved_tensors
+            grad_input = grad_weight = grad_bias = None
+            if ctx.needs_input_grad[0]:
+                grad_input = torch.nn.grad.conv2d_input(input.size(), weight_q, grad_output,
+                                                        stride=stride, padding=padding,
+                                                        dilation=dilation, groups=groups)
+            if ctx.needs_input_grad[1]:
+                grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output,
+                                                          stride=stride, padding=padding,
+                                                          dilation=dilation, groups=groups)
+                if 1 < bit_width < 32:
+                    grad_weight = grad_weight * (1 - torch.pow(torch.tanh(weight), 2)) / torch.tanh(max_weight)
+            if bias is not None and ctx.needs_input_grad[2]:
+                grad_bias = grad_output.sum((0, 2, 3))
+            if bias is not None:
+                return grad_input, grad_weight, grad_bias
+            return grad_input, grad_weight
+
+    return _QuantConv2d

@@ -1,0 +1,7 @@
+"""Public layer surface — the names of QuantTorch/layers/__init__.py for the four hot-path
+families."""
+from .binary_layers import LinearBin, BinConv2d, ShiftNormBatch1d, ShiftNormBatch2d
+from .dorefa_layers import LinearDorefa, DorefaConv2d
+from .terner_layers import LinearTer, TerConv2d
+from .xnor_layers import LinearXNOR, XNORConv2d
+from .common import QLayer

@@ -1,0 +1,154 @@
+"""BinaryNet layers (reference: QuantTorch/layers/binary_layers.py)."""
+from math import sqrt as _sqrt
+
+import torch
+
+from ..functions import binary_connect, _fused
+from .common import QLayer, EvalSwapMixin
+
+
+class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
+    """nn.Linear whose weight is binarised on the fly (binary_layers.py:7-46).
+
+    ``binary_input``: None (default) = detect +-1 activations (tag from BinaryConnect, else a
+    device-side check); True = caller guarantees +-1 activations; False = never take the packed
+    path.  Only consulted for device tensors.
+    """
+
+    @staticmethod
+    def convert(other, deterministic=True):
+        if not isinstance(other, torch.nn.Linear):
+            raise TypeError("Expected a torch.nn.Linear ! Receive:  {}".format(other.__class__))
+        # like upstream, a FRESH layer: weights are not copied (binary_layers.py:8-12)
+        return LinearBin(other.in_features, other.out_features, other.bias is not None, deterministic)
+
+    def __init__(self, in_features, out_features, bias=True, deterministic=True):
+        torch.nn.Linear.__init__(self, in_features, out_features, bias=bias)
+        self.deterministic = deterministic
+        self.bin_op = binary_connect.BinaryConnectDeterministic if deterministic \
+            else binary_connect.BinaryConnectStochastic
+        self.binary_input = None
+
+    def reset_parameters(self):
+        self.weight.data.normal_(0, _sqrt(1. / self.in_features))
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def clamp(self):
+        self.weight.data.clamp_(-1, 1)
+        if self.bias is not None:  # upstream clamps the bias as well (binary_layers.py:27-28)
+            self.bias.data.clamp_(-1, 1)
+
+    def _quantized_weight_for_eval(self):
+        return self.bin_op.apply(self.weight)
+
+    def forward(self, input):
+        if not input.is_cuda:
+            w = self.bin_op.apply(self.weight) if self.training else self.weight
+            return torch.nn.functional.linear(input, w, self.bias)
+        if self.training:
+            wq = None if self.deterministic else self.bin_op.apply(self.weight.detach())
+            return _fused.QuantLinearFn.apply(input, self.weight, self.bias, "binary", wq,
+                                              self.binary_input)
+        # eval: weight already holds the binarised image; planes are cached
+        return _eval_linear(self, input, "binary")
+
+
+def _eval_linear(layer, input, kind):
+    """Eval-mode forward of a device layer: F.linear(input, weight, bias) (binary_layers.py:46)
+    with the packed path when the activation is +-1."""
+    xp = _fused.activation_planes(input, layer.binary_input)
+    if xp is None or torch.is_grad_enabled() and (input.requires_grad or layer.weight.requires_grad):
+        # general fp32 path / autograd needed: this IS the reference expression
+        return torch.nn.functional.linear(input, layer.weight, layer.bias)
+    wp = layer._eval_planes(lambda w2: _fused.pack_weight(w2, kind))
+    return _fused.quant_linear_forward(input, layer.weight, layer.bias, kind,
+                                       weight_q=layer.weight, weight_planes=wp, binary_input=True)
+
+
+class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
+    """nn.Conv2d with binarised weight (binary_layers.py:48-106)."""
+
+    @staticmethod
+    def convert(other, deterministic=True):
+        if not isinstance(other, torch.nn.Conv2d):
+            raise TypeError("Expected a torch.nn.Conv2d ! Receive:  {}".format(other.__class__))
+        return BinConv2d(other.in_channels, other.out_channels, other.kernel_size,
+                         stride=other.stride, padding=other.padding, dilation=other.dilation,
+                         groups=other.groups, bias=other.bias is not None,
+                         deterministic=deterministic)
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, deterministic=True):
+        torch.nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride=stride,
+                                 padding=padding, dilation=dilation, groups=groups, bias=bias)
+        self.bin_op = binary_connect.BinaryConnectDeterministic if deterministic \
+            else binary_connect.BinaryConnectStochastic
+        self.deterministic = deterministic
+        self.binary_input = None
+
+    def clamp(self):
+        """Clamp the real weight to [-1, 1] (bias untouched, binary_layers.py:81-85)."""
+        self.weight.data.clamp_(-1, 1)
+
+    def _quantized_weight_for_eval(self):
+        return self.bin_op.apply(self.weight)
+
+    def forward(self, input):
+        w = self.bin_op.apply(self.weight) if self.training else self.weight
+        return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
+                                          self.dilation, self.groups)
+
+
+class ShiftNormBatch1d(torch.nn.Module):
+    """Shift-based batch norm, 1-D (binary_layers.py:110-132); torch ops, off the hot path.
+    weight/bias are created uninitialised like upstream."""
+    __constants__ = ['momentum', 'eps']
+
+    def __init__(self, in_dim, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.in_features = in_dim
+        self.weight = torch.nn.Parameter(torch.empty(in_dim))
+        self.bias = torch.nn.Parameter(torch.empty(in_dim))
+        self.register_buffer('running_mean', torch.zeros(in_dim))
+        self.register_buffer('running_var', torch.ones(in_dim))
+        self.eps = eps
+        self.momentum = momentum
+
+    def forward(self, x):
+        m = self.momentum
+        self.running_mean = (1 - m) * self.running_mean + m * torch.mean(x, 0).detach()
+        c = x - self.running_mean
+        self.running_var = (1 - m) * self.running_var + m * torch.mean(c * binary_connect.AP2(c), 0).detach()
+        return binary_connect.ShiftBatch.apply(x, self.running_mean, self.running_var, self.weight,
+                                               self.bias, self.eps)
+
+
+class ShiftNormBatch2d(torch.nn.Module):
+    """Shift-based batch norm, 2-D (binary_layers.py:137-160)."""
+    __constants__ = ['momentum', 'eps']
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.in_features = in_channels
+        self.weight = torch.nn.Parameter(torch.empty(in_channels))
+        self.bias = torch.nn.Parameter(torch.empty(in_channels))
+        self.register_buffer('running_mean', torch.zeros(in_channels))
+        self.register_buffer('running_var', torch.ones(in_channels))
+        self.eps = eps
+        self.momentum = momentum
+
+    @staticmethod
+    def _tile(tensor, dim):
+        return tensor.repeat(dim[0], dim[1], 1).transpose(2, 0)
+
+    def forward(self, x):
+        dim = x.size()[-2:]
+        m = self.momentum
+        self.running_mean = (1 - m) * self.running_mean + m * torch.mean(x, [0, 2, 3]).detach()
+        curr_mean = self._tile(self.running_mean, dim)
+        c = x - curr_mean
+        self.running_var = (1 - m) * self.running_var + m * torch.mean(c * binary_connect.AP2(c), [0, 2, 3]).detach()
+        return binary_connect.ShiftBatch.apply(x, curr_mean, self._tile(self.running_var, dim),
+                                               self._tile(self.weight, dim),
+                                               self._tile(self.bias, dim), self.eps)

@@ -1,0 +1,62 @@
+"""Layer plumbing shared by every quantised layer family."""
+import torch
+
+
+class QLayer():
+    """Marker mixin used by model-surgery tooling (reference: QuantTorch/layers/common.py:1-9)."""
+
+    def get_quant_weight(self):
+        raise NotImplementedError
+
+    def set_quant_weight(self):
+        raise NotImplementedError
+
+    def restore_weight(self):
+        raise NotImplementedError
+
+
+class EvalSwapMixin:
+    """The reference's train()/eval() protocol, identical in every layer family
+    (layers/binary_layers.py:30-40, terner_layers.py:30-40, dorefa_layers.py:29-39):
+
+      * train -> eval : stash the real weight in the non-persistent attribute ``weight.org`` and
+        overwrite ``weight.data`` with its quantised image;
+      * eval -> train : copy ``weight.org`` back.
+
+    ``state_dict()`` taken in eval mode therefore holds the QUANTISED weight (upstream hazard,
+    SURVEY.md section 5) — kept bit-for-bit.  On top of it the mixin keeps a cache of the packed
+    bit planes of the eval-mode weight, keyed on the weight's version counter, so eval-mode
+    forwards of a device layer never re-pack.
+    """
+
+    def _quantized_weight_for_eval(self) -> torch.Tensor:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def train(self, mode=True):
+        if self.training == mode:
+            return self
+        self.training = mode
+        self._qt_eval_planes = None
+        if mode:
+            self.weight.data.copy_(self.weight.org.data)
+        else:
+            if not hasattr(self.weight, 'org'):
+                self.weight.org = self.weight.data.clone()
+            self.weight.org.data.copy_(self.weight.data)
+            with torch.no_grad():
+                self.weight.data.copy_(self._quantized_weight_for_eval().detach())
+            self._qt_eval_version = self.weight._version
+        return self
+
+    def _eval_planes(self, packer):
+        """Packed planes of the eval-mode (already quantised) weight; rebuilt if the weight tensor
+        was written since eval() (load_state_dict, manual edits, .to(device))."""
+        w = self.weight
+        cached = getattr(self, "_qt_eval_planes", None)
+        if cached is not None:
+            planes, version, ptr = cached
+            if version == w._version and ptr == w.data_ptr():
+                return planes
+        planes = packer(w.detach().reshape(w.shape[0], -1))
+        self._qt_eval_planes = (planes, w._version, w.data_ptr())
+        return planes

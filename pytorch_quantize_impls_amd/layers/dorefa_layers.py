@@ -1,0 +1,58 @@
+"""DoReFa-Net layers (reference: QuantTorch/layers/dorefa_layers.py)."""
+import torch
+
+from ..functions import dorefa_connect
+from .common import QLayer, EvalSwapMixin
+
+
+class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
+    """nn.Linear with a k-bit DoReFa weight (dorefa_layers.py:11-45)."""
+
+    @staticmethod
+    def convert(other, bit_width=3):
+        if not isinstance(other, torch.nn.Linear):
+            raise TypeError("Expected a torch.nn.Linear ! Receive:  {}".format(other.__class__))
+        return LinearDorefa(other.in_features, other.out_features, other.bias is not None,
+                            bit_width=bit_width)
+
+    def __init__(self, in_features, out_features, bias=True, bit_width=3):
+        torch.nn.Linear.__init__(self, in_features, out_features, bias=bias)
+        self.bit_width = bit_width
+        self.weight_op = dorefa_connect.nnQuantWeight(bit_width=bit_width)
+
+    def extra_repr(self):
+        return "bit_width = {}".format(self.bit_width)
+
+    def _quantized_weight_for_eval(self):
+        return self.weight_op.forward(self.weight)
+
+    def forward(self, input):
+        w = self.weight_op.forward(self.weight) if self.training else self.weight
+        return torch.nn.functional.linear(input, w, self.bias)
+
+
+class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
+    """nn.Conv2d with a k-bit DoReFa weight (dorefa_layers.py:48-82)."""
+
+    @staticmethod
+    def convert(other, bit_width=3):
+        if not isinstance(other, torch.nn.Conv2d):
+            raise TypeError("Expected a torch.nn.Conv2d ! Receive:  {}".format(other.__class__))
+        return DorefaConv2d(other.in_channels, other.out_channels, other.kernel_size,
+                            stride=other.stride, padding=other.padding, dilation=other.dilation,
+                            groups=other.groups, bias=other.bias is not None, bit_width=bit_width)
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, bit_width=3):
+        torch.nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride=stride,
+                                 padding=padding, dilation=dilation, groups=groups, bias=bias)
+        self.bit_width = bit_width
+        self.weight_op = dorefa_connect.nnQuantWeight(bit_width=bit_width)
+
+    def _quantized_weight_for_eval(self):
+        return self.weight_op.forward(self.weight)
+
+    def forward(self, input):
+        w = self.weight_op.forward(self.weight) if self.training else self.weight
+        return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
+                                          self.dilation, self.groups)

@@ -1,0 +1,85 @@
+"""TernaryNet layers (reference: QuantTorch/layers/terner_layers.py)."""
+from math import sqrt
+
+import torch
+
+from ..functions import terner_connect, _fused
+from .common import QLayer, EvalSwapMixin
+from .binary_layers import _eval_linear
+
+
+def _ter_op(deterministic):
+    return terner_connect.TernaryConnectDeterministic if deterministic \
+        else terner_connect.TernaryConnectStochastic
+
+
+class LinearTer(EvalSwapMixin, torch.nn.Linear, QLayer):
+    """nn.Linear with a ternarised weight (terner_layers.py:10-51)."""
+
+    @staticmethod
+    def convert(other, dtype="lin", deterministic=True):
+        if not isinstance(other, torch.nn.Linear):
+            raise TypeError("Expected a torch.nn.Linear ! Receive:  {}".format(other.__class__))
+        return LinearTer(other.in_features, other.out_features, other.bias is not None,
+                         deterministic=deterministic)
+
+    def __init__(self, in_features, out_features, bias=True, deterministic=True):
+        torch.nn.Linear.__init__(self, in_features, out_features, bias=bias)
+        self.deterministic = deterministic
+        self.ter_op = _ter_op(deterministic)
+        self.binary_input = None
+
+    def reset_parameters(self):
+        self.weight.data.normal_(0, sqrt(1. / self.in_features))
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def clamp(self):
+        self.weight.data.clamp_(-1, 1)
+        if self.bias is not None:
+            self.bias.data.clamp_(-1, 1)
+
+    def _quantized_weight_for_eval(self):
+        return self.ter_op.apply(self.weight)
+
+    def forward(self, input):
+        if not input.is_cuda:
+            w = self.ter_op.apply(self.weight) if self.training else self.weight
+            return torch.nn.functional.linear(input, w, self.bias)
+        if self.training:
+            wq = None if self.deterministic else self.ter_op.apply(self.weight.detach())
+            return _fused.QuantLinearFn.apply(input, self.weight, self.bias, "ternary", wq,
+                                              self.binary_input)
+        return _eval_linear(self, input, "ternary")
+
+
+class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
+    """nn.Conv2d with a ternarised weight (terner_layers.py:54-92)."""
+
+    @staticmethod
+    def convert(other, deterministic=True):
+        if not isinstance(other, torch.nn.Conv2d):
+            raise TypeError("Expected a torch.nn.Conv2d ! Receive:  {}".format(other.__class__))
+        return TerConv2d(other.in_channels, other.out_channels, other.kernel_size,
+                         stride=other.stride, padding=other.padding, dilation=other.dilation,
+                         groups=other.groups, bias=other.bias is not None,
+                         deterministic=deterministic)
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, deterministic=True):
+        torch.nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride=stride,
+                                 padding=padding, dilation=dilation, groups=groups, bias=bias)
+        self.deterministic = deterministic
+        self.ter_op = _ter_op(deterministic)
+        self.binary_input = None
+
+    def clamp(self):
+        self.weight.data.clamp_(-1, 1)
+
+    def _quantized_weight_for_eval(self):
+        return self.ter_op.apply(self.weight)
+
+    def forward(self, input):
+        w = self.ter_op.apply(self.weight) if self.training else self.weight
+        return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
+                                          self.dilation, self.groups)

@@ -1,0 +1,61 @@
+"""XNOR-Net layers (reference: QuantTorch/layers/xnor_layers.py).
+
+Upstream's eval swap crashes (free variable ``dim`` at xnor_layers.py:30,61) and XNORConv2d drops
+its ``dim`` / forces quant_input=False (:47-49).  Numerics are reproduced; the crashes are fixed by
+using the stored ``self.dim`` (documented in DESIGN.md)."""
+import torch
+
+from ..functions import xnor_connect
+from .common import QLayer, EvalSwapMixin
+
+
+class LinearXNOR(EvalSwapMixin, torch.nn.Linear, QLayer):
+    """y = x . (sign(W) * mean|W|)^T + b, scale per INPUT feature (global DIM=0 upstream)."""
+
+    @staticmethod
+    def convert(other, dim=[0, 1]):
+        if not isinstance(other, torch.nn.Linear):
+            raise TypeError("Expected a torch.nn.Linear ! Receive:  {}".format(other.__class__))
+        return LinearXNOR(other.in_features, other.out_features, other.bias is not None, dim=dim)
+
+    def __init__(self, in_features, out_features, bias=True, dim=[0, 1]):
+        super().__init__(in_features, out_features, bias=bias)
+        self.lin_op = xnor_connect.XNORDense(dim=dim)
+        self.dim = dim
+
+    def _quantized_weight_for_eval(self):
+        # fixed form of xnor_layers.py:30; the forward op reduces over xnor_connect.DIM whatever
+        # ``dim`` says, so the eval image uses the same reduction to stay consistent with it
+        return xnor_connect.xnor_weight(self.weight, xnor_connect.DIM)[0]
+
+    def forward(self, input):
+        return self.lin_op.apply(input, self.weight, self.bias)
+
+
+class XNORConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
+    """conv2d(x, sign(W) * mean(|W|, dim)) (xnor_layers.py:36-69)."""
+
+    @staticmethod
+    def convert(other, dim=[0, 1], quant_input=False):
+        if not isinstance(other, torch.nn.Conv2d):
+            raise TypeError("Expected a torch.nn.Conv2d ! Receive:  {}".format(other.__class__))
+        return XNORConv2d(other.in_channels, other.out_channels, other.kernel_size,
+                          stride=other.stride, padding=other.padding, dilation=other.dilation,
+                          groups=other.groups, bias=other.bias is not None, dim=dim,
+                          quant_input=quant_input)
+
+    def __init__(self, *kargs, dim=[0, 1], quant_input=False, **kwargs):
+        torch.nn.Conv2d.__init__(self, *kargs, **kwargs)
+        self.dim = dim
+        # upstream hard-codes quant_input=False here (xnor_layers.py:49); reproduced
+        self.conv_op = xnor_connect.XNORConv2d(dim, False, self.stride, self.padding,
+                                               self.dilation, self.groups)
+
+    def _quantized_weight_for_eval(self):
+        return xnor_connect.xnor_weight(self.weight, self.dim)[0]
+
+    def clamp(self):
+        pass
+
+    def forward(self, input):
+        return self.conv_op.apply(input, self.weight, self.bias)

@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C-ABI (include/qt_hip.h).
+
+Everything here takes/returns torch tensors that live on a HIP device ("cuda" in PyTorch-ROCm);
+torch is used only for device memory, streams and dtype bookkeeping.  All buffers are allocated
+by torch, kernels are enqueued on ``torch.cuda.current_stream()`` and nothing synchronises.
+A CPU tensor is a programming error here (``TypeError``) — there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+STE_THRESHOLD = 1.001  # functions/binary_connect.py:37, terner_connect.py:33
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise TypeError(f"{name}: expected a tensor on a HIP device, got device {t.device}; "
+                        "the HIP backend has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def packed_ld(K: int) -> int:
+    """Row stride (uint32 words) of a bit plane holding K bits: ceil(K/32) rounded up to 4."""
+    kw = (int(K) + 31) // 32
+    return max(4, (kw + 3) // 4 * 4)
+
+
+@dataclass
+class BitPlanes:
+    """Bit-plane image of a [rows, K] matrix of +-1 (sign only) or {-1,0,+1} (mask + sign).
+
+    ``sign``/``mask`` are int32 tensors of shape [rows, ld] (the C side treats them as uint32);
+    bit j of word w is element 32*w+j; sign bit 1 <=> negative; mask bit 1 <=> non-zero;
+    all bits past K are zero.
+    """
+    sign: torch.Tensor
+    rows: int
+    K: int
+    mask: Optional[torch.Tensor] = None
+
+    @property
+    def ld(self) -> int:
+        return int(self.sign.shape[1])
+
+    @property
+    def device(self):
+        return self.sign.device
+
+    @property
+    def is_ternary(self) -> bool:
+        return self.mask is not None
+
+
+# ----------------------------------------------------------------------------------------------
+# elementwise
+# ----------------------------------------------------------------------------------------------
+
+def _unary(name: str, x: torch.Tensor, *extra) -> torch.Tensor:
+    x = _require(x, "input").contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.call(name, _p(x), _p(y), ctypes.c_int64(x.numel()), *extra, _stream(x.device))
+    return y
+
+
+def binarize(x: torch.Tensor) -> torch.Tensor:
+    """safeSign: x<0 -> -1 else +1 (functions/common.py:4-7)."""
+    return _unary("qt_binarize_f32", x)
+
+
+def ternarize(x: torch.Tensor) -> torch.Tensor:
+    """TernaryConnectDeterministic.forward (functions/terner_connect.py:24-27)."""
+    return _unary("qt_ternarize_f32", x)
+
+
+def dorefa_quantize(x: torch.Tensor, bit_width: int) -> torch.Tensor:
+    """_quantize (functions/dorefa_connect.py:11-25)."""
+    return _unary("qt_dorefa_quantize_f32", x, ctypes.c_int(int(bit_width)))
+
+
+def _binary(name: str, a: torch.Tensor, b: torch.Tensor, *extra) -> torch.Tensor:
+    a = _require(a, "a").contiguous()
+    b = _require(b, "b").contiguous()
+    if a.shape != b.shape:
+        raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.call(name, _p(a), _p(b), _p(y), ctypes.c_int64(a.numel()), *extra, _stream(a.device))
+    return y
+
+
+def binarize_stochastic(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """-1 + 2*[z < hardsigmoid(x)] with caller-drawn z ~ U[0,1) (binary_connect.py:57-61)."""
+    return _binary("qt_binarize_stochastic_f32", x, z)
+
+
+def ternarize_stochastic(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """s - s*[z > |x|] (terner_connect.py:54-56)."""
+    return _binary("qt_ternarize_stochastic_f32", x, z)
+
+
+def ste_mask(grad_out: torch.Tensor, x: torch.Tensor, thr: float = STE_THRESHOLD) -> torch.Tensor:
+    """grad_out * 1[|x| <= thr] (binary_connect.py:31-38)."""
+    return _binary("qt_ste_mask_f32", grad_out, x, ctypes.c_float(thr))
+
+
+# ----------------------------------------------------------------------------------------------
+# packing
+# ----------------------------------------------------------------------------------------------
+
+def _as_rows(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() < 1:
+        raise ValueError("need at least 1 dimension")
+    x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+def sign_pack(x: torch.Tensor, want_f32: bool = False) -> Tuple[BitPlanes, Optional[torch.Tensor]]:
+    """Sign plane of safeSign(x) packed along the last dimension.
+
+    Returns (planes, y) where y is the +-1 fp32 image (same shape as x) when ``want_f32``.
+    """
+    _require(x, "input")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = packed_ld(K)
+    plane = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
+    y = torch.empty((rows, K), dtype=torch.float32, device=x.device) if want_f32 else None
+    with torch.cuda.device(x.device):
+        _lib.call("qt_sign_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(plane), ctypes.c_int64(ld), _p(y), ctypes.c_int64(K), ctypes.c_int64(rows),
+                  ctypes.c_int64(K), _stream(x.device))
+    if y is not None:
+        y = y.view(x.shape)
+    return BitPlanes(sign=plane, rows=rows, K=K), y
+
+
+def ternary_pack(x: torch.Tensor) -> BitPlanes:
+    """Mask + sign planes of TernaryConnectDeterministic(x), packed along the last dimension."""
+    _require(x, "input")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = packed_ld(K)
+    mask = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
+    sign = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("qt_ternary_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(mask), _p(sign), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
+                  _stream(x.device))
+    return BitPlanes(sign=sign, rows=rows, K=K, mask=mask)
+
+
+def check_pm1(x: torch.Tensor) -> torch.Tensor:
+    """Device flag (int32 scalar tensor): non-zero iff some element of x is not exactly +-1."""
+    x = _require(x, "input").contiguous()
+    flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("qt_check_pm1_f32", _p(x), ctypes.c_int64(x.numel()), _p(flag), _stream(x.device))
+    return flag
+
+
+# ----------------------------------------------------------------------------------------------
+# packed GEMMs
+# ----------------------------------------------------------------------------------------------
+
+def _check_bias(bias, N, device):
+    if bias is None:
+        return None
+    bias = _require(bias, "bias").contiguous()
+    if bias.numel() != N or bias.device != device:
+        raise ValueError("bias must be a length-N fp32 tensor on the same device")
+    return bias
+
+
+def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) for +-1 operands given as sign planes."""
+    if x.K != w.K:
+        raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
+    if x.is_ternary or w.is_ternary:
+        raise ValueError("xnor_gemm takes sign-only planes; use tern_gemm for ternary weights")
+    M, N, K = x.rows, w.rows, x.K
+    dev = x.device
+    bias = _check_bias(bias, N, dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("qt_xnor_gemm", _p(x.sign), ctypes.c_int64(x.ld), _p(w.sign), ctypes.c_int64(w.ld),
+                  _p(bias), _p(out), ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)),
+                  ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_int64(K), _stream(dev))
+    return out
+
+
+def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias): +-1 activations (sign plane) x ternary weights."""
+    if x.K != w.K:
+        raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
+    if x.is_ternary or not w.is_ternary:
+        raise ValueError("tern_gemm takes binary activations and ternary (mask+sign) weights")
+    M, N, K = x.rows, w.rows, x.K
+    dev = x.device
+    bias = _check_bias(bias, N, dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("qt_tern_gemm", _p(x.sign), ctypes.c_int64(x.ld), _p(w.mask), _p(w.sign),
+                  ctypes.c_int64(w.ld), _p(bias), _p(out),
+                  ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)),
+                  ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_int64(K), _stream(dev))
+    return out
