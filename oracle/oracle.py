@@ -1,0 +1,248 @@
+"""numpy front-end of the CPU oracle (oracle/qt_oracle.c) — TEST INFRASTRUCTURE ONLY.
+
+Each function restates one expression of the reference (Enderdead/Pytorch_Quantize_impls,
+paths relative to its root) on numpy float32 arrays.  Elementwise / integer work is done by the
+C restatement through ctypes; the thin layer-level compositions (LinearBin.forward = linear(x,
+safeSign(W), b), ...) are written here.  Parity with the reference itself is pinned by
+tests/golden (see tests/golden/make_golden.py) and tests/test_oracle_golden.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libqt_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_i64 = ctypes.c_int64
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc, a second or two)."""
+    src = os.path.join(_HERE, "qt_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _u(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(_u32p)
+
+
+def _optf(a):
+    if a is None:
+        return None, None
+    return _f(a)
+
+
+# ---- elementwise ---------------------------------------------------------------------------
+
+def safe_sign(x):
+    """functions/common.py:4-7."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_safe_sign(xp, y.ctypes.data_as(_f32p), _i64(x.size))
+    return y
+
+
+def ste_mask(grad, x, thr=1.001):
+    """functions/binary_connect.py:31-38 (same in terner_connect.py:29-34)."""
+    g, gp = _f(grad)
+    x, xp = _f(x)
+    out = np.empty_like(g)
+    lib().qo_ste_mask(gp, xp, out.ctypes.data_as(_f32p), _i64(g.size), ctypes.c_float(thr))
+    return out
+
+
+def ternarize(x):
+    """functions/terner_connect.py:24-27."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_ternarize(xp, y.ctypes.data_as(_f32p), _i64(x.size))
+    return y
+
+
+def binarize_stochastic(x, z):
+    """functions/binary_connect.py:57-61 with explicit uniforms."""
+    x, xp = _f(x)
+    z, zp = _f(z)
+    y = np.empty_like(x)
+    lib().qo_binarize_stochastic(xp, zp, y.ctypes.data_as(_f32p), _i64(x.size))
+    return y
+
+
+def ternarize_stochastic(x, z):
+    """functions/terner_connect.py:52-56 with explicit uniforms."""
+    x, xp = _f(x)
+    z, zp = _f(z)
+    y = np.empty_like(x)
+    lib().qo_ternarize_stochastic(xp, zp, y.ctypes.data_as(_f32p), _i64(x.size))
+    return y
+
+
+def dorefa_quantize(x, k):
+    """functions/dorefa_connect.py:11-25."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_dorefa_quantize(xp, y.ctypes.data_as(_f32p), _i64(x.size), ctypes.c_int(int(k)))
+    return y
+
+
+# ---- packed format ---------------------------------------------------------------------------
+
+def packed_ld(K: int) -> int:
+    kw = (int(K) + 31) // 32
+    return max(4, (kw + 3) // 4 * 4)
+
+
+def sign_pack(x2d):
+    x, xp = _f(x2d)
+    rows, K = x.shape
+    ld = packed_ld(K)
+    plane = np.zeros((rows, ld), dtype=np.uint32)
+    lib().qo_sign_pack(xp, _i64(K), plane.ctypes.data_as(_u32p), _i64(ld), _i64(rows), _i64(K))
+    return plane
+
+
+def ternary_pack(x2d):
+    x, xp = _f(x2d)
+    rows, K = x.shape
+    ld = packed_ld(K)
+    mask = np.zeros((rows, ld), dtype=np.uint32)
+    sign = np.zeros((rows, ld), dtype=np.uint32)
+    lib().qo_ternary_pack(xp, _i64(K), mask.ctypes.data_as(_u32p), sign.ctypes.data_as(_u32p),
+                          _i64(ld), _i64(rows), _i64(K))
+    return mask, sign
+
+
+def xnor_gemm(xs, ws, K, bias=None):
+    xs, xsp = _u(xs)
+    ws, wsp = _u(ws)
+    M, N = xs.shape[0], ws.shape[0]
+    b, bp = _optf(bias)
+    y = np.empty((M, N), dtype=np.float32)
+    lib().qo_xnor_gemm(xsp, _i64(xs.shape[1]), wsp, _i64(ws.shape[1]), bp,
+                       y.ctypes.data_as(_f32p), _i64(N), _i64(M), _i64(N), _i64(K))
+    return y
+
+
+def tern_gemm(xs, wmask, wsign, K, bias=None):
+    xs, xsp = _u(xs)
+    wm, wmp = _u(wmask)
+    wsn, wsnp = _u(wsign)
+    M, N = xs.shape[0], wm.shape[0]
+    b, bp = _optf(bias)
+    y = np.empty((M, N), dtype=np.float32)
+    lib().qo_tern_gemm(xsp, _i64(xs.shape[1]), wmp, wsnp, _i64(wm.shape[1]), bp,
+                       y.ctypes.data_as(_f32p), _i64(N), _i64(M), _i64(N), _i64(K))
+    return y
+
+
+# ---- contractions (third-party in the reference: torch.nn.functional.linear / conv2d) ----------
+
+def linear(x, w, bias=None):
+    x, xp = _f(x)
+    w, wp = _f(w)
+    lead = x.shape[:-1]
+    K = x.shape[-1]
+    M = int(np.prod(lead)) if lead else 1
+    N = w.shape[0]
+    b, bp = _optf(bias)
+    y = np.empty((M, N), dtype=np.float32)
+    lib().qo_linear_f64acc(xp, wp, bp, y.ctypes.data_as(_f32p), _i64(M), _i64(N), _i64(K))
+    return y.reshape(*lead, N)
+
+
+def _pair(v):
+    return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    x, xp = _f(x)
+    w, wp = _f(w)
+    Nb, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    b, bp = _optf(bias)
+    y = np.empty((Nb, Cout, Ho, Wo), dtype=np.float32)
+    lib().qo_conv2d_f64acc(xp, wp, bp, y.ctypes.data_as(_f32p), _i64(Nb), _i64(Cin), _i64(H),
+                           _i64(W), _i64(Cout), _i64(kh), _i64(kw), _i64(sh), _i64(sw), _i64(ph),
+                           _i64(pw), _i64(dh), _i64(dw), _i64(groups))
+    return y
+
+
+# ---- layer-level compositions ----------------------------------------------------------------
+
+def linear_bin_forward(x, weight, bias=None, training=True):
+    """LinearBin.forward (layers/binary_layers.py:42-46)."""
+    return linear(x, safe_sign(weight) if training else weight, bias)
+
+
+def linear_ter_forward(x, weight, bias=None, training=True):
+    """LinearTer.forward (layers/terner_layers.py:47-51)."""
+    return linear(x, ternarize(weight) if training else weight, bias)
+
+
+def bin_conv2d_forward(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, training=True):
+    """BinConv2d.forward (layers/binary_layers.py:103-106)."""
+    return conv2d(x, safe_sign(weight) if training else weight, bias, stride, padding, dilation, groups)
+
+
+def ter_conv2d_forward(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, training=True):
+    """TerConv2d.forward (layers/terner_layers.py:89-92)."""
+    return conv2d(x, ternarize(weight) if training else weight, bias, stride, padding, dilation, groups)
+
+
+def dorefa_weight(weight, k):
+    """nnQuantWeight(k).forward (functions/dorefa_connect.py:99-111).  tanh / mean / max are the
+    host libm's: last-ulp differences against torch's vectorised tanh can move a value across a
+    rounding boundary, so tests compare the integer CODES with a +-1 allowance on such ties."""
+    w = np.asarray(weight, dtype=np.float32)
+    if k == 1:
+        E = np.mean(np.abs(w), dtype=np.float32)
+        return safe_sign(w) * np.float32(E)
+    if k == 32:
+        return w.copy()
+    if np.max(np.abs(w)) == 0.0:
+        return np.zeros_like(w)
+    t = np.tanh(w).astype(np.float32)
+    t = t / (np.float32(2) * np.max(np.abs(t))) + np.float32(0.5)
+    return np.float32(2) * dorefa_quantize(t, k) - np.float32(1)
+
+
+def xnor_dense_weight(weight):
+    """XNORDense forward weight: sign(W)*mean(|W|, DIM=0, keepdim) (functions/xnor_connect.py:112-113)."""
+    w = np.asarray(weight, dtype=np.float32)
+    mean = np.mean(np.abs(w), axis=0, keepdims=True, dtype=np.float32)
+    return np.sign(w).astype(np.float32) * mean
+
+
+def xnor_conv_weight(weight, dim=(0, 1)):
+    """XNORConv2d forward weight: sign(W)*mean(|W|, dim, keepdim) (functions/xnor_connect.py:140-141)."""
+    w = np.asarray(weight, dtype=np.float32)
+    mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True, dtype=np.float32)
+    return np.sign(w).astype(np.float32) * mean

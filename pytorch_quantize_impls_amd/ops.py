@@ -229,3 +229,48 @@ def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
                   ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)),
                   ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_int64(K), _stream(dev))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# formulation-agnostic front (bench.py and the layers go through this)
+# ----------------------------------------------------------------------------------------------
+
+GEMM_IMPLS = ("valu",)  # extended as formulations are added ("mfma": fp4 nibble planes)
+
+
+def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
+    """'auto' -> the fastest formulation available for the shape."""
+    if requested == "auto":
+        return "valu"
+    if requested not in GEMM_IMPLS:
+        raise NotImplementedError(f"packed GEMM formulation {requested!r} is not built "
+                                  f"(available: {GEMM_IMPLS})")
+    return requested
+
+
+def pack_activations(x: torch.Tensor, impl: str = "valu") -> BitPlanes:
+    """Sign planes of a +-1 (or about-to-be-binarised) activation matrix."""
+    if impl == "valu":
+        return sign_pack(x)[0]
+    raise NotImplementedError(impl)
+
+
+def pack_weights(w: torch.Tensor, kind: str = "binary", impl: str = "valu") -> BitPlanes:
+    w2 = w.reshape(w.shape[0], -1)
+    if impl == "valu":
+        return sign_pack(w2)[0] if kind == "binary" else ternary_pack(w2)
+    raise NotImplementedError(impl)
+
+
+def packed_gemm(x: BitPlanes, w: BitPlanes, bias=None, out=None, impl: str = "valu") -> torch.Tensor:
+    if impl == "valu":
+        return tern_gemm(x, w, bias, out) if w.is_ternary else xnor_gemm(x, w, bias, out)
+    raise NotImplementedError(impl)
+
+
+def packed_gemm_algorithmic_bytes(M: int, N: int, K: int, impl: str = "valu", planes_w: int = 1,
+                                  bias: bool = False) -> float:
+    """Algorithmic HBM bytes of ONE packed-GEMM launch (DESIGN.md 'Kernels'): every operand read
+    once, the fp32 result written once.  bit planes: 1 bit/element/plane; nibble planes: 4 bits."""
+    bits = 1 if impl == "valu" else 4
+    return M * K * bits / 8.0 + planes_w * N * K * bits / 8.0 + 4.0 * M * N + (4.0 * N if bias else 0.0)

@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Vectors produced by running the reference (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(GOLDEN_DIR, "golden_v1.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_hashes():
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+def same(a, b):
+    """Bitwise-style equality for fp32 arrays, treating NaN == NaN."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def norm_err(a, b):
+    """max|a-b| / max|b| — the float-tail parity metric of SURVEY.md section 8d."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))

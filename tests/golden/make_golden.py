@@ -1,0 +1,302 @@
+#!/usr/bin/env python
+"""Generate the golden vectors of tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; CPU torch).  Nothing of the reference
+travels: the outputs are data files (inputs + the reference's outputs, or SHA-256 digests of
+integer-exact outputs whose inputs come from the build-owned counter PRNG in
+pytorch_quantize_impls_amd/synth.py).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz, golden_hashes.json
+
+The import shim is environment-only: two names removed from
+torch._jit_internal are re-added as identities and QuantTorch/__init__.py (which pulls optuna /
+torchvision / progress, absent here) is bypassed by pre-registering an empty package object.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+
+from pytorch_quantize_impls_amd import synth  # noqa: E402
+
+
+def import_reference():
+    import torch._jit_internal as J
+    for n in ("weak_module", "weak_script_method"):
+        if not hasattr(J, n):
+            setattr(J, n, lambda x: x)
+    pkg = types.ModuleType("QuantTorch")
+    pkg.__path__ = [os.path.join(REF, "QuantTorch")]
+    sys.modules["QuantTorch"] = pkg
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import QuantTorch.functions as RF
+        import QuantTorch.layers as RL
+    return RF, RL
+
+
+RF, RL = import_reference()
+torch.manual_seed(0)
+T = torch.tensor
+out = {}
+
+
+def put(name, value):
+    if isinstance(value, torch.Tensor):
+        value = value.detach().cpu().numpy().copy()
+    out[name] = np.asarray(value)
+
+
+def f32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# G1  safeSign / BinaryConnectDeterministic forward + STE backward on edge values
+# ---------------------------------------------------------------------------------------------
+edge = np.array([0.0, -0.0, 1e-45, -1e-45, np.inf, -np.inf, np.nan, 0.5, -0.5, 1, -1, 1.001,
+                 -1.001, 1.0011, -1.0011, 2, -2, 0.33, -0.33], dtype=np.float32)
+put("g1_edge_x", edge)
+put("g1_safe_sign", RF.safeSign(f32(edge)))
+put("g1_bin_det_fwd", RF.BinaryConnectDeterministic.apply(f32(edge)))
+xg = f32(edge).clone().requires_grad_(True)
+g = f32(np.linspace(-3, 3, edge.size))
+RF.BinaryConnectDeterministic.apply(xg).backward(g)
+put("g1_bwd_gout", g)
+put("g1_bin_det_bwd", xg.grad)
+mask_x = np.array([2, 0.5, -1.0005, 1.001, -1.0011, 0], dtype=np.float32)
+xg = f32(mask_x).clone().requires_grad_(True)
+RF.BinaryConnectDeterministic.apply(xg).backward(torch.ones(6))
+put("g1_mask_x", mask_x)
+put("g1_mask", xg.grad)
+
+# ---------------------------------------------------------------------------------------------
+# G2  TernaryConnectDeterministic
+# ---------------------------------------------------------------------------------------------
+ter = np.array([0.75, 0.5, 0.25, 0, -1, -0.2, -0.5, 0.4999, -0.5001, 0.49999997, -0.50000006,
+                np.nan, np.inf, -np.inf, -0.0, 1e-45, 3, -3], dtype=np.float32)
+put("g2_x", ter)
+put("g2_ter_det_fwd", RF.TernaryConnectDeterministic.apply(f32(ter)))
+xg = f32(ter).clone().requires_grad_(True)
+g = f32(np.linspace(-2, 2, ter.size))
+RF.TernaryConnectDeterministic.apply(xg).backward(g)
+put("g2_bwd_gout", g)
+put("g2_ter_det_bwd", xg.grad)
+
+# ---------------------------------------------------------------------------------------------
+# G3  DoReFa _quantize / nnDorefaQuant / nnQuantWeight
+# ---------------------------------------------------------------------------------------------
+from QuantTorch.functions.dorefa_connect import _quantize as ref_quantize  # noqa: E402
+
+for k in (1, 2, 3, 4, 8, 16, 25, 31, 32):
+    n = float(2 ** k - 1)
+    vals = np.array([0.5 / n, 1.5 / n, 2.5 / n, 3.5 / n, -0.5 / n, -1.5 / n, 0.0, -0.0, 1.0, 0.3,
+                     -0.7, 3.2, -12.25, 0.49999997, 1e-8, 0.999, 1 / 3, 2 / 3], dtype=np.float32)
+    put(f"g3_quant_x_k{k}", vals)
+    put(f"g3_quant_y_k{k}", ref_quantize(f32(vals), bit_width=k))
+wq_in = synth.uniform(301, (6, 10), -2.5, 2.5)
+put("g3_wq_x", wq_in)
+for k in (1, 2, 3, 4, 8, 32):
+    w = f32(wq_in).clone().requires_grad_(True)
+    q = RF.nnQuantWeight(k)(w)
+    put(f"g3_wq_y_k{k}", q)
+    (q * f32(synth.uniform(302, (6, 10)))).sum().backward()
+    put(f"g3_wq_grad_k{k}", w.grad)
+put("g3_wq_gout", synth.uniform(302, (6, 10)))
+put("g3_wq_zero_k3", RF.nnQuantWeight(3)(torch.zeros(3, 2)))
+
+# ---------------------------------------------------------------------------------------------
+# G4  layers: forward + grads on small odd shapes
+# ---------------------------------------------------------------------------------------------
+lin_cases = []
+seed = 400
+for K in (31, 33, 96):
+    for binary_in in (True, False):
+        for with_bias in (False, True):
+            seed += 1
+            B, N = 5, 7
+            x = synth.pm1(seed, (B, K)) if binary_in else synth.normal(seed, (B, K))
+            w = synth.uniform(seed + 1000, (N, K), -1.5, 1.5)
+            b = synth.normal(seed + 2000, (N,)) if with_bias else None
+            gout = synth.normal(seed + 3000, (B, N))
+            tagname = f"K{K}_{'pm1' if binary_in else 'real'}_{'bias' if with_bias else 'nobias'}"
+            lin_cases.append(tagname)
+            put(f"g4_lin_{tagname}_x", x)
+            put(f"g4_lin_{tagname}_w", w)
+            if b is not None:
+                put(f"g4_lin_{tagname}_b", b)
+            put(f"g4_lin_{tagname}_gout", gout)
+            fams = {
+                "bin": lambda: RL.LinearBin(K, N, bias=with_bias),
+                "ter": lambda: RL.LinearTer(K, N, bias=with_bias),
+                "dorefa1": lambda: RL.LinearDorefa(K, N, bias=with_bias, bit_width=1),
+                "dorefa3": lambda: RL.LinearDorefa(K, N, bias=with_bias, bit_width=3),
+                "xnor": lambda: RL.LinearXNOR(K, N, bias=with_bias),
+            }
+            for fam, ctor in fams.items():
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    layer = ctor()
+                layer.weight.data.copy_(f32(w))
+                if with_bias:
+                    layer.bias.data.copy_(f32(b))
+                xi = f32(x).clone().requires_grad_(True)
+                y = layer(xi)
+                y.backward(f32(gout))
+                put(f"g4_lin_{tagname}_{fam}_y", y)
+                put(f"g4_lin_{tagname}_{fam}_gx", xi.grad)
+                put(f"g4_lin_{tagname}_{fam}_gw", layer.weight.grad)
+                if with_bias:
+                    put(f"g4_lin_{tagname}_{fam}_gb", layer.bias.grad)
+out["g4_lin_cases"] = np.array(lin_cases)
+
+conv_cases = []
+conv_cfgs = [  # (Cin, Cout, k, stride, pad, H, binary_in, bias)
+    (3, 4, 3, 1, 1, 6, False, True),
+    (32, 5, 3, 1, 1, 5, True, False),
+    (32, 5, 1, 1, 0, 4, True, True),
+    (64, 6, 5, 2, 2, 7, True, False),
+    (64, 3, 3, 2, 0, 7, True, True),
+    (96, 4, 3, 1, 2, 4, True, False),
+    (40, 4, 3, 1, 1, 4, True, False),   # Cin not a multiple of 32
+]
+for (Cin, Cout, k, st, pd, H, binary_in, with_bias) in conv_cfgs:
+    seed += 1
+    Bn = 2
+    x = synth.pm1(seed, (Bn, Cin, H, H)) if binary_in else synth.normal(seed, (Bn, Cin, H, H))
+    w = synth.uniform(seed + 1000, (Cout, Cin, k, k), -1.5, 1.5)
+    b = synth.normal(seed + 2000, (Cout,)) if with_bias else None
+    tagname = f"c{Cin}_o{Cout}_k{k}_s{st}_p{pd}_h{H}_{'pm1' if binary_in else 'real'}_{'bias' if with_bias else 'nobias'}"
+    conv_cases.append(tagname)
+    put(f"g4_conv_{tagname}_x", x)
+    put(f"g4_conv_{tagname}_w", w)
+    if b is not None:
+        put(f"g4_conv_{tagname}_b", b)
+    fams = {
+        "bin": lambda: RL.BinConv2d(Cin, Cout, k, stride=st, padding=pd, bias=with_bias),
+        "ter": lambda: RL.TerConv2d(Cin, Cout, k, stride=st, padding=pd, bias=with_bias),
+        "dorefa1": lambda: RL.DorefaConv2d(Cin, Cout, k, stride=st, padding=pd, bias=with_bias, bit_width=1),
+        "xnor": lambda: RL.XNORConv2d(Cin, Cout, k, stride=st, padding=pd, bias=with_bias),
+    }
+    for fam, ctor in fams.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            layer = ctor()
+        layer.weight.data.copy_(f32(w))
+        if with_bias:
+            layer.bias.data.copy_(f32(b))
+        y = layer(f32(x))
+        put(f"g4_conv_{tagname}_{fam}_y", y)
+out["g4_conv_cases"] = np.array(conv_cases)
+
+# ---------------------------------------------------------------------------------------------
+# G5  train/eval weight-swap traces
+# ---------------------------------------------------------------------------------------------
+w5 = synth.uniform(501, (4, 9), -1.5, 1.5)
+x5 = synth.normal(502, (3, 9))
+put("g5_w", w5)
+put("g5_x", x5)
+for fam, ctor in {"bin": lambda: RL.LinearBin(9, 4, bias=False),
+                  "ter": lambda: RL.LinearTer(9, 4, bias=False),
+                  "dorefa3": lambda: RL.LinearDorefa(9, 4, bias=False, bit_width=3)}.items():
+    layer = ctor()
+    layer.weight.data.copy_(f32(w5))
+    put(f"g5_{fam}_y_train", layer(f32(x5)))
+    layer.train(False)
+    put(f"g5_{fam}_w_eval", layer.weight.data)
+    put(f"g5_{fam}_y_eval", layer(f32(x5)))
+    layer.train(True)
+    put(f"g5_{fam}_w_back", layer.weight.data)
+
+# ---------------------------------------------------------------------------------------------
+# G6  stochastic ops with injected uniforms (torch.rand_like patched for the duration)
+# ---------------------------------------------------------------------------------------------
+x6 = np.concatenate([synth.uniform(601, (60,), -1.5, 1.5),
+                     np.array([0, -0.0, 1, -1, 0.5, -0.5, np.nan, 2, -2], dtype=np.float32)])
+z6 = synth.uniform(602, x6.shape, 0.0, 1.0)
+put("g6_x", x6)
+put("g6_z", z6)
+_orig = torch.rand_like
+torch.rand_like = lambda t, **kw: f32(z6).reshape(t.shape).clone()
+try:
+    put("g6_bin_sto", RF.BinaryConnectStochastic.apply(f32(x6)))
+    put("g6_ter_sto", RF.TernaryConnectStochastic.apply(f32(x6)))
+finally:
+    torch.rand_like = _orig
+
+# ---------------------------------------------------------------------------------------------
+# G7  config-sized cases: outputs / digests with PRNG-regenerated inputs
+# ---------------------------------------------------------------------------------------------
+hashes = {}
+
+
+def digest_int(y: torch.Tensor) -> str:
+    a = y.detach().cpu().numpy()
+    ai = a.astype(np.int32)
+    assert np.array_equal(ai.astype(np.float32), a), "output is not integer-valued"
+    return hashlib.sha256(np.ascontiguousarray(ai).tobytes()).hexdigest()
+
+
+# C1: MLP 784-512-10, batch 128 (benchmark/BinaryNet/MLPBin.py:40-56 cut to one hidden layer)
+x1 = synth.normal(0x5EED + 1, (128, 784))
+l1 = RL.LinearBin(784, 512)
+l2 = RL.LinearBin(512, 10)
+l1.weight.data.copy_(f32(synth.normal(0x5EED + 11, (512, 784), std=(1 / 784) ** 0.5)))
+l2.weight.data.copy_(f32(synth.normal(0x5EED + 12, (10, 512), std=(1 / 512) ** 0.5)))
+bn = torch.nn.BatchNorm1d(512, eps=1e-4, momentum=0.15)
+h = torch.relu(l1(f32(x1)))
+put("g7_c1_hidden_prebn", h)
+h = RF.BinaryConnectDeterministic.apply(bn(h))
+logits = torch.log_softmax(l2(h), dim=1)
+put("g7_c1_hidden_sign", h)
+put("g7_c1_logits", logits)
+
+# C2: LinearBin 4096x4096, batch 4096, +-1 input, bias 0 -> SHA-256 of the int32 result
+with torch.no_grad():
+    for (B, K, N, tag) in [(4096, 4096, 4096, "c2_full"), (256, 4096, 512, "c2_slice"),
+                           (64, 9216, 256, "c3_fc1_slice"), (33, 784, 65, "odd")]:
+        x2 = synth.pm1(0x5EED + 2, (B, K))
+        w2 = synth.uniform(0x5EED + 22, (N, K), -0.125, 0.125)
+        lin = RL.LinearBin(K, N)
+        lin.weight.data.copy_(f32(w2))
+        y2 = lin(f32(x2))
+        hashes[f"linbin_{tag}"] = {"B": B, "K": K, "N": N, "x_seed": 0x5EED + 2, "w_seed": 0x5EED + 22,
+                                   "w_lo": -0.125, "w_hi": 0.125, "sha256_int32": digest_int(y2),
+                                   "sum": float(y2.double().sum()), "abs_sum": float(y2.double().abs().sum())}
+        ter = RL.LinearTer(K, N)
+        ter.weight.data.copy_(f32(synth.uniform(0x5EED + 23, (N, K), -1.5, 1.5)))
+        y3 = ter(f32(x2))
+        hashes[f"linter_{tag}"] = {"B": B, "K": K, "N": N, "x_seed": 0x5EED + 2, "w_seed": 0x5EED + 23,
+                                   "w_lo": -1.5, "w_hi": 1.5, "sha256_int32": digest_int(y3),
+                                   "sum": float(y3.double().sum()), "abs_sum": float(y3.double().abs().sum())}
+
+    # C3 conv layers (A.1) at batch 2, +-1 input, bias 0
+    for (Cin, Cout, k, st, pd, H, tag) in [(192, 576, 5, 1, 2, 27, "alex_conv2"),
+                                           (576, 1152, 3, 1, 1, 13, "alex_conv3"),
+                                           (768, 256, 3, 1, 1, 13, "alex_conv5")]:
+        xc = synth.pm1(0x5EED + 3, (2, Cin, H, H))
+        wc = synth.uniform(0x5EED + 33, (Cout, Cin, k, k), -1.0, 1.0)
+        conv = RL.BinConv2d(Cin, Cout, k, stride=st, padding=pd)
+        conv.weight.data.copy_(f32(wc))
+        conv.bias.data.zero_()
+        yc = conv(f32(xc))
+        hashes[f"binconv_{tag}"] = {"B": 2, "Cin": Cin, "Cout": Cout, "k": k, "stride": st, "pad": pd,
+                                    "H": H, "x_seed": 0x5EED + 3, "w_seed": 0x5EED + 33,
+                                    "sha256_int32": digest_int(yc), "sum": float(yc.double().sum()),
+                                    "abs_sum": float(yc.double().abs().sum())}
+
+np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)
+with open(os.path.join(HERE, "golden_hashes.json"), "w") as fh:
+    json.dump({"torch": torch.__version__, "cases": hashes}, fh, indent=1, sort_keys=True)
+print(f"wrote {len(out)} arrays, {len(hashes)} digests; npz bytes =",
+      os.path.getsize(os.path.join(HERE, "golden_v1.npz")))

@@ -1,0 +1,264 @@
+"""Host logic of the functions/layers mirror on CPU tensors, modelled on the reference's own unit
+tests (tests/implementations/{BinaryNet,Terner,Dorefa}/*.py: closed-form known answers, train/eval
+swap protocol, STE gradients, statistics of the stochastic ops) and on the golden vectors."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import same, norm_err
+from pytorch_quantize_impls_amd.functions import (BinaryConnectDeterministic, BinaryConnectStochastic,
+                                                  BinaryConnect, BinaryDense, TernaryConnectDeterministic,
+                                                  TernaryConnectStochastic, TernaryDense, nnDorefaQuant,
+                                                  DorefaQuant, nnQuantWeight, safeSign, XNORDense,
+                                                  nnQuantXnor)
+from pytorch_quantize_impls_amd.functions.dorefa_connect import _quantize
+from pytorch_quantize_impls_amd.functions import binary_connect, terner_connect
+from pytorch_quantize_impls_amd.layers import (LinearBin, BinConv2d, LinearTer, TerConv2d, LinearDorefa,
+                                               DorefaConv2d, LinearXNOR, XNORConv2d, QLayer)
+
+T = torch.tensor
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+# ---- functions vs golden ---------------------------------------------------------------------
+
+def test_safe_sign_and_binary_connect_golden(golden):
+    x = t(golden["g1_edge_x"])
+    assert same(safeSign(x).numpy(), golden["g1_safe_sign"])
+    assert same(BinaryConnectDeterministic.apply(x).numpy(), golden["g1_bin_det_fwd"])
+    xg = x.clone().requires_grad_(True)
+    BinaryConnectDeterministic.apply(xg).backward(t(golden["g1_bwd_gout"]))
+    assert same(xg.grad.numpy(), golden["g1_bin_det_bwd"])
+
+
+def test_ternary_connect_golden(golden):
+    x = t(golden["g2_x"])
+    assert same(TernaryConnectDeterministic.apply(x).numpy(), golden["g2_ter_det_fwd"])
+    xg = x.clone().requires_grad_(True)
+    TernaryConnectDeterministic.apply(xg).backward(t(golden["g2_bwd_gout"]))
+    assert same(xg.grad.numpy(), golden["g2_ter_det_bwd"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 16, 25, 31, 32])
+def test_dorefa_quantize_golden(golden, k):
+    x = t(golden[f"g3_quant_x_k{k}"])
+    assert same(_quantize(x, k).numpy(), golden[f"g3_quant_y_k{k}"])
+    assert same(nnDorefaQuant(k)(x).numpy(), golden[f"g3_quant_y_k{k}"])
+    assert same(DorefaQuant(x, k).numpy(), golden[f"g3_quant_y_k{k}"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 32])
+def test_dorefa_weight_golden(golden, k):
+    w = t(golden["g3_wq_x"]).clone().requires_grad_(True)
+    q = nnQuantWeight(k)(w)
+    assert same(q.detach().numpy(), golden[f"g3_wq_y_k{k}"])
+    (q * t(golden["g3_wq_gout"])).sum().backward()
+    assert norm_err(w.grad.numpy(), golden[f"g3_wq_grad_k{k}"]) <= 1e-6
+    assert same(nnQuantWeight(3)(torch.zeros(3, 2)).numpy(), golden["g3_wq_zero_k3"])
+
+
+def test_stochastic_ops_with_injected_uniforms(golden):
+    x, z = t(golden["g6_x"]), t(golden["g6_z"])
+    assert same(binary_connect.stochastic_binarize(x, z).numpy(), golden["g6_bin_sto"])
+    assert same(terner_connect.stochastic_ternarize(x, z).numpy(), golden["g6_ter_sto"])
+
+
+def test_stochastic_statistics():
+    # tests/implementations/BinaryNet/function_test.py:36-44
+    w = T([[1., 0., -1.]])
+    r = torch.cat([BinaryConnectStochastic.apply(w) for _ in range(151)], 0).mean(0)
+    assert r[0] == 1 and r[2] == -1 and -0.2 < r[1] < 0.2
+    # tests/implementations/Terner/function_test.py:30-46
+    x = T([[1, 0, 0.45, -1, -0.9]])
+    res = torch.cat([TernaryConnectStochastic.apply(x) for _ in range(1000)], 0)
+    assert set(np.unique(res.numpy()).tolist()) <= {-1.0, 0.0, 1.0}
+    assert torch.all((res.mean(0) - x[0]).abs() < 5e-2)
+
+
+# ---- layers vs golden --------------------------------------------------------------------------
+
+def _mk(fam, K, N, bias):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return {"bin": lambda: LinearBin(K, N, bias=bias), "ter": lambda: LinearTer(K, N, bias=bias),
+                "dorefa1": lambda: LinearDorefa(K, N, bias=bias, bit_width=1),
+                "dorefa3": lambda: LinearDorefa(K, N, bias=bias, bit_width=3),
+                "xnor": lambda: LinearXNOR(K, N, bias=bias)}[fam]()
+
+
+def test_linear_layers_forward_backward_golden(golden):
+    for name in golden["g4_lin_cases"].tolist():
+        g = lambda s: golden[f"g4_lin_{name}_{s}"]
+        has_b = f"g4_lin_{name}_b" in golden.files
+        x, w, gout = g("x"), g("w"), g("gout")
+        for fam in ("bin", "ter", "dorefa1", "dorefa3", "xnor"):
+            layer = _mk(fam, x.shape[1], w.shape[0], has_b)
+            layer.weight.data.copy_(t(w))
+            if has_b:
+                layer.bias.data.copy_(t(g("b")))
+            xi = t(x).clone().requires_grad_(True)
+            y = layer(xi)
+            y.backward(t(gout))
+            if "_pm1_" in name and not has_b and fam in ("bin", "ter"):
+                assert same(y.detach().numpy(), g(f"{fam}_y")), (name, fam)
+            else:
+                assert norm_err(y.detach().numpy(), g(f"{fam}_y")) <= 1e-5, (name, fam)
+            assert norm_err(xi.grad.numpy(), g(f"{fam}_gx")) <= 1e-5, (name, fam)
+            assert norm_err(layer.weight.grad.numpy(), g(f"{fam}_gw")) <= 1e-5, (name, fam)
+            if has_b:
+                assert norm_err(layer.bias.grad.numpy(), g(f"{fam}_gb")) <= 1e-5
+
+
+def test_conv_layers_forward_golden(golden):
+    for name in golden["g4_conv_cases"].tolist():
+        p = name.split("_")
+        Cin, Cout, k, st, pd = int(p[0][1:]), int(p[1][1:]), int(p[2][1:]), int(p[3][1:]), int(p[4][1:])
+        has_b = p[7] == "bias"
+        x, w = golden[f"g4_conv_{name}_x"], golden[f"g4_conv_{name}_w"]
+        ctors = {"bin": lambda: BinConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b),
+                 "ter": lambda: TerConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b),
+                 "dorefa1": lambda: DorefaConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b, bit_width=1),
+                 "xnor": lambda: XNORConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b)}
+        for fam, ctor in ctors.items():
+            layer = ctor()
+            layer.weight.data.copy_(t(w))
+            if has_b:
+                layer.bias.data.copy_(t(golden[f"g4_conv_{name}_b"]))
+            y = layer(t(x)).detach().numpy()
+            assert norm_err(y, golden[f"g4_conv_{name}_{fam}_y"]) <= 1e-5, (name, fam)
+
+
+def test_eval_swap_protocol_golden(golden):
+    w, x = golden["g5_w"], golden["g5_x"]
+    for fam, ctor in {"bin": lambda: LinearBin(9, 4, bias=False), "ter": lambda: LinearTer(9, 4, bias=False),
+                      "dorefa3": lambda: LinearDorefa(9, 4, bias=False, bit_width=3)}.items():
+        layer = ctor()
+        layer.weight.data.copy_(t(w))
+        assert norm_err(layer(t(x)).detach().numpy(), golden[f"g5_{fam}_y_train"]) <= 1e-6
+        layer.train(False)
+        assert same(layer.weight.data.numpy(), golden[f"g5_{fam}_w_eval"])
+        assert hasattr(layer.weight, "org") and same(layer.weight.org.numpy(), w)
+        assert norm_err(layer(t(x)).detach().numpy(), golden[f"g5_{fam}_y_eval"]) <= 1e-6
+        layer.eval()  # no-op when already in eval mode
+        layer.train(True)
+        assert same(layer.weight.data.numpy(), golden[f"g5_{fam}_w_back"])
+
+
+# ---- known answers lifted from the reference's tests (values, not code) ----------------------------
+
+def test_known_answer_linear_bin():
+    # BinaryNet/layer_test.py:16-21: sign([.5, 0, -.5]) . [2, 1, -3] = 2 + 1 + 3 = 6
+    lin = LinearBin(3, 1, bias=False)
+    lin.weight.data.copy_(T([[0.5, 0, -0.5]]))
+    assert lin(T([[2., 1., -3.]])).item() == 6.0
+    lin2 = LinearBin(3, 1, bias=True)
+    lin2.weight.data.copy_(T([[0.5, 0, -0.5]]))
+    lin2.bias.data.copy_(T([3.]))
+    assert lin2(T([[2., 1., -3.]])).item() == 9.0
+
+
+def test_known_answer_bin_conv():
+    # BinaryNet/layer_test.py:37-63 (2x2 kernel over a 2x2x2 input)
+    w = T([[0.5, -0.5], [-0.5, 0.5], [1, -1], [0.5, 0.5]]).view(1, 2, 2, 2)
+    x = T([[1.1, 2.1], [15, .01], [1, 0], [1., 1.0]]).view(1, 2, 2, 2)
+    conv = BinConv2d(2, 1, [2, 2], stride=1, bias=False)
+    conv.weight.data.copy_(w)
+    expect = torch.nn.functional.conv2d(x, torch.where(w < 0, -1.0, 1.0))
+    assert torch.equal(conv(x), expect)
+    conv.train(False)
+    assert torch.equal(conv.weight.data, torch.where(w < 0, -1.0, 1.0))
+    assert torch.equal(conv(x), expect)
+    conv.train(True)
+    assert torch.equal(conv.weight.data, w)
+
+
+def test_ste_gradients_known_answers():
+    # BinaryNet/function_test.py:49-84
+    inputs = T([[2., -0.5, 1.]])
+    w1 = T([[0.5], [-0.5], [0.5]]).requires_grad_(True)
+    loss = inputs.mm(BinaryConnectDeterministic.apply(w1))
+    assert loss.item() == 2 + 0.5 + 1
+    loss.backward()
+    assert torch.equal(w1.grad, inputs.view(3, 1))
+    w2 = T([[2.], [0.5], [0.5]]).requires_grad_(True)
+    inputs.mm(BinaryConnectDeterministic.apply(w2)).backward()
+    assert torch.equal(w2.grad, T([[0.], [-0.5], [1.]]))
+    w3 = T([[2.], [0.5], [0.5]]).requires_grad_(True)
+    inputs.mm(BinaryConnectStochastic.apply(w3)).backward()
+    assert w3.grad[0] == 0.0
+    # Terner/function_test.py:82-94: gradient vanishes for |x| > 1
+    x = T([2, 1.0, 0.0, -1, -3]).requires_grad_(True)
+    TernaryConnectDeterministic.apply(x).sum().backward()
+    assert x.grad.tolist() == [0, 1, 1, 1, 0]
+    # Terner/layer_test.py:247-271: LinearTer weight grad is zero where |w| > 1
+    layer = LinearTer(4, 1)
+    layer.weight.data.copy_(T([[1., 4., 0., 3.]]))
+    (layer(torch.randn(5, 4)) ** 2).sum().backward()
+    assert layer.weight.grad[0, 1] == 0 and layer.weight.grad[0, 3] == 0
+
+
+def test_binary_dense_plain_backward():
+    # BinaryDense backward has NO STE mask (binary_connect.py:104-112), unlike LinearBin
+    x = torch.randn(4, 6, requires_grad=True)
+    w = (torch.randn(3, 6) * 2).requires_grad_(True)
+    b = torch.randn(3, requires_grad=True)
+    g = torch.randn(4, 3)
+    BinaryDense.apply(x, w, b).backward(g)
+    assert torch.allclose(w.grad, g.t().mm(x.detach()))
+    assert torch.allclose(x.grad, g.mm(torch.where(w.detach() < 0, -1.0, 1.0)))
+    assert torch.allclose(b.grad, g.sum(0))
+
+
+def test_api_surface_and_errors():
+    assert issubclass(LinearBin, QLayer) and issubclass(LinearBin, torch.nn.Linear)
+    assert issubclass(BinConv2d, torch.nn.Conv2d)
+    with pytest.raises(TypeError, match="Expected a torch.nn.Linear"):
+        LinearBin.convert(torch.nn.Conv2d(1, 1, 1))
+    with pytest.raises(TypeError, match="Expected a torch.nn.Conv2d"):
+        BinConv2d.convert(torch.nn.Linear(1, 1))
+    conv = BinConv2d.convert(torch.nn.Conv2d(3, 8, 3, stride=2, padding=1, bias=False))
+    assert (conv.in_channels, conv.out_channels, conv.stride, conv.padding, conv.bias) == (3, 8, (2, 2), (1, 1), None)
+    lin = LinearTer.convert(torch.nn.Linear(5, 2))
+    assert isinstance(lin, LinearTer) and lin.bias is not None
+    assert isinstance(LinearDorefa.convert(torch.nn.Linear(5, 2), bit_width=2), LinearDorefa)
+    with pytest.raises(RuntimeError):
+        nnQuantXnor(dim=3)
+    with pytest.warns(DeprecationWarning):
+        binary_connect.BinaryConv2d()
+    assert isinstance(BinaryConnect(), torch.nn.Module)
+    lin = LinearBin(8, 4)
+    assert float(lin.bias.abs().sum()) == 0.0            # reset_parameters: bias 0
+    lin.weight.data.mul_(100)
+    lin.bias.data.fill_(5)
+    lin.clamp()
+    assert float(lin.weight.abs().max()) <= 1 and float(lin.bias.max()) == 1  # bias clamped too
+    seq = torch.nn.Sequential(LinearBin(8, 4), BinaryConnect(), LinearBin(4, 2))
+    assert seq(torch.randn(3, 8)).shape == (3, 2)
+
+
+def test_xnor_layers_numerics_and_fixed_eval():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lin = LinearXNOR(6, 3, bias=False)
+    w = torch.randn(3, 6)
+    lin.weight.data.copy_(w)
+    x = torch.randn(4, 6)
+    alpha = w.abs().mean(0, keepdim=True)           # per INPUT feature (global DIM = 0 upstream)
+    assert torch.allclose(lin(x), x.mm((torch.sign(w) * alpha).t()), atol=1e-6)
+    lin.train(False)                                 # upstream raises NameError here; fixed
+    assert torch.allclose(lin.weight.data, torch.sign(w) * alpha)
+    lin.train(True)
+    assert torch.equal(lin.weight.data, w)
+    conv = XNORConv2d(4, 2, 3, padding=1, bias=False)
+    wc = torch.randn(2, 4, 3, 3)
+    conv.weight.data.copy_(wc)
+    xc = torch.randn(1, 4, 5, 5)
+    a = wc.abs().mean((0, 1), keepdim=True)
+    assert torch.allclose(conv(xc), torch.nn.functional.conv2d(xc, torch.sign(wc) * a, padding=1), atol=1e-5)
+    conv.train(False)
+    assert torch.allclose(conv.weight.data, torch.sign(wc) * a)
