@@ -23,9 +23,11 @@
  *                Row stride ("ldp", in words) must be a multiple of 4 (16-byte rows);
  *                every bit/word between K and 32*ldp is ZERO in every plane.
  *   nib plane  : FP4-E2M1 nibbles (two per byte, element 2i in the low nibble), value set
- *                {+1 = 0x2, -1 = 0xA, 0 = 0x0}; 8 elements per uint32 word.  Row stride in
- *                words must be a multiple of 8 (K padded to 64 with zero nibbles).  This is
- *                the MFMA operand format (v_mfma_scale_f32_32x32x64_f8f6f4, exact for +-1/0).
+ *                {+1 = 0x2, -1 = 0xA, 0 = 0x0}; 8 elements per uint32 word, element k of a row in
+ *                nibble (k & 7) of word (k >> 3).  Row stride in words must be a multiple of 4
+ *                (16-byte rows); every nibble between K and 8*ldp is ZERO.  This is the MFMA
+ *                operand format (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales is
+ *                exact for +-1 / 0 operands and K < 2^24).
  *
  * Reference interfaces replaced (paths relative to the reference repo root):
  *   the reference has NO native code; the functions below replace the ATen calls made from
@@ -134,6 +136,41 @@ int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t l
 int qt_tern_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
                  int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
                  int64_t K, qt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Matrix-core formulation of the same contractions (nibble planes, MX-fp4 MFMA).  Bit-identical
+ * results to qt_xnor_gemm / qt_tern_gemm; used for large M*N*K where the popcount path is
+ * VALU-bound (DESIGN.md "Kernels").
+ * ---------------------------------------------------------------------------------------- */
+
+/* nibble plane of safeSign(x): +1 -> 0x2, -1 -> 0xA (functions/common.py:4-7). */
+int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
+                         int64_t rows, int64_t K, qt_stream_t stream);
+
+/* nibble plane of TernaryConnectDeterministic(x): 0 -> 0x0 (functions/terner_connect.py:24-27). */
+int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
+                            int64_t rows, int64_t K, qt_stream_t stream);
+
+/* Y[M,N] = Xn . Wn^T (+ bias): replaces the same F.linear call sites as qt_xnor_gemm /
+ * qt_tern_gemm (binary and ternary weights share this entry point: zero is a nibble value). */
+int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp,
+                const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                qt_stream_t stream);
+
+/* nibble plane from existing bit planes (sign only: mask_plane == NULL; ternary: mask + sign).
+ * 1 bit -> 4 bits per element; lets the canonical 1-bit planes (what the quantisers emit and what
+ * eval-mode layers cache) feed the matrix-core GEMM without re-reading the fp32 tensor. */
+int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
+                   uint32_t* nib_plane, int64_t ldn, int64_t rows, int64_t K, qt_stream_t stream);
+
+/* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration
+ * (5 = 256x256 tile, LDS-DMA via builtin, any row stride % 4; 6 = same tile, asm-issued DMA
+ * interleaved with the MFMAs, needs row strides % 32 words and < 2 GiB operands; 0,1,2,4 and
+ * 1xx are earlier / ablation configurations kept for A/B measurements).
+ * qt_nib_gemm picks 6 when its contract holds, else 5. */
+int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
+                        int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,
+                        int64_t N, int64_t K, qt_stream_t stream);
 
 #ifdef __cplusplus
 }

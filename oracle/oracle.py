@@ -158,6 +158,44 @@ def tern_gemm(xs, wmask, wsign, K, bias=None):
     return y
 
 
+def packed_ld_nib(K: int) -> int:
+    kw = (int(K) + 7) // 8
+    return max(32, (kw + 31) // 32 * 32)
+
+
+def pack_nib(x2d, ternary=False):
+    x, xp = _f(x2d)
+    rows, K = x.shape
+    ld = packed_ld_nib(K)
+    out = np.zeros((rows, ld), dtype=np.uint32)
+    lib().qo_pack_nib(xp, _i64(K), out.ctypes.data_as(_u32p), _i64(ld), _i64(rows), _i64(K),
+                      ctypes.c_int(1 if ternary else 0))
+    return out
+
+
+def bits_to_nib(sign, mask, K):
+    sg, sgp = _u(sign)
+    rows, ldb = sg.shape
+    mp = None
+    if mask is not None:
+        mk, mp = _u(mask)
+    ld = packed_ld_nib(K)
+    out = np.zeros((rows, ld), dtype=np.uint32)
+    lib().qo_bits_to_nib(sgp, mp, _i64(ldb), out.ctypes.data_as(_u32p), _i64(ld), _i64(rows), _i64(K))
+    return out
+
+
+def nib_gemm(xn, wn, K, bias=None):
+    xn, xnp = _u(xn)
+    wn, wnp = _u(wn)
+    M, N = xn.shape[0], wn.shape[0]
+    b, bp = _optf(bias)
+    y = np.empty((M, N), dtype=np.float32)
+    lib().qo_nib_gemm(xnp, _i64(xn.shape[1]), wnp, _i64(wn.shape[1]), bp, y.ctypes.data_as(_f32p),
+                      _i64(N), _i64(M), _i64(N), _i64(K))
+    return y
+
+
 # ---- contractions (third-party in the reference: torch.nn.functional.linear / conv2d) ----------
 
 def linear(x, w, bias=None):

@@ -44,32 +44,38 @@ def quantize_weight_f32(weight: torch.Tensor, kind: str) -> torch.Tensor:
     raise ValueError(f"unknown quantiser kind {kind!r}")
 
 
-def pack_weight(weight_2d: torch.Tensor, kind: str) -> ops.BitPlanes:
-    """Bit planes of the deterministic quantiser applied to a [N, K] device weight.  Both
-    quantisers are idempotent, so this is also right for an already-quantised (eval / stochastic)
-    weight image."""
-    if kind == "binary":
-        return ops.sign_pack(weight_2d)[0]
-    if kind == "ternary":
-        return ops.ternary_pack(weight_2d)
-    raise ValueError(f"unknown quantiser kind {kind!r}")
+#: 'auto' | 'valu' | 'mfma' — packed-GEMM formulation used by the layers (both are bit-exact;
+#: 'auto' picks by shape, see ops.select_gemm_impl).
+GEMM_IMPL = "auto"
 
 
-def activation_planes(input: torch.Tensor, binary_input: Optional[bool]) -> Optional[ops.BitPlanes]:
-    """Sign planes of a device activation if it is (known to be) exactly +-1, else None."""
+def pack_weight(weight_2d: torch.Tensor, kind: str, impl: str = "valu"):
+    """Packed image (bit planes for 'valu', nibble plane for 'mfma') of the deterministic
+    quantiser applied to a [N, K] device weight.  Both quantisers are idempotent, so this is also
+    right for an already-quantised (eval / stochastic) weight image."""
+    if kind not in ("binary", "ternary"):
+        raise ValueError(f"unknown quantiser kind {kind!r}")
+    return ops.pack_weights(weight_2d, kind, impl)
+
+
+def activation_planes(input: torch.Tensor, binary_input: Optional[bool], impl: str = "valu"):
+    """Packed image (format of ``impl``) of a device activation if it is (known to be) exactly
+    +-1, else None."""
     if input.dtype != torch.float32 or input.numel() == 0:
         return None
     tagged = packed.lookup(input, packed.ROWS_LAST)
     if tagged is not None:
-        return tagged
+        K = input.shape[-1]
+        if tagged.K == K and tagged.rows * K == input.numel():
+            return ops.to_impl(tagged, impl)   # bit planes from the quantiser (1 bit -> 4 bits if mfma)
     if binary_input is False:
         return None
-    if binary_input is None:
+    if binary_input is None and tagged is None:
         if not DETECT_BINARY_INPUT:
             return None
         if int(ops.check_pm1(input).item()) != 0:  # host sync: only for un-tagged inputs
             return None
-    return ops.sign_pack(input)[0]
+    return ops.pack_activations(input, impl)
 
 
 def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -85,16 +91,18 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
         wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
         return F.linear(input, wq, bias)
 
-    xp = activation_planes(input, binary_input)
+    K = input.shape[-1]
+    N = weight.shape[0]
+    M = input.numel() // max(K, 1)
+    impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
+    xp = activation_planes(input, binary_input, impl)
     if xp is not None:
-        K = input.shape[-1]
-        if xp.K != K or xp.rows * K != input.numel():
-            xp = ops.sign_pack(input)[0]
         wp = weight_planes
         if wp is None:
-            wp = pack_weight(weight_q if weight_q is not None else weight, kind)
-        y = ops.xnor_gemm(xp, wp, bias) if kind == "binary" else ops.tern_gemm(xp, wp, bias)
-        return y.view(*input.shape[:-1], wp.rows)
+            wq = weight_q if weight_q is not None else weight
+            wp = pack_weight(wq.reshape(N, -1), kind, impl)
+        y = ops.packed_gemm(xp, wp, bias, impl=impl)
+        return y.view(*input.shape[:-1], N)
 
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
     return F.linear(input, wq, bias)

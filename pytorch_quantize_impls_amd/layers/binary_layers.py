@@ -57,13 +57,17 @@ class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
 def _eval_linear(layer, input, kind):
     """Eval-mode forward of a device layer: F.linear(input, weight, bias) (binary_layers.py:46)
     with the packed path when the activation is +-1."""
-    xp = _fused.activation_planes(input, layer.binary_input)
-    if xp is None or torch.is_grad_enabled() and (input.requires_grad or layer.weight.requires_grad):
-        # general fp32 path / autograd needed: this IS the reference expression
+    if torch.is_grad_enabled() and (input.requires_grad or layer.weight.requires_grad):
+        # autograd needed: this IS the reference expression (dense GEMM on the quantised image)
         return torch.nn.functional.linear(input, layer.weight, layer.bias)
-    wp = layer._eval_planes(lambda w2: _fused.pack_weight(w2, kind))
-    return _fused.quant_linear_forward(input, layer.weight, layer.bias, kind,
-                                       weight_q=layer.weight, weight_planes=wp, binary_input=True)
+    K, N = input.shape[-1], layer.weight.shape[0]
+    impl = _fused.ops.select_gemm_impl(_fused.GEMM_IMPL, input.numel() // max(K, 1), N, K)
+    xp = _fused.activation_planes(input, layer.binary_input, impl)
+    if xp is None:
+        return torch.nn.functional.linear(input, layer.weight, layer.bias)
+    wp = layer._eval_planes(lambda w2: _fused.pack_weight(w2, kind, impl), key=impl)
+    y = _fused.ops.packed_gemm(xp, wp, layer.bias, impl=impl)
+    return y.view(*input.shape[:-1], N)
 
 
 class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):

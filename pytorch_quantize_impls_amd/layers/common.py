@@ -48,15 +48,15 @@ class EvalSwapMixin:
             self._qt_eval_version = self.weight._version
         return self
 
-    def _eval_planes(self, packer):
-        """Packed planes of the eval-mode (already quantised) weight; rebuilt if the weight tensor
-        was written since eval() (load_state_dict, manual edits, .to(device))."""
+    def _eval_planes(self, packer, key="valu"):
+        """Packed image of the eval-mode (already quantised) weight in the operand format ``key``;
+        rebuilt if the weight tensor was written since eval() (load_state_dict, manual edits,
+        .to(device))."""
         w = self.weight
-        cached = getattr(self, "_qt_eval_planes", None)
-        if cached is not None:
-            planes, version, ptr = cached
-            if version == w._version and ptr == w.data_ptr():
-                return planes
-        planes = packer(w.detach().reshape(w.shape[0], -1))
-        self._qt_eval_planes = (planes, w._version, w.data_ptr())
-        return planes
+        cache = getattr(self, "_qt_eval_planes", None)
+        if not isinstance(cache, dict) or cache.get("version") != w._version or cache.get("ptr") != w.data_ptr():
+            cache = {"version": w._version, "ptr": w.data_ptr()}
+            self._qt_eval_planes = cache
+        if key not in cache:
+            cache[key] = packer(w.detach().reshape(w.shape[0], -1))
+        return cache[key]

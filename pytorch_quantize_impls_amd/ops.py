@@ -232,39 +232,144 @@ def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
 
 
 # ----------------------------------------------------------------------------------------------
+# matrix-core formulation: nibble planes (fp4-e2m1 +-1/0) + MX-fp4 MFMA GEMM
+# ----------------------------------------------------------------------------------------------
+
+def packed_ld_nib(K: int) -> int:
+    """Row stride (uint32 words) of a nibble plane: ceil(K/8) rounded up to 32 words (one 128-byte
+    K stage of the MFMA kernel), so the fast pipelined kernel's contract always holds."""
+    kw = (int(K) + 7) // 8
+    return max(32, (kw + 31) // 32 * 32)
+
+
+@dataclass
+class NibPlanes:
+    """fp4-e2m1 nibble image of a [rows, K] matrix with values in {-1, 0, +1}: int32 tensor
+    [rows, ld], element k in nibble (k & 7) of word (k >> 3); +1 = 0x2, -1 = 0xA, 0 = 0x0; pad = 0."""
+    words: torch.Tensor
+    rows: int
+    K: int
+
+    @property
+    def ld(self) -> int:
+        return int(self.words.shape[1])
+
+    @property
+    def device(self):
+        return self.words.device
+
+
+def _nib_pack(entry: str, x: torch.Tensor) -> NibPlanes:
+    _require(x, "input")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = packed_ld_nib(K)
+    words = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call(entry, _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)), _p(words),
+                  ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K), _stream(x.device))
+    return NibPlanes(words=words, rows=rows, K=K)
+
+
+def sign_pack_nib(x: torch.Tensor) -> NibPlanes:
+    """Nibble plane of safeSign(x) along the last dimension."""
+    return _nib_pack("qt_sign_pack_nib_f32", x)
+
+
+def ternary_pack_nib(x: torch.Tensor) -> NibPlanes:
+    """Nibble plane of TernaryConnectDeterministic(x) along the last dimension."""
+    return _nib_pack("qt_ternary_pack_nib_f32", x)
+
+
+def bits_to_nib(planes: BitPlanes) -> NibPlanes:
+    """Expand 1-bit planes (sign, or mask + sign) to the nibble plane the MFMA GEMM consumes."""
+    ld = packed_ld_nib(planes.K)
+    words = torch.empty((planes.rows, ld), dtype=torch.int32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        _lib.call("qt_bits_to_nib", _p(planes.sign), _p(planes.mask), ctypes.c_int64(planes.ld),
+                  _p(words), ctypes.c_int64(ld), ctypes.c_int64(planes.rows), ctypes.c_int64(planes.K),
+                  _stream(planes.device))
+    return NibPlanes(words=words, rows=planes.rows, K=planes.K)
+
+
+def nib_gemm(x: NibPlanes, w: NibPlanes, bias: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None, variant: Optional[int] = None) -> torch.Tensor:
+    """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) on the matrix cores; bit-identical to the popcount
+    GEMMs.  ``variant`` selects an explicit kernel configuration (tuning only)."""
+    if x.K != w.K:
+        raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
+    M, N, K = x.rows, w.rows, x.K
+    dev = x.device
+    bias = _check_bias(bias, N, dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    args = (_p(x.words), ctypes.c_int64(x.ld), _p(w.words), ctypes.c_int64(w.ld), _p(bias), _p(out),
+            ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M), ctypes.c_int64(N),
+            ctypes.c_int64(K), _stream(dev))
+    with torch.cuda.device(dev):
+        if variant is None:
+            _lib.call("qt_nib_gemm", *args)
+        else:
+            _lib.call("qt_nib_gemm_variant", ctypes.c_int(int(variant)), *args)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # formulation-agnostic front (bench.py and the layers go through this)
 # ----------------------------------------------------------------------------------------------
 
-GEMM_IMPLS = ("valu",)  # extended as formulations are added ("mfma": fp4 nibble planes)
+GEMM_IMPLS = ("valu", "mfma")
+
+#: shapes at least this large go to the matrix-core kernel under 'auto' (its 256x256 tile and
+#: ~10 us fixed cost only pay off for big problems; small-batch / small-N layers stay on the
+#: popcount kernel whose traffic is 4x smaller).
+MFMA_MIN_M, MFMA_MIN_N, MFMA_MIN_K = 192, 192, 256
 
 
 def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
-    """'auto' -> the fastest formulation available for the shape."""
+    """'auto' -> the faster formulation for the shape (both are bit-exact)."""
     if requested == "auto":
-        return "valu"
+        return "mfma" if (M >= MFMA_MIN_M and N >= MFMA_MIN_N and K >= MFMA_MIN_K and K < (1 << 24)) else "valu"
     if requested not in GEMM_IMPLS:
         raise NotImplementedError(f"packed GEMM formulation {requested!r} is not built "
                                   f"(available: {GEMM_IMPLS})")
     return requested
 
 
-def pack_activations(x: torch.Tensor, impl: str = "valu") -> BitPlanes:
-    """Sign planes of a +-1 (or about-to-be-binarised) activation matrix."""
+def pack_activations(x: torch.Tensor, impl: str = "valu"):
+    """Packed image of safeSign(x) in the operand format of ``impl``."""
     if impl == "valu":
         return sign_pack(x)[0]
+    if impl == "mfma":
+        return sign_pack_nib(x)
     raise NotImplementedError(impl)
 
 
-def pack_weights(w: torch.Tensor, kind: str = "binary", impl: str = "valu") -> BitPlanes:
+def pack_weights(w: torch.Tensor, kind: str = "binary", impl: str = "valu"):
     w2 = w.reshape(w.shape[0], -1)
     if impl == "valu":
         return sign_pack(w2)[0] if kind == "binary" else ternary_pack(w2)
+    if impl == "mfma":
+        return sign_pack_nib(w2) if kind == "binary" else ternary_pack_nib(w2)
     raise NotImplementedError(impl)
 
 
-def packed_gemm(x: BitPlanes, w: BitPlanes, bias=None, out=None, impl: str = "valu") -> torch.Tensor:
+def to_impl(planes, impl: str):
+    """Convert packed operands to the format ``impl`` consumes (bit planes -> nibble planes only)."""
+    if impl == "valu":
+        if isinstance(planes, BitPlanes):
+            return planes
+        raise TypeError("nibble planes cannot feed the popcount GEMM")
+    if isinstance(planes, NibPlanes):
+        return planes
+    return bits_to_nib(planes)
+
+
+def packed_gemm(x, w, bias=None, out=None, impl: str = "valu") -> torch.Tensor:
     if impl == "valu":
         return tern_gemm(x, w, bias, out) if w.is_ternary else xnor_gemm(x, w, bias, out)
+    if impl == "mfma":
+        return nib_gemm(to_impl(x, "mfma"), to_impl(w, "mfma"), bias, out)
     raise NotImplementedError(impl)
 
 
@@ -272,5 +377,6 @@ def packed_gemm_algorithmic_bytes(M: int, N: int, K: int, impl: str = "valu", pl
                                   bias: bool = False) -> float:
     """Algorithmic HBM bytes of ONE packed-GEMM launch (DESIGN.md 'Kernels'): every operand read
     once, the fp32 result written once.  bit planes: 1 bit/element/plane; nibble planes: 4 bits."""
-    bits = 1 if impl == "valu" else 4
-    return M * K * bits / 8.0 + planes_w * N * K * bits / 8.0 + 4.0 * M * N + (4.0 * N if bias else 0.0)
+    if impl == "valu":
+        return M * K / 8.0 + planes_w * N * K / 8.0 + 4.0 * M * N + (4.0 * N if bias else 0.0)
+    return M * K / 2.0 + N * K / 2.0 + 4.0 * M * N + (4.0 * N if bias else 0.0)

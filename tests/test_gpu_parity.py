@@ -192,6 +192,72 @@ def test_tern_gemm_vs_oracle(dev, oracle, M, N, K):
     assert same(y, oracle.linear(x, oracle.ternarize(w)))
 
 
+# ---- matrix-core formulation (nibble planes + MX-fp4 MFMA) ------------------------------------------------
+
+@pytest.mark.parametrize("rows,K", PACK_SHAPES)
+def test_nib_pack_vs_oracle(dev, oracle, rows, K):
+    x = synth.uniform(rows * 31 + K, (rows, K), -1.2, 1.2)
+    x[0, 0] = -0.0
+    if K > 2:
+        x[0, 1], x[0, 2] = 0.5, np.nan
+    with used("qt_sign_pack_nib_f32", "qt_ternary_pack_nib_f32", "qt_bits_to_nib"):
+        pn = ops.sign_pack_nib(g(x, dev))
+        tn = ops.ternary_pack_nib(g(x, dev))
+        assert pn.ld % 32 == 0
+        assert np.array_equal(planes_np(pn.words), oracle.pack_nib(x))
+        assert np.array_equal(planes_np(tn.words), oracle.pack_nib(x, ternary=True))
+        # 1-bit planes -> nibbles gives the same image
+        assert np.array_equal(planes_np(ops.bits_to_nib(ops.sign_pack(g(x, dev))[0]).words), oracle.pack_nib(x))
+        assert np.array_equal(planes_np(ops.bits_to_nib(ops.ternary_pack(g(x, dev))).words),
+                              oracle.pack_nib(x, ternary=True))
+
+
+NIB_GEMM_SHAPES = GEMM_SHAPES + [(256, 256, 256), (512, 256, 4096), (255, 257, 300), (300, 520, 1000)]
+
+
+@pytest.mark.parametrize("M,N,K", NIB_GEMM_SHAPES)
+@pytest.mark.parametrize("variant", [None, 5, 6])
+def test_nib_gemm_vs_oracle(dev, oracle, M, N, K, variant):
+    x = synth.pm1(M * 7 + K, (M, K))
+    w = synth.uniform(N * 5 + K, (N, K), -1.5, 1.5)
+    b = synth.normal(N, (N,))
+    with used("qt_nib_gemm" if variant is None else "qt_nib_gemm_variant"):
+        xn = ops.sign_pack_nib(g(x, dev))
+        y = n(ops.nib_gemm(xn, ops.sign_pack_nib(g(w, dev)), variant=variant))
+        yt = n(ops.nib_gemm(xn, ops.ternary_pack_nib(g(w, dev)), g(b, dev), variant=variant))
+    assert same(y, oracle.linear(x, oracle.safe_sign(w)))                    # the reference computation
+    assert same(yt, oracle.linear(x, oracle.ternarize(w)) + b[None, :])       # integer part exact + bias once
+
+
+def test_nib_gemm_equals_popcount_gemm_large(dev):
+    """Both formulations are bit-identical on a large ragged problem (MFMA tile edges, K tail)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    x = torch.randn((1000, 5000), device=dev, generator=gen)
+    w = torch.randn((777, 5000), device=dev, generator=gen)
+    ref = ops.xnor_gemm(ops.sign_pack(x)[0], ops.sign_pack(w)[0])
+    for variant in (None, 5, 6):
+        assert torch.equal(ops.nib_gemm(ops.sign_pack_nib(x), ops.sign_pack_nib(w), variant=variant), ref)
+    reft = ops.tern_gemm(ops.sign_pack(x)[0], ops.ternary_pack(w))
+    assert torch.equal(ops.nib_gemm(ops.bits_to_nib(ops.sign_pack(x)[0]), ops.bits_to_nib(ops.ternary_pack(w))), reft)
+
+
+def test_layers_route_large_shapes_to_mfma(dev, oracle):
+    x = synth.normal(41, (256, 512))
+    w = synth.uniform(42, (320, 512), -1, 1)
+    want = oracle.linear_bin_forward(oracle.safe_sign(x), w)
+    for cls, wantf in ((LinearBin, want), (LinearTer, oracle.linear_ter_forward(oracle.safe_sign(x), w))):
+        layer = cls(512, 320, bias=False).to(dev)
+        layer.weight.data.copy_(g(w, dev))
+        with used("qt_nib_gemm", "qt_bits_to_nib"):
+            y = layer(BinaryConnectDeterministic.apply(g(x, dev)))
+        assert same(n(y), wantf)
+        layer.eval()
+        with torch.no_grad(), used("qt_nib_gemm"):
+            y2 = layer(BinaryConnectDeterministic.apply(g(x, dev)))
+        assert same(n(y2), wantf)
+
+
 def test_gemm_empty_and_errors(dev):
     xp = ops.sign_pack(torch.ones((4, 64), device=dev))[0]
     wp = ops.sign_pack(torch.ones((0, 64), device=dev))[0]
@@ -318,10 +384,16 @@ def test_reference_digests(dev, golden_hashes, case):
     cls = LinearBin if case.startswith("linbin") else LinearTer
     layer = cls(h["K"], h["N"], bias=False).to(dev)
     layer.weight.data.copy_(g(w, dev))
-    with torch.no_grad(), used("qt_xnor_gemm" if cls is LinearBin else "qt_tern_gemm"):
-        y = layer(BinaryConnectDeterministic.apply(g(x, dev)))
-    yi = n(y).astype(np.int32)
-    assert hashlib.sha256(yi.tobytes()).hexdigest() == h["sha256_int32"]
+    from pytorch_quantize_impls_amd.functions import _fused
+    for impl, entry in (("valu", "qt_xnor_gemm" if cls is LinearBin else "qt_tern_gemm"), ("mfma", "qt_nib_gemm")):
+        _fused.GEMM_IMPL = impl
+        try:
+            with torch.no_grad(), used(entry):
+                y = layer(BinaryConnectDeterministic.apply(g(x, dev)))
+        finally:
+            _fused.GEMM_IMPL = "auto"
+        yi = n(y).astype(np.int32)
+        assert hashlib.sha256(yi.tobytes()).hexdigest() == h["sha256_int32"], impl
 
 
 def test_c2_full_size_properties(dev):

@@ -160,3 +160,19 @@ def test_g7_digests_packed_oracle(golden_hashes, oracle, case):
         m, s = oracle.ternary_pack(w)
         y = oracle.tern_gemm(oracle.sign_pack(x), m, s, h["K"])
     assert hashlib.sha256(y.astype(np.int32).tobytes()).hexdigest() == h["sha256_int32"]
+
+
+def test_nibble_formulation_equals_reference(golden, oracle):
+    """The fp4-nibble restatement (what the MFMA kernel computes) reproduces the reference too."""
+    for name in golden["g4_lin_cases"].tolist():
+        if "_pm1_" not in name or name.endswith("_bias"):
+            continue
+        x, w, b, _ = _lin_case(golden, name)
+        K = x.shape[1]
+        xn = oracle.pack_nib(x)
+        assert np.array_equal(xn, oracle.bits_to_nib(oracle.sign_pack(x), None, K))
+        assert same(oracle.nib_gemm(xn, oracle.pack_nib(w), K), golden[f"g4_lin_{name}_bin_y"])
+        wt = oracle.pack_nib(w, ternary=True)
+        m, s = oracle.ternary_pack(w)
+        assert np.array_equal(wt, oracle.bits_to_nib(s, m, K))
+        assert same(oracle.nib_gemm(xn, wt, K), golden[f"g4_lin_{name}_ter_y"])
