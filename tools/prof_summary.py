@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (kernel-trace --stats, and separate --pmc passes) into the text
+summary committed under profiles/.
+
+    python tools/prof_summary.py gpurun_out/r1 > profiles/r1_bench_c2_rocprof.md
+
+Expects <dir>/kt (kernel stats), and optionally <dir>/pmc_fetch, pmc_write, pmc_l2.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF the bytes of a wide coalesced
+read stream (MI355X_MICROARCH.md, HBM section) so the corrected column doubles it; WRITE_SIZE is
+uncorrected (uncalibrated)."""
+import collections
+import csv
+import os
+import sys
+
+d = sys.argv[1]
+ours = ("nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
+        "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
+        "check_pm1_kernel", "conv", "im2col")
+
+
+def short(n):
+    for k in ours:
+        if k in n:
+            tail = ""
+            if "<" in n and k in ("nib_gemm_kernel", "popc_gemm_kernel"):
+                tail = n[n.index("<"):n.index(">") + 1][:60]
+            return k + tail
+    return n.split("(")[0][-60:]
+
+
+print(f"# rocprofv3 summary of `{d}`\n")
+ks = os.path.join(d, "kt", "bench_kernel_stats.csv")
+if os.path.exists(ks):
+    print("## kernel-trace --stats (top kernels)\n")
+    print("| kernel | calls | total us | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in list(csv.DictReader(open(ks)))[:8]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | "
+              f"{float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
+print("\n## PMC (separate passes, per-dispatch averages)\n")
+print("| kernel | counter | dispatches | avg value | as bytes |")
+print("|---|---|---|---|---|")
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    f = os.path.join(d, sub, "bench_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, dd in sorted(agg.items()):
+        if not any(o in k for o in ours):
+            continue
+        for c, v in dd.items():
+            avg = sum(v) / len(v)
+            note = ""
+            if c == "FETCH_SIZE":
+                note = f"{avg*1024/1e6:.1f} MB raw, {2*avg*1024/1e6:.1f} MB corrected (x2, gfx950)"
+            elif c == "WRITE_SIZE":
+                note = f"{avg*1024/1e6:.1f} MB (uncalibrated)"
+            print(f"| {k} | {c} | {len(v)} | {avg:.1f} | {note} |")
