@@ -163,6 +163,20 @@ int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ld
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
                    uint32_t* nib_plane, int64_t ldn, int64_t rows, int64_t K, qt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Quantised conv2d = packed-domain im2col + packed GEMM (replaces torch.nn.functional.conv2d on
+ * quantised operands: layers/binary_layers.py:105,106; layers/terner_layers.py:91,92).
+ * P: NHWC pixel plane [N][H][W][Cw] of words (bit or nibble plane of the channel vector, Cw % 4 == 0,
+ * pad channels zero).  A: rows m = (n,ho,wo) in [m_begin, m_begin+m_count), each the kh*kw taps' Cw
+ * words (ZERO words for taps in the padding), zero-filled up to ldA.  With nibble planes the zero
+ * words are the reference's zero padding exactly.  Y = A . Wpacked^T with Wpacked[Cout][kh*kw*Cw]
+ * (weights packed per (cout, tap) with the same Cw) is then the NHWC conv output.
+ * ---------------------------------------------------------------------------------------- */
+int qt_im2col_words(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t kh,
+                    int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                    int64_t dw, uint32_t* A, int64_t ldA, int64_t m_begin, int64_t m_count,
+                    qt_stream_t stream);
+
 /* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration
  * (5 = 256x256 tile, LDS-DMA via builtin, any row stride % 4; 6 = same tile, asm-issued DMA
  * interleaved with the MFMAs, needs row strides % 32 words and < 2 GiB operands; 0,1,2,4 and

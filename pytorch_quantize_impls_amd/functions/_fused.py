@@ -108,13 +108,85 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
     return F.linear(input, wq, bias)
 
 
+def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool]):
+    """NHWC nibble pixel plane of a device activation that is (known to be) exactly +-1, else None."""
+    if input.dtype != torch.float32 or input.dim() != 4 or input.numel() == 0:
+        return None
+    tagged = packed.lookup(input, packed.NHWC)
+    if tagged is not None:
+        N, C, H, W = input.shape
+        if tagged.K == C and tagged.rows == N * H * W:
+            return ops.bits_to_nib(tagged, ld=ops.pixel_ld_nib(C))
+    if binary_input is False:
+        return None
+    if binary_input is None and tagged is None:
+        if not DETECT_BINARY_INPUT:
+            return None
+        if int(ops.check_pm1(input).item()) != 0:   # host sync: only for un-tagged inputs
+            return None
+    return ops.pack_pixels_nib(input)
+
+
 def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
-                         weight_q: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """conv2d(input, Q(weight), bias, ...).  Weight quantisation runs in the HIP elementwise
-    kernel; the contraction of a device tensor currently goes to the dense conv library on the
-    exact +-1/0 weight image (bit-packed conv: DESIGN.md 'next')."""
+                         weight_q: Optional[torch.Tensor] = None, weight_planes=None,
+                         binary_input: Optional[bool] = None, padding_mode: str = "zeros") -> torch.Tensor:
+    """conv2d(input, Q(weight), bias, ...).
+
+    Device tensor with +-1 activations, groups == 1, zero padding: NHWC pixel planes -> packed-domain
+    im2col -> matrix-core packed GEMM (libqt_hip.so); the result keeps the input's memory format
+    (channels_last in -> channels_last out, like torch's own conv).  Otherwise (first layer with real
+    pixels, grouped conv): weight quantised by the HIP elementwise kernel, contraction by the dense
+    conv library on the exact +-1/0 weight image."""
+    packable = (input.is_cuda and groups == 1 and padding_mode == "zeros" and input.dim() == 4
+                and not isinstance(padding, str))
+    if packable:
+        px = _pixel_planes(input, binary_input)
+        if px is not None:
+            wq = weight_q if weight_q is not None else weight
+            wp = weight_planes if weight_planes is not None else ops.pack_conv_weight_nib(wq, kind)
+            N, C, H, W = input.shape
+            kh, kw = int(weight.shape[2]), int(weight.shape[3])
+            y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), bias, stride, padding, dilation)
+            Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+            y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # NCHW view, NHWC storage
+            if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous()                                         # caller works in NCHW storage
+            return y
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
+
+
+class QuantConv2dFn(torch.autograd.Function):
+    """Autograd node of BinConv2d / TerConv2d in training mode: forward F.conv2d(x, Q(W), b, ...)
+    (layers/binary_layers.py:105); backward = what autograd derives from F.conv2d plus the STE mask
+    of the weight quantiser."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, kind, weight_q, binary_input, conv_args):
+        ctx.kind, ctx.conv_args, ctx.has_bias = kind, conv_args, bias is not None
+        ctx.save_for_backward(input, weight, weight_q)
+        stride, padding, dilation, groups = conv_args
+        return quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind,
+                                    weight_q=weight_q, binary_input=binary_input)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from .common import ste_mask
+        input, weight, weight_q = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        grad_input = grad_weight = grad_bias = None
+        go = grad_output.contiguous()
+        if ctx.needs_input_grad[0]:
+            wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
+            grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
+                                                    dilation=dilation, groups=groups)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
+                                             dilation=dilation, groups=groups)
+            grad_weight = ste_mask(gw.contiguous(), weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = go.sum((0, 2, 3))
+        return grad_input, grad_weight, grad_bias, None, None, None, None
 
 
 class QuantLinearFn(torch.autograd.Function):

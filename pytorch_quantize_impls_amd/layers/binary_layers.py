@@ -99,9 +99,25 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self.bin_op.apply(self.weight)
 
     def forward(self, input):
-        w = self.bin_op.apply(self.weight) if self.training else self.weight
-        return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
-                                          self.dilation, self.groups)
+        if not input.is_cuda:
+            w = self.bin_op.apply(self.weight) if self.training else self.weight
+            return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
+                                              self.dilation, self.groups)
+        args = (self.stride, self.padding, self.dilation, self.groups)
+        if self.training:
+            wq = None if self.deterministic else self.bin_op.apply(self.weight.detach())
+            return _fused.QuantConv2dFn.apply(input, self.weight, self.bias, "binary", wq,
+                                              self.binary_input, args)
+        # eval: weight already holds the quantised image; its packed planes are cached
+        if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
+        wp = None
+        if self.groups == 1 and self.padding_mode == "zeros":
+            wp = self._eval_planes(lambda _w2: _fused.ops.pack_conv_weight_nib(self.weight.detach(), "binary"),
+                                   key="conv_nib")
+        return _fused.quant_conv2d_forward(input, self.weight, self.bias, *args, "binary",
+                                           weight_q=self.weight, weight_planes=wp,
+                                           binary_input=self.binary_input, padding_mode=self.padding_mode)
 
 
 class ShiftNormBatch1d(torch.nn.Module):

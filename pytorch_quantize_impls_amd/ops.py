@@ -259,11 +259,11 @@ class NibPlanes:
         return self.words.device
 
 
-def _nib_pack(entry: str, x: torch.Tensor) -> NibPlanes:
+def _nib_pack(entry: str, x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
     _require(x, "input")
     x2 = _as_rows(x)
     rows, K = int(x2.shape[0]), int(x2.shape[1])
-    ld = packed_ld_nib(K)
+    ld = packed_ld_nib(K) if ld is None else int(ld)
     words = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.call(entry, _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)), _p(words),
@@ -271,19 +271,19 @@ def _nib_pack(entry: str, x: torch.Tensor) -> NibPlanes:
     return NibPlanes(words=words, rows=rows, K=K)
 
 
-def sign_pack_nib(x: torch.Tensor) -> NibPlanes:
-    """Nibble plane of safeSign(x) along the last dimension."""
-    return _nib_pack("qt_sign_pack_nib_f32", x)
+def sign_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
+    """Nibble plane of safeSign(x) along the last dimension (``ld``: row stride in words, % 4)."""
+    return _nib_pack("qt_sign_pack_nib_f32", x, ld)
 
 
-def ternary_pack_nib(x: torch.Tensor) -> NibPlanes:
+def ternary_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
     """Nibble plane of TernaryConnectDeterministic(x) along the last dimension."""
-    return _nib_pack("qt_ternary_pack_nib_f32", x)
+    return _nib_pack("qt_ternary_pack_nib_f32", x, ld)
 
 
-def bits_to_nib(planes: BitPlanes) -> NibPlanes:
+def bits_to_nib(planes: BitPlanes, ld: Optional[int] = None) -> NibPlanes:
     """Expand 1-bit planes (sign, or mask + sign) to the nibble plane the MFMA GEMM consumes."""
-    ld = packed_ld_nib(planes.K)
+    ld = packed_ld_nib(planes.K) if ld is None else int(ld)
     words = torch.empty((planes.rows, ld), dtype=torch.int32, device=planes.device)
     with torch.cuda.device(planes.device):
         _lib.call("qt_bits_to_nib", _p(planes.sign), _p(planes.mask), ctypes.c_int64(planes.ld),
@@ -312,6 +312,85 @@ def nib_gemm(x: NibPlanes, w: NibPlanes, bias: Optional[torch.Tensor] = None,
         else:
             _lib.call("qt_nib_gemm_variant", ctypes.c_int(int(variant)), *args)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# quantised conv2d = NHWC pixel planes -> packed-domain im2col -> packed GEMM
+# ----------------------------------------------------------------------------------------------
+
+def pixel_ld_nib(C: int) -> int:
+    """Words per pixel of an NHWC nibble pixel plane: ceil(C/8) rounded up to 4 (16-byte chunks)."""
+    return max(4, ((int(C) + 7) // 8 + 3) // 4 * 4)
+
+
+def _pairs(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def conv_out_hw(H, W, kh, kw, stride, padding, dilation):
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+
+
+def pack_conv_weight_nib(weight: torch.Tensor, kind: str) -> NibPlanes:
+    """[Cout, Cin, kh, kw] fp32 -> nibble plane [Cout, kh*kw*Cw] (tap-major, channels inside a tap,
+    Cw words per tap = pixel_ld_nib(Cin)), row stride padded to a whole GEMM stage."""
+    _require(weight, "weight")
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    Cw = pixel_ld_nib(Cin)
+    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)   # plumbing (weights are small)
+    taps = sign_pack_nib(wt, ld=Cw) if kind == "binary" else ternary_pack_nib(wt, ld=Cw)
+    kwords = kh * kw * Cw
+    ld = max(32, (kwords + 31) // 32 * 32)
+    words = taps.words.view(Cout, kwords)
+    if ld != kwords:
+        padded = torch.zeros((Cout, ld), dtype=torch.int32, device=weight.device)
+        padded[:, :kwords] = words
+        words = padded
+    return NibPlanes(words=words, rows=Cout, K=kwords * 8)
+
+
+def pack_pixels_nib(x: torch.Tensor) -> NibPlanes:
+    """+-1 activation [N, C, H, W] (any memory format) -> NHWC nibble pixel plane [N*H*W, Cw]."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    nhwc = x.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()          # NCHW storage: one transpose copy (plumbing)
+    return sign_pack_nib(nhwc.view(N * H * W, C), ld=pixel_ld_nib(C))
+
+
+#: upper bound on the bytes of the temporary im2col matrix (the batch is processed in chunks)
+IM2COL_MAX_BYTES = 1 << 30
+
+
+def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=None, stride=1,
+               padding=0, dilation=1) -> torch.Tensor:
+    """Quantised conv2d on packed operands.  pixels: NHWC nibble pixel plane of the +-1 activation
+    (shape ``in_shape`` = (N, C, H, W)); wplanes: pack_conv_weight_nib(...).  Returns the NHWC result
+    as a [N*Ho*Wo, Cout] fp32 matrix."""
+    N, C, H, W = (int(v) for v in in_shape)
+    kh, kw = kernel_hw
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    Cw = pixels.ld
+    if wplanes.K != kh * kw * Cw * 8:
+        raise ValueError("weight planes do not match the activation's channel packing")
+    Cout, ldA = wplanes.rows, wplanes.ld
+    M = N * Ho * Wo
+    dev = pixels.device
+    bias = _check_bias(bias, Cout, dev)
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+    rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
+    A = torch.empty((rows_per_chunk, ldA), dtype=torch.int32, device=dev)
+    I = ctypes.c_int64
+    for m0 in range(0, M, rows_per_chunk):
+        cnt = min(rows_per_chunk, M - m0)
+        with torch.cuda.device(dev):
+            _lib.call("qt_im2col_words", _p(pixels.words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh),
+                      I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
+        nib_gemm(NibPlanes(words=A[:cnt], rows=cnt, K=wplanes.K), wplanes, bias, out=y[m0:m0 + cnt])
+    return y
 
 
 # ----------------------------------------------------------------------------------------------

@@ -321,6 +321,56 @@ def test_conv_layers_golden_forward(dev, golden):
                 assert norm_err(y, ref) <= TOL, (name, fam)
 
 
+@pytest.mark.parametrize("case", ["binconv_alex_conv2", "binconv_alex_conv3", "binconv_alex_conv5"])
+@pytest.mark.parametrize("fmt", ["nchw", "channels_last", "tagged"])
+def test_conv_reference_digests(dev, golden_hashes, case, fmt):
+    """AlexNet-Bin conv layers at batch 2: SHA-256 of the int32 result the
+    REFERENCE produced, through the packed conv path (pixel planes -> packed im2col -> MFMA GEMM)."""
+    h = golden_hashes[case]
+    x = synth.pm1(h["x_seed"], (h["B"], h["Cin"], h["H"], h["H"]))
+    w = synth.uniform(h["w_seed"], (h["Cout"], h["Cin"], h["k"], h["k"]), -1.0, 1.0)
+    conv = BinConv2d(h["Cin"], h["Cout"], h["k"], stride=h["stride"], padding=h["pad"]).to(dev)
+    conv.weight.data.copy_(g(w, dev))
+    conv.bias.data.zero_()
+    xd = g(x, dev)
+    if fmt != "nchw":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    if fmt == "tagged":
+        xd = BinaryConnectDeterministic.apply(xd)
+        assert packed.lookup(xd, packed.NHWC) is not None
+    for training in (True, False):
+        conv.train(training)
+        with torch.no_grad(), used("qt_im2col_words", "qt_nib_gemm"):
+            y = conv(xd)
+        assert y.shape == (h["B"], h["Cout"], h["H"], h["H"])
+        assert y.is_contiguous(memory_format=torch.channels_last) == (fmt != "nchw")
+        yi = n(y.contiguous()).astype(np.int32)
+        assert hashlib.sha256(yi.tobytes()).hexdigest() == h["sha256_int32"], (fmt, training)
+
+
+def test_conv_backward_matches_dense(dev):
+    """Training-mode BinConv2d / TerConv2d: packed forward, autograd backward = dense conv + STE mask."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    x = torch.randn((3, 32, 9, 9), device=dev, generator=gen).sign()
+    for cls in (BinConv2d, TerConv2d):
+        layer = cls(32, 6, 3, stride=2, padding=1).to(dev)
+        layer.weight.data.mul_(8)          # some |w| > 1.001 so the STE mask matters
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi)
+        go = torch.randn(y.shape, device=dev, generator=gen)
+        y.backward(go)
+        wq = (ops.binarize if cls is BinConv2d else ops.ternarize)(layer.weight.detach())
+        xr = x.clone().requires_grad_(True)
+        wr = wq.clone().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, layer.bias, stride=2, padding=1)
+        yr.backward(go)
+        assert torch.equal(y, yr + 0)      # integer-valued + same bias add
+        assert norm_err(n(xi.grad), n(xr.grad)) <= TOL
+        mask = (layer.weight.detach().abs() <= 1.001).float()
+        assert norm_err(n(layer.weight.grad), n(wr.grad * mask)) <= TOL
+
+
 def test_eval_swap_on_device(dev, golden):
     w, x = golden["g5_w"], golden["g5_x"]
     for fam, cls in (("bin", LinearBin), ("ter", LinearTer)):
