@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--gemm", default="auto", choices=["auto", "valu", "mfma"],
                     help="packed GEMM formulation (auto = fastest available for the shape)")
+    ap.add_argument("--alexnet-batch", type=int, default=256, help="images per GPU (0 = skip)")
+    ap.add_argument("--alexnet-iters", type=int, default=5)
     return ap.parse_args()
 
 
@@ -158,6 +160,10 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- BinaryNet-AlexNet images/s (second half of BASELINE.json's metric) ---------------------------
+    if args.alexnet_batch > 0:
+        result["alexnet"] = bench_alexnet(args, dev, dist, world, rank)
+
     # ---- parity gate + CPU baseline (rank 0, N = 1 only) --------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_port
@@ -178,6 +184,50 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_alexnet(args, dev, dist, world, rank):
+    """BinaryNet-AlexNet (models/Alexnet/Alexnet_Bin.py topology) eval-mode
+    forward, 3x224x224, batch per GPU = --alexnet-batch, channels_last, weights pre-quantised and
+    pre-packed by .eval() (the reference's eval protocol)."""
+    import bench_models
+    B = args.alexnet_batch
+    torch.manual_seed(1234 + rank)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn((B, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for _ in range(2):
+            y = model(x)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.alexnet_iters):
+            y = model(x)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    out = {"images_per_s": world * B * args.alexnet_iters / el, "batch_per_gpu": B,
+           "ms_per_forward": el / args.alexnet_iters * 1e3, "mode": "eval (pre-packed weights), channels_last",
+           "macs_per_image": 4.9349e9, "finite": bool(torch.isfinite(y).all())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = min(B, 16)
+        cpu_model = bench_models.AlexNetBin()
+        cpu_model.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        cpu_model.eval()
+        xc = x[:cb].cpu().contiguous()
+        from oracle import torch_port
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            med, iters = torch_port.time_callable(lambda: cpu_model(xc), budget_s=min(args.cpu_budget_s, 8.0))
+        out["cpu_baseline"] = {"images_per_s": cb / med, "batch": cb, "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"{iters} forwards of the same topology on CPU tensors, median"}
+    return out
 
 
 def _cpu_model():

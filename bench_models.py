@@ -1,0 +1,79 @@
+"""Model compositions used by bench.py / tests — the reference's topologies rebuilt from this
+package's layers (the reference's own model files are not importable).
+
+AlexNetBin: models/Alexnet/Alexnet_Bin.py:6-69 (coef = 3).
+BinMLP    : benchmark/BinaryNet/MLPBin.py:6-56 cut to one hidden layer (BASELINE config C1).
+"""
+import torch
+from torch import nn
+
+from pytorch_quantize_impls_amd.functions import BinaryConnect
+from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
+
+
+class AlexNetBin(nn.Module):
+    def __init__(self, num_classes=10, coef=3):
+        super().__init__()
+        c = coef
+        self.features = nn.Sequential(
+            BinConv2d(3, 64 * c, kernel_size=11, stride=4, padding=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(64 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            BinConv2d(64 * c, 192 * c, kernel_size=5, padding=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(192 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            BinConv2d(192 * c, 384 * c, kernel_size=3, padding=1),
+            nn.BatchNorm2d(384 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            BinConv2d(384 * c, 256 * c, kernel_size=3, padding=1),
+            nn.BatchNorm2d(256 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            BinConv2d(256 * c, 256, kernel_size=3, padding=1),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(256), nn.Hardtanh(inplace=True),
+        )
+        self.classifieur = nn.Sequential(
+            BinaryConnect(stochastic=False), LinearBin(256 * 6 * 6, 4096),
+            nn.BatchNorm1d(4096), nn.Hardtanh(inplace=True),
+            BinaryConnect(stochastic=False), LinearBin(4096, 4096),
+            nn.BatchNorm1d(4096), nn.Hardtanh(inplace=True),
+            BinaryConnect(stochastic=False), LinearBin(4096, num_classes),
+            nn.LogSoftmax(dim=1),
+        )
+
+    def clip(self):
+        for layer in self.modules():
+            if isinstance(layer, (BinConv2d, LinearBin)):
+                layer.clamp()
+
+    def forward(self, x):
+        x = self.features(x)
+        x = x.reshape(x.size(0), 256 * 6 * 6)   # logical NCHW order whatever the memory format
+        return self.classifieur(x)
+
+
+class BinMLP(nn.Module):
+    def __init__(self, in_features=784, hidden=512, out_features=10):
+        super().__init__()
+        self.linear1 = LinearBin(in_features, hidden)
+        self.norm1 = nn.BatchNorm1d(hidden, eps=1e-4, momentum=0.15)
+        self.act = BinaryConnect()
+        self.linear2 = LinearBin(hidden, out_features)
+
+    def forward(self, x):
+        x = torch.relu(self.linear1(x.view(x.shape[0], -1)))
+        x = self.act(self.norm1(x))
+        return torch.log_softmax(self.linear2(x), dim=1)
+
+
+def randomize_bn(model, seed=0):
+    """Give BatchNorm layers non-trivial eval statistics so sign(BN(x)) is a real threshold."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 3)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 50 + 50)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)

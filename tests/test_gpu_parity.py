@@ -479,3 +479,41 @@ def test_c2_full_size_properties(dev):
     wt = ops.ternarize(w).to(torch.float64)
     assert torch.equal(yt.to(torch.float64).sum(1), xs.to(torch.float64) @ wt.sum(0))
     assert torch.equal(yt[idx][:, jdx].to(torch.float64), xs[idx].to(torch.float64) @ wt[jdx].t())
+
+
+def test_alexnet_bin_layerwise(dev):
+    """Every binarised layer of AlexNet-Bin on the GPU against the same layer on
+    the CPU, fed with the CPU model's own intermediate activations (so a sign flip near a BN threshold
+    in one layer cannot mask or fake a mismatch in the next)."""
+    import bench_models
+    torch.manual_seed(5)
+    cpu = bench_models.AlexNetBin()
+    bench_models.randomize_bn(cpu)
+    cpu.eval()
+    gpu = bench_models.AlexNetBin()
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.to(dev).eval()
+    captured = {}
+    hooks = []
+    names = {m: k for k, m in cpu.named_modules()}
+    for m in cpu.modules():
+        if isinstance(m, (BinConv2d, LinearBin)):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out: captured.__setitem__(names[mod], (inp[0], out))))
+    with torch.no_grad():
+        cpu(torch.randn(2, 3, 224, 224))
+    for h in hooks:
+        h.remove()
+    gmods = dict(gpu.named_modules())
+    assert len(captured) == 8
+    for name, (xin, yout) in captured.items():
+        binary = bool(((xin == 1) | (xin == -1)).all())
+        before = _lib.call_counts["qt_nib_gemm"] + _lib.call_counts["qt_xnor_gemm"]
+        with torch.no_grad():
+            y = gmods[name](xin.to(dev))
+        ran_packed = _lib.call_counts["qt_nib_gemm"] + _lib.call_counts["qt_xnor_gemm"] > before
+        assert ran_packed == binary, name                   # only features.0 sees real pixels
+        assert norm_err(n(y), yout.numpy()) <= TOL, name
+        if binary:   # integer part exact: subtract the bias and compare as integers
+            b = gmods[name].bias.detach().cpu().numpy()
+            shape = (1, -1, 1, 1) if y.dim() == 4 else (1, -1)
+            assert np.array_equal(np.rint(n(y) - b.reshape(shape)), np.rint(yout.numpy() - b.reshape(shape))), name
