@@ -147,6 +147,8 @@ def main():
                             "achieved_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
                             "frac_of_8TBs": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(gemm_impl)
+
     result = {
         "metric": "XNOR-popcount GEMM TOPS (LinearBin 4096x4096 forward, batch 4096 per GPU)",
         "value": value, "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,10 +169,11 @@ def main():
     # ---- parity gate + CPU baseline (rank 0, N = 1 only) --------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_port
-        torch.set_num_threads(os.cpu_count() or 1)
         xc, wc = x.cpu(), w.cpu()
         ref = torch_port.linear_bin_forward(xc, wc)
         result["parity_vs_cpu_port"] = bool(torch.equal(ref, y.cpu()))
+        # the host has far more logical CPUs than MKL scales to: use the fastest thread count
+        nthreads, _ = torch_port.best_thread_count(lambda: torch_port.linear_bin_forward(xc, wc))
         med, iters = torch_port.time_callable(lambda: torch_port.linear_bin_forward(xc, wc),
                                               budget_s=args.cpu_budget_s)
         result["cpu_baseline"] = {
@@ -222,12 +225,27 @@ def bench_alexnet(args, dev, dist, world, rank):
         cpu_model.eval()
         xc = x[:cb].cpu().contiguous()
         from oracle import torch_port
-        torch.set_num_threads(os.cpu_count() or 1)
         with torch.no_grad():
+            torch_port.best_thread_count(lambda: cpu_model(xc), probe_iters=1)
             med, iters = torch_port.time_callable(lambda: cpu_model(xc), budget_s=min(args.cpu_budget_s, 8.0))
         out["cpu_baseline"] = {"images_per_s": cb / med, "batch": cb, "cores": torch.get_num_threads(),
                                "kind": "port", "sample": f"{iters} forwards of the same topology on CPU tensors, median"}
     return out
+
+
+def pmc_traffic(gemm_impl):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    this same command (profiles/pmc_latest.json; counters cannot be collected from inside the
+    process).  FETCH_SIZE is doubled (gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md
+    HBM section); WRITE_SIZE as reported."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        k = d["kernels"]["nib_gemm_kernel" if gemm_impl == "mfma" else "popc_gemm_kernel"]
+        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, d.get("source", path)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def _cpu_model():

@@ -43,3 +43,25 @@ def time_callable(fn, budget_s: float = 12.0, warmup: int = 2, min_iters: int = 
             times.append(time.perf_counter() - t0)
     times.sort()
     return times[len(times) // 2], len(times)
+
+
+def best_thread_count(fn, candidates=None, probe_iters: int = 2):
+    """The reference path is torch CPU ops; on a many-core host the default (all logical CPUs) is often
+    far from the fastest.  Probe a few thread counts with ``fn`` and return the best (threads, time)."""
+    import os
+    ncpu = os.cpu_count() or 1
+    if candidates is None:
+        candidates = sorted({c for c in (8, 16, 32, 64, 128, ncpu // 2, ncpu) if 1 <= c <= ncpu})
+    best = None
+    with torch.no_grad():
+        for c in candidates:
+            torch.set_num_threads(c)
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(probe_iters):
+                fn()
+            dt = (time.perf_counter() - t0) / probe_iters
+            if best is None or dt < best[1]:
+                best = (c, dt)
+    torch.set_num_threads(best[0])
+    return best

@@ -73,7 +73,7 @@ def activation_planes(input: torch.Tensor, binary_input: Optional[bool], impl: s
     if binary_input is None and tagged is None:
         if not DETECT_BINARY_INPUT:
             return None
-        if int(ops.check_pm1(input).item()) != 0:  # host sync: only for un-tagged inputs
+        if not ops.is_pm1(input):  # host sync: only for un-tagged inputs
             return None
     return ops.pack_activations(input, impl)
 
@@ -122,7 +122,7 @@ def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool]):
     if binary_input is None and tagged is None:
         if not DETECT_BINARY_INPUT:
             return None
-        if int(ops.check_pm1(input).item()) != 0:   # host sync: only for un-tagged inputs
+        if not ops.is_pm1(input):   # host sync: only for un-tagged inputs
             return None
     return ops.pack_pixels_nib(input)
 

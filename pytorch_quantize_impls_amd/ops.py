@@ -170,13 +170,26 @@ def ternary_pack(x: torch.Tensor) -> BitPlanes:
     return BitPlanes(sign=sign, rows=rows, K=K, mask=mask)
 
 
-def check_pm1(x: torch.Tensor) -> torch.Tensor:
-    """Device flag (int32 scalar tensor): non-zero iff some element of x is not exactly +-1."""
-    x = _require(x, "input").contiguous()
+def check_pm1(x: torch.Tensor, limit: Optional[int] = None) -> torch.Tensor:
+    """Device flag (int32 scalar tensor): non-zero iff some element of x (of its first ``limit``
+    elements in storage order) is not exactly +-1."""
+    x = _require(x, "input")
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+        x = x.contiguous()
+    n = x.numel() if limit is None else min(int(limit), x.numel())
     flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call("qt_check_pm1_f32", _p(x), ctypes.c_int64(x.numel()), _p(flag), _stream(x.device))
+        _lib.call("qt_check_pm1_f32", _p(x), ctypes.c_int64(n), _p(flag), _stream(x.device))
     return flag
+
+
+def is_pm1(x: torch.Tensor) -> bool:
+    """Host-side answer (synchronises): is every element exactly +-1?  A 4096-element prefix is
+    looked at first so real-valued tensors (first layer of every model) are rejected after a tiny
+    kernel instead of a full pass."""
+    if x.numel() > 8192 and int(check_pm1(x, 4096).item()) != 0:
+        return False
+    return int(check_pm1(x).item()) == 0
 
 
 # ----------------------------------------------------------------------------------------------
