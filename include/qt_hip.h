@@ -157,6 +157,33 @@ int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ld
                 const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                 qt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DoReFa k-bit path: int8 code planes + int8 MFMA (v_mfma_i32_32x32x32_i8), exact int32 accumulate.
+ * Replaces F.linear / F.conv2d on DoReFa-quantised operands (layers/dorefa_layers.py:43,45,79,81)
+ * when the activation is a k-bit code image (output of nnDorefaQuant, functions/dorefa_connect.py:28-45)
+ * and the weight is 1-bit (sign(W) * E, functions/dorefa_connect.py:99-102).
+ * code plane: int8 per element, row stride in uint32 words % 4 (16-byte rows), pad bytes zero.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Activation codes: q = rint((2^k - 1) * x) as int8, optionally also the fp32 image
+ * y = fl(fl(1/(2^k-1)) * q) that nnDorefaQuant returns (y_f32 may be NULL).  *overflow (int32,
+ * device, caller-zeroed) is OR-ed with 1 if any |q| > 127 (the reference does NOT clamp; the caller
+ * must then use the dense path). 2 <= bit_width <= 8. */
+int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_bytes, float* y_f32,
+                       int64_t ldy, int64_t rows, int64_t K, int bit_width, int32_t* overflow,
+                       qt_stream_t stream);
+
+/* Weight codes: ternary == 0: safeSign(w) as +1/-1 ; ternary != 0: TernaryConnect codes {-1,0,+1}. */
+int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,
+                       int64_t K, int ternary, qt_stream_t stream);
+
+/* Y[M,N] = scale * (*scale_dev) * (Xc . Wc^T) + bias, Xc / Wc int8 code planes (ld in uint32 words).
+ * scale_dev: optional DEVICE scalar (e.g. E = mean|W| computed on the device) so no host sync is
+ * needed; NULL = 1.  max_abs_code bounds |x codes| (<= 127); requires max_abs_code * K < 2^24. */
+int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,
+               float scale, const float* scale_dev, int64_t max_abs_code, float* Y, int64_t ldy,
+               int64_t M, int64_t N, int64_t K, qt_stream_t stream);
+
 /* nibble plane from existing bit planes (sign only: mask_plane == NULL; ternary: mask + sign).
  * 1 bit -> 4 bits per element; lets the canonical 1-bit planes (what the quantisers emit and what
  * eval-mode layers cache) feed the matrix-core GEMM without re-reading the fp32 tensor. */
@@ -177,11 +204,13 @@ int qt_im2col_words(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t 
                     int64_t dw, uint32_t* A, int64_t ldA, int64_t m_begin, int64_t m_count,
                     qt_stream_t stream);
 
-/* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration
- * (5 = 256x256 tile, LDS-DMA via builtin, any row stride % 4; 6 = same tile, asm-issued DMA
- * interleaved with the MFMAs, needs row strides % 32 words and < 2 GiB operands; 0,1,2,4 and
- * 1xx are earlier / ablation configurations kept for A/B measurements).
- * qt_nib_gemm picks 6 when its contract holds, else 5. */
+/* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration.
+ * 0 = automatic (what qt_nib_gemm does: tile width 256/128/64 by N; the pipelined asm-DMA kernel
+ * when row strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);
+ * 6/7/8 = pipelined kernel with tile 256x256 / 256x128 / 256x64 (QT_ERR_ALIGNMENT if its contract
+ * does not hold); 5/9/10 = generic kernel with the same tiles; 11/13 = pipelined kernel with 64-byte
+ * K stages (4 waves 256x128, two workgroups per CU / 8 waves 256x256); 161..164 = profiling ablations of 6
+ * (no MFMA / no DMA / epilogue only / no LDS reads; results are NOT valid). */
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,
                         int64_t N, int64_t K, qt_stream_t stream);

@@ -284,3 +284,20 @@ def xnor_conv_weight(weight, dim=(0, 1)):
     w = np.asarray(weight, dtype=np.float32)
     mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True, dtype=np.float32)
     return np.sign(w).astype(np.float32) * mean
+
+
+def dorefa_w1a_linear(x_real, weight, bias, k_act=4):
+    """nnDorefaQuant(k_act)(relu(x)) -> LinearDorefa(bit_width=1) (layers/dorefa_layers.py:41-45,
+    functions/dorefa_connect.py:24-25,99-102), evaluated the way the int8 path factors it:
+    y = (E/n) * sum q*s + b with integer q = rint(n * relu(x)), s = safeSign(W), E = mean|W| —
+    in double, as the fp64 evaluation the tolerance is stated against."""
+    n = float(2 ** k_act - 1)
+    x = np.maximum(np.asarray(x_real, dtype=np.float32), 0)
+    q = np.rint(np.float32(n) * x).astype(np.float64)
+    s = safe_sign(weight).astype(np.float64)
+    E = float(np.mean(np.abs(np.asarray(weight, dtype=np.float32)), dtype=np.float32))
+    inv_n = float(np.float32(1) / np.float32(n))
+    y = (q @ s.T) * (E * inv_n)
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float64)
+    return y.astype(np.float32)

@@ -1,0 +1,96 @@
+// int8 code planes for the DoReFa k-bit path (include/qt_hip.h).  HBM-bound elementwise kernels:
+// fp32 in (4 B/element), int8 out (1 B/element) (+ optional fp32 image, 4 B/element).
+//   activations: q = rint((2^k-1) * x)   (functions/dorefa_connect.py:24-25; round-half-even, NO clamp:
+//                an |q| > 127 is reported through *overflow and the caller leaves the packed path)
+//   weights    : safeSign(w) -> +-1  (k = 1 weights are sign(W) * E with the scalar E applied in the
+//                GEMM epilogue, functions/dorefa_connect.py:99-102) or ternary codes.
+#include "qt_common.h"
+
+namespace {
+
+// One thread = 4 consecutive elements of the padded row (ldc bytes, multiple of 16): slots past K
+// write zero bytes so the pad-is-zero invariant of the plane holds.
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void codes_kernel(const float* __restrict__ x, int64_t ldx,
+                                                    int8_t* __restrict__ codes, int64_t ldc,
+                                                    float* __restrict__ yf, int64_t ldy, int64_t rows,
+                                                    int64_t K, float n, float inv_n, int ternary,
+                                                    int32_t* __restrict__ overflow, int vec) {
+    const int64_t slots_per_row = ldc / 4;
+    const int64_t total = rows * slots_per_row;
+    int bad = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
+        const int64_t k0 = slot * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && k0 + 3 < K) {
+            const float4 t = *reinterpret_cast<const float4*>(x + row * ldx + k0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < K) v[e] = x[row * ldx + k0 + e];
+        }
+        uint32_t word = 0;
+        float q4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int q = 0;
+            if (k0 + e < K) {
+                if (WEIGHT) {
+                    q = (int)(ternary ? qt_ternarize(v[e]) : qt_safe_sign(v[e]));
+                } else {
+                    const float r = rintf(n * v[e]);
+                    q4[e] = r;
+                    // NaN / inf / out-of-range codes cannot be represented: flag them
+                    if (!(r >= -127.0f && r <= 127.0f)) { bad = 1; q = 0; } else q = (int)r;
+                }
+            }
+            word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(codes + row * ldc + k0) = word;
+        if (!WEIGHT && yf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < K) yf[row * ldy + k0 + e] = inv_n * q4[e];   // fl(fl(1/n) * r), as _quantize
+        }
+    }
+    if (!WEIGHT && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_bytes, float* y_f32,
+                       int64_t ldy, int64_t rows, int64_t K, int bit_width, int32_t* overflow,
+                       qt_stream_t stream) {
+    if (rows < 0 || K < 0 || ldx < K || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!codes || !overflow || (!x && K > 0) || (y_f32 && ldy < K)) return QT_ERR_INVALID_ARG;
+    if (ldc_bytes < K || (ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
+    if (ldc_bytes == 0) return QT_OK;
+    const float n = (float)((1 << bit_width) - 1);
+    const int vec = qt_aligned16(x) && (ldx % 4 == 0);
+    const int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
+    hipLaunchKernelGGL((codes_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, codes,
+                       ldc_bytes, y_f32, ldy, rows, K, n, 1.0f / n, 0, overflow, vec);
+    return qt_check_launch();
+}
+
+int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,
+                       int64_t K, int ternary, qt_stream_t stream) {
+    if (rows < 0 || K < 0 || ldw < K) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!codes || (!w && K > 0)) return QT_ERR_INVALID_ARG;
+    if (ldc_bytes < K || (ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
+    if (ldc_bytes == 0) return QT_OK;
+    const int vec = qt_aligned16(w) && (ldw % 4 == 0);
+    const int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
+    hipLaunchKernelGGL((codes_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, w, ldw, codes,
+                       ldc_bytes, nullptr, 0, rows, K, 0.0f, 0.0f, ternary, nullptr, vec);
+    return qt_check_launch();
+}
+
+}  // extern "C"

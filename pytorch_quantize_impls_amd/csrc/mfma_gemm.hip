@@ -1,0 +1,571 @@
+// Packed low-bit GEMMs on the matrix cores.
+//
+//   fp4 ("nibble planes", include/qt_hip.h): +-1 / {-1,0,+1} operands as FP4-E2M1 nibbles, contracted
+//       with the block-scaled MX MFMA  v_mfma_scale_f32_32x32x64_f8f6f4  (A = B = fp4, every block
+//       scale 2^0).  E2M1 holds -1, 0, +1 exactly and the accumulator is fp32, so every partial sum is
+//       an integer of magnitude <= K < 2^24: bit-identical to the popcount formulation and to the
+//       reference's fp32 GEMM on +-1 tensors.  Measured issue rate on MI355X: 9.0 PFLOP/s vs 1.49 Pop/s
+//       for the xor+bcnt pair (profiles/r1_ubench.txt) — which is why large shapes are routed here.
+//   int8 ("code planes"): DoReFa k-bit activation codes q = rint((2^k-1) x) x +-1/0 weight codes with
+//       v_mfma_i32_32x32x32_i8, int32 accumulate (exact), one fp32 scale in the epilogue.
+//
+// Y[m,n] = scale * sum_k X[m,k] * W[n,k] (+ bias[n]);  X: M x K, W: N x K, row-major byte rows.
+//
+// One kernel template serves both: everything is organised in BYTES of K.  A stage is 128 bytes of K
+// per row (256 nibbles / 128 int8) = 4 MFMA k-steps of 32 bytes; lane l of a wave supplies, for the
+// 32x32 MFMA, row (l & 31) and the 16-byte chunk (2*kk + (l >> 5)) of the stage row.
+//
+// Workgroup = 8 waves (2 per SIMD).  X is the MFMA "A" operand (D rows = m) and W the "B" operand
+// (D cols = n): with the 32x32 C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) a
+// store instruction then writes two full 128-byte lines of Y.  (The transposed assignment gives each
+// lane a float4 but scatters every store instruction over 32 rows 16 KB apart: measured 2x slower
+// epilogue, DESIGN.md.)
+//
+// LDS: stage rows are eight 16-byte chunks, chunk c of row r stored at position c ^ ((r>>1)&7): the 16
+// rows a ds_read_b128 lane group touches (distinct mod 16) fall on 16 distinct 16-B slots of the 256-B
+// bank row -> conflict-free fragment reads.  Two stage buffers (X tile + W tile each).
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip; the swizzle is applied on the
+// per-lane SOURCE address because the LDS side of the instruction is lane-linear).
+//   PIPE = 1 (fast path): the DMA is issued from inline asm, so hipcc has no outstanding-DMA knowledge
+//       (with the builtin it drains vmcnt(0) in front of the next ds_read, serialising DMA against
+//       fragment reads + MFMAs); the pieces of stage s+1 are interleaved with the per-k-step fragment
+//       reads (software-pipelined one k-step ahead) and MFMAs of stage s; one manual vmcnt(0) + barrier
+//       per stage.  The steady-state body is branch-free (last stage peeled) so it stays one basic
+//       block and the sched_barriers can hold the interleave.  Contract: row strides are whole stages
+//       (ld % 32 words == 0, pad zero) and each operand spans < 2^31 bytes (32-bit lane offsets).
+//   PIPE = 0 (generic): builtin DMA, 64-bit addresses, any ld % 4 words; chunks past the row stride
+//       read a 16-byte zero word.  All fragment reads of a stage are issued before the DMA of the next.
+#include <type_traits>
+#include "qt_common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// K bytes per row per stage (SB): 128 (4 MFMA k-steps) or 64 (2 k-steps).
+
+// 16 zero bytes in global memory: the source of every DMA chunk that lies past a row's stride.
+__device__ __attribute__((aligned(16))) const unsigned char zero16_storage[16] = {0};
+
+// chunk swizzle: SB = 128 -> 8 chunks/row, two rows per 256-B bank row: c ^ ((r>>1)&7);
+//                SB = 64  -> 4 chunks/row, four rows per bank row:      c ^ ((r>>2)&3).
+// Either way 16 rows distinct mod 16 land on 16 distinct 16-byte slots.
+template <int SB>
+__device__ __forceinline__ int swz(int row, int chunk) {
+    return SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+}
+
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_dst), issued
+// from inline asm.  Address form: 64-bit SGPR base + 32-bit per-lane VGPR byte offset.  M0 = LDS byte
+// address; M0 is compiler-reserved, so it is saved/restored inside the same statement; the s_nop covers
+// the SALU-write-M0 -> LDS-DMA hazard.  No VGPR destination, so the statement is register-safe; the DATA
+// is ordered for readers only by our own s_waitcnt vmcnt(0) + barrier at the end of a stage.
+__device__ __forceinline__ void glds16_asm(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+// ---- element types ----------------------------------------------------------------------------------
+struct ElemFp4 {
+    using acc_t = v16f;
+    __device__ __forceinline__ static int kbytes(int K) { return (K + 1) / 2; }
+    __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
+        const v8i av = (v8i){(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+        const v8i bv = (v8i){(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+        // cbsz = blgp = 4: both operands FP4; scales 0x7f = E8M0 for 2^0 on every 32-element block
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    __device__ __forceinline__ static float out(float v, float scale, float bias) { return v + bias; }
+};
+struct ElemI8 {
+    using acc_t = v16i;
+    __device__ __forceinline__ static int kbytes(int K) { return K; }
+    __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
+        const v4i av = (v4i){(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        const v4i bv = (v4i){(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+    }
+    // exact int32 -> fp32 (|acc| < 2^24 is checked by the launcher), ONE scale multiply, bias once
+    __device__ __forceinline__ static float out(int v, float scale, float bias) { return (float)v * scale + bias; }
+};
+
+// Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
+//   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
+//   4 = no LDS fragment reads.
+template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128>
+struct GemmCfg {
+    using E = E_;
+    static constexpr int WM = WM_, WN = WN_, TMW = TMW_, TNW = TNW_, PIPE = PIPE_, ABL = ABL_;
+    static constexpr int STAGE_BYTES = SB_, KK = SB_ / 32;
+    static constexpr int ROWS_PER_PIECE = 1024 / SB_;   // one DMA piece = 1 KiB of LDS
+    static constexpr int CHUNKS = SB_ / 16;
+    static constexpr int NWAVES = WM * WN, NTHREADS = NWAVES * 64;
+    static constexpr int TM = WM * TMW * 32, TN = WN * TNW * 32;  // workgroup tile
+    static constexpr int X_STAGE = TM * STAGE_BYTES, W_STAGE = TN * STAGE_BYTES;
+    static constexpr int BUF = X_STAGE + W_STAGE;
+    static constexpr int LDS_BYTES = 2 * BUF;  // double-buffered
+    static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
+    static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && TN % (ROWS_PER_PIECE * NWAVES) == 0,
+                  "DMA pieces divide evenly over the waves");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 2) void mfma_gemm_kernel(
+    const uint32_t* __restrict__ X, int64_t ldx, const uint32_t* __restrict__ W, int64_t ldw,
+    const float* __restrict__ bias, float scale, const float* __restrict__ scale_dev,
+    float* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    using E = typename C::E;
+    using acc_t = typename E::acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [buf][X stage | W stage]
+    constexpr int BUF = C::BUF, STAGE_BYTES = C::STAGE_BYTES, KK = C::KK;
+    constexpr int RPP = C::ROWS_PER_PIECE, CH = C::CHUNKS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave % C::WN, wave_m = wave / C::WN;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never relied on
+    // for correctness).  When the tile grid divides into 4 (m) x 8 (n) super-tiles, XCD x owns a
+    // contiguous range of the super-tile-major order, so the tiles sharing an L2 share X / W panels.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        if ((gx & 7) == 0 && (gy & 3) == 0) {
+            const int b = blockIdx.y * gx + blockIdx.x;
+            const int o = (b & 7) * ((gx * gy) >> 3) + (b >> 3);  // bijective: 8 | gx*gy
+            const int st = o >> 5, in_st = o & 31, sgx = gx >> 3;
+            tile_m = (st / sgx) * 4 + (in_st >> 3);
+            tile_n = (st % sgx) * 8 + (in_st & 7);
+        }
+    }
+    const int m0 = tile_m * C::TM, n0 = tile_n * C::TN;
+
+    const int64_t ldx_b = ldx * 4, ldw_b = ldw * 4;  // row strides in bytes
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
+
+    acc_t acc[C::TMW][C::TNW];
+#pragma unroll
+    for (int a = 0; a < C::TMW; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    const int nstages = C::ABL == 3 ? 0 : (E::kbytes(K) + STAGE_BYTES - 1) / STAGE_BYTES;
+
+    auto read_frags = [&](const unsigned char* xs, const unsigned char* ws, int kk,
+                          uint4 (&xf)[C::TMW], uint4 (&wf)[C::TNW]) {
+        const int c = kk * 2 + lhalf;
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a) {
+            const int row = (wave_m * C::TMW + a) * 32 + lrow;
+            xf[a] = *reinterpret_cast<const uint4*>(xs + row * STAGE_BYTES + swz<STAGE_BYTES>(row, c) * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int row = (wave_n * C::TNW + b) * 32 + lrow;
+            wf[b] = *reinterpret_cast<const uint4*>(ws + row * STAGE_BYTES + swz<STAGE_BYTES>(row, c) * 16);
+        }
+    };
+    auto mfma_step = [&](uint4 (&xf)[C::TMW], uint4 (&wf)[C::TNW]) {
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a)
+#pragma unroll
+            for (int b = 0; b < C::TNW; ++b) acc[a][b] = E::mfma(xf[a], wf[b], acc[a][b]);
+    };
+
+    if constexpr (C::PIPE == 1) {
+        // ---- pipelined main loop (asm-issued DMA) -----------------------------------------------
+        constexpr int XP = C::TM / RPP / C::NWAVES, WP = C::TN / RPP / C::NWAVES;  // DMA pieces per wave
+        constexpr int NP = XP + WP;
+        const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+        const int uwave = __builtin_amdgcn_readfirstlane(wave);
+        const int p = lane % CH, rsub = lane / CH;   // lane -> (LDS chunk position, row within piece)
+        // loop-invariant per-lane byte offsets of this wave's pieces (row clamped to the last valid
+        // row: products of out-of-range rows are never stored).  Lane i lands on LDS position p of
+        // its row, so it fetches the logical chunk swz(row, p) (the swizzle is an involution).
+        unsigned voffx[XP], voffw[WP];
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int row = (j * C::NWAVES + uwave) * RPP + rsub;
+            voffx[j] = (unsigned)(min(m0 + row, M - 1) * ldx_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int row = (j * C::NWAVES + uwave) * RPP + rsub;
+            voffw[j] = (unsigned)(min(n0 + row, N - 1) * ldw_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
+        }
+        auto issue_piece = [&](int j, int s, int buf) {  // j is a compile-time constant after unrolling
+            const unsigned ldsbuf = lds0 + buf * BUF;
+            if (j < XP) {
+                const unsigned dst = ldsbuf + ((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
+                glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], __builtin_amdgcn_readfirstlane(dst));
+            } else {
+                const int jw = j - XP;
+                const unsigned dst = ldsbuf + C::X_STAGE + ((jw * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
+                glds16_asm(Wb + (int64_t)s * STAGE_BYTES, voffw[jw >= 0 && jw < WP ? jw : 0],
+                           __builtin_amdgcn_readfirstlane(dst));
+            }
+        };
+        if (nstages > 0) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        auto stage_body = [&](int s, auto more_tag) {
+            constexpr bool more = decltype(more_tag)::value;
+            const int buf = s & 1;
+            const unsigned char* xs = smem + buf * BUF;
+            const unsigned char* ws = xs + C::X_STAGE;
+            uint4 xfA[C::TMW], wfA[C::TNW], xfB[C::TMW], wfB[C::TNW];
+            if constexpr (C::ABL == 4) {
+#pragma unroll
+                for (int a = 0; a < C::TMW; ++a) xfA[a] = xfB[a] = make_uint4(0x22222222u, 0x2a2a2a2au, lane, s);
+#pragma unroll
+                for (int b = 0; b < C::TNW; ++b) wfA[b] = wfB[b] = make_uint4(0xa2a2a2a2u, 0x2a2a2a2au, lane, s);
+            }
+            if constexpr (C::ABL != 4) read_frags(xs, ws, 0, xfA, wfA);
+#pragma unroll
+            for (int kk = 0; kk < KK; kk += 2) {
+                // DMA pieces are spread over the k-steps; fragments of step kk+1 are requested before
+                // the MFMAs of step kk so LDS latency hides under the matrix pipe.
+                if constexpr (more && C::ABL != 2) {
+#pragma unroll
+                    for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                }
+                if constexpr (C::ABL != 4) read_frags(xs, ws, kk + 1, xfB, wfB);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C::ABL != 1) mfma_step(xfA, wfA);
+                else asm volatile("" ::"v"(xfA[0].x), "v"(wfA[0].x), "v"(xfA[C::TMW - 1].w), "v"(wfA[C::TNW - 1].w));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more && C::ABL != 2) {
+#pragma unroll
+                    for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                }
+                if constexpr (C::ABL != 4) {
+                    if (kk + 2 < KK) read_frags(xs, ws, kk + 2, xfA, wfA);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C::ABL != 1) mfma_step(xfB, wfB);
+                else asm volatile("" ::"v"(xfB[0].x), "v"(wfB[0].x), "v"(xfB[C::TMW - 1].w), "v"(wfB[C::TNW - 1].w));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+            __syncthreads();                                   // ... and everyone's are visible
+        };
+        for (int s = 0; s + 1 < nstages; ++s) stage_body(s, std::true_type{});
+        if (nstages > 0) stage_body(nstages - 1, std::false_type{});
+    } else {
+        // ---- generic main loop (builtin DMA, 64-bit addresses, any row stride % 4 words) ------------
+        const unsigned char* zero16 = zero16_storage;
+        auto dma_operand = [&](const unsigned char* G, int64_t ld_b, int row0_global, int nrows_valid,
+                               unsigned char* ls, int tile_rows, int s) {
+            const int p = lane % CH, rsub = lane / CH;
+            const int uwave = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+            for (int q = 0; q < (C::TM > C::TN ? C::TM : C::TN) / RPP / C::NWAVES; ++q) {
+                const int g = q * C::NWAVES + uwave;
+                if (g >= tile_rows / RPP) break;
+                const int r0 = g * RPP, row = r0 + rsub;
+                const int c = swz<STAGE_BYTES>(row, p);
+                const int64_t kb = (int64_t)s * STAGE_BYTES + c * 16;
+                const int grow = min(row0_global + row, nrows_valid - 1);
+                const unsigned char* src = (kb < ld_b) ? G + (int64_t)grow * ld_b + kb : zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ls + r0 * STAGE_BYTES),
+                                                 16, 0, 0);
+            }
+        };
+        if (nstages > 0) {
+            dma_operand(Xb, ldx_b, m0, M, smem, C::TM, 0);
+            dma_operand(Wb, ldw_b, n0, N, smem + C::X_STAGE, C::TN, 0);
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)): buffer 0 is ready
+        for (int s = 0; s < nstages; ++s) {
+            const int buf = s & 1;
+            const unsigned char* xs = smem + buf * BUF;
+            const unsigned char* ws = xs + C::X_STAGE;
+            // (1) every fragment of this stage into registers, (2) DMA of the next stage, (3) the
+            // register-only MFMAs while it is in flight (hipcc drains vmcnt(0) in front of any ds_read
+            // that follows a builtin LDS-DMA, so no LDS read may sit between (2) and the barrier).
+            uint4 xf[KK][C::TMW], wf[KK][C::TNW];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) read_frags(xs, ws, kk, xf[kk], wf[kk]);
+            if (s + 1 < nstages) {
+                dma_operand(Xb, ldx_b, m0, M, smem + (buf ^ 1) * BUF, C::TM, s + 1);
+                dma_operand(Wb, ldw_b, n0, N, smem + (buf ^ 1) * BUF + C::X_STAGE, C::TN, s + 1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) mfma_step(xf[kk], wf[kk]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the barrier's vmcnt(0)
+            __syncthreads();
+        }
+    }
+
+    if (scale_dev) scale *= *scale_dev;   // device-resident factor (e.g. DoReFa's E = mean|W|): no host sync
+    // ---- epilogue: D[row = m][col = n]; lane owns column n, rows m = mb + (r&3) + 8*(r>>2) + 4*lhalf ---
+#pragma unroll
+    for (int b = 0; b < C::TNW; ++b) {
+        const int n = n0 + (wave_n * C::TNW + b) * 32 + lrow;
+        const float bv = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a) {
+            const int mb = m0 + (wave_m * C::TMW + a) * 32 + 4 * lhalf;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < M && n < N) Y[(int64_t)m * ldy + n] = E::out(acc[a][b][r], scale, bv);
+            }
+        }
+    }
+}
+
+template <class C>
+int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,
+               float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+               qt_stream_t stream) {
+    const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
+    if (gy > 65535) return QT_ERR_UNSUPPORTED;
+    // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+        return QT_ERR_LAUNCH;
+    hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3((unsigned)gx, (unsigned)gy), dim3(C::NTHREADS),
+                       C::LDS_BYTES, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
+                       (int)M, (int)N, (int)K);
+    return qt_check_launch();
+}
+
+// tile shapes: 256x256 (wave 128x64), 256x128 (wave 128x32), 256x64 (wave 64x32)
+template <class E, int PIPE, int ABL = 0> using Cfg256 = GemmCfg<E, 2, 4, 4, 2, PIPE, ABL>;
+template <class E, int PIPE> using Cfg128 = GemmCfg<E, 2, 4, 4, 1, PIPE>;
+template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
+// 4-wave workgroups with 64-byte stages: 48 KiB of LDS, <= 256 VGPRs -> TWO independent workgroups per
+// CU (different barrier domains fill each other's fill/drain bubbles and epilogues).
+template <class E, int PIPE> using Cfg2x = GemmCfg<E, 2, 2, 4, 2, PIPE, 0, 64>;      // 256x128 tile
+template <class E, int PIPE> using Cfg2z = GemmCfg<E, 2, 4, 4, 2, PIPE, 0, 64>;      // 8 waves 256x256, 64-B stages (64 KiB: 2/CU by LDS, VGPR-limited)
+
+int check_common(const void* Xn, int64_t ldxp, const void* Wn, int64_t ldwp, const float* Y, int64_t ldy,
+                 int64_t M, int64_t N, int64_t K, int64_t kwords) {
+    if (M < 0 || N < 0 || K < 0) return QT_ERR_INVALID_ARG;
+    if (M == 0 || N == 0) return 1;  // nothing to do
+    if (!Y || ldy < N) return QT_ERR_INVALID_ARG;
+    if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return QT_ERR_UNSUPPORTED;
+    if (K > 0 && (!Xn || !Wn)) return QT_ERR_INVALID_ARG;
+    if (ldxp < kwords || ldwp < kwords) return QT_ERR_INVALID_ARG;
+    if ((ldxp & 3) || (ldwp & 3)) return QT_ERR_ALIGNMENT;
+    if (K > 0 && (!qt_aligned16(Xn) || !qt_aligned16(Wn))) return QT_ERR_ALIGNMENT;
+    return QT_OK;
+}
+
+template <class E>
+int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp,
+                  const float* bias, float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, qt_stream_t stream) {
+    const bool pipe_ok = !(ldxp & 31) && !(ldwp & 31) && M * ldxp * 4 < (1ll << 31) &&
+                         N * ldwp * 4 < (1ll << 31);
+#define QT_GO(...) return launch_cfg<__VA_ARGS__>(Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream)
+    switch (variant) {
+        case 0:  // automatic: tile width by N, fast path when its contract holds
+            if (pipe_ok) {
+                if (N > 160) QT_GO(Cfg256<E, 1>);
+                if (N > 80) QT_GO(Cfg128<E, 1>);
+                QT_GO(Cfg64<E, 1>);
+            }
+            if (N > 160) QT_GO(Cfg256<E, 0>);
+            if (N > 80) QT_GO(Cfg128<E, 0>);
+            QT_GO(Cfg64<E, 0>);
+        case 5: QT_GO(Cfg256<E, 0>);
+        case 6: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1>);
+        case 7: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg128<E, 1>);
+        case 8: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg64<E, 1>);
+        case 11: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2x<E, 1>);
+        case 13: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2z<E, 1>);
+        case 9: QT_GO(Cfg128<E, 0>);
+        case 10: QT_GO(Cfg64<E, 0>);
+        case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
+        case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);
+        case 163: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 3>);
+        case 164: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 4>);
+        default: return QT_ERR_UNSUPPORTED;
+    }
+#undef QT_GO
+}
+
+// ---- fp32 -> nibble plane ------------------------------------------------------------------------
+struct NibSign {  // safeSign: +1 -> 0x2, -1 -> 0xA
+    __device__ __forceinline__ static uint32_t nib(float x) { return x < 0.0f ? 0xAu : 0x2u; }
+};
+struct NibTernary {  // TernaryConnectDeterministic: 0 -> 0x0
+    __device__ __forceinline__ static uint32_t nib(float x) {
+        const float t = qt_ternarize(x);
+        return t == 0.0f ? 0x0u : (t < 0.0f ? 0xAu : 0x2u);
+    }
+};
+
+// One work item = one float4 slot of the padded row (ldp words = ldp*2 slots); two adjacent lanes
+// form one output word.  Slots past K/4 produce zero nibbles, so the pad-is-zero invariant holds.
+template <class Enc>
+__global__ __launch_bounds__(256) void nib_pack_vec_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           uint32_t* __restrict__ out, int64_t ldp,
+                                                           int64_t rows, int64_t K) {
+    const int64_t slots_per_row = ldp * 2;
+    const int64_t total = rows * slots_per_row;  // even
+    const int64_t k4 = K / 4;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
+        uint32_t h = 0;
+        if (slot < k4) {
+            const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + slot * 4);
+            h = Enc::nib(v.x) | (Enc::nib(v.y) << 4) | (Enc::nib(v.z) << 8) | (Enc::nib(v.w) << 12);
+        }
+        const uint32_t other = __shfl_xor(h, 1);
+        if ((threadIdx.x & 1) == 0) out[row * ldp + (slot >> 1)] = h | (other << 16);
+    }
+}
+
+// Generic path (any K / alignment): one thread per output word, scalar loads.
+template <class Enc>
+__global__ __launch_bounds__(256) void nib_pack_scalar_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              uint32_t* __restrict__ out, int64_t ldp,
+                                                              int64_t rows, int64_t K) {
+    const int64_t total = rows * ldp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ldp, w = i - row * ldp;
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t k = w * 8 + e;
+            if (k < K) word |= Enc::nib(x[row * ldx + k]) << (4 * e);
+        }
+        out[i] = word;
+    }
+}
+
+// ---- bit planes -> nibble plane (derived MFMA operand format) ---------------------------------------
+// spread the 8 bits of a byte to bit 0 of 8 nibbles
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+    uint32_t t = b & 0xFFu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t;
+}
+// One thread = one 32-bit word of the planes -> four nibble words (16 B).  sign-only planes:
+// nibble = 0x2 | s<<3.  mask+sign: nibble = m<<1 | (s&m)<<3.  Words past the bit planes' stride are 0.
+__global__ __launch_bounds__(256) void bits_to_nib_kernel(const uint32_t* __restrict__ sign,
+                                                          const uint32_t* __restrict__ mask,
+                                                          int64_t ldb, uint32_t* __restrict__ out,
+                                                          int64_t ldn, int64_t rows, int64_t K) {
+    const int64_t groups_per_row = ldn / 4;  // one group = 4 nibble words = 32 elements
+    const int64_t total = rows * groups_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / groups_per_row, g = i - row * groups_per_row;
+        uint32_t sw = 0, mw = 0;
+        if (g < ldb) {
+            sw = sign[row * ldb + g];
+            if (mask) {
+                mw = mask[row * ldb + g];
+            } else {  // binary: every element inside K is non-zero
+                const int64_t rem = K - g * 32;
+                mw = rem >= 32 ? 0xFFFFFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+            }
+        }
+        sw &= mw;
+        uint4 o;
+        o.x = (spread8(mw) << 1) | (spread8(sw) << 3);
+        o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
+        o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
+        o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
+        *reinterpret_cast<uint4*>(out + row * ldn + g * 4) = o;
+    }
+}
+
+template <class Enc>
+int launch_nib_pack(const float* x, int64_t ldx, uint32_t* out, int64_t ldp, int64_t rows, int64_t K,
+                    qt_stream_t stream) {
+    if (rows < 0 || K < 0 || ldx < K) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!out || (!x && K > 0)) return QT_ERR_INVALID_ARG;
+    const int64_t kw = (K + 7) / 8;
+    if (ldp < kw || (ldp & 3) != 0 || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (ldp == 0) return QT_OK;
+    const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && qt_aligned16(x);
+    if (vec) {
+        const int grid = qt_stream_grid((rows * ldp * 2 + 255) / 256);
+        hipLaunchKernelGGL((nib_pack_vec_kernel<Enc>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                           ldx, out, ldp, rows, K);
+    } else {
+        const int grid = qt_stream_grid((rows * ldp + 255) / 256);
+        hipLaunchKernelGGL((nib_pack_scalar_kernel<Enc>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           x, ldx, out, ldp, rows, K);
+    }
+    return qt_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp, int64_t rows,
+                         int64_t K, qt_stream_t stream) {
+    return launch_nib_pack<NibSign>(x, ldx, nib_plane, ldp, rows, K, stream);
+}
+
+int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
+                            int64_t rows, int64_t K, qt_stream_t stream) {
+    return launch_nib_pack<NibTernary>(x, ldx, nib_plane, ldp, rows, K, stream);
+}
+
+int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
+                        int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
+                        int64_t K, qt_stream_t stream) {
+    const int rc = check_common(Xn, ldxp, Wn, ldwp, Y, ldy, M, N, K, (K + 7) / 8);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    if (K >= (1 << 24)) return QT_ERR_UNSUPPORTED;  // fp32-exact bound of the accumulator
+    return dispatch_gemm<ElemFp4>(variant, Xn, ldxp, Wn, ldwp, bias, 1.0f, nullptr, Y, ldy, M, N, K, stream);
+}
+
+int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,
+                float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream) {
+    return qt_nib_gemm_variant(0, Xn, ldxp, Wn, ldwp, bias, Y, ldy, M, N, K, stream);
+}
+
+int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,
+               float scale, const float* scale_dev, int64_t max_abs_code, float* Y, int64_t ldy, int64_t M,
+               int64_t N, int64_t K, qt_stream_t stream) {
+    const int rc = check_common(Xc, ldxp, Wc, ldwp, Y, ldy, M, N, K, (K + 3) / 4);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    // |sum| <= max|x code| * max|w code| * K must stay below 2^24 so the int32 -> fp32 conversion in
+    // the epilogue is exact (weights are +-1/0 codes)
+    if (max_abs_code < 0 || max_abs_code > 127 || max_abs_code * K >= (1ll << 24)) return QT_ERR_UNSUPPORTED;
+    return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
+}
+
+int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
+                   uint32_t* nib_plane, int64_t ldn, int64_t rows, int64_t K, qt_stream_t stream) {
+    if (rows < 0 || K < 0) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!nib_plane || (K > 0 && !sign_plane)) return QT_ERR_INVALID_ARG;
+    if (ldb < (K + 31) / 32 || ldn < (K + 7) / 8) return QT_ERR_INVALID_ARG;
+    if ((ldb & 3) || (ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid((rows * (ldn / 4) + 255) / 256);
+    hipLaunchKernelGGL(bits_to_nib_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sign_plane,
+                       mask_plane, ldb, nib_plane, ldn, rows, K);
+    return qt_check_launch();
+}
+
+}  // extern "C"

@@ -189,6 +189,106 @@ class QuantConv2dFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None, None, None, None
 
 
+def _dorefa_w1_scale(weight: torch.Tensor, prequantized: bool) -> torch.Tensor:
+    """E of the 1-bit DoReFa weight sign(W)*E as a device scalar.  Training: E = mean|W|
+    (functions/dorefa_connect.py:100).  Eval: the weight already holds sign(W)*E, so |w| == E for
+    every entry and amax recovers it exactly."""
+    return weight.detach().abs().amax() if prequantized else weight.detach().abs().mean()
+
+
+def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None):
+    """LinearDorefa(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:41-45):
+    y = x . (sign(W)*E)^T + b.  If the activation carries k-bit DoReFa codes (nnDorefaQuant output)
+    the contraction runs on the int8 matrix cores: y = (E/n) * sum q*s + b; otherwise the dense GEMM
+    library on the HIP-quantised weight image."""
+    E = _dorefa_w1_scale(weight, prequantized)
+    codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
+    K, N = input.shape[-1], weight.shape[0]
+    if (codes is not None and codes.K == K and codes.rows * K == input.numel()
+            and 127 * K < (1 << 24) and codes.usable()):
+        wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
+        y = ops.i8_gemm(codes, wc, codes.inv_n, bias, scale_dev=E)
+        return y.view(*input.shape[:-1], N)
+    wq = weight if prequantized else ops.binarize(weight.detach()) * E
+    return F.linear(input, wq, bias)
+
+
+def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, weight_codes=None,
+                           padding_mode: str = "zeros"):
+    """DorefaConv2d(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:77-82)."""
+    stride, padding, dilation, groups = conv_args
+    E = _dorefa_w1_scale(weight, prequantized)
+    codes = None
+    if (input.dtype == torch.float32 and input.dim() == 4 and groups == 1 and padding_mode == "zeros"
+            and not isinstance(padding, str)):
+        codes = packed.lookup_codes(input, packed.NHWC)
+    if codes is not None:
+        N_, C, H, W = input.shape
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        Kb = kh * kw * codes.codes.shape[1]
+        if codes.K == C and codes.rows == N_ * H * W and 127 * Kb < (1 << 24) and codes.usable():
+            wc = weight_codes if weight_codes is not None else ops.pack_conv_weight_codes(weight.detach())
+            y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding,
+                                  dilation, scale_dev=E)
+            Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+            return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
+    wq = weight if prequantized else ops.binarize(weight.detach()) * E
+    return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
+
+
+class DorefaW1LinearFn(torch.autograd.Function):
+    """Training-mode LinearDorefa(bit_width=1): forward above; backward as autograd derives it from
+    F.linear(x, _ignore_factor_op(sign(W), E), b): grad_x = g . (sign(W) E), grad_W = g^T . x passed
+    through UNscaled (functions/dorefa_connect.py:66-79) with the identity STE of the quantiser."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias):
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(input, weight)
+        return dorefa_w1_linear_forward(input, weight, bias, prequantized=False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            wq = ops.binarize(weight) * weight.abs().mean()
+            grad_input = g2.mm(wq).view(input.shape)
+        if ctx.needs_input_grad[1]:
+            grad_weight = g2.t().mm(input.reshape(-1, input.shape[-1]))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = g2.sum(0)
+        return grad_input, grad_weight, grad_bias
+
+
+class DorefaW1Conv2dFn(torch.autograd.Function):
+    """Training-mode DorefaConv2d(bit_width=1); see DorefaW1LinearFn."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, conv_args):
+        ctx.has_bias, ctx.conv_args = bias is not None, conv_args
+        ctx.save_for_backward(input, weight)
+        return dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        go = grad_output.contiguous()
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            wq = ops.binarize(weight) * weight.abs().mean()
+            grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
+                                                    dilation=dilation, groups=groups)
+        if ctx.needs_input_grad[1]:
+            grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
+                                                      dilation=dilation, groups=groups)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = go.sum((0, 2, 3))
+        return grad_input, grad_weight, grad_bias, None
+
+
 class QuantLinearFn(torch.autograd.Function):
     """Autograd node of LinearBin / LinearTer in training mode.
 

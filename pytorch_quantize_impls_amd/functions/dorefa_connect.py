@@ -3,7 +3,7 @@ import warnings
 
 import torch
 
-from .. import ops
+from .. import ops, packed
 from .common import front, safeSign
 
 warnings.simplefilter("always", DeprecationWarning)
@@ -18,6 +18,16 @@ def _quantize(x, bit_width=3):
     if bit_width == 32:
         return x
     if x.is_cuda and x.dtype == torch.float32:
+        if 2 <= bit_width <= 8 and x.dim() >= 2 and x.numel() > 0:
+            # same values as qt_dorefa_quantize_f32, plus the int8 codes the next DoReFa layer's
+            # int8-MFMA path consumes (attached to the returned tensor, see packed.py)
+            if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+                nhwc = x.permute(0, 2, 3, 1)
+                cp, y = ops.dorefa_codes(nhwc, bit_width, ld_bytes=ops.code_ld_bytes(x.shape[1], 16))
+                return packed.attach_codes(y.permute(0, 3, 1, 2), cp, packed.NHWC)
+            if x.is_contiguous():
+                cp, y = ops.dorefa_codes(x, bit_width)
+                return packed.attach_codes(y, cp, packed.ROWS_LAST)
         return ops.dorefa_quantize(x, bit_width)
     n = torch.pow(torch.full_like(x, 2.0), bit_width) - 1
     return (1 / n) * torch.round(n * x)

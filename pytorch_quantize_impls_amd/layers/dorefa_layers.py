@@ -1,7 +1,7 @@
 """DoReFa-Net layers (reference: QuantTorch/layers/dorefa_layers.py)."""
 import torch
 
-from ..functions import dorefa_connect
+from ..functions import dorefa_connect, _fused
 from .common import QLayer, EvalSwapMixin
 
 
@@ -27,6 +27,13 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         return self.weight_op.forward(self.weight)
 
     def forward(self, input):
+        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
+            # W1Ak: int8 matrix-core path when the activation carries DoReFa codes
+            if self.training:
+                return _fused.DorefaW1LinearFn.apply(input, self.weight, self.bias)
+            if not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)):
+                wc = self._eval_planes(lambda w2: _fused.ops.weight_codes(w2), key="i8")
+                return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc)
         w = self.weight_op.forward(self.weight) if self.training else self.weight
         return torch.nn.functional.linear(input, w, self.bias)
 
@@ -53,6 +60,16 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self.weight_op.forward(self.weight)
 
     def forward(self, input):
+        args = (self.stride, self.padding, self.dilation, self.groups)
+        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
+            if self.training:
+                return _fused.DorefaW1Conv2dFn.apply(input, self.weight, self.bias, args)
+            if not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)):
+                wc = None
+                if self.groups == 1 and self.padding_mode == "zeros":
+                    wc = self._eval_planes(lambda _w2: _fused.ops.pack_conv_weight_codes(self.weight.detach()),
+                                           key="conv_i8")
+                return _fused.dorefa_w1_conv_forward(input, self.weight, self.bias, args, True, wc,
+                                                     self.padding_mode)
         w = self.weight_op.forward(self.weight) if self.training else self.weight
-        return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
-                                          self.dilation, self.groups)
+        return torch.nn.functional.conv2d(input, w, self.bias, *args)

@@ -17,6 +17,9 @@ from . import _lib
 
 STE_THRESHOLD = 1.001  # functions/binary_connect.py:37, terner_connect.py:33
 
+#: upper bound on the bytes of the temporary im2col matrix (the batch is processed in chunks)
+IM2COL_MAX_BYTES = 1 << 30
+
 
 def _p(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
@@ -328,6 +331,151 @@ def nib_gemm(x: NibPlanes, w: NibPlanes, bias: Optional[torch.Tensor] = None,
 
 
 # ----------------------------------------------------------------------------------------------
+# DoReFa k-bit path: int8 code planes + int8 MFMA GEMM
+# ----------------------------------------------------------------------------------------------
+
+def code_ld_bytes(K: int, granule: int = 128) -> int:
+    """Row stride in BYTES of an int8 code plane: K rounded up to a whole GEMM stage (128 B), or to
+    16 B for NHWC pixel planes (granule=16)."""
+    return max(granule, (int(K) + granule - 1) // granule * granule)
+
+
+@dataclass
+class CodePlanes:
+    """int8 code image of a [rows, K] matrix: activations q = rint((2^k-1) x) (value = inv_n * q) or
+    weight codes in {-1, 0, +1}.  ``codes``: int8 tensor [rows, ld_bytes], pad bytes zero."""
+    codes: torch.Tensor
+    rows: int
+    K: int
+    inv_n: float = 1.0
+    bit_width: int = 1
+    overflow: Optional[torch.Tensor] = None   # device int32 flag: some |q| > 127 (then do not use)
+    _usable: Optional[bool] = None             # host-resolved once (one sync per activation tensor)
+
+    def usable(self) -> bool:
+        """True iff every code fits int8 (the reference does not clamp; an out-of-range activation
+        leaves the packed path).  Resolving the device flag synchronises once per tensor."""
+        if self._usable is None:
+            self._usable = self.overflow is None or int(self.overflow.item()) == 0
+        return self._usable
+
+    @property
+    def ld_words(self) -> int:
+        return int(self.codes.shape[1]) // 4
+
+    @property
+    def device(self):
+        return self.codes.device
+
+
+def dorefa_codes(x: torch.Tensor, bit_width: int, want_f32: bool = True, ld_bytes: Optional[int] = None):
+    """k-bit DoReFa activation quantiser producing int8 codes (and the fp32 image _quantize returns,
+    functions/dorefa_connect.py:24-25) in one pass.  Returns (CodePlanes, y or None)."""
+    _require(x, "input")
+    if not 2 <= int(bit_width) <= 8:
+        raise ValueError("int8 code planes exist for 2 <= bit_width <= 8")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = code_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
+    codes = torch.empty((rows, ld), dtype=torch.int8, device=x.device)
+    y = torch.empty((rows, K), dtype=torch.float32, device=x.device) if want_f32 else None
+    flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("qt_dorefa_codes_i8", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(codes), ctypes.c_int64(ld), _p(y), ctypes.c_int64(K), ctypes.c_int64(rows),
+                  ctypes.c_int64(K), ctypes.c_int(int(bit_width)), _p(flag), _stream(x.device))
+    n = float((1 << int(bit_width)) - 1)
+    inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+    if y is not None:
+        y = y.view(x.shape)
+    return CodePlanes(codes=codes, rows=rows, K=K, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
+
+
+def weight_codes(w2d: torch.Tensor, ternary: bool = False, ld_bytes: Optional[int] = None) -> CodePlanes:
+    """int8 codes of safeSign(w) (or the ternary quantiser) for a [N, K] weight."""
+    _require(w2d, "weight")
+    w2 = _as_rows(w2d)
+    rows, K = int(w2.shape[0]), int(w2.shape[1])
+    ld = code_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
+    codes = torch.empty((rows, ld), dtype=torch.int8, device=w2d.device)
+    with torch.cuda.device(w2d.device):
+        _lib.call("qt_weight_codes_i8", _p(w2), ctypes.c_int64(w2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(codes), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
+                  ctypes.c_int(1 if ternary else 0), _stream(w2d.device))
+    return CodePlanes(codes=codes, rows=rows, K=K)
+
+
+def i8_gemm(x: CodePlanes, w: CodePlanes, scale: float, bias: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None, max_abs_code: int = 127,
+            scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y[M,N] = scale * scale_dev * (x codes . w codes^T) + bias on the int8 matrix cores (exact int32
+    accumulate).  ``scale_dev``: optional fp32 device scalar factor (no host sync)."""
+    if x.K != w.K:
+        raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
+    M, N, K = x.rows, w.rows, x.K
+    dev = x.device
+    bias = _check_bias(bias, N, dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("qt_i8_gemm", _p(x.codes), ctypes.c_int64(x.ld_words), _p(w.codes), ctypes.c_int64(w.ld_words),
+                  _p(bias), ctypes.c_float(float(scale)),
+                  _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None),
+                  ctypes.c_int64(int(max_abs_code)), _p(out),
+                  ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M), ctypes.c_int64(N),
+                  ctypes.c_int64(K), _stream(dev))
+    return out
+
+
+def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodePlanes:
+    """[Cout, Cin, kh, kw] -> int8 code plane [Cout, kh*kw*Cb] (tap-major, Cb = Cin rounded to 16 B),
+    row stride padded to a whole GEMM stage."""
+    _require(weight, "weight")
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    Cb = code_ld_bytes(Cin, 16)
+    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
+    taps = weight_codes(wt, ternary, ld_bytes=Cb)
+    kbytes = kh * kw * Cb
+    ld = code_ld_bytes(kbytes)
+    codes = taps.codes.view(Cout, kbytes)
+    if ld != kbytes:
+        padded = torch.zeros((Cout, ld), dtype=torch.int8, device=weight.device)
+        padded[:, :kbytes] = codes
+        codes = padded
+    return CodePlanes(codes=codes, rows=Cout, K=kbytes)
+
+
+def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, scale: float, bias=None,
+                 stride=1, padding=0, dilation=1, scale_dev=None) -> torch.Tensor:
+    """DoReFa conv2d on int8 code planes: NHWC pixel codes -> packed-domain im2col (zero bytes for
+    padding taps = the reference's zero padding, code 0 <-> value 0) -> int8 MFMA GEMM.
+    Returns the NHWC result [N*Ho*Wo, Cout]."""
+    N, C, H, W = (int(v) for v in in_shape)
+    kh, kw = kernel_hw
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    Cw = pixels.ld_words
+    if wplanes.K != kh * kw * Cw * 4:
+        raise ValueError("weight codes do not match the activation's channel packing")
+    Cout, ldA = wplanes.rows, wplanes.ld_words
+    M = N * Ho * Wo
+    dev = pixels.device
+    bias = _check_bias(bias, Cout, dev)
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+    rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
+    A = torch.empty((rows_per_chunk, ldA * 4), dtype=torch.int8, device=dev)
+    I = ctypes.c_int64
+    for m0 in range(0, M, rows_per_chunk):
+        cnt = min(rows_per_chunk, M - m0)
+        with torch.cuda.device(dev):
+            _lib.call("qt_im2col_words", _p(pixels.codes), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh),
+                      I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
+        i8_gemm(CodePlanes(codes=A[:cnt], rows=cnt, K=wplanes.K), wplanes, scale, bias, out=y[m0:m0 + cnt],
+                scale_dev=scale_dev)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
 # quantised conv2d = NHWC pixel planes -> packed-domain im2col -> packed GEMM
 # ----------------------------------------------------------------------------------------------
 
@@ -373,8 +521,6 @@ def pack_pixels_nib(x: torch.Tensor) -> NibPlanes:
     return sign_pack_nib(nhwc.view(N * H * W, C), ld=pixel_ld_nib(C))
 
 
-#: upper bound on the bytes of the temporary im2col matrix (the batch is processed in chunks)
-IM2COL_MAX_BYTES = 1 << 30
 
 
 def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=None, stride=1,

@@ -19,6 +19,7 @@ import torch
 from .ops import BitPlanes
 
 _ATTR = "_qt_planes"
+_ATTR_CODES = "_qt_codes"
 
 ROWS_LAST = "rows_last"  # planes pack the LAST dimension of the (logically row-major) tensor
 NHWC = "nhwc"            # planes pack the channel dimension of an [N,C,H,W] tensor, rows = N*H*W
@@ -37,3 +38,19 @@ def lookup(t: torch.Tensor, layout: str) -> Optional[BitPlanes]:
     if lay != layout or version != t._version or shape != tuple(t.shape):
         return None
     return planes
+
+
+def attach_codes(t: torch.Tensor, codes, layout: str) -> torch.Tensor:
+    """Same side channel for DoReFa activation codes (ops.CodePlanes) produced by nnDorefaQuant."""
+    setattr(t, _ATTR_CODES, (codes, layout, t._version, tuple(t.shape)))
+    return t
+
+
+def lookup_codes(t: torch.Tensor, layout: str):
+    tag = getattr(t, _ATTR_CODES, None)
+    if tag is None:
+        return None
+    codes, lay, version, shape = tag
+    if lay != layout or version != t._version or shape != tuple(t.shape):
+        return None
+    return codes

@@ -295,6 +295,52 @@ with torch.no_grad():
                                     "sha256_int32": digest_int(yc), "sum": float(yc.double().sum()),
                                     "abs_sum": float(yc.double().abs().sum())}
 
+# ---------------------------------------------------------------------------------------------
+# G8  DoReFa W1A4: nnDorefaQuant(4)(relu(x)) -> LinearDorefa / DorefaConv2d (bit_width=1)
+#     (the W1A4 composition of BASELINE config C4; activation quantiser applied to the unclamped relu)
+# ---------------------------------------------------------------------------------------------
+w1a4 = []
+for (B, K, N, with_bias) in [(5, 31, 7, False), (9, 96, 12, True), (130, 200, 70, True)]:
+    seed += 1
+    xr = synth.normal(seed, (B, K)) * 1.5
+    w = synth.uniform(seed + 1000, (N, K), -1.5, 1.5)
+    b = synth.normal(seed + 2000, (N,)) if with_bias else None
+    gout = synth.normal(seed + 3000, (B, N))
+    name = f"lin_B{B}_K{K}_N{N}_{'bias' if with_bias else 'nobias'}"
+    w1a4.append(name)
+    put(f"g8_{name}_x", xr); put(f"g8_{name}_w", w); put(f"g8_{name}_gout", gout)
+    if b is not None:
+        put(f"g8_{name}_b", b)
+    layer = RL.LinearDorefa(K, N, bias=with_bias, bit_width=1)
+    layer.weight.data.copy_(f32(w))
+    if with_bias:
+        layer.bias.data.copy_(f32(b))
+    xi = f32(xr).clone().requires_grad_(True)
+    xq = RF.nnDorefaQuant(4)(torch.relu(xi))
+    y = layer(xq)
+    y.backward(f32(gout))
+    put(f"g8_{name}_xq", xq); put(f"g8_{name}_y", y); put(f"g8_{name}_gx", xi.grad)
+    put(f"g8_{name}_gw", layer.weight.grad)
+    layer.train(False)
+    put(f"g8_{name}_y_eval", layer(xq.detach()))
+for (Cin, Cout, k, st, pd, H, with_bias) in [(16, 5, 3, 1, 1, 6, False), (64, 8, 3, 2, 1, 8, True), (40, 6, 1, 1, 0, 5, True)]:
+    seed += 1
+    xr = synth.normal(seed, (2, Cin, H, H)) * 1.5
+    w = synth.uniform(seed + 1000, (Cout, Cin, k, k), -1.5, 1.5)
+    b = synth.normal(seed + 2000, (Cout,)) if with_bias else None
+    name = f"conv_c{Cin}_o{Cout}_k{k}_s{st}_p{pd}_h{H}_{'bias' if with_bias else 'nobias'}"
+    w1a4.append(name)
+    put(f"g8_{name}_x", xr); put(f"g8_{name}_w", w)
+    if b is not None:
+        put(f"g8_{name}_b", b)
+    layer = RL.DorefaConv2d(Cin, Cout, k, stride=st, padding=pd, bias=with_bias, bit_width=1)
+    layer.weight.data.copy_(f32(w))
+    if with_bias:
+        layer.bias.data.copy_(f32(b))
+    xq = RF.nnDorefaQuant(4)(torch.relu(f32(xr)))
+    put(f"g8_{name}_xq", xq); put(f"g8_{name}_y", layer(xq))
+out["g8_cases"] = np.array(w1a4)
+
 np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)
 with open(os.path.join(HERE, "golden_hashes.json"), "w") as fh:
     json.dump({"torch": torch.__version__, "cases": hashes}, fh, indent=1, sort_keys=True)

@@ -17,7 +17,8 @@ from pytorch_quantize_impls_amd.functions import (BinaryConnectDeterministic, Bi
                                                   TernaryConnectDeterministic, BinaryConnect, BinaryDense,
                                                   nnDorefaQuant, safeSign)
 from pytorch_quantize_impls_amd.functions import binary_connect, terner_connect  # noqa: E402
-from pytorch_quantize_impls_amd.layers import LinearBin, LinearTer, BinConv2d, TerConv2d  # noqa: E402
+from pytorch_quantize_impls_amd.layers import (LinearBin, LinearTer, BinConv2d, TerConv2d,  # noqa: E402
+                                               LinearDorefa, DorefaConv2d)
 
 TOL = 1e-5
 
@@ -216,7 +217,7 @@ NIB_GEMM_SHAPES = GEMM_SHAPES + [(256, 256, 256), (512, 256, 4096), (255, 257, 3
 
 
 @pytest.mark.parametrize("M,N,K", NIB_GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [None, 5, 6])
+@pytest.mark.parametrize("variant", [None, 5, 6, 7, 8, 9, 10])
 def test_nib_gemm_vs_oracle(dev, oracle, M, N, K, variant):
     x = synth.pm1(M * 7 + K, (M, K))
     w = synth.uniform(N * 5 + K, (N, K), -1.5, 1.5)
@@ -236,7 +237,7 @@ def test_nib_gemm_equals_popcount_gemm_large(dev):
     x = torch.randn((1000, 5000), device=dev, generator=gen)
     w = torch.randn((777, 5000), device=dev, generator=gen)
     ref = ops.xnor_gemm(ops.sign_pack(x)[0], ops.sign_pack(w)[0])
-    for variant in (None, 5, 6):
+    for variant in (None, 5, 6, 7, 8, 9, 10):
         assert torch.equal(ops.nib_gemm(ops.sign_pack_nib(x), ops.sign_pack_nib(w), variant=variant), ref)
     reft = ops.tern_gemm(ops.sign_pack(x)[0], ops.ternary_pack(w))
     assert torch.equal(ops.nib_gemm(ops.bits_to_nib(ops.sign_pack(x)[0]), ops.bits_to_nib(ops.ternary_pack(w))), reft)
@@ -517,3 +518,61 @@ def test_alexnet_bin_layerwise(dev):
             b = gmods[name].bias.detach().cpu().numpy()
             shape = (1, -1, 1, 1) if y.dim() == 4 else (1, -1)
             assert np.array_equal(np.rint(n(y) - b.reshape(shape)), np.rint(yout.numpy() - b.reshape(shape))), name
+
+
+# ---- DoReFa W1A4: int8 code planes + int8 MFMA --------------------------------------------------------------
+
+def test_dorefa_codes_and_i8_gemm_vs_oracle(dev, oracle):
+    for (M, N, K) in [(5, 7, 31), (130, 70, 200), (300, 260, 1000), (257, 129, 4096)]:
+        x = np.maximum(synth.normal(M + K, (M, K)) * 1.5, 0)
+        w = synth.uniform(N + K, (N, K), -1.5, 1.5)
+        b = synth.normal(N, (N,))
+        with used("qt_dorefa_codes_i8", "qt_weight_codes_i8", "qt_i8_gemm"):
+            cp, y = ops.dorefa_codes(g(x, dev), 4)
+            wc = ops.weight_codes(g(w, dev))
+            out = n(ops.i8_gemm(cp, wc, 0.25, g(b, dev), scale_dev=torch.tensor(2.0, device=dev)))
+        assert same(n(y), oracle.dorefa_quantize(x, 4))
+        q = np.rint(np.float32(15) * x)
+        assert np.array_equal(n(cp.codes)[:, :K].astype(np.float32), q) and not n(cp.codes)[:, K:].any()
+        assert np.array_equal(n(wc.codes)[:, :K].astype(np.float32), oracle.safe_sign(w))
+        assert cp.usable()
+        want = (q.astype(np.float64) @ oracle.safe_sign(w).astype(np.float64).T).astype(np.float32) * np.float32(0.5) + b
+        assert same(out, want)                      # integer part exact, one scale multiply, bias once
+    # the reference does not clamp: a code beyond int8 must be flagged, not wrapped
+    big = np.zeros((3, 40), np.float32)
+    big[1, 7] = 9.0                                   # 15 * 9 = 135 > 127
+    assert not ops.dorefa_codes(g(big, dev), 4)[0].usable()
+    assert ops.dorefa_codes(g(big * 0.9, dev), 4)[0].usable()   # 121.5 -> 122 fits
+
+
+def test_dorefa_w1a4_layers_golden(dev, golden):
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant as Q
+    for name in golden["g8_cases"].tolist():
+        x, w = golden[f"g8_{name}_x"], golden[f"g8_{name}_w"]
+        has_b = f"g8_{name}_b" in golden.files
+        if name.startswith("lin"):
+            layer = LinearDorefa(w.shape[1], w.shape[0], bias=has_b, bit_width=1).to(dev)
+        else:
+            p = name.split("_")
+            layer = DorefaConv2d(w.shape[1], w.shape[0], w.shape[2], stride=int(p[4][1:]), padding=int(p[5][1:]),
+                                 bias=has_b, bit_width=1).to(dev)
+        layer.weight.data.copy_(g(w, dev))
+        if has_b:
+            layer.bias.data.copy_(g(golden[f"g8_{name}_b"], dev))
+        xi = g(x, dev)
+        if not name.startswith("lin"):
+            xi = xi.contiguous(memory_format=torch.channels_last)
+        xi.requires_grad_(True)
+        with used("qt_dorefa_codes_i8", "qt_i8_gemm"):
+            xq = Q(4)(torch.relu(xi))
+            y = layer(xq)
+        assert same(n(xq), golden[f"g8_{name}_xq"])
+        assert norm_err(n(y), golden[f"g8_{name}_y"]) <= TOL, name
+        if name.startswith("lin"):
+            y.backward(g(golden[f"g8_{name}_gout"], dev))
+            assert norm_err(n(xi.grad), golden[f"g8_{name}_gx"]) <= TOL
+            assert norm_err(n(layer.weight.grad), golden[f"g8_{name}_gw"]) <= TOL
+            layer.train(False)
+            with torch.no_grad(), used("qt_i8_gemm"):
+                ye = layer(Q(4)(torch.relu(g(x, dev))))
+            assert norm_err(n(ye), golden[f"g8_{name}_y_eval"]) <= TOL

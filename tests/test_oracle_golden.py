@@ -176,3 +176,24 @@ def test_nibble_formulation_equals_reference(golden, oracle):
         m, s = oracle.ternary_pack(w)
         assert np.array_equal(wt, oracle.bits_to_nib(s, m, K))
         assert same(oracle.nib_gemm(xn, wt, K), golden[f"g4_lin_{name}_ter_y"])
+
+
+def test_g8_dorefa_w1a4(golden, oracle):
+    for name in golden["g8_cases"].tolist():
+        x, w = golden[f"g8_{name}_x"], golden[f"g8_{name}_w"]
+        b = golden[f"g8_{name}_b"] if f"g8_{name}_b" in golden.files else None
+        xq = oracle.dorefa_quantize(np.maximum(x, 0), 4)
+        assert same(xq, golden[f"g8_{name}_xq"])
+        wq = oracle.dorefa_weight(w, 1)
+        if name.startswith("lin"):
+            assert norm_err(oracle.linear(xq, wq, b), golden[f"g8_{name}_y"]) <= TOL
+            assert norm_err(oracle.dorefa_w1a_linear(x, w, b), golden[f"g8_{name}_y"]) <= TOL   # int8 factoring
+            assert norm_err(oracle.linear(xq, wq, b), golden[f"g8_{name}_y_eval"]) <= TOL
+            gout = golden[f"g8_{name}_gout"]
+            assert norm_err(oracle.linear(gout.T.copy(), xq.T.copy()), golden[f"g8_{name}_gw"]) <= TOL   # unscaled by E
+            gx = oracle.linear(gout, wq.T.copy()) * (x > 0)
+            assert norm_err(gx, golden[f"g8_{name}_gx"]) <= TOL
+        else:
+            p = name.split("_")
+            st, pd = int(p[4][1:]), int(p[5][1:])
+            assert norm_err(oracle.conv2d(xq, wq, b, st, pd), golden[f"g8_{name}_y"]) <= TOL
