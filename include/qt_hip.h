@@ -96,6 +96,13 @@ int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, fl
 int qt_dorefa_quantize_f32(const float* x, float* y, int64_t n, int bit_width,
                            qt_stream_t stream);
 
+/* XNOR-Net weight quantiser over a row-major [R, C] view of the weight:
+ * alpha[c] = mean_r |w[r,c]| ;  wq[r,c] = sign(w[r,c]) * alpha[c]  (torch.sign: 0 -> 0).  wq may be NULL
+ * (alpha only).  XNORDense: R = N, C = K (functions/xnor_connect.py:112-113, global DIM = 0);
+ * XNORConv2d(dim=[0,1]): R = Cout*Cin, C = kh*kw (functions/xnor_connect.py:140-141). */
+int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int64_t ldq, int64_t R,
+                       int64_t C, qt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bit-pack kernels (fp32 -> packed planes).  rows x K fp32 (row stride ldx) ->
  * rows x ldp uint32 (only the first ceil(K/32) words of a row carry data, the rest are 0).

@@ -8,6 +8,7 @@ The reference module is unfinished upstream; observable numerics are reproduced,
 """
 import torch
 
+from .. import ops
 from .common import front
 
 DIM = 0
@@ -56,6 +57,13 @@ def QuantXnor(input, dim=1):
 
 def xnor_weight(weight, dims):
     """sign(W) * mean(|W|, dims, keepdim) — torch.sign, so W == 0 stays 0 (xnor_connect.py:112-113)."""
+    lead = None
+    if isinstance(dims, int):
+        lead = 1 if dims == 0 else None
+    elif list(dims) == list(range(len(dims))):
+        lead = len(dims)
+    if weight.is_cuda and weight.dtype == torch.float32 and lead is not None and weight.numel() > 0:
+        return ops.xnor_weight(weight.detach(), lead)   # qt_xnor_weight_f32 (column mean + sign*alpha)
     mean = torch.mean(torch.abs(weight), dims, keepdim=True)
     return torch.sign(weight) * mean, mean
 

@@ -125,6 +125,22 @@ def ste_mask(grad_out: torch.Tensor, x: torch.Tensor, thr: float = STE_THRESHOLD
     return _binary("qt_ste_mask_f32", grad_out, x, ctypes.c_float(thr))
 
 
+def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
+    """XNOR-Net weight quantiser: (sign(w) * alpha, alpha) with alpha = mean(|w|) over the first
+    ``lead_dims`` dimensions, keepdim (functions/xnor_connect.py:112-113, 140-141)."""
+    w = _require(w, "weight").contiguous()
+    R = 1
+    for d in w.shape[:lead_dims]:
+        R *= int(d)
+    C = w.numel() // max(R, 1)
+    alpha = torch.empty((C,), dtype=torch.float32, device=w.device)
+    wq = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _lib.call("qt_xnor_weight_f32", _p(w), ctypes.c_int64(C), _p(alpha), _p(wq), ctypes.c_int64(C),
+                  ctypes.c_int64(R), ctypes.c_int64(C), _stream(w.device))
+    return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
+
+
 # ----------------------------------------------------------------------------------------------
 # packing
 # ----------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ from pytorch_quantize_impls_amd.functions import (BinaryConnectDeterministic, Bi
                                                   nnDorefaQuant, safeSign)
 from pytorch_quantize_impls_amd.functions import binary_connect, terner_connect  # noqa: E402
 from pytorch_quantize_impls_amd.layers import (LinearBin, LinearTer, BinConv2d, TerConv2d,  # noqa: E402
-                                               LinearDorefa, DorefaConv2d)
+                                               LinearDorefa, DorefaConv2d, LinearXNOR, XNORConv2d)
 
 TOL = 1e-5
 
@@ -576,3 +576,48 @@ def test_dorefa_w1a4_layers_golden(dev, golden):
             with torch.no_grad(), used("qt_i8_gemm"):
                 ye = layer(Q(4)(torch.relu(g(x, dev))))
             assert norm_err(n(ye), golden[f"g8_{name}_y_eval"]) <= TOL
+
+
+# ---- XNOR-Net: HIP weight quantiser (sign * column mean), dense fp32 contraction -----------------------------
+
+def test_xnor_weight_kernel_vs_oracle(dev, oracle):
+    for shape, lead in (((7, 33), 1), ((300, 1000), 1), ((6, 5, 3, 3), 2), ((64, 96, 5, 5), 2), ((3, 1), 1)):
+        w = synth.uniform(sum(shape), shape, -2, 2)
+        w.reshape(-1)[::7] = 0.0
+        with used("qt_xnor_weight_f32"):
+            wq, alpha = ops.xnor_weight(g(w, dev), lead)
+        want = oracle.xnor_dense_weight(w) if lead == 1 else oracle.xnor_conv_weight(w)
+        assert alpha.shape == ((1,) * lead + tuple(shape[lead:]))
+        assert norm_err(n(wq), want) <= TOL   # fp32 column sums: order-dependent in the last ulps
+        assert np.array_equal(n(wq) == 0, w == 0)           # torch.sign keeps zeros
+
+
+def test_xnor_layers_golden(dev, golden):
+    for name in golden["g4_lin_cases"].tolist():
+        gg = lambda s: golden[f"g4_lin_{name}_{s}"]
+        has_b = f"g4_lin_{name}_b" in golden.files
+        x, w, gout = gg("x"), gg("w"), gg("gout")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            layer = LinearXNOR(x.shape[1], w.shape[0], bias=has_b).to(dev)
+        layer.weight.data.copy_(g(w, dev))
+        if has_b:
+            layer.bias.data.copy_(g(gg("b"), dev))
+        xi = g(x, dev).requires_grad_(True)
+        with used("qt_xnor_weight_f32"):
+            y = layer(xi)
+        y.backward(g(gout, dev))
+        assert norm_err(n(y), gg("xnor_y")) <= TOL, name
+        assert norm_err(n(xi.grad), gg("xnor_gx")) <= TOL
+        assert norm_err(n(layer.weight.grad), gg("xnor_gw")) <= TOL
+    for name in golden["g4_conv_cases"].tolist():
+        p = name.split("_")
+        Cin, Cout, k, st, pd = int(p[0][1:]), int(p[1][1:]), int(p[2][1:]), int(p[3][1:]), int(p[4][1:])
+        has_b = p[7] == "bias"
+        layer = XNORConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b).to(dev)
+        layer.weight.data.copy_(g(golden[f"g4_conv_{name}_w"], dev))
+        if has_b:
+            layer.bias.data.copy_(g(golden[f"g4_conv_{name}_b"], dev))
+        with used("qt_xnor_weight_f32"):
+            y = layer(g(golden[f"g4_conv_{name}_x"], dev))
+        assert norm_err(n(y), golden[f"g4_conv_{name}_xnor_y"]) <= TOL, name
