@@ -1,0 +1,117 @@
+"""Parity at the layer shapes of BASELINE.json configs C3 / C4 / C5, batch-reduced
+only where the activation would not matter for the code path.  The independent check is the dense fp32
+conv / matmul of the SAME quantised fp32 images on the device (integer-exact for +-1 / ternary operands,
+so equality is bitwise; DoReFa's float scale gets the normalised 1e-5 tolerance)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import _lib, ops  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic, nnDorefaQuant  # noqa: E402
+from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, LinearTer, DorefaConv2d, LinearBin  # noqa: E402
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _gen(dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return g
+
+
+def _nerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+# C5: ternary VGG-16 (A.3).  (Cin, Cout, H, batch)
+VGG = [(64, 64, 224, 2), (64, 128, 112, 4), (128, 128, 112, 4), (128, 256, 56, 8), (256, 256, 56, 8),
+       (256, 512, 28, 16), (512, 512, 28, 32), (512, 512, 14, 64)]
+
+
+@pytest.mark.parametrize("Cin,Cout,H,B", VGG)
+def test_c5_ternary_vgg_conv(dev, Cin, Cout, H, B):
+    g = _gen(dev, Cin + Cout + H)
+    x = torch.randn((B, Cin, H, H), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    conv = TerConv2d(Cin, Cout, 3, padding=1).to(dev)
+    conv.weight.data.copy_(torch.randn(conv.weight.shape, device=dev, generator=g) * 0.8)
+    conv.bias.data.zero_()
+    before = _lib.call_counts["qt_nib_gemm"]
+    with torch.no_grad():
+        xs = BinaryConnectDeterministic.apply(x)
+        y = conv(xs)
+        ref = F.conv2d(xs, ops.ternarize(conv.weight.detach()), None, padding=1)
+    assert _lib.call_counts["qt_nib_gemm"] > before
+    assert torch.equal(y, ref)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_c5_ternary_vgg_fc(dev):
+    g = _gen(dev, 5)
+    for (K, N, B) in [(25088, 4096, 256), (4096, 4096, 256), (4096, 1000, 256)]:
+        x = torch.randn((B, K), device=dev, generator=g)
+        fc = LinearTer(K, N).to(dev)
+        fc.weight.data.copy_(torch.randn((N, K), device=dev, generator=g) * 0.8)
+        fc.bias.data.zero_()
+        with torch.no_grad():
+            xs = BinaryConnectDeterministic.apply(x)
+            y = fc(xs)
+            ref = xs.double() @ ops.ternarize(fc.weight.detach()).double().t()
+        assert torch.equal(y.double(), ref)
+
+
+# C4: DoReFa ResNet-18 W1A4 on 32x32 inputs, batch 256 (A.2).  (Cin, Cout, k, stride, H)
+RESNET = [(64, 64, 3, 1, 32), (64, 128, 3, 2, 32), (128, 128, 3, 1, 16), (64, 128, 1, 2, 32),
+          (128, 256, 3, 2, 16), (256, 256, 3, 1, 8), (256, 512, 3, 2, 8), (512, 512, 3, 1, 4), (256, 512, 1, 2, 8)]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,H", RESNET)
+def test_c4_dorefa_resnet_conv(dev, Cin, Cout, k, stride, H):
+    g = _gen(dev, Cin * 3 + Cout + k + H)
+    B = 256
+    x = (torch.randn((B, Cin, H, H), device=dev, generator=g) * 0.7).contiguous(memory_format=torch.channels_last)
+    conv = DorefaConv2d(Cin, Cout, k, stride=stride, padding=k // 2, bias=False, bit_width=1).to(dev)
+    conv.weight.data.copy_(torch.randn(conv.weight.shape, device=dev, generator=g) * 0.1)
+    before = _lib.call_counts["qt_i8_gemm"]
+    with torch.no_grad():
+        xq = nnDorefaQuant(4)(torch.relu(x))          # unclamped relu(bn(x)) stand-in, as ResNet_Dorefa.py:26,35
+        y = conv(xq)
+        wq = ops.binarize(conv.weight.detach()) * conv.weight.detach().abs().mean()
+        ref = F.conv2d(xq.double(), wq.double(), None, stride=stride, padding=k // 2)
+    assert _lib.call_counts["qt_i8_gemm"] > before
+    assert _nerr(y, ref) <= TOL
+    # integer core: divide the scale back out and compare codes exactly
+    scale = float(conv.weight.detach().abs().mean()) / 15.0
+    acc = torch.round(y.double() / scale)
+    acc_ref = F.conv2d(torch.round(xq.double() * 15), ops.binarize(conv.weight.detach()).double(), None,
+                       stride=stride, padding=k // 2)
+    assert torch.equal(acc, acc_ref)
+
+
+# C3: AlexNet-Bin conv layers at the full batch 256 (A.1): checksum-of-checksums against fp64
+@pytest.mark.parametrize("Cin,Cout,k,pad,H", [(192, 576, 5, 2, 27), (576, 1152, 3, 1, 13), (1152, 768, 3, 1, 13),
+                                              (768, 256, 3, 1, 13)])
+def test_c3_alexnet_conv_full_batch(dev, Cin, Cout, k, pad, H):
+    g = _gen(dev, Cin + Cout)
+    x = torch.randn((256, Cin, H, H), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    conv = BinConv2d(Cin, Cout, k, padding=pad).to(dev)
+    conv.bias.data.zero_()
+    with torch.no_grad():
+        xs = BinaryConnectDeterministic.apply(x)
+        y = conv(xs)
+        wb = ops.binarize(conv.weight.detach())
+        # sum over output channels of y == conv of x with the channel-summed kernel (linearity)
+        ref_sum = F.conv2d(xs.double(), wb.double().sum(0, keepdim=True), None, padding=pad)
+        assert torch.equal(y.double().sum(1, keepdim=True), ref_sum)
+        # a slice of 8 images against the dense conv
+        assert torch.equal(y[:8], F.conv2d(xs[:8], wb, None, padding=pad))
+    yi = y.to(torch.int64)
+    assert torch.equal(yi.to(torch.float32), y) and int(yi.abs().max()) <= Cin * k * k
