@@ -218,6 +218,26 @@ def bench_alexnet(args, dev, dist, world, rank):
     out = {"images_per_s": world * B * args.alexnet_iters / el, "batch_per_gpu": B,
            "ms_per_forward": el / args.alexnet_iters * 1e3, "mode": "eval (pre-packed weights), channels_last",
            "macs_per_image": 4.9349e9, "finite": bool(torch.isfinite(y).all())}
+    # same network with the inter-layer chains fused (layers.fused: MaxPool+BN+Hardtanh+sign+pack in one kernel)
+    fused = bench_models.FusedAlexNetBin(model)
+    with torch.no_grad():
+        for _ in range(2):
+            yf = fused(x)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.alexnet_iters):
+            yf = fused(x)
+        torch.cuda.synchronize()
+        elf = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elf], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elf = float(tt.item())
+    out["fused"] = {"images_per_s": world * B * args.alexnet_iters / elf,
+                    "ms_per_forward": elf / args.alexnet_iters * 1e3,
+                    "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), y.argmax(1)))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = min(B, 16)
         cpu_model = bench_models.AlexNetBin()

@@ -54,6 +54,32 @@ class AlexNetBin(nn.Module):
         return self.classifieur(x)
 
 
+class FusedAlexNetBin(nn.Module):
+    """Inference form of an (eval-mode) AlexNetBin: every [MaxPool, BatchNorm, Hardtanh, BinaryConnect]
+    run is one FusedPoolBnSign kernel, activations between binarised layers exist only as bit planes.
+    Shares the parameters of the model it was built from.  The last feature block's planes are flattened
+    in (h, w, c) order, so the first classifier layer gets its weight columns permuted once."""
+
+    def __init__(self, model: AlexNetBin):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import FusedPoolBnSign, fuse_sequential, permute_fc_weight_hwc
+        assert not model.training, "fuse an eval-mode model"
+        f = list(model.features.children())
+        self.features = fuse_sequential(nn.Sequential(*f[:-3]))      # ... up to the last BinConv2d
+        self.last = FusedPoolBnSign(f[-2], pool=f[-3], flatten_hwc=True)   # MaxPool, BN, (Hardtanh), + classifier's BinaryConnect
+        c = list(model.classifieur.children())
+        fc1 = LinearBin(c[1].in_features, c[1].out_features).to(c[1].weight.device)
+        fc1.weight.data.copy_(permute_fc_weight_hwc(c[1].weight.data, 256, 6, 6))
+        fc1.bias.data.copy_(c[1].bias.data)
+        fc1.eval()                                                   # weights above are already +-1 images
+        fc1._qt_eval_version = fc1.weight._version
+        self.classifieur = fuse_sequential(nn.Sequential(fc1, *c[2:]))
+        self.eval()
+
+    def forward(self, x):
+        return self.classifieur(self.last(self.features(x)))
+
+
 class BinMLP(nn.Module):
     def __init__(self, in_features=784, hidden=512, out_features=10):
         super().__init__()

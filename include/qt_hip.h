@@ -191,6 +191,17 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
                float scale, const float* scale_dev, int64_t max_abs_code, float* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t K, qt_stream_t stream);
 
+/* Fused inference epilogue between binarised layers:
+ *   [MaxPool2d(pool_k, pool_s, no padding, floor)] -> BatchNorm(eval) -> Hardtanh -> BinaryConnect -> pack
+ * as ONE pass: bit = (max_window(x) * alpha[c] + beta[c]) < 0.  x: NHWC fp32 [N][H][W][C], C % 4 == 0;
+ * alpha/beta: the folded eval BatchNorm (alpha = weight/sqrt(var+eps), beta = bias - mean*alpha);
+ * pool_k = pool_s = 1 means no pooling; H = W = 1 covers BatchNorm1d on [N, C].
+ * Output: NHWC pixel sign plane [N*Ho*Wo][ldp].  Replaces models/Alexnet/Alexnet_Bin.py:14-17 style
+ * chains (MaxPool2d, BatchNorm2d, Hardtanh, BinaryConnect) in eval mode. */
+int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
+                                  int64_t pool_k, int64_t pool_s, const float* alpha, const float* beta,
+                                  uint32_t* sign_plane, int64_t ldp, qt_stream_t stream);
+
 /* nibble plane from existing bit planes (sign only: mask_plane == NULL; ternary: mask + sign).
  * 1 bit -> 4 bits per element; lets the canonical 1-bit planes (what the quantisers emit and what
  * eval-mode layers cache) feed the matrix-core GEMM without re-reading the fp32 tensor. */

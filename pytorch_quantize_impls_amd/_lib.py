@@ -60,6 +60,8 @@ SIGNATURES = {
     "qt_weight_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_i8_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                             _c_i64, _c_i64, _c_p]),
+    "qt_pool_affine_sign_pack_nhwc": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
+                                               _c_p, _c_i64, _c_p]),
     "qt_im2col_words": (_c_int, [_c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_nib_gemm_variant": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64,
                                      _c_i64, _c_i64, _c_p]),

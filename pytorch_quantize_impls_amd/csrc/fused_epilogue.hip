@@ -1,0 +1,86 @@
+// Fused inference epilogue between binarised layers:
+//     [MaxPool2d(k, s)] -> BatchNorm(eval) -> Hardtanh -> BinaryConnectDeterministic -> bit-pack
+// (the chain models/Alexnet/Alexnet_Bin.py:14-17 and benchmark/BinaryNet/MLPBin.py:42-44 put between
+// two binarised layers).  In eval mode BatchNorm is the per-channel affine t = x*alpha[c] + beta[c]
+// (alpha = weight/sqrt(var+eps), beta = bias - mean*alpha: the fold ATen's CPU kernel itself performs),
+// Hardtanh never changes the sign, and safeSign(t) = (t < 0 ? -1 : +1): the whole chain collapses to one
+// comparison per element on the max-pooled conv output.  The kernel reads the fp32 NHWC tensor ONCE and
+// writes only the sign bit plane (1/32 of a fp32 tensor) — none of the four intermediate fp32 tensors
+// the unfused chain materialises exists any more.
+//
+// Layout: x is NHWC fp32 [N][H][W][C] (C % 4 == 0), out is the NHWC pixel bit plane [N*Ho*Wo][ldp].
+// One work item = 4 consecutive channels of one output pixel; 8 adjacent lanes = one 32-channel word.
+// HBM-bound: algorithmic bytes = 4*N*H*W*C (read) + N*Ho*Wo*C/8 (write).
+#include "qt_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+    v |= __shfl_xor(v, 1);
+    v |= __shfl_xor(v, 2);
+    v |= __shfl_xor(v, 4);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
+    const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta,
+    uint32_t* __restrict__ plane, int64_t ldp, int64_t N, int H, int W, int C, int pk, int ps, int Ho,
+    int Wo) {
+    const int64_t slots_per_pixel = ldp * 8;  // float4 slots per output pixel incl. pad (pad -> bit 0)
+    const int64_t total = N * Ho * Wo * slots_per_pixel;  // multiple of 32 (ldp % 4 == 0)
+    const int c4max = C / 4;
+    const int lane8 = threadIdx.x & 7;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = s / slots_per_pixel;
+        const int slot = (int)(s - pix * slots_per_pixel);
+        uint32_t nib = 0;
+        if (slot < c4max) {
+            const int64_t n = pix / ((int64_t)Ho * Wo);
+            const int rem = (int)(pix - n * Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            const float* base = x + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * C + slot * 4;
+            float4 m = *reinterpret_cast<const float4*>(base);
+            for (int i = 0; i < pk; ++i)
+                for (int j = 0; j < pk; ++j) {
+                    if (i == 0 && j == 0) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)i * W + j) * C);
+                    // torch max_pool2d propagates NaN
+                    m.x = (v.x > m.x || v.x != v.x) ? v.x : m.x;
+                    m.y = (v.y > m.y || v.y != v.y) ? v.y : m.y;
+                    m.z = (v.z > m.z || v.z != v.z) ? v.z : m.z;
+                    m.w = (v.w > m.w || v.w != v.w) ? v.w : m.w;
+                }
+            const float4 a = *reinterpret_cast<const float4*>(alpha + slot * 4);
+            const float4 b = *reinterpret_cast<const float4*>(beta + slot * 4);
+            // two roundings (mul, add), like the un-fused x*alpha + beta
+            nib = qt_neg_bit(m.x * a.x + b.x) | (qt_neg_bit(m.y * a.y + b.y) << 1) |
+                  (qt_neg_bit(m.z * a.z + b.z) << 2) | (qt_neg_bit(m.w * a.w + b.w) << 3);
+        }
+        const uint32_t word = or_reduce8(nib << (4 * lane8));
+        if (lane8 == 0) plane[pix * ldp + (slot >> 3)] = word;
+    }
+}
+
+}  // namespace
+
+extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
+                                             int64_t pool_k, int64_t pool_s, const float* alpha,
+                                             const float* beta, uint32_t* sign_plane, int64_t ldp,
+                                             qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || pool_k < 1 || pool_s < 1) return QT_ERR_INVALID_ARG;
+    if (pool_k > H || pool_k > W) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!x || !alpha || !beta || !sign_plane) return QT_ERR_INVALID_ARG;
+    if ((C & 3) || ldp < (C + 31) / 32 || (ldp & 3)) return QT_ERR_ALIGNMENT;
+    if (!qt_aligned16(x) || !qt_aligned16(alpha) || !qt_aligned16(beta) || !qt_aligned16(sign_plane))
+        return QT_ERR_ALIGNMENT;
+    if (H > INT32_MAX / 2 || W > INT32_MAX / 2 || C > INT32_MAX / 2) return QT_ERR_UNSUPPORTED;
+    const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;  // floor mode, no padding
+    const int64_t total = N * Ho * Wo * ldp * 8;
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(pool_affine_sign_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, alpha,
+                       beta, sign_plane, ldp, N, (int)H, (int)W, (int)C, (int)pool_k, (int)pool_s, (int)Ho,
+                       (int)Wo);
+    return qt_check_launch();
+}

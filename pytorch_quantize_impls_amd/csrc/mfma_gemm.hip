@@ -118,7 +118,7 @@ struct GemmCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS, 2) void mfma_gemm_kernel(
+__global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kernel(
     const uint32_t* __restrict__ X, int64_t ldx, const uint32_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, float scale, const float* __restrict__ scale_dev,
     float* __restrict__ Y, int64_t ldy, int M, int N, int K) {
@@ -353,6 +353,9 @@ template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
 // 4-wave workgroups with 64-byte stages: 48 KiB of LDS, <= 256 VGPRs -> TWO independent workgroups per
 // CU (different barrier domains fill each other's fill/drain bubbles and epilogues).
 template <class E, int PIPE> using Cfg2x = GemmCfg<E, 2, 2, 4, 2, PIPE, 0, 64>;      // 256x128 tile
+// 4 waves = ONE wave per SIMD with the whole 512-register file: wave tile 128x128 (16 MFMA tiles,
+// 0.5 KiB of LDS fragment traffic per MFMA instead of 0.75), everything overlapped inside the wave.
+template <class E, int PIPE> using Cfg1w = GemmCfg<E, 2, 2, 4, 4, PIPE>;
 template <class E, int PIPE> using Cfg2z = GemmCfg<E, 2, 4, 4, 2, PIPE, 0, 64>;      // 8 waves 256x256, 64-B stages (64 KiB: 2/CU by LDS, VGPR-limited)
 
 int check_common(const void* Xn, int64_t ldxp, const void* Wn, int64_t ldwp, const float* Y, int64_t ldy,
@@ -391,6 +394,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 8: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg64<E, 1>);
         case 11: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2x<E, 1>);
         case 13: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2z<E, 1>);
+        case 14: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg1w<E, 1>);
         case 9: QT_GO(Cfg128<E, 0>);
         case 10: QT_GO(Cfg64<E, 0>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);

@@ -156,6 +156,40 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
+def packed_linear(layer, act, kind: str) -> torch.Tensor:
+    """Eval-mode LinearBin / LinearTer on a PackedActivation (row planes): planes -> packed GEMM."""
+    if layer.training:
+        raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
+    N = layer.weight.shape[0]
+    M, K = act.planes.rows, act.planes.K
+    if K != layer.weight.shape[1]:
+        raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
+    impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
+    wp = layer._eval_planes(lambda w2: pack_weight(w2, kind, impl), key=impl)
+    y = ops.packed_gemm(ops.to_impl(act.planes, impl), wp, layer.bias, impl=impl)
+    return y.view(*act.shape[:-1], N)
+
+
+def packed_conv2d(layer, act, kind: str) -> torch.Tensor:
+    """Eval-mode BinConv2d / TerConv2d on a PackedActivation (NHWC planes).  Returns a channels_last
+    [N, Cout, Ho, Wo] fp32 tensor."""
+    if layer.training:
+        raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
+    if layer.groups != 1 or layer.padding_mode != "zeros":
+        raise ValueError("packed conv needs groups == 1 and zero padding")
+    N, C, H, W = act.shape
+    wp = layer._eval_planes(lambda _w2: ops.pack_conv_weight_nib(layer.weight.detach(), kind), key="conv_nib")
+    kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
+    px = ops.bits_to_nib(act.planes, ld=ops.pixel_ld_nib(C))
+    y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), layer.bias, layer.stride, layer.padding, layer.dilation)
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
+    return y2.view(N, Ho, Wo, layer.weight.shape[0]).permute(0, 3, 1, 2)
+
+
+#: dispatch used by the layers' forward for PackedActivation inputs: [is_linear] -> function
+PACKED_FWD = {True: packed_linear, False: packed_conv2d}
+
+
 class QuantConv2dFn(torch.autograd.Function):
     """Autograd node of BinConv2d / TerConv2d in training mode: forward F.conv2d(x, Q(W), b, ...)
     (layers/binary_layers.py:105); backward = what autograd derives from F.conv2d plus the STE mask

@@ -5,6 +5,7 @@ import torch
 
 from ..functions import binary_connect, _fused
 from .common import QLayer, EvalSwapMixin
+from ..packed import PackedActivation as _PackedActivation
 
 
 class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
@@ -43,6 +44,8 @@ class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
         return self.bin_op.apply(self.weight)
 
     def forward(self, input):
+        if isinstance(input, _PackedActivation):
+            return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
         if not input.is_cuda:
             w = self.bin_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.linear(input, w, self.bias)
@@ -99,6 +102,8 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self.bin_op.apply(self.weight)
 
     def forward(self, input):
+        if isinstance(input, _PackedActivation):
+            return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
         if not input.is_cuda:
             w = self.bin_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,

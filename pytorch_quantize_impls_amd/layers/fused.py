@@ -1,0 +1,105 @@
+"""Inference-time fusion of the chain the reference puts between two binarised layers
+(SURVEY.md section 8f, n1):
+
+    [MaxPool2d] -> BatchNorm{1,2}d (eval) -> [Hardtanh] -> BinaryConnect(deterministic)
+
+(models/Alexnet/Alexnet_Bin.py:14-17, benchmark/BinaryNet/MLPBin.py:42-44).  In eval mode it is a
+per-channel threshold on the max-pooled tensor; ``FusedPoolBnSign`` evaluates it in ONE HIP kernel
+(qt_pool_affine_sign_pack_nhwc) that emits the sign bit plane directly as a ``PackedActivation`` —
+none of the intermediate fp32 tensors is materialised, and the next BinConv2d / LinearBin / *Ter layer
+consumes the planes without re-reading anything.  Opt-in (``fuse_sequential``): the un-fused modules keep
+working exactly as in the reference.
+
+Numerics: BatchNorm is folded to x*alpha + beta with alpha = weight * (1/sqrt(var+eps)),
+beta = bias - mean*alpha — the fold ATen's own CPU kernel performs — evaluated with two fp32 roundings.
+A value within an ulp of the threshold can land on the other side of it than in a differently-ordered
+evaluation (MIOpen's, say); everything else is identical.
+"""
+import torch
+
+from .. import ops, packed
+from ..functions.common import _FunctionModule
+from ..functions.binary_connect import BinaryConnectDeterministic
+
+
+def fold_batchnorm(bn):
+    """(alpha, beta) of eval-mode BatchNorm: y = x*alpha + beta."""
+    invstd = 1.0 / torch.sqrt(bn.running_var.detach() + bn.eps)
+    w = bn.weight.detach() if bn.affine else torch.ones_like(invstd)
+    b = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
+    alpha = invstd * w
+    beta = b - bn.running_mean.detach() * alpha
+    return alpha.float().contiguous(), beta.float().contiguous()
+
+
+class FusedPoolBnSign(torch.nn.Module):
+    """[MaxPool2d(k, s)] + eval BatchNorm + [Hardtanh] + BinaryConnect(deterministic) -> PackedActivation."""
+
+    def __init__(self, bn, pool=None, flatten_hwc=False):
+        super().__init__()
+        if pool is not None:
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+            pad = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+            dil = pool.dilation if isinstance(pool.dilation, int) else pool.dilation[0]
+            if pad != 0 or dil != 1 or pool.ceil_mode:
+                raise ValueError("only un-padded, un-dilated, floor-mode MaxPool2d can be fused")
+            self.pool_k, self.pool_s = int(k), int(st)
+        else:
+            self.pool_k = self.pool_s = 1
+        self.bn = bn
+        self.flatten_hwc = flatten_hwc
+        self._folded = None
+
+    def refold(self):
+        self._folded = None
+
+    def forward(self, x):
+        if self.bn.training:
+            raise RuntimeError("FusedPoolBnSign is an inference module: call .eval() first")
+        if not x.is_cuda:
+            raise TypeError("FusedPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
+        if self._folded is None or self._folded[0].device != x.device:
+            self._folded = fold_batchnorm(self.bn)
+        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, self._folded[0], self._folded[1], self.pool_k, self.pool_s)
+        if x.dim() == 2:
+            return packed.PackedActivation(planes, (x.shape[0], x.shape[1]))
+        act = packed.PackedActivation(planes, (x.shape[0], x.shape[1], Ho, Wo))
+        return act.flatten_hwc() if self.flatten_hwc else act
+
+
+def _is_det_binary_connect(m):
+    return isinstance(m, _FunctionModule) and m.core is BinaryConnectDeterministic
+
+
+def fuse_sequential(seq: torch.nn.Sequential) -> torch.nn.Sequential:
+    """New nn.Sequential where every [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)] run is
+    replaced by one FusedPoolBnSign (sharing the original BatchNorm's parameters)."""
+    mods = list(seq.children())
+    out, i = [], 0
+    while i < len(mods):
+        j = i
+        pool = None
+        if isinstance(mods[j], torch.nn.MaxPool2d):
+            pool, j = mods[j], j + 1
+        if j < len(mods) and isinstance(mods[j], (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            bn, j2 = mods[j], j + 1
+            if j2 < len(mods) and isinstance(mods[j2], torch.nn.Hardtanh) and mods[j2].min_val < 0 < mods[j2].max_val:
+                j2 += 1
+            if j2 < len(mods) and _is_det_binary_connect(mods[j2]):
+                try:
+                    out.append(FusedPoolBnSign(bn, pool))
+                    i = j2 + 1
+                    continue
+                except ValueError:
+                    pass
+        out.append(mods[i])
+        i += 1
+    return torch.nn.Sequential(*out)
+
+
+def permute_fc_weight_hwc(weight: torch.Tensor, C: int, H: int, W: int) -> torch.Tensor:
+    """Columns of an FC weight that expects the NCHW flattening (c*H*W + h*W + w) re-ordered to the
+    (h, w, c) order of PackedActivation.flatten_hwc()."""
+    N = weight.shape[0]
+    return weight.view(N, C, H, W).permute(0, 2, 3, 1).reshape(N, H * W * C).contiguous()

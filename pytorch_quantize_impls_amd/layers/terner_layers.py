@@ -5,6 +5,7 @@ import torch
 
 from ..functions import terner_connect, _fused
 from .common import QLayer, EvalSwapMixin
+from ..packed import PackedActivation as _PackedActivation
 from .binary_layers import _eval_linear
 
 
@@ -43,6 +44,8 @@ class LinearTer(EvalSwapMixin, torch.nn.Linear, QLayer):
         return self.ter_op.apply(self.weight)
 
     def forward(self, input):
+        if isinstance(input, _PackedActivation):
+            return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
         if not input.is_cuda:
             w = self.ter_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.linear(input, w, self.bias)
@@ -80,6 +83,8 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self.ter_op.apply(self.weight)
 
     def forward(self, input):
+        if isinstance(input, _PackedActivation):
+            return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
         if not input.is_cuda:
             w = self.ter_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,

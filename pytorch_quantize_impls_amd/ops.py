@@ -189,6 +189,35 @@ def ternary_pack(x: torch.Tensor) -> BitPlanes:
     return BitPlanes(sign=sign, rows=rows, K=K, mask=mask)
 
 
+def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, pool_k: int = 1,
+                          pool_s: int = 1):
+    """Fused [MaxPool2d(pool_k, pool_s)] -> eval-BatchNorm (x*alpha+beta) -> Hardtanh -> sign -> bit-pack.
+    x: [N, C, H, W] fp32 (channels_last storage is used as-is, NCHW storage is transposed once) or
+    [N, C].  Returns (BitPlanes with rows = N*Ho*Wo, K = C; (Ho, Wo))."""
+    _require(x, "input")
+    if x.dim() == 2:
+        N, C = (int(v) for v in x.shape)
+        H = W = 1
+        nhwc = x.contiguous()
+    else:
+        N, C, H, W = (int(v) for v in x.shape)
+        nhwc = x.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+    if C % 4:
+        raise ValueError("the fused epilogue needs C % 4 == 0")
+    Ho, Wo = (H - pool_k) // pool_s + 1, (W - pool_k) // pool_s + 1
+    ld = packed_ld(C)
+    plane = torch.empty((N * Ho * Wo, ld), dtype=torch.int32, device=x.device)
+    alpha = _require(alpha, "alpha").contiguous()
+    beta = _require(beta, "beta").contiguous()
+    I = ctypes.c_int64
+    with torch.cuda.device(x.device):
+        _lib.call("qt_pool_affine_sign_pack_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)),
+                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), _stream(x.device))
+    return BitPlanes(sign=plane, rows=N * Ho * Wo, K=C), (Ho, Wo)
+
+
 def check_pm1(x: torch.Tensor, limit: Optional[int] = None) -> torch.Tensor:
     """Device flag (int32 scalar tensor): non-zero iff some element of x (of its first ``limit``
     elements in storage order) is not exactly +-1."""

@@ -54,3 +54,38 @@ def lookup_codes(t: torch.Tensor, layout: str):
     if lay != layout or version != t._version or shape != tuple(t.shape):
         return None
     return codes
+
+
+class PackedActivation:
+    """A +-1 activation that exists ONLY as bit planes (no fp32 image): what the fused inference
+    epilogue (layers.fused.FusedPoolBnSign) hands to the next binarised layer.
+
+    ``planes``: ops.BitPlanes; ``shape``: the logical shape of the +-1 tensor it stands for,
+    (N, C, H, W) with NHWC planes (rows = N*H*W, K = C) or (N, K) with row planes (rows = N)."""
+    is_cuda = True
+    dtype = torch.float32
+    requires_grad = False
+
+    def __init__(self, planes: BitPlanes, shape):
+        self.planes = planes
+        self.shape = tuple(int(v) for v in shape)
+
+    @property
+    def device(self):
+        return self.planes.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def flatten_hwc(self) -> "PackedActivation":
+        """(N, C, H, W) NHWC planes -> (N, H*W*C) row planes in (h, w, c) order.  Needs C % 32 == 0 and
+        an unpadded pixel stride so the words of one image are contiguous; the consumer's weight
+        columns must be permuted to the same order (layers.fused.permute_fc_weight_hwc)."""
+        N, C, H, W = self.shape
+        if self.planes.ld * 32 != C:
+            raise ValueError("flatten_hwc needs C to be a multiple of 128 (unpadded 16-byte pixel rows)")
+        words = self.planes.sign.view(N, H * W * self.planes.ld)
+        return PackedActivation(BitPlanes(sign=words, rows=N, K=H * W * C), (N, H * W * C))

@@ -621,3 +621,53 @@ def test_xnor_layers_golden(dev, golden):
         with used("qt_xnor_weight_f32"):
             y = layer(g(golden[f"g4_conv_{name}_x"], dev))
         assert norm_err(n(y), golden[f"g4_conv_{name}_xnor_y"]) <= TOL, name
+
+
+# ---- fused inference epilogue -------------------------------------------------------------------
+
+def test_fused_pool_bn_sign_pack_vs_unfused(dev, oracle):
+    from pytorch_quantize_impls_amd.layers import FusedPoolBnSign
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    for (N, C, H, pk, ps) in [(3, 64, 13, 3, 2), (2, 192, 55, 3, 2), (4, 36, 9, 1, 1), (5, 128, 1, 1, 1)]:
+        x = (torch.randn((N, C, H, H), device=dev, generator=gen) * 20).round()      # integer-valued like conv outputs
+        x = x.contiguous(memory_format=torch.channels_last)
+        bn = torch.nn.BatchNorm2d(C).to(dev).eval()
+        bn.running_mean.copy_(torch.randn(C, device=dev, generator=gen) * 3 + 0.37)
+        bn.running_var.copy_(torch.rand(C, device=dev, generator=gen) * 50 + 1)
+        bn.weight.data.copy_(torch.randn(C, device=dev, generator=gen))               # negative gammas too
+        bn.bias.data.copy_(torch.randn(C, device=dev, generator=gen))
+        pool = torch.nn.MaxPool2d(pk, ps) if pk > 1 else None
+        with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc"):
+            act = FusedPoolBnSign(bn, pool)(x)
+            xin = pool(x) if pool is not None else x
+            alpha, beta = (1.0 / torch.sqrt(bn.running_var + bn.eps)) * bn.weight, None
+            beta = bn.bias - bn.running_mean * alpha
+            t = xin * alpha.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)                 # the folded expression
+            want = ops.sign_pack(ops.binarize(t).permute(0, 2, 3, 1).contiguous())[0]
+        assert act.shape == tuple(xin.shape)
+        assert torch.equal(act.planes.sign, want.sign)
+        # and against torch's own eval BatchNorm + Hardtanh + sign: identical except (rarely) at a threshold
+        with torch.no_grad():
+            ref = torch.nn.functional.hardtanh(bn(xin))
+            ref_bits = ops.sign_pack(ops.binarize(ref).permute(0, 2, 3, 1).contiguous())[0].sign
+        diff = (act.planes.sign ^ ref_bits)
+        flips = sum(bin(int(v) & 0xFFFFFFFF).count("1") for v in diff.flatten().tolist() if v)
+        assert flips <= max(2, int(1e-5 * xin.numel())), flips
+
+
+def test_fused_alexnet_matches_unfused(dev):
+    import bench_models
+    torch.manual_seed(9)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    fused = bench_models.FusedAlexNetBin(model)
+    x = torch.randn((4, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc", "qt_nib_gemm", "qt_im2col_words"):
+        yf = fused(x)
+        yu = model(x)
+    assert yf.shape == yu.shape == (4, 10)
+    # logits are log-softmax of integer sums: identical unless a BN threshold tie flipped a bit upstream
+    assert norm_err(n(yf), n(yu)) <= 1e-3
+    assert torch.equal(yf.argmax(1), yu.argmax(1))
