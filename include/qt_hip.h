@@ -202,6 +202,26 @@ int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t 
                                   int64_t pool_k, int64_t pool_s, const float* alpha, const float* beta,
                                   uint32_t* sign_plane, int64_t ldp, qt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Real-valued activation x quantised weight (first layer of every model, XNOR-Net layers, the general
+ * case of LinearBin/LinearTer/BinConv2d/TerConv2d.forward: layers/binary_layers.py:44,105 with an
+ * arbitrary fp32 input).  fp32 activations are split EXACTLY into bf16 triples (x = hi + mid + lo) and
+ * contracted with +-1/0 bf16 weights (replicated x3) on the bf16 matrix cores: fp32-GEMM accuracy
+ * (only the fp32 accumulation order differs) at 1/3 of the bf16 MFMA rate instead of the fp32 rate.
+ * ---------------------------------------------------------------------------------------- */
+
+/* mode 0: activation triples of x (times alpha[k] if alpha != NULL: XNORDense's per-input-feature scale,
+ * functions/xnor_connect.py:112-113); mode 1/2/3: weight triples of safeSign(x) / TernaryConnect(x) /
+ * torch.sign(x).  out: bf16 [rows][ld_bytes/2], element 3k+s = term s of element k; ld_bytes % 16 == 0,
+ * ld_bytes >= 6*K, pad zero. */
+int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out, int64_t ld_bytes,
+                       int64_t rows, int64_t K, int mode, qt_stream_t stream);
+
+/* Y[M,N] = Xh . Wh^T (+ bias) over K bf16 elements per row (K = 3 * features for triple planes);
+ * ld in uint32 words. */
+int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,
+                 float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
+
 /* nibble plane from existing bit planes (sign only: mask_plane == NULL; ternary: mask + sign).
  * 1 bit -> 4 bits per element; lets the canonical 1-bit planes (what the quantisers emit and what
  * eval-mode layers cache) feed the matrix-core GEMM without re-reading the fp32 tensor. */

@@ -97,6 +97,23 @@ struct ElemI8 {
     __device__ __forceinline__ static float out(int v, float scale, float bias) { return (float)v * scale + bias; }
 };
 
+// bf16 operands (the "real-valued activation x quantised weight" path): fp32 activations are split
+// EXACTLY into three bf16 terms (x = hi + mid + lo: 3 x 8 significand bits) laid out as consecutive
+// triples, weights are +-1/0 replicated three times; v_mfma_f32_32x32x16_bf16 forms exact products and
+// accumulates in fp32, so the result has fp32-GEMM accuracy at the bf16 matrix rate / 3.
+struct ElemBf16 {
+    using acc_t = v16f;
+    __device__ __forceinline__ static int kbytes(int K) { return 2 * K; }
+    __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
+        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+        bf8 av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    }
+    __device__ __forceinline__ static float out(float v, float scale, float bias) { return v + bias; }
+};
+
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
 //   4 = no LDS fragment reads.
@@ -546,6 +563,13 @@ int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uin
 int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,
                 float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream) {
     return qt_nib_gemm_variant(0, Xn, ldxp, Wn, ldwp, bias, Y, ldy, M, N, K, stream);
+}
+
+int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,
+                 float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream) {
+    const int rc = check_common(Xh, ldxp, Wh, ldwp, Y, ldy, M, N, K, (K + 1) / 2);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    return dispatch_gemm<ElemBf16>(0, Xh, ldxp, Wh, ldwp, bias, 1.0f, nullptr, Y, ldy, M, N, K, stream);
 }
 
 int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,

@@ -44,6 +44,11 @@ def quantize_weight_f32(weight: torch.Tensor, kind: str) -> torch.Tensor:
     raise ValueError(f"unknown quantiser kind {kind!r}")
 
 
+#: How a REAL-valued device activation meets a quantised weight: "bf16x3" = exact bf16 triple split +
+#: bf16 MFMA GEMM in libqt_hip.so (fp32-GEMM accuracy); "library" = dense fp32 GEMM / conv library on
+#: the HIP-quantised weight image (the reference computation itself).
+FLOAT_PATH = "bf16x3"
+
 #: 'auto' | 'valu' | 'mfma' — packed-GEMM formulation used by the layers (both are bit-exact;
 #: 'auto' picks by shape, see ops.select_gemm_impl).
 GEMM_IMPL = "auto"
@@ -104,6 +109,11 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
         y = ops.packed_gemm(xp, wp, bias, impl=impl)
         return y.view(*input.shape[:-1], N)
 
+    if FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+        # the quantisers are idempotent, so an explicit quantised image (eval / stochastic) goes through
+        # the same weight packer
+        return ops.float_linear(input, weight_q if weight_q is not None else weight, kind, bias,
+                                weight_triples=weight_planes if isinstance(weight_planes, ops.TriplePlanes) else None)
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
     return F.linear(input, wq, bias)
 
@@ -129,7 +139,8 @@ def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool]):
 
 def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
                          weight_q: Optional[torch.Tensor] = None, weight_planes=None,
-                         binary_input: Optional[bool] = None, padding_mode: str = "zeros") -> torch.Tensor:
+                         binary_input: Optional[bool] = None, padding_mode: str = "zeros",
+                         weight_triples_fn=None) -> torch.Tensor:
     """conv2d(input, Q(weight), bias, ...).
 
     Device tensor with +-1 activations, groups == 1, zero padding: NHWC pixel planes -> packed-domain
@@ -143,7 +154,7 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
         px = _pixel_planes(input, binary_input)
         if px is not None:
             wq = weight_q if weight_q is not None else weight
-            wp = weight_planes if weight_planes is not None else ops.pack_conv_weight_nib(wq, kind)
+            wp = weight_planes if isinstance(weight_planes, ops.NibPlanes) else ops.pack_conv_weight_nib(wq, kind)
             N, C, H, W = input.shape
             kh, kw = int(weight.shape[2]), int(weight.shape[3])
             y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), bias, stride, padding, dilation)

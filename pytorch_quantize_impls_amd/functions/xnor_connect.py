@@ -74,6 +74,12 @@ def XNORDense(dim=[0, 1]):
     class _XNORDense(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
+            if input.is_cuda and input.dtype == torch.float32 and weight.dim() == 2 and input.numel() > 0:
+                # alpha on the device (qt_xnor_weight_f32), folded into the activation split; sign(W) on
+                # the bf16 matrix cores: fl(x*alpha) * (+-1) is the product fl(x * (+-alpha)) exactly
+                _, mean = ops.xnor_weight(weight.detach(), 1)
+                ctx.save_for_backward(input, weight, mean, bias)
+                return ops.float_linear(input, weight.detach(), "sign", bias, alpha=mean.view(-1))
             weight_q, mean = xnor_weight(weight, DIM)
             ctx.save_for_backward(input, weight, mean, bias)
             return torch.nn.functional.linear(input, weight_q, bias)

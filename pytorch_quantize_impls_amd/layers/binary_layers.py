@@ -67,6 +67,9 @@ def _eval_linear(layer, input, kind):
     impl = _fused.ops.select_gemm_impl(_fused.GEMM_IMPL, input.numel() // max(K, 1), N, K)
     xp = _fused.activation_planes(input, layer.binary_input, impl)
     if xp is None:
+        if _fused.FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+            wt = layer._eval_planes(lambda w2: _fused.ops.weight_bf16x3(w2, kind), key="bf16x3")
+            return _fused.ops.float_linear(input, layer.weight, kind, layer.bias, weight_triples=wt)
         return torch.nn.functional.linear(input, layer.weight, layer.bias)
     wp = layer._eval_planes(lambda w2: _fused.pack_weight(w2, kind, impl), key=impl)
     y = _fused.ops.packed_gemm(xp, wp, layer.bias, impl=impl)
@@ -122,7 +125,10 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                    key="conv_nib")
         return _fused.quant_conv2d_forward(input, self.weight, self.bias, *args, "binary",
                                            weight_q=self.weight, weight_planes=wp,
-                                           binary_input=self.binary_input, padding_mode=self.padding_mode)
+                                           binary_input=self.binary_input, padding_mode=self.padding_mode,
+                                           weight_triples_fn=lambda: self._eval_planes(
+                                               lambda _w2: _fused.ops.pack_conv_weight_bf16x3(self.weight.detach(), "binary"),
+                                               key="conv_bf16x3"))
 
 
 class ShiftNormBatch1d(torch.nn.Module):

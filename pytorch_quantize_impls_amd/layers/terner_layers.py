@@ -103,4 +103,7 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                    key="conv_nib")
         return _fused.quant_conv2d_forward(input, self.weight, self.bias, *args, "ternary",
                                            weight_q=self.weight, weight_planes=wp,
-                                           binary_input=self.binary_input, padding_mode=self.padding_mode)
+                                           binary_input=self.binary_input, padding_mode=self.padding_mode,
+                                           weight_triples_fn=lambda: self._eval_planes(
+                                               lambda _w2: _fused.ops.pack_conv_weight_bf16x3(self.weight.detach(), "ternary"),
+                                               key="conv_bf16x3"))

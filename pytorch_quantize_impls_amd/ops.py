@@ -598,6 +598,139 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
 
 
 # ----------------------------------------------------------------------------------------------
+# real-valued activation x quantised weight: exact bf16 triples + bf16 MFMA GEMM
+# ----------------------------------------------------------------------------------------------
+
+_TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3}
+
+
+def triple_ld_bytes(K: int, granule: int = 128) -> int:
+    """Row stride in bytes of a bf16 triple plane holding K features (6 bytes each)."""
+    return max(granule, (6 * int(K) + granule - 1) // granule * granule)
+
+
+@dataclass
+class TriplePlanes:
+    """bf16 triple image of a [rows, K] fp32 matrix: int16 tensor [rows, ld_bytes/2]; element 3k+s is
+    term s of x[k] = hi + mid + lo (activations) or the quantised weight value replicated (weights)."""
+    data: torch.Tensor
+    rows: int
+    K: int
+
+    @property
+    def ld_words(self) -> int:
+        return int(self.data.shape[1]) // 2
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_bytes: Optional[int]) -> TriplePlanes:
+    _require(x, "input")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = triple_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
+    out = torch.empty((rows, ld // 2), dtype=torch.int16, device=x.device)
+    if alpha is not None:
+        alpha = _require(alpha, "alpha").contiguous().view(-1)
+        if alpha.numel() != K:
+            raise ValueError("alpha must have one entry per input feature")
+    with torch.cuda.device(x.device):
+        _lib.call("qt_bf16x3_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(alpha), _p(out), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
+                  ctypes.c_int(mode), _stream(x.device))
+    return TriplePlanes(data=out, rows=rows, K=K)
+
+
+def split_bf16x3(x: torch.Tensor, alpha: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None) -> TriplePlanes:
+    """Exact hi/mid/lo bf16 split of an fp32 activation (optionally of x * alpha[k])."""
+    return _triple_pack(x, 0, alpha, ld_bytes)
+
+
+def weight_bf16x3(w2d: torch.Tensor, kind: str, ld_bytes: Optional[int] = None) -> TriplePlanes:
+    """bf16 triples of the quantised weight: kind 'binary' (safeSign), 'ternary', 'sign' (torch.sign)."""
+    return _triple_pack(w2d, _TRIPLE_MODES[kind], None, ld_bytes)
+
+
+def bf16_gemm(x: TriplePlanes, w: TriplePlanes, bias: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.K != w.K:
+        raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
+    M, N = x.rows, w.rows
+    dev = x.device
+    bias = _check_bias(bias, N, dev)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("qt_bf16_gemm", _p(x.data), ctypes.c_int64(x.ld_words), _p(w.data), ctypes.c_int64(w.ld_words),
+                  _p(bias), _p(out), ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M),
+                  ctypes.c_int64(N), ctypes.c_int64(3 * x.K), _stream(dev))
+    return out
+
+
+def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, alpha=None,
+                 weight_triples: Optional[TriplePlanes] = None) -> torch.Tensor:
+    """y = x . Q(weight)^T (+ bias) for REAL-valued x: Q in {safeSign, ternary, torch.sign}; ``alpha``
+    (per input feature) multiplies x first (XNORDense).  fp32-GEMM accuracy on the bf16 matrix cores."""
+    N = weight.shape[0]
+    wt = weight_triples if weight_triples is not None else weight_bf16x3(weight.reshape(N, -1), kind)
+    y = bf16_gemm(split_bf16x3(x, alpha), wt, bias)
+    return y.view(*x.shape[:-1], N)
+
+
+def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str) -> TriplePlanes:
+    """[Cout, Cin, kh, kw] -> triple plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 6*Cin bytes rounded to 16)."""
+    _require(weight, "weight")
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    Cb = triple_ld_bytes(Cin, 16)
+    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
+    taps = weight_bf16x3(wt, kind, ld_bytes=Cb)
+    kbytes = kh * kw * Cb
+    ld = max(128, (kbytes + 127) // 128 * 128)
+    data = taps.data.view(Cout, kbytes // 2)
+    if ld != kbytes:
+        padded = torch.zeros((Cout, ld // 2), dtype=torch.int16, device=weight.device)
+        padded[:, :kbytes // 2] = data
+        data = padded
+    return TriplePlanes(data=data, rows=Cout, K=kbytes // 6)   # K only used for consistency checks
+
+
+def float_conv2d(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0, dilation=1,
+                 weight_triples: Optional[TriplePlanes] = None) -> torch.Tensor:
+    """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
+    packed-domain im2col (zero words for padding taps) -> bf16 MFMA GEMM.  Returns NHWC [N*Ho*Wo, Cout]."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    Cout, _, kh, kw = (int(v) for v in weight.shape)
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    nhwc = x.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    Cb = triple_ld_bytes(C, 16)
+    px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb)
+    wt = weight_triples if weight_triples is not None else pack_conv_weight_bf16x3(weight, kind)
+    Cw, ldA = Cb // 4, wt.ld_words
+    M = N * Ho * Wo
+    dev = x.device
+    bias = _check_bias(bias, Cout, dev)
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+    rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
+    A = torch.empty((rows_per_chunk, ldA * 2), dtype=torch.int16, device=dev)
+    I = ctypes.c_int64
+    kel = kh * kw * Cb // 2     # bf16 elements per im2col row actually carrying taps
+    for m0 in range(0, M, rows_per_chunk):
+        cnt = min(rows_per_chunk, M - m0)
+        with torch.cuda.device(dev):
+            _lib.call("qt_im2col_words", _p(px.data), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw),
+                      I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
+            _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
+                      I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
 # formulation-agnostic front (bench.py and the layers go through this)
 # ----------------------------------------------------------------------------------------------
 

@@ -671,3 +671,55 @@ def test_fused_alexnet_matches_unfused(dev):
     # logits are log-softmax of integer sums: identical unless a BN threshold tie flipped a bit upstream
     assert norm_err(n(yf), n(yu)) <= 1e-3
     assert torch.equal(yf.argmax(1), yu.argmax(1))
+
+
+# ---- real-valued activations: exact bf16 triple split + bf16 MFMA GEMM -----------------------------------------
+
+def test_bf16x3_split_is_exact(dev):
+    x = np.concatenate([synth.normal(1, (5000,)) * 3, synth.uniform(2, (5000,), -1e-3, 1e-3),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.14159274, 1e-20, -1e20, 65504.0, 1.0000001], np.float32)])
+    x = x.reshape(1, -1).astype(np.float32)
+    with used("qt_bf16x3_pack_f32"):
+        tp = ops.split_bf16x3(g(x, dev))
+    raw = n(tp.data).view(np.uint16)[0, :3 * x.shape[1]].astype(np.uint32) << 16
+    terms = raw.view(np.float32).reshape(-1, 3).astype(np.float64)
+    assert np.array_equal(terms.sum(1).astype(np.float32), x[0])                 # hi + mid + lo == x exactly
+    assert not n(tp.data)[0, 3 * x.shape[1]:].any()                                  # zero pad
+    w = synth.uniform(3, (4, 37), -1.5, 1.5)
+    w[0, 0] = 0.0
+    for kind, q in (("binary", np.where(w < 0, -1.0, 1.0)), ("sign", np.sign(w)),
+                    ("ternary", np.where(w >= 0.5, 1.0, np.where(w < -0.5, -1.0, 0.0)))):
+        wt = ops.weight_bf16x3(g(w, dev), kind)
+        vals = (n(wt.data).view(np.uint16)[:, :3 * 37].astype(np.uint32) << 16).view(np.float32).reshape(4, 37, 3)
+        assert np.array_equal(vals, np.repeat(q[:, :, None], 3, 2).astype(np.float32)), kind
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 7, 31), (130, 70, 363), (300, 260, 1000), (257, 129, 4096), (1024, 1024, 784)])
+def test_float_linear_bf16x3_vs_fp64(dev, M, N, K):
+    x = synth.normal(M + K, (M, K)) * 2.0
+    w = synth.uniform(N + K, (N, K), -1.5, 1.5)
+    b = synth.normal(N, (N,))
+    alpha = np.abs(synth.normal(K, (K,))) + 0.1
+    for kind, q in (("binary", np.where(w < 0, -1.0, 1.0)), ("ternary", np.where(w >= 0.5, 1.0, np.where(w < -0.5, -1.0, 0.0)))):
+        with used("qt_bf16x3_pack_f32", "qt_bf16_gemm"):
+            y = n(ops.float_linear(g(x, dev), g(w, dev), kind, g(b, dev)))
+        ref = x.astype(np.float64) @ q.T + b
+        assert norm_err(y, ref) <= 1e-6, kind                       # fp32-GEMM class accuracy
+    ya = n(ops.float_linear(g(x, dev), g(w, dev), "sign", None, alpha=g(alpha, dev)))
+    refa = (x * alpha[None, :]).astype(np.float32).astype(np.float64) @ np.sign(w).T
+    assert norm_err(ya, refa) <= 1e-6
+
+
+def test_float_conv_bf16x3_vs_fp64(dev):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(21)
+    for (Cin, Cout, k, st, pd, H) in [(3, 192, 11, 4, 2, 224), (3, 64, 3, 1, 1, 32), (20, 9, 5, 2, 2, 17)]:
+        x = torch.randn((2, Cin, H, H), device=dev, generator=gen)
+        w = torch.randn((Cout, Cin, k, k), device=dev, generator=gen)
+        b = torch.randn((Cout,), device=dev, generator=gen)
+        with used("qt_bf16x3_pack_f32", "qt_im2col_words", "qt_bf16_gemm"):
+            y2 = ops.float_conv2d(x, w, "binary", b, st, pd)
+        Ho = (H + 2 * pd - k) // st + 1
+        y = y2.view(2, Ho, Ho, Cout).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x.double(), ops.binarize(w).double(), b.double(), st, pd)
+        assert norm_err(n(y), n(ref)) <= 1e-6
