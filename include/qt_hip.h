@@ -242,6 +242,17 @@ int qt_im2col_words(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t 
                     int64_t dw, uint32_t* A, int64_t ldA, int64_t m_begin, int64_t m_count,
                     qt_stream_t stream);
 
+/* Implicit-GEMM form of the same conv: no im2col matrix is materialised — the GEMM kernel's LDS-DMA
+ * gathers 16-byte pixel chunks straight from the NHWC plane P (zero page for padding taps).
+ * elem: 0 = fp4 nibble planes (scale ignored), 1 = int8 code planes (Y = scale * (*scale_dev) * acc),
+ * 2 = bf16 triple planes.  Wmat: [Cout][ldwp] words, row = kh*kw taps x Cw words, ldwp % 32 == 0.
+ * Y: NHWC [N*Ho*Wo][ldy] fp32. */
+int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                       int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                       int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias,
+                       float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t Cout,
+                       qt_stream_t stream);
+
 /* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration.
  * 0 = automatic (what qt_nib_gemm does: tile width 256/128/64 by N; the pipelined asm-DMA kernel
  * when row strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);

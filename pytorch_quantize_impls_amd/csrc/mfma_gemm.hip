@@ -73,6 +73,26 @@ __device__ __forceinline__ void glds16_asm(const unsigned char* sbase, unsigned 
         : "memory");
 }
 
+// Same, with a full 64-bit per-lane source address (implicit-GEMM conv: the source of a chunk is a
+// pixel of the NHWC plane or the zero page, so there is no common base).
+__device__ __forceinline__ void glds16_asm64(const unsigned char* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_dst)
+        : "memory");
+}
+
+// Implicit-GEMM conv: the X operand is not a matrix but the NHWC pixel plane P[N][H][W][cpp*16 bytes];
+// row m = (n, ho, wo), K byte index = ((i*kw + j)*cpp + sub)*16 + byte: chunk q of a row is 16 bytes of
+// pixel (ho*sh - ph + i*dh, wo*sw - pw + j*dw) or zeros when that pixel is padding / q is past the taps.
+struct ConvArgs {
+    int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+    int cpp;                       // 16-byte chunks per pixel
+    unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
+};
+
 // ---- element types ----------------------------------------------------------------------------------
 struct ElemFp4 {
     using acc_t = v16f;
@@ -117,9 +137,10 @@ struct ElemBf16 {
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
 //   4 = no LDS fragment reads.
-template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128>
+template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, bool CONV_ = false>
 struct GemmCfg {
     using E = E_;
+    static constexpr bool CONV = CONV_;
     static constexpr int WM = WM_, WN = WN_, TMW = TMW_, TNW = TNW_, PIPE = PIPE_, ABL = ABL_;
     static constexpr int STAGE_BYTES = SB_, KK = SB_ / 32;
     static constexpr int ROWS_PER_PIECE = 1024 / SB_;   // one DMA piece = 1 KiB of LDS
@@ -138,7 +159,7 @@ template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kernel(
     const uint32_t* __restrict__ X, int64_t ldx, const uint32_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, float scale, const float* __restrict__ scale_dev,
-    float* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    float* __restrict__ Y, int64_t ldy, int M, int N, int K, ConvArgs cg) {
     using E = typename C::E;
     using acc_t = typename E::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [buf][X stage | W stage]
@@ -210,21 +231,58 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         // row: products of out-of-range rows are never stored).  Lane i lands on LDS position p of
         // its row, so it fetches the logical chunk swz(row, p) (the swizzle is an involution).
         unsigned voffx[XP], voffw[WP];
+        // implicit conv: per piece the output pixel's top-left input coordinate and its pixel index;
+        // the lane's logical chunk c within a stage is the same for all its pieces.
+        int ch0[C::CONV ? XP : 1], cw0[C::CONV ? XP : 1];
+        long long cpix[C::CONV ? XP : 1];
+        const int lchunk = swz<STAGE_BYTES>(uwave * RPP + rsub, p);   // rows of a lane's pieces differ by multiples of 64
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
             const int row = (j * C::NWAVES + uwave) * RPP + rsub;
-            voffx[j] = (unsigned)(min(m0 + row, M - 1) * ldx_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
+            if constexpr (C::CONV) {
+                const int m = min(m0 + row, M - 1);
+                const int hw = cg.Ho * cg.Wo;
+                const int n = m / hw, rem = m - n * hw;
+                const int ho = rem / cg.Wo, wo = rem - ho * cg.Wo;
+                ch0[j] = ho * cg.sh - cg.ph;
+                cw0[j] = wo * cg.sw - cg.pw;
+                cpix[j] = ((long long)n * cg.H + ch0[j]) * cg.W + cw0[j];
+                voffx[j] = 0;
+            } else {
+                voffx[j] = (unsigned)(min(m0 + row, M - 1) * ldx_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
+            }
         }
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
             const int row = (j * C::NWAVES + uwave) * RPP + rsub;
             voffw[j] = (unsigned)(min(n0 + row, N - 1) * ldw_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
         }
+        // implicit conv: tap coordinates of this lane's chunk in stage s (shared by all its X pieces)
+        int tap_i = 0, tap_j = 0, tap_sub = 0;
+        bool tap_ok = false;
+        auto conv_stage = [&](int s) {
+            const unsigned q = (unsigned)(s * CH + lchunk);
+            const unsigned tap = cg.cpp == 1 ? q : __umulhi(q, cg.magic_cpp);
+            tap_sub = (int)(q - tap * cg.cpp);
+            const unsigned ti = cg.kw == 1 ? tap : __umulhi(tap, cg.magic_kw);
+            tap_i = (int)ti;
+            tap_j = (int)(tap - ti * cg.kw);
+            tap_ok = tap_i < cg.kh;
+        };
         auto issue_piece = [&](int j, int s, int buf) {  // j is a compile-time constant after unrolling
             const unsigned ldsbuf = lds0 + buf * BUF;
             if (j < XP) {
                 const unsigned dst = ldsbuf + ((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
-                glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], __builtin_amdgcn_readfirstlane(dst));
+                if constexpr (C::CONV) {
+                    const int jj = j < XP ? j : 0;
+                    const int hi = ch0[jj] + tap_i * cg.dh, wi = cw0[jj] + tap_j * cg.dw;
+                    const bool ok = tap_ok && hi >= 0 && hi < cg.H && wi >= 0 && wi < cg.W;
+                    const long long pix = cpix[jj] + (long long)tap_i * cg.dh * cg.W + tap_j * cg.dw;
+                    const unsigned char* src = ok ? Xb + (pix * cg.cpp + tap_sub) * 16 : zero16_storage;
+                    glds16_asm64(src, __builtin_amdgcn_readfirstlane(dst));
+                } else {
+                    glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], __builtin_amdgcn_readfirstlane(dst));
+                }
             } else {
                 const int jw = j - XP;
                 const unsigned dst = ldsbuf + C::X_STAGE + ((jw * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
@@ -233,6 +291,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             }
         };
         if (nstages > 0) {
+            if constexpr (C::CONV) conv_stage(0);
 #pragma unroll
             for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0);
         }
@@ -252,6 +311,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 for (int b = 0; b < C::TNW; ++b) wfA[b] = wfB[b] = make_uint4(0xa2a2a2a2u, 0x2a2a2a2au, lane, s);
             }
             if constexpr (C::ABL != 4) read_frags(xs, ws, 0, xfA, wfA);
+            if constexpr (C::CONV && more) conv_stage(s + 1);
 #pragma unroll
             for (int kk = 0; kk < KK; kk += 2) {
                 // DMA pieces are spread over the k-steps; fragments of step kk+1 are requested before
@@ -350,7 +410,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 template <class C>
 int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,
                float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
-               qt_stream_t stream) {
+               qt_stream_t stream, const ConvArgs& cg = ConvArgs{}) {
     const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
     if (gy > 65535) return QT_ERR_UNSUPPORTED;
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
@@ -359,7 +419,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
         return QT_ERR_LAUNCH;
     hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3((unsigned)gx, (unsigned)gy), dim3(C::NTHREADS),
                        C::LDS_BYTES, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
-                       (int)M, (int)N, (int)K);
+                       (int)M, (int)N, (int)K, cg);
     return qt_check_launch();
 }
 
@@ -374,6 +434,11 @@ template <class E, int PIPE> using Cfg2x = GemmCfg<E, 2, 2, 4, 2, PIPE, 0, 64>; 
 // 0.5 KiB of LDS fragment traffic per MFMA instead of 0.75), everything overlapped inside the wave.
 template <class E, int PIPE> using Cfg1w = GemmCfg<E, 2, 2, 4, 4, PIPE>;
 template <class E, int PIPE> using Cfg2z = GemmCfg<E, 2, 4, 4, 2, PIPE, 0, 64>;      // 8 waves 256x256, 64-B stages (64 KiB: 2/CU by LDS, VGPR-limited)
+
+// implicit-conv configurations (pipelined kernel only)
+template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
+template <class E> using Conv128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, true>;
+template <class E> using Conv64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, true>;
 
 int check_common(const void* Xn, int64_t ldxp, const void* Wn, int64_t ldwp, const float* Y, int64_t ldy,
                  int64_t M, int64_t N, int64_t K, int64_t kwords) {
@@ -581,6 +646,44 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     // the epilogue is exact (weights are +-1/0 codes)
     if (max_abs_code < 0 || max_abs_code > 127 || max_abs_code * K >= (1ll << 24)) return QT_ERR_UNSUPPORTED;
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
+}
+
+// elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes
+int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                       int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                       int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                       const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream) {
+    if (Nimg < 0 || H <= 0 || W <= 0 || Cw <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 ||
+        dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 2)
+        return QT_ERR_INVALID_ARG;
+    const int64_t Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+    if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
+    const int64_t M = Nimg * Ho * Wo;
+    if (M == 0 || Cout == 0) return QT_OK;
+    if (!P || !Wmat || !Y || ldy < Cout) return QT_ERR_INVALID_ARG;
+    const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
+    if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
+    if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767)
+        return QT_ERR_UNSUPPORTED;
+    const int64_t kbytes = kwords * 4;
+    const int64_t K = elem == 0 ? kbytes * 2 : (elem == 1 ? kbytes : kbytes / 2);   // elements
+    if (elem == 0 && K >= (1 << 24)) return QT_ERR_UNSUPPORTED;
+    ConvArgs cg;
+    cg.H = (int)H; cg.W = (int)W; cg.Ho = (int)Ho; cg.Wo = (int)Wo; cg.kh = (int)kh; cg.kw = (int)kw;
+    cg.sh = (int)sh; cg.sw = (int)sw; cg.ph = (int)ph; cg.pw = (int)pw; cg.dh = (int)dh; cg.dw = (int)dw;
+    cg.cpp = (int)(Cw / 4);
+    cg.magic_cpp = cg.cpp > 1 ? (unsigned)((1ull << 32) / (unsigned)cg.cpp + 1) : 0;
+    cg.magic_kw = kw > 1 ? (unsigned)((1ull << 32) / (unsigned)kw + 1) : 0;
+#define QT_CONV(E)                                                                                              \
+    do {                                                                                                        \
+        if (Cout > 160) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
+        if (Cout > 80) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg);  \
+        return launch_cfg<Conv64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg);                 \
+    } while (0)
+    if (elem == 0) QT_CONV(ElemFp4);
+    if (elem == 1) QT_CONV(ElemI8);
+    QT_CONV(ElemBf16);
+#undef QT_CONV
 }
 
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,

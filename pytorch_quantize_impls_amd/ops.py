@@ -20,6 +20,31 @@ STE_THRESHOLD = 1.001  # functions/binary_connect.py:37, terner_connect.py:33
 #: upper bound on the bytes of the temporary im2col matrix (the batch is processed in chunks)
 IM2COL_MAX_BYTES = 1 << 30
 
+#: True: quantised convs run as an implicit GEMM (the LDS-DMA gathers pixel chunks from the NHWC plane,
+#: nothing is materialised).  False: explicit packed-domain im2col + GEMM (kept for A/B and as a fallback).
+CONV_IMPLICIT = True
+
+
+def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
+                   ldw_words: int, bias, scale: float, scale_dev, Cout: int) -> Optional[torch.Tensor]:
+    """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back)."""
+    (sh, sw), (ph, pw), (dh, dw) = geom
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    M = N * Ho * Wo
+    if M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32:
+        return None
+    dev = pixels_words.device
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+    I = ctypes.c_int64
+    with torch.cuda.device(dev):
+        _lib.call("qt_conv2d_implicit", ctypes.c_int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw),
+                  I(sh), I(sw), I(ph), I(pw), I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias),
+                  ctypes.c_float(float(scale)),
+                  _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None),
+                  _p(y), I(Cout), I(Cout), _stream(dev))
+    return y
+
 
 def _p(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
@@ -506,6 +531,11 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
+    if CONV_IMPLICIT and 127 * kh * kw * Cw * 4 < (1 << 24):
+        y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
+                           ldA, bias, scale, scale_dev, Cout)
+        if y is not None:
+            return y
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 4), dtype=torch.int8, device=dev)
@@ -584,6 +614,11 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
+    if CONV_IMPLICIT:
+        y = _conv_implicit(0, pixels.words, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.words,
+                           ldA, bias, 1.0, None, Cout)
+        if y is not None:
+            return y
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA), dtype=torch.int32, device=dev)
@@ -715,6 +750,11 @@ def float_conv2d(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, st
     M = N * Ho * Wo
     dev = x.device
     bias = _check_bias(bias, Cout, dev)
+    if CONV_IMPLICIT:
+        y = _conv_implicit(2, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
+                           1.0, None, Cout)
+        if y is not None:
+            return y
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 2), dtype=torch.int16, device=dev)

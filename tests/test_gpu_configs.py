@@ -44,12 +44,12 @@ def test_c5_ternary_vgg_conv(dev, Cin, Cout, H, B):
     conv = TerConv2d(Cin, Cout, 3, padding=1).to(dev)
     conv.weight.data.copy_(torch.randn(conv.weight.shape, device=dev, generator=g) * 0.8)
     conv.bias.data.zero_()
-    before = _lib.call_counts["qt_nib_gemm"]
+    before = _lib.call_counts["qt_conv2d_implicit"]
     with torch.no_grad():
         xs = BinaryConnectDeterministic.apply(x)
         y = conv(xs)
         ref = F.conv2d(xs, ops.ternarize(conv.weight.detach()), None, padding=1)
-    assert _lib.call_counts["qt_nib_gemm"] > before
+    assert _lib.call_counts["qt_conv2d_implicit"] > before
     assert torch.equal(y, ref)
     assert y.is_contiguous(memory_format=torch.channels_last)
 
@@ -80,13 +80,13 @@ def test_c4_dorefa_resnet_conv(dev, Cin, Cout, k, stride, H):
     x = (torch.randn((B, Cin, H, H), device=dev, generator=g) * 0.7).contiguous(memory_format=torch.channels_last)
     conv = DorefaConv2d(Cin, Cout, k, stride=stride, padding=k // 2, bias=False, bit_width=1).to(dev)
     conv.weight.data.copy_(torch.randn(conv.weight.shape, device=dev, generator=g) * 0.1)
-    before = _lib.call_counts["qt_i8_gemm"]
+    before = _lib.call_counts["qt_conv2d_implicit"]
     with torch.no_grad():
         xq = nnDorefaQuant(4)(torch.relu(x))          # unclamped relu(bn(x)) stand-in, as ResNet_Dorefa.py:26,35
         y = conv(xq)
         wq = ops.binarize(conv.weight.detach()) * conv.weight.detach().abs().mean()
         ref = F.conv2d(xq.double(), wq.double(), None, stride=stride, padding=k // 2)
-    assert _lib.call_counts["qt_i8_gemm"] > before
+    assert _lib.call_counts["qt_conv2d_implicit"] > before
     assert _nerr(y, ref) <= TOL
     # integer core: divide the scale back out and compare codes exactly
     scale = float(conv.weight.detach().abs().mean()) / 15.0
