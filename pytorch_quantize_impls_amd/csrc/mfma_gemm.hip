@@ -427,6 +427,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
 template <class E, int PIPE, int ABL = 0> using Cfg256 = GemmCfg<E, 2, 4, 4, 2, PIPE, ABL>;
 template <class E, int PIPE> using Cfg128 = GemmCfg<E, 2, 4, 4, 1, PIPE>;
 template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
+template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 256x192 (wave 64x96): N = 576, 1152, ...
 // 4-wave workgroups with 64-byte stages: 48 KiB of LDS, <= 256 VGPRs -> TWO independent workgroups per
 // CU (different barrier domains fill each other's fill/drain bubbles and epilogues).
 template <class E, int PIPE> using Cfg2x = GemmCfg<E, 2, 2, 4, 2, PIPE, 0, 64>;      // 256x128 tile
@@ -439,6 +440,19 @@ template <class E, int PIPE> using Cfg2z = GemmCfg<E, 2, 4, 4, 2, PIPE, 0, 64>; 
 template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
 template <class E> using Conv128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, true>;
 template <class E> using Conv64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, true>;
+template <class E> using Conv192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, true>;
+
+// tile width (256 / 192 / 128 / 64) that wastes the fewest padded columns; ties go to the wider tile
+int pick_tile_n(int64_t N) {
+    int best = 256;
+    int64_t best_pad = (N + 255) / 256 * 256;
+    const int cands[3] = {192, 128, 64};
+    for (int c : cands) {
+        const int64_t pad = (N + c - 1) / c * c;
+        if (pad < best_pad) { best = c; best_pad = pad; }
+    }
+    return best;
+}
 
 int check_common(const void* Xn, int64_t ldxp, const void* Wn, int64_t ldwp, const float* Y, int64_t ldy,
                  int64_t M, int64_t N, int64_t K, int64_t kwords) {
@@ -461,15 +475,21 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
                          N * ldwp * 4 < (1ll << 31);
 #define QT_GO(...) return launch_cfg<__VA_ARGS__>(Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream)
     switch (variant) {
-        case 0:  // automatic: tile width by N, fast path when its contract holds
+        case 0: {  // automatic: tile width by N, fast path when its contract holds
+            const int tn = pick_tile_n(N);
             if (pipe_ok) {
-                if (N > 160) QT_GO(Cfg256<E, 1>);
-                if (N > 80) QT_GO(Cfg128<E, 1>);
+                if (tn == 256) QT_GO(Cfg256<E, 1>);
+                if (tn == 192) QT_GO(Cfg192<E, 1>);
+                if (tn == 128) QT_GO(Cfg128<E, 1>);
                 QT_GO(Cfg64<E, 1>);
             }
-            if (N > 160) QT_GO(Cfg256<E, 0>);
-            if (N > 80) QT_GO(Cfg128<E, 0>);
+            if (tn == 256) QT_GO(Cfg256<E, 0>);
+            if (tn == 192) QT_GO(Cfg192<E, 0>);
+            if (tn == 128) QT_GO(Cfg128<E, 0>);
             QT_GO(Cfg64<E, 0>);
+        }
+        case 15: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg192<E, 1>);
+        case 16: QT_GO(Cfg192<E, 0>);
         case 5: QT_GO(Cfg256<E, 0>);
         case 6: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1>);
         case 7: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg128<E, 1>);
@@ -676,8 +696,10 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int
     cg.magic_kw = kw > 1 ? (unsigned)((1ull << 32) / (unsigned)kw + 1) : 0;
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
-        if (Cout > 160) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
-        if (Cout > 80) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg);  \
+        const int tn = pick_tile_n(Cout);                                                                       \
+        if (tn == 256) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
+        if (tn == 192) return launch_cfg<Conv192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
+        if (tn == 128) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
         return launch_cfg<Conv64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg);                 \
     } while (0)
     if (elem == 0) QT_CONV(ElemFp4);

@@ -163,6 +163,18 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous()                                         # caller works in NCHW storage
             return y
+    if packable and FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+        # real-valued activation (first layer): exact bf16 triples + implicit-GEMM conv on the bf16
+        # matrix cores; the quantisers are idempotent so an explicit quantised image is packed the same way
+        wt = weight_triples_fn() if weight_triples_fn is not None else None
+        y2 = ops.float_conv2d(input, weight_q if weight_q is not None else weight, kind, bias, stride, padding,
+                              dilation, weight_triples=wt)
+        N, C, H, W = input.shape
+        Ho, Wo = ops.conv_out_hw(H, W, int(weight.shape[2]), int(weight.shape[3]), stride, padding, dilation)
+        y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+        if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous()
+        return y
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 

@@ -217,7 +217,7 @@ NIB_GEMM_SHAPES = GEMM_SHAPES + [(256, 256, 256), (512, 256, 4096), (255, 257, 3
 
 
 @pytest.mark.parametrize("M,N,K", NIB_GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [None, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [None, 5, 6, 7, 8, 9, 10, 15, 16])
 def test_nib_gemm_vs_oracle(dev, oracle, M, N, K, variant):
     x = synth.pm1(M * 7 + K, (M, K))
     w = synth.uniform(N * 5 + K, (N, K), -1.5, 1.5)
@@ -237,7 +237,7 @@ def test_nib_gemm_equals_popcount_gemm_large(dev):
     x = torch.randn((1000, 5000), device=dev, generator=gen)
     w = torch.randn((777, 5000), device=dev, generator=gen)
     ref = ops.xnor_gemm(ops.sign_pack(x)[0], ops.sign_pack(w)[0])
-    for variant in (None, 5, 6, 7, 8, 9, 10):
+    for variant in (None, 5, 6, 7, 8, 9, 10, 15, 16):
         assert torch.equal(ops.nib_gemm(ops.sign_pack_nib(x), ops.sign_pack_nib(w), variant=variant), ref)
     reft = ops.tern_gemm(ops.sign_pack(x)[0], ops.ternary_pack(w))
     assert torch.equal(ops.nib_gemm(ops.bits_to_nib(ops.sign_pack(x)[0]), ops.bits_to_nib(ops.ternary_pack(w))), reft)
@@ -520,7 +520,8 @@ def test_alexnet_bin_layerwise(dev):
             y = gmods[name](xin.to(dev))
         ran_float = _lib.call_counts["qt_bf16x3_pack_f32"] > float_before   # real-valued input: bf16x3 path
         ran_packed = sum(_lib.call_counts[k] for k in packed_entries) > before and not ran_float
-        assert ran_packed == binary, name                   # only features.0 sees real pixels
+        assert ran_packed == binary, name                   # only features.0 sees real pixels ...
+        assert ran_float == (not binary), name              # ... and it takes the bf16x3 path, not a library
         assert norm_err(n(y), yout.numpy()) <= TOL, name
         if binary:   # integer part exact: subtract the bias and compare as integers
             b = gmods[name].bias.detach().cpu().numpy()
