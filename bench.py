@@ -128,6 +128,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": "fp4 MFMA packed GEMM", "achieved": achieved,
                     "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_FP4_PEAK_TFLOPS,
                     "traffic": None, "kernel_ms": gemm_ms,
+                    "kernel_ms_note": "HIP-event bracket around each launch inside the timed region; includes the "
+                                      "marker packets / kernel boundary (~3-5 us): rocprofv3 kernel duration is in profiles/",
                     "hbm_equiv": {"algorithmic_bytes": gemm_bytes,
                                   "achieved_GBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9,
                                   "frac_of_8TBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -262,7 +264,7 @@ def pmc_traffic(gemm_impl):
     try:
         with open(path) as fh:
             d = json.load(fh)
-        k = d["kernels"]["nib_gemm_kernel" if gemm_impl == "mfma" else "popc_gemm_kernel"]
+        k = d["kernels"]["mfma_gemm_kernel" if gemm_impl == "mfma" else "popc_gemm_kernel"]
         return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, d.get("source", path)
     except (OSError, KeyError, ValueError):
         return None, None

@@ -14,17 +14,25 @@ import os
 import sys
 
 d = sys.argv[1]
-ours = ("nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
+ours = ("mfma_gemm_kernel", "pool_affine_sign_pack_kernel", "triple_kernel", "codes_kernel", "im2col_words_kernel",
+        "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
         "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
         "check_pm1_kernel", "conv", "im2col")
+
+
+import re
 
 
 def short(n):
     for k in ours:
         if k in n:
             tail = ""
-            if "<" in n and k in ("nib_gemm_kernel", "popc_gemm_kernel"):
-                tail = n[n.index("<"):n.index(">") + 1][:60]
+            m = re.search(r"GemmCfg<\(anonymous namespace\)::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>", n)
+            if m:
+                tail = (f"<{m.group(1)}, tile {int(m.group(2))*int(m.group(4))*32}x{int(m.group(3))*int(m.group(5))*32}, "
+                        f"pipe={m.group(6)}{', conv' if m.group(9) == 'true' else ''}>")
+            elif "<" in n and k == "popc_gemm_kernel":
+                tail = n[n.index("<"):n.index(">") + 1][:40]
             return k + tail
     return n.split("(")[0][-60:]
 
@@ -35,7 +43,7 @@ if os.path.exists(ks):
     print("## kernel-trace --stats (top kernels)\n")
     print("| kernel | calls | total us | avg us | % |")
     print("|---|---|---|---|---|")
-    for r in list(csv.DictReader(open(ks)))[:8]:
+    for r in list(csv.DictReader(open(ks)))[:16]:
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | "
               f"{float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
 print("\n## PMC (separate passes, per-dispatch averages)\n")
