@@ -217,6 +217,14 @@ int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t 
 int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out, int64_t ld_bytes,
                        int64_t rows, int64_t K, int mode, qt_stream_t stream);
 
+/* Space-to-depth gather + split for strided first-layer convs: out pixel (n, Y, X), element
+ * e = (c*s + dy)*s + dx  <-  triple of x[n, c, s*Y+dy-ph, s*X+dx-pw] (zero outside).  x is addressed by
+ * element strides (sN, sC, sH, sW): NCHW or NHWC storage.  Plane rows = N * ceil((H+2ph)/s) * ceil((W+2pw)/s).
+ * A k x k / stride s / padding p conv on x == a ceil(k/s)^2, stride-1, un-padded conv on this plane. */
+int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, uint16_t* out,
+                           int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s,
+                           int64_t ph, int64_t pw, qt_stream_t stream);
+
 /* Y[M,N] = Xh . Wh^T (+ bias) over K bf16 elements per row (K = 3 * features for triple planes);
  * ld in uint32 words. */
 int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,

@@ -67,7 +67,69 @@ __global__ __launch_bounds__(256) void triple_kernel(const float* __restrict__ x
     }
 }
 
+// Space-to-depth gather + split in one pass: pixel (n, Y, X) of the output plane holds, for every
+// e = (c*s + dy)*s + dx, the triple of x[n, c, s*Y + dy - ph, s*X + dx - pw] (zero outside the image).
+// A strided first-layer conv (k x k, stride s, padding p) on x equals a stride-1 ceil(k/s)^2 conv on this
+// plane.  x is addressed through element strides, so NCHW and NHWC storage both work without a copy.
+__global__ __launch_bounds__(256) void s2d_triple_kernel(const float* __restrict__ x, int64_t sN, int64_t sC,
+                                                         int64_t sH, int64_t sW, uint16_t* __restrict__ out,
+                                                         int64_t ld_elems, int64_t N, int C, int H, int W,
+                                                         int s, int ph, int pw, int Hs, int Ws) {
+    const int E = C * s * s;                      // s2d channels
+    const int64_t pairs_per_row = ld_elems / 6;  // 2 elements (6 bf16) per work item; ld_elems % 8 == 0
+    const int64_t tail_words = (ld_elems - pairs_per_row * 6) / 2;
+    const int64_t total = N * Hs * Ws * (pairs_per_row + 1);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / (pairs_per_row + 1), p = t - pix * (pairs_per_row + 1);
+        uint32_t* orow = reinterpret_cast<uint32_t*>(out + pix * ld_elems);
+        if (p == pairs_per_row) {
+            for (int64_t w = 0; w < tail_words; ++w) orow[pairs_per_row * 3 + w] = 0;
+            continue;
+        }
+        const int64_t n = pix / ((int64_t)Hs * Ws);
+        const int rem = (int)(pix - n * Hs * Ws);
+        const int Y = rem / Ws, X = rem - Y * Ws;
+        uint32_t h[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const int e = (int)p * 2 + e2;
+            if (e >= E) continue;
+            const int c = e / (s * s), r = e - c * s * s, dy = r / s, dx = r - dy * s;
+            const int hh = s * Y + dy - ph, ww = s * X + dx - pw;
+            float v = 0.0f;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = x[n * sN + c * sC + hh * sH + ww * sW];
+            const uint32_t a = bf16_rn_bits(v);
+            const float r1 = v - bf16_bits_to_f32(a);
+            const uint32_t b = bf16_rn_bits(r1);
+            const float r2 = r1 - bf16_bits_to_f32(b);
+            h[3 * e2] = a; h[3 * e2 + 1] = b; h[3 * e2 + 2] = bf16_rn_bits(r2);
+        }
+        orow[p * 3 + 0] = h[0] | (h[1] << 16);
+        orow[p * 3 + 1] = h[2] | (h[3] << 16);
+        orow[p * 3 + 2] = h[4] | (h[5] << 16);
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW,
+                                      uint16_t* out, int64_t ld_bytes, int64_t N, int64_t C, int64_t H,
+                                      int64_t W, int64_t s, int64_t ph, int64_t pw, qt_stream_t stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || s < 1 || ph < 0 || pw < 0) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!x || !out) return QT_ERR_INVALID_ARG;
+    const int64_t E = C * s * s;
+    if (ld_bytes < 6 * E || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (H > 32767 || W > 32767 || E > 4096) return QT_ERR_UNSUPPORTED;
+    const int64_t Hs = (H + 2 * ph + s - 1) / s, Ws = (W + 2 * pw + s - 1) / s;
+    const int64_t ld_elems = ld_bytes / 2;
+    const int64_t total = N * Hs * Ws * (ld_elems / 6 + 1);
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(s2d_triple_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, sN, sC, sH, sW,
+                       out, ld_elems, N, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws);
+    return qt_check_launch();
+}
 
 extern "C" int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out,
                                   int64_t ld_bytes, int64_t rows, int64_t K, int mode, qt_stream_t stream) {

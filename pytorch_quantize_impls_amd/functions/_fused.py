@@ -49,6 +49,9 @@ def quantize_weight_f32(weight: torch.Tensor, kind: str) -> torch.Tensor:
 #: the HIP-quantised weight image (the reference computation itself).
 FLOAT_PATH = "bf16x3"
 
+#: Re-express strided few-channel convs (first layers) as stride-1 convs on the space-to-depth image.
+USE_S2D = True
+
 #: 'auto' | 'valu' | 'mfma' — packed-GEMM formulation used by the layers (both are bit-exact;
 #: 'auto' picks by shape, see ops.select_gemm_impl).
 GEMM_IMPL = "auto"
@@ -166,12 +169,33 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
     if packable and FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
         # real-valued activation (first layer): exact bf16 triples + implicit-GEMM conv on the bf16
         # matrix cores; the quantisers are idempotent so an explicit quantised image is packed the same way
-        wt = weight_triples_fn() if weight_triples_fn is not None else None
-        y2 = ops.float_conv2d(input, weight_q if weight_q is not None else weight, kind, bias, stride, padding,
-                              dilation, weight_triples=wt)
         N, C, H, W = input.shape
-        Ho, Wo = ops.conv_out_hw(H, W, int(weight.shape[2]), int(weight.shape[3]), stride, padding, dilation)
-        y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        if USE_S2D and ops.s2d_applicable(C, kh, kw, stride, dilation):
+            # strided few-channel conv (conv1) == stride-1 conv on the space-to-depth image; the gather and
+            # the exact bf16 split are one kernel, the transformed weight is cached by eval-mode layers
+            sd = ops._pairs(stride)[0]
+            px, (Hs, Ws) = ops.s2d_triple_pack(input, sd, padding)
+            cached = weight_triples_fn("s2d") if weight_triples_fn is not None else None
+            if cached is not None:
+                ws_shape, wtr = cached
+            else:
+                wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+                ws = ops.s2d_weight(wq.detach(), sd)
+                ws_shape, wtr = tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")   # zeros stay zeros
+            k2 = ws_shape[2]
+            y2 = ops.float_conv2d(None, torch.empty(ws_shape, device="meta"), "sign", bias, 1, 0, 1,
+                                  weight_triples=wtr, pixels=px, in_shape=(N, C * sd * sd, Hs, Ws))
+            H2, W2 = Hs - k2 + 1, Ws - k2 + 1
+            y = y2.view(N, H2, W2, weight.shape[0])[:, :Ho, :Wo, :].permute(0, 3, 1, 2)
+            if H2 != Ho or W2 != Wo:
+                y = y.contiguous(memory_format=torch.channels_last)
+        else:
+            wt = weight_triples_fn("plain") if weight_triples_fn is not None else None
+            y2 = ops.float_conv2d(input, weight_q if weight_q is not None else weight, kind, bias, stride, padding,
+                                  dilation, weight_triples=wt)
+            y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
         if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous()
         return y

@@ -82,6 +82,19 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def _quantized_weight_for_eval(self):
         return self.ter_op.apply(self.weight)
 
+    def _conv_triples(self, form):
+        """Cached bf16 triple image of the eval-mode (already quantised) weight for real-valued inputs:
+        'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the space-to-depth form."""
+        ops = _fused.ops
+        if form == "plain":
+            return self._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x3(self.weight.detach(), "ternary"),
+                                     key="conv_bf16x3")
+
+        def build(_w2):
+            ws = ops.s2d_weight(self.weight.detach(), self.stride[0])
+            return tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")
+        return self._eval_planes(build, key="conv_bf16x3_s2d")
+
     def forward(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
@@ -104,6 +117,4 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return _fused.quant_conv2d_forward(input, self.weight, self.bias, *args, "ternary",
                                            weight_q=self.weight, weight_planes=wp,
                                            binary_input=self.binary_input, padding_mode=self.padding_mode,
-                                           weight_triples_fn=lambda: self._eval_planes(
-                                               lambda _w2: _fused.ops.pack_conv_weight_bf16x3(self.weight.detach(), "ternary"),
-                                               key="conv_bf16x3"))
+                                           weight_triples_fn=self._conv_triples)

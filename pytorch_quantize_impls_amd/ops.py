@@ -731,20 +731,47 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str) -> TriplePlanes:
     return TriplePlanes(data=data, rows=Cout, K=kbytes // 6)   # K only used for consistency checks
 
 
-def float_conv2d(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0, dilation=1,
-                 weight_triples: Optional[TriplePlanes] = None) -> torch.Tensor:
-    """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
-    packed-domain im2col (zero words for padding taps) -> bf16 MFMA GEMM.  Returns NHWC [N*Ho*Wo, Cout]."""
+def s2d_triple_pack(x: torch.Tensor, s: int, padding) -> Tuple[TriplePlanes, Tuple[int, int]]:
+    """Space-to-depth gather + exact bf16 split of [N, C, H, W] (any storage) in one kernel.
+    Returns (pixel planes with rows = N*Hs*Ws and K = C*s*s, (Hs, Ws))."""
     _require(x, "input")
     N, C, H, W = (int(v) for v in x.shape)
+    ph, pw = _pairs(padding)
+    Hs, Ws = (H + 2 * ph + s - 1) // s, (W + 2 * pw + s - 1) // s
+    E = C * s * s
+    ld = triple_ld_bytes(E, 16)
+    out = torch.empty((N * Hs * Ws, ld // 2), dtype=torch.int16, device=x.device)
+    I = ctypes.c_int64
+    sN, sC, sH, sW = (int(v) for v in x.stride())
+    with torch.cuda.device(x.device):
+        _lib.call("qt_bf16x3_s2d_pack_f32", _p(x), I(sN), I(sC), I(sH), I(sW), _p(out), I(ld), I(N), I(C), I(H),
+                  I(W), I(int(s)), I(ph), I(pw), _stream(x.device))
+    return TriplePlanes(data=out, rows=N * Hs * Ws, K=E), (Hs, Ws)
+
+
+def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0,
+                 dilation=1, weight_triples: Optional[TriplePlanes] = None, pixels: Optional[TriplePlanes] = None,
+                 in_shape=None) -> torch.Tensor:
+    """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
+    implicit-GEMM conv on the bf16 matrix cores.  ``pixels``/``in_shape``: pre-built pixel planes (e.g. from
+    s2d_triple_pack) instead of x.  Returns NHWC [N*Ho*Wo, Cout]."""
+    if pixels is None:
+        _require(x, "input")
+        N, C, H, W = (int(v) for v in x.shape)
+    else:
+        N, C, H, W = (int(v) for v in in_shape)
     Cout, _, kh, kw = (int(v) for v in weight.shape)
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-    nhwc = x.permute(0, 2, 3, 1)
-    if not nhwc.is_contiguous():
-        nhwc = nhwc.contiguous()
     Cb = triple_ld_bytes(C, 16)
-    px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb)
+    if pixels is None:
+        nhwc = x.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+        px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb)
+    else:
+        px = pixels
+        x = pixels.data
     wt = weight_triples if weight_triples is not None else pack_conv_weight_bf16x3(weight, kind)
     Cw, ldA = Cb // 4, wt.ld_words
     M = N * Ho * Wo
@@ -768,6 +795,32 @@ def float_conv2d(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, st
             _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
                       I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
     return y
+
+
+def s2d_applicable(C: int, kh: int, kw: int, stride, dilation) -> bool:
+    """Strided first-layer style convs (few input channels) are re-expressed as stride-1 convs on the
+    space-to-depth image: no padding waste in the pixel planes and ~(k/ceil(k/s)s)^2 of the K bytes."""
+    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
+    return sh == sw and sh > 1 and dh == dw == 1 and kh == kw and C * sh * sh <= 64 and kh >= sh
+
+
+def s2d_weight(wq: torch.Tensor, s: int) -> torch.Tensor:
+    """[Cout, C, k, k] QUANTISED weight -> [Cout, C*s*s, k', k'] (k' = ceil(k/s)); the taps added by the
+    rounding up are true zeros."""
+    Cout, C, k, _ = wq.shape
+    k2 = (k + s - 1) // s * s
+    wp = torch.nn.functional.pad(wq, (0, k2 - k, 0, k2 - k))
+    return torch.nn.functional.pixel_unshuffle(wp, s).contiguous()
+
+
+def s2d_input(x: torch.Tensor, s: int, padding) -> torch.Tensor:
+    """[N, C, H, W] -> zero-padded, space-to-depth [N, C*s*s, ceil((H+2p)/s), ceil((W+2p)/s)] in NHWC storage."""
+    ph, pw = _pairs(padding)
+    N, C, H, W = x.shape
+    Hp, Wp = H + 2 * ph, W + 2 * pw
+    eh, ew = (-Hp) % s, (-Wp) % s
+    xp = torch.nn.functional.pad(x, (pw, pw + ew, ph, ph + eh))
+    return torch.nn.functional.pixel_unshuffle(xp, s).contiguous(memory_format=torch.channels_last)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -739,3 +739,25 @@ def test_float_conv_bf16x3_vs_fp64(dev):
         y = y2.view(2, Ho, Ho, Cout).permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(x.double(), ops.binarize(w).double(), b.double(), st, pd)
         assert norm_err(n(y), n(ref)) <= TOL
+
+
+def test_strided_first_layer_conv_s2d_vs_fp64(dev):
+    """BinConv2d on real pixels with stride > 1 goes through the space-to-depth form; same numbers."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(33)
+    for (Cin, Cout, k, st, pd, H) in [(3, 192, 11, 4, 2, 224), (3, 16, 7, 2, 3, 33), (1, 8, 5, 3, 1, 20)]:
+        x = torch.randn((2, Cin, H, H), device=dev, generator=gen).contiguous(memory_format=torch.channels_last)
+        conv = BinConv2d(Cin, Cout, k, stride=st, padding=pd).to(dev)
+        ref = torch.nn.functional.conv2d(x.double(), ops.binarize(conv.weight.detach()).double(),
+                                         conv.bias.detach().double(), st, pd)
+        outs = []
+        for use in (True, False):
+            _fused.USE_S2D = use
+            try:
+                with torch.no_grad(), used("qt_conv2d_implicit", "qt_bf16x3_pack_f32"):
+                    outs.append(conv(x))
+            finally:
+                _fused.USE_S2D = True
+        assert outs[0].shape == ref.shape
+        assert norm_err(n(outs[0]), n(ref)) <= TOL and norm_err(n(outs[1]), n(ref)) <= TOL
