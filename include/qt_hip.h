@@ -139,6 +139,11 @@ int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t l
                  const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                  qt_stream_t stream);
 
+/* Tuning / test hook (process-global, not thread-safe): which popcount kernel qt_xnor_gemm / qt_tern_gemm
+ * use: 0 = automatic (skinny weight-streaming kernel for small M or N, 128x128-tile kernel otherwise),
+ * 1 = always tiled, 2 = always skinny. */
+int qt_popc_force_kernel(int which);
+
 /* Binary activations x ternary weights (two planes): y = popc(m) - 2*popc((x ^ s) & m). */
 int qt_tern_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
                  int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,

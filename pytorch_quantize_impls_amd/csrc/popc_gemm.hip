@@ -22,6 +22,10 @@
 //     1024 workgroups = exactly one resident round on 256 CUs.
 #include "qt_common.h"
 
+int qt_launch_popc_skinny(bool ternary, const uint32_t* Xs, int64_t ldx, const uint32_t* W0,
+                          const uint32_t* W1, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                          int64_t M, int64_t N, int64_t K, qt_stream_t stream);  // popc_skinny.hip
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -178,6 +182,9 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
     }
 }
 
+// 0 = automatic, 1 = 128x128-tile kernel, 2 = skinny (weight-streaming) kernel
+static int g_popc_force = 0;
+
 template <bool TERNARY>
 int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const uint32_t* W1,
                      int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
@@ -192,6 +199,12 @@ int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const 
     if ((ldx & 3) || (ldw & 3)) return QT_ERR_ALIGNMENT;
     if (K > 0 && (!qt_aligned16(Xs) || !qt_aligned16(W0) || (TERNARY && !qt_aligned16(W1))))
         return QT_ERR_ALIGNMENT;
+    // weight-streaming regime: few batch rows or few output features -> the tiled kernel would leave
+    // most CUs idle (tiles = ceil(M/128)*ceil(N/128) << 256) while the skinny kernel spreads N over waves
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const bool skinny = g_popc_force == 2 || (g_popc_force == 0 && (M <= 64 || N <= 64 || tiles < 128) && M <= 4096);
+    if (skinny && (M + 63) / 64 <= 65535)
+        return qt_launch_popc_skinny(TERNARY, Xs, ldx, W0, W1, ldw, bias, Y, ldy, M, N, K, stream);
     const int64_t gy = (M + BM - 1) / BM, gx = (N + BN - 1) / BN;
     if (gy > 65535) return QT_ERR_UNSUPPORTED;  // callers split M (conv im2col rows) above this
     const int vec_store = qt_aligned16(Y) && (ldy % 4 == 0);
@@ -209,6 +222,13 @@ int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const 
 }  // namespace
 
 extern "C" {
+
+/* tuning: 0 = automatic choice between the tiled and the skinny popcount kernels, 1 / 2 = force one */
+int qt_popc_force_kernel(int which) {
+    if (which < 0 || which > 2) return QT_ERR_INVALID_ARG;
+    g_popc_force = which;
+    return QT_OK;
+}
 
 int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
                  const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,

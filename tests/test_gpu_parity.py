@@ -165,9 +165,18 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 31), (5, 7, 32), (5, 7, 33), (128, 128, 512), (
                (130, 260, 784), (64, 10, 4096), (257, 65, 9216), (3, 300, 1000), (200, 130, 96)]
 
 
-@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "tiled", "skinny"])
+def popc_kernel(request):
+    """Run a popcount-GEMM test under the automatic choice and with each kernel forced."""
+    import ctypes
+    _lib.load().qt_popc_force_kernel(ctypes.c_int(request.param))
+    yield request.param
+    _lib.load().qt_popc_force_kernel(ctypes.c_int(0))
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(64, 4096, 4096), (1, 1000, 9216), (256, 10, 4096), (70, 33, 10000)])
 @pytest.mark.parametrize("with_bias", [False, True])
-def test_xnor_gemm_vs_oracle(dev, oracle, M, N, K, with_bias):
+def test_xnor_gemm_vs_oracle(dev, oracle, popc_kernel, M, N, K, with_bias):
     x = synth.pm1(M * 7 + K, (M, K))
     w = synth.uniform(N * 5 + K, (N, K), -1, 1)
     b = synth.normal(N, (N,)) if with_bias else None
@@ -184,8 +193,8 @@ def test_xnor_gemm_vs_oracle(dev, oracle, M, N, K, with_bias):
         assert norm_err(y, oracle.linear(x, oracle.safe_sign(w), b)) <= TOL
 
 
-@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_tern_gemm_vs_oracle(dev, oracle, M, N, K):
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(64, 1000, 4096), (256, 10, 4096)])
+def test_tern_gemm_vs_oracle(dev, oracle, popc_kernel, M, N, K):
     x = synth.pm1(M * 3 + K, (M, K))
     w = synth.uniform(N * 9 + K, (N, K), -1.5, 1.5)
     with used("qt_ternary_pack_f32", "qt_tern_gemm"):
