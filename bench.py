@@ -46,6 +46,9 @@ def parse_args():
                     help="packed GEMM formulation (auto = fastest available for the shape)")
     ap.add_argument("--alexnet-batch", type=int, default=256, help="images per GPU (0 = skip)")
     ap.add_argument("--alexnet-iters", type=int, default=5)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (smoke tests)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="smoke test only: every rank uses cuda:0 (exercise the N>1 code path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -60,13 +63,18 @@ def main():
                      f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(args.dist_backend)
         dist = dist_mod
 
     from pytorch_quantize_impls_amd import _lib, ops
