@@ -270,8 +270,7 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
  * 0 = automatic (what qt_nib_gemm does: tile width 256/128/64 by N; the pipelined asm-DMA kernel
  * when row strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);
  * 6/7/8 = pipelined kernel with tile 256x256 / 256x128 / 256x64 (QT_ERR_ALIGNMENT if its contract
- * does not hold); 5/9/10 = generic kernel with the same tiles; 15/16 = 256x192 tile (pipelined / generic); 11/13 = pipelined kernel with 64-byte
- * K stages (4 waves 256x128, two workgroups per CU / 8 waves 256x256); 161..164 = profiling ablations of 6
+ * does not hold); 5/9/10 = generic kernel with the same tiles; 15/16 = 256x192 tile (pipelined / generic); 161..164 = profiling ablations of 6
  * (no MFMA / no DMA / epilogue only / no LDS reads; results are NOT valid). */
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,

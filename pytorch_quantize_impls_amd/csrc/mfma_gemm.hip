@@ -428,13 +428,6 @@ template <class E, int PIPE, int ABL = 0> using Cfg256 = GemmCfg<E, 2, 4, 4, 2, 
 template <class E, int PIPE> using Cfg128 = GemmCfg<E, 2, 4, 4, 1, PIPE>;
 template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
 template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 256x192 (wave 64x96): N = 576, 1152, ...
-// 4-wave workgroups with 64-byte stages: 48 KiB of LDS, <= 256 VGPRs -> TWO independent workgroups per
-// CU (different barrier domains fill each other's fill/drain bubbles and epilogues).
-template <class E, int PIPE> using Cfg2x = GemmCfg<E, 2, 2, 4, 2, PIPE, 0, 64>;      // 256x128 tile
-// 4 waves = ONE wave per SIMD with the whole 512-register file: wave tile 128x128 (16 MFMA tiles,
-// 0.5 KiB of LDS fragment traffic per MFMA instead of 0.75), everything overlapped inside the wave.
-template <class E, int PIPE> using Cfg1w = GemmCfg<E, 2, 2, 4, 4, PIPE>;
-template <class E, int PIPE> using Cfg2z = GemmCfg<E, 2, 4, 4, 2, PIPE, 0, 64>;      // 8 waves 256x256, 64-B stages (64 KiB: 2/CU by LDS, VGPR-limited)
 
 // implicit-conv configurations (pipelined kernel only)
 template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
@@ -494,9 +487,6 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 6: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1>);
         case 7: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg128<E, 1>);
         case 8: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg64<E, 1>);
-        case 11: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2x<E, 1>);
-        case 13: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg2z<E, 1>);
-        case 14: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg1w<E, 1>);
         case 9: QT_GO(Cfg128<E, 0>);
         case 10: QT_GO(Cfg64<E, 0>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);

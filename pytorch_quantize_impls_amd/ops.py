@@ -829,16 +829,20 @@ def s2d_input(x: torch.Tensor, s: int, padding) -> torch.Tensor:
 
 GEMM_IMPLS = ("valu", "mfma")
 
-#: shapes at least this large go to the matrix-core kernel under 'auto' (its 256x256 tile and
-#: ~10 us fixed cost only pay off for big problems; small-batch / small-N layers stay on the
-#: popcount kernel whose traffic is 4x smaller).
-MFMA_MIN_M, MFMA_MIN_N, MFMA_MIN_K = 192, 192, 256
+#: 'auto' thresholds (tools/bench_crossover.py, MI355X): the matrix-core kernel works on 256-row x
+#: {256,192,128,64}-column tiles, one tile per CU walking the whole K loop, plus a ~10 us fixed cost and (for
+#: tagged activations) a bits->nibble expansion launch.  It only wins when the problem fills the chip AND is
+#: long: otherwise the popcount kernels (tiled / skinny, 4x less operand traffic) are faster.
+MFMA_MIN_TILES, MFMA_MIN_OPS = 64, 3.0e10
 
 
 def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
     """'auto' -> the faster formulation for the shape (both are bit-exact)."""
     if requested == "auto":
-        return "mfma" if (M >= MFMA_MIN_M and N >= MFMA_MIN_N and K >= MFMA_MIN_K and K < (1 << 24)) else "valu"
+        tn = min((256, 192, 128, 64), key=lambda c: ((N + c - 1) // c * c, -c))
+        tiles = ((M + 255) // 256) * ((N + tn - 1) // tn)
+        big = tiles >= MFMA_MIN_TILES and 2.0 * M * N * K >= MFMA_MIN_OPS and K < (1 << 24)
+        return "mfma" if big else "valu"
     if requested not in GEMM_IMPLS:
         raise NotImplementedError(f"packed GEMM formulation {requested!r} is not built "
                                   f"(available: {GEMM_IMPLS})")

@@ -253,6 +253,17 @@ def test_nib_gemm_equals_popcount_gemm_large(dev):
 
 
 def test_layers_route_large_shapes_to_mfma(dev, oracle):
+    assert ops.select_gemm_impl("auto", 4096, 4096, 4096) == "mfma"
+    assert ops.select_gemm_impl("auto", 256, 4096, 4096) == "valu" and ops.select_gemm_impl("auto", 4096, 10, 4096) == "valu"
+    from pytorch_quantize_impls_amd.functions import _fused
+    _fused.GEMM_IMPL = "mfma"      # small shapes below: force the formulation under test
+    try:
+        _route_mfma_body(dev, oracle)
+    finally:
+        _fused.GEMM_IMPL = "auto"
+
+
+def _route_mfma_body(dev, oracle):
     x = synth.normal(41, (256, 512))
     w = synth.uniform(42, (320, 512), -1, 1)
     want = oracle.linear_bin_forward(oracle.safe_sign(x), w)
