@@ -267,11 +267,13 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
                        qt_stream_t stream);
 
 /* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration.
- * 0 = automatic (what qt_nib_gemm does: tile width 256/128/64 by N; the pipelined asm-DMA kernel
- * when row strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);
- * 6/7/8 = pipelined kernel with tile 256x256 / 256x128 / 256x64 (QT_ERR_ALIGNMENT if its contract
- * does not hold); 5/9/10 = generic kernel with the same tiles; 15/16 = 256x192 tile (pipelined / generic); 161..164 = profiling ablations of 6
- * (no MFMA / no DMA / epilogue only / no LDS reads; results are NOT valid). */
+ * 0 = automatic (what qt_nib_gemm does: tile width 256/192/128/64 by N; an asm-DMA kernel when row
+ * strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);
+ * 20/21 = ping-pong kernel (64-byte stages, ring of 4, SIMD partners alternate load / compute
+ * segments), tile 256x256 / 256x128; 6/7/8/15 = double-buffered pipelined kernel, tile 256x256 /
+ * 256x128 / 256x64 / 256x192 (QT_ERR_ALIGNMENT if the contract does not hold); 5/9/10/16 = generic
+ * kernel with the same tiles; 161..164 = profiling ablations of 6 (no MFMA / no DMA / epilogue only /
+ * no LDS reads) and 165 = ping-pong with cycle stamps written over Y (results are NOT valid). */
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,
                         int64_t N, int64_t K, qt_stream_t stream);

@@ -84,6 +84,13 @@ __device__ __forceinline__ void glds16_asm64(const unsigned char* src, unsigned 
         : "memory");
 }
 
+// profiling builds only (ABL == 5): shader-cycle stamp that neither the compiler nor a branch can move
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 // Implicit-GEMM conv: the X operand is not a matrix but the NHWC pixel plane P[N][H][W][cpp*16 bytes];
 // row m = (n, ho, wo), K byte index = ((i*kw + j)*cpp + sub)*16 + byte: chunk q of a row is 16 bytes of
 // pixel (ho*sh - ph + i*dh, wo*sw - pw + j*dw) or zeros when that pixel is padding / q is past the taps.
@@ -136,7 +143,7 @@ struct ElemBf16 {
 
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
-//   4 = no LDS fragment reads.
+//   4 = no LDS fragment reads, 5 = (ping-pong) cycle stamps of one mid-loop stage written over Y.
 template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, bool CONV_ = false>
 struct GemmCfg {
     using E = E_;
@@ -149,7 +156,9 @@ struct GemmCfg {
     static constexpr int TM = WM * TMW * 32, TN = WN * TNW * 32;  // workgroup tile
     static constexpr int X_STAGE = TM * STAGE_BYTES, W_STAGE = TN * STAGE_BYTES;
     static constexpr int BUF = X_STAGE + W_STAGE;
-    static constexpr int LDS_BYTES = 2 * BUF;  // double-buffered
+    static constexpr int NBUF = PIPE_ == 2 ? 4 : 2;  // stage buffers: double-buffered, or a ring of 4 (ping-pong)
+    static constexpr int LDS_BYTES = NBUF * BUF + (PIPE_ == 2 ? 64 : 0);  // + the waves' SIMD ids (ping-pong)
+    static_assert(PIPE_ != 2 || (SB_ == 64 && NWAVES == 8), "ping-pong: 64-byte stages, two waves per SIMD");
     static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
     static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && TN % (ROWS_PER_PIECE * NWAVES) == 0,
                   "DMA pieces divide evenly over the waves");
@@ -197,6 +206,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
+    unsigned long long dbg_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ABL == 5: cycle stamps of one mid-loop stage
+    unsigned long long dbg_wall[5] = {0, 0, 0, 0, 0}, dbg_end = 0, dbg_loop0 = 0;
+    int dbg_simd = 0;
+    dbg_ts[7] = __builtin_readcyclecounter();
+    if constexpr (C::ABL == 5) dbg_wall[0] = wall_clock64();
     const int nstages = C::ABL == 3 ? 0 : (E::kbytes(K) + STAGE_BYTES - 1) / STAGE_BYTES;
 
     auto read_frags = [&](const unsigned char* xs, const unsigned char* ws, int kk,
@@ -220,8 +234,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             for (int b = 0; b < C::TNW; ++b) acc[a][b] = E::mfma(xf[a], wf[b], acc[a][b]);
     };
 
-    if constexpr (C::PIPE == 1) {
-        // ---- pipelined main loop (asm-issued DMA) -----------------------------------------------
+    if constexpr (C::PIPE >= 1) {
+        // ---- pipelined main loops (asm-issued DMA) ----------------------------------------------
         constexpr int XP = C::TM / RPP / C::NWAVES, WP = C::TN / RPP / C::NWAVES;  // DMA pieces per wave
         constexpr int NP = XP + WP;
         const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
@@ -290,58 +304,142 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                            __builtin_amdgcn_readfirstlane(dst));
             }
         };
-        if (nstages > 0) {
-            if constexpr (C::CONV) conv_stage(0);
+        if constexpr (C::PIPE == 2) {
+            // ---- ping-pong: the two waves of a SIMD alternate roles every 64-byte stage ----------------
+            // An in-order wave cannot issue MFMAs while it is issuing LDS-DMA pieces / fragment reads, and
+            // two waves running the SAME interleaved stream stall at the same places (measured: stage time
+            // = MFMA time + load time, tools/ubench/mfma_power.hip + the ABL variants).  Here a wave's
+            // stage is a LOAD segment (all 12 fragment reads of the stage into registers + its 4 DMA pieces
+            // of stage s+3) followed by a COMPUTE segment (16 register-only MFMAs), one s_barrier after
+            // each, and waves 4-7 (the SIMD partners of waves 0-3) run one segment ahead: in every slot one
+            // wave per SIMD owns the matrix pipe while its partner owns the LDS / DMA issue.
+            //   slot 2s: B = waves 4-7 load stage s   | A = waves 0-3 compute stage s-1
+            //   slot 2s+1: B compute stage s          | A load stage s
+            // Ring of 4 stage buffers; stage s+3 is written into the buffer stage s-1 was read from (reads
+            // finished, lgkmcnt(0), before the barrier that ends slot 2s-1).  A wave has three stages of
+            // pieces in flight; at the end of load(s) it waits for its pieces of stage s+1 (vmcnt(2*NP)),
+            // and the barrier publishes them before the first reader (B, slot 2s+2).
+            constexpr int AHEAD = 3;
+            // Role = rank of the wave among the workgroup's waves on ITS SIMD (read from HW_ID), so the two
+            // co-resident waves of a SIMD always get opposite roles whatever the dispatcher's placement
+            // (correctness does not depend on it: any split with equal barrier counts is valid).
+            int grp;
+            {
+                volatile int* simd_of = reinterpret_cast<volatile int*>(smem + C::NBUF * BUF);
+                const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_ID.SIMD_ID
+                if (lane == 0) simd_of[uwave] = simd;
+                __syncthreads();
+                int rank = 0;
+                for (int w2 = 0; w2 < C::NWAVES; ++w2) rank += (w2 < uwave && simd_of[w2] == simd) ? 1 : 0;
+                grp = __builtin_amdgcn_readfirstlane(rank & 1);
+                if constexpr (C::ABL == 5) dbg_simd = simd;
+            }
 #pragma unroll
-            for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+            for (int s = 0; s < AHEAD; ++s)
+                if (s < nstages) {
+                    if constexpr (C::CONV) conv_stage(s);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) issue_piece(j, s, s);
+                }
+            if (nstages >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if constexpr (C::ABL == 5) { dbg_wall[1] = wall_clock64(); dbg_loop0 = __builtin_readcyclecounter(); }
+            if (grp == 0 && nstages > 0) __syncthreads();   // group A trails by one slot
 
-        auto stage_body = [&](int s, auto more_tag) {
-            constexpr bool more = decltype(more_tag)::value;
-            const int buf = s & 1;
-            const unsigned char* xs = smem + buf * BUF;
-            const unsigned char* ws = xs + C::X_STAGE;
-            uint4 xfA[C::TMW], wfA[C::TNW], xfB[C::TMW], wfB[C::TNW];
-            if constexpr (C::ABL == 4) {
+            auto pp_stage = [&](int s, auto issue_tag, auto last_tag) {
+                constexpr bool issue = decltype(issue_tag)::value, last = decltype(last_tag)::value;
+                const unsigned char* xs = smem + (s & 3) * BUF;
+                const unsigned char* ws = xs + C::X_STAGE;
+                uint4 xf0[C::TMW], wf0[C::TNW], xf1[C::TMW], wf1[C::TNW];
+                if constexpr (C::ABL == 5 && issue) dbg_ts[0] = stamp_now();
+                read_frags(xs, ws, 0, xf0, wf0);
+                read_frags(xs, ws, 1, xf1, wf1);
+                if constexpr (C::ABL == 5 && issue) dbg_ts[1] = stamp_now();
+                if constexpr (issue) {
+                    if constexpr (C::CONV) conv_stage(s + AHEAD);
 #pragma unroll
-                for (int a = 0; a < C::TMW; ++a) xfA[a] = xfB[a] = make_uint4(0x22222222u, 0x2a2a2a2au, lane, s);
-#pragma unroll
-                for (int b = 0; b < C::TNW; ++b) wfA[b] = wfB[b] = make_uint4(0xa2a2a2a2u, 0x2a2a2a2au, lane, s);
+                    for (int j = 0; j < NP; ++j) issue_piece(j, s + AHEAD, (s + AHEAD) & 3);
+                    if constexpr (C::ABL == 5 && issue) dbg_ts[2] = stamp_now();
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                if constexpr (C::ABL == 5 && issue) dbg_ts[3] = stamp_now();
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C::ABL == 5 && issue) dbg_ts[4] = stamp_now();
+                mfma_step(xf0, wf0);
+                mfma_step(xf1, wf1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C::ABL == 5 && issue) dbg_ts[5] = stamp_now();
+                if (!(last && grp == 0)) __syncthreads();   // A's last compute has no partner segment
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C::ABL == 5 && issue) dbg_ts[6] = stamp_now();
+            };
+            int s = 0;
+            for (; s + AHEAD < nstages; ++s) pp_stage(s, std::true_type{}, std::false_type{});
+            for (; s + 1 < nstages; ++s) pp_stage(s, std::false_type{}, std::false_type{});
+            if (nstages > 0) pp_stage(nstages - 1, std::false_type{}, std::true_type{});
+            if constexpr (C::ABL == 5) {   // profiling only: the (0,0) tile's waves overwrite Y row 0.. with their stamps
+                dbg_end = __builtin_readcyclecounter();
+                dbg_wall[2] = wall_clock64();
             }
-            if constexpr (C::ABL != 4) read_frags(xs, ws, 0, xfA, wfA);
-            if constexpr (C::CONV && more) conv_stage(s + 1);
-#pragma unroll
-            for (int kk = 0; kk < KK; kk += 2) {
-                // DMA pieces are spread over the k-steps; fragments of step kk+1 are requested before
-                // the MFMAs of step kk so LDS latency hides under the matrix pipe.
-                if constexpr (more && C::ABL != 2) {
-#pragma unroll
-                    for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
-                }
-                if constexpr (C::ABL != 4) read_frags(xs, ws, kk + 1, xfB, wfB);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (C::ABL != 1) mfma_step(xfA, wfA);
-                else asm volatile("" ::"v"(xfA[0].x), "v"(wfA[0].x), "v"(xfA[C::TMW - 1].w), "v"(wfA[C::TNW - 1].w));
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more && C::ABL != 2) {
-#pragma unroll
-                    for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
-                }
-                if constexpr (C::ABL != 4) {
-                    if (kk + 2 < KK) read_frags(xs, ws, kk + 2, xfA, wfA);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (C::ABL != 1) mfma_step(xfB, wfB);
-                else asm volatile("" ::"v"(xfB[0].x), "v"(wfB[0].x), "v"(xfB[C::TMW - 1].w), "v"(wfB[C::TNW - 1].w));
-                __builtin_amdgcn_sched_barrier(0);
+        } else {
+        if (nstages > 0) {
+                if constexpr (C::CONV) conv_stage(0);
+    #pragma unroll
+                for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
-            __syncthreads();                                   // ... and everyone's are visible
-        };
-        for (int s = 0; s + 1 < nstages; ++s) stage_body(s, std::true_type{});
-        if (nstages > 0) stage_body(nstages - 1, std::false_type{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+    
+            auto stage_body = [&](int s, auto more_tag) {
+                constexpr bool more = decltype(more_tag)::value;
+                const int buf = s & 1;
+                const unsigned char* xs = smem + buf * BUF;
+                const unsigned char* ws = xs + C::X_STAGE;
+                uint4 xfA[C::TMW], wfA[C::TNW], xfB[C::TMW], wfB[C::TNW];
+                if constexpr (C::ABL == 4) {
+    #pragma unroll
+                    for (int a = 0; a < C::TMW; ++a) xfA[a] = xfB[a] = make_uint4(0x22222222u, 0x2a2a2a2au, lane, s);
+    #pragma unroll
+                    for (int b = 0; b < C::TNW; ++b) wfA[b] = wfB[b] = make_uint4(0xa2a2a2a2u, 0x2a2a2a2au, lane, s);
+                }
+                if constexpr (C::ABL != 4) read_frags(xs, ws, 0, xfA, wfA);
+                if constexpr (C::CONV && more) conv_stage(s + 1);
+    #pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    // DMA pieces are spread over the k-steps; fragments of step kk+1 are requested before
+                    // the MFMAs of step kk so LDS latency hides under the matrix pipe.
+                    if constexpr (more && C::ABL != 2) {
+    #pragma unroll
+                        for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                    }
+                    if constexpr (C::ABL != 4) read_frags(xs, ws, kk + 1, xfB, wfB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (C::ABL != 1) mfma_step(xfA, wfA);
+                    else asm volatile("" ::"v"(xfA[0].x), "v"(wfA[0].x), "v"(xfA[C::TMW - 1].w), "v"(wfA[C::TNW - 1].w));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (more && C::ABL != 2) {
+    #pragma unroll
+                        for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                    }
+                    if constexpr (C::ABL != 4) {
+                        if (kk + 2 < KK) read_frags(xs, ws, kk + 2, xfA, wfA);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (C::ABL != 1) mfma_step(xfB, wfB);
+                    else asm volatile("" ::"v"(xfB[0].x), "v"(wfB[0].x), "v"(xfB[C::TMW - 1].w), "v"(wfB[C::TNW - 1].w));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+                __syncthreads();                                   // ... and everyone's are visible
+            };
+            for (int s = 0; s + 1 < nstages; ++s) stage_body(s, std::true_type{});
+            if (nstages > 0) stage_body(nstages - 1, std::false_type{});
+        }
     } else {
         // ---- generic main loop (builtin DMA, 64-bit addresses, any row stride % 4 words) ------------
         const unsigned char* zero16 = zero16_storage;
@@ -405,6 +503,19 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             }
         }
     }
+    if constexpr (C::ABL == 5) {   // profiling only: waves 0 and 4 overwrite the head of their own first Y row
+        dbg_wall[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_wall[4] = wall_clock64();
+        if (lane == 0 && wave_n == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(Y + (int64_t)(m0 + wave_m * C::TMW * 32) * ldy + n0);
+            for (int i = 0; i < 8; ++i) o[i] = dbg_ts[i];
+            o[8] = dbg_end;
+            for (int i = 0; i < 5; ++i) o[9 + i] = dbg_wall[i];
+            o[14] = (unsigned long long)dbg_simd;
+            o[15] = dbg_end - dbg_loop0;
+        }
+    }
 }
 
 template <class C>
@@ -428,6 +539,10 @@ template <class E, int PIPE, int ABL = 0> using Cfg256 = GemmCfg<E, 2, 4, 4, 2, 
 template <class E, int PIPE> using Cfg128 = GemmCfg<E, 2, 4, 4, 1, PIPE>;
 template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
 template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 256x192 (wave 64x96): N = 576, 1152, ...
+
+// ping-pong configurations (64-byte stages, ring of 4)
+template <class E, int ABL = 0> using PP256 = GemmCfg<E, 2, 4, 4, 2, 2, ABL, 64, false>;
+template <class E> using PP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, false>;
 
 // implicit-conv configurations (pipelined kernel only)
 template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
@@ -471,9 +586,9 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 0: {  // automatic: tile width by N, fast path when its contract holds
             const int tn = pick_tile_n(N);
             if (pipe_ok) {
-                if (tn == 256) QT_GO(Cfg256<E, 1>);
+                if (tn == 256) QT_GO(PP256<E>);
                 if (tn == 192) QT_GO(Cfg192<E, 1>);
-                if (tn == 128) QT_GO(Cfg128<E, 1>);
+                if (tn == 128) QT_GO(PP128<E>);
                 QT_GO(Cfg64<E, 1>);
             }
             if (tn == 256) QT_GO(Cfg256<E, 0>);
@@ -489,6 +604,9 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 8: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg64<E, 1>);
         case 9: QT_GO(Cfg128<E, 0>);
         case 10: QT_GO(Cfg64<E, 0>);
+        case 20: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E>);
+        case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
+        case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
         case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);
         case 163: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 3>);
