@@ -273,7 +273,7 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
  * segments), tile 256x256 / 256x128; 6/7/8/15 = double-buffered pipelined kernel, tile 256x256 /
  * 256x128 / 256x64 / 256x192 (QT_ERR_ALIGNMENT if the contract does not hold); 5/9/10/16 = generic
  * kernel with the same tiles; 161..164 = profiling ablations of 6 (no MFMA / no DMA / epilogue only /
- * no LDS reads) and 165 = ping-pong with cycle stamps written over Y (results are NOT valid). */
+ * no LDS reads) and 165 / 166 = ping-pong with per-segment + phase / phase-only stamps written over Y (results are NOT valid). */
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,
                         int64_t N, int64_t K, qt_stream_t stream);

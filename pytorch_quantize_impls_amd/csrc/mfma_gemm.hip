@@ -143,7 +143,7 @@ struct ElemBf16 {
 
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
-//   4 = no LDS fragment reads, 5 = (ping-pong) cycle stamps of one mid-loop stage written over Y.
+//   4 = no LDS fragment reads, 5 = (ping-pong) per-segment cycle stamps + wall-clock phase stamps written over Y, 6 = phase stamps only.
 template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, bool CONV_ = false>
 struct GemmCfg {
     using E = E_;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     unsigned long long dbg_wall[5] = {0, 0, 0, 0, 0}, dbg_end = 0, dbg_loop0 = 0;
     int dbg_simd = 0;
     dbg_ts[7] = __builtin_readcyclecounter();
-    if constexpr (C::ABL == 5) dbg_wall[0] = wall_clock64();
+    if constexpr (C::ABL >= 5) dbg_wall[0] = wall_clock64();
     const int nstages = C::ABL == 3 ? 0 : (E::kbytes(K) + STAGE_BYTES - 1) / STAGE_BYTES;
 
     auto read_frags = [&](const unsigned char* xs, const unsigned char* ws, int kk,
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 int rank = 0;
                 for (int w2 = 0; w2 < C::NWAVES; ++w2) rank += (w2 < uwave && simd_of[w2] == simd) ? 1 : 0;
                 grp = __builtin_amdgcn_readfirstlane(rank & 1);
-                if constexpr (C::ABL == 5) dbg_simd = simd;
+                if constexpr (C::ABL >= 5) dbg_simd = simd;
             }
 #pragma unroll
             for (int s = 0; s < AHEAD; ++s)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             if (nstages >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if constexpr (C::ABL == 5) { dbg_wall[1] = wall_clock64(); dbg_loop0 = __builtin_readcyclecounter(); }
+            if constexpr (C::ABL >= 5) { dbg_wall[1] = wall_clock64(); dbg_loop0 = __builtin_readcyclecounter(); }
             if (grp == 0 && nstages > 0) __syncthreads();   // group A trails by one slot
 
             auto pp_stage = [&](int s, auto issue_tag, auto last_tag) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             for (; s + AHEAD < nstages; ++s) pp_stage(s, std::true_type{}, std::false_type{});
             for (; s + 1 < nstages; ++s) pp_stage(s, std::false_type{}, std::false_type{});
             if (nstages > 0) pp_stage(nstages - 1, std::false_type{}, std::true_type{});
-            if constexpr (C::ABL == 5) {   // profiling only: the (0,0) tile's waves overwrite Y row 0.. with their stamps
+            if constexpr (C::ABL >= 5) {   // profiling only: the (0,0) tile's waves overwrite Y row 0.. with their stamps
                 dbg_end = __builtin_readcyclecounter();
                 dbg_wall[2] = wall_clock64();
             }
@@ -489,21 +489,55 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 
     if (scale_dev) scale *= *scale_dev;   // device-resident factor (e.g. DoReFa's E = mean|W|): no host sync
     // ---- epilogue: D[row = m][col = n]; lane owns column n, rows m = mb + (r&3) + 8*(r>>2) + 4*lhalf ---
+    // The store tail is store-ISSUE bound (1024 dword wave-stores per CU: 13 us of a 41 us kernel at
+    // 4096^3, tools/pp_stamps.py), so each 32x32 tile is transposed through a wave-private 4 KiB LDS
+    // patch (the stage buffers are dead: every fragment read was waited for before the last barrier and
+    // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
+    // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
+    const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    if (wide) {
+        float* T = reinterpret_cast<float*>(smem) + wave * 1024;
 #pragma unroll
-    for (int b = 0; b < C::TNW; ++b) {
-        const int n = n0 + (wave_n * C::TNW + b) * 32 + lrow;
-        const float bv = (bias && n < N) ? bias[n] : 0.0f;
+        for (int b = 0; b < C::TNW; ++b) {
+            const int nb = n0 + (wave_n * C::TNW + b) * 32;
+            const float bv = (bias && nb + lrow < N) ? bias[nb + lrow] : 0.0f;
 #pragma unroll
-        for (int a = 0; a < C::TMW; ++a) {
-            const int mb = m0 + (wave_m * C::TMW + a) * 32 + 4 * lhalf;
+            for (int a = 0; a < C::TMW; ++a) {
+                const int mb = m0 + (wave_m * C::TMW + a) * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M && n < N) Y[(int64_t)m * ldy + n] = E::out(acc[a][b][r], scale, bv);
+                for (int r = 0; r < 16; ++r)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = E::out(acc[a][b][r], scale, bv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                    const float4 v = *reinterpret_cast<const float4*>(T + row * 32 + c4);
+                    const int m = mb + row, n = nb + c4;
+                    if (m < M && n < N) *reinterpret_cast<float4*>(Y + (int64_t)m * ldy + n) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int n = n0 + (wave_n * C::TNW + b) * 32 + lrow;
+            const float bv = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < C::TMW; ++a) {
+                const int mb = m0 + (wave_m * C::TMW + a) * 32 + 4 * lhalf;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < M && n < N) Y[(int64_t)m * ldy + n] = E::out(acc[a][b][r], scale, bv);
+                }
             }
         }
     }
-    if constexpr (C::ABL == 5) {   // profiling only: waves 0 and 4 overwrite the head of their own first Y row
+    if constexpr (C::ABL >= 5) {   // profiling only: waves 0 and 4 overwrite the head of their own first Y row
         dbg_wall[3] = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         dbg_wall[4] = wall_clock64();
@@ -606,6 +640,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 10: QT_GO(Cfg64<E, 0>);
         case 20: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E>);
         case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
+        case 166: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 6>);
         case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
         case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 from pytorch_quantize_impls_amd import _lib
 M = N = K = 4096
+VAR = int(sys.argv[1]) if len(sys.argv) > 1 else 165
 dev = torch.device("cuda:0")
 x = torch.randn((M, K), device=dev); w = torch.randn((N, K), device=dev)
 ld = K // 8
@@ -16,7 +17,7 @@ _lib.call("qt_sign_pack_nib_f32", P(x), I(K), P(xn), I(ld), I(M), I(K), st)
 _lib.call("qt_sign_pack_nib_f32", P(w), I(K), P(wn), I(ld), I(N), I(K), st)
 y = torch.zeros((M, N), device=dev)
 for rep in range(3):
-    _lib.call("qt_nib_gemm_variant", ctypes.c_int(165), P(xn), I(ld), P(wn), I(ld), ctypes.c_void_p(0), P(y), I(N), I(M), I(N), I(K), st)
+    _lib.call("qt_nib_gemm_variant", ctypes.c_int(VAR), P(xn), I(ld), P(wn), I(ld), ctypes.c_void_p(0), P(y), I(N), I(M), I(N), I(K), st)
     torch.cuda.synchronize()
 yi = y.view(torch.int32).cpu().numpy()
 rows = []
