@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle and the reference-generated
 golden vectors.  Integer / bit / index results: bit-exact.  Float tails: max|a-b|/max|b| <= 1e-5.
 Every test asserts that the libqt_hip.so entry points actually ran (no silent torch path)."""
+import copy
 import hashlib
 import warnings
 
@@ -781,3 +782,36 @@ def test_strided_first_layer_conv_s2d_vs_fp64(dev):
                 _fused.USE_S2D = True
         assert outs[0].shape == ref.shape
         assert norm_err(n(outs[0]), n(ref)) <= TOL and norm_err(n(outs[1]), n(ref)) <= TOL
+
+
+# ---- utils: packed checkpoint on a device model -----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["binary", "ternary", "dorefa1"])
+def test_packed_state_device_planes_equal_cpu_planes(dev, family):
+    import torch.nn as nn
+    from pytorch_quantize_impls_amd import utils as U
+    conv = {"binary": U.binary_net_convert, "ternary": U.ternary_net_convert,
+            "dorefa1": lambda n: U.dorefa_net_convert(n, weight_bit=1)}[family]
+    torch.manual_seed(11)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.Hardtanh(), nn.Flatten(),
+                        nn.Linear(8 * 5 * 5, 37))
+    m = conv(net)
+    for p in m.parameters():
+        p.data.uniform_(-1.2, 1.2)
+    m.eval()
+    st_cpu = U.packed_state_dict(m)
+    before = dict(_lib.call_counts)
+    md = copy.deepcopy(m).to(dev)
+    st_dev = U.packed_state_dict(md)
+    name = "qt_ternary_pack_f32" if family == "ternary" else "qt_sign_pack_f32"
+    assert _lib.call_counts.get(name, 0) - before.get(name, 0) == 2      # packed by the HIP kernels
+    for k, e in st_cpu["layers"].items():
+        assert torch.equal(e["sign"], st_dev["layers"][k]["sign"])
+        if family == "ternary":
+            assert torch.equal(e["mask"], st_dev["layers"][k]["mask"])
+    fresh = conv(net).to(dev)
+    U.load_packed_state_dict(fresh, st_cpu)
+    x = torch.randn(4, 3, 5, 5)
+    y_dev = fresh(x.to(dev)).cpu()
+    y_cpu = m(x)
+    assert (y_dev - y_cpu).abs().max() <= 1e-5 * y_cpu.abs().max()
