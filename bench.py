@@ -214,41 +214,37 @@ def bench_alexnet(args, dev, dist, world, rank):
     bench_models.randomize_bn(model)
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
     x = torch.randn((B, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        for _ in range(2):
-            y = model(x)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.alexnet_iters):
-            y = model(x)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    def timed(fn):
+        """`alexnet_iters` forwards, barrier + sync on both sides, MAX over ranks; best of 3 such runs (a
+        one-off host stall of tens of ms otherwise dominates a 5-forward sample)."""
+        best, last = None, None
+        with torch.no_grad():
+            for _ in range(3):
+                last = fn(x)
+            for _ in range(3):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.alexnet_iters):
+                    last = fn(x)
+                torch.cuda.synchronize()
+                e = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([e], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    e = float(tt.item())
+                best = e if best is None else min(best, e)
+        return best, last
+
+    el, y = timed(model)
     out = {"images_per_s": world * B * args.alexnet_iters / el, "batch_per_gpu": B,
-           "ms_per_forward": el / args.alexnet_iters * 1e3, "mode": "eval (pre-packed weights), channels_last",
+           "ms_per_forward": el / args.alexnet_iters * 1e3, "mode": "eval (pre-packed weights), channels_last; best of 3 runs of alexnet_iters forwards",
            "macs_per_image": 4.9349e9, "finite": bool(torch.isfinite(y).all())}
-    # same network with the inter-layer chains fused (layers.fused: MaxPool+BN+Hardtanh+sign+pack in one kernel)
+    # same network fused for inference (layers.fused): every BinConv2d emits BatchNorm-threshold bits, MaxPool runs
+    # on bits, FC blocks use the BN+Hardtanh+sign+pack kernel: no fp32 activation between binarised layers
     fused = bench_models.FusedAlexNetBin(model)
-    with torch.no_grad():
-        for _ in range(2):
-            yf = fused(x)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.alexnet_iters):
-            yf = fused(x)
-        torch.cuda.synchronize()
-        elf = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elf], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elf = float(tt.item())
+    elf, yf = timed(fused)
     out["fused"] = {"images_per_s": world * B * args.alexnet_iters / elf,
                     "ms_per_forward": elf / args.alexnet_iters * 1e3,
                     "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), y.argmax(1)))}

@@ -60,13 +60,20 @@ class FusedAlexNetBin(nn.Module):
     Shares the parameters of the model it was built from.  The last feature block's planes are flattened
     in (h, w, c) order, so the first classifier layer gets its weight columns permuted once."""
 
-    def __init__(self, model: AlexNetBin):
+    def __init__(self, model: AlexNetBin, fuse_conv: bool = True):
         super().__init__()
-        from pytorch_quantize_impls_amd.layers import FusedPoolBnSign, fuse_sequential, permute_fc_weight_hwc
+        from pytorch_quantize_impls_amd.layers import (FusedConvPoolBnSign, FusedPoolBnSign, fuse_sequential,
+                                                       permute_fc_weight_hwc)
         assert not model.training, "fuse an eval-mode model"
         f = list(model.features.children())
-        self.features = fuse_sequential(nn.Sequential(*f[:-3]))      # ... up to the last BinConv2d
-        self.last = FusedPoolBnSign(f[-2], pool=f[-3], flatten_hwc=True)   # MaxPool, BN, (Hardtanh), + classifier's BinaryConnect
+        if fuse_conv:
+            # every BinConv2d emits threshold bits (no fp32 activation between the binarised layers at all);
+            # the last block = conv5, MaxPool, BN, (Hardtanh) + the classifier's BinaryConnect
+            self.features = fuse_sequential(nn.Sequential(*f[:-4]), fuse_conv=True)
+            self.last = FusedConvPoolBnSign(f[-4], f[-2], pool=f[-3], flatten_hwc=True)
+        else:
+            self.features = fuse_sequential(nn.Sequential(*f[:-3]))      # ... up to the last BinConv2d
+            self.last = FusedPoolBnSign(f[-2], pool=f[-3], flatten_hwc=True)   # MaxPool, BN, (Hardtanh), + classifier's BinaryConnect
         c = list(model.classifieur.children())
         fc1 = LinearBin(c[1].in_features, c[1].out_features).to(c[1].weight.device)
         fc1.weight.data.copy_(permute_fc_weight_hwc(c[1].weight.data, 256, 6, 6))

@@ -266,6 +266,26 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
                        float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t Cout,
                        qt_stream_t stream);
 
+/* Same conv with the threshold-bit epilogue (inference fusion of
+ *   BinConv2d -> [MaxPool2d] -> BatchNorm2d(eval) -> Hardtanh -> BinaryConnect, models/Alexnet/Alexnet_Bin.py:13-17):
+ * no fp32 output is written; per output element t = acc (+ bias), v = fl(fl(t * alpha[c]) + beta[c]) and
+ * bit c%32 of word c/32 of row (n, ho, wo) of neg_plane is (v < 0).  neg_plane: [N*Ho*Wo][ldb] words,
+ * ldb % 4 == 0, ldb >= ceil(Cout/32); words past the last tile column are NOT written (pre-zero the plane).
+ * alpha/beta: folded eval BatchNorm, Cout floats each.  Follow with qt_pool_bits when a MaxPool sits
+ * between conv and BatchNorm. */
+int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                            int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias,
+                            float scale, const float* scale_dev, const float* alpha, const float* beta,
+                            uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream);
+
+/* MaxPool2d(pool_k, pool_s, no padding, floor mode) evaluated on threshold bits: out = AND over the
+ * window where alpha >= 0, OR where alpha < 0 (max-pooling commutes with the monotone map x*alpha+beta;
+ * bit-identical to pooling the fp32 tensor first, NaNs excepted).  in_plane: [N*H*W][ld] words NHWC
+ * pixel plane, out_plane: [N*Ho*Wo][ld]; neg_alpha: ld words, bit c = (alpha[c] < 0). */
+int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld, int64_t pool_k,
+                 int64_t pool_s, const uint32_t* neg_alpha, uint32_t* out_plane, qt_stream_t stream);
+
 /* Tuning / diagnostic entry: same contract as qt_nib_gemm with an explicit kernel configuration.
  * 0 = automatic (what qt_nib_gemm does: tile width 256/192/128/64 by N; an asm-DMA kernel when row
  * strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);

@@ -301,3 +301,39 @@ def dorefa_w1a_linear(x_real, weight, bias, k_act=4):
     if bias is not None:
         y = y + np.asarray(bias, dtype=np.float64)
     return y.astype(np.float32)
+
+
+# ---- the eval-mode chain between two binarised layers ------------------------------------------
+
+def maxpool2d(x, k, s):
+    """nn.MaxPool2d(k, s) (no padding, floor mode) on NCHW, as models/Alexnet/Alexnet_Bin.py:14 uses it."""
+    x = np.asarray(x, dtype=np.float32)
+    Nb, C, H, W = x.shape
+    Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+    out = np.full((Nb, C, Ho, Wo), -np.inf, dtype=np.float32)
+    for i in range(k):
+        for j in range(k):
+            out = np.maximum(out, x[:, :, i:i + s * Ho:s, j:j + s * Wo:s])
+    return out
+
+
+def pool_bn_sign_planes(y, alpha, beta, pool_k=1, pool_s=1):
+    """[MaxPool2d] -> eval BatchNorm folded to t = fl(fl(y*alpha) + beta) -> Hardtanh (sign-neutral) ->
+    BinaryConnectDeterministic -> NHWC sign plane (models/Alexnet/Alexnet_Bin.py:14-17 in eval mode).
+    Returns (plane [N*Ho*Wo][ld] uint32, (Ho, Wo))."""
+    y = np.asarray(y, dtype=np.float32)
+    if pool_k > 1 or pool_s > 1:
+        y = maxpool2d(y, pool_k, pool_s)
+    a = np.asarray(alpha, dtype=np.float32).reshape(1, -1, 1, 1)
+    b = np.asarray(beta, dtype=np.float32).reshape(1, -1, 1, 1)
+    t = (y * a).astype(np.float32) + b          # two fp32 roundings
+    Nb, C, Ho, Wo = t.shape
+    nhwc = np.ascontiguousarray(t.astype(np.float32).transpose(0, 2, 3, 1)).reshape(Nb * Ho * Wo, C)
+    return sign_pack(nhwc), (Ho, Wo)
+
+
+def bin_conv_pool_bn_sign_planes(x, weight_q, bias, stride, padding, dilation, alpha, beta, pool_k=1, pool_s=1):
+    """Eval-mode BinConv2d / TerConv2d (weight already quantised, layers/binary_layers.py:106) followed by
+    pool_bn_sign_planes: what FusedConvPoolBnSign must reproduce bit for bit."""
+    y = conv2d(x, weight_q, bias, stride, padding, dilation)
+    return pool_bn_sign_planes(y, alpha, beta, pool_k, pool_s)

@@ -62,7 +62,54 @@ __global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
     }
 }
 
+// MaxPool on threshold bits.  With bit = [x*alpha + beta < 0] per conv-output pixel (the threshold-bit
+// epilogue of the matrix-core conv), max-pooling commutes with the monotone affine map:
+//   alpha >= 0:  [max(x)*alpha + beta < 0] = AND over the window of the pixel bits
+//   alpha <  0:  [max(x)*alpha + beta < 0] = OR  over the window of the pixel bits
+// (fp32 multiply by a constant and add of a constant are monotone, so fl(fl(max x * a) + b) equals the
+// max / min over the window of fl(fl(x * a) + b): bit-identical to pooling the fp32 tensor first, NaNs
+// excepted.)  neg_alpha: 1 bit per channel, 1 <=> alpha < 0.  One thread = one output word.
+__global__ __launch_bounds__(256) void pool_bits_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                        const uint32_t* __restrict__ neg_alpha, int64_t ld,
+                                                        int64_t N, int H, int W, int pk, int ps, int Ho, int Wo) {
+    const int64_t total = N * Ho * Wo * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / ld;
+        const int w = (int)(i - pix * ld);
+        const int64_t n = pix / ((int64_t)Ho * Wo);
+        const int rem = (int)(pix - n * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ld + w;
+        uint32_t all = 0xffffffffu, any = 0u;
+        for (int a = 0; a < pk; ++a)
+            for (int b = 0; b < pk; ++b) {
+                const uint32_t v = base[((int64_t)a * W + b) * ld];
+                all &= v;
+                any |= v;
+            }
+        const uint32_t na = neg_alpha[w];
+        out[i] = (all & ~na) | (any & na);
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld,
+                            int64_t pool_k, int64_t pool_s, const uint32_t* neg_alpha, uint32_t* out_plane,
+                            qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || ld <= 0 || pool_k < 1 || pool_s < 1) return QT_ERR_INVALID_ARG;
+    if (pool_k > H || pool_k > W) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!in_plane || !out_plane || !neg_alpha) return QT_ERR_INVALID_ARG;
+    if (ld & 3) return QT_ERR_ALIGNMENT;
+    if (H > INT32_MAX / 2 || W > INT32_MAX / 2) return QT_ERR_UNSUPPORTED;
+    const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;
+    const int grid = qt_stream_grid((N * Ho * Wo * ld + 255) / 256);
+    hipLaunchKernelGGL(pool_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in_plane, out_plane,
+                       neg_alpha, ld, N, (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo);
+    return qt_check_launch();
+}
 
 extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
                                              int64_t pool_k, int64_t pool_s, const float* alpha,

@@ -100,6 +100,15 @@ struct ConvArgs {
     unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
 };
 
+// Threshold-bit epilogue (inference fusion of conv -> [MaxPool] -> BatchNorm(eval) -> Hardtanh -> sign):
+// when alpha != nullptr the kernel does not store fp32 Y but, per output element,
+//     t = out(acc) (+ bias);  v = fl(fl(t * alpha[n]) + beta[n]);  bit = v < 0
+// into the bit plane (uint32_t*)Y with ldy WORDS per row (bit n%32 of word n/32 of row m).
+struct EpiArgs {
+    const float* alpha = nullptr;
+    const float* beta = nullptr;
+};
+
 // ---- element types ----------------------------------------------------------------------------------
 struct ElemFp4 {
     using acc_t = v16f;
@@ -168,7 +177,7 @@ template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kernel(
     const uint32_t* __restrict__ X, int64_t ldx, const uint32_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, float scale, const float* __restrict__ scale_dev,
-    float* __restrict__ Y, int64_t ldy, int M, int N, int K, ConvArgs cg) {
+    float* __restrict__ Y, int64_t ldy, int M, int N, int K, ConvArgs cg, EpiArgs epi) {
     using E = typename C::E;
     using acc_t = typename E::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [buf][X stage | W stage]
@@ -495,7 +504,35 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
     // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
     const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-    if (wide) {
+    if (epi.alpha) {
+        // threshold bits: a v_cmp over the wave yields, per accumulator register, the 32-channel word of
+        // two output rows (lanes 0-31 -> row R, lanes 32-63 -> row R + 4); lane i keeps row i's word and
+        // one 32-lane store per 32x32 tile writes them.  Channels >= N compare 0 < 0 -> bit 0.
+        uint32_t* B = reinterpret_cast<uint32_t*>(Y);
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int nb = n0 + (wave_n * C::TNW + b) * 32;
+            const int n = nb + lrow;
+            const float bv = (bias && n < N) ? bias[n] : 0.0f;
+            const float al = n < N ? epi.alpha[n] : 0.0f, be = n < N ? epi.beta[n] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < C::TMW; ++a) {
+                uint32_t myword = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = E::out(acc[a][b][r], scale, bv);
+                    const float v = t * al + be;   // two roundings (-ffp-contract=off), as the un-fused chain
+                    const unsigned long long mask = __ballot(v < 0.0f);
+                    const int R = (r & 3) + 8 * (r >> 2);
+                    if (lane == R) myword = (uint32_t)mask;
+                    if (lane == R + 4) myword = (uint32_t)(mask >> 32);
+                }
+                const int m = m0 + (wave_m * C::TMW + a) * 32 + lane;
+                const int wcol = nb >> 5;
+                if (lane < 32 && m < M && wcol < ldy) B[(int64_t)m * ldy + wcol] = myword;
+            }
+        }
+    } else if (wide) {
         float* T = reinterpret_cast<float*>(smem) + wave * 1024;
 #pragma unroll
         for (int b = 0; b < C::TNW; ++b) {
@@ -555,7 +592,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 template <class C>
 int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,
                float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
-               qt_stream_t stream, const ConvArgs& cg = ConvArgs{}) {
+               qt_stream_t stream, const ConvArgs& cg = ConvArgs{}, const EpiArgs& epi = EpiArgs{}) {
     const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
     if (gy > 65535) return QT_ERR_UNSUPPORTED;
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
@@ -564,7 +601,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
         return QT_ERR_LAUNCH;
     hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3((unsigned)gx, (unsigned)gy), dim3(C::NTHREADS),
                        C::LDS_BYTES, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
-                       (int)M, (int)N, (int)K, cg);
+                       (int)M, (int)N, (int)K, cg, epi);
     return qt_check_launch();
 }
 
@@ -811,11 +848,13 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 
-// elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes
-int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
-                       int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
-                       int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
-                       const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream) {
+// elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes.  epi.alpha != nullptr:
+// Y is the threshold-bit plane and ldy its row stride in words.
+static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                              int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                              const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream,
+                              const EpiArgs& epi) {
     if (Nimg < 0 || H <= 0 || W <= 0 || Cw <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 ||
         dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 2)
         return QT_ERR_INVALID_ARG;
@@ -823,7 +862,7 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int
     if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
     const int64_t M = Nimg * Ho * Wo;
     if (M == 0 || Cout == 0) return QT_OK;
-    if (!P || !Wmat || !Y || ldy < Cout) return QT_ERR_INVALID_ARG;
+    if (!P || !Wmat || !Y || ldy < (epi.alpha ? (Cout + 31) / 32 : Cout)) return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
     if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767)
@@ -840,15 +879,37 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
-        if (tn == 256) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
-        if (tn == 192) return launch_cfg<Conv192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
-        if (tn == 128) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg); \
-        return launch_cfg<Conv64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg);                 \
+        if (tn == 256) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        if (tn == 192) return launch_cfg<Conv192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        if (tn == 128) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        return launch_cfg<Conv64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);                 \
     } while (0)
     if (elem == 0) QT_CONV(ElemFp4);
     if (elem == 1) QT_CONV(ElemI8);
     QT_CONV(ElemBf16);
 #undef QT_CONV
+}
+
+int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                       int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                       int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                       const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream) {
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, Y, ldy, Cout, stream, EpiArgs{});
+}
+
+int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                            int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                            const float* scale_dev, const float* alpha, const float* beta,
+                            uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream) {
+    if (!alpha || !beta) return QT_ERR_INVALID_ARG;
+    if (ldb & 3) return QT_ERR_ALIGNMENT;
+    EpiArgs epi;
+    epi.alpha = alpha;
+    epi.beta = beta;
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, reinterpret_cast<float*>(neg_plane), ldb, Cout, stream, epi);
 }
 
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,

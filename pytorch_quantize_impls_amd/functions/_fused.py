@@ -143,8 +143,11 @@ def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool]):
 def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
                          weight_q: Optional[torch.Tensor] = None, weight_planes=None,
                          binary_input: Optional[bool] = None, padding_mode: str = "zeros",
-                         weight_triples_fn=None) -> torch.Tensor:
+                         weight_triples_fn=None, epi=None):
     """conv2d(input, Q(weight), bias, ...).
+
+    ``epi`` = (alpha, beta) (inference fusion, layers/fused.py): the conv does not write fp32 but the
+    threshold bits [(conv + bias) * alpha + beta < 0]; returns (BitPlanes NHWC pixel plane, (N, Cout, Ho, Wo)).
 
     Device tensor with +-1 activations, groups == 1, zero padding: NHWC pixel planes -> packed-domain
     im2col -> matrix-core packed GEMM (libqt_hip.so); the result keeps the input's memory format
@@ -160,8 +163,10 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
             wp = weight_planes if isinstance(weight_planes, ops.NibPlanes) else ops.pack_conv_weight_nib(wq, kind)
             N, C, H, W = input.shape
             kh, kw = int(weight.shape[2]), int(weight.shape[3])
-            y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), bias, stride, padding, dilation)
+            y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), bias, stride, padding, dilation, epi=epi)
             Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+            if epi is not None:
+                return y2, (N, int(weight.shape[0]), Ho, Wo)
             y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # NCHW view, NHWC storage
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous()                                         # caller works in NCHW storage
@@ -186,19 +191,28 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
                 ws_shape, wtr = tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")   # zeros stay zeros
             k2 = ws_shape[2]
             y2 = ops.float_conv2d(None, torch.empty(ws_shape, device="meta"), "sign", bias, 1, 0, 1,
-                                  weight_triples=wtr, pixels=px, in_shape=(N, C * sd * sd, Hs, Ws))
+                                  weight_triples=wtr, pixels=px, in_shape=(N, C * sd * sd, Hs, Ws), epi=epi)
             H2, W2 = Hs - k2 + 1, Ws - k2 + 1
+            if epi is not None:
+                if H2 != Ho or W2 != Wo:   # drop the pixels the space-to-depth rounding added
+                    sg = y2.sign.view(N, H2, W2, -1)[:, :Ho, :Wo, :].contiguous().view(N * Ho * Wo, -1)
+                    y2 = ops.BitPlanes(sign=sg, rows=N * Ho * Wo, K=y2.K)
+                return y2, (N, int(weight.shape[0]), Ho, Wo)
             y = y2.view(N, H2, W2, weight.shape[0])[:, :Ho, :Wo, :].permute(0, 3, 1, 2)
             if H2 != Ho or W2 != Wo:
                 y = y.contiguous(memory_format=torch.channels_last)
         else:
             wt = weight_triples_fn("plain") if weight_triples_fn is not None else None
             y2 = ops.float_conv2d(input, weight_q if weight_q is not None else weight, kind, bias, stride, padding,
-                                  dilation, weight_triples=wt)
+                                  dilation, weight_triples=wt, epi=epi)
+            if epi is not None:
+                return y2, (N, int(weight.shape[0]), Ho, Wo)
             y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
         if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous()
         return y
+    if epi is not None:
+        raise ValueError("the threshold-bit epilogue needs a device fp32 NCHW input, groups == 1 and zero padding")
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
@@ -217,9 +231,10 @@ def packed_linear(layer, act, kind: str) -> torch.Tensor:
     return y.view(*act.shape[:-1], N)
 
 
-def packed_conv2d(layer, act, kind: str) -> torch.Tensor:
+def packed_conv2d(layer, act, kind: str, epi=None):
     """Eval-mode BinConv2d / TerConv2d on a PackedActivation (NHWC planes).  Returns a channels_last
-    [N, Cout, Ho, Wo] fp32 tensor."""
+    [N, Cout, Ho, Wo] fp32 tensor, or with ``epi`` = (alpha, beta) the threshold-bit planes and shape
+    (see quant_conv2d_forward)."""
     if layer.training:
         raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
     if layer.groups != 1 or layer.padding_mode != "zeros":
@@ -228,8 +243,11 @@ def packed_conv2d(layer, act, kind: str) -> torch.Tensor:
     wp = layer._eval_planes(lambda _w2: ops.pack_conv_weight_nib(layer.weight.detach(), kind), key="conv_nib")
     kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
     px = ops.bits_to_nib(act.planes, ld=ops.pixel_ld_nib(C))
-    y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), layer.bias, layer.stride, layer.padding, layer.dilation)
+    y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), layer.bias, layer.stride, layer.padding, layer.dilation,
+                        epi=epi)
     Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
+    if epi is not None:
+        return y2, (N, int(layer.weight.shape[0]), Ho, Wo)
     return y2.view(N, Ho, Wo, layer.weight.shape[0]).permute(0, 3, 1, 2)
 
 

@@ -5,4 +5,5 @@ from .dorefa_layers import LinearDorefa, DorefaConv2d
 from .terner_layers import LinearTer, TerConv2d
 from .xnor_layers import LinearXNOR, XNORConv2d
 from .common import QLayer
-from .fused import FusedPoolBnSign, fuse_sequential, fold_batchnorm, permute_fc_weight_hwc
+from .fused import (FusedPoolBnSign, FusedConvPoolBnSign, fuse_sequential, fold_batchnorm,
+                    permute_fc_weight_hwc)

@@ -68,17 +68,87 @@ class FusedPoolBnSign(torch.nn.Module):
         return act.flatten_hwc() if self.flatten_hwc else act
 
 
+class FusedConvPoolBnSign(torch.nn.Module):
+    """BinConv2d / TerConv2d (eval) + [MaxPool2d(k, s)] + eval BatchNorm2d + [Hardtanh] + BinaryConnect(det)
+    -> PackedActivation, with NO fp32 activation in between:
+
+      * the conv runs with the threshold-bit epilogue (qt_conv2d_implicit_bits): per output pixel and
+        channel the bit [(acc + bias) * alpha + beta < 0] — 1/32 of the fp32 tensor;
+      * MaxPool is evaluated on those bits (qt_pool_bits): max-pooling commutes with the monotone map
+        x*alpha + beta, so the pooled sign is the AND (alpha >= 0) / OR (alpha < 0) of the window's bits.
+
+    Bit-identical to conv -> FusedPoolBnSign (and hence to the un-fused chain up to BatchNorm's own
+    evaluation order, see the module docstring) for NaN-free activations.  Input: a PackedActivation, or a
+    real-valued device tensor (first layer; exact bf16-triple conv)."""
+
+    def __init__(self, conv, bn, pool=None, flatten_hwc=False):
+        super().__init__()
+        from .binary_layers import BinConv2d
+        from .terner_layers import TerConv2d
+        if isinstance(conv, BinConv2d):
+            self.kind = "binary"
+        elif isinstance(conv, TerConv2d):
+            self.kind = "ternary"
+        else:
+            raise ValueError("FusedConvPoolBnSign fuses BinConv2d / TerConv2d only")
+        if conv.groups != 1 or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+            raise ValueError("only groups == 1, zero-padded convs can be fused")
+        if not isinstance(bn, torch.nn.BatchNorm2d) or bn.num_features != conv.out_channels:
+            raise ValueError("BatchNorm2d over the conv's output channels expected")
+        self._pool = FusedPoolBnSign(bn, pool)           # validates the pooling geometry, owns the fold cache
+        self.conv, self.bn = conv, bn
+        self.flatten_hwc = flatten_hwc
+        self._neg_alpha = None
+
+    def refold(self):
+        self._pool.refold()
+        self._neg_alpha = None
+
+    def forward(self, x):
+        from ..functions import _fused
+        if self.bn.training or self.conv.training:
+            raise RuntimeError("FusedConvPoolBnSign is an inference module: call .eval() first")
+        conv, fp = self.conv, self._pool
+        dev = conv.weight.device
+        if fp._folded is None or fp._folded[0].device != dev or self._neg_alpha is None:
+            fp._folded = fold_batchnorm(self.bn)
+            self._neg_alpha = ops.neg_alpha_words(fp._folded[0])
+        epi = fp._folded
+        if isinstance(x, packed.PackedActivation):
+            planes, shape = _fused.packed_conv2d(conv, x, self.kind, epi=epi)
+        else:
+            if not (isinstance(x, torch.Tensor) and x.is_cuda):
+                raise TypeError("FusedConvPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
+            wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
+            planes, shape = _fused.quant_conv2d_forward(
+                x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups, self.kind,
+                weight_q=conv.weight, weight_planes=wp, binary_input=conv.binary_input,
+                padding_mode=conv.padding_mode, weight_triples_fn=conv._conv_triples, epi=epi)
+        N, Cout, Ho, Wo = shape
+        if fp.pool_k != 1 or fp.pool_s != 1:
+            planes, (Ho, Wo) = ops.pool_bits(planes, N, Ho, Wo, fp.pool_k, fp.pool_s, self._neg_alpha)
+        act = packed.PackedActivation(planes, (N, Cout, Ho, Wo))
+        return act.flatten_hwc() if self.flatten_hwc else act
+
+
 def _is_det_binary_connect(m):
     return isinstance(m, _FunctionModule) and m.core is BinaryConnectDeterministic
 
 
-def fuse_sequential(seq: torch.nn.Sequential) -> torch.nn.Sequential:
+def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.nn.Sequential:
     """New nn.Sequential where every [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)] run is
-    replaced by one FusedPoolBnSign (sharing the original BatchNorm's parameters)."""
+    replaced by one FusedPoolBnSign (sharing the original BatchNorm's parameters).  With ``fuse_conv`` a
+    BinConv2d / TerConv2d directly in front of such a run joins it (FusedConvPoolBnSign: the conv emits
+    threshold bits, no fp32 activation is written at all)."""
+    from .binary_layers import BinConv2d
+    from .terner_layers import TerConv2d
     mods = list(seq.children())
     out, i = [], 0
     while i < len(mods):
         j = i
+        conv = None
+        if fuse_conv and isinstance(mods[j], (BinConv2d, TerConv2d)) and j + 1 < len(mods):
+            conv, j = mods[j], j + 1
         pool = None
         if isinstance(mods[j], torch.nn.MaxPool2d):
             pool, j = mods[j], j + 1
@@ -88,11 +158,14 @@ def fuse_sequential(seq: torch.nn.Sequential) -> torch.nn.Sequential:
                 j2 += 1
             if j2 < len(mods) and _is_det_binary_connect(mods[j2]):
                 try:
-                    out.append(FusedPoolBnSign(bn, pool))
+                    out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None else FusedPoolBnSign(bn, pool))
                     i = j2 + 1
                     continue
                 except ValueError:
-                    pass
+                    if conv is not None:     # the conv cannot join: keep it, fuse the rest on the next turn
+                        out.append(conv)
+                        i += 1
+                        continue
         out.append(mods[i])
         i += 1
     return torch.nn.Sequential(*out)

@@ -26,8 +26,10 @@ CONV_IMPLICIT = True
 
 
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
-                   ldw_words: int, bias, scale: float, scale_dev, Cout: int) -> Optional[torch.Tensor]:
-    """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back)."""
+                   ldw_words: int, bias, scale: float, scale_dev, Cout: int, epi=None):
+    """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back).
+    ``epi`` = (alpha, beta): threshold-bit epilogue (qt_conv2d_implicit_bits) — returns the BitPlanes of
+    [(acc + bias) * alpha + beta < 0] per output pixel instead of the fp32 result."""
     (sh, sw), (ph, pw), (dh, dw) = geom
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
@@ -35,14 +37,22 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
     if M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32:
         return None
     dev = pixels_words.device
-    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     I = ctypes.c_int64
+    head = (ctypes.c_int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw),
+            I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias), ctypes.c_float(float(scale)),
+            _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None))
+    if epi is not None:
+        alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi, ("alpha", "beta")))
+        if alpha.numel() != Cout or beta.numel() != Cout:
+            raise ValueError(f"alpha/beta must have {Cout} entries")
+        ldb = packed_ld(Cout)
+        plane = torch.zeros((M, ldb), dtype=torch.int32, device=dev)   # words past the last tile column stay 0
+        with torch.cuda.device(dev):
+            _lib.call("qt_conv2d_implicit_bits", *head, _p(alpha), _p(beta), _p(plane), I(ldb), I(Cout), _stream(dev))
+        return BitPlanes(sign=plane, rows=M, K=Cout)
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("qt_conv2d_implicit", ctypes.c_int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw),
-                  I(sh), I(sw), I(ph), I(pw), I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias),
-                  ctypes.c_float(float(scale)),
-                  _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None),
-                  _p(y), I(Cout), I(Cout), _stream(dev))
+        _lib.call("qt_conv2d_implicit", *head, _p(y), I(Cout), I(Cout), _stream(dev))
     return y
 
 
@@ -357,6 +367,31 @@ def _nib_pack(entry: str, x: torch.Tensor, ld: Optional[int] = None) -> NibPlane
     return NibPlanes(words=words, rows=rows, K=K)
 
 
+def neg_alpha_words(alpha: torch.Tensor) -> torch.Tensor:
+    """[packed_ld(C)] int32 words, bit c = (alpha[c] < 0): the AND/OR selector of pool_bits."""
+    planes, _ = sign_pack(_require(alpha, "alpha").reshape(1, -1))
+    return planes.sign.reshape(-1)
+
+
+def pool_bits(planes: BitPlanes, N: int, H: int, W: int, pool_k: int, pool_s: int,
+              neg_alpha: torch.Tensor) -> Tuple[BitPlanes, Tuple[int, int]]:
+    """MaxPool2d(pool_k, pool_s) on threshold bits (qt_pool_bits): AND over the window where alpha >= 0,
+    OR where alpha < 0.  planes: NHWC pixel plane [N*H*W][ld] from the conv's threshold-bit epilogue."""
+    if planes.rows != N * H * W or planes.mask is not None:
+        raise ValueError("pool_bits expects the sign-only pixel plane of an [N, C, H, W] activation")
+    if neg_alpha.numel() != planes.ld or neg_alpha.dtype != torch.int32:
+        raise ValueError("neg_alpha must be neg_alpha_words(alpha) of the same channel count")
+    if pool_k > H or pool_k > W:
+        raise ValueError("pooling window larger than the image")
+    Ho, Wo = (H - pool_k) // pool_s + 1, (W - pool_k) // pool_s + 1
+    out = torch.empty((N * Ho * Wo, planes.ld), dtype=torch.int32, device=planes.device)
+    I = ctypes.c_int64
+    with torch.cuda.device(planes.device):
+        _lib.call("qt_pool_bits", _p(planes.sign), I(N), I(H), I(W), I(planes.ld), I(pool_k), I(pool_s),
+                  _p(neg_alpha), _p(out), _stream(planes.device))
+    return BitPlanes(sign=out, rows=N * Ho * Wo, K=planes.K), (Ho, Wo)
+
+
 def sign_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
     """Nibble plane of safeSign(x) along the last dimension (``ld``: row stride in words, % 4)."""
     return _nib_pack("qt_sign_pack_nib_f32", x, ld)
@@ -599,7 +634,7 @@ def pack_pixels_nib(x: torch.Tensor) -> NibPlanes:
 
 
 def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=None, stride=1,
-               padding=0, dilation=1) -> torch.Tensor:
+               padding=0, dilation=1, epi=None):
     """Quantised conv2d on packed operands.  pixels: NHWC nibble pixel plane of the +-1 activation
     (shape ``in_shape`` = (N, C, H, W)); wplanes: pack_conv_weight_nib(...).  Returns the NHWC result
     as a [N*Ho*Wo, Cout] fp32 matrix."""
@@ -616,9 +651,11 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     bias = _check_bias(bias, Cout, dev)
     if CONV_IMPLICIT:
         y = _conv_implicit(0, pixels.words, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.words,
-                           ldA, bias, 1.0, None, Cout)
+                           ldA, bias, 1.0, None, Cout, epi=epi)
         if y is not None:
             return y
+    if epi is not None:
+        raise ValueError("the threshold-bit epilogue needs the implicit-GEMM conv (shape outside its limits)")
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA), dtype=torch.int32, device=dev)
@@ -751,7 +788,7 @@ def s2d_triple_pack(x: torch.Tensor, s: int, padding) -> Tuple[TriplePlanes, Tup
 
 def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0,
                  dilation=1, weight_triples: Optional[TriplePlanes] = None, pixels: Optional[TriplePlanes] = None,
-                 in_shape=None) -> torch.Tensor:
+                 in_shape=None, epi=None):
     """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
     implicit-GEMM conv on the bf16 matrix cores.  ``pixels``/``in_shape``: pre-built pixel planes (e.g. from
     s2d_triple_pack) instead of x.  Returns NHWC [N*Ho*Wo, Cout]."""
@@ -779,9 +816,11 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     bias = _check_bias(bias, Cout, dev)
     if CONV_IMPLICIT:
         y = _conv_implicit(2, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
-                           1.0, None, Cout)
+                           1.0, None, Cout, epi=epi)
         if y is not None:
             return y
+    if epi is not None:
+        raise ValueError("the threshold-bit epilogue needs the implicit-GEMM conv (shape outside its limits)")
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 2), dtype=torch.int16, device=dev)

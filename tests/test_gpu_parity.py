@@ -815,3 +815,96 @@ def test_packed_state_device_planes_equal_cpu_planes(dev, family):
     y_dev = fresh(x.to(dev)).cpu()
     y_cpu = m(x)
     assert (y_dev - y_cpu).abs().max() <= 1e-5 * y_cpu.abs().max()
+
+
+# ---- conv with the threshold-bit epilogue + pooling on bits (no fp32 activation between binarised layers) ----
+
+@pytest.mark.gpu
+def test_pool_bits_vs_numpy(dev):
+    rng = np.random.default_rng(5)
+    for (N, C, H, W, k, s) in [(2, 40, 7, 9, 3, 2), (1, 192, 13, 13, 3, 2), (3, 33, 6, 6, 2, 2), (2, 64, 5, 5, 3, 1)]:
+        ld = ops.packed_ld(C)
+        bits = rng.integers(0, 2, size=(N, H, W, C), dtype=np.uint8)
+        alpha = rng.standard_normal(C).astype(np.float32)
+        alpha[::7] = 0.0
+        plane, _ = ops.sign_pack(g(np.where(bits.reshape(-1, C) == 1, -1.0, 1.0).astype(np.float32), dev))
+        na = ops.neg_alpha_words(g(alpha, dev))
+        with used("qt_pool_bits"):
+            out, (Ho, Wo) = ops.pool_bits(plane, N, H, W, k, s, na)
+        assert (Ho, Wo) == ((H - k) // s + 1, (W - k) // s + 1) and out.ld == ld
+        win = np.stack([bits[:, i:i + s * Ho:s, j:j + s * Wo:s, :] for i in range(k) for j in range(k)])
+        want = np.where(alpha < 0, win.max(0), win.min(0)).astype(np.uint8)        # OR where alpha < 0, else AND
+        got, _ = ops.sign_pack(g(np.where(want.reshape(-1, C) == 1, -1.0, 1.0).astype(np.float32), dev))
+        assert torch.equal(out.sign, got.sign)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,k,st,pd,pool", [(64, 96, 3, 1, 1, None), (32, 70, 5, 1, 2, (3, 2)), (96, 256, 3, 1, 1, (3, 2)),
+                                                   (64, 192, 3, 2, 1, (2, 2)), (40, 33, 1, 1, 0, None)])
+@pytest.mark.parametrize("kind", ["binary", "ternary"])
+def test_fused_conv_pool_bn_sign_vs_oracle(dev, oracle, Cin, Cout, k, st, pd, pool, kind):
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, FusedConvPoolBnSign, FusedPoolBnSign
+    from pytorch_quantize_impls_amd import packed as pk
+    N, H = 3, 13
+    x = synth.pm1(Cin + Cout, (N, Cin, H, H))
+    w = synth.uniform(Cout + k, (Cout, Cin, k, k), -1.2, 1.2)
+    b = synth.normal(k + 3, (Cout,)) * 2
+    cls = BinConv2d if kind == "binary" else TerConv2d
+    conv = cls(Cin, Cout, k, stride=st, padding=pd).to(dev)
+    conv.weight.data.copy_(g(w, dev)); conv.bias.data.copy_(g(b, dev))
+    conv.eval()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+    bn.running_mean.copy_(g(synth.normal(1, (Cout,)) * 5, dev)); bn.running_var.copy_(g(synth.uniform(2, (Cout,), 1, 60), dev))
+    bn.weight.data.copy_(g(synth.normal(3, (Cout,)), dev)); bn.bias.data.copy_(g(synth.normal(4, (Cout,)), dev))   # negative gammas too
+    mp = torch.nn.MaxPool2d(*pool) if pool else None
+    fused = FusedConvPoolBnSign(conv, bn, mp)
+    xin = g(x, dev).contiguous(memory_format=torch.channels_last)
+    act_in = pk.PackedActivation(ops.sign_pack(xin.permute(0, 2, 3, 1).contiguous())[0], tuple(xin.shape))
+    with torch.no_grad(), used("qt_conv2d_implicit_bits"):
+        act = fused(act_in)                       # packed in, packed out
+        act_t = fused(xin)                        # +-1 fp32 tensor in (detected), packed out
+        two_step = FusedPoolBnSign(bn, mp)(conv(xin)) if Cout % 4 == 0 else None   # fp32 conv output -> pool/BN/sign kernel
+    assert torch.equal(act.planes.sign, act_t.planes.sign) and act.shape == act_t.shape
+    if two_step is not None:                                           # (that kernel needs C % 4 == 0; the bit route does not)
+        assert act.shape == two_step.shape and torch.equal(act.planes.sign, two_step.planes.sign)
+    from pytorch_quantize_impls_amd.layers import fold_batchnorm
+    alpha, beta = (n(t) for t in fold_batchnorm(bn))
+    wq = oracle.safe_sign(w) if kind == "binary" else oracle.ternarize(w)
+    want, (Ho, Wo) = oracle.bin_conv_pool_bn_sign_planes(x, wq, b, st, pd, 1, alpha, beta, *(pool or (1, 1)))
+    assert act.shape == (N, Cout, Ho, Wo)
+    assert np.array_equal(n(act.planes.sign).view(np.uint32), want)    # and to the CPU restatement of the chain
+
+
+@pytest.mark.gpu
+def test_fused_first_layer_conv_bits_match_fp32_route(dev):
+    """Real-valued input (bf16-triple conv, space-to-depth form): the threshold-bit epilogue sees the same
+    accumulators as the fp32 epilogue, so the planes must equal conv -> FusedPoolBnSign exactly."""
+    from pytorch_quantize_impls_amd.layers import BinConv2d, FusedConvPoolBnSign, FusedPoolBnSign
+    torch.manual_seed(3)
+    for (Cin, Cout, k, st, pd, HW, pool) in [(3, 192, 11, 4, 2, 67, (3, 2)), (3, 64, 3, 1, 1, 20, None), (3, 40, 5, 2, 2, 31, (2, 2))]:
+        conv = BinConv2d(Cin, Cout, k, stride=st, padding=pd).to(dev).eval()
+        bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 30); bn.weight.data.normal_(); bn.bias.data.normal_()
+        mp = torch.nn.MaxPool2d(*pool) if pool else None
+        x = torch.randn((2, Cin, HW, HW), device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad(), used("qt_conv2d_implicit_bits"):
+            act = FusedConvPoolBnSign(conv, bn, mp)(x)
+            ref = FusedPoolBnSign(bn, mp)(conv(x))
+        assert act.shape == ref.shape and torch.equal(act.planes.sign, ref.planes.sign)
+
+
+@pytest.mark.gpu
+def test_fused_alexnet_conv_bits_equals_fp32_fusion(dev):
+    import bench_models
+    torch.manual_seed(9)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn((4, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad(), used("qt_conv2d_implicit_bits", "qt_pool_bits"):
+        y_bits = bench_models.FusedAlexNetBin(model, fuse_conv=True)(x)
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        y_f32 = bench_models.FusedAlexNetBin(model, fuse_conv=False)(x)
+    assert _lib.call_counts["qt_conv2d_implicit_bits"] == before["qt_conv2d_implicit_bits"]
+    assert torch.equal(y_bits, y_f32)
