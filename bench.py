@@ -36,8 +36,8 @@ EVENT_EVERY = 5                 # GEMM launches bracketed by HIP events: every 5
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="rows per GPU")
     ap.add_argument("--in-features", type=int, default=4096)
     ap.add_argument("--out-features", type=int, default=4096)

@@ -169,8 +169,8 @@ struct GemmCfg {
     static constexpr int LDS_BYTES = NBUF * BUF + (PIPE_ == 2 ? 64 : 0);  // + the waves' SIMD ids (ping-pong)
     static_assert(PIPE_ != 2 || (SB_ == 64 && NWAVES == 8), "ping-pong: 64-byte stages, two waves per SIMD");
     static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
-    static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && TN % (ROWS_PER_PIECE * NWAVES) == 0,
-                  "DMA pieces divide evenly over the waves");
+    static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && (TN % (ROWS_PER_PIECE * NWAVES) == 0 || PIPE_ == 2),
+                  "DMA pieces divide evenly over the waves (ping-pong: W pieces may wrap)");
 };
 
 template <class C>
@@ -245,7 +245,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 
     if constexpr (C::PIPE >= 1) {
         // ---- pipelined main loops (asm-issued DMA) ----------------------------------------------
-        constexpr int XP = C::TM / RPP / C::NWAVES, WP = C::TN / RPP / C::NWAVES;  // DMA pieces per wave
+        // DMA pieces per wave.  When the W tile's pieces do not divide over the waves (ping-pong tiles 192 /
+        // 64 wide) the piece index wraps: the surplus waves re-load a piece (same bytes to the same LDS
+        // address), which keeps every wave's outstanding-DMA count — and so its vmcnt immediates — equal.
+        constexpr int WPIECES = C::TN / RPP;
+        constexpr int XP = C::TM / RPP / C::NWAVES, WP = (WPIECES + C::NWAVES - 1) / C::NWAVES;
         constexpr int NP = XP + WP;
         const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
         const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         }
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
-            const int row = (j * C::NWAVES + uwave) * RPP + rsub;
+            const int row = ((j * C::NWAVES + uwave) % WPIECES) * RPP + rsub;
             voffw[j] = (unsigned)(min(n0 + row, N - 1) * ldw_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
         }
         // implicit conv: tap coordinates of this lane's chunk in stage s (shared by all its X pieces)
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 }
             } else {
                 const int jw = j - XP;
-                const unsigned dst = ldsbuf + C::X_STAGE + ((jw * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
+                const unsigned dst = ldsbuf + C::X_STAGE + (((jw * C::NWAVES + uwave) % WPIECES) * RPP) * STAGE_BYTES;
                 glds16_asm(Wb + (int64_t)s * STAGE_BYTES, voffw[jw >= 0 && jw < WP ? jw : 0],
                            __builtin_amdgcn_readfirstlane(dst));
             }
@@ -614,6 +618,12 @@ template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 2
 // ping-pong configurations (64-byte stages, ring of 4)
 template <class E, int ABL = 0> using PP256 = GemmCfg<E, 2, 4, 4, 2, 2, ABL, 64, false>;
 template <class E> using PP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, false>;
+template <class E> using PP192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, false>;
+template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
+template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, true>;
+template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, true>;
+template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, true>;
+template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, true>;
 
 // implicit-conv configurations (pipelined kernel only)
 template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
@@ -658,7 +668,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
             const int tn = pick_tile_n(N);
             if (pipe_ok) {
                 if (tn == 256) QT_GO(PP256<E>);
-                if (tn == 192) QT_GO(Cfg192<E, 1>);
+                if (tn == 192) QT_GO(PP192<E>);
                 if (tn == 128) QT_GO(PP128<E>);
                 QT_GO(Cfg64<E, 1>);
             }
@@ -679,6 +689,8 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
         case 166: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 6>);
         case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
+        case 22: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP192<E>);
+        case 23: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP64<E>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
         case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);
         case 163: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 3>);
@@ -848,6 +860,11 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 
+// qt_conv_force_kernel: 0 = automatic (= double-buffered: in conv mode the per-piece tap arithmetic makes the
+// ping-pong load segment longer than its compute segment; measured 3-7 % slower on the AlexNet convs),
+// 1 = double-buffered, 2 = ping-pong
+static int g_conv_force = 0;
+
 // elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes.  epi.alpha != nullptr:
 // Y is the threshold-bit plane and ldy its row stride in words.
 static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
@@ -879,6 +896,12 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
+        if (g_conv_force == 2) {                                                                                \
+            if (tn == 256) return launch_cfg<ConvPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (tn == 192) return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (tn == 128) return launch_cfg<ConvPP128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            return launch_cfg<ConvPP64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);                 \
+        }                                                                                                       \
         if (tn == 256) return launch_cfg<Conv256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (tn == 192) return launch_cfg<Conv192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (tn == 128) return launch_cfg<Conv128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
@@ -888,6 +911,12 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (elem == 1) QT_CONV(ElemI8);
     QT_CONV(ElemBf16);
 #undef QT_CONV
+}
+
+int qt_conv_force_kernel(int which) {
+    if (which < 0 || which > 2) return QT_ERR_INVALID_ARG;
+    g_conv_force = which;
+    return QT_OK;
 }
 
 int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,

@@ -908,3 +908,25 @@ def test_fused_alexnet_conv_bits_equals_fp32_fusion(dev):
         y_f32 = bench_models.FusedAlexNetBin(model, fuse_conv=False)(x)
     assert _lib.call_counts["qt_conv2d_implicit_bits"] == before["qt_conv2d_implicit_bits"]
     assert torch.equal(y_bits, y_f32)
+
+
+@pytest.mark.gpu
+def test_conv_ping_pong_kernels_equal_double_buffered(dev):
+    """qt_conv_force_kernel(2): the ping-pong main loop (ring of 4 64-byte stages, wrapped W pieces for the
+    192- and 64-wide tiles) must reproduce the default conv kernels bit for bit, all four tile widths."""
+    import ctypes
+    from pytorch_quantize_impls_amd.layers import BinConv2d
+    try:
+        for (Cin, Cout, k, st, pd, H) in [(64, 256, 3, 1, 1, 13), (96, 192, 5, 1, 2, 14), (32, 128, 3, 2, 1, 17), (64, 40, 1, 1, 0, 9),
+                                          (3, 192, 11, 4, 2, 67)]:
+            conv = BinConv2d(Cin, Cout, k, stride=st, padding=pd).to(dev).eval()
+            x = g(synth.pm1(Cin + H, (3, Cin, H, H)) if Cin > 3 else synth.normal(7, (3, Cin, H, H)), dev)
+            x = x.contiguous(memory_format=torch.channels_last)
+            outs = []
+            for which in (1, 2):
+                _lib.call("qt_conv_force_kernel", ctypes.c_int(which))
+                with torch.no_grad(), used("qt_conv2d_implicit"):
+                    outs.append(conv(x).clone())
+            assert torch.equal(outs[0], outs[1]), (Cin, Cout, k)
+    finally:
+        _lib.call("qt_conv_force_kernel", ctypes.c_int(0))
