@@ -43,6 +43,10 @@ class AlexNetBin(nn.Module):
             nn.LogSoftmax(dim=1),
         )
 
+        # the first layer sees real pixels: tell it so (binary_input hint of the layers), which skips the
+        # +-1 detection of un-tagged inputs and its host sync
+        self.features[0].binary_input = False
+
     def clip(self):
         for layer in self.modules():
             if isinstance(layer, (BinConv2d, LinearBin)):
