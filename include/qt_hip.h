@@ -267,7 +267,8 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
                        qt_stream_t stream);
 
 /* Tuning / test hook (process-global, not thread-safe): main loop of the implicit-GEMM conv kernels:
- * 0 = automatic (currently the double-buffered pipelined kernel), 1 = double-buffered, 2 = ping-pong. */
+ * 0 = automatic (ping-pong 384x192 tile for 192-wide column tiles, double-buffered otherwise),
+ * 1 = double-buffered, 2 = ping-pong. */
 int qt_conv_force_kernel(int which);
 
 /* Same conv with the threshold-bit epilogue (inference fusion of
@@ -294,7 +295,7 @@ int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int6
  * 0 = automatic (what qt_nib_gemm does: tile width 256/192/128/64 by N; an asm-DMA kernel when row
  * strides are % 32 words and operands < 2 GiB, else the generic builtin-DMA kernel);
  * 20/21/22/23 = ping-pong kernel (64-byte stages, ring of 4, SIMD partners alternate load / compute
- * segments), tile 256x256 / 256x128 / 256x192 / 256x64; 6/7/8/15 = double-buffered pipelined kernel, tile 256x256 /
+ * segments), tile 256x256 / 256x128 / 256x192 / 256x64, 24 = ping-pong 384x192; 6/7/8/15 = double-buffered pipelined kernel, tile 256x256 /
  * 256x128 / 256x64 / 256x192 (QT_ERR_ALIGNMENT if the contract does not hold); 5/9/10/16 = generic
  * kernel with the same tiles; 161..164 = profiling ablations of 6 (no MFMA / no DMA / epilogue only /
  * no LDS reads) and 165 / 166 = ping-pong with per-segment + phase / phase-only stamps written over Y (results are NOT valid). */

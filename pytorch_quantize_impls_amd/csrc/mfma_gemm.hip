@@ -273,7 +273,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 const int ho = rem / cg.Wo, wo = rem - ho * cg.Wo;
                 ch0[j] = ho * cg.sh - cg.ph;
                 cw0[j] = wo * cg.sw - cg.pw;
-                cpix[j] = ((long long)n * cg.H + ch0[j]) * cg.W + cw0[j];
+                // byte address of chunk 0 of the window's top-left pixel (may lie before the plane: only
+                // dereferenced for in-range taps)
+                cpix[j] = (long long)(uintptr_t)Xb + ((((long long)n * cg.H + ch0[j]) * cg.W + cw0[j]) * cg.cpp) * 16;
                 voffx[j] = 0;
             } else {
                 voffx[j] = (unsigned)(min(m0 + row, M - 1) * ldx_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
@@ -285,16 +287,20 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             voffw[j] = (unsigned)(min(n0 + row, N - 1) * ldw_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
         }
         // implicit conv: tap coordinates of this lane's chunk in stage s (shared by all its X pieces)
-        int tap_i = 0, tap_j = 0, tap_sub = 0;
+        // per stage: the tap's row / column displacement and its byte offset from the window's top-left chunk
+        int tap_di = 0, tap_dj = 0, tap_boff = 0;
         bool tap_ok = false;
+        const long long zero_addr = (long long)(uintptr_t)zero16_storage;
         auto conv_stage = [&](int s) {
             const unsigned q = (unsigned)(s * CH + lchunk);
             const unsigned tap = cg.cpp == 1 ? q : __umulhi(q, cg.magic_cpp);
-            tap_sub = (int)(q - tap * cg.cpp);
+            const int tap_sub = (int)(q - tap * cg.cpp);
             const unsigned ti = cg.kw == 1 ? tap : __umulhi(tap, cg.magic_kw);
-            tap_i = (int)ti;
-            tap_j = (int)(tap - ti * cg.kw);
-            tap_ok = tap_i < cg.kh;
+            const int tj = (int)(tap - ti * cg.kw);
+            tap_di = (int)ti * cg.dh;
+            tap_dj = tj * cg.dw;
+            tap_ok = (int)ti < cg.kh;
+            tap_boff = ((tap_di * cg.W + tap_dj) * cg.cpp + tap_sub) * 16;   // < 2^31: host checks H*W*cpp*16
         };
         auto issue_piece = [&](int j, int s, int buf) {  // j is a compile-time constant after unrolling
             const unsigned ldsbuf = lds0 + buf * BUF;
@@ -302,11 +308,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 const unsigned dst = ldsbuf + ((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
                 if constexpr (C::CONV) {
                     const int jj = j < XP ? j : 0;
-                    const int hi = ch0[jj] + tap_i * cg.dh, wi = cw0[jj] + tap_j * cg.dw;
-                    const bool ok = tap_ok && hi >= 0 && hi < cg.H && wi >= 0 && wi < cg.W;
-                    const long long pix = cpix[jj] + (long long)tap_i * cg.dh * cg.W + tap_j * cg.dw;
-                    const unsigned char* src = ok ? Xb + (pix * cg.cpp + tap_sub) * 16 : zero16_storage;
-                    glds16_asm64(src, __builtin_amdgcn_readfirstlane(dst));
+                    const unsigned hi = (unsigned)(ch0[jj] + tap_di), wi = (unsigned)(cw0[jj] + tap_dj);
+                    const bool ok = tap_ok & (hi < (unsigned)cg.H) & (wi < (unsigned)cg.W);   // unsigned: < 0 wraps high
+                    const long long a = cpix[jj] + tap_boff;
+                    const long long src = ok ? a : zero_addr;          // two v_cndmask, no branch
+                    glds16_asm64(reinterpret_cast<const unsigned char*>(src), __builtin_amdgcn_readfirstlane(dst));
                 } else {
                     glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], __builtin_amdgcn_readfirstlane(dst));
                 }
@@ -619,9 +625,10 @@ template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 2
 template <class E, int ABL = 0> using PP256 = GemmCfg<E, 2, 4, 4, 2, 2, ABL, 64, false>;
 template <class E> using PP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, false>;
 template <class E> using PP192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, false>;
+template <class E> using PP384x192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, false>;   // wave tile 96x96: 6 fragment reads per 9 MFMAs
 template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
 template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, true>;
-template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, true>;
+template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, true>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
 template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, true>;
 template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, true>;
 
@@ -641,6 +648,16 @@ int pick_tile_n(int64_t N) {
         if (pad < best_pad) { best = c; best_pad = pad; }
     }
     return best;
+}
+
+// 192-wide column tiles come with 256 or 384 rows.  The 384-row tile does 50 % more work per workgroup at a
+// better MFMA : fragment-read ratio; it wins unless it leaves CUs idle (fewer tiles than the 256 CUs) or adds a
+// partial round.  Cost model: rounds of 256 concurrent workgroups x rows per tile; ties go to 384.
+bool prefer_384_rows(int64_t M, int64_t N) {
+    const int64_t nt = (N + 191) / 192;
+    const int64_t c256 = (((M + 255) / 256) * nt + 255) / 256 * 256;
+    const int64_t c384 = (((M + 383) / 384) * nt + 255) / 256 * 384;
+    return c384 <= c256;
 }
 
 int check_common(const void* Xn, int64_t ldxp, const void* Wn, int64_t ldwp, const float* Y, int64_t ldy,
@@ -668,6 +685,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
             const int tn = pick_tile_n(N);
             if (pipe_ok) {
                 if (tn == 256) QT_GO(PP256<E>);
+                if (tn == 192 && prefer_384_rows(M, N)) QT_GO(PP384x192<E>);
                 if (tn == 192) QT_GO(PP192<E>);
                 if (tn == 128) QT_GO(PP128<E>);
                 QT_GO(Cfg64<E, 1>);
@@ -691,6 +709,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
         case 22: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP192<E>);
         case 23: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP64<E>);
+        case 24: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP384x192<E>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
         case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);
         case 163: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 3>);
@@ -860,9 +879,9 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 
-// qt_conv_force_kernel: 0 = automatic (= double-buffered: in conv mode the per-piece tap arithmetic makes the
-// ping-pong load segment longer than its compute segment; measured 3-7 % slower on the AlexNet convs),
-// 1 = double-buffered, 2 = ping-pong
+// qt_conv_force_kernel: 0 = automatic (192-wide tiles: ping-pong on a 384x192 tile, whose 96x96 wave tiles
+// keep the load segment under the compute segment: AlexNet conv2 302 -> 275 us; other widths: double-buffered,
+// equal or faster there), 1 = double-buffered, 2 = ping-pong
 static int g_conv_force = 0;
 
 // elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes.  epi.alpha != nullptr:
@@ -882,7 +901,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (!P || !Wmat || !Y || ldy < (epi.alpha ? (Cout + 31) / 32 : Cout)) return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
-    if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767)
+    if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767 ||
+        H * W * Cw * 4 >= (1ll << 31))   // per-image plane bytes: 32-bit tap offsets
         return QT_ERR_UNSUPPORTED;
     const int64_t kbytes = kwords * 4;
     const int64_t K = elem == 0 ? kbytes * 2 : (elem == 1 ? kbytes : kbytes / 2);   // elements
@@ -896,6 +916,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
+        if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
+            return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 2) {                                                                                \
             if (tn == 256) return launch_cfg<ConvPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 192) return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \

@@ -34,7 +34,8 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
     M = N * Ho * Wo
-    if M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32:
+    if (M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32
+            or H * W * Cw * 4 >= (1 << 31)):
         return None
     dev = pixels_words.device
     I = ctypes.c_int64

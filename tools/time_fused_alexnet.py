@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import bench_models
 dev = torch.device("cuda:0")
+if os.environ.get("CONV_FORCE"):
+    import ctypes
+    from pytorch_quantize_impls_amd import _lib
+    _lib.call("qt_conv_force_kernel", ctypes.c_int(int(os.environ["CONV_FORCE"])))
 torch.manual_seed(0)
 model = bench_models.AlexNetBin(); bench_models.randomize_bn(model)
 model = model.to(dev).to(memory_format=torch.channels_last).eval()
