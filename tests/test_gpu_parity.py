@@ -227,7 +227,7 @@ NIB_GEMM_SHAPES = GEMM_SHAPES + [(256, 256, 256), (512, 256, 4096), (255, 257, 3
 
 
 @pytest.mark.parametrize("M,N,K", NIB_GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [None, 5, 6, 7, 8, 9, 10, 15, 16])
+@pytest.mark.parametrize("variant", [None, 5, 6, 7, 8, 9, 10, 15, 16, 20, 21, 22, 23, 24])
 def test_nib_gemm_vs_oracle(dev, oracle, M, N, K, variant):
     x = synth.pm1(M * 7 + K, (M, K))
     w = synth.uniform(N * 5 + K, (N, K), -1.5, 1.5)
@@ -247,7 +247,7 @@ def test_nib_gemm_equals_popcount_gemm_large(dev):
     x = torch.randn((1000, 5000), device=dev, generator=gen)
     w = torch.randn((777, 5000), device=dev, generator=gen)
     ref = ops.xnor_gemm(ops.sign_pack(x)[0], ops.sign_pack(w)[0])
-    for variant in (None, 5, 6, 7, 8, 9, 10, 15, 16):
+    for variant in (None, 5, 6, 7, 8, 9, 10, 15, 16, 20, 21, 22, 23, 24):
         assert torch.equal(ops.nib_gemm(ops.sign_pack_nib(x), ops.sign_pack_nib(w), variant=variant), ref)
     reft = ops.tern_gemm(ops.sign_pack(x)[0], ops.ternary_pack(w))
     assert torch.equal(ops.nib_gemm(ops.bits_to_nib(ops.sign_pack(x)[0]), ops.bits_to_nib(ops.ternary_pack(w))), reft)
