@@ -650,6 +650,16 @@ int pick_tile_n(int64_t N) {
     return best;
 }
 
+// GEMM tile width: the padding-minimal width, narrowed while the launch would leave most of the 256 CUs
+// without a tile (a workgroup walks the whole K loop alone, so a 256x4096x9216 problem on 16 wide tiles
+// takes 50 us and on 64 narrow ones 24 us).
+int pick_tile_n_gemm(int64_t M, int64_t N) {
+    int tn = pick_tile_n(N);
+    const int64_t mt = (M + 255) / 256;
+    while (tn > 64 && mt * ((N + tn - 1) / tn) < 160) tn = tn == 256 ? 128 : 64;
+    return tn;
+}
+
 // 192-wide column tiles come with 256 or 384 rows.  The 384-row tile does 50 % more work per workgroup at a
 // better MFMA : fragment-read ratio; it wins unless it leaves CUs idle (fewer tiles than the 256 CUs) or adds a
 // partial round.  Cost model: rounds of 256 concurrent workgroups x rows per tile; ties go to 384.
@@ -681,8 +691,8 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
                          N * ldwp * 4 < (1ll << 31);
 #define QT_GO(...) return launch_cfg<__VA_ARGS__>(Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream)
     switch (variant) {
-        case 0: {  // automatic: tile width by N, fast path when its contract holds
-            const int tn = pick_tile_n(N);
+        case 0: {  // automatic: tile width by N and CU fill, fast path when its contract holds
+            const int tn = pick_tile_n_gemm(M, N);
             if (pipe_ok) {
                 if (tn == 256) QT_GO(PP256<E>);
                 if (tn == 192 && prefer_384_rows(M, N)) QT_GO(PP384x192<E>);

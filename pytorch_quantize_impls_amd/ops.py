@@ -869,19 +869,19 @@ def s2d_input(x: torch.Tensor, s: int, padding) -> torch.Tensor:
 
 GEMM_IMPLS = ("valu", "mfma")
 
-#: 'auto' thresholds (tools/bench_crossover.py, MI355X): the matrix-core kernel works on 256-row x
-#: {256,192,128,64}-column tiles, one tile per CU walking the whole K loop, plus a ~10 us fixed cost and (for
-#: tagged activations) a bits->nibble expansion launch.  It only wins when the problem fills the chip AND is
-#: long: otherwise the popcount kernels (tiled / skinny, 4x less operand traffic) are faster.
-MFMA_MIN_TILES, MFMA_MIN_OPS = 64, 3.0e10
+#: 'auto' thresholds (tools/bench_crossover.py, MI355X).  The matrix-core route costs two launches for tagged
+#: activations (bits -> nibbles, GEMM) and a workgroup walks its whole K loop alone, so it has a floor of
+#: ~30 us end to end; the popcount kernels (tiled / skinny, 4x less operand traffic) start at ~20 us and grow
+#: with the work.  Measured crossover: the MFMA route wins from ~8e9 ops when K is long (256x4096x4096: 33 vs
+#: 38 us, 256x4096x9216: 47 vs 67 us, 2048^3: 31 vs 38 us) and from ~3e10 ops regardless (4096^3: 36 vs 148 us).
+MFMA_MIN_OPS_LONG_K, MFMA_LONG_K, MFMA_MIN_OPS = 8.0e9, 2048, 3.0e10
 
 
 def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
     """'auto' -> the faster formulation for the shape (both are bit-exact)."""
     if requested == "auto":
-        tn = min((256, 192, 128, 64), key=lambda c: ((N + c - 1) // c * c, -c))
-        tiles = ((M + 255) // 256) * ((N + tn - 1) // tn)
-        big = tiles >= MFMA_MIN_TILES and 2.0 * M * N * K >= MFMA_MIN_OPS and K < (1 << 24)
+        ops_ = 2.0 * M * N * K
+        big = (ops_ >= MFMA_MIN_OPS or (ops_ >= MFMA_MIN_OPS_LONG_K and K >= MFMA_LONG_K)) and K < (1 << 24)
         return "mfma" if big else "valu"
     if requested not in GEMM_IMPLS:
         raise NotImplementedError(f"packed GEMM formulation {requested!r} is not built "

@@ -255,7 +255,8 @@ def test_nib_gemm_equals_popcount_gemm_large(dev):
 
 def test_layers_route_large_shapes_to_mfma(dev, oracle):
     assert ops.select_gemm_impl("auto", 4096, 4096, 4096) == "mfma"
-    assert ops.select_gemm_impl("auto", 256, 4096, 4096) == "valu" and ops.select_gemm_impl("auto", 4096, 10, 4096) == "valu"
+    assert ops.select_gemm_impl("auto", 256, 4096, 4096) == "mfma" and ops.select_gemm_impl("auto", 4096, 10, 4096) == "valu"
+    assert ops.select_gemm_impl("auto", 1024, 4096, 1024) == "valu" and ops.select_gemm_impl("auto", 128, 512, 784) == "valu"
     from pytorch_quantize_impls_amd.functions import _fused
     _fused.GEMM_IMPL = "mfma"      # small shapes below: force the formulation under test
     try:

@@ -17,7 +17,8 @@ def t(fn, n=20):
 
 for (M, N, K) in [(4096, 32, 4096), (4096, 64, 4096), (4096, 128, 4096), (4096, 192, 4096), (64, 4096, 4096),
                   (128, 4096, 4096), (192, 4096, 4096), (256, 4096, 4096), (512, 4096, 4096), (1024, 1024, 1024),
-                  (256, 256, 4096), (4096, 4096, 128), (4096, 4096, 256), (4096, 4096, 512), (256, 4096, 9216)]:
+                  (256, 256, 4096), (4096, 4096, 128), (4096, 4096, 256), (4096, 4096, 512), (256, 4096, 9216),
+                  (256, 10, 4096), (256, 1000, 4096), (32, 4096, 4096), (8, 4096, 4096), (1024, 4096, 1024), (2048, 2048, 2048), (512, 512, 512), (128, 512, 784)]:
     x = torch.randn((M, K), device=dev); w = torch.randn((N, K), device=dev)
     xb, wb = ops.sign_pack(x)[0], ops.sign_pack(w)[0]
     wn = ops.sign_pack_nib(w)
