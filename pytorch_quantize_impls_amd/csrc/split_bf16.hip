@@ -111,6 +111,83 @@ __global__ __launch_bounds__(256) void s2d_triple_kernel(const float* __restrict
     }
 }
 
+
+// Same result, organised for the memory system (channels-last images: sC == 1, sW == C): one workgroup per
+// output row (n, Y).  Phase 1 copies the s input rows the row needs into LDS with full-line coalesced
+// loads (rows outside the image become zeros); phase 2 produces the output row 16 bytes per lane per step
+// (fully coalesced dwordx4 stores), gathering its up-to-4 source values from LDS through a per-workgroup
+// table e -> (LDS offset, column displacement) so no per-element division is left.  A 16-byte chunk holds
+// bf16 positions p0 .. p0+7 with p0 = 8*cq; its alignment against the 3-term triples has three phases.
+__device__ __forceinline__ void split3(float v, uint32_t (&t)[3]) {
+    t[0] = bf16_rn_bits(v);
+    const float r1 = v - bf16_bits_to_f32(t[0]);
+    t[1] = bf16_rn_bits(r1);
+    t[2] = bf16_rn_bits(r1 - bf16_bits_to_f32(t[1]));
+}
+
+__global__ __launch_bounds__(256) void s2d_triple_rows_kernel(const float* __restrict__ x, int64_t sN, int64_t sH,
+                                                              uint16_t* __restrict__ out, int64_t ld_bytes,
+                                                              int C, int H, int W, int s, int ph, int pw, int Hs,
+                                                              int Ws, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2d_smem[];
+    const int E = C * s * s, rowf = W * C, rowf4 = (rowf + 3) & ~3;
+    float* rows = reinterpret_cast<float*>(s2d_smem);                     // [s][rowf4]
+    int* lut_off = reinterpret_cast<int*>(rows + (size_t)s * rowf4);      // [E] dy*rowf4 + (dx - pw)*C + c
+    int* lut_dx = lut_off + E;                                            // [E] dx - pw
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / Hs, Y = blockIdx.x - n * Hs;
+    for (int e = tid; e < E; e += 256) {
+        const int c = e / (s * s), r = e - c * s * s, dy = r / s, dx = r - dy * s;
+        lut_off[e] = dy * rowf4 + (dx - pw) * C + c;
+        lut_dx[e] = dx - pw;
+    }
+    for (int dy = 0; dy < s; ++dy) {
+        const int hh = s * Y + dy - ph;
+        const bool ok = hh >= 0 && hh < H;
+        const float* src = x + (int64_t)n * sN + (int64_t)(ok ? hh : 0) * sH;
+        float* dst = rows + dy * rowf4;
+        if (vec_ok) {
+            for (int i = tid * 4; i < rowf; i += 1024)
+                *reinterpret_cast<float4*>(dst + i) = ok ? *reinterpret_cast<const float4*>(src + i) : make_float4(0, 0, 0, 0);
+        } else {
+            for (int i = tid; i < rowf; i += 256) dst[i] = ok ? src[i] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int cpp = (int)(ld_bytes >> 4), total = Ws * cpp;
+    uint4* orow = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + ((int64_t)blockIdx.x * Ws) * ld_bytes);
+    for (int q = tid; q < total; q += 256) {
+        const int X = q / cpp, cq = q - X * cpp;
+        const int p0 = cq * 8;
+        const int e0 = (int)(((unsigned)p0 * 43691u) >> 17);      // p0 / 3 (exact for p0 < 98304)
+        const int ph3 = p0 - 3 * e0;                              // 0, 1, 2: first position's term index
+        const int base = s * X * C, wx = s * X;
+        uint32_t t[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j;
+            float v = 0.0f;
+            if (e < E) {
+                const int ww = wx + lut_dx[e];
+                if ((unsigned)ww < (unsigned)W) v = rows[lut_off[e] + base];
+            }
+            split3(v, t[j]);
+        }
+        uint4 o;
+        if (ph3 == 0) {
+            o.x = t[0][0] | (t[0][1] << 16); o.y = t[0][2] | (t[1][0] << 16);
+            o.z = t[1][1] | (t[1][2] << 16); o.w = t[2][0] | (t[2][1] << 16);
+        } else if (ph3 == 1) {
+            o.x = t[0][1] | (t[0][2] << 16); o.y = t[1][0] | (t[1][1] << 16);
+            o.z = t[1][2] | (t[2][0] << 16); o.w = t[2][1] | (t[2][2] << 16);
+        } else {
+            o.x = t[0][2] | (t[1][0] << 16); o.y = t[1][1] | (t[1][2] << 16);
+            o.z = t[2][0] | (t[2][1] << 16); o.w = t[2][2] | (t[3][0] << 16);
+        }
+        orow[q] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW,
@@ -124,6 +201,16 @@ extern "C" int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, in
     if (H > 32767 || W > 32767 || E > 4096) return QT_ERR_UNSUPPORTED;
     const int64_t Hs = (H + 2 * ph + s - 1) / s, Ws = (W + 2 * pw + s - 1) / s;
     const int64_t ld_elems = ld_bytes / 2;
+    // channels-last images take the row-staged kernel (coalesced on both sides)
+    const int64_t rowf4 = (W * C + 3) & ~3ll;
+    const int64_t lds = s * rowf4 * 4 + E * 8;
+    if (sC == 1 && sW == C && lds <= 60 * 1024 && N * Hs < (1ll << 31) && ld_bytes / 2 < 98304 && sH >= W * C) {
+        const int vec_ok = ((W * C) % 4 == 0) && qt_aligned16(x) && (sH % 4 == 0) && (sN % 4 == 0);
+        hipLaunchKernelGGL(s2d_triple_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds,
+                           (hipStream_t)stream, x, sN, sH, out, ld_bytes, (int)C, (int)H, (int)W, (int)s, (int)ph,
+                           (int)pw, (int)Hs, (int)Ws, vec_ok);
+        return qt_check_launch();
+    }
     const int64_t total = N * Hs * Ws * (ld_elems / 6 + 1);
     const int grid = qt_stream_grid((total + 255) / 256);
     hipLaunchKernelGGL(s2d_triple_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, sN, sC, sH, sW,

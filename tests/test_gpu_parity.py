@@ -931,3 +931,19 @@ def test_conv_ping_pong_kernels_equal_double_buffered(dev):
             assert torch.equal(outs[0], outs[1]), (Cin, Cout, k)
     finally:
         _lib.call("qt_conv_force_kernel", ctypes.c_int(0))
+
+
+@pytest.mark.gpu
+def test_s2d_triple_pack_row_staged_kernel_equals_generic(dev):
+    """Channels-last images take the LDS-staged kernel, NCHW storage the generic gather: identical planes
+    (incl. zero padding rows/columns, ragged sizes, the non-vectorisable W*C % 4 != 0 case)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    for (N, C, H, W, s, pad) in [(2, 3, 224, 224, 4, 2), (3, 3, 33, 35, 2, 3), (2, 1, 20, 23, 3, 1), (1, 4, 17, 9, 2, 0), (2, 3, 31, 30, 4, (1, 2))]:
+        x = torch.randn((N, C, H, W), device=dev, generator=gen)
+        xl = x.contiguous(memory_format=torch.channels_last)
+        with used("qt_bf16x3_s2d_pack_f32"):
+            a, hw_a = ops.s2d_triple_pack(xl, s, pad)
+            b, hw_b = ops.s2d_triple_pack(x.contiguous(), s, pad)
+        assert hw_a == hw_b and a.data.shape == b.data.shape
+        assert torch.equal(a.data, b.data), (N, C, H, W, s, pad)
