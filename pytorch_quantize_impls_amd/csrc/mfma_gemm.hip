@@ -91,6 +91,25 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 
+// Lean forms for the ping-pong load segment, where the wave's instruction count IS the segment length (an
+// in-order wave issues one instruction per ~6-10 cycles beside its partner's MFMA stream): M0 is written
+// directly by the SALU add and NOT restored per piece — the caller brackets the whole run of pieces with
+// m0_save() / m0_restore().
+__device__ __forceinline__ unsigned m0_save() {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+    return keep;
+}
+__device__ __forceinline__ void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
+__device__ __forceinline__ void glds16_lean(const unsigned char* sbase, unsigned voff, unsigned lds_a, unsigned lds_b) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b) : "memory", "scc");
+}
+__device__ __forceinline__ void glds16_lean64(const unsigned char* src, unsigned lds_a, unsigned lds_b) {
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_a), "s"(lds_b) : "memory", "scc");
+}
+
 // Implicit-GEMM conv: the X operand is not a matrix but the NHWC pixel plane P[N][H][W][cpp*16 bytes];
 // row m = (n, ho, wo), K byte index = ((i*kw + j)*cpp + sub)*16 + byte: chunk q of a row is 16 bytes of
 // pixel (ho*sh - ph + i*dh, wo*sw - pw + j*dw) or zeros when that pixel is padding / q is past the taps.
@@ -302,25 +321,29 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             tap_ok = (int)ti < cg.kh;
             tap_boff = ((tap_di * cg.W + tap_dj) * cg.cpp + tap_sub) * 16;   // < 2^31: host checks H*W*cpp*16
         };
-        auto issue_piece = [&](int j, int s, int buf) {  // j is a compile-time constant after unrolling
-            const unsigned ldsbuf = lds0 + buf * BUF;
+        auto issue_piece = [&](int j, int s, int buf, auto lean_tag) {  // j is a compile-time constant after unrolling
+            constexpr bool lean = decltype(lean_tag)::value;   // caller brackets the run with m0_save / m0_restore
+            const unsigned ldsbuf = __builtin_amdgcn_readfirstlane(lds0 + buf * BUF);
             if (j < XP) {
-                const unsigned dst = ldsbuf + ((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES;
+                const unsigned poff = __builtin_amdgcn_readfirstlane(((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES);
                 if constexpr (C::CONV) {
                     const int jj = j < XP ? j : 0;
                     const unsigned hi = (unsigned)(ch0[jj] + tap_di), wi = (unsigned)(cw0[jj] + tap_dj);
                     const bool ok = tap_ok & (hi < (unsigned)cg.H) & (wi < (unsigned)cg.W);   // unsigned: < 0 wraps high
                     const long long a = cpix[jj] + tap_boff;
                     const long long src = ok ? a : zero_addr;          // two v_cndmask, no branch
-                    glds16_asm64(reinterpret_cast<const unsigned char*>(src), __builtin_amdgcn_readfirstlane(dst));
+                    if constexpr (lean) glds16_lean64(reinterpret_cast<const unsigned char*>(src), ldsbuf, poff);
+                    else glds16_asm64(reinterpret_cast<const unsigned char*>(src), ldsbuf + poff);
                 } else {
-                    glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], __builtin_amdgcn_readfirstlane(dst));
+                    if constexpr (lean) glds16_lean(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], ldsbuf, poff);
+                    else glds16_asm(Xb + (int64_t)s * STAGE_BYTES, voffx[j < XP ? j : 0], ldsbuf + poff);
                 }
             } else {
                 const int jw = j - XP;
-                const unsigned dst = ldsbuf + C::X_STAGE + (((jw * C::NWAVES + uwave) % WPIECES) * RPP) * STAGE_BYTES;
-                glds16_asm(Wb + (int64_t)s * STAGE_BYTES, voffw[jw >= 0 && jw < WP ? jw : 0],
-                           __builtin_amdgcn_readfirstlane(dst));
+                const unsigned poff = __builtin_amdgcn_readfirstlane(
+                    C::X_STAGE + (((jw * C::NWAVES + uwave) % WPIECES) * RPP) * STAGE_BYTES);
+                if constexpr (lean) glds16_lean(Wb + (int64_t)s * STAGE_BYTES, voffw[jw >= 0 && jw < WP ? jw : 0], ldsbuf, poff);
+                else glds16_asm(Wb + (int64_t)s * STAGE_BYTES, voffw[jw >= 0 && jw < WP ? jw : 0], ldsbuf + poff);
             }
         };
         if constexpr (C::PIPE == 2) {
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 if (s < nstages) {
                     if constexpr (C::CONV) conv_stage(s);
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) issue_piece(j, s, s);
+                    for (int j = 0; j < NP; ++j) issue_piece(j, s, s, std::false_type{});
                 }
             if (nstages >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,8 +400,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 if constexpr (C::ABL == 5 && issue) dbg_ts[1] = stamp_now();
                 if constexpr (issue) {
                     if constexpr (C::CONV) conv_stage(s + AHEAD);
+                    const unsigned m0_keep = m0_save();
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) issue_piece(j, s + AHEAD, (s + AHEAD) & 3);
+                    for (int j = 0; j < NP; ++j) issue_piece(j, s + AHEAD, (s + AHEAD) & 3, std::true_type{});
+                    m0_restore(m0_keep);
                     if constexpr (C::ABL == 5 && issue) dbg_ts[2] = stamp_now();
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NP) : "memory");
                 } else {
@@ -409,7 +434,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         if (nstages > 0) {
                 if constexpr (C::CONV) conv_stage(0);
     #pragma unroll
-                for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0);
+                for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0, std::false_type{});
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     // the MFMAs of step kk so LDS latency hides under the matrix pipe.
                     if constexpr (more && C::ABL != 2) {
     #pragma unroll
-                        for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                        for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1, std::false_type{});
                     }
                     if constexpr (C::ABL != 4) read_frags(xs, ws, kk + 1, xfB, wfB);
                     __builtin_amdgcn_sched_barrier(0);
@@ -443,7 +468,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (more && C::ABL != 2) {
     #pragma unroll
-                        for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1);
+                        for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1, std::false_type{});
                     }
                     if constexpr (C::ABL != 4) {
                         if (kk + 2 < KK) read_frags(xs, ws, kk + 2, xfA, wfA);
@@ -630,6 +655,7 @@ template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
 template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, true>;
 template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, true>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
 template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, true>;
+template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, true>;   // profiling only (qt_conv_force_kernel(3))
 template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, true>;
 
 // implicit-conv configurations (pipelined kernel only)
@@ -926,6 +952,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
+        if (g_conv_force == 3 && tn == 192 && !epi.alpha)                                                       \
+            return launch_cfg<ConvPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
             return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 2) {                                                                                \
@@ -946,7 +974,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 }
 
 int qt_conv_force_kernel(int which) {
-    if (which < 0 || which > 2) return QT_ERR_INVALID_ARG;
+    if (which < 0 || which > 3) return QT_ERR_INVALID_ARG;   // 3 = stamped 384x192 ping-pong (profiling; Y is garbage)
     g_conv_force = which;
     return QT_OK;
 }
