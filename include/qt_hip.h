@@ -241,6 +241,14 @@ int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t l
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
                    uint32_t* nib_plane, int64_t ldn, int64_t rows, int64_t K, qt_stream_t stream);
 
+/* Same expansion into a PHYSICALLY zero-padded NHWC pixel plane: sign/mask planes hold N*H*W pixel rows,
+ * nib_plane gets N*(H+2ph)*(W+2pw) rows of ldn words whose border pixels are fp4 zeros.  A conv with zero
+ * padding (ph, pw) on the original image equals the un-padded conv on this plane, which the implicit-GEMM
+ * kernels run without per-tap bounds checks (F.conv2d's padding argument, layers/binary_layers.py:105). */
+int qt_bits_to_nib_pad(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
+                       uint32_t* nib_plane, int64_t ldn, int64_t N, int64_t H, int64_t W, int64_t ph,
+                       int64_t pw, int64_t K, qt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Quantised conv2d = packed-domain im2col + packed GEMM (replaces torch.nn.functional.conv2d on
  * quantised operands: layers/binary_layers.py:105,106; layers/terner_layers.py:91,92).
@@ -268,7 +276,8 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
 
 /* Tuning / test hook (process-global, not thread-safe): main loop of the implicit-GEMM conv kernels:
  * 0 = automatic (ping-pong 384x192 tile for 192-wide column tiles, double-buffered otherwise),
- * 1 = double-buffered, 2 = ping-pong. */
+ * 1 = double-buffered, 2 = ping-pong, 3 = stamped 384x192 ping-pong (profiling only: Y is garbage),
+ * 4 = automatic without the un-padded fast path (A/B only). */
 int qt_conv_force_kernel(int which);
 
 /* Same conv with the threshold-bit epilogue (inference fusion of

@@ -116,6 +116,7 @@ __device__ __forceinline__ void glds16_lean64(const unsigned char* src, unsigned
 struct ConvArgs {
     int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
     int cpp;                       // 16-byte chunks per pixel
+    int kbytes;                    // K bytes per (virtual) im2col row
     unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
 };
 
@@ -172,10 +173,12 @@ struct ElemBf16 {
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
 //   4 = no LDS fragment reads, 5 = (ping-pong) per-segment cycle stamps + wall-clock phase stamps written over Y, 6 = phase stamps only.
-template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, bool CONV_ = false>
+template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, int CONV_ = 0>
 struct GemmCfg {
     using E = E_;
-    static constexpr bool CONV = CONV_;
+    // CONV_: 0 = GEMM, 1 = implicit conv (zero padding by per-tap bounds checks, 64-bit per-lane addresses),
+    // 2 = implicit conv on an un-padded / physically padded plane (every tap in bounds: 32-bit offsets from one base)
+    static constexpr bool CONV = CONV_ != 0, VALID = CONV_ == 2;
     static constexpr int WM = WM_, WN = WN_, TMW = TMW_, TNW = TNW_, PIPE = PIPE_, ABL = ABL_;
     static constexpr int STAGE_BYTES = SB_, KK = SB_ / 32;
     static constexpr int ROWS_PER_PIECE = 1024 / SB_;   // one DMA piece = 1 KiB of LDS
@@ -185,7 +188,8 @@ struct GemmCfg {
     static constexpr int X_STAGE = TM * STAGE_BYTES, W_STAGE = TN * STAGE_BYTES;
     static constexpr int BUF = X_STAGE + W_STAGE;
     static constexpr int NBUF = PIPE_ == 2 ? 4 : 2;  // stage buffers: double-buffered, or a ring of 4 (ping-pong)
-    static constexpr int LDS_BYTES = NBUF * BUF + (PIPE_ == 2 ? 64 : 0);  // + the waves' SIMD ids (ping-pong)
+    static constexpr int LDS_FIXED = NBUF * BUF + 64;   // stage buffers + the waves' SIMD ids (ping-pong)
+    static constexpr int LDS_BYTES = LDS_FIXED;         // VALID conv: + the tap table (launch_cfg adds nstages * CHUNKS * 4)
     static_assert(PIPE_ != 2 || (SB_ == 64 && NWAVES == 8), "ping-pong: 64-byte stages, two waves per SIMD");
     static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
     static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && (TN % (ROWS_PER_PIECE * NWAVES) == 0 || PIPE_ == 2),
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 // byte address of chunk 0 of the window's top-left pixel (may lie before the plane: only
                 // dereferenced for in-range taps)
                 cpix[j] = (long long)(uintptr_t)Xb + ((((long long)n * cg.H + ch0[j]) * cg.W + cw0[j]) * cg.cpp) * 16;
-                voffx[j] = 0;
+                // VALID: ph = pw = 0, the plane is < 4 GiB (host check): byte offset of the window's first chunk
+                voffx[j] = C::VALID ? (unsigned)((((unsigned)n * cg.H + ch0[j]) * cg.W + cw0[j]) * cg.cpp) * 16u : 0u;
             } else {
                 voffx[j] = (unsigned)(min(m0 + row, M - 1) * ldx_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
             }
@@ -305,28 +310,54 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             const int row = ((j * C::NWAVES + uwave) % WPIECES) * RPP + rsub;
             voffw[j] = (unsigned)(min(n0 + row, N - 1) * ldw_b) + (unsigned)(swz<STAGE_BYTES>(row, p) * 16);
         }
-        // implicit conv: tap coordinates of this lane's chunk in stage s (shared by all its X pieces)
-        // per stage: the tap's row / column displacement and its byte offset from the window's top-left chunk
+        // implicit conv: tap coordinates of this lane's chunk in stage s (shared by all its X pieces): the tap's
+        // row / column displacement and its byte offset from the window's top-left chunk.
+        // Beside the partner's MFMA stream a VALU instruction of the loading wave costs ~12 cycles whatever its
+        // type (tools/pp_stamps_conv.py; an add/select formulation that advances the state without multiplies
+        // measured SLOWER than this 14-instruction from-scratch form), so the count is what matters:
+        //   general mode: evaluated per stage (two magic divisions);
+        //   VALID mode:   the byte offset of every (stage, chunk) is tabulated ONCE in LDS behind the stage
+        //                 buffers (tap_table, filled in the prologue) and a stage costs one ds_read_b32.
         int tap_di = 0, tap_dj = 0, tap_boff = 0;
         bool tap_ok = false;
         const long long zero_addr = (long long)(uintptr_t)zero16_storage;
-        auto conv_stage = [&](int s) {
-            const unsigned q = (unsigned)(s * CH + lchunk);
+        const int last_boff = (((cg.kh - 1) * cg.dh * cg.W + (cg.kw - 1) * cg.dw) * cg.cpp + cg.cpp - 1) * 16;
+        auto tap_eval = [&](unsigned q, int& di, int& dj, int& boff, bool& ok) {
             const unsigned tap = cg.cpp == 1 ? q : __umulhi(q, cg.magic_cpp);
             const int tap_sub = (int)(q - tap * cg.cpp);
             const unsigned ti = cg.kw == 1 ? tap : __umulhi(tap, cg.magic_kw);
             const int tj = (int)(tap - ti * cg.kw);
-            tap_di = (int)ti * cg.dh;
-            tap_dj = tj * cg.dw;
-            tap_ok = (int)ti < cg.kh;
-            tap_boff = ((tap_di * cg.W + tap_dj) * cg.cpp + tap_sub) * 16;   // < 2^31: host checks H*W*cpp*16
+            di = (int)ti * cg.dh;
+            dj = tj * cg.dw;
+            ok = (int)ti < cg.kh;             // false for chunks past the last tap (K tail of the last stage)
+            boff = ((di * cg.W + dj) * cg.cpp + tap_sub) * 16;   // < 2^31: host checks H*W*cpp*16
+        };
+        int* tap_table = reinterpret_cast<int*>(smem + C::NBUF * BUF + 64);   // VALID: [nstages][CH] byte offsets
+        if constexpr (C::VALID) {
+            for (int e = tid; e < nstages * CH; e += C::NTHREADS) {
+                int di, dj, boff;
+                bool ok;
+                tap_eval((unsigned)e, di, dj, boff, ok);
+                // no zero page in this mode: chunks past the last tap (their weights are zero) re-read the
+                // window's last in-range chunk, which is finite data
+                tap_table[e] = ok ? boff : last_boff;
+            }
+            __syncthreads();
+        }
+        auto conv_stage = [&](int s) {
+            if constexpr (C::VALID) tap_boff = tap_table[s * CH + lchunk];
+            else tap_eval((unsigned)(s * CH + lchunk), tap_di, tap_dj, tap_boff, tap_ok);
         };
         auto issue_piece = [&](int j, int s, int buf, auto lean_tag) {  // j is a compile-time constant after unrolling
             constexpr bool lean = decltype(lean_tag)::value;   // caller brackets the run with m0_save / m0_restore
             const unsigned ldsbuf = __builtin_amdgcn_readfirstlane(lds0 + buf * BUF);
             if (j < XP) {
                 const unsigned poff = __builtin_amdgcn_readfirstlane(((j * C::NWAVES + uwave) * RPP) * STAGE_BYTES);
-                if constexpr (C::CONV) {
+                if constexpr (C::VALID) {
+                    const unsigned voff = voffx[j < XP ? j : 0] + (unsigned)tap_boff;     // one VALU add per piece
+                    if constexpr (lean) glds16_lean(Xb, voff, ldsbuf, poff);
+                    else glds16_asm(Xb, voff, ldsbuf + poff);
+                } else if constexpr (C::CONV) {
                     const int jj = j < XP ? j : 0;
                     const unsigned hi = (unsigned)(ch0[jj] + tap_di), wi = (unsigned)(cw0[jj] + tap_dj);
                     const bool ok = tap_ok & (hi < (unsigned)cg.H) & (wi < (unsigned)cg.W);   // unsigned: < 0 wraps high
@@ -631,11 +662,14 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
     if (gy > 65535) return QT_ERR_UNSUPPORTED;
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
+    // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
+    const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0);
+    if (lds_bytes > 160 * 1024) return QT_ERR_UNSUPPORTED;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
         return QT_ERR_LAUNCH;
     hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3((unsigned)gx, (unsigned)gy), dim3(C::NTHREADS),
-                       C::LDS_BYTES, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
+                       lds_bytes, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
                        (int)M, (int)N, (int)K, cg, epi);
     return qt_check_launch();
 }
@@ -652,17 +686,26 @@ template <class E> using PP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, false>;
 template <class E> using PP192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, false>;
 template <class E> using PP384x192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, false>;   // wave tile 96x96: 6 fragment reads per 9 MFMAs
 template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
-template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, true>;
-template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, true>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
-template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, true>;
-template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, true>;   // profiling only (qt_conv_force_kernel(3))
-template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, true>;
+template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 1>;
+template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 1>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
+template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, 1>;
+template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 1>;   // profiling only (qt_conv_force_kernel(3))
+template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, 1>;
 
 // implicit-conv configurations (pipelined kernel only)
-template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, true>;
-template <class E> using Conv128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, true>;
-template <class E> using Conv64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, true>;
-template <class E> using Conv192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, true>;
+template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, 1>;
+template <class E> using Conv128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, 1>;
+template <class E> using Conv64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, 1>;
+template <class E> using Conv192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, 1>;
+
+// ... and on un-padded / physically padded planes (CONV_ = 2)
+template <class E> using ConvV256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, 2>;
+template <class E> using ConvV128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, 2>;
+template <class E> using ConvV64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, 2>;
+template <class E> using ConvV192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, 2>;
+template <class E> using ConvVPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 2>;
+template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
+template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling only
 
 // tile width (256 / 192 / 128 / 64) that wastes the fewest padded columns; ties go to the wider tile
 int pick_tile_n(int64_t N) {
@@ -847,6 +890,43 @@ __global__ __launch_bounds__(256) void bits_to_nib_kernel(const uint32_t* __rest
     }
 }
 
+// Same expansion into a PHYSICALLY zero-padded NHWC pixel plane [N][H + 2ph][W + 2pw][ldn]: border pixels
+// are fp4 zeros, so a padded conv becomes an un-padded one on this plane and takes the conv kernels'
+// VALID mode (no per-tap bounds checks, 32-bit offsets).
+__global__ __launch_bounds__(256) void bits_to_nib_pad_kernel(const uint32_t* __restrict__ sign,
+                                                              const uint32_t* __restrict__ mask, int64_t ldb,
+                                                              uint32_t* __restrict__ out, int64_t ldn, int64_t N,
+                                                              int H, int W, int ph, int pw, int64_t K) {
+    const int64_t groups_per_row = ldn / 4;
+    const int Hp = H + 2 * ph, Wp = W + 2 * pw;
+    const int64_t total = N * Hp * Wp * groups_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t orow = i / groups_per_row, g = i - orow * groups_per_row;
+        const int64_t n = orow / ((int64_t)Hp * Wp);
+        const int rem = (int)(orow - n * Hp * Wp);
+        const int y = rem / Wp - ph, x = rem % Wp - pw;
+        uint32_t sw = 0, mw = 0;
+        if (g < ldb && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const int64_t row = (n * H + y) * W + x;
+            sw = sign[row * ldb + g];
+            if (mask) {
+                mw = mask[row * ldb + g];
+            } else {
+                const int64_t r2 = K - g * 32;
+                mw = r2 >= 32 ? 0xFFFFFFFFu : (r2 > 0 ? ((1u << r2) - 1u) : 0u);
+            }
+        }
+        sw &= mw;
+        uint4 o;
+        o.x = (spread8(mw) << 1) | (spread8(sw) << 3);
+        o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
+        o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
+        o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
+        *reinterpret_cast<uint4*>(out + orow * ldn + g * 4) = o;
+    }
+}
+
 template <class Enc>
 int launch_nib_pack(const float* x, int64_t ldx, uint32_t* out, int64_t ldp, int64_t rows, int64_t K,
                     qt_stream_t stream) {
@@ -947,11 +1027,27 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     cg.H = (int)H; cg.W = (int)W; cg.Ho = (int)Ho; cg.Wo = (int)Wo; cg.kh = (int)kh; cg.kw = (int)kw;
     cg.sh = (int)sh; cg.sw = (int)sw; cg.ph = (int)ph; cg.pw = (int)pw; cg.dh = (int)dh; cg.dw = (int)dw;
     cg.cpp = (int)(Cw / 4);
+    cg.kbytes = (int)(kwords * 4);
     cg.magic_cpp = cg.cpp > 1 ? (unsigned)((1ull << 32) / (unsigned)cg.cpp + 1) : 0;
     cg.magic_kw = kw > 1 ? (unsigned)((1ull << 32) / (unsigned)kw + 1) : 0;
+    // un-padded conv on a plane < 4 GiB: every tap of every window is in bounds -> 32-bit offsets, no checks
+    const bool valid = ph == 0 && pw == 0 && Nimg * H * W * Cw * 4 < (1ll << 32) && kwords * 4 <= 32768;
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
+        if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha)                                              \
+            return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
+            if (g_conv_force != 1) {                                                                            \
+                if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
+                    return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                if (tn == 256) return launch_cfg<ConvVPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            }                                                                                                   \
+            if (tn == 256) return launch_cfg<ConvV256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (tn == 192) return launch_cfg<ConvV192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (tn == 128) return launch_cfg<ConvV128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            return launch_cfg<ConvV64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);                 \
+        }                                                                                                       \
         if (g_conv_force == 3 && tn == 192 && !epi.alpha)                                                       \
             return launch_cfg<ConvPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
@@ -974,7 +1070,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 }
 
 int qt_conv_force_kernel(int which) {
-    if (which < 0 || which > 3) return QT_ERR_INVALID_ARG;   // 3 = stamped 384x192 ping-pong (profiling; Y is garbage)
+    // 3 = stamped 384x192 ping-pong (profiling; Y is garbage), 4 = automatic without the un-padded fast path
+    if (which < 0 || which > 4) return QT_ERR_INVALID_ARG;
     g_conv_force = which;
     return QT_OK;
 }
@@ -1011,6 +1108,22 @@ int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64
     const int grid = qt_stream_grid((rows * (ldn / 4) + 255) / 256);
     hipLaunchKernelGGL(bits_to_nib_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sign_plane,
                        mask_plane, ldb, nib_plane, ldn, rows, K);
+    return qt_check_launch();
+}
+
+int qt_bits_to_nib_pad(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb, uint32_t* nib_plane,
+                       int64_t ldn, int64_t N, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t K,
+                       qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || K < 0) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!nib_plane || (K > 0 && !sign_plane)) return QT_ERR_INVALID_ARG;
+    if (ldb < (K + 31) / 32 || ldn < (K + 7) / 8) return QT_ERR_INVALID_ARG;
+    if ((ldb & 3) || (ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
+    if (H + 2 * ph > 32767 || W + 2 * pw > 32767) return QT_ERR_UNSUPPORTED;
+    const int64_t total = N * (H + 2 * ph) * (W + 2 * pw) * (ldn / 4);
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(bits_to_nib_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sign_plane, mask_plane,
+                       ldb, nib_plane, ldn, N, (int)H, (int)W, (int)ph, (int)pw, K);
     return qt_check_launch();
 }
 

@@ -55,6 +55,8 @@ USE_S2D = True
 #: 'auto' | 'valu' | 'mfma' — packed-GEMM formulation used by the layers (both are bit-exact;
 #: 'auto' picks by shape, see ops.select_gemm_impl).
 GEMM_IMPL = "auto"
+#: packed-activation convs: expand the bits into a physically zero-padded pixel plane (un-padded conv kernel)
+PAD_PLANES = True
 
 
 def pack_weight(weight_2d: torch.Tensor, kind: str, impl: str = "valu"):
@@ -242,9 +244,16 @@ def packed_conv2d(layer, act, kind: str, epi=None):
     N, C, H, W = act.shape
     wp = layer._eval_planes(lambda _w2: ops.pack_conv_weight_nib(layer.weight.detach(), kind), key="conv_nib")
     kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
-    px = ops.bits_to_nib(act.planes, ld=ops.pixel_ld_nib(C))
-    y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), layer.bias, layer.stride, layer.padding, layer.dilation,
-                        epi=epi)
+    ph, pw = ops._pairs(layer.padding)
+    if PAD_PLANES and (ph or pw):
+        # zero padding made physical while the bits are expanded: the conv runs un-padded (no per-tap checks)
+        px = ops.bits_to_nib_pad(act.planes, N, H, W, (ph, pw), ld=ops.pixel_ld_nib(C))
+        y2 = ops.conv2d_nib(px, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,
+                            layer.dilation, epi=epi)
+    else:
+        px = ops.bits_to_nib(act.planes, ld=ops.pixel_ld_nib(C))
+        y2 = ops.conv2d_nib(px, (N, C, H, W), wp, (kh, kw), layer.bias, layer.stride, layer.padding, layer.dilation,
+                            epi=epi)
     Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
     if epi is not None:
         return y2, (N, int(layer.weight.shape[0]), Ho, Wo)

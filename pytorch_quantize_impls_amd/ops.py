@@ -414,6 +414,22 @@ def bits_to_nib(planes: BitPlanes, ld: Optional[int] = None) -> NibPlanes:
     return NibPlanes(words=words, rows=planes.rows, K=planes.K)
 
 
+def bits_to_nib_pad(planes: BitPlanes, N: int, H: int, W: int, padding, ld: Optional[int] = None) -> NibPlanes:
+    """NHWC pixel bit planes ([N*H*W] rows) -> nibble pixel plane of the zero-padded image
+    ([N*(H+2ph)*(W+2pw)] rows; border pixels are fp4 zeros)."""
+    ph, pw = _pairs(padding)
+    if planes.rows != N * H * W:
+        raise ValueError("planes do not hold an [N, C, H, W] activation")
+    ld = packed_ld_nib(planes.K) if ld is None else int(ld)
+    rows = N * (H + 2 * ph) * (W + 2 * pw)
+    words = torch.empty((rows, ld), dtype=torch.int32, device=planes.device)
+    I = ctypes.c_int64
+    with torch.cuda.device(planes.device):
+        _lib.call("qt_bits_to_nib_pad", _p(planes.sign), _p(planes.mask), I(planes.ld), _p(words), I(ld), I(N), I(H),
+                  I(W), I(ph), I(pw), I(planes.K), _stream(planes.device))
+    return NibPlanes(words=words, rows=rows, K=planes.K)
+
+
 def nib_gemm(x: NibPlanes, w: NibPlanes, bias: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None, variant: Optional[int] = None) -> torch.Tensor:
     """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) on the matrix cores; bit-identical to the popcount

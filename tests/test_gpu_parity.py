@@ -947,3 +947,29 @@ def test_s2d_triple_pack_row_staged_kernel_equals_generic(dev):
             b, hw_b = ops.s2d_triple_pack(x.contiguous(), s, pad)
         assert hw_a == hw_b and a.data.shape == b.data.shape
         assert torch.equal(a.data, b.data), (N, C, H, W, s, pad)
+
+
+@pytest.mark.gpu
+def test_padded_pixel_planes_route_equals_bounds_checked_route(dev, oracle):
+    """Packed-activation convs expand their bits into a physically zero-padded plane and run the un-padded
+    (VALID) conv kernels; the bounds-checked kernels on the original plane must give the same bits / floats."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d
+    from pytorch_quantize_impls_amd import packed as pk
+    for (cls, Cin, Cout, k, st, pd, dil, H) in [(BinConv2d, 64, 192, 5, 1, 2, 1, 13), (TerConv2d, 96, 256, 3, 2, 1, 1, 15),
+                                               (BinConv2d, 32, 70, 3, 1, (2, 1), 2, 12), (BinConv2d, 192, 384, 3, 1, 1, 1, 13)]:
+        conv = cls(Cin, Cout, k, stride=st, padding=pd, dilation=dil).to(dev).eval()
+        x = g(synth.pm1(Cin + Cout, (3, Cin, H, H + 1)), dev).contiguous(memory_format=torch.channels_last)
+        act = pk.PackedActivation(ops.sign_pack(x.permute(0, 2, 3, 1).contiguous())[0], tuple(x.shape))
+        outs = []
+        for flag in (True, False):
+            _fused.PAD_PLANES = flag
+            try:
+                with torch.no_grad(), used("qt_bits_to_nib_pad" if flag else "qt_bits_to_nib", "qt_conv2d_implicit"):
+                    outs.append(conv(act))
+            finally:
+                _fused.PAD_PLANES = True
+        assert torch.equal(outs[0], outs[1]), (Cin, Cout, k)
+        wq = oracle.safe_sign(n(conv.weight)) if cls is BinConv2d else n(conv.weight)
+        ref = oracle.conv2d(n(x), wq, n(conv.bias), st, pd, dil)
+        assert norm_err(n(outs[0]), ref) <= TOL

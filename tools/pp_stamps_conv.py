@@ -34,6 +34,10 @@ for which in (1, 0):
         e0.record(); f(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     print(f"physically padded plane, conv padding 0, force {which}: median {sorted(ts)[5]:.1f} us")
 _lib.call("qt_conv_force_kernel", ctypes.c_int(3))
+PADDED = len(sys.argv) > 1 and sys.argv[1] == "padded"
+if PADDED:
+    run = lambda: ops.conv2d_nib(px2, (N, C, H + 2 * pad, H + 2 * pad), wp, (k, k), None, 1, 0, 1)
+    print("stamps below: un-padded (VALID) kernel on the physically padded plane")
 for _ in range(2):
     y = run()
 torch.cuda.synchronize()

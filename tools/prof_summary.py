@@ -30,7 +30,7 @@ def short(n):
             m = re.search(r"GemmCfg<\(anonymous namespace\)::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>", n)
             if m:
                 tail = (f"<{m.group(1)}, tile {int(m.group(2))*int(m.group(4))*32}x{int(m.group(3))*int(m.group(5))*32}, "
-                        f"pipe={m.group(6)}{', conv' if m.group(9) == 'true' else ''}>")
+                        f"pipe={m.group(6)}{', conv' if m.group(9) in ('true', '1') else (', conv-valid' if m.group(9) == '2' else '')}>")
             elif "<" in n and k == "popc_gemm_kernel":
                 tail = n[n.index("<"):n.index(">") + 1][:40]
             return k + tail
