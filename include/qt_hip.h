@@ -191,7 +191,9 @@ int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_b
 
 /* Y[M,N] = scale * (*scale_dev) * (Xc . Wc^T) + bias, Xc / Wc int8 code planes (ld in uint32 words).
  * scale_dev: optional DEVICE scalar (e.g. E = mean|W| computed on the device) so no host sync is
- * needed; NULL = 1.  max_abs_code bounds |x codes| (<= 127); requires max_abs_code * K < 2^24. */
+ * needed; NULL = 1.  max_abs_code bounds |x code * w code| (127 for +-1/0 weight codes, up to 127*127 for k-bit DoReFa
+ * weight codes c = rint((2^k-1) w_q)); requires max_abs_code * K < 2^31 (int32 accumulator); the result is exact
+ * while max_abs_code * K < 2^24, beyond that the int32 -> fp32 conversion rounds once. */
 int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,
                float scale, const float* scale_dev, int64_t max_abs_code, float* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t K, qt_stream_t stream);

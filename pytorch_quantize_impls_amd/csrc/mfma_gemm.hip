@@ -989,9 +989,10 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
                int64_t N, int64_t K, qt_stream_t stream) {
     const int rc = check_common(Xc, ldxp, Wc, ldwp, Y, ldy, M, N, K, (K + 3) / 4);
     if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
-    // |sum| <= max|x code| * max|w code| * K must stay below 2^24 so the int32 -> fp32 conversion in
-    // the epilogue is exact (weights are +-1/0 codes)
-    if (max_abs_code < 0 || max_abs_code > 127 || max_abs_code * K >= (1ll << 24)) return QT_ERR_UNSUPPORTED;
+    // max_abs_code bounds |x code * w code| (127 for +-1/0 weight codes, up to 127*127 for k-bit weight codes):
+    // |sum| <= max_abs_code * K must fit the int32 accumulator; below 2^24 the int32 -> fp32 conversion in
+    // the epilogue is exact as well (the +-1/0 weight case), above it rounds once (relative 6e-8)
+    if (max_abs_code < 0 || max_abs_code > 127 * 127 || max_abs_code * K >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 

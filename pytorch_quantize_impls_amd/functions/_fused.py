@@ -344,6 +344,50 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
+def _inv_levels(bit_width: int) -> float:
+    """fl32(1 / (2^k - 1)) as _quantize forms it (functions/dorefa_connect.py:24)."""
+    n = float((1 << int(bit_width)) - 1)
+    return float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+
+
+def dorefa_wk_linear_forward(input, weight_q, bias, bit_width: int, weight_codes):
+    """Eval-mode LinearDorefa(bit_width = k, 2 <= k <= 7) on a device activation that carries DoReFa codes:
+    with x = q / n_a and w_q = c / n_w (c = odd integer level, functions/dorefa_connect.py:108-112)
+        y = (1 / (n_a n_w)) * sum q c + b
+    on the int8 matrix cores (int32 accumulate).  The reference sums fl(x) * fl(w_q) in fp32, so parity is the
+    float-tail tolerance, not bit equality.  Returns None when the activation has no usable codes."""
+    codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
+    K, N = input.shape[-1], weight_q.shape[0]
+    n_w = (1 << int(bit_width)) - 1
+    if (codes is None or codes.K != K or codes.rows * K != input.numel() or 127 * n_w * K >= (1 << 31)
+            or not codes.usable()):
+        return None
+    y = ops.i8_gemm(codes, weight_codes, codes.inv_n * _inv_levels(bit_width), bias, max_abs_code=127 * n_w)
+    return y.view(*input.shape[:-1], N)
+
+
+def dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width: int, weight_codes, padding_mode="zeros"):
+    """Eval-mode DorefaConv2d(bit_width = k, 2 <= k <= 7) on a code-carrying activation; see
+    dorefa_wk_linear_forward.  Returns None when the packed path does not apply."""
+    stride, padding, dilation, groups = conv_args
+    if not (input.dtype == torch.float32 and input.dim() == 4 and groups == 1 and padding_mode == "zeros"
+            and not isinstance(padding, str)):
+        return None
+    codes = packed.lookup_codes(input, packed.NHWC)
+    if codes is None:
+        return None
+    N_, C, H, W = input.shape
+    kh, kw = int(weight_q.shape[2]), int(weight_q.shape[3])
+    Kb = kh * kw * codes.codes.shape[1]
+    n_w = (1 << int(bit_width)) - 1
+    if codes.K != C or codes.rows != N_ * H * W or 127 * n_w * Kb >= (1 << 31) or not codes.usable():
+        return None
+    y2 = ops.conv2d_codes(codes, (N_, C, H, W), weight_codes, (kh, kw), codes.inv_n * _inv_levels(bit_width), bias,
+                          stride, padding, dilation, max_abs_code=127 * n_w)
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    return y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
+
+
 class DorefaW1LinearFn(torch.autograd.Function):
     """Training-mode LinearDorefa(bit_width=1): forward above; backward as autograd derives it from
     F.linear(x, _ignore_factor_op(sign(W), E), b): grad_x = g . (sign(W) E), grad_W = g^T . x passed

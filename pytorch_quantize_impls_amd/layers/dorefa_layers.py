@@ -34,6 +34,13 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
             if not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)):
                 wc = self._eval_planes(lambda w2: _fused.ops.weight_codes(w2), key="i8")
                 return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc)
+        if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
+                and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
+            # WkAk inference: integer weight levels x activation codes on the int8 matrix cores
+            wc = self._eval_planes(lambda w2: _fused.ops.dorefa_weight_codes(w2, self.bit_width), key="i8k")
+            y = _fused.dorefa_wk_linear_forward(input, self.weight, self.bias, self.bit_width, wc)
+            if y is not None:
+                return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
         return torch.nn.functional.linear(input, w, self.bias)
 
@@ -71,5 +78,13 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                            key="conv_i8")
                 return _fused.dorefa_w1_conv_forward(input, self.weight, self.bias, args, True, wc,
                                                      self.padding_mode)
+        if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
+                and self.groups == 1 and self.padding_mode == "zeros"
+                and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
+            wc = self._eval_planes(
+                lambda _w2: _fused.ops.pack_conv_weight_dorefa_codes(self.weight.detach(), self.bit_width), key="conv_i8k")
+            y = _fused.dorefa_wk_conv_forward(input, self.weight, self.bias, args, self.bit_width, wc, self.padding_mode)
+            if y is not None:
+                return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
         return torch.nn.functional.conv2d(input, w, self.bias, *args)

@@ -527,6 +527,35 @@ def weight_codes(w2d: torch.Tensor, ternary: bool = False, ld_bytes: Optional[in
     return CodePlanes(codes=codes, rows=rows, K=K)
 
 
+def dorefa_weight_codes(wq2d: torch.Tensor, bit_width: int, ld_bytes: Optional[int] = None) -> CodePlanes:
+    """int8 codes c = rint((2^k-1) * w_q) of an already quantised k-bit DoReFa weight image w_q
+    (nnQuantWeight.forward, functions/dorefa_connect.py:108-112: w_q = 2*quantize_k(...) - 1, an odd multiple of
+    1/(2^k-1) up to fp32 rounding, so rint recovers the integer level exactly).  2 <= k <= 7 (|c| <= 127)."""
+    if not 2 <= int(bit_width) <= 7:
+        raise ValueError("k-bit weight codes fit int8 for 2 <= bit_width <= 7")
+    cp, _ = dorefa_codes(wq2d, bit_width, want_f32=False, ld_bytes=ld_bytes)
+    cp.overflow = None          # |c| <= 2^k - 1 <= 127 by construction
+    return cp
+
+
+def pack_conv_weight_dorefa_codes(wq: torch.Tensor, bit_width: int) -> CodePlanes:
+    """[Cout, Cin, kh, kw] quantised k-bit DoReFa weight -> int8 code plane in the conv kernels' tap-major layout
+    (see pack_conv_weight_codes)."""
+    _require(wq, "weight")
+    Cout, Cin, kh, kw = (int(v) for v in wq.shape)
+    Cb = code_ld_bytes(Cin, 16)
+    wt = wq.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
+    taps = dorefa_weight_codes(wt, bit_width, ld_bytes=Cb)
+    kbytes = kh * kw * Cb
+    ld = code_ld_bytes(kbytes)
+    codes = taps.codes.view(Cout, kbytes)
+    if ld != kbytes:
+        padded = torch.zeros((Cout, ld), dtype=torch.int8, device=wq.device)
+        padded[:, :kbytes] = codes
+        codes = padded
+    return CodePlanes(codes=codes, rows=Cout, K=kbytes, bit_width=int(bit_width))
+
+
 def i8_gemm(x: CodePlanes, w: CodePlanes, scale: float, bias: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, max_abs_code: int = 127,
             scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -568,7 +597,7 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
 
 
 def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, scale: float, bias=None,
-                 stride=1, padding=0, dilation=1, scale_dev=None) -> torch.Tensor:
+                 stride=1, padding=0, dilation=1, scale_dev=None, max_abs_code: int = 127) -> torch.Tensor:
     """DoReFa conv2d on int8 code planes: NHWC pixel codes -> packed-domain im2col (zero bytes for
     padding taps = the reference's zero padding, code 0 <-> value 0) -> int8 MFMA GEMM.
     Returns the NHWC result [N*Ho*Wo, Cout]."""
@@ -583,7 +612,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
-    if CONV_IMPLICIT and 127 * kh * kw * Cw * 4 < (1 << 24):
+    if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
         y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
                            ldA, bias, scale, scale_dev, Cout)
         if y is not None:
@@ -598,7 +627,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
             _lib.call("qt_im2col_words", _p(pixels.codes), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh),
                       I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
         i8_gemm(CodePlanes(codes=A[:cnt], rows=cnt, K=wplanes.K), wplanes, scale, bias, out=y[m0:m0 + cnt],
-                scale_dev=scale_dev)
+                scale_dev=scale_dev, max_abs_code=max_abs_code)
     return y
 
 

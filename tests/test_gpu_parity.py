@@ -973,3 +973,43 @@ def test_padded_pixel_planes_route_equals_bounds_checked_route(dev, oracle):
         wq = oracle.safe_sign(n(conv.weight)) if cls is BinConv2d else n(conv.weight)
         ref = oracle.conv2d(n(x), wq, n(conv.bias), st, pd, dil)
         assert norm_err(n(outs[0]), ref) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw_bits,ka_bits", [(2, 2), (3, 4), (4, 4), (7, 3)])
+def test_dorefa_wk_ak_inference_on_int8_matrix_cores(dev, oracle, kw_bits, ka_bits):
+    """Eval-mode LinearDorefa / DorefaConv2d with k-bit weights (2..7) on code-carrying activations: integer
+    weight levels x activation codes on the int8 MFMA kernels, against the fp64 evaluation of the reference
+    formula (functions/dorefa_connect.py:82-113 weights, :11-25 activations) and the layer's own dense route."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant as Q
+    # linear
+    x = np.abs(synth.normal(kw_bits + 10, (37, 200))) * 0.6
+    w = synth.normal(ka_bits + 20, (29, 200)) * 0.8
+    b = synth.normal(3, (29,))
+    layer = LinearDorefa(200, 29, bit_width=kw_bits).to(dev)
+    layer.weight.data.copy_(g(w, dev)); layer.bias.data.copy_(g(b, dev))
+    layer.eval()
+    wq = oracle.dorefa_weight(w, kw_bits).astype(np.float64)
+    with torch.no_grad(), used("qt_dorefa_codes_i8", "qt_i8_gemm"):
+        xq = Q(ka_bits)(g(x, dev))
+        y = layer(xq)
+        codes = ops.dorefa_weight_codes(layer.weight.detach(), kw_bits)
+    n_w = (1 << kw_bits) - 1
+    lv = n(codes.codes)[:, :200].astype(np.int64)
+    assert np.array_equal(lv, np.rint(wq * n_w).astype(np.int64)) and np.all(np.abs(lv) % 2 == 1) and np.abs(lv).max() <= n_w
+    ref = oracle.dorefa_quantize(x, ka_bits).astype(np.float64) @ wq.T + b
+    assert norm_err(n(y), ref) <= TOL
+    with torch.no_grad():
+        dense = torch.nn.functional.linear(xq.clone(), layer.weight, layer.bias)      # clone: no tag -> library route
+    assert norm_err(n(y), n(dense)) <= TOL
+    # conv
+    xc = np.abs(synth.normal(kw_bits + 30, (2, 24, 9, 9))) * 0.5
+    wc = synth.normal(ka_bits + 40, (40, 24, 3, 3)) * 0.7
+    conv = DorefaConv2d(24, 40, 3, stride=1, padding=1, bit_width=kw_bits).to(dev)
+    conv.weight.data.copy_(g(wc, dev))
+    conv.eval()
+    with torch.no_grad(), used("qt_conv2d_implicit"):
+        xq = Q(ka_bits)(g(xc, dev).contiguous(memory_format=torch.channels_last))
+        yc = conv(xq)
+    refc = oracle.conv2d(oracle.dorefa_quantize(xc, ka_bits), oracle.dorefa_weight(wc, kw_bits), n(conv.bias), 1, 1)
+    assert norm_err(n(yc), refc) <= TOL
