@@ -1013,3 +1013,30 @@ def test_dorefa_wk_ak_inference_on_int8_matrix_cores(dev, oracle, kw_bits, ka_bi
         yc = conv(xq)
     refc = oracle.conv2d(oracle.dorefa_quantize(xc, ka_bits), oracle.dorefa_weight(wc, kw_bits), n(conv.bias), 1, 1)
     assert norm_err(n(yc), refc) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", ["bin", "ter"])
+def test_linear_backward_on_bf16_matrix_cores_vs_fp64(dev, cls):
+    """Large training-mode LinearBin / LinearTer: grad_x = g . Q(W) and grad_W = (g^T . x) * STE mask run through the
+    exact-split bf16 GEMM (x is a tagged +-1 activation); compare with the fp64 evaluation."""
+    from pytorch_quantize_impls_amd.layers import LinearTer
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    M, K, N = 640, 768, 512
+    torch.manual_seed(21)
+    layer = (LinearBin if cls == "bin" else LinearTer)(K, N).to(dev)
+    layer.weight.data.uniform_(-1.3, 1.3)
+    pre = torch.randn((M, K), device=dev, requires_grad=True)
+    gout = torch.randn((M, N), device=dev)
+    before = dict(_lib.call_counts)
+    y = layer(BinaryConnect()(pre))
+    y.backward(gout)
+    assert _lib.call_counts["qt_bf16_gemm"] - before.get("qt_bf16_gemm", 0) == 2       # both backward GEMMs
+    w = layer.weight.detach().double()
+    wq = (torch.where(w < 0, -1.0, 1.0) if cls == "bin" else torch.where(w >= 0.5, 1.0, torch.where(w < -0.5, -1.0, 0.0))).double()
+    xq = torch.where(pre.detach() < 0, -1.0, 1.0).double()
+    gx_ref = (gout.double() @ wq) * (pre.detach().abs() <= 1.001).double()
+    gw_ref = (gout.double().t() @ xq) * (w.abs() <= 1.001).double()
+    assert norm_err(n(pre.grad), n(gx_ref)) <= TOL
+    assert norm_err(n(layer.weight.grad), n(gw_ref)) <= TOL
+    assert norm_err(n(layer.bias.grad), n(gout.double().sum(0))) <= TOL
