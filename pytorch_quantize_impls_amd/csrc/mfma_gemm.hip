@@ -8,34 +8,42 @@
 //       for the xor+bcnt pair (profiles/r1_ubench.txt) — which is why large shapes are routed here.
 //   int8 ("code planes"): DoReFa k-bit activation codes q = rint((2^k-1) x) x +-1/0 weight codes with
 //       v_mfma_i32_32x32x32_i8, int32 accumulate (exact), one fp32 scale in the epilogue.
+//   bf16 ("triple planes"): real-valued activations split exactly into hi + mid + lo bf16 terms x +-1/0 weights
+//       replicated three times, v_mfma_f32_32x32x16_bf16, fp32 accumulate (fp32-GEMM accuracy).
 //
-// Y[m,n] = scale * sum_k X[m,k] * W[n,k] (+ bias[n]);  X: M x K, W: N x K, row-major byte rows.
+// Y[m,n] = scale * sum_k X[m,k] * W[n,k] (+ bias);  X: M x K, W: N x K, row-major byte rows.
 //
-// One kernel template serves both: everything is organised in BYTES of K.  A stage is 128 bytes of K
-// per row (256 nibbles / 128 int8) = 4 MFMA k-steps of 32 bytes; lane l of a wave supplies, for the
-// 32x32 MFMA, row (l & 31) and the 16-byte chunk (2*kk + (l >> 5)) of the stage row.
+// One kernel template serves all three: everything is organised in BYTES of K.  A stage is 128 (PIPE 0/1) or 64
+// (PIPE 2) bytes of K per row = 4 / 2 MFMA k-steps of 32 bytes; lane l of a wave supplies, for the 32x32 MFMA,
+// row (l & 31) and the 16-byte chunk (2*kk + (l >> 5)) of the stage row.
 //
-// Workgroup = 8 waves (2 per SIMD).  X is the MFMA "A" operand (D rows = m) and W the "B" operand
-// (D cols = n): with the 32x32 C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) a
-// store instruction then writes two full 128-byte lines of Y.  (The transposed assignment gives each
-// lane a float4 but scatters every store instruction over 32 rows 16 KB apart: measured 2x slower
-// epilogue, DESIGN.md.)
+// Workgroup = 8 waves (2 per SIMD).  X is the MFMA "A" operand (D rows = m) and W the "B" operand (D cols = n).
+// Epilogues: fp32 Y through a wave-private LDS transpose and dwordx4 full-line stores (or dword stores when Y is
+// not 16-byte friendly), or — inference fusion — one THRESHOLD BIT per output ([(acc + bias) * alpha + beta < 0],
+// EpiArgs) assembled with wave ballots.
 //
-// LDS: stage rows are eight 16-byte chunks, chunk c of row r stored at position c ^ ((r>>1)&7): the 16
-// rows a ds_read_b128 lane group touches (distinct mod 16) fall on 16 distinct 16-B slots of the 256-B
-// bank row -> conflict-free fragment reads.  Two stage buffers (X tile + W tile each).
+// LDS: stage rows are 16-byte chunks, chunk c of row r stored at position c ^ f(r) (swz<>): the 16 rows a
+// ds_read_b128 lane group touches (distinct mod 16) fall on 16 distinct 16-B slots of the 256-B bank row ->
+// conflict-free fragment reads.
 //
-// Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip; the swizzle is applied on the
-// per-lane SOURCE address because the LDS side of the instruction is lane-linear).
-//   PIPE = 1 (fast path): the DMA is issued from inline asm, so hipcc has no outstanding-DMA knowledge
-//       (with the builtin it drains vmcnt(0) in front of the next ds_read, serialising DMA against
-//       fragment reads + MFMAs); the pieces of stage s+1 are interleaved with the per-k-step fragment
-//       reads (software-pipelined one k-step ahead) and MFMAs of stage s; one manual vmcnt(0) + barrier
-//       per stage.  The steady-state body is branch-free (last stage peeled) so it stays one basic
-//       block and the sched_barriers can hold the interleave.  Contract: row strides are whole stages
-//       (ld % 32 words == 0, pad zero) and each operand spans < 2^31 bytes (32-bit lane offsets).
-//   PIPE = 0 (generic): builtin DMA, 64-bit addresses, any ld % 4 words; chunks past the row stride
-//       read a 16-byte zero word.  All fragment reads of a stage are issued before the DMA of the next.
+// Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip; the swizzle is applied on the per-lane SOURCE
+// address because the LDS side of the instruction is lane-linear).
+//   PIPE = 2 (ping-pong; every GEMM tile, conv on the 384x192 / 256x256 tiles): 64-byte stages in a ring of 4;
+//       a wave's stage is a LOAD segment (all fragment reads of the stage + its DMA pieces of stage s+3) followed
+//       by a COMPUTE segment (register-only MFMAs), and the two waves of a SIMD run one segment apart, so one owns
+//       the matrix pipe while the other owns LDS / DMA issue.  See the comment at the loop.
+//   PIPE = 1 (double-buffered; the remaining conv tiles): the DMA is issued from inline asm, so hipcc has no
+//       outstanding-DMA knowledge (with the builtin it drains vmcnt(0) in front of the next ds_read); the pieces of
+//       stage s+1 are interleaved with software-pipelined fragment reads and the MFMAs of stage s; one manual
+//       vmcnt(0) + barrier per stage; last stage peeled so the steady-state body is one basic block.
+//       Contract of PIPE 1/2: row strides are whole 128-byte stages (ld % 32 words == 0, pad zero) and each operand
+//       spans < 2^31 bytes (32-bit lane offsets).
+//   PIPE = 0 (generic): builtin DMA, 64-bit addresses, any ld % 4 words; chunks past the row stride read a 16-byte
+//       zero word.  All fragment reads of a stage are issued before the DMA of the next.
+// Conv (CONV_ = 1 / 2): the X operand is an NHWC pixel plane and a stage gathers the 16-byte chunks of the taps it
+// covers (implicit GEMM, no im2col buffer): per-tap bounds checks + zero page (1), or — un-padded / physically
+// padded planes — plain 32-bit offsets with the per-(stage, chunk) tap offsets tabulated once in LDS (2).
+// Profiling-only variants (ABL_ != 0) are reachable through qt_nib_gemm_variant / qt_conv_force_kernel(3).
 #include <type_traits>
 #include "qt_common.h"
 
