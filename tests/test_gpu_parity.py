@@ -1040,3 +1040,104 @@ def test_linear_backward_on_bf16_matrix_cores_vs_fp64(dev, cls):
     assert norm_err(n(pre.grad), n(gx_ref)) <= TOL
     assert norm_err(n(layer.weight.grad), n(gw_ref)) <= TOL
     assert norm_err(n(layer.bias.grad), n(gout.double().sum(0))) <= TOL
+
+
+# ---- seeded fuzz over shapes: conv / fused conv blocks / packed GEMM against the oracle (bit-exact cases) ----------
+
+@pytest.mark.gpu
+def test_fuzz_packed_conv_vs_oracle(dev, oracle):
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, FusedConvPoolBnSign, fold_batchnorm
+    from pytorch_quantize_impls_amd import packed as pk
+    rng = np.random.default_rng(20260928)
+    for it in range(40):
+        Cin = int(rng.choice([1, 3, 8, 24, 32, 40, 64, 96, 130]))
+        Cout = int(rng.choice([1, 7, 32, 48, 64, 100, 192, 200, 260]))
+        kh, kw = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        st = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        pd = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        dl = (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+        N = int(rng.integers(1, 4))
+        H = int(rng.integers(dl[0] * (kh - 1) + 1, 15)) + 2
+        W = int(rng.integers(dl[1] * (kw - 1) + 1, 15)) + 2
+        ter = bool(rng.integers(0, 2))
+        cls = TerConv2d if ter else BinConv2d
+        conv = cls(Cin, Cout, (kh, kw), stride=st, padding=pd, dilation=dl, bias=False).to(dev)
+        w = synth.uniform(1000 + it, (Cout, Cin, kh, kw), -1.4, 1.4)
+        conv.weight.data.copy_(g(w, dev))
+        conv.eval()
+        x = synth.pm1(2000 + it, (N, Cin, H, W))
+        wq = oracle.ternarize(w) if ter else oracle.safe_sign(w)
+        want = oracle.conv2d(x, wq, None, st, pd, dl)
+        xt = g(x, dev).contiguous(memory_format=torch.channels_last)
+        act = pk.PackedActivation(ops.sign_pack(xt.permute(0, 2, 3, 1).contiguous())[0], tuple(xt.shape))
+        cfg = (it, Cin, Cout, kh, kw, st, pd, dl, N, H, W, ter)
+        with torch.no_grad():
+            y_t = conv(xt)                 # +-1 tensor in: bounds-checked conv kernels
+            y_p = conv(act)                # packed in: physically padded plane + un-padded kernels
+        assert np.array_equal(n(y_t), want), cfg
+        assert np.array_equal(n(y_p), want), cfg
+        # fused block on the same conv (pooling when the output is large enough)
+        Ho, Wo = want.shape[2:]
+        pool = torch.nn.MaxPool2d(2, 2) if min(Ho, Wo) >= 2 and it % 2 == 0 else None
+        bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+        bn.running_mean.copy_(g(synth.normal(3000 + it, (Cout,)) * 3, dev))
+        bn.running_var.copy_(g(synth.uniform(4000 + it, (Cout,), 0.5, 40), dev))
+        bn.weight.data.copy_(g(synth.normal(5000 + it, (Cout,)), dev))
+        bn.bias.data.copy_(g(synth.normal(6000 + it, (Cout,)), dev))
+        with torch.no_grad():
+            out = FusedConvPoolBnSign(conv, bn, pool)(act)
+        alpha, beta = (n(t) for t in fold_batchnorm(bn))
+        want_bits, _ = oracle.bin_conv_pool_bn_sign_planes(x, wq, None, st, pd, dl, alpha, beta, *((2, 2) if pool else (1, 1)))
+        assert np.array_equal(n(out.planes.sign).view(np.uint32), want_bits), cfg
+
+
+@pytest.mark.gpu
+def test_fuzz_packed_gemm_vs_oracle(dev, oracle):
+    rng = np.random.default_rng(77)
+    for it in range(30):
+        M, N, K = (int(v) for v in rng.integers(1, 700, size=3))
+        if it % 5 == 0:
+            M, N = 384 * int(rng.integers(1, 3)) + int(rng.integers(0, 9)), 192 * int(rng.integers(1, 3))
+        x = synth.pm1(100 + it, (M, K))
+        w = synth.uniform(200 + it, (N, K), -1.5, 1.5)
+        ref_b = oracle.linear(x, oracle.safe_sign(w))
+        ref_t = oracle.linear(x, oracle.ternarize(w))
+        xb = ops.sign_pack(g(x, dev))[0]
+        wb, wt = ops.sign_pack(g(w, dev))[0], ops.ternary_pack(g(w, dev))
+        assert np.array_equal(n(ops.xnor_gemm(xb, wb)), ref_b), (M, N, K)
+        assert np.array_equal(n(ops.tern_gemm(xb, wt)), ref_t), (M, N, K)
+        xn = ops.bits_to_nib(xb)
+        assert np.array_equal(n(ops.nib_gemm(xn, ops.bits_to_nib(wb))), ref_b), (M, N, K)
+        assert np.array_equal(n(ops.nib_gemm(xn, ops.bits_to_nib(wt))), ref_t), (M, N, K)
+
+
+@pytest.mark.gpu
+def test_fuzz_real_input_conv_vs_fp64(dev):
+    """First-layer style convs on real-valued inputs (exact bf16-triple route; space-to-depth form when strided)."""
+    rng = np.random.default_rng(4242)
+    from pytorch_quantize_impls_amd.layers import TerConv2d
+    for it in range(24):
+        Cin = int(rng.choice([1, 3, 4, 6, 16]))
+        Cout = int(rng.choice([5, 32, 64, 96, 192]))
+        k = int(rng.integers(1, 8))
+        st = int(rng.integers(1, 5))
+        pd = int(rng.integers(0, 4))
+        H, W = int(rng.integers(k, 40)) + 3, int(rng.integers(k, 40)) + 3
+        cls = TerConv2d if it % 3 == 0 else BinConv2d
+        conv = cls(Cin, Cout, k, stride=st, padding=pd).to(dev)
+        conv.weight.data.uniform_(-1.3, 1.3)
+        conv.bias.data.normal_()
+        conv.binary_input = False
+        x = torch.randn((2, Cin, H, W), device=dev) * 2.0
+        if it % 2:
+            x = x.contiguous(memory_format=torch.channels_last)
+        w = conv.weight.detach().double()
+        wq = (torch.where(w < 0, -1.0, 1.0) if cls is BinConv2d
+              else torch.where(w >= 0.5, 1.0, torch.where(w < -0.5, -1.0, 0.0))).double()
+        ref = torch.nn.functional.conv2d(x.double(), wq, conv.bias.detach().double(), st, pd)
+        for mode in ("train", "eval"):
+            conv.train(mode == "train")
+            with torch.no_grad(), used("qt_conv2d_implicit"):
+                y = conv(x)
+            assert y.shape == ref.shape and norm_err(n(y), n(ref)) <= TOL, (it, Cin, Cout, k, st, pd, H, W, mode)
+        conv.train()
