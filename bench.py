@@ -95,8 +95,7 @@ def main():
     ev_pairs = []
 
     def step(record=False):
-        xp = ops.pack_activations(x, gemm_impl)
-        wp = ops.pack_weights(w, "binary", gemm_impl)
+        xp, wp = ops.pack_linear_operands(x, w, "binary", gemm_impl)   # both operands, one launch on the mfma route
         if record:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)

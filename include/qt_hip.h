@@ -163,6 +163,13 @@ int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64
 int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
                             int64_t rows, int64_t K, qt_stream_t stream);
 
+/* Both operands of one LinearBin / LinearTer forward (layers/binary_layers.py:44: F.linear(x, bin_op(W), b) on a
+ * +-1 activation that is not packed yet) in ONE launch: x -> safeSign nibble plane, w -> safeSign (w_ternary = 0)
+ * or ternary (1) nibble plane.  Same formats and contracts as the two single-operand entries. */
+int qt_pack_pair_nib_f32(const float* x, int64_t ldx, uint32_t* x_plane, int64_t ldxp, int64_t rows_x,
+                         const float* w, int64_t ldw, uint32_t* w_plane, int64_t ldwp, int64_t rows_w,
+                         int64_t K, int w_ternary, qt_stream_t stream);
+
 /* Y[M,N] = Xn . Wn^T (+ bias): replaces the same F.linear call sites as qt_xnor_gemm /
  * qt_tern_gemm (binary and ternary weights share this entry point: zero is a nibble value). */
 int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp,

@@ -839,6 +839,33 @@ __global__ __launch_bounds__(256) void nib_pack_vec_kernel(const float* __restri
     }
 }
 
+// Both operands of one LinearBin / LinearTer forward in ONE launch (activation: safeSign, weight: EncW): saves a
+// kernel boundary and one ramp / tail of a ~12 us HBM-bound kernel.  Same work item as nib_pack_vec_kernel.
+template <class EncW>
+__global__ __launch_bounds__(256) void nib_pack_pair_kernel(const float* __restrict__ xa, int64_t lda,
+                                                            uint32_t* __restrict__ oa, int64_t ldpa, int64_t rowsa,
+                                                            const float* __restrict__ xb, int64_t ldb,
+                                                            uint32_t* __restrict__ ob, int64_t ldpb, int64_t rowsb,
+                                                            int64_t K) {
+    const int64_t ta = rowsa * ldpa * 2, total = ta + rowsb * ldpb * 2;   // both even
+    const int64_t k4 = K / 4;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const bool second = s >= ta;
+        const int64_t t = second ? s - ta : s;
+        const int64_t spr = (second ? ldpb : ldpa) * 2;
+        const int64_t row = t / spr, slot = t - row * spr;
+        uint32_t h = 0;
+        if (slot < k4) {
+            const float4 v = *reinterpret_cast<const float4*>((second ? xb + row * ldb : xa + row * lda) + slot * 4);
+            h = second ? (EncW::nib(v.x) | (EncW::nib(v.y) << 4) | (EncW::nib(v.z) << 8) | (EncW::nib(v.w) << 12))
+                       : (NibSign::nib(v.x) | (NibSign::nib(v.y) << 4) | (NibSign::nib(v.z) << 8) | (NibSign::nib(v.w) << 12));
+        }
+        const uint32_t other = __shfl_xor(h, 1);
+        if ((threadIdx.x & 1) == 0) (second ? ob + row * ldpb : oa + row * ldpa)[slot >> 1] = h | (other << 16);
+    }
+}
+
 // Generic path (any K / alignment): one thread per output word, scalar loads.
 template <class Enc>
 __global__ __launch_bounds__(256) void nib_pack_scalar_kernel(const float* __restrict__ x, int64_t ldx,
@@ -969,6 +996,31 @@ int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64
 int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
                             int64_t rows, int64_t K, qt_stream_t stream) {
     return launch_nib_pack<NibTernary>(x, ldx, nib_plane, ldp, rows, K, stream);
+}
+
+int qt_pack_pair_nib_f32(const float* x, int64_t ldx, uint32_t* x_plane, int64_t ldxp, int64_t rows_x,
+                         const float* w, int64_t ldw, uint32_t* w_plane, int64_t ldwp, int64_t rows_w, int64_t K,
+                         int w_ternary, qt_stream_t stream) {
+    if (rows_x < 0 || rows_w < 0 || K < 0 || ldx < K || ldw < K) return QT_ERR_INVALID_ARG;
+    const bool vec = rows_x > 0 && rows_w > 0 && K > 0 && (K % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) &&
+                     qt_aligned16(x) && qt_aligned16(w) && x && w && x_plane && w_plane;
+    if (!vec) {   // ragged / empty operands: the two single-operand launches handle every case
+        const int rc = launch_nib_pack<NibSign>(x, ldx, x_plane, ldxp, rows_x, K, stream);
+        if (rc != QT_OK) return rc;
+        return w_ternary ? launch_nib_pack<NibTernary>(w, ldw, w_plane, ldwp, rows_w, K, stream)
+                         : launch_nib_pack<NibSign>(w, ldw, w_plane, ldwp, rows_w, K, stream);
+    }
+    const int64_t kw = (K + 7) / 8;
+    if (ldxp < kw || ldwp < kw || (ldxp & 3) || (ldwp & 3) || !qt_aligned16(x_plane) || !qt_aligned16(w_plane))
+        return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid(((rows_x * ldxp + rows_w * ldwp) * 2 + 255) / 256);
+    if (w_ternary)
+        hipLaunchKernelGGL((nib_pack_pair_kernel<NibTernary>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           x_plane, ldxp, rows_x, w, ldw, w_plane, ldwp, rows_w, K);
+    else
+        hipLaunchKernelGGL((nib_pack_pair_kernel<NibSign>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           x_plane, ldxp, rows_x, w, ldw, w_plane, ldwp, rows_w, K);
+    return qt_check_launch();
 }
 
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,

@@ -105,6 +105,13 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
     N = weight.shape[0]
     M = input.numel() // max(K, 1)
     impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
+    if (impl == "mfma" and weight_planes is None and input.dtype == torch.float32 and input.numel() > 0
+            and binary_input is not False and packed.lookup(input, packed.ROWS_LAST) is None
+            and (binary_input or (DETECT_BINARY_INPUT and ops.is_pm1(input)))):
+        # neither operand is packed yet (un-tagged +-1 activation, training-mode weight): one launch packs both
+        wq = weight_q if weight_q is not None else weight
+        xp, wp = ops.pack_linear_operands(input, wq.reshape(N, -1), kind, impl)
+        return ops.packed_gemm(xp, wp, bias, impl=impl).view(*input.shape[:-1], N)
     xp = activation_planes(input, binary_input, impl)
     if xp is not None:
         wp = weight_planes

@@ -952,6 +952,28 @@ def pack_weights(w: torch.Tensor, kind: str = "binary", impl: str = "valu"):
     raise NotImplementedError(impl)
 
 
+def pack_linear_operands(x: torch.Tensor, w: torch.Tensor, kind: str = "binary", impl: str = "valu"):
+    """(packed safeSign(x), packed Q(w)) for one quantised linear forward.  On the matrix-core route both nibble
+    planes come out of ONE launch (qt_pack_pair_nib_f32)."""
+    if impl != "mfma":
+        return pack_activations(x, impl), pack_weights(w, kind, impl)
+    _require(x, "input")
+    _require(w, "weight")
+    x2, w2 = _as_rows(x), _as_rows(w.reshape(w.shape[0], -1))
+    (M, K), (N, Kw) = (int(v) for v in x2.shape), (int(v) for v in w2.shape)
+    if K != Kw:
+        raise ValueError(f"K mismatch: activations {K} vs weights {Kw}")
+    ld = packed_ld_nib(K)
+    xn = torch.empty((M, ld), dtype=torch.int32, device=x.device)
+    wn = torch.empty((N, ld), dtype=torch.int32, device=x.device)
+    I = ctypes.c_int64
+    with torch.cuda.device(x.device):
+        _lib.call("qt_pack_pair_nib_f32", _p(x2), I(x2.stride(0) if M > 1 else max(K, 1)), _p(xn), I(ld), I(M),
+                  _p(w2), I(w2.stride(0) if N > 1 else max(K, 1)), _p(wn), I(ld), I(N), I(K),
+                  ctypes.c_int(0 if kind == "binary" else 1), _stream(x.device))
+    return NibPlanes(words=xn, rows=M, K=K), NibPlanes(words=wn, rows=N, K=K)
+
+
 def to_impl(planes, impl: str):
     """Convert packed operands to the format ``impl`` consumes (bit planes -> nibble planes only)."""
     if impl == "valu":

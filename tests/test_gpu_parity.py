@@ -1141,3 +1141,24 @@ def test_fuzz_real_input_conv_vs_fp64(dev):
                 y = conv(x)
             assert y.shape == ref.shape and norm_err(n(y), n(ref)) <= TOL, (it, Cin, Cout, k, st, pd, H, W, mode)
         conv.train()
+
+
+@pytest.mark.gpu
+def test_pack_pair_equals_single_operand_packs(dev):
+    for (M, N, K) in [(4096, 4096, 4096), (300, 77, 1000), (5, 9, 12), (64, 64, 31), (1, 1, 4)]:
+        x = g(synth.normal(M + K, (M, K)), dev)
+        w = g(synth.uniform(N + K, (N, K), -1.5, 1.5), dev)
+        for kind in ("binary", "ternary"):
+            with used("qt_pack_pair_nib_f32"):
+                xp, wp = ops.pack_linear_operands(x, w, kind, "mfma")
+            assert torch.equal(xp.words, ops.sign_pack_nib(x).words)
+            assert torch.equal(wp.words, (ops.sign_pack_nib(w) if kind == "binary" else ops.ternary_pack_nib(w)).words)
+    # the layer takes this route for an un-tagged +-1 activation in training mode (large shape -> matrix cores)
+    layer = LinearBin(2048, 1024).to(dev)
+    xs = torch.randn((2048, 2048), device=dev).sign()
+    xs[xs == 0] = 1
+    with used("qt_pack_pair_nib_f32", "qt_nib_gemm"):
+        y = layer(xs)
+    ref = torch.nn.functional.linear(xs.double(), torch.where(layer.weight.detach() < 0, -1.0, 1.0).double(),
+                                     layer.bias.detach().double())
+    assert norm_err(n(y), n(ref)) <= TOL
