@@ -114,3 +114,82 @@ def randomize_bn(model, seed=0):
             m.running_var.copy_(torch.rand(m.num_features, generator=g) * 50 + 50)
             m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+# ---- BASELINE configs C4 / C5 as parity-test models -----------------------------
+
+class _DorefaBlock(nn.Module):
+    """Residual block of the C4 net: two 3x3 DorefaConv2d (1-bit weights) + BatchNorm, k-bit activation
+    quantiser applied to the UNCLAMPED relu(bn(.)) (models/samples/ResNet_Dorefa.py pattern), 1x1 stride-2
+    DorefaConv2d shortcut when the shape changes; the second conv consumes the first one's output (the
+    upstream block feeds x twice, models/Resnet/Resnet_bin.py:29 — fixed here as SURVEY 8d specifies)."""
+
+    def __init__(self, cin, cout, stride, w_bits, a_bits):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import DorefaConv2d
+        from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+        self.conv1 = DorefaConv2d(cin, cout, 3, stride=stride, padding=1, bias=False, bit_width=w_bits)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = DorefaConv2d(cout, cout, 3, stride=1, padding=1, bias=False, bit_width=w_bits)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.quant = nnDorefaQuant(a_bits)
+        self.shortcut = None
+        if stride != 1 or cin != cout:
+            self.shortcut = nn.Sequential(DorefaConv2d(cin, cout, 1, stride=stride, bias=False, bit_width=w_bits),
+                                          nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        out = self.quant(torch.relu(self.bn1(self.conv1(x))))
+        out = self.bn2(self.conv2(out))
+        out = out + (x if self.shortcut is None else self.shortcut(x))
+        return self.quant(torch.relu(out))
+
+
+class DorefaResNet18(nn.Module):
+    """C4: DoReFa ResNet-18 W1A4 for 3x32x32 inputs (fp32 stem, avg_pool 4, Linear(512))."""
+
+    def __init__(self, num_classes=10, w_bits=1, a_bits=4):
+        super().__init__()
+        from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+        self.stem = nn.Conv2d(3, 64, 3, padding=1, bias=False)
+        self.bn = nn.BatchNorm2d(64)
+        self.quant = nnDorefaQuant(a_bits)
+        blocks, cin = [], 64
+        for cout, stride in ((64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1)):
+            blocks.append(_DorefaBlock(cin, cout, stride, w_bits, a_bits))
+            cin = cout
+        self.blocks = nn.Sequential(*blocks)
+        self.linear = nn.Linear(512, num_classes)
+
+    def forward(self, x):
+        out = self.quant(torch.relu(self.bn(self.stem(x))))
+        out = self.blocks(out)
+        out = torch.nn.functional.avg_pool2d(out, 4)
+        return self.linear(out.reshape(out.size(0), -1))
+
+
+class TernaryVGG16(nn.Module):
+    """C5: VGG-16 (13 conv3x3 p1 + 3 FC) from TerConv2d / LinearTer with BinaryConnect activations, in the
+    conv -> BatchNorm -> Hardtanh -> BinaryConnect pattern of models/FullNet/terMNIST.py:48-59.  ``image`` sets the
+    input resolution (224 in the config; the classifier width follows)."""
+    CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+    def __init__(self, num_classes=1000, image=224, fc=4096):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import LinearTer, TerConv2d
+        layers, cin = [], 3
+        for v in self.CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+                continue
+            layers += [TerConv2d(cin, v, 3, padding=1), nn.BatchNorm2d(v), nn.Hardtanh(), BinaryConnect(stochastic=False)]
+            cin = v
+        self.features = nn.Sequential(*layers)
+        side = image // 32
+        self.classifier = nn.Sequential(LinearTer(512 * side * side, fc), nn.BatchNorm1d(fc), nn.Hardtanh(),
+                                        BinaryConnect(stochastic=False), LinearTer(fc, fc), nn.BatchNorm1d(fc),
+                                        nn.Hardtanh(), BinaryConnect(stochastic=False), LinearTer(fc, num_classes))
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(x.reshape(x.size(0), -1))

@@ -2,6 +2,8 @@
 only where the activation would not matter for the code path.  The independent check is the dense fp32
 conv / matmul of the SAME quantised fp32 images on the device (integer-exact for +-1 / ternary operands,
 so equality is bitwise; DoReFa's float scale gets the normalised 1e-5 tolerance)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -115,3 +117,81 @@ def test_c3_alexnet_conv_full_batch(dev, Cin, Cout, k, pad, H):
         assert torch.equal(y[:8], F.conv2d(xs[:8], wb, None, padding=pad))
     yi = y.to(torch.int64)
     assert torch.equal(yi.to(torch.float32), y) and int(yi.abs().max()) <= Cin * k * k
+
+
+# ---- whole C4 / C5 networks: device forward against the same modules on CPU tensors (torch ops = the reference's
+# ---- expression), small batch / reduced resolution so the CPU side stays in seconds ------------------------------
+
+def _unit_scale_weights(model, seed):
+    gen = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+            m.weight.data.copy_(torch.empty_like(m.weight).uniform_(-1.2, 1.2, generator=gen))
+            if m.bias is not None:
+                m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen))
+
+
+@pytest.mark.gpu
+def test_c4_dorefa_resnet18_forward_vs_cpu(dev):
+    """W1A4 ResNet-18, 17 quantiser layers deep.  A conv sum within rounding distance of a rint() boundary flips one
+    activation code (1/15) and the flip propagates, so end-to-end agreement is looser than per-layer parity; with
+    1-bit weights (y = E/15 * integer on both sides) the fixed seed below gives <= 2e-4 normalised."""
+    import bench_models
+    torch.manual_seed(4)
+    model = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(model, seed=3)
+    for m in model.modules():                       # keep activations in the codes' int8 range for most layers
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.mul_(4.0)
+    model.eval()
+    x = torch.randn(4, 3, 32, 32)
+    with torch.no_grad():
+        ref = model(x)
+        before = dict(_lib.call_counts)
+        got = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)(
+            x.to(dev).contiguous(memory_format=torch.channels_last)).cpu()
+    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) >= 15   # int8 matrix-core convs ran
+    assert (got - ref).abs().max() <= 2e-4 * ref.abs().max(), float((got - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w_bits", [1, 2, 3, 4])
+@pytest.mark.parametrize("cin,cout,k,st,pd,H", [(64, 64, 3, 1, 1, 32), (64, 128, 3, 2, 1, 32), (64, 128, 1, 2, 0, 32),
+                                                 (128, 128, 3, 1, 1, 16), (256, 512, 3, 2, 1, 8), (512, 512, 3, 1, 1, 4)])
+def test_c4_dorefa_wk_a4_layers_vs_fp64(dev, w_bits, cin, cout, k, st, pd, H):
+    """Every conv shape of the C4 net with 1..4-bit weights on 4-bit activation codes (int8 matrix cores) against
+    the fp64 evaluation of the same layer: per-layer parity is the float-tail tolerance (the reference's w_q levels
+    carry their own fp32 representation error of up to 4e-7, which an integer-level formulation cannot mimic)."""
+    torch.manual_seed(cin + cout + w_bits)
+    conv = DorefaConv2d(cin, cout, k, stride=st, padding=pd, bias=False, bit_width=w_bits)
+    conv.weight.data.uniform_(-1.2, 1.2)
+    conv.eval()
+    x = torch.rand(4, cin, H, H) * 2.0
+    q = nnDorefaQuant(4)
+    with torch.no_grad():
+        ref = copy.deepcopy(conv).double()(q(x).double()).float()
+        before = dict(_lib.call_counts)
+        got = copy.deepcopy(conv).to(dev)(q(x.to(dev).contiguous(memory_format=torch.channels_last))).cpu()
+    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) == 1
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_c5_ternary_vgg16_forward_vs_cpu(dev):
+    import bench_models
+    from pytorch_quantize_impls_amd import _lib
+    torch.manual_seed(5)
+    model = bench_models.TernaryVGG16(num_classes=100, image=64, fc=512)
+    _unit_scale_weights(model, 8)
+    bench_models.randomize_bn(model, seed=5)
+    model.eval()
+    x = torch.randn(3, 3, 64, 64)
+    with torch.no_grad():
+        ref = model(x)
+        before = dict(_lib.call_counts)
+        got = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)(
+            x.to(dev).contiguous(memory_format=torch.channels_last)).cpu()
+    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) == 13
+    # BatchNorm thresholds: MIOpen and ATen-CPU may land a value within an ulp of 0 on different sides, flipping one
+    # +-1 activation; logits are sums over 512 ternary-weighted signs, so allow a handful of unit steps
+    assert (got - ref).abs().max() <= 0.02 * ref.abs().max() + 1e-3, float((got - ref).abs().max())
