@@ -1162,3 +1162,28 @@ def test_pack_pair_equals_single_operand_packs(dev):
     ref = torch.nn.functional.linear(xs.double(), torch.where(layer.weight.detach() < 0, -1.0, 1.0).double(),
                                      layer.bias.detach().double())
     assert norm_err(n(y), n(ref)) <= TOL
+
+
+@pytest.mark.gpu
+def test_graphed_fused_alexnet_replay_equals_eager(dev):
+    """utils.graphed: the fused inference forward captured as a hipGraph (C-ABI launches included) replays
+    bit-identically for new inputs."""
+    import bench_models
+    from pytorch_quantize_impls_amd.utils import graphed
+    torch.manual_seed(2)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    fused = bench_models.FusedAlexNetBin(model)
+    xs = [torch.randn((4, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    gm = graphed(fused, xs[0])
+    before = dict(_lib.call_counts)
+    for x in xs[::-1]:
+        with torch.no_grad():
+            want = fused(x)
+        n_calls = sum(_lib.call_counts.values())
+        got = gm(x).clone()
+        assert sum(_lib.call_counts.values()) == n_calls          # replay: no Python-side launches
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError, match="captured for input"):
+        gm(xs[0][:2])
