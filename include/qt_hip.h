@@ -293,7 +293,7 @@ int qt_conv_force_kernel(int which);
  *   BinConv2d -> [MaxPool2d] -> BatchNorm2d(eval) -> Hardtanh -> BinaryConnect, models/Alexnet/Alexnet_Bin.py:13-17):
  * no fp32 output is written; per output element t = acc (+ bias), v = fl(fl(t * alpha[c]) + beta[c]) and
  * bit c%32 of word c/32 of row (n, ho, wo) of neg_plane is (v < 0).  neg_plane: [N*Ho*Wo][ldb] words,
- * ldb % 4 == 0, ldb >= ceil(Cout/32); words past the last tile column are NOT written (pre-zero the plane).
+ * ldb % 4 == 0, ceil(Cout/32) <= ldb < ceil(Cout/32) + 64; every word of every row is written (pad words as 0).
  * alpha/beta: folded eval BatchNorm, Cout floats each.  Follow with qt_pool_bits when a MaxPool sits
  * between conv and BatchNorm. */
 int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,

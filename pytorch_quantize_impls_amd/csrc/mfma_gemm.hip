@@ -604,6 +604,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 const int m = m0 + (wave_m * C::TMW + a) * 32 + lane;
                 const int wcol = nb >> 5;
                 if (lane < 32 && m < M && wcol < ldy) B[(int64_t)m * ldy + wcol] = myword;
+                // the row's pad words past the last column tile (ldy rounds ceil(N/32) up to 4) are zeroed here, so
+                // the plane needs no memset
+                if (b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && m < M)
+                    for (int wc = (n0 + C::TN) >> 5; wc < ldy; ++wc) B[(int64_t)m * ldy + wc] = 0u;
             }
         }
     } else if (wide) {

@@ -47,7 +47,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         if alpha.numel() != Cout or beta.numel() != Cout:
             raise ValueError(f"alpha/beta must have {Cout} entries")
         ldb = packed_ld(Cout)
-        plane = torch.zeros((M, ldb), dtype=torch.int32, device=dev)   # words past the last tile column stay 0
+        plane = torch.empty((M, ldb), dtype=torch.int32, device=dev)   # the kernel writes every word incl. the pad
         with torch.cuda.device(dev):
             _lib.call("qt_conv2d_implicit_bits", *head, _p(alpha), _p(beta), _p(plane), I(ldb), I(Cout), _stream(dev))
         return BitPlanes(sign=plane, rows=M, K=Cout)
