@@ -218,18 +218,27 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     const int wave_n = wave % C::WN, wave_m = wave / C::WN;
     const int lrow = lane & 31, lhalf = lane >> 5;
 
-    // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never relied on
-    // for correctness).  When the tile grid divides into 4 (m) x 8 (n) super-tiles, XCD x owns a
-    // contiguous range of the super-tile-major order, so the tiles sharing an L2 share X / W panels.
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    // XCD-aware tile order (1-D grid).  Workgroup b is observed to run on XCD b % 8 (speed only, never relied on
+    // for correctness): XCD x gets a CONTIGUOUS range of the tile order, so tiles that run at the same time on one
+    // XCD (= one L2) are neighbours and share operand panels.
+    //   tile grid divisible into 4 (m) x 8 (n) super-tiles: super-tile-major order (X and W panels both shared);
+    //   otherwise: n-fastest order, so the column tiles of one row tile — which read the same X rows / pixels —
+    //   sit on one XCD (conv with 3-6 column tiles: X is fetched into one L2 instead of 3-6).
+    // The grid is padded to a multiple of 8 workgroups; the surplus ones exit.
+    int tile_m, tile_n;
     {
-        const int gx = gridDim.x, gy = gridDim.y;
+        const int gx = (N + C::TN - 1) / C::TN, gy = (M + C::TM - 1) / C::TM;
+        const int ntiles = gx * gy, per_xcd = (ntiles + 7) >> 3;
+        const int b = blockIdx.x;
+        const int o = (b & 7) * per_xcd + (b >> 3);
+        if (o >= ntiles) return;                       // uniform for the workgroup, before any barrier
         if ((gx & 7) == 0 && (gy & 3) == 0) {
-            const int b = blockIdx.y * gx + blockIdx.x;
-            const int o = (b & 7) * ((gx * gy) >> 3) + (b >> 3);  // bijective: 8 | gx*gy
             const int st = o >> 5, in_st = o & 31, sgx = gx >> 3;
             tile_m = (st / sgx) * 4 + (in_st >> 3);
             tile_n = (st % sgx) * 8 + (in_st & 7);
+        } else {
+            tile_m = o / gx;
+            tile_n = o - tile_m * gx;
         }
     }
     const int m0 = tile_m * C::TM, n0 = tile_n * C::TN;
@@ -672,7 +681,8 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
                float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                qt_stream_t stream, const ConvArgs& cg = ConvArgs{}, const EpiArgs& epi = EpiArgs{}) {
     const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
-    if (gy > 65535) return QT_ERR_UNSUPPORTED;
+    if (gx * gy > (1ll << 30)) return QT_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((gx * gy + 7) / 8 * 8);
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
     // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
     const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0);
@@ -680,7 +690,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
         return QT_ERR_LAUNCH;
-    hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3((unsigned)gx, (unsigned)gy), dim3(C::NTHREADS),
+    hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3(grid), dim3(C::NTHREADS),
                        lds_bytes, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
                        (int)M, (int)N, (int)K, cg, epi);
     return qt_check_launch();

@@ -606,6 +606,8 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
     Cw = pixels.ld_words
+    if pixels.rows != N * H * W or int(pixels.codes.shape[0]) < N * H * W:
+        raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
     if wplanes.K != kh * kw * Cw * 4:
         raise ValueError("weight codes do not match the activation's channel packing")
     Cout, ldA = wplanes.rows, wplanes.ld_words
@@ -689,6 +691,8 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
     Cw = pixels.ld
+    if pixels.rows != N * H * W or int(pixels.words.shape[0]) < N * H * W:
+        raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
     if wplanes.K != kh * kw * Cw * 8:
         raise ValueError("weight planes do not match the activation's channel packing")
     Cout, ldA = wplanes.rows, wplanes.ld
@@ -855,6 +859,8 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     else:
         px = pixels
         x = pixels.data
+        if pixels.rows != N * H * W or int(pixels.data.shape[0]) < N * H * W:
+            raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
     wt = weight_triples if weight_triples is not None else pack_conv_weight_bf16x3(weight, kind)
     Cw, ldA = Cb // 4, wt.ld_words
     M = N * Ho * Wo

@@ -1187,3 +1187,17 @@ def test_graphed_fused_alexnet_replay_equals_eager(dev):
         assert torch.equal(got, want)
     with pytest.raises(ValueError, match="captured for input"):
         gm(xs[0][:2])
+
+
+@pytest.mark.gpu
+def test_conv_wrappers_reject_mismatched_pixel_planes(dev):
+    """A pixel plane that does not hold N*H*W pixels would make the gather read out of bounds: refuse it."""
+    x = g(synth.pm1(1, (2, 32, 6, 6)), dev).contiguous(memory_format=torch.channels_last)
+    px = ops.pack_pixels_nib(x)
+    wp = ops.pack_conv_weight_nib(g(synth.uniform(2, (8, 32, 3, 3), -1, 1), dev), "binary")
+    with pytest.raises(ValueError, match="pixel plane holds"):
+        ops.conv2d_nib(px, (2, 32, 8, 8), wp, (3, 3), None, 1, 1, 1)
+    codes, _ = ops.dorefa_codes(torch.rand((2 * 6 * 6, 32), device=dev), 4, want_f32=False, ld_bytes=32)
+    wc = ops.pack_conv_weight_codes(g(synth.uniform(3, (8, 32, 3, 3), -1, 1), dev))
+    with pytest.raises(ValueError, match="pixel plane holds"):
+        ops.conv2d_codes(codes, (2, 32, 7, 6), wc, (3, 3), 1.0, None, 1, 1, 1)

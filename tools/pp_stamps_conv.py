@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from pytorch_quantize_impls_amd import _lib, ops
 dev = torch.device("cuda:0")
+CONV1 = len(sys.argv) > 1 and sys.argv[1] == "conv1"     # AlexNet conv1: real input, bf16 triples, space-to-depth form
 N, C, H, Cout, k, pad = 256, 192, 27, 576, 5, 2
 x = torch.randn((N, C, H, H), device=dev).contiguous(memory_format=torch.channels_last)
 w = torch.randn((Cout, C, k, k), device=dev)
@@ -14,6 +15,16 @@ px = ops.pack_pixels_nib(x)
 wp = ops.pack_conv_weight_nib(w, "binary")
 def run():
     return ops.conv2d_nib(px, (N, C, H, H), wp, (k, k), None, 1, pad, 1)
+if CONV1:
+    x1 = torch.randn((N, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+    w1 = torch.randn((192, 3, 11, 11), device=dev).sign()
+    px1, (Hs, Ws) = ops.s2d_triple_pack(x1, 4, 2)
+    ws1 = ops.s2d_weight(w1, 4)
+    wt1 = ops.pack_conv_weight_bf16x3(ws1, "sign")
+    meta = torch.empty(tuple(ws1.shape), device="meta")
+    run = lambda: ops.float_conv2d(None, meta, "sign", None, 1, 0, 1, weight_triples=wt1, pixels=px1, in_shape=(N, 48, Hs, Ws))
+    OUT_GRID = (192, 55)       # Cout, Ho for the decode below
+    STAGES = (9 * 288 + 63) // 64
 for which in (1, 0):
     _lib.call("qt_conv_force_kernel", ctypes.c_int(which))
     for _ in range(3): run()
@@ -33,6 +44,7 @@ for which in (1, 0):
     for _ in range(10):
         e0.record(); f(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     print(f"physically padded plane, conv padding 0, force {which}: median {sorted(ts)[5]:.1f} us")
+STAGES = globals().get("STAGES", 192 * 25 // 2 // 64)
 _lib.call("qt_conv_force_kernel", ctypes.c_int(3))
 PADDED = len(sys.argv) > 1 and sys.argv[1] == "padded"
 if PADDED:
@@ -42,6 +54,8 @@ for _ in range(2):
     y = run()
 torch.cuda.synchronize()
 _lib.call("qt_conv_force_kernel", ctypes.c_int(0))
+if CONV1:
+    Cout, H = OUT_GRID
 M = N * H * H
 yi = y.view(torch.int32).cpu().numpy()
 rows = []
@@ -66,5 +80,5 @@ for i in range(4):
     print(f"  {lab[i]} -> {lab[i+1]}: median {np.median(d[:, i]):6.2f} us  max {d[:, i].max():6.2f}")
 loop_us = wall[:, 2] - wall[:, 1]
 print(f"main loop: median {np.median(t[:, 15]):.0f} cycles in {np.median(loop_us):.2f} us -> {np.median(t[:, 15] / loop_us) / 1e3:.3f} GHz; "
-      f"stages = {192 * 25 // 2 // 64} -> {np.median(t[:, 15]) / (192 * 25 // 2 // 64):.0f} cycles per 64-byte stage (18 MFMAs per wave = 576 cycles of pipe per slot, 2 slots)")
+      f"stages = {STAGES} -> {np.median(t[:, 15]) / STAGES:.0f} cycles per 64-byte stage (18 MFMAs per wave = 576 cycles of pipe per slot, 2 slots)")
 print(f"kernel span: {wall[:, 4].max() - w0:.1f} us; workgroups {len(t) // 4}")
