@@ -8,7 +8,8 @@ dev = torch.device("cuda:0")
 if os.environ.get("CONV_FORCE"):
     import ctypes
     from pytorch_quantize_impls_amd import _lib
-    _lib.call("qt_conv_force_kernel", ctypes.c_int(int(os.environ["CONV_FORCE"])))
+    for v in os.environ["CONV_FORCE"].split(","):
+        _lib.call("qt_conv_force_kernel", ctypes.c_int(int(v)))
 torch.manual_seed(0)
 model = bench_models.AlexNetBin(); bench_models.randomize_bn(model)
 model = model.to(dev).to(memory_format=torch.channels_last).eval()
