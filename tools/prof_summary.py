@@ -15,7 +15,7 @@ import sys
 
 d = sys.argv[1]
 ours = ("mfma_gemm_kernel", "pool_affine_sign_pack_kernel", "triple_kernel", "codes_kernel", "im2col_words_kernel",
-        "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
+        "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_pair_kernel", "bits_to_nib_pad_kernel", "s2d_triple_rows_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
         "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
         "check_pm1_kernel", "pool_bits_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
 
