@@ -50,3 +50,48 @@ def test_batch_shard_world2(tmp_path):
     full = O.linear_bin_forward(O.safe_sign(x), w)
     got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)], 0)
     assert np.array_equal(got, full)
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    """Data-parallel training step: the layers are ordinary nn.Modules, so torch DDP (gradient all-reduce; RCCL on
+    device, gloo here) averages the STE-masked gradients — nothing quantisation-specific crosses ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import bench_models
+    torch.manual_seed(0)                                   # identical replicas
+    model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
+    ddp = DDP(model)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 40, generator=g)
+    tgt = torch.randint(0, 5, (16,), generator=g)
+    lo, hi = rank * 8, (rank + 1) * 8
+    loss = torch.nn.functional.nll_loss(ddp(x[lo:hi]), tgt[lo:hi])
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    torch.save(grads, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_average_over_ranks(tmp_path):
+    """world_size 2 on CPU: after backward every rank holds the mean of the two per-shard gradients.  BatchNorm uses
+    per-shard batch statistics (the reference has no SyncBN either), so the expectation is built the same way."""
+    world = 2
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import bench_models
+    g0, g1 = (torch.load(tmp_path / f"g{r}.pt") for r in range(world))
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k                 # all-reduced: identical on both ranks
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 40, generator=gen)
+    tgt = torch.randint(0, 5, (16,), generator=gen)
+    want = None
+    for r in range(world):
+        torch.manual_seed(0)
+        model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
+        torch.nn.functional.nll_loss(model(x[r * 8:(r + 1) * 8]), tgt[r * 8:(r + 1) * 8]).backward()
+        gr = {k: p.grad for k, p in model.named_parameters()}
+        want = gr if want is None else {k: (want[k] + gr[k]) / 2 for k in gr}
+    for k in want:
+        assert torch.allclose(g0[k], want[k], rtol=1e-5, atol=1e-6), k
