@@ -96,6 +96,17 @@ int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, fl
 int qt_dorefa_quantize_f32(const float* x, float* y, int64_t n, int bit_width,
                            qt_stream_t stream);
 
+/* Lin / Log fixed-point quantisers of "CNNs using Logarithmic Data Representation" (functions/log_lin_connect.py).
+ * Lin (:61-67): step = 2^(fsr - bit_width); mode 0: clamp(round(x/step)*step, 0, 2^fsr); mode 1 (with_sign):
+ * sign(x) * the same of |x|; mode 2: the quantised-gradient backward (:79) sign(g) * clamp(round(g/step)*step, 0,
+ * 2^fsr) (negative g -> -0, as upstream); bit_width 32 = identity.  round = half to even, sign(0) = 0, NaN kept.
+ * Log (:31-33): [sign(x) *] 2^clamp(round(log2|x|), fsr - 2^bit_width, fsr); x = 0 -> 0 (signed) / 2^(fsr-2^bits).
+ * log2 is the device's fp32 log2f: inputs within an ulp of 2^(k+1/2) may round to the other neighbour than on
+ * the host (measure-zero boundary). */
+int qt_lin_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_width, int mode, qt_stream_t stream);
+int qt_log_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_width, int with_sign,
+                        qt_stream_t stream);
+
 /* XNOR-Net weight quantiser over a row-major [R, C] view of the weight:
  * alpha[c] = mean_r |w[r,c]| ;  wq[r,c] = sign(w[r,c]) * alpha[c]  (torch.sign: 0 -> 0).  wq may be NULL
  * (alpha only).  XNORDense: R = N, C = K (functions/xnor_connect.py:112-113, global DIM = 0);
@@ -227,7 +238,8 @@ int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t 
 /* mode 0: activation triples of x (times alpha[k] if alpha != NULL: XNORDense's per-input-feature scale,
  * functions/xnor_connect.py:112-113); mode 1/2/3: weight triples of safeSign(x) / TernaryConnect(x) /
  * torch.sign(x).  out: bf16 [rows][ld_bytes/2], element 3k+s = term s of element k; ld_bytes % 16 == 0,
- * ld_bytes >= 6*K, pad zero. */
+ * ld_bytes >= 6*K, pad zero.  mode 4 = raw weight: bf16_rn(w) replicated three times, for weights that are exactly
+ * representable in bf16 (Lin / Log fixed-point levels, layers/log_lin_layers.py). */
 int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out, int64_t ld_bytes,
                        int64_t rows, int64_t K, int mode, qt_stream_t stream);
 

@@ -108,6 +108,24 @@ def dorefa_quantize(x, k):
     return y
 
 
+def lin_quantize(x, fsr, bits, mode=1):
+    """functions/log_lin_connect.py:61-79 (mode 0 unsigned, 1 with_sign, 2 quantised-gradient backward)."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_lin_quantize(xp, y.ctypes.data_as(_f32p), _i64(x.size), ctypes.c_int(int(fsr)), ctypes.c_int(int(bits)),
+                          ctypes.c_int(int(mode)))
+    return y
+
+
+def log_quantize(x, fsr, bits, with_sign=True):
+    """functions/log_lin_connect.py:31-40."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_log_quantize(xp, y.ctypes.data_as(_f32p), _i64(x.size), ctypes.c_int(int(fsr)), ctypes.c_int(int(bits)),
+                          ctypes.c_int(1 if with_sign else 0))
+    return y
+
+
 # ---- packed format ---------------------------------------------------------------------------
 
 def packed_ld(K: int) -> int:

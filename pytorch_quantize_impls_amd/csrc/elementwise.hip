@@ -21,6 +21,31 @@ struct OpCopy {
     __device__ __forceinline__ float operator()(float x) const { return x; }
 };
 
+// ---- Lin / Log fixed-point quantisers (functions/log_lin_connect.py) -----------------------------------------
+// torch.sign = (0 < x) - (x < 0): sign(+-0) = +0, sign(NaN) = NaN
+__device__ __forceinline__ float qt_torch_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x != x ? x : 0.0f)); }
+__device__ __forceinline__ float qt_torch_clamp(float v, float lo, float hi) {   // torch.clamp propagates NaN
+    return v != v ? v : (v < lo ? lo : (v > hi ? hi : v));   // compare chain: clamp(-0, 0, hi) stays -0, like ATen
+}
+struct OpLinQuant {   // log_lin_connect.py:61-67: mode 0: clamp(round(x/step)*step, 0, 2^fsr); mode 1: sign(x) * the
+    float step, maxv;  // same of |x|; mode 2: sign(g) * clamp(round(g/step)*step, 0, 2^fsr) (the quantised-gradient
+    int mode;          // backward, :79 — negative g clamps to 0, so it yields -0: reproduced)
+    __device__ __forceinline__ float operator()(float x) const {
+        const float a = mode == 1 ? fabsf(x) : x;
+        const float q = qt_torch_clamp(rintf(a / step) * step, 0.0f, maxv);
+        return mode == 0 ? q : qt_torch_sign(x) * q;
+    }
+};
+struct OpLogQuant {   // log_lin_connect.py:31-33: [sign(x) *] 2^clamp(round(log2|x|), fsr - 2^bits, fsr)
+    float lo, hi;
+    int with_sign;
+    __device__ __forceinline__ float operator()(float x) const {
+        const float e = qt_torch_clamp(rintf(log2f(fabsf(x))), lo, hi);   // x = 0: -inf -> lo
+        const float p = exp2f(e);                                        // integer e: exact (0 below 2^-149)
+        return with_sign ? qt_torch_sign(x) * p : p;
+    }
+};
+
 template <class Op>
 __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x,
                                                     float* __restrict__ y, int64_t n, int64_t head,
@@ -131,6 +156,20 @@ int qt_dorefa_quantize_f32(const float* x, float* y, int64_t n, int bit_width,
     const float two_k = (float)(1ull << bit_width);
     const float nf = two_k - 1.0f;
     OpDorefa op{nf, 1.0f / nf};
+    return launch_unary(x, y, n, stream, op);
+}
+
+int qt_lin_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_width, int mode, qt_stream_t stream) {
+    if (bit_width < 1 || bit_width > 32 || mode < 0 || mode > 2 || fsr < -60 || fsr > 60) return QT_ERR_INVALID_ARG;
+    if (bit_width == 32) return launch_unary(x, y, n, stream, OpCopy{});
+    OpLinQuant op{ldexpf(1.0f, fsr - bit_width), ldexpf(1.0f, fsr), mode};
+    return launch_unary(x, y, n, stream, op);
+}
+
+int qt_log_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_width, int with_sign,
+                        qt_stream_t stream) {
+    if (bit_width < 1 || bit_width > 16 || fsr < -60 || fsr > 60) return QT_ERR_INVALID_ARG;
+    OpLogQuant op{(float)fsr - (float)(1 << bit_width), (float)fsr, with_sign ? 1 : 0};
     return launch_unary(x, y, n, stream, op);
 }
 

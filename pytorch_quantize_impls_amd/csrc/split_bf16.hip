@@ -22,7 +22,8 @@ __device__ __forceinline__ uint32_t bf16_rn_bits(float f) {  // round-to-nearest
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
-// mode: 0 = activation split, 1 = safeSign weight, 2 = ternary weight, 3 = torch.sign weight (0 -> 0)
+// mode: 0 = activation split, 1 = safeSign weight, 2 = ternary weight, 3 = torch.sign weight (0 -> 0),
+//       4 = raw weight: bf16_rn(w) replicated (for weights that are exact in bf16: Lin / Log fixed-point levels)
 template <int MODE>
 __global__ __launch_bounds__(256) void triple_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ alpha,
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void triple_kernel(const float* __restrict__ x
                 float q;
                 if (MODE == 1) q = qt_safe_sign(v);
                 else if (MODE == 2) q = qt_ternarize(v);
-                else q = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+                else if (MODE == 3) q = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+                else q = v;
                 const uint32_t qb = bf16_rn_bits(q);
                 h[3 * e] = h[3 * e + 1] = h[3 * e + 2] = qb;
             }
@@ -220,7 +222,7 @@ extern "C" int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, in
 
 extern "C" int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out,
                                   int64_t ld_bytes, int64_t rows, int64_t K, int mode, qt_stream_t stream) {
-    if (rows < 0 || K < 0 || ldx < K || mode < 0 || mode > 3) return QT_ERR_INVALID_ARG;
+    if (rows < 0 || K < 0 || ldx < K || mode < 0 || mode > 4) return QT_ERR_INVALID_ARG;
     if (rows == 0) return QT_OK;
     if (!out || (!x && K > 0)) return QT_ERR_INVALID_ARG;
     if (ld_bytes < 6 * K || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
@@ -233,7 +235,8 @@ extern "C" int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alph
         case 0: QT_LAUNCH(0); break;
         case 1: QT_LAUNCH(1); break;
         case 2: QT_LAUNCH(2); break;
-        default: QT_LAUNCH(3); break;
+        case 3: QT_LAUNCH(3); break;
+        default: QT_LAUNCH(4); break;
     }
 #undef QT_LAUNCH
     return qt_check_launch();

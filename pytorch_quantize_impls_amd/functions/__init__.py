@@ -6,4 +6,5 @@ from .dorefa_connect import nnDorefaQuant, DorefaQuant, nnQuantWeight, QuantDens
 from .terner_connect import (TernaryConnectDeterministic, TernaryConnectStochastic, TernaryConnect,
                              TernaryDense, TernaryConv2d)
 from .xnor_connect import nnQuantXnor, QuantXnor, XNORDense, XNORConv2d
+from .log_lin_connect import LogQuant, LinQuant, nnQuant, Quant
 from .common import safeSign

@@ -135,6 +135,17 @@ def dorefa_quantize(x: torch.Tensor, bit_width: int) -> torch.Tensor:
     return _unary("qt_dorefa_quantize_f32", x, ctypes.c_int(int(bit_width)))
 
 
+def lin_quantize(x: torch.Tensor, fsr: int, bit_width: int, mode: int = 1) -> torch.Tensor:
+    """LinQuant forward (mode 0 unsigned / 1 with_sign) or its quantised-gradient backward (mode 2)
+    (functions/log_lin_connect.py:61-79)."""
+    return _unary("qt_lin_quantize_f32", x, ctypes.c_int(int(fsr)), ctypes.c_int(int(bit_width)), ctypes.c_int(int(mode)))
+
+
+def log_quantize(x: torch.Tensor, fsr: int, bit_width: int, with_sign: bool = True) -> torch.Tensor:
+    """LogQuant forward / quantised-gradient backward (functions/log_lin_connect.py:31-40)."""
+    return _unary("qt_log_quantize_f32", x, ctypes.c_int(int(fsr)), ctypes.c_int(int(bit_width)), ctypes.c_int(1 if with_sign else 0))
+
+
 def _binary(name: str, a: torch.Tensor, b: torch.Tensor, *extra) -> torch.Tensor:
     a = _require(a, "a").contiguous()
     b = _require(b, "b").contiguous()
@@ -723,7 +734,7 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
 # real-valued activation x quantised weight: exact bf16 triples + bf16 MFMA GEMM
 # ----------------------------------------------------------------------------------------------
 
-_TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3}
+_TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3, "raw": 4}
 
 
 def triple_ld_bytes(K: int, granule: int = 128) -> int:

@@ -9,6 +9,8 @@ Deliberate deviations, both upstream defects:
   * ``dorefa_net_convert(net, weight_bit=3)`` upstream forwards ``weight_bit=`` to
     ``LinearDorefa.convert(other, bit_width)`` and dies with a TypeError (utils/convertor.py:47-51);
     here the argument reaches the layer as ``bit_width``.
+  * ``log_lin_net_convert(net, fsr, bitwight, dtype)`` upstream forwards ``bitwight=`` to ``convert(other, ..., bit_width)``
+    (utils/convertor.py:60-64): TypeError; here it arrives as ``bit_width`` (the misspelt keyword is kept as an alias).
   * ``xnor_net_convert`` upstream forwards ``quant_input`` to ``LinearXNOR.convert`` which does not take
     it (layers/xnor_layers.py:9-13); here only the conv layer receives it.
 """
@@ -21,6 +23,7 @@ from ..layers.binary_layers import LinearBin, BinConv2d
 from ..layers.terner_layers import LinearTer, TerConv2d
 from ..layers.dorefa_layers import LinearDorefa, DorefaConv2d
 from ..layers.xnor_layers import LinearXNOR, XNORConv2d
+from ..layers.log_lin_layers import LinearQuant, QuantConv2d
 
 
 def _target(entry):
@@ -63,3 +66,9 @@ def dorefa_net_convert(net, weight_bit=3):
 def xnor_net_convert(net, dim=[0, 1], quant_input=False):
     return convert(net, {nn.Linear: (LinearXNOR, {"dim": dim}),
                          nn.Conv2d: (XNORConv2d, {"dim": dim, "quant_input": quant_input})})
+
+
+def log_lin_net_convert(net, fsr=7, bit_width=3, dtype="lin", bitwight=None):
+    """Lin / Log fixed-point family (utils/convertor.py:60-64)."""
+    kw = {"fsr": fsr, "bit_width": bit_width if bitwight is None else bitwight, "dtype": dtype}
+    return convert(net, {nn.Linear: (LinearQuant, kw), nn.Conv2d: (QuantConv2d, kw)})

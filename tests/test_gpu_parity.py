@@ -3,6 +3,7 @@ golden vectors.  Integer / bit / index results: bit-exact.  Float tails: max|a-b
 Every test asserts that the libqt_hip.so entry points actually ran (no silent torch path)."""
 import copy
 import hashlib
+import os
 import warnings
 
 import numpy as np
@@ -1201,3 +1202,71 @@ def test_conv_wrappers_reject_mismatched_pixel_planes(dev):
     wc = ops.pack_conv_weight_codes(g(synth.uniform(3, (8, 32, 3, 3), -1, 1), dev))
     with pytest.raises(ValueError, match="pixel plane holds"):
         ops.conv2d_codes(codes, (2, 32, 7, 6), wc, (3, 3), 1.0, None, 1, 1, 1)
+
+
+# ---- Lin / Log fixed-point family ---------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def g9():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_loglin_v1.npz"))
+
+
+def _same_nan(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and \
+        np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)])
+
+
+@pytest.mark.gpu
+def test_lin_log_kernels_vs_reference_vectors(dev, oracle, g9):
+    from pytorch_quantize_impls_amd.functions import LinQuant, LogQuant
+    for fsr, bits in g9["g9_cfgs"].tolist():
+        for sign in (1, 0):
+            for nm in ("edge", "rand"):
+                x = g(g9[f"g9_{nm}"], dev)
+                tag = f"f{fsr}_b{bits}_s{sign}_{nm}"
+                with used("qt_lin_quantize_f32", "qt_log_quantize_f32"):
+                    yl = LinQuant(fsr, bits, bool(sign)).apply(x)
+                    yg = LogQuant(fsr, bits, bool(sign)).apply(x)
+                assert _same_nan(n(yl), g9[f"g9_lin_{tag}"]), ("lin", tag)
+                assert _same_nan(n(yg), g9[f"g9_log_{tag}"]), ("log", tag)
+        gr = g(g9["g9_rand"], dev)
+        xin = torch.ones_like(gr, requires_grad=True)
+        LogQuant(fsr, bits, True, lin_back=False).apply(xin).backward(gr)
+        assert _same_nan(n(xin.grad), g9[f"g9_logbwd_f{fsr}_b{bits}_rand"])
+        xin = torch.ones_like(gr, requires_grad=True)
+        LinQuant(fsr, bits, True, lin_back=False).apply(xin).backward(gr)
+        assert _same_nan(n(xin.grad), oracle.lin_quantize(g9["g9_rand"], fsr, bits, 2))
+    # odd length / misaligned views exercise the scalar head and tail of the elementwise kernel
+    x = g(synth.normal(3, (1003,)) * 9, dev)
+    assert _same_nan(n(ops.log_quantize(x[1:], 3, 2)), oracle.log_quantize(n(x)[1:], 3, 2))
+    assert _same_nan(n(ops.lin_quantize(x[1:], 3, 2, 1)), oracle.lin_quantize(n(x)[1:], 3, 2, 1))
+
+
+@pytest.mark.gpu
+def test_lin_log_layers_vs_reference_vectors(dev, g9):
+    """LinearQuant / QuantConv2d: device forward (exact-bf16 weight levels x bf16-triple activations on the matrix
+    cores in eval / no-grad mode, dense library under autograd) against the reference's outputs and gradients."""
+    from pytorch_quantize_impls_amd.layers import LinearQuant, QuantConv2d
+    for name in g9["g9_layer_cases"].tolist():
+        p = name.split("_")
+        dtype, fsr, bits = p[1], int(p[-2][1:]), int(p[-1][1:])
+        w, b, x = (g(g9[f"g9_{name}_{k}"], dev) for k in ("w", "b", "x"))
+        if name.startswith("lin_"):
+            layer = LinearQuant(w.shape[1], w.shape[0], True, dtype=dtype, fsr=fsr, bit_width=bits).to(dev)
+        else:
+            layer = QuantConv2d(w.shape[1], w.shape[0], w.shape[2], stride=int(p[5][1:]), padding=int(p[6][1:]),
+                                bias=True, fsr=fsr, bit_width=bits, dtype=dtype).to(dev)
+        layer.weight.data.copy_(w); layer.bias.data.copy_(b)
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi)
+        y.backward(g(g9[f"g9_{name}_gout"], dev))
+        assert norm_err(n(y), g9[f"g9_{name}_y"]) <= TOL, name
+        assert norm_err(n(xi.grad), g9[f"g9_{name}_gx"]) <= TOL and norm_err(n(layer.weight.grad), g9[f"g9_{name}_gw"]) <= TOL
+        with torch.no_grad(), used("qt_bf16x3_pack_f32", "qt_bf16_gemm" if name.startswith("lin_") else "qt_conv2d_implicit"):
+            y_ng = layer(x)                                        # training-mode weights, matrix-core route
+        assert norm_err(n(y_ng), g9[f"g9_{name}_y"]) <= TOL, name
+        layer.train(False)
+        with torch.no_grad(), used("qt_bf16_gemm" if name.startswith("lin_") else "qt_conv2d_implicit"):
+            ye = layer(x)
+        assert norm_err(n(ye), g9[f"g9_{name}_y_eval"]) <= TOL, name

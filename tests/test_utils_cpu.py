@@ -39,6 +39,9 @@ def test_family_converters_and_kwargs():
     d = dorefa_net_convert(net, weight_bit=2)       # upstream dies here (kwarg name), see convertor.py
     assert isinstance(d[0], L.DorefaConv2d) and isinstance(d[5], L.LinearDorefa)
     assert d[0].bit_width == 2 and d[5].bit_width == 2
+    from pytorch_quantize_impls_amd.utils import log_lin_net_convert
+    ll = log_lin_net_convert(net, fsr=2, bitwight=4, dtype="log")    # upstream's (misspelt) keyword, which crashes there
+    assert isinstance(ll[0], L.QuantConv2d) and isinstance(ll[5], L.LinearQuant) and ll[5].bit_width == 4 and ll[0].qdtype == "log"
     x = xnor_net_convert(net, dim=[0, 1])
     assert isinstance(x[0], L.XNORConv2d) and isinstance(x[5], L.LinearXNOR)
 
