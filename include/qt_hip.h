@@ -107,6 +107,9 @@ int qt_lin_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_wi
 int qt_log_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_width, int with_sign,
                         qt_stream_t stream);
 
+/* AP2 of the shift-based batch norm (functions/binary_connect.py:157-169): safeSign(x) * 2^round(log2|x|). */
+int qt_ap2_f32(const float* x, float* y, int64_t n, qt_stream_t stream);
+
 /* XNOR-Net weight quantiser over a row-major [R, C] view of the weight:
  * alpha[c] = mean_r |w[r,c]| ;  wq[r,c] = sign(w[r,c]) * alpha[c]  (torch.sign: 0 -> 0).  wq may be NULL
  * (alpha only).  XNORDense: R = N, C = K (functions/xnor_connect.py:112-113, global DIM = 0);

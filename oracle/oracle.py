@@ -126,6 +126,14 @@ def log_quantize(x, fsr, bits, with_sign=True):
     return y
 
 
+def ap2(x):
+    """functions/binary_connect.py:157-169."""
+    x, xp = _f(x)
+    y = np.empty_like(x)
+    lib().qo_ap2(xp, y.ctypes.data_as(_f32p), _i64(x.size))
+    return y
+
+
 # ---- packed format ---------------------------------------------------------------------------
 
 def packed_ld(K: int) -> int:

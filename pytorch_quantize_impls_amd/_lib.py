@@ -49,6 +49,7 @@ SIGNATURES = {
     "qt_check_pm1_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p]),
     "qt_lin_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_int, _c_int, _c_p]),
     "qt_log_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_int, _c_int, _c_p]),
+    "qt_ap2_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "qt_popc_force_kernel": (_c_int, [_c_int]),
     "qt_conv_force_kernel": (_c_int, [_c_int]),
     "qt_xnor_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,

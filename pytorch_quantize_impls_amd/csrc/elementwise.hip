@@ -42,7 +42,7 @@ struct OpLogQuant {   // log_lin_connect.py:31-33: [sign(x) *] 2^clamp(round(log
     __device__ __forceinline__ float operator()(float x) const {
         const float e = qt_torch_clamp(rintf(log2f(fabsf(x))), lo, hi);   // x = 0: -inf -> lo
         const float p = exp2f(e);                                        // integer e: exact (0 below 2^-149)
-        return with_sign ? qt_torch_sign(x) * p : p;
+        return with_sign == 2 ? qt_safe_sign(x) * p : (with_sign ? qt_torch_sign(x) * p : p);   // 2: AP2's safeSign
     }
 };
 
@@ -170,6 +170,11 @@ int qt_log_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_wi
                         qt_stream_t stream) {
     if (bit_width < 1 || bit_width > 16 || fsr < -60 || fsr > 60) return QT_ERR_INVALID_ARG;
     OpLogQuant op{(float)fsr - (float)(1 << bit_width), (float)fsr, with_sign ? 1 : 0};
+    return launch_unary(x, y, n, stream, op);
+}
+
+int qt_ap2_f32(const float* x, float* y, int64_t n, qt_stream_t stream) {
+    OpLogQuant op{-INFINITY, INFINITY, 2};   // safeSign(x) * 2^round(log2|x|), no clamp
     return launch_unary(x, y, n, stream, op);
 }
 

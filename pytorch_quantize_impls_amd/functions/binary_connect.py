@@ -129,8 +129,9 @@ def BinaryConv2d(stride=1, padding=1, dilation=1, groups=1):
 
 
 def AP2(x):
-    """sign(x) * 2^round(log2|x|) (binary_connect.py:157-169). Elementwise torch; not on the
-    GEMM hot path."""
+    """safeSign(x) * 2^round(log2|x|) (binary_connect.py:157-169); HIP kernel for device fp32 tensors."""
+    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+        return ops.ap2(x)
     return safeSign(x) * torch.pow(torch.full_like(x, 2.0), torch.round(torch.log2(torch.abs(x))))
 
 

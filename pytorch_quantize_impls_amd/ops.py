@@ -146,6 +146,11 @@ def log_quantize(x: torch.Tensor, fsr: int, bit_width: int, with_sign: bool = Tr
     return _unary("qt_log_quantize_f32", x, ctypes.c_int(int(fsr)), ctypes.c_int(int(bit_width)), ctypes.c_int(1 if with_sign else 0))
 
 
+def ap2(x: torch.Tensor) -> torch.Tensor:
+    """safeSign(x) * 2^round(log2|x|) (functions/binary_connect.py:157-169)."""
+    return _unary("qt_ap2_f32", x)
+
+
 def _binary(name: str, a: torch.Tensor, b: torch.Tensor, *extra) -> torch.Tensor:
     a = _require(a, "a").contiguous()
     b = _require(b, "b").contiguous()

@@ -1270,3 +1270,11 @@ def test_lin_log_layers_vs_reference_vectors(dev, g9):
         with torch.no_grad(), used("qt_bf16_gemm" if name.startswith("lin_") else "qt_conv2d_implicit"):
             ye = layer(x)
         assert norm_err(n(ye), g9[f"g9_{name}_y_eval"]) <= TOL, name
+
+
+@pytest.mark.gpu
+def test_ap2_kernel_vs_reference_vector(dev, g9):
+    from pytorch_quantize_impls_amd.functions import AP2
+    with used("qt_ap2_f32"):
+        y = AP2(g(g9["g9_ap2_in"], dev))
+    assert _same_nan(n(y), g9["g9_ap2_out"])

@@ -99,3 +99,10 @@ def test_layer_plumbing():
     assert conv.stride == (2, 2) and conv.bit_width == 2
     conv.weight.data.fill_(100.0); conv.clamp()
     assert float(conv.weight.detach().max()) == 2.0
+
+
+def test_ap2_oracle_and_cpu_function_vs_reference_vector(oracle, g9):
+    from pytorch_quantize_impls_amd.functions import AP2
+    x = g9["g9_ap2_in"]
+    assert same(oracle.ap2(x), g9["g9_ap2_out"])
+    assert same(AP2(torch.from_numpy(x)).numpy(), g9["g9_ap2_out"])
