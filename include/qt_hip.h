@@ -246,6 +246,14 @@ int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t 
 int qt_bf16x3_pack_f32(const float* x, int64_t ldx, const float* alpha, uint16_t* out, int64_t ld_bytes,
                        int64_t rows, int64_t K, int mode, qt_stream_t stream);
 
+/* Six-term planes for REAL x REAL contractions (XNORConv2d: weights sign(W) * alpha[kh,kw] are not bf16 values,
+ * functions/xnor_connect.py:135-146).  Element k -> bf16 slots 6k..6k+5: role 0 (activation) [xh xh xh xm xm xl],
+ * role 1 (weight) [wh wm wl wh wm wh] with x = xh + xm + xl the exact bf16 split: a bf16 GEMM / implicit conv over
+ * 6K of the two planes sums the six largest cross terms, i.e. x*w to ~2^-24 relative with fp32 accumulation.
+ * out: [rows][ld_bytes/2] bf16, ld_bytes % 16 == 0, ld_bytes >= 12*K, pad zero. */
+int qt_bf16x6_pack_f32(const float* x, int64_t ldx, uint16_t* out, int64_t ld_bytes, int64_t rows, int64_t K,
+                       int role, qt_stream_t stream);
+
 /* Space-to-depth gather + split for strided first-layer convs: out pixel (n, Y, X), element
  * e = (c*s + dy)*s + dx  <-  triple of x[n, c, s*Y+dy-ph, s*X+dx-pw] (zero outside).  x is addressed by
  * element strides (sN, sC, sH, sW): NCHW or NHWC storage.  Plane rows = N * ceil((H+2ph)/s) * ceil((W+2pw)/s).

@@ -69,6 +69,46 @@ __global__ __launch_bounds__(256) void triple_kernel(const float* __restrict__ x
     }
 }
 
+// Six-term planes for REAL x REAL products (XNOR-Net convs: weights sign(W) * alpha are not bf16 values).
+// With x = xh + xm + xl and w = wh + wm + wl (exact bf16 splits), the six largest of the nine cross terms,
+//     xh*wh + xh*wm + xh*wl + xm*wh + xm*wm + xl*wh,
+// reproduce x*w to ~2^-24 relative (the dropped terms are <= 2^-25 |x w|), each product exact in the fp32
+// accumulator.  Element k occupies bf16 slots 6k..6k+5:  role 0 (activation) [xh xh xh xm xm xl],
+// role 1 (weight) [wh wm wl wh wm wh], so a plain bf16 GEMM over 6K of the two planes pairs them term by term.
+template <int ROLE>
+__global__ __launch_bounds__(256) void sext_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                   int64_t ld_elems, int64_t rows, int64_t K) {
+    const int64_t per_row = ld_elems / 6;                     // one work item = 1 element = 6 bf16 = 12 B
+    const int64_t tail_words = (ld_elems - per_row * 6) / 2;
+    const int64_t total = rows * (per_row + 1);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / (per_row + 1), k = t - row * (per_row + 1);
+        uint32_t* orow = reinterpret_cast<uint32_t*>(out + row * ld_elems);
+        if (k == per_row) {
+            for (int64_t w = 0; w < tail_words; ++w) orow[per_row * 3 + w] = 0;
+            continue;
+        }
+        uint32_t h = 0, m = 0, l = 0;
+        if (k < K) {
+            const float v = x[row * ldx + k];
+            h = bf16_rn_bits(v);
+            const float r1 = v - bf16_bits_to_f32(h);
+            m = bf16_rn_bits(r1);
+            l = bf16_rn_bits(r1 - bf16_bits_to_f32(m));
+        }
+        if (ROLE == 0) {
+            orow[k * 3 + 0] = h | (h << 16);
+            orow[k * 3 + 1] = h | (m << 16);
+            orow[k * 3 + 2] = m | (l << 16);
+        } else {
+            orow[k * 3 + 0] = h | (m << 16);
+            orow[k * 3 + 1] = l | (h << 16);
+            orow[k * 3 + 2] = m | (h << 16);
+        }
+    }
+}
+
 // Space-to-depth gather + split in one pass: pixel (n, Y, X) of the output plane holds, for every
 // e = (c*s + dy)*s + dx, the triple of x[n, c, s*Y + dy - ph, s*X + dx - pw] (zero outside the image).
 // A strided first-layer conv (k x k, stride s, padding p) on x equals a stride-1 ceil(k/s)^2 conv on this
@@ -217,6 +257,22 @@ extern "C" int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, in
     const int grid = qt_stream_grid((total + 255) / 256);
     hipLaunchKernelGGL(s2d_triple_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, sN, sC, sH, sW,
                        out, ld_elems, N, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws);
+    return qt_check_launch();
+}
+
+extern "C" int qt_bf16x6_pack_f32(const float* x, int64_t ldx, uint16_t* out, int64_t ld_bytes, int64_t rows,
+                                  int64_t K, int role, qt_stream_t stream) {
+    if (rows < 0 || K < 0 || ldx < K || role < 0 || role > 1) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!out || (!x && K > 0)) return QT_ERR_INVALID_ARG;
+    if (ld_bytes < 12 * K || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (ld_bytes == 0) return QT_OK;
+    const int64_t ld_elems = ld_bytes / 2;
+    const int grid = qt_stream_grid((rows * (ld_elems / 6 + 1) + 255) / 256);
+    if (role == 0)
+        hipLaunchKernelGGL((sext_kernel<0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ld_elems, rows, K);
+    else
+        hipLaunchKernelGGL((sext_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ld_elems, rows, K);
     return qt_check_launch();
 }
 

@@ -111,6 +111,18 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
             if quant_input:
                 input = torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
             ctx.save_for_backward(input, weight, mean_weight, bias)
+            if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0
+                    and groups == 1 and not isinstance(padding, str)):
+                # sign(W) * alpha[kh, kw] is a REAL weight: six-term bf16 planes, implicit-GEMM conv on the
+                # matrix cores (fp32-GEMM accuracy); the result keeps the input's memory format
+                y2 = ops.real_conv2d(input, weight_b.detach(), bias, stride, padding, dilation)
+                if y2 is not None:
+                    N_, _, H, W = input.shape
+                    Ho, Wo = ops.conv_out_hw(H, W, weight.shape[2], weight.shape[3], stride, padding, dilation)
+                    y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+                    if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                        y = y.contiguous()
+                    return y
             return torch.nn.functional.conv2d(input, weight_b, bias=bias, stride=stride,
                                               padding=padding, dilation=dilation, groups=groups)
 

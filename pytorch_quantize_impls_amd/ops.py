@@ -807,6 +807,72 @@ def bf16_gemm(x: TriplePlanes, w: TriplePlanes, bias: Optional[torch.Tensor] = N
     return out
 
 
+# ---- real x real: six-term planes ----------------------------------------------------------------------------
+
+def sext_ld_bytes(K: int, granule: int = 128) -> int:
+    """Row stride in bytes of a six-term plane holding K features (12 bytes each)."""
+    return max(granule, (12 * int(K) + granule - 1) // granule * granule)
+
+
+def split_bf16x6(x: torch.Tensor, role: int, ld_bytes: Optional[int] = None) -> TriplePlanes:
+    """Six-term bf16 plane of an fp32 matrix: role 0 = activation order, 1 = weight order (qt_bf16x6_pack_f32).
+    Returned as TriplePlanes with K = 2 * features, so that 3*K is the bf16 length of a row."""
+    _require(x, "input")
+    x2 = _as_rows(x)
+    rows, K = int(x2.shape[0]), int(x2.shape[1])
+    ld = sext_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
+    out = torch.empty((rows, ld // 2), dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("qt_bf16x6_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)), _p(out),
+                  ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K), ctypes.c_int(int(role)), _stream(x.device))
+    return TriplePlanes(data=out, rows=rows, K=2 * K)
+
+
+def real_linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """y = x . weight^T (+ bias) for REAL x and REAL weight on the bf16 matrix cores (six-term planes): fp32-GEMM
+    accuracy at 6 MFMA products per multiply-accumulate."""
+    N = weight.shape[0]
+    y = bf16_gemm(split_bf16x6(x, 0), split_bf16x6(weight.reshape(N, -1), 1), bias)
+    return y.view(*x.shape[:-1], N)
+
+
+def pack_conv_weight_bf16x6(weight: torch.Tensor) -> TriplePlanes:
+    """[Cout, Cin, kh, kw] REAL weight -> six-term plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 12*Cin bytes rounded to 16)."""
+    _require(weight, "weight")
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    Cb = sext_ld_bytes(Cin, 16)
+    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
+    taps = split_bf16x6(wt, 1, ld_bytes=Cb)
+    kbytes = kh * kw * Cb
+    ld = max(128, (kbytes + 127) // 128 * 128)
+    data = taps.data.view(Cout, kbytes // 2)
+    if ld != kbytes:
+        padded = torch.zeros((Cout, ld // 2), dtype=torch.int16, device=weight.device)
+        padded[:, :kbytes // 2] = data
+        data = padded
+    return TriplePlanes(data=data, rows=Cout, K=kbytes // 6)
+
+
+def real_conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=1, padding=0, dilation=1,
+                weight_planes: Optional[TriplePlanes] = None) -> Optional[torch.Tensor]:
+    """conv2d(x, weight) for REAL x and REAL weight (groups = 1, zero padding) as an implicit GEMM over six-term
+    planes on the bf16 matrix cores.  Returns the NHWC result [N*Ho*Wo, Cout], or None if the shape is outside the
+    implicit kernel's limits (caller falls back to the dense library)."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    Cout, _, kh, kw = (int(v) for v in weight.shape)
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Cb = sext_ld_bytes(C, 16)
+    nhwc = x.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    px = split_bf16x6(nhwc.view(N * H * W, C), 0, ld_bytes=Cb)
+    wt = weight_planes if weight_planes is not None else pack_conv_weight_bf16x6(weight)
+    bias = _check_bias(bias, Cout, x.device)
+    return _conv_implicit(2, px.data, N, H, W, Cb // 4, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, wt.ld_words,
+                          bias, 1.0, None, Cout)
+
+
 def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, alpha=None,
                  weight_triples: Optional[TriplePlanes] = None) -> torch.Tensor:
     """y = x . Q(weight)^T (+ bias) for REAL-valued x: Q in {safeSign, ternary, torch.sign}; ``alpha``

@@ -1278,3 +1278,41 @@ def test_ap2_kernel_vs_reference_vector(dev, g9):
     with used("qt_ap2_f32"):
         y = AP2(g(g9["g9_ap2_in"], dev))
     assert _same_nan(n(y), g9["g9_ap2_out"])
+
+
+@pytest.mark.gpu
+def test_real_x_real_six_term_route_vs_fp64(dev):
+    """REAL activations x REAL weights through six-term bf16 planes (XNORConv2d's contraction): fp32-GEMM accuracy."""
+    torch.manual_seed(12)
+    for (M, N, K) in [(5, 7, 31), (300, 130, 777), (1024, 512, 2048)]:
+        x = torch.randn((M, K), device=dev) * 3
+        w = torch.randn((N, K), device=dev) * 0.2
+        b = torch.randn((N,), device=dev)
+        with used("qt_bf16x6_pack_f32", "qt_bf16_gemm"):
+            y = ops.real_linear(x, w, b)
+        ref = x.double() @ w.double().t() + b.double()
+        assert norm_err(n(y), n(ref)) <= TOL, (M, N, K)
+    for (Cin, Cout, k, st, pd, H) in [(3, 16, 3, 1, 1, 12), (32, 48, 5, 2, 2, 15), (64, 192, 3, 1, 1, 13)]:
+        x = torch.randn((2, Cin, H, H), device=dev)
+        w = torch.randn((Cout, Cin, k, k), device=dev) * 0.3
+        b = torch.randn((Cout,), device=dev)
+        with used("qt_bf16x6_pack_f32", "qt_conv2d_implicit"):
+            y2 = ops.real_conv2d(x, w, b, st, pd, 1)
+        Ho = (H + 2 * pd - k) // st + 1
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), st, pd)
+        assert norm_err(n(y2.view(2, Ho, Ho, Cout).permute(0, 3, 1, 2)), n(ref)) <= TOL
+
+
+@pytest.mark.gpu
+def test_xnor_conv2d_layer_runs_on_the_matrix_cores(dev, golden):
+    name = golden["g4_conv_cases"].tolist()[0]
+    p = name.split("_")
+    Cin, Cout, k, st, pd = int(p[0][1:]), int(p[1][1:]), int(p[2][1:]), int(p[3][1:]), int(p[4][1:])
+    has_b = p[7] == "bias"
+    layer = XNORConv2d(Cin, Cout, k, stride=st, padding=pd, bias=has_b).to(dev)
+    layer.weight.data.copy_(g(golden[f"g4_conv_{name}_w"], dev))
+    if has_b:
+        layer.bias.data.copy_(g(golden[f"g4_conv_{name}_b"], dev))
+    with used("qt_xnor_weight_f32", "qt_bf16x6_pack_f32", "qt_conv2d_implicit"):
+        y = layer(g(golden[f"g4_conv_{name}_x"], dev))
+    assert norm_err(n(y), golden[f"g4_conv_{name}_xnor_y"]) <= TOL
