@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Longer randomised parity soak (not part of the test-suite): packed conv (tensor + packed routes, fused blocks),
+packed GEMM in both formulations, real-input convs, against CPU float64 evaluations.  python tools/soak_fuzz.py [seed] [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from pytorch_quantize_impls_amd import ops, packed as pk
+from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, LinearBin, FusedConvPoolBnSign, fold_batchnorm
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+rng = np.random.default_rng(seed)
+torch.manual_seed(seed)
+dev = torch.device("cuda:0")
+def tern(w): return torch.where(w >= 0.5, 1.0, torch.where(w < -0.5, -1.0, 0.0)).double()
+def sgn(w): return torch.where(w < 0, -1.0, 1.0).double()
+bad = 0
+t0 = time.time()
+for it in range(iters):
+    # ---- conv
+    Cin = int(rng.choice([1, 3, 16, 32, 48, 64, 96, 128, 192, 256, 320]))
+    Cout = int(rng.choice([8, 32, 64, 96, 128, 192, 256, 384, 400]))
+    k = int(rng.integers(1, 6)); st = int(rng.integers(1, 3)); pd = int(rng.integers(0, 3)); dl = int(rng.integers(1, 3))
+    N = int(rng.integers(1, 9)); H = int(rng.integers(dl * (k - 1) + 1, 30)) + 1; W = int(rng.integers(dl * (k - 1) + 1, 30)) + 1
+    ter = bool(rng.integers(0, 2))
+    conv = (TerConv2d if ter else BinConv2d)(Cin, Cout, k, stride=st, padding=pd, dilation=dl).to(dev)
+    conv.weight.data.uniform_(-1.3, 1.3); conv.bias.data.zero_()
+    conv.eval()
+    x = torch.randn((N, Cin, H, W), device=dev).sign(); x[x == 0] = 1
+    x = x.contiguous(memory_format=torch.channels_last)
+    wq = tern(conv.weight.detach().cpu()) if ter else sgn(conv.weight.detach().cpu())
+    ref = torch.nn.functional.conv2d(x.cpu().double(), wq, None, st, pd, dl)
+    act = pk.PackedActivation(ops.sign_pack(x.permute(0, 2, 3, 1).contiguous())[0], tuple(x.shape))
+    with torch.no_grad():
+        y1, y2 = conv(x).cpu().double(), conv(act).cpu().double()
+    if not (torch.equal(y1, ref) and torch.equal(y2, ref)):
+        bad += 1; print("CONV MISMATCH", (Cin, Cout, k, st, pd, dl, N, H, W, ter), float((y1 - ref).abs().max()), float((y2 - ref).abs().max()))
+    # fused block vs the same chain in float64 (skip elements within 1e-4 of the threshold)
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+    bn.running_mean.normal_(0, 4); bn.running_var.uniform_(0.5, 30); bn.weight.data.normal_(); bn.bias.data.normal_()
+    Ho, Wo = ref.shape[2:]
+    pool = torch.nn.MaxPool2d(2, 2) if min(Ho, Wo) >= 2 and it % 2 else None
+    with torch.no_grad():
+        out = FusedConvPoolBnSign(conv, bn, pool)(act)
+        al, be = (t.cpu().double() for t in fold_batchnorm(bn))
+        t_ = ref if pool is None else torch.nn.functional.max_pool2d(ref, 2, 2)
+        v = t_ * al.view(1, -1, 1, 1) + be.view(1, -1, 1, 1)
+        want_neg = (v < 0).permute(0, 2, 3, 1).reshape(-1, Cout)
+        got = ((out.planes.sign.cpu().unsqueeze(-1) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(out.planes.rows, -1)[:, :Cout].bool()
+        margin = (v.abs() > 1e-4).permute(0, 2, 3, 1).reshape(-1, Cout)
+    if not torch.equal(got[margin], want_neg[margin]):
+        bad += 1; print("FUSED MISMATCH", (Cin, Cout, k, st, pd, dl, N, H, W, ter, pool is not None), int((got[margin] != want_neg[margin]).sum()))
+    # ---- GEMM
+    M, Nn, K = int(rng.integers(1, 1500)), int(rng.integers(1, 1200)), int(rng.integers(1, 3000))
+    xm = torch.randn((M, K), device=dev); wm = torch.randn((Nn, K), device=dev)
+    refg = sgn(xm.cpu()) @ sgn(wm.cpu()).t()
+    xb, wb = ops.sign_pack(xm)[0], ops.sign_pack(wm)[0]
+    a = ops.xnor_gemm(xb, wb).cpu().double(); b = ops.nib_gemm(ops.bits_to_nib(xb), ops.bits_to_nib(wb)).cpu().double()
+    if not (torch.equal(a, refg) and torch.equal(b, refg)):
+        bad += 1; print("GEMM MISMATCH", (M, Nn, K))
+    # ---- real-input conv
+    if it % 3 == 0:
+        c1 = BinConv2d(int(rng.choice([1, 3, 4])), Cout, int(rng.integers(1, 12)), stride=int(rng.integers(1, 5)), padding=int(rng.integers(0, 4))).to(dev)
+        c1.binary_input = False
+        c1.eval()
+        Hh = int(rng.integers(c1.kernel_size[0], 70)) + 2
+        xr = torch.randn((2, c1.in_channels, Hh, Hh), device=dev) * 2
+        refr = torch.nn.functional.conv2d(xr.cpu().double(), sgn(c1.weight.detach().cpu()), c1.bias.detach().cpu().double(), c1.stride, c1.padding)
+        with torch.no_grad():
+            yr = c1(xr).cpu().double()
+        err = float((yr - refr).abs().max() / refr.abs().max())
+        if err > 1e-5:
+            bad += 1; print("REAL CONV", err, (c1.in_channels, Cout, c1.kernel_size, c1.stride, c1.padding, Hh))
+print(f"seed {seed}: {iters} iterations, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
