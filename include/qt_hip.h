@@ -224,11 +224,12 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
  * as ONE pass: bit = (max_window(x) * alpha[c] + beta[c]) < 0.  x: NHWC fp32 [N][H][W][C], C % 4 == 0;
  * alpha/beta: the folded eval BatchNorm (alpha = weight/sqrt(var+eps), beta = bias - mean*alpha);
  * pool_k = pool_s = 1 means no pooling; H = W = 1 covers BatchNorm1d on [N, C].
- * Output: NHWC pixel sign plane [N*Ho*Wo][ldp].  Replaces models/Alexnet/Alexnet_Bin.py:14-17 style
+ * pre_relu != 0 inserts a ReLU between the pooling and the BatchNorm (the Linear -> ReLU -> BatchNorm1d ->
+ * BinaryConnect pattern of benchmark/BinaryNet/MLPBin.py:42-44).  Output: NHWC pixel sign plane [N*Ho*Wo][ldp].  Replaces models/Alexnet/Alexnet_Bin.py:14-17 style
  * chains (MaxPool2d, BatchNorm2d, Hardtanh, BinaryConnect) in eval mode. */
 int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
                                   int64_t pool_k, int64_t pool_s, const float* alpha, const float* beta,
-                                  uint32_t* sign_plane, int64_t ldp, qt_stream_t stream);
+                                  uint32_t* sign_plane, int64_t ldp, int pre_relu, qt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Real-valued activation x quantised weight (first layer of every model, XNOR-Net layers, the general

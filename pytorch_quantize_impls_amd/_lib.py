@@ -68,7 +68,7 @@ SIGNATURES = {
     "qt_i8_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                             _c_i64, _c_i64, _c_p]),
     "qt_pool_affine_sign_pack_nhwc": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
-                                               _c_p, _c_i64, _c_p]),
+                                               _c_p, _c_i64, _c_int, _c_p]),
     "qt_bf16x3_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_bf16x3_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_bf16x6_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),

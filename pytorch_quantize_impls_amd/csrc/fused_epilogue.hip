@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 __global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
     const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta,
     uint32_t* __restrict__ plane, int64_t ldp, int64_t N, int H, int W, int C, int pk, int ps, int Ho,
-    int Wo) {
+    int Wo, int pre_relu) {
     const int64_t slots_per_pixel = ldp * 8;  // float4 slots per output pixel incl. pad (pad -> bit 0)
     const int64_t total = N * Ho * Wo * slots_per_pixel;  // multiple of 32 (ldp % 4 == 0)
     const int c4max = C / 4;
@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
                     m.z = (v.z > m.z || v.z != v.z) ? v.z : m.z;
                     m.w = (v.w > m.w || v.w != v.w) ? v.w : m.w;
                 }
+            if (pre_relu) {   // ReLU in front of the BatchNorm (benchmark/BinaryNet/MLPBin.py:42-44); NaN kept
+                m.x = m.x < 0.0f ? 0.0f : m.x; m.y = m.y < 0.0f ? 0.0f : m.y;
+                m.z = m.z < 0.0f ? 0.0f : m.z; m.w = m.w < 0.0f ? 0.0f : m.w;
+            }
             const float4 a = *reinterpret_cast<const float4*>(alpha + slot * 4);
             const float4 b = *reinterpret_cast<const float4*>(beta + slot * 4);
             // two roundings (mul, add), like the un-fused x*alpha + beta
@@ -114,7 +118,7 @@ extern "C" int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int6
 extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
                                              int64_t pool_k, int64_t pool_s, const float* alpha,
                                              const float* beta, uint32_t* sign_plane, int64_t ldp,
-                                             qt_stream_t stream) {
+                                             int pre_relu, qt_stream_t stream) {
     if (N < 0 || H <= 0 || W <= 0 || C <= 0 || pool_k < 1 || pool_s < 1) return QT_ERR_INVALID_ARG;
     if (pool_k > H || pool_k > W) return QT_ERR_INVALID_ARG;
     if (N == 0) return QT_OK;
@@ -128,6 +132,6 @@ extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t 
     const int grid = qt_stream_grid((total + 255) / 256);
     hipLaunchKernelGGL(pool_affine_sign_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, alpha,
                        beta, sign_plane, ldp, N, (int)H, (int)W, (int)C, (int)pool_k, (int)pool_s, (int)Ho,
-                       (int)Wo);
+                       (int)Wo, pre_relu ? 1 : 0);
     return qt_check_launch();
 }

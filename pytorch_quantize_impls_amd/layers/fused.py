@@ -35,8 +35,9 @@ def fold_batchnorm(bn):
 class FusedPoolBnSign(torch.nn.Module):
     """[MaxPool2d(k, s)] + eval BatchNorm + [Hardtanh] + BinaryConnect(deterministic) -> PackedActivation."""
 
-    def __init__(self, bn, pool=None, flatten_hwc=False):
+    def __init__(self, bn, pool=None, flatten_hwc=False, pre_relu=False):
         super().__init__()
+        self.pre_relu = bool(pre_relu)     # ReLU between the pooling and the BatchNorm (MLPBin.py:42-44 pattern)
         if pool is not None:
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
             st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
@@ -61,7 +62,8 @@ class FusedPoolBnSign(torch.nn.Module):
             raise TypeError("FusedPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
         if self._folded is None or self._folded[0].device != x.device:
             self._folded = fold_batchnorm(self.bn)
-        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, self._folded[0], self._folded[1], self.pool_k, self.pool_s)
+        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, self._folded[0], self._folded[1], self.pool_k, self.pool_s,
+                                                     pre_relu=self.pre_relu)
         if x.dim() == 2:
             return packed.PackedActivation(planes, (x.shape[0], x.shape[1]))
         act = packed.PackedActivation(planes, (x.shape[0], x.shape[1], Ho, Wo))
@@ -152,13 +154,18 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.
         pool = None
         if isinstance(mods[j], torch.nn.MaxPool2d):
             pool, j = mods[j], j + 1
+        pre_relu = False
+        if conv is None and j + 1 < len(mods) and isinstance(mods[j], torch.nn.ReLU) and \
+                isinstance(mods[j + 1], (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            pre_relu, j = True, j + 1           # Linear -> ReLU -> BatchNorm -> BinaryConnect (MLPBin.py:42-44)
         if j < len(mods) and isinstance(mods[j], (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
             bn, j2 = mods[j], j + 1
             if j2 < len(mods) and isinstance(mods[j2], torch.nn.Hardtanh) and mods[j2].min_val < 0 < mods[j2].max_val:
                 j2 += 1
             if j2 < len(mods) and _is_det_binary_connect(mods[j2]):
                 try:
-                    out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None else FusedPoolBnSign(bn, pool))
+                    out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None
+                               else FusedPoolBnSign(bn, pool, pre_relu=pre_relu))
                     i = j2 + 1
                     continue
                 except ValueError:

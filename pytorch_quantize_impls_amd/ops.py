@@ -242,7 +242,7 @@ def ternary_pack(x: torch.Tensor) -> BitPlanes:
 
 
 def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, pool_k: int = 1,
-                          pool_s: int = 1):
+                          pool_s: int = 1, pre_relu: bool = False):
     """Fused [MaxPool2d(pool_k, pool_s)] -> eval-BatchNorm (x*alpha+beta) -> Hardtanh -> sign -> bit-pack.
     x: [N, C, H, W] fp32 (channels_last storage is used as-is, NCHW storage is transposed once) or
     [N, C].  Returns (BitPlanes with rows = N*Ho*Wo, K = C; (Ho, Wo))."""
@@ -266,7 +266,8 @@ def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tens
     I = ctypes.c_int64
     with torch.cuda.device(x.device):
         _lib.call("qt_pool_affine_sign_pack_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)),
-                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), _stream(x.device))
+                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), ctypes.c_int(1 if pre_relu else 0),
+                  _stream(x.device))
     return BitPlanes(sign=plane, rows=N * Ho * Wo, K=C), (Ho, Wo)
 
 

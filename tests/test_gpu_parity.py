@@ -1316,3 +1316,30 @@ def test_xnor_conv2d_layer_runs_on_the_matrix_cores(dev, golden):
     with used("qt_xnor_weight_f32", "qt_bf16x6_pack_f32", "qt_conv2d_implicit"):
         y = layer(g(golden[f"g4_conv_{name}_x"], dev))
     assert norm_err(n(y), golden[f"g4_conv_{name}_xnor_y"]) <= TOL
+
+
+@pytest.mark.gpu
+def test_fused_relu_bn_sign_mlp_pattern(dev):
+    """Linear -> ReLU -> BatchNorm1d -> BinaryConnect (benchmark/BinaryNet/MLPBin.py:42-44) fused: fuse_sequential
+    recognises the ReLU in front of the BatchNorm; planes equal the un-fused modules' sign bits."""
+    from pytorch_quantize_impls_amd.layers import fuse_sequential, FusedPoolBnSign
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    torch.manual_seed(6)
+    seq = torch.nn.Sequential(LinearBin(200, 96), torch.nn.ReLU(), torch.nn.BatchNorm1d(96), BinaryConnect(),
+                              LinearBin(96, 10)).to(dev).eval()
+    bn = seq[2]
+    bn.running_mean.normal_(2, 3); bn.running_var.uniform_(0.5, 20); bn.weight.data.normal_(); bn.bias.data.normal_()
+    fused = fuse_sequential(seq)
+    assert isinstance(fused[1], FusedPoolBnSign) and fused[1].pre_relu and len(fused) == 3
+    x = torch.randn((64, 200), device=dev).sign()
+    with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc"):
+        yf = fused(x)
+        h = seq[0](x)
+        act = fused[1](h)
+        alpha, beta = (1.0 / torch.sqrt(bn.running_var + bn.eps)) * bn.weight, None
+        beta = bn.bias - bn.running_mean * alpha
+        want = ops.sign_pack(ops.binarize(torch.relu(h) * alpha + beta))[0]
+    assert torch.equal(act.planes.sign, want.sign)
+    with torch.no_grad():
+        yu = seq(x)
+    assert norm_err(n(yf), n(yu)) <= 1e-3       # identical unless a BatchNorm threshold tie flips a bit (MIOpen vs folded form)
