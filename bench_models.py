@@ -59,36 +59,19 @@ class AlexNetBin(nn.Module):
 
 
 class FusedAlexNetBin(nn.Module):
-    """Inference form of an (eval-mode) AlexNetBin: every [MaxPool, BatchNorm, Hardtanh, BinaryConnect]
-    run is one FusedPoolBnSign kernel, activations between binarised layers exist only as bit planes.
-    Shares the parameters of the model it was built from.  The last feature block's planes are flattened
-    in (h, w, c) order, so the first classifier layer gets its weight columns permuted once."""
+    """Inference form of an (eval-mode) AlexNetBin (layers.FusedFeatureClassifier): every BinConv2d emits
+    BatchNorm-threshold bits, MaxPool runs on bits, activations between binarised layers exist only as bit planes.
+    Shares the parameters of the model it was built from.  ``fuse_conv=False`` keeps fp32 conv outputs and fuses
+    only the [MaxPool, BatchNorm, Hardtanh, BinaryConnect] runs (one kernel each)."""
 
     def __init__(self, model: AlexNetBin, fuse_conv: bool = True):
         super().__init__()
-        from pytorch_quantize_impls_amd.layers import (FusedConvPoolBnSign, FusedPoolBnSign, fuse_sequential,
-                                                       permute_fc_weight_hwc)
+        from pytorch_quantize_impls_amd.layers import FusedFeatureClassifier
         assert not model.training, "fuse an eval-mode model"
-        f = list(model.features.children())
-        if fuse_conv:
-            # every BinConv2d emits threshold bits (no fp32 activation between the binarised layers at all);
-            # the last block = conv5, MaxPool, BN, (Hardtanh) + the classifier's BinaryConnect
-            self.features = fuse_sequential(nn.Sequential(*f[:-4]), fuse_conv=True)
-            self.last = FusedConvPoolBnSign(f[-4], f[-2], pool=f[-3], flatten_hwc=True)
-        else:
-            self.features = fuse_sequential(nn.Sequential(*f[:-3]))      # ... up to the last BinConv2d
-            self.last = FusedPoolBnSign(f[-2], pool=f[-3], flatten_hwc=True)   # MaxPool, BN, (Hardtanh), + classifier's BinaryConnect
-        c = list(model.classifieur.children())
-        fc1 = LinearBin(c[1].in_features, c[1].out_features).to(c[1].weight.device)
-        fc1.weight.data.copy_(permute_fc_weight_hwc(c[1].weight.data, 256, 6, 6))
-        fc1.bias.data.copy_(c[1].bias.data)
-        fc1.eval()                                                   # weights above are already +-1 images
-        fc1._qt_eval_version = fc1.weight._version
-        self.classifieur = fuse_sequential(nn.Sequential(fc1, *c[2:]))
-        self.eval()
+        self.net = FusedFeatureClassifier(model.features, model.classifieur, (256, 6, 6), fuse_conv=fuse_conv)
 
     def forward(self, x):
-        return self.classifieur(self.last(self.features(x)))
+        return self.net(x)
 
 
 class BinMLP(nn.Module):

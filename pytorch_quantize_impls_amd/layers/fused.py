@@ -178,6 +178,60 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.
     return torch.nn.Sequential(*out)
 
 
+class FusedFeatureClassifier(torch.nn.Module):
+    """Inference form of the reference's CNN layout (models/Alexnet/Alexnet_Bin.py:12-54):
+
+        features   = nn.Sequential(..., BinConv2d, [MaxPool2d], BatchNorm2d, [Hardtanh])      # ends before the sign
+        x          = features(x).view(N, C*H*W)                                              # NCHW flattening
+        classifier = nn.Sequential(BinaryConnect, LinearBin, ...)
+
+    Every [conv, pool, BN, Hardtanh, BinaryConnect] run becomes one FusedConvPoolBnSign (threshold bits, no fp32
+    activation), the last feature block absorbs the classifier's leading BinaryConnect and hands its planes over
+    flattened in (h, w, c) order, and the first classifier layer gets its weight columns permuted once to that
+    order.  Shares every other parameter with the modules it was built from (which must be in eval mode).
+    ``feat_chw`` = (C, H, W) of the feature map the classifier was trained on."""
+
+    def __init__(self, features: torch.nn.Sequential, classifier: torch.nn.Sequential, feat_chw, fuse_conv: bool = True):
+        super().__init__()
+        from .binary_layers import BinConv2d, LinearBin
+        from .terner_layers import TerConv2d, LinearTer
+        f, c = list(features.children()), list(classifier.children())
+        if not c or not _is_det_binary_connect(c[0]) or len(c) < 2 or not isinstance(c[1], (LinearBin, LinearTer)):
+            raise ValueError("classifier must start with BinaryConnect(deterministic) followed by LinearBin / LinearTer")
+        j = len(f)
+        if j and isinstance(f[j - 1], torch.nn.Hardtanh):
+            j -= 1
+        if not j or not isinstance(f[j - 1], torch.nn.BatchNorm2d):
+            raise ValueError("features must end with BatchNorm2d [Hardtanh]")
+        bn, j = f[j - 1], j - 1
+        pool = None
+        if j and isinstance(f[j - 1], torch.nn.MaxPool2d):
+            pool, j = f[j - 1], j - 1
+        if any(m.training for m in (features, classifier)):
+            raise ValueError("fuse eval-mode modules")
+        if fuse_conv and j and isinstance(f[j - 1], (BinConv2d, TerConv2d)):
+            self.features = fuse_sequential(torch.nn.Sequential(*f[:j - 1]), fuse_conv=True)
+            self.last = FusedConvPoolBnSign(f[j - 1], bn, pool=pool, flatten_hwc=True)
+        else:
+            self.features = fuse_sequential(torch.nn.Sequential(*f[:j]), fuse_conv=fuse_conv)
+            self.last = FusedPoolBnSign(bn, pool=pool, flatten_hwc=True)
+        C, H, W = (int(v) for v in feat_chw)
+        src = c[1]
+        if src.in_features != C * H * W:
+            raise ValueError(f"classifier expects {src.in_features} features, feat_chw gives {C * H * W}")
+        fc1 = type(src)(src.in_features, src.out_features, bias=src.bias is not None).to(src.weight.device)
+        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))
+        if src.bias is not None:
+            fc1.bias.data.copy_(src.bias.data)
+        fc1.eval()                                   # the copied weight already is the quantised image
+        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))
+        self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[2:]))
+        self.eval()
+
+    def forward(self, x):
+        return self.classifier(self.last(self.features(x)))
+
+
 def permute_fc_weight_hwc(weight: torch.Tensor, C: int, H: int, W: int) -> torch.Tensor:
     """Columns of an FC weight that expects the NCHW flattening (c*H*W + h*W + w) re-ordered to the
     (h, w, c) order of PackedActivation.flatten_hwc()."""

@@ -16,7 +16,7 @@ model = model.to(dev).to(memory_format=torch.channels_last).eval()
 x = torch.randn((256, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
 for fc in (True, False):
     fused = bench_models.FusedAlexNetBin(model, fuse_conv=fc)
-    mods = list(fused.features.children()) + [fused.last] + list(fused.classifieur.children())
+    mods = list(fused.net.features.children()) + [fused.net.last] + list(fused.net.classifier.children())
     with torch.no_grad():
         for _ in range(3): fused(x)
         torch.cuda.synchronize()
