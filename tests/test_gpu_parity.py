@@ -1343,3 +1343,28 @@ def test_fused_relu_bn_sign_mlp_pattern(dev):
     with torch.no_grad():
         yu = seq(x)
     assert norm_err(n(yf), n(yu)) <= 1e-3       # identical unless a BatchNorm threshold tie flips a bit (MIOpen vs folded form)
+
+
+@pytest.mark.gpu
+def test_assume_codes_fit_skips_the_overflow_sync_and_allows_graph_capture(dev):
+    """ops.ASSUME_CODES_FIT: a DoReFa W1A4 block whose activations are clipped to [0, 1] never overflows int8, so the
+    per-tensor host check can be waived; the forward then captures as a hipGraph and replays identically."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    from pytorch_quantize_impls_amd.utils import graphed
+    torch.manual_seed(8)
+    net = torch.nn.Sequential(torch.nn.Hardtanh(0.0, 1.0), nnDorefaQuant(4), DorefaConv2d(16, 32, 3, padding=1, bit_width=1),
+                              torch.nn.Hardtanh(0.0, 1.0), nnDorefaQuant(4), DorefaConv2d(32, 8, 3, padding=1, bit_width=1)).to(dev).eval()
+    x = torch.rand((4, 16, 10, 10), device=dev).contiguous(memory_format=torch.channels_last) * 1.5
+    with torch.no_grad():
+        want = net(x)
+    ops.ASSUME_CODES_FIT = True
+    try:
+        with torch.no_grad():
+            assert torch.equal(net(x), want)
+        gm = graphed(net, x)
+        x2 = torch.rand_like(x)
+        with torch.no_grad():
+            want2 = net(x2)
+        assert torch.equal(gm(x2), want2)
+    finally:
+        ops.ASSUME_CODES_FIT = False
