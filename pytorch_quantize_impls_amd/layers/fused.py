@@ -133,15 +133,42 @@ class FusedConvPoolBnSign(torch.nn.Module):
         return act.flatten_hwc() if self.flatten_hwc else act
 
 
+class PackedMaxPool(torch.nn.Module):
+    """MaxPool2d(k, s) of a +-1 activation that exists only as bit planes (a pool placed AFTER the sign, as in
+    VGG-style stacks: conv -> BatchNorm -> Hardtanh -> BinaryConnect -> MaxPool): max of +-1 values is -1 only if the
+    whole window is -1, i.e. the AND of the negative bits — qt_pool_bits with an all-zero alpha-sign mask."""
+
+    def __init__(self, pool):
+        super().__init__()
+        k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+        st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+        pad = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+        dil = pool.dilation if isinstance(pool.dilation, int) else pool.dilation[0]
+        if pad != 0 or dil != 1 or pool.ceil_mode:
+            raise ValueError("only un-padded, un-dilated, floor-mode MaxPool2d can be fused")
+        self.pool_k, self.pool_s = int(k), int(st)
+        self._zero_mask = None
+
+    def forward(self, act):
+        if not isinstance(act, packed.PackedActivation) or len(act.shape) != 4:
+            raise TypeError("PackedMaxPool consumes the PackedActivation of a fused conv block")
+        N, C, H, W = act.shape
+        if self._zero_mask is None or self._zero_mask.device != act.device or self._zero_mask.numel() != act.planes.ld:
+            self._zero_mask = torch.zeros((act.planes.ld,), dtype=torch.int32, device=act.device)
+        planes, (Ho, Wo) = ops.pool_bits(act.planes, N, H, W, self.pool_k, self.pool_s, self._zero_mask)
+        return packed.PackedActivation(planes, (N, C, Ho, Wo))
+
+
 def _is_det_binary_connect(m):
     return isinstance(m, _FunctionModule) and m.core is BinaryConnectDeterministic
 
 
-def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.nn.Sequential:
+def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_pool: bool = False) -> torch.nn.Sequential:
     """New nn.Sequential where every [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)] run is
     replaced by one FusedPoolBnSign (sharing the original BatchNorm's parameters).  With ``fuse_conv`` a
     BinConv2d / TerConv2d directly in front of such a run joins it (FusedConvPoolBnSign: the conv emits
-    threshold bits, no fp32 activation is written at all)."""
+    threshold bits, no fp32 activation is written at all).  With ``packed_pool`` a MaxPool2d that directly follows a
+    fused block (pool AFTER the sign, VGG style) becomes a PackedMaxPool on the bit planes."""
     from .binary_layers import BinConv2d
     from .terner_layers import TerConv2d
     mods = list(seq.children())
@@ -167,6 +194,13 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.
                     out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None
                                else FusedPoolBnSign(bn, pool, pre_relu=pre_relu))
                     i = j2 + 1
+                    if packed_pool and i < len(mods) and isinstance(mods[i], torch.nn.MaxPool2d) and bn.weight.dim() == 1 \
+                            and isinstance(bn, torch.nn.BatchNorm2d):
+                        try:
+                            out.append(PackedMaxPool(mods[i]))
+                            i += 1
+                        except ValueError:
+                            pass
                     continue
                 except ValueError:
                     if conv is not None:     # the conv cannot join: keep it, fuse the rest on the next turn
@@ -179,57 +213,53 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False) -> torch.
 
 
 class FusedFeatureClassifier(torch.nn.Module):
-    """Inference form of the reference's CNN layout (models/Alexnet/Alexnet_Bin.py:12-54):
+    """Inference form of the reference's CNN layout (models/Alexnet/Alexnet_Bin.py:12-54, and VGG-style stacks):
 
-        features   = nn.Sequential(..., BinConv2d, [MaxPool2d], BatchNorm2d, [Hardtanh])      # ends before the sign
-        x          = features(x).view(N, C*H*W)                                              # NCHW flattening
-        classifier = nn.Sequential(BinaryConnect, LinearBin, ...)
+        features   = nn.Sequential(...)                       # binarised conv blocks
+        x          = features(x).view(N, C*H*W)               # NCHW flattening
+        classifier = nn.Sequential([BinaryConnect,] LinearBin | LinearTer, ...)
 
-    Every [conv, pool, BN, Hardtanh, BinaryConnect] run becomes one FusedConvPoolBnSign (threshold bits, no fp32
-    activation), the last feature block absorbs the classifier's leading BinaryConnect and hands its planes over
-    flattened in (h, w, c) order, and the first classifier layer gets its weight columns permuted once to that
-    order.  Shares every other parameter with the modules it was built from (which must be in eval mode).
-    ``feat_chw`` = (C, H, W) of the feature map the classifier was trained on."""
+    Every [conv, pool?, BatchNorm, Hardtanh?, BinaryConnect] run becomes one FusedConvPoolBnSign (threshold bits, no
+    fp32 activation), a MaxPool placed after the sign runs on the bit planes, a BinaryConnect that opens the
+    classifier is pulled into the last feature block, the planes are flattened in (h, w, c) order and the first
+    classifier layer gets its weight columns permuted once to that order.  Shares every other parameter with the
+    modules it was built from (which must be in eval mode).  ``feat_chw`` = (C, H, W) of the feature map the
+    classifier was trained on."""
 
     def __init__(self, features: torch.nn.Sequential, classifier: torch.nn.Sequential, feat_chw, fuse_conv: bool = True):
         super().__init__()
-        from .binary_layers import BinConv2d, LinearBin
-        from .terner_layers import TerConv2d, LinearTer
-        f, c = list(features.children()), list(classifier.children())
-        if not c or not _is_det_binary_connect(c[0]) or len(c) < 2 or not isinstance(c[1], (LinearBin, LinearTer)):
-            raise ValueError("classifier must start with BinaryConnect(deterministic) followed by LinearBin / LinearTer")
-        j = len(f)
-        if j and isinstance(f[j - 1], torch.nn.Hardtanh):
-            j -= 1
-        if not j or not isinstance(f[j - 1], torch.nn.BatchNorm2d):
-            raise ValueError("features must end with BatchNorm2d [Hardtanh]")
-        bn, j = f[j - 1], j - 1
-        pool = None
-        if j and isinstance(f[j - 1], torch.nn.MaxPool2d):
-            pool, j = f[j - 1], j - 1
+        from .binary_layers import LinearBin
+        from .terner_layers import LinearTer
         if any(m.training for m in (features, classifier)):
             raise ValueError("fuse eval-mode modules")
-        if fuse_conv and j and isinstance(f[j - 1], (BinConv2d, TerConv2d)):
-            self.features = fuse_sequential(torch.nn.Sequential(*f[:j - 1]), fuse_conv=True)
-            self.last = FusedConvPoolBnSign(f[j - 1], bn, pool=pool, flatten_hwc=True)
-        else:
-            self.features = fuse_sequential(torch.nn.Sequential(*f[:j]), fuse_conv=fuse_conv)
-            self.last = FusedPoolBnSign(bn, pool=pool, flatten_hwc=True)
+        f, c = list(features.children()), list(classifier.children())
+        if c and _is_det_binary_connect(c[0]):
+            f, c = f + [c[0]], c[1:]
+        if not c or not isinstance(c[0], (LinearBin, LinearTer)):
+            raise ValueError("classifier must start with [BinaryConnect(deterministic),] LinearBin / LinearTer")
+        self.features = fuse_sequential(torch.nn.Sequential(*f), fuse_conv=fuse_conv, packed_pool=True)
+        tail = list(self.features.children())[-1] if len(self.features) else None
+        if not isinstance(tail, (FusedConvPoolBnSign, FusedPoolBnSign, PackedMaxPool)):
+            raise ValueError("features must end with BatchNorm2d [Hardtanh] (+ the classifier's BinaryConnect), or with "
+                             "BatchNorm2d [Hardtanh] BinaryConnect [MaxPool2d]: the last block has to produce sign bits")
         C, H, W = (int(v) for v in feat_chw)
-        src = c[1]
+        src = c[0]
         if src.in_features != C * H * W:
             raise ValueError(f"classifier expects {src.in_features} features, feat_chw gives {C * H * W}")
         fc1 = type(src)(src.in_features, src.out_features, bias=src.bias is not None).to(src.weight.device)
-        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))
         if src.bias is not None:
             fc1.bias.data.copy_(src.bias.data)
-        fc1.eval()                                   # the copied weight already is the quantised image
-        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))
-        self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[2:]))
+        fc1.eval()
+        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))      # already the quantised image
+        self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[1:]))
         self.eval()
 
+    @property
+    def last(self):
+        return list(self.features.children())[-1]
+
     def forward(self, x):
-        return self.classifier(self.last(self.features(x)))
+        return self.classifier(self.features(x).flatten_hwc())
 
 
 def permute_fc_weight_hwc(weight: torch.Tensor, C: int, H: int, W: int) -> torch.Tensor:

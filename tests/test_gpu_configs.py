@@ -195,3 +195,27 @@ def test_c5_ternary_vgg16_forward_vs_cpu(dev):
     # BatchNorm thresholds: MIOpen and ATen-CPU may land a value within an ulp of 0 on different sides, flipping one
     # +-1 activation; logits are sums over 512 ternary-weighted signs, so allow a handful of unit steps
     assert (got - ref).abs().max() <= 0.02 * ref.abs().max() + 1e-3, float((got - ref).abs().max())
+
+
+@pytest.mark.gpu
+def test_c5_ternary_vgg16_fused_matches_unfused(dev):
+    """FusedFeatureClassifier on the VGG layout (sign BEFORE the pool, classifier without a leading BinaryConnect):
+    threshold-bit convs + PackedMaxPool on bit planes against the module-by-module device forward."""
+    import bench_models
+    from pytorch_quantize_impls_amd.layers import FusedFeatureClassifier, PackedMaxPool
+    torch.manual_seed(5)
+    model = bench_models.TernaryVGG16(num_classes=100, image=64, fc=512)
+    _unit_scale_weights(model, 8)
+    bench_models.randomize_bn(model, seed=5)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    model.features[0].binary_input = False
+    fused = FusedFeatureClassifier(model.features, model.classifier, (512, 2, 2))
+    assert sum(isinstance(m, PackedMaxPool) for m in fused.features) == 5
+    x = torch.randn(3, 3, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        yf = fused(x)
+        assert _lib.call_counts["qt_conv2d_implicit_bits"] - before.get("qt_conv2d_implicit_bits", 0) == 13
+        yu = model(x)
+    # identical unless a BatchNorm threshold tie flips a bit (MIOpen's BatchNorm vs the folded form)
+    assert (yf - yu).abs().max() <= 0.02 * yu.abs().max() + 1e-3, float((yf - yu).abs().max())

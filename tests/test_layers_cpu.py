@@ -271,14 +271,21 @@ def test_fused_feature_classifier_validates_its_inputs():
     feats = nn.Sequential(BinConv2d(3, 8, 3, padding=1), nn.MaxPool2d(2, 2), nn.BatchNorm2d(8), nn.Hardtanh()).eval()
     clf = nn.Sequential(BinaryConnect(stochastic=False), LinearBin(8 * 4 * 4, 10)).eval()
     m = FusedFeatureClassifier(feats, clf, (8, 4, 4))
-    assert type(m.last).__name__ == "FusedConvPoolBnSign" and m.last.flatten_hwc and len(m.features) == 0
+    assert type(m.last).__name__ == "FusedConvPoolBnSign" and len(m.features) == 1
     w = clf[1].weight.data.view(10, 8, 4, 4).permute(0, 2, 3, 1).reshape(10, -1)
     assert torch.equal(m.classifier[0].weight.data, torch.where(w < 0, -1.0, 1.0))       # (h, w, c) columns, quantised image
     with pytest.raises(ValueError, match="feat_chw"):
         FusedFeatureClassifier(feats, clf, (8, 3, 3))
-    with pytest.raises(ValueError, match="must start with BinaryConnect"):
+    with pytest.raises(ValueError, match="has to produce sign bits"):       # no BinaryConnect anywhere after the BN
         FusedFeatureClassifier(feats, nn.Sequential(LinearBin(128, 10)).eval(), (8, 4, 4))
-    with pytest.raises(ValueError, match="end with BatchNorm2d"):
+    with pytest.raises(ValueError, match="must start with"):
+        FusedFeatureClassifier(feats, nn.Sequential(BinaryConnect(stochastic=False), nn.Linear(128, 10)).eval(), (8, 4, 4))
+    with pytest.raises(ValueError, match="has to produce sign bits"):
         FusedFeatureClassifier(nn.Sequential(BinConv2d(3, 8, 3)).eval(), clf, (8, 4, 4))
+    # VGG style: sign before the pool, classifier without a leading BinaryConnect
+    vgg = nn.Sequential(BinConv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.Hardtanh(), BinaryConnect(stochastic=False),
+                        nn.MaxPool2d(2, 2)).eval()
+    mv = FusedFeatureClassifier(vgg, nn.Sequential(LinearBin(128, 10)).eval(), (8, 4, 4))
+    assert [type(x).__name__ for x in mv.features] == ["FusedConvPoolBnSign", "PackedMaxPool"]
     with pytest.raises(ValueError, match="eval-mode"):
         FusedFeatureClassifier(feats.train(), clf, (8, 4, 4))

@@ -28,6 +28,12 @@ x5 = torch.randn((B5, 3, 224, 224), device=dev).contiguous(memory_format=torch.c
 with torch.no_grad():
     ms = t(lambda: m5(x5), n=5)
 print(f"C5 ternary VGG-16, batch {B5}: {ms:.3f} ms/forward = {B5 / ms * 1e3:.0f} img/s (un-fused reference graph)")
+from pytorch_quantize_impls_amd.layers import FusedFeatureClassifier
+f5 = FusedFeatureClassifier(m5.features, m5.classifier, (512, 7, 7))
+with torch.no_grad():
+    same = torch.equal(f5(x5).argmax(1), m5(x5).argmax(1))
+    ms = t(lambda: f5(x5), n=5)
+print(f"C5 ternary VGG-16, batch {B5}, fused (threshold-bit convs, pools on bits): {ms:.3f} ms/forward = {B5 / ms * 1e3:.0f} img/s, same argmax {same}")
 # how much of C4 is the per-activation overflow check (one host sync per quantised tensor)?
 from pytorch_quantize_impls_amd import ops
 orig = ops.CodePlanes.usable

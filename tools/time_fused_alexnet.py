@@ -16,7 +16,8 @@ model = model.to(dev).to(memory_format=torch.channels_last).eval()
 x = torch.randn((256, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
 for fc in (True, False):
     fused = bench_models.FusedAlexNetBin(model, fuse_conv=fc)
-    mods = list(fused.net.features.children()) + [fused.net.last] + list(fused.net.classifier.children())
+    nfeat = len(fused.net.features)
+    mods = list(fused.net.features.children()) + list(fused.net.classifier.children())
     with torch.no_grad():
         for _ in range(3): fused(x)
         torch.cuda.synchronize()
@@ -25,7 +26,9 @@ for fc in (True, False):
         torch.cuda.synchronize()
         print(f"fuse_conv={fc}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms / forward")
         h = x
-        for m in mods:
+        for mi, m in enumerate(mods):
+            if mi == nfeat:
+                h = h.flatten_hwc()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5): out = m(h)
             t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
