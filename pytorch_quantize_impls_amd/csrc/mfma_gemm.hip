@@ -181,7 +181,7 @@ struct ElemBf16 {
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
 //   4 = no LDS fragment reads, 5 = (ping-pong) per-segment cycle stamps + wall-clock phase stamps written over Y, 6 = phase stamps only.
-template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, int CONV_ = 0>
+template <class E_, int WM_, int WN_, int TMW_, int TNW_, int PIPE_, int ABL_ = 0, int SB_ = 128, int CONV_ = 0, int OCC_ = 1>
 struct GemmCfg {
     using E = E_;
     // CONV_: 0 = GEMM, 1 = implicit conv (zero padding by per-tap bounds checks, 64-bit per-lane addresses),
@@ -199,9 +199,11 @@ struct GemmCfg {
     static constexpr int LDS_FIXED = NBUF * BUF + 64;   // stage buffers + the waves' SIMD ids (ping-pong)
     static constexpr int LDS_BYTES = LDS_FIXED;         // VALID conv: + the tap table (launch_cfg adds nstages * CHUNKS * 4)
     static_assert(PIPE_ != 2 || (SB_ == 64 && NWAVES == 8), "ping-pong: 64-byte stages, two waves per SIMD");
-    static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
-    static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && (TN % (ROWS_PER_PIECE * NWAVES) == 0 || PIPE_ == 2),
-                  "DMA pieces divide evenly over the waves (ping-pong: W pieces may wrap)");
+    // OCC_ workgroups per CU the register budget is sized for (small-accumulator tiles: 2 workgroups overlap each
+    // other's prologue latency, which dominates convs whose K is only a few stages)
+    static constexpr int WAVES_PER_SIMD = OCC_ * ((NWAVES + 3) / 4);
+    static_assert(TM % (ROWS_PER_PIECE * NWAVES) == 0 && (TN % (ROWS_PER_PIECE * NWAVES) == 0 || PIPE_ >= 1),
+                  "DMA pieces divide evenly over the waves (asm-DMA pipelines: W pieces may wrap)");
 };
 
 template <class C>
@@ -726,6 +728,8 @@ template <class E> using ConvV128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, 2>;
 template <class E> using ConvV64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, 2>;
 template <class E> using ConvV192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, 2>;
 template <class E> using ConvVPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 2>;
+template <class E> using ConvV64x2 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 64, 2, 3>;    // 256x64 tile, 64-byte stages, 3 workgroups / CU
+template <class E> using ConvV128x2 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 64, 2, 2>;   // 256x128 tile, same
 template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling only
 
@@ -1118,6 +1122,10 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                     return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 if (tn == 256) return launch_cfg<ConvVPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             }                                                                                                   \
+            if (g_conv_force == 0 && tn == 64 && kwords * 4 <= 1024)                                            \
+                return launch_cfg<ConvV64x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (g_conv_force == 0 && tn == 128 && kwords * 4 <= 1024)                                           \
+                return launch_cfg<ConvV128x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 256) return launch_cfg<ConvV256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 192) return launch_cfg<ConvV192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 128) return launch_cfg<ConvV128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \

@@ -186,7 +186,7 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
         N, C, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-        if USE_S2D and ops.s2d_applicable(C, kh, kw, stride, dilation):
+        if USE_S2D and ops.s2d_applicable(C, kh, kw, stride, dilation, padding):
             # strided few-channel conv (conv1) == stride-1 conv on the space-to-depth image; the gather and
             # the exact bf16 split are one kernel, the transformed weight is cached by eval-mode layers
             sd = ops._pairs(stride)[0]

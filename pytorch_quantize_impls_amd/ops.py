@@ -980,11 +980,15 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     return y
 
 
-def s2d_applicable(C: int, kh: int, kw: int, stride, dilation) -> bool:
+def s2d_applicable(C: int, kh: int, kw: int, stride, dilation, padding=0) -> bool:
     """Strided first-layer style convs (few input channels) are re-expressed as stride-1 convs on the
-    space-to-depth image: no padding waste in the pixel planes and ~(k/ceil(k/s)s)^2 of the K bytes."""
-    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
-    return sh == sw and sh > 1 and dh == dw == 1 and kh == kw and C * sh * sh <= 64 and kh >= sh
+    space-to-depth image: no padding waste in the pixel planes and ~(k/ceil(k/s)s)^2 of the K bytes.  With stride 1
+    the same gather (s = 1) is simply the physically zero-padded pixel plane, which lets a padded few-channel conv
+    (VGG's 3 -> 64 first layer) run on the un-padded conv kernels."""
+    (sh, sw), (dh, dw), (ph, pw) = _pairs(stride), _pairs(dilation), _pairs(padding)
+    if not (sh == sw and dh == dw == 1 and kh == kw and C * sh * sh <= 64 and kh >= sh):
+        return False
+    return sh > 1 or ph > 0 or pw > 0
 
 
 def s2d_weight(wq: torch.Tensor, s: int) -> torch.Tensor:
