@@ -206,6 +206,21 @@ int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_b
                        int64_t ldy, int64_t rows, int64_t K, int bit_width, int32_t* overflow,
                        qt_stream_t stream);
 
+/* Inference fusion of the DoReFa activation chain between two quantised layers (k-bit form; the
+ * module sequence conv -> BatchNorm2d(eval) [-> + shortcut] -> ReLU -> nnDorefaQuant(k) of
+ * models/samples/ResNet_Dorefa.py:26,35 collapsed into one pass over the conv output):
+ *   t = fl(fl(x*alpha[c]) + beta[c])                       eval BatchNorm folded to per-channel (alpha, beta)
+ *   t += fl(fl(r*res_alpha[c]) + res_beta[c])              res_f32 != NULL (res_alpha/res_beta NULL: t += r)
+ *   t += fl(res_scale * code)                              res_codes != NULL (identity shortcut held as codes)
+ *   t = max(t, 0) if relu ; q = rint((2^k-1) * t)          functions/dorefa_connect.py:24-25, unclamped
+ * codes <- q as int8 (pad bytes of the 16-byte rows zero), y_f32 (may be NULL) <- fl(fl(1/(2^k-1)) * q).
+ * *overflow is OR-ed with 1 if any |q| > 127 or NaN (code written as 0), as qt_dorefa_codes_i8. */
+int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                              const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                              const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                              int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
+                              int32_t* overflow, qt_stream_t stream);
+
 /* Weight codes: ternary == 0: safeSign(w) as +1/-1 ; ternary != 0: TernaryConnect codes {-1,0,+1}. */
 int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,
                        int64_t K, int ternary, qt_stream_t stream);
@@ -273,6 +288,12 @@ int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t l
  * eval-mode layers cache) feed the matrix-core GEMM without re-reading the fp32 tensor. */
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,
                    uint32_t* nib_plane, int64_t ldn, int64_t rows, int64_t K, qt_stream_t stream);
+
+/* Physical zero padding of an NHWC pixel plane of any element type (nibble, int8 code, bf16 triple: pixels are whole
+ * 16-byte chunks, zero bytes = value 0): P [N][H][W][Cw words] -> Q [N][H+2ph][W+2pw][Cw], border pixels zero, Cw % 4 == 0.
+ * The zero-padded conv on P (F.conv2d's padding argument) is the un-padded conv on Q. */
+int qt_pad_pixel_plane(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t ph, int64_t pw,
+                       uint32_t* Q, qt_stream_t stream);
 
 /* Same expansion into a PHYSICALLY zero-padded NHWC pixel plane: sign/mask planes hold N*H*W pixel rows,
  * nib_plane gets N*(H+2ph)*(W+2pw) rows of ldn words whose border pixels are fp4 zeros.  A conv with zero

@@ -108,6 +108,28 @@ def dorefa_quantize(x, k):
     return y
 
 
+def affine_relu_dorefa_codes(x, alpha, beta, k, relu=True, res=None, res_affine=None):
+    """The eval-mode chain  BatchNorm (folded: t = fl(fl(x*alpha) + beta), channel = dim 1) [+ residual, itself
+    optionally through a folded BatchNorm] [-> ReLU] -> nnDorefaQuant(k)  of a DoReFa ResNet block
+    (models/samples/ResNet_Dorefa.py:26,35 ; functions/dorefa_connect.py:11-25) in fp32 steps.
+    Returns (integer codes rint(n*t) as float32, fp32 image = dorefa_quantize(t, k))."""
+    x = np.asarray(x, dtype=np.float32)
+    shp = [1] * x.ndim
+    shp[1] = -1
+    a, b = (np.asarray(v, dtype=np.float32).reshape(shp) for v in (alpha, beta))
+    t = (x * a).astype(np.float32) + b
+    if res is not None:
+        u = np.asarray(res, dtype=np.float32)
+        if res_affine is not None:
+            ra, rb = (np.asarray(v, dtype=np.float32).reshape(shp) for v in res_affine)
+            u = (u * ra).astype(np.float32) + rb
+        t = (t + u).astype(np.float32)
+    if relu:
+        t = np.where(t < 0, np.float32(0), t).astype(np.float32)
+    n = np.float32((1 << int(k)) - 1)
+    return np.rint((n * t).astype(np.float32)).astype(np.float32), dorefa_quantize(t, k)
+
+
 def lin_quantize(x, fsr, bits, mode=1):
     """functions/log_lin_connect.py:61-79 (mode 0 unsigned, 1 with_sign, 2 quantised-gradient backward)."""
     x, xp = _f(x)

@@ -64,6 +64,8 @@ SIGNATURES = {
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
+    "qt_affine_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
+                                           _c_int, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "qt_weight_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_i8_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                             _c_i64, _c_i64, _c_p]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "qt_conv2d_implicit_bits": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
                                                                          _c_p, _c_i64, _c_i64, _c_p]),
     "qt_pool_bits": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p, _c_p]),
+    "qt_pad_pixel_plane": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p]),
     "qt_bits_to_nib_pad": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64] + [_c_i64] * 6 + [_c_p]),
     "qt_im2col_words": (_c_int, [_c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_nib_gemm_variant": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64,

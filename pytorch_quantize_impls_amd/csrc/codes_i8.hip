@@ -59,9 +59,100 @@ __global__ __launch_bounds__(256) void codes_kernel(const float* __restrict__ x,
     if (!WEIGHT && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
 
+// Inference fusion of the DoReFa activation chain (k-bit form):
+//   conv / linear output x -> eval BatchNorm folded to t = fl(fl(x*alpha[c]) + beta[c])
+//     [+ residual: fl(fl(r*ralpha[c]) + rbeta[c]) of an fp32 tensor (a shortcut conv before ITS BatchNorm), or
+//        fl(rscale * code) of an int8 code plane (identity shortcut that carries DoReFa codes)]
+//     [-> ReLU] -> nnDorefaQuant(k): q = rint(n * t)   (functions/dorefa_connect.py:24-25, unclamped)
+// written as the next layer's int8 code plane (and, on request, the fp32 image fl(fl(1/n) * q)).
+// One thread = 4 consecutive channels; per element 4 B in (+ 4 B or 1 B residual), 1 B out: HBM-bound.
+__global__ __launch_bounds__(256) void affine_codes_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ rf, int64_t ldr, const float* __restrict__ ralpha, const float* __restrict__ rbeta,
+    const int8_t* __restrict__ rc, int64_t ldrc, float rscale, int relu, int8_t* __restrict__ codes, int64_t ldc,
+    float* __restrict__ yf, int64_t ldy, int64_t rows, int64_t C, float n, float inv_n,
+    int32_t* __restrict__ overflow, int vec) {
+    const int64_t slots_per_row = ldc / 4;
+    const int64_t total = rows * slots_per_row;
+    int bad = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
+        const int64_t k0 = slot * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = k0 + 3 < C;
+        if (vec && full) {
+            const float4 t = *reinterpret_cast<const float4*>(x + row * ldx + k0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            if (rf) {
+                const float4 u = *reinterpret_cast<const float4*>(rf + row * ldr + k0);
+                r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < C) {
+                    v[e] = x[row * ldx + k0 + e];
+                    if (rf) r[e] = rf[row * ldr + k0 + e];
+                }
+        }
+        uint32_t rword = 0;
+        if (rc) rword = *reinterpret_cast<const uint32_t*>(rc + row * ldrc + k0);   // plane rows are 16-byte padded
+        uint32_t word = 0;
+        float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int q = 0;
+            if (k0 + e < C) {
+                float t = __fadd_rn(__fmul_rn(v[e], alpha[k0 + e]), beta[k0 + e]);
+                if (rf) {
+                    float u = r[e];
+                    if (ralpha) u = __fadd_rn(__fmul_rn(u, ralpha[k0 + e]), rbeta[k0 + e]);
+                    t = __fadd_rn(t, u);
+                }
+                if (rc) t = __fadd_rn(t, __fmul_rn(rscale, (float)(int8_t)(rword >> (8 * e))));
+                if (relu) t = t < 0.0f ? 0.0f : t;                  // NaN stays NaN (flagged below)
+                const float q_ = rintf(__fmul_rn(n, t));
+                q4[e] = q_;
+                if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad = 1; q = 0; } else q = (int)q_;
+            }
+            word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(codes + row * ldc + k0) = word;
+        if (yf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < C) yf[row * ldy + k0 + e] = inv_n * q4[e];
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+}
+
 }  // namespace
 
 extern "C" {
+
+int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                              const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                              const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                              int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
+                              int32_t* overflow, qt_stream_t stream) {
+    if (rows < 0 || C < 0 || ldx < C || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!codes || !overflow || !alpha || !beta || (!x && C > 0) || (y_f32 && ldy < C)) return QT_ERR_INVALID_ARG;
+    if ((res_f32 && ldr < C) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;
+    if (ldc_bytes < C || (ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
+    if (res_codes && (ldrc_bytes < ((C + 3) & ~(int64_t)3) || (ldrc_bytes & 3) || ((uintptr_t)res_codes & 3)))
+        return QT_ERR_ALIGNMENT;
+    if (ldc_bytes == 0) return QT_OK;
+    const float n = (float)((1 << bit_width) - 1);
+    const int vec = qt_aligned16(x) && (ldx % 4 == 0) && (!res_f32 || (qt_aligned16(res_f32) && ldr % 4 == 0));
+    const int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
+    hipLaunchKernelGGL(affine_codes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, beta,
+                       res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes, ldc_bytes,
+                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec);
+    return qt_check_launch();
+}
 
 int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_bytes, float* y_f32,
                        int64_t ldy, int64_t rows, int64_t K, int bit_width, int32_t* overflow,

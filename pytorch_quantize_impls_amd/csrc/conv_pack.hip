@@ -47,7 +47,42 @@ __global__ __launch_bounds__(256) void im2col_words_kernel(const uint32_t* __res
     }
 }
 
+// Physical zero padding of an NHWC pixel plane (any element type: nibble / int8 code / bf16-triple pixels are whole
+// 16-byte chunks and their zero bytes are the value 0): P[N][H][W][Cw] -> Q[N][H+2ph][W+2pw][Cw], border = 0.
+// A padded conv on P is the un-padded conv on Q, which the implicit-GEMM kernels run without per-tap checks.
+__global__ __launch_bounds__(256) void pad_pixel_plane_kernel(const uint32_t* __restrict__ P, uint32_t* __restrict__ Q,
+                                                              int64_t N, int H, int W, int Cw, int ph, int pw) {
+    const int Hp = H + 2 * ph, Wp = W + 2 * pw, cpp = Cw / 4;
+    const int64_t total = N * Hp * Wp * cpp;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / cpp;
+        const int c = (int)(t - pix * cpp);
+        const int64_t n = pix / ((int64_t)Hp * Wp);
+        const int rem = (int)(pix - n * Hp * Wp);
+        const int y = rem / Wp - ph, x = rem % Wp - pw;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            v = *reinterpret_cast<const uint4*>(P + (((n * H + y) * W + x) * (int64_t)Cw) + c * 4);
+        *reinterpret_cast<uint4*>(Q + pix * Cw + c * 4) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_pad_pixel_plane(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t ph,
+                                  int64_t pw, uint32_t* Q, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Cw <= 0 || ph < 0 || pw < 0) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!P || !Q) return QT_ERR_INVALID_ARG;
+    if ((Cw & 3) || !qt_aligned16(P) || !qt_aligned16(Q)) return QT_ERR_ALIGNMENT;
+    if (H + 2 * ph > 32767 || W + 2 * pw > 32767 || Cw > (1 << 20)) return QT_ERR_UNSUPPORTED;
+    const int64_t total = N * (H + 2 * ph) * (W + 2 * pw) * (Cw / 4);
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(pad_pixel_plane_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P, Q, N, (int)H, (int)W,
+                       (int)Cw, (int)ph, (int)pw);
+    return qt_check_launch();
+}
 
 extern "C" int qt_im2col_words(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                                int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,

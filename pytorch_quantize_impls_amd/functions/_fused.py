@@ -311,14 +311,22 @@ def _dorefa_w1_scale(weight: torch.Tensor, prequantized: bool) -> torch.Tensor:
     return weight.detach().abs().amax() if prequantized else weight.detach().abs().mean()
 
 
-def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None):
+def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None, scale=None):
     """LinearDorefa(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:41-45):
     y = x . (sign(W)*E)^T + b.  If the activation carries k-bit DoReFa codes (nnDorefaQuant output)
     the contraction runs on the int8 matrix cores: y = (E/n) * sum q*s + b; otherwise the dense GEMM
     library on the HIP-quantised weight image."""
-    E = _dorefa_w1_scale(weight, prequantized)
-    codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
+    E = scale if scale is not None else _dorefa_w1_scale(weight, prequantized)
     K, N = input.shape[-1], weight.shape[0]
+    if isinstance(input, packed.CodeActivation):
+        codes = input.codes
+        if len(input.shape) != 2 or codes.K != K or 127 * K >= (1 << 24):
+            raise ValueError(f"CodeActivation {input.shape} does not fit LinearDorefa({K}, {N})")
+        wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
+        y = ops.i8_gemm(codes, wc, codes.inv_n, bias, scale_dev=E)
+        y._qt_overflow = codes.overflow
+        return y
+    codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
     if (codes is not None and codes.K == K and codes.rows * K == input.numel()
             and 127 * K < (1 << 24) and codes.usable()):
         wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
@@ -329,10 +337,25 @@ def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_cod
 
 
 def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, weight_codes=None,
-                           padding_mode: str = "zeros"):
+                           padding_mode: str = "zeros", scale=None):
     """DorefaConv2d(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:77-82)."""
     stride, padding, dilation, groups = conv_args
-    E = _dorefa_w1_scale(weight, prequantized)
+    E = scale if scale is not None else _dorefa_w1_scale(weight, prequantized)
+    if isinstance(input, packed.CodeActivation):
+        # fused inference: the activation exists only as codes (range checked once, at the end of the network)
+        codes = input.codes
+        N_, C, H, W = input.shape
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        if (groups != 1 or padding_mode != "zeros" or isinstance(padding, str) or codes.K != C
+                or C != weight.shape[1] or 127 * kh * kw * codes.codes.shape[1] >= (1 << 24)):
+            raise ValueError(f"CodeActivation {input.shape} does not fit this DorefaConv2d")
+        wc = weight_codes if weight_codes is not None else ops.pack_conv_weight_codes(weight.detach())
+        y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding, dilation,
+                              scale_dev=E)
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+        y._qt_overflow = codes.overflow          # the chain's range flag rides on to the next fused quantiser
+        return y
     codes = None
     if (input.dtype == torch.float32 and input.dim() == 4 and groups == 1 and padding_mode == "zeros"
             and not isinstance(padding, str)):

@@ -2,6 +2,7 @@
 import torch
 
 from ..functions import dorefa_connect, _fused
+from ..packed import CodeActivation as _CodeActivation
 from .common import QLayer, EvalSwapMixin
 
 
@@ -27,13 +28,17 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         return self.weight_op.forward(self.weight)
 
     def forward(self, input):
+        if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
+            raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
+                               "call .eval() first (k-bit weights: pass input.float())")
         if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
             # W1Ak: int8 matrix-core path when the activation carries DoReFa codes
             if self.training:
                 return _fused.DorefaW1LinearFn.apply(input, self.weight, self.bias)
             if not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)):
                 wc = self._eval_planes(lambda w2: _fused.ops.weight_codes(w2), key="i8")
-                return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc)
+                E = self._eval_planes(lambda w2: w2.abs().amax(), key="E")      # |w| == E everywhere after eval()
+                return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc, scale=E)
         if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             # WkAk inference: integer weight levels x activation codes on the int8 matrix cores
@@ -68,6 +73,9 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
 
     def forward(self, input):
         args = (self.stride, self.padding, self.dilation, self.groups)
+        if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
+            raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
+                               "call .eval() first (k-bit weights: pass input.float())")
         if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
             if self.training:
                 return _fused.DorefaW1Conv2dFn.apply(input, self.weight, self.bias, args)
@@ -76,8 +84,9 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                 if self.groups == 1 and self.padding_mode == "zeros":
                     wc = self._eval_planes(lambda _w2: _fused.ops.pack_conv_weight_codes(self.weight.detach()),
                                            key="conv_i8")
+                E = self._eval_planes(lambda w2: w2.abs().amax(), key="E")      # |w| == E everywhere after eval()
                 return _fused.dorefa_w1_conv_forward(input, self.weight, self.bias, args, True, wc,
-                                                     self.padding_mode)
+                                                     self.padding_mode, scale=E)
         if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
                 and self.groups == 1 and self.padding_mode == "zeros"
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):

@@ -70,6 +70,69 @@ class FusedPoolBnSign(torch.nn.Module):
         return act.flatten_hwc() if self.flatten_hwc else act
 
 
+class FusedBnDorefaQuant(torch.nn.Module):
+    """eval BatchNorm [+ residual] [-> ReLU] -> nnDorefaQuant(k) over the fp32 output of a conv / linear layer, as
+    ONE kernel that writes the next layer's int8 code plane (``packed.CodeActivation``): the
+    ``quant(relu(bn(conv(x))))`` / ``quant(relu(bn2(conv2(.)) + shortcut))`` chains of a DoReFa ResNet
+    (models/samples/ResNet_Dorefa.py:26,35) without BatchNorm / add / ReLU / quantiser passes over fp32 tensors.
+
+    forward(x, residual=None, residual_bn=None):
+      x           fp32 [N, C, H, W] (channels_last, as the conv kernels return it) or [N, C]
+      residual    None | CodeActivation (identity shortcut; value inv_n * code) | fp32 tensor shaped like x
+      residual_bn BatchNorm applied to an fp32 residual first (the 1x1-conv shortcut's own BatchNorm)
+    BatchNorm is folded to t = fl(fl(x*alpha) + beta) (``fold_batchnorm``); the oracle restates exactly this chain
+    (oracle.affine_relu_dorefa_codes).  The quantiser is unclamped like the reference's, so codes may leave int8:
+    the kernel raises a device flag shared along the chain and ``CodeActivation.check()/float()`` raises."""
+
+    def __init__(self, bn, bit_width: int, relu: bool = True):
+        super().__init__()
+        if not 2 <= int(bit_width) <= 8:
+            raise ValueError("code planes exist for 2 <= bit_width <= 8")
+        self.bn, self.bit_width, self.relu = bn, int(bit_width), bool(relu)
+        self._folded = None
+        self._folded_res = None
+
+    def refold(self):
+        self._folded = self._folded_res = None
+
+    def forward(self, x, residual=None, residual_bn=None):
+        if self.bn.training:
+            raise RuntimeError("FusedBnDorefaQuant folds running statistics: call .eval() first")
+        if self._folded is None:
+            self._folded = fold_batchnorm(self.bn)
+        alpha, beta = self._folded
+        if x.dim() == 4:
+            N, C, H, W = x.shape
+            x2 = x.permute(0, 2, 3, 1)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            x2 = x2.view(N * H * W, C)
+        elif x.dim() == 2:
+            x2 = x.contiguous()
+        else:
+            raise ValueError("FusedBnDorefaQuant takes [N, C, H, W] or [N, C] inputs")
+        res_f32 = res_codes = res_affine = None
+        flag = getattr(x, "_qt_overflow", None)
+        if isinstance(residual, packed.CodeActivation):
+            if residual.shape != tuple(x.shape):
+                raise ValueError(f"residual {residual.shape} vs input {tuple(x.shape)}")
+            res_codes = residual.codes
+            flag = flag if flag is not None else residual.codes.overflow
+        elif residual is not None:
+            if tuple(residual.shape) != tuple(x.shape):
+                raise ValueError(f"residual {tuple(residual.shape)} vs input {tuple(x.shape)}")
+            r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
+            res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(x2.shape)
+            if residual_bn is not None:
+                if self._folded_res is None:
+                    self._folded_res = fold_batchnorm(residual_bn)
+                res_affine = self._folded_res
+        codes, _ = ops.affine_dorefa_codes(x2, alpha, beta, self.bit_width, self.relu, res_f32, res_affine, res_codes,
+                                           overflow=flag,
+                                           ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None)
+        return packed.CodeActivation(codes, x.shape)
+
+
 class FusedConvPoolBnSign(torch.nn.Module):
     """BinConv2d / TerConv2d (eval) + [MaxPool2d(k, s)] + eval BatchNorm2d + [Hardtanh] + BinaryConnect(det)
     -> PackedActivation, with NO fp32 activation in between:

@@ -539,6 +539,53 @@ def dorefa_codes(x: torch.Tensor, bit_width: int, want_f32: bool = True, ld_byte
     return CodePlanes(codes=codes, rows=rows, K=K, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
 
 
+def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, bit_width: int, relu: bool = True,
+                        res_f32: Optional[torch.Tensor] = None, res_affine=None,
+                        res_codes: Optional[CodePlanes] = None, want_f32: bool = False,
+                        overflow: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None):
+    """Fused eval BatchNorm (folded alpha, beta) [+ residual] [-> ReLU] -> k-bit DoReFa quantiser over a
+    [rows, C] fp32 matrix (a conv output viewed as pixels x channels): returns (CodePlanes, fp32 image or None).
+    ``res_f32``: fp32 [rows, C] residual, optionally with its own folded BatchNorm ``res_affine`` = (alpha, beta);
+    ``res_codes``: residual held as DoReFa codes (value inv_n * code).  ``overflow``: device int32 flag to OR into
+    (a fresh one is made when None)."""
+    _require(x2, "input")
+    if x2.dim() != 2 or x2.dtype != torch.float32 or (x2.shape[1] > 1 and x2.stride(1) != 1):
+        raise ValueError("affine_dorefa_codes takes a [rows, C] fp32 matrix with unit channel stride")
+    if not 2 <= int(bit_width) <= 8:
+        raise ValueError("int8 code planes exist for 2 <= bit_width <= 8")
+    rows, C = int(x2.shape[0]), int(x2.shape[1])
+    dev = x2.device
+    alpha, beta = _check_bias(alpha, C, dev), _check_bias(beta, C, dev)
+    ra = rb = None
+    ldr = 0
+    if res_f32 is not None:
+        if tuple(res_f32.shape) != (rows, C) or res_f32.dtype != torch.float32 or (C > 1 and res_f32.stride(1) != 1):
+            raise ValueError("fp32 residual must be a [rows, C] fp32 matrix like the input")
+        ldr = res_f32.stride(0) if rows > 1 else max(C, 1)
+        if res_affine is not None:
+            ra, rb = _check_bias(res_affine[0], C, dev), _check_bias(res_affine[1], C, dev)
+    elif res_affine is not None:
+        raise ValueError("res_affine needs res_f32")
+    rscale, ldrc = 0.0, 0
+    if res_codes is not None:
+        if res_codes.rows != rows or res_codes.K != C:
+            raise ValueError("residual codes must be a [rows, C] code plane like the input")
+        rscale, ldrc = float(res_codes.inv_n), int(res_codes.codes.shape[1])
+    ld = code_ld_bytes(C) if ld_bytes is None else int(ld_bytes)
+    codes = torch.empty((rows, ld), dtype=torch.int8, device=dev)
+    y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_f32 else None
+    flag = overflow if overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
+    I = ctypes.c_int64
+    with torch.cuda.device(dev):
+        _lib.call("qt_affine_dorefa_codes_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
+                  _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
+                  ctypes.c_float(rscale), ctypes.c_int(1 if relu else 0), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
+                  ctypes.c_int(int(bit_width)), _p(flag), _stream(dev))
+    n = float((1 << int(bit_width)) - 1)
+    inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+    return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
+
+
 def weight_codes(w2d: torch.Tensor, ternary: bool = False, ld_bytes: Optional[int] = None) -> CodePlanes:
     """int8 codes of safeSign(w) (or the ternary quantiser) for a [N, K] weight."""
     _require(w2d, "weight")
@@ -641,7 +688,10 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
     if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
-        y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
+        pc_, H_, W_, pad_ = pixels.codes, H, W, (ph, pw)
+        if PAD_PIXEL_PLANES and (ph or pw):
+            pc_, H_, W_, pad_ = pad_pixel_plane(pixels.codes, N, H, W, (ph, pw)), H + 2 * ph, W + 2 * pw, (0, 0)
+        y = _conv_implicit(1, pc_, N, H_, W_, Cw, kh, kw, ((sh, sw), pad_, (dh, dw)), wplanes.codes,
                            ldA, bias, scale, scale_dev, Cout)
         if y is not None:
             return y
@@ -707,6 +757,25 @@ def pack_pixels_nib(x: torch.Tensor) -> NibPlanes:
 
 
 
+#: True: padded convs on packed pixel planes first make the zero padding physical (qt_pad_pixel_plane: one pass over a
+#: plane that is 1/8 .. 1/4 of the fp32 tensor) and then run the un-padded conv kernels (32-bit offsets, no per-tap
+#: checks).  Measured neutral on the module-by-module networks (tools/ab_pad_planes.py: AlexNet-Bin 3.21 -> 3.19 ms,
+#: VGG-16 6.51 -> 6.44 ms, DoReFa ResNet-18 3.59 -> 3.63 ms), so off by default; the fused inference path pads inside
+#: its own pack kernel (qt_bits_to_nib_pad) where it is free.
+PAD_PIXEL_PLANES = False
+
+
+def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> torch.Tensor:
+    """[N*H*W, Cw] pixel words (any element type) -> [N*(H+2ph)*(W+2pw), Cw] with a zero border."""
+    ph, pw = _pairs(padding)
+    ld = int(words.shape[1]) * words.element_size() // 4          # row stride in 32-bit words
+    out = torch.empty((N * (H + 2 * ph) * (W + 2 * pw), words.shape[1]), dtype=words.dtype, device=words.device)
+    I = ctypes.c_int64
+    with torch.cuda.device(words.device):
+        _lib.call("qt_pad_pixel_plane", _p(words), I(N), I(H), I(W), I(ld), I(ph), I(pw), _p(out), _stream(words.device))
+    return out
+
+
 def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=None, stride=1,
                padding=0, dilation=1, epi=None):
     """Quantised conv2d on packed operands.  pixels: NHWC nibble pixel plane of the +-1 activation
@@ -726,7 +795,10 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
     if CONV_IMPLICIT:
-        y = _conv_implicit(0, pixels.words, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.words,
+        pw_, H_, W_, pad_ = pixels.words, H, W, (ph, pw)
+        if PAD_PIXEL_PLANES and (ph or pw):
+            pw_, H_, W_, pad_ = pad_pixel_plane(pixels.words, N, H, W, (ph, pw)), H + 2 * ph, W + 2 * pw, (0, 0)
+        y = _conv_implicit(0, pw_, N, H_, W_, Cw, kh, kw, ((sh, sw), pad_, (dh, dw)), wplanes.words,
                            ldA, bias, 1.0, None, Cout, epi=epi)
         if y is not None:
             return y

@@ -89,3 +89,47 @@ class PackedActivation:
             raise ValueError("flatten_hwc needs C to be a multiple of 128 (unpadded 16-byte pixel rows)")
         words = self.planes.sign.view(N, H * W * self.planes.ld)
         return PackedActivation(BitPlanes(sign=words, rows=N, K=H * W * C), (N, H * W * C))
+
+
+class CodeActivation:
+    """A k-bit DoReFa activation that exists ONLY as an int8 code plane (value = inv_n * code, no fp32 image):
+    what layers.fused.FusedBnDorefaQuant hands to the next DorefaConv2d / LinearDorefa in eval mode.
+
+    ``codes``: ops.CodePlanes; ``shape``: logical shape, (N, C, H, W) with NHWC planes (rows = N*H*W, K = C) or
+    (N, K).  The reference does not clamp the quantiser, so a code may not fit int8: the kernels then raise the
+    shared device flag ``codes.overflow`` and ``check()`` / ``float()`` (one host sync, normally at the end of the
+    network) turn it into an error — there is no fp32 image to fall back to."""
+    is_cuda = True
+    dtype = torch.float32
+    requires_grad = False
+
+    def __init__(self, codes, shape):
+        self.codes = codes
+        self.shape = tuple(int(v) for v in shape)
+
+    @property
+    def device(self):
+        return self.codes.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def check(self):
+        from . import ops
+        if not ops.ASSUME_CODES_FIT and self.codes.overflow is not None and int(self.codes.overflow.item()) != 0:
+            raise RuntimeError("a DoReFa activation code exceeded int8 (|q| > 127 or NaN) inside the fused code-plane "
+                               "path: run this model module by module (the fp32 route keeps unclamped activations)")
+        return self
+
+    def float(self) -> torch.Tensor:
+        """The fp32 image nnDorefaQuant would have returned, fl(fl(1/n) * q); (N, C, H, W) comes back channels_last."""
+        self.check()
+        C = self.codes.K
+        y = self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n
+        if len(self.shape) == 4:
+            N, C_, H, W = self.shape
+            return y.view(N, H, W, C_).permute(0, 3, 1, 2)
+        return y.view(self.shape)

@@ -1204,6 +1204,119 @@ def test_conv_wrappers_reject_mismatched_pixel_planes(dev):
         ops.conv2d_codes(codes, (2, 32, 7, 6), wc, (3, 3), 1.0, None, 1, 1, 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,Cout,k,st,pd", [(32, 48, 3, 1, 1), (64, 200, 5, 1, 2), (96, 64, 3, 2, 1), (32, 16, 3, 1, (2, 0))])
+def test_physical_padding_equals_bounds_checked_conv(dev, monkeypatch, C, Cout, k, st, pd):
+    """ops.PAD_PIXEL_PLANES (zero border made physical, un-padded kernels) is bit-identical to the per-tap
+    bounds-checked kernels, for nibble planes and for DoReFa int8 code planes."""
+    N, H, W = 3, 9, 11
+    x = g(synth.pm1(5, (N, C, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    px = ops.pack_pixels_nib(x)
+    wp = ops.pack_conv_weight_nib(g(synth.uniform(6, (Cout, C, k, k), -1, 1), dev), "ternary")
+    b = g(synth.uniform(7, (Cout,), -1, 1), dev)
+    codes, _ = ops.dorefa_codes(torch.rand((N * H * W, C), device=dev), 4, want_f32=False, ld_bytes=C)
+    wc = ops.pack_conv_weight_codes(g(synth.uniform(8, (Cout, C, k, k), -1, 1), dev), ternary=True)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "PAD_PIXEL_PLANES", flag)
+        outs[flag] = (ops.conv2d_nib(px, (N, C, H, W), wp, (k, k), b, st, pd, 1),
+                      ops.conv2d_codes(codes, (N, C, H, W), wc, (k, k), 1.0 / 15, b, st, pd, 1))
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1])
+    ph, pw = (pd, pd) if isinstance(pd, int) else pd
+    q = ops.pad_pixel_plane(codes.codes, N, H, W, pd).view(N, H + 2 * ph, W + 2 * pw, C)
+    assert torch.equal(q[:, ph:ph + H, pw:pw + W], codes.codes.view(N, H, W, C))
+    assert int(q.abs().sum()) == int(codes.codes.abs().sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,k,relu,res", [((3, 64, 5, 7), 4, True, None), ((2, 36, 4, 4), 4, True, "codes"),
+                                              ((2, 128, 3, 5), 3, True, "f32"), ((2, 20, 6, 3), 4, False, "f32bn"),
+                                              ((5, 48), 2, True, "codes"), ((4, 7, 3, 3), 8, True, "f32")])
+def test_fused_bn_dorefa_quant_vs_oracle(dev, oracle, shape, k, relu, res):
+    """layers.FusedBnDorefaQuant (BatchNorm + residual + ReLU + k-bit quantiser in one kernel, int8 code plane out)
+    against the oracle's fp32 restatement of the chain: codes and fp32 image bit for bit."""
+    from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant, fold_batchnorm
+    from pytorch_quantize_impls_amd import packed
+    C = shape[1]
+    x = synth.uniform(11, shape, -3, 3)
+    bn = (torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d)(C)
+    bn.running_mean.copy_(torch.from_numpy(synth.uniform(12, (C,), -1, 1)))
+    bn.running_var.copy_(torch.from_numpy(synth.uniform(13, (C,), 0.5, 4)))
+    bn.weight.data.copy_(torch.from_numpy(synth.uniform(14, (C,), -1.5, 1.5)))
+    bn.bias.data.copy_(torch.from_numpy(synth.uniform(15, (C,), -0.5, 0.5)))
+    bn = bn.to(dev).eval()
+    bn_r = copy.deepcopy(bn)
+    bn_r.weight.data.mul_(0.5)
+    xg = g(x, dev)
+    if len(shape) == 4:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    alpha, beta = (v.cpu().numpy() for v in fold_batchnorm(bn))
+    residual = res_np = res_aff = res_bn = None
+    if res == "codes":
+        r_in = synth.uniform(16, shape, 0, 2)
+        r2 = g(r_in, dev)
+        r2 = r2.permute(0, 2, 3, 1).reshape(-1, C) if len(shape) == 4 else r2
+        rc, ry = ops.dorefa_codes(r2.contiguous(), k, want_f32=True)
+        residual = packed.CodeActivation(rc, shape)
+        res_np = ry.cpu().numpy().reshape((shape[0],) + tuple(shape[2:]) + (C,))
+        res_np = np.moveaxis(res_np, -1, 1) if len(shape) == 4 else res_np
+        np.testing.assert_array_equal(residual.float().cpu().numpy(), res_np)      # code plane round trip
+    elif res is not None:
+        res_np = synth.uniform(17, shape, -2, 2)
+        residual = g(res_np, dev)
+        if res == "f32bn":
+            res_bn = bn_r
+            res_aff = tuple(v.cpu().numpy() for v in fold_batchnorm(bn_r))
+    mod = FusedBnDorefaQuant(bn, k, relu=relu)
+    act = mod(xg, residual=residual, residual_bn=res_bn)
+    want_q, want_y = oracle.affine_relu_dorefa_codes(x, alpha, beta, k, relu, res_np, res_aff)
+    assert act.shape == tuple(shape) and act.codes.codes.shape[1] % 16 == 0
+    got_q = act.codes.codes[:, :C].cpu().numpy().astype(np.float32)
+    got_q = got_q.reshape((shape[0],) + tuple(shape[2:]) + (C,))
+    got_q = np.moveaxis(got_q, -1, 1) if len(shape) == 4 else got_q
+    fits = np.abs(want_q) <= 127
+    np.testing.assert_array_equal(got_q[fits], want_q[fits])
+    assert int(act.codes.overflow.item()) == int(not fits.all())
+    assert int(act.codes.codes[:, C:].abs().sum()) == 0                                # pad bytes stay zero
+    if fits.all():
+        np.testing.assert_array_equal(act.float().cpu().numpy(), want_y)
+    else:
+        with pytest.raises(RuntimeError, match="exceeded int8"):
+            act.float()
+
+
+@pytest.mark.gpu
+def test_fused_dorefa_resnet_matches_module_graph(dev):
+    """C4 in its fused inference form (code planes between the DorefaConv2d layers) against the module-by-module
+    eval graph: BatchNorm folding re-associates fp32 rounding, so a code may flip at a rounding boundary — the
+    logits agree to the float tail and the codes of the first block agree except at such ties."""
+    import bench_models
+    torch.manual_seed(0)
+    m = bench_models.DorefaResNet18()
+    bench_models.randomize_bn(m, seed=3)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_var.mul_(4.0)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    f = bench_models.FusedDorefaResNet18(m)
+    x = torch.randn((16, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        before = dict(_lib.call_counts)
+        got = f(x)
+        used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+        want = m(x)
+        a0 = f.q0(f.stem(x))
+        ref0 = m.quant(torch.relu(m.bn(m.stem(x))))
+    assert used.get("qt_affine_dorefa_codes_i8") == 17 and used.get("qt_conv2d_implicit", 0) >= 19, used
+    assert "qt_dorefa_codes_i8" not in used
+    flips = (a0.float() != ref0).float().mean().item()
+    assert flips < 1e-3, flips
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 0.05 * scale      # a flipped 4-bit code moves a logit by O(1/15)
+    assert (got.argmax(1) == want.argmax(1)).float().mean().item() >= 0.8
+
+
 # ---- Lin / Log fixed-point family (SURVEY 8f n4) ---------------------------------------------------------------
 
 @pytest.fixture(scope="module")

@@ -42,3 +42,10 @@ with torch.no_grad():
     ms2 = t(lambda: m4(x4))
 ops.CodePlanes.usable = orig
 print(f"C4 without the int8-overflow host check: {ms2:.3f} ms/forward = {256 / ms2 * 1e3:.0f} img/s")
+ops.CodePlanes.usable = orig
+f4 = bench_models.FusedDorefaResNet18(m4)
+with torch.no_grad():
+    same = (f4(x4).argmax(1) == m4(x4).argmax(1)).float().mean().item()
+    ms = t(lambda: f4(x4), n=20)
+print(f"C4 fused (BatchNorm + shortcut + ReLU + quantiser in one pass per conv, code planes between layers): "
+      f"{ms:.3f} ms/forward = {256 / ms * 1e3:.0f} img/s, argmax agreement {same:.3f}")
