@@ -155,31 +155,36 @@ class _FusedDorefaBlock(nn.Module):
     """Inference form of _DorefaBlock: activations between the DorefaConv2d layers exist only as int8 code planes
     (layers.FusedBnDorefaQuant folds BatchNorm + shortcut add + ReLU + quantiser into one pass per conv output)."""
 
-    def __init__(self, blk: _DorefaBlock, a_bits: int):
+    def __init__(self, blk: _DorefaBlock, a_bits: int, fuse_conv: bool = True):
         super().__init__()
-        from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant
-        self.conv1, self.conv2 = blk.conv1, blk.conv2
-        self.q1 = FusedBnDorefaQuant(blk.bn1, a_bits)
-        self.q2 = FusedBnDorefaQuant(blk.bn2, a_bits)
+        from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant, FusedDorefaConvBnQuant
+        self.fuse_conv = fuse_conv
+        if fuse_conv:       # the whole tail in the conv epilogue: no fp32 conv output at all
+            self.c1 = FusedDorefaConvBnQuant(blk.conv1, blk.bn1, a_bits)
+            self.c2 = FusedDorefaConvBnQuant(blk.conv2, blk.bn2, a_bits)
+        else:               # fp32 conv output + one fused elementwise pass
+            self.conv1, self.conv2 = blk.conv1, blk.conv2
+            self.q1 = FusedBnDorefaQuant(blk.bn1, a_bits)
+            self.q2 = FusedBnDorefaQuant(blk.bn2, a_bits)
         self.sc_conv, self.sc_bn = (blk.shortcut[0], blk.shortcut[1]) if blk.shortcut is not None else (None, None)
 
     def forward(self, act):
-        y = self.conv2(self.q1(self.conv1(act)))
-        if self.sc_conv is None:
-            return self.q2(y, residual=act)
-        return self.q2(y, residual=self.sc_conv(act), residual_bn=self.sc_bn)
+        res = act if self.sc_conv is None else self.sc_conv(act)
+        if self.fuse_conv:
+            return self.c2(self.c1(act), residual=res, residual_bn=self.sc_bn)
+        return self.q2(self.conv2(self.q1(self.conv1(act))), residual=res, residual_bn=self.sc_bn)
 
 
 class FusedDorefaResNet18(nn.Module):
     """Inference form of an eval-mode DorefaResNet18 (shares its parameters)."""
 
-    def __init__(self, model: DorefaResNet18, a_bits: int = 4):
+    def __init__(self, model: DorefaResNet18, a_bits: int = 4, fuse_conv: bool = True):
         super().__init__()
         from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant
         assert not model.training, "fuse an eval-mode model"
         self.stem, self.linear = model.stem, model.linear
         self.q0 = FusedBnDorefaQuant(model.bn, a_bits)
-        self.blocks = nn.Sequential(*[_FusedDorefaBlock(b, a_bits) for b in model.blocks])
+        self.blocks = nn.Sequential(*[_FusedDorefaBlock(b, a_bits, fuse_conv) for b in model.blocks])
 
     def forward(self, x):
         out = self.blocks(self.q0(self.stem(x))).float()

@@ -347,6 +347,20 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
                             float scale, const float* scale_dev, const float* alpha, const float* beta,
                             uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream);
 
+/* The same conv with the k-bit DoReFa chain of qt_affine_dorefa_codes_i8 applied to the accumulators (code epilogue):
+ *   t = fl(fl(y*alpha[c]) + beta[c]) [+ residual as there] ; [ReLU] ; q = rint((2^k-1) * t)
+ * where y is exactly the fp32 value qt_conv2d_implicit would have stored.  codes: int8 [N*Ho*Wo][ldc_bytes]
+ * (ldc_bytes % 16 == 0, >= Cout rounded up to 4; pad bytes zeroed), i.e. the NHWC code plane the next DorefaConv2d
+ * gathers from: no fp32 activation is written between two quantised convs.  Residual rows are output pixels
+ * (res_f32 [N*Ho*Wo][ldr] / res_codes [N*Ho*Wo][ldrc_bytes]).  *overflow as qt_dorefa_codes_i8. */
+int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                             int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                             int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
+                             const float* scale_dev, const float* alpha, const float* beta, const float* res_f32,
+                             int64_t ldr, const float* res_alpha, const float* res_beta, const int8_t* res_codes,
+                             int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
+                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, qt_stream_t stream);
+
 /* MaxPool2d(pool_k, pool_s, no padding, floor mode) evaluated on threshold bits: out = AND over the
  * window where alpha >= 0, OR where alpha < 0 (max-pooling commutes with the monotone map x*alpha+beta;
  * bit-identical to pooling the fp32 tensor first, NaNs excepted).  in_plane: [N*H*W][ld] words NHWC

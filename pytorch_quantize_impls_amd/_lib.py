@@ -79,6 +79,9 @@ SIGNATURES = {
                                                                     _c_i64, _c_p]),
     "qt_conv2d_implicit_bits": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
                                                                          _c_p, _c_i64, _c_i64, _c_p]),
+    "qt_conv2d_implicit_codes": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
+                                                                          _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
+                                                                          _c_int, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "qt_pool_bits": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p, _c_p]),
     "qt_pad_pixel_plane": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p]),
     "qt_bits_to_nib_pad": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64] + [_c_i64] * 6 + [_c_p]),

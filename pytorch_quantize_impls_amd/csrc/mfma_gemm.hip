@@ -132,9 +132,25 @@ struct ConvArgs {
 // when alpha != nullptr the kernel does not store fp32 Y but, per output element,
 //     t = out(acc) (+ bias);  v = fl(fl(t * alpha[n]) + beta[n]);  bit = v < 0
 // into the bit plane (uint32_t*)Y with ldy WORDS per row (bit n%32 of word n/32 of row m).
+//
+// Code epilogue (mode == 2; inference fusion of conv -> BatchNorm(eval) [-> + shortcut] -> ReLU -> nnDorefaQuant(k),
+// the chain qt_affine_dorefa_codes_i8 runs on an fp32 tensor, applied to the accumulators instead):
+//     t = fl(fl(out(acc) * alpha[n]) + beta[n]) [+ fl(fl(r*ralpha[n]) + rbeta[n]) | + fl(rscale * rcode)]
+//     t = max(t, 0) if relu;  q = rint(levels * t)  ->  int8 code plane (int8_t*)Y with ldy BYTES per row
+// (pad bytes zero; |q| > 127 or NaN -> code 0 and *overflow |= 1).
 struct EpiArgs {
     const float* alpha = nullptr;
     const float* beta = nullptr;
+    int mode = 0;                      // 0: threshold bits iff alpha != nullptr ; 2: int8 codes
+    int relu = 0;
+    float levels = 0.0f;               // 2^k - 1
+    float rscale = 0.0f;
+    const float* res_f32 = nullptr;    // [M][ldr] fp32 residual, optionally through its own (ralpha, rbeta)
+    const float* ralpha = nullptr;
+    const float* rbeta = nullptr;
+    const int8_t* res_codes = nullptr; // [M][ldrc bytes] residual held as codes
+    int64_t ldr = 0, ldrc = 0;
+    int32_t* overflow = nullptr;
 };
 
 // ---- element types ----------------------------------------------------------------------------------
@@ -589,7 +605,86 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
     // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
     const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-    if (epi.alpha) {
+    if (epi.mode == 2) {
+        // int8 codes: the 32x32 tile is transposed through the wave-private LDS patch as in the fp32 store below,
+        // so a lane holds 4 consecutive channels of one output row: per-channel affine, residual, ReLU, rint ->
+        // one dword of codes per lane (4x less store traffic than fp32, and no fp32 activation in HBM at all).
+        int8_t* Q = reinterpret_cast<int8_t*>(Y);
+        float* T = reinterpret_cast<float*>(smem) + wave * 1024;
+        const bool rwide = epi.res_f32 && ((epi.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(epi.res_f32) & 15) == 0);
+        int bad = 0;
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int nb = n0 + (wave_n * C::TNW + b) * 32;
+            const float bv = (bias && nb + lrow < N) ? bias[nb + lrow] : 0.0f;
+            const int n = nb + (lane & 7) * 4;
+            float al[4], be[4], ral[4], rbe[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = n + e < N;
+                al[e] = in ? epi.alpha[n + e] : 0.0f;
+                be[e] = in ? epi.beta[n + e] : 0.0f;
+                ral[e] = (in && epi.ralpha) ? epi.ralpha[n + e] : 1.0f;
+                rbe[e] = (in && epi.ralpha) ? epi.rbeta[n + e] : 0.0f;
+            }
+#pragma unroll
+            for (int a = 0; a < C::TMW; ++a) {
+                const int mb = m0 + (wave_m * C::TMW + a) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = E::out(acc[a][b][r], scale, bv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3);
+                    const float4 v4 = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
+                    const int m = mb + row;
+                    if (m < M && n < ldy) {
+                        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                        float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (epi.res_f32) {
+                            const float* rp = epi.res_f32 + (int64_t)m * epi.ldr + n;
+                            if (rwide && n + 3 < N) {
+                                const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                                u[0] = r4.x; u[1] = r4.y; u[2] = r4.z; u[3] = r4.w;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < N) u[e] = rp[e];
+                            }
+                        }
+                        uint32_t rword = 0;
+                        if (epi.res_codes && n < N)
+                            rword = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)m * epi.ldrc + n);
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int q = 0;
+                            if (n + e < N) {
+                                float t = v[e] * al[e] + be[e];          // two roundings (-ffp-contract=off)
+                                if (epi.res_f32) t = t + (epi.ralpha ? u[e] * ral[e] + rbe[e] : u[e]);
+                                if (epi.res_codes) t = t + epi.rscale * (float)(int8_t)(rword >> (8 * e));
+                                if (epi.relu) t = t < 0.0f ? 0.0f : t;
+                                const float qf = rintf(epi.levels * t);
+                                if (!(qf >= -127.0f && qf <= 127.0f)) bad = 1; else q = (int)qf;
+                            }
+                            word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
+                        }
+                        *reinterpret_cast<uint32_t*>(Q + (int64_t)m * ldy + n) = word;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // pad bytes past the last column tile (row strides rounded beyond the tile width)
+                if (b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && mb + lane < M)
+                    for (int c = n0 + C::TN; c < ldy; c += 4)
+                        *reinterpret_cast<uint32_t*>(Q + (int64_t)(mb + lane) * ldy + c) = 0u;
+            }
+        }
+        if (__any(bad) && lane == 0) atomicOr(epi.overflow, 1);
+    } else if (epi.alpha) {
         // threshold bits: a v_cmp over the wave yields, per accumulator register, the 32-channel word of
         // two output rows (lanes 0-31 -> row R, lanes 32-63 -> row R + 4); lane i keeps row i's word and
         // one 32-lane store per 32x32 tile writes them.  Channels >= N compare 0 < 0 -> bit 0.
@@ -1093,7 +1188,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
     const int64_t M = Nimg * Ho * Wo;
     if (M == 0 || Cout == 0) return QT_OK;
-    if (!P || !Wmat || !Y || ldy < (epi.alpha ? (Cout + 31) / 32 : Cout)) return QT_ERR_INVALID_ARG;
+    if (!P || !Wmat || !Y || ldy < (epi.mode == 2 ? ((Cout + 3) & ~3ll) : epi.alpha ? (Cout + 31) / 32 : Cout))
+        return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
     if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767 ||
@@ -1179,6 +1275,36 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H
     epi.beta = beta;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(neg_plane), ldb, Cout, stream, epi);
+}
+
+int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                             int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                             int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                             const float* scale_dev, const float* alpha, const float* beta, const float* res_f32,
+                             int64_t ldr, const float* res_alpha, const float* res_beta, const int8_t* res_codes,
+                             int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
+                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, qt_stream_t stream) {
+    if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if ((res_f32 && ldr < Cout) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;
+    if ((ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
+    if (res_codes && (ldrc_bytes < ((Cout + 3) & ~3ll) || (ldrc_bytes & 3) || (reinterpret_cast<uintptr_t>(res_codes) & 3)))
+        return QT_ERR_ALIGNMENT;
+    EpiArgs epi;
+    epi.alpha = alpha;
+    epi.beta = beta;
+    epi.mode = 2;
+    epi.relu = relu;
+    epi.levels = (float)((1 << bit_width) - 1);
+    epi.res_f32 = res_f32;
+    epi.ldr = ldr;
+    epi.ralpha = res_alpha;
+    epi.rbeta = res_beta;
+    epi.res_codes = res_codes;
+    epi.ldrc = ldrc_bytes;
+    epi.rscale = res_scale;
+    epi.overflow = overflow;
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi);
 }
 
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,

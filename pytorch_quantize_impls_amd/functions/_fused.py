@@ -337,7 +337,7 @@ def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_cod
 
 
 def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, weight_codes=None,
-                           padding_mode: str = "zeros", scale=None):
+                           padding_mode: str = "zeros", scale=None, epi=None):
     """DorefaConv2d(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:77-82)."""
     stride, padding, dilation, groups = conv_args
     E = scale if scale is not None else _dorefa_w1_scale(weight, prequantized)
@@ -350,12 +350,18 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
                 or C != weight.shape[1] or 127 * kh * kw * codes.codes.shape[1] >= (1 << 24)):
             raise ValueError(f"CodeActivation {input.shape} does not fit this DorefaConv2d")
         wc = weight_codes if weight_codes is not None else ops.pack_conv_weight_codes(weight.detach())
+        if epi is not None and epi.overflow is None:
+            epi.overflow = codes.overflow
         y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding, dilation,
-                              scale_dev=E)
+                              scale_dev=E, epi=epi)
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        if epi is not None:
+            return packed.CodeActivation(y2, (N_, weight.shape[0], Ho, Wo))
         y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
         y._qt_overflow = codes.overflow          # the chain's range flag rides on to the next fused quantiser
         return y
+    if epi is not None:
+        raise TypeError("the code epilogue takes a CodeActivation input")
     codes = None
     if (input.dtype == torch.float32 and input.dim() == 4 and groups == 1 and padding_mode == "zeros"
             and not isinstance(padding, str)):

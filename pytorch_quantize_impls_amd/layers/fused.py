@@ -133,6 +133,50 @@ class FusedBnDorefaQuant(torch.nn.Module):
         return packed.CodeActivation(codes, x.shape)
 
 
+class FusedDorefaConvBnQuant(torch.nn.Module):
+    """DorefaConv2d(bit_width=1, eval) -> BatchNorm(eval) [+ residual] [-> ReLU] -> nnDorefaQuant(k) with the whole
+    tail in the conv kernel's epilogue (qt_conv2d_implicit_codes): CodeActivation in, CodeActivation out, no fp32
+    activation in HBM.  Same arithmetic as ``FusedBnDorefaQuant`` applied to the conv's fp32 output (the epilogue
+    forms exactly the value the conv would have stored), so the two are bit-identical.
+
+    forward(act, residual=None, residual_bn=None): residual over the conv's OUTPUT pixels, as FusedBnDorefaQuant."""
+
+    def __init__(self, conv, bn, bit_width: int, relu: bool = True):
+        super().__init__()
+        if getattr(conv, "bit_width", None) != 1 or conv.groups != 1 or conv.padding_mode != "zeros":
+            raise ValueError("FusedDorefaConvBnQuant takes an un-grouped, zero-padded DorefaConv2d(bit_width=1)")
+        self.conv, self.bn, self.bit_width, self.relu = conv, bn, int(bit_width), bool(relu)
+        self._folded = self._folded_res = None
+
+    def refold(self):
+        self._folded = self._folded_res = None
+
+    def forward(self, act, residual=None, residual_bn=None):
+        conv = self.conv
+        if conv.training or self.bn.training:
+            raise RuntimeError("FusedDorefaConvBnQuant is an inference form: call .eval() first")
+        if not isinstance(act, packed.CodeActivation):
+            raise TypeError("FusedDorefaConvBnQuant consumes a CodeActivation (FusedBnDorefaQuant output)")
+        if self._folded is None:
+            self._folded = fold_batchnorm(self.bn)
+        epi = ops.CodeEpilogue(self._folded[0], self._folded[1], self.bit_width, self.relu)
+        if isinstance(residual, packed.CodeActivation):
+            epi.res_codes = residual.codes
+        elif residual is not None:
+            r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
+            epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
+            if residual_bn is not None:
+                if self._folded_res is None:
+                    self._folded_res = fold_batchnorm(residual_bn)
+                epi.res_affine = self._folded_res
+        from ..functions import _fused
+        wc = conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(conv.weight.detach()), key="conv_i8")
+        E = conv._eval_planes(lambda w2: w2.abs().amax(), key="E")
+        return _fused.dorefa_w1_conv_forward(act, conv.weight, conv.bias,
+                                             (conv.stride, conv.padding, conv.dilation, conv.groups), True, wc,
+                                             conv.padding_mode, scale=E, epi=epi)
+
+
 class FusedConvPoolBnSign(torch.nn.Module):
     """BinConv2d / TerConv2d (eval) + [MaxPool2d(k, s)] + eval BatchNorm2d + [Hardtanh] + BinaryConnect(det)
     -> PackedActivation, with NO fp32 activation in between:

@@ -25,6 +25,21 @@ IM2COL_MAX_BYTES = 1 << 30
 CONV_IMPLICIT = True
 
 
+@dataclass
+class CodeEpilogue:
+    """Arguments of the conv code epilogue (qt_conv2d_implicit_codes): folded BatchNorm (alpha, beta), optional
+    residual over the OUTPUT pixels (fp32 [M, Cout] with optional own folded BatchNorm, or CodePlanes), ReLU,
+    k-bit DoReFa quantiser; ``overflow``: device int32 flag shared along the chain (None: a fresh one)."""
+    alpha: torch.Tensor
+    beta: torch.Tensor
+    bit_width: int
+    relu: bool = True
+    res_f32: Optional[torch.Tensor] = None
+    res_affine: Optional[tuple] = None
+    res_codes: Optional["CodePlanes"] = None
+    overflow: Optional[torch.Tensor] = None
+
+
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
                    ldw_words: int, bias, scale: float, scale_dev, Cout: int, epi=None):
     """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back).
@@ -42,6 +57,34 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
     head = (ctypes.c_int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw),
             I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias), ctypes.c_float(float(scale)),
             _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None))
+    if isinstance(epi, CodeEpilogue):
+        alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
+        if not 2 <= int(epi.bit_width) <= 8:
+            raise ValueError("int8 code planes exist for 2 <= bit_width <= 8")
+        rf, ra, rb, rc, ldr, ldrc, rscale = None, None, None, None, 0, 0, 0.0
+        if epi.res_f32 is not None:
+            rf = _require(epi.res_f32, "residual")
+            if tuple(rf.shape) != (M, Cout) or (Cout > 1 and rf.stride(1) != 1):
+                raise ValueError(f"fp32 residual must be [{M}, {Cout}] with unit channel stride, got {tuple(rf.shape)}")
+            ldr = rf.stride(0) if M > 1 else max(Cout, 1)
+            if epi.res_affine is not None:
+                ra, rb = _check_bias(epi.res_affine[0], Cout, dev), _check_bias(epi.res_affine[1], Cout, dev)
+        elif epi.res_affine is not None:
+            raise ValueError("res_affine needs res_f32")
+        if epi.res_codes is not None:
+            if epi.res_codes.rows != M or epi.res_codes.K != Cout:
+                raise ValueError(f"residual codes must be a [{M}, {Cout}] plane")
+            rc, ldrc, rscale = epi.res_codes.codes, int(epi.res_codes.codes.shape[1]), float(epi.res_codes.inv_n)
+        ldc = code_ld_bytes(Cout, 16)
+        codes = torch.empty((M, ldc), dtype=torch.int8, device=dev)
+        flag = epi.overflow if epi.overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("qt_conv2d_implicit_codes", *head, _p(alpha), _p(beta), _p(rf), I(ldr), _p(ra), _p(rb), _p(rc),
+                      I(ldrc), ctypes.c_float(rscale), ctypes.c_int(1 if epi.relu else 0),
+                      ctypes.c_int(int(epi.bit_width)), _p(codes), I(ldc), I(Cout), _p(flag), _stream(dev))
+        n = float((1 << int(epi.bit_width)) - 1)
+        inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+        return CodePlanes(codes=codes, rows=M, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
     if epi is not None:
         alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi, ("alpha", "beta")))
         if alpha.numel() != Cout or beta.numel() != Cout:
@@ -670,10 +713,11 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
 
 
 def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, scale: float, bias=None,
-                 stride=1, padding=0, dilation=1, scale_dev=None, max_abs_code: int = 127) -> torch.Tensor:
+                 stride=1, padding=0, dilation=1, scale_dev=None, max_abs_code: int = 127, epi=None):
     """DoReFa conv2d on int8 code planes: NHWC pixel codes -> packed-domain im2col (zero bytes for
     padding taps = the reference's zero padding, code 0 <-> value 0) -> int8 MFMA GEMM.
-    Returns the NHWC result [N*Ho*Wo, Cout]."""
+    Returns the NHWC result [N*Ho*Wo, Cout]; with ``epi`` (a CodeEpilogue) the CodePlanes of the fused
+    BatchNorm / residual / ReLU / quantiser chain instead (implicit-GEMM kernel only)."""
     N, C, H, W = (int(v) for v in in_shape)
     kh, kw = kernel_hw
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
@@ -692,9 +736,11 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
         if PAD_PIXEL_PLANES and (ph or pw):
             pc_, H_, W_, pad_ = pad_pixel_plane(pixels.codes, N, H, W, (ph, pw)), H + 2 * ph, W + 2 * pw, (0, 0)
         y = _conv_implicit(1, pc_, N, H_, W_, Cw, kh, kw, ((sh, sw), pad_, (dh, dw)), wplanes.codes,
-                           ldA, bias, scale, scale_dev, Cout)
+                           ldA, bias, scale, scale_dev, Cout, epi=epi)
         if y is not None:
             return y
+    if epi is not None:
+        raise ValueError("the code epilogue exists on the implicit-GEMM conv kernel only (shape outside its limits)")
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 4), dtype=torch.int8, device=dev)

@@ -1287,6 +1287,114 @@ def test_fused_bn_dorefa_quant_vs_oracle(dev, oracle, shape, k, relu, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,ksz,st,pd,k,res", [(32, 64, 3, 1, 1, 4, "codes"), (64, 40, 3, 2, 1, 4, "f32bn"),
+                                                       (16, 200, 1, 2, 0, 3, None), (48, 130, 3, 1, 1, 2, "f32"),
+                                                       (128, 256, 3, 1, 1, 4, "codes"), (64, 64, 3, 1, 1, 8, None)])
+def test_conv_code_epilogue_equals_conv_then_fused_quantiser(dev, oracle, Cin, Cout, ksz, st, pd, k, res):
+    """layers.FusedDorefaConvBnQuant (BatchNorm / residual / ReLU / quantiser in the conv kernel's epilogue) is
+    bit-identical to DorefaConv2d -> FusedBnDorefaQuant (itself pinned to the oracle), and to the oracle's chain on
+    the oracle's own conv when that conv is exact in fp32."""
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant, fold_batchnorm
+    N, H, W = 3, 9, 8
+    torch.manual_seed(7)
+    conv = DorefaConv2d(Cin, Cout, ksz, stride=st, padding=pd, bias=True, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 4); bn.weight.data.normal_(); bn.bias.data.normal_()
+    bn.eval()
+    bn_r = copy.deepcopy(bn)
+    bn_r.weight.data.mul_(-0.7)
+    x_codes, _ = ops.dorefa_codes(torch.rand((N * H * W, Cin), device=dev) * 1.5, 4, want_f32=False,
+                                  ld_bytes=ops.code_ld_bytes(Cin, 16))
+    act = packed.CodeActivation(x_codes, (N, Cin, H, W))
+    Ho, Wo = ops.conv_out_hw(H, W, ksz, ksz, st, pd, 1)
+    residual = res_bn = None
+    if res == "codes":
+        r_codes, _ = ops.dorefa_codes(torch.rand((N * Ho * Wo, Cout), device=dev) * 2, k, want_f32=False,
+                                      ld_bytes=ops.code_ld_bytes(Cout, 16))
+        residual = packed.CodeActivation(r_codes, (N, Cout, Ho, Wo))
+    elif res is not None:
+        residual = torch.randn((N, Cout, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
+        res_bn = bn_r if res == "f32bn" else None
+    with torch.no_grad():
+        fused = FusedDorefaConvBnQuant(conv, bn, k)(act, residual=residual, residual_bn=res_bn)
+        two_step = FusedBnDorefaQuant(bn, k)(conv(act), residual=residual, residual_bn=res_bn)
+    assert fused.shape == two_step.shape == (N, Cout, Ho, Wo)
+    assert torch.equal(fused.codes.codes, two_step.codes.codes)
+    assert int(fused.codes.overflow.item()) == int(two_step.codes.overflow.item())
+    # the shared flag: both calls OR into the input activation's flag
+    assert fused.codes.overflow.data_ptr() == x_codes.overflow.data_ptr()
+
+
+@pytest.mark.gpu
+def test_fuzz_conv_code_epilogue_vs_oracle(dev, oracle):
+    """Random DorefaConv2d geometries through the code epilogue: against the two-step HIP path (bit-identical) and
+    against the oracle's conv + chain on the same codes.  The oracle's fp32 conv sums in another order than the
+    int32 accumulate, so an output whose n*t lands within float rounding of a .5 tie may differ by one code: such
+    positions are identified from the oracle's own pre-rounding value and excluded (they are < 1e-3 of the outputs)."""
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant, fold_batchnorm
+    rng = np.random.default_rng(20260929)
+    checked = skipped = 0
+    for it in range(30):
+        Cin = int(rng.choice([4, 16, 24, 32, 64, 100]))
+        Cout = int(rng.choice([1, 7, 30, 32, 64, 100, 130, 192, 260]))
+        kh, kw = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        st = (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+        pd = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        dl = (int(rng.integers(1, 3)), 1)
+        N = int(rng.integers(1, 4))
+        H = int(rng.integers(dl[0] * (kh - 1) + 1, 12)) + 2
+        W = int(rng.integers(kw, 12)) + 2
+        k = int(rng.choice([2, 3, 4, 5]))
+        relu = bool(it % 5)
+        res_kind = ("codes", "f32", "f32bn", None)[it % 4]
+        cfg = (it, Cin, Cout, kh, kw, st, pd, dl, N, H, W, k, relu, res_kind)
+        conv = DorefaConv2d(Cin, Cout, (kh, kw), stride=st, padding=pd, dilation=dl, bias=bool(it % 3), bit_width=1).to(dev)
+        conv.weight.data.copy_(g(synth.uniform(100 + it, (Cout, Cin, kh, kw), -1, 1), dev))
+        conv.eval()
+        bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+        bn.running_mean.copy_(g(synth.normal(200 + it, (Cout,)) * 0.2, dev))
+        bn.running_var.copy_(g(synth.uniform(300 + it, (Cout,), 0.5, 4), dev))
+        bn.weight.data.copy_(g(synth.normal(400 + it, (Cout,)) * 0.3, dev))
+        bn.bias.data.copy_(g(synth.normal(500 + it, (Cout,)) * 0.3, dev))
+        bn_r = copy.deepcopy(bn)
+        bn_r.weight.data.mul_(0.5)
+        xin = synth.uniform(600 + it, (N, H, W, Cin), 0, 1.2)
+        x_codes, x_img = ops.dorefa_codes(g(xin.reshape(-1, Cin), dev), 4, want_f32=True, ld_bytes=ops.code_ld_bytes(Cin, 16))
+        act = packed.CodeActivation(x_codes, (N, Cin, H, W))
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, st, pd, dl)
+        residual = res_bn = res_np = res_aff = None
+        if res_kind == "codes":
+            r_codes, r_img = ops.dorefa_codes(g(synth.uniform(700 + it, (N * Ho * Wo, Cout), 0, 1), dev), k, want_f32=True,
+                                              ld_bytes=ops.code_ld_bytes(Cout, 16))
+            residual = packed.CodeActivation(r_codes, (N, Cout, Ho, Wo))
+            res_np = np.moveaxis(n(r_img).reshape(N, Ho, Wo, Cout), -1, 1)
+        elif res_kind is not None:
+            res_np = synth.uniform(800 + it, (N, Cout, Ho, Wo), -1, 1)
+            residual = g(res_np, dev).contiguous(memory_format=torch.channels_last)
+            if res_kind == "f32bn":
+                res_bn, res_aff = bn_r, tuple(n(v) for v in fold_batchnorm(bn_r))
+        with torch.no_grad():
+            fused = FusedDorefaConvBnQuant(conv, bn, k, relu=relu)(act, residual=residual, residual_bn=res_bn)
+            two = FusedBnDorefaQuant(bn, k, relu=relu)(conv(act), residual=residual, residual_bn=res_bn)
+        assert torch.equal(fused.codes.codes, two.codes.codes), cfg
+        # oracle: conv of the fp32 activation image with the eval weight (sign(W) * E), then the chain
+        x_nchw = np.moveaxis(n(x_img).reshape(N, H, W, Cin), -1, 1)
+        yc = oracle.conv2d(x_nchw, n(conv.weight), None if conv.bias is None else n(conv.bias), st, pd, dl)
+        alpha, beta = (n(v) for v in fold_batchnorm(bn))
+        want_q, _ = oracle.affine_relu_dorefa_codes(yc, alpha, beta, k, relu, res_np, res_aff)
+        got_q = np.moveaxis(n(fused.codes.codes[:, :Cout]).astype(np.float32).reshape(N, Ho, Wo, Cout), -1, 1)
+        fits = np.abs(want_q) <= 126                      # beyond int8 the kernel writes 0 and raises the flag
+        if not (np.abs(want_q) <= 128).all():
+            assert int(fused.codes.overflow.item()) == 1, cfg
+        diff = (got_q != want_q) & fits
+        assert np.abs((got_q - want_q)[fits]).max(initial=0) <= 1, cfg
+        assert diff.mean() <= 2e-3, (cfg, diff.mean())
+        checked += diff.size
+        skipped += int(diff.sum())
+    assert skipped <= 1e-3 * checked, (skipped, checked)
+
+
+@pytest.mark.gpu
 def test_fused_dorefa_resnet_matches_module_graph(dev):
     """C4 in its fused inference form (code planes between the DorefaConv2d layers) against the module-by-module
     eval graph: BatchNorm folding re-associates fp32 rounding, so a code may flip at a rounding boundary — the
@@ -1299,17 +1407,25 @@ def test_fused_dorefa_resnet_matches_module_graph(dev):
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.running_var.mul_(4.0)
     m = m.to(dev).to(memory_format=torch.channels_last).eval()
-    f = bench_models.FusedDorefaResNet18(m)
+    f = bench_models.FusedDorefaResNet18(m, fuse_conv=False)
+    fc = bench_models.FusedDorefaResNet18(m, fuse_conv=True)
     x = torch.randn((16, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         before = dict(_lib.call_counts)
         got = f(x)
         used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+        before = dict(_lib.call_counts)
+        got_c = fc(x)
+        used_c = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
         want = m(x)
         a0 = f.q0(f.stem(x))
         ref0 = m.quant(torch.relu(m.bn(m.stem(x))))
     assert used.get("qt_affine_dorefa_codes_i8") == 17 and used.get("qt_conv2d_implicit", 0) >= 19, used
     assert "qt_dorefa_codes_i8" not in used
+    # conv-epilogue form: 16 code-epilogue convs, 3 fp32 shortcut convs, only the stem quantiser as its own pass
+    assert used_c.get("qt_conv2d_implicit_codes") == 16 and used_c.get("qt_conv2d_implicit") == 3, used_c
+    assert used_c.get("qt_affine_dorefa_codes_i8") == 1
+    assert torch.equal(got_c, got)
     flips = (a0.float() != ref0).float().mean().item()
     assert flips < 1e-3, flips
     scale = want.abs().max().item()

@@ -37,3 +37,34 @@ def test_maxpool_commutes_with_the_folded_batchnorm():
             bits = f(x) < 0
             on_bits = bits.any(1) if a < 0 else bits.all(1)
             assert np.array_equal(pooled_first, on_bits), (a, b)
+
+
+def test_oracle_dorefa_block_chain_matches_torch_modules(oracle):
+    """oracle.affine_relu_dorefa_codes = folded BatchNorm + shortcut + ReLU + the reference quantiser
+    (functions/dorefa_connect.py:24-25, restated by the package's CPU nnDorefaQuant, itself pinned to golden G3)."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    torch.manual_seed(2)
+    N, C, H = 2, 19, 5
+    x = torch.randn(N, C, H, H) * 2
+    r = torch.randn(N, C, H, H)
+    bn, bn_r = torch.nn.BatchNorm2d(C).eval(), torch.nn.BatchNorm2d(C).eval()
+    for b in (bn, bn_r):
+        b.running_mean.normal_(); b.running_var.uniform_(0.5, 4); b.weight.data.normal_(); b.bias.data.normal_()
+    (a, be), (ra, rb) = fold_batchnorm(bn), fold_batchnorm(bn_r)
+    v = lambda p: p.view(1, -1, 1, 1)
+    for k in (2, 4, 8):
+        quant = nnDorefaQuant(k)
+        n = float((1 << k) - 1)
+        for relu in (True, False):
+            for res, aff in ((None, None), (r, None), (r, (ra, rb))):
+                with torch.no_grad():
+                    t = x * v(a) + v(be)
+                    if res is not None:
+                        t = t + (res * v(ra) + v(rb) if aff is not None else res)
+                    t = torch.relu(t) if relu else t
+                    want = quant(t)
+                q, y = oracle.affine_relu_dorefa_codes(x.numpy(), a.numpy(), be.numpy(), k, relu,
+                                                       None if res is None else res.numpy(),
+                                                       None if aff is None else (ra.numpy(), rb.numpy()))
+                assert np.array_equal(y, want.numpy())
+                assert np.array_equal(q, torch.round(n * t).numpy())

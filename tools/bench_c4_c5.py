@@ -43,9 +43,23 @@ with torch.no_grad():
 ops.CodePlanes.usable = orig
 print(f"C4 without the int8-overflow host check: {ms2:.3f} ms/forward = {256 / ms2 * 1e3:.0f} img/s")
 ops.CodePlanes.usable = orig
+f4 = bench_models.FusedDorefaResNet18(m4, fuse_conv=False)
+with torch.no_grad():
+    ms = t(lambda: f4(x4), n=20)
+print(f"C4 fused, fp32 conv outputs + one BatchNorm/shortcut/ReLU/quantiser pass each: {ms:.3f} ms/forward = {256 / ms * 1e3:.0f} img/s")
 f4 = bench_models.FusedDorefaResNet18(m4)
 with torch.no_grad():
     same = (f4(x4).argmax(1) == m4(x4).argmax(1)).float().mean().item()
     ms = t(lambda: f4(x4), n=20)
-print(f"C4 fused (BatchNorm + shortcut + ReLU + quantiser in one pass per conv, code planes between layers): "
+print(f"C4 fused (BatchNorm + shortcut + ReLU + quantiser in the conv epilogue, code planes between layers): "
       f"{ms:.3f} ms/forward = {256 / ms * 1e3:.0f} img/s, argmax agreement {same:.3f}")
+# launch-bound? replay the fused C4 forward as a hipGraph (needs the range check waived: it is a host sync)
+from pytorch_quantize_impls_amd import utils
+ops.ASSUME_CODES_FIT = True
+with torch.no_grad():
+    g4 = utils.graphed(f4, x4)
+    same = torch.equal(g4(x4), f4(x4))
+    ms = t(lambda: g4(x4), n=20)
+    ms_e = t(lambda: f4(x4), n=20)
+ops.ASSUME_CODES_FIT = False
+print(f"C4 fused as a hipGraph replay: {ms:.3f} ms/forward = {256 / ms * 1e3:.0f} img/s (eager with the same waiver {ms_e:.3f} ms), identical {same}")
