@@ -351,7 +351,7 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
  *   t = fl(fl(y*alpha[c]) + beta[c]) [+ residual as there] ; [ReLU] ; q = rint((2^k-1) * t)
  * where y is exactly the fp32 value qt_conv2d_implicit would have stored.  codes: int8 [N*Ho*Wo][ldc_bytes]
  * (ldc_bytes % 16 == 0, >= Cout rounded up to 4; pad bytes zeroed), i.e. the NHWC code plane the next DorefaConv2d
- * gathers from: no fp32 activation is written between two quantised convs.  Residual rows are output pixels
+ * gathers from: no fp32 activation is written between two quantised convs.  elem must be 1 (int8 code planes).  Residual rows are output pixels
  * (res_f32 [N*Ho*Wo][ldr] / res_codes [N*Ho*Wo][ldrc_bytes]).  *overflow as qt_dorefa_codes_i8. */
 int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,

@@ -13,7 +13,8 @@ import threading
 from collections import Counter
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqt_hip.so")
+# QT_HIP_LIB: A/B builds of the same ABI (tools/); the product path is the in-tree library
+LIB_PATH = os.environ.get("QT_HIP_LIB") or os.path.join(_HERE, "lib", "libqt_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "qt_hip.h"))
 
 

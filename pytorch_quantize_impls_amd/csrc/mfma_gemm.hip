@@ -156,6 +156,7 @@ struct EpiArgs {
 // ---- element types ----------------------------------------------------------------------------------
 struct ElemFp4 {
     using acc_t = v16f;
+    static constexpr bool CODE_EPI = false;
     __device__ __forceinline__ static int kbytes(int K) { return (K + 1) / 2; }
     __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
         const v8i av = (v8i){(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
@@ -167,6 +168,7 @@ struct ElemFp4 {
 };
 struct ElemI8 {
     using acc_t = v16i;
+    static constexpr bool CODE_EPI = true;   // the DoReFa code epilogue is instantiated for int8 conv configs only
     __device__ __forceinline__ static int kbytes(int K) { return K; }
     __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
         const v4i av = (v4i){(int)a.x, (int)a.y, (int)a.z, (int)a.w};
@@ -183,6 +185,7 @@ struct ElemI8 {
 // accumulates in fp32, so the result has fp32-GEMM accuracy at the bf16 matrix rate / 3.
 struct ElemBf16 {
     using acc_t = v16f;
+    static constexpr bool CODE_EPI = false;
     __device__ __forceinline__ static int kbytes(int K) { return 2 * K; }
     __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
         typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
     // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
     const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-    if (epi.mode == 2) {
+    if constexpr (E::CODE_EPI && C::CONV) if (epi.mode == 2) {
         // int8 codes: the 32x32 tile is transposed through the wave-private LDS patch as in the fp32 store below,
         // so a lane holds 4 consecutive channels of one output row: per-channel affine, residual, ReLU, rint ->
         // one dword of codes per lane (4x less store traffic than fp32, and no fp32 activation in HBM at all).
@@ -684,7 +687,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             }
         }
         if (__any(bad) && lane == 0) atomicOr(epi.overflow, 1);
-    } else if (epi.alpha) {
+        return;
+    }
+    if (epi.alpha) {
         // threshold bits: a v_cmp over the wave yields, per accumulator register, the 32-channel word of
         // two output rows (lanes 0-31 -> row R, lanes 32-63 -> row R + 4); lane i keeps row i's word and
         // one 32-lane store per 32x32 tile writes them.  Channels >= N compare 0 < 0 -> bit 0.
@@ -1285,6 +1290,7 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
                              int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
                              int64_t ldc_bytes, int64_t Cout, int32_t* overflow, qt_stream_t stream) {
     if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (elem != 1) return QT_ERR_UNSUPPORTED;   // the epilogue is instantiated for the int8 (DoReFa) configs
     if ((res_f32 && ldr < Cout) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;
     if ((ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
     if (res_codes && (ldrc_bytes < ((Cout + 3) & ~3ll) || (ldrc_bytes & 3) || (reinterpret_cast<uintptr_t>(res_codes) & 3)))
