@@ -295,6 +295,11 @@ int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64
 int qt_pad_pixel_plane(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t ph, int64_t pw,
                        uint32_t* Q, qt_stream_t stream);
 
+/* Zero the border pixels (only) of a halo plane Q [N][H + 2*halo_h][W + 2*halo_w][Cw words]: what the caller of
+ * qt_conv2d_implicit_codes does to the output plane before (or after) the conv writes its interior. */
+int qt_zero_halo(uint32_t* Q, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t halo_h, int64_t halo_w,
+                 qt_stream_t stream);
+
 /* Same expansion into a PHYSICALLY zero-padded NHWC pixel plane: sign/mask planes hold N*H*W pixel rows,
  * nib_plane gets N*(H+2ph)*(W+2pw) rows of ldn words whose border pixels are fp4 zeros.  A conv with zero
  * padding (ph, pw) on the original image equals the un-padded conv on this plane, which the implicit-GEMM
@@ -352,14 +357,29 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
  * where y is exactly the fp32 value qt_conv2d_implicit would have stored.  codes: int8 [N*Ho*Wo][ldc_bytes]
  * (ldc_bytes % 16 == 0, >= Cout rounded up to 4; pad bytes zeroed), i.e. the NHWC code plane the next DorefaConv2d
  * gathers from: no fp32 activation is written between two quantised convs.  elem must be 1 (int8 code planes).  Residual rows are output pixels
- * (res_f32 [N*Ho*Wo][ldr] / res_codes [N*Ho*Wo][ldrc_bytes]).  *overflow as qt_dorefa_codes_i8. */
+ * (res_f32 [N*Ho*Wo][ldr] / res_codes [N*Ho*Wo][ldrc_bytes]).  *overflow as qt_dorefa_codes_i8.
+ * Halo planes: a pixel plane may carry a zero border of (halo_h, halo_w) pixels around every image,
+ * [N][H + 2*halo_h][W + 2*halo_w][C]: the zero padding of a conv that reads it is then physical and the conv runs
+ * the un-padded kernels (no per-tap bounds checks).  in_halo_*: halo of P (needs ph <= in_halo_h, pw <= in_halo_w;
+ * QT_ERR_UNSUPPORTED when the plane exceeds 4 GiB); out_halo_*: halo of `codes` — the caller zeroes the border
+ * (qt_zero_halo or a fill), the kernel writes the interior pixels; res_halo_*: halo of `res_codes`. */
 int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                              int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
                              const float* scale_dev, const float* alpha, const float* beta, const float* res_f32,
                              int64_t ldr, const float* res_alpha, const float* res_beta, const int8_t* res_codes,
                              int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
-                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, qt_stream_t stream);
+                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
+                             int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
+                             int64_t res_halo_w, qt_stream_t stream);
+
+/* qt_conv2d_implicit reading a halo plane P [N][H + 2*halo_h][W + 2*halo_w][Cw] (see qt_conv2d_implicit_codes):
+ * fp32 output as qt_conv2d_implicit.  ph <= halo_h, pw <= halo_w. */
+int qt_conv2d_implicit_halo(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                            int64_t halo_h, int64_t halo_w, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                            int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldw,
+                            const float* bias, float scale, const float* scale_dev, float* Y, int64_t ldy,
+                            int64_t Cout, qt_stream_t stream);
 
 /* MaxPool2d(pool_k, pool_s, no padding, floor mode) evaluated on threshold bits: out = AND over the
  * window where alpha >= 0, OR where alpha < 0 (max-pooling commutes with the monotone map x*alpha+beta;

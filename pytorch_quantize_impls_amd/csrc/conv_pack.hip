@@ -68,7 +68,44 @@ __global__ __launch_bounds__(256) void pad_pixel_plane_kernel(const uint32_t* __
     }
 }
 
+// Zero only the border pixels of a halo plane Q[N][H+2hy][W+2hx][Cw] (the interior is written by a conv epilogue).
+// Border pixel b of an image: the first hy*Wp (top rows), then per interior row the 2*hx side pixels, then the bottom.
+__global__ __launch_bounds__(256) void zero_halo_kernel(uint32_t* __restrict__ Q, int64_t N, int H, int W, int Cw,
+                                                        int hy, int hx) {
+    const int Hp = H + 2 * hy, Wp = W + 2 * hx, cpp = Cw / 4;
+    const int top = hy * Wp, side = 2 * hx * H, per_img = 2 * top + side;
+    const int64_t total = N * per_img * cpp;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bp = t / cpp;
+        const int c = (int)(t - bp * cpp);
+        const int64_t n = bp / per_img;
+        const int b = (int)(bp - n * per_img);
+        int pix;
+        if (b < top) pix = b;
+        else if (b < top + side) {
+            const int s = b - top, r = s / (2 * hx), k = s - r * 2 * hx;
+            pix = (hy + r) * Wp + (k < hx ? k : W + k);
+        } else pix = (hy + H) * Wp + (b - top - side);
+        *reinterpret_cast<uint4*>(Q + (n * Hp * Wp + pix) * (int64_t)Cw + c * 4) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_zero_halo(uint32_t* Q, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t hy, int64_t hx,
+                            qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Cw <= 0 || hy < 0 || hx < 0) return QT_ERR_INVALID_ARG;
+    if (N == 0 || (hy == 0 && hx == 0)) return QT_OK;
+    if (!Q) return QT_ERR_INVALID_ARG;
+    if ((Cw & 3) || !qt_aligned16(Q)) return QT_ERR_ALIGNMENT;
+    if (H + 2 * hy > 32767 || W + 2 * hx > 32767 || Cw > (1 << 20)) return QT_ERR_UNSUPPORTED;
+    const int64_t total = N * (2 * hy * (W + 2 * hx) + 2 * hx * H) * (Cw / 4);
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(zero_halo_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Q, N, (int)H, (int)W, (int)Cw,
+                       (int)hy, (int)hx);
+    return qt_check_launch();
+}
 
 extern "C" int qt_pad_pixel_plane(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t ph,
                                   int64_t pw, uint32_t* Q, qt_stream_t stream) {

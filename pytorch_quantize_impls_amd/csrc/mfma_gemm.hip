@@ -151,6 +151,13 @@ struct EpiArgs {
     const int8_t* res_codes = nullptr; // [M][ldrc bytes] residual held as codes
     int64_t ldr = 0, ldrc = 0;
     int32_t* overflow = nullptr;
+    // halo planes: the code plane (and a residual code plane) may carry a zero border of (hy, hx) pixels around
+    // each image, [N][Ho + 2hy][Wo + 2hx][ld]: output row m = (img, ho, wo) lands on pixel
+    // (img, ho + hy, wo + hx) so the NEXT conv's zero padding is physical and it runs the un-padded kernels.  The caller
+    // zero-fills a halo plane (writing the border from the edge pixels' lanes was measured: +10 us per conv of the C4
+    // ResNet against 5 us for the fill — divergent short loops in an already VALU-heavy epilogue).
+    int ohy = 0, ohx = 0, rhy = 0, rhx = 0;
+    unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
 
 // ---- element types ----------------------------------------------------------------------------------
@@ -616,6 +623,25 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         float* T = reinterpret_cast<float*>(smem) + wave * 1024;
         const bool rwide = epi.res_f32 && ((epi.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(epi.res_f32) & 15) == 0);
         int bad = 0;
+        // plane rows of this lane's 4 x TMW output pixels (identity without halos)
+        const bool halo = (epi.ohy | epi.ohx | epi.rhy | epi.rhx) != 0;
+        int orow[C::TMW][4], rrow[C::TMW][4];
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + (wave_m * C::TMW + a) * 32 + i * 8 + (lane >> 3);
+                orow[a][i] = rrow[a][i] = m;
+                if (halo && m < M) {
+                    const unsigned um = (unsigned)m;
+                    const unsigned img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
+                    const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
+                    const unsigned ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
+                    const unsigned wo = rem - ho * (unsigned)cg.Wo;
+                    orow[a][i] = (int)((img * (unsigned)(cg.Ho + 2 * epi.ohy) + ho + epi.ohy) * (unsigned)(cg.Wo + 2 * epi.ohx) + wo + epi.ohx);
+                    rrow[a][i] = (int)((img * (unsigned)(cg.Ho + 2 * epi.rhy) + ho + epi.rhy) * (unsigned)(cg.Wo + 2 * epi.rhx) + wo + epi.rhx);
+                }
+            }
 #pragma unroll
         for (int b = 0; b < C::TNW; ++b) {
             const int nb = n0 + (wave_n * C::TNW + b) * 32;
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                         }
                         uint32_t rword = 0;
                         if (epi.res_codes && n < N)
-                            rword = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)m * epi.ldrc + n);
+                            rword = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)rrow[a][i] * epi.ldrc + n);
                         uint32_t word = 0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -675,13 +701,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             }
                             word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
                         }
-                        *reinterpret_cast<uint32_t*>(Q + (int64_t)m * ldy + n) = word;
+                        *reinterpret_cast<uint32_t*>(Q + (int64_t)orow[a][i] * ldy + n) = word;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 // pad bytes past the last column tile (row strides rounded beyond the tile width)
-                if (b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && mb + lane < M)
+                // (a halo plane is zero-filled by the caller: its border pixels belong to no tile)
+                if (!halo && b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && mb + lane < M)
                     for (int c = n0 + C::TN; c < ldy; c += 4)
                         *reinterpret_cast<uint32_t*>(Q + (int64_t)(mb + lane) * ldy + c) = 0u;
             }
@@ -1185,7 +1212,11 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                               int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
                               const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream,
-                              const EpiArgs& epi) {
+                              const EpiArgs& epi_in, int64_t hy = 0, int64_t hx = 0) {
+    // (hy, hx): halo of the INPUT plane, [N][H + 2hy][W + 2hx][Cw] with a zero border: a conv whose padding fits in
+    // the halo runs as the un-padded conv on the window that starts (hy - ph, hx - pw) into the plane.
+    EpiArgs epi = epi_in;
+    if (hy < 0 || hx < 0 || ((hy | hx) && (ph > hy || pw > hx))) return QT_ERR_INVALID_ARG;
     if (Nimg < 0 || H <= 0 || W <= 0 || Cw <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 ||
         dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 2)
         return QT_ERR_INVALID_ARG;
@@ -1197,9 +1228,17 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
-    if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || H > 32767 || W > 32767 ||
-        H * W * Cw * 4 >= (1ll << 31))   // per-image plane bytes: 32-bit tap offsets
+    const int64_t Hp = H + 2 * hy, Wp = W + 2 * hx;
+    if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || Hp > 32767 || Wp > 32767 ||
+        Hp * Wp * Cw * 4 >= (1ll << 31))   // per-image plane bytes: 32-bit tap offsets
         return QT_ERR_UNSUPPORTED;
+    if (epi.mode == 2 && (epi.ohy | epi.ohx | epi.rhy | epi.rhx)) {
+        if (Nimg * (Ho + 2 * epi.ohy) * (Wo + 2 * epi.ohx) > INT32_MAX || Nimg * (Ho + 2 * epi.rhy) * (Wo + 2 * epi.rhx) > INT32_MAX)
+            return QT_ERR_UNSUPPORTED;
+        const unsigned long long hw = (unsigned long long)(Ho * Wo), wo_ = (unsigned long long)Wo;
+        epi.magic_hw = hw > 1 ? ~0ull / hw + 1 : 0;     // ceil(2^64 / d) for d > 1 (exact quotients for 32-bit numerators)
+        epi.magic_w = wo_ > 1 ? ~0ull / wo_ + 1 : 0;
+    }
     const int64_t kbytes = kwords * 4;
     const int64_t K = elem == 0 ? kbytes * 2 : (elem == 1 ? kbytes : kbytes / 2);   // elements
     if (elem == 0 && K >= (1 << 24)) return QT_ERR_UNSUPPORTED;
@@ -1211,7 +1250,13 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     cg.magic_cpp = cg.cpp > 1 ? (unsigned)((1ull << 32) / (unsigned)cg.cpp + 1) : 0;
     cg.magic_kw = kw > 1 ? (unsigned)((1ull << 32) / (unsigned)kw + 1) : 0;
     // un-padded conv on a plane < 4 GiB: every tap of every window is in bounds -> 32-bit offsets, no checks
-    const bool valid = ph == 0 && pw == 0 && Nimg * H * W * Cw * 4 < (1ll << 32) && kwords * 4 <= 32768;
+    bool valid = ph == 0 && pw == 0 && Nimg * H * W * Cw * 4 < (1ll << 32) && kwords * 4 <= 32768;
+    if (hy | hx) {
+        valid = Nimg * Hp * Wp * Cw * 4 < (1ll << 32) && kwords * 4 <= 32768;
+        if (!valid) return QT_ERR_UNSUPPORTED;      // the caller strips the halo and uses the bounds-checked kernels
+        cg.H = (int)Hp; cg.W = (int)Wp; cg.ph = cg.pw = 0;
+        P += ((hy - ph) * Wp + (hx - pw)) * Cw;
+    }
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
@@ -1288,8 +1333,13 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
                              const float* scale_dev, const float* alpha, const float* beta, const float* res_f32,
                              int64_t ldr, const float* res_alpha, const float* res_beta, const int8_t* res_codes,
                              int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
-                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, qt_stream_t stream) {
+                             int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
+                             int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
+                             int64_t res_halo_w, qt_stream_t stream) {
     if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (out_halo_h < 0 || out_halo_w < 0 || res_halo_h < 0 || res_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64 ||
+        res_halo_h > 64 || res_halo_w > 64 || ((res_halo_h | res_halo_w) && !res_codes))
+        return QT_ERR_INVALID_ARG;
     if (elem != 1) return QT_ERR_UNSUPPORTED;   // the epilogue is instantiated for the int8 (DoReFa) configs
     if ((res_f32 && ldr < Cout) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;
     if ((ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
@@ -1309,8 +1359,22 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
     epi.ldrc = ldrc_bytes;
     epi.rscale = res_scale;
     epi.overflow = overflow;
+    epi.ohy = (int)out_halo_h;
+    epi.ohx = (int)out_halo_w;
+    epi.rhy = (int)res_halo_h;
+    epi.rhx = (int)res_halo_w;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
-                              scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi);
+                              scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi, in_halo_h,
+                              in_halo_w);
+}
+
+int qt_conv2d_implicit_halo(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                            int64_t halo_h, int64_t halo_w, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                            int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp,
+                            const float* bias, float scale, const float* scale_dev, float* Y, int64_t ldy,
+                            int64_t Cout, qt_stream_t stream) {
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, Y, ldy, Cout, stream, EpiArgs{}, halo_h, halo_w);
 }
 
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,

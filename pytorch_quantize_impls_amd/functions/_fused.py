@@ -353,10 +353,10 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
         if epi is not None and epi.overflow is None:
             epi.overflow = codes.overflow
         y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding, dilation,
-                              scale_dev=E, epi=epi)
+                              scale_dev=E, epi=epi, in_halo=input.halo)
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
         if epi is not None:
-            return packed.CodeActivation(y2, (N_, weight.shape[0], Ho, Wo))
+            return packed.CodeActivation(y2, (N_, weight.shape[0], Ho, Wo), halo=epi.out_halo)
         y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
         y._qt_overflow = codes.overflow          # the chain's range flag rides on to the next fused quantiser
         return y

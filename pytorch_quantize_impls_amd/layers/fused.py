@@ -84,11 +84,14 @@ class FusedBnDorefaQuant(torch.nn.Module):
     (oracle.affine_relu_dorefa_codes).  The quantiser is unclamped like the reference's, so codes may leave int8:
     the kernel raises a device flag shared along the chain and ``CodeActivation.check()/float()`` raises."""
 
-    def __init__(self, bn, bit_width: int, relu: bool = True):
+    def __init__(self, bn, bit_width: int, relu: bool = True, out_halo=0):
         super().__init__()
         if not 2 <= int(bit_width) <= 8:
             raise ValueError("code planes exist for 2 <= bit_width <= 8")
         self.bn, self.bit_width, self.relu = bn, int(bit_width), bool(relu)
+        # out_halo: zero border for the consuming conv's padding (see FusedDorefaConvBnQuant); made here by one
+        # qt_pad_pixel_plane pass over the code plane
+        self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
         self._folded = None
         self._folded_res = None
 
@@ -116,7 +119,7 @@ class FusedBnDorefaQuant(torch.nn.Module):
         if isinstance(residual, packed.CodeActivation):
             if residual.shape != tuple(x.shape):
                 raise ValueError(f"residual {residual.shape} vs input {tuple(x.shape)}")
-            res_codes = residual.codes
+            res_codes = residual.without_halo().codes
             flag = flag if flag is not None else residual.codes.overflow
         elif residual is not None:
             if tuple(residual.shape) != tuple(x.shape):
@@ -130,6 +133,13 @@ class FusedBnDorefaQuant(torch.nn.Module):
         codes, _ = ops.affine_dorefa_codes(x2, alpha, beta, self.bit_width, self.relu, res_f32, res_affine, res_codes,
                                            overflow=flag,
                                            ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None)
+        if x.dim() == 4 and any(self.out_halo):
+            N, C, H, W = x.shape
+            hy, hx = self.out_halo
+            codes = ops.CodePlanes(codes=ops.pad_pixel_plane(codes.codes, N, H, W, (hy, hx)),
+                                   rows=N * (H + 2 * hy) * (W + 2 * hx), K=codes.K, inv_n=codes.inv_n,
+                                   bit_width=codes.bit_width, overflow=codes.overflow)
+            return packed.CodeActivation(codes, x.shape, halo=self.out_halo)
         return packed.CodeActivation(codes, x.shape)
 
 
@@ -141,11 +151,14 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
 
     forward(act, residual=None, residual_bn=None): residual over the conv's OUTPUT pixels, as FusedBnDorefaQuant."""
 
-    def __init__(self, conv, bn, bit_width: int, relu: bool = True):
+    def __init__(self, conv, bn, bit_width: int, relu: bool = True, out_halo=0):
         super().__init__()
         if getattr(conv, "bit_width", None) != 1 or conv.groups != 1 or conv.padding_mode != "zeros":
             raise ValueError("FusedDorefaConvBnQuant takes an un-grouped, zero-padded DorefaConv2d(bit_width=1)")
         self.conv, self.bn, self.bit_width, self.relu = conv, bn, int(bit_width), bool(relu)
+        # out_halo = the padding of the conv(s) that consume this activation: the epilogue writes into a plane with
+        # that zero border, so they run the un-padded kernels (a residual CodeActivation may carry any halo)
+        self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
         self._folded = self._folded_res = None
 
     def refold(self):
@@ -159,9 +172,9 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
             raise TypeError("FusedDorefaConvBnQuant consumes a CodeActivation (FusedBnDorefaQuant output)")
         if self._folded is None:
             self._folded = fold_batchnorm(self.bn)
-        epi = ops.CodeEpilogue(self._folded[0], self._folded[1], self.bit_width, self.relu)
+        epi = ops.CodeEpilogue(self._folded[0], self._folded[1], self.bit_width, self.relu, out_halo=self.out_halo)
         if isinstance(residual, packed.CodeActivation):
-            epi.res_codes = residual.codes
+            epi.res_codes, epi.res_halo = residual.codes, residual.halo
         elif residual is not None:
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])

@@ -7,7 +7,8 @@ A CPU tensor is a programming error here (``TypeError``) — there is no fallbac
 """
 from __future__ import annotations
 
-import ctypes
+import contextlib
+import functools
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -25,6 +26,13 @@ IM2COL_MAX_BYTES = 1 << 30
 CONV_IMPLICIT = True
 
 
+@functools.lru_cache(maxsize=None)
+def inv_levels(bit_width: int) -> float:
+    """fl32(1 / (2^k - 1)) exactly as _quantize forms it (functions/dorefa_connect.py:24: a float32 division)."""
+    n = float((1 << int(bit_width)) - 1)
+    return float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+
+
 @dataclass
 class CodeEpilogue:
     """Arguments of the conv code epilogue (qt_conv2d_implicit_codes): folded BatchNorm (alpha, beta), optional
@@ -38,10 +46,12 @@ class CodeEpilogue:
     res_affine: Optional[tuple] = None
     res_codes: Optional["CodePlanes"] = None
     overflow: Optional[torch.Tensor] = None
+    out_halo: tuple = (0, 0)        # zero border (pixels) of the produced plane: [N][Ho + 2hy][Wo + 2hx][ld]
+    res_halo: tuple = (0, 0)        # halo of the residual code plane
 
 
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
-                   ldw_words: int, bias, scale: float, scale_dev, Cout: int, epi=None):
+                   ldw_words: int, bias, scale: float, scale_dev, Cout: int, epi=None, in_halo=(0, 0)):
     """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back).
     ``epi`` = (alpha, beta): threshold-bit epilogue (qt_conv2d_implicit_bits) — returns the BitPlanes of
     [(acc + bias) * alpha + beta < 0] per output pixel instead of the fp32 result."""
@@ -49,13 +59,17 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
     M = N * Ho * Wo
-    if (M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32
-            or H * W * Cw * 4 >= (1 << 31)):
+    hy, hx = (int(v) for v in in_halo)
+    Hp, Wp = H + 2 * hy, W + 2 * hx
+    if (M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or Hp > 32767 or Wp > 32767 or ldw_words % 32
+            or Hp * Wp * Cw * 4 >= (1 << 31)):
         return None
+    if (hy or hx) and (ph > hy or pw > hx or N * Hp * Wp * Cw * 4 >= (1 << 32) or kh * kw * Cw * 4 > 32768):
+        return None                      # the caller strips the halo
     dev = pixels_words.device
-    I = ctypes.c_int64
-    head = (ctypes.c_int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw),
-            I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias), ctypes.c_float(float(scale)),
+    I = int
+    head = (int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw),
+            I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias), float(float(scale)),
             _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None))
     if isinstance(epi, CodeEpilogue):
         alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
@@ -71,41 +85,73 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
                 ra, rb = _check_bias(epi.res_affine[0], Cout, dev), _check_bias(epi.res_affine[1], Cout, dev)
         elif epi.res_affine is not None:
             raise ValueError("res_affine needs res_f32")
+        ohy, ohx = (int(v) for v in epi.out_halo)
+        rhy, rhx = (int(v) for v in epi.res_halo)
+        Mo = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
         if epi.res_codes is not None:
-            if epi.res_codes.rows != M or epi.res_codes.K != Cout:
-                raise ValueError(f"residual codes must be a [{M}, {Cout}] plane")
+            if epi.res_codes.rows != N * (Ho + 2 * rhy) * (Wo + 2 * rhx) or epi.res_codes.K != Cout:
+                raise ValueError(f"residual codes must be a [{N}x{Ho + 2 * rhy}x{Wo + 2 * rhx}, {Cout}] plane")
             rc, ldrc, rscale = epi.res_codes.codes, int(epi.res_codes.codes.shape[1]), float(epi.res_codes.inv_n)
+        elif rhy or rhx:
+            raise ValueError("res_halo needs res_codes")
         ldc = code_ld_bytes(Cout, 16)
-        codes = torch.empty((M, ldc), dtype=torch.int8, device=dev)
+        codes = torch.empty((Mo, ldc), dtype=torch.int8, device=dev)
+        if ohy or ohx:      # only the border of a halo plane needs zeros (the next conv's padding); the conv writes the rest
+            with _on(dev):
+                _lib.call("qt_zero_halo", _p(codes), I(N), I(Ho), I(Wo), I(ldc // 4), I(ohy), I(ohx), _stream(dev))
         flag = epi.overflow if epi.overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("qt_conv2d_implicit_codes", *head, _p(alpha), _p(beta), _p(rf), I(ldr), _p(ra), _p(rb), _p(rc),
-                      I(ldrc), ctypes.c_float(rscale), ctypes.c_int(1 if epi.relu else 0),
-                      ctypes.c_int(int(epi.bit_width)), _p(codes), I(ldc), I(Cout), _p(flag), _stream(dev))
-        n = float((1 << int(epi.bit_width)) - 1)
-        inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
-        return CodePlanes(codes=codes, rows=M, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
+                      I(ldrc), float(rscale), int(1 if epi.relu else 0),
+                      int(int(epi.bit_width)), _p(codes), I(ldc), I(Cout), _p(flag), I(hy), I(hx), I(ohy),
+                      I(ohx), I(rhy), I(rhx), _stream(dev))
+        inv_n = inv_levels(epi.bit_width)
+        return CodePlanes(codes=codes, rows=Mo, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
+    if hy or hx:
+        if epi is not None:
+            raise ValueError("halo planes exist for int8 code planes (fp32 / code-epilogue outputs) only")
+        y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv2d_implicit_halo", int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(hy),
+                      I(hx), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw), I(dh), I(dw), *head[14:], _p(y), I(Cout), I(Cout),
+                      _stream(dev))
+        return y
     if epi is not None:
         alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi, ("alpha", "beta")))
         if alpha.numel() != Cout or beta.numel() != Cout:
             raise ValueError(f"alpha/beta must have {Cout} entries")
         ldb = packed_ld(Cout)
         plane = torch.empty((M, ldb), dtype=torch.int32, device=dev)   # the kernel writes every word incl. the pad
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("qt_conv2d_implicit_bits", *head, _p(alpha), _p(beta), _p(plane), I(ldb), I(Cout), _stream(dev))
         return BitPlanes(sign=plane, rows=M, K=Cout)
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("qt_conv2d_implicit", *head, _p(y), I(Cout), I(Cout), _stream(dev))
     return y
 
 
+# Argument marshalling: _lib declares argtypes for every entry point, so plain Python ints / floats / None convert in
+# ctypes' C path; building ctypes objects per argument cost more host time than the launch itself (the fused
+# ResNet-18 forward is ~40 launches of 20-40 arguments: tools/host_profile_c4.py).
 def _p(t: Optional[torch.Tensor]):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    return t.data_ptr() if t is not None else None
 
 
-def _stream(device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+_SAME_DEVICE = contextlib.nullcontext()
+
+
+def _on(device):
+    """Device guard for a launch: a no-op when ``device`` already is the current device (the usual one-process-per-GPU
+    case; torch.cuda.device() costs several microseconds per launch)."""
+    idx = device.index
+    return _SAME_DEVICE if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+
+def _stream(device) -> int:
+    """Raw hipStream_t of torch's current stream on ``device`` (what the kernels are enqueued on)."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch.cuda.current_device())
 
 
 def _require(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -158,8 +204,8 @@ class BitPlanes:
 def _unary(name: str, x: torch.Tensor, *extra) -> torch.Tensor:
     x = _require(x, "input").contiguous()
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
-        _lib.call(name, _p(x), _p(y), ctypes.c_int64(x.numel()), *extra, _stream(x.device))
+    with _on(x.device):
+        _lib.call(name, _p(x), _p(y), int(x.numel()), *extra, _stream(x.device))
     return y
 
 
@@ -175,18 +221,18 @@ def ternarize(x: torch.Tensor) -> torch.Tensor:
 
 def dorefa_quantize(x: torch.Tensor, bit_width: int) -> torch.Tensor:
     """_quantize (functions/dorefa_connect.py:11-25)."""
-    return _unary("qt_dorefa_quantize_f32", x, ctypes.c_int(int(bit_width)))
+    return _unary("qt_dorefa_quantize_f32", x, int(int(bit_width)))
 
 
 def lin_quantize(x: torch.Tensor, fsr: int, bit_width: int, mode: int = 1) -> torch.Tensor:
     """LinQuant forward (mode 0 unsigned / 1 with_sign) or its quantised-gradient backward (mode 2)
     (functions/log_lin_connect.py:61-79)."""
-    return _unary("qt_lin_quantize_f32", x, ctypes.c_int(int(fsr)), ctypes.c_int(int(bit_width)), ctypes.c_int(int(mode)))
+    return _unary("qt_lin_quantize_f32", x, int(int(fsr)), int(int(bit_width)), int(int(mode)))
 
 
 def log_quantize(x: torch.Tensor, fsr: int, bit_width: int, with_sign: bool = True) -> torch.Tensor:
     """LogQuant forward / quantised-gradient backward (functions/log_lin_connect.py:31-40)."""
-    return _unary("qt_log_quantize_f32", x, ctypes.c_int(int(fsr)), ctypes.c_int(int(bit_width)), ctypes.c_int(1 if with_sign else 0))
+    return _unary("qt_log_quantize_f32", x, int(int(fsr)), int(int(bit_width)), int(1 if with_sign else 0))
 
 
 def ap2(x: torch.Tensor) -> torch.Tensor:
@@ -200,8 +246,8 @@ def _binary(name: str, a: torch.Tensor, b: torch.Tensor, *extra) -> torch.Tensor
     if a.shape != b.shape:
         raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
     y = torch.empty_like(a)
-    with torch.cuda.device(a.device):
-        _lib.call(name, _p(a), _p(b), _p(y), ctypes.c_int64(a.numel()), *extra, _stream(a.device))
+    with _on(a.device):
+        _lib.call(name, _p(a), _p(b), _p(y), int(a.numel()), *extra, _stream(a.device))
     return y
 
 
@@ -217,7 +263,7 @@ def ternarize_stochastic(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
 
 def ste_mask(grad_out: torch.Tensor, x: torch.Tensor, thr: float = STE_THRESHOLD) -> torch.Tensor:
     """grad_out * 1[|x| <= thr] (binary_connect.py:31-38)."""
-    return _binary("qt_ste_mask_f32", grad_out, x, ctypes.c_float(thr))
+    return _binary("qt_ste_mask_f32", grad_out, x, float(thr))
 
 
 def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
@@ -230,9 +276,9 @@ def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
     C = w.numel() // max(R, 1)
     alpha = torch.empty((C,), dtype=torch.float32, device=w.device)
     wq = torch.empty_like(w)
-    with torch.cuda.device(w.device):
-        _lib.call("qt_xnor_weight_f32", _p(w), ctypes.c_int64(C), _p(alpha), _p(wq), ctypes.c_int64(C),
-                  ctypes.c_int64(R), ctypes.c_int64(C), _stream(w.device))
+    with _on(w.device):
+        _lib.call("qt_xnor_weight_f32", _p(w), int(C), _p(alpha), _p(wq), int(C),
+                  int(R), int(C), _stream(w.device))
     return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
 
 
@@ -260,10 +306,10 @@ def sign_pack(x: torch.Tensor, want_f32: bool = False) -> Tuple[BitPlanes, Optio
     ld = packed_ld(K)
     plane = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
     y = torch.empty((rows, K), dtype=torch.float32, device=x.device) if want_f32 else None
-    with torch.cuda.device(x.device):
-        _lib.call("qt_sign_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
-                  _p(plane), ctypes.c_int64(ld), _p(y), ctypes.c_int64(K), ctypes.c_int64(rows),
-                  ctypes.c_int64(K), _stream(x.device))
+    with _on(x.device):
+        _lib.call("qt_sign_pack_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(plane), int(ld), _p(y), int(K), int(rows),
+                  int(K), _stream(x.device))
     if y is not None:
         y = y.view(x.shape)
     return BitPlanes(sign=plane, rows=rows, K=K), y
@@ -277,9 +323,9 @@ def ternary_pack(x: torch.Tensor) -> BitPlanes:
     ld = packed_ld(K)
     mask = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
     sign = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call("qt_ternary_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
-                  _p(mask), _p(sign), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
+    with _on(x.device):
+        _lib.call("qt_ternary_pack_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(mask), _p(sign), int(ld), int(rows), int(K),
                   _stream(x.device))
     return BitPlanes(sign=sign, rows=rows, K=K, mask=mask)
 
@@ -306,10 +352,10 @@ def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tens
     plane = torch.empty((N * Ho * Wo, ld), dtype=torch.int32, device=x.device)
     alpha = _require(alpha, "alpha").contiguous()
     beta = _require(beta, "beta").contiguous()
-    I = ctypes.c_int64
-    with torch.cuda.device(x.device):
+    I = int
+    with _on(x.device):
         _lib.call("qt_pool_affine_sign_pack_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)),
-                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), ctypes.c_int(1 if pre_relu else 0),
+                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), int(1 if pre_relu else 0),
                   _stream(x.device))
     return BitPlanes(sign=plane, rows=N * Ho * Wo, K=C), (Ho, Wo)
 
@@ -322,8 +368,8 @@ def check_pm1(x: torch.Tensor, limit: Optional[int] = None) -> torch.Tensor:
         x = x.contiguous()
     n = x.numel() if limit is None else min(int(limit), x.numel())
     flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call("qt_check_pm1_f32", _p(x), ctypes.c_int64(n), _p(flag), _stream(x.device))
+    with _on(x.device):
+        _lib.call("qt_check_pm1_f32", _p(x), int(n), _p(flag), _stream(x.device))
     return flag
 
 
@@ -361,10 +407,10 @@ def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.call("qt_xnor_gemm", _p(x.sign), ctypes.c_int64(x.ld), _p(w.sign), ctypes.c_int64(w.ld),
-                  _p(bias), _p(out), ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)),
-                  ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_int64(K), _stream(dev))
+    with _on(dev):
+        _lib.call("qt_xnor_gemm", _p(x.sign), int(x.ld), _p(w.sign), int(w.ld),
+                  _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)),
+                  int(M), int(N), int(K), _stream(dev))
     return out
 
 
@@ -380,11 +426,11 @@ def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.call("qt_tern_gemm", _p(x.sign), ctypes.c_int64(x.ld), _p(w.mask), _p(w.sign),
-                  ctypes.c_int64(w.ld), _p(bias), _p(out),
-                  ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)),
-                  ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_int64(K), _stream(dev))
+    with _on(dev):
+        _lib.call("qt_tern_gemm", _p(x.sign), int(x.ld), _p(w.mask), _p(w.sign),
+                  int(w.ld), _p(bias), _p(out),
+                  int(out.stride(0) if M > 1 else max(N, 1)),
+                  int(M), int(N), int(K), _stream(dev))
     return out
 
 
@@ -422,9 +468,9 @@ def _nib_pack(entry: str, x: torch.Tensor, ld: Optional[int] = None) -> NibPlane
     rows, K = int(x2.shape[0]), int(x2.shape[1])
     ld = packed_ld_nib(K) if ld is None else int(ld)
     words = torch.empty((rows, ld), dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call(entry, _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)), _p(words),
-                  ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K), _stream(x.device))
+    with _on(x.device):
+        _lib.call(entry, _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)), _p(words),
+                  int(ld), int(rows), int(K), _stream(x.device))
     return NibPlanes(words=words, rows=rows, K=K)
 
 
@@ -446,8 +492,8 @@ def pool_bits(planes: BitPlanes, N: int, H: int, W: int, pool_k: int, pool_s: in
         raise ValueError("pooling window larger than the image")
     Ho, Wo = (H - pool_k) // pool_s + 1, (W - pool_k) // pool_s + 1
     out = torch.empty((N * Ho * Wo, planes.ld), dtype=torch.int32, device=planes.device)
-    I = ctypes.c_int64
-    with torch.cuda.device(planes.device):
+    I = int
+    with _on(planes.device):
         _lib.call("qt_pool_bits", _p(planes.sign), I(N), I(H), I(W), I(planes.ld), I(pool_k), I(pool_s),
                   _p(neg_alpha), _p(out), _stream(planes.device))
     return BitPlanes(sign=out, rows=N * Ho * Wo, K=planes.K), (Ho, Wo)
@@ -467,9 +513,9 @@ def bits_to_nib(planes: BitPlanes, ld: Optional[int] = None) -> NibPlanes:
     """Expand 1-bit planes (sign, or mask + sign) to the nibble plane the MFMA GEMM consumes."""
     ld = packed_ld_nib(planes.K) if ld is None else int(ld)
     words = torch.empty((planes.rows, ld), dtype=torch.int32, device=planes.device)
-    with torch.cuda.device(planes.device):
-        _lib.call("qt_bits_to_nib", _p(planes.sign), _p(planes.mask), ctypes.c_int64(planes.ld),
-                  _p(words), ctypes.c_int64(ld), ctypes.c_int64(planes.rows), ctypes.c_int64(planes.K),
+    with _on(planes.device):
+        _lib.call("qt_bits_to_nib", _p(planes.sign), _p(planes.mask), int(planes.ld),
+                  _p(words), int(ld), int(planes.rows), int(planes.K),
                   _stream(planes.device))
     return NibPlanes(words=words, rows=planes.rows, K=planes.K)
 
@@ -483,8 +529,8 @@ def bits_to_nib_pad(planes: BitPlanes, N: int, H: int, W: int, padding, ld: Opti
     ld = packed_ld_nib(planes.K) if ld is None else int(ld)
     rows = N * (H + 2 * ph) * (W + 2 * pw)
     words = torch.empty((rows, ld), dtype=torch.int32, device=planes.device)
-    I = ctypes.c_int64
-    with torch.cuda.device(planes.device):
+    I = int
+    with _on(planes.device):
         _lib.call("qt_bits_to_nib_pad", _p(planes.sign), _p(planes.mask), I(planes.ld), _p(words), I(ld), I(N), I(H),
                   I(W), I(ph), I(pw), I(planes.K), _stream(planes.device))
     return NibPlanes(words=words, rows=rows, K=planes.K)
@@ -501,14 +547,14 @@ def nib_gemm(x: NibPlanes, w: NibPlanes, bias: Optional[torch.Tensor] = None,
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    args = (_p(x.words), ctypes.c_int64(x.ld), _p(w.words), ctypes.c_int64(w.ld), _p(bias), _p(out),
-            ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M), ctypes.c_int64(N),
-            ctypes.c_int64(K), _stream(dev))
-    with torch.cuda.device(dev):
+    args = (_p(x.words), int(x.ld), _p(w.words), int(w.ld), _p(bias), _p(out),
+            int(out.stride(0) if M > 1 else max(N, 1)), int(M), int(N),
+            int(K), _stream(dev))
+    with _on(dev):
         if variant is None:
             _lib.call("qt_nib_gemm", *args)
         else:
-            _lib.call("qt_nib_gemm_variant", ctypes.c_int(int(variant)), *args)
+            _lib.call("qt_nib_gemm_variant", int(int(variant)), *args)
     return out
 
 
@@ -571,12 +617,11 @@ def dorefa_codes(x: torch.Tensor, bit_width: int, want_f32: bool = True, ld_byte
     codes = torch.empty((rows, ld), dtype=torch.int8, device=x.device)
     y = torch.empty((rows, K), dtype=torch.float32, device=x.device) if want_f32 else None
     flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call("qt_dorefa_codes_i8", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
-                  _p(codes), ctypes.c_int64(ld), _p(y), ctypes.c_int64(K), ctypes.c_int64(rows),
-                  ctypes.c_int64(K), ctypes.c_int(int(bit_width)), _p(flag), _stream(x.device))
-    n = float((1 << int(bit_width)) - 1)
-    inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+    with _on(x.device):
+        _lib.call("qt_dorefa_codes_i8", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(codes), int(ld), _p(y), int(K), int(rows),
+                  int(K), int(int(bit_width)), _p(flag), _stream(x.device))
+    inv_n = inv_levels(bit_width)
     if y is not None:
         y = y.view(x.shape)
     return CodePlanes(codes=codes, rows=rows, K=K, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
@@ -618,14 +663,13 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
     codes = torch.empty((rows, ld), dtype=torch.int8, device=dev)
     y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_f32 else None
     flag = overflow if overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
-    I = ctypes.c_int64
-    with torch.cuda.device(dev):
+    I = int
+    with _on(dev):
         _lib.call("qt_affine_dorefa_codes_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
                   _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
-                  ctypes.c_float(rscale), ctypes.c_int(1 if relu else 0), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
-                  ctypes.c_int(int(bit_width)), _p(flag), _stream(dev))
-    n = float((1 << int(bit_width)) - 1)
-    inv_n = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
+                  float(rscale), int(1 if relu else 0), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
+                  int(int(bit_width)), _p(flag), _stream(dev))
+    inv_n = inv_levels(bit_width)
     return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
 
 
@@ -636,10 +680,10 @@ def weight_codes(w2d: torch.Tensor, ternary: bool = False, ld_bytes: Optional[in
     rows, K = int(w2.shape[0]), int(w2.shape[1])
     ld = code_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
     codes = torch.empty((rows, ld), dtype=torch.int8, device=w2d.device)
-    with torch.cuda.device(w2d.device):
-        _lib.call("qt_weight_codes_i8", _p(w2), ctypes.c_int64(w2.stride(0) if rows > 1 else max(K, 1)),
-                  _p(codes), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
-                  ctypes.c_int(1 if ternary else 0), _stream(w2d.device))
+    with _on(w2d.device):
+        _lib.call("qt_weight_codes_i8", _p(w2), int(w2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(codes), int(ld), int(rows), int(K),
+                  int(1 if ternary else 0), _stream(w2d.device))
     return CodePlanes(codes=codes, rows=rows, K=K)
 
 
@@ -684,13 +728,13 @@ def i8_gemm(x: CodePlanes, w: CodePlanes, scale: float, bias: Optional[torch.Ten
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.call("qt_i8_gemm", _p(x.codes), ctypes.c_int64(x.ld_words), _p(w.codes), ctypes.c_int64(w.ld_words),
-                  _p(bias), ctypes.c_float(float(scale)),
+    with _on(dev):
+        _lib.call("qt_i8_gemm", _p(x.codes), int(x.ld_words), _p(w.codes), int(w.ld_words),
+                  _p(bias), float(float(scale)),
                   _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None),
-                  ctypes.c_int64(int(max_abs_code)), _p(out),
-                  ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M), ctypes.c_int64(N),
-                  ctypes.c_int64(K), _stream(dev))
+                  int(int(max_abs_code)), _p(out),
+                  int(out.stride(0) if M > 1 else max(N, 1)), int(M), int(N),
+                  int(K), _stream(dev))
     return out
 
 
@@ -713,7 +757,8 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
 
 
 def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, scale: float, bias=None,
-                 stride=1, padding=0, dilation=1, scale_dev=None, max_abs_code: int = 127, epi=None):
+                 stride=1, padding=0, dilation=1, scale_dev=None, max_abs_code: int = 127, epi=None,
+                 in_halo=(0, 0)):
     """DoReFa conv2d on int8 code planes: NHWC pixel codes -> packed-domain im2col (zero bytes for
     padding taps = the reference's zero padding, code 0 <-> value 0) -> int8 MFMA GEMM.
     Returns the NHWC result [N*Ho*Wo, Cout]; with ``epi`` (a CodeEpilogue) the CodePlanes of the fused
@@ -723,14 +768,27 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
     Cw = pixels.ld_words
-    if pixels.rows != N * H * W or int(pixels.codes.shape[0]) < N * H * W:
-        raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
+    hy, hx = (int(v) for v in in_halo)
+    npix = N * (H + 2 * hy) * (W + 2 * hx)
+    if pixels.rows != npix or int(pixels.codes.shape[0]) < npix:
+        raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} (halo {(hy, hx)}) needs {npix}")
     if wplanes.K != kh * kw * Cw * 4:
         raise ValueError("weight codes do not match the activation's channel packing")
     Cout, ldA = wplanes.rows, wplanes.ld_words
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
+    if hy or hx:
+        y = None
+        if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
+            y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
+                               ldA, bias, scale, scale_dev, Cout, epi=epi, in_halo=(hy, hx))
+        if y is not None:
+            return y
+        # padding larger than the halo / plane beyond the un-padded kernels' limits: drop the halo (one copy)
+        inner = pixels.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W].contiguous()
+        pixels = CodePlanes(codes=inner.view(N * H * W, -1), rows=N * H * W, K=pixels.K, inv_n=pixels.inv_n,
+                            bit_width=pixels.bit_width, overflow=pixels.overflow)
     if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
         pc_, H_, W_, pad_ = pixels.codes, H, W, (ph, pw)
         if PAD_PIXEL_PLANES and (ph or pw):
@@ -744,10 +802,10 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 4), dtype=torch.int8, device=dev)
-    I = ctypes.c_int64
+    I = int
     for m0 in range(0, M, rows_per_chunk):
         cnt = min(rows_per_chunk, M - m0)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("qt_im2col_words", _p(pixels.codes), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh),
                       I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
         i8_gemm(CodePlanes(codes=A[:cnt], rows=cnt, K=wplanes.K), wplanes, scale, bias, out=y[m0:m0 + cnt],
@@ -816,8 +874,8 @@ def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> tor
     ph, pw = _pairs(padding)
     ld = int(words.shape[1]) * words.element_size() // 4          # row stride in 32-bit words
     out = torch.empty((N * (H + 2 * ph) * (W + 2 * pw), words.shape[1]), dtype=words.dtype, device=words.device)
-    I = ctypes.c_int64
-    with torch.cuda.device(words.device):
+    I = int
+    with _on(words.device):
         _lib.call("qt_pad_pixel_plane", _p(words), I(N), I(H), I(W), I(ld), I(ph), I(pw), _p(out), _stream(words.device))
     return out
 
@@ -853,10 +911,10 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA), dtype=torch.int32, device=dev)
-    I = ctypes.c_int64
+    I = int
     for m0 in range(0, M, rows_per_chunk):
         cnt = min(rows_per_chunk, M - m0)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("qt_im2col_words", _p(pixels.words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh),
                       I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
         nib_gemm(NibPlanes(words=A[:cnt], rows=cnt, K=wplanes.K), wplanes, bias, out=y[m0:m0 + cnt])
@@ -902,10 +960,10 @@ def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_b
         alpha = _require(alpha, "alpha").contiguous().view(-1)
         if alpha.numel() != K:
             raise ValueError("alpha must have one entry per input feature")
-    with torch.cuda.device(x.device):
-        _lib.call("qt_bf16x3_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)),
-                  _p(alpha), _p(out), ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K),
-                  ctypes.c_int(mode), _stream(x.device))
+    with _on(x.device):
+        _lib.call("qt_bf16x3_pack_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)),
+                  _p(alpha), _p(out), int(ld), int(rows), int(K),
+                  int(mode), _stream(x.device))
     return TriplePlanes(data=out, rows=rows, K=K)
 
 
@@ -928,10 +986,10 @@ def bf16_gemm(x: TriplePlanes, w: TriplePlanes, bias: Optional[torch.Tensor] = N
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.call("qt_bf16_gemm", _p(x.data), ctypes.c_int64(x.ld_words), _p(w.data), ctypes.c_int64(w.ld_words),
-                  _p(bias), _p(out), ctypes.c_int64(out.stride(0) if M > 1 else max(N, 1)), ctypes.c_int64(M),
-                  ctypes.c_int64(N), ctypes.c_int64(3 * x.K), _stream(dev))
+    with _on(dev):
+        _lib.call("qt_bf16_gemm", _p(x.data), int(x.ld_words), _p(w.data), int(w.ld_words),
+                  _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)), int(M),
+                  int(N), int(3 * x.K), _stream(dev))
     return out
 
 
@@ -950,9 +1008,9 @@ def split_bf16x6(x: torch.Tensor, role: int, ld_bytes: Optional[int] = None) -> 
     rows, K = int(x2.shape[0]), int(x2.shape[1])
     ld = sext_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
     out = torch.empty((rows, ld // 2), dtype=torch.int16, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.call("qt_bf16x6_pack_f32", _p(x2), ctypes.c_int64(x2.stride(0) if rows > 1 else max(K, 1)), _p(out),
-                  ctypes.c_int64(ld), ctypes.c_int64(rows), ctypes.c_int64(K), ctypes.c_int(int(role)), _stream(x.device))
+    with _on(x.device):
+        _lib.call("qt_bf16x6_pack_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)), _p(out),
+                  int(ld), int(rows), int(K), int(int(role)), _stream(x.device))
     return TriplePlanes(data=out, rows=rows, K=2 * K)
 
 
@@ -1038,9 +1096,9 @@ def s2d_triple_pack(x: torch.Tensor, s: int, padding) -> Tuple[TriplePlanes, Tup
     E = C * s * s
     ld = triple_ld_bytes(E, 16)
     out = torch.empty((N * Hs * Ws, ld // 2), dtype=torch.int16, device=x.device)
-    I = ctypes.c_int64
+    I = int
     sN, sC, sH, sW = (int(v) for v in x.stride())
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.call("qt_bf16x3_s2d_pack_f32", _p(x), I(sN), I(sC), I(sH), I(sW), _p(out), I(ld), I(N), I(C), I(H),
                   I(W), I(int(s)), I(ph), I(pw), _stream(x.device))
     return TriplePlanes(data=out, rows=N * Hs * Ws, K=E), (Hs, Ws)
@@ -1086,11 +1144,11 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     rows_per_chunk = max(1, min(M, IM2COL_MAX_BYTES // (ldA * 4)))
     A = torch.empty((rows_per_chunk, ldA * 2), dtype=torch.int16, device=dev)
-    I = ctypes.c_int64
+    I = int
     kel = kh * kw * Cb // 2     # bf16 elements per im2col row actually carrying taps
     for m0 in range(0, M, rows_per_chunk):
         cnt = min(rows_per_chunk, M - m0)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("qt_im2col_words", _p(px.data), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw),
                       I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
             _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
@@ -1186,11 +1244,11 @@ def pack_linear_operands(x: torch.Tensor, w: torch.Tensor, kind: str = "binary",
     ld = packed_ld_nib(K)
     xn = torch.empty((M, ld), dtype=torch.int32, device=x.device)
     wn = torch.empty((N, ld), dtype=torch.int32, device=x.device)
-    I = ctypes.c_int64
-    with torch.cuda.device(x.device):
+    I = int
+    with _on(x.device):
         _lib.call("qt_pack_pair_nib_f32", _p(x2), I(x2.stride(0) if M > 1 else max(K, 1)), _p(xn), I(ld), I(M),
                   _p(w2), I(w2.stride(0) if N > 1 else max(K, 1)), _p(wn), I(ld), I(N), I(K),
-                  ctypes.c_int(0 if kind == "binary" else 1), _stream(x.device))
+                  int(0 if kind == "binary" else 1), _stream(x.device))
     return NibPlanes(words=xn, rows=M, K=K), NibPlanes(words=wn, rows=N, K=K)
 
 

@@ -103,9 +103,19 @@ class CodeActivation:
     dtype = torch.float32
     requires_grad = False
 
-    def __init__(self, codes, shape):
+    def __init__(self, codes, shape, halo=(0, 0)):
         self.codes = codes
         self.shape = tuple(int(v) for v in shape)
+        # (hy, hx): the NHWC plane carries a zero border of that many pixels around every image,
+        # rows = N*(H + 2hy)*(W + 2hx): the next conv's zero padding is then physical (un-padded kernels)
+        self.halo = tuple(int(v) for v in halo)
+        if any(self.halo) and len(self.shape) != 4:
+            raise ValueError("only (N, C, H, W) activations carry a halo")
+        if len(self.shape) == 4:
+            N, C, H, W = self.shape
+            want = N * (H + 2 * self.halo[0]) * (W + 2 * self.halo[1])
+            if codes.rows != want:
+                raise ValueError(f"code plane holds {codes.rows} pixels, shape {self.shape} with halo {self.halo} needs {want}")
 
     @property
     def device(self):
@@ -116,6 +126,18 @@ class CodeActivation:
 
     def size(self, i=None):
         return self.shape if i is None else self.shape[i]
+
+    def without_halo(self) -> "CodeActivation":
+        """The same activation as a plain [N*H*W, ld] plane (one copy; identity without a halo)."""
+        if not any(self.halo):
+            return self
+        from . import ops
+        N, C, H, W = self.shape
+        hy, hx = self.halo
+        inner = self.codes.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W].contiguous()
+        planes = ops.CodePlanes(codes=inner.view(N * H * W, -1), rows=N * H * W, K=self.codes.K, inv_n=self.codes.inv_n,
+                                bit_width=self.codes.bit_width, overflow=self.codes.overflow)
+        return CodeActivation(planes, self.shape)
 
     def check(self):
         from . import ops
@@ -128,8 +150,9 @@ class CodeActivation:
         """The fp32 image nnDorefaQuant would have returned, fl(fl(1/n) * q); (N, C, H, W) comes back channels_last."""
         self.check()
         C = self.codes.K
-        y = self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n
         if len(self.shape) == 4:
             N, C_, H, W = self.shape
-            return y.view(N, H, W, C_).permute(0, 3, 1, 2)
-        return y.view(self.shape)
+            hy, hx = self.halo
+            q = self.codes.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W, :C]
+            return (q.to(torch.float32) * self.codes.inv_n).permute(0, 3, 1, 2)
+        return (self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n).view(self.shape)

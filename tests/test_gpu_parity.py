@@ -1326,6 +1326,64 @@ def test_conv_code_epilogue_equals_conv_then_fused_quantiser(dev, oracle, Cin, C
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,ksz,st,pd,in_halo,out_halo,res_halo", [
+    (64, 64, 3, 1, 1, (1, 1), (1, 1), (1, 1)), (32, 100, 3, 2, 1, (1, 1), (1, 1), None),
+    (16, 48, 1, 2, 0, (1, 1), (0, 0), (2, 1)), (64, 130, 3, 1, (1, 0), (2, 1), (1, 2), (0, 0)),
+    (128, 64, 5, 1, 2, (2, 2), (3, 0), None), (32, 32, 3, 1, 2, (1, 1), (1, 1), (1, 1))])
+def test_halo_planes_equal_plain_planes(dev, Cin, Cout, ksz, st, pd, in_halo, out_halo, res_halo):
+    """Code planes with a physical zero border (CodeActivation.halo): a conv reading one (fp32 output and code
+    epilogue), the epilogue writing one and a residual held in one give exactly the plain-plane results; a padding
+    larger than the halo falls back to the stripped plane."""
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedDorefaConvBnQuant
+    N, H, W = 3, 10, 7
+    torch.manual_seed(11)
+    conv = DorefaConv2d(Cin, Cout, ksz, stride=st, padding=pd, bias=True, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 4); bn.weight.data.normal_(); bn.bias.data.normal_()
+    bn.eval()
+    x_codes, _ = ops.dorefa_codes(torch.rand((N * H * W, Cin), device=dev), 4, want_f32=False,
+                                  ld_bytes=ops.code_ld_bytes(Cin, 16))
+    plain = packed.CodeActivation(x_codes, (N, Cin, H, W))
+
+    def with_halo(act, halo):
+        Nn, C, Hh, Ww = act.shape
+        q = ops.pad_pixel_plane(act.codes.codes, Nn, Hh, Ww, halo)
+        cp = ops.CodePlanes(codes=q, rows=q.shape[0], K=act.codes.K, inv_n=act.codes.inv_n,
+                            bit_width=act.codes.bit_width, overflow=act.codes.overflow)
+        return packed.CodeActivation(cp, act.shape, halo=halo)
+
+    haloed = with_halo(plain, in_halo)
+    assert torch.equal(haloed.without_halo().codes.codes, plain.codes.codes)
+    assert torch.equal(haloed.float(), plain.float())
+    Ho, Wo = ops.conv_out_hw(H, W, ksz, ksz, st, pd, 1)
+    res_plain = res_h = None
+    if res_halo is not None:
+        r_codes, _ = ops.dorefa_codes(torch.rand((N * Ho * Wo, Cout), device=dev) * 2, 4, want_f32=False,
+                                      ld_bytes=ops.code_ld_bytes(Cout, 16))
+        res_plain = packed.CodeActivation(r_codes, (N, Cout, Ho, Wo))
+        res_h = with_halo(res_plain, res_halo) if any(res_halo) else res_plain
+    with torch.no_grad():
+        before = dict(_lib.call_counts)
+        y_h = conv(haloed)
+        used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+        assert torch.equal(y_h, conv(plain))
+        fits = all(p_ <= h_ for p_, h_ in zip((pd, pd) if isinstance(pd, int) else pd, in_halo))
+        assert ("qt_conv2d_implicit_halo" in used) == fits, used
+        want = FusedDorefaConvBnQuant(conv, bn, 4)(plain, residual=res_plain)
+        # the output plane comes from torch.empty: poison the block the caching allocator will hand out, so a border
+        # byte the kernel failed to write shows up
+        junk = torch.full((N * (Ho + 2 * out_halo[0]) * (Wo + 2 * out_halo[1]), ops.code_ld_bytes(Cout, 16)), 85,
+                          dtype=torch.int8, device=dev)
+        del junk
+        got = FusedDorefaConvBnQuant(conv, bn, 4, out_halo=out_halo)(haloed, residual=res_h)
+    assert got.halo == tuple(out_halo) and got.shape == want.shape
+    assert torch.equal(got.without_halo().codes.codes, want.codes.codes)
+    if any(out_halo):       # the border really is zero
+        full = got.codes.codes.view(N, Ho + 2 * out_halo[0], Wo + 2 * out_halo[1], -1)
+        assert int(full.abs().sum()) == int(want.codes.codes.abs().sum())
+
+
+@pytest.mark.gpu
 def test_fuzz_conv_code_epilogue_vs_oracle(dev, oracle):
     """Random DorefaConv2d geometries through the code epilogue: against the two-step HIP path (bit-identical) and
     against the oracle's conv + chain on the same codes.  The oracle's fp32 conv sums in another order than the
@@ -1423,9 +1481,11 @@ def test_fused_dorefa_resnet_matches_module_graph(dev):
     assert used.get("qt_affine_dorefa_codes_i8") == 17 and used.get("qt_conv2d_implicit", 0) >= 19, used
     assert "qt_dorefa_codes_i8" not in used
     # conv-epilogue form: 16 code-epilogue convs, 3 fp32 shortcut convs, only the stem quantiser as its own pass
-    assert used_c.get("qt_conv2d_implicit_codes") == 16 and used_c.get("qt_conv2d_implicit") == 3, used_c
+    assert used_c.get("qt_conv2d_implicit_codes") == 16 and used_c.get("qt_conv2d_implicit_halo") == 3, used_c
     assert used_c.get("qt_affine_dorefa_codes_i8") == 1
     assert torch.equal(got_c, got)
+    with torch.no_grad():
+        assert torch.equal(bench_models.FusedDorefaResNet18(m, fuse_conv=True, halo=0)(x), got)
     flips = (a0.float() != ref0).float().mean().item()
     assert flips < 1e-3, flips
     scale = want.abs().max().item()
