@@ -212,7 +212,9 @@ int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_b
  *   t = fl(fl(x*alpha[c]) + beta[c])                       eval BatchNorm folded to per-channel (alpha, beta)
  *   t += fl(fl(r*res_alpha[c]) + res_beta[c])              res_f32 != NULL (res_alpha/res_beta NULL: t += r)
  *   t += fl(res_scale * code)                              res_codes != NULL (identity shortcut held as codes)
- *   t = max(t, 0) if relu ; q = rint((2^k-1) * t)          functions/dorefa_connect.py:24-25, unclamped
+ *   t = max(t, 0) if relu == 1 ; q = rint((2^k-1) * t)     functions/dorefa_connect.py:24-25, unclamped
+ * relu == 2: ReLU BEFORE the BatchNorm instead (x = max(x, 0) first: the Linear -> ReLU -> BatchNorm -> quant order of
+ * models/FullNet/DorefaMNIST.py:46-48), no ReLU after.
  * codes <- q as int8 (pad bytes of the 16-byte rows zero), y_f32 (may be NULL) <- fl(fl(1/(2^k-1)) * q).
  * *overflow is OR-ed with 1 if any |q| > 127 or NaN (code written as 0), as qt_dorefa_codes_i8. */
 int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
@@ -220,6 +222,14 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
                               const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
                               int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
                               int32_t* overflow, qt_stream_t stream);
+
+/* MaxPool2d(pool_k, pool_s) (no padding, floor mode) on an NHWC int8 DoReFa code plane: the reference pools after the
+ * quantiser (models/samples/AlexNet_Dorefa.py:38-41) and fl(inv_n * code) is monotone in the code, so the max over
+ * the codes is bit-identical to pooling the fp32 image and re-deriving the codes.
+ * in [N][H][W][ld_bytes] -> out [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ld_bytes], interior pixels only (zero the
+ * border of a halo plane with qt_zero_halo).  ld_bytes % 16 == 0. */
+int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld_bytes, int64_t pool_k,
+                     int64_t pool_s, int8_t* out_plane, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
 
 /* Weight codes: ternary == 0: safeSign(w) as +1/-1 ; ternary != 0: TernaryConnect codes {-1,0,+1}. */
 int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,

@@ -114,6 +114,8 @@ def affine_relu_dorefa_codes(x, alpha, beta, k, relu=True, res=None, res_affine=
     (models/samples/ResNet_Dorefa.py:26,35 ; functions/dorefa_connect.py:11-25) in fp32 steps.
     Returns (integer codes rint(n*t) as float32, fp32 image = dorefa_quantize(t, k))."""
     x = np.asarray(x, dtype=np.float32)
+    if relu == "pre":                       # ReLU in front of the BatchNorm (models/FullNet/DorefaMNIST.py:46-48)
+        x = np.where(x < 0, np.float32(0), x).astype(np.float32)
     shp = [1] * x.ndim
     shp[1] = -1
     a, b = (np.asarray(v, dtype=np.float32).reshape(shp) for v in (alpha, beta))
@@ -124,7 +126,7 @@ def affine_relu_dorefa_codes(x, alpha, beta, k, relu=True, res=None, res_affine=
             ra, rb = (np.asarray(v, dtype=np.float32).reshape(shp) for v in res_affine)
             u = (u * ra).astype(np.float32) + rb
         t = (t + u).astype(np.float32)
-    if relu:
+    if relu and relu != "pre":
         t = np.where(t < 0, np.float32(0), t).astype(np.float32)
     n = np.float32((1 << int(k)) - 1)
     return np.rint((n * t).astype(np.float32)).astype(np.float32), dorefa_quantize(t, k)

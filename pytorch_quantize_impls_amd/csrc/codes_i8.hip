@@ -104,14 +104,15 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
         for (int e = 0; e < 4; ++e) {
             int q = 0;
             if (k0 + e < C) {
-                float t = __fadd_rn(__fmul_rn(v[e], alpha[k0 + e]), beta[k0 + e]);
+                const float x0 = (relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];          // ReLU in front of the BatchNorm
+                float t = __fadd_rn(__fmul_rn(x0, alpha[k0 + e]), beta[k0 + e]);
                 if (rf) {
                     float u = r[e];
                     if (ralpha) u = __fadd_rn(__fmul_rn(u, ralpha[k0 + e]), rbeta[k0 + e]);
                     t = __fadd_rn(t, u);
                 }
                 if (rc) t = __fadd_rn(t, __fmul_rn(rscale, (float)(int8_t)(rword >> (8 * e))));
-                if (relu) t = t < 0.0f ? 0.0f : t;                  // NaN stays NaN (flagged below)
+                if (relu == 1) t = t < 0.0f ? 0.0f : t;             // NaN stays NaN (flagged below)
                 const float q_ = rintf(__fmul_rn(n, t));
                 q4[e] = q_;
                 if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad = 1; q = 0; } else q = (int)q_;
@@ -137,7 +138,7 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
                               const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
                               int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
                               int32_t* overflow, qt_stream_t stream) {
-    if (rows < 0 || C < 0 || ldx < C || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (rows < 0 || C < 0 || ldx < C || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (rows == 0) return QT_OK;
     if (!codes || !overflow || !alpha || !beta || (!x && C > 0) || (y_f32 && ldy < C)) return QT_ERR_INVALID_ARG;
     if ((res_f32 && ldr < C) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;

@@ -97,7 +97,58 @@ __global__ __launch_bounds__(256) void pool_bits_kernel(const uint32_t* __restri
     }
 }
 
+// MaxPool2d(k, s) on an int8 DoReFa code plane (the reference pools AFTER the quantiser,
+// models/samples/AlexNet_Dorefa.py:38-41: x = quant(relu(bn(conv))); x = pool(x)).  value = fl(inv_n * code) is
+// monotone in the code, so the max of the codes IS the code of the max: bit-identical to pooling the fp32 image.
+// in [N][H][W][ld bytes] -> out [N][Ho + 2hy][Wo + 2hx][ld] (interior only; the caller zeroes a halo border).
+// One thread = 4 channels (one dword) of one output pixel.
+__global__ __launch_bounds__(256) void pool_codes_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                         int64_t ldw, int64_t N, int H, int W, int pk, int ps, int Ho,
+                                                         int Wo, int hy, int hx) {
+    const int64_t total = N * Ho * Wo * ldw;
+    const int Hop = Ho + 2 * hy, Wop = Wo + 2 * hx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / ldw;
+        const int w = (int)(i - pix * ldw);
+        const int64_t n = pix / ((int64_t)Ho * Wo);
+        const int rem = (int)(pix - n * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ldw + w;
+        int m0 = -128, m1 = -128, m2 = -128, m3 = -128;
+        for (int a = 0; a < pk; ++a)
+            for (int b = 0; b < pk; ++b) {
+                const uint32_t v = base[((int64_t)a * W + b) * ldw];
+                m0 = max(m0, (int)(int8_t)v);
+                m1 = max(m1, (int)(int8_t)(v >> 8));
+                m2 = max(m2, (int)(int8_t)(v >> 16));
+                m3 = max(m3, (int)(int8_t)(v >> 24));
+            }
+        out[((n * Hop + ho + hy) * Wop + wo + hx) * ldw + w] =
+            (uint32_t)(uint8_t)m0 | ((uint32_t)(uint8_t)m1 << 8) | ((uint32_t)(uint8_t)m2 << 16) | ((uint32_t)(uint8_t)m3 << 24);
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld_bytes,
+                                int64_t pool_k, int64_t pool_s, int8_t* out_plane, int64_t out_halo_h,
+                                int64_t out_halo_w, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || ld_bytes <= 0 || pool_k < 1 || pool_s < 1 || out_halo_h < 0 || out_halo_w < 0)
+        return QT_ERR_INVALID_ARG;
+    if (pool_k > H || pool_k > W) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!in_plane || !out_plane) return QT_ERR_INVALID_ARG;
+    if ((ld_bytes & 15) || !qt_aligned16(in_plane) || !qt_aligned16(out_plane)) return QT_ERR_ALIGNMENT;
+    if (H > 32767 || W > 32767 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_UNSUPPORTED;
+    const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;  // floor mode, no padding
+    const int64_t ldw = ld_bytes / 4;
+    const int grid = qt_stream_grid((N * Ho * Wo * ldw + 255) / 256);
+    hipLaunchKernelGGL(pool_codes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t*>(in_plane), reinterpret_cast<uint32_t*>(out_plane), ldw, N,
+                       (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo, (int)out_halo_h, (int)out_halo_w);
+    return qt_check_launch();
+}
 
 extern "C" int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld,
                             int64_t pool_k, int64_t pool_s, const uint32_t* neg_alpha, uint32_t* out_plane,

@@ -692,10 +692,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                         for (int e = 0; e < 4; ++e) {
                             int q = 0;
                             if (n + e < N) {
-                                float t = v[e] * al[e] + be[e];          // two roundings (-ffp-contract=off)
+                                const float x0 = (epi.relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];   // ReLU before the BatchNorm
+                                float t = x0 * al[e] + be[e];            // two roundings (-ffp-contract=off)
                                 if (epi.res_f32) t = t + (epi.ralpha ? u[e] * ral[e] + rbe[e] : u[e]);
                                 if (epi.res_codes) t = t + epi.rscale * (float)(int8_t)(rword >> (8 * e));
-                                if (epi.relu) t = t < 0.0f ? 0.0f : t;
+                                if (epi.relu == 1) t = t < 0.0f ? 0.0f : t;
                                 const float qf = rintf(epi.levels * t);
                                 if (!(qf >= -127.0f && qf <= 127.0f)) bad = 1; else q = (int)qf;
                             }
@@ -1336,7 +1337,7 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
                              int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
                              int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
                              int64_t res_halo_w, qt_stream_t stream) {
-    if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8) return QT_ERR_INVALID_ARG;
+    if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (out_halo_h < 0 || out_halo_w < 0 || res_halo_h < 0 || res_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64 ||
         res_halo_h > 64 || res_halo_w > 64 || ((res_halo_h | res_halo_w) && !res_codes))
         return QT_ERR_INVALID_ARG;

@@ -76,6 +76,9 @@ class FusedBnDorefaQuant(torch.nn.Module):
     ``quant(relu(bn(conv(x))))`` / ``quant(relu(bn2(conv2(.)) + shortcut))`` chains of a DoReFa ResNet
     (models/samples/ResNet_Dorefa.py:26,35) without BatchNorm / add / ReLU / quantiser passes over fp32 tensors.
 
+    ``relu``: True / "post" (after BatchNorm and residual), "pre" (before the BatchNorm: the Linear -> ReLU ->
+    BatchNorm -> quant order of models/FullNet/DorefaMNIST.py:46-48) or False.
+
     forward(x, residual=None, residual_bn=None):
       x           fp32 [N, C, H, W] (channels_last, as the conv kernels return it) or [N, C]
       residual    None | CodeActivation (identity shortcut; value inv_n * code) | fp32 tensor shaped like x
@@ -84,11 +87,11 @@ class FusedBnDorefaQuant(torch.nn.Module):
     (oracle.affine_relu_dorefa_codes).  The quantiser is unclamped like the reference's, so codes may leave int8:
     the kernel raises a device flag shared along the chain and ``CodeActivation.check()/float()`` raises."""
 
-    def __init__(self, bn, bit_width: int, relu: bool = True, out_halo=0):
+    def __init__(self, bn, bit_width: int, relu=True, out_halo=0):
         super().__init__()
         if not 2 <= int(bit_width) <= 8:
             raise ValueError("code planes exist for 2 <= bit_width <= 8")
-        self.bn, self.bit_width, self.relu = bn, int(bit_width), bool(relu)
+        self.bn, self.bit_width, self.relu = bn, int(bit_width), ops.relu_mode(relu)
         # out_halo: zero border for the consuming conv's padding (see FusedDorefaConvBnQuant); made here by one
         # qt_pad_pixel_plane pass over the code plane
         self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
@@ -151,11 +154,11 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
 
     forward(act, residual=None, residual_bn=None): residual over the conv's OUTPUT pixels, as FusedBnDorefaQuant."""
 
-    def __init__(self, conv, bn, bit_width: int, relu: bool = True, out_halo=0):
+    def __init__(self, conv, bn, bit_width: int, relu=True, out_halo=0):
         super().__init__()
         if getattr(conv, "bit_width", None) != 1 or conv.groups != 1 or conv.padding_mode != "zeros":
             raise ValueError("FusedDorefaConvBnQuant takes an un-grouped, zero-padded DorefaConv2d(bit_width=1)")
-        self.conv, self.bn, self.bit_width, self.relu = conv, bn, int(bit_width), bool(relu)
+        self.conv, self.bn, self.bit_width, self.relu = conv, bn, int(bit_width), ops.relu_mode(relu)
         # out_halo = the padding of the conv(s) that consume this activation: the epilogue writes into a plane with
         # that zero border, so they run the un-padded kernels (a residual CodeActivation may carry any halo)
         self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
@@ -188,6 +191,32 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
         return _fused.dorefa_w1_conv_forward(act, conv.weight, conv.bias,
                                              (conv.stride, conv.padding, conv.dilation, conv.groups), True, wc,
                                              conv.padding_mode, scale=E, epi=epi)
+
+
+class CodeMaxPool(torch.nn.Module):
+    """MaxPool2d on a CodeActivation (the reference's DoReFa CNNs pool AFTER the quantiser,
+    models/samples/AlexNet_Dorefa.py:38-41): the max of the int8 codes, bit-identical to pooling the fp32 image.
+    ``out_halo``: zero border for the next conv's padding."""
+
+    def __init__(self, pool, out_halo=0):
+        super().__init__()
+        k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+        st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+        pad = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+        dil = pool.dilation if isinstance(pool.dilation, int) else pool.dilation[0]
+        if pad != 0 or dil != 1 or pool.ceil_mode:
+            raise ValueError("only un-padded, un-dilated, floor-mode MaxPool2d runs on code planes")
+        self.pool_k, self.pool_s = int(k), int(st)
+        self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
+
+    def forward(self, act):
+        if not isinstance(act, packed.CodeActivation) or len(act.shape) != 4:
+            raise TypeError("CodeMaxPool consumes the (N, C, H, W) CodeActivation of a fused DoReFa block")
+        act = act.without_halo()
+        N, C, H, W = act.shape
+        out = ops.pool_codes(act.codes, N, H, W, self.pool_k, self.pool_s, self.out_halo)
+        Ho, Wo = (H - self.pool_k) // self.pool_s + 1, (W - self.pool_k) // self.pool_s + 1
+        return packed.CodeActivation(out, (N, C, Ho, Wo), halo=self.out_halo)
 
 
 class FusedConvPoolBnSign(torch.nn.Module):

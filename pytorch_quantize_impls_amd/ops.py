@@ -33,6 +33,19 @@ def inv_levels(bit_width: int) -> float:
     return float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(n, dtype=torch.float32))
 
 
+def relu_mode(relu) -> int:
+    """ReLU placement of the fused DoReFa chain: False / None -> 0 (none), True / "post" -> 1 (after BatchNorm and
+    residual: quant(relu(bn(x) + r))), "pre" -> 2 (before the BatchNorm: quant(bn(relu(x))),
+    models/FullNet/DorefaMNIST.py:46-48)."""
+    if relu in (False, None, 0):
+        return 0
+    if relu in (True, 1, "post"):
+        return 1
+    if relu in (2, "pre"):
+        return 2
+    raise ValueError(f"relu must be False, True / 'post' or 'pre', got {relu!r}")
+
+
 @dataclass
 class CodeEpilogue:
     """Arguments of the conv code epilogue (qt_conv2d_implicit_codes): folded BatchNorm (alpha, beta), optional
@@ -102,7 +115,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         flag = epi.overflow if epi.overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
         with _on(dev):
             _lib.call("qt_conv2d_implicit_codes", *head, _p(alpha), _p(beta), _p(rf), I(ldr), _p(ra), _p(rb), _p(rc),
-                      I(ldrc), float(rscale), int(1 if epi.relu else 0),
+                      I(ldrc), float(rscale), relu_mode(epi.relu),
                       int(int(epi.bit_width)), _p(codes), I(ldc), I(Cout), _p(flag), I(hy), I(hx), I(ohy),
                       I(ohx), I(rhy), I(rhx), _stream(dev))
         inv_n = inv_levels(epi.bit_width)
@@ -667,10 +680,30 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
     with _on(dev):
         _lib.call("qt_affine_dorefa_codes_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
                   _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
-                  float(rscale), int(1 if relu else 0), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
+                  float(rscale), relu_mode(relu), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
                   int(int(bit_width)), _p(flag), _stream(dev))
     inv_n = inv_levels(bit_width)
     return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
+
+
+def pool_codes(codes: CodePlanes, N: int, H: int, W: int, pool_k: int, pool_s: int, out_halo=(0, 0)) -> CodePlanes:
+    """MaxPool2d(pool_k, pool_s) on an NHWC code plane [N*H*W, ld] -> [N*(Ho+2hy)*(Wo+2hx), ld] (max of codes =
+    code of the max: the quantised value is monotone in its code)."""
+    if codes.rows != N * H * W:
+        raise ValueError(f"code plane holds {codes.rows} pixels, ({N}, {H}, {W}) needs {N * H * W}")
+    hy, hx = (int(v) for v in out_halo)
+    Ho, Wo = (H - pool_k) // pool_s + 1, (W - pool_k) // pool_s + 1
+    ld = int(codes.codes.shape[1])
+    dev = codes.device
+    out = torch.empty((N * (Ho + 2 * hy) * (Wo + 2 * hx), ld), dtype=torch.int8, device=dev)
+    I = int
+    with _on(dev):
+        if hy or hx:
+            _lib.call("qt_zero_halo", _p(out), I(N), I(Ho), I(Wo), I(ld // 4), I(hy), I(hx), _stream(dev))
+        _lib.call("qt_pool_codes_i8", _p(codes.codes), I(N), I(H), I(W), I(ld), I(pool_k), I(pool_s), _p(out), I(hy),
+                  I(hx), _stream(dev))
+    return CodePlanes(codes=out, rows=int(out.shape[0]), K=codes.K, inv_n=codes.inv_n, bit_width=codes.bit_width,
+                      overflow=codes.overflow)
 
 
 def weight_codes(w2d: torch.Tensor, ternary: bool = False, ld_bytes: Optional[int] = None) -> CodePlanes:

@@ -139,6 +139,24 @@ class CodeActivation:
                                 bit_width=self.codes.bit_width, overflow=self.codes.overflow)
         return CodeActivation(planes, self.shape)
 
+    def flatten_hwc(self) -> "CodeActivation":
+        """(N, C, H, W) -> (N, H*W*C) row codes in (h, w, c) order for a LinearDorefa whose weight columns were permuted
+        to that order (layers.fused.permute_fc_weight_hwc).  A view when the pixel rows are unpadded (C % 16 == 0) and a
+        row is a whole number of 128-byte GEMM stages; otherwise one gather copy into a padded plane."""
+        from . import ops
+        act = self.without_halo()
+        N, C, H, W = act.shape
+        K = H * W * C
+        ld = int(act.codes.codes.shape[1])
+        if ld == C and K % 128 == 0:
+            rows = act.codes.codes.view(N, K)
+        else:
+            rows = torch.zeros((N, ops.code_ld_bytes(K)), dtype=torch.int8, device=act.device)
+            rows[:, :K] = act.codes.codes.view(N, H * W, ld)[:, :, :C].reshape(N, K)
+        planes = ops.CodePlanes(codes=rows, rows=N, K=K, inv_n=act.codes.inv_n, bit_width=act.codes.bit_width,
+                                overflow=act.codes.overflow)
+        return CodeActivation(planes, (N, K))
+
     def check(self):
         from . import ops
         if not ops.ASSUME_CODES_FIT and self.codes.overflow is not None and int(self.codes.overflow.item()) != 0:

@@ -1326,6 +1326,91 @@ def test_conv_code_epilogue_equals_conv_then_fused_quantiser(dev, oracle, Cin, C
 
 
 @pytest.mark.gpu
+def test_fused_dorefa_pre_relu_and_code_pool_vs_oracle(dev, oracle):
+    """The two other module orders of the reference's DoReFa examples: ReLU in front of the BatchNorm
+    (models/FullNet/DorefaMNIST.py:46-48) and MaxPool2d after the quantiser (models/samples/AlexNet_Dorefa.py:38-41),
+    the latter as a max over the int8 codes."""
+    from pytorch_quantize_impls_amd.layers import (CodeMaxPool, DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant,
+                                                   fold_batchnorm)
+    N, C, H, W, k = 3, 40, 9, 11, 3
+    x = synth.uniform(21, (N, C, H, W), -2, 2)
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    bn.running_mean.copy_(g(synth.uniform(22, (C,), -0.5, 0.5), dev))
+    bn.running_var.copy_(g(synth.uniform(23, (C,), 0.5, 4), dev))
+    bn.weight.data.copy_(g(synth.uniform(24, (C,), -1.5, 1.5), dev))
+    bn.bias.data.copy_(g(synth.uniform(25, (C,), -0.5, 0.5), dev))
+    bn.eval()
+    alpha, beta = (n(v) for v in fold_batchnorm(bn))
+    xg = g(x, dev).contiguous(memory_format=torch.channels_last)
+    act = FusedBnDorefaQuant(bn, k, relu="pre")(xg)
+    want_q, want_y = oracle.affine_relu_dorefa_codes(x, alpha, beta, k, "pre")
+    assert (np.abs(want_q) <= 127).all()
+    np.testing.assert_array_equal(n(act.float()), want_y)
+    # pre-ReLU in the conv epilogue == conv -> one-pass form
+    conv = DorefaConv2d(C, 24, 3, padding=1, bias=False, bit_width=1).to(dev).eval()
+    with torch.no_grad():
+        e1 = FusedDorefaConvBnQuant(conv, torch.nn.BatchNorm2d(24).to(dev).eval(), k, relu="pre")(act)
+        e2 = FusedBnDorefaQuant(torch.nn.BatchNorm2d(24).to(dev).eval(), k, relu="pre")(conv(act))
+    assert torch.equal(e1.codes.codes, e2.codes.codes)
+    # MaxPool on the codes == MaxPool of the fp32 image (oracle.maxpool2d), with and without an output halo
+    for (pk, ps, halo) in ((2, 2, (0, 0)), (3, 2, (1, 1)), (2, 1, (2, 1))):
+        pooled = CodeMaxPool(torch.nn.MaxPool2d(pk, ps), out_halo=halo)(act)
+        want = oracle.maxpool2d(want_y, pk, ps)
+        assert pooled.halo == halo and pooled.shape == want.shape
+        np.testing.assert_array_equal(n(pooled.float()), want)
+        full = pooled.codes.codes.view(N, want.shape[2] + 2 * halo[0], want.shape[3] + 2 * halo[1], -1)
+        assert int(full.abs().sum()) == int(pooled.without_halo().codes.codes.abs().sum())      # zero border
+    with pytest.raises(ValueError, match="relu must be"):
+        FusedBnDorefaQuant(bn, k, relu="both")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C1", [64, 40])
+def test_fused_dorefa_cnn_chain_matches_module_graph(dev, C1):
+    """A small CNN in the module order of models/samples/AlexNet_Dorefa.py (conv, BatchNorm, ReLU, quant, MaxPool ...
+    flatten, LinearDorefa, BatchNorm1d, ReLU, quant, LinearDorefa) run (a) module by module and (b) as code planes end
+    to end: code-epilogue conv, pool on codes, flatten_hwc into the int8 GEMM, one-pass quantiser after the FC."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    from pytorch_quantize_impls_amd.layers import (CodeMaxPool, DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant,
+                                                   LinearDorefa, permute_fc_weight_hwc)
+    torch.manual_seed(5)
+    k, N = 4, 8
+    conv0 = DorefaConv2d(3, 32, 3, padding=1, bias=False, bit_width=1)
+    conv1 = DorefaConv2d(32, C1, 3, padding=1, bias=True, bit_width=1)
+    lin2, lin3 = LinearDorefa(C1 * 4 * 4, 128, bit_width=1), LinearDorefa(128, 10, bit_width=1)
+    bn0, bn1, bn2 = torch.nn.BatchNorm2d(32), torch.nn.BatchNorm2d(C1), torch.nn.BatchNorm1d(128)
+    for i, b in enumerate((bn0, bn1, bn2)):
+        b.running_mean.copy_(torch.from_numpy(synth.normal(30 + i, (b.num_features,))) * 0.1)
+        b.running_var.copy_(torch.from_numpy(synth.uniform(40 + i, (b.num_features,), 0.5, 2)))
+        b.weight.data.copy_(torch.from_numpy(synth.uniform(50 + i, (b.num_features,), 0.3, 0.8)))
+        b.bias.data.copy_(torch.from_numpy(synth.uniform(60 + i, (b.num_features,), 0.0, 0.4)))
+    mods = torch.nn.ModuleList([conv0, conv1, lin2, lin3, bn0, bn1, bn2]).to(dev).eval()
+    quant, pool = nnDorefaQuant(k), torch.nn.MaxPool2d(2)
+    x = g(synth.normal(70, (N, 3, 16, 16)), dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        h = pool(quant(torch.relu(bn0(conv0(x)))))
+        h = pool(quant(torch.relu(bn1(conv1(h)))))
+        h = quant(torch.relu(bn2(lin2(h.reshape(N, -1)))))
+        want = lin3(h)
+        # fused: the FC weight takes the (h, w, c) column order of flatten_hwc
+        lin2f = LinearDorefa(C1 * 4 * 4, 128, bit_width=1).to(dev)
+        lin2f.weight.data.copy_(permute_fc_weight_hwc(lin2.weight.org if hasattr(lin2.weight, "org") else lin2.weight, C1, 4, 4))
+        lin2f.bias.data.copy_(lin2.bias)
+        lin2f.eval()
+        before = dict(_lib.call_counts)
+        a = CodeMaxPool(pool, out_halo=1)(FusedBnDorefaQuant(bn0, k)(conv0(x)))
+        a = CodeMaxPool(pool)(FusedDorefaConvBnQuant(conv1, bn1, k)(a))
+        flat = a.flatten_hwc()
+        assert torch.equal(flat.float(), a.float().permute(0, 2, 3, 1).reshape(N, -1))
+        a2 = FusedBnDorefaQuant(bn2, k)(lin2f(flat))
+        got = lin3(a2)
+        used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+    assert used.get("qt_conv2d_implicit_codes") == 1 and used.get("qt_pool_codes_i8") == 2 and used.get("qt_i8_gemm") == 2, used
+    assert isinstance(got, torch.Tensor) and got.shape == want.shape
+    assert (got - want).abs().max().item() <= 0.05 * want.abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,ksz,st,pd,in_halo,out_halo,res_halo", [
     (64, 64, 3, 1, 1, (1, 1), (1, 1), (1, 1)), (32, 100, 3, 2, 1, (1, 1), (1, 1), None),
     (16, 48, 1, 2, 0, (1, 1), (0, 0), (2, 1)), (64, 130, 3, 1, (1, 0), (2, 1), (1, 2), (0, 0)),

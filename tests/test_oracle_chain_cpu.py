@@ -55,13 +55,13 @@ def test_oracle_dorefa_block_chain_matches_torch_modules(oracle):
     for k in (2, 4, 8):
         quant = nnDorefaQuant(k)
         n = float((1 << k) - 1)
-        for relu in (True, False):
+        for relu in (True, False, "pre"):
             for res, aff in ((None, None), (r, None), (r, (ra, rb))):
                 with torch.no_grad():
-                    t = x * v(a) + v(be)
+                    t = (torch.relu(x) if relu == "pre" else x) * v(a) + v(be)
                     if res is not None:
                         t = t + (res * v(ra) + v(rb) if aff is not None else res)
-                    t = torch.relu(t) if relu else t
+                    t = torch.relu(t) if relu is True else t
                     want = quant(t)
                 q, y = oracle.affine_relu_dorefa_codes(x.numpy(), a.numpy(), be.numpy(), k, relu,
                                                        None if res is None else res.numpy(),
