@@ -14,5 +14,5 @@ for m in m4.modules():
     if isinstance(m, torch.nn.BatchNorm2d): m.running_var.mul_(4.0)
 net = bench_models.FusedDorefaResNet18(m4) if os.environ.get("FUSED", "0") == "1" else m4
 with torch.no_grad():
-    for _ in range(13): net(x4)
+    for _ in range(int(os.environ.get("ITERS", "13"))): net(x4)
 torch.cuda.synchronize()
