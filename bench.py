@@ -247,6 +247,18 @@ def bench_alexnet(args, dev, dist, world, rank):
     out["fused"] = {"images_per_s": world * B * args.alexnet_iters / elf,
                     "ms_per_forward": elf / args.alexnet_iters * 1e3,
                     "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), y.argmax(1)))}
+    # SURVEY 8d asks for the train-mode form as well: the quantised layers in training mode (sign + pack of W on every
+    # call, STE autograd nodes), BatchNorm kept on its running statistics for determinism
+    from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
+    qlayers = [m for m in model.modules() if isinstance(m, (BinConv2d, LinearBin))]
+    for m in qlayers:
+        m.train()
+    elt, yt = timed(model)
+    for m in qlayers:
+        m.eval()
+    out["train_mode_layers"] = {"images_per_s": world * B * args.alexnet_iters / elt,
+                                "ms_per_forward": elt / args.alexnet_iters * 1e3,
+                                "same_logits_as_eval": bool(torch.equal(yt, y))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = min(B, 16)
         cpu_model = bench_models.AlexNetBin()
