@@ -70,5 +70,60 @@ for it in range(iters):
         err = float((yr - refr).abs().max() / refr.abs().max())
         if err > 1e-5:
             bad += 1; print("REAL CONV", err, (c1.in_channels, Cout, c1.kernel_size, c1.stride, c1.padding, Hh))
+    # ---- DoReFa code planes: conv code epilogue (halo in / out, residual forms, ReLU placement) and pool on codes,
+    # against the same chain in float64 (codes within 1e-3 of a rounding tie are skipped)
+    if it % 2 == 0:
+        from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedDorefaConvBnQuant, FusedBnDorefaQuant, CodeMaxPool
+        ka = int(rng.choice([2, 3, 4, 5])); kq = int(rng.choice([2, 3, 4]))
+        Ci = int(rng.choice([16, 32, 48, 64, 128, 200])); Co = int(rng.choice([8, 30, 64, 100, 128, 192, 260]))
+        kk = int(rng.integers(1, 4)); st2 = int(rng.integers(1, 3)); pd2 = int(rng.integers(0, 2)); 
+        Nb = int(rng.integers(1, 6)); Hh = int(rng.integers(kk, 20)) + 2; Ww = int(rng.integers(kk, 20)) + 2
+        dconv = DorefaConv2d(Ci, Co, kk, stride=st2, padding=pd2, bias=bool(it % 4), bit_width=1).to(dev)
+        dconv.weight.data.uniform_(-1, 1); dconv.eval()
+        dbn = torch.nn.BatchNorm2d(Co).to(dev).eval()
+        dbn.running_mean.normal_(0, 0.2); dbn.running_var.uniform_(0.5, 3); dbn.weight.data.uniform_(0.1, 0.6); dbn.bias.data.uniform_(-0.2, 0.3)
+        xin = torch.rand((Nb * Hh * Ww, Ci), device=dev)
+        xc, ximg = ops.dorefa_codes(xin, ka, want_f32=True, ld_bytes=ops.code_ld_bytes(Ci, 16))
+        in_halo = (pd2 + int(rng.integers(0, 2)),) * 2 if it % 4 == 0 else (0, 0)
+        if any(in_halo):
+            xc = ops.CodePlanes(codes=ops.pad_pixel_plane(xc.codes, Nb, Hh, Ww, in_halo), rows=Nb * (Hh + 2 * in_halo[0]) * (Ww + 2 * in_halo[1]),
+                                K=Ci, inv_n=xc.inv_n, bit_width=ka, overflow=xc.overflow)
+        dact = pk.CodeActivation(xc, (Nb, Ci, Hh, Ww), halo=in_halo)
+        relu = (True, "pre", False)[it % 3]
+        out_halo = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        Ho2, Wo2 = ops.conv_out_hw(Hh, Ww, kk, kk, st2, pd2, 1)
+        res = rd = None
+        if it % 6 < 4:
+            rimg_in = torch.rand((Nb * Ho2 * Wo2, Co), device=dev)
+            rc, rimg = ops.dorefa_codes(rimg_in, kq, want_f32=True, ld_bytes=ops.code_ld_bytes(Co, 16))
+            res = pk.CodeActivation(rc, (Nb, Co, Ho2, Wo2))
+            rd = rimg.view(Nb, Ho2, Wo2, Co).permute(0, 3, 1, 2).cpu().double()
+        with torch.no_grad():
+            got_act = FusedDorefaConvBnQuant(dconv, dbn, kq, relu=relu, out_halo=out_halo)(dact, residual=res)
+            al, be = (t.cpu().double() for t in fold_batchnorm(dbn))
+            xd = ximg.view(Nb, Hh, Ww, Ci).permute(0, 3, 1, 2).cpu().double()
+            yd = torch.nn.functional.conv2d(xd, dconv.weight.detach().cpu().double(),
+                                            None if dconv.bias is None else dconv.bias.detach().cpu().double(), st2, pd2)
+            if relu == "pre": yd = yd.clamp_min(0)
+            t_ = yd * al.view(1, -1, 1, 1) + be.view(1, -1, 1, 1)
+            if rd is not None: t_ = t_ + rd
+            if relu is True: t_ = t_.clamp_min(0)
+            nq = float((1 << kq) - 1)
+            want = torch.round(nq * t_)
+            safe = ((nq * t_ - torch.floor(nq * t_) - 0.5).abs() > 1e-3) & (want.abs() <= 126)
+            gq = got_act.without_halo().codes.codes[:, :Co].view(Nb, Ho2, Wo2, Co).permute(0, 3, 1, 2).cpu().double()
+        if not torch.equal(gq[safe], want[safe]):
+            bad += 1; print("DOREFA EPILOGUE MISMATCH", (Ci, Co, kk, st2, pd2, Nb, Hh, Ww, ka, kq, relu, in_halo, out_halo, rd is not None), int((gq[safe] != want[safe]).sum()))
+        if any(out_halo):
+            full = got_act.codes.codes.view(Nb, Ho2 + 2 * out_halo[0], Wo2 + 2 * out_halo[1], -1)
+            if int(full.abs().sum()) != int(got_act.without_halo().codes.codes.abs().sum()):
+                bad += 1; print("HALO BORDER NOT ZERO", (Ci, Co, out_halo))
+        if min(Ho2, Wo2) >= 2:
+            with torch.no_grad():
+                pooled = CodeMaxPool(torch.nn.MaxPool2d(2, 2), out_halo=(it % 3, 1))(got_act)
+                wantp = torch.nn.functional.max_pool2d(gq, 2, 2)
+                gp = pooled.without_halo().codes.codes[:, :Co].view(Nb, Ho2 // 2, Wo2 // 2, Co).permute(0, 3, 1, 2).cpu().double()
+            if not torch.equal(gp, wantp):
+                bad += 1; print("CODE POOL MISMATCH", (Co, Ho2, Wo2))
 print(f"seed {seed}: {iters} iterations, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
