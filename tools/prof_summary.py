@@ -17,7 +17,7 @@ d = sys.argv[1]
 ours = ("mfma_gemm_kernel", "pool_affine_sign_pack_kernel", "triple_kernel", "codes_kernel", "im2col_words_kernel",
         "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_pair_kernel", "bits_to_nib_pad_kernel", "s2d_triple_rows_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
         "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
-        "check_pm1_kernel", "pool_bits_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
+        "check_pm1_kernel", "pool_bits_kernel", "affine_codes_kernel", "pool_codes_kernel", "zero_halo_kernel", "pad_pixel_plane_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
 
 
 import re
@@ -27,10 +27,11 @@ def short(n):
     for k in ours:
         if k in n:
             tail = ""
-            m = re.search(r"GemmCfg<\(anonymous namespace\)::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>", n)
+            m = re.search(r"GemmCfg<\(anonymous namespace\)::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)(?:, (\d+))? ?>", n)
             if m:
+                occ = f", {m.group(10)} wg/CU" if m.group(10) and m.group(10) != "1" else ""
                 tail = (f"<{m.group(1)}, tile {int(m.group(2))*int(m.group(4))*32}x{int(m.group(3))*int(m.group(5))*32}, "
-                        f"pipe={m.group(6)}{', conv' if m.group(9) in ('true', '1') else (', conv-valid' if m.group(9) == '2' else '')}>")
+                        f"pipe={m.group(6)}{', conv' if m.group(9) in ('true', '1') else (', conv-valid' if m.group(9) == '2' else '')}{occ}>")
             elif "<" in n and k == "popc_gemm_kernel":
                 tail = n[n.index("<"):n.index(">") + 1][:40]
             return k + tail
