@@ -362,6 +362,23 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
                             float scale, const float* scale_dev, const float* alpha, const float* beta,
                             uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream);
 
+/* qt_conv2d_implicit_bits with the sign bits written as the NEXT conv's operand instead: an fp4 nibble pixel plane
+ * (+1 = 0x2, -1 = 0xA, channels >= Cout zero), nib_plane [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ldn words],
+ * ldn == ceil(Cout/32)*4.  The kernel writes the interior pixels; the caller zeroes the border of a halo
+ * plane (qt_zero_halo) — the halo is the next conv's zero padding.  Replaces qt_conv2d_implicit_bits +
+ * qt_bits_to_nib_pad when no pooling sits between two binarised convs. */
+int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                           int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                           int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
+                           const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
+                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
+
+/* qt_pool_bits with the pooled bits written the same way (nibble pixel plane of C channels, optional halo):
+ * qt_pool_bits + qt_bits_to_nib_pad in one pass. */
+int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld, int64_t pool_k,
+                     int64_t pool_s, const uint32_t* neg_alpha, uint32_t* nib_plane, int64_t ldn, int64_t C,
+                     int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
+
 /* The same conv with the k-bit DoReFa chain of qt_affine_dorefa_codes_i8 applied to the accumulators (code epilogue):
  *   t = fl(fl(y*alpha[c]) + beta[c]) [+ residual as there] ; [ReLU] ; q = rint((2^k-1) * t)
  * where y is exactly the fp32 value qt_conv2d_implicit would have stored.  codes: int8 [N*Ho*Wo][ldc_bytes]

@@ -97,6 +97,54 @@ __global__ __launch_bounds__(256) void pool_bits_kernel(const uint32_t* __restri
     }
 }
 
+// qt_pool_bits with the result expanded to the next conv's fp4 nibble pixel plane (+1 = 0x2, -1 = 0xA, channels >= C
+// zero), optionally into a halo plane [N][Ho + 2hy][Wo + 2hx][ldn] (interior only): pool_bits + bits_to_nib_pad in
+// one pass.  One thread = one 32-channel group of one output pixel (4 nibble words).
+__device__ __forceinline__ uint32_t fe_spread8(uint32_t b) {
+    uint32_t t = b & 0xFFu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t;
+}
+__global__ __launch_bounds__(256) void pool_bits_nib_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                            const uint32_t* __restrict__ neg_alpha, int64_t ld,
+                                                            int64_t ldn, int64_t N, int H, int W, int pk, int ps, int Ho,
+                                                            int Wo, int hy, int hx, int C) {
+    const int64_t groups = ldn / 4;
+    const int64_t total = N * Ho * Wo * groups;
+    const int Hop = Ho + 2 * hy, Wop = Wo + 2 * hx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / groups;
+        const int g = (int)(i - pix * groups);
+        const int64_t n = pix / ((int64_t)Ho * Wo);
+        const int rem = (int)(pix - n * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        uint32_t sw = 0, mw = 0;
+        if (g < ld) {
+            const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ld + g;
+            uint32_t all = 0xffffffffu, any = 0u;
+            for (int a = 0; a < pk; ++a)
+                for (int b = 0; b < pk; ++b) {
+                    const uint32_t v = base[((int64_t)a * W + b) * ld];
+                    all &= v;
+                    any |= v;
+                }
+            const uint32_t na = neg_alpha[g];
+            const int left = C - g * 32;
+            mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
+            sw = ((all & ~na) | (any & na)) & mw;
+        }
+        uint4 o;
+        o.x = (fe_spread8(mw) << 1) | (fe_spread8(sw) << 3);
+        o.y = (fe_spread8(mw >> 8) << 1) | (fe_spread8(sw >> 8) << 3);
+        o.z = (fe_spread8(mw >> 16) << 1) | (fe_spread8(sw >> 16) << 3);
+        o.w = (fe_spread8(mw >> 24) << 1) | (fe_spread8(sw >> 24) << 3);
+        *reinterpret_cast<uint4*>(out + ((n * Hop + ho + hy) * Wop + wo + hx) * ldn + g * 4) = o;
+    }
+}
+
 // MaxPool2d(k, s) on an int8 DoReFa code plane (the reference pools AFTER the quantiser,
 // models/samples/AlexNet_Dorefa.py:38-41: x = quant(relu(bn(conv))); x = pool(x)).  value = fl(inv_n * code) is
 // monotone in the code, so the max of the codes IS the code of the max: bit-identical to pooling the fp32 image.
@@ -130,6 +178,24 @@ __global__ __launch_bounds__(256) void pool_codes_kernel(const uint32_t* __restr
 }
 
 }  // namespace
+
+extern "C" int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld, int64_t pool_k,
+                                int64_t pool_s, const uint32_t* neg_alpha, uint32_t* nib_plane, int64_t ldn, int64_t C,
+                                int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || ld <= 0 || pool_k < 1 || pool_s < 1 || C <= 0 || out_halo_h < 0 || out_halo_w < 0)
+        return QT_ERR_INVALID_ARG;
+    if (pool_k > H || pool_k > W || ld < (C + 31) / 32 || ldn < (C + 7) / 8) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!in_plane || !nib_plane || !neg_alpha) return QT_ERR_INVALID_ARG;
+    if ((ld & 3) || (ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
+    if (H > 32767 || W > 32767 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_UNSUPPORTED;
+    const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;
+    const int grid = qt_stream_grid((N * Ho * Wo * (ldn / 4) + 255) / 256);
+    hipLaunchKernelGGL(pool_bits_nib_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in_plane, nib_plane,
+                       neg_alpha, ld, ldn, N, (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo,
+                       (int)out_halo_h, (int)out_halo_w, (int)C);
+    return qt_check_launch();
+}
 
 extern "C" int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld_bytes,
                                 int64_t pool_k, int64_t pool_s, int8_t* out_plane, int64_t out_halo_h,

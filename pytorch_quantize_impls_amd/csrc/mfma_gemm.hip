@@ -141,7 +141,9 @@ struct ConvArgs {
 struct EpiArgs {
     const float* alpha = nullptr;
     const float* beta = nullptr;
-    int mode = 0;                      // 0: threshold bits iff alpha != nullptr ; 2: int8 codes
+    int mode = 0;                      // 0: threshold bits iff alpha != nullptr ; 2: int8 codes ; 3: threshold bits
+                                       // expanded to the NEXT conv's fp4 nibble pixel plane (+1 = 0x2, -1 = 0xA), ldy WORDS per
+                                       // pixel, optionally with an (ohy, ohx) zero halo (border zeroed by the caller)
     int relu = 0;
     float levels = 0.0f;               // 2^k - 1
     float rscale = 0.0f;
@@ -159,6 +161,15 @@ struct EpiArgs {
     int ohy = 0, ohx = 0, rhy = 0, rhx = 0;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
+
+// spread the 8 bits of a byte to bit 0 of 8 nibbles
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+    uint32_t t = b & 0xFFu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t;
+}
 
 // ---- element types ----------------------------------------------------------------------------------
 struct ElemFp4 {
@@ -742,6 +753,31 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 }
                 const int m = m0 + (wave_m * C::TMW + a) * 32 + lane;
                 const int wcol = nb >> 5;
+                if constexpr (C::CONV) if (epi.mode == 3) {
+                    // the sign word of (pixel m, channels nb..nb+31) as 32 fp4 nibbles = 4 words of the next conv's
+                    // pixel plane (what qt_bits_to_nib_pad would produce from the bit plane in a second pass)
+                    if (lane < 32 && m < M && wcol * 4 < ldy) {
+                        int orow = m;
+                        if (epi.ohy | epi.ohx) {
+                            const unsigned um = (unsigned)m;
+                            const unsigned img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
+                            const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
+                            const unsigned ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
+                            const unsigned wo = rem - ho * (unsigned)cg.Wo;
+                            orow = (int)((img * (unsigned)(cg.Ho + 2 * epi.ohy) + ho + epi.ohy) * (unsigned)(cg.Wo + 2 * epi.ohx) + wo + epi.ohx);
+                        }
+                        const int left = N - nb;
+                        const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
+                        const uint32_t sw = myword & mw;
+                        uint4 o;
+                        o.x = (spread8(mw) << 1) | (spread8(sw) << 3);
+                        o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
+                        o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
+                        o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
+                        *reinterpret_cast<uint4*>(B + (int64_t)orow * ldy + wcol * 4) = o;
+                    }
+                    continue;
+                }
                 if (lane < 32 && m < M && wcol < ldy) B[(int64_t)m * ldy + wcol] = myword;
                 // the row's pad words past the last column tile (ldy rounds ceil(N/32) up to 4) are zeroed here, so
                 // the plane needs no memset
@@ -1032,14 +1068,6 @@ __global__ __launch_bounds__(256) void nib_pack_scalar_kernel(const float* __res
 }
 
 // ---- bit planes -> nibble plane (derived MFMA operand format) ---------------------------------------
-// spread the 8 bits of a byte to bit 0 of 8 nibbles
-__device__ __forceinline__ uint32_t spread8(uint32_t b) {
-    uint32_t t = b & 0xFFu;
-    t = (t | (t << 12)) & 0x000F000Fu;
-    t = (t | (t << 6)) & 0x03030303u;
-    t = (t | (t << 3)) & 0x11111111u;
-    return t;
-}
 // One thread = one 32-bit word of the planes -> four nibble words (16 B).  sign-only planes:
 // nibble = 0x2 | s<<3.  mask+sign: nibble = m<<1 | (s&m)<<3.  Words past the bit planes' stride are 0.
 __global__ __launch_bounds__(256) void bits_to_nib_kernel(const uint32_t* __restrict__ sign,
@@ -1225,7 +1253,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
     const int64_t M = Nimg * Ho * Wo;
     if (M == 0 || Cout == 0) return QT_OK;
-    if (!P || !Wmat || !Y || ldy < (epi.mode == 2 ? ((Cout + 3) & ~3ll) : epi.alpha ? (Cout + 31) / 32 : Cout))
+    if (!P || !Wmat || !Y || ldy < (epi.mode == 2 ? ((Cout + 3) & ~3ll) : epi.mode == 3 ? (Cout + 31) / 32 * 4 : epi.alpha ? (Cout + 31) / 32 : Cout))
         return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
@@ -1233,7 +1261,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || Hp > 32767 || Wp > 32767 ||
         Hp * Wp * Cw * 4 >= (1ll << 31))   // per-image plane bytes: 32-bit tap offsets
         return QT_ERR_UNSUPPORTED;
-    if (epi.mode == 2 && (epi.ohy | epi.ohx | epi.rhy | epi.rhx)) {
+    if ((epi.mode == 2 || epi.mode == 3) && (epi.ohy | epi.ohx | epi.rhy | epi.rhx)) {
         if (Nimg * (Ho + 2 * epi.ohy) * (Wo + 2 * epi.ohx) > INT32_MAX || Nimg * (Ho + 2 * epi.rhy) * (Wo + 2 * epi.rhx) > INT32_MAX)
             return QT_ERR_UNSUPPORTED;
         const unsigned long long hw = (unsigned long long)(Ho * Wo), wo_ = (unsigned long long)Wo;
@@ -1326,6 +1354,25 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H
     epi.beta = beta;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(neg_plane), ldb, Cout, stream, epi);
+}
+
+int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                           int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                           int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                           const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
+                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream) {
+    if (!alpha || !beta) return QT_ERR_INVALID_ARG;
+    if (out_halo_h < 0 || out_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_INVALID_ARG;
+    if ((ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
+    if (ldn != (Cout + 31) / 32 * 4) return QT_ERR_INVALID_ARG;   // every word of a pixel is written by a column block
+    EpiArgs epi;
+    epi.alpha = alpha;
+    epi.beta = beta;
+    epi.mode = 3;
+    epi.ohy = (int)out_halo_h;
+    epi.ohx = (int)out_halo_w;
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, reinterpret_cast<float*>(nib_plane), ldn, Cout, stream, epi);
 }
 
 int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,

@@ -199,6 +199,11 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
                 ws = ops.s2d_weight(wq.detach(), sd)
                 ws_shape, wtr = tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")   # zeros stay zeros
             k2 = ws_shape[2]
+            # a nibble-plane epilogue maps output rows with the kernel's own (Hs - k2 + 1, Ws - k2 + 1) geometry: when
+            # the space-to-depth rounding added pixels, take threshold bits, crop, and expand afterwards
+            nib_epi = epi if isinstance(epi, ops.NibEpilogue) else None
+            if nib_epi is not None and (Hs - k2 + 1 != Ho or Ws - k2 + 1 != Wo):
+                epi = (nib_epi.alpha, nib_epi.beta)
             y2 = ops.float_conv2d(None, torch.empty(ws_shape, device="meta"), "sign", bias, 1, 0, 1,
                                   weight_triples=wtr, pixels=px, in_shape=(N, C * sd * sd, Hs, Ws), epi=epi)
             H2, W2 = Hs - k2 + 1, Ws - k2 + 1
@@ -206,6 +211,8 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
                 if H2 != Ho or W2 != Wo:   # drop the pixels the space-to-depth rounding added
                     sg = y2.sign.view(N, H2, W2, -1)[:, :Ho, :Wo, :].contiguous().view(N * Ho * Wo, -1)
                     y2 = ops.BitPlanes(sign=sg, rows=N * Ho * Wo, K=y2.K)
+                if nib_epi is not None and isinstance(y2, ops.BitPlanes):
+                    y2 = ops.bits_to_nib_pad(y2, N, Ho, Wo, nib_epi.out_halo, ld=ops.pixel_ld_nib(y2.K))
                 return y2, (N, int(weight.shape[0]), Ho, Wo)
             y = y2.view(N, H2, W2, weight.shape[0])[:, :Ho, :Wo, :].permute(0, 3, 1, 2)
             if H2 != Ho or W2 != Wo:
@@ -252,7 +259,13 @@ def packed_conv2d(layer, act, kind: str, epi=None):
     wp = layer._eval_planes(lambda _w2: ops.pack_conv_weight_nib(layer.weight.detach(), kind), key="conv_nib")
     kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
     ph, pw = ops._pairs(layer.padding)
-    if PAD_PLANES and (ph or pw):
+    if act.nib is not None:
+        # the producer already wrote this conv's operand: nibble pixel plane with the padding as a physical zero border
+        if act.halo != (ph, pw):
+            raise ValueError(f"activation carries a {act.halo} halo, this conv pads {(ph, pw)}: re-link the fused modules")
+        y2 = ops.conv2d_nib(act.nib, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,
+                            layer.dilation, epi=epi)
+    elif PAD_PLANES and (ph or pw):
         # zero padding made physical while the bits are expanded: the conv runs un-padded (no per-tap checks)
         px = ops.bits_to_nib_pad(act.planes, N, H, W, (ph, pw), ld=ops.pixel_ld_nib(C))
         y2 = ops.conv2d_nib(px, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,

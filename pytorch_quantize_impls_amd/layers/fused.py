@@ -250,6 +250,10 @@ class FusedConvPoolBnSign(torch.nn.Module):
         self.conv, self.bn = conv, bn
         self.flatten_hwc = flatten_hwc
         self._neg_alpha = None
+        # (ph, pw) of the fused conv that consumes this block's output (set by fuse_sequential): the block then writes
+        # that conv's operand itself — an fp4 nibble pixel plane with the padding as a zero border — from the conv
+        # epilogue (no pooling) or from the pooling kernel, instead of bit planes the consumer would expand again
+        self.out_nib_halo = None
 
     def refold(self):
         self._pool.refold()
@@ -265,18 +269,31 @@ class FusedConvPoolBnSign(torch.nn.Module):
             fp._folded = fold_batchnorm(self.bn)
             self._neg_alpha = ops.neg_alpha_words(fp._folded[0])
         epi = fp._folded
+        pooled = fp.pool_k != 1 or fp.pool_s != 1
+        nib_out = self.out_nib_halo is not None and not self.flatten_hwc
         if isinstance(x, packed.PackedActivation):
+            if nib_out and not pooled:
+                epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo)
             planes, shape = _fused.packed_conv2d(conv, x, self.kind, epi=epi)
+            if isinstance(planes, ops.NibPlanes):
+                return packed.PackedActivation(None, shape, nib=planes, halo=self.out_nib_halo)
         else:
             if not (isinstance(x, torch.Tensor) and x.is_cuda):
                 raise TypeError("FusedConvPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
             wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
+            if nib_out and not pooled:
+                epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo)
             planes, shape = _fused.quant_conv2d_forward(
                 x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups, self.kind,
                 weight_q=conv.weight, weight_planes=wp, binary_input=conv.binary_input,
                 padding_mode=conv.padding_mode, weight_triples_fn=conv._conv_triples, epi=epi)
+        if isinstance(planes, ops.NibPlanes):
+            return packed.PackedActivation(None, shape, nib=planes, halo=self.out_nib_halo)
         N, Cout, Ho, Wo = shape
-        if fp.pool_k != 1 or fp.pool_s != 1:
+        if pooled and nib_out:
+            nib, (Ho, Wo) = ops.pool_bits_nib(planes, N, Ho, Wo, fp.pool_k, fp.pool_s, self._neg_alpha, self.out_nib_halo)
+            return packed.PackedActivation(None, (N, Cout, Ho, Wo), nib=nib, halo=self.out_nib_halo)
+        if pooled:
             planes, (Ho, Wo) = ops.pool_bits(planes, N, Ho, Wo, fp.pool_k, fp.pool_s, self._neg_alpha)
         act = packed.PackedActivation(planes, (N, Cout, Ho, Wo))
         return act.flatten_hwc() if self.flatten_hwc else act
@@ -297,13 +314,20 @@ class PackedMaxPool(torch.nn.Module):
             raise ValueError("only un-padded, un-dilated, floor-mode MaxPool2d can be fused")
         self.pool_k, self.pool_s = int(k), int(st)
         self._zero_mask = None
+        self.out_nib_halo = None        # see FusedConvPoolBnSign.out_nib_halo
 
     def forward(self, act):
         if not isinstance(act, packed.PackedActivation) or len(act.shape) != 4:
             raise TypeError("PackedMaxPool consumes the PackedActivation of a fused conv block")
+        if act.planes is None:
+            raise ValueError("PackedMaxPool pools bit planes; its producer was linked to hand over a conv operand")
         N, C, H, W = act.shape
         if self._zero_mask is None or self._zero_mask.device != act.device or self._zero_mask.numel() != act.planes.ld:
             self._zero_mask = torch.zeros((act.planes.ld,), dtype=torch.int32, device=act.device)
+        if self.out_nib_halo is not None:
+            nib, (Ho, Wo) = ops.pool_bits_nib(act.planes, N, H, W, self.pool_k, self.pool_s, self._zero_mask,
+                                              self.out_nib_halo)
+            return packed.PackedActivation(None, (N, C, Ho, Wo), nib=nib, halo=self.out_nib_halo)
         planes, (Ho, Wo) = ops.pool_bits(act.planes, N, H, W, self.pool_k, self.pool_s, self._zero_mask)
         return packed.PackedActivation(planes, (N, C, Ho, Wo))
 
@@ -358,7 +382,20 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_po
                         continue
         out.append(mods[i])
         i += 1
+    link_nib_planes(out)
     return torch.nn.Sequential(*out)
+
+
+def link_nib_planes(mods) -> None:
+    """Where a fused conv block directly consumes the output of another fused block (or of a PackedMaxPool), let the
+    producer write the consumer's operand — the fp4 nibble pixel plane with the consumer's padding as a zero border —
+    instead of bit planes (saves the consumer's qt_bits_to_nib_pad pass: 10 % of the fused VGG-16 forward)."""
+    from ..functions import _fused
+    for a, b in zip(mods, mods[1:]):
+        if isinstance(a, (FusedConvPoolBnSign, PackedMaxPool)):
+            a.out_nib_halo = None
+            if (_fused.PAD_PLANES and isinstance(b, FusedConvPoolBnSign) and not getattr(a, "flatten_hwc", False)):
+                a.out_nib_halo = tuple(int(v) for v in ops._pairs(b.conv.padding))
 
 
 class FusedFeatureClassifier(torch.nn.Module):

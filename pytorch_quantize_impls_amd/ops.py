@@ -63,6 +63,15 @@ class CodeEpilogue:
     res_halo: tuple = (0, 0)        # halo of the residual code plane
 
 
+@dataclass
+class NibEpilogue:
+    """Threshold-bit epilogue written as the NEXT conv's fp4 nibble pixel plane (qt_conv2d_implicit_nib): folded
+    BatchNorm (alpha, beta); ``out_halo`` = zero border in pixels (the next conv's padding)."""
+    alpha: torch.Tensor
+    beta: torch.Tensor
+    out_halo: tuple = (0, 0)
+
+
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
                    ldw_words: int, bias, scale: float, scale_dev, Cout: int, epi=None, in_halo=(0, 0)):
     """qt_conv2d_implicit; returns None if the shape is outside its limits (caller falls back).
@@ -120,6 +129,20 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
                       I(ohx), I(rhy), I(rhx), _stream(dev))
         inv_n = inv_levels(epi.bit_width)
         return CodePlanes(codes=codes, rows=Mo, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
+    if isinstance(epi, NibEpilogue):
+        if hy or hx:
+            raise ValueError("input halos are passed as a physically padded image for nibble planes")
+        alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
+        ohy, ohx = (int(v) for v in epi.out_halo)
+        ldn = pixel_ld_nib(Cout)
+        rows = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
+        plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)
+        with _on(dev):
+            if ohy or ohx:
+                _lib.call("qt_zero_halo", _p(plane), I(N), I(Ho), I(Wo), I(ldn), I(ohy), I(ohx), _stream(dev))
+            _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(plane), I(ldn), I(Cout), I(ohy), I(ohx),
+                      _stream(dev))
+        return NibPlanes(words=plane, rows=rows, K=Cout)
     if hy or hx:
         if epi is not None:
             raise ValueError("halo planes exist for int8 code planes (fp32 / code-epilogue outputs) only")
@@ -510,6 +533,30 @@ def pool_bits(planes: BitPlanes, N: int, H: int, W: int, pool_k: int, pool_s: in
         _lib.call("qt_pool_bits", _p(planes.sign), I(N), I(H), I(W), I(planes.ld), I(pool_k), I(pool_s),
                   _p(neg_alpha), _p(out), _stream(planes.device))
     return BitPlanes(sign=out, rows=N * Ho * Wo, K=planes.K), (Ho, Wo)
+
+
+def pool_bits_nib(planes: BitPlanes, N: int, H: int, W: int, pool_k: int, pool_s: int, neg_alpha: torch.Tensor,
+                  out_halo=(0, 0)) -> Tuple[NibPlanes, Tuple[int, int]]:
+    """pool_bits with the result written as the next conv's nibble pixel plane, optionally with a zero halo
+    (qt_pool_bits_nib = qt_pool_bits + qt_bits_to_nib_pad in one pass)."""
+    if planes.rows != N * H * W or planes.mask is not None:
+        raise ValueError("pool_bits expects the sign-only pixel plane of an [N, C, H, W] activation")
+    if neg_alpha.numel() != planes.ld or neg_alpha.dtype != torch.int32:
+        raise ValueError("neg_alpha must be neg_alpha_words(alpha) of the same channel count")
+    if pool_k > H or pool_k > W:
+        raise ValueError("pooling window larger than the image")
+    hy, hx = (int(v) for v in out_halo)
+    Ho, Wo = (H - pool_k) // pool_s + 1, (W - pool_k) // pool_s + 1
+    ldn = pixel_ld_nib(planes.K)
+    rows = N * (Ho + 2 * hy) * (Wo + 2 * hx)
+    out = torch.empty((rows, ldn), dtype=torch.int32, device=planes.device)
+    I = int
+    with _on(planes.device):
+        if hy or hx:
+            _lib.call("qt_zero_halo", _p(out), I(N), I(Ho), I(Wo), I(ldn), I(hy), I(hx), _stream(planes.device))
+        _lib.call("qt_pool_bits_nib", _p(planes.sign), I(N), I(H), I(W), I(planes.ld), I(pool_k), I(pool_s),
+                  _p(neg_alpha), _p(out), I(ldn), I(planes.K), I(hy), I(hx), _stream(planes.device))
+    return NibPlanes(words=out, rows=rows, K=planes.K), (Ho, Wo)
 
 
 def sign_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:

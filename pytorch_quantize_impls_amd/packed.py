@@ -66,13 +66,20 @@ class PackedActivation:
     dtype = torch.float32
     requires_grad = False
 
-    def __init__(self, planes: BitPlanes, shape):
+    def __init__(self, planes: Optional[BitPlanes], shape, nib=None, halo=(0, 0)):
+        # Between two fused binarised convs the producer may hand over the consumer's operand itself instead of bit
+        # planes: ``nib`` = ops.NibPlanes of the (N, C, H, W) activation as an fp4 nibble pixel plane with a zero border
+        # of ``halo`` pixels (= the consuming conv's padding); ``planes`` is then None.
+        if (planes is None) == (nib is None):
+            raise ValueError("a PackedActivation holds either bit planes or a nibble pixel plane")
         self.planes = planes
+        self.nib = nib
+        self.halo = tuple(int(v) for v in halo)
         self.shape = tuple(int(v) for v in shape)
 
     @property
     def device(self):
-        return self.planes.device
+        return self.planes.device if self.planes is not None else self.nib.device
 
     def dim(self):
         return len(self.shape)
@@ -84,6 +91,8 @@ class PackedActivation:
         """(N, C, H, W) NHWC planes -> (N, H*W*C) row planes in (h, w, c) order.  Needs C % 32 == 0 and
         an unpadded pixel stride so the words of one image are contiguous; the consumer's weight
         columns must be permuted to the same order (layers.fused.permute_fc_weight_hwc)."""
+        if self.planes is None:
+            raise ValueError("this activation was produced as a conv operand (nibble plane): no bit planes to flatten")
         N, C, H, W = self.shape
         if self.planes.ld * 32 != C:
             raise ValueError("flatten_hwc needs C to be a multiple of 128 (unpadded 16-byte pixel rows)")

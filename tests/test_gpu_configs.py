@@ -215,7 +215,17 @@ def test_c5_ternary_vgg16_fused_matches_unfused(dev):
     before = dict(_lib.call_counts)
     with torch.no_grad():
         yf = fused(x)
-        assert _lib.call_counts["qt_conv2d_implicit_bits"] - before.get("qt_conv2d_implicit_bits", 0) == 13
+        used = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
+        # 13 convs: the 5 in front of a pool emit threshold bits, the 8 that feed another conv directly (the real-input
+        # first layer included) emit that conv's nibble operand; 4 of the 5 pools do the same (the last feeds the FC)
+        assert used.get("qt_conv2d_implicit_bits") == 5 and used.get("qt_conv2d_implicit_nib") == 8, used
+        assert used.get("qt_pool_bits_nib") == 4 and used.get("qt_pool_bits") == 1, used
+        assert "qt_bits_to_nib_pad" not in used, used               # no bit plane is expanded in a second pass
         yu = model(x)
+        # the hand-over of conv operands changes no bit: same logits with the links removed
+        for m in fused.features:
+            if hasattr(m, "out_nib_halo"):
+                m.out_nib_halo = None
+        assert torch.equal(fused(x), yf)
     # identical unless a BatchNorm threshold tie flips a bit (MIOpen's BatchNorm vs the folded form)
     assert (yf - yu).abs().max() <= 0.02 * yu.abs().max() + 1e-3, float((yf - yu).abs().max())

@@ -1326,6 +1326,36 @@ def test_conv_code_epilogue_equals_conv_then_fused_quantiser(dev, oracle, Cin, C
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,ksz,st,pd,halo", [(32, 64, 3, 1, 1, (1, 1)), (64, 40, 3, 2, 1, (0, 0)), (96, 200, 5, 1, 2, (2, 1)),
+                                                      (32, 7, 1, 1, 0, (1, 0)), (128, 384, 3, 1, 1, (1, 1))])
+def test_nibble_plane_epilogue_equals_bits_then_expand(dev, Cin, Cout, ksz, st, pd, halo):
+    """qt_conv2d_implicit_nib (threshold bits written as the next conv's fp4 nibble pixel plane, with a zero halo) ==
+    qt_conv2d_implicit_bits followed by qt_bits_to_nib_pad; qt_pool_bits_nib == qt_pool_bits + qt_bits_to_nib_pad."""
+    N, H, W = 3, 10, 9
+    x = g(synth.pm1(31, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    px = ops.pack_pixels_nib(x)
+    wp = ops.pack_conv_weight_nib(g(synth.uniform(32, (Cout, Cin, ksz, ksz), -1, 1), dev), "ternary")
+    b = g(synth.uniform(33, (Cout,), -2, 2), dev)
+    alpha, beta = g(synth.uniform(34, (Cout,), -1, 1), dev), g(synth.uniform(35, (Cout,), -3, 3), dev)
+    Ho, Wo = ops.conv_out_hw(H, W, ksz, ksz, st, pd, 1)
+    bits = ops.conv2d_nib(px, (N, Cin, H, W), wp, (ksz, ksz), b, st, pd, 1, epi=(alpha, beta))
+    want = ops.bits_to_nib_pad(bits, N, Ho, Wo, halo, ld=ops.pixel_ld_nib(Cout))
+    junk = torch.full(tuple(want.words.shape), 0x55555555, dtype=torch.int32, device=dev)   # poison the block torch.empty reuses
+    del junk
+    got = ops.conv2d_nib(px, (N, Cin, H, W), wp, (ksz, ksz), b, st, pd, 1, epi=ops.NibEpilogue(alpha, beta, halo))
+    assert isinstance(got, ops.NibPlanes) and got.rows == want.rows and got.K == Cout
+    assert torch.equal(got.words, want.words)
+    if min(Ho, Wo) >= 2:
+        na = ops.neg_alpha_words(alpha)
+        pooled, (Hq, Wq) = ops.pool_bits(bits, N, Ho, Wo, 2, 2, na)
+        want_p = ops.bits_to_nib_pad(pooled, N, Hq, Wq, halo, ld=ops.pixel_ld_nib(Cout))
+        junk = torch.full(tuple(want_p.words.shape), 0x55555555, dtype=torch.int32, device=dev)
+        del junk
+        got_p, hw = ops.pool_bits_nib(bits, N, Ho, Wo, 2, 2, na, halo)
+        assert hw == (Hq, Wq) and torch.equal(got_p.words, want_p.words)
+
+
+@pytest.mark.gpu
 def test_fused_dorefa_pre_relu_and_code_pool_vs_oracle(dev, oracle):
     """The two other module orders of the reference's DoReFa examples: ReLU in front of the BatchNorm
     (models/FullNet/DorefaMNIST.py:46-48) and MaxPool2d after the quantiser (models/samples/AlexNet_Dorefa.py:38-41),
