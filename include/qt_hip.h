@@ -226,8 +226,8 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
 /* MaxPool2d(pool_k, pool_s) (no padding, floor mode) on an NHWC int8 DoReFa code plane: the reference pools after the
  * quantiser (models/samples/AlexNet_Dorefa.py:38-41) and fl(inv_n * code) is monotone in the code, so the max over
  * the codes is bit-identical to pooling the fp32 image and re-deriving the codes.
- * in [N][H][W][ld_bytes] -> out [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ld_bytes], interior pixels only (zero the
- * border of a halo plane with qt_zero_halo).  ld_bytes % 16 == 0. */
+ * in [N][H][W][ld_bytes] -> out [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ld_bytes], border pixels written as zeros.
+ * ld_bytes % 16 == 0. */
 int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld_bytes, int64_t pool_k,
                      int64_t pool_s, int8_t* out_plane, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
 
@@ -305,8 +305,8 @@ int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64
 int qt_pad_pixel_plane(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t ph, int64_t pw,
                        uint32_t* Q, qt_stream_t stream);
 
-/* Zero the border pixels (only) of a halo plane Q [N][H + 2*halo_h][W + 2*halo_w][Cw words]: what the caller of
- * qt_conv2d_implicit_codes does to the output plane before (or after) the conv writes its interior. */
+/* Zero the border pixels (only) of a halo plane Q [N][H + 2*halo_h][W + 2*halo_w][Cw words]: for callers that fill
+ * the interior of such a plane themselves (the conv / pooling entry points above write their own borders). */
 int qt_zero_halo(uint32_t* Q, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t halo_h, int64_t halo_w,
                  qt_stream_t stream);
 
@@ -364,8 +364,8 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
 
 /* qt_conv2d_implicit_bits with the sign bits written as the NEXT conv's operand instead: an fp4 nibble pixel plane
  * (+1 = 0x2, -1 = 0xA, channels >= Cout zero), nib_plane [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ldn words],
- * ldn == ceil(Cout/32)*4.  The kernel writes the interior pixels; the caller zeroes the border of a halo
- * plane (qt_zero_halo) — the halo is the next conv's zero padding.  Replaces qt_conv2d_implicit_bits +
+ * ldn == ceil(Cout/32)*4.  The launch writes every word of the plane, the zero border included — the halo is the next
+ * conv's zero padding.  Replaces qt_conv2d_implicit_bits +
  * qt_bits_to_nib_pad when no pooling sits between two binarised convs. */
 int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
@@ -388,8 +388,8 @@ int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, 
  * Halo planes: a pixel plane may carry a zero border of (halo_h, halo_w) pixels around every image,
  * [N][H + 2*halo_h][W + 2*halo_w][C]: the zero padding of a conv that reads it is then physical and the conv runs
  * the un-padded kernels (no per-tap bounds checks).  in_halo_*: halo of P (needs ph <= in_halo_h, pw <= in_halo_w;
- * QT_ERR_UNSUPPORTED when the plane exceeds 4 GiB); out_halo_*: halo of `codes` — the caller zeroes the border
- * (qt_zero_halo or a fill), the kernel writes the interior pixels; res_halo_*: halo of `res_codes`. */
+ * QT_ERR_UNSUPPORTED when the plane exceeds 4 GiB); out_halo_*: halo of `codes` — the launch writes
+ * the interior pixels and the zero border (every byte of the plane); res_halo_*: halo of `res_codes`. */
 int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                              int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void pool_bits_kernel(const uint32_t* __restri
 }
 
 // qt_pool_bits with the result expanded to the next conv's fp4 nibble pixel plane (+1 = 0x2, -1 = 0xA, channels >= C
-// zero), optionally into a halo plane [N][Ho + 2hy][Wo + 2hx][ldn] (interior only): pool_bits + bits_to_nib_pad in
-// one pass.  One thread = one 32-channel group of one output pixel (4 nibble words).
+// zero), optionally into a halo plane [N][Ho + 2hy][Wo + 2hx][ldn] (border written as zeros): pool_bits +
+// bits_to_nib_pad in one pass.  One thread = one 32-channel group of one output pixel (4 nibble words).
 __device__ __forceinline__ uint32_t fe_spread8(uint32_t b) {
     uint32_t t = b & 0xFFu;
     t = (t | (t << 12)) & 0x000F000Fu;
@@ -112,17 +112,17 @@ __global__ __launch_bounds__(256) void pool_bits_nib_kernel(const uint32_t* __re
                                                             int64_t ldn, int64_t N, int H, int W, int pk, int ps, int Ho,
                                                             int Wo, int hy, int hx, int C) {
     const int64_t groups = ldn / 4;
-    const int64_t total = N * Ho * Wo * groups;
     const int Hop = Ho + 2 * hy, Wop = Wo + 2 * hx;
+    const int64_t total = N * Hop * Wop * groups;           // every pixel of the halo plane: border pixels get zeros
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = i / groups;
         const int g = (int)(i - pix * groups);
-        const int64_t n = pix / ((int64_t)Ho * Wo);
-        const int rem = (int)(pix - n * Ho * Wo);
-        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const int64_t n = pix / ((int64_t)Hop * Wop);
+        const int rem = (int)(pix - n * Hop * Wop);
+        const int ho = rem / Wop - hy, wo = rem % Wop - hx;
         uint32_t sw = 0, mw = 0;
-        if (g < ld) {
+        if (g < ld && (unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
             const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ld + g;
             uint32_t all = 0xffffffffu, any = 0u;
             for (int a = 0; a < pk; ++a)
@@ -141,39 +141,43 @@ __global__ __launch_bounds__(256) void pool_bits_nib_kernel(const uint32_t* __re
         o.y = (fe_spread8(mw >> 8) << 1) | (fe_spread8(sw >> 8) << 3);
         o.z = (fe_spread8(mw >> 16) << 1) | (fe_spread8(sw >> 16) << 3);
         o.w = (fe_spread8(mw >> 24) << 1) | (fe_spread8(sw >> 24) << 3);
-        *reinterpret_cast<uint4*>(out + ((n * Hop + ho + hy) * Wop + wo + hx) * ldn + g * 4) = o;
+        *reinterpret_cast<uint4*>(out + pix * ldn + g * 4) = o;
     }
 }
 
 // MaxPool2d(k, s) on an int8 DoReFa code plane (the reference pools AFTER the quantiser,
 // models/samples/AlexNet_Dorefa.py:38-41: x = quant(relu(bn(conv))); x = pool(x)).  value = fl(inv_n * code) is
 // monotone in the code, so the max of the codes IS the code of the max: bit-identical to pooling the fp32 image.
-// in [N][H][W][ld bytes] -> out [N][Ho + 2hy][Wo + 2hx][ld] (interior only; the caller zeroes a halo border).
+// in [N][H][W][ld bytes] -> out [N][Ho + 2hy][Wo + 2hx][ld] (the halo border is written as zeros).
 // One thread = 4 channels (one dword) of one output pixel.
 __global__ __launch_bounds__(256) void pool_codes_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                          int64_t ldw, int64_t N, int H, int W, int pk, int ps, int Ho,
                                                          int Wo, int hy, int hx) {
-    const int64_t total = N * Ho * Wo * ldw;
     const int Hop = Ho + 2 * hy, Wop = Wo + 2 * hx;
+    const int64_t total = N * Hop * Wop * ldw;              // every pixel of the halo plane: border pixels get zeros
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = i / ldw;
         const int w = (int)(i - pix * ldw);
-        const int64_t n = pix / ((int64_t)Ho * Wo);
-        const int rem = (int)(pix - n * Ho * Wo);
-        const int ho = rem / Wo, wo = rem - ho * Wo;
-        const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ldw + w;
-        int m0 = -128, m1 = -128, m2 = -128, m3 = -128;
-        for (int a = 0; a < pk; ++a)
-            for (int b = 0; b < pk; ++b) {
-                const uint32_t v = base[((int64_t)a * W + b) * ldw];
-                m0 = max(m0, (int)(int8_t)v);
-                m1 = max(m1, (int)(int8_t)(v >> 8));
-                m2 = max(m2, (int)(int8_t)(v >> 16));
-                m3 = max(m3, (int)(int8_t)(v >> 24));
-            }
-        out[((n * Hop + ho + hy) * Wop + wo + hx) * ldw + w] =
-            (uint32_t)(uint8_t)m0 | ((uint32_t)(uint8_t)m1 << 8) | ((uint32_t)(uint8_t)m2 << 16) | ((uint32_t)(uint8_t)m3 << 24);
+        const int64_t n = pix / ((int64_t)Hop * Wop);
+        const int rem = (int)(pix - n * Hop * Wop);
+        const int ho = rem / Wop - hy, wo = rem % Wop - hx;
+        uint32_t word = 0;
+        if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
+            const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ldw + w;
+            int m0 = -128, m1 = -128, m2 = -128, m3 = -128;
+            for (int a = 0; a < pk; ++a)
+                for (int b = 0; b < pk; ++b) {
+                    const uint32_t v = base[((int64_t)a * W + b) * ldw];
+                    m0 = max(m0, (int)(int8_t)v);
+                    m1 = max(m1, (int)(int8_t)(v >> 8));
+                    m2 = max(m2, (int)(int8_t)(v >> 16));
+                    m3 = max(m3, (int)(int8_t)(v >> 24));
+                }
+            word = (uint32_t)(uint8_t)m0 | ((uint32_t)(uint8_t)m1 << 8) | ((uint32_t)(uint8_t)m2 << 16) |
+                   ((uint32_t)(uint8_t)m3 << 24);
+        }
+        out[pix * ldw + w] = word;
     }
 }
 
@@ -190,7 +194,7 @@ extern "C" int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, 
     if ((ld & 3) || (ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
     if (H > 32767 || W > 32767 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_UNSUPPORTED;
     const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;
-    const int grid = qt_stream_grid((N * Ho * Wo * (ldn / 4) + 255) / 256);
+    const int grid = qt_stream_grid((N * (Ho + 2 * out_halo_h) * (Wo + 2 * out_halo_w) * (ldn / 4) + 255) / 256);
     hipLaunchKernelGGL(pool_bits_nib_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in_plane, nib_plane,
                        neg_alpha, ld, ldn, N, (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo,
                        (int)out_halo_h, (int)out_halo_w, (int)C);
@@ -209,7 +213,7 @@ extern "C" int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, in
     if (H > 32767 || W > 32767 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_UNSUPPORTED;
     const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;  // floor mode, no padding
     const int64_t ldw = ld_bytes / 4;
-    const int grid = qt_stream_grid((N * Ho * Wo * ldw + 255) / 256);
+    const int grid = qt_stream_grid((N * (Ho + 2 * out_halo_h) * (Wo + 2 * out_halo_w) * ldw + 255) / 256);
     hipLaunchKernelGGL(pool_codes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint32_t*>(in_plane), reinterpret_cast<uint32_t*>(out_plane), ldw, N,
                        (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo, (int)out_halo_h, (int)out_halo_w);

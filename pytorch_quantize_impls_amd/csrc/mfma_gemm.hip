@@ -155,9 +155,9 @@ struct EpiArgs {
     int32_t* overflow = nullptr;
     // halo planes: the code plane (and a residual code plane) may carry a zero border of (hy, hx) pixels around
     // each image, [N][Ho + 2hy][Wo + 2hx][ld]: output row m = (img, ho, wo) lands on pixel
-    // (img, ho + hy, wo + hx) so the NEXT conv's zero padding is physical and it runs the un-padded kernels.  The caller
-    // zero-fills a halo plane (writing the border from the edge pixels' lanes was measured: +10 us per conv of the C4
-    // ResNet against 5 us for the fill — divergent short loops in an already VALU-heavy epilogue).
+    // (img, ho + hy, wo + hx) so the NEXT conv's zero padding is physical and it runs the un-padded kernels.  The border
+    // is zeroed by 64 extra workgroups appended to the launch (zero_halo_border); writing it from the edge pixels' lanes
+    // was measured at +10 us per conv of the C4 ResNet (divergent short loops in an already VALU-heavy epilogue).
     int ohy = 0, ohx = 0, rhy = 0, rhx = 0;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
@@ -169,6 +169,31 @@ __device__ __forceinline__ uint32_t spread8(uint32_t b) {
     t = (t | (t << 6)) & 0x03030303u;
     t = (t | (t << 3)) & 0x11111111u;
     return t;
+}
+
+// Zero border of a halo output plane [nimg][Ho + 2hy][Wo + 2hx][cpp 16-byte chunks], done by the surplus workgroups a
+// halo-plane launch appends to its grid (they run in the tail of the launch, when CUs idle anyway): a separate 5 us
+// launch per conv otherwise (9 % of the fused DoReFa ResNet-18 forward).  Border pixel order: top rows, then the 2*hx side
+// pixels of every interior row, then the bottom rows.
+__device__ __forceinline__ void zero_halo_border(void* plane, int cpp, int64_t nimg, int H, int W, int hy, int hx,
+                                                 int zb, int nzb) {
+    const int Hp = H + 2 * hy, Wp = W + 2 * hx;
+    const int top = hy * Wp, side = 2 * hx * H, per_img = 2 * top + side;
+    const int64_t total = nimg * per_img * cpp;
+    uint4* Q = reinterpret_cast<uint4*>(plane);
+    for (int64_t t = (int64_t)zb * blockDim.x + threadIdx.x; t < total; t += (int64_t)nzb * blockDim.x) {
+        const int64_t bp = t / cpp;
+        const int c = (int)(t - bp * cpp);
+        const int64_t n = bp / per_img;
+        const int b = (int)(bp - n * per_img);
+        int pix;
+        if (b < top) pix = b;
+        else if (b < top + side) {
+            const int s2 = b - top, r = s2 / (2 * hx), k = s2 - r * 2 * hx;
+            pix = (hy + r) * Wp + (k < hx ? k : W + k);
+        } else pix = (hy + H) * Wp + (b - top - side);
+        Q[(n * Hp * Wp + pix) * (int64_t)cpp + c] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 // ---- element types ----------------------------------------------------------------------------------
@@ -269,6 +294,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         const int gx = (N + C::TN - 1) / C::TN, gy = (M + C::TM - 1) / C::TM;
         const int ntiles = gx * gy, per_xcd = (ntiles + 7) >> 3;
         const int b = blockIdx.x;
+        if constexpr (C::CONV) {
+            if (b >= 8 * per_xcd) {                    // appended by launch_cfg for halo output planes
+                zero_halo_border(Y, (int)(epi.mode == 2 ? ldy / 16 : ldy / 4), (int64_t)M / (cg.Ho * cg.Wo), cg.Ho, cg.Wo,
+                                 epi.ohy, epi.ohx, b - 8 * per_xcd, (int)gridDim.x - 8 * per_xcd);
+                return;
+            }
+        }
         const int o = (b & 7) * per_xcd + (b >> 3);
         if (o >= ntiles) return;                       // uniform for the workgroup, before any barrier
         if ((gx & 7) == 0 && (gy & 3) == 0) {
@@ -719,7 +751,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 // pad bytes past the last column tile (row strides rounded beyond the tile width)
-                // (a halo plane is zero-filled by the caller: its border pixels belong to no tile)
+                // (a halo plane has ldy == Cout rounded up to 16: no bytes past the tile columns)
                 if (!halo && b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && mb + lane < M)
                     for (int c = n0 + C::TN; c < ldy; c += 4)
                         *reinterpret_cast<uint32_t*>(Q + (int64_t)(mb + lane) * ldy + c) = 0u;
@@ -848,7 +880,8 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
                qt_stream_t stream, const ConvArgs& cg = ConvArgs{}, const EpiArgs& epi = EpiArgs{}) {
     const int64_t gy = (M + C::TM - 1) / C::TM, gx = (N + C::TN - 1) / C::TN;
     if (gx * gy > (1ll << 30)) return QT_ERR_UNSUPPORTED;
-    const unsigned grid = (unsigned)((gx * gy + 7) / 8 * 8);
+    unsigned grid = (unsigned)((gx * gy + 7) / 8 * 8);
+    if (C::CONV && (epi.mode == 2 || epi.mode == 3) && (epi.ohy | epi.ohx)) grid += 64;   // border-zeroing workgroups
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
     // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
     const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0);

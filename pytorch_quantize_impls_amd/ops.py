@@ -117,10 +117,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         elif rhy or rhx:
             raise ValueError("res_halo needs res_codes")
         ldc = code_ld_bytes(Cout, 16)
-        codes = torch.empty((Mo, ldc), dtype=torch.int8, device=dev)
-        if ohy or ohx:      # only the border of a halo plane needs zeros (the next conv's padding); the conv writes the rest
-            with _on(dev):
-                _lib.call("qt_zero_halo", _p(codes), I(N), I(Ho), I(Wo), I(ldc // 4), I(ohy), I(ohx), _stream(dev))
+        codes = torch.empty((Mo, ldc), dtype=torch.int8, device=dev)   # the launch writes every byte, halo border included
         flag = epi.overflow if epi.overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
         with _on(dev):
             _lib.call("qt_conv2d_implicit_codes", *head, _p(alpha), _p(beta), _p(rf), I(ldr), _p(ra), _p(rb), _p(rc),
@@ -138,8 +135,6 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         rows = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
         plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)
         with _on(dev):
-            if ohy or ohx:
-                _lib.call("qt_zero_halo", _p(plane), I(N), I(Ho), I(Wo), I(ldn), I(ohy), I(ohx), _stream(dev))
             _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(plane), I(ldn), I(Cout), I(ohy), I(ohx),
                       _stream(dev))
         return NibPlanes(words=plane, rows=rows, K=Cout)
@@ -552,8 +547,6 @@ def pool_bits_nib(planes: BitPlanes, N: int, H: int, W: int, pool_k: int, pool_s
     out = torch.empty((rows, ldn), dtype=torch.int32, device=planes.device)
     I = int
     with _on(planes.device):
-        if hy or hx:
-            _lib.call("qt_zero_halo", _p(out), I(N), I(Ho), I(Wo), I(ldn), I(hy), I(hx), _stream(planes.device))
         _lib.call("qt_pool_bits_nib", _p(planes.sign), I(N), I(H), I(W), I(planes.ld), I(pool_k), I(pool_s),
                   _p(neg_alpha), _p(out), I(ldn), I(planes.K), I(hy), I(hx), _stream(planes.device))
     return NibPlanes(words=out, rows=rows, K=planes.K), (Ho, Wo)
@@ -745,8 +738,6 @@ def pool_codes(codes: CodePlanes, N: int, H: int, W: int, pool_k: int, pool_s: i
     out = torch.empty((N * (Ho + 2 * hy) * (Wo + 2 * hx), ld), dtype=torch.int8, device=dev)
     I = int
     with _on(dev):
-        if hy or hx:
-            _lib.call("qt_zero_halo", _p(out), I(N), I(Ho), I(Wo), I(ld // 4), I(hy), I(hx), _stream(dev))
         _lib.call("qt_pool_codes_i8", _p(codes.codes), I(N), I(H), I(W), I(ld), I(pool_k), I(pool_s), _p(out), I(hy),
                   I(hx), _stream(dev))
     return CodePlanes(codes=out, rows=int(out.shape[0]), K=codes.K, inv_n=codes.inv_n, bit_width=codes.bit_width,
@@ -958,6 +949,18 @@ def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> tor
     with _on(words.device):
         _lib.call("qt_pad_pixel_plane", _p(words), I(N), I(H), I(W), I(ld), I(ph), I(pw), _p(out), _stream(words.device))
     return out
+
+
+def zero_halo(words: torch.Tensor, N: int, H: int, W: int, halo) -> torch.Tensor:
+    """Zero (in place) the border pixels of a halo plane [N*(H+2hy)*(W+2hx), Cw] of any element type; for callers that
+    fill the interior themselves (the conv / pooling entry points write their own borders)."""
+    hy, hx = _pairs(halo)
+    ld = int(words.shape[1]) * words.element_size() // 4
+    if int(words.shape[0]) != N * (H + 2 * hy) * (W + 2 * hx):
+        raise ValueError("plane does not hold an [N, H + 2hy, W + 2hx] image")
+    with _on(words.device):
+        _lib.call("qt_zero_halo", _p(words), int(N), int(H), int(W), ld, hy, hx, _stream(words.device))
+    return words
 
 
 def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=None, stride=1,

@@ -1356,6 +1356,19 @@ def test_nibble_plane_epilogue_equals_bits_then_expand(dev, Cin, Cout, ksz, st, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("halo", [(1, 1), (2, 0), (0, 3)])
+def test_zero_halo_touches_only_the_border(dev, halo):
+    N, H, W, C = 3, 5, 7, 48
+    hy, hx = halo
+    plane = torch.randint(1, 100, (N * (H + 2 * hy) * (W + 2 * hx), C), dtype=torch.int8, device=dev)
+    before = plane.clone().view(N, H + 2 * hy, W + 2 * hx, C)
+    ops.zero_halo(plane, N, H, W, halo)
+    after = plane.view(N, H + 2 * hy, W + 2 * hx, C)
+    assert torch.equal(after[:, hy:hy + H, hx:hx + W], before[:, hy:hy + H, hx:hx + W])
+    assert int(after.sum()) == int(before[:, hy:hy + H, hx:hx + W].sum())
+
+
+@pytest.mark.gpu
 def test_fused_dorefa_pre_relu_and_code_pool_vs_oracle(dev, oracle):
     """The two other module orders of the reference's DoReFa examples: ReLU in front of the BatchNorm
     (models/FullNet/DorefaMNIST.py:46-48) and MaxPool2d after the quantiser (models/samples/AlexNet_Dorefa.py:38-41),
