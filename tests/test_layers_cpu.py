@@ -289,3 +289,44 @@ def test_fused_feature_classifier_validates_its_inputs():
     assert [type(x).__name__ for x in mv.features] == ["FusedConvPoolBnSign", "PackedMaxPool"]
     with pytest.raises(ValueError, match="eval-mode"):
         FusedFeatureClassifier(feats.train(), clf, (8, 4, 4))
+
+
+def test_fused_module_host_logic():
+    """Host-side logic of the inference-fusion modules that needs no GPU: operand hand-over links, ReLU placement
+    parsing, shape validation of code / nibble activations, and that CPU tensors are refused loudly."""
+    import pytest
+    import torch
+    from pytorch_quantize_impls_amd import ops, packed
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    from pytorch_quantize_impls_amd.layers import (BinConv2d, CodeMaxPool, FusedBnDorefaQuant, FusedConvPoolBnSign,
+                                                   PackedMaxPool, fuse_sequential)
+    seq = torch.nn.Sequential(
+        BinConv2d(32, 64, 3, padding=1), torch.nn.BatchNorm2d(64), torch.nn.Hardtanh(), BinaryConnect(stochastic=False),
+        BinConv2d(64, 64, 5, padding=(2, 1)), torch.nn.BatchNorm2d(64), torch.nn.Hardtanh(), BinaryConnect(stochastic=False),
+        torch.nn.MaxPool2d(2, 2),
+        BinConv2d(64, 32, 3, padding=0), torch.nn.MaxPool2d(2, 2), torch.nn.BatchNorm2d(32), torch.nn.Hardtanh(),
+        BinaryConnect(stochastic=False)).eval()
+    fused = list(fuse_sequential(seq, fuse_conv=True, packed_pool=True))
+    assert [type(m) for m in fused] == [FusedConvPoolBnSign, FusedConvPoolBnSign, PackedMaxPool, FusedConvPoolBnSign]
+    # each producer is told the padding of the fused conv that consumes it; the last block has no consumer
+    assert fused[0].out_nib_halo == (2, 1)          # feeds the 5x5 conv padded (2, 1)
+    assert fused[1].out_nib_halo is None            # feeds a PackedMaxPool, which needs bit planes
+    assert fused[2].out_nib_halo == (0, 0)          # the pool feeds the un-padded 3x3 conv
+    assert fused[3].out_nib_halo is None
+    assert [ops.relu_mode(v) for v in (False, None, True, "post", "pre")] == [0, 0, 1, 1, 2]
+    with pytest.raises(ValueError, match="relu must be"):
+        ops.relu_mode("around")
+    # activations validate their geometry
+    codes = ops.CodePlanes(codes=torch.zeros((2 * 6 * 7, 16), dtype=torch.int8), rows=2 * 6 * 7, K=12)
+    with pytest.raises(ValueError, match="needs"):
+        packed.CodeActivation(codes, (2, 12, 4, 5))                 # 2*4*5 pixels expected, plane holds 2*6*7
+    act = packed.CodeActivation(codes, (2, 12, 4, 5), halo=(1, 1))  # ... which is the same image with a 1-pixel halo
+    assert act.without_halo().codes.rows == 2 * 4 * 5 and act.without_halo().halo == (0, 0)
+    with pytest.raises(ValueError, match="either bit planes or a nibble"):
+        packed.PackedActivation(None, (1, 8, 2, 2))
+    with pytest.raises(ValueError, match="only un-padded"):
+        CodeMaxPool(torch.nn.MaxPool2d(3, 2, padding=1))
+    # no CPU fallback: the fused quantiser refuses host tensors instead of computing something else
+    q = FusedBnDorefaQuant(torch.nn.BatchNorm2d(12).eval(), 4)
+    with pytest.raises(TypeError, match="HIP device"):
+        q(torch.zeros(1, 12, 3, 3))
