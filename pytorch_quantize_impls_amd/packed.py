@@ -106,8 +106,8 @@ class CodeActivation:
 
     ``codes``: ops.CodePlanes; ``shape``: logical shape, (N, C, H, W) with NHWC planes (rows = N*H*W, K = C) or
     (N, K).  The reference does not clamp the quantiser, so a code may not fit int8: the kernels then raise the
-    shared device flag ``codes.overflow`` and ``check()`` / ``float()`` (one host sync, normally at the end of the
-    network) turn it into an error — there is no fp32 image to fall back to."""
+    shared device flag ``codes.overflow``; ``float()`` turns a raised flag into an all-NaN result on the device (no
+    host sync) and ``check()`` / ``float(check=True)`` into an error — there is no fp32 image to fall back to."""
     is_cuda = True
     dtype = torch.float32
     requires_grad = False
@@ -173,13 +173,23 @@ class CodeActivation:
                                "path: run this model module by module (the fp32 route keeps unclamped activations)")
         return self
 
-    def float(self) -> torch.Tensor:
-        """The fp32 image nnDorefaQuant would have returned, fl(fl(1/n) * q); (N, C, H, W) comes back channels_last."""
-        self.check()
+    def float(self, check: bool = False) -> torch.Tensor:
+        """The fp32 image nnDorefaQuant would have returned, fl(fl(1/n) * q); (N, C, H, W) comes back channels_last.
+
+        The int8 range flag of the chain is applied ON THE DEVICE: if any code of the chain left int8 the whole
+        result is NaN (no host sync, so the host keeps enqueueing the next forward; 0.89 -> 0.77 ms on the fused
+        ResNet-18).  ``check=True`` (or ``check()``) synchronises and raises instead."""
+        if check:
+            self.check()
         C = self.codes.K
         if len(self.shape) == 4:
             N, C_, H, W = self.shape
             hy, hx = self.halo
             q = self.codes.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W, :C]
-            return (q.to(torch.float32) * self.codes.inv_n).permute(0, 3, 1, 2)
-        return (self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n).view(self.shape)
+            y = (q.to(torch.float32) * self.codes.inv_n).permute(0, 3, 1, 2)
+        else:
+            y = (self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n).view(self.shape)
+        from . import ops
+        if self.codes.overflow is not None and not ops.ASSUME_CODES_FIT:
+            y = torch.where(self.codes.overflow.reshape(()) != 0, torch.full((), float("nan"), device=y.device), y)
+        return y

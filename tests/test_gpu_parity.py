@@ -1283,7 +1283,10 @@ def test_fused_bn_dorefa_quant_vs_oracle(dev, oracle, shape, k, relu, res):
         np.testing.assert_array_equal(act.float().cpu().numpy(), want_y)
     else:
         with pytest.raises(RuntimeError, match="exceeded int8"):
-            act.float()
+            act.check()
+        with pytest.raises(RuntimeError, match="exceeded int8"):
+            act.float(check=True)
+        assert bool(torch.isnan(act.float()).all())          # device-side predication: no sync, NaN result
 
 
 @pytest.mark.gpu
