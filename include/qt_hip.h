@@ -366,12 +366,17 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
  * (+1 = 0x2, -1 = 0xA, channels >= Cout zero), nib_plane [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ldn words],
  * ldn == ceil(Cout/32)*4.  The launch writes every word of the plane, the zero border included — the halo is the next
  * conv's zero padding.  Replaces qt_conv2d_implicit_bits +
- * qt_bits_to_nib_pad when no pooling sits between two binarised convs. */
+ * qt_bits_to_nib_pad when no pooling sits between two binarised convs.
+ * d2s_cout != 0 (depth-to-space by 2): Cout == 4*d2s_cout columns ordered (dy, dx, channel) are written to pixel
+ * (2*ho + dy, 2*wo + dx) of a [N][2*Ho + 2*halo_h][2*Wo + 2*halo_w][ldn] plane with d2s_cout channels
+ * (ldn == ceil(d2s_cout/32)*4, d2s_cout % 32 == 0): the epilogue of the 2x2 output-blocked form of a few-channel
+ * stride-1 3x3 first layer (a 4x4 stride-2 conv embedding the four shifted copies of the 3x3 kernel). */
 int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                            int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
                            const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
-                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
+                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, int64_t d2s_cout,
+                           qt_stream_t stream);
 
 /* qt_pool_bits with the pooled bits written the same way (nibble pixel plane of C channels, optional halo):
  * qt_pool_bits + qt_bits_to_nib_pad in one pass. */

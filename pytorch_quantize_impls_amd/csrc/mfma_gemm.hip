@@ -159,6 +159,11 @@ struct EpiArgs {
     // is zeroed by 64 extra workgroups appended to the launch (zero_halo_border); writing it from the edge pixels' lanes
     // was measured at +10 us per conv of the C4 ResNet (divergent short loops in an already VALU-heavy epilogue).
     int ohy = 0, ohx = 0, rhy = 0, rhx = 0;
+    // mode 3 only: depth-to-space by 2.  The N = 4*d2s_cout output columns are (dy, dx, channel): column block nb of
+    // output row (img, ho, wo) belongs to pixel (img, 2*ho + dy, 2*wo + dx) of a [2*Ho][2*Wo] image with d2s_cout
+    // channels — the 2x2 output-blocked form of a few-channel stride-1 first layer (a 4x4 stride-2 conv that embeds
+    // the four shifted copies of the 3x3 kernel), which gathers a quarter of the bytes of the direct form.
+    int d2s_cout = 0;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
 
@@ -296,8 +301,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         const int b = blockIdx.x;
         if constexpr (C::CONV) {
             if (b >= 8 * per_xcd) {                    // appended by launch_cfg for halo output planes
-                zero_halo_border(Y, (int)(epi.mode == 2 ? ldy / 16 : ldy / 4), (int64_t)M / (cg.Ho * cg.Wo), cg.Ho, cg.Wo,
-                                 epi.ohy, epi.ohx, b - 8 * per_xcd, (int)gridDim.x - 8 * per_xcd);
+                const int zs = epi.d2s_cout ? 2 : 1;
+                zero_halo_border(Y, (int)(epi.mode == 2 ? ldy / 16 : ldy / 4), (int64_t)M / (cg.Ho * cg.Wo), zs * cg.Ho,
+                                 zs * cg.Wo, epi.ohy, epi.ohx, b - 8 * per_xcd, (int)gridDim.x - 8 * per_xcd);
                 return;
             }
         }
@@ -788,17 +794,28 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 if constexpr (C::CONV) if (epi.mode == 3) {
                     // the sign word of (pixel m, channels nb..nb+31) as 32 fp4 nibbles = 4 words of the next conv's
                     // pixel plane (what qt_bits_to_nib_pad would produce from the bit plane in a second pass)
-                    if (lane < 32 && m < M && wcol * 4 < ldy) {
+                    int cgrp = wcol, left = N - nb, dyx = 0;
+                    bool live = wcol * 4 < ldy;
+                    if (epi.d2s_cout) {
+                        dyx = nb / epi.d2s_cout;
+                        const int cb = nb - dyx * epi.d2s_cout;
+                        cgrp = cb >> 5;
+                        left = epi.d2s_cout - cb;
+                        live = nb < N;
+                    }
+                    if (lane < 32 && m < M && live) {
                         int orow = m;
-                        if (epi.ohy | epi.ohx) {
+                        if (epi.ohy | epi.ohx | epi.d2s_cout) {
                             const unsigned um = (unsigned)m;
                             const unsigned img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
                             const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
                             const unsigned ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
                             const unsigned wo = rem - ho * (unsigned)cg.Wo;
-                            orow = (int)((img * (unsigned)(cg.Ho + 2 * epi.ohy) + ho + epi.ohy) * (unsigned)(cg.Wo + 2 * epi.ohx) + wo + epi.ohx);
+                            const unsigned zs = epi.d2s_cout ? 2u : 1u;
+                            const unsigned oh = zs * ho + (unsigned)(dyx >> 1), ow = zs * wo + (unsigned)(dyx & 1);
+                            orow = (int)((img * (zs * (unsigned)cg.Ho + 2u * (unsigned)epi.ohy) + oh + (unsigned)epi.ohy) *
+                                             (zs * (unsigned)cg.Wo + 2u * (unsigned)epi.ohx) + ow + (unsigned)epi.ohx);
                         }
-                        const int left = N - nb;
                         const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
                         const uint32_t sw = myword & mw;
                         uint4 o;
@@ -806,7 +823,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                         o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
                         o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
                         o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
-                        *reinterpret_cast<uint4*>(B + (int64_t)orow * ldy + wcol * 4) = o;
+                        *reinterpret_cast<uint4*>(B + (int64_t)orow * ldy + cgrp * 4) = o;
                     }
                     continue;
                 }
@@ -1286,7 +1303,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
     const int64_t M = Nimg * Ho * Wo;
     if (M == 0 || Cout == 0) return QT_OK;
-    if (!P || !Wmat || !Y || ldy < (epi.mode == 2 ? ((Cout + 3) & ~3ll) : epi.mode == 3 ? (Cout + 31) / 32 * 4 : epi.alpha ? (Cout + 31) / 32 : Cout))
+    if (!P || !Wmat || !Y || ldy < (epi.mode == 2 ? ((Cout + 3) & ~3ll) : epi.mode == 3 ? ((epi.d2s_cout ? epi.d2s_cout : Cout) + 31) / 32 * 4 : epi.alpha ? (Cout + 31) / 32 : Cout))
         return QT_ERR_INVALID_ARG;
     const int64_t kwords = kh * kw * Cw;                 // words per (virtual) im2col row
     if ((Cw & 3) || (ldwp & 31) || ldwp < kwords || !qt_aligned16(P) || !qt_aligned16(Wmat)) return QT_ERR_ALIGNMENT;
@@ -1294,8 +1311,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (M > INT32_MAX || kwords * 4 >= (1 << 20) || Cout * ldwp * 4 >= (1ll << 31) || Hp > 32767 || Wp > 32767 ||
         Hp * Wp * Cw * 4 >= (1ll << 31))   // per-image plane bytes: 32-bit tap offsets
         return QT_ERR_UNSUPPORTED;
-    if ((epi.mode == 2 || epi.mode == 3) && (epi.ohy | epi.ohx | epi.rhy | epi.rhx)) {
-        if (Nimg * (Ho + 2 * epi.ohy) * (Wo + 2 * epi.ohx) > INT32_MAX || Nimg * (Ho + 2 * epi.rhy) * (Wo + 2 * epi.rhx) > INT32_MAX)
+    if ((epi.mode == 2 || epi.mode == 3) && (epi.ohy | epi.ohx | epi.rhy | epi.rhx | epi.d2s_cout)) {
+        const int64_t zs = epi.d2s_cout ? 2 : 1;
+        if (Nimg * (zs * Ho + 2 * epi.ohy) * (zs * Wo + 2 * epi.ohx) > INT32_MAX || Nimg * (Ho + 2 * epi.rhy) * (Wo + 2 * epi.rhx) > INT32_MAX)
             return QT_ERR_UNSUPPORTED;
         const unsigned long long hw = (unsigned long long)(Ho * Wo), wo_ = (unsigned long long)Wo;
         epi.magic_hw = hw > 1 ? ~0ull / hw + 1 : 0;     // ceil(2^64 / d) for d > 1 (exact quotients for 32-bit numerators)
@@ -1325,6 +1343,10 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha)                                              \
             return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
+            /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
+            /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
+            if (g_conv_force == 0 && tn == 256 && kwords * 4 <= 1024)                                           \
+                return launch_cfg<ConvV128x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (g_conv_force != 1) {                                                                            \
                 if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
                     return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
@@ -1393,17 +1415,21 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t Nimg, int64_t H,
                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                            int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
                            const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
-                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream) {
+                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, int64_t d2s_cout,
+                           qt_stream_t stream) {
     if (!alpha || !beta) return QT_ERR_INVALID_ARG;
     if (out_halo_h < 0 || out_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_INVALID_ARG;
     if ((ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
-    if (ldn != (Cout + 31) / 32 * 4) return QT_ERR_INVALID_ARG;   // every word of a pixel is written by a column block
+    if (d2s_cout < 0 || (d2s_cout && (d2s_cout % 32 || Cout != 4 * d2s_cout))) return QT_ERR_INVALID_ARG;
+    // every word of a pixel is written by a column block
+    if (ldn != ((d2s_cout ? d2s_cout : Cout) + 31) / 32 * 4) return QT_ERR_INVALID_ARG;
     EpiArgs epi;
     epi.alpha = alpha;
     epi.beta = beta;
     epi.mode = 3;
     epi.ohy = (int)out_halo_h;
     epi.ohx = (int)out_halo_w;
+    epi.d2s_cout = (int)d2s_cout;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(nib_plane), ldn, Cout, stream, epi);
 }

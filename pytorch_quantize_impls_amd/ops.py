@@ -70,6 +70,7 @@ class NibEpilogue:
     alpha: torch.Tensor
     beta: torch.Tensor
     out_halo: tuple = (0, 0)
+    d2s_cout: int = 0               # depth-to-space by 2: the conv's 4*d2s_cout columns are (dy, dx, channel)
 
 
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
@@ -131,13 +132,17 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
             raise ValueError("input halos are passed as a physically padded image for nibble planes")
         alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
         ohy, ohx = (int(v) for v in epi.out_halo)
-        ldn = pixel_ld_nib(Cout)
-        rows = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
-        plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)
+        d2s = int(epi.d2s_cout)
+        if d2s and (d2s % 32 or Cout != 4 * d2s):
+            raise ValueError("depth-to-space epilogue: the conv must have 4 * d2s_cout columns, d2s_cout % 32 == 0")
+        zs, Cpix = (2, d2s) if d2s else (1, Cout)
+        ldn = pixel_ld_nib(Cpix)
+        rows = N * (zs * Ho + 2 * ohy) * (zs * Wo + 2 * ohx)
+        plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)     # the launch writes every word, border included
         with _on(dev):
             _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(plane), I(ldn), I(Cout), I(ohy), I(ohx),
-                      _stream(dev))
-        return NibPlanes(words=plane, rows=rows, K=Cout)
+                      I(d2s), _stream(dev))
+        return NibPlanes(words=plane, rows=rows, K=Cpix)
     if hy or hx:
         if epi is not None:
             raise ValueError("halo planes exist for int8 code planes (fp32 / code-epilogue outputs) only")
@@ -1257,6 +1262,23 @@ def s2d_weight(wq: torch.Tensor, s: int) -> torch.Tensor:
     k2 = (k + s - 1) // s * s
     wp = torch.nn.functional.pad(wq, (0, k2 - k, 0, k2 - k))
     return torch.nn.functional.pixel_unshuffle(wp, s).contiguous()
+
+
+def d2s_first_layer_applicable(Cin: int, Cout: int, kernel_hw, stride, padding, dilation, H: int, W: int) -> bool:
+    """A 3x3 / stride 1 / padding 1 conv over a few input channels (VGG's 3 -> 64 first layer) can run in its 2x2
+    output-blocked form: see ``d2s_first_layer_weight``."""
+    return (tuple(kernel_hw) == (3, 3) and _pairs(stride) == (1, 1) and _pairs(padding) == (1, 1)
+            and _pairs(dilation) == (1, 1) and Cin * 4 <= 64 and Cout % 32 == 0 and H % 2 == 0 and W % 2 == 0)
+
+
+def d2s_first_layer_weight(wq: torch.Tensor) -> torch.Tensor:
+    """[Cout, C, 3, 3] QUANTISED weight -> [4*Cout, C, 4, 4]: row (dy*2 + dx)*Cout + co holds the 3x3 kernel of channel
+    co shifted by (dy, dx) inside a 4x4 window (zeros elsewhere).  The 4x4 / stride-2 / padding-1 conv with this weight
+    computes, at block (by, bx), the four outputs (2by + dy, 2bx + dx) of the original 3x3 / stride-1 / padding-1 conv
+    (same products; each 4x4 window of the padded image is gathered once for 2x2 output pixels instead of four 3x3
+    windows), and as a stride-2 conv it takes the space-to-depth route (2x2 taps over 4C channels)."""
+    parts = [torch.nn.functional.pad(wq, (dx, 1 - dx, dy, 1 - dy)) for dy in (0, 1) for dx in (0, 1)]
+    return torch.cat(parts, 0).contiguous()
 
 
 def s2d_input(x: torch.Tensor, s: int, padding) -> torch.Tensor:

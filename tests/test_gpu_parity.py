@@ -1359,6 +1359,42 @@ def test_nibble_plane_epilogue_equals_bits_then_expand(dev, Cin, Cout, ksz, st, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,Cout,H,W", [("binary", 64, 16, 12), ("ternary", 96, 10, 14), ("binary", 32, 6, 6)])
+def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, kind, Cout, H, W):
+    """The 2x2 output-blocked form of a real-input 3x3 / stride-1 / padding-1 first layer (4x4 stride-2 conv with the
+    four shifted kernels, depth-to-space in the nibble epilogue) computes the same products as the direct form: with
+    inputs whose partial sums are exact in fp32 (multiples of 1/8) the operand handed to the next conv is identical
+    bit for bit; with Gaussian inputs only exact threshold ties may differ."""
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, FusedConvPoolBnSign, fused as fused_mod
+    N, Cin = 3, 3
+    conv = (BinConv2d if kind == "binary" else TerConv2d)(Cin, Cout, 3, padding=1).to(dev)
+    conv.weight.data.copy_(g(synth.uniform(41, (Cout, Cin, 3, 3), -1.2, 1.2), dev))
+    conv.bias.data.copy_(g(synth.uniform(42, (Cout,), -1, 1), dev))
+    conv.binary_input = False
+    conv.eval()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+    bn.running_mean.copy_(g(synth.normal(43, (Cout,)), dev)); bn.running_var.copy_(g(synth.uniform(44, (Cout,), 0.5, 4), dev))
+    bn.weight.data.copy_(g(synth.normal(45, (Cout,)), dev)); bn.bias.data.copy_(g(synth.normal(46, (Cout,)), dev))
+    blk = FusedConvPoolBnSign(conv, bn)
+    blk.out_nib_halo = (1, 1)
+    x_exact = g(np.round(synth.normal(47, (N, Cin, H, W)) * 16) / 8, dev).contiguous(memory_format=torch.channels_last)
+    x_gauss = g(synth.normal(48, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(fused_mod, "D2S_FIRST_LAYER", flag)
+        before = dict(_lib.call_counts)
+        with torch.no_grad():
+            outs[flag] = (blk(x_exact), blk(x_gauss))
+        used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+        assert used.get("qt_conv2d_implicit_nib") == 2, used
+    a, b = outs[True], outs[False]
+    assert a[0].shape == b[0].shape == (N, Cout, H, W) and a[0].halo == (1, 1)
+    assert torch.equal(a[0].nib.words, b[0].nib.words)
+    diff = (a[1].nib.words != b[1].nib.words).float().mean().item()
+    assert diff < 1e-3, diff
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("halo", [(1, 1), (2, 0), (0, 3)])
 def test_zero_halo_touches_only_the_border(dev, halo):
     N, H, W, C = 3, 5, 7, 48
