@@ -776,18 +776,24 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             const int nb = n0 + (wave_n * C::TNW + b) * 32;
             const int n = nb + lrow;
             const float bv = (bias && n < N) ? bias[n] : 0.0f;
-            const float al = n < N ? epi.alpha[n] : 0.0f, be = n < N ? epi.beta[n] : 0.0f;
+            const float al = n < N ? epi.alpha[n] : 0.0f, nbe = n < N ? -epi.beta[n] : 0.0f;
 #pragma unroll
             for (int a = 0; a < C::TMW; ++a) {
                 uint32_t myword = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float t = E::out(acc[a][b][r], scale, bv);
-                    const float v = t * al + be;   // two roundings (-ffp-contract=off), as the un-fused chain
-                    const unsigned long long mask = __ballot(v < 0.0f);
+                    // fl(fl(t*al) + be) < 0  <=>  fl(t*al) < -be: an IEEE sum of two floats has the sign of the exact
+                    // sum (a non-zero exact sum is a multiple of the smallest subnormal and cannot round to zero), NaN
+                    // and inf - inf compare false on both sides — one VALU op less per accumulator register
+                    const unsigned long long mask = __ballot(t * al < nbe);
                     const int R = (r & 3) + 8 * (r >> 2);
-                    if (lane == R) myword = (uint32_t)mask;
-                    if (lane == R + 4) myword = (uint32_t)(mask >> 32);
+                    // v_writelane: the two halves of the (scalar) ballot straight into lanes R and R + 4 (a compare + select
+                    // each before).  gfx950 does not interlock a VALU-written SGPR read by the next VALU (2 wait states)
+                    // and the hazard recogniser does not look inside inline asm: the s_nop covers the v_cmp -> first
+                    // write, the first write covers the second (they are chained through myword).
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
                 }
                 const int m = m0 + (wave_m * C::TMW + a) * 32 + lane;
                 const int wcol = nb >> 5;
@@ -816,13 +822,20 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             orow = (int)((img * (zs * (unsigned)cg.Ho + 2u * (unsigned)epi.ohy) + oh + (unsigned)epi.ohy) *
                                              (zs * (unsigned)cg.Wo + 2u * (unsigned)epi.ohx) + ow + (unsigned)epi.ohx);
                         }
-                        const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
-                        const uint32_t sw = myword & mw;
                         uint4 o;
-                        o.x = (spread8(mw) << 1) | (spread8(sw) << 3);
-                        o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
-                        o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
-                        o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
+                        if (left >= 32) {        // wave-uniform: all 32 channels exist, the magnitude nibbles are constant
+                            o.x = 0x22222222u | (spread8(myword) << 3);
+                            o.y = 0x22222222u | (spread8(myword >> 8) << 3);
+                            o.z = 0x22222222u | (spread8(myword >> 16) << 3);
+                            o.w = 0x22222222u | (spread8(myword >> 24) << 3);
+                        } else {
+                            const uint32_t mw = left > 0 ? ((1u << left) - 1u) : 0u;
+                            const uint32_t sw = myword & mw;
+                            o.x = (spread8(mw) << 1) | (spread8(sw) << 3);
+                            o.y = (spread8(mw >> 8) << 1) | (spread8(sw >> 8) << 3);
+                            o.z = (spread8(mw >> 16) << 1) | (spread8(sw >> 16) << 3);
+                            o.w = (spread8(mw >> 24) << 1) | (spread8(sw >> 24) << 3);
+                        }
                         *reinterpret_cast<uint4*>(B + (int64_t)orow * ldy + cgrp * 4) = o;
                     }
                     continue;
