@@ -378,6 +378,19 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, in
                            int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, int64_t d2s_cout,
                            qt_stream_t stream);
 
+/* Direct form of the 3x3 / stride 1 / padding 1 conv of a +-1 activation for few channels at large spatial size
+ * (VGG / ResNet early layers), where the implicit-GEMM gather of qt_conv2d_implicit_* is bound by L2 traffic (each
+ * input pixel fetched 9 times).  P: fp4 nibble pixel plane WITH a 1-pixel zero halo, [N][H+2][W+2][Cw words], Cw = 8 or
+ * 16 (64 / 128 channels); Wmat [Cout][ldw words] as for qt_conv2d_implicit (tap-major K); Cout <= 128.
+ * Threshold epilogue as qt_conv2d_implicit_bits (alpha, beta = folded BatchNorm, bit = fl((acc + bias)*alpha) + beta < 0):
+ *   out_bits == 0: out = the NEXT conv's operand, nibble plane [N][H+2][W+2][ldo] with the same halo (ldo ==
+ *                  ceil(Cout/32)*4); every word is written, the halo as zeros;
+ *   out_bits != 0: out = bit plane [N*H*W][ldo] (ldo >= ceil(Cout/32)), for a MaxPool on bits.
+ * Bit-identical to the implicit-GEMM entry points.  QT_ERR_UNSUPPORTED for other channel counts. */
+int qt_conv3x3_direct_nib(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, const uint32_t* Wmat,
+                          int64_t ldw, const float* bias, const float* alpha, const float* beta, uint32_t* out,
+                          int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream);
+
 /* qt_pool_bits with the pooled bits written the same way (nibble pixel plane of C channels, optional halo):
  * qt_pool_bits + qt_bits_to_nib_pad in one pass. */
 int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld, int64_t pool_k,

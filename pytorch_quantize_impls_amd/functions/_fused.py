@@ -263,6 +263,10 @@ def packed_conv2d(layer, act, kind: str, epi=None):
         # the producer already wrote this conv's operand: nibble pixel plane with the padding as a physical zero border
         if act.halo != (ph, pw):
             raise ValueError(f"activation carries a {act.halo} halo, this conv pads {(ph, pw)}: re-link the fused modules")
+        if ops.direct_conv3x3_applicable(C, int(layer.weight.shape[0]), (kh, kw), layer.stride, layer.padding,
+                                         layer.dilation, act.halo, epi):
+            y2 = ops.conv3x3_direct_nib(act.nib, N, C, H, W, wp, layer.bias, epi)
+            return y2, (N, int(layer.weight.shape[0]), H, W)
         y2 = ops.conv2d_nib(act.nib, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,
                             layer.dilation, epi=epi)
     elif PAD_PLANES and (ph or pw):

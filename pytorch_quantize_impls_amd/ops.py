@@ -956,6 +956,49 @@ def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> tor
     return out
 
 
+#: True: 3x3 / stride-1 / padding-1 convs of 64- / 128-channel nibble planes that carry a 1-pixel halo run in the direct
+#: form (qt_conv3x3_direct_nib: the tile's input patch is loaded once instead of gathered per tap).  Bit-identical, but
+#: its first implementation is slower than the implicit-GEMM kernels (VGG-16 conv2 779 vs 447 us), so it is off.
+DIRECT_CONV3X3 = False
+
+
+def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation, in_halo, epi) -> bool:
+    if not (DIRECT_CONV3X3 and tuple(kernel_hw) == (3, 3) and _pairs(stride) == (1, 1) and _pairs(padding) == (1, 1)
+            and _pairs(dilation) == (1, 1) and tuple(in_halo) == (1, 1) and pixel_ld_nib(C) in (8, 16) and Cout <= 128):
+        return False
+    if isinstance(epi, NibEpilogue):
+        return tuple(epi.out_halo) == (1, 1) and not epi.d2s_cout
+    return isinstance(epi, tuple) and len(epi) == 2
+
+
+def conv3x3_direct_nib(pixels: NibPlanes, N: int, C: int, H: int, W: int, wplanes: NibPlanes, bias, epi):
+    """Direct 3x3 conv of a halo-1 nibble plane with the threshold epilogue; returns BitPlanes ([N*H*W] rows) for
+    ``epi`` = (alpha, beta) or the halo-1 NibPlanes of the next conv for a NibEpilogue."""
+    Cw = pixel_ld_nib(C)
+    if pixels.rows != N * (H + 2) * (W + 2) or pixels.ld != Cw:
+        raise ValueError("direct conv expects the [N, H+2, W+2] halo plane of the activation")
+    if wplanes.K != 9 * Cw * 8:
+        raise ValueError("weight planes do not match the activation's channel packing")
+    Cout = wplanes.rows
+    dev = pixels.device
+    nib_out = isinstance(epi, NibEpilogue)
+    alpha, beta = (epi.alpha, epi.beta) if nib_out else epi
+    alpha, beta, bias = _check_bias(alpha, Cout, dev), _check_bias(beta, Cout, dev), _check_bias(bias, Cout, dev)
+    if nib_out:
+        ldo = pixel_ld_nib(Cout)
+        out = torch.empty((N * (H + 2) * (W + 2), ldo), dtype=torch.int32, device=dev)
+    else:
+        ldo = packed_ld(Cout)
+        out = torch.empty((N * H * W, ldo), dtype=torch.int32, device=dev)
+    with _on(dev):
+        _lib.call("qt_conv3x3_direct_nib", _p(pixels.words), int(N), int(H), int(W), int(Cw), _p(wplanes.words),
+                  int(wplanes.ld), _p(bias), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1,
+                  _stream(dev))
+    if nib_out:
+        return NibPlanes(words=out, rows=int(out.shape[0]), K=Cout)
+    return BitPlanes(sign=out, rows=N * H * W, K=Cout)
+
+
 def zero_halo(words: torch.Tensor, N: int, H: int, W: int, halo) -> torch.Tensor:
     """Zero (in place) the border pixels of a halo plane [N*(H+2hy)*(W+2hx), Cw] of any element type; for callers that
     fill the interior themselves (the conv / pooling entry points write their own borders)."""

@@ -1395,6 +1395,34 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,Cout,N,H,W,kind", [(64, 64, 3, 14, 17, "binary"), (64, 128, 2, 9, 30, "ternary"),
+                                               (128, 128, 2, 12, 12, "binary"), (128, 40, 1, 5, 7, "ternary"),
+                                               (64, 100, 5, 33, 6, "binary"), (40, 64, 2, 8, 8, "ternary")])
+def test_direct_conv3x3_equals_implicit_gemm(dev, monkeypatch, C, Cout, N, H, W, kind):
+    """qt_conv3x3_direct_nib (input patch loaded once per tile, taps read from LDS) against the implicit-GEMM kernels:
+    threshold bits and the next conv's nibble halo plane, bit for bit (incl. the halo the kernel writes itself)."""
+    x = g(synth.pm1(51, (N, C, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    bits = ops.sign_pack(x.permute(0, 2, 3, 1).contiguous())[0]
+    px = ops.bits_to_nib_pad(bits, N, H, W, (1, 1), ld=ops.pixel_ld_nib(C))
+    wp = ops.pack_conv_weight_nib(g(synth.uniform(52, (Cout, C, 3, 3), -1, 1), dev), kind)
+    b = g(synth.uniform(53, (Cout,), -3, 3), dev)
+    alpha, beta = g(synth.uniform(54, (Cout,), -1, 1), dev), g(synth.uniform(55, (Cout,), -20, 20), dev)
+    monkeypatch.setattr(ops, "DIRECT_CONV3X3", True)
+    assert ops.direct_conv3x3_applicable(C, Cout, (3, 3), 1, 1, 1, (1, 1), (alpha, beta))
+    want_bits = ops.conv2d_nib(px, (N, C, H + 2, W + 2), wp, (3, 3), b, 1, 0, 1, epi=(alpha, beta))
+    want_nib = ops.conv2d_nib(px, (N, C, H + 2, W + 2), wp, (3, 3), b, 1, 0, 1, epi=ops.NibEpilogue(alpha, beta, (1, 1)))
+    for shape in (want_bits.sign.shape, want_nib.words.shape):          # poison what torch.empty will hand out
+        junk = torch.full(tuple(shape), 0x55555555, dtype=torch.int32, device=dev)
+        del junk
+    before = dict(_lib.call_counts)
+    got_bits = ops.conv3x3_direct_nib(px, N, C, H, W, wp, b, (alpha, beta))
+    got_nib = ops.conv3x3_direct_nib(px, N, C, H, W, wp, b, ops.NibEpilogue(alpha, beta, (1, 1)))
+    assert _lib.call_counts["qt_conv3x3_direct_nib"] - before.get("qt_conv3x3_direct_nib", 0) == 2
+    assert torch.equal(got_bits.sign, want_bits.sign)
+    assert torch.equal(got_nib.words, want_nib.words)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("halo", [(1, 1), (2, 0), (0, 3)])
 def test_zero_halo_touches_only_the_border(dev, halo):
     N, H, W, C = 3, 5, 7, 48
