@@ -355,12 +355,17 @@ int qt_conv_force_kernel(int which);
  * bit c%32 of word c/32 of row (n, ho, wo) of neg_plane is (v < 0).  neg_plane: [N*Ho*Wo][ldb] words,
  * ldb % 4 == 0, ceil(Cout/32) <= ldb < ceil(Cout/32) + 64; every word of every row is written (pad words as 0).
  * alpha/beta: folded eval BatchNorm, Cout floats each.  Follow with qt_pool_bits when a MaxPool sits
- * between conv and BatchNorm. */
+ * between conv and BatchNorm.
+ * thr (may be NULL; elem 0 / 1 only): per-channel INTEGER thresholds T_c such that, for every integer accumulator value
+ * |acc| <= K,  fl(fl(acc + bias_c)*alpha_c) + beta_c < 0  <=>  (acc < T_c) xor (alpha_c < 0)  — the left side is a
+ * monotone step function of the integer acc, so T_c exists and the caller finds it by bisection once per layer.  The
+ * kernel then spends one compare per output instead of add + multiply + compare ("BatchNorm + sign collapses to a
+ * per-channel integer threshold on the popcount"); bias / beta are ignored, the sign of alpha is still read. */
 int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                             int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
                             int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias,
                             float scale, const float* scale_dev, const float* alpha, const float* beta,
-                            uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream);
+                            const float* thr, uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream);
 
 /* qt_conv2d_implicit_bits with the sign bits written as the NEXT conv's operand instead: an fp4 nibble pixel plane
  * (+1 = 0x2, -1 = 0xA, channels >= Cout zero), nib_plane [N][Ho + 2*out_halo_h][Wo + 2*out_halo_w][ldn words],
@@ -374,9 +379,9 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t N, int64_t H, i
 int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                            int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
-                           const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
-                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, int64_t d2s_cout,
-                           qt_stream_t stream);
+                           const float* scale_dev, const float* alpha, const float* beta, const float* thr,
+                           uint32_t* nib_plane, int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w,
+                           int64_t d2s_cout, qt_stream_t stream);
 
 /* Direct form of the 3x3 / stride 1 / padding 1 conv of a +-1 activation for few channels at large spatial size
  * (VGG / ResNet early layers), where the implicit-GEMM gather of qt_conv2d_implicit_* is bound by L2 traffic (each

@@ -79,7 +79,7 @@ SIGNATURES = {
     "qt_conv2d_implicit": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64,
                                                                     _c_i64, _c_p]),
     "qt_conv2d_implicit_bits": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
-                                                                         _c_p, _c_i64, _c_i64, _c_p]),
+                                                                         _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "qt_conv2d_implicit_codes": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
                                                                           _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
                                                                           _c_int, _c_int, _c_p, _c_i64, _c_i64, _c_p]
@@ -87,7 +87,7 @@ SIGNATURES = {
     "qt_conv2d_implicit_halo": (_c_int, [_c_int, _c_p] + [_c_i64] * 14 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64,
                                                                           _c_i64, _c_p]),
     "qt_conv2d_implicit_nib": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
-                                                                        _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+                                                                        _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_conv3x3_direct_nib": (_c_int, [_c_p] + [_c_i64] * 4 + [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int,
                                         _c_p]),
     "qt_pool_bits_nib": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p] + [_c_i64] * 4 + [_c_p]),

@@ -164,6 +164,12 @@ struct EpiArgs {
     // channels — the 2x2 output-blocked form of a few-channel stride-1 first layer (a 4x4 stride-2 conv that embeds
     // the four shifted copies of the 3x3 kernel), which gathers a quarter of the bytes of the direct form.
     int d2s_cout = 0;
+    // threshold modes (0 / 3) with EXACT INTEGER accumulators (+-1 / 0 operands): thr[c] = the integer T_c with
+    //   fl(fl(acc + bias_c) * alpha_c) + beta_c < 0   <=>   (acc < T_c) xor (alpha_c < 0)      for every |acc| <= K
+    // (the left side is a monotone step function of the integer acc; the caller finds T_c by bisection, once per layer:
+    // ops.integer_thresholds).  One compare per accumulator register instead of add + multiply + compare — the
+    // "BatchNorm + sign collapses to a per-channel integer threshold on the popcount" of SURVEY 8f n1.
+    const float* thr = nullptr;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
 
@@ -777,16 +783,24 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             const int n = nb + lrow;
             const float bv = (bias && n < N) ? bias[n] : 0.0f;
             const float al = n < N ? epi.alpha[n] : 0.0f, nbe = n < N ? -epi.beta[n] : 0.0f;
-#pragma unroll
-            for (int a = 0; a < C::TMW; ++a) {
+            // integer-threshold form: channels >= N compare acc < -inf -> bit 0
+            const float thr = (epi.thr && n < N) ? epi.thr[n] : -3.0e38f;
+            const unsigned long long negmask = epi.thr ? __ballot(al < 0.0f) : 0ull;
+            // the 32-channel sign words of the 32 rows of accumulator tile (a, b): lane i (< 32) ends up with row i's word
+            auto word_of = [&](int a, auto use_thr) -> uint32_t {
                 uint32_t myword = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float t = E::out(acc[a][b][r], scale, bv);
-                    // fl(fl(t*al) + be) < 0  <=>  fl(t*al) < -be: an IEEE sum of two floats has the sign of the exact
-                    // sum (a non-zero exact sum is a multiple of the smallest subnormal and cannot round to zero), NaN
-                    // and inf - inf compare false on both sides — one VALU op less per accumulator register
-                    const unsigned long long mask = __ballot(t * al < nbe);
+                    unsigned long long mask;
+                    if constexpr (decltype(use_thr)::value) {
+                        mask = __ballot((float)acc[a][b][r] < thr);     // channels with alpha < 0 are flipped below
+                    } else {
+                        const float t = E::out(acc[a][b][r], scale, bv);
+                        // fl(fl(t*al) + be) < 0  <=>  fl(t*al) < -be: an IEEE sum of two floats has the sign of the
+                        // exact sum (a non-zero exact sum is a multiple of the smallest subnormal and cannot round to
+                        // zero), NaN and inf - inf compare false on both sides — one VALU op less per register
+                        mask = __ballot(t * al < nbe);
+                    }
                     const int R = (r & 3) + 8 * (r >> 2);
                     // v_writelane: the two halves of the (scalar) ballot straight into lanes R and R + 4 (a compare + select
                     // each before).  gfx950 does not interlock a VALU-written SGPR read by the next VALU (2 wait states)
@@ -795,6 +809,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
                     asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
                 }
+                // every row's word holds the same 32 channels: one xor flips the alpha < 0 channels of all rows
+                if constexpr (decltype(use_thr)::value) myword ^= (uint32_t)negmask;
+                return myword;
+            };
+#pragma unroll
+            for (int a = 0; a < C::TMW; ++a) {
+                const uint32_t myword = epi.thr ? word_of(a, std::true_type{}) : word_of(a, std::false_type{});
                 const int m = m0 + (wave_m * C::TMW + a) * 32 + lane;
                 const int wcol = nb >> 5;
                 if constexpr (C::CONV) if (epi.mode == 3) {
@@ -1413,13 +1434,15 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int
 int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
                             int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                             int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
-                            const float* scale_dev, const float* alpha, const float* beta,
+                            const float* scale_dev, const float* alpha, const float* beta, const float* thr,
                             uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream) {
     if (!alpha || !beta) return QT_ERR_INVALID_ARG;
+    if (thr && elem == 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
     if (ldb & 3) return QT_ERR_ALIGNMENT;
     EpiArgs epi;
     epi.alpha = alpha;
     epi.beta = beta;
+    epi.thr = thr;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(neg_plane), ldb, Cout, stream, epi);
 }
@@ -1427,10 +1450,11 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H
 int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
                            int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                            int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
-                           const float* scale_dev, const float* alpha, const float* beta, uint32_t* nib_plane,
-                           int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w, int64_t d2s_cout,
-                           qt_stream_t stream) {
+                           const float* scale_dev, const float* alpha, const float* beta, const float* thr,
+                           uint32_t* nib_plane, int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w,
+                           int64_t d2s_cout, qt_stream_t stream) {
     if (!alpha || !beta) return QT_ERR_INVALID_ARG;
+    if (thr && elem == 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
     if (out_halo_h < 0 || out_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_INVALID_ARG;
     if ((ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
     if (d2s_cout < 0 || (d2s_cout && (d2s_cout % 32 || Cout != 4 * d2s_cout))) return QT_ERR_INVALID_ARG;
@@ -1440,6 +1464,7 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t Nimg, int64_t H,
     epi.alpha = alpha;
     epi.beta = beta;
     epi.mode = 3;
+    epi.thr = thr;
     epi.ohy = (int)out_halo_h;
     epi.ohx = (int)out_halo_w;
     epi.d2s_cout = (int)d2s_cout;

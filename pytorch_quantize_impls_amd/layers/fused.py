@@ -254,10 +254,12 @@ class FusedConvPoolBnSign(torch.nn.Module):
         # that conv's operand itself — an fp4 nibble pixel plane with the padding as a zero border — from the conv
         # epilogue (no pooling) or from the pooling kernel, instead of bit planes the consumer would expand again
         self.out_nib_halo = None
+        self._thr = None
 
     def refold(self):
         self._pool.refold()
         self._neg_alpha = None
+        self._thr = None
 
     def forward(self, x):
         from ..functions import _fused
@@ -268,12 +270,21 @@ class FusedConvPoolBnSign(torch.nn.Module):
         if fp._folded is None or fp._folded[0].device != dev or self._neg_alpha is None:
             fp._folded = fold_batchnorm(self.bn)
             self._neg_alpha = ops.neg_alpha_words(fp._folded[0])
+            self._thr = None
         epi = fp._folded
         pooled = fp.pool_k != 1 or fp.pool_s != 1
         nib_out = self.out_nib_halo is not None and not self.flatten_hwc
         if isinstance(x, packed.PackedActivation):
+            # +-1 activations x +-1 / 0 weights: the accumulator is an exact integer, so BatchNorm + sign is one integer
+            # threshold per channel (found once, by bisection on the kernel's own fp32 expression)
+            bkey = None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version)
+            if INTEGER_THRESHOLDS and (self._thr is None or self._thr[0] != bkey or self._thr[1].device != dev):
+                kmax = conv.in_channels * conv.kernel_size[0] * conv.kernel_size[1]
+                self._thr = (bkey, ops.integer_thresholds(conv.bias, epi[0], epi[1], kmax))
+            thr = self._thr[1] if INTEGER_THRESHOLDS else None
+            epi = (epi[0], epi[1], thr)
             if nib_out and not pooled:
-                epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo)
+                epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo, thr=thr)
             planes, shape = _fused.packed_conv2d(conv, x, self.kind, epi=epi)
             if isinstance(planes, ops.NibPlanes):
                 return packed.PackedActivation(None, shape, nib=planes, halo=self.out_nib_halo)
@@ -327,6 +338,8 @@ class FusedConvPoolBnSign(torch.nn.Module):
 
 #: real-valued 3x3 / stride-1 / padding-1 first layers of fused stacks run in the 2x2 output-blocked form
 D2S_FIRST_LAYER = True
+#: fused conv blocks on +-1 activations use per-channel integer thresholds (ops.integer_thresholds) in the epilogue
+INTEGER_THRESHOLDS = True
 
 
 class PackedMaxPool(torch.nn.Module):

@@ -63,6 +63,34 @@ class CodeEpilogue:
     res_halo: tuple = (0, 0)        # halo of the residual code plane
 
 
+def integer_thresholds(bias: Optional[torch.Tensor], alpha: torch.Tensor, beta: torch.Tensor, kmax: int) -> torch.Tensor:
+    """Per-channel integer thresholds T of the threshold epilogue for EXACT INTEGER accumulators (|acc| <= kmax):
+
+        fl(fl(acc + bias) * alpha) + beta < 0   <=>   (acc < T) xor (alpha < 0)
+
+    The left side — evaluated with exactly the fp32 roundings of the kernel's float form — is a monotone step function
+    of the integer acc (rounding and multiplication by a constant are monotone), so T exists; it is found by bisection
+    over [-kmax, kmax + 1], vectorised over the channels (~log2(2 kmax) fp32 evaluations, once per layer).  Constant
+    predicates (alpha == 0, NaN parameters) come out as T = kmax + 1 (always) / -kmax (never).  Returns fp32 [C]."""
+    alpha = alpha.detach().to(torch.float32)
+    beta = beta.detach().to(torch.float32)
+    b = torch.zeros_like(alpha) if bias is None else bias.detach().to(torch.float32)
+    neg = alpha < 0
+    nbe = -beta
+
+    def p(k):      # the kernel's predicate, flipped for alpha < 0 so that it is "true for small k" in every channel
+        return ((k.to(torch.float32) + b) * alpha < nbe) ^ neg
+
+    lo = torch.full_like(alpha, -int(kmax), dtype=torch.int64)
+    hi = torch.full_like(alpha, int(kmax) + 1, dtype=torch.int64)          # p(hi) counts as false
+    for _ in range(max(1, (2 * int(kmax) + 2).bit_length())):
+        mid = torch.div(lo + hi, 2, rounding_mode="floor")
+        t = p(mid) & (mid <= kmax)
+        lo = torch.where(t, mid + 1, lo)
+        hi = torch.where(t, hi, mid)
+    return hi.to(torch.float32).contiguous()        # the smallest k with p(k) false
+
+
 @dataclass
 class NibEpilogue:
     """Threshold-bit epilogue written as the NEXT conv's fp4 nibble pixel plane (qt_conv2d_implicit_nib): folded
@@ -71,6 +99,7 @@ class NibEpilogue:
     beta: torch.Tensor
     out_halo: tuple = (0, 0)
     d2s_cout: int = 0               # depth-to-space by 2: the conv's 4*d2s_cout columns are (dy, dx, channel)
+    thr: Optional[torch.Tensor] = None      # integer_thresholds(...): exact one-compare form for +-1 / 0 operands
 
 
 def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor,
@@ -140,8 +169,9 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         rows = N * (zs * Ho + 2 * ohy) * (zs * Wo + 2 * ohx)
         plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)     # the launch writes every word, border included
         with _on(dev):
-            _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(plane), I(ldn), I(Cout), I(ohy), I(ohx),
-                      I(d2s), _stream(dev))
+            thr = _check_bias(epi.thr, Cout, dev) if (epi.thr is not None and elem != 2) else None
+            _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(thr), _p(plane), I(ldn), I(Cout), I(ohy),
+                      I(ohx), I(d2s), _stream(dev))
         return NibPlanes(words=plane, rows=rows, K=Cpix)
     if hy or hx:
         if epi is not None:
@@ -153,13 +183,15 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
                       _stream(dev))
         return y
     if epi is not None:
-        alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi, ("alpha", "beta")))
+        alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi[:2], ("alpha", "beta")))
+        thr = _check_bias(epi[2], Cout, dev) if (len(epi) > 2 and epi[2] is not None and elem != 2) else None
         if alpha.numel() != Cout or beta.numel() != Cout:
             raise ValueError(f"alpha/beta must have {Cout} entries")
         ldb = packed_ld(Cout)
         plane = torch.empty((M, ldb), dtype=torch.int32, device=dev)   # the kernel writes every word incl. the pad
         with _on(dev):
-            _lib.call("qt_conv2d_implicit_bits", *head, _p(alpha), _p(beta), _p(plane), I(ldb), I(Cout), _stream(dev))
+            _lib.call("qt_conv2d_implicit_bits", *head, _p(alpha), _p(beta), _p(thr), _p(plane), I(ldb), I(Cout),
+                      _stream(dev))
         return BitPlanes(sign=plane, rows=M, K=Cout)
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     with _on(dev):
@@ -968,7 +1000,7 @@ def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dil
         return False
     if isinstance(epi, NibEpilogue):
         return tuple(epi.out_halo) == (1, 1) and not epi.d2s_cout
-    return isinstance(epi, tuple) and len(epi) == 2
+    return isinstance(epi, tuple) and len(epi) in (2, 3)
 
 
 def conv3x3_direct_nib(pixels: NibPlanes, N: int, C: int, H: int, W: int, wplanes: NibPlanes, bias, epi):
@@ -982,7 +1014,7 @@ def conv3x3_direct_nib(pixels: NibPlanes, N: int, C: int, H: int, W: int, wplane
     Cout = wplanes.rows
     dev = pixels.device
     nib_out = isinstance(epi, NibEpilogue)
-    alpha, beta = (epi.alpha, epi.beta) if nib_out else epi
+    alpha, beta = (epi.alpha, epi.beta) if nib_out else epi[:2]
     alpha, beta, bias = _check_bias(alpha, Cout, dev), _check_bias(beta, Cout, dev), _check_bias(bias, Cout, dev)
     if nib_out:
         ldo = pixel_ld_nib(Cout)

@@ -1423,6 +1423,34 @@ def test_direct_conv3x3_equals_implicit_gemm(dev, monkeypatch, C, Cout, N, H, W,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,ksz,st,pd,kind", [(32, 64, 3, 1, 1, "binary"), (96, 200, 5, 1, 2, "ternary"),
+                                                      (64, 40, 3, 2, 0, "binary"), (256, 384, 3, 1, 1, "ternary")])
+def test_integer_threshold_epilogue_equals_float_epilogue(dev, Cin, Cout, ksz, st, pd, kind):
+    """The one-compare epilogue (per-channel integer thresholds from ops.integer_thresholds) produces the bits of the
+    float epilogue for every sign / magnitude of the folded BatchNorm, as bit planes and as nibble planes."""
+    N, H, W = 3, 11, 9
+    x = g(synth.pm1(61, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    px = ops.pack_pixels_nib(x)
+    wp = ops.pack_conv_weight_nib(g(synth.uniform(62, (Cout, Cin, ksz, ksz), -1, 1), dev), kind)
+    b = g(synth.uniform(63, (Cout,), -4, 4), dev)
+    alpha = g(synth.uniform(64, (Cout,), -0.2, 0.2), dev)
+    beta = g(synth.uniform(65, (Cout,), -8, 8), dev)
+    alpha[0] = 0.0
+    alpha[1], beta[1] = 0.0, -1.0
+    beta[2] = 1e6
+    beta[3] = -1e6
+    thr = ops.integer_thresholds(b, alpha, beta, Cin * ksz * ksz)
+    args = (px, (N, Cin, H, W), wp, (ksz, ksz), b, st, pd, 1)
+    want = ops.conv2d_nib(*args, epi=(alpha, beta))
+    got = ops.conv2d_nib(*args, epi=(alpha, beta, thr))
+    assert torch.equal(got.sign, want.sign)
+    assert 0.02 < float((want.sign != 0).float().mean())            # not a degenerate all-zero comparison
+    want_n = ops.conv2d_nib(*args, epi=ops.NibEpilogue(alpha, beta, (1, 1)))
+    got_n = ops.conv2d_nib(*args, epi=ops.NibEpilogue(alpha, beta, (1, 1), thr=thr))
+    assert torch.equal(got_n.words, want_n.words)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("halo", [(1, 1), (2, 0), (0, 3)])
 def test_zero_halo_touches_only_the_border(dev, halo):
     N, H, W, C = 3, 5, 7, 48

@@ -330,3 +330,32 @@ def test_fused_module_host_logic():
     q = FusedBnDorefaQuant(torch.nn.BatchNorm2d(12).eval(), 4)
     with pytest.raises(TypeError, match="HIP device"):
         q(torch.zeros(1, 12, 3, 3))
+
+
+def test_integer_thresholds_reproduce_the_float_predicate_exactly():
+    """ops.integer_thresholds: for every integer accumulator value the one-compare form (acc < T) xor (alpha < 0) equals
+    the kernel's float predicate fl(fl(acc + bias) * alpha) < -beta, brute force over the whole accumulator range,
+    including alpha <= 0, always / never cases, huge offsets and NaN parameters."""
+    import torch
+    from pytorch_quantize_impls_amd import ops
+    torch.manual_seed(3)
+    C, kmax = 64, 300
+    alpha = torch.randn(C) * 0.05
+    beta = torch.randn(C) * 3
+    bias = torch.randn(C) * 5
+    alpha[0], alpha[1], beta[1] = 0.0, 0.0, -1.0                    # constant predicates
+    alpha[2], beta[2] = 1e-3, 1e6                                    # never
+    alpha[3], beta[3] = -1e-3, 1e6                                   # never (negative slope)
+    alpha[4], beta[4] = 2.0, -1e6                                    # always
+    alpha[5] = float("nan")
+    beta[6] = float("nan")
+    bias[7] = 1e9                                                    # acc is absorbed by the bias: a constant again
+    alpha[8], beta[8], bias[8] = 0.37, -0.37 * 12.5, 0.0             # boundary between two integers
+    alpha[9], beta[9], bias[9] = -1.0, 7.0, 0.0                      # exact tie at acc == 7
+    for b in (bias, None):
+        thr = ops.integer_thresholds(b, alpha, beta, kmax)
+        bb = torch.zeros(C) if b is None else b
+        k = torch.arange(-kmax, kmax + 1, dtype=torch.float32).view(-1, 1)
+        want = (k + bb) * alpha < -beta
+        got = (k < thr) ^ (alpha < 0)
+        assert torch.equal(got, want)
