@@ -10,13 +10,15 @@
 // walks position tiles persistently, loads the three runs once per tile and reads the A fragment of tap (i, j) as an
 // LDS load at patch[i][pos + j].
 //
-// STATUS (round 1): bit-identical to the implicit-GEMM kernels (tests/test_gpu_parity.py) but NOT yet faster — this
-// first form has no overlap of the patch load with the MFMAs inside a workgroup and plain (non-DMA) loads: VGG-16
-// batch 256: conv2 779 us (implicit GEMM 447), conv3 369 (207), conv4 781 (207); a register prefetch of the next
-// tile's patch made it slower still (1085 us: register pressure).  ops.DIRECT_CONV3X3 therefore defaults to False; the
-// kernel is the tested starting point for the LDS-DMA / double-buffered version.  Border positions produce no output pixel: in nibble-plane output mode (the next
-// conv's operand, same halo geometry) they are written as zeros — the kernel writes its own halo —, in bit-plane
-// mode (a MaxPool follows) they are skipped.
+// STATUS (round 1): bit-identical to the implicit-GEMM kernels (tests/test_gpu_parity.py).  tools/bench_direct_conv.py,
+// batch 256, nibble-plane / bit-plane output:   64 -> 64 at 224^2   366 / 329 us  (implicit GEMM 620 / 499)
+//                                               64 -> 128 at 112^2  167 / 141 us  (246 / 183)
+//                                               128 -> 128 at 112^2 281 / 265 us  (328 / 261)
+// What it took after the first (1.6x slower than the implicit GEMM) version: the tap loop rolled over the kernel rows —
+// fully unrolled, the scheduler hoisted all 36 fragment reads (198 VGPRs, 2 waves per SIMD) —, the next tile's patch
+// prefetched into registers right after the barrier that publishes the current one, and 8 waves (4 position x 2 column)
+// per workgroup for 128 input channels, whose LDS footprint allows one workgroup per CU.
+// Not done yet: LDS-DMA for the patch, XCD-aware tile order.
 //
 // fp4 MFMA operand layout as in mfma_gemm.hip: v_mfma_scale_f32_32x32x64_f8f6f4, lane l supplies 16 bytes (32
 // nibbles) of row l % 32: K elements 0..31 from lanes 0..31, 32..63 from lanes 32..63; accumulator register r of lane
@@ -56,21 +58,23 @@ struct D3Args {
 
 constexpr int D3_TM = 256, D3_RUN = D3_TM + 2;
 
-// CPP: 16-byte chunks per input pixel (Cin = 32 * CPP); TNW: 32-column blocks (Cout <= 32 * TNW)
-template <int CPP, int TNW>
-__global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
+// CPP: 16-byte chunks per input pixel (Cin = 32 * CPP); a workgroup = 4 (position) x WN (column) waves, each wave owns
+// 64 positions x TNW 32-column blocks (Cout <= 32 * TNW * WN); OCC: waves per SIMD the register budget is sized for
+template <int CPP, int TNW, int WN, int OCC>
+__global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
+    constexpr int NT = 256 * WN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WROW = 9 * CPP * 16 + 16;        // + 16: consecutive rows land on different bank groups
-    constexpr int WBYTES = TNW * 32 * WROW;
+    constexpr int WBYTES = TNW * WN * 32 * WROW;
     unsigned char* wl = smem;
     unsigned char* patch = smem + WBYTES;          // [3][RUN][CPP chunks], chunk c of pixel px at c ^ swz(px)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wave_n = tid >> 8;
     const int lrow = lane & 31, lhalf = lane >> 5;
     // conflict-free ds_read_b128 of 8 consecutive pixels: spread their chunk over the 128-byte bank line
     auto swz = [](int px) { return (px * CPP / 8) & (CPP - 1); };
 
     // weights: resident for the whole launch
-    for (int e = tid; e < TNW * 32 * 9 * CPP; e += 256) {
+    for (int e = tid; e < TNW * WN * 32 * 9 * CPP; e += NT) {
         const int row = e / (9 * CPP), c = e - row * (9 * CPP);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < g.Cout) v = *reinterpret_cast<const uint4*>(g.Wm + (long long)row * g.ldw + c * 16);
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
     float al[TNW], nbe[TNW], bv[TNW];
 #pragma unroll
     for (int b = 0; b < TNW; ++b) {
-        const int n = b * 32 + lrow;
+        const int n = (wave_n * TNW + b) * 32 + lrow;
         const bool in = n < g.Cout;
         al[b] = in ? g.alpha[n] : 0.0f;
         nbe[b] = in ? -g.beta[n] : 0.0f;
@@ -87,18 +91,37 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
     }
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const unsigned plane = (unsigned)(g.Hp * g.Wp);
+    // the patch of the NEXT tile travels through registers while this tile computes (global latency off the critical
+    // path): NLD 16-byte loads per thread, issued right after the barrier that publishes the current patch
+    constexpr int NLD = (3 * D3_RUN * CPP + NT - 1) / NT;
+    uint4 pre[NLD];
+    auto fetch = [&](long long t) {
+        const long long q0n = t * D3_TM;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int run = e / (D3_RUN * CPP), rem = e - run * (D3_RUN * CPP);
+            const int px = rem / CPP, c = rem - px * CPP;
+            long long src = q0n + (long long)(run - 1) * g.Wp - 1 + px;
+            src = src < 0 ? 0 : (src >= g.total ? g.total - 1 : src);      // only border / tail positions, never stored
+            pre[k] = make_uint4(0, 0, 0, 0);
+            if (e < 3 * D3_RUN * CPP) pre[k] = *reinterpret_cast<const uint4*>(g.P + (src * CPP + c) * 16);
+        }
+    };
+    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long q0 = tile * D3_TM;
         __syncthreads();                            // the previous tile's fragment reads (and the weight fill) are done
-        for (int e = tid; e < 3 * D3_RUN * CPP; e += 256) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
             const int run = e / (D3_RUN * CPP), rem = e - run * (D3_RUN * CPP);
             const int px = rem / CPP, c = rem - px * CPP;
-            long long src = q0 + (long long)(run - 1) * g.Wp - 1 + px;
-            src = src < 0 ? 0 : (src >= g.total ? g.total - 1 : src);      // only border / tail positions, never stored
-            const uint4 v = *reinterpret_cast<const uint4*>(g.P + (src * CPP + c) * 16);
-            *reinterpret_cast<uint4*>(patch + ((run * D3_RUN + px) * CPP + (c ^ swz(px))) * 16) = v;
+            if (e < 3 * D3_RUN * CPP)
+                *reinterpret_cast<uint4*>(patch + ((run * D3_RUN + px) * CPP + (c ^ swz(px))) * 16) = pre[k];
         }
         __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         d3_v16f acc[2][TNW];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -106,9 +129,13 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
             for (int b = 0; b < TNW; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        // one kernel row at a time: a fully unrolled tap loop lets the scheduler hoist all 36 fragment reads (198 VGPRs,
+        // 2 waves per SIMD); rolled over i it keeps 12 in flight
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int i = tap / 3, j = tap - i * 3;
+        for (int j = 0; j < 3; ++j) {
+            const int tap = i * 3 + j;
 #pragma unroll
             for (int kk = 0; kk < CPP / 2; ++kk) {
                 const int c = kk * 2 + lhalf;
@@ -120,7 +147,7 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
                 }
 #pragma unroll
                 for (int b = 0; b < TNW; ++b)
-                    wf[b] = *reinterpret_cast<const uint4*>(wl + (b * 32 + lrow) * WROW + (tap * CPP + c) * 16);
+                    wf[b] = *reinterpret_cast<const uint4*>(wl + ((wave_n * TNW + b) * 32 + lrow) * WROW + (tap * CPP + c) * 16);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -153,15 +180,16 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
                     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
                     asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
                 }
+                const int bg = wave_n * TNW + b;                            // column block of the whole tile
                 if (lane < 32 && q < g.total) {
                     if (g.out_bits) {
-                        if (valid && b < g.ldo) {
-                            g.out[mrow * g.ldo + b] = myword;
-                            if (b == TNW - 1)
-                                for (int wc = TNW; wc < g.ldo; ++wc) g.out[mrow * g.ldo + wc] = 0u;
+                        if (valid && bg < g.ldo) {
+                            g.out[mrow * g.ldo + bg] = myword;
+                            if (bg == TNW * WN - 1)
+                                for (int wc = TNW * WN; wc < g.ldo; ++wc) g.out[mrow * g.ldo + wc] = 0u;
                         }
-                    } else if (b * 4 < g.ldo) {
-                        const int left = g.Cout - b * 32;
+                    } else if (bg * 4 < g.ldo) {
+                        const int left = g.Cout - bg * 32;
                         uint4 o = make_uint4(0, 0, 0, 0);                 // border position: the output plane's halo
                         if (valid) {
                             const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
                             o.z = (d3_spread8(mw >> 16) << 1) | (d3_spread8(sw >> 16) << 3);
                             o.w = (d3_spread8(mw >> 24) << 1) | (d3_spread8(sw >> 24) << 3);
                         }
-                        *reinterpret_cast<uint4*>(g.out + q * g.ldo + b * 4) = o;
+                        *reinterpret_cast<uint4*>(g.out + q * g.ldo + bg * 4) = o;
                     }
                 }
             }
@@ -179,16 +207,16 @@ __global__ __launch_bounds__(256) void direct3x3_kernel(D3Args g) {
     }
 }
 
-template <int CPP, int TNW>
+template <int CPP, int TNW, int WN, int OCC>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
-    const int lds = TNW * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW>),
+    const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const long long cap = 256ll * wg_per_cu;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW>), dim3(grid), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC>), dim3(grid), dim3(256 * WN), lds, stream, g);
     return qt_check_launch();
 }
 
@@ -215,6 +243,7 @@ extern "C" int qt_conv3x3_direct_nib(const uint32_t* P, int64_t N, int64_t H, in
     g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;     // divisors >= 9: ceil(2^64 / d)
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
     hipStream_t s = (hipStream_t)stream;
-    if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2>(g, 3, s) : d3_launch<2, 4>(g, 2, s);
-    return Cout <= 64 ? d3_launch<4, 2>(g, 1, s) : d3_launch<4, 4>(g, 1, s);
+    // LDS per workgroup: 44 / 64 KB (64 input channels), 87 / 125 KB (128)
+    if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3>(g, 3, s) : d3_launch<2, 4, 1, 2>(g, 2, s);
+    return Cout <= 64 ? d3_launch<4, 1, 2, 2>(g, 1, s) : d3_launch<4, 2, 2, 2>(g, 1, s);
 }

@@ -988,10 +988,10 @@ def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> tor
     return out
 
 
-#: True: 3x3 / stride-1 / padding-1 convs of 64- / 128-channel nibble planes that carry a 1-pixel halo run in the direct
-#: form (qt_conv3x3_direct_nib: the tile's input patch is loaded once instead of gathered per tap).  Bit-identical, but
-#: its first implementation is slower than the implicit-GEMM kernels (VGG-16 conv2 779 vs 447 us), so it is off.
-DIRECT_CONV3X3 = False
+#: 3x3 / stride-1 / padding-1 convs of <= 128-channel nibble planes that carry a 1-pixel halo run in the direct form
+#: (qt_conv3x3_direct_nib: the tile's input patch is loaded once instead of gathered per tap; tools/bench_direct_conv.py,
+#: batch 256: 64->64 at 224^2 620 -> 366 us, 64->128 at 112^2 246 -> 167 us, 128->128 at 112^2 328 -> 281 us)
+DIRECT_CONV3X3 = True
 
 
 def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation, in_halo, epi) -> bool:
