@@ -125,5 +125,50 @@ for it in range(iters):
                 gp = pooled.without_halo().codes.codes[:, :Co].view(Nb, Ho2 // 2, Wo2 // 2, Co).permute(0, 3, 1, 2).cpu().double()
             if not torch.equal(gp, wantp):
                 bad += 1; print("CODE POOL MISMATCH", (Co, Ho2, Wo2))
+    # ---- two fused conv blocks in a row (operand hand-over: nibble epilogue / pooled nibbles / direct 3x3 kernel, integer
+    # thresholds) against the float64 chain; threshold ties (|v| < 1e-4) of the FIRST block invalidate a sample, so the
+    # first block's BatchNorm is kept away from integers
+    if it % 2 == 1:
+        from pytorch_quantize_impls_amd.layers import fuse_sequential
+        from pytorch_quantize_impls_amd.functions import BinaryConnect
+        C0 = int(rng.choice([32, 64, 96, 128])); C1 = int(rng.choice([32, 64, 100, 128, 192])); C2 = int(rng.choice([8, 64, 130]))
+        k2 = int(rng.choice([1, 3, 5])); p2 = int(rng.integers(0, k2 // 2 + 1)); pool1 = bool(rng.integers(0, 2))
+        Nb = int(rng.integers(1, 5)); Hh = int(rng.integers(12, 26)); Ww = int(rng.integers(12, 26))
+        cls = TerConv2d if it % 4 == 1 else BinConv2d
+        m = [cls(C0, C1, 3, padding=1)] + ([torch.nn.MaxPool2d(2, 2)] if pool1 else []) + \
+            [torch.nn.BatchNorm2d(C1), torch.nn.Hardtanh(), BinaryConnect(stochastic=False),
+             cls(C1, C2, k2, padding=p2), torch.nn.BatchNorm2d(C2), torch.nn.Hardtanh(), BinaryConnect(stochastic=False)]
+        seq = torch.nn.Sequential(*m).to(dev)
+        for mod in seq:
+            if isinstance(mod, (BinConv2d, TerConv2d)):
+                mod.weight.data.uniform_(-1.3, 1.3); mod.bias.data.uniform_(-0.4, 0.4)
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-3, 3); mod.running_mean.add_(0.37); mod.running_var.uniform_(0.5, 30)
+                mod.weight.data.normal_(); mod.bias.data.normal_()
+        seq.eval()
+        fz = fuse_sequential(seq, fuse_conv=True, packed_pool=True)
+        xx = torch.randn((Nb, C0, Hh, Ww), device=dev).sign(); xx[xx == 0] = 1
+        xx = xx.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            a_in = pk.PackedActivation(ops.sign_pack(xx.permute(0, 2, 3, 1).contiguous())[0], tuple(xx.shape))
+            out2 = fz(a_in)
+            # float64 chain
+            convs = [mm for mm in seq if isinstance(mm, (BinConv2d, TerConv2d))]
+            bns = [mm for mm in seq if isinstance(mm, torch.nn.BatchNorm2d)]
+            q = (lambda w: tern(w)) if cls is TerConv2d else (lambda w: sgn(w))
+            y1 = torch.nn.functional.conv2d(xx.cpu().double(), q(convs[0].weight.detach().cpu()), convs[0].bias.detach().cpu().double(), 1, 1)
+            if pool1: y1 = torch.nn.functional.max_pool2d(y1, 2, 2)
+            a1, b1 = (t.cpu().double() for t in fold_batchnorm(bns[0]))
+            v1 = y1 * a1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1)
+            s1 = torch.where(v1 < 0, -1.0, 1.0).double()
+            y2 = torch.nn.functional.conv2d(s1, q(convs[1].weight.detach().cpu()), convs[1].bias.detach().cpu().double(), 1, p2)
+            a2, b2 = (t.cpu().double() for t in fold_batchnorm(bns[1]))
+            v2 = y2 * a2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)
+        if float(v1.abs().min()) > 1e-4:
+            want_neg = (v2 < 0).permute(0, 2, 3, 1).reshape(-1, C2)
+            got = ((out2.planes.sign.cpu().unsqueeze(-1) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(out2.planes.rows, -1)[:, :C2].bool()
+            margin = (v2.abs() > 1e-4).permute(0, 2, 3, 1).reshape(-1, C2)
+            if not torch.equal(got[margin], want_neg[margin]):
+                bad += 1; print("FUSED CHAIN MISMATCH", (C0, C1, C2, k2, p2, pool1, Nb, Hh, Ww, cls.__name__), int((got[margin] != want_neg[margin]).sum()))
 print(f"seed {seed}: {iters} iterations, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
