@@ -1397,7 +1397,9 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
 @pytest.mark.gpu
 @pytest.mark.parametrize("C,Cout,N,H,W,kind", [(64, 64, 3, 14, 17, "binary"), (64, 128, 2, 9, 30, "ternary"),
                                                (128, 128, 2, 12, 12, "binary"), (128, 40, 1, 5, 7, "ternary"),
-                                               (64, 100, 5, 33, 6, "binary"), (40, 64, 2, 8, 8, "ternary")])
+                                               (64, 100, 5, 33, 6, "binary"), (40, 64, 2, 8, 8, "ternary"),
+                                               (64, 64, 1, 1, 1, "binary"), (128, 96, 2, 1, 5, "ternary"),
+                                               (64, 7, 3, 2, 1, "binary"), (64, 64, 40, 17, 19, "ternary")])
 def test_direct_conv3x3_equals_implicit_gemm(dev, monkeypatch, C, Cout, N, H, W, kind):
     """qt_conv3x3_direct_nib (input patch loaded once per tile, taps read from LDS) against the implicit-GEMM kernels:
     threshold bits and the next conv's nibble halo plane, bit for bit (incl. the halo the kernel writes itself)."""
