@@ -11,14 +11,15 @@
 // LDS load at patch[i][pos + j].
 //
 // STATUS (round 1): bit-identical to the implicit-GEMM kernels (tests/test_gpu_parity.py).  tools/bench_direct_conv.py,
-// batch 256, nibble-plane / bit-plane output:   64 -> 64 at 224^2   366 / 329 us  (implicit GEMM 620 / 499)
-//                                               64 -> 128 at 112^2  167 / 141 us  (246 / 183)
-//                                               128 -> 128 at 112^2 281 / 265 us  (328 / 261)
+// batch 256, nibble-plane / bit-plane output:   64 -> 64 at 224^2   350 / 324 us  (implicit GEMM 615 / 505)
+//                                               64 -> 128 at 112^2  168 / 143 us  (247 / 186)
+//                                               128 -> 128 at 112^2 275 / 256 us  (321 / 255)
 // What it took after the first (1.6x slower than the implicit GEMM) version: the tap loop rolled over the kernel rows —
 // fully unrolled, the scheduler hoisted all 36 fragment reads (198 VGPRs, 2 waves per SIMD) —, the next tile's patch
 // prefetched into registers right after the barrier that publishes the current one, and 8 waves (4 position x 2 column)
-// per workgroup for 128 input channels, whose LDS footprint allows one workgroup per CU.
-// Not done yet: LDS-DMA for the patch, XCD-aware tile order.
+// per workgroup for 128 input channels, whose LDS footprint allows one workgroup per CU, and a contiguous range of
+// tiles per workgroup (consecutive tiles share two of their three input rows in that workgroup's L2).
+// Not done yet: LDS-DMA for the patch, keeping the two shared rows in LDS across consecutive tiles.
 //
 // fp4 MFMA operand layout as in mfma_gemm.hip: v_mfma_scale_f32_32x32x64_f8f6f4, lane l supplies 16 bytes (32
 // nibbles) of row l % 32: K elements 0..31 from lanes 0..31, 32..63 from lanes 32..63; accumulator register r of lane
@@ -108,8 +109,13 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
             if (e < 3 * D3_RUN * CPP) pre[k] = *reinterpret_cast<const uint4*>(g.P + (src * CPP + c) * 16);
         }
     };
-    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // every workgroup walks a CONTIGUOUS range of position tiles: consecutive tiles share two of their three input rows,
+    // which then come from this workgroup's own L2 instead of being fetched into every XCD's L2
+    const long long per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long long t_begin = (long long)blockIdx.x * per_wg;
+    const long long t_end = t_begin + per_wg < ntiles ? t_begin + per_wg : ntiles;
+    if (t_begin < t_end) fetch(t_begin);
+    for (long long tile = t_begin; tile < t_end; ++tile) {
         const long long q0 = tile * D3_TM;
         __syncthreads();                            // the previous tile's fragment reads (and the weight fill) are done
 #pragma unroll
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                 *reinterpret_cast<uint4*>(patch + ((run * D3_RUN + px) * CPP + (c ^ swz(px))) * 16) = pre[k];
         }
         __syncthreads();
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if (tile + 1 < t_end) fetch(tile + 1);
         d3_v16f acc[2][TNW];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
