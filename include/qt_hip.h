@@ -391,9 +391,12 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, in
  *   out_bits == 0: out = the NEXT conv's operand, nibble plane [N][H+2][W+2][ldo] with the same halo (ldo ==
  *                  ceil(Cout/32)*4); every word is written, the halo as zeros;
  *   out_bits != 0: out = bit plane [N*H*W][ldo] (ldo >= ceil(Cout/32)), for a MaxPool on bits.
- * Bit-identical to the implicit-GEMM entry points.  QT_ERR_UNSUPPORTED for other channel counts. */
-int qt_conv3x3_direct_nib(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, const uint32_t* Wmat,
-                          int64_t ldw, const float* bias, const float* alpha, const float* beta, uint32_t* out,
+ * elem 0: fp4 nibble planes as above; elem 2: bf16 triple planes of a REAL-valued input (first layer: <= 5 channels, 32-byte
+ * pixels, Cw = 8; weights as for the bf16 implicit conv).  Bit-identical to the implicit-GEMM entry points for integer
+ * accumulators (elem 0); elem 2 sums the same exact products in fp32 in tap order.  QT_ERR_UNSUPPORTED for other channel
+ * counts. */
+int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                          const uint32_t* Wmat, int64_t ldw, const float* bias, const float* alpha, const float* beta, uint32_t* out,
                           int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream);
 
 /* qt_pool_bits with the pooled bits written the same way (nibble pixel plane of C channels, optional halo):

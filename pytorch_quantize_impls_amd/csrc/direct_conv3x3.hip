@@ -37,6 +37,16 @@ __device__ __forceinline__ d3_v16f d3_mfma(const uint4& a, const uint4& b, d3_v1
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
+// bf16 triple planes (real-valued first layers: x = hi + mid + lo exactly, weights +-1 / 0 replicated three times):
+// v_mfma_f32_32x32x16_bf16 takes the same 16 bytes per lane (8 bf16: K 0..7 from lanes 0..31, 8..15 from lanes 32..63)
+__device__ __forceinline__ d3_v16f d3_mfma_bf16(const uint4& a, const uint4& b, d3_v16f c) {
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    bf8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ uint32_t d3_spread8(uint32_t b) {
     uint32_t t = b & 0xFFu;
     t = (t | (t << 12)) & 0x000F000Fu;
@@ -61,7 +71,7 @@ constexpr int D3_TM = 256, D3_RUN = D3_TM + 2;
 
 // CPP: 16-byte chunks per input pixel (Cin = 32 * CPP); a workgroup = 4 (position) x WN (column) waves, each wave owns
 // 64 positions x TNW 32-column blocks (Cout <= 32 * TNW * WN); OCC: waves per SIMD the register budget is sized for
-template <int CPP, int TNW, int WN, int OCC>
+template <int CPP, int TNW, int WN, int OCC, bool BF16>
 __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     constexpr int NT = 256 * WN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -157,7 +167,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < TNW; ++b) acc[a][b] = d3_mfma(xf[a], wf[b], acc[a][b]);
+                    for (int b = 0; b < TNW; ++b)
+                        acc[a][b] = BF16 ? d3_mfma_bf16(xf[a], wf[b], acc[a][b]) : d3_mfma(xf[a], wf[b], acc[a][b]);
             }
         }
         // ---- threshold epilogue (same arithmetic as mfma_gemm.hip: bit = fl((acc + bias) * alpha) < -beta) ----
@@ -213,29 +224,30 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     }
 }
 
-template <int CPP, int TNW, int WN, int OCC>
+template <int CPP, int TNW, int WN, int OCC, bool BF16 = false>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
     const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, BF16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const long long cap = 256ll * wg_per_cu;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC>), dim3(grid), dim3(256 * WN), lds, stream, g);
+    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC, BF16>), dim3(grid), dim3(256 * WN), lds, stream, g);
     return qt_check_launch();
 }
 
 }  // namespace
 
-extern "C" int qt_conv3x3_direct_nib(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                                      const uint32_t* Wmat, int64_t ldw, const float* bias, const float* alpha,
                                      const float* beta, uint32_t* out, int64_t ldo, int64_t Cout, int out_bits,
                                      qt_stream_t stream) {
     if (N < 0 || H <= 0 || W <= 0 || Cout <= 0 || ldo <= 0) return QT_ERR_INVALID_ARG;
     if (N == 0) return QT_OK;
     if (!P || !Wmat || !alpha || !beta || !out) return QT_ERR_INVALID_ARG;
-    if ((Cw != 8 && Cw != 16) || Cout > 128) return QT_ERR_UNSUPPORTED;   // 64 / 128 input channels, one column tile
+    if (elem != 0 && elem != 2) return QT_ERR_INVALID_ARG;
+    if ((Cw != 8 && Cw != 16) || Cout > 128 || (elem == 2 && Cw != 8)) return QT_ERR_UNSUPPORTED;   // 32 / 64-byte pixels, one column tile
     if (ldw < 9 * Cw || (ldw & 3) || !qt_aligned16(P) || !qt_aligned16(Wmat) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
     if (out_bits ? (ldo < (Cout + 31) / 32) : (ldo != (Cout + 31) / 32 * 4)) return QT_ERR_INVALID_ARG;
     if (H + 2 > 32767 || W + 2 > 32767 || N * (H + 2) * (W + 2) > (1ll << 31)) return QT_ERR_UNSUPPORTED;
@@ -250,6 +262,7 @@ extern "C" int qt_conv3x3_direct_nib(const uint32_t* P, int64_t N, int64_t H, in
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
     hipStream_t s = (hipStream_t)stream;
     // LDS per workgroup: 44 / 64 KB (64 input channels), 87 / 125 KB (128)
+    if (elem == 2) return Cout <= 64 ? d3_launch<2, 2, 1, 3, true>(g, 3, s) : d3_launch<2, 4, 1, 2, true>(g, 2, s);
     if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3>(g, 3, s) : d3_launch<2, 4, 1, 2>(g, 2, s);
     return Cout <= 64 ? d3_launch<4, 1, 2, 2>(g, 1, s) : d3_launch<4, 2, 2, 2>(g, 1, s);
 }

@@ -292,16 +292,31 @@ class FusedConvPoolBnSign(torch.nn.Module):
             if not (isinstance(x, torch.Tensor) and x.is_cuda):
                 raise TypeError("FusedConvPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
             wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
-            if nib_out and not pooled:
+            planes = shape = None
+            if (DIRECT_FIRST_LAYER and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
+                    and (not nib_out or pooled or tuple(self.out_nib_halo) == (1, 1))
+                    and ops.direct_first_layer_applicable(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride,
+                                                          conv.padding, conv.dilation)):
+                # real-valued 3x3 / stride-1 / padding-1 first layer: direct kernel on the padded bf16-triple plane
+                N, C, H, W = (int(v) for v in x.shape)
+                px, _ = ops.s2d_triple_pack(x, 1, 1)
+                wtr = conv._conv_triples("plain")
+                e2 = ops.NibEpilogue(epi[0], epi[1], (1, 1)) if (nib_out and not pooled) else epi
+                planes = ops.conv3x3_direct_nib(px, N, C, H, W, wtr, conv.bias, e2)
+                shape = (N, conv.out_channels, H, W)
+                if isinstance(planes, ops.NibPlanes):
+                    return packed.PackedActivation(None, shape, nib=planes, halo=(1, 1))
+            elif nib_out and not pooled:
                 if (D2S_FIRST_LAYER and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
                         and ops.d2s_first_layer_applicable(conv.in_channels, conv.out_channels, conv.kernel_size,
                                                            conv.stride, conv.padding, conv.dilation, x.shape[2], x.shape[3])):
                     return self._first_layer_d2s(x, epi)
                 epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo)
-            planes, shape = _fused.quant_conv2d_forward(
-                x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups, self.kind,
-                weight_q=conv.weight, weight_planes=wp, binary_input=conv.binary_input,
-                padding_mode=conv.padding_mode, weight_triples_fn=conv._conv_triples, epi=epi)
+            if planes is None:
+                planes, shape = _fused.quant_conv2d_forward(
+                    x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups, self.kind,
+                    weight_q=conv.weight, weight_planes=wp, binary_input=conv.binary_input,
+                    padding_mode=conv.padding_mode, weight_triples_fn=conv._conv_triples, epi=epi)
         if isinstance(planes, ops.NibPlanes):
             return packed.PackedActivation(None, shape, nib=planes, halo=self.out_nib_halo)
         N, Cout, Ho, Wo = shape
@@ -338,6 +353,9 @@ class FusedConvPoolBnSign(torch.nn.Module):
 
 #: real-valued 3x3 / stride-1 / padding-1 first layers of fused stacks run in the 2x2 output-blocked form
 D2S_FIRST_LAYER = True
+#: real-valued 3x3 / stride-1 / padding-1 first layers with <= 5 channels run on the direct kernel (bf16 triple planes);
+#: takes precedence over the output-blocked form
+DIRECT_FIRST_LAYER = True
 #: fused conv blocks on +-1 activations use per-channel integer thresholds (ops.integer_thresholds) in the epilogue
 INTEGER_THRESHOLDS = True
 

@@ -1005,16 +1005,27 @@ def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dil
     return isinstance(epi, tuple) and len(epi) in (2, 3) and pixel_ld_nib(C) == 8
 
 
-def conv3x3_direct_nib(pixels: NibPlanes, N: int, C: int, H: int, W: int, wplanes: NibPlanes, bias, epi):
-    """Direct 3x3 conv of a halo-1 nibble plane with the threshold epilogue; returns BitPlanes ([N*H*W] rows) for
-    ``epi`` = (alpha, beta) or the halo-1 NibPlanes of the next conv for a NibEpilogue."""
-    Cw = pixel_ld_nib(C)
-    if pixels.rows != N * (H + 2) * (W + 2) or pixels.ld != Cw:
+def conv3x3_direct_nib(pixels, N: int, C: int, H: int, W: int, wplanes, bias, epi):
+    """Direct 3x3 conv of a halo-1 pixel plane with the threshold epilogue; returns BitPlanes ([N*H*W] rows) for
+    ``epi`` = (alpha, beta[, thr]) or the halo-1 NibPlanes of the next conv for a NibEpilogue.  ``pixels`` / ``wplanes``:
+    NibPlanes (+-1 activations) or TriplePlanes (real-valued first layer, <= 5 channels)."""
+    real = isinstance(pixels, TriplePlanes)
+    if real:
+        Cw = triple_ld_bytes(C, 16) // 4
+        words, ldw_words, Cout = pixels.data, wplanes.ld_words, wplanes.rows
+        if Cw != 8 or int(pixels.data.shape[1]) * 2 != Cw * 4 or ldw_words < 9 * Cw:
+            raise ValueError("direct first-layer conv expects 32-byte triple pixels (<= 5 channels)")
+        wwords = wplanes.data
+    else:
+        Cw = pixel_ld_nib(C)
+        words, wwords, ldw_words, Cout = pixels.words, wplanes.words, wplanes.ld, wplanes.rows
+        if pixels.ld != Cw:
+            raise ValueError("direct conv expects the [N, H+2, W+2] halo plane of the activation")
+        if wplanes.K != 9 * Cw * 8:
+            raise ValueError("weight planes do not match the activation's channel packing")
+    if pixels.rows != N * (H + 2) * (W + 2):
         raise ValueError("direct conv expects the [N, H+2, W+2] halo plane of the activation")
-    if wplanes.K != 9 * Cw * 8:
-        raise ValueError("weight planes do not match the activation's channel packing")
-    Cout = wplanes.rows
-    dev = pixels.device
+    dev = words.device
     nib_out = isinstance(epi, NibEpilogue)
     alpha, beta = (epi.alpha, epi.beta) if nib_out else epi[:2]
     alpha, beta, bias = _check_bias(alpha, Cout, dev), _check_bias(beta, Cout, dev), _check_bias(bias, Cout, dev)
@@ -1025,12 +1036,19 @@ def conv3x3_direct_nib(pixels: NibPlanes, N: int, C: int, H: int, W: int, wplane
         ldo = packed_ld(Cout)
         out = torch.empty((N * H * W, ldo), dtype=torch.int32, device=dev)
     with _on(dev):
-        _lib.call("qt_conv3x3_direct_nib", _p(pixels.words), int(N), int(H), int(W), int(Cw), _p(wplanes.words),
-                  int(wplanes.ld), _p(bias), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1,
+        _lib.call("qt_conv3x3_direct_nib", 2 if real else 0, _p(words), int(N), int(H), int(W), int(Cw), _p(wwords),
+                  int(ldw_words), _p(bias), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1,
                   _stream(dev))
     if nib_out:
         return NibPlanes(words=out, rows=int(out.shape[0]), K=Cout)
     return BitPlanes(sign=out, rows=N * H * W, K=Cout)
+
+
+def direct_first_layer_applicable(Cin: int, Cout: int, kernel_hw, stride, padding, dilation) -> bool:
+    """Real-valued 3x3 / stride-1 / padding-1 first layer with 32-byte bf16-triple pixels (<= 5 channels): the direct
+    kernel on the physically padded triple plane (s2d_triple_pack(x, 1, 1))."""
+    return (DIRECT_CONV3X3 and tuple(kernel_hw) == (3, 3) and _pairs(stride) == (1, 1) and _pairs(padding) == (1, 1)
+            and _pairs(dilation) == (1, 1) and triple_ld_bytes(Cin, 16) == 32 and Cout <= 128)
 
 
 def zero_halo(words: torch.Tensor, N: int, H: int, W: int, halo) -> torch.Tensor:

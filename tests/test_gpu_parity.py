@@ -1379,6 +1379,13 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
     blk.out_nib_halo = (1, 1)
     x_exact = g(np.round(synth.normal(47, (N, Cin, H, W)) * 16) / 8, dev).contiguous(memory_format=torch.channels_last)
     x_gauss = g(synth.normal(48, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    # third form: the direct 3x3 kernel on the padded bf16-triple plane (what the fused stacks use by default)
+    monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", True)
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        direct = (blk(x_exact), blk(x_gauss))
+    assert _lib.call_counts["qt_conv3x3_direct_nib"] - before.get("qt_conv3x3_direct_nib", 0) == 2
+    monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", False)
     outs = {}
     for flag in (True, False):
         monkeypatch.setattr(fused_mod, "D2S_FIRST_LAYER", flag)
@@ -1392,6 +1399,16 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
     assert torch.equal(a[0].nib.words, b[0].nib.words)
     diff = (a[1].nib.words != b[1].nib.words).float().mean().item()
     assert diff < 1e-3, diff
+    assert direct[0].halo == (1, 1) and torch.equal(direct[0].nib.words, b[0].nib.words)
+    assert (direct[1].nib.words != b[1].nib.words).float().mean().item() < 1e-3
+    # pooled first block (bit planes into the pooling kernel) through the direct kernel as well
+    blk_p = FusedConvPoolBnSign(conv, bn, torch.nn.MaxPool2d(2, 2))
+    with torch.no_grad():
+        monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", True)
+        p1 = blk_p(x_exact)
+        monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", False)
+        p0 = blk_p(x_exact)
+    assert torch.equal(p1.planes.sign, p0.planes.sign)
 
 
 @pytest.mark.gpu
