@@ -399,6 +399,16 @@ int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int
                           const uint32_t* Wmat, int64_t ldw, const float* bias, const float* alpha, const float* beta, uint32_t* out,
                           int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream);
 
+/* The direct 3x3 kernel for DoReFa int8 code planes with the code epilogue of qt_conv2d_implicit_codes (same arithmetic,
+ * bit-identical): P, codes and (optional) res_codes are planes with a 1-pixel halo of identical geometry,
+ * [N][H+2][W+2][.]; every byte of `codes` is written, the halo as zeros.  Cw = 16 words (64 input channels), Cout <= 64,
+ * ldc_bytes == Cout rounded up to 16.  QT_ERR_UNSUPPORTED for other channel counts. */
+int qt_conv3x3_direct_codes(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, const uint32_t* Wmat,
+                            int64_t ldw, const float* bias, float scale, const float* scale_dev, const float* alpha,
+                            const float* beta, const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu,
+                            int bit_width, int8_t* codes, int64_t ldc_bytes, int64_t Cout, int32_t* overflow,
+                            qt_stream_t stream);
+
 /* qt_pool_bits with the pooled bits written the same way (nibble pixel plane of C channels, optional halo):
  * qt_pool_bits + qt_bits_to_nib_pad in one pass. */
 int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int64_t ld, int64_t pool_k,

@@ -90,6 +90,8 @@ SIGNATURES = {
                                                                         _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_conv3x3_direct_nib": (_c_int, [_c_int, _c_p] + [_c_i64] * 4 + [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64,
                                         _c_int, _c_p]),
+    "qt_conv3x3_direct_codes": (_c_int, [_c_p] + [_c_i64] * 4 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_i64,
+                                          _c_f32, _c_int, _c_int, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "qt_pool_bits_nib": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p] + [_c_i64] * 4 + [_c_p]),
     "qt_pool_bits": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p, _c_p]),
     "qt_pool_codes_i8": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_i64, _c_i64, _c_p]),

@@ -24,6 +24,8 @@
 // fp4 MFMA operand layout as in mfma_gemm.hip: v_mfma_scale_f32_32x32x64_f8f6f4, lane l supplies 16 bytes (32
 // nibbles) of row l % 32: K elements 0..31 from lanes 0..31, 32..63 from lanes 32..63; accumulator register r of lane
 // l = (row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31).
+#include <type_traits>
+
 #include "qt_common.h"
 
 namespace {
@@ -47,6 +49,15 @@ __device__ __forceinline__ d3_v16f d3_mfma_bf16(const uint4& a, const uint4& b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
 }
 
+// int8 code planes (DoReFa activations x +-1 weight codes): v_mfma_i32_32x32x32_i8, 16 bytes = 16 K elements per lane
+typedef int d3_v4i __attribute__((ext_vector_type(4)));
+typedef int d3_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ d3_v16i d3_mfma_i8(const uint4& a, const uint4& b, d3_v16i c) {
+    const d3_v4i av = (d3_v4i){(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+    const d3_v4i bv = (d3_v4i){(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ uint32_t d3_spread8(uint32_t b) {
     uint32_t t = b & 0xFFu;
     t = (t | (t << 12)) & 0x000F000Fu;
@@ -65,15 +76,23 @@ struct D3Args {
     long long total;          // N * Hp * Wp positions
     int H, W, Hp, Wp, Cout, ldw, ldo, out_bits;
     unsigned long long magic_plane, magic_wp;   // ceil(2^64 / (Hp*Wp)), ceil(2^64 / Wp): exact 32-bit quotients
+    // EL == 1 (int8 code planes, DoReFa code epilogue as qt_conv2d_implicit_codes; out = int8 halo plane, ldo in BYTES)
+    float scale, rscale, levels;
+    const float* scale_dev;
+    const unsigned char* res_codes;   // residual code plane with the same halo geometry, ldrc bytes per pixel
+    int ldrc, relu;
+    int* overflow;
 };
 
 constexpr int D3_TM = 256, D3_RUN = D3_TM + 2;
 
 // CPP: 16-byte chunks per input pixel (Cin = 32 * CPP); a workgroup = 4 (position) x WN (column) waves, each wave owns
 // 64 positions x TNW 32-column blocks (Cout <= 32 * TNW * WN); OCC: waves per SIMD the register budget is sized for
-template <int CPP, int TNW, int WN, int OCC, bool BF16>
+template <int CPP, int TNW, int WN, int OCC, int EL>
 __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     constexpr int NT = 256 * WN;
+    constexpr bool I8 = EL == 1, BF16 = EL == 2;
+    using acc_t = typename std::conditional<I8, d3_v16i, d3_v16f>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WROW = 9 * CPP * 16 + 16;        // + 16: consecutive rows land on different bank groups
     constexpr int WBYTES = TNW * WN * 32 * WROW;
@@ -138,13 +157,13 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
         }
         __syncthreads();
         if (tile + 1 < t_end) fetch(tile + 1);
-        d3_v16f acc[2][TNW];
+        acc_t acc[2][TNW];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < TNW; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
         // one kernel row at a time: a fully unrolled tap loop lets the scheduler hoist all 36 fragment reads (198 VGPRs,
         // 2 waves per SIMD); rolled over i it keeps 12 in flight
 #pragma unroll 1
@@ -167,56 +186,137 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < TNW; ++b)
-                        acc[a][b] = BF16 ? d3_mfma_bf16(xf[a], wf[b], acc[a][b]) : d3_mfma(xf[a], wf[b], acc[a][b]);
+                    for (int b = 0; b < TNW; ++b) {
+                        if constexpr (I8) acc[a][b] = d3_mfma_i8(xf[a], wf[b], acc[a][b]);
+                        else if constexpr (BF16) acc[a][b] = d3_mfma_bf16(xf[a], wf[b], acc[a][b]);
+                        else acc[a][b] = d3_mfma(xf[a], wf[b], acc[a][b]);
+                    }
             }
         }
-        // ---- threshold epilogue (same arithmetic as mfma_gemm.hip: bit = fl((acc + bias) * alpha) < -beta) ----
+        if constexpr (I8) {
+            // ---- DoReFa code epilogue (arithmetic of mfma_gemm.hip's mode-2 epilogue): y = (float)acc * scale + bias is the
+            // fp32 value the conv would store; t = fl(fl(y*alpha) + beta) [+ fl(rscale * rcode)]; ReLU; q = rint(levels*t).
+            // The 32x32 tile goes through a wave-private LDS patch so that a lane holds 4 consecutive channels of a row.
+            float* T = reinterpret_cast<float*>(patch + 3 * D3_RUN * CPP * 16) + (tid >> 6) * 1024;
+            const float sc = g.scale_dev ? g.scale * *g.scale_dev : g.scale;
+            int bad = 0;
+            unsigned vmask = 0;                     // validity of this lane's 4 rows per a: bit a*4 + i
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const long long q = q0 + wave * 64 + a * 32 + lrow;           // lanes 0..31 own the 32 positions
-            bool valid = false;
-            long long mrow = 0;
-            if (q < g.total) {
-                const unsigned uq = (unsigned)q;                       // total <= 2^31 (host check)
-                const unsigned img = (unsigned)__umul64hi((unsigned long long)uq, g.magic_plane);
-                const unsigned rem = uq - img * plane;
-                const int y = (int)__umul64hi((unsigned long long)rem, g.magic_wp), x = (int)rem - y * g.Wp;
-                valid = y >= 1 && y <= g.H && x >= 1 && x <= g.W;
-                mrow = ((long long)img * g.H + (y - 1)) * g.W + (x - 1);
-            }
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long q = q0 + wave * 64 + a * 32 + i * 8 + (lane >> 3);
+                    if (q < g.total) {
+                        const unsigned uq = (unsigned)q;
+                        const unsigned img = (unsigned)__umul64hi((unsigned long long)uq, g.magic_plane);
+                        const unsigned rem = uq - img * plane;
+                        const int y = (int)__umul64hi((unsigned long long)rem, g.magic_wp), x = (int)rem - y * g.Wp;
+                        if (y >= 1 && y <= g.H && x >= 1 && x <= g.W) vmask |= 1u << (a * 4 + i);
+                    }
+                }
+            unsigned char* Q = reinterpret_cast<unsigned char*>(g.out);
 #pragma unroll
             for (int b = 0; b < TNW; ++b) {
-                uint32_t myword = 0;
+                const int nb = (wave_n * TNW + b) * 32;
+                const float bvv = (g.bias && nb + lrow < g.Cout) ? g.bias[nb + lrow] : 0.0f;
+                const int n = nb + (lane & 7) * 4;
+                float al4[4], be4[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = acc[a][b][r] + bv[b];
-                    const unsigned long long mask = __ballot(t * al[b] < nbe[b]);
-                    const int R = (r & 3) + 8 * (r >> 2);
-                    // gfx950 does not interlock a VALU-written SGPR read by the next VALU: see mfma_gemm.hip
-                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = n + e < g.Cout;
+                    al4[e] = in ? g.alpha[n + e] : 0.0f;
+                    be4[e] = in ? g.beta[n + e] : 0.0f;
                 }
-                const int bg = wave_n * TNW + b;                            // column block of the whole tile
-                if (lane < 32 && q < g.total) {
-                    if (g.out_bits) {
-                        if (valid && bg < g.ldo) {
-                            g.out[mrow * g.ldo + bg] = myword;
-                            if (bg == TNW * WN - 1)
-                                for (int wc = TNW * WN; wc < g.ldo; ++wc) g.out[mrow * g.ldo + wc] = 0u;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = (float)acc[a][b][r] * sc + bvv;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 8 + (lane >> 3);
+                        const float4 v4 = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
+                        const long long q = q0 + wave * 64 + a * 32 + row;
+                        if (q < g.total && n < g.ldo) {
+                            uint32_t word = 0;                       // border position: the output plane's halo
+                            if ((vmask >> (a * 4 + i)) & 1u) {
+                                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                                uint32_t rword = 0;
+                                if (g.res_codes && n < g.Cout)
+                                    rword = *reinterpret_cast<const uint32_t*>(g.res_codes + q * g.ldrc + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    int qc = 0;
+                                    if (n + e < g.Cout) {
+                                        const float x0 = (g.relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];
+                                        float t = x0 * al4[e] + be4[e];                 // two roundings (-ffp-contract=off)
+                                        if (g.res_codes) t = t + g.rscale * (float)(int8_t)(rword >> (8 * e));
+                                        if (g.relu == 1) t = t < 0.0f ? 0.0f : t;
+                                        const float qf = rintf(g.levels * t);
+                                        if (!(qf >= -127.0f && qf <= 127.0f)) bad = 1; else qc = (int)qf;
+                                    }
+                                    word |= (uint32_t)(uint8_t)(int8_t)qc << (8 * e);
+                                }
+                            }
+                            *reinterpret_cast<uint32_t*>(Q + q * g.ldo + n) = word;
                         }
-                    } else if (bg * 4 < g.ldo) {
-                        const int left = g.Cout - bg * 32;
-                        uint4 o = make_uint4(0, 0, 0, 0);                 // border position: the output plane's halo
-                        if (valid) {
-                            const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
-                            const uint32_t sw = myword & mw;
-                            o.x = (d3_spread8(mw) << 1) | (d3_spread8(sw) << 3);
-                            o.y = (d3_spread8(mw >> 8) << 1) | (d3_spread8(sw >> 8) << 3);
-                            o.z = (d3_spread8(mw >> 16) << 1) | (d3_spread8(sw >> 16) << 3);
-                            o.w = (d3_spread8(mw >> 24) << 1) | (d3_spread8(sw >> 24) << 3);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (__any(bad) && lane == 0) atomicOr(g.overflow, 1);
+        } else {
+            // ---- threshold epilogue (same arithmetic as mfma_gemm.hip: bit = fl((acc + bias) * alpha) < -beta) ----
+    #pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const long long q = q0 + wave * 64 + a * 32 + lrow;           // lanes 0..31 own the 32 positions
+                bool valid = false;
+                long long mrow = 0;
+                if (q < g.total) {
+                    const unsigned uq = (unsigned)q;                       // total <= 2^31 (host check)
+                    const unsigned img = (unsigned)__umul64hi((unsigned long long)uq, g.magic_plane);
+                    const unsigned rem = uq - img * plane;
+                    const int y = (int)__umul64hi((unsigned long long)rem, g.magic_wp), x = (int)rem - y * g.Wp;
+                    valid = y >= 1 && y <= g.H && x >= 1 && x <= g.W;
+                    mrow = ((long long)img * g.H + (y - 1)) * g.W + (x - 1);
+                }
+    #pragma unroll
+                for (int b = 0; b < TNW; ++b) {
+                    uint32_t myword = 0;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = acc[a][b][r] + bv[b];
+                        const unsigned long long mask = __ballot(t * al[b] < nbe[b]);
+                        const int R = (r & 3) + 8 * (r >> 2);
+                        // gfx950 does not interlock a VALU-written SGPR read by the next VALU: see mfma_gemm.hip
+                        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
+                    }
+                    const int bg = wave_n * TNW + b;                            // column block of the whole tile
+                    if (lane < 32 && q < g.total) {
+                        if (g.out_bits) {
+                            if (valid && bg < g.ldo) {
+                                g.out[mrow * g.ldo + bg] = myword;
+                                if (bg == TNW * WN - 1)
+                                    for (int wc = TNW * WN; wc < g.ldo; ++wc) g.out[mrow * g.ldo + wc] = 0u;
+                            }
+                        } else if (bg * 4 < g.ldo) {
+                            const int left = g.Cout - bg * 32;
+                            uint4 o = make_uint4(0, 0, 0, 0);                 // border position: the output plane's halo
+                            if (valid) {
+                                const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
+                                const uint32_t sw = myword & mw;
+                                o.x = (d3_spread8(mw) << 1) | (d3_spread8(sw) << 3);
+                                o.y = (d3_spread8(mw >> 8) << 1) | (d3_spread8(sw >> 8) << 3);
+                                o.z = (d3_spread8(mw >> 16) << 1) | (d3_spread8(sw >> 16) << 3);
+                                o.w = (d3_spread8(mw >> 24) << 1) | (d3_spread8(sw >> 24) << 3);
+                            }
+                            *reinterpret_cast<uint4*>(g.out + q * g.ldo + bg * 4) = o;
                         }
-                        *reinterpret_cast<uint4*>(g.out + q * g.ldo + bg * 4) = o;
                     }
                 }
             }
@@ -224,16 +324,16 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     }
 }
 
-template <int CPP, int TNW, int WN, int OCC, bool BF16 = false>
+template <int CPP, int TNW, int WN, int OCC, int EL = 0>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
-    const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, BF16>),
+    const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16 + (EL == 1 ? 4 * WN * 4096 : 0);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const long long cap = 256ll * wg_per_cu;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC, BF16>), dim3(grid), dim3(256 * WN), lds, stream, g);
+    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC, EL>), dim3(grid), dim3(256 * WN), lds, stream, g);
     return qt_check_launch();
 }
 
@@ -262,7 +362,41 @@ extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
     hipStream_t s = (hipStream_t)stream;
     // LDS per workgroup: 44 / 64 KB (64 input channels), 87 / 125 KB (128)
-    if (elem == 2) return Cout <= 64 ? d3_launch<2, 2, 1, 3, true>(g, 3, s) : d3_launch<2, 4, 1, 2, true>(g, 2, s);
+    if (elem == 2) return Cout <= 64 ? d3_launch<2, 2, 1, 3, 2>(g, 3, s) : d3_launch<2, 4, 1, 2, 2>(g, 2, s);
     if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3>(g, 3, s) : d3_launch<2, 4, 1, 2>(g, 2, s);
     return Cout <= 64 ? d3_launch<4, 1, 2, 2>(g, 1, s) : d3_launch<4, 2, 2, 2>(g, 1, s);
+}
+
+// The same direct kernel for DoReFa int8 code planes with the code epilogue of qt_conv2d_implicit_codes: P and codes are
+// halo-1 planes of identical geometry [N][H+2][W+2][.], res_codes (optional) likewise.  64 input channels (Cw = 16 words),
+// Cout <= 64.
+extern "C" int qt_conv3x3_direct_codes(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, const uint32_t* Wmat,
+                                       int64_t ldw, const float* bias, float scale, const float* scale_dev,
+                                       const float* alpha, const float* beta, const int8_t* res_codes, int64_t ldrc_bytes,
+                                       float res_scale, int relu, int bit_width, int8_t* codes, int64_t ldc_bytes,
+                                       int64_t Cout, int32_t* overflow, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Cout <= 0 || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2)
+        return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!P || !Wmat || !alpha || !beta || !codes || !overflow) return QT_ERR_INVALID_ARG;
+    if (Cw != 16 || Cout > 64) return QT_ERR_UNSUPPORTED;
+    if (ldw < 9 * Cw || (ldw & 3) || !qt_aligned16(P) || !qt_aligned16(Wmat) || !qt_aligned16(codes) || (ldc_bytes & 15))
+        return QT_ERR_ALIGNMENT;
+    if (ldc_bytes != ((Cout + 15) & ~15ll)) return QT_ERR_INVALID_ARG;
+    if (res_codes && (ldrc_bytes < ((Cout + 3) & ~3ll) || (ldrc_bytes & 3) || (reinterpret_cast<uintptr_t>(res_codes) & 3)))
+        return QT_ERR_ALIGNMENT;
+    if (H + 2 > 32767 || W + 2 > 32767 || N * (H + 2) * (W + 2) > (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    D3Args g;
+    g.P = reinterpret_cast<const unsigned char*>(P);
+    g.Wm = reinterpret_cast<const unsigned char*>(Wmat);
+    g.bias = bias; g.alpha = alpha; g.beta = beta; g.out = reinterpret_cast<uint32_t*>(codes);
+    g.H = (int)H; g.W = (int)W; g.Hp = (int)H + 2; g.Wp = (int)W + 2;
+    g.total = N * (int64_t)g.Hp * g.Wp;
+    g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldc_bytes; g.out_bits = 0;
+    g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;
+    g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
+    g.scale = scale; g.scale_dev = scale_dev; g.rscale = res_scale; g.levels = (float)((1 << bit_width) - 1);
+    g.res_codes = reinterpret_cast<const unsigned char*>(res_codes); g.ldrc = (int)ldrc_bytes; g.relu = relu;
+    g.overflow = overflow;
+    return d3_launch<4, 1, 2, 2, 1>(g, 1, (hipStream_t)stream);
 }

@@ -369,6 +369,10 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
         wc = weight_codes if weight_codes is not None else ops.pack_conv_weight_codes(weight.detach())
         if epi is not None and epi.overflow is None:
             epi.overflow = codes.overflow
+        if epi is not None and ops.direct_conv3x3_codes_applicable(C, int(weight.shape[0]), (kh, kw), stride, padding,
+                                                                   dilation, input.halo, epi):
+            y2 = ops.conv3x3_direct_codes(codes, N_, C, H, W, wc, codes.inv_n, bias, E, epi)
+            return packed.CodeActivation(y2, (N_, weight.shape[0], H, W), halo=(1, 1))
         y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding, dilation,
                               scale_dev=E, epi=epi, in_halo=input.halo)
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)

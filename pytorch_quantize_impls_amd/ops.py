@@ -1044,6 +1044,49 @@ def conv3x3_direct_nib(pixels, N: int, C: int, H: int, W: int, wplanes, bias, ep
     return BitPlanes(sign=out, rows=N * H * W, K=Cout)
 
 
+#: the int8 (DoReFa code plane) variant of the direct kernel is bit-identical but not faster than the implicit GEMM at the
+#: shapes that fit it (ResNet-18 stage 1, 64 -> 64 at 32^2, batch 256: 42.6 vs 41 us: 4.5 tiles per CU at one 8-wave
+#: workgroup per CU), so it is not dispatched
+DIRECT_CONV3X3_CODES = False
+
+
+def direct_conv3x3_codes_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation, in_halo, epi) -> bool:
+    """DoReFa code planes: 3x3 / stride 1 / padding 1, 64 input channels, <= 64 output channels, halo 1 in and out, residual
+    (if any) as codes with the same halo."""
+    return (DIRECT_CONV3X3_CODES and isinstance(epi, CodeEpilogue) and tuple(kernel_hw) == (3, 3) and _pairs(stride) == (1, 1)
+            and _pairs(padding) == (1, 1) and _pairs(dilation) == (1, 1) and tuple(in_halo) == (1, 1)
+            and tuple(epi.out_halo) == (1, 1) and code_ld_bytes(C, 16) == 64 and Cout <= 64 and epi.res_f32 is None
+            and (epi.res_codes is None or tuple(epi.res_halo) == (1, 1)))
+
+
+def conv3x3_direct_codes(pixels: CodePlanes, N: int, C: int, H: int, W: int, wplanes: CodePlanes, scale: float, bias,
+                         scale_dev, epi: CodeEpilogue) -> CodePlanes:
+    """Direct 3x3 conv of a halo-1 int8 code plane with the DoReFa code epilogue -> halo-1 code plane."""
+    Cw = int(pixels.codes.shape[1]) // 4
+    rows = N * (H + 2) * (W + 2)
+    if pixels.rows != rows or Cw != 16 or wplanes.K != 9 * Cw * 4:
+        raise ValueError("direct code conv expects the [N, H+2, W+2] halo plane of a 64-channel activation")
+    Cout = wplanes.rows
+    dev = pixels.device
+    alpha, beta, bias = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev), _check_bias(bias, Cout, dev)
+    rc, ldrc, rscale = None, 0, 0.0
+    if epi.res_codes is not None:
+        if epi.res_codes.rows != rows or epi.res_codes.K != Cout:
+            raise ValueError("residual codes must be a halo-1 plane of the output's geometry")
+        rc, ldrc, rscale = epi.res_codes.codes, int(epi.res_codes.codes.shape[1]), float(epi.res_codes.inv_n)
+    ldc = code_ld_bytes(Cout, 16)
+    codes = torch.empty((rows, ldc), dtype=torch.int8, device=dev)
+    flag = epi.overflow if epi.overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
+    with _on(dev):
+        _lib.call("qt_conv3x3_direct_codes", _p(pixels.codes), int(N), int(H), int(W), int(Cw), _p(wplanes.codes),
+                  int(wplanes.ld_words), _p(bias), float(scale),
+                  _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None), _p(alpha), _p(beta),
+                  _p(rc), int(ldrc), float(rscale), relu_mode(epi.relu), int(epi.bit_width), _p(codes), int(ldc), int(Cout),
+                  _p(flag), _stream(dev))
+    return CodePlanes(codes=codes, rows=rows, K=Cout, inv_n=inv_levels(epi.bit_width), bit_width=int(epi.bit_width),
+                      overflow=flag)
+
+
 def direct_first_layer_applicable(Cin: int, Cout: int, kernel_hw, stride, padding, dilation) -> bool:
     """Real-valued 3x3 / stride-1 / padding-1 first layer with 32-byte bf16-triple pixels (<= 5 channels): the direct
     kernel on the physically padded triple plane (s2d_triple_pack(x, 1, 1))."""

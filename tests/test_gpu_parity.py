@@ -1470,6 +1470,45 @@ def test_integer_threshold_epilogue_equals_float_epilogue(dev, Cin, Cout, ksz, s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cout,N,H,W,k,relu,res", [(64, 3, 12, 9, 4, True, True), (64, 2, 32, 32, 4, True, False),
+                                                   (40, 4, 7, 5, 3, "pre", True), (64, 1, 1, 1, 4, False, True)])
+def test_direct_code_conv_equals_implicit_code_epilogue(dev, monkeypatch, Cout, N, H, W, k, relu, res):
+    """qt_conv3x3_direct_codes (direct 3x3 kernel, int8 code planes, DoReFa code epilogue) == qt_conv2d_implicit_codes on
+    the same halo planes, byte for byte including the halo it writes and the shared overflow flag."""
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedDorefaConvBnQuant
+    C = 64
+    torch.manual_seed(71)
+    conv = DorefaConv2d(C, Cout, 3, padding=1, bias=True, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev)
+    bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 3); bn.weight.data.uniform_(-0.6, 0.6); bn.bias.data.uniform_(-0.2, 0.3)
+    bn.eval()
+
+    def halo_act(x2, Cn, kk):
+        cp, _ = ops.dorefa_codes(x2, kk, want_f32=False, ld_bytes=ops.code_ld_bytes(Cn, 16))
+        q = ops.pad_pixel_plane(cp.codes, N, H, W, (1, 1))
+        cp = ops.CodePlanes(codes=q, rows=int(q.shape[0]), K=Cn, inv_n=cp.inv_n, bit_width=kk, overflow=cp.overflow)
+        return packed.CodeActivation(cp, (N, Cn, H, W), halo=(1, 1))
+
+    act = halo_act(torch.rand((N * H * W, C), device=dev) * 1.2, C, 4)
+    residual = halo_act(torch.rand((N * H * W, Cout), device=dev), Cout, k) if res else None
+    blk = FusedDorefaConvBnQuant(conv, bn, k, relu=relu, out_halo=1)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "DIRECT_CONV3X3_CODES", flag)
+        junk = torch.full((N * (H + 2) * (W + 2), ops.code_ld_bytes(Cout, 16)), 85, dtype=torch.int8, device=dev)
+        del junk
+        before = dict(_lib.call_counts)
+        with torch.no_grad():
+            outs[flag] = blk(act, residual=residual)
+        used = {k_: v - before.get(k_, 0) for k_, v in _lib.call_counts.items() if v - before.get(k_, 0)}
+        assert ("qt_conv3x3_direct_codes" in used) == flag and ("qt_conv2d_implicit_codes" in used) == (not flag), used
+    a, b = outs[True], outs[False]
+    assert a.halo == b.halo == (1, 1) and a.shape == b.shape
+    assert torch.equal(a.codes.codes, b.codes.codes)
+    assert int(a.codes.overflow.item()) == int(b.codes.overflow.item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("halo", [(1, 1), (2, 0), (0, 3)])
 def test_zero_halo_touches_only_the_border(dev, halo):
     N, H, W, C = 3, 5, 7, 48
