@@ -359,3 +359,26 @@ def test_integer_thresholds_reproduce_the_float_predicate_exactly():
         want = (k + bb) * alpha < -beta
         got = (k < thr) ^ (alpha < 0)
         assert torch.equal(got, want)
+
+
+def test_output_blocked_first_layer_weight_is_the_same_conv():
+    """ops.d2s_first_layer_weight: the 4x4 / stride-2 / padding-1 conv with the four shifted copies of a 3x3 kernel,
+    followed by depth-to-space, IS the 3x3 / stride-1 / padding-1 conv; and its space-to-depth form (ops.s2d_input /
+    ops.s2d_weight with s = 2: 2x2 taps over 4C channels) is the same conv again (integer-valued inputs, so equality is exact)."""
+    import torch
+    from pytorch_quantize_impls_amd import ops
+    torch.manual_seed(4)
+    N, C, H, W, Cout = 2, 3, 8, 6, 5
+    x = torch.randint(-50, 50, (N, C, H, W)).to(torch.float64)          # integer values: every summation order is exact
+    w = torch.randn(Cout, C, 3, 3, dtype=torch.float64).sign()
+    want = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    w4 = ops.d2s_first_layer_weight(w)
+    assert tuple(w4.shape) == (4 * Cout, C, 4, 4)
+    y4 = torch.nn.functional.conv2d(x, w4, None, 2, 1)                     # [N, (dy, dx, co), H/2, W/2]
+    got = y4.view(N, 2, 2, Cout, H // 2, W // 2).permute(0, 3, 4, 1, 5, 2).reshape(N, Cout, H, W)
+    assert torch.equal(got, want)
+    ys = torch.nn.functional.conv2d(ops.s2d_input(x, 2, 1), ops.s2d_weight(w4, 2), None, 1, 0)
+    assert torch.equal(ys, y4)
+    assert ops.d2s_first_layer_applicable(3, 64, (3, 3), 1, 1, 1, 224, 224)
+    assert not ops.d2s_first_layer_applicable(3, 64, (3, 3), 1, 1, 1, 223, 224)      # odd size: no 2x2 blocking
+    assert not ops.d2s_first_layer_applicable(3, 48, (3, 3), 1, 1, 1, 224, 224)      # channel groups of 32 in the epilogue
