@@ -64,7 +64,7 @@ __device__ __attribute__((aligned(16))) const unsigned char zero16_storage[16] =
 // Either way 16 rows distinct mod 16 land on 16 distinct 16-byte slots.
 template <int SB>
 __device__ __forceinline__ int swz(int row, int chunk) {
-    return SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+    return SB == 256 ? (chunk ^ (row & 15)) : SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
 }
 
 // One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_dst), issued
@@ -950,7 +950,10 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
 template <class E, int PIPE, int ABL = 0> using Cfg256 = GemmCfg<E, 2, 4, 4, 2, PIPE, ABL>;
 template <class E, int PIPE> using Cfg128 = GemmCfg<E, 2, 4, 4, 1, PIPE>;
 template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
-template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;   // 256x192 (wave 64x96): N = 576, 1152, ...
+template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;
+// skinny GEMMs (M <= 256: FC layers): 128x64 tiles (2x the workgroups) with 256-byte stages (half the latency-bound
+// stage round trips of the K loop)
+template <class E> using CfgSkinny = GemmCfg<E, 4, 2, 1, 1, 1, 0, 256>;   // 256x192 (wave 64x96): N = 576, 1152, ...
 
 // ping-pong configurations (64-byte stages, ring of 4)
 template <class E, int ABL = 0> using PP256 = GemmCfg<E, 2, 4, 4, 2, 2, ABL, 64, false>;
@@ -1036,6 +1039,9 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
     switch (variant) {
         case 0: {  // automatic: tile width by N and CU fill, fast path when its contract holds
             const int tn = pick_tile_n_gemm(M, N);
+            // skinny (FC at batch <= 512): the K loop is a chain of latency-bound stage round trips on a quarter of
+            // the CUs — 128x64 tiles and 256-byte stages (tools/bench_gemm_variants.py: 256x4096x25088 75 -> 48 us)
+            if (pipe_ok && M <= 512 && !((ldxp | ldwp) & 63)) QT_GO(CfgSkinny<E>);
             if (pipe_ok) {
                 if (tn == 256) QT_GO(PP256<E>);
                 if (tn == 192 && prefer_384_rows(M, N)) QT_GO(PP384x192<E>);
@@ -1056,6 +1062,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 8: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg64<E, 1>);
         case 9: QT_GO(Cfg128<E, 0>);
         case 10: QT_GO(Cfg64<E, 0>);
+        case 30: if (!pipe_ok || ((ldxp | ldwp) & 63)) return QT_ERR_ALIGNMENT; QT_GO(CfgSkinny<E>);
         case 20: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E>);
         case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
         case 166: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 6>);
