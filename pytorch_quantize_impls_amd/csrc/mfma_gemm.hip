@@ -64,7 +64,7 @@ __device__ __attribute__((aligned(16))) const unsigned char zero16_storage[16] =
 // Either way 16 rows distinct mod 16 land on 16 distinct 16-byte slots.
 template <int SB>
 __device__ __forceinline__ int swz(int row, int chunk) {
-    return SB == 256 ? (chunk ^ (row & 15)) : SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+    return SB == 512 ? (chunk ^ (row & 31)) : SB == 256 ? (chunk ^ (row & 15)) : SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
 }
 
 // One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_dst), issued
@@ -953,7 +953,8 @@ template <class E, int PIPE> using Cfg64 = GemmCfg<E, 4, 2, 2, 1, PIPE>;
 template <class E, int PIPE> using Cfg192 = GemmCfg<E, 4, 2, 2, 3, PIPE>;
 // skinny GEMMs (M <= 256: FC layers): 128x64 tiles (2x the workgroups) with 256-byte stages (half the latency-bound
 // stage round trips of the K loop)
-template <class E> using CfgSkinny = GemmCfg<E, 4, 2, 1, 1, 1, 0, 256>;   // 256x192 (wave 64x96): N = 576, 1152, ...
+template <class E> using CfgSkinny = GemmCfg<E, 4, 2, 1, 1, 1, 0, 256>;
+template <class E> using CfgSkinny512 = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512>;   // 64x64 tiles, 512-byte stages, 4 waves   // 256x192 (wave 64x96): N = 576, 1152, ...
 
 // ping-pong configurations (64-byte stages, ring of 4)
 template <class E, int ABL = 0> using PP256 = GemmCfg<E, 2, 4, 4, 2, 2, ABL, 64, false>;
@@ -1041,6 +1042,8 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
             const int tn = pick_tile_n_gemm(M, N);
             // skinny (FC at batch <= 512): the K loop is a chain of latency-bound stage round trips on a quarter of
             // the CUs — 128x64 tiles and 256-byte stages (tools/bench_gemm_variants.py: 256x4096x25088 75 -> 48 us)
+            // ... and 64x64 tiles with 512-byte stages up to M = 256 (256x4096x9216: 21.4 -> 13.7 us)
+            if (pipe_ok && M <= 256 && !((ldxp | ldwp) & 127)) QT_GO(CfgSkinny512<E>);
             if (pipe_ok && M <= 512 && !((ldxp | ldwp) & 63)) QT_GO(CfgSkinny<E>);
             if (pipe_ok) {
                 if (tn == 256) QT_GO(PP256<E>);
@@ -1063,6 +1066,7 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 9: QT_GO(Cfg128<E, 0>);
         case 10: QT_GO(Cfg64<E, 0>);
         case 30: if (!pipe_ok || ((ldxp | ldwp) & 63)) return QT_ERR_ALIGNMENT; QT_GO(CfgSkinny<E>);
+        case 31: if (!pipe_ok || ((ldxp | ldwp) & 127)) return QT_ERR_ALIGNMENT; QT_GO(CfgSkinny512<E>);
         case 20: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E>);
         case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
         case 166: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 6>);
