@@ -1448,7 +1448,11 @@ def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
     if requested == "auto":
         ops_ = 2.0 * M * N * K
         big = (ops_ >= MFMA_MIN_OPS or (ops_ >= MFMA_MIN_OPS_LONG_K and K >= MFMA_LONG_K)) and K < (1 << 24)
-        return "mfma" if big else "valu"
+        # skinny, long-K products (FC layers at batch <= 256): the 64x64 / 512-byte-stage matrix-core configuration beats
+        # the weight-streaming popcount kernel even with the bits -> nibble expansion of the activation in front of it
+        # (256x1000x4096: 5 + 4.5 us vs 19.7 us; tools/bench_gemm_variants.py variant 31)
+        skinny = M <= 256 and N >= 256 and K >= MFMA_LONG_K and K % 1024 == 0 and K < (1 << 24)
+        return "mfma" if (big or skinny) else "valu"
     if requested not in GEMM_IMPLS:
         raise NotImplementedError(f"packed GEMM formulation {requested!r} is not built "
                                   f"(available: {GEMM_IMPLS})")
