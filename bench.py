@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--gemm", default="auto", choices=["auto", "valu", "mfma"],
                     help="packed GEMM formulation (auto = fastest available for the shape)")
     ap.add_argument("--alexnet-batch", type=int, default=256, help="images per GPU (0 = skip)")
-    ap.add_argument("--alexnet-iters", type=int, default=5)
+    ap.add_argument("--alexnet-iters", type=int, default=10)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (smoke tests)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (exercise the N>1 code path on a 1-GPU box)")
