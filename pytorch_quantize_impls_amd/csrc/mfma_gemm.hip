@@ -64,7 +64,10 @@ __device__ __attribute__((aligned(16))) const unsigned char zero16_storage[16] =
 // Either way 16 rows distinct mod 16 land on 16 distinct 16-byte slots.
 template <int SB>
 __device__ __forceinline__ int swz(int row, int chunk) {
-    return SB == 512 ? (chunk ^ (row & 31)) : SB == 256 ? (chunk ^ (row & 15)) : SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+    // 512-byte stages (4-wave 64x64 tiles): only row bits 0..2, so that the pieces of one lane (rows 8 apart) share
+    // their logical chunk (the conv tap table is looked up once per stage), and 8 consecutive rows — one 128-byte LDS
+    // cycle of a ds_read_b128 — still land on 8 different chunk positions
+    return SB == 512 ? (chunk ^ (row & 7)) : SB == 256 ? (chunk ^ (row & 15)) : SB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
 }
 
 // One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_dst), issued
@@ -983,6 +986,9 @@ template <class E> using ConvVPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 2>;
 template <class E> using ConvV64x2 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 64, 2, 3>;    // 256x64 tile, 64-byte stages, 3 workgroups / CU
 template <class E> using ConvV128x2 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 64, 2, 2>;   // 256x128 tile, same
 template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
+// small M (small-batch inference): few tiles and a long, latency-bound K loop — 64x64 tiles with 512-byte stages, as the
+// skinny GEMM configuration (weight rows must be padded to whole 512-byte stages)
+template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling only
 
 // tile width (256 / 192 / 128 / 64) that wastes the fewest padded columns; ties go to the wider tile
@@ -1388,6 +1394,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha)                                              \
             return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
+            if (g_conv_force == 0 && M <= 4096 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout)        \
+                return launch_cfg<ConvVSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
             /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
             if (g_conv_force == 0 && tn == 256 && kwords * 4 <= 1024)                                           \

@@ -815,7 +815,7 @@ def pack_conv_weight_dorefa_codes(wq: torch.Tensor, bit_width: int) -> CodePlane
     wt = wq.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
     taps = dorefa_weight_codes(wt, bit_width, ld_bytes=Cb)
     kbytes = kh * kw * Cb
-    ld = code_ld_bytes(kbytes)
+    ld = code_ld_bytes(kbytes, 512 if kbytes >= 2048 else 128)      # whole 512-byte stages for long K (skinny conv tiles)
     codes = taps.codes.view(Cout, kbytes)
     if ld != kbytes:
         padded = torch.zeros((Cout, ld), dtype=torch.int8, device=wq.device)
@@ -855,7 +855,7 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
     taps = weight_codes(wt, ternary, ld_bytes=Cb)
     kbytes = kh * kw * Cb
-    ld = code_ld_bytes(kbytes)
+    ld = code_ld_bytes(kbytes, 512 if kbytes >= 2048 else 128)      # whole 512-byte stages for long K (skinny conv tiles)
     codes = taps.codes.view(Cout, kbytes)
     if ld != kbytes:
         padded = torch.zeros((Cout, ld), dtype=torch.int8, device=weight.device)
@@ -948,7 +948,7 @@ def pack_conv_weight_nib(weight: torch.Tensor, kind: str) -> NibPlanes:
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)   # plumbing (weights are small)
     taps = sign_pack_nib(wt, ld=Cw) if kind == "binary" else ternary_pack_nib(wt, ld=Cw)
     kwords = kh * kw * Cw
-    ld = max(32, (kwords + 31) // 32 * 32)
+    ld = max(32, (kwords + 127) // 128 * 128 if kwords * 4 >= 2048 else (kwords + 31) // 32 * 32)   # whole 512-byte stages for long K
     words = taps.words.view(Cout, kwords)
     if ld != kwords:
         padded = torch.zeros((Cout, ld), dtype=torch.int32, device=weight.device)
