@@ -986,8 +986,10 @@ template <class E> using ConvVPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 2>;
 template <class E> using ConvV64x2 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 64, 2, 3>;    // 256x64 tile, 64-byte stages, 3 workgroups / CU
 template <class E> using ConvV128x2 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 64, 2, 2>;   // 256x128 tile, same
 template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
-// small M (small-batch inference): few tiles and a long, latency-bound K loop — 64x64 tiles with 512-byte stages, as the
-// skinny GEMM configuration (weight rows must be padded to whole 512-byte stages)
+// small M (small-batch inference, late layers of small images): few tiles and a long, latency-bound K loop — 64x64 tiles
+// with 512-byte stages, as the skinny GEMM configuration (weight rows must be padded to whole 512-byte stages).  Taken
+// for M <= 4096, and beyond that while the standard tiling leaves CUs idle (< 256 tiles) and the weight re-reads of the
+// small row tiles ((M / 64) x the weight matrix through L2) stay under 256 MB
 template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling only
 
@@ -1394,7 +1396,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha)                                              \
             return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
-            if (g_conv_force == 0 && M <= 4096 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout)        \
+            if (g_conv_force == 0 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout &&                  \
+                (M <= 4096 || (((M + 255) / 256) * ((Cout + tn - 1) / tn) < 256 &&                              \
+                               (M / 64) * Cout * kwords * 4 <= (256ll << 20))))                                 \
                 return launch_cfg<ConvVSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
             /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
