@@ -30,11 +30,25 @@
 // everything issued two or more stages ago has completed: the DMA of the next stage, the fp32 loads converted in the
 // next stage, the store whose signal goes out in the next stage and the poll that is checked in the next stage.
 //
+// STATUS (round 2, MI355X, 4096^3, tools/check_linear_fused.py / tools/stamps_fused.py): bit-identical to the two-launch
+// route on every case, but SLOWER: 76 us per call against 60 us for qt_pack_pair_nib_f32 + qt_nib_gemm, so nothing
+// dispatches here by default (ops.linear_fused is explicit).  Where the time goes (median workgroup, us since launch):
+// fill done 15.0 (slowest 20.3: the K-major column-panel order reads HBM at 4.7 TB/s and unevenly, the row-streaming
+// pack kernel gets 6.1) -> chunk 0 complete from all 16 partners 20.8 -> loop start 24.1 -> 12 stages with packing done
+// 45.4 (1.75 us per stage) -> 20 drain stages done 62.5 (0.85 us per stage; the plain GEMM loop runs 0.57-0.68) ->
+// stores drained 68.3.  Ablations on the same build: without the in-loop store / signal / poll operations the loop takes
+// 24 us instead of 38 (those are ~1-2 us fabric round trips and vmcnt retires IN ORDER: a slow operation delays the
+// completion count of every LDS-DMA piece issued behind it, and a piece has only two stages = 1.1 us of slack); with
+// them removed AND L2-hot sources the 12 packing stages still cost 12.3 us against 6.9 for plain stages: the 25 VALU
+// of the conversion sit in the load segment beside the partner wave's MFMA stream at ~12 cycles each.  Even with free
+// communication the launch would take ~54 us (an un-overlapped fill of 15-20 us + hand-off + 24 us loop + 6 us store
+// tail), i.e. the overlap this design can reach is worth at most ~6 us over two launches.  Kept as a tested reference
+// for the hand-off protocol and as the measured answer to "why not one persistent launch" (DESIGN.md section 4).
+//
 // Cross-workgroup visibility (MI355X_MICROARCH.md, "inter-workgroup visibility"): payload = 16-byte sc1 stores
 // (write-through), read by sc1 LDS-DMA loads; flag = device-scope atomic add issued only after the store is known
 // complete (counted vmcnt), polled with sc1 loads.  Every spin is bounded; a timeout raises the error word of the
 // sync area and the launch terminates with garbage instead of hanging.
-#include <cstdlib>
 #include <type_traits>
 #include "qt_common.h"
 #include "pp_common.h"
@@ -105,14 +119,11 @@ __device__ __forceinline__ uint32_t pair_select(uint32_t w, uint32_t table) {
 constexpr uint32_t LF_TBL_SIGN = 0xAAA22A22u;     // bit = 1 -> 0xA (-1), bit = 0 -> 0x2 (+1), two elements per byte
 constexpr uint32_t LF_TBL_SPREAD = 0x11100100u;   // bit -> bit 0 of its nibble
 
-template <int DBG>
+// LDS-DMA piece with sc1: the source was written by another CU's write-through stores in this launch (a plain
+// load measured stale lines, tools/check_linear_fused.py; sc1 measured no slower)
 __device__ __forceinline__ void dma16_sc1(const unsigned char* sbase, unsigned voff, unsigned lds_a, unsigned lds_b) {
-    if constexpr (DBG & 2)
-        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc0 sc1"
-                     :: "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b) : "memory", "scc");
-    else
-        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
-                     :: "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b) : "memory", "scc");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b) : "memory", "scc");
 }
 
 __device__ __forceinline__ v16f mfma_fp4(const v4u& a, const v4u& b, v16f c) {
@@ -175,6 +186,8 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
     const int nch = K / LF_KC, nstages = nch * 4;
     const int rowb = K >> 1;                                  // nibble row stride in bytes
 
+    unsigned long long dbg_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (DBG & 8) dbg_t[0] = wall_clock64();
     const uint32_t epoch = sync[LF_SYNC_EPOCH];               // bumped by the last workgroup of the previous launch
     uint32_t* cnt = sync + LF_SYNC_SETS + (epoch & 1u) * LF_SET_WORDS;
     {
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
     // registers live, spills with vmcnt(0) drains all over the loop).  Fast path: both polled values (vx, vw) show the
     // counters of chunk c complete.  Slow path: bounded spin; a timeout sets bit 0 of `spin_err`, reported once after the
     // loop.  vmcnt is 0 after the slow path, which only makes the counted waits that follow stricter.
-    unsigned spin_err = 0;
+    unsigned spin_err = 0, spin_count = 0;
     auto check_ready = [&](unsigned vx, unsigned vw, int c) {
         unsigned it, t;
         asm volatile(
@@ -239,6 +252,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
             "s_cbranch_scc1 2f\n\t"
             "s_mov_b32 %[it], 0\n"
             "1:\n\t"
+            "s_add_u32 %[cnt], %[cnt], 1\n\t"
             "s_sleep 4\n\t"
             "global_load_dword %[vx], %[off], %[px] sc1\n\t"
             "global_load_dword %[vw], %[off], %[pw] sc1\n\t"
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
             "s_cbranch_scc1 1b\n\t"
             "s_or_b32 %[err], %[err], 1\n"
             "2:"
-            : [vx] "+v"(vx), [vw] "+v"(vw), [it] "=&s"(it), [t] "=&s"(t), [err] "+s"(spin_err)
+            : [vx] "+v"(vx), [vw] "+v"(vw), [it] "=&s"(it), [t] "=&s"(t), [err] "+s"(spin_err), [cnt] "+s"(spin_count)
             : [off] "v"(c * 4), [px] "s"(pollX), [pw] "s"(pollW), [need] "n"(LF_ARRIVALS), [lim] "s"(LF_SPIN_MAX)
             : "memory", "scc");
     };
@@ -293,7 +307,9 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
         const v4f b0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s + 1024));
         stage_put((LEAD - 1) & 1, 0, conv8(a0, b0));
     }
+    if constexpr (DBG & 8) dbg_t[1] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's nibble stores are complete (write-through)
+    if constexpr (DBG & 8) dbg_t[2] = wall_clock64();
 #pragma unroll
     for (int c = 0; c < LEAD - 1; ++c) signal(c, 1u);
     auto issue_job_loads = [&](v4f& a, v4f& b, int c, int p) {
@@ -346,11 +362,11 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
         const unsigned ldsbuf = __builtin_amdgcn_readfirstlane(lds0 + (s & 3) * BUF);
 #pragma unroll
         for (int j = 0; j < XP; ++j)
-            dma16_sc1<DBG>(Xn + (int64_t)s * SB, voffx[j], ldsbuf,
+            dma16_sc1(Xn + (int64_t)s * SB, voffx[j], ldsbuf,
                       __builtin_amdgcn_readfirstlane(((j * LF_NWAVES + wave) * LF_RPP) * SB));
 #pragma unroll
         for (int j = 0; j < WP; ++j)
-            dma16_sc1<DBG>(Wn + (int64_t)s * SB, voffw[j], ldsbuf,
+            dma16_sc1(Wn + (int64_t)s * SB, voffw[j], ldsbuf,
                       __builtin_amdgcn_readfirstlane(LF_XSTAGE + ((j * LF_NWAVES + wave) * LF_RPP) * SB));
     };
 
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
 
     // ---- hand-off of chunk 0 (and the first look at chunk 1) ------------------------------------------
     check_ready(0u, 0u, 0);
+    if constexpr (DBG & 8) dbg_t[3] = wall_clock64();
     unsigned pvx = __hip_atomic_load(pollX + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned pvw = __hip_atomic_load(pollW + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pvx), "+v"(pvw) :: "memory");
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
     __syncthreads();
     if (grp == 0) __syncthreads();   // group A trails by one slot
+    if constexpr (DBG & 8) dbg_t[4] = wall_clock64();
 
     auto stage = [&](int s, auto cfg) {
         using C = decltype(cfg);
@@ -419,10 +437,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
             const int sc = ((s - 1) >> 2) + LEAD - 2;
             signal(sc, sc >= LEAD - 1 ? 1u : 0u);   // chunks < LEAD-1 were signalled by the fill: add 0 keeps the op count
         }
-        if constexpr (C::CHECK) {
-            check_ready(pvx, pvw, (s + 3) >> 2);   // before the DMA of the first stage of chunk (s + 3) / 4
-            if constexpr (DBG & 4) asm volatile("buffer_inv sc1" ::: "memory");
-        }
+        if constexpr (C::CHECK) check_ready(pvx, pvw, (s + 3) >> 2);   // before the DMA of the first stage of chunk (s + 3) / 4
         if constexpr (C::POLL) {
             const int pc = (s + 6) >> 2;
             asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(pvx) : "v"(pc * 4), "s"(pollX) : "memory");
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
         asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
                      : "+v"(xf0[0]), "+v"(xf0[1]), "+v"(xf0[2]), "+v"(xf0[3]), "+v"(wf0[0]), "+v"(wf0[1]), "+v"(xf1[0]),
                        "+v"(xf1[1]), "+v"(xf1[2]), "+v"(xf1[3]), "+v"(wf1[0]), "+v"(wf1[1])
-                     : "n"((C::ISSUE && !(DBG & 1)) ? C::NEND : 0)
+                     : "n"(C::ISSUE ? C::NEND : 0)
                      : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -468,6 +483,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
         stage(s + 2, Steady<2, 7 + 9>{});
         stage(s + 3, Steady<3, 9 + 6>{});
     }
+    if constexpr (DBG & 8) dbg_t[5] = wall_clock64();
     // phase 2: LEAD - 1 drain periods
     auto drain = [&](auto q_) {
         constexpr int Q = decltype(q_)::value;
@@ -489,6 +505,7 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
     stage(s + 2, StageCfg<2, 0, false, false, false, false, false, false, false, false>{});
     stage(s + 3, StageCfg<3, 0, false, false, false, false, false, false, false, true>{});
 
+    if constexpr (DBG & 8) dbg_t[6] = wall_clock64();
     // every poll of this launch is done: the last workgroup to get here flips the counter set for the next launch
     if (spin_err && lane == 0) atomicOr(sync + LF_SYNC_ERR, 1u);
     if (tid == 0) {
@@ -524,6 +541,16 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (DBG & 8) {   // bring-up only: waves 0 and 4 overwrite the head of their first Y row with phase stamps
+        dbg_t[7] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_t[8] = wall_clock64();
+        dbg_t[9] = spin_count;
+        if (lane == 0 && wave_n == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(Y + (int64_t)(m0 + wave_m * TMW * 32) * ldy + n0);
+            for (int i = 0; i < 10; ++i) o[i] = dbg_t[i];
+        }
+    }
 }
 
 constexpr int LF_LEAD = 5;
@@ -531,10 +558,11 @@ constexpr int LF_LEAD = 5;
 template <class EncW>
 int launch_fused(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                  int64_t M, int64_t N, int64_t K, unsigned char* ws, qt_stream_t stream) {
-    static const int dbg = getenv("QT_LF_DBG") ? atoi(getenv("QT_LF_DBG")) : 0;   // bring-up only
-    auto kern = dbg == 1 ? linear_fused_kernel<EncW, LF_LEAD, 1> : dbg == 2 ? linear_fused_kernel<EncW, LF_LEAD, 2>
-              : dbg == 4 ? linear_fused_kernel<EncW, LF_LEAD, 4> : dbg == 7 ? linear_fused_kernel<EncW, LF_LEAD, 7>
-              : linear_fused_kernel<EncW, LF_LEAD, 0>;
+#ifdef QT_LF_STAMPS   // bring-up build only (tools/stamps_fused.py): phase stamps are written over Y
+    auto kern = linear_fused_kernel<EncW, LF_LEAD, 8>;
+#else
+    auto kern = linear_fused_kernel<EncW, LF_LEAD, 0>;
+#endif
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS) != hipSuccess)
         return QT_ERR_LAUNCH;
     uint32_t* sync = reinterpret_cast<uint32_t*>(ws);
