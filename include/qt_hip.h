@@ -117,6 +117,17 @@ int qt_ap2_f32(const float* x, float* y, int64_t n, qt_stream_t stream);
 int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int64_t ldq, int64_t R,
                        int64_t C, qt_stream_t stream);
 
+/* XNOR-Net ACTIVATION quantiser on a row-major [R, C] tensor (_quantOpXnor / nnQuantXnor / QuantXnor,
+ * functions/xnor_connect.py:17-66):  y = sign(x) * mean(x, dim)  with torch.sign (0 -> 0) and the SIGNED mean the
+ * reference computes (:21-28).  dim = 1: mean[R] per row; dim = 0: mean[C] per column; dim = -1: mean[1] over all
+ * elements (needs `work`, qt_xnor_act_work_floats() floats; NULL otherwise).  `mean` is an output (saved for backward).
+ * Backward (:30-37): gin = sign(x) * mean(g * sign(x), dim, keepdim) + g * mean;  gmean = scratch of mean's size. */
+int64_t qt_xnor_act_work_floats(void);
+int qt_xnor_act_f32(const float* x, int64_t ldx, float* mean, float* work, float* y, int64_t ldy, int64_t R, int64_t C,
+                    int dim, qt_stream_t stream);
+int qt_xnor_act_backward_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* mean, float* gmean,
+                             float* work, float* gin, int64_t ldi, int64_t R, int64_t C, int dim, qt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bit-pack kernels (fp32 -> packed planes).  rows x K fp32 (row stride ldx) ->
  * rows x ldp uint32 (only the first ceil(K/32) words of a row carry data, the rest are 0).

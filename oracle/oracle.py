@@ -336,6 +336,57 @@ def xnor_conv_weight(weight, dim=(0, 1)):
     return np.sign(w).astype(np.float32) * mean
 
 
+def xnor_act(x, dim):
+    """_quantOpXnor forward (functions/xnor_connect.py:17-28): sign(x) * mean(x, dim) with np.sign == torch.sign
+    (0 -> 0) and the SIGNED mean the reference computes; the mean is accumulated in double (the float tail
+    tolerance is stated against it).  dim = 1: per row, dim = 0: per column, dim = -1: whole tensor."""
+    x = np.asarray(x, dtype=np.float32)
+    xd = x.astype(np.float64)
+    if dim < 0:
+        mean = np.float32(xd.mean())
+        return np.sign(x) * mean, np.asarray([mean], dtype=np.float32)
+    mean = xd.mean(axis=dim).astype(np.float32)
+    shape = (1, -1) if dim == 0 else (-1, 1)
+    return (np.sign(x) * mean.reshape(shape)).astype(np.float32), mean
+
+
+def xnor_act_backward(g, x, dim):
+    """_quantOpXnor backward (functions/xnor_connect.py:30-37):
+    sign(x) * mean(g * sign(x), dim, keepdim) + g * mean(x, dim)."""
+    x = np.asarray(x, dtype=np.float32)
+    g = np.asarray(g, dtype=np.float32)
+    sgn = np.sign(x).astype(np.float64)
+    gd, xd = g.astype(np.float64), x.astype(np.float64)
+    if dim < 0:
+        return (sgn * (gd * sgn).mean() + gd * np.float32(xd.mean())).astype(np.float32)
+    shape = (1, -1) if dim == 0 else (-1, 1)
+    mean = xd.mean(axis=dim).astype(np.float32).reshape(shape)
+    return (sgn * (gd * sgn).mean(axis=dim, keepdims=True) + gd * mean).astype(np.float32)
+
+
+def functional_ternary_weight(weight):
+    """Deterministic branch of the functional TernaryDense / TernaryConv2d (functions/terner_connect.py:85-90,
+    :123-128): (sign(w) + sign(w - 0.5 sign(w))) / 2 with torch.sign, so w = +-0.5 gives +-0.5 and w = 0 gives 0
+    (unlike TernaryConnectDeterministic, which uses safeSign)."""
+    w = np.asarray(weight, dtype=np.float32)
+    s = np.sign(w).astype(np.float32)
+    return ((s + np.sign(w - np.float32(0.5) * s).astype(np.float32)) / np.float32(2)).astype(np.float32)
+
+
+def functional_quant_weight(weight, k, conv=False):
+    """QuantDense / QuantConv2d forward weight (functions/dorefa_connect.py:124-130, :170-176): k = 1: safeSign(W) *
+    mean|W|; k = 32: W; else 2 quantize_k(1/2 + tanh W / (2 m)) - 1 with m = max|tanh W| (dense) or tanh(max|W|)
+    (conv) — the same number mathematically, different roundings."""
+    w = np.asarray(weight, dtype=np.float32)
+    if k == 1:
+        return safe_sign(w) * np.float32(np.mean(np.abs(w), dtype=np.float64))
+    if k == 32:
+        return w
+    t = np.tanh(w).astype(np.float32)
+    m = np.tanh(np.max(np.abs(w))).astype(np.float32) if conv else np.max(np.abs(t))
+    return np.float32(2) * dorefa_quantize(np.float32(0.5) + t / (np.float32(2) * m), k) - np.float32(1)
+
+
 def dorefa_w1a_linear(x_real, weight, bias, k_act=4):
     """nnDorefaQuant(k_act)(relu(x)) -> LinearDorefa(bit_width=1) (layers/dorefa_layers.py:41-45,
     functions/dorefa_connect.py:24-25,99-102), evaluated the way the int8 path factors it:

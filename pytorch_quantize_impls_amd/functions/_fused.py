@@ -233,6 +233,35 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
+def real_weight_linear(input: torch.Tensor, weight_q: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """F.linear(input, weight_q, bias) for an ALREADY QUANTISED, real-valued weight image (the deprecated functional
+    forms: TernaryDense's torch.sign formula keeps w = +-0.5 as +-0.5, QuantDense's levels are odd integers / (2^k - 1),
+    functions/terner_connect.py:85-94, dorefa_connect.py:124-132).  Device fp32 2-D: six-term bf16 planes on the matrix
+    cores (ops.real_linear, fp32-GEMM accuracy); everything else: the torch expression."""
+    if (input.is_cuda and input.dtype == torch.float32 and weight_q.dtype == torch.float32 and input.dim() == 2
+            and input.numel() > 0 and weight_q.numel() > 0):
+        return ops.real_linear(input.detach(), weight_q.detach(), bias.detach() if bias is not None else None)
+    return F.linear(input, weight_q, bias)
+
+
+def real_weight_conv2d(input: torch.Tensor, weight_q: torch.Tensor, bias, stride, padding, dilation, groups) -> torch.Tensor:
+    """F.conv2d(input, weight_q, ...) for an already quantised real-valued weight image (TernaryConv2d / QuantConv2d /
+    XNORConv2d functional forms): implicit-GEMM conv over six-term bf16 planes (ops.real_conv2d) for device fp32 NCHW
+    inputs with groups == 1 and numeric zero padding; the result keeps the input's memory format."""
+    if (input.is_cuda and input.dtype == torch.float32 and weight_q.dtype == torch.float32 and input.dim() == 4
+            and input.numel() > 0 and groups == 1 and not isinstance(padding, str)):
+        y2 = ops.real_conv2d(input.detach(), weight_q.detach(), bias.detach() if bias is not None else None, stride,
+                             padding, dilation)
+        if y2 is not None:
+            N_, _, H, W = input.shape
+            Ho, Wo = ops.conv_out_hw(H, W, weight_q.shape[2], weight_q.shape[3], stride, padding, dilation)
+            y = y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)
+            if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous()
+            return y
+    return F.conv2d(input, weight_q, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
+
+
 def packed_linear(layer, act, kind: str) -> torch.Tensor:
     """Eval-mode LinearBin / LinearTer on a PackedActivation (row planes): planes -> packed GEMM."""
     if layer.training:

@@ -5,6 +5,7 @@ import torch
 
 from .. import ops, packed
 from .common import front, safeSign
+from . import _fused
 
 warnings.simplefilter("always", DeprecationWarning)
 
@@ -109,7 +110,7 @@ def QuantDense(bit_width=3):
                 weight_q = weight
             else:
                 weight_q = 2 * _quantize(0.5 + torch.tanh(weight) / (2 * max_abs), bit_width=bit_width) - 1
-            output = torch.nn.functional.linear(input, weight_q, bias)
+            output = _fused.real_weight_linear(input, weight_q, bias)
             ctx.save_for_backward(input, weight, weight_q, max_abs, bias)
             return output
 
@@ -146,8 +147,7 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
                 weight_q = 2 * _quantize(0.5 + torch.tanh(weight) / (2 * torch.tanh(max_weight)),
                                          bit_width=bit_width) - 1
             ctx.save_for_backward(input, weight, weight_q, max_weight, bias)
-            return torch.nn.functional.conv2d(input, weight_q, bias=bias, stride=stride,
-                                              padding=padding, dilation=dilation, groups=groups)
+            return _fused.real_weight_conv2d(input, weight_q, bias, stride, padding, dilation, groups)
 
         @staticmethod
         def backward(ctx, grad_output):

@@ -73,7 +73,7 @@ def TernaryDense(stochastic=False):
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)
             ctx.save_for_backward(input, weight, weight_t, bias)
-            return torch.nn.functional.linear(input, weight_t, bias)
+            return _fused.real_weight_linear(input, weight_t, bias)
 
         @staticmethod
         def backward(ctx, grad_output):
@@ -99,8 +99,7 @@ def TernaryConv2d(stochastic=True, stride=1, padding=1, dilation=1, groups=1):
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)
             ctx.save_for_backward(input, weight, weight_t, bias)
-            return torch.nn.functional.conv2d(input, weight_t, bias=bias, stride=stride,
-                                              padding=padding, dilation=dilation, groups=groups)
+            return _fused.real_weight_conv2d(input, weight_t, bias, stride, padding, dilation, groups)
 
         @staticmethod
         def backward(ctx, grad_output):

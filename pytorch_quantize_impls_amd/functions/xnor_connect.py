@@ -18,6 +18,10 @@ def _quantOpXnor(dim=1):
     class _QuantXNOR(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input):
+            if input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.numel() > 0:
+                out, mean = ops.xnor_act(input.detach(), dim)        # qt_xnor_act_f32: reduction + sign * mean
+                ctx.save_for_backward(input, mean if dim >= 0 else mean.view(()))
+                return out
             mean = torch.mean(input) if dim < 0 else torch.mean(input, dim)
             ctx.save_for_backward(input, mean)
             if dim < 0:
@@ -28,6 +32,9 @@ def _quantOpXnor(dim=1):
         @staticmethod
         def backward(ctx, grad_outputs):
             input, mean = ctx.saved_tensors
+            if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.numel() > 0
+                    and grad_outputs.dtype == torch.float32):
+                return ops.xnor_act_backward(grad_outputs, input, mean.reshape(-1), dim)   # qt_xnor_act_backward_f32
             sgn = torch.sign(input)
             if dim < 0:
                 return sgn * torch.mean(grad_outputs * sgn) + grad_outputs * mean

@@ -350,6 +350,47 @@ def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
     return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
 
 
+def _xnor_act_buffers(x: torch.Tensor, dim: int):
+    R, C = (int(v) for v in x.shape)
+    n = R if dim == 1 else (C if dim == 0 else 1)
+    mean = torch.empty((n,), dtype=torch.float32, device=x.device)
+    work = torch.empty((int(_lib.load().qt_xnor_act_work_floats()),), dtype=torch.float32, device=x.device) if dim < 0 else None
+    return R, C, mean, work
+
+
+def xnor_act(x: torch.Tensor, dim: int):
+    """XNOR activation quantiser of a 2-D tensor: (sign(x) * mean(x, dim), mean) — qt_xnor_act_f32
+    (functions/xnor_connect.py:17-28; the signed mean, as upstream)."""
+    x = _require(x, "input")
+    if x.dim() != 2:
+        raise ValueError("xnor_act: expected a 2-D tensor")
+    if x.stride(1) != 1 and x.numel() > 0:
+        x = x.contiguous()
+    R, C, mean, work = _xnor_act_buffers(x, dim)
+    y = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _lib.call("qt_xnor_act_f32", _p(x), int(x.stride(0)) if R > 1 else max(C, 1), _p(mean), _p(work), _p(y), max(C, 1),
+                  R, C, int(dim), _stream(x.device))
+    return y, mean
+
+
+def xnor_act_backward(grad_out: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, dim: int) -> torch.Tensor:
+    """sign(x) * mean(g * sign(x), dim, keepdim) + g * mean — qt_xnor_act_backward_f32 (xnor_connect.py:30-37)."""
+    x = _require(x, "input")
+    g = _require(grad_out, "grad_output")
+    if x.stride(1) != 1 and x.numel() > 0:
+        x = x.contiguous()
+    if g.stride(1) != 1 and g.numel() > 0:
+        g = g.contiguous()
+    R, C, gmean, work = _xnor_act_buffers(x, dim)
+    gin = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _lib.call("qt_xnor_act_backward_f32", _p(g), int(g.stride(0)) if R > 1 else max(C, 1), _p(x),
+                  int(x.stride(0)) if R > 1 else max(C, 1), _p(mean), _p(gmean), _p(work), _p(gin), max(C, 1), R, C, int(dim),
+                  _stream(x.device))
+    return gin
+
+
 # ----------------------------------------------------------------------------------------------
 # packing
 # ----------------------------------------------------------------------------------------------

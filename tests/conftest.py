@@ -23,6 +23,18 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r2():
+    """Round-2 vectors (tests/golden/make_golden_r2.py): XNOR activation op, deprecated functional forms."""
+    return np.load(os.path.join(GOLDEN_DIR, "golden_r2_v1.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_hashes_r2():
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes_r2.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.fixture(scope="session")
 def golden_hashes():
     with open(os.path.join(GOLDEN_DIR, "golden_hashes.json")) as fh:
         return json.load(fh)["cases"]

@@ -1,0 +1,525 @@
+"""Round-2 GPU parity: the rows and shapes VERDICT r1 found unpinned.
+
+  * XNOR activation quantiser (a18) and the deprecated functional forms (a11 / a17) against reference-generated
+    vectors (tests/golden/make_golden_r2.py) and the oracle;
+  * reference digests of one C5 and one C4 conv layer at their configured spatial size;
+  * the direct 3x3 kernel against the ORACLE's restatement of conv -> BatchNorm -> sign at the C5 shapes it is
+    dispatched for (224 x 224 and 112 x 112, batch 8), binary, ternary and the real-valued first layer;
+  * the fused C5 / C4 / C3 networks LAYER BY LAYER at the configured image size, every block fed with the CPU
+    chain's own intermediate and compared bit for bit with the CPU evaluation of the same folded expression;
+  * the one-launch linear forward (csrc/linear_fused.hip) against the reference's digest of the full C2 layer.
+
+Integer / bit results: exact.  Float tails: max|a-b| / max|b| <= 1e-5."""
+import copy
+import hashlib
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import same, norm_err
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import _lib, ops, packed, synth  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic  # noqa: E402
+from pytorch_quantize_impls_amd.layers import (BinConv2d, TerConv2d, LinearBin, LinearTer, FusedConvPoolBnSign,  # noqa: E402
+                                               PackedMaxPool, FusedFeatureClassifier, fold_batchnorm)
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def g(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+class used:
+    def __init__(self, *names):
+        self.names = names
+
+    def __enter__(self):
+        self.before = dict(_lib.call_counts)
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            for k in self.names:
+                assert _lib.call_counts[k] > self.before.get(k, 0), f"{k} did not run"
+
+
+# ---- a18: XNOR activation quantiser -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dim", [-1, 0, 1])
+def test_xnor_act_golden(dev, golden_r2, dim):
+    from pytorch_quantize_impls_amd.functions.xnor_connect import QuantXnor, nnQuantXnor
+    for tag in golden_r2["g10_cases"]:
+        x, gout = golden_r2[f"g10_{tag}_x"], golden_r2[f"g10_{tag}_g"]
+        xi = g(x, dev).requires_grad_(True)
+        with used("qt_xnor_act_f32", "qt_xnor_act_backward_f32"):
+            y = QuantXnor(xi, dim=dim)
+            y.backward(g(gout, dev))
+        assert norm_err(n(y), golden_r2[f"g10_{tag}_d{dim}_y"]) <= TOL, (tag, dim)
+        assert np.array_equal(n(y) == 0, golden_r2[f"g10_{tag}_d{dim}_y"] == 0)
+        assert norm_err(n(xi.grad), golden_r2[f"g10_{tag}_d{dim}_gx"]) <= TOL, (tag, dim)
+        with torch.no_grad():
+            assert same(n(nnQuantXnor(dim)(g(x, dev))), n(y))          # module form = functional form
+
+
+@pytest.mark.parametrize("R,C", [(4096, 4096), (300, 7), (3, 10000), (1, 1)])
+@pytest.mark.parametrize("dim", [-1, 0, 1])
+def test_xnor_act_vs_oracle(dev, oracle, R, C, dim):
+    x = synth.normal(R + C + dim, (R, C)) + np.float32(0.25)     # a non-zero mean, so the signed mean has something to carry
+    x.reshape(-1)[::7] = 0.0
+    gout = synth.normal(R * 3 + C, (R, C))
+    y, mean = ops.xnor_act(g(x, dev), dim)
+    yo, mo = oracle.xnor_act(x, dim)
+    assert norm_err(n(mean), mo) <= TOL
+    assert norm_err(n(y), yo) <= TOL and np.array_equal(n(y) == 0, yo == 0)
+    gin = ops.xnor_act_backward(g(gout, dev), g(x, dev), mean, dim)
+    assert norm_err(n(gin), oracle.xnor_act_backward(gout, x, dim)) <= TOL
+    # strided rows
+    big = torch.zeros((R, C + 5), device=dev)
+    big[:, :C] = g(x, dev)
+    y2, _ = ops.xnor_act(big[:, :C], dim)
+    assert torch.equal(y2, y)
+
+
+def test_xnor_act_empty_and_errors(dev):
+    y, m = ops.xnor_act(torch.zeros((0, 5), device=dev), 1)
+    assert y.shape == (0, 5)
+    with pytest.raises(ValueError):
+        ops.xnor_act(torch.zeros((2, 3, 4), device=dev), 1)
+    with pytest.raises(_lib.QtStatusError):
+        ops.xnor_act(torch.zeros((2, 3), device=dev), 2)
+
+
+# ---- a11 / a17: functional forms on the device -----------------------------------------------------------------------
+
+def _functional_ops():
+    from pytorch_quantize_impls_amd.functions.binary_connect import BinaryConv2d
+    from pytorch_quantize_impls_amd.functions.dorefa_connect import QuantConv2d, QuantDense
+    from pytorch_quantize_impls_amd.functions.terner_connect import TernaryConv2d, TernaryDense
+    return BinaryConv2d, QuantConv2d, QuantDense, TernaryConv2d, TernaryDense
+
+
+@pytest.mark.parametrize("name", ["ter", "q1", "q3", "q32"])
+def test_functional_dense_forms_golden(dev, golden_r2, name):
+    _, _, QuantDense, _, TernaryDense = _functional_ops()
+    op = {"ter": lambda: TernaryDense(stochastic=False), "q1": lambda: QuantDense(1), "q3": lambda: QuantDense(3),
+          "q32": lambda: QuantDense(32)}[name]()
+    for tag in golden_r2["g11_lin_cases"]:
+        x, w, gout = (golden_r2[f"g11_lin_{tag}_{k}"] for k in ("x", "w", "g"))
+        has_b = f"g11_lin_{tag}_b" in golden_r2.files
+        xi, wi = g(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True)
+        bi = g(golden_r2[f"g11_lin_{tag}_b"], dev).requires_grad_(True) if has_b else None
+        with used("qt_bf16x6_pack_f32", "qt_bf16_gemm"):        # the contraction runs on the matrix cores, not in a library
+            y = op.apply(xi, wi, bi) if has_b else op.apply(xi, wi)
+        y.backward(g(gout, dev))
+        assert norm_err(n(y), golden_r2[f"g11_lin_{tag}_{name}_y"]) <= TOL, (tag, name)
+        assert norm_err(n(xi.grad), golden_r2[f"g11_lin_{tag}_{name}_gx"]) <= TOL
+        assert norm_err(n(wi.grad), golden_r2[f"g11_lin_{tag}_{name}_gw"]) <= TOL
+        if has_b:
+            assert norm_err(n(bi.grad), golden_r2[f"g11_lin_{tag}_{name}_gb"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["ter", "q1", "q3", "bin"])
+def test_functional_conv_forms_golden(dev, golden_r2, name):
+    BinaryConv2d, QuantConv2d, _, TernaryConv2d, _ = _functional_ops()
+    for tag in golden_r2["g11_conv_cases"]:
+        parts = dict((p[0], int(p[1:])) for p in str(tag).split("_")[:6])
+        st, pd = parts["s"], parts["p"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            op = {"ter": lambda: TernaryConv2d(stochastic=False, stride=st, padding=pd), "q1": lambda: QuantConv2d(st, pd, bit_width=1),
+                  "q3": lambda: QuantConv2d(st, pd, bit_width=3), "bin": lambda: BinaryConv2d(st, pd)}[name]()
+        x, w, gout = (golden_r2[f"g11_conv_{tag}_{k}"] for k in ("x", "w", "g"))
+        has_b = f"g11_conv_{tag}_b" in golden_r2.files
+        xi, wi = g(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True)
+        bi = g(golden_r2[f"g11_conv_{tag}_b"], dev).requires_grad_(True) if has_b else None
+        with used("qt_conv2d_implicit"):
+            y = op.apply(xi, wi, bi) if has_b else op.apply(xi, wi)
+        y.backward(g(gout, dev))
+        assert norm_err(n(y), golden_r2[f"g11_conv_{tag}_{name}_y"]) <= TOL, (tag, name)
+        assert norm_err(n(xi.grad), golden_r2[f"g11_conv_{tag}_{name}_gx"]) <= TOL
+        assert norm_err(n(wi.grad), golden_r2[f"g11_conv_{tag}_{name}_gw"]) <= TOL
+        if has_b:
+            assert norm_err(n(bi.grad), golden_r2[f"g11_conv_{tag}_{name}_gb"]) <= TOL
+
+
+# ---- reference digests at configured spatial sizes -----------------------------------------------------------------
+
+def test_c5_conv_reference_digest(dev, golden_hashes_r2):
+    """TerConv2d 64 -> 64, 3x3, padding 1, 224 x 224 (VGG-16 conv2 of config C5) on +-1 input: SHA-256 of the int32 result
+    the REFERENCE layer produced (terner_layers.py:89-92), train and eval mode, tagged and un-tagged input."""
+    h = golden_hashes_r2["terconv_c5_64_64_224"]
+    x = synth.pm1(h["x_seed"], (h["B"], h["Cin"], h["H"], h["H"]))
+    w = synth.uniform(h["w_seed"], (h["Cout"], h["Cin"], 3, 3), h["w_lo"], h["w_hi"])
+    conv = TerConv2d(h["Cin"], h["Cout"], 3, padding=1).to(dev)
+    conv.weight.data.copy_(g(w, dev))
+    conv.bias.data.zero_()
+    for tagged in (False, True):
+        xd = g(x, dev).contiguous(memory_format=torch.channels_last)
+        if tagged:
+            xd = BinaryConnectDeterministic.apply(xd)
+        for training in (True, False):
+            conv.train(training)
+            with torch.no_grad(), used("qt_conv2d_implicit"):
+                y = conv(xd)
+            yi = n(y.contiguous()).astype(np.int32)          # NCHW order, as the reference's tensor
+            assert hashlib.sha256(np.ascontiguousarray(yi).tobytes()).hexdigest() == h["sha256_int32"], (tagged, training)
+            assert float(y.double().sum()) == h["sum"]
+        conv.train(True)
+        conv.weight.data.copy_(g(w, dev))
+
+
+def test_c4_conv_integer_core_reference_digest(dev, golden_hashes_r2):
+    """Integer core of a C4 layer (64 -> 64, 3x3, 32 x 32, batch 64): 4-bit activation codes x sign weights on the int8
+    matrix cores with unit scale, against the digest of the reference's F.conv2d on the same integers
+    (binary_layers.py:105, what DorefaConv2d(bit_width=1) contracts up to its scale E/15)."""
+    h = golden_hashes_r2["w1a4_core_c4_64_64_32"]
+    B, C, H = h["B"], h["Cin"], h["H"]
+    codes = np.floor(synth.uniform(h["x_seed"], (B, C, H, H), 0.0, 16.0)).clip(0, 15).astype(np.float32)
+    w = synth.uniform(h["w_seed"], (h["Cout"], C, 3, 3), h["w_lo"], h["w_hi"])
+    xq = (g(codes, dev) / 15.0).contiguous(memory_format=torch.channels_last)     # rint(15 * fl(c / 15)) == c
+    px, _ = ops.dorefa_codes(xq.permute(0, 2, 3, 1).reshape(B * H * H, C), 4, want_f32=False, ld_bytes=ops.code_ld_bytes(C, 16))
+    assert torch.equal(px.codes[:, :C].to(torch.float32).view(B, H, H, C).permute(0, 3, 1, 2), g(codes, dev))
+    wp = ops.pack_conv_weight_codes(g(w, dev))
+    with used("qt_conv2d_implicit"):
+        y2 = ops.conv2d_codes(px, (B, C, H, H), wp, (3, 3), 1.0, None, 1, 1, 1)
+    y = y2.view(B, H, H, h["Cout"]).permute(0, 3, 1, 2).contiguous()
+    assert hashlib.sha256(np.ascontiguousarray(n(y).astype(np.int32)).tobytes()).hexdigest() == h["sha256_int32"]
+
+
+# ---- direct 3x3 kernel against the oracle chain at the dispatched C5 shapes -----------------------------------------
+
+def _decode(act):
+    """PackedActivation -> +-1 (0 for nibble zeros) fp32 tensor [N, C, H, W] on the host."""
+    N, C, H, W = act.shape
+    if act.planes is not None:
+        words = act.planes.sign.view(N, H, W, -1).cpu().numpy().view(np.uint32)
+        bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(N, H, W, -1)[..., :C]
+        return torch.from_numpy(np.where(bits == 1, -1.0, 1.0).astype(np.float32)).permute(0, 3, 1, 2)
+    hy, hx = act.halo
+    words = act.nib.words.view(N, H + 2 * hy, W + 2 * hx, -1).cpu().numpy().view(np.uint32)
+    nib = ((words[..., None] >> (4 * np.arange(8, dtype=np.uint32))) & 0xF).reshape(N, H + 2 * hy, W + 2 * hx, -1)
+    val = np.select([nib == 0x2, nib == 0xA, nib == 0], [1.0, -1.0, 0.0], default=np.nan).astype(np.float32)
+    assert not np.isnan(val).any(), "a nibble outside {0x0, 0x2, 0xA}"
+    border = np.ones(val.shape[:3], dtype=bool)
+    border[:, hy:hy + H, hx:hx + W] = False
+    assert (val[border] == 0).all(), "the halo of a nibble plane must be zero"
+    assert (val[:, :, :, C:] == 0).all(), "pad channels must be zero"
+    return torch.from_numpy(val[:, hy:hy + H, hx:hx + W, :C]).permute(0, 3, 1, 2)
+
+
+def _as_input(x_pm1: torch.Tensor, producer, dev):
+    """The +-1 host tensor in the form the producing fused block would have handed over: bit planes, or the consumer's
+    nibble plane with its zero halo."""
+    N, C, H, W = x_pm1.shape
+    xd = x_pm1.to(dev).contiguous(memory_format=torch.channels_last)
+    bits = ops.sign_pack(xd.permute(0, 2, 3, 1).reshape(N * H * W, C))[0]
+    halo = getattr(producer, "out_nib_halo", None) if producer is not None else None
+    if halo is None:
+        return packed.PackedActivation(bits, (N, C, H, W))
+    nib = ops.bits_to_nib_pad(bits, N, H, W, tuple(halo), ld=ops.pixel_ld_nib(C))
+    return packed.PackedActivation(None, (N, C, H, W), nib=nib, halo=tuple(halo))
+
+
+@pytest.mark.parametrize("C,Cout,H,kind", [(64, 64, 224, "ternary"), (64, 128, 112, "binary"), (128, 128, 112, "ternary")])
+def test_direct_conv3x3_vs_oracle_chain_at_c5_shapes(dev, oracle, C, Cout, H, kind):
+    """qt_conv3x3_direct_nib at the shapes it is dispatched for in the fused VGG-16 (batch 8), threshold bits and the
+    next conv's nibble halo plane, against oracle.bin_conv_pool_bn_sign_planes on the first and the last image."""
+    N = 8
+    x = synth.pm1(C + H, (N, C, H, H))
+    w = synth.uniform(Cout + H, (Cout, C, 3, 3), -1.4, 1.4)
+    b = synth.normal(7, (Cout,)) * 3
+    alpha = synth.uniform(8, (Cout,), -0.3, 0.3)
+    beta = synth.uniform(9, (Cout,), -4, 4)
+    xd = g(x, dev).contiguous(memory_format=torch.channels_last)
+    bits = ops.sign_pack(xd.permute(0, 2, 3, 1).reshape(N * H * H, C))[0]
+    px = ops.bits_to_nib_pad(bits, N, H, H, (1, 1), ld=ops.pixel_ld_nib(C))
+    wq = oracle.safe_sign(w) if kind == "binary" else oracle.ternarize(w)
+    wp = ops.pack_conv_weight_nib(g(wq, dev), kind)
+    al, be, bd = g(alpha, dev), g(beta, dev), g(b, dev)
+    outs = []
+    for epi in ((al, be), ops.NibEpilogue(al, be, (1, 1))):
+        if not ops.direct_conv3x3_applicable(C, Cout, (3, 3), 1, 1, 1, (1, 1), epi):
+            continue
+        with used("qt_conv3x3_direct_nib"):
+            out = ops.conv3x3_direct_nib(px, N, C, H, H, wp, bd, epi)
+        outs.append(packed.PackedActivation(out, (N, Cout, H, H)) if isinstance(out, ops.BitPlanes)
+                    else packed.PackedActivation(None, (N, Cout, H, H), nib=out, halo=(1, 1)))
+    assert outs, "the direct kernel must take at least one output form of this shape"
+    for img in (0, N - 1):
+        want, (Ho, Wo) = oracle.bin_conv_pool_bn_sign_planes(x[img:img + 1], wq, b, 1, 1, 1, alpha, beta, 1, 1)
+        wbits = ((want.reshape(Ho, Wo, -1)[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(Ho, Wo, -1)[..., :Cout]
+        want_pm1 = np.where(wbits == 1, -1.0, 1.0).astype(np.float32).transpose(2, 0, 1)
+        for act in outs:
+            assert np.array_equal(_decode(act)[img].numpy(), want_pm1), (img, "nib" if act.nib is not None else "bits")
+
+
+def test_direct_first_layer_vs_oracle_chain(dev, oracle):
+    """The real-valued 3 -> 64 first layer at 224 x 224 (bf16 triple planes, direct kernel): its accumulators are fp32
+    sums of real products, so a bit may differ from the oracle's double-accumulated chain only where the folded value is
+    within float rounding of zero."""
+    N, C, Cout, H = 4, 3, 64, 224
+    x = synth.normal(31, (N, C, H, H))
+    w = synth.uniform(32, (Cout, C, 3, 3), -1.4, 1.4)
+    conv = TerConv2d(C, Cout, 3, padding=1).to(dev)
+    conv.weight.data.copy_(g(w, dev)); conv.bias.data.copy_(g(synth.normal(33, (Cout,)), dev))
+    conv.eval()
+    conv.binary_input = False
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+    bn.running_mean.copy_(g(synth.normal(34, (Cout,)), dev)); bn.running_var.copy_(g(synth.uniform(35, (Cout,), 2, 30), dev))
+    bn.weight.data.copy_(g(synth.normal(36, (Cout,)), dev)); bn.bias.data.copy_(g(synth.normal(37, (Cout,)), dev))
+    blk = FusedConvPoolBnSign(conv, bn)
+    with torch.no_grad(), used("qt_conv3x3_direct_nib"):
+        act = blk(g(x, dev).contiguous(memory_format=torch.channels_last))
+    alpha, beta = (n(t) for t in fold_batchnorm(bn))
+    wq = oracle.ternarize(w)
+    got = _decode(act).numpy()
+    for img in (0, N - 1):
+        yconv = oracle.conv2d(x[img:img + 1], wq, n(conv.bias), 1, 1)[0].astype(np.float64)
+        v = yconv * alpha.astype(np.float64)[:, None, None] + beta.astype(np.float64)[:, None, None]
+        want = np.where(v < 0, -1.0, 1.0)
+        diff = got[img] != want
+        scale = np.abs(v).mean()
+        assert diff.mean() <= 1e-4, diff.mean()
+        assert np.all(np.abs(v[diff]) <= 1e-5 * scale), float(np.abs(v[diff]).max() / scale)   # ties only
+
+
+# ---- fused networks, layer by layer at the configured image size ----------------------------------------------------
+
+def _unit_scale_weights(model, seed):
+    gen = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+            m.weight.data.copy_(torch.empty_like(m.weight).uniform_(-1.2, 1.2, generator=gen))
+            if m.bias is not None:
+                m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen))
+
+
+def _folded_sign(acc_plus_bias: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """The fused blocks' expression on the host, in fp32 with two roundings: fl(fl(t * alpha) + beta) < 0 -> -1."""
+    shape = (1, -1, 1, 1) if acc_plus_bias.dim() == 4 else (1, -1)
+    v = (acc_plus_bias * alpha.view(shape)) + beta.view(shape)
+    return torch.where(v < 0, -1.0, 1.0), v
+
+
+def _check_block_vs_modules(pm1_folded, v_folded, module_out_pm1, name):
+    """Folded form vs the un-fused module chain (BatchNorm's own arithmetic): they may disagree only on ties."""
+    diff = pm1_folded != module_out_pm1
+    if diff.any():
+        scale = float(v_folded.abs().mean())
+        assert float(diff.float().mean()) <= 1e-5, (name, float(diff.float().mean()))
+        assert float(v_folded[diff].abs().max()) <= 1e-5 * scale, (name, float(v_folded[diff].abs().max()) / scale)
+
+
+def test_c5_fused_vgg16_layerwise_at_224(dev):
+    """Config C5's network at 3 x 224 x 224: every fused block of FusedFeatureClassifier (threshold-bit convs incl. the
+    direct 3x3 kernels, pools on bits, nibble hand-overs) on the GPU against the host evaluation of the same folded
+    expression, each block fed with the HOST chain's intermediate in the form its producer would have handed over."""
+    import bench_models
+    torch.manual_seed(5)
+    model = bench_models.TernaryVGG16(num_classes=1000, image=224, fc=4096)
+    _unit_scale_weights(model, 8)
+    bench_models.randomize_bn(model, seed=5)
+    model.eval()                                          # TerConv2d / LinearTer now hold their ternarised weights
+    gmodel = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)
+    gmodel.features[0].binary_input = False
+    fused = FusedFeatureClassifier(gmodel.features, gmodel.classifier, (512, 7, 7))
+    blocks = list(fused.features.children())
+    assert sum(isinstance(b, FusedConvPoolBnSign) for b in blocks) == 13 and sum(isinstance(b, PackedMaxPool) for b in blocks) == 5
+    N = 2
+    x = torch.randn(N, 3, 224, 224)
+    convs = [m for m in model.features if isinstance(m, TerConv2d)]
+    bns = [m for m in model.features if isinstance(m, torch.nn.BatchNorm2d)]
+    before = dict(_lib.call_counts)
+    cur, prev, ci = x, None, 0
+    with torch.no_grad():
+        for bi, blk in enumerate(blocks):
+            if isinstance(blk, PackedMaxPool):
+                want = F.max_pool2d(cur, 2, 2)
+                got = _decode(blk(_as_input(cur, prev, dev)))
+                assert torch.equal(got, want), f"pool block {bi}"
+                cur, prev = want, blk
+                continue
+            conv, bn = convs[ci], bns[ci]
+            acc = F.conv2d(cur, conv.weight, conv.bias, padding=1)          # exact integers + bias for +-1 inputs
+            alpha, beta = (t.cpu() for t in fold_batchnorm(blk.bn))
+            want, v = _folded_sign(acc, alpha, beta)
+            inp = x.to(dev).contiguous(memory_format=torch.channels_last) if ci == 0 else _as_input(cur, prev, dev)
+            got = _decode(blk(inp))
+            if ci == 0:      # real-valued input: fp32 accumulation order differs -> ties only
+                diff = got != want
+                assert float(diff.float().mean()) <= 1e-4 and (not diff.any() or float(v[diff].abs().max()) <= 1e-5 * float(v.abs().mean()))
+            else:
+                assert torch.equal(got, want), f"conv block {bi} ({conv.in_channels}->{conv.out_channels})"
+            module_out = torch.where(F.hardtanh(bn(conv(cur))) < 0, -1.0, 1.0)
+            _check_block_vs_modules(want, v, module_out, f"block {bi}")
+            cur, prev, ci = want, blk, ci + 1
+        # classifier: fused FC blocks on the flattened planes vs the host modules
+        flat_in = _as_input(cur, None, dev).flatten_hwc()
+        y_gpu = fused.classifier(flat_in).cpu()
+        y_cpu = model.classifier(cur.reshape(N, -1))
+    used_ = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
+    assert used_.get("qt_conv3x3_direct_nib", 0) >= 3, used_        # conv1 (real input), conv2, conv3 take the direct kernel
+    assert norm_err(y_gpu.numpy(), y_cpu.numpy()) <= 0.02, norm_err(y_gpu.numpy(), y_cpu.numpy())   # BatchNorm1d ties in two FC blocks
+
+
+def test_c3_fused_alexnet_layerwise(dev):
+    """Config C3's network (batch 4 of 3 x 224 x 224): the fused AlexNet-Bin feature blocks (conv -> MaxPool ->
+    BatchNorm -> Hardtanh -> sign as threshold bits + pooling on bits) one by one against the host's folded chain."""
+    import bench_models
+    torch.manual_seed(6)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model, seed=6)
+    model.eval()
+    gmodel = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)
+    fusedm = bench_models.FusedAlexNetBin(gmodel)
+    blocks = [b for b in fusedm.net.features.children()]
+    convs = [m for m in model.features if isinstance(m, BinConv2d)]
+    N = 4
+    x = torch.randn(N, 3, 224, 224)
+    cur, prev = x, None
+    with torch.no_grad():
+        for bi, blk in enumerate(blocks):
+            assert isinstance(blk, FusedConvPoolBnSign), type(blk)
+            conv = convs[bi]
+            acc = F.conv2d(cur, conv.weight, conv.bias, conv.stride, conv.padding)
+            if blk._pool.pool_k != 1 or blk._pool.pool_s != 1:
+                # the reference order: MaxPool, then the (monotone) BatchNorm map, then the sign
+                # (models/Alexnet/Alexnet_Bin.py:13-17); the kernel pools the threshold bits instead (AND / OR by the
+                # sign of alpha), which is the same function of the window
+                acc = F.max_pool2d(acc, blk._pool.pool_k, blk._pool.pool_s)
+            alpha, beta = (t.cpu() for t in fold_batchnorm(blk.bn))
+            want, v = _folded_sign(acc, alpha, beta)
+            inp = x.to(dev).contiguous(memory_format=torch.channels_last) if bi == 0 else _as_input(cur, prev, dev)
+            out = blk(inp)
+            got = _decode(out) if len(out.shape) == 4 else None
+            if got is None:        # the last block flattens for the classifier: undo (h, w, c)
+                Cc, Hh, Ww = want.shape[1:]
+                words = out.planes.sign.cpu().numpy().view(np.uint32)
+                bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(N, -1)[:, :Hh * Ww * Cc]
+                got = torch.from_numpy(np.where(bits == 1, -1.0, 1.0).astype(np.float32)).view(N, Hh, Ww, Cc).permute(0, 3, 1, 2)
+            if bi == 0:
+                diff = got != want
+                assert float(diff.float().mean()) <= 1e-4 and (not diff.any() or float(v[diff].abs().max()) <= 1e-5 * float(v.abs().mean()))
+            else:
+                assert torch.equal(got, want), f"block {bi}"
+            cur, prev = want, blk
+
+
+def test_c4_fused_dorefa_resnet18_layerwise(dev, oracle):
+    """Config C4's network (3 x 32 x 32, batch 32): every code-epilogue conv of the fused DoReFa ResNet-18 against the
+    oracle's restatement of BatchNorm -> (+ shortcut) -> ReLU -> nnDorefaQuant(4) applied to the host's exact integer
+    conv result, each conv fed with the HOST chain's codes (as the halo plane its producer writes)."""
+    import bench_models
+    torch.manual_seed(4)
+    model = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(model, seed=3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.mul_(4.0)
+    model.eval()
+    gmodel = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)
+    fusedm = bench_models.FusedDorefaResNet18(gmodel, a_bits=4)
+    N = 32
+    x = torch.randn(N, 3, 32, 32)
+
+    inv_n = np.float32(ops.inv_levels(4))
+
+    def codes_act(q: torch.Tensor, halo: int):
+        """host integer codes [N, C, H, W] -> the CodeActivation its producer writes: NHWC int8 plane with a zero halo"""
+        Nn, C, H, W = q.shape
+        qd = (q.to(dev) * float(inv_n)).contiguous(memory_format=torch.channels_last)      # rint(15 * fl(c / 15)) == c
+        planes, _ = ops.dorefa_codes(qd.permute(0, 2, 3, 1).reshape(Nn * H * W, C), 4, want_f32=False, ld_bytes=ops.code_ld_bytes(C, 16))
+        ld = int(planes.codes.shape[1])
+        full = torch.zeros((Nn, H + 2 * halo, W + 2 * halo, ld), dtype=torch.int8, device=dev)
+        full[:, halo:halo + H, halo:halo + W] = planes.codes.view(Nn, H, W, ld)
+        pl = ops.CodePlanes(codes=full.view(-1, ld), rows=Nn * (H + 2 * halo) * (W + 2 * halo), K=planes.K, inv_n=planes.inv_n,
+                            bit_width=planes.bit_width, overflow=planes.overflow)
+        return packed.CodeActivation(pl, (Nn, C, H, W), halo=(halo, halo))
+
+    def decode_codes(act):
+        a = act.without_halo()
+        Nn, C, H, W = a.shape
+        return a.codes.codes.view(Nn, H, W, -1)[..., :C].permute(0, 3, 1, 2).to(torch.float32).cpu()
+
+    def expected_codes(conv_out_fp32, bn, residual_fp32=None):
+        """oracle.affine_relu_dorefa_codes (fp32 steps, channel = dim 1) on the host's fp32 conv image, k = 4"""
+        alpha, beta = (n(t) for t in fold_batchnorm(bn))
+        q, _ = oracle.affine_relu_dorefa_codes(conv_out_fp32.numpy(), alpha, beta, 4, relu=True,
+                                               res=None if residual_fp32 is None else residual_fp32.numpy())
+        assert np.abs(q).max() <= 127
+        return torch.from_numpy(q.astype(np.float32))
+
+    def conv_image(codes, conv):
+        """fl(acc * fl(inv_n * E)) — what the int8 conv stores: exact integer accumulators, ONE scale multiply"""
+        E = np.float32(conv.weight.abs().amax().item())          # eval-mode weights hold sign(W) * E
+        acc = F.conv2d(codes, torch.sign(conv.weight), None, conv.stride, conv.padding)
+        assert float(acc.abs().max()) < 2 ** 24
+        return acc * torch.tensor(inv_n * E)
+
+    with torch.no_grad():
+        # stem: fp32 library conv + one fused quantiser pass; MIOpen and ATen sum in different orders -> rint ties only
+        q_host = expected_codes(model.stem(x), model.bn)
+        q_gpu = decode_codes(fusedm.q0(gmodel.stem(x.to(dev).contiguous(memory_format=torch.channels_last))))
+        d = q_gpu != q_host
+        assert float(d.float().mean()) <= 1e-4 and (not d.any() or float((q_gpu - q_host).abs().max()) <= 1)
+        cur = q_host
+        before = dict(_lib.call_counts)
+        for bi, (blk, fblk) in enumerate(zip(model.blocks, fusedm.blocks)):
+            a_in = codes_act(cur, 1)
+            q1_host = expected_codes(conv_image(cur, blk.conv1), blk.bn1)
+            assert torch.equal(decode_codes(fblk.c1(a_in)), q1_host), f"block {bi} conv1"
+            y2 = conv_image(q1_host, blk.conv2)
+            if blk.shortcut is None:
+                res_host = cur * torch.tensor(inv_n)             # identity shortcut: the block input's fp32 image fl(inv_n * q)
+                res_gpu, sc_bn = a_in, None
+            else:
+                ys = conv_image(cur, blk.shortcut[0])
+                al_s, be_s = (t.cpu() for t in fold_batchnorm(blk.shortcut[1]))
+                res_host = ys * al_s.view(1, -1, 1, 1) + be_s.view(1, -1, 1, 1)
+                res_gpu, sc_bn = fblk.sc_conv(a_in), fblk.sc_bn
+                assert torch.equal(res_gpu.cpu(), ys), f"block {bi} shortcut conv"      # integer core x one scale: exact
+            q2_host = expected_codes(y2, blk.bn2, res_host)
+            q2_gpu = decode_codes(fblk.c2(codes_act(q1_host, 1), residual=res_gpu, residual_bn=sc_bn))
+            assert torch.equal(q2_gpu, q2_host), f"block {bi} conv2"
+            cur = q2_host
+    ran = _lib.call_counts["qt_conv2d_implicit_codes"] - before.get("qt_conv2d_implicit_codes", 0)
+    assert ran == 16, ran
+
+
+# ---- one-launch linear forward ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["linbin_c2_full", "linter_c2_full"])
+def test_linear_fused_reference_digest(dev, golden_hashes, case):
+    """qt_linear_fused_f32 (pack of both operands overlapped with the fp4 MFMA GEMM in one persistent launch) reproduces
+    the SHA-256 the REFERENCE produced for the full 4096 x 4096 x 4096 C2 layer, twice in a row on one workspace."""
+    h = golden_hashes[case]
+    B, K, N = h["B"], h["K"], h["N"]
+    if not ops.linear_fused_supported(B, N, K):
+        pytest.skip("shape not taken by the fused entry point")
+    x = g(synth.pm1(h["x_seed"], (B, K)), dev)
+    w = g(synth.uniform(h["w_seed"], (N, K), h["w_lo"], h["w_hi"]), dev)
+    kind = "binary" if case.startswith("linbin") else "ternary"
+    for _ in range(2):
+        with used("qt_linear_fused_f32"):
+            y = ops.linear_fused(x, w, None, kind)
+        assert hashlib.sha256(n(y).astype(np.int32).tobytes()).hexdigest() == h["sha256_int32"]
+        assert ops.linear_fused_error(dev, B, N, K) == 0
+    # ... and with a bias (float tail) against the two-launch route
+    b = g(synth.normal(3, (N,)), dev)
+    xp, wp = ops.pack_linear_operands(x, w, kind, "mfma")
+    assert torch.equal(ops.linear_fused(x, w, b, kind), ops.packed_gemm(xp, wp, b, impl="mfma"))
