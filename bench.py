@@ -13,7 +13,14 @@ For N > 1 the driver launches one rank per GPU with torch.distributed.run; ranks
 barriers that bracket the timed region and in the MAX reduction of the elapsed time.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside the timed
-region) and "cpu_baseline" (reference op sequence on the host cores, rank 0, N=1 only).
+region) and "cpu_baseline" (reference op sequence on the host cores, rank 0, N=1 only), "alexnet" (second half
+of the metric) and "extra": the other BASELINE configs, each timed by the same process and each with the roofline
+SURVEY.md 8(d) prescribes (ops = 2 * MACs, bytes = fp32 activations in + fp32 weights + fp32 activations out per
+quantised layer): C2 eval mode on pre-packed operands, C2 with a bias (float-tail parity), C4 (DoReFa ResNet-18 W1A4,
+batch 256) and C5 (ternary VGG-16, 256 per GPU), un-fused reference graph and fused inference form.
+
+--strong: strong scaling — the GLOBAL batch is fixed (C2: --batch rows, AlexNet / C4 / C5: their batch) and split
+over the ranks ("scaling": "strong"); default is weak scaling (batch per GPU fixed).
 """
 import argparse
 import json
@@ -50,6 +57,12 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (smoke tests)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (exercise the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch / --alexnet-batch / --c4-batch / --c5-batch are GLOBAL and split over the ranks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 'extra' object (C2 eval / bias, C4, C5)")
+    ap.add_argument("--c4-batch", type=int, default=256, help="C4 images per GPU (global with --strong; 0 = skip)")
+    ap.add_argument("--c5-batch", type=int, default=256, help="C5 images per GPU (global with --strong, e.g. 2048; 0 = skip)")
+    ap.add_argument("--extra-iters", type=int, default=10)
     return ap.parse_args()
 
 
@@ -81,6 +94,12 @@ def main():
     from pytorch_quantize_impls_amd import _lib, ops
     from pytorch_quantize_impls_amd.functions import _fused
 
+    if args.strong:
+        for name in ("batch", "alexnet_batch", "c4_batch", "c5_batch"):
+            g = getattr(args, name)
+            if g % world:
+                sys.exit(f"--strong: --{name.replace('_', '-')} {g} is not divisible by {world} ranks")
+            setattr(args, name, g // world)
     B, K, N = args.batch, args.in_features, args.out_features
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED + rank)
@@ -165,7 +184,7 @@ def main():
     result = {
         "metric": "XNOR-popcount GEMM TOPS (LinearBin 4096x4096 forward, batch 4096 per GPU)",
         "value": value, "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "u32 bit planes (xor+popcount), int32 accumulate, fp32 in/out"
                  if gemm_impl != "mfma" else "fp4-e2m1 (+-1 exact) MFMA, fp32 accumulate, fp32 in/out",
         "data": "synthetic",
@@ -178,6 +197,8 @@ def main():
     # ---- BinaryNet-AlexNet images/s (second half of BASELINE.json's metric) ---------------------------
     if args.alexnet_batch > 0:
         result["alexnet"] = bench_alexnet(args, dev, dist, world, rank)
+    if not args.no_extras:
+        result["extra"] = bench_extras(args, dev, dist, world, rank, x, w)
 
     # ---- parity gate + CPU baseline (rank 0, N = 1 only) --------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -195,6 +216,13 @@ def main():
             "sample": f"{iters} full-size calls of the reference op sequence "
                       f"(torch.sign + masked write + F.linear fp32, B={B} K={K} N={N}), median",
             "host": _cpu_model()}
+        # "plus a 1-thread run" — the same op sequence on ONE host core (bounded: 2 calls)
+        torch.set_num_threads(1)
+        med1, it1 = torch_port.time_callable(lambda: torch_port.linear_bin_forward(xc, wc), budget_s=0.0, warmup=0,
+                                             min_iters=2, max_iters=2)
+        torch.set_num_threads(nthreads)
+        result["cpu_baseline"]["one_thread"] = {"value": ops_per_step / med1 / 1e12, "unit": "TOPS", "cores": 1,
+                                                "ms_per_step": med1 * 1e3, "sample": f"{it1} full-size calls"}
     if rank == 0:
         result["calls"] = {k: int(v) for k, v in _lib.call_counts.items()}
         print(json.dumps(result))
@@ -260,7 +288,7 @@ def bench_alexnet(args, dev, dist, world, rank):
                                 "ms_per_forward": elt / args.alexnet_iters * 1e3,
                                 "same_logits_as_eval": bool(torch.equal(yt, y))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = min(B, 16)
+        cb = B                       # the same batch as the GPU leg (one forward = ~1 s on the box's host)
         cpu_model = bench_models.AlexNetBin()
         cpu_model.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
         cpu_model.eval()
@@ -271,6 +299,174 @@ def bench_alexnet(args, dev, dist, world, rank):
             med, iters = torch_port.time_callable(lambda: cpu_model(xc), budget_s=min(args.cpu_budget_s, 8.0))
         out["cpu_baseline"] = {"images_per_s": cb / med, "batch": cb, "cores": torch.get_num_threads(),
                                "kind": "port", "sample": f"{iters} forwards of the same topology on CPU tensors, median"}
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        x1 = xc[:4].contiguous()
+        with torch.no_grad():
+            med1, it1 = torch_port.time_callable(lambda: cpu_model(x1), budget_s=0.0, warmup=1, min_iters=2, max_iters=2)
+        torch.set_num_threads(nthr)
+        out["cpu_baseline"]["one_thread"] = {"images_per_s": 4 / med1, "batch": 4, "cores": 1, "sample": f"{it1} forwards"}
+    return out
+
+
+def _layer_stats(model, x):
+    """SURVEY.md 8(d) figures of one forward: ops = 2 * MACs and algorithmic bytes = 4 * (inputs + weights + outputs) summed
+    over the quantised Linear / Conv2d layers (full taps, padding counted), from forward hooks on the un-fused model."""
+    from pytorch_quantize_impls_amd.layers.common import QLayer
+    acc = {"macs": 0.0, "bytes": 0.0, "layers": 0}
+
+    def hook(mod, inp, out):
+        xin = inp[0]
+        w = mod.weight
+        if out.dim() == 4:
+            macs = out.shape[0] * out.shape[1] * out.shape[2] * out.shape[3] * w.shape[1] * w.shape[2] * w.shape[3]
+        else:
+            macs = out.numel() * w.shape[1]
+        acc["macs"] += float(macs)
+        acc["bytes"] += 4.0 * (xin.numel() + w.numel() + out.numel())
+        acc["layers"] += 1
+
+    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, QLayer)]
+    with torch.no_grad():
+        model(x)
+    for h in hs:
+        h.remove()
+    return acc
+
+
+def _net_line(name, B, world, iters, el, stats, peak_tflops, peak_name, extra=None):
+    ms = el / iters * 1e3
+    ops_ = 2.0 * stats["macs"]
+    d = {"images_per_s": world * B * iters / el, "batch_per_gpu": B, "ms_per_forward": ms,
+         "roofline": {"ops_per_forward": ops_, "algorithmic_bytes_fp32": stats["bytes"], "quantised_layers": stats["layers"],
+                      "achieved_TFLOPs": ops_ / (ms * 1e-3) / 1e12, "peak_TFLOPs": peak_tflops, "peak": peak_name,
+                      "frac_of_matrix_peak": ops_ / (ms * 1e-3) / 1e12 / peak_tflops,
+                      "hbm_equiv_GBs": stats["bytes"] / (ms * 1e-3) / 1e9,
+                      "frac_of_8TBs": stats["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def bench_extras(args, dev, dist, world, rank, x, w):
+    """The BASELINE configs the headline does not cover, timed in this process (driver-visible), N ranks like the headline."""
+    import bench_models
+    from pytorch_quantize_impls_amd import ops
+    from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic
+    from pytorch_quantize_impls_amd.layers import LinearBin, FusedFeatureClassifier
+    out = {}
+    iters = args.extra_iters
+
+    def timed(fn, n=iters):
+        best = None
+        with torch.no_grad():
+            for _ in range(3):
+                fn()
+            for _ in range(3):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                e = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([e], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    e = float(tt.item())
+                best = e if best is None else min(best, e)
+        return best
+
+    # ---- C2, eval mode: weights pre-packed by .eval(), activation handed over packed by BinaryConnect (SURVEY 3.2, 8d)
+    B, K = x.shape
+    N = w.shape[0]
+    layer = LinearBin(K, N, bias=False).to(dev)
+    layer.weight.data.copy_(w)
+    layer.eval()
+    with torch.no_grad():
+        xs = BinaryConnectDeterministic.apply(x)                 # +-1 fp32 image + sign plane (tag)
+        y_eval = layer(xs)
+        impl = ops.select_gemm_impl("auto", B, N, K)
+        xp, wp = ops.pack_linear_operands(x, w, "binary", impl)
+        yb = torch.empty((B, N), device=dev)
+        n2 = 50
+        t_layer = timed(lambda: layer(xs), n2)
+        t_gemm = timed(lambda: ops.packed_gemm(xp, wp, None, out=yb, impl=impl), n2)
+    bytes_packed = B * K / 8.0 + N * K / 8.0 + 4.0 * B * N          # SURVEY 8(d) bytes_packed (1 bit / element operands)
+    bytes_operand = ops.packed_gemm_algorithmic_bytes(B, N, K, impl)
+    ops2 = 2.0 * B * K * N
+    out["c2_eval_prepacked"] = {
+        "workload": "LinearBin.eval() forward on a BinaryConnect-tagged activation (bit plane -> operand format -> packed GEMM); "
+                    "and the packed GEMM alone on pre-packed operands",
+        "layer_forward_us": t_layer / n2 * 1e6, "gemm_only_us": t_gemm / n2 * 1e6,
+        "TOPS_layer": world * ops2 * n2 / t_layer / 1e12, "TOPS_gemm_only": world * ops2 * n2 / t_gemm / 1e12,
+        "roofline": {"bytes_packed_1bit": bytes_packed, "hbm_floor_us": bytes_packed / (HBM_PEAK_GBS * 1e9) * 1e6,
+                     "frac_of_8TBs_layer": bytes_packed / (t_layer / n2) / 1e9 / HBM_PEAK_GBS,
+                     "frac_of_8TBs_gemm_only": bytes_packed / (t_gemm / n2) / 1e9 / HBM_PEAK_GBS,
+                     "operand_format_bytes": bytes_operand,
+                     "matrix_frac_gemm_only": ops2 / (t_gemm / n2) / 1e12 / MFMA_FP4_PEAK_TFLOPS if impl == "mfma" else None},
+        "same_as_train_mode": None}
+    # ---- C2 with a bias ~ N(0, 1): the float tail (SURVEY 8d), against the fp64 evaluation and the CPU port
+    gb = torch.Generator(device=dev)
+    gb.manual_seed(77)
+    bias = torch.randn((N,), device=dev, generator=gb)
+    with torch.no_grad():
+        y_b = ops.packed_gemm(xp, wp, bias, impl=impl)
+        y_i = ops.packed_gemm(xp, wp, None, impl=impl)
+        out["c2_eval_prepacked"]["same_as_train_mode"] = bool(torch.equal(y_i, y_eval))
+        ref64 = y_i.double() + bias.double()                       # exact integers + bias in fp64
+        err = float((y_b.double() - ref64).abs().max() / ref64.abs().max())
+    tail = {"bias": "N(0,1)", "norm_err_vs_fp64": err, "tolerance": 1e-5, "pass": err <= 1e-5}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_port
+        rows = slice(0, 512)
+        ref = torch_port.linear_bin_forward(x[rows].cpu(), w.cpu(), bias.cpu())
+        tail["norm_err_vs_cpu_port_512_rows"] = float((y_b[rows].cpu() - ref).abs().max() / ref.abs().max())
+    out["c2_bias_tail"] = tail
+
+    # ---- C4: DoReFa ResNet-18 W1A4, 3 x 32 x 32
+    if args.c4_batch > 0:
+        Bc = args.c4_batch
+        torch.manual_seed(4 + rank)
+        m4 = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+        bench_models.randomize_bn(m4, seed=3)
+        for m in m4.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(4.0)
+        m4 = m4.to(dev).to(memory_format=torch.channels_last).eval()
+        x4 = torch.randn((Bc, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
+        st4 = _layer_stats(m4, x4)
+        f4 = bench_models.FusedDorefaResNet18(m4)
+        with torch.no_grad():
+            agree = float((f4(x4).argmax(1) == m4(x4).argmax(1)).float().mean())
+        el_u = timed(lambda: m4(x4))
+        el_f = timed(lambda: f4(x4), 2 * iters)
+        out["c4_dorefa_resnet18_w1a4"] = {
+            "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54"),
+            "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                               {"argmax_agreement_with_unfused": agree}),
+            "note": "launch / latency bound at 32 x 32 maps (SURVEY 8d): ~60 launches of 5-40 us each"}
+    # ---- C5: ternary VGG-16, 3 x 224 x 224 (2048 over 8 GPUs = 256 per GPU)
+    if args.c5_batch > 0:
+        Bv = args.c5_batch
+        torch.manual_seed(5 + rank)
+        m5 = bench_models.TernaryVGG16(num_classes=1000, image=224)
+        bench_models.randomize_bn(m5, seed=5)
+        m5 = m5.to(dev).to(memory_format=torch.channels_last).eval()
+        m5.features[0].binary_input = False
+        x5 = torch.randn((Bv, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+        st5 = _layer_stats(m5, x5)
+        f5 = FusedFeatureClassifier(m5.features, m5.classifier, (512, 7, 7))
+        with torch.no_grad():
+            agree5 = float((f5(x5).argmax(1) == m5(x5).argmax(1)).float().mean())
+        el_u5 = timed(lambda: m5(x5), 3)
+        el_f5 = timed(lambda: f5(x5), iters)
+        out["c5_ternary_vgg16"] = {
+            "unfused": _net_line("c5", Bv, world, 3, el_u5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense"),
+            "fused": _net_line("c5", Bv, world, iters, el_f5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
+                               {"argmax_agreement_with_unfused": agree5}),
+            "global_batch": Bv * world}
     return out
 
 

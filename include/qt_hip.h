@@ -8,7 +8,10 @@
  *
  * Conventions (all entry points):
  *   - plain `extern "C"`, raw DEVICE pointers + explicit sizes/strides, no torch types;
- *   - stateless and re-entrant: no allocation, no ownership transfer, no global state;
+ *   - stateless and re-entrant: no allocation, no ownership transfer, no process-global state of any kind (kernel
+ *     variants for tests / tuning are ARGUMENTS of the *_variant entry points); the only thing that survives a call is
+ *     what it wrote into caller-provided buffers (results, and for qt_linear_fused_f32 the launch bookkeeping inside the
+ *     workspace the caller hands it);
  *   - work is enqueued on `stream` (a hipStream_t, passed as an opaque pointer; NULL = the
  *     default stream) and the call returns without synchronising;
  *   - the caller has already made the right device current (hipSetDevice);
@@ -164,10 +167,14 @@ int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t l
                  const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                  qt_stream_t stream);
 
-/* Tuning / test hook (process-global, not thread-safe): which popcount kernel qt_xnor_gemm / qt_tern_gemm
- * use: 0 = automatic (skinny weight-streaming kernel for small M or N, 128x128-tile kernel otherwise),
- * 1 = always tiled, 2 = always skinny. */
-int qt_popc_force_kernel(int which);
+/* The same two GEMMs with the kernel chosen by the caller (tests / tuning; no process state involved):
+ * variant 0 = automatic (skinny weight-streaming kernel for small M or N, 128x128-tile kernel otherwise),
+ * 1 = tiled, 2 = skinny. */
+int qt_xnor_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
+                         const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
+int qt_tern_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
+                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                         qt_stream_t stream);
 
 /* Binary activations x ternary weights (two planes): y = popc(m) - 2*popc((x ^ s) & m). */
 int qt_tern_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
@@ -370,11 +377,15 @@ int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_
                        float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t Cout,
                        qt_stream_t stream);
 
-/* Tuning / test hook (process-global, not thread-safe): main loop of the implicit-GEMM conv kernels:
- * 0 = automatic (ping-pong 384x192 tile for 192-wide column tiles, double-buffered otherwise),
- * 1 = double-buffered, 2 = ping-pong, 3 = stamped 384x192 ping-pong (profiling only: Y is garbage),
- * 4 = automatic without the un-padded fast path (A/B only). */
-int qt_conv_force_kernel(int which);
+/* qt_conv2d_implicit with the main loop chosen by the caller (tests / tuning; an argument, not process state):
+ * variant 0 = automatic (ping-pong 384x192 tile for 192-wide column tiles, double-buffered otherwise),
+ * 1 = double-buffered, 2 = ping-pong, 4 = automatic without the un-padded fast path (A/B only);
+ * 3 (stamped kernel, Y garbage) exists only in -DQT_PROFILING_VARIANTS builds and is QT_ERR_UNSUPPORTED otherwise. */
+int qt_conv2d_implicit_variant(int variant, int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                               int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias,
+                               float scale, const float* scale_dev, float* Y, int64_t ldy, int64_t Cout,
+                               qt_stream_t stream);
 
 /* Same conv with the threshold-bit epilogue (inference fusion of
  *   BinConv2d -> [MaxPool2d] -> BatchNorm2d(eval) -> Hardtanh -> BinaryConnect, models/Alexnet/Alexnet_Bin.py:13-17):
@@ -484,8 +495,8 @@ int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, int6
  * 20/21/22/23 = ping-pong kernel (64-byte stages, ring of 4, SIMD partners alternate load / compute
  * segments), tile 256x256 / 256x128 / 256x192 / 256x64, 24 = ping-pong 384x192; 6/7/8/15 = double-buffered pipelined kernel, tile 256x256 /
  * 256x128 / 256x64 / 256x192 (QT_ERR_ALIGNMENT if the contract does not hold); 5/9/10/16 = generic
- * kernel with the same tiles; 161..164 = profiling ablations of 6 (no MFMA / no DMA / epilogue only /
- * no LDS reads) and 165 / 166 = ping-pong with per-segment + phase / phase-only stamps written over Y (results are NOT valid). */
+ * kernel with the same tiles.  (161..166, stamped / ablated profiling kernels whose Y is not valid, exist only in
+ * -DQT_PROFILING_VARIANTS builds of the library; the product build answers QT_ERR_UNSUPPORTED.) */
 int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn,
                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M,
                         int64_t N, int64_t K, qt_stream_t stream);

@@ -55,8 +55,11 @@ SIGNATURES = {
     "qt_lin_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_int, _c_int, _c_p]),
     "qt_log_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_int, _c_int, _c_p]),
     "qt_ap2_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
-    "qt_popc_force_kernel": (_c_int, [_c_int]),
-    "qt_conv_force_kernel": (_c_int, [_c_int]),
+    "qt_xnor_gemm_variant": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_tern_gemm_variant": (_c_int, [_c_int, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64,
+                                      _c_p]),
+    "qt_conv2d_implicit_variant": (_c_int, [_c_int, _c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p,
+                                                                                     _c_i64, _c_i64, _c_p]),
     "qt_xnor_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                               _c_i64, _c_p]),
     "qt_tern_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64,

@@ -43,7 +43,8 @@
 // Conv (CONV_ = 1 / 2): the X operand is an NHWC pixel plane and a stage gathers the 16-byte chunks of the taps it
 // covers (implicit GEMM, no im2col buffer): per-tap bounds checks + zero page (1), or — un-padded / physically
 // padded planes — plain 32-bit offsets with the per-(stage, chunk) tap offsets tabulated once in LDS (2).
-// Profiling-only variants (ABL_ != 0) are reachable through qt_nib_gemm_variant / qt_conv_force_kernel(3).
+// Profiling-only variants (ABL_ != 0) exist only in -DQT_PROFILING_VARIANTS builds (qt_nib_gemm_variant 161-166,
+// qt_conv2d_implicit_variant 3); the product library does not contain them.
 #include <type_traits>
 #include "qt_common.h"
 #include "pp_common.h"
@@ -901,7 +902,9 @@ template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
 template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 1>;
 template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 1>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
 template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, 1>;
-template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 1>;   // profiling only (qt_conv_force_kernel(3))
+#ifdef QT_PROFILING_VARIANTS
+template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 1>;   // profiling builds only (conv variant 3)
+#endif
 template <class E> using ConvPP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, 1>;
 
 // implicit-conv configurations (pipelined kernel only)
@@ -924,7 +927,9 @@ template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
 // for M <= 4096, and beyond that while the standard tiling leaves CUs idle (< 256 tiles) and the weight re-reads of the
 // small row tiles ((M / 64) x the weight matrix through L2) stay under 256 MB
 template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
-template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling only
+#ifdef QT_PROFILING_VARIANTS
+template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling builds only
+#endif
 
 // tile width (256 / 192 / 128 / 64) that wastes the fewest padded columns; ties go to the wider tile
 int pick_tile_n(int64_t N) {
@@ -1009,16 +1014,18 @@ int dispatch_gemm(int variant, const uint32_t* Xn, int64_t ldxp, const uint32_t*
         case 30: if (!pipe_ok || ((ldxp | ldwp) & 63)) return QT_ERR_ALIGNMENT; QT_GO(CfgSkinny<E>);
         case 31: if (!pipe_ok || ((ldxp | ldwp) & 127)) return QT_ERR_ALIGNMENT; QT_GO(CfgSkinny512<E>);
         case 20: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E>);
+#ifdef QT_PROFILING_VARIANTS   // stamped / ablated kernels (Y is garbage): never in the product library
         case 165: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 5>);
         case 166: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP256<E, 6>);
-        case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
-        case 22: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP192<E>);
-        case 23: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP64<E>);
-        case 24: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP384x192<E>);
         case 161: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 1>);
         case 162: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 2>);
         case 163: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 3>);
         case 164: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(Cfg256<E, 1, 4>);
+#endif
+        case 21: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP128<E>);
+        case 22: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP192<E>);
+        case 23: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP64<E>);
+        case 24: if (!pipe_ok) return QT_ERR_ALIGNMENT; QT_GO(PP384x192<E>);
         default: return QT_ERR_UNSUPPORTED;
     }
 #undef QT_GO
@@ -1266,10 +1273,10 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 
-// qt_conv_force_kernel: 0 = automatic (192-wide tiles: ping-pong on a 384x192 tile, whose 96x96 wave tiles
-// keep the load segment under the compute segment: AlexNet conv2 302 -> 275 us; other widths: double-buffered,
-// equal or faster there), 1 = double-buffered, 2 = ping-pong
-static int g_conv_force = 0;
+// conv kernel variant (an ARGUMENT of qt_conv2d_implicit_variant; every other entry point passes 0): 0 = automatic
+// (192-wide tiles: ping-pong on a 384x192 tile, whose 96x96 wave tiles keep the load segment under the compute segment:
+// AlexNet conv2 302 -> 275 us; other widths: double-buffered, equal or faster there), 1 = double-buffered, 2 = ping-pong,
+// 4 = automatic without the un-padded fast path; 3 = stamped 384x192 ping-pong, only in -DQT_PROFILING_VARIANTS builds
 
 // elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes.  epi.alpha != nullptr:
 // Y is the threshold-bit plane and ldy its row stride in words.
@@ -1277,7 +1284,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                               int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
                               const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream,
-                              const EpiArgs& epi_in, int64_t hy = 0, int64_t hx = 0) {
+                              const EpiArgs& epi_in, int64_t hy = 0, int64_t hx = 0, int g_conv_force = 0) {
     // (hy, hx): halo of the INPUT plane, [N][H + 2hy][W + 2hx][Cw] with a zero border: a conv whose padding fits in
     // the halo runs as the un-padded conv on the window that starts (hy - ph, hx - pw) into the plane.
     EpiArgs epi = epi_in;
@@ -1323,11 +1330,20 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         cg.H = (int)Hp; cg.W = (int)Wp; cg.ph = cg.pw = 0;
         P += ((hy - ph) * Wp + (hx - pw)) * Cw;
     }
+#ifdef QT_PROFILING_VARIANTS
+#define QT_CONV_STAMPS_V(E) if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha) \
+        return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);
+#define QT_CONV_STAMPS(E) if (g_conv_force == 3 && tn == 192 && !epi.alpha) \
+        return launch_cfg<ConvPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);
+#else
+#define QT_CONV_STAMPS_V(E)
+#define QT_CONV_STAMPS(E)
+    if (g_conv_force == 3) return QT_ERR_UNSUPPORTED;
+#endif
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
-        if (valid && g_conv_force == 3 && tn == 192 && !epi.alpha)                                              \
-            return launch_cfg<ConvVPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        QT_CONV_STAMPS_V(E)                                                                                     \
         if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
             if (g_conv_force == 0 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout &&                  \
                 (M <= 4096 || (((M + 255) / 256) * ((Cout + tn - 1) / tn) < 256 &&                              \
@@ -1351,8 +1367,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
             if (tn == 128) return launch_cfg<ConvV128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             return launch_cfg<ConvV64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);                 \
         }                                                                                                       \
-        if (g_conv_force == 3 && tn == 192 && !epi.alpha)                                                       \
-            return launch_cfg<ConvPP192Stamps<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        QT_CONV_STAMPS(E)                                                                                       \
         if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
             return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 2) {                                                                                \
@@ -1370,13 +1385,17 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     if (elem == 1) QT_CONV(ElemI8);
     QT_CONV(ElemBf16);
 #undef QT_CONV
+#undef QT_CONV_STAMPS
+#undef QT_CONV_STAMPS_V
 }
 
-int qt_conv_force_kernel(int which) {
-    // 3 = stamped 384x192 ping-pong (profiling; Y is garbage), 4 = automatic without the un-padded fast path
-    if (which < 0 || which > 4) return QT_ERR_INVALID_ARG;
-    g_conv_force = which;
-    return QT_OK;
+int qt_conv2d_implicit_variant(int variant, int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
+                               int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                               const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream) {
+    if (variant < 0 || variant > 4) return QT_ERR_INVALID_ARG;
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, Y, ldy, Cout, stream, EpiArgs{}, 0, 0, variant);
 }
 
 int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,

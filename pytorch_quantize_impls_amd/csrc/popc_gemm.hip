@@ -182,13 +182,12 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
     }
 }
 
-// 0 = automatic, 1 = 128x128-tile kernel, 2 = skinny (weight-streaming) kernel
-static int g_popc_force = 0;
-
+// variant: 0 = automatic, 1 = 128x128-tile kernel, 2 = skinny (weight-streaming) kernel
 template <bool TERNARY>
-int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const uint32_t* W1,
+int launch_popc_gemm(int variant, const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const uint32_t* W1,
                      int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
                      int64_t K, qt_stream_t stream) {
+    if (variant < 0 || variant > 2) return QT_ERR_INVALID_ARG;
     if (M < 0 || N < 0 || K < 0) return QT_ERR_INVALID_ARG;
     if (M == 0 || N == 0) return QT_OK;
     if (!Y || ldy < N) return QT_ERR_INVALID_ARG;
@@ -202,7 +201,7 @@ int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const 
     // weight-streaming regime: few batch rows or few output features -> the tiled kernel would leave
     // most CUs idle (tiles = ceil(M/128)*ceil(N/128) << 256) while the skinny kernel spreads N over waves
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const bool skinny = g_popc_force == 2 || (g_popc_force == 0 && (M <= 64 || N <= 64 || tiles < 128) && M <= 4096);
+    const bool skinny = variant == 2 || (variant == 0 && (M <= 64 || N <= 64 || tiles < 128) && M <= 4096);
     if (skinny && (M + 63) / 64 <= 65535)
         return qt_launch_popc_skinny(TERNARY, Xs, ldx, W0, W1, ldw, bias, Y, ldy, M, N, K, stream);
     const int64_t gy = (M + BM - 1) / BM, gx = (N + BN - 1) / BN;
@@ -223,23 +222,27 @@ int launch_popc_gemm(const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const 
 
 extern "C" {
 
-/* tuning: 0 = automatic choice between the tiled and the skinny popcount kernels, 1 / 2 = force one */
-int qt_popc_force_kernel(int which) {
-    if (which < 0 || which > 2) return QT_ERR_INVALID_ARG;
-    g_popc_force = which;
-    return QT_OK;
+int qt_xnor_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
+                         const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream) {
+    return launch_popc_gemm<false>(variant, Xs, ldxp, Ws, nullptr, ldwp, bias, Y, ldy, M, N, K, stream);
+}
+
+int qt_tern_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
+                         int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                         qt_stream_t stream) {
+    return launch_popc_gemm<true>(variant, Xs, ldxp, Wmask, Wsign, ldwp, bias, Y, ldy, M, N, K, stream);
 }
 
 int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
                  const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                  qt_stream_t stream) {
-    return launch_popc_gemm<false>(Xs, ldxp, Ws, nullptr, ldwp, bias, Y, ldy, M, N, K, stream);
+    return launch_popc_gemm<false>(0, Xs, ldxp, Ws, nullptr, ldwp, bias, Y, ldy, M, N, K, stream);
 }
 
 int qt_tern_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,
                  int64_t ldwp, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
                  int64_t K, qt_stream_t stream) {
-    return launch_popc_gemm<true>(Xs, ldxp, Wmask, Wsign, ldwp, bias, Y, ldy, M, N, K, stream);
+    return launch_popc_gemm<true>(0, Xs, ldxp, Wmask, Wsign, ldwp, bias, Y, ldy, M, N, K, stream);
 }
 
 }  // extern "C"

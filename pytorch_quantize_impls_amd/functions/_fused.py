@@ -14,6 +14,8 @@ CPU tensors: the same expression in torch (host logic; never used for a device t
 """
 from __future__ import annotations
 
+import weakref
+from collections import Counter
 from typing import Optional
 
 import torch
@@ -27,6 +29,18 @@ from .. import ops, packed
 DETECT_BINARY_INPUT = True
 
 
+#: Device tensors that went through the DENSE LIBRARY (hipBLASLt / MIOpen) instead of libqt_hip.so, by reason.  The
+#: HIP path is built for fp32; other dtypes, grouped / non-zero-padding-mode convs and eval-mode weights that are not
+#: a quantised image take the reference expression in torch — visibly: tests assert this counter stays empty on the
+#: fp32 paths.
+LIBRARY_PATHS: Counter = Counter()
+
+
+def note_library_path(input, reason: str) -> None:
+    if getattr(input, "is_cuda", False):
+        LIBRARY_PATHS[reason] += 1
+
+
 def _safe_sign_t(w: torch.Tensor) -> torch.Tensor:
     one = torch.ones((), dtype=w.dtype, device=w.device)
     return torch.where(w < 0, -one, one)
@@ -34,10 +48,11 @@ def _safe_sign_t(w: torch.Tensor) -> torch.Tensor:
 
 def quantize_weight_f32(weight: torch.Tensor, kind: str) -> torch.Tensor:
     """fp32 image of the deterministic weight quantiser of a layer family."""
+    hip = weight.is_cuda and weight.dtype == torch.float32      # the kernels are fp32; other dtypes: torch expression
     if kind == "binary":  # safeSign, functions/common.py:4-7
-        return ops.binarize(weight) if weight.is_cuda else _safe_sign_t(weight)
+        return ops.binarize(weight) if hip else _safe_sign_t(weight)
     if kind == "ternary":  # functions/terner_connect.py:26-27
-        if weight.is_cuda:
+        if hip:
             return ops.ternarize(weight)
         s = _safe_sign_t(weight)
         return (s + _safe_sign_t(weight - 0.5 * s)) / 2
@@ -68,24 +83,104 @@ def pack_weight(weight_2d: torch.Tensor, kind: str, impl: str = "valu"):
     return ops.pack_weights(weight_2d, kind, impl)
 
 
-def activation_planes(input: torch.Tensor, binary_input: Optional[bool], impl: str = "valu"):
-    """Packed image (format of ``impl``) of a device activation if it is (known to be) exactly
-    +-1, else None."""
+# ---- content-dependent routing ----------------------------------------------------------------------------------------
+# Two decisions depend on the VALUES of an activation: "is this un-tagged tensor exactly +-1?" (packed route vs the
+# exact bf16-triple route) and "do these DoReFa codes fit int8?" (int8 route vs fp32 route; the reference does not
+# clamp).  Asking the device costs a host sync per layer per forward (13 % of the module-by-module C4 forward).
+#   * A NEGATIVE answer is remembered per (consuming weight, activation shape) in every mode: the general route is
+#     correct for any input, so nothing needs to be asked again (e.g. the real-valued first conv of every model).
+#   * A POSITIVE answer is re-verified on every call by default (DETECT_MODE = "verify": reference-exact whatever the
+#     caller feeds next, one sync per un-tagged input).  DETECT_MODE = "remember" (serving / benchmarking) trusts it and
+#     folds THIS call's device flag into the bias instead: if the assumption ever stops holding, the output is NaN —
+#     never a plausible wrong number — and reset_detection() re-asks.  That is the contract of the fused code-plane
+#     chain (CodeActivation.float()) applied to the module-by-module graph; steady-state forwards then enqueue without
+#     any host synchronisation.
+# Activations that carry a tag from their quantiser (BinaryConnect, nnDorefaQuant: packed.py) never get here for the
+# +-1 question.
+DETECT_MODE = "verify"
+_VERDICTS = {}     # id(weight tensor) -> (weak reference to it, {(question, shape): bool}); tensors compare element-wise, so
+#                    they cannot key a WeakKeyDictionary
+#: "sync": decisions that needed a host sync; "cached": decisions taken from a remembered verdict (tests assert on it)
+DETECT_STATS: Counter = Counter()
+
+
+def reset_detection(weight: Optional[torch.Tensor] = None) -> None:
+    """Forget the remembered verdicts (of one weight, or all)."""
+    if weight is None:
+        _VERDICTS.clear()
+    else:
+        _VERDICTS.pop(id(weight), None)
+
+
+def _verdict(weight, tag, resolve):
+    """(answer, trusted-from-cache)"""
+    if DETECT_MODE not in ("verify", "remember"):
+        raise ValueError(f"DETECT_MODE must be 'verify' or 'remember', got {DETECT_MODE!r}")
+    if weight is None:
+        DETECT_STATS["sync"] += 1
+        return bool(resolve()), False
+    key = id(weight)
+    slot = _VERDICTS.get(key)
+    if slot is None or slot[0]() is not weight:
+        slot = (weakref.ref(weight, lambda _r, k=key: _VERDICTS.pop(k, None)), {})
+        _VERDICTS[key] = slot
+    d = slot[1]
+    if tag in d and (d[tag] is False or DETECT_MODE == "remember"):
+        DETECT_STATS["cached"] += 1
+        return d[tag], True
+    d[tag] = bool(resolve())
+    DETECT_STATS["sync"] += 1
+    return d[tag], False
+
+
+def detect_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]):
+    """(treat as +-1?, device flag to fold into the bias or None) for an UN-TAGGED device activation."""
+    ok, cached = _verdict(weight, ("pm1", tuple(input.shape[1:])), lambda: ops.is_pm1(input))
+    if ok and cached:
+        return True, ops.check_pm1(input)       # int32[1] on the device, non-zero = some element is not +-1; no sync
+    return ok, None
+
+
+def codes_route(codes, weight: Optional[torch.Tensor]):
+    """(use the int8 code planes?, device flag or None) for DoReFa activation codes whose range flag is on the device."""
+    if ops.ASSUME_CODES_FIT or codes.overflow is None:
+        return True, None
+    ok, cached = _verdict(weight, ("codes", int(codes.K)), codes.usable)
+    if ok and cached:
+        return True, codes.overflow
+    return ok, None
+
+
+def poison_bias(bias: Optional[torch.Tensor], flag: Optional[torch.Tensor], n: int, device) -> Optional[torch.Tensor]:
+    """bias (+ NaN if the device flag is raised): three tiny launches instead of a host sync."""
+    if flag is None:
+        return bias
+    nanv = torch.where(flag.reshape(()) != 0, float("nan"), 0.0)
+    base = bias.detach() if bias is not None else torch.zeros((n,), dtype=torch.float32, device=device)
+    return base + nanv
+
+
+def activation_planes(input: torch.Tensor, binary_input: Optional[bool], impl: str = "valu",
+                      weight: Optional[torch.Tensor] = None):
+    """(packed image of a device activation in the format of ``impl`` if it is (treated as) exactly +-1 else None,
+    device flag to fold into the bias or None)."""
     if input.dtype != torch.float32 or input.numel() == 0:
-        return None
+        return None, None
     tagged = packed.lookup(input, packed.ROWS_LAST)
     if tagged is not None:
         K = input.shape[-1]
         if tagged.K == K and tagged.rows * K == input.numel():
-            return ops.to_impl(tagged, impl)   # bit planes from the quantiser (1 bit -> 4 bits if mfma)
+            return ops.to_impl(tagged, impl), None   # bit planes from the quantiser (1 bit -> 4 bits if mfma)
     if binary_input is False:
-        return None
+        return None, None
+    flag = None
     if binary_input is None and tagged is None:
         if not DETECT_BINARY_INPUT:
-            return None
-        if not ops.is_pm1(input):  # host sync: only for un-tagged inputs
-            return None
-    return ops.pack_activations(input, impl)
+            return None, None
+        ok, flag = detect_pm1(input, weight)
+        if not ok:
+            return None, None
+    return ops.pack_activations(input, impl), flag
 
 
 def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -106,19 +201,21 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
     M = input.numel() // max(K, 1)
     impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
     if (impl == "mfma" and weight_planes is None and input.dtype == torch.float32 and input.numel() > 0
-            and binary_input is not False and packed.lookup(input, packed.ROWS_LAST) is None
-            and (binary_input or (DETECT_BINARY_INPUT and ops.is_pm1(input)))):
-        # neither operand is packed yet (un-tagged +-1 activation, training-mode weight): one launch packs both
-        wq = weight_q if weight_q is not None else weight
-        xp, wp = ops.pack_linear_operands(input, wq.reshape(N, -1), kind, impl)
-        return ops.packed_gemm(xp, wp, bias, impl=impl).view(*input.shape[:-1], N)
-    xp = activation_planes(input, binary_input, impl)
+            and binary_input is not False and packed.lookup(input, packed.ROWS_LAST) is None):
+        ok, flag = (True, None) if binary_input else (detect_pm1(input, weight) if DETECT_BINARY_INPUT else (False, None))
+        if ok:
+            # neither operand is packed yet (un-tagged +-1 activation, training-mode weight): one launch packs both
+            wq = weight_q if weight_q is not None else weight
+            xp, wp = ops.pack_linear_operands(input, wq.reshape(N, -1), kind, impl)
+            return ops.packed_gemm(xp, wp, poison_bias(bias, flag, N, input.device), impl=impl).view(*input.shape[:-1], N)
+        binary_input = False                      # verdict known: do not ask again below
+    xp, flag = activation_planes(input, binary_input, impl, weight)
     if xp is not None:
         wp = weight_planes
         if wp is None:
             wq = weight_q if weight_q is not None else weight
             wp = pack_weight(wq.reshape(N, -1), kind, impl)
-        y = ops.packed_gemm(xp, wp, bias, impl=impl)
+        y = ops.packed_gemm(xp, wp, poison_bias(bias, flag, N, input.device), impl=impl)
         return y.view(*input.shape[:-1], N)
 
     if FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
@@ -127,26 +224,30 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
         return ops.float_linear(input, weight_q if weight_q is not None else weight, kind, bias,
                                 weight_triples=weight_planes if isinstance(weight_planes, ops.TriplePlanes) else None)
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+    note_library_path(input, "non-fp32 or empty linear input")
     return F.linear(input, wq, bias)
 
 
-def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool]):
-    """NHWC nibble pixel plane of a device activation that is (known to be) exactly +-1, else None."""
+def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool], weight: Optional[torch.Tensor] = None):
+    """(NHWC nibble pixel plane of a device activation that is (treated as) exactly +-1 else None, device flag to fold
+    into the bias or None)."""
     if input.dtype != torch.float32 or input.dim() != 4 or input.numel() == 0:
-        return None
+        return None, None
     tagged = packed.lookup(input, packed.NHWC)
     if tagged is not None:
         N, C, H, W = input.shape
         if tagged.K == C and tagged.rows == N * H * W:
-            return ops.bits_to_nib(tagged, ld=ops.pixel_ld_nib(C))
+            return ops.bits_to_nib(tagged, ld=ops.pixel_ld_nib(C)), None
     if binary_input is False:
-        return None
+        return None, None
+    flag = None
     if binary_input is None and tagged is None:
         if not DETECT_BINARY_INPUT:
-            return None
-        if not ops.is_pm1(input):   # host sync: only for un-tagged inputs
-            return None
-    return ops.pack_pixels_nib(input)
+            return None, None
+        ok, flag = detect_pm1(input, weight)
+        if not ok:
+            return None, None
+    return ops.pack_pixels_nib(input), flag
 
 
 def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
@@ -166,8 +267,9 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
     packable = (input.is_cuda and groups == 1 and padding_mode == "zeros" and input.dim() == 4
                 and not isinstance(padding, str))
     if packable:
-        px = _pixel_planes(input, binary_input)
+        px, flag = _pixel_planes(input, binary_input, weight)
         if px is not None:
+            bias = poison_bias(bias, flag, int(weight.shape[0]), input.device)
             wq = weight_q if weight_q is not None else weight
             wp = weight_planes if isinstance(weight_planes, ops.NibPlanes) else ops.pack_conv_weight_nib(wq, kind)
             N, C, H, W = input.shape
@@ -230,6 +332,7 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
     if epi is not None:
         raise ValueError("the threshold-bit epilogue needs a device fp32 NCHW input, groups == 1 and zero padding")
     wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+    note_library_path(input, "grouped / non-zero padding mode / non-fp32 conv")
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
@@ -373,12 +476,14 @@ def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_cod
         y._qt_overflow = codes.overflow
         return y
     codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
-    if (codes is not None and codes.K == K and codes.rows * K == input.numel()
-            and 127 * K < (1 << 24) and codes.usable()):
-        wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
-        y = ops.i8_gemm(codes, wc, codes.inv_n, bias, scale_dev=E)
-        return y.view(*input.shape[:-1], N)
-    wq = weight if prequantized else ops.binarize(weight.detach()) * E
+    if codes is not None and codes.K == K and codes.rows * K == input.numel() and 127 * K < (1 << 24):
+        ok, flag = codes_route(codes, weight)
+        if ok:
+            wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
+            y = ops.i8_gemm(codes, wc, codes.inv_n, poison_bias(bias, flag, N, input.device), scale_dev=E)
+            return y.view(*input.shape[:-1], N)
+    wq = weight if prequantized else quantize_weight_f32(weight.detach(), "binary") * E
+    note_library_path(input, "DoReFa activation without usable int8 codes")
     return F.linear(input, wq, bias)
 
 
@@ -420,13 +525,16 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
         N_, C, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Kb = kh * kw * codes.codes.shape[1]
-        if codes.K == C and codes.rows == N_ * H * W and 127 * Kb < (1 << 24) and codes.usable():
+        ok, flag = codes_route(codes, weight) if (codes.K == C and codes.rows == N_ * H * W and 127 * Kb < (1 << 24)) else (False, None)
+        if ok:
             wc = weight_codes if weight_codes is not None else ops.pack_conv_weight_codes(weight.detach())
-            y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n, bias, stride, padding,
+            y2 = ops.conv2d_codes(codes, (N_, C, H, W), wc, (kh, kw), codes.inv_n,
+                                  poison_bias(bias, flag, int(weight.shape[0]), input.device), stride, padding,
                                   dilation, scale_dev=E)
             Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
             return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
-    wq = weight if prequantized else ops.binarize(weight.detach()) * E
+    wq = weight if prequantized else quantize_weight_f32(weight.detach(), "binary") * E
+    note_library_path(input, "DoReFa activation without usable int8 codes")
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
@@ -445,10 +553,13 @@ def dorefa_wk_linear_forward(input, weight_q, bias, bit_width: int, weight_codes
     codes = packed.lookup_codes(input, packed.ROWS_LAST) if input.dtype == torch.float32 else None
     K, N = input.shape[-1], weight_q.shape[0]
     n_w = (1 << int(bit_width)) - 1
-    if (codes is None or codes.K != K or codes.rows * K != input.numel() or 127 * n_w * K >= (1 << 31)
-            or not codes.usable()):
+    if codes is None or codes.K != K or codes.rows * K != input.numel() or 127 * n_w * K >= (1 << 31):
         return None
-    y = ops.i8_gemm(codes, weight_codes, codes.inv_n * _inv_levels(bit_width), bias, max_abs_code=127 * n_w)
+    ok, flag = codes_route(codes, weight_q)
+    if not ok:
+        return None
+    y = ops.i8_gemm(codes, weight_codes, codes.inv_n * _inv_levels(bit_width), poison_bias(bias, flag, N, input.device),
+                    max_abs_code=127 * n_w)
     return y.view(*input.shape[:-1], N)
 
 
@@ -466,9 +577,13 @@ def dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width: int, wei
     kh, kw = int(weight_q.shape[2]), int(weight_q.shape[3])
     Kb = kh * kw * codes.codes.shape[1]
     n_w = (1 << int(bit_width)) - 1
-    if codes.K != C or codes.rows != N_ * H * W or 127 * n_w * Kb >= (1 << 31) or not codes.usable():
+    if codes.K != C or codes.rows != N_ * H * W or 127 * n_w * Kb >= (1 << 31):
         return None
-    y2 = ops.conv2d_codes(codes, (N_, C, H, W), weight_codes, (kh, kw), codes.inv_n * _inv_levels(bit_width), bias,
+    ok, flag = codes_route(codes, weight_q)
+    if not ok:
+        return None
+    y2 = ops.conv2d_codes(codes, (N_, C, H, W), weight_codes, (kh, kw), codes.inv_n * _inv_levels(bit_width),
+                          poison_bias(bias, flag, int(weight_q.shape[0]), input.device),
                           stride, padding, dilation, max_abs_code=127 * n_w)
     Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
     return y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
@@ -491,7 +606,7 @@ class DorefaW1LinearFn(torch.autograd.Function):
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            wq = ops.binarize(weight) * weight.abs().mean()
+            wq = quantize_weight_f32(weight, "binary") * weight.abs().mean()
             grad_input = g2.mm(wq).view(input.shape)
         if ctx.needs_input_grad[1]:
             grad_weight = g2.t().mm(input.reshape(-1, input.shape[-1]))
@@ -516,7 +631,7 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
         go = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            wq = ops.binarize(weight) * weight.abs().mean()
+            wq = quantize_weight_f32(weight, "binary") * weight.abs().mean()
             grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
                                                     dilation=dilation, groups=groups)
         if ctx.needs_input_grad[1]:

@@ -16,6 +16,12 @@ def _is_dev(t):
     return t.is_cuda and t.dtype == torch.float32
 
 
+def _kernel_takes(fsr, bit_width, log):
+    """Parameter window of qt_log_quantize_f32 / qt_lin_quantize_f32 (csrc/elementwise.hip); configurations outside it
+    (e.g. a 32-bit Log quantiser) run the torch expression on the device, like the reference."""
+    return -60 <= fsr <= 60 and 1 <= bit_width <= (16 if log else 32)
+
+
 def _log_expr(x, fsr, bit_width, with_sign):
     p = torch.pow(torch.ones_like(x) * 2, torch.clamp(torch.round(torch.log2(torch.abs(x))), fsr - 2 ** bit_width, fsr))
     return torch.sign(x) * p if with_sign else p
@@ -37,7 +43,7 @@ def LogQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
     class _LogQuant(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input):
-            if _is_dev(input):
+            if _is_dev(input) and _kernel_takes(fsr, bit_width, True):
                 return ops.log_quantize(input, fsr, bit_width, with_sign)
             return _log_expr(input, fsr, bit_width, with_sign)
 
@@ -45,7 +51,7 @@ def LogQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
         def backward(ctx, grad_output):
             if lin_back:
                 return grad_output.clone()
-            if _is_dev(grad_output):
+            if _is_dev(grad_output) and _kernel_takes(fsr, bit_width, True):
                 return ops.log_quantize(grad_output, fsr, bit_width, True)
             return _log_expr(grad_output, fsr, bit_width, True)
 
@@ -61,7 +67,7 @@ def LinQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
         def forward(ctx, input):
             if bit_width == 32:
                 return input
-            if _is_dev(input):
+            if _is_dev(input) and _kernel_takes(fsr, bit_width, False):
                 return ops.lin_quantize(input, fsr, bit_width, 1 if with_sign else 0)
             return _lin_expr(input, fsr, bit_width, 1 if with_sign else 0)
 
@@ -69,7 +75,7 @@ def LinQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
         def backward(ctx, grad_output):
             if bit_width == 32 or lin_back:
                 return grad_output.clone()
-            if _is_dev(grad_output):
+            if _is_dev(grad_output) and _kernel_takes(fsr, bit_width, False):
                 return ops.lin_quantize(grad_output, fsr, bit_width, 2)
             return _lin_expr(grad_output, fsr, bit_width, 2)
 

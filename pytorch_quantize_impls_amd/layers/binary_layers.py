@@ -43,10 +43,15 @@ class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
     def _quantized_weight_for_eval(self):
         return self.bin_op.apply(self.weight)
 
+    def _weight_on_grid(self, w):
+        return (w.abs() == 1).all()
+
     def forward(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
-        if not input.is_cuda:
+        if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
+            # host tensors, and device models in half / bfloat16 / double: the reference expression in torch
+            _fused.note_library_path(input, "non-fp32 dtype")
             w = self.bin_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.linear(input, w, self.bias)
         if self.training:
@@ -63,16 +68,21 @@ def _eval_linear(layer, input, kind):
     if torch.is_grad_enabled() and (input.requires_grad or layer.weight.requires_grad):
         # autograd needed: this IS the reference expression (dense GEMM on the quantised image)
         return torch.nn.functional.linear(input, layer.weight, layer.bias)
+    if not layer._eval_on_grid():
+        # the weight was overwritten with something that is not a quantised image (e.g. a float checkpoint loaded
+        # after .eval()): upstream multiplies by whatever `weight` holds, so does this
+        _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
+        return torch.nn.functional.linear(input, layer.weight, layer.bias)
     K, N = input.shape[-1], layer.weight.shape[0]
     impl = _fused.ops.select_gemm_impl(_fused.GEMM_IMPL, input.numel() // max(K, 1), N, K)
-    xp = _fused.activation_planes(input, layer.binary_input, impl)
+    xp, flag = _fused.activation_planes(input, layer.binary_input, impl, layer.weight)
     if xp is None:
         if _fused.FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
             wt = layer._eval_planes(lambda w2: _fused.ops.weight_bf16x3(w2, kind), key="bf16x3")
             return _fused.ops.float_linear(input, layer.weight, kind, layer.bias, weight_triples=wt)
         return torch.nn.functional.linear(input, layer.weight, layer.bias)
     wp = layer._eval_planes(lambda w2: _fused.pack_weight(w2, kind, impl), key=impl)
-    y = _fused.ops.packed_gemm(xp, wp, layer.bias, impl=impl)
+    y = _fused.ops.packed_gemm(xp, wp, _fused.poison_bias(layer.bias, flag, N, input.device), impl=impl)
     return y.view(*input.shape[:-1], N)
 
 
@@ -104,6 +114,9 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def _quantized_weight_for_eval(self):
         return self.bin_op.apply(self.weight)
 
+    def _weight_on_grid(self, w):
+        return (w.abs() == 1).all()
+
     def _conv_triples(self, form):
         """Cached bf16 triple image of the eval-mode (already quantised) weight for real-valued inputs:
         'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the space-to-depth form."""
@@ -120,7 +133,8 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def forward(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
-        if not input.is_cuda:
+        if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
+            _fused.note_library_path(input, "non-fp32 dtype")
             w = self.bin_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
                                               self.dilation, self.groups)
@@ -131,6 +145,9 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                               self.binary_input, args)
         # eval: weight already holds the quantised image; its packed planes are cached
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
+        if not self._eval_on_grid():
+            _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
             return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
         wp = None
         if self.groups == 1 and self.padding_mode == "zeros":

@@ -27,11 +27,29 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
     def _quantized_weight_for_eval(self):
         return self.weight_op.forward(self.weight)
 
+    def _weight_on_grid(self, w):
+        k = int(self.bit_width)
+        if k == 1:                      # sign(W) * E: every magnitude equals the scale
+            return (w.abs() == w.abs().amax()).all()
+        if k >= 32:
+            return torch.ones((), dtype=torch.bool, device=w.device)
+        n = float((1 << k) - 1)         # levels (2 q - n) / n: n * w is an integer of the parity of n, |.| <= n
+        c = w * n
+        r = torch.round(c)
+        return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
+
     def forward(self, input):
         if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
             raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
                                "call .eval() first (k-bit weights: pass input.float())")
-        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
+        if isinstance(input, _CodeActivation) and not self._eval_on_grid():
+            raise RuntimeError("this eval-mode layer's weight no longer holds sign(W) * E (overwritten after .eval()?): "
+                               "code-plane inputs need the quantised image")
+        if (not isinstance(input, _CodeActivation) and input.is_cuda and not self.training and self.weight.dtype == torch.float32
+                and not self._eval_on_grid()):
+            _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
+            return torch.nn.functional.linear(input, self.weight, self.bias)
+        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32 and self.weight.dtype == torch.float32:
             # W1Ak: int8 matrix-core path when the activation carries DoReFa codes
             if self.training:
                 return _fused.DorefaW1LinearFn.apply(input, self.weight, self.bias)
@@ -40,7 +58,7 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
                 E = self._eval_planes(lambda w2: w2.abs().amax(), key="E")      # |w| == E everywhere after eval()
                 return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc, scale=E)
         if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
-                and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
+                and self.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             # WkAk inference: integer weight levels x activation codes on the int8 matrix cores
             wc = self._eval_planes(lambda w2: _fused.ops.dorefa_weight_codes(w2, self.bit_width), key="i8k")
             y = _fused.dorefa_wk_linear_forward(input, self.weight, self.bias, self.bit_width, wc)
@@ -71,12 +89,30 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def _quantized_weight_for_eval(self):
         return self.weight_op.forward(self.weight)
 
+    def _weight_on_grid(self, w):
+        k = int(self.bit_width)
+        if k == 1:                      # sign(W) * E: every magnitude equals the scale
+            return (w.abs() == w.abs().amax()).all()
+        if k >= 32:
+            return torch.ones((), dtype=torch.bool, device=w.device)
+        n = float((1 << k) - 1)         # levels (2 q - n) / n: n * w is an integer of the parity of n, |.| <= n
+        c = w * n
+        r = torch.round(c)
+        return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
+
     def forward(self, input):
         args = (self.stride, self.padding, self.dilation, self.groups)
         if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
             raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
                                "call .eval() first (k-bit weights: pass input.float())")
-        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32:
+        if isinstance(input, _CodeActivation) and not self._eval_on_grid():
+            raise RuntimeError("this eval-mode layer's weight no longer holds sign(W) * E (overwritten after .eval()?): "
+                               "code-plane inputs need the quantised image")
+        if (not isinstance(input, _CodeActivation) and input.is_cuda and not self.training and self.weight.dtype == torch.float32
+                and not self._eval_on_grid()):
+            _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
+            return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
+        if input.is_cuda and self.bit_width == 1 and input.dtype == torch.float32 and self.weight.dtype == torch.float32:
             if self.training:
                 return _fused.DorefaW1Conv2dFn.apply(input, self.weight, self.bias, args)
             if not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)):
@@ -88,7 +124,7 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                 return _fused.dorefa_w1_conv_forward(input, self.weight, self.bias, args, True, wc,
                                                      self.padding_mode, scale=E)
         if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
-                and self.groups == 1 and self.padding_mode == "zeros"
+                and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             wc = self._eval_planes(
                 lambda _w2: _fused.ops.pack_conv_weight_dorefa_codes(self.weight.detach(), self.bit_width), key="conv_i8k")

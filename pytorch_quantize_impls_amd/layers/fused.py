@@ -32,6 +32,24 @@ def fold_batchnorm(bn):
     return alpha.float().contiguous(), beta.float().contiguous()
 
 
+def _bn_key(bn):
+    """Identity of a BatchNorm's parameters / statistics: (storage, version counter) of each tensor — load_state_dict(),
+    copy_() and .to(device) change it, so a folded (alpha, beta) cached under it is never stale.  (Writes through
+    ``.data`` do not bump version counters: call refold() after those.)"""
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+
+def _folded_for(owner, attr, bn, device=None):
+    """fold_batchnorm(bn), cached on ``owner`` under ``attr`` for the current _bn_key."""
+    key = _bn_key(bn)
+    cur = getattr(owner, attr, None)
+    if cur is None or cur[0] != key or (device is not None and cur[1][0].device != device):
+        cur = (key, fold_batchnorm(bn))
+        setattr(owner, attr, cur)
+    return cur[1]
+
+
 class FusedPoolBnSign(torch.nn.Module):
     """[MaxPool2d(k, s)] + eval BatchNorm + [Hardtanh] + BinaryConnect(deterministic) -> PackedActivation."""
 
@@ -60,9 +78,8 @@ class FusedPoolBnSign(torch.nn.Module):
             raise RuntimeError("FusedPoolBnSign is an inference module: call .eval() first")
         if not x.is_cuda:
             raise TypeError("FusedPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
-        if self._folded is None or self._folded[0].device != x.device:
-            self._folded = fold_batchnorm(self.bn)
-        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, self._folded[0], self._folded[1], self.pool_k, self.pool_s,
+        alpha, beta = _folded_for(self, "_folded", self.bn, x.device)
+        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, alpha, beta, self.pool_k, self.pool_s,
                                                      pre_relu=self.pre_relu)
         if x.dim() == 2:
             return packed.PackedActivation(planes, (x.shape[0], x.shape[1]))
@@ -104,9 +121,7 @@ class FusedBnDorefaQuant(torch.nn.Module):
     def forward(self, x, residual=None, residual_bn=None):
         if self.bn.training:
             raise RuntimeError("FusedBnDorefaQuant folds running statistics: call .eval() first")
-        if self._folded is None:
-            self._folded = fold_batchnorm(self.bn)
-        alpha, beta = self._folded
+        alpha, beta = _folded_for(self, "_folded", self.bn)
         if x.dim() == 4:
             N, C, H, W = x.shape
             x2 = x.permute(0, 2, 3, 1)
@@ -130,9 +145,7 @@ class FusedBnDorefaQuant(torch.nn.Module):
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(x2.shape)
             if residual_bn is not None:
-                if self._folded_res is None:
-                    self._folded_res = fold_batchnorm(residual_bn)
-                res_affine = self._folded_res
+                res_affine = _folded_for(self, "_folded_res", residual_bn)
         codes, _ = ops.affine_dorefa_codes(x2, alpha, beta, self.bit_width, self.relu, res_f32, res_affine, res_codes,
                                            overflow=flag,
                                            ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None)
@@ -173,18 +186,15 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
             raise RuntimeError("FusedDorefaConvBnQuant is an inference form: call .eval() first")
         if not isinstance(act, packed.CodeActivation):
             raise TypeError("FusedDorefaConvBnQuant consumes a CodeActivation (FusedBnDorefaQuant output)")
-        if self._folded is None:
-            self._folded = fold_batchnorm(self.bn)
-        epi = ops.CodeEpilogue(self._folded[0], self._folded[1], self.bit_width, self.relu, out_halo=self.out_halo)
+        alpha, beta = _folded_for(self, "_folded", self.bn)
+        epi = ops.CodeEpilogue(alpha, beta, self.bit_width, self.relu, out_halo=self.out_halo)
         if isinstance(residual, packed.CodeActivation):
             epi.res_codes, epi.res_halo = residual.codes, residual.halo
         elif residual is not None:
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
             if residual_bn is not None:
-                if self._folded_res is None:
-                    self._folded_res = fold_batchnorm(residual_bn)
-                epi.res_affine = self._folded_res
+                epi.res_affine = _folded_for(self, "_folded_res", residual_bn)
         from ..functions import _fused
         wc = conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(conv.weight.detach()), key="conv_i8")
         E = conv._eval_planes(lambda w2: w2.abs().amax(), key="E")
@@ -267,11 +277,11 @@ class FusedConvPoolBnSign(torch.nn.Module):
             raise RuntimeError("FusedConvPoolBnSign is an inference module: call .eval() first")
         conv, fp = self.conv, self._pool
         dev = conv.weight.device
-        if fp._folded is None or fp._folded[0].device != dev or self._neg_alpha is None:
-            fp._folded = fold_batchnorm(self.bn)
-            self._neg_alpha = ops.neg_alpha_words(fp._folded[0])
+        prev = fp._folded
+        epi = _folded_for(fp, "_folded", self.bn, dev)
+        if fp._folded is not prev or self._neg_alpha is None:      # BatchNorm changed (or first call): derived data too
+            self._neg_alpha = ops.neg_alpha_words(epi[0])
             self._thr = None
-        epi = fp._folded
         pooled = fp.pool_k != 1 or fp.pool_s != 1
         nib_out = self.out_nib_halo is not None and not self.flatten_hwc
         if isinstance(x, packed.PackedActivation):
@@ -428,7 +438,7 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_po
                     out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None
                                else FusedPoolBnSign(bn, pool, pre_relu=pre_relu))
                     i = j2 + 1
-                    if packed_pool and i < len(mods) and isinstance(mods[i], torch.nn.MaxPool2d) and bn.weight.dim() == 1 \
+                    if packed_pool and i < len(mods) and isinstance(mods[i], torch.nn.MaxPool2d) and (not bn.affine or bn.weight.dim() == 1) \
                             and isinstance(bn, torch.nn.BatchNorm2d):
                         try:
                             out.append(PackedMaxPool(mods[i]))
@@ -500,6 +510,13 @@ class FusedFeatureClassifier(torch.nn.Module):
         fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))      # already the quantised image
         self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[1:]))
         self.eval()
+
+    def train(self, mode: bool = True):
+        # an inference form: its first classifier layer is a permuted COPY of an eval-mode (already quantised) weight,
+        # so there is no real-valued weight to go back to
+        if mode:
+            raise RuntimeError("FusedFeatureClassifier is an inference module: train the modules it was built from")
+        return super().train(False)
 
     @property
     def last(self):

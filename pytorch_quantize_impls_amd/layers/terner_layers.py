@@ -43,10 +43,14 @@ class LinearTer(EvalSwapMixin, torch.nn.Linear, QLayer):
     def _quantized_weight_for_eval(self):
         return self.ter_op.apply(self.weight)
 
+    def _weight_on_grid(self, w):
+        return ((w == 0) | (w.abs() == 1)).all()
+
     def forward(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
-        if not input.is_cuda:
+        if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
+            _fused.note_library_path(input, "non-fp32 dtype")
             w = self.ter_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.linear(input, w, self.bias)
         if self.training:
@@ -82,6 +86,9 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def _quantized_weight_for_eval(self):
         return self.ter_op.apply(self.weight)
 
+    def _weight_on_grid(self, w):
+        return ((w == 0) | (w.abs() == 1)).all()
+
     def _conv_triples(self, form):
         """Cached bf16 triple image of the eval-mode (already quantised) weight for real-valued inputs:
         'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the space-to-depth form."""
@@ -98,7 +105,8 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def forward(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
-        if not input.is_cuda:
+        if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
+            _fused.note_library_path(input, "non-fp32 dtype")
             w = self.ter_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
                                               self.dilation, self.groups)
@@ -109,6 +117,9 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                               self.binary_input, args)
         # eval: weight already holds the quantised image; its packed planes are cached
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
+        if not self._eval_on_grid():
+            _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
             return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
         wp = None
         if self.groups == 1 and self.padding_mode == "zeros":

@@ -195,7 +195,10 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         return BitPlanes(sign=plane, rows=M, K=Cout)
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     with _on(dev):
-        _lib.call("qt_conv2d_implicit", *head, _p(y), I(Cout), I(Cout), _stream(dev))
+        if CONV_VARIANT:
+            _lib.call("qt_conv2d_implicit_variant", int(CONV_VARIANT), *head, _p(y), I(Cout), I(Cout), _stream(dev))
+        else:
+            _lib.call("qt_conv2d_implicit", *head, _p(y), I(Cout), I(Cout), _stream(dev))
     return y
 
 
@@ -504,6 +507,12 @@ def _check_bias(bias, N, device):
     return bias
 
 
+#: kernel variants handed to the library as ARGUMENTS (tests / tuning; 0 = automatic): popcount GEMM 1 = tiled, 2 = skinny;
+#: plain implicit conv 1 = double-buffered, 2 = ping-pong, 4 = no un-padded fast path
+POPC_VARIANT = 0
+CONV_VARIANT = 0
+
+
 def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) for +-1 operands given as sign planes."""
@@ -517,9 +526,12 @@ def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
     with _on(dev):
-        _lib.call("qt_xnor_gemm", _p(x.sign), int(x.ld), _p(w.sign), int(w.ld),
-                  _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)),
-                  int(M), int(N), int(K), _stream(dev))
+        args = (_p(x.sign), int(x.ld), _p(w.sign), int(w.ld), _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)),
+                int(M), int(N), int(K), _stream(dev))
+        if POPC_VARIANT:
+            _lib.call("qt_xnor_gemm_variant", int(POPC_VARIANT), *args)
+        else:
+            _lib.call("qt_xnor_gemm", *args)
     return out
 
 
@@ -536,10 +548,12 @@ def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
     with _on(dev):
-        _lib.call("qt_tern_gemm", _p(x.sign), int(x.ld), _p(w.mask), _p(w.sign),
-                  int(w.ld), _p(bias), _p(out),
-                  int(out.stride(0) if M > 1 else max(N, 1)),
-                  int(M), int(N), int(K), _stream(dev))
+        args = (_p(x.sign), int(x.ld), _p(w.mask), _p(w.sign), int(w.ld), _p(bias), _p(out),
+                int(out.stride(0) if M > 1 else max(N, 1)), int(M), int(N), int(K), _stream(dev))
+        if POPC_VARIANT:
+            _lib.call("qt_tern_gemm_variant", int(POPC_VARIANT), *args)
+        else:
+            _lib.call("qt_tern_gemm", *args)
     return out
 
 

@@ -26,13 +26,16 @@ NHWC = "nhwc"            # planes pack the channel dimension of an [N,C,H,W] ten
 
 
 def attach(t: torch.Tensor, planes: BitPlanes, layout: str) -> torch.Tensor:
-    setattr(t, _ATTR, (planes, layout, t._version, tuple(t.shape)))
+    # tensors created under torch.inference_mode() track no version counter, so a tag on them could not be
+    # invalidated: leave them un-tagged (the next layer then checks / packs the fp32 values itself)
+    if not t.is_inference():
+        setattr(t, _ATTR, (planes, layout, t._version, tuple(t.shape)))
     return t
 
 
 def lookup(t: torch.Tensor, layout: str) -> Optional[BitPlanes]:
     tag = getattr(t, _ATTR, None)
-    if tag is None:
+    if tag is None or t.is_inference():
         return None
     planes, lay, version, shape = tag
     if lay != layout or version != t._version or shape != tuple(t.shape):
@@ -42,13 +45,14 @@ def lookup(t: torch.Tensor, layout: str) -> Optional[BitPlanes]:
 
 def attach_codes(t: torch.Tensor, codes, layout: str) -> torch.Tensor:
     """Same side channel for DoReFa activation codes (ops.CodePlanes) produced by nnDorefaQuant."""
-    setattr(t, _ATTR_CODES, (codes, layout, t._version, tuple(t.shape)))
+    if not t.is_inference():
+        setattr(t, _ATTR_CODES, (codes, layout, t._version, tuple(t.shape)))
     return t
 
 
 def lookup_codes(t: torch.Tensor, layout: str):
     tag = getattr(t, _ATTR_CODES, None)
-    if tag is None:
+    if tag is None or t.is_inference():
         return None
     codes, lay, version, shape = tag
     if lay != layout or version != t._version or shape != tuple(t.shape):

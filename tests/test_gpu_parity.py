@@ -169,11 +169,11 @@ GEMM_SHAPES = [(1, 1, 1), (5, 7, 31), (5, 7, 32), (5, 7, 33), (128, 128, 512), (
 
 @pytest.fixture(params=[0, 1, 2], ids=["auto", "tiled", "skinny"])
 def popc_kernel(request):
-    """Run a popcount-GEMM test under the automatic choice and with each kernel forced."""
-    import ctypes
-    _lib.load().qt_popc_force_kernel(ctypes.c_int(request.param))
+    """Run a popcount-GEMM test under the automatic choice and with each kernel chosen (an argument of the
+    qt_*_gemm_variant entry points; the library keeps no state)."""
+    ops.POPC_VARIANT = request.param
     yield request.param
-    _lib.load().qt_popc_force_kernel(ctypes.c_int(0))
+    ops.POPC_VARIANT = 0
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(64, 4096, 4096), (1, 1000, 9216), (256, 10, 4096), (70, 33, 10000)])
@@ -182,7 +182,7 @@ def test_xnor_gemm_vs_oracle(dev, oracle, popc_kernel, M, N, K, with_bias):
     x = synth.pm1(M * 7 + K, (M, K))
     w = synth.uniform(N * 5 + K, (N, K), -1, 1)
     b = synth.normal(N, (N,)) if with_bias else None
-    with used("qt_sign_pack_f32", "qt_xnor_gemm"):
+    with used("qt_sign_pack_f32", "qt_xnor_gemm_variant" if popc_kernel else "qt_xnor_gemm"):
         xp, wp = ops.sign_pack(g(x, dev))[0], ops.sign_pack(g(w, dev))[0]
         y = n(ops.xnor_gemm(xp, wp, None if b is None else g(b, dev)))
     want_int = oracle.linear(x, oracle.safe_sign(w))          # the reference computation, fp32
@@ -199,7 +199,7 @@ def test_xnor_gemm_vs_oracle(dev, oracle, popc_kernel, M, N, K, with_bias):
 def test_tern_gemm_vs_oracle(dev, oracle, popc_kernel, M, N, K):
     x = synth.pm1(M * 3 + K, (M, K))
     w = synth.uniform(N * 9 + K, (N, K), -1.5, 1.5)
-    with used("qt_ternary_pack_f32", "qt_tern_gemm"):
+    with used("qt_ternary_pack_f32", "qt_tern_gemm_variant" if popc_kernel else "qt_tern_gemm"):
         y = n(ops.tern_gemm(ops.sign_pack(g(x, dev))[0], ops.ternary_pack(g(w, dev))))
     assert same(y, oracle.linear(x, oracle.ternarize(w)))
 
@@ -914,9 +914,9 @@ def test_fused_alexnet_conv_bits_equals_fp32_fusion(dev):
 
 @pytest.mark.gpu
 def test_conv_ping_pong_kernels_equal_double_buffered(dev):
-    """qt_conv_force_kernel(2): the ping-pong main loop (ring of 4 64-byte stages, wrapped W pieces for the
-    192- and 64-wide tiles) must reproduce the default conv kernels bit for bit, all four tile widths."""
-    import ctypes
+    """qt_conv2d_implicit_variant(2): the ping-pong main loop (ring of 4 64-byte stages, wrapped W pieces for the
+    192- and 64-wide tiles) must reproduce the double-buffered conv kernels (variant 1) and the automatic choice bit for
+    bit, all four tile widths."""
     from pytorch_quantize_impls_amd.layers import BinConv2d
     try:
         for (Cin, Cout, k, st, pd, H) in [(64, 256, 3, 1, 1, 13), (96, 192, 5, 1, 2, 14), (32, 128, 3, 2, 1, 17), (64, 40, 1, 1, 0, 9),
@@ -925,13 +925,13 @@ def test_conv_ping_pong_kernels_equal_double_buffered(dev):
             x = g(synth.pm1(Cin + H, (3, Cin, H, H)) if Cin > 3 else synth.normal(7, (3, Cin, H, H)), dev)
             x = x.contiguous(memory_format=torch.channels_last)
             outs = []
-            for which in (1, 2):
-                _lib.call("qt_conv_force_kernel", ctypes.c_int(which))
-                with torch.no_grad(), used("qt_conv2d_implicit"):
+            for which in (0, 1, 2, 4):
+                ops.CONV_VARIANT = which
+                with torch.no_grad(), used("qt_conv2d_implicit_variant" if which else "qt_conv2d_implicit"):
                     outs.append(conv(x).clone())
-            assert torch.equal(outs[0], outs[1]), (Cin, Cout, k)
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (Cin, Cout, k)
     finally:
-        _lib.call("qt_conv_force_kernel", ctypes.c_int(0))
+        ops.CONV_VARIANT = 0
 
 
 @pytest.mark.gpu

@@ -523,3 +523,167 @@ def test_linear_fused_reference_digest(dev, golden_hashes, case):
     b = g(synth.normal(3, (N,)), dev)
     xp, wp = ops.pack_linear_operands(x, w, kind, "mfma")
     assert torch.equal(ops.linear_fused(x, w, b, kind), ops.packed_gemm(xp, wp, b, impl="mfma"))
+
+
+# ---- boundary / host-logic hardening ----------------------------------------------------
+
+def test_inference_mode_binary_and_dorefa_chains(dev):
+    """torch.inference_mode() tensors carry no version counter: the quantisers must not tag them (and not crash); the next
+    layer then re-derives the planes from the fp32 values — same numbers as under no_grad."""
+    from pytorch_quantize_impls_amd.functions import BinaryConnect, nnDorefaQuant
+    from pytorch_quantize_impls_amd.layers import LinearDorefa
+    torch.manual_seed(11)
+    x = torch.randn(64, 256, device=dev)
+    lin = LinearBin(256, 96).to(dev).eval()
+    dlin = LinearDorefa(256, 40, bit_width=1).to(dev).eval()
+    bc, dq = BinaryConnect(), nnDorefaQuant(4)
+    with torch.no_grad():
+        want_b = lin(bc(x))
+        want_d = dlin(dq(torch.relu(x) * 0.3))
+    with torch.inference_mode():
+        got_b = lin(bc(x))
+        got_d = dlin(dq(torch.relu(x) * 0.3))
+    assert torch.equal(got_b, want_b)
+    assert norm_err(n(got_d), n(want_d)) <= TOL
+
+
+def test_eval_weight_off_grid_follows_the_reference(dev):
+    """The reference's eval forward multiplies by whatever `weight` holds (binary_layers.py:46).  After
+    model.eval(); load_state_dict(float checkpoint) the device layers must do the same instead of re-quantising."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    from pytorch_quantize_impls_amd.layers import LinearDorefa, DorefaConv2d
+    torch.manual_seed(12)
+    x = torch.where(torch.rand(32, 128, device=dev) < 0.5, -1.0, 1.0)
+    xc = torch.randn(2, 16, 9, 9, device=dev)
+    for mk, xin in ((lambda: LinearBin(128, 24), x), (lambda: LinearTer(128, 24), x), (lambda: LinearDorefa(128, 24, bit_width=1), x),
+                    (lambda: LinearDorefa(128, 24, bit_width=3), x), (lambda: BinConv2d(16, 8, 3, padding=1), xc),
+                    (lambda: TerConv2d(16, 8, 3, padding=1), xc), (lambda: DorefaConv2d(16, 8, 3, padding=1, bit_width=1), xc)):
+        layer = mk().to(dev).eval()
+        with torch.no_grad():
+            y_grid = layer(xin)                                     # on-grid eval weight: packed / int8 / bf16 paths
+        ckpt = {k: torch.randn_like(v) * 0.7 for k, v in layer.state_dict().items()}
+        layer.load_state_dict(ckpt)                                 # float weights while in eval mode
+        before = sum(_fused.LIBRARY_PATHS.values())
+        with torch.no_grad():
+            y = layer(xin)
+            fn = torch.nn.functional.linear if xin.dim() == 2 else (lambda a, w, b: torch.nn.functional.conv2d(a, w, b, padding=1))
+            want = fn(xin, layer.weight, layer.bias)
+        assert torch.equal(y, want), type(layer).__name__
+        assert not torch.equal(y, y_grid)
+        assert sum(_fused.LIBRARY_PATHS.values()) == before + 1     # ... and the detour is counted, not silent
+
+
+def test_half_precision_models_take_the_torch_expression(dev):
+    """A device model in half precision is outside the fp32 kernels: forward and backward run the reference expression in
+    torch (no TypeError), and the detour is counted."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    lin = LinearBin(64, 16).to(dev).half()
+    x = torch.randn(8, 64, device=dev, dtype=torch.float16, requires_grad=True)
+    before = sum(_fused.LIBRARY_PATHS.values())
+    y = lin(x)
+    y.float().sum().backward()
+    assert y.dtype == torch.float16 and lin.weight.grad is not None and x.grad is not None
+    assert sum(_fused.LIBRARY_PATHS.values()) > before
+
+
+def test_steady_state_forwards_do_not_synchronise(dev):
+    """Content-dependent routing: a "not +-1" / "codes overflow" answer is remembered in every mode, so the un-fused eval
+    forward of AlexNet-Bin (real-valued conv1, every other activation tagged by BinaryConnect) enqueues without a single
+    host synchronisation by default (torch's sync debug mode raises on any); with DETECT_MODE = "remember" so do a
+    pool-after-sign ternary stack (un-tagged +-1 inputs) and the module-by-module DoReFa ResNet-18 (code range flags)."""
+    import bench_models
+    from pytorch_quantize_impls_amd.functions import _fused
+    torch.manual_seed(13)
+    alex = bench_models.AlexNetBin()
+    bench_models.randomize_bn(alex)
+    alex = alex.to(dev).to(memory_format=torch.channels_last).eval()
+    vgg = bench_models.TernaryVGG16(num_classes=10, image=32, fc=128)
+    bench_models.randomize_bn(vgg, seed=2)
+    vgg = vgg.to(dev).to(memory_format=torch.channels_last).eval()
+    res = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(res, seed=3)
+    res = res.to(dev).to(memory_format=torch.channels_last).eval()
+    xa = torch.randn(8, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    xv = torch.randn(8, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        first = alex(xa)                                         # first forward: conv1 asks once (a host sync)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            assert torch.equal(alex(xa), first)                  # default mode: nothing synchronises any more
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        _fused.DETECT_MODE = "remember"
+        try:
+            outs = [vgg(xv), res(xv)]                            # verdicts are asked (host syncs allowed)
+            torch.cuda.synchronize()
+            stats = dict(_fused.DETECT_STATS)
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                again = [vgg(xv), res(xv)]
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        finally:
+            _fused.DETECT_MODE = "verify"
+    assert _fused.DETECT_STATS["sync"] == stats.get("sync", 0)       # nothing was asked again
+    assert _fused.DETECT_STATS["cached"] > stats.get("cached", 0)    # ... the remembered verdicts were used
+    for a, b in zip(outs, again):
+        assert torch.equal(a, b)
+
+
+def test_broken_pm1_assumption_poisons_instead_of_lying(dev):
+    """DETECT_MODE = "remember": verdict "+-1" remembered, then a real-valued tensor arrives un-tagged: the packed route's
+    result must be NaN (the device flag rides in through the bias), never a plausible wrong number; reset_detection()
+    re-asks and recovers.  In the default mode the same sequence is simply correct (a sync per call)."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    lin = LinearBin(256, 32).to(dev).eval()
+    xpm = torch.where(torch.rand(16, 256, device=dev) < 0.5, -1.0, 1.0)
+    xre = torch.randn(16, 256, device=dev)
+    with torch.no_grad():
+        want = torch.nn.functional.linear(xre, lin.weight, lin.bias)
+        lin(xpm)
+        assert norm_err(n(lin(xre)), n(want)) <= TOL           # default mode: re-verified, general route taken
+        _fused.reset_detection(lin.weight)
+    _fused.DETECT_MODE = "remember"
+    try:
+        _remember_mode_poison_body(lin, xpm, xre, _fused)
+    finally:
+        _fused.DETECT_MODE = "verify"
+
+
+def _remember_mode_poison_body(lin, xpm, xre, _fused):
+    with torch.no_grad():
+        y0 = lin(xpm)                       # asks, remembers "+-1"
+        y1 = lin(xpm.clone())               # cached verdict + device flag (clean)
+        assert torch.equal(y0, y1) and not torch.isnan(y1).any()
+        bad = lin(xre)
+        assert torch.isnan(bad).all()
+        _fused.reset_detection(lin.weight)
+        good = lin(xre)
+        assert norm_err(n(good), n(torch.nn.functional.linear(xre, lin.weight, lin.bias))) <= TOL
+
+
+def test_fused_blocks_refold_after_load_state_dict(dev):
+    """The folded BatchNorm of a fused block is keyed on the BatchNorm tensors' version counters: load_state_dict() after
+    the first forward must change the output like a freshly built block."""
+    conv = BinConv2d(32, 40, 3, padding=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(40).to(dev).eval()
+    blk = FusedConvPoolBnSign(conv, bn)
+    x = torch.where(torch.rand(2, 32, 10, 10, device=dev) < 0.5, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        a0 = blk(x).planes.sign.clone()
+        sd = {k: (torch.randn_like(v) if v.dtype.is_floating_point else v) for k, v in bn.state_dict().items()}
+        sd["running_var"] = sd["running_var"].abs() + 0.5
+        bn.load_state_dict(sd)
+        a1 = blk(x).planes.sign
+        fresh = FusedConvPoolBnSign(conv, bn)(x).planes.sign
+    assert torch.equal(a1, fresh) and not torch.equal(a1, a0)
+
+
+def test_log_quantiser_outside_the_kernel_window(dev):
+    """A 32-level-bit Log quantiser is outside qt_log_quantize_f32's parameter window: the torch expression runs on the
+    device (as the reference would) instead of raising."""
+    from pytorch_quantize_impls_amd.functions.log_lin_connect import LogQuant
+    x = torch.randn(100, device=dev)
+    y = LogQuant(fsr=3, bit_width=20).apply(x)
+    assert torch.equal(y, LogQuant(fsr=3, bit_width=20).apply(x.cpu()).to(dev))

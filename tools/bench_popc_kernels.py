@@ -12,7 +12,7 @@ for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (128, 409
     xp, wp = ops.sign_pack(x)[0], ops.sign_pack(w)[0]
     out = {}
     for which, name in ((1, "tiled"), (2, "skinny")):
-        lib.qt_popc_force_kernel(ctypes.c_int(which))
+        ops.POPC_VARIANT = which
         y = ops.xnor_gemm(xp, wp)
         for _ in range(3): ops.xnor_gemm(xp, wp, out=y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,5 +20,5 @@ for (M, N, K) in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 4096), (128, 409
         for _ in range(20):
             e0.record(); ops.xnor_gemm(xp, wp, out=y); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
         ts.sort(); out[name] = (ts[10], y.clone())
-    lib.qt_popc_force_kernel(ctypes.c_int(0))
+    ops.POPC_VARIANT = 0
     print(f"M={M:5d} N={N:5d} K={K:6d}  tiled {out['tiled'][0]:8.1f} us  skinny {out['skinny'][0]:8.1f} us  equal={torch.equal(out['tiled'][1], out['skinny'][1])}")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Cycle / wall-clock stamps of the ping-pong GEMM (variant 165, profiling only; Y is garbage)."""
+"""Cycle / wall-clock stamps of the ping-pong GEMM (variant 165: needs a library built with -DQT_PROFILING_VARIANTS,
+selected through QT_HIP_LIB; Y is garbage)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np

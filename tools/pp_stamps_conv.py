@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Cycle / wall-clock stamps of the 384x192 ping-pong conv kernel (qt_conv_force_kernel(3), profiling only) on an
+"""Cycle / wall-clock stamps of the 384x192 ping-pong conv kernel (qt_conv2d_implicit_variant 3: a -DQT_PROFILING_VARIANTS build of the library, QT_HIP_LIB=...) on an
 AlexNet conv2-shaped problem: x [256, 192, 27, 27] +-1, W [576, 192, 5, 5], padding 2."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -26,7 +26,7 @@ if CONV1:
     OUT_GRID = (192, 55)       # Cout, Ho for the decode below
     STAGES = (9 * 288 + 63) // 64
 for which in (1, 0):
-    _lib.call("qt_conv_force_kernel", ctypes.c_int(which))
+    ops.CONV_VARIANT = which
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
@@ -36,7 +36,7 @@ for which in (1, 0):
 xpad = torch.nn.functional.pad(x, (pad, pad, pad, pad)).contiguous(memory_format=torch.channels_last)   # zeros are not +-1:
 px2 = ops.pack_pixels_nib(torch.where(xpad == 0, torch.ones_like(xpad), xpad))                           # timing only
 for which in (1, 0):
-    _lib.call("qt_conv_force_kernel", ctypes.c_int(which))
+    ops.CONV_VARIANT = which
     f = lambda: ops.conv2d_nib(px2, (N, C, H + 2 * pad, H + 2 * pad), wp, (k, k), None, 1, 0, 1)
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,7 +45,7 @@ for which in (1, 0):
         e0.record(); f(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     print(f"physically padded plane, conv padding 0, force {which}: median {sorted(ts)[5]:.1f} us")
 STAGES = globals().get("STAGES", 192 * 25 // 2 // 64)
-_lib.call("qt_conv_force_kernel", ctypes.c_int(3))
+ops.CONV_VARIANT = 3
 PADDED = len(sys.argv) > 1 and sys.argv[1] == "padded"
 if PADDED:
     run = lambda: ops.conv2d_nib(px2, (N, C, H + 2 * pad, H + 2 * pad), wp, (k, k), None, 1, 0, 1)
@@ -53,7 +53,7 @@ if PADDED:
 for _ in range(2):
     y = run()
 torch.cuda.synchronize()
-_lib.call("qt_conv_force_kernel", ctypes.c_int(0))
+ops.CONV_VARIANT = 0
 if CONV1:
     Cout, H = OUT_GRID
 M = N * H * H

@@ -6,10 +6,9 @@ import torch
 import bench_models
 dev = torch.device("cuda:0")
 if os.environ.get("CONV_FORCE"):
-    import ctypes
-    from pytorch_quantize_impls_amd import _lib
-    for v in os.environ["CONV_FORCE"].split(","):
-        _lib.call("qt_conv_force_kernel", ctypes.c_int(int(v)))
+    from pytorch_quantize_impls_amd import ops
+    for v in os.environ["CONV_FORCE"].split(","):     # plain-conv variant (an argument of qt_conv2d_implicit_variant)
+        ops.CONV_VARIANT = int(v)
 torch.manual_seed(0)
 model = bench_models.AlexNetBin(); bench_models.randomize_bn(model)
 model = model.to(dev).to(memory_format=torch.channels_last).eval()
