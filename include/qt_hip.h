@@ -113,6 +113,15 @@ int qt_log_quantize_f32(const float* x, float* y, int64_t n, int fsr, int bit_wi
 /* AP2 of the shift-based batch norm (functions/binary_connect.py:157-169): safeSign(x) * 2^round(log2|x|). */
 int qt_ap2_f32(const float* x, float* y, int64_t n, qt_stream_t stream);
 
+/* Shift-based batch-norm primitive, ShiftBatch.forward (functions/binary_connect.py:173-186; layers ShiftNormBatch1d / 2d,
+ * layers/binary_layers.py:110-160): y = ((x - mean) * AP2(1 / sqrt(var + eps))) * AP2(weight) + bias over x[N, E] with E-entry
+ * statistics / affine vectors broadcast over N (each product / sum rounded separately, as the torch expression).
+ * norm (optional, [N, ldn]) = (x - mean) * AP2(1 / sqrt(var + eps)) and sqrtvar (optional, [E]) are what the reference saves
+ * for its backward (:188-204). */
+int qt_shift_batch_f32(const float* x, int64_t ldx, const float* running_mean, const float* running_var, const float* weight,
+                       const float* bias, float eps, float* y, int64_t ldy, float* norm, int64_t ldn, float* sqrtvar, int64_t N,
+                       int64_t E, qt_stream_t stream);
+
 /* XNOR-Net weight quantiser over a row-major [R, C] view of the weight:
  * alpha[c] = mean_r |w[r,c]| ;  wq[r,c] = sign(w[r,c]) * alpha[c]  (torch.sign: 0 -> 0).  wq may be NULL
  * (alpha only).  XNORDense: R = N, C = K (functions/xnor_connect.py:112-113, global DIM = 0);

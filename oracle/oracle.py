@@ -336,6 +336,16 @@ def xnor_conv_weight(weight, dim=(0, 1)):
     return np.sign(w).astype(np.float32) * mean
 
 
+def shift_batch(x, mean, var, weight, bias, eps):
+    """ShiftBatch.forward (functions/binary_connect.py:177-183): ((x - mean) * AP2(1 / sqrt(var + eps))) * AP2(weight)
+    + bias in fp32 steps (the statistics broadcast over the leading dimension)."""
+    x = np.asarray(x, dtype=np.float32)
+    sv = np.sqrt((np.asarray(var, np.float32) + np.float32(eps)).astype(np.float32)).astype(np.float32)
+    a = ap2((np.float32(1) / sv).astype(np.float32))
+    norm = ((x - np.asarray(mean, np.float32)).astype(np.float32) * a).astype(np.float32)
+    return ((norm * ap2(np.asarray(weight, np.float32))).astype(np.float32) + np.asarray(bias, np.float32)).astype(np.float32), norm
+
+
 def xnor_act(x, dim):
     """_quantOpXnor forward (functions/xnor_connect.py:17-28): sign(x) * mean(x, dim) with np.sign == torch.sign
     (0 -> 0) and the SIGNED mean the reference computes; the mean is accumulated in double (the float tail

@@ -45,6 +45,8 @@ SIGNATURES = {
     "qt_ste_mask_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f32, _c_p]),
     "qt_dorefa_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     "qt_xnor_weight_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_shift_batch_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64,
+                                    _c_i64, _c_p]),
     "qt_xnor_act_work_floats": (_c_i64, []),
     "qt_xnor_act_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_xnor_act_backward_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int,

@@ -430,6 +430,9 @@ class QuantConv2dFn(torch.autograd.Function):
         ctx.kind, ctx.conv_args, ctx.has_bias = kind, conv_args, bias is not None
         ctx.save_for_backward(input, weight, weight_q)
         stride, padding, dilation, groups = conv_args
+        # +-1 activation known without a device check (tag of a quantiser, or the layer's binary_input hint)?
+        ctx.x_is_pm1 = bool(binary_input) or (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                                              and packed.lookup(input, packed.NHWC) is not None)
         return quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind,
                                     weight_q=weight_q, binary_input=binary_input)
 
@@ -440,13 +443,24 @@ class QuantConv2dFn(torch.autograd.Function):
         stride, padding, dilation, groups = ctx.conv_args
         grad_input = grad_weight = grad_bias = None
         go = grad_output.contiguous()
+        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
             wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
-            grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
-                                                    dilation=dilation, groups=groups)
+            if mfma:     # real gradient x +-1 / 0 weight: the forward's exact-split conv on flipped weights
+                grad_input = ops.conv2d_grad_input_q(input.shape, wq, go, stride, padding, dilation)
+            if grad_input is None:
+                note_library_path(go, "conv grad_input outside the matrix-core route")
+                grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
+                                                        dilation=dilation, groups=groups)
         if ctx.needs_input_grad[1]:
-            gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
-                                             dilation=dilation, groups=groups)
+            gw = None
+            if mfma and ctx.x_is_pm1:     # +-1 activation x real gradient, contraction over the pixels
+                gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
+            if gw is None:
+                note_library_path(go, "conv grad_weight outside the matrix-core route")
+                gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
+                                                 dilation=dilation, groups=groups)
             grad_weight = ste_mask(gw.contiguous(), weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = go.sum((0, 2, 3))
@@ -647,6 +661,10 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
 #: +-1/0 operand is exact in bf16, accumulation is fp32 — fp32-GEMM accuracy at ~2.5x the fp32 library's speed
 #: (4096^3: 0.51 vs 1.03 ms per GEMM incl. transposes and splits, max error 1.6e-6 vs 3.0e-6 of fp64; tools/bench_backward.py).  Below it the dense library is used (launch-bound either way).
 BWD_MFMA_MIN_MACS = 1 << 27
+
+
+#: backward convs with a +-1 / 0 operand on the bf16 matrix cores (ops.conv2d_grad_input_q / conv2d_grad_weight_pm1)
+BWD_CONV_MFMA = True
 
 
 def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor) -> torch.Tensor:

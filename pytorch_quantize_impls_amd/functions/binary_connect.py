@@ -136,10 +136,19 @@ def AP2(x):
 
 
 class ShiftBatch(torch.autograd.Function):
-    """Shift-based batch-norm primitive (binary_connect.py:173-214); torch ops, off the hot path."""
+    """Shift-based batch-norm primitive (binary_connect.py:173-214).  Device fp32 tensors whose statistics / affine
+    tensors broadcast over the leading dimension (how ShiftNormBatch1d / 2d call it): one HIP kernel
+    (qt_shift_batch_f32); anything else: the torch expression."""
 
     @staticmethod
     def forward(ctx, input, running_mean, running_var, weight, bias, eps):
+        per = input[0].numel() if input.dim() > 0 and input.shape[0] > 0 else -1
+        if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0
+                and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == per and tuple(t.shape) == tuple(input.shape[1:])[-t.dim():]
+                        for t in (running_mean, running_var, weight, bias))):
+            out, norm_inputs, sv = ops.shift_batch(input, running_mean, running_var, weight, bias, float(eps))
+            ctx.save_for_backward(input, weight, sv.view(running_var.shape), norm_inputs)
+            return out
         centred = input - running_mean
         sqrtvar = torch.sqrt(running_var + eps)
         norm_inputs = centred * AP2(1 / sqrtvar)

@@ -353,6 +353,29 @@ def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
     return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
 
 
+def shift_batch(x: torch.Tensor, running_mean, running_var, weight, bias, eps: float, want_saved: bool = True):
+    """ShiftBatch.forward on the device (qt_shift_batch_f32): x [N, ...], the four statistic / affine tensors hold one
+    entry per element of x[0] (broadcast over N).  Returns (y, norm_inputs or None, sqrtvar or None)."""
+    x = _require(x, "input")
+    N = int(x.shape[0]) if x.dim() > 0 else 1
+    E = x.numel() // max(N, 1)
+    vs = []
+    for t, nm in ((running_mean, "running_mean"), (running_var, "running_var"), (weight, "weight"), (bias, "bias")):
+        t = _require(t.detach(), nm)
+        if t.numel() != E:
+            raise ValueError(f"{nm} must hold one entry per element of input[0] ({E}), got {t.numel()}")
+        vs.append(t.contiguous().view(-1))
+    xc = x.detach().contiguous().view(N, E)
+    y = torch.empty_like(xc)
+    norm = torch.empty_like(xc) if want_saved else None
+    sv = torch.empty((E,), dtype=torch.float32, device=x.device) if want_saved else None
+    with _on(x.device):
+        _lib.call("qt_shift_batch_f32", _p(xc), max(E, 1), _p(vs[0]), _p(vs[1]), _p(vs[2]), _p(vs[3]), float(eps), _p(y),
+                  max(E, 1), _p(norm), max(E, 1), _p(sv), N, E, _stream(x.device))
+    shape = tuple(x.shape)
+    return y.view(shape), (norm.view(shape) if norm is not None else None), sv
+
+
 def _xnor_act_buffers(x: torch.Tensor, dim: int):
     R, C = (int(v) for v in x.shape)
     n = R if dim == 1 else (C if dim == 0 else 1)
@@ -1435,6 +1458,94 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
             _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
                       I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
     return y
+
+
+# ---- backward of a quantised conv on the bf16 matrix cores ----------------------------------------------
+# Both gradients of conv2d(x, Q(W)) have one +-1 / 0 operand, so the exact-split route of the forward applies:
+#   grad_x = conv2d(g, flip(Q(W))^T, padding k-1-p)                 (stride 1): real g x quantised weight, the forward kernel
+#   grad_W[co, ci, i, j] = sum_{n, ho, wo} g[n, co, ho, wo] x[n, ci, ho s - p + i d, wo s - p + j d]
+#          = conv2d(x^T, g^T) with batch <-> channel swapped (x^T: [Cin, N, H, W], "weight" g^T: [Cout, N, Ho, Wo], stride and
+#            dilation exchanged): +-1 x as the replicated bf16 operand, g as the exact hi/mid/lo triple operand, the
+#            contraction over (n, ho, wo) on the matrix cores; the batch is cut into chunks that keep a row of the
+#            "weight" under the kernel's 1 MiB K limit and give the launch enough tiles, partial results added in fp32.
+# Reference expressions: functions/binary_connect.py:141-143 (torch.nn.grad.conv2d_input / conv2d_weight).
+
+def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation):
+    """grad wrt the input of conv2d(x, weight_q) for a +-1 / 0 weight_q; None when the shape is outside the route
+    (stride / dilation != 1, padding > k - 1): the caller uses torch.nn.grad.conv2d_input."""
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Cout, Cin, kh, kw = (int(v) for v in weight_q.shape)
+    if (sh, sw, dh, dw) != (1, 1, 1, 1) or ph > kh - 1 or pw > kw - 1:
+        return None
+    N, C, H, W = (int(v) for v in input_shape)
+    wT = weight_q.detach().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, kh, kw]
+    y2 = float_conv2d(grad_output, wT, "sign", None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+    return y2.view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+#: largest output map (Ho * Wo) for which the weight gradient takes the matrix-core route (see conv2d_grad_weight_pm1)
+WEIGHT_GRAD_MAX_PIXELS = 256
+
+
+def _weight_grad_chunk(HoWo: int, batch: int) -> int:
+    """Images per launch of the weight-gradient conv: the largest power of two whose "weight" row (Ho*Wo pixels of
+    6-byte triples, 16-byte pixel granule) stays under the implicit-GEMM kernel's K limit."""
+    for nc in (32, 16, 8, 4, 2):
+        if nc <= max(batch, 2) and HoWo * triple_ld_bytes(nc, 16) < (1 << 20) - 4096:
+            return nc
+    return 0
+
+
+def conv2d_grad_weight_pm1(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, stride, padding, dilation,
+                           max_launches: int = 64):
+    """grad wrt the weight of conv2d(x, W) for a +-1 (or 0) activation x; None when outside the route."""
+    _require(x_pm1, "input")
+    _require(grad_output, "grad_output")
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    N, Cin, H, W = (int(v) for v in x_pm1.shape)
+    _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    nc = _weight_grad_chunk(Ho * Wo, N)
+    if nc == 0 or (N + nc - 1) // nc > max_launches or Cin * H * W >= (1 << 31):
+        return None
+    # measured against MIOpen's fp32 weight gradient at batch 256 (tools/bench_conv_backward.py): 13 x 13 maps with
+    # 576-1152 channels 3.6 / 4.1 ms vs 4.1 / 5.5 ms; 27 x 27 x 192 -> 576 13.1 vs 11.0 ms; 112 x 112 x 64 -> 64 (batch 32)
+    # 17.9 vs 0.3 ms — the swapped conv has only Cin * kh * kw output rows, so it pays on small maps with many channels only
+    if Ho * Wo > WEIGHT_GRAD_MAX_PIXELS or Cin * kh * kw < 1024:
+        return None
+    # output of the swapped conv: ((H + 2p - s (Ho - 1) - 1) // d) + 1 >= kh positions; the surplus (when the forward conv
+    # dropped trailing rows / columns) is cropped
+    kh2 = (H + 2 * ph - sh * (Ho - 1) - 1) // dh + 1
+    kw2 = (W + 2 * pw - sw * (Wo - 1) - 1) // dw + 1
+    if kh2 < kh or kw2 < kw:
+        return None
+    Cb = triple_ld_bytes(nc, 16)
+    kbytes = Ho * Wo * Cb
+    ld = max(128, (kbytes + 127) // 128 * 128)
+    dev = x_pm1.device
+    acc = None
+    meta_w = torch.empty((Cout, nc, Ho, Wo), device="meta")
+    for n0 in range(0, N, nc):
+        cnt = min(nc, N - n0)
+        xs, gs = x_pm1[n0:n0 + cnt], grad_output[n0:n0 + cnt]
+        if cnt < nc:      # ragged tail: zero images contribute nothing
+            xs = torch.cat([xs, torch.zeros((nc - cnt,) + tuple(xs.shape[1:]), device=dev)], 0)
+            gs = torch.cat([gs, torch.zeros((nc - cnt,) + tuple(gs.shape[1:]), device=dev)], 0)
+        xt = xs.permute(1, 2, 3, 0).contiguous().view(Cin * H * W, nc)          # "pixels" (ci, h, w) x "channels" n
+        px = weight_bf16x3(xt, "sign", ld_bytes=Cb)                              # +-1 / 0 replicated three times
+        gt = gs.permute(1, 2, 3, 0).contiguous().view(Cout * Ho * Wo, nc)
+        tr = split_bf16x3(gt, ld_bytes=Cb)                                       # exact hi / mid / lo of the gradient
+        data = tr.data.view(Cout, kbytes // 2)
+        if ld != kbytes:
+            padded = torch.zeros((Cout, ld // 2), dtype=torch.int16, device=dev)
+            padded[:, :kbytes // 2] = data
+            data = padded
+        wt = TriplePlanes(data=data, rows=Cout, K=kbytes // 6)
+        y2 = float_conv2d(None, meta_w, "sign", None, (dh, dw), (ph, pw), (sh, sw), weight_triples=wt, pixels=px,
+                          in_shape=(Cin, nc, H, W))
+        acc = y2 if acc is None else acc.add_(y2)
+    gw = acc.view(Cin, kh2, kw2, Cout)[:, :kh, :kw, :].permute(3, 0, 1, 2)
+    return gw.contiguous()
 
 
 def s2d_applicable(C: int, kh: int, kw: int, stride, dilation, padding=0) -> bool:

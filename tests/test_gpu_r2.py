@@ -610,9 +610,10 @@ def test_steady_state_forwards_do_not_synchronise(dev):
         torch.cuda.synchronize()
         torch.cuda.set_sync_debug_mode("error")
         try:
-            assert torch.equal(alex(xa), first)                  # default mode: nothing synchronises any more
+            second = alex(xa)                                    # default mode: nothing synchronises any more
         finally:
             torch.cuda.set_sync_debug_mode("default")
+        assert torch.equal(second, first)
         _fused.DETECT_MODE = "remember"
         try:
             outs = [vgg(xv), res(xv)]                            # verdicts are asked (host syncs allowed)
@@ -687,3 +688,68 @@ def test_log_quantiser_outside_the_kernel_window(dev):
     x = torch.randn(100, device=dev)
     y = LogQuant(fsr=3, bit_width=20).apply(x)
     assert torch.equal(y, LogQuant(fsr=3, bit_width=20).apply(x.cpu()).to(dev))
+
+
+# ---- shift-based batch norm + backward convs on the matrix cores -----------------------------------------------------
+
+def test_shift_batch_kernel_golden_and_oracle(dev, golden_r2, oracle):
+    from pytorch_quantize_impls_amd.functions.binary_connect import ShiftBatch
+    from pytorch_quantize_impls_amd.layers import ShiftNormBatch1d, ShiftNormBatch2d
+    for tag in golden_r2["g13_cases"]:
+        x, mean, var, w, b = (golden_r2[f"g13_{tag}_{k}"] for k in ("x", "mean", "var", "w", "b"))
+        with used("qt_shift_batch_f32"):
+            y = ShiftBatch.apply(g(x, dev), g(mean, dev), g(var, dev), g(w, dev), g(b, dev), 1e-4)
+        assert norm_err(n(y), golden_r2[f"g13_{tag}_y"]) <= TOL, tag
+        yo, normo = oracle.shift_batch(x, mean, var, w, b, 1e-4)
+        assert norm_err(n(y), yo) <= TOL
+    for name, cls in (("bn1d", ShiftNormBatch1d), ("bn2d", ShiftNormBatch2d)):
+        x = golden_r2[f"g13_{name}_x"]
+        m = cls(x.shape[1]).to(dev)
+        m.weight.data.copy_(g(golden_r2[f"g13_{name}_w"], dev)); m.bias.data.copy_(g(golden_r2[f"g13_{name}_b"], dev))
+        xi = g(x, dev).requires_grad_(True)
+        with used("qt_shift_batch_f32"):
+            y = m(xi)
+        assert norm_err(n(y), golden_r2[f"g13_{name}_y"]) <= TOL, name
+        y.sum().backward()                                     # the reference's backward expressions, on saved device tensors
+        assert xi.grad is not None and torch.isfinite(xi.grad).all()
+    big = torch.randn(4096, 4096, device=dev)
+    p = [torch.randn(4096, device=dev), torch.rand(4096, device=dev) + 0.1, torch.randn(4096, device=dev), torch.randn(4096, device=dev)]
+    yb = ShiftBatch.apply(big, *p, 1e-5)
+    yo, _ = oracle.shift_batch(n(big)[:64], *(n(t) for t in p), 1e-5)
+    assert norm_err(n(yb)[:64], yo) <= TOL
+
+
+@pytest.mark.parametrize("Cin,Cout,k,pd,H,B,kind", [(192, 576, 5, 2, 27, 16, "binary"), (576, 1152, 3, 1, 13, 16, "ternary"),
+                                                      (128, 96, 3, 1, 20, 5, "binary"), (120, 40, 3, 0, 9, 3, "ternary")])
+def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind):
+    """Backward of a training-mode BinConv2d / TerConv2d on a BinaryConnect-tagged activation at AlexNet conv2 / conv3
+    shapes: grad_input = the exact-split conv of the gradient with the flipped quantised weight, grad_weight = the
+    pixel contraction with batch and channels swapped, both on the bf16 matrix cores, against the fp64 evaluation of
+    torch.nn.grad.conv2d_input / conv2d_weight (functions/binary_connect.py:141-143) and the STE mask."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    torch.manual_seed(Cin + Cout)
+    cls = BinConv2d if kind == "binary" else TerConv2d
+    conv = cls(Cin, Cout, k, padding=pd).to(dev)
+    conv.weight.data.uniform_(-1.3, 1.3)
+    xr = torch.randn(B, Cin, H, H, device=dev, requires_grad=True)
+    xs = BinaryConnectDeterministic.apply(xr.contiguous(memory_format=torch.channels_last))
+    xs.retain_grad()
+    before = dict(_lib.call_counts)
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = conv(xs)
+    gout = torch.randn_like(y)
+    old_min, old_pix = _fused.BWD_MFMA_MIN_MACS, ops.WEIGHT_GRAD_MAX_PIXELS
+    _fused.BWD_MFMA_MIN_MACS, ops.WEIGHT_GRAD_MAX_PIXELS = 0, 1 << 30      # exercise the routes at every test shape
+    try:
+        y.backward(gout)
+    finally:
+        _fused.BWD_MFMA_MIN_MACS, ops.WEIGHT_GRAD_MAX_PIXELS = old_min, old_pix
+    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) >= 3          # forward + both gradients
+    assert dict(_fused.LIBRARY_PATHS) == lib_before                                                 # no dense-library detour
+    wq = (torch.where(conv.weight < 0, -1.0, 1.0) if kind == "binary" else ops.ternarize(conv.weight.detach())).double()
+    gi = torch.nn.grad.conv2d_input(xs.shape, wq, gout.double(), padding=pd)
+    gw = torch.nn.grad.conv2d_weight(xs.detach().double(), conv.weight.shape, gout.double(), padding=pd)
+    gw = torch.where(conv.weight.detach().abs() > 1.001, torch.zeros_like(gw), gw)
+    assert norm_err(n(xs.grad), gi.cpu().numpy()) <= TOL
+    assert norm_err(n(conv.weight.grad), gw.cpu().numpy()) <= TOL
+    assert norm_err(n(conv.bias.grad), gout.double().sum((0, 2, 3)).cpu().numpy()) <= TOL
