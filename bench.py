@@ -37,7 +37,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TOPS = 2516.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 32 MAC / 2 lane-ops x 2 ops
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MXFP4 (MI355X_MICROARCH.md)
-EVENT_EVERY = 5                 # GEMM launches bracketed by HIP events: every 5th timed step
+EVENT_EVERY = 10                # GEMM launches bracketed by HIP events: every 10th timed step (a pair costs ~7.6 us of stream time)
 
 
 def parse_args():
