@@ -365,8 +365,10 @@ def real_weight_conv2d(input: torch.Tensor, weight_q: torch.Tensor, bias, stride
     return F.conv2d(input, weight_q, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
-def packed_linear(layer, act, kind: str) -> torch.Tensor:
-    """Eval-mode LinearBin / LinearTer on a PackedActivation (row planes): planes -> packed GEMM."""
+def packed_linear(layer, act, kind: str, hwc=None) -> torch.Tensor:
+    """Eval-mode LinearBin / LinearTer on a PackedActivation (row planes): planes -> packed GEMM.  ``hwc`` = (C, H, W):
+    the rows are a feature map flattened in (h, w, c) order (PackedActivation.flatten_hwc) while the layer's weight
+    expects the NCHW flattening — the packed weight is built from the column-permuted image (cached like the plain one)."""
     if layer.training:
         raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
     N = layer.weight.shape[0]
@@ -374,7 +376,13 @@ def packed_linear(layer, act, kind: str) -> torch.Tensor:
     if K != layer.weight.shape[1]:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
     impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
-    wp = layer._eval_planes(lambda w2: pack_weight(w2, kind, impl), key=impl)
+    if hwc is None:
+        wp = layer._eval_planes(lambda w2: pack_weight(w2, kind, impl), key=impl)
+    else:
+        from ..layers.fused import permute_fc_weight_hwc
+        C, H, W = (int(v) for v in hwc)
+        wp = layer._eval_planes(lambda w2: pack_weight(permute_fc_weight_hwc(w2, C, H, W), kind, impl),
+                                key=(impl, "hwc", C, H, W))
     y = ops.packed_gemm(ops.to_impl(act.planes, impl), wp, layer.bias, impl=impl)
     return y.view(*act.shape[:-1], N)
 

@@ -7,7 +7,7 @@ import warnings as _warnings
 
 import torch
 
-from .. import ops, packed
+from .. import ops, packed, lazy
 from .common import front, safeSign, ste_mask
 from . import _fused
 
@@ -32,6 +32,16 @@ def _binarize_and_tag(input: torch.Tensor) -> torch.Tensor:
 
 class BinaryConnectDeterministic(torch.autograd.Function):
     """r_b = sign(r) (0 -> +1); d r_b / d r = 1_{|r| <= 1}  (binary_connect.py:14-38)."""
+    _qt_records_sign = True      # on a deferred conv chain (lazy.py) the op is recorded, not executed
+
+    @classmethod
+    def apply(cls, input):
+        if isinstance(input, lazy.LazyActivation):
+            out = lazy.sign(input)
+            if out is not None:
+                return out
+            input = input.value()
+        return super().apply(input)
 
     @staticmethod
     def forward(ctx, input):

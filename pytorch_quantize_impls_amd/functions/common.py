@@ -1,7 +1,7 @@
 """Shared pieces of the STE function family (reference: QuantTorch/functions/common.py)."""
 import torch
 
-from .. import ops
+from .. import ops, lazy
 
 
 def safeSign(tensor: torch.Tensor) -> torch.Tensor:
@@ -25,6 +25,12 @@ class _FunctionModule(torch.nn.Module):
         self.core = fn_class
 
     def forward(self, x):
+        if isinstance(x, lazy.LazyActivation):
+            # a deferred conv chain (lazy.py): BinaryConnect(deterministic) is recorded, anything else gets the value
+            out = lazy.sign(x) if getattr(self.core, "_qt_records_sign", False) else None
+            if out is not None:
+                return out
+            x = x.value()
         return self.core.apply(x)
 
 

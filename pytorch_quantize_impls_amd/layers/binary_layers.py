@@ -4,6 +4,7 @@ from math import sqrt as _sqrt
 import torch
 
 from ..functions import binary_connect, _fused
+from .. import lazy
 from .common import QLayer, EvalSwapMixin
 from ..packed import PackedActivation as _PackedActivation
 
@@ -47,6 +48,9 @@ class LinearBin(EvalSwapMixin, torch.nn.Linear, QLayer):
         return (w.abs() == 1).all()
 
     def forward(self, input):
+        return lazy.linear_forward(self, input, "binary")
+
+    def _forward_impl(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
         if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
@@ -131,6 +135,12 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self._eval_planes(build, key="conv_bf16x3_s2d")
 
     def forward(self, input):
+        """Eval mode without autograd on a HIP device: returns a deferred activation (``lazy.LazyActivation``: a Tensor
+        that runs this conv fused with the BatchNorm / pooling / Hardtanh / BinaryConnect modules that follow it, or
+        computes the plain fp32 result on any other use); every other case computes right here."""
+        return lazy.conv_forward(self, input, "binary")
+
+    def _forward_impl(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "binary")
         if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:

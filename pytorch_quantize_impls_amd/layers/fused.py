@@ -17,7 +17,7 @@ evaluation (MIOpen's, say); everything else is identical.
 """
 import torch
 
-from .. import ops, packed
+from .. import ops, packed, lazy
 from ..functions.common import _FunctionModule
 from ..functions.binary_connect import BinaryConnectDeterministic
 
@@ -76,6 +76,7 @@ class FusedPoolBnSign(torch.nn.Module):
     def forward(self, x):
         if self.bn.training:
             raise RuntimeError("FusedPoolBnSign is an inference module: call .eval() first")
+        x = lazy.resolve(x)
         if not x.is_cuda:
             raise TypeError("FusedPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
         alpha, beta = _folded_for(self, "_folded", self.bn, x.device)
@@ -122,6 +123,7 @@ class FusedBnDorefaQuant(torch.nn.Module):
         if self.bn.training:
             raise RuntimeError("FusedBnDorefaQuant folds running statistics: call .eval() first")
         alpha, beta = _folded_for(self, "_folded", self.bn)
+        x, residual = lazy.resolve(x), lazy.resolve(residual)
         if x.dim() == 4:
             N, C, H, W = x.shape
             x2 = x.permute(0, 2, 3, 1)
@@ -276,6 +278,7 @@ class FusedConvPoolBnSign(torch.nn.Module):
         if self.bn.training or self.conv.training:
             raise RuntimeError("FusedConvPoolBnSign is an inference module: call .eval() first")
         conv, fp = self.conv, self._pool
+        x = lazy.resolve(x)
         dev = conv.weight.device
         prev = fp._folded
         epi = _folded_for(fp, "_folded", self.bn, dev)

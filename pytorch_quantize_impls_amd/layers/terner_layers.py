@@ -4,6 +4,7 @@ from math import sqrt
 import torch
 
 from ..functions import terner_connect, _fused
+from .. import lazy
 from .common import QLayer, EvalSwapMixin
 from ..packed import PackedActivation as _PackedActivation
 from .binary_layers import _eval_linear
@@ -47,6 +48,9 @@ class LinearTer(EvalSwapMixin, torch.nn.Linear, QLayer):
         return ((w == 0) | (w.abs() == 1)).all()
 
     def forward(self, input):
+        return lazy.linear_forward(self, input, "ternary")
+
+    def _forward_impl(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
         if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:
@@ -103,6 +107,10 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self._eval_planes(build, key="conv_bf16x3_s2d")
 
     def forward(self, input):
+        """See BinConv2d.forward: eval mode without autograd on a HIP device returns a deferred activation."""
+        return lazy.conv_forward(self, input, "ternary")
+
+    def _forward_impl(self, input):
         if isinstance(input, _PackedActivation):
             return _fused.PACKED_FWD[isinstance(self, torch.nn.Linear)](self, input, "ternary")
         if not input.is_cuda or input.dtype != torch.float32 or self.weight.dtype != torch.float32:

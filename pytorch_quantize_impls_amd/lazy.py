@@ -1,0 +1,472 @@
+"""Deferred activations: the reference's module-by-module inference graph, executed as the fused chain.
+
+The reference builds its binarised CNNs from separate modules (models/Alexnet/Alexnet_Bin.py:12-33,
+models/FullNet/terMNIST.py:48-59):
+
+    BinConv2d / TerConv2d -> [MaxPool2d] -> BatchNorm2d -> Hardtanh -> BinaryConnect -> [MaxPool2d] -> next layer
+
+and every arrow is an fp32 tensor.  On the device four of those five modules are not this package's (torch's pooling /
+Hardtanh kernels, MIOpen's BatchNorm) and they are 40-60 % of the forward's kernel time.  ``layers.fused`` removes them,
+but only for callers that re-build their model with ``fuse_sequential`` / ``FusedFeatureClassifier``.
+
+This module gets the same execution WITHOUT touching the model: in eval mode under ``torch.no_grad()`` /
+``inference_mode()`` a binarised conv on a HIP device does not run; it returns a ``LazyActivation`` — a ``torch.Tensor``
+wrapper subclass with the right shape / dtype / device and no storage — that remembers (layer, input).  The
+``__torch_function__`` protocol then sees ``F.max_pool2d``, ``F.batch_norm`` (eval), ``F.hardtanh``, ``reshape`` /
+``flatten`` and BinaryConnect as they are applied by the un-modified ``nn`` modules and only RECORDS them.  Execution
+is pulled by the consumer:
+
+  * the next BinConv2d / TerConv2d / LinearBin / LinearTer asks for the activation as a ``PackedActivation`` and the
+    recorded chain runs as ``layers.fused.FusedConvPoolBnSign`` — conv with the BatchNorm-threshold epilogue, MaxPool on
+    bits, output written directly as the consumer's operand (its padding as a zero border) — i.e. exactly the kernels
+    of the opt-in fused form, bit-identical to it;
+  * ANY other use (an op that is not in the grammar above, printing, ``.cpu()``, arithmetic, a hook, autograd) makes
+    the tensor materialise: the conv runs through the layer's ordinary eval path and the recorded ops are replayed with
+    the torch functions that were intercepted, so the caller gets what the module-by-module graph would have produced.
+
+Nothing is deferred in training mode, with autograd enabled, on CPU tensors, for non-fp32 dtypes, grouped convs or
+non-zero padding modes.  ``lazy.ENABLED = False`` (or the ``eager()`` context manager) switches the mechanism off;
+``lazy.STATS`` counts what happened (tests assert on it).
+"""
+from __future__ import annotations
+
+import collections
+import contextlib
+import weakref
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch.utils._pytree import tree_map_only
+
+from . import ops, packed
+
+#: master switch (module-by-module execution when False)
+ENABLED = True
+#: "deferred" convs that returned a LazyActivation, "fused" chains executed as fused blocks, "materialised" lazies that
+#: had to produce their fp32 value, "fallback:<func>" the functions that forced it
+STATS = collections.Counter()
+
+
+@contextlib.contextmanager
+def eager():
+    """Run the enclosed forwards module by module (no deferred activations)."""
+    global ENABLED
+    prev, ENABLED = ENABLED, False
+    try:
+        yield
+    finally:
+        ENABLED = prev
+
+
+class _Node:
+    """One recorded step.  ``parent is None``: the deferred conv itself (``layer``, ``kind``, ``input`` = device tensor or
+    PackedActivation); otherwise ``op`` applied to ``parent``.  The flags summarise the chain from the root."""
+    __slots__ = ("parent", "op", "layer", "kind", "input", "shape", "value", "packed_cache",
+                 "pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw", "stamp")
+
+    def __init__(self, parent: Optional["_Node"], op, shape, layer=None, kind=None, input=None):
+        self.parent, self.op, self.shape = parent, op, tuple(int(v) for v in shape)
+        self.value = None
+        self.packed_cache = None
+        if parent is None:
+            self.layer, self.kind, self.input = layer, kind, input
+            self.pool = self.bn = self.hardtanh = self.pool2 = None
+            self.flat = self.signed = False
+            self.chw = None
+            self.stamp = _stamp(input, layer.weight, layer.bias) if hasattr(layer, "weight") else ()
+        else:
+            self.stamp = _stamp(*op[1:5]) if op[0] == "bn" else ()
+            self.layer, self.kind, self.input = parent.layer, parent.kind, parent.input
+            for f in ("pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw"):
+                setattr(self, f, getattr(parent, f))
+            tag = op[0]
+            if tag == "pool":
+                self.pool = op[1:]
+            elif tag == "bn":
+                self.bn = op[1:]
+            elif tag == "hardtanh":
+                self.hardtanh = op[1:]
+            elif tag == "flat":
+                self.flat, self.chw = True, parent.shape[1:]
+            elif tag == "sign":
+                self.signed = True
+            elif tag == "pool2":
+                self.pool2 = op[1:]
+
+    def check_unmodified(self):
+        """A deferred activation reads its producers when it is USED; like autograd's saved tensors they must not have
+        been written in place in between (version counters: load_state_dict / copy_ / optimizer steps / in-place ops)."""
+        node = self
+        while node is not None:
+            for t, ptr, version in node.stamp:
+                if t.data_ptr() != ptr or t._version != version:
+                    raise RuntimeError(
+                        "a tensor a deferred activation depends on (the input, weight / bias of a binarised conv, or the "
+                        "statistics of the BatchNorm that followed it) was modified in place before the activation was "
+                        "used; use the activation first (any tensor op, or .value()), or run the forward under "
+                        "pytorch_quantize_impls_amd.lazy.eager()")
+            node = node.parent
+
+    # ---- the un-fused value ------------------------------------------------------------------------------------
+    def materialise(self) -> torch.Tensor:
+        if self.value is None:
+            self.check_unmodified()
+            STATS["materialised"] += 1
+            if self.parent is None:
+                y = self.layer._forward_impl(self.input)
+            else:
+                x = self.parent.materialise()
+                tag = self.op[0]
+                if tag in ("pool", "pool2"):
+                    y = F.max_pool2d(x, self.op[1], self.op[2])
+                elif tag == "bn":
+                    rm, rv, w, b, eps = self.op[1:]
+                    y = F.batch_norm(x, rm, rv, w, b, False, 0.0, eps)
+                elif tag == "hardtanh":
+                    y = F.hardtanh(x, self.op[1], self.op[2])
+                elif tag == "flat":
+                    y = x.reshape(self.shape)
+                else:   # sign
+                    from .functions.binary_connect import _binarize_and_tag
+                    y = _binarize_and_tag(x)
+            self.value = y
+        return self.value
+
+    # ---- the fused execution -----------------------------------------------------------------------------------
+    def force(self, halo=None):
+        """PackedActivation of a signed chain: (N, C, H, W) bit planes, or the consumer's nibble operand with a zero border
+        of ``halo`` pixels, or (flat chains) row planes in (h, w, c) order.  None if this chain cannot run fused."""
+        if not self.signed or self.bn is None:
+            return None
+        if self.flat:
+            halo = None
+        key = halo
+        if self.packed_cache is None:
+            self.packed_cache = {}
+        if key in self.packed_cache:
+            return self.packed_cache[key]
+        self.check_unmodified()
+        try:
+            block = _fused_block(self.layer, self.bn, self.pool, flatten=self.flat and self.pool2 is None,
+                                 halo=halo if self.pool2 is None else None)
+            act = block(self.input)
+            if self.pool2 is not None:
+                act = _packed_pool(self.pool2, halo)(act)
+                if self.flat:
+                    act = act.flatten_hwc()
+        except ValueError:
+            act = None
+        if act is not None:
+            STATS["fused"] += 1
+        self.packed_cache[key] = act
+        return act
+
+
+def _stamp(*tensors):
+    """(tensor, storage pointer, version counter) of every real tensor among ``tensors`` (inference tensors track no
+    version counter and cannot be written in place outside inference mode: skipped)."""
+    return tuple((t, t.data_ptr(), t._version) for t in tensors
+                 if isinstance(t, torch.Tensor) and not isinstance(t, LazyActivation) and not t.is_inference())
+
+
+class _BnView(torch.nn.BatchNorm2d):
+    """The tensors F.batch_norm was called with, presented as the BatchNorm2d module layers.fused folds (shares them)."""
+
+    def __init__(self, rm, rv, w, b, eps):
+        torch.nn.Module.__init__(self)
+        self.num_features, self.eps, self.momentum = int(rm.numel()), float(eps), None
+        self.affine, self.track_running_stats = w is not None, True
+        for name, t in (("running_mean", rm), ("running_var", rv), ("weight", w), ("bias", b)):
+            object.__setattr__(self, name, t)
+        self.training = False
+
+
+_BLOCKS = weakref.WeakKeyDictionary()      # conv layer -> OrderedDict(key -> FusedConvPoolBnSign)
+_POOLS = {}
+_MAX_BLOCKS_PER_LAYER = 8
+
+
+def _fused_block(layer, bn, pool, flatten: bool, halo):
+    from .layers import fused
+    rm, rv, w, b, eps = bn
+    key = (id(rm), id(rv), id(w), id(b), eps, pool, flatten, halo)
+    per = _BLOCKS.get(layer)
+    if per is None:
+        per = _BLOCKS[layer] = collections.OrderedDict()
+    blk = per.get(key)
+    if blk is None:
+        pm = torch.nn.MaxPool2d(pool[0], pool[1]) if pool is not None else None
+        blk = fused.FusedConvPoolBnSign(layer, _BnView(rm, rv, w, b, eps), pm, flatten_hwc=flatten)
+        blk.out_nib_halo = halo
+        per[key] = blk
+        while len(per) > _MAX_BLOCKS_PER_LAYER:
+            per.popitem(last=False)
+    else:
+        per.move_to_end(key)
+    return blk
+
+
+def _packed_pool(pool, halo):
+    from .layers import fused
+    key = (pool, halo)
+    pm = _POOLS.get(key)
+    if pm is None:
+        pm = fused.PackedMaxPool(torch.nn.MaxPool2d(pool[0], pool[1]))
+        pm.out_nib_halo = halo
+        _POOLS[key] = pm
+    return pm
+
+
+class LazyActivation(torch.Tensor):
+    """fp32 activation of a binarised conv chain that has not been computed (see the module docstring)."""
+
+    @staticmethod
+    def __new__(cls, node: _Node, device):
+        t = torch.Tensor._make_wrapper_subclass(cls, node.shape, dtype=torch.float32, device=device, requires_grad=False)
+        t._qt = node
+        return t
+
+    def value(self) -> torch.Tensor:
+        """The ordinary fp32 tensor this activation stands for (computed module by module on first use)."""
+        return self._qt.materialise()
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _METADATA:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        handler = _HANDLERS.get(func)
+        if handler is not None:
+            out = handler(*args, **kwargs)
+            if out is not NotImplemented:
+                return out
+        STATS["fallback:" + getattr(func, "__name__", str(func))] += 1
+        args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs))
+        return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # safety net: an ATen op reached the dispatcher with a deferred activation (C++ callers, autograd internals)
+        args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs or {}))
+        return func(*args, **kwargs)
+
+
+_T = torch.Tensor
+_METADATA = {_T.dim, _T.size, _T.numel, _T.ndimension, _T.nelement, _T.is_floating_point, _T.is_complex, _T.element_size,
+             _T.shape.__get__, _T.dtype.__get__, _T.device.__get__, _T.is_cuda.__get__, _T.ndim.__get__,
+             _T.requires_grad.__get__, _T.layout.__get__, _T.grad_fn.__get__, _T.is_leaf.__get__, _T.is_inference,
+             _T.is_sparse.__get__, _T.is_quantized.__get__, _T.is_meta.__get__, _T.get_device, _T.__len__,
+             _T._version.__get__}
+
+
+def _wrap(node: _Node, device) -> LazyActivation:
+    return LazyActivation(node, device)
+
+
+def resolve(x):
+    """``x`` itself, or the fp32 tensor a deferred activation stands for (entry guard of every consumer that does not
+    take part in the fused chain)."""
+    return x._qt.materialise() if isinstance(x, LazyActivation) else x
+
+
+# ---- recording handlers ----------------------------------------------------------------------------------------------
+
+def _square(v):
+    if isinstance(v, int):
+        return int(v)
+    v = tuple(v)
+    if len(v) == 1:
+        return int(v[0])
+    if len(v) == 2 and v[0] == v[1]:
+        return int(v[0])
+    return None
+
+
+def _h_max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
+    if not isinstance(input, LazyActivation) or return_indices or ceil_mode:
+        return NotImplemented
+    n = input._qt
+    k = _square(kernel_size)
+    s = _square(stride) if stride not in (None, [], ()) else k
+    if k is None or s is None or _square(padding) != 0 or _square(dilation) != 1 or len(n.shape) != 4:
+        return NotImplemented
+    N, C, H, W = n.shape
+    if H < k or W < k:
+        return NotImplemented
+    shape = (N, C, (H - k) // s + 1, (W - k) // s + 1)
+    if n.bn is None and n.pool is None:
+        return _wrap(_Node(n, ("pool", k, s), shape), input.device)
+    if n.signed and not n.flat and n.pool2 is None:
+        return _wrap(_Node(n, ("pool2", k, s), shape), input.device)
+    return NotImplemented
+
+
+def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+    if not isinstance(input, LazyActivation) or training or running_mean is None or running_var is None:
+        return NotImplemented
+    n = input._qt
+    if n.bn is not None or n.flat or len(n.shape) != 4:
+        return NotImplemented
+    C = n.shape[1]
+    for t in (running_mean, running_var, weight, bias):
+        if t is None:
+            continue
+        if (isinstance(t, LazyActivation) or t.device != input.device or t.dtype != torch.float32 or t.dim() != 1
+                or t.numel() != C):
+            return NotImplemented
+    if (weight is None) != (bias is None):
+        return NotImplemented
+    return _wrap(_Node(n, ("bn", running_mean, running_var, weight, bias, float(eps)), n.shape), input.device)
+
+
+def _h_hardtanh(input, min_val=-1.0, max_val=1.0, inplace=False):
+    if not isinstance(input, LazyActivation):
+        return NotImplemented
+    n = input._qt
+    if n.bn is None or n.hardtanh is not None or n.signed or not (min_val < 0 < max_val):
+        return NotImplemented
+    child = _Node(n, ("hardtanh", float(min_val), float(max_val)), n.shape)
+    if inplace:                      # same shape: the wrapper object itself moves on, as an in-place op's result would
+        input._qt = child
+        return input
+    return _wrap(child, input.device)
+
+
+def _h_dropout(input, p=0.5, training=True, inplace=False):
+    if not isinstance(input, LazyActivation) or training:
+        return NotImplemented
+    return input
+
+
+def _flat_target(n: _Node, shape):
+    """True iff ``shape`` (ints, at most one -1) flattens the (N, C, H, W) chain to (N, C*H*W)."""
+    if len(n.shape) != 4 or n.flat or n.bn is None:
+        return False
+    N, C, H, W = n.shape
+    shape = tuple(int(v) for v in shape)
+    if len(shape) != 2:
+        return False
+    a, b = shape
+    if a == -1 and b == -1:
+        return False
+    if a == -1:
+        a = N if b == C * H * W else -2
+    if b == -1:
+        b = C * H * W if a == N else -2
+    return (a, b) == (N, C * H * W)
+
+
+def _as_flat(input, ok):
+    if not ok:
+        return NotImplemented
+    n = input._qt
+    N, C, H, W = n.shape
+    return _wrap(_Node(n, ("flat",), (N, C * H * W)), input.device)
+
+
+def _h_reshape(input, *shape):
+    if not isinstance(input, LazyActivation):
+        return NotImplemented
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    if not all(isinstance(v, int) for v in shape):
+        return NotImplemented
+    return _as_flat(input, _flat_target(input._qt, shape))
+
+
+def _h_flatten(input, start_dim=0, end_dim=-1):
+    if not isinstance(input, LazyActivation):
+        return NotImplemented
+    n = input._qt
+    ok = len(n.shape) == 4 and start_dim == 1 and end_dim in (-1, 3) and not n.flat and n.bn is not None
+    return _as_flat(input, ok)
+
+
+_HANDLERS = {
+    F.max_pool2d: _h_max_pool2d,
+    F.batch_norm: _h_batch_norm,
+    F.hardtanh: _h_hardtanh,
+    F.dropout: _h_dropout,
+    _T.reshape: _h_reshape,
+    _T.view: _h_reshape,
+    torch.reshape: _h_reshape,
+    _T.flatten: _h_flatten,
+    torch.flatten: _h_flatten,
+}
+
+
+def sign(x: LazyActivation):
+    """BinaryConnect (deterministic) of a deferred activation: recorded if the chain allows it, else None (the caller
+    then binarises the materialised value)."""
+    n = x._qt
+    if n.signed:
+        return x                     # sign(+-1) == itself
+    if n.bn is None:
+        return None
+    return _wrap(_Node(n, ("sign",), n.shape), x.device)
+
+
+# ---- layer entry points ----------------------------------------------------------------------------------------------
+
+def _no_autograd(layer) -> bool:
+    return not torch.is_grad_enabled()
+
+
+def _conv_can_defer(layer, input) -> bool:
+    if layer.training or not _no_autograd(layer) or layer.groups != 1 or layer.padding_mode != "zeros" \
+            or isinstance(layer.padding, str):
+        return False
+    w = layer.weight
+    if not w.is_cuda or w.dtype != torch.float32:
+        return False
+    if isinstance(input, packed.PackedActivation):
+        ok = len(input.shape) == 4
+    else:
+        ok = (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+              and input.numel() > 0)
+    return ok and int(input.shape[1]) == layer.in_channels and layer._eval_on_grid()
+
+
+def conv_forward(layer, input, kind: str):
+    """forward() of BinConv2d / TerConv2d: consumes a deferred activation as packed planes and, when it may, defers
+    itself; everything else goes to the layer's ordinary path (``_forward_impl``)."""
+    if isinstance(input, LazyActivation):
+        act = None
+        n = input._qt
+        if n.signed and not n.flat and _conv_can_defer(layer, _ShapeOnly(n.shape)):
+            from .functions import _fused
+            act = n.force(tuple(int(v) for v in ops._pairs(layer.padding)) if _fused.PAD_PLANES else None)
+        input = act if act is not None else n.materialise()
+    if ENABLED and _conv_can_defer(layer, input):
+        N, C, H, W = (int(v) for v in input.shape)
+        kh, kw = layer.kernel_size
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
+        if Ho > 0 and Wo > 0:
+            STATS["deferred"] += 1
+            dev = input.device
+            return _wrap(_Node(None, None, (N, layer.out_channels, Ho, Wo), layer=layer, kind=kind, input=input), dev)
+    return layer._forward_impl(input)
+
+
+class _ShapeOnly(packed.PackedActivation):
+    """Stand-in used to ask _conv_can_defer about an activation that has not been forced yet."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+def linear_forward(layer, input, kind: str):
+    """forward() of LinearBin / LinearTer: a flattened, binarised deferred activation arrives as row planes in (h, w, c)
+    order and meets the weight with its columns permuted to that order (cached per weight version)."""
+    if isinstance(input, LazyActivation):
+        n = input._qt
+        if (n.signed and n.flat and not layer.training and _no_autograd(layer) and layer.weight.is_cuda
+                and layer.weight.dtype == torch.float32 and n.shape[1] == layer.in_features and layer._eval_on_grid()):
+            act = n.force()
+            if act is not None:
+                from .functions import _fused
+                return _fused.packed_linear(layer, act, kind, hwc=n.chw)
+        input = n.materialise()
+    return layer._forward_impl(input)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from pytorch_quantize_impls_amd import _lib, ops  # noqa: E402
+from pytorch_quantize_impls_amd import _lib, lazy, ops  # noqa: E402
 from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic, nnDorefaQuant  # noqa: E402
 from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, LinearTer, DorefaConv2d, LinearBin  # noqa: E402
 
@@ -186,15 +186,19 @@ def test_c5_ternary_vgg16_forward_vs_cpu(dev):
     bench_models.randomize_bn(model, seed=5)
     model.eval()
     x = torch.randn(3, 3, 64, 64)
+    gm = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         ref = model(x)
         before = dict(_lib.call_counts)
-        got = copy.deepcopy(model).to(dev).to(memory_format=torch.channels_last)(
-            x.to(dev).contiguous(memory_format=torch.channels_last)).cpu()
-    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) == 13
+        with lazy.eager():                                   # module by module: 13 fp32-output implicit convs
+            got = gm(xd).cpu()
+        assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) == 13
+        got_deferred = gm(xd).cpu()                          # the same graph, executed as the fused chain (lazy.py)
     # BatchNorm thresholds: MIOpen and ATen-CPU may land a value within an ulp of 0 on different sides, flipping one
     # +-1 activation; logits are sums over 512 ternary-weighted signs, so allow a handful of unit steps
     assert (got - ref).abs().max() <= 0.02 * ref.abs().max() + 1e-3, float((got - ref).abs().max())
+    assert (got_deferred - ref).abs().max() <= 0.02 * ref.abs().max() + 1e-3, float((got_deferred - ref).abs().max())
 
 
 @pytest.mark.gpu

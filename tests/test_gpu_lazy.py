@@ -1,0 +1,232 @@
+"""Deferred activations (pytorch_quantize_impls_amd/lazy.py): the un-modified module-by-module model must
+  * run the fused kernels (lazy.STATS / _lib.call_counts), bit-identical to the opt-in fused form built from the same
+    modules (whose own parity against the oracle / the CPU chain is pinned in test_gpu_parity.py / test_gpu_r2.py),
+  * hand out exactly the module-by-module value whenever a deferred activation is used by anything else."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import _lib, lazy  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnect, _fused  # noqa: E402
+from pytorch_quantize_impls_amd.functions.binary_connect import BinaryConnectDeterministic  # noqa: E402
+from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, LinearBin, FusedFeatureClassifier  # noqa: E402
+import bench_models  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_stats():
+    lazy.STATS.clear()
+    _fused.LIBRARY_PATHS.clear()
+    yield
+    assert lazy.ENABLED
+
+
+def _alexnet(dev, seed=0):
+    torch.manual_seed(seed)
+    m = bench_models.AlexNetBin(num_classes=10)
+    bench_models.randomize_bn(m, seed)
+    return m.to(dev).to(memory_format=torch.channels_last).eval()
+
+
+def test_alexnet_module_graph_runs_fused_and_equals_the_fused_form(dev):
+    m = _alexnet(dev)
+    x = torch.randn(16, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    fused = bench_models.FusedAlexNetBin(m)
+    with torch.no_grad():
+        ref = fused(x)
+        before = dict(_lib.call_counts)
+        lazy.STATS.clear()
+        y = m(x)
+        with lazy.eager():
+            e = m(x)
+    assert type(y) is torch.Tensor and type(e) is torch.Tensor          # the classifier's LinearBin returns real tensors
+    assert torch.equal(y, ref)                                          # same kernels, same bits
+    assert lazy.STATS["deferred"] == 5 and lazy.STATS["fused"] == 5 and lazy.STATS["materialised"] == 0, lazy.STATS
+    assert not any(k.startswith("fallback") for k in lazy.STATS), lazy.STATS
+    assert _lib.call_counts["qt_conv2d_implicit_bits"] + _lib.call_counts["qt_conv2d_implicit_nib"] \
+        > before.get("qt_conv2d_implicit_bits", 0) + before.get("qt_conv2d_implicit_nib", 0)
+    assert not _fused.LIBRARY_PATHS, _fused.LIBRARY_PATHS
+    # against the module-by-module evaluation: same class for (almost) every image — BatchNorm ties aside
+    assert (y.argmax(1) == e.argmax(1)).float().mean().item() >= 0.9
+    assert torch.isfinite(y).all()
+
+
+def test_ternary_vgg_module_graph_equals_the_fused_form(dev):
+    torch.manual_seed(1)
+    m = bench_models.TernaryVGG16(num_classes=10, image=64, fc=256)
+    bench_models.randomize_bn(m, 1)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(4, 3, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+    fused = FusedFeatureClassifier(m.features, m.classifier, (512, 2, 2))
+    with torch.no_grad():
+        ref = fused(x)
+        lazy.STATS.clear()
+        y = m(x)
+    assert torch.equal(y, ref)
+    assert lazy.STATS["deferred"] == 13 and lazy.STATS["fused"] == 13 and lazy.STATS["materialised"] == 0, lazy.STATS
+
+
+def _block(dev, kind=BinConv2d, cin=64, cout=128, pool=True):
+    torch.manual_seed(3)
+    mods = [kind(cin, cout, 3, padding=1)]
+    if pool:
+        mods.append(nn.MaxPool2d(2, 2))
+    mods += [nn.BatchNorm2d(cout), nn.Hardtanh(inplace=True), BinaryConnect()]
+    seq = nn.Sequential(*mods)
+    bench_models.randomize_bn(seq, 3)
+    return seq.to(dev).eval()
+
+
+def _pm1(shape, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, 2, shape, generator=g).float() * 2 - 1).to(dev)
+
+
+@pytest.mark.parametrize("kind", [BinConv2d, TerConv2d])
+def test_escaping_activations_equal_the_module_by_module_value(dev, kind):
+    seq = _block(dev, kind)
+    x = BinaryConnectDeterministic.apply(_pm1((4, 64, 20, 20), dev))
+    with torch.no_grad():
+        with lazy.eager():
+            e_conv = seq[0](x)
+            e_bn = seq[2](seq[1](e_conv))
+            e_all = seq(x)
+        y = seq[0](x)
+        assert isinstance(y, lazy.LazyActivation) and isinstance(y, torch.Tensor)
+        assert y.shape == e_conv.shape and y.dtype == torch.float32 and y.device == e_conv.device and y.dim() == 4
+        assert torch.equal(y + 0, e_conv)                       # arithmetic materialises: the conv's own fp32 result
+        assert torch.equal(y.cpu(), e_conv.cpu())
+        assert torch.equal(torch.relu(seq[2](seq[1](seq[0](x)))), torch.relu(e_bn))      # un-recordable op after BN
+        out = seq(x)                                             # ends with BinaryConnect: still deferred
+        assert isinstance(out, lazy.LazyActivation) and out._qt.signed
+        assert torch.equal(out.value(), e_all)                   # replayed module by module
+        assert torch.equal(out * 1.0, e_all)
+        s = repr(out)
+        assert s.startswith("tensor(")
+        assert float(out.abs().min()) == 1.0
+    assert lazy.STATS["fused"] == 0 and lazy.STATS["materialised"] > 0
+
+
+def test_chain_feeding_a_second_conv_and_a_linear(dev):
+    a, b = _block(dev, BinConv2d, 64, 128, pool=True), _block(dev, TerConv2d, 128, 128, pool=False)
+    fc = LinearBin(128 * 10 * 10, 32).to(dev).eval()
+    x = _pm1((3, 64, 20, 20), dev)
+    with torch.no_grad():
+        with lazy.eager():
+            e = fc(b(a(x)).reshape(3, -1))
+        lazy.STATS.clear()
+        y = fc(torch.flatten(b(a(x)), 1))
+        y2 = fc(nn.Flatten()(b(a(x))))
+        y3 = fc(b(a(x)).view(3, -1))
+    assert type(y) is torch.Tensor
+    assert torch.equal(y, e) and torch.equal(y2, e) and torch.equal(y3, e)      # +-1 / 0 operands: exact integers
+    assert lazy.STATS["fused"] == 6 and lazy.STATS["materialised"] == 0, lazy.STATS
+
+
+def test_nothing_is_deferred_with_autograd_training_or_cpu(dev):
+    seq = _block(dev)
+    x = _pm1((2, 64, 12, 12), dev)
+    assert type(seq(x)) is torch.Tensor                          # grad mode: autograd graph needed
+    seq.train()
+    with torch.no_grad():
+        assert type(seq[0](x)) is torch.Tensor
+    seq.eval()
+    with torch.no_grad():
+        assert isinstance(seq[0](x), lazy.LazyActivation)
+        assert type(copy.deepcopy(seq).cpu()[0](x.cpu())) is torch.Tensor
+        with lazy.eager():
+            assert type(seq[0](x)) is torch.Tensor
+        g = BinConv2d(64, 64, 3, padding=1, groups=2).to(dev).eval()
+        assert type(g(x)) is torch.Tensor
+    assert lazy.STATS["deferred"] == 1
+
+
+def test_inference_mode_and_hooks(dev):
+    a, b = _block(dev, BinConv2d, 64, 128, pool=True), _block(dev, BinConv2d, 128, 64, pool=False)
+    x = _pm1((2, 64, 16, 16), dev)
+    seen = []
+    h = a[2].register_forward_hook(lambda mod, inp, out: seen.append((type(inp[0]), tuple(out.shape))))
+    with torch.no_grad(), lazy.eager():
+        e = b(a(x)) + 0
+    with torch.inference_mode():
+        y = b(a(x))
+        assert isinstance(y, lazy.LazyActivation)
+        assert torch.equal(y + 0, e)
+    h.remove()
+    assert seen[-1][1] == (2, 128, 8, 8)
+
+
+def test_batchnorm_update_is_picked_up(dev):
+    a, b = _block(dev, BinConv2d, 64, 128, pool=False), _block(dev, BinConv2d, 128, 64, pool=False)
+    x = _pm1((2, 64, 16, 16), dev)
+    with torch.no_grad():
+        y0 = b(a(x)) + 0
+        a[1].running_mean.add_(40.0)                              # in place: same storage, new version counter
+        with lazy.eager():
+            e1 = b(a(x)) + 0
+        y1 = b(a(x)) + 0
+        sd = {k: v.clone() for k, v in a[1].state_dict().items()}
+        sd["running_mean"] -= 40.0
+        a[1].load_state_dict(sd)
+        y2 = b(a(x)) + 0
+    assert torch.equal(y1, e1) and not torch.equal(y0, y1) and torch.equal(y2, y0)
+
+
+def test_in_place_modification_before_use_is_an_error_not_a_wrong_value(dev):
+    a = _block(dev, BinConv2d, 64, 128, pool=False)
+    x = _pm1((2, 64, 16, 16), dev)
+    with torch.no_grad():
+        y = a(x)
+        a[0].load_state_dict({k: torch.sign(torch.randn_like(v)) for k, v in a[0].state_dict().items()})
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y + 0
+        y = a[0](x)
+        x.neg_()
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y.cpu()
+        y = a(x)
+        a[1].running_var.mul_(2.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y.value()
+        y = a(x)
+        v = y + 0                          # used first: later writes do not matter
+        a[1].running_var.mul_(0.5)
+        assert torch.equal(y + 0, v)
+
+
+def test_same_deferred_activation_used_twice(dev):
+    a = _block(dev, BinConv2d, 64, 128, pool=True)
+    c1 = BinConv2d(128, 64, 3, padding=1).to(dev).eval()
+    c2 = BinConv2d(128, 32, 1).to(dev).eval()
+    x = _pm1((2, 64, 16, 16), dev)
+    with torch.no_grad():
+        with lazy.eager():
+            t = a(x)
+            e1, e2 = c1(t), c2(t)
+        t = a(x)
+        y1, y2 = c1(t) + 0, c2(t) + 0        # different paddings: the producer writes two operands
+    assert torch.equal(y1, e1) and torch.equal(y2, e2)
+
+
+def test_module_graph_in_a_hipgraph(dev):
+    from pytorch_quantize_impls_amd import utils
+    m = _alexnet(dev, 5)
+    x = torch.randn(8, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = m(x)
+        graphed = utils.graphed(m, x)
+        y = graphed(x).clone()          # the graph owns one output buffer
+        x2 = torch.randn_like(x)
+        assert torch.equal(graphed(x2), m(x2))
+    assert torch.equal(y, ref)

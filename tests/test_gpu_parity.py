@@ -14,7 +14,7 @@ from conftest import same, norm_err
 
 pytestmark = pytest.mark.gpu
 
-from pytorch_quantize_impls_amd import _lib, ops, packed, synth  # noqa: E402
+from pytorch_quantize_impls_amd import _lib, lazy, ops, packed, synth  # noqa: E402
 from pytorch_quantize_impls_amd.functions import (BinaryConnectDeterministic, BinaryConnectStochastic,  # noqa: E402
                                                   TernaryConnectDeterministic, BinaryConnect, BinaryDense,
                                                   nnDorefaQuant, safeSign)
@@ -368,7 +368,7 @@ def test_conv_reference_digests(dev, golden_hashes, case, fmt):
             for training in (True, False):
                 conv.train(training)
                 with torch.no_grad(), used(*entries):
-                    y = conv(xd)
+                    y = lazy.resolve(conv(xd))           # eval mode defers the conv: take its own fp32 result here
                 assert y.shape == (h["B"], h["Cout"], h["H"], h["H"])
                 assert y.is_contiguous(memory_format=torch.channels_last) == (fmt != "nchw")
                 yi = n(y.contiguous()).astype(np.int32)
@@ -540,7 +540,7 @@ def test_alexnet_bin_layerwise(dev):
         float_before = _lib.call_counts["qt_bf16x3_pack_f32"]
         before = sum(_lib.call_counts[k] for k in packed_entries)
         with torch.no_grad():
-            y = gmods[name](xin.to(dev))
+            y = lazy.resolve(gmods[name](xin.to(dev)))
         ran_float = _lib.call_counts["qt_bf16x3_pack_f32"] > float_before   # real-valued input: bf16x3 path
         ran_packed = sum(_lib.call_counts[k] for k in packed_entries) > before and not ran_float
         assert ran_packed == binary, name                   # only features.0 sees real pixels ...
@@ -696,9 +696,9 @@ def test_fused_alexnet_matches_unfused(dev):
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
     fused = bench_models.FusedAlexNetBin(model)
     x = torch.randn((4, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc", "qt_conv2d_implicit", "qt_xnor_gemm"):
+    with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc", "qt_conv2d_implicit", "qt_xnor_gemm"), lazy.eager():
         yf = fused(x)
-        yu = model(x)
+        yu = model(x)                  # module by module (the deferred execution of the same graph: test_gpu_lazy.py)
     assert yf.shape == yu.shape == (4, 10)
     # logits are log-softmax of integer sums: identical unless a BN threshold tie flipped a bit upstream
     assert norm_err(n(yf), n(yu)) <= 1e-3
@@ -967,7 +967,7 @@ def test_padded_pixel_planes_route_equals_bounds_checked_route(dev, oracle):
             _fused.PAD_PLANES = flag
             try:
                 with torch.no_grad(), used("qt_bits_to_nib_pad" if flag else "qt_bits_to_nib", "qt_conv2d_implicit"):
-                    outs.append(conv(act))
+                    outs.append(lazy.resolve(conv(act)))
             finally:
                 _fused.PAD_PLANES = True
         assert torch.equal(outs[0], outs[1]), (Cin, Cout, k)
@@ -1139,7 +1139,7 @@ def test_fuzz_real_input_conv_vs_fp64(dev):
         for mode in ("train", "eval"):
             conv.train(mode == "train")
             with torch.no_grad(), used("qt_conv2d_implicit"):
-                y = conv(x)
+                y = lazy.resolve(conv(x))
             assert y.shape == ref.shape and norm_err(n(y), n(ref)) <= TOL, (it, Cin, Cout, k, st, pd, H, W, mode)
         conv.train()
 

@@ -23,7 +23,7 @@ from conftest import same, norm_err
 
 pytestmark = pytest.mark.gpu
 
-from pytorch_quantize_impls_amd import _lib, ops, packed, synth  # noqa: E402
+from pytorch_quantize_impls_amd import _lib, lazy, ops, packed, synth  # noqa: E402
 from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic  # noqa: E402
 from pytorch_quantize_impls_amd.layers import (BinConv2d, TerConv2d, LinearBin, LinearTer, FusedConvPoolBnSign,  # noqa: E402
                                                PackedMaxPool, FusedFeatureClassifier, fold_batchnorm)
@@ -175,7 +175,7 @@ def test_c5_conv_reference_digest(dev, golden_hashes_r2):
         for training in (True, False):
             conv.train(training)
             with torch.no_grad(), used("qt_conv2d_implicit"):
-                y = conv(xd)
+                y = lazy.resolve(conv(xd))
             yi = n(y.contiguous()).astype(np.int32)          # NCHW order, as the reference's tensor
             assert hashlib.sha256(np.ascontiguousarray(yi).tobytes()).hexdigest() == h["sha256_int32"], (tagged, training)
             assert float(y.double().sum()) == h["sum"]
@@ -560,7 +560,7 @@ def test_eval_weight_off_grid_follows_the_reference(dev):
                     (lambda: TerConv2d(16, 8, 3, padding=1), xc), (lambda: DorefaConv2d(16, 8, 3, padding=1, bit_width=1), xc)):
         layer = mk().to(dev).eval()
         with torch.no_grad():
-            y_grid = layer(xin)                                     # on-grid eval weight: packed / int8 / bf16 paths
+            y_grid = lazy.resolve(layer(xin))                       # on-grid eval weight: packed / int8 / bf16 paths
         ckpt = {k: torch.randn_like(v) * 0.7 for k, v in layer.state_dict().items()}
         layer.load_state_dict(ckpt)                                 # float weights while in eval mode
         before = sum(_fused.LIBRARY_PATHS.values())
