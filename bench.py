@@ -264,17 +264,32 @@ def bench_alexnet(args, dev, dist, world, rank):
                 best = e if best is None else min(best, e)
         return best, last
 
+    from pytorch_quantize_impls_amd import lazy
+    lazy.STATS.clear()
     el, y = timed(model)
+    stats = dict(lazy.STATS)
     out = {"images_per_s": world * B * args.alexnet_iters / el, "batch_per_gpu": B,
-           "ms_per_forward": el / args.alexnet_iters * 1e3, "mode": "eval (pre-packed weights), channels_last; best of 3 runs of alexnet_iters forwards",
+           "ms_per_forward": el / args.alexnet_iters * 1e3,
+           "mode": "eval (pre-packed weights), channels_last, the reference's module-by-module nn.Sequential graph, un-modified; "
+                   "binarised convs return deferred activations (lazy.py) so the graph executes as the fused chain; "
+                   "best of 3 runs of alexnet_iters forwards",
+           "deferred_convs_per_forward": stats.get("deferred", 0) / max(1, 3 + 3 * args.alexnet_iters),
+           "materialised": stats.get("materialised", 0),
            "macs_per_image": 4.9349e9, "finite": bool(torch.isfinite(y).all())}
+    # the same un-modified graph with deferral switched off: every module computes its fp32 output (r1 / early-r2 numbers)
+    with lazy.eager():
+        ele, ye = timed(model)
+    out["module_by_module_eager"] = {"images_per_s": world * B * args.alexnet_iters / ele,
+                                     "ms_per_forward": ele / args.alexnet_iters * 1e3,
+                                     "same_argmax_as_deferred": bool(torch.equal(ye.argmax(1), y.argmax(1)))}
     # same network fused for inference (layers.fused): every BinConv2d emits BatchNorm-threshold bits, MaxPool runs
     # on bits, FC blocks use the BN+Hardtanh+sign+pack kernel: no fp32 activation between binarised layers
     fused = bench_models.FusedAlexNetBin(model)
     elf, yf = timed(fused)
     out["fused"] = {"images_per_s": world * B * args.alexnet_iters / elf,
                     "ms_per_forward": elf / args.alexnet_iters * 1e3,
-                    "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), y.argmax(1)))}
+                    "same_logits_as_module_graph": bool(torch.equal(yf, y)),
+                    "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), ye.argmax(1)))}
     # SURVEY 8d asks for the train-mode form as well: the quantised layers in training mode (sign + pack of W on every
     # call, STE autograd nodes), BatchNorm kept on its running statistics for determinism
     from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
@@ -286,7 +301,7 @@ def bench_alexnet(args, dev, dist, world, rank):
         m.eval()
     out["train_mode_layers"] = {"images_per_s": world * B * args.alexnet_iters / elt,
                                 "ms_per_forward": elt / args.alexnet_iters * 1e3,
-                                "same_logits_as_eval": bool(torch.equal(yt, y))}
+                                "same_logits_as_eval": bool(torch.equal(yt, ye))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = B                       # the same batch as the GPU leg (one forward = ~1 s on the box's host)
         cpu_model = bench_models.AlexNetBin()
@@ -457,12 +472,27 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         m5.features[0].binary_input = False
         x5 = torch.randn((Bv, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
         st5 = _layer_stats(m5, x5)
+        from pytorch_quantize_impls_amd import lazy
         f5 = FusedFeatureClassifier(m5.features, m5.classifier, (512, 7, 7))
         with torch.no_grad():
-            agree5 = float((f5(x5).argmax(1) == m5(x5).argmax(1)).float().mean())
-        el_u5 = timed(lambda: m5(x5), 3)
+            yf5, yd5 = f5(x5), m5(x5)
+            with lazy.eager():
+                ye5 = m5(x5)
+            agree5 = float((yf5.argmax(1) == ye5.argmax(1)).float().mean())
+            same5 = bool(torch.equal(yf5, yd5))
+            del yf5, yd5, ye5
+
+        def eager5():
+            with lazy.eager():
+                return m5(x5)
+        el_u5 = timed(eager5, 3)
+        el_d5 = timed(lambda: m5(x5), iters)
         el_f5 = timed(lambda: f5(x5), iters)
         out["c5_ternary_vgg16"] = {
+            # the reference's module-by-module graph, un-modified; convs return deferred activations (lazy.py)
+            "module_graph": _net_line("c5", Bv, world, iters, el_d5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
+                                      {"same_logits_as_fused_form": same5}),
+            # the same graph with deferral off: every module writes its fp32 output
             "unfused": _net_line("c5", Bv, world, 3, el_u5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense"),
             "fused": _net_line("c5", Bv, world, iters, el_f5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
                                {"argmax_agreement_with_unfused": agree5}),
