@@ -452,12 +452,25 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         m4 = m4.to(dev).to(memory_format=torch.channels_last).eval()
         x4 = torch.randn((Bc, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
         st4 = _layer_stats(m4, x4)
+        from pytorch_quantize_impls_amd import lazy
         f4 = bench_models.FusedDorefaResNet18(m4)
+
+        def eager4():
+            with lazy.eager():
+                return m4(x4)
         with torch.no_grad():
-            agree = float((f4(x4).argmax(1) == m4(x4).argmax(1)).float().mean())
-        el_u = timed(lambda: m4(x4))
+            ye4 = eager4()
+            agree = float((f4(x4).argmax(1) == ye4.argmax(1)).float().mean())
+            agree_d = float((m4(x4).argmax(1) == ye4.argmax(1)).float().mean())
+        el_u = timed(eager4)
+        el_d = timed(lambda: m4(x4), 2 * iters)
         el_f = timed(lambda: f4(x4), 2 * iters)
         out["c4_dorefa_resnet18_w1a4"] = {
+            # the un-modified module graph: DorefaConv2d layers return deferred activations, BatchNorm / shortcut add / ReLU /
+            # nnDorefaQuant are recorded and run in the conv's code epilogue (lazy.py); the fp32 stem stays module by module
+            "module_graph": _net_line("c4", Bc, world, 2 * iters, el_d, st4, 5000.0,
+                                      "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                      {"argmax_agreement_with_unfused": agree_d}),
             "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54"),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                {"argmax_agreement_with_unfused": agree}),

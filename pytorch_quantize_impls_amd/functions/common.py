@@ -28,6 +28,9 @@ class _FunctionModule(torch.nn.Module):
         if isinstance(x, lazy.LazyActivation):
             # a deferred conv chain (lazy.py): BinaryConnect(deterministic) is recorded, anything else gets the value
             out = lazy.sign(x) if getattr(self.core, "_qt_records_sign", False) else None
+            bits = getattr(self.core, "_qt_quant_bits", None)
+            if bits is not None:                   # nnDorefaQuant(k) on a deferred DorefaConv2d chain
+                out = lazy.quant(x, bits)
             if out is not None:
                 return out
             x = x.value()

@@ -3,7 +3,7 @@ import warnings
 
 import torch
 
-from .. import ops, packed
+from .. import ops, packed, lazy
 from .common import front, safeSign
 from . import _fused
 
@@ -36,6 +36,17 @@ def _quantize(x, bit_width=3):
 
 def _make_quant_function(bit_width):
     class _Quant(torch.autograd.Function):
+        _qt_quant_bits = bit_width          # on a deferred DorefaConv2d chain (lazy.py) the quantiser is recorded
+
+        @classmethod
+        def apply(cls, input):
+            if isinstance(input, lazy.LazyActivation):
+                out = lazy.quant(input, bit_width)
+                if out is not None:
+                    return out
+                input = input.value()
+            return super().apply(input)
+
         @staticmethod
         def forward(ctx, input):
             return _quantize(input, bit_width=bit_width)

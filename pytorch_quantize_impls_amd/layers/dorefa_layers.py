@@ -2,6 +2,7 @@
 import torch
 
 from ..functions import dorefa_connect, _fused
+from .. import lazy
 from ..packed import CodeActivation as _CodeActivation
 from .common import QLayer, EvalSwapMixin
 
@@ -39,6 +40,7 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
 
     def forward(self, input):
+        input = lazy.resolve(input)
         if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
             raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
                                "call .eval() first (k-bit weights: pass input.float())")
@@ -101,6 +103,12 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
 
     def forward(self, input):
+        """1-bit weights, eval mode, no autograd, input carrying int8 codes on a HIP device: returns a deferred activation
+        (lazy.py) that runs this conv with the BatchNorm / shortcut add / ReLU / nnDorefaQuant modules that follow it in
+        the conv's code epilogue; otherwise computes here."""
+        return lazy.dorefa_conv_forward(self, input)
+
+    def _forward_impl(self, input):
         args = (self.stride, self.padding, self.dilation, self.groups)
         if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
             raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "

@@ -63,36 +63,46 @@ class _Node:
     """One recorded step.  ``parent is None``: the deferred conv itself (``layer``, ``kind``, ``input`` = device tensor or
     PackedActivation); otherwise ``op`` applied to ``parent``.  The flags summarise the chain from the root."""
     __slots__ = ("parent", "op", "layer", "kind", "input", "shape", "value", "packed_cache",
-                 "pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw", "stamp")
+                 "pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw", "stamp", "add", "relu", "quant", "device")
 
     def __init__(self, parent: Optional["_Node"], op, shape, layer=None, kind=None, input=None):
-        self.parent, self.op, self.shape = parent, op, tuple(int(v) for v in shape)
+        self.parent, self.op, self.shape = parent, op, shape          # shape: tuple of ints
         self.value = None
         self.packed_cache = None
         if parent is None:
             self.layer, self.kind, self.input = layer, kind, input
-            self.pool = self.bn = self.hardtanh = self.pool2 = None
-            self.flat = self.signed = False
+            self.device = input.device
+            self.pool = self.bn = self.hardtanh = self.pool2 = self.add = self.quant = None
+            self.flat = self.signed = self.relu = False
             self.chw = None
             self.stamp = _stamp(input, layer.weight, layer.bias) if hasattr(layer, "weight") else ()
-        else:
-            self.stamp = _stamp(*op[1:5]) if op[0] == "bn" else ()
-            self.layer, self.kind, self.input = parent.layer, parent.kind, parent.input
-            for f in ("pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw"):
-                setattr(self, f, getattr(parent, f))
-            tag = op[0]
-            if tag == "pool":
-                self.pool = op[1:]
-            elif tag == "bn":
-                self.bn = op[1:]
-            elif tag == "hardtanh":
-                self.hardtanh = op[1:]
-            elif tag == "flat":
-                self.flat, self.chw = True, parent.shape[1:]
-            elif tag == "sign":
-                self.signed = True
-            elif tag == "pool2":
-                self.pool2 = op[1:]
+            return
+        p = parent
+        self.layer, self.kind, self.input, self.device = p.layer, p.kind, p.input, p.device
+        self.pool, self.bn, self.hardtanh, self.flat, self.signed = p.pool, p.bn, p.hardtanh, p.flat, p.signed
+        self.pool2, self.chw, self.add, self.relu, self.quant = p.pool2, p.chw, p.add, p.relu, p.quant
+        self.stamp = ()
+        tag = op[0]
+        if tag == "pool":
+            self.pool = op[1:]
+        elif tag == "bn":
+            self.bn = op[1:]
+            self.stamp = _stamp(*op[1:5])
+        elif tag == "hardtanh":
+            self.hardtanh = op[1:]
+        elif tag == "flat":
+            self.flat, self.chw = True, parent.shape[1:]
+        elif tag == "sign":
+            self.signed = True
+        elif tag == "pool2":
+            self.pool2 = op[1:]
+        elif tag == "add":
+            self.add = op[1]
+            self.stamp = _stamp(op[1])
+        elif tag == "relu":
+            self.relu = True
+        elif tag == "quant":
+            self.quant = op[1]
 
     def check_unmodified(self):
         """A deferred activation reads its producers when it is USED; like autograd's saved tensors they must not have
@@ -113,7 +123,12 @@ class _Node:
         if self.value is None:
             self.check_unmodified()
             STATS["materialised"] += 1
-            if self.parent is None:
+            codes = self.force_any() if (self.kind == "dorefa" and self.quant is not None) else None
+            if codes is not None:
+                # a quantised DoReFa chain always evaluates through the code epilogue (one arithmetic for every consumer):
+                # the int8 codes, expanded; the chain's int8-range flag is applied on the device (NaN, no host sync)
+                y = codes.float()
+            elif self.parent is None:
                 y = self.layer._forward_impl(self.input)
             else:
                 x = self.parent.materialise()
@@ -127,6 +142,13 @@ class _Node:
                     y = F.hardtanh(x, self.op[1], self.op[2])
                 elif tag == "flat":
                     y = x.reshape(self.shape)
+                elif tag == "add":
+                    y = x + resolve(self.op[1])
+                elif tag == "relu":
+                    y = torch.relu(x)
+                elif tag == "quant":
+                    from .functions.dorefa_connect import _quantize
+                    y = _quantize(x, bit_width=self.op[1])
                 else:   # sign
                     from .functions.binary_connect import _binarize_and_tag
                     y = _binarize_and_tag(x)
@@ -136,7 +158,10 @@ class _Node:
     # ---- the fused execution -----------------------------------------------------------------------------------
     def force(self, halo=None):
         """PackedActivation of a signed chain: (N, C, H, W) bit planes, or the consumer's nibble operand with a zero border
-        of ``halo`` pixels, or (flat chains) row planes in (h, w, c) order.  None if this chain cannot run fused."""
+        of ``halo`` pixels, or (flat chains) row planes in (h, w, c) order.  DoReFa chains: the CodeActivation of a
+        quantised chain (int8 code plane, ``halo`` = zero border).  None if this chain cannot run fused."""
+        if self.kind == "dorefa":
+            return self._force_codes(halo)
         if not self.signed or self.bn is None:
             return None
         if self.flat:
@@ -168,6 +193,65 @@ def _stamp(*tensors):
     version counter and cannot be written in place outside inference mode: skipped)."""
     return tuple((t, t.data_ptr(), t._version) for t in tensors
                  if isinstance(t, torch.Tensor) and not isinstance(t, LazyActivation) and not t.is_inference())
+
+
+def _force_codes(self, halo=None):
+    if self.quant is None or self.bn is None or self.flat:
+        return None
+    halo = tuple(halo) if halo is not None else (0, 0)
+    if self.packed_cache is None:
+        self.packed_cache = {}
+    if halo in self.packed_cache:
+        return self.packed_cache[halo]
+    self.check_unmodified()
+    from .layers import fused
+    try:
+        blk = _code_block(self.layer, self.bn, self.quant, self.relu, halo if self.pool2 is None else (0, 0))
+        res = res_bn = None
+        if self.add is not None:
+            other = self.add
+            if isinstance(other, LazyActivation):
+                o = other._qt
+                if o.quant is not None:                       # identity shortcut: the block's own (quantised) input
+                    res = o.force_any()
+                else:                                         # conv + BatchNorm shortcut: fp32 conv output, BN folded
+                    res, res_bn = o.parent.materialise(), _bn_view(blk, o.bn)
+            else:
+                res = other
+            if res is None:
+                raise ValueError("residual cannot join the fused chain")
+        act = blk(self.input, residual=res, residual_bn=res_bn)
+        if self.pool2 is not None:
+            act = fused.CodeMaxPool(torch.nn.MaxPool2d(self.pool2[0], self.pool2[1]), out_halo=halo)(act)
+    except ValueError:
+        act = None
+    if act is not None:
+        STATS["fused"] += 1
+    self.packed_cache[halo] = act
+    return act
+
+
+def _force_any(self):
+    """The chain's CodeActivation with whatever halo it was already produced with (a residual may carry any)."""
+    for act in (self.packed_cache or {}).values():
+        if act is not None:
+            return act
+    return self.force(None)
+
+
+_Node._force_codes = _force_codes
+_Node.force_any = _force_any
+
+
+def _bn_view(owner_block, bn):
+    """_BnView of the shortcut's BatchNorm, cached on the fused block that folds it."""
+    key = tuple(id(t) for t in bn[:4]) + (bn[4],)
+    cache = owner_block.__dict__.setdefault("_qt_res_bn", {})
+    if key not in cache:
+        if len(cache) > 4:
+            cache.clear()
+        cache[key] = _BnView(*bn)
+    return cache[key]
 
 
 class _BnView(torch.nn.BatchNorm2d):
@@ -207,6 +291,24 @@ def _fused_block(layer, bn, pool, flatten: bool, halo):
     return blk
 
 
+def _code_block(layer, bn, bit_width, relu, halo):
+    from .layers import fused
+    rm, rv, w, b, eps = bn
+    key = (id(rm), id(rv), id(w), id(b), eps, "codes", bit_width, relu, halo)
+    per = _BLOCKS.get(layer)
+    if per is None:
+        per = _BLOCKS[layer] = collections.OrderedDict()
+    blk = per.get(key)
+    if blk is None:
+        blk = fused.FusedDorefaConvBnQuant(layer, _BnView(rm, rv, w, b, eps), bit_width, relu=relu, out_halo=halo)
+        per[key] = blk
+        while len(per) > _MAX_BLOCKS_PER_LAYER:
+            per.popitem(last=False)
+    else:
+        per.move_to_end(key)
+    return blk
+
+
 def _packed_pool(pool, halo):
     from .layers import fused
     key = (pool, halo)
@@ -222,8 +324,9 @@ class LazyActivation(torch.Tensor):
     """fp32 activation of a binarised conv chain that has not been computed (see the module docstring)."""
 
     @staticmethod
-    def __new__(cls, node: _Node, device):
-        t = torch.Tensor._make_wrapper_subclass(cls, node.shape, dtype=torch.float32, device=device, requires_grad=False)
+    def __new__(cls, node: _Node, device=None):
+        t = torch.Tensor._make_wrapper_subclass(cls, node.shape, dtype=torch.float32, device=node.device,
+                                                requires_grad=False)
         t._qt = node
         return t
 
@@ -234,14 +337,17 @@ class LazyActivation(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func in _METADATA:
-            with torch._C.DisableTorchFunctionSubclass():
-                return func(*args, **kwargs)
         handler = _HANDLERS.get(func)
         if handler is not None:
             out = handler(*args, **kwargs)
             if out is not NotImplemented:
                 return out
+        elif func in _METADATA:
+            fast = _META_FAST.get(func)
+            if fast is not None and not kwargs:
+                return fast(*args)
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
         STATS["fallback:" + getattr(func, "__name__", str(func))] += 1
         args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs))
         return func(*args, **kwargs)
@@ -261,8 +367,29 @@ _METADATA = {_T.dim, _T.size, _T.numel, _T.ndimension, _T.nelement, _T.is_floati
              _T._version.__get__}
 
 
-def _wrap(node: _Node, device) -> LazyActivation:
-    return LazyActivation(node, device)
+def _size(t, dim=None):
+    shape = t._qt.shape
+    return torch.Size(shape) if dim is None else shape[dim]
+
+
+def _numel(t):
+    n = 1
+    for v in t._qt.shape:
+        n *= v
+    return n
+
+
+#: the metadata queries nn modules make on every call, answered from the node without entering the dispatcher
+_META_FAST = {_T.dim: lambda t: len(t._qt.shape), _T.ndimension: lambda t: len(t._qt.shape),
+              _T.ndim.__get__: lambda t: len(t._qt.shape), _T.size: _size, _T.shape.__get__: lambda t: torch.Size(t._qt.shape),
+              _T.dtype.__get__: lambda t: torch.float32, _T.device.__get__: lambda t: t._qt.device,
+              _T.is_cuda.__get__: lambda t: t._qt.device.type == "cuda", _T.numel: _numel, _T.nelement: _numel,
+              _T.requires_grad.__get__: lambda t: False, _T.is_floating_point: lambda t: True,
+              _T.__len__: lambda t: t._qt.shape[0]}
+
+
+def _wrap(node: _Node, device=None) -> LazyActivation:
+    return LazyActivation(node)
 
 
 def resolve(x):
@@ -296,10 +423,14 @@ def _h_max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_m
     if H < k or W < k:
         return NotImplemented
     shape = (N, C, (H - k) // s + 1, (W - k) // s + 1)
+    if n.kind == "dorefa":
+        if n.quant is not None and n.pool2 is None:          # DoReFa CNNs pool AFTER the quantiser: max of the codes
+            return _wrap(_Node(n, ("pool2", k, s), shape))
+        return NotImplemented
     if n.bn is None and n.pool is None:
-        return _wrap(_Node(n, ("pool", k, s), shape), input.device)
+        return _wrap(_Node(n, ("pool", k, s), shape))
     if n.signed and not n.flat and n.pool2 is None:
-        return _wrap(_Node(n, ("pool2", k, s), shape), input.device)
+        return _wrap(_Node(n, ("pool2", k, s), shape))
     return NotImplemented
 
 
@@ -307,31 +438,31 @@ def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, trai
     if not isinstance(input, LazyActivation) or training or running_mean is None or running_var is None:
         return NotImplemented
     n = input._qt
-    if n.bn is not None or n.flat or len(n.shape) != 4:
+    if n.bn is not None or n.flat or len(n.shape) != 4 or n.add is not None:
         return NotImplemented
     C = n.shape[1]
     for t in (running_mean, running_var, weight, bias):
         if t is None:
             continue
-        if (isinstance(t, LazyActivation) or t.device != input.device or t.dtype != torch.float32 or t.dim() != 1
+        if (type(t) is LazyActivation or t.device != n.device or t.dtype != torch.float32 or t.dim() != 1
                 or t.numel() != C):
             return NotImplemented
     if (weight is None) != (bias is None):
         return NotImplemented
-    return _wrap(_Node(n, ("bn", running_mean, running_var, weight, bias, float(eps)), n.shape), input.device)
+    return _wrap(_Node(n, ("bn", running_mean, running_var, weight, bias, float(eps)), n.shape))
 
 
 def _h_hardtanh(input, min_val=-1.0, max_val=1.0, inplace=False):
     if not isinstance(input, LazyActivation):
         return NotImplemented
     n = input._qt
-    if n.bn is None or n.hardtanh is not None or n.signed or not (min_val < 0 < max_val):
+    if n.kind == "dorefa" or n.bn is None or n.hardtanh is not None or n.signed or not (min_val < 0 < max_val):
         return NotImplemented
     child = _Node(n, ("hardtanh", float(min_val), float(max_val)), n.shape)
     if inplace:                      # same shape: the wrapper object itself moves on, as an in-place op's result would
         input._qt = child
         return input
-    return _wrap(child, input.device)
+    return _wrap(child)
 
 
 def _h_dropout(input, p=0.5, training=True, inplace=False):
@@ -340,9 +471,72 @@ def _h_dropout(input, p=0.5, training=True, inplace=False):
     return input
 
 
+def _h_relu(input, inplace=False):
+    if not isinstance(input, LazyActivation):
+        return NotImplemented
+    n = input._qt
+    if n.kind != "dorefa" or n.bn is None or n.relu or n.quant is not None:
+        return NotImplemented
+    child = _Node(n, ("relu",), n.shape)
+    if inplace:
+        input._qt = child
+        return input
+    return _wrap(child)
+
+
+def _h_relu_(input):
+    return _h_relu(input, inplace=True)
+
+
+def _conv_macs(n: _Node) -> int:
+    w = n.layer.weight
+    return int(w.shape[1]) * int(w.shape[2]) * int(w.shape[3])
+
+
+def _residual_ok(main: _Node, other) -> bool:
+    if isinstance(other, LazyActivation):
+        o = other._qt
+        if o.kind != "dorefa" or o.shape != main.shape or o.flat:
+            return False
+        if o.quant is not None:
+            return True
+        return o.bn is not None and o.parent is not None and o.parent.parent is None       # exactly conv -> BatchNorm
+    return (isinstance(other, torch.Tensor) and other.device == main.input.device and other.dtype == torch.float32
+            and tuple(other.shape) == main.shape and not other.requires_grad)
+
+
+def _mainline(n: _Node) -> bool:
+    return (n.kind == "dorefa" and n.bn is not None and n.add is None and not n.relu and n.quant is None and not n.flat
+            and len(n.shape) == 4)
+
+
+def _h_add(a, b, *, alpha=1, out=None, _inplace=False):
+    """bn(conv(x)) + shortcut: the residual add of a DoReFa ResNet block, folded into the conv's code epilogue."""
+    if alpha != 1 or out is not None:
+        return NotImplemented
+    cands = []
+    if isinstance(a, LazyActivation) and _mainline(a._qt) and _residual_ok(a._qt, b):
+        cands.append((a, b))
+    if not _inplace and isinstance(b, LazyActivation) and _mainline(b._qt) and _residual_ok(b._qt, a):
+        cands.append((b, a))
+    if not cands:
+        return NotImplemented
+    # both operands conv -> BatchNorm (3x3 main path + 1x1 shortcut): the bigger conv keeps its epilogue
+    main, other = max(cands, key=lambda c: _conv_macs(c[0]._qt))
+    child = _Node(main._qt, ("add", other), main._qt.shape)
+    if _inplace:
+        a._qt = child
+        return a
+    return _wrap(child)
+
+
+def _h_iadd(a, b, *, alpha=1):
+    return _h_add(a, b, alpha=alpha, _inplace=True)
+
+
 def _flat_target(n: _Node, shape):
     """True iff ``shape`` (ints, at most one -1) flattens the (N, C, H, W) chain to (N, C*H*W)."""
-    if len(n.shape) != 4 or n.flat or n.bn is None:
+    if len(n.shape) != 4 or n.flat or n.bn is None or n.kind == "dorefa":
         return False
     N, C, H, W = n.shape
     shape = tuple(int(v) for v in shape)
@@ -363,7 +557,7 @@ def _as_flat(input, ok):
         return NotImplemented
     n = input._qt
     N, C, H, W = n.shape
-    return _wrap(_Node(n, ("flat",), (N, C * H * W)), input.device)
+    return _wrap(_Node(n, ("flat",), (N, C * H * W)))
 
 
 def _h_reshape(input, *shape):
@@ -380,7 +574,8 @@ def _h_flatten(input, start_dim=0, end_dim=-1):
     if not isinstance(input, LazyActivation):
         return NotImplemented
     n = input._qt
-    ok = len(n.shape) == 4 and start_dim == 1 and end_dim in (-1, 3) and not n.flat and n.bn is not None
+    ok = (len(n.shape) == 4 and start_dim == 1 and end_dim in (-1, 3) and not n.flat and n.bn is not None
+          and n.kind != "dorefa")
     return _as_flat(input, ok)
 
 
@@ -394,6 +589,9 @@ _HANDLERS = {
     torch.reshape: _h_reshape,
     _T.flatten: _h_flatten,
     torch.flatten: _h_flatten,
+    torch.relu: _h_relu, _T.relu: _h_relu, F.relu: _h_relu, torch.relu_: _h_relu_, _T.relu_: _h_relu_,
+    torch.add: _h_add, _T.add: _h_add, _T.__add__: _h_add, _T.__radd__: _h_add,
+    _T.add_: _h_iadd, _T.__iadd__: _h_iadd,
 }
 
 
@@ -401,11 +599,22 @@ def sign(x: LazyActivation):
     """BinaryConnect (deterministic) of a deferred activation: recorded if the chain allows it, else None (the caller
     then binarises the materialised value)."""
     n = x._qt
+    if n.kind == "dorefa":
+        return None
     if n.signed:
         return x                     # sign(+-1) == itself
     if n.bn is None:
         return None
-    return _wrap(_Node(n, ("sign",), n.shape), x.device)
+    return _wrap(_Node(n, ("sign",), n.shape))
+
+
+def quant(x: LazyActivation, bit_width: int):
+    """nnDorefaQuant(k) of a deferred DorefaConv2d chain (conv -> BatchNorm [-> + shortcut] [-> ReLU]): recorded when
+    the code epilogue can produce it (2 <= k <= 8), else None."""
+    n = x._qt
+    if n.kind != "dorefa" or n.bn is None or n.quant is not None or n.flat or not 2 <= int(bit_width) <= 8:
+        return None
+    return _wrap(_Node(n, ("quant", int(bit_width)), n.shape))
 
 
 # ---- layer entry points ----------------------------------------------------------------------------------------------
@@ -445,9 +654,64 @@ def conv_forward(layer, input, kind: str):
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
         if Ho > 0 and Wo > 0:
             STATS["deferred"] += 1
-            dev = input.device
-            return _wrap(_Node(None, None, (N, layer.out_channels, Ho, Wo), layer=layer, kind=kind, input=input), dev)
+            return _wrap(_Node(None, None, (N, int(layer.out_channels), int(Ho), int(Wo)), layer=layer, kind=kind,
+                               input=input))
     return layer._forward_impl(input)
+
+
+def _dorefa_can_defer(layer, input) -> bool:
+    if (layer.training or not _no_autograd(layer) or layer.groups != 1 or layer.padding_mode != "zeros"
+            or isinstance(layer.padding, str) or layer.bit_width != 1):
+        return False
+    w = layer.weight
+    if not w.is_cuda or w.dtype != torch.float32 or not isinstance(input, packed.CodeActivation) or len(input.shape) != 4:
+        return False
+    return int(input.shape[1]) == layer.in_channels and layer._eval_on_grid()
+
+
+def dorefa_conv_forward(layer, input):
+    """forward() of DorefaConv2d: a 1-bit-weight conv in eval mode whose input carries int8 codes (the tag nnDorefaQuant
+    leaves on its result, a CodeActivation, or a deferred quantised chain) defers itself."""
+    if isinstance(input, LazyActivation):
+        n = input._qt
+        act = None
+        if n.kind == "dorefa" and n.quant is not None and _dorefa_can_defer(layer, _CodeShapeOnly(n.shape)):
+            pad = tuple(int(v) for v in ops._pairs(layer.padding))
+            # a plane already produced for another consumer serves this one too if its zero border covers the padding
+            # (the kernels read a halo plane at an offset of halo - padding pixels): e.g. the 1x1 shortcut conv of a
+            # ResNet block after the 3x3 conv that shares its input
+            for halo, done in (n.packed_cache or {}).items():
+                if done is not None and halo[0] >= pad[0] and halo[1] >= pad[1]:
+                    act = done
+                    break
+            if act is None:
+                act = n.force(pad)
+        input = act if act is not None else n.materialise()
+    tagged = None
+    if ENABLED and not isinstance(input, packed.CodeActivation) and isinstance(input, torch.Tensor) and input.is_cuda \
+            and input.dtype == torch.float32 and input.dim() == 4 and not torch.is_grad_enabled() and not layer.training \
+            and layer.bit_width == 1:
+        codes = packed.lookup_codes(input, packed.NHWC)
+        N, C, H, W = (int(v) for v in input.shape)
+        if codes is not None and codes.K == C and codes.rows == N * H * W:
+            cand = packed.CodeActivation(codes, (N, C, H, W))
+            if _dorefa_can_defer(layer, cand):
+                tagged, input = input, cand
+    if ENABLED and _dorefa_can_defer(layer, input):
+        N, C, H, W = (int(v) for v in input.shape)
+        kh, kw = layer.kernel_size
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
+        if Ho > 0 and Wo > 0 and 127 * kh * kw * int(input.codes.codes.shape[1]) < (1 << 24):
+            STATS["deferred"] += 1
+            node = _Node(None, None, (N, int(layer.out_channels), int(Ho), int(Wo)), layer=layer, kind="dorefa", input=input)
+            node.stamp += _stamp(tagged)          # the fp32 tensor whose code tag is being used
+            return _wrap(node)
+    return layer._forward_impl(tagged if tagged is not None else input)
+
+
+class _CodeShapeOnly(packed.CodeActivation):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
 
 
 class _ShapeOnly(packed.PackedActivation):

@@ -230,3 +230,66 @@ def test_module_graph_in_a_hipgraph(dev):
         x2 = torch.randn_like(x)
         assert torch.equal(graphed(x2), m(x2))
     assert torch.equal(y, ref)
+
+
+# ---- DoReFa chains: conv -> BatchNorm [-> + shortcut] -> ReLU -> nnDorefaQuant(k) ------------------------------------
+
+def _resnet(dev, seed=4):
+    torch.manual_seed(seed)
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_var.mul_(4.0)
+    return m.to(dev).to(memory_format=torch.channels_last).eval()
+
+
+def test_dorefa_resnet_blocks_run_in_the_code_epilogue_and_equal_the_fused_form(dev):
+    from pytorch_quantize_impls_amd import packed
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    m = _resnet(dev)
+    fused_blocks = nn.Sequential(*[bench_models._FusedDorefaBlock(b, 4, True, 1) for b in m.blocks])
+    x = torch.randn(8, 64, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        q = nnDorefaQuant(4)(torch.relu(x))                       # fp32 image + int8 code tag
+        codes = packed.lookup_codes(q, packed.NHWC)
+        assert codes is not None
+        ref = fused_blocks(packed.CodeActivation(codes, tuple(q.shape))).float()
+        before = dict(_lib.call_counts)
+        lazy.STATS.clear()
+        y = m.blocks(q)
+        assert isinstance(y, lazy.LazyActivation) and y._qt.quant == 4
+        got = y + 0
+        with lazy.eager():
+            e = m.blocks(q)
+    assert torch.equal(got, ref)
+    # 16 block convs run with the code epilogue; the 3 shortcut convs give the fp32 residual their BatchNorm is folded over
+    assert lazy.STATS["deferred"] == 19 and lazy.STATS["fused"] == 16 and lazy.STATS["materialised"] == 4, lazy.STATS
+    assert _lib.call_counts["qt_conv2d_implicit_codes"] - before.get("qt_conv2d_implicit_codes", 0) >= 13
+    # against the module-by-module evaluation (MIOpen BatchNorm, separate add / ReLU / quantiser passes): the same codes
+    # except where a value sits within an ulp of a quantiser step
+    lvl = 1.0 / 15.0
+    d = (got - e).abs()
+    assert float(d.max()) <= 2 * lvl + 1e-6 and float((d > 1e-6).float().mean()) < 5e-3
+
+
+def test_dorefa_resnet_whole_model_and_escapes(dev):
+    m = _resnet(dev, 6)
+    x = torch.randn(16, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = m(x)
+        with lazy.eager():
+            e = m(x)
+        blk = m.blocks[2]                                         # stride-2 block with a conv shortcut
+        q = m.quant(torch.relu(m.bn(m.stem(x))))
+        a = m.blocks[1](m.blocks[0](q))
+        with lazy.eager():
+            ae = m.blocks[1](m.blocks[0](q))
+            t_e = blk.bn1(blk.conv1(ae))
+        t = blk.bn1(blk.conv1(a))                                 # conv -> BatchNorm, then something off the grammar
+        assert isinstance(t, lazy.LazyActivation)
+        assert torch.allclose(torch.sigmoid(t), torch.sigmoid(t_e), atol=1e-2)
+        assert type(blk.conv1(a) * 2.0) is torch.Tensor
+    assert type(y) is torch.Tensor and torch.isfinite(y).all()
+    assert (y.argmax(1) == e.argmax(1)).float().mean().item() >= 0.8
+    assert float((y - e).abs().max()) <= 0.05 * float(e.abs().max()) + 1e-3
