@@ -63,7 +63,8 @@ class _Node:
     """One recorded step.  ``parent is None``: the deferred conv itself (``layer``, ``kind``, ``input`` = device tensor or
     PackedActivation); otherwise ``op`` applied to ``parent``.  The flags summarise the chain from the root."""
     __slots__ = ("parent", "op", "layer", "kind", "input", "shape", "value", "packed_cache",
-                 "pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw", "stamp", "add", "relu", "quant", "device")
+                 "pool", "bn", "hardtanh", "flat", "signed", "pool2", "chw", "stamp", "add", "relu", "quant", "device",
+                 "captured")
 
     def __init__(self, parent: Optional["_Node"], op, shape, layer=None, kind=None, input=None):
         self.parent, self.op, self.shape = parent, op, shape          # shape: tuple of ints
@@ -76,6 +77,7 @@ class _Node:
             self.flat = self.signed = self.relu = False
             self.chw = None
             self.stamp = _stamp(input, layer.weight, layer.bias) if hasattr(layer, "weight") else ()
+            self.captured = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
             return
         p = parent
         self.layer, self.kind, self.input, self.device = p.layer, p.kind, p.input, p.device
@@ -109,6 +111,11 @@ class _Node:
         been written in place in between (version counters: load_state_dict / copy_ / optimizer steps / in-place ops)."""
         node = self
         while node is not None:
+            if node.parent is None and node.captured and not torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(
+                    "a deferred activation created while a stream was being captured (hipGraph) was not used inside the "
+                    "captured region, so its kernels are not part of the graph; end the region with an op on it (or "
+                    ".value()), use pytorch_quantize_impls_amd.utils.graphed(), or capture under lazy.eager()")
             for t, ptr, version in node.stamp:
                 if t.data_ptr() != ptr or t._version != version:
                     raise RuntimeError(
@@ -120,6 +127,14 @@ class _Node:
 
     # ---- the un-fused value ------------------------------------------------------------------------------------
     def materialise(self) -> torch.Tensor:
+        """The fp32 tensor.  Always evaluated without autograd — the mode the chain was deferred in — whatever mode the
+        first use happens in (a deferred activation never requires grad)."""
+        if self.value is None:
+            with torch.no_grad():
+                self._materialise()
+        return self.value
+
+    def _materialise(self) -> None:
         if self.value is None:
             self.check_unmodified()
             STATS["materialised"] += 1
@@ -153,7 +168,6 @@ class _Node:
                     from .functions.binary_connect import _binarize_and_tag
                     y = _binarize_and_tag(x)
             self.value = y
-        return self.value
 
     # ---- the fused execution -----------------------------------------------------------------------------------
     def force(self, halo=None):
@@ -173,13 +187,14 @@ class _Node:
             return self.packed_cache[key]
         self.check_unmodified()
         try:
-            block = _fused_block(self.layer, self.bn, self.pool, flatten=self.flat and self.pool2 is None,
-                                 halo=halo if self.pool2 is None else None)
-            act = block(self.input)
-            if self.pool2 is not None:
-                act = _packed_pool(self.pool2, halo)(act)
-                if self.flat:
-                    act = act.flatten_hwc()
+            with torch.no_grad():
+                block = _fused_block(self.layer, self.bn, self.pool, flatten=self.flat and self.pool2 is None,
+                                     halo=halo if self.pool2 is None else None)
+                act = block(self.input)
+                if self.pool2 is not None:
+                    act = _packed_pool(self.pool2, halo)(act)
+                    if self.flat:
+                        act = act.flatten_hwc()
         except ValueError:
             act = None
         if act is not None:
@@ -206,23 +221,24 @@ def _force_codes(self, halo=None):
     self.check_unmodified()
     from .layers import fused
     try:
-        blk = _code_block(self.layer, self.bn, self.quant, self.relu, halo if self.pool2 is None else (0, 0))
-        res = res_bn = None
-        if self.add is not None:
-            other = self.add
-            if isinstance(other, LazyActivation):
-                o = other._qt
-                if o.quant is not None:                       # identity shortcut: the block's own (quantised) input
-                    res = o.force_any()
-                else:                                         # conv + BatchNorm shortcut: fp32 conv output, BN folded
-                    res, res_bn = o.parent.materialise(), _bn_view(blk, o.bn)
-            else:
-                res = other
-            if res is None:
-                raise ValueError("residual cannot join the fused chain")
-        act = blk(self.input, residual=res, residual_bn=res_bn)
-        if self.pool2 is not None:
-            act = fused.CodeMaxPool(torch.nn.MaxPool2d(self.pool2[0], self.pool2[1]), out_halo=halo)(act)
+        with torch.no_grad():
+            blk = _code_block(self.layer, self.bn, self.quant, self.relu, halo if self.pool2 is None else (0, 0))
+            res = res_bn = None
+            if self.add is not None:
+                other = self.add
+                if isinstance(other, LazyActivation):
+                    o = other._qt
+                    if o.quant is not None:                       # identity shortcut: the block's own (quantised) input
+                        res = o.force_any()
+                    else:                                         # conv + BatchNorm shortcut: fp32 conv output, BN folded
+                        res, res_bn = o.parent.materialise(), _bn_view(blk, o.bn)
+                else:
+                    res = other
+                if res is None:
+                    raise ValueError("residual cannot join the fused chain")
+            act = blk(self.input, residual=res, residual_bn=res_bn)
+            if self.pool2 is not None:
+                act = fused.CodeMaxPool(torch.nn.MaxPool2d(self.pool2[0], self.pool2[1]), out_halo=halo)(act)
     except ValueError:
         act = None
     if act is not None:

@@ -7,6 +7,9 @@ requirement is a forward without host synchronisation (no un-tagged +-1 detectio
 ``binary_input = False``; no DoReFa code-overflow check inside the captured region).
 """
 import torch
+from torch.utils._pytree import tree_map_only
+
+from .. import lazy
 
 
 class GraphedModule(torch.nn.Module):
@@ -26,7 +29,10 @@ class GraphedModule(torch.nn.Module):
                 module(self._static_in)
             torch.cuda.synchronize(example_input.device)
             with torch.cuda.graph(self._graph, stream=self._stream):
-                self._static_out = module(self._static_in)
+                out = module(self._static_in)
+                # a module that ends in a quantised conv chain returns a deferred activation (lazy.py): its kernels
+                # have to be part of the graph, so it is turned into its value inside the captured region
+                self._static_out = tree_map_only(lazy.LazyActivation, lambda t: t.value(), out)
         torch.cuda.synchronize(example_input.device)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

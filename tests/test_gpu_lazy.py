@@ -152,6 +152,26 @@ def test_nothing_is_deferred_with_autograd_training_or_cpu(dev):
     assert lazy.STATS["deferred"] == 1
 
 
+def test_first_use_outside_no_grad(dev):
+    """Deferred under no_grad, used after the block ended (autograd on again): evaluated as deferred, by the HIP path."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d
+    seq = _block(dev, BinConv2d, 64, 128, pool=False)
+    x = _pm1((2, 64, 12, 12), dev)
+    dconv = DorefaConv2d(16, 32, 3, padding=1, bit_width=1).to(dev).eval()
+    xq = torch.rand(2, 16, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        with lazy.eager():
+            e, q = seq[0](x), nnDorefaQuant(4)(xq)
+            ed = dconv(q)
+        y, yd = seq[0](x), dconv(q)
+    assert isinstance(yd, lazy.LazyActivation)
+    assert torch.is_grad_enabled()
+    v, vd = y * 1.0, yd * 1.0
+    assert torch.equal(v, e) and torch.equal(vd, ed) and not v.requires_grad and not vd.requires_grad
+    assert not _fused.LIBRARY_PATHS, _fused.LIBRARY_PATHS
+
+
 def test_inference_mode_and_hooks(dev):
     a, b = _block(dev, BinConv2d, 64, 128, pool=True), _block(dev, BinConv2d, 128, 64, pool=False)
     x = _pm1((2, 64, 16, 16), dev)
@@ -293,3 +313,33 @@ def test_dorefa_resnet_whole_model_and_escapes(dev):
     assert type(y) is torch.Tensor and torch.isfinite(y).all()
     assert (y.argmax(1) == e.argmax(1)).float().mean().item() >= 0.8
     assert float((y - e).abs().max()) <= 0.05 * float(e.abs().max()) + 1e-3
+
+
+def test_deferred_output_and_stream_capture(dev):
+    """A graph whose output is a deferred activation: utils.graphed turns it into its value inside the capture; a manual
+    capture that lets it escape is an error, not a tensor that replays would never update."""
+    from pytorch_quantize_impls_amd import utils
+    seq = _block(dev, BinConv2d, 64, 128, pool=True)[:3]          # conv -> pool -> BatchNorm: the output stays deferred
+    seq[0].binary_input = True                                    # no +-1 detection (a host sync) inside the capture
+    x = _pm1((2, 64, 16, 16), dev)
+    with torch.no_grad():
+        with lazy.eager():
+            e = seq(x)
+        assert isinstance(seq(x), lazy.LazyActivation)
+        g = utils.graphed(seq, x)
+        assert type(g(x)) is torch.Tensor and torch.equal(g(x), e)
+        x2 = -x
+        with lazy.eager():
+            e2 = seq(x2)
+        assert torch.equal(g(x2), e2)
+        s = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        xs = x.clone()
+        with torch.cuda.stream(s):
+            seq(xs) + 0
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=s):
+                out = seq(xs)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="captured"):
+            out + 0
