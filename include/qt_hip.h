@@ -10,8 +10,7 @@
  *   - plain `extern "C"`, raw DEVICE pointers + explicit sizes/strides, no torch types;
  *   - stateless and re-entrant: no allocation, no ownership transfer, no process-global state of any kind (kernel
  *     variants for tests / tuning are ARGUMENTS of the *_variant entry points); the only thing that survives a call is
- *     what it wrote into caller-provided buffers (results, and for qt_linear_fused_f32 the launch bookkeeping inside the
- *     workspace the caller hands it);
+ *     what it wrote into caller-provided buffers;
  *   - work is enqueued on `stream` (a hipStream_t, passed as an opaque pointer; NULL = the
  *     default stream) and the call returns without synchronising;
  *   - the caller has already made the right device current (hipSetDevice);
@@ -210,22 +209,6 @@ int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, in
 int qt_pack_pair_nib_f32(const float* x, int64_t ldx, uint32_t* x_plane, int64_t ldxp, int64_t rows_x,
                          const float* w, int64_t ldw, uint32_t* w_plane, int64_t ldwp, int64_t rows_w,
                          int64_t K, int w_ternary, qt_stream_t stream);
-
-/* LinearBin / LinearTer TRAINING-MODE forward as ONE launch: y = safeSign(x) . Q(w)^T (+ bias) from the fp32 tensors,
- * Q = safeSign (w_ternary = 0; layers/binary_layers.py:44) or TernaryConnectDeterministic (1; layers/terner_layers.py:49).
- * Packing of both operands (HBM-bound) and the MX-fp4 MFMA contraction (matrix-bound) run overlapped inside one
- * persistent launch of (M/256)*(N/256) co-resident workgroups that hand nibble chunks to each other through
- * `workspace` (csrc/linear_fused.hip).  Same integers as qt_pack_pair_nib_f32 + qt_nib_gemm.
- * Shapes: qt_linear_fused_workspace_bytes(M, N, K) returns 0 for a shape this entry does not take (today: M = N = 4096,
- * K a multiple of 512 in [3072, 65536]; the device needs one CU per 256x256 tile) — callers fall back to the
- * two-launch route — else the size of `workspace`: 4 KiB-aligned device memory, ZERO-FILLED ONCE by the caller before
- * its first use and from then on owned by this entry point (launch bookkeeping that survives between calls; it holds
- * no results).  Word 2 of the workspace is an error flag: non-zero after a launch means a hand-off timed out (a
- * workgroup was not resident) and y is invalid.  x must hold +-1 (as for qt_pack_pair_nib_f32). */
-int64_t qt_linear_fused_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int qt_linear_fused_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                        int64_t ldy, int64_t M, int64_t N, int64_t K, int w_ternary, void* workspace,
-                        int64_t workspace_bytes, qt_stream_t stream);
 
 /* Y[M,N] = Xn . Wn^T (+ bias): replaces the same F.linear call sites as qt_xnor_gemm /
  * qt_tern_gemm (binary and ternary weights share this entry point: zero is a nibble value). */

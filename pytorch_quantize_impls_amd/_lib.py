@@ -70,9 +70,6 @@ SIGNATURES = {
     "qt_ternary_pack_nib_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_pack_pair_nib_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64,
                                       _c_int, _c_p]),
-    "qt_linear_fused_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
-    "qt_linear_fused_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p,
-                                     _c_i64, _c_p]),
     "qt_nib_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -1,4 +1,4 @@
-// Device helpers shared by the matrix-core kernels (mfma_gemm.hip, linear_fused.hip): vector types, the LDS chunk
+// Device helpers shared by the matrix-core kernels (mfma_gemm.hip; tools/experiments/linear_fused.hip): vector types, the LDS chunk
 // swizzle of a K stage and the inline-asm LDS-DMA forms.  Everything is static / inline: each translation unit
 // gets its own copy.
 #pragma once

@@ -1665,56 +1665,6 @@ def pack_linear_operands(x: torch.Tensor, w: torch.Tensor, kind: str = "binary",
     return NibPlanes(words=xn, rows=M, K=K), NibPlanes(words=wn, rows=N, K=K)
 
 
-# ---- one-launch training-mode linear forward (csrc/linear_fused.hip) -------------------------------------------
-_FUSED_WS = {}   # (device index, M, N, K) -> zero-initialised workspace, owned by the entry point between calls
-
-
-def linear_fused_supported(M: int, N: int, K: int) -> bool:
-    """True when qt_linear_fused_f32 takes the shape (it answers through its workspace size)."""
-    return int(_lib.load().qt_linear_fused_workspace_bytes(int(M), int(N), int(K))) > 0
-
-
-def linear_fused_workspace(device, M: int, N: int, K: int) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(M), int(N), int(K))
-    ws = _FUSED_WS.get(key)
-    if ws is None:
-        nbytes = int(_lib.load().qt_linear_fused_workspace_bytes(int(M), int(N), int(K)))
-        if nbytes <= 0:
-            raise NotImplementedError(f"qt_linear_fused_f32 does not take M={M}, N={N}, K={K}")
-        raw = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=device)
-        off = (-raw.data_ptr()) % 4096
-        ws = raw[off:off + nbytes]
-        _FUSED_WS[key] = ws
-    return ws
-
-
-def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, kind: str = "binary",
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """safeSign(x) . Q(w)^T (+ bias) from the fp32 tensors in ONE launch (pack of both operands overlapped with the
-    matrix-core GEMM).  x must hold +-1; raises NotImplementedError for shapes the entry point does not take."""
-    _require(x, "input")
-    _require(w, "weight")
-    x2, w2 = _as_rows(x), _as_rows(w.reshape(w.shape[0], -1))
-    (M, K), (N, Kw) = (int(v) for v in x2.shape), (int(v) for v in w2.shape)
-    if K != Kw:
-        raise ValueError(f"K mismatch: activations {K} vs weights {Kw}")
-    ws = linear_fused_workspace(x.device, M, N, K)
-    bias = _check_bias(bias, N, x.device)
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    I = int
-    with _on(x.device):
-        _lib.call("qt_linear_fused_f32", _p(x2), I(x2.stride(0)), _p(w2), I(w2.stride(0)), _p(bias), _p(out),
-                  I(out.stride(0)), I(M), I(N), I(K), int(0 if kind == "binary" else 1), _p(ws), I(ws.numel()),
-                  _stream(x.device))
-    return out
-
-
-def linear_fused_error(device, M: int, N: int, K: int) -> int:
-    """Error word of the shape's workspace (synchronises): non-zero = a hand-off of some launch timed out."""
-    return int(linear_fused_workspace(device, M, N, K)[8:12].view(torch.int32).item())
-
-
 def to_impl(planes, impl: str):
     """Convert packed operands to the format ``impl`` consumes (bit planes -> nibble planes only)."""
     if impl == "valu":

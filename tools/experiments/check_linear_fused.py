@@ -1,6 +1,6 @@
 """GPU check + timing of qt_linear_fused_f32 against the two-launch route (qt_pack_pair_nib_f32 + qt_nib_gemm).
 
-    python tools/check_linear_fused.py [--iters 200] [--K 4096]
+    python tools/experiments/check_linear_fused.py [--iters 200] [--K 4096]
 
 Bit-exact comparison on fresh data every launch (a stale hand-off would show up as a mismatch), edge values in the
 weights, ternary weights, bias; then stream-time per call of both routes (HIP events around `iters` back-to-back calls).
@@ -11,7 +11,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lf  # noqa: E402  (also puts the repo root on sys.path)
 from pytorch_quantize_impls_amd import ops  # noqa: E402
 
 
@@ -40,10 +41,10 @@ def main():
             edge = torch.tensor([0.0, -0.0, float("nan"), 1e-45, -1e-45, 0.5, -0.5, float("inf"), -float("inf")], device=dev)
             w.view(-1)[: edge.numel() * 1000] = edge.repeat(1000)
         bias = torch.randn(N, device=dev, generator=g) if r % 2 else None
-        y = ops.linear_fused(x, w, bias, kind)
+        y = lf.linear_fused(x, w, bias, kind)
         ref = two_launch(x, w, bias, kind)
         torch.cuda.synchronize()
-        err = ops.linear_fused_error(dev, M, N, K)
+        err = lf.linear_fused_error(dev, M, N, K)
         same = torch.equal(y, ref)
         nbad = int((y != ref).sum().item()) if not same else 0
         print(f"round {r} kind={kind} bias={bias is not None}: equal={same} mismatches={nbad} error_word={err}", flush=True)
@@ -62,7 +63,7 @@ def main():
     # back-to-back launches on changing data (the counter sets alternate; a stale panel would be caught at the end)
     xs = [torch.where(torch.rand((M, K), device=dev, generator=g) < 0.5, -1.0, 1.0) for _ in range(3)]
     ws = [torch.randn((N, K), device=dev, generator=g) / 64 for _ in range(3)]
-    outs = [ops.linear_fused(xs[i % 3], ws[(i * 2) % 3], None, "binary").clone() for i in range(9)]
+    outs = [lf.linear_fused(xs[i % 3], ws[(i * 2) % 3], None, "binary").clone() for i in range(9)]
     torch.cuda.synchronize()
     for i in range(9):
         ref = two_launch(xs[i % 3], ws[(i * 2) % 3], None, "binary")
@@ -87,11 +88,11 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / a.iters
 
-    t_f = timeit(lambda: ops.linear_fused(x, w, None, "binary", out=y))
+    t_f = timeit(lambda: lf.linear_fused(x, w, None, "binary", out=y))
     t_2 = timeit(lambda: two_launch(x, w, None, "binary"))
     byt = 4.0 * (M * K + N * K + M * N)
     print(f"fused: {t_f:.1f} us/call ({byt / t_f / 1e6:.2f} TB/s = {byt / t_f / 8e6:.3f} of 8 TB/s)   "
-          f"two-launch: {t_2:.1f} us/call ({byt / t_2 / 8e6:.3f})   error_word={ops.linear_fused_error(dev, M, N, K)}")
+          f"two-launch: {t_2:.1f} us/call ({byt / t_2 / 8e6:.3f})   error_word={lf.linear_fused_error(dev, M, N, K)}")
     print("RESULT", "PASS" if ok else "FAIL")
     return 0 if ok else 1
 

@@ -30,9 +30,14 @@
 // everything issued two or more stages ago has completed: the DMA of the next stage, the fp32 loads converted in the
 // next stage, the store whose signal goes out in the next stage and the poll that is checked in the next stage.
 //
-// STATUS (round 2, MI355X, 4096^3, tools/check_linear_fused.py / tools/stamps_fused.py): bit-identical to the two-launch
-// route on every case, but SLOWER: 76 us per call against 60 us for qt_pack_pair_nib_f32 + qt_nib_gemm, so nothing
-// dispatches here by default (ops.linear_fused is explicit).  Where the time goes (median workgroup, us since launch):
+// STATUS (round 2, MI355X, 4096^3): EXPERIMENT, not part of libqt_hip.so (built by tools/experiments/lf.py).
+//  * check_linear_fused.py / stamps_fused.py: bit-identical to the two-launch route on an otherwise idle device, but
+//    SLOWER: 76 us per call against 60 us for qt_pack_pair_nib_f32 + qt_nib_gemm.
+//  * stress_linear_fused.py: with another stream's kernel occupying CUs (workgroups start staggered, consumers already
+//    spinning when a signal lands) EVERY launch has a stale (panel, chunk) hand-off with error word 0; -DLF_FIX=1 (agent
+//    release before each signal) -> 4 / 300 launches stale at 436 us per call, -DLF_FIX=2 (agent acquire after the check)
+//    -> no change.  The write-through store + counted vmcnt + atomic flag form below is therefore NOT a valid hand-off
+//    under uneven load, and the entry point was removed from the library.  Where the time goes (median workgroup, us since launch):
 // fill done 15.0 (slowest 20.3: the K-major column-panel order reads HBM at 4.7 TB/s and unevenly, the row-streaming
 // pack kernel gets 6.1) -> chunk 0 complete from all 16 partners 20.8 -> loop start 24.1 -> 12 stages with packing done
 // 45.4 (1.75 us per stage) -> 20 drain stages done 62.5 (0.85 us per stage; the plain GEMM loop runs 0.57-0.68) ->
@@ -267,6 +272,9 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
             "s_cbranch_scc1 1b\n\t"
             "s_or_b32 %[err], %[err], 1\n"
             "2:"
+#if defined(LF_FIX) && (LF_FIX & 2)
+            "\n\tbuffer_inv sc1"
+#endif
             : [vx] "+v"(vx), [vw] "+v"(vw), [it] "=&s"(it), [t] "=&s"(t), [err] "+s"(spin_err), [cnt] "+s"(spin_count)
             : [off] "v"(c * 4), [px] "s"(pollX), [pw] "s"(pollW), [need] "n"(LF_ARRIVALS), [lim] "s"(LF_SPIN_MAX)
             : "memory", "scc");
@@ -274,6 +282,9 @@ __global__ __launch_bounds__(LF_NTHREADS, 2) void linear_fused_kernel(
     // one device-scope atomic from lane 0 only, EXEC narrowed inside the statement (an `if (lane == 0)` is a branch)
     auto signal = [&](int c, unsigned inc) {
         unsigned long long keep;
+#if defined(LF_FIX) && (LF_FIX & 1)
+        asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#endif
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3\n\ts_mov_b64 exec, %0"
                      : "=&s"(keep) : "v"(c * 4), "v"(inc), "s"(mycnt) : "memory");
     };

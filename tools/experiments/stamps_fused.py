@@ -1,18 +1,18 @@
 """Phase stamps of the fused linear kernel.  Needs a library built with the stamps variant (the product build has none):
 
-    cd pytorch_quantize_impls_amd/csrc && make clean && make HIPCC="/opt/rocm/bin/hipcc -DQT_LF_STAMPS" OUT=../lib/libqt_hip_stamps.so
-    QT_HIP_LIB=pytorch_quantize_impls_amd/lib/libqt_hip_stamps.so python tools/stamps_fused.py
+    python tools/experiments/lf.py -DQT_LF_STAMPS && python tools/experiments/stamps_fused.py
 """
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lf  # noqa: E402  (also puts the repo root on sys.path)
 from pytorch_quantize_impls_amd import ops
 dev = torch.device("cuda:0")
 M = N = K = 4096
 x = torch.where(torch.rand((M, K), device=dev) < 0.5, -1.0, 1.0)
 w = torch.randn((N, K), device=dev) / 64
 for _ in range(5):
-    y = ops.linear_fused(x, w, None, "binary")
+    y = lf.linear_fused(x, w, None, "binary")
 torch.cuda.synchronize()
 yb = y.cpu().numpy()
 names = ["start", "fill issued", "fill drained", "chunk0 ready", "loop start", "phase1 end", "loop end", "epi issued", "epi drained"]

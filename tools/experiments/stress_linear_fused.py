@@ -6,7 +6,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lf  # noqa: E402  (also puts the repo root on sys.path)
 from pytorch_quantize_impls_amd import ops, synth  # noqa: E402
 
 
@@ -36,9 +37,9 @@ def main():
             big.mul_(1.0)                          # memory-bound work queued right in front on the same stream
         elif mode == 3:
             torch.cuda.synchronize()
-        y = ops.linear_fused(x, ws[i], None, kind)
+        y = lf.linear_fused(x, ws[i], None, kind)
         ok = bool(torch.equal(y, refs[(kind, i)]))
-        err = ops.linear_fused_error(dev, B, N, K)
+        err = lf.linear_fused_error(dev, B, N, K)
         if not ok or err:
             bad += 1
             diff = int((y != refs[(kind, i)]).sum())
