@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Results must not depend on what else the device is doing: the C2 step (pack + matrix-core GEMM, popcount GEMM), the
+fused AlexNet forward and the DoReFa ResNet-18 forward are repeated while a long library GEMM runs on ANOTHER stream (the
+workgroups of the kernels under test then start staggered, on whatever CUs are free) and compared bit for bit with the
+results obtained on the quiet device."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench_models  # noqa: E402
+from pytorch_quantize_impls_amd import ops, synth  # noqa: E402
+
+
+def run(iters: int = 60, verbose: bool = True) -> dict:
+    dev = torch.device("cuda:0")
+    B = K = N = 4096
+    x = torch.from_numpy(synth.pm1(1, (B, K))).to(dev)
+    w = torch.from_numpy(synth.uniform(2, (N, K), -1.0, 1.0)).to(dev)
+    torch.manual_seed(0)
+    alex = bench_models.AlexNetBin()
+    bench_models.randomize_bn(alex)
+    alex = alex.to(dev).to(memory_format=torch.channels_last).eval()
+    xa = torch.randn(64, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    res = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(res, seed=3)
+    res = res.to(dev).to(memory_format=torch.channels_last).eval()
+    xr = torch.randn(128, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def c2(kind, impl):
+        xp, wp = ops.pack_linear_operands(x, w, kind, impl)
+        return ops.packed_gemm(xp, wp, None, impl=impl)
+
+    cases = {"c2 binary mfma": lambda: c2("binary", "mfma"), "c2 ternary mfma": lambda: c2("ternary", "mfma"),
+             "c2 binary popcount": lambda: c2("binary", "valu"), "alexnet module graph": lambda: alex(xa),
+             "dorefa resnet18 module graph": lambda: res(xr)}
+    side = torch.cuda.Stream(device=dev)
+    big = torch.randn(8192, 8192, device=dev)
+    bad = {k: 0 for k in cases}
+    with torch.no_grad():
+        quiet = {k: f().clone() for k, f in cases.items()}
+        torch.cuda.synchronize()
+        for it in range(iters):
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    big @ big
+            for k, f in cases.items():
+                y = f()
+                if not torch.equal(y, quiet[k]):
+                    bad[k] += 1
+                    if verbose:
+                        print(f"it {it} {k}: {int((y != quiet[k]).sum())} mismatches", flush=True)
+        torch.cuda.synchronize()
+    return bad
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    bad = run(iters)
+    print(f"{iters} rounds under concurrent load:", {k: f"{v} bad" for k, v in bad.items()})
+    sys.exit(1 if any(bad.values()) else 0)
+
+
+if __name__ == "__main__":
+    main()
