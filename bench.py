@@ -465,12 +465,22 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         el_u = timed(eager4)
         el_d = timed(lambda: m4(x4), 2 * iters)
         el_f = timed(lambda: f4(x4), 2 * iters)
+        # the deferred forward is ~1.7 ms of Python for < 1 ms of GPU work: replayed as a hipGraph (utils.graphed captures
+        # the un-modified module; same kernels, no host work)
+        from pytorch_quantize_impls_amd import utils
+        g4 = utils.graphed(m4, x4)
+        with torch.no_grad():
+            same_g = bool(torch.equal(g4(x4), m4(x4)))
+        el_g = timed(lambda: g4(x4), 2 * iters)
         out["c4_dorefa_resnet18_w1a4"] = {
             # the un-modified module graph: DorefaConv2d layers return deferred activations, BatchNorm / shortcut add / ReLU /
             # nnDorefaQuant are recorded and run in the conv's code epilogue (lazy.py); the fp32 stem stays module by module
             "module_graph": _net_line("c4", Bc, world, 2 * iters, el_d, st4, 5000.0,
                                       "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                       {"argmax_agreement_with_unfused": agree_d}),
+            "module_graph_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_g, st4, 5000.0,
+                                               "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                               {"same_logits_as_module_graph": same_g}),
             "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54"),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                {"argmax_agreement_with_unfused": agree}),
