@@ -76,3 +76,46 @@ def test_everything_else_materialises():
         lz2 += 1
         assert torch.equal(lz2, x * 2 + 1)
     assert lazy.STATS["materialised"] > 0
+
+
+def test_a_deferred_activation_behaves_like_the_tensor_it_stands_for():
+    """Everything user code can do to a conv output: the value comes out, computed once, never requiring grad."""
+    import copy
+    import io
+    import pickle
+
+    import numpy as np
+    x = torch.randn(2, 3, 4, 4)
+    ref = x * 2
+
+    def save_load(t):
+        b = io.BytesIO()
+        torch.save(t, b)
+        b.seek(0)
+        return torch.load(b, weights_only=False)
+
+    uses = {
+        "deepcopy": lambda t: torch.equal(copy.deepcopy(t), ref), "clone": lambda t: torch.equal(t.clone(), ref),
+        "detach": lambda t: torch.equal(t.detach(), ref), "data": lambda t: torch.equal(t.data, ref),
+        "numpy": lambda t: np.array_equal(t.numpy(), ref.numpy()), "asarray": lambda t: np.array_equal(np.asarray(t), ref.numpy()),
+        "tolist": lambda t: t.tolist() == ref.tolist(), "index": lambda t: torch.equal(t[0], ref[0]),
+        "iter": lambda t: all(torch.equal(a, b) for a, b in zip(t, ref)), "item": lambda t: t.sum().item() == ref.sum().item(),
+        "to": lambda t: torch.equal(t.to(torch.float64), ref.double()), "stride": lambda t: t.stride() == ref.stride(),
+        "contiguous": lambda t: t.is_contiguous() and torch.equal(t.contiguous(), ref), "data_ptr": lambda t: t.data_ptr() != 0,
+        "pickle": lambda t: torch.equal(pickle.loads(pickle.dumps(t)), ref), "save": lambda t: torch.equal(save_load(t), ref),
+        "as_tensor": lambda t: torch.equal(torch.as_tensor(t), ref), "stack": lambda t: torch.equal(torch.stack([t, t]), torch.stack([ref, ref])),
+        "matmul": lambda t: torch.equal(t @ t.mT, ref @ ref.mT), "permute": lambda t: torch.equal(t.permute(0, 2, 3, 1), ref.permute(0, 2, 3, 1)),
+        "compare": lambda t: torch.equal(t > 0, ref > 0), "mul_": lambda t: torch.equal(t.mul_(2), ref * 2),
+        "conv": lambda t: torch.equal(F.conv2d(t, torch.ones(1, 3, 1, 1)), F.conv2d(ref, torch.ones(1, 3, 1, 1))),
+        "module": lambda t: nn.AdaptiveAvgPool2d(1)(t).shape == (2, 3, 1, 1), "repr": lambda t: repr(t).startswith("tensor"),
+        "zeros_like": lambda t: torch.zeros_like(t).shape == ref.shape, "unbind": lambda t: len(t.unbind(0)) == 2,
+        "shape": lambda t: tuple(t.shape) == (2, 3, 4, 4) and t.size(-1) == 4 and t.shape[1] == 3,
+    }
+    with torch.no_grad():
+        for name, use in uses.items():
+            assert use(_lazy(x)), name
+    w = torch.ones(2, 3, 1, 1, requires_grad=True)          # first use with autograd on: a constant of the graph
+    t = _lazy(x)
+    y = F.conv2d(t, w)
+    y.sum().backward()
+    assert w.grad is not None and not (t * 2).requires_grad
