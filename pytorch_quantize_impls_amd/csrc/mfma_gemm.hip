@@ -63,6 +63,11 @@ struct ConvArgs {
     int cpp;                       // 16-byte chunks per pixel
     int kbytes;                    // K bytes per (virtual) im2col row
     unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
+    // GEMM mode, bf16 only (qt_bf16_gemm_taps): a launch of blockIdx.y = tap * z_nslice + slice problems of one shape —
+    // X and W advance by z_kslice_bytes per slice along K, W additionally by the tap's offset (tap = row * z_kw + col:
+    // col * z_w_copy_bytes + row * z_w_row_bytes), Y by z_y_stride floats per problem.  z_nslice == 0: a plain launch.
+    int z_nslice = 0, z_kw = 1;
+    long long z_kslice_bytes = 0, z_w_copy_bytes = 0, z_w_row_bytes = 0, z_y_stride = 0;
 };
 
 // Threshold-bit epilogue (inference fusion of conv -> [MaxPool] -> BatchNorm(eval) -> Hardtanh -> sign):
@@ -266,6 +271,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     const int64_t ldx_b = ldx * 4, ldw_b = ldw * 4;  // row strides in bytes
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
+    if constexpr (!C::CONV && std::is_same<E, ElemBf16>::value) {
+        if (cg.z_nslice > 0) {
+            // dispatch order: taps fastest, so the workgroups running at the same time walk the SAME K slice of X (and
+            // shifted views of the same W rows): one HBM read serves all taps through the L2s / MALL
+            const int z = blockIdx.y, slice = z / cg.H, tap = z - slice * cg.H;
+            const int tr = tap / cg.z_kw, tc = tap - tr * cg.z_kw;
+            Xb += (int64_t)slice * cg.z_kslice_bytes;
+            Wb += (int64_t)slice * cg.z_kslice_bytes + (int64_t)tc * cg.z_w_copy_bytes + (int64_t)tr * cg.z_w_row_bytes;
+            Y += ((int64_t)tap * cg.z_nslice + slice) * cg.z_y_stride;
+        }
+    }
 
     acc_t acc[C::TMW][C::TNW];
 #pragma unroll
@@ -891,7 +907,8 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
         return QT_ERR_LAUNCH;
-    hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3(grid), dim3(C::NTHREADS),
+    const unsigned nz = (!C::CONV && cg.z_nslice > 0) ? (unsigned)(cg.z_nslice * cg.H) : 1u;   // GEMM batch: cg.H = taps
+    hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3(grid, nz), dim3(C::NTHREADS),
                        lds_bytes, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,
                        (int)M, (int)N, (int)K, cg, epi);
     return qt_check_launch();
@@ -1273,6 +1290,36 @@ int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t l
     const int rc = check_common(Xh, ldxp, Wh, ldwp, Y, ldy, M, N, K, (K + 1) / 2);
     if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
     return dispatch_gemm<ElemBf16>(0, Xh, ldxp, Wh, ldwp, bias, 1.0f, nullptr, Y, ldy, M, N, K, stream);
+}
+
+int qt_bf16_gemm_taps(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, float* Y, int64_t ldy,
+                      int64_t M, int64_t N, int64_t K, int64_t tap_rows, int64_t tap_cols, int64_t nslice,
+                      int64_t w_copy_bytes, int64_t w_row_bytes, int64_t y_stride, qt_stream_t stream) {
+    const int rc = check_common(Xh, ldxp, Wh, ldwp, Y, ldy, M, N, K, 0);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    if (tap_rows < 1 || tap_cols < 1 || nslice < 1 || tap_rows * tap_cols * nslice > 65535) return QT_ERR_INVALID_ARG;
+    if (K <= 0 || (K & 31)) return QT_ERR_ALIGNMENT;                       // whole 64-byte stages per slice
+    if ((w_copy_bytes | w_row_bytes) & 15) return QT_ERR_ALIGNMENT;        // every tap's W base stays 16-byte aligned
+    if (y_stride < M * ldy || (ldy & 3) || !qt_aligned16(Y) || (y_stride & 3)) return QT_ERR_ALIGNMENT;
+    if ((ldxp & 31) || (ldwp & 31) || M * ldxp * 4 >= (1ll << 31) || N * ldwp * 4 >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    ConvArgs cg{};
+    cg.H = (int)(tap_rows * tap_cols);
+    cg.z_nslice = (int)nslice;
+    cg.z_kw = (int)tap_cols;
+    cg.z_kslice_bytes = K * 2;
+    cg.z_w_copy_bytes = w_copy_bytes;
+    cg.z_w_row_bytes = w_row_bytes;
+    cg.z_y_stride = y_stride;
+#define QT_GOZ(...) return launch_cfg<__VA_ARGS__>(Xh, ldxp, Wh, ldwp, nullptr, 1.0f, nullptr, Y, ldy, M, N, K, stream, cg)
+    const int tn = pick_tile_n(N);
+    if (tn == 256) QT_GOZ(PP256<ElemBf16>);
+    if (tn == 192) {
+        if ((M + 383) / 384 * 384 <= (M + 255) / 256 * 256) QT_GOZ(PP384x192<ElemBf16>);
+        QT_GOZ(PP192<ElemBf16>);
+    }
+    if (tn == 128) QT_GOZ(PP128<ElemBf16>);
+    QT_GOZ(PP64<ElemBf16>);
+#undef QT_GOZ
 }
 
 int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,

@@ -464,12 +464,17 @@ class QuantConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = None
             if mfma and ctx.x_is_pm1:     # +-1 activation x real gradient, contraction over the pixels
-                gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
-            if gw is None:
-                note_library_path(go, "conv grad_weight outside the matrix-core route")
-                gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
-                                                 dilation=dilation, groups=groups)
-            grad_weight = ste_mask(gw.contiguous(), weight)
+                if ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
+                    # batched bf16 GEMMs over K-major planes; the STE mask of the weight quantiser is its epilogue
+                    grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, weight=weight)
+                if grad_weight is None:
+                    gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
+            if grad_weight is None:
+                if gw is None:
+                    note_library_path(go, "conv grad_weight outside the matrix-core route")
+                    gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
+                                                     dilation=dilation, groups=groups)
+                grad_weight = ste_mask(gw.contiguous(), weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None, None, None, None

@@ -1548,6 +1548,105 @@ def conv2d_grad_weight_pm1(x_pm1: torch.Tensor, grad_output: torch.Tensor, kerne
     return gw.contiguous()
 
 
+#: working-set budget (bytes) of one weight-gradient GEMM launch (operand planes + partial results); larger batches are
+#: processed in chunks whose results are accumulated
+WGRAD_GEMM_BYTES = 6 << 30
+#: workgroups one weight-gradient launch aims for (K slices = this / (tiles x taps))
+WGRAD_WORKGROUPS = 1024
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def wgrad_gemm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
+    """Shapes for which conv2d_grad_weight_gemm beats the fp32 library (tools/check_wgrad_gemm.py, batch 256, MI355X):
+    27 x 27 x 192 -> 576 k5 5.1 vs 11.1 ms, 13 x 13 x 576 -> 1152 2.4 vs 4.2, 13 x 13 x 1152 -> 768 3.0 vs 5.5, 28 x 28 x
+    512 -> 512 4.0 vs 7.5, 14 x 14 x 512 -> 512 1.2 vs 1.9; it loses on big maps with few channels (56 x 56 x 256 -> 256 10.6 vs
+    7.1, 224 x 224 x 64 -> 64 14 vs 1.3 at batch 32: every tap re-reads the gradient planes and the tiles are narrow)."""
+    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    return (sh == sw == 1 and dh == dw == 1 and kw <= 8 and int(g_shape[2]) * int(g_shape[3]) <= 1024
+            and int(x_shape[1]) >= 128 and int(g_shape[1]) >= 128)
+
+
+def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
+                            weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD):
+    """grad wrt the weight of a STRIDE-1, un-dilated conv2d(x, Q(W)) for an activation whose values are exact in bf16
+    (+-1 / 0): batched bf16 matrix-core GEMMs over K-major operand planes (csrc/wgrad.hip).  ``weight``: apply the
+    quantiser's straight-through mask 1[|W| <= ste_threshold] to the result.  Returns [Cout, Cin, kh, kw] fp32, or None
+    when the shape is outside the route."""
+    _require(x_pm1, "input")
+    _require(grad_output, "grad_output")
+    kh, kw = (int(v) for v in kernel_hw)
+    ph, pw = _pairs(padding)
+    N, Cin, H, W = (int(v) for v in x_pm1.shape)
+    N2, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    if N2 != N or Ho != H + 2 * ph - kh + 1 or Wo != W + 2 * pw - kw + 1 or Ho <= 0 or Wo <= 0 or kw > 8 or N == 0:
+        return None
+    Wq = _round_up(W + 2 * pw, 8)
+    Hp = H + 2 * ph
+    M, taps = 3 * Cout, kh * kw
+    ldc = _round_up(Cin, 4)
+    tn = 256
+    for c in (192, 128, 64):                                  # the GEMM's own tile-width rule (pick_tile_n)
+        if _round_up(Cin, c) < _round_up(Cin, tn):
+            tn = c
+    tm = 384 if (tn == 192 and _round_up(M, 384) <= _round_up(M, 256)) else 256
+    tiles = (_round_up(M, tm) // tm) * (_round_up(Cin, tn) // tn)
+    nslice = max(1, min(64, -(-WGRAD_WORKGROUPS // (tiles * taps))))
+
+    def plan(nc):
+        ktot = Ho * nc * Wq
+        ks = _round_up(-(-ktot // nslice), 32)
+        kpad = ks * nslice
+        lda = _round_up(kpad, 64)
+        ldb = _round_up(max(Hp * nc * Wq, (kh - 1) * nc * Wq + kpad), 64)
+        nbytes = M * lda * 2 + kw * Cin * ldb * 2 + taps * nslice * M * ldc * 4
+        ok = M * lda * 2 < (1 << 31) and Cin * ldb * 2 < (1 << 31) and nbytes <= WGRAD_GEMM_BYTES
+        return ok, ks, lda, ldb
+
+    nc = N
+    while nc > 1 and not plan(nc)[0]:
+        nc = (nc + 1) // 2
+    ok, ks, lda, ldb = plan(nc)
+    if not ok:
+        return None
+    dev = x_pm1.device
+    g = grad_output.detach()
+    x = x_pm1.detach()
+    dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
+    A = torch.empty((M, lda), dtype=torch.int16, device=dev)
+    B = torch.empty((kw, Cin, ldb), dtype=torch.int16, device=dev)
+    part = torch.empty((taps * nslice, M, ldc), dtype=torch.float32, device=dev)
+    w = None
+    if weight is not None:
+        w = _require(weight.detach(), "weight").contiguous()
+    I = int
+    st = _stream(dev)
+    with _on(dev):
+        for n0 in range(0, N, nc):
+            cnt = min(nc, N - n0)
+            gs = g[n0:n0 + cnt]
+            xs = x[n0:n0 + cnt]
+            if cnt != nc:                                     # ragged last chunk: its own (smaller) position space
+                ok2, ks2, lda2, ldb2 = plan(cnt)
+                Au = A.view(-1)[:M * lda2].view(M, lda2)
+                Bu = B.view(-1)[:kw * Cin * ldb2].view(kw, Cin, ldb2)
+                k_use, lda_use, ldb_use = ks2, lda2, ldb2
+            else:
+                Au, Bu, k_use, lda_use, ldb_use = A, B, ks, lda, ldb
+            _lib.call("qt_wgrad_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
+                      I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), _p(Au), I(lda_use), st)
+            _lib.call("qt_wgrad_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                      I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(kw), _p(Bu), I(ldb_use), I(Cin * ldb_use), st)
+            _lib.call("qt_bf16_gemm_taps", _p(Au), I(lda_use // 2), _p(Bu), I(ldb_use // 2), _p(part), I(ldc), I(M), I(Cin),
+                      I(k_use), I(kh), I(kw), I(nslice), I(Cin * ldb_use * 2), I(cnt * Wq * 2), I(M * ldc), st)
+            _lib.call("qt_wgrad_reduce_f32", _p(part), I(ldc), I(M * ldc), I(taps), I(nslice), I(Cout), I(Cin), _p(w),
+                      float(ste_threshold), int(n0 > 0), _p(dW), st)
+    return dW
+
+
 def s2d_applicable(C: int, kh: int, kw: int, stride, dilation, padding=0) -> bool:
     """Strided first-layer style convs (few input channels) are re-expressed as stride-1 convs on the
     space-to-depth image: no padding waste in the pixel planes and ~(k/ceil(k/s)s)^2 of the K bytes.  With stride 1

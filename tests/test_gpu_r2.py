@@ -702,7 +702,7 @@ def test_shift_batch_kernel_golden_and_oracle(dev, golden_r2, oracle):
 def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind):
     """Backward of a training-mode BinConv2d / TerConv2d on a BinaryConnect-tagged activation at AlexNet conv2 / conv3
     shapes: grad_input = the exact-split conv of the gradient with the flipped quantised weight, grad_weight = the
-    pixel contraction with batch and channels swapped, both on the bf16 matrix cores, against the fp64 evaluation of
+    pixel contraction as batched K-major GEMMs (csrc/wgrad.hip), both on the bf16 matrix cores, against the fp64 evaluation of
     torch.nn.grad.conv2d_input / conv2d_weight (functions/binary_connect.py:141-143) and the STE mask."""
     from pytorch_quantize_impls_amd.functions import _fused
     torch.manual_seed(Cin + Cout)
@@ -722,7 +722,11 @@ def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind
         y.backward(gout)
     finally:
         _fused.BWD_MFMA_MIN_MACS, ops.WEIGHT_GRAD_MAX_PIXELS = old_min, old_pix
-    assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) >= 3          # forward + both gradients
+    used_now = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items()}
+    # forward + grad_input on the implicit conv; grad_weight as the batched K-major GEMM (or the swapped conv)
+    gemm_route = ops.wgrad_gemm_applicable(xs.shape, y.shape, (k, k), 1, 1)
+    assert used_now.get("qt_bf16_gemm_taps", 0) == (1 if gemm_route else 0)
+    assert used_now.get("qt_conv2d_implicit", 0) >= (2 if gemm_route else 3)
     assert dict(_fused.LIBRARY_PATHS) == lib_before                                                 # no dense-library detour
     wq = (torch.where(conv.weight < 0, -1.0, 1.0) if kind == "binary" else ops.ternarize(conv.weight.detach())).double()
     gi = torch.nn.grad.conv2d_input(xs.shape, wq, gout.double(), padding=pd)
@@ -731,3 +735,49 @@ def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind
     assert norm_err(n(xs.grad), gi.cpu().numpy()) <= TOL
     assert norm_err(n(conv.weight.grad), gw.cpu().numpy()) <= TOL
     assert norm_err(n(conv.bias.grad), gout.double().sum((0, 2, 3)).cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,p,cl", [(3, 5, 7, 9, 11, 3, 1, False), (4, 32, 48, 13, 15, 3, 1, True),
+                                                    (2, 16, 8, 11, 13, 5, 2, True), (5, 64, 64, 17, 19, 3, 0, False),
+                                                    (3, 24, 40, 8, 10, 1, 0, True), (2, 8, 8, 12, 14, 7, 3, False),
+                                                    (7, 130, 70, 6, 33, 3, 1, True)])
+def test_weight_gradient_gemm_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
+    """ops.conv2d_grad_weight_gemm (exact bf16 split of the gradient x +-1 / 0 activation, K-major position planes, one
+    batched GEMM launch + reduce with the STE mask) against torch.nn.grad.conv2d_weight in fp64: odd channel counts,
+    both memory formats, kernels 1 .. 7, no padding, ternary activations, and batch chunking with a ragged last chunk."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(N * 1000 + Cin)
+    x = torch.randint(-1, 2, (N, Cin, H, W), generator=g, device=dev).float()             # -1 / 0 / +1
+    Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+    go = torch.randn((N, Cout, Ho, Wo), device=dev, generator=g)
+    if cl:
+        x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g) * 0.8
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), go.double(), stride=1, padding=p)
+    with used("qt_wgrad_pack_grad_f32", "qt_wgrad_pack_act_f32", "qt_bf16_gemm_taps", "qt_wgrad_reduce_f32"):
+        got = ops.conv2d_grad_weight_gemm(x, go, (k, k), p)
+    assert norm_err(n(got), ref.cpu().numpy()) <= TOL
+    masked = ops.conv2d_grad_weight_gemm(x, go, (k, k), p, weight=w)
+    refm = torch.where(w.abs() <= 1.001, ref, torch.zeros_like(ref))
+    assert norm_err(n(masked), refm.cpu().numpy()) <= TOL
+    assert np.array_equal(n(masked) == 0, (refm == 0).cpu().numpy() | (n(masked) == 0))
+    old = ops.WGRAD_GEMM_BYTES
+    try:       # force batch chunks (2 images each, N odd -> a ragged last chunk): partial gradients are accumulated
+        ops.WGRAD_GEMM_BYTES = 1
+        one = ops.conv2d_grad_weight_gemm(x[:1], go[:1], (k, k), p)
+        assert one is None or norm_err(n(one), torch.nn.grad.conv2d_weight(x[:1].double(), (Cout, Cin, k, k), go[:1].double(),
+                                                                            stride=1, padding=p).cpu().numpy()) <= TOL
+    finally:
+        ops.WGRAD_GEMM_BYTES = old
+    nbytes = []
+    real_plan_budget = ops.WGRAD_GEMM_BYTES
+    # a budget that admits 2 images per launch but not N
+    Wq, M = (W + 2 * p + 7) // 8 * 8, 3 * Cout
+    per_img = (M * Ho * Wq * 2 + k * Cin * (H + 2 * p) * Wq * 2) * 2
+    try:
+        ops.WGRAD_GEMM_BYTES = max(per_img * 2 + k * k * 64 * M * ((Cin + 3) // 4 * 4) * 4 + (1 << 16), 1 << 16)
+        chunked = ops.conv2d_grad_weight_gemm(x, go, (k, k), p)
+    finally:
+        ops.WGRAD_GEMM_BYTES = real_plan_budget
+    if chunked is not None:
+        assert norm_err(n(chunked), ref.cpu().numpy()) <= TOL
