@@ -194,6 +194,26 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- the reference's own op sequence on THIS GPU (torch.sign + masked write + F.linear fp32 through ROCm PyTorch):
+    # what the un-modified QuantTorch package gets here; per-rank work like the headline, a reported baseline only
+    if not args.no_extras:
+        from oracle import torch_port
+        with torch.no_grad():
+            yr = torch_port.linear_bin_forward(x, w)
+            same = bool(torch.equal(yr, y))
+            del yr
+            for _ in range(2):
+                torch_port.linear_bin_forward(x, w)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                torch_port.linear_bin_forward(x, w)
+            torch.cuda.synchronize()
+            ref_ms = (time.perf_counter() - t0) / 10 * 1e3
+        result["reference_ops_on_gpu"] = {"value": ops_per_step / (ref_ms * 1e-3) / 1e12, "unit": "TOPS (per GPU)",
+                                          "ms_per_step": ref_ms, "same_result": same,
+                                          "what": "oracle/torch_port.linear_bin_forward on the device tensors, 10 calls"}
+
     # ---- BinaryNet-AlexNet images/s (second half of BASELINE.json's metric) ---------------------------
     if args.alexnet_batch > 0:
         result["alexnet"] = bench_alexnet(args, dev, dist, world, rank)
@@ -302,6 +322,18 @@ def bench_alexnet(args, dev, dist, world, rank):
     out["train_mode_layers"] = {"images_per_s": world * B * args.alexnet_iters / elt,
                                 "ms_per_forward": elt / args.alexnet_iters * 1e3,
                                 "same_logits_as_eval": bool(torch.equal(yt, ye))}
+    # the reference's own op sequence (torch.sign + F.conv2d / F.linear fp32 + the torch modules) on THIS GPU: what the
+    # un-modified QuantTorch package gets from ROCm PyTorch (MIOpen / hipBLASLt) for the same eval forward
+    from oracle import torch_port
+
+    def ref_ops(xin):
+        h = torch_port.sequential_forward(model.features, xin)
+        return torch_port.sequential_forward(model.classifieur, h.reshape(h.size(0), 256 * 6 * 6))
+    elr, yr = timed(ref_ops)
+    out["reference_ops_on_gpu"] = {"images_per_s": world * B * args.alexnet_iters / elr,
+                                   "ms_per_forward": elr / args.alexnet_iters * 1e3,
+                                   "same_argmax_as_module_by_module": bool(torch.equal(yr.argmax(1), ye.argmax(1))),
+                                   "what": "oracle/torch_port.sequential_forward: the reference's eval-mode ops in torch on the device"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = B                       # the same batch as the GPU leg (one forward = ~1 s on the box's host)
         cpu_model = bench_models.AlexNetBin()

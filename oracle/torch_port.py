@@ -30,6 +30,24 @@ def bin_conv2d_forward(x, weight, bias=None, stride=1, padding=0, dilation=1, gr
     return F.conv2d(x, safe_sign(weight), bias, stride, padding, dilation, groups)
 
 
+def sequential_forward(seq, x):
+    """An nn.Sequential of this package's binarised layers + torch modules, evaluated with the REFERENCE's op sequence
+    only (torch.sign + masked write, F.conv2d / F.linear in fp32, the torch modules as they are) on whatever device the
+    tensors live on: what the un-modified reference computes in eval mode (layers/binary_layers.py:46,106; the eval-mode
+    weight already holds sign(W), functions/binary_connect.py:22-28 for the BinaryConnect modules)."""
+    for m in seq:
+        name = type(m).__name__
+        if name in ("BinConv2d", "TerConv2d"):
+            x = F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+        elif name in ("LinearBin", "LinearTer"):
+            x = F.linear(x, m.weight, m.bias)
+        elif name == "_FunctionModule":               # BinaryConnect(): deterministic sign
+            x = safe_sign(x)
+        else:
+            x = m(x)
+    return x
+
+
 def time_callable(fn, budget_s: float = 12.0, warmup: int = 2, min_iters: int = 3, max_iters: int = 50):
     """Median wall time of fn() over a bounded sample (about ``budget_s`` seconds of CPU work)."""
     with torch.no_grad():
