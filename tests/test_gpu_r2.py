@@ -781,3 +781,19 @@ def test_weight_gradient_gemm_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
         ops.WGRAD_GEMM_BYTES = real_plan_budget
     if chunked is not None:
         assert norm_err(n(chunked), ref.cpu().numpy()) <= TOL
+
+
+def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
+    """One whole training step of BinaryNet-AlexNet (packed forward, STE masks, grad_input / grad_weight of every conv and
+    linear layer on the matrix cores) against the reference's op sequence in torch on the same device (torch.sign,
+    F.conv2d / F.linear fp32, the STE of functions/binary_connect.py:31-38), on +-1 pixels so that both forward passes
+    are the same integers: every parameter gradient within 1e-5 normalised (2e-5: the reference side is MIOpen fp32)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_train_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_train_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with used("qt_bf16_gemm_taps", "qt_conv2d_implicit", "qt_nib_gemm"):
+        worst = mod.gradient_agreement(16)
+    assert worst <= 2e-5, worst

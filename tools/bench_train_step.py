@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Training step of BinaryNet-AlexNet (forward + backward, batch 256, channels_last) on one MI355X:
+  a) this backend, all matrix-core routes on;  b) backward convs left to MIOpen (_fused.BWD_CONV_MFMA = False);
+  c) the reference's op sequence in torch on the same GPU (sign via torch ops, F.conv2d / F.linear fp32, STE by autograd
+     Functions restated from functions/binary_connect.py:14-38) — what the un-modified package does here."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench_models  # noqa: E402
+from pytorch_quantize_impls_amd.functions import _fused  # noqa: E402
+
+
+class _RefSign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        r = torch.sign(x)
+        r[r == 0] = 1
+        return r
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        g = g.clone()
+        g[x.abs() > 1.001] = 0
+        return g
+
+
+def ref_forward(model, x):
+    def run(seq, h):
+        for m in seq:
+            name = type(m).__name__
+            if name == "BinConv2d":
+                h = F.conv2d(h, _RefSign.apply(m.weight), m.bias, m.stride, m.padding)
+            elif name == "LinearBin":
+                h = F.linear(h, _RefSign.apply(m.weight), m.bias)
+            elif name == "_FunctionModule":
+                h = _RefSign.apply(h)
+            else:
+                h = m(h)
+        return h
+    h = run(model.features, x)
+    return run(model.classifieur, h.reshape(h.size(0), 256 * 6 * 6))
+
+
+def step_time(fwd, model, x, target, n=5):
+    def one():
+        model.zero_grad(set_to_none=True)
+        loss = F.nll_loss(fwd(x), target)
+        loss.backward()
+        return loss
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = one()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, float(loss)
+
+
+def gradient_agreement(B: int = 16, seed: int = 0) -> float:
+    """Worst normalised difference between this backend's parameter gradients and the reference op sequence's for one
+    AlexNet-Bin training step on +-1 pixels (identical forward passes); zero-gradient biases excluded."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    model = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.where(torch.randn(B, 3, 224, 224, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    target = torch.randint(0, 10, (B,), device=dev)
+    grads = []
+    for fwd in (model, lambda t: ref_forward(model, t)):
+        model.zero_grad(set_to_none=True)
+        F.nll_loss(fwd(x), target).backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    ours, ref = grads
+    top = max(float(g.abs().max()) for g in ref.values())
+    return max(float((ours[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)) for k in ours
+               if not (k.endswith(".bias") and ref[k].abs().max() < 1e-3 * top))
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    torch.manual_seed(0)
+    model = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(B, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    if os.environ.get("PM1_INPUT"):      # +-1 pixels: every conv sum is an exact integer on both sides, so no sign can flip
+        x = torch.where(x < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    target = torch.randint(0, 10, (B,), device=dev)
+    ta, la = step_time(model, model, x, target)
+    grads_a = {k: p.grad.clone() for k, p in model.named_parameters()}
+    _fused.BWD_CONV_MFMA = False
+    tb, lb = step_time(model, model, x, target)
+    _fused.BWD_CONV_MFMA = True
+    tc, lc = step_time(lambda t: ref_forward(model, t), model, x, target)
+    grads_c = {k: p.grad.clone() for k, p in model.named_parameters()}
+    diffs = {k: float((grads_a[k] - grads_c[k]).abs().max() / (grads_c[k].abs().max() + 1e-30)) for k in grads_a}
+    if os.environ.get("VERBOSE"):
+        for k, v in diffs.items():
+            print(f"  {k:28s} diff {v:.2e}   |grad|max ours {float(grads_a[k].abs().max()):.3e}  reference ops {float(grads_c[k].abs().max()):.3e}")
+    # a bias in front of a training-mode BatchNorm has a mathematically zero gradient (the batch mean is subtracted): what
+    # both sides report for it is rounding noise, so those entries are left out of the comparison
+    worst = max(v for k, v in diffs.items() if not (k.endswith(".bias") and grads_c[k].abs().max() < 1e-3 * max(
+        float(g.abs().max()) for g in grads_c.values())))
+    print(f"AlexNet-Bin training step, batch {B}: this backend {ta:.2f} ms ({B / ta * 1e3:.0f} img/s), with MIOpen backward convs "
+          f"{tb:.2f} ms, reference op sequence on the same GPU {tc:.2f} ms ({B / tc * 1e3:.0f} img/s)")
+    print(f"loss {la:.6f} / {lb:.6f} / {lc:.6f}; worst normalised gradient difference vs the reference ops {worst:.2e} "
+          "(with real-valued pixels conv1's fp32 rounding differs between the routes, a few signs flip behind the training-mode "
+          "BatchNorm and the nets diverge; PM1_INPUT=1 feeds +-1 pixels, for which the forward passes are identical)")
+
+
+if __name__ == "__main__":
+    main()
