@@ -45,6 +45,7 @@
 // padded planes — plain 32-bit offsets with the per-(stage, chunk) tap offsets tabulated once in LDS (2).
 // Profiling-only variants (ABL_ != 0) exist only in -DQT_PROFILING_VARIANTS builds (qt_nib_gemm_variant 161-166,
 // qt_conv2d_implicit_variant 3); the product library does not contain them.
+#include <cstdlib>
 #include <type_traits>
 #include "qt_common.h"
 #include "pp_common.h"
@@ -1349,6 +1350,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     // (hy, hx): halo of the INPUT plane, [N][H + 2hy][W + 2hx][Cw] with a zero border: a conv whose padding fits in
     // the halo runs as the un-padded conv on the window that starts (hy - ph, hx - pw) into the plane.
     EpiArgs epi = epi_in;
+#ifdef QT_EXPERIMENT   // A/B builds only (make EXTRA=-DQT_EXPERIMENT): a variant for the entry points that take none
+    if (g_conv_force == 0 && getenv("QT_CONV_FORCE_EXP")) g_conv_force = atoi(getenv("QT_CONV_FORCE_EXP"));
+#endif
     if (hy < 0 || hx < 0 || ((hy | hx) && (ph > hy || pw > hx))) return QT_ERR_INVALID_ARG;
     if (Nimg < 0 || H <= 0 || W <= 0 || Cw <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 ||
         dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 2)
