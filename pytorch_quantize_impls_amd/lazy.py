@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import collections
 import contextlib
+import threading
 import weakref
 from typing import Optional
 
@@ -48,15 +49,22 @@ ENABLED = True
 STATS = collections.Counter()
 
 
+_tls = threading.local()
+
+
+def enabled() -> bool:
+    """Deferral is on: the master switch ``ENABLED`` and no ``eager()`` block open in this thread."""
+    return ENABLED and not getattr(_tls, "eager_depth", 0)
+
+
 @contextlib.contextmanager
 def eager():
-    """Run the enclosed forwards module by module (no deferred activations)."""
-    global ENABLED
-    prev, ENABLED = ENABLED, False
+    """Run the enclosed forwards module by module (no deferred activations); per thread, re-entrant."""
+    _tls.eager_depth = getattr(_tls, "eager_depth", 0) + 1
     try:
         yield
     finally:
-        ENABLED = prev
+        _tls.eager_depth -= 1
 
 
 class _Node:
@@ -664,7 +672,7 @@ def conv_forward(layer, input, kind: str):
             from .functions import _fused
             act = n.force(tuple(int(v) for v in ops._pairs(layer.padding)) if _fused.PAD_PLANES else None)
         input = act if act is not None else n.materialise()
-    if ENABLED and _conv_can_defer(layer, input):
+    if enabled() and _conv_can_defer(layer, input):
         N, C, H, W = (int(v) for v in input.shape)
         kh, kw = layer.kernel_size
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
@@ -704,7 +712,7 @@ def dorefa_conv_forward(layer, input):
                 act = n.force(pad)
         input = act if act is not None else n.materialise()
     tagged = None
-    if ENABLED and not isinstance(input, packed.CodeActivation) and isinstance(input, torch.Tensor) and input.is_cuda \
+    if enabled() and not isinstance(input, packed.CodeActivation) and isinstance(input, torch.Tensor) and input.is_cuda \
             and input.dtype == torch.float32 and input.dim() == 4 and not torch.is_grad_enabled() and not layer.training \
             and layer.bit_width == 1:
         codes = packed.lookup_codes(input, packed.NHWC)
@@ -713,7 +721,7 @@ def dorefa_conv_forward(layer, input):
             cand = packed.CodeActivation(codes, (N, C, H, W))
             if _dorefa_can_defer(layer, cand):
                 tagged, input = input, cand
-    if ENABLED and _dorefa_can_defer(layer, input):
+    if enabled() and _dorefa_can_defer(layer, input):
         N, C, H, W = (int(v) for v in input.shape)
         kh, kw = layer.kernel_size
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
