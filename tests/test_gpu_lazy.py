@@ -357,3 +357,63 @@ def test_results_do_not_depend_on_concurrent_load(dev):
     spec.loader.exec_module(mod)
     bad = mod.run(6, verbose=False)
     assert not any(bad.values()), bad
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_fuzz_random_stacks_deferred_equals_fuse_sequential(dev, seed):
+    """Random binarised / ternarised conv stacks (kernel, stride, padding, pooling before the BatchNorm or after the sign,
+    channel counts that are not multiples of 32, optional Hardtanh / Dropout) closed by a conv that consumes the last
+    activation: the un-modified nn.Sequential (deferred execution) against layers.fuse_sequential built from the same
+    modules — exact integers, so bit for bit — and against the module-by-module evaluation up to BatchNorm ties."""
+    import random
+    from pytorch_quantize_impls_amd.layers import fuse_sequential
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    cin = rng.choice([3, 16, 40, 64])
+    H = rng.choice([24, 33, 40, 48])
+    mods, c = [], cin
+    first = True
+    for _ in range(rng.randint(2, 4)):
+        cout = rng.choice([24, 32, 64, 72, 128])
+        k = rng.choice([1, 3, 3, 5])
+        conv = rng.choice([BinConv2d, TerConv2d])(c, cout, k, stride=rng.choice([1, 1, 2]), padding=rng.choice([0, k // 2]))
+        if first:
+            conv.binary_input = False                     # real-valued pixels
+            first = False
+        mods.append(conv)
+        pre_pool = rng.random() < 0.3
+        if pre_pool:
+            mods.append(nn.MaxPool2d(2, 2))
+        mods.append(nn.BatchNorm2d(cout))
+        if rng.random() < 0.7:
+            mods.append(nn.Hardtanh(inplace=rng.random() < 0.5))
+        mods.append(BinaryConnect())
+        if not pre_pool and rng.random() < 0.3:
+            mods.append(nn.MaxPool2d(2, 2))
+        if rng.random() < 0.2:
+            mods.append(nn.Dropout(0.3))
+        c = cout
+    mods.append(BinConv2d(c, 16, 1))
+    seq = nn.Sequential(*mods)
+    bench_models.randomize_bn(seq, seed)
+    seq = seq.to(dev).eval()
+    x = torch.randn(3, cin, H, H, device=dev)
+    if rng.random() < 0.5:
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        with lazy.eager():
+            try:
+                e = seq(x)
+            except RuntimeError:                          # a map shrank below a kernel / pooling window
+                pytest.skip("degenerate geometry")
+        # (the explicit fused form has no Dropout module for packed activations; in eval mode it is the identity)
+        fused = fuse_sequential(nn.Sequential(*[m for m in seq if not isinstance(m, nn.Dropout)]), fuse_conv=True,
+                                packed_pool=True)
+        ref = fused(x)
+        lazy.STATS.clear()
+        y = seq(x)
+        assert isinstance(y, lazy.LazyActivation)
+        got = y + 0
+    assert lazy.STATS["fused"] >= 1
+    assert torch.equal(got, ref), (seed, lazy.STATS)
+    assert float((got - e).abs().max()) <= 0.1 * float(e.abs().max()) + 1e-3      # sign flips at BatchNorm ties only
