@@ -468,6 +468,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 #pragma unroll
                     for (int j = 0; j < NP; ++j) issue_piece(j, s, s, std::false_type{});
                 }
+            int tap_next = 0;
+            if constexpr (C::VALID) tap_next = tap_table[min(AHEAD, max(nstages - 1, 0)) * CH + lchunk];
             if (nstages >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -484,13 +486,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 read_frags(xs, ws, 1, xf1, wf1);
                 if constexpr (C::ABL == 5 && issue) dbg_ts[1] = stamp_now();
                 if constexpr (issue) {
-                    if constexpr (C::CONV) conv_stage(s + AHEAD);
+                    // VALID conv: the stage's tap offset was read from the LDS table at the END of the previous load
+                    // segment (tap_next).  Read here, the pieces would wait for it behind the twelve fragment reads
+                    // just issued (LDS returns in order): the whole fragment latency in front of the DMA issue.
+                    if constexpr (C::VALID) tap_boff = tap_next;
+                    else if constexpr (C::CONV) conv_stage(s + AHEAD);
                     const unsigned m0_keep = m0_save();
 #pragma unroll
                     for (int j = 0; j < NP; ++j) issue_piece(j, s + AHEAD, (s + AHEAD) & 3, std::true_type{});
                     m0_restore(m0_keep);
+                    if constexpr (C::VALID) tap_next = tap_table[min(s + 1 + AHEAD, nstages - 1) * CH + lchunk];
                     if constexpr (C::ABL == 5 && issue) dbg_ts[2] = stamp_now();
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NP) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(tap_next) : "n"(2 * NP) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
