@@ -267,25 +267,26 @@ int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_b
  * K-major operands in the position space q = (y * N + n) * Wq + x (Wq: row pitch, multiple of 8, >= W + 2 pw):
  *   qt_wgrad_pack_grad_f32 : g (fp32, element strides given; channels-last sources take an LDS-tiled transpose) -> A[(t * Cout + co) * lda + q], t = hi / mid / lo of the exact bf16
  *                            split; zero for x >= Wo and q >= Ho * N * Wq.  lda: elements per row, multiple of 64.
- *   qt_wgrad_pack_act_f32  : x (fp32, any strides, values exact in bf16: +-1 / 0) -> kw_count shifted copies
+ *   qt_wgrad_pack_act_f32  : x (fp32, any strides; x * x_scale must be exact in bf16: +-1 / 0, or k-bit DoReFa activations
+ *                            with x_scale = 2^k - 1, whose products are the integer codes) -> kw_count shifted copies
  *                            B[j * copy_elems + ci * ldb + q] = xpad[q + j] (0 outside the image / past the pitch);
  *                            copy_elems == Cin * ldb.
  *   qt_bf16_gemm_taps      : for tap = (r, c), r < tap_rows, c < tap_cols and K slice s < nslice (blockIdx.y):
  *                            Y[(tap * nslice + s) * y_stride + m * ldy + n] = sum_{k < K} X[m][s K + k] * W_tap[n][s K + k],
  *                            W_tap = W + c * w_copy_bytes + r * w_row_bytes (bytes).  K: multiple of 32; ldxp / ldwp in 32-bit
  *                            words, multiples of 32.  Plain bf16 GEMM semantics otherwise (qt_bf16_gemm).
- *   qt_wgrad_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= sum over slices and the three row blocks of the partials,
+ *   qt_wgrad_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= out_scale * sum over slices and the three row blocks of the partials,
  *                            times 1[|weight| <= ste_threshold] when weight != NULL (the quantiser's straight-through mask). */
 int qt_wgrad_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                            int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, uint16_t* A, int64_t lda, qt_stream_t stream);
 int qt_wgrad_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
-                          int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t kw_count, uint16_t* B,
-                          int64_t ldb, int64_t copy_elems, qt_stream_t stream);
+                          int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t kw_count, float x_scale,
+                          uint16_t* B, int64_t ldb, int64_t copy_elems, qt_stream_t stream);
 int qt_bf16_gemm_taps(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, float* Y, int64_t ldy,
                       int64_t M, int64_t N, int64_t K, int64_t tap_rows, int64_t tap_cols, int64_t nslice,
                       int64_t w_copy_bytes, int64_t w_row_bytes, int64_t y_stride, qt_stream_t stream);
 int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int64_t taps, int64_t nslice, int64_t Cout,
-                        int64_t Cin, const float* weight, float ste_threshold, int accumulate, float* dW,
+                        int64_t Cin, const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
                         qt_stream_t stream);
 
 /* Y[M,N] = scale * (*scale_dev) * (Xc . Wc^T) + bias, Xc / Wc int8 code planes (ld in uint32 words).

@@ -73,10 +73,11 @@ SIGNATURES = {
     "qt_wgrad_pack_grad_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p,
                                         _c_i64, _c_p]),
     "qt_wgrad_pack_act_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
-                                       _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p]),
+                                       _c_i64, _c_i64, _c_f32, _c_p, _c_i64, _c_i64, _c_p]),
     "qt_bf16_gemm_taps": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                    _c_i64, _c_i64, _c_i64, _c_p]),
-    "qt_wgrad_reduce_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_f32, _c_int, _c_p, _c_p]),
+    "qt_wgrad_reduce_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_f32, _c_f32, _c_int, _c_p,
+                                     _c_p]),
     "qt_nib_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),

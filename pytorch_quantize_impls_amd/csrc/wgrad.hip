@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void wgrad_pack_grad_kernel(const float* __res
 // one work item = 8 consecutive positions of one input channel, all kw_count shifted copies
 __global__ __launch_bounds__(256) void wgrad_pack_act_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh_,
                                                              int64_t sw, int N, int Cin, int H, int W, int ph, int pw,
-                                                             int Hp, int Wq, int kw_count, uint16_t* __restrict__ B,
-                                                             int64_t ldb, int64_t copy_elems) {
+                                                             int Hp, int Wq, int kw_count, float x_scale,
+                                                             uint16_t* __restrict__ B, int64_t ldb, int64_t copy_elems) {
     const int64_t chunks = ldb >> 3;
     const int64_t total = (int64_t)Cin * chunks;
     const int64_t row_elems = (int64_t)N * Wq;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void wgrad_pack_act_kernel(const float* __rest
         for (int i = 0; i < 16; ++i) {
             const int xx = x0 + i - pw;
             float f = 0.0f;
-            if (row_ok && i < 8 + kw_count - 1 && x0 + i < Wq && xx >= 0 && xx < W) f = src[(int64_t)xx * sw];
+            if (row_ok && i < 8 + kw_count - 1 && x0 + i < Wq && xx >= 0 && xx < W) f = src[(int64_t)xx * sw] * x_scale;
             v[i] = wg_bf16_rn_bits(f);
         }
         for (int j = 0; j < kw_count; ++j) {
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void wgrad_pack_grad_nhwc_kernel(const float* 
 
 __global__ __launch_bounds__(256) void wgrad_pack_act_nhwc_kernel(const float* __restrict__ x, int64_t sn, int64_t sh_, int64_t sw,
                                                                   int N, int Cin, int H, int W, int ph, int pw, int Wq,
-                                                                  int kw_count, uint16_t* __restrict__ B, int64_t ldb,
-                                                                  int64_t copy_elems) {
+                                                                  int kw_count, float x_scale, uint16_t* __restrict__ B,
+                                                                  int64_t ldb, int64_t copy_elems) {
     __shared__ uint16_t tile[40][66];
     const int xb = blockIdx.x * 32, c0 = blockIdx.y * 64;
     const int row = blockIdx.z;                       // y * N + n over the PADDED rows
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void wgrad_pack_act_nhwc_kernel(const float* _
         for (int p = p0; p < 40; p += 4) {
             const int xq = xb + p, xx = xq - pw;
             float v = 0.0f;
-            if (row_ok && xq < Wq && xx >= 0 && xx < W) v = x[(int64_t)n * sn + (int64_t)yy * sh_ + (int64_t)xx * sw + c0 + c];
+            if (row_ok && xq < Wq && xx >= 0 && xx < W) v = x[(int64_t)n * sn + (int64_t)yy * sh_ + (int64_t)xx * sw + c0 + c] * x_scale;
             tile[p][c] = (uint16_t)wg_bf16_rn_bits(v);
         }
     }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_zero_tail_kernel(uint16_t* __restri
 // one work item = one (tap, co, ci): sums the K slices and the hi / mid / lo row blocks, applies the STE mask
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ C, int64_t ldc, int64_t z_stride, int taps,
                                                            int nslice, int Cout, int Cin, const float* __restrict__ weight,
-                                                           float thr, int accumulate, float* __restrict__ dW) {
+                                                           float thr, float out_scale, int accumulate, float* __restrict__ dW) {
     const int64_t total = (int64_t)taps * Cout * Cin;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(t % Cin);
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             s += (base[((int64_t)2 * Cout + co) * ldc] + base[((int64_t)Cout + co) * ldc]) + base[(int64_t)co * ldc];
         }
         const int64_t o = ((int64_t)co * Cin + ci) * taps + tap;
+        s *= out_scale;
         if (weight && !(fabsf(weight[o]) <= thr)) s = 0.0f;   // STE of the weight quantiser; NaN weights pass nothing
         dW[o] = accumulate ? dW[o] + s : s;
     }
@@ -239,8 +240,8 @@ int qt_wgrad_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, i
 }
 
 int qt_wgrad_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
-                          int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t kw_count, uint16_t* B,
-                          int64_t ldb, int64_t copy_elems, qt_stream_t stream) {
+                          int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t kw_count, float x_scale,
+                          uint16_t* B, int64_t ldb, int64_t copy_elems, qt_stream_t stream) {
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || !x || !B) return QT_ERR_INVALID_ARG;
     if (kw_count < 1 || kw_count > 8) return QT_ERR_UNSUPPORTED;
     if (Wq < W + 2 * pw || (Wq & 7) || (ldb & 63) || (copy_elems & 7) || copy_elems != Cin * ldb || !qt_aligned16(B))
@@ -250,7 +251,7 @@ int qt_wgrad_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, in
     if (stride_c == 1 && Hp * N <= 65535 && (Cin + 63) / 64 <= 65535 && ldb >= ptot) {
         hipLaunchKernelGGL(wgrad_pack_act_nhwc_kernel, dim3((unsigned)((Wq + 31) / 32), (unsigned)((Cin + 63) / 64), (unsigned)(Hp * N)),
                            dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W,
-                           (int)ph, (int)pw, (int)Wq, (int)kw_count, B, ldb, copy_elems);
+                           (int)ph, (int)pw, (int)Wq, (int)kw_count, x_scale, B, ldb, copy_elems);
         if (ldb > ptot)   // the kw_count copies are kw_count * Cin rows of pitch ldb (copy_elems == Cin * ldb is required below)
             hipLaunchKernelGGL(wgrad_zero_tail_kernel, dim3(qt_stream_grid((kw_count * Cin * ((ldb - ptot) >> 3) + 255) / 256)),
                                dim3(256), 0, (hipStream_t)stream, B, kw_count * Cin, ldb, ptot);
@@ -258,20 +259,20 @@ int qt_wgrad_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, in
     }
     const int grid = qt_stream_grid((Cin * (ldb >> 3) + 255) / 256);
     hipLaunchKernelGGL(wgrad_pack_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c, stride_h,
-                       stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)(H + 2 * ph), (int)Wq, (int)kw_count, B,
-                       ldb, copy_elems);
+                       stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)(H + 2 * ph), (int)Wq, (int)kw_count, x_scale,
+                       B, ldb, copy_elems);
     return qt_check_launch();
 }
 
 int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int64_t taps, int64_t nslice, int64_t Cout,
-                        int64_t Cin, const float* weight, float ste_threshold, int accumulate, float* dW,
+                        int64_t Cin, const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
                         qt_stream_t stream) {
     if (taps <= 0 || nslice <= 0 || Cout <= 0 || Cin <= 0 || !partial || !dW || ldc < Cin || z_stride < 3 * Cout * ldc)
         return QT_ERR_INVALID_ARG;
     if (taps * Cout * Cin >= (1ll << 40)) return QT_ERR_UNSUPPORTED;
     const int grid = qt_stream_grid((taps * Cout * Cin + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, ldc, z_stride, (int)taps,
-                       (int)nslice, (int)Cout, (int)Cin, weight, ste_threshold, accumulate, dW);
+                       (int)nslice, (int)Cout, (int)Cin, weight, ste_threshold, out_scale, accumulate, dW);
     return qt_check_launch();
 }
 

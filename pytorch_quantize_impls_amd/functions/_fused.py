@@ -649,6 +649,13 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
     def forward(ctx, input, weight, bias, conv_args):
         ctx.has_bias, ctx.conv_args = bias is not None, conv_args
         ctx.save_for_backward(input, weight)
+        # k-bit activation with valid int8 codes (the tag nnDorefaQuant leaves): its image is codes / (2^k - 1), so the
+        # weight gradient can contract the integer codes on the bf16 matrix cores
+        ctx.x_levels = None
+        if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4:
+            codes = packed.lookup_codes(input, packed.NHWC)
+            if codes is not None and codes.K == input.shape[1]:
+                ctx.x_levels = float((1 << int(codes.bit_width)) - 1)
         return dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False)
 
     @staticmethod
@@ -657,13 +664,28 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
         stride, padding, dilation, groups = ctx.conv_args
         go = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
+        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
-            wq = quantize_weight_f32(weight, "binary") * weight.abs().mean()
-            grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
-                                                    dilation=dilation, groups=groups)
+            sgn = quantize_weight_f32(weight, "binary")
+            E = weight.abs().mean()
+            if mfma:     # g * (sign(W) E) = E * (g * sign(W)): the exact-split conv on the flipped +-1 weight, scaled after
+                grad_input = ops.conv2d_grad_input_q(input.shape, sgn, go, stride, padding, dilation)
+                if grad_input is not None:
+                    grad_input = grad_input * E
+            if grad_input is None:
+                note_library_path(go, "conv grad_input outside the matrix-core route")
+                grad_input = torch.nn.grad.conv2d_input(input.shape, sgn * E, go, stride=stride, padding=padding,
+                                                        dilation=dilation, groups=groups)
         if ctx.needs_input_grad[1]:
-            grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
-                                                      dilation=dilation, groups=groups)
+            if (mfma and ctx.x_levels is not None and ctx.x_levels <= 255
+                    and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation)):
+                # UNscaled and un-masked, as upstream (_ignore_factor_op, identity STE): functions/dorefa_connect.py:66-79
+                grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
+            if grad_weight is None:
+                note_library_path(go, "conv grad_weight outside the matrix-core route")
+                grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
+                                                          dilation=dilation, groups=groups)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None

@@ -1571,11 +1571,13 @@ def wgrad_gemm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool
 
 
 def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
-                            weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD):
+                            weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
+                            x_levels: float = 1.0):
     """grad wrt the weight of a STRIDE-1, un-dilated conv2d(x, Q(W)) for an activation whose values are exact in bf16
     (+-1 / 0): batched bf16 matrix-core GEMMs over K-major operand planes (csrc/wgrad.hip).  ``weight``: apply the
-    quantiser's straight-through mask 1[|W| <= ste_threshold] to the result.  Returns [Cout, Cin, kh, kw] fp32, or None
-    when the shape is outside the route."""
+    quantiser's straight-through mask 1[|W| <= ste_threshold] to the result.  ``x_levels`` = n: the activation is a k-bit
+    DoReFa image q / n (n = 2^k - 1 <= 255); it enters the GEMM as its integer codes (x * n, exact in bf16) and the result
+    is scaled by fl(1 / n).  Returns [Cout, Cin, kh, kw] fp32, or None when the shape is outside the route."""
     _require(x_pm1, "input")
     _require(grad_output, "grad_output")
     kh, kw = (int(v) for v in kernel_hw)
@@ -1615,6 +1617,7 @@ def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kern
     dev = x_pm1.device
     g = grad_output.detach()
     x = x_pm1.detach()
+    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
     A = torch.empty((M, lda), dtype=torch.int16, device=dev)
     B = torch.empty((kw, Cin, ldb), dtype=torch.int16, device=dev)
@@ -1639,11 +1642,12 @@ def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kern
             _lib.call("qt_wgrad_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
                       I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), _p(Au), I(lda_use), st)
             _lib.call("qt_wgrad_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
-                      I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(kw), _p(Bu), I(ldb_use), I(Cin * ldb_use), st)
+                      I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(kw), float(x_levels), _p(Bu), I(ldb_use),
+                      I(Cin * ldb_use), st)
             _lib.call("qt_bf16_gemm_taps", _p(Au), I(lda_use // 2), _p(Bu), I(ldb_use // 2), _p(part), I(ldc), I(M), I(Cin),
                       I(k_use), I(kh), I(kw), I(nslice), I(Cin * ldb_use * 2), I(cnt * Wq * 2), I(M * ldc), st)
             _lib.call("qt_wgrad_reduce_f32", _p(part), I(ldc), I(M * ldc), I(taps), I(nslice), I(Cout), I(Cin), _p(w),
-                      float(ste_threshold), int(n0 > 0), _p(dW), st)
+                      float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
     return dW
 
 

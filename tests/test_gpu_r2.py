@@ -797,3 +797,37 @@ def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
     with used("qt_bf16_gemm_taps", "qt_conv2d_implicit", "qt_nib_gemm"):
         worst = mod.gradient_agreement(16)
     assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize("Cin,Cout,k,pd,H,B,bits", [(128, 128, 3, 1, 16, 8, 4), (256, 128, 3, 1, 8, 16, 2), (128, 192, 1, 0, 12, 8, 8)])
+def test_dorefa_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, bits):
+    """Training-mode DorefaConv2d(bit_width=1) on a k-bit activation (nnDorefaQuant's tagged image): grad_input = E x the
+    exact-split conv of the gradient with flipped sign(W), grad_weight = the K-major GEMMs over the INTEGER codes scaled
+    by fl(1 / n) — against the fp64 evaluation of what autograd derives upstream (functions/dorefa_connect.py:66-79:
+    scaled weight in the forward, UNscaled weight gradient, identity STE)."""
+    from pytorch_quantize_impls_amd.functions import _fused, nnDorefaQuant
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d
+    torch.manual_seed(Cin + bits)
+    conv = DorefaConv2d(Cin, Cout, k, padding=pd, bit_width=1).to(dev)
+    top = min(1.2, 120.0 / ((1 << bits) - 1))          # the un-clamped quantiser's codes must stay in int8
+    xr = (torch.rand(B, Cin, H, H, device=dev) * top).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xq = nnDorefaQuant(bits)(xr)
+    xq.retain_grad()
+    old_min = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    try:
+        with used("qt_bf16_gemm_taps", "qt_conv2d_implicit"):
+            y = conv(xq)
+            gout = torch.randn_like(y)
+            y.backward(gout)
+    finally:
+        _fused.BWD_MFMA_MIN_MACS = old_min
+    assert dict(_fused.LIBRARY_PATHS) == lib_before
+    w = conv.weight.detach().double()
+    E = w.abs().mean()
+    wq = torch.where(w < 0, -torch.ones_like(w), torch.ones_like(w)) * E
+    gi = torch.nn.grad.conv2d_input(xq.shape, wq, gout.double(), padding=pd)
+    gw = torch.nn.grad.conv2d_weight(xq.detach().double(), conv.weight.shape, gout.double(), padding=pd)
+    assert norm_err(n(xq.grad), gi.cpu().numpy()) <= TOL
+    assert norm_err(n(conv.weight.grad), gw.cpu().numpy()) <= TOL
