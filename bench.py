@@ -17,7 +17,11 @@ region) and "cpu_baseline" (reference op sequence on the host cores, rank 0, N=1
 of the metric) and "extra": the other BASELINE configs, each timed by the same process and each with the roofline
 SURVEY.md 8(d) prescribes (ops = 2 * MACs, bytes = fp32 activations in + fp32 weights + fp32 activations out per
 quantised layer): C2 eval mode on pre-packed operands, C2 with a bias (float-tail parity), C4 (DoReFa ResNet-18 W1A4,
-batch 256) and C5 (ternary VGG-16, 256 per GPU), un-fused reference graph and fused inference form.
+batch 256) and C5 (ternary VGG-16, 256 per GPU): the un-modified module graph (deferred activations, lazy.py), the same
+graph module by module, and the explicit fused inference form.  "reference_ops_on_gpu" (C2 and AlexNet) is a second
+BASELINE leg beside cpu_baseline: the reference's op sequence (oracle/torch_port.py: torch.sign + F.linear / F.conv2d in
+fp32 + the torch modules) executed by ROCm PyTorch on this same GPU — what the un-modified reference gets here; like the
+CPU leg it is only reported, never part of `value`, and it is the only other place bench.py touches oracle/.
 
 --strong: strong scaling — the GLOBAL batch is fixed (C2: --batch rows, AlexNet / C4 / C5: their batch) and split
 over the ranks ("scaling": "strong"); default is weak scaling (batch per GPU fixed).
