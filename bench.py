@@ -338,6 +338,34 @@ def bench_alexnet(args, dev, dist, world, rank):
                                    "ms_per_forward": elr / args.alexnet_iters * 1e3,
                                    "same_argmax_as_module_by_module": bool(torch.equal(yr.argmax(1), ye.argmax(1))),
                                    "what": "oracle/torch_port.sequential_forward: the reference's eval-mode ops in torch on the device"}
+    # small-batch serving: the un-modified module graph at batch 1 / 8 / 32, eager (host-bound: ~25 Python-driven launches)
+    # and replayed as a hipGraph captured from the same model (utils.graphed; per-rank latencies, no aggregation)
+    if not args.no_extras:
+        from pytorch_quantize_impls_amd import utils
+        serving = {}
+        for sb in (1, 8, 32):
+            xs = torch.randn((sb, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
+            with torch.no_grad():
+                want = model(xs)
+                gm = utils.graphed(model, xs)
+                same = bool(torch.equal(gm(xs), want))
+
+                def lat(fn, n=30):
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / n * 1e3
+                te, tg = lat(lambda: model(xs)), lat(lambda: gm(xs))
+                with lazy.eager():
+                    tm = lat(lambda: model(xs))
+            serving[f"batch_{sb}"] = {"eager_ms": te, "module_by_module_eager_ms": tm, "hipgraph_ms": tg,
+                                      "hipgraph_images_per_s": sb / tg * 1e3, "same_logits": same}
+            del gm
+        out["serving_small_batch"] = serving
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = B                       # the same batch as the GPU leg (one forward = ~1 s on the box's host)
         cpu_model = bench_models.AlexNetBin()
