@@ -153,6 +153,17 @@ def main():
     ops_per_step = 2.0 * B * K * N
     value = world * ops_per_step * args.steps / elapsed / 1e12
     gemm_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
+    # what an event pair measures around NOTHING on a busy stream (marker packets only): the part of the bracket that is
+    # not kernel time; calibrated outside the timed region, behind the same pack kernel as in a step
+    empty = []
+    for _ in range(20):
+        ops.pack_linear_operands(x, w, "binary", gemm_impl)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        empty.append((e0, e1))
+    torch.cuda.synchronize()
+    empty_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
 
     # ---- roofline of the dominant kernel (the packed GEMM) ------------------------------------
     gemm_bytes = ops.packed_gemm_algorithmic_bytes(B, N, K, gemm_impl)  # DESIGN.md "Kernels"
@@ -164,6 +175,11 @@ def main():
                     "kernel_ms_note": f"HIP-event bracket around the launch on every {EVENT_EVERY}th step of the timed region; "
                                       "includes the marker packets / kernel boundary (~3-5 us): rocprofv3 kernel "
                                       "duration is in profiles/",
+                    # an event pair around nothing, measured behind the same pack kernel: the bracket minus this is a LOWER
+                    # bound of the kernel time (part of the marker cost overlaps the kernel); rocprofv3's duration lies
+                    # between the two.  `frac` stays on the bracket (conservative).
+                    "event_pair_empty_ms": empty_ms,
+                    "kernel_ms_lower_bound": max(gemm_ms - empty_ms, 0.0),
                     "hbm_equiv": {"algorithmic_bytes": gemm_bytes,
                                   "achieved_GBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9,
                                   "frac_of_8TBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
