@@ -97,12 +97,10 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
     const int kw = (K + 31) / 32;
     const int ntiles = (kw + KT - 1) / KT;
 
-    // one K-tile travels global -> registers -> (barrier) -> LDS; the registers of tile kt + 1 are loaded right after tile
-    // kt was published, so the global latency runs under tile kt's xor / popcount string instead of in front of it
-    // (round 2: 146.6 -> see profiles/r2_popc_pmc.md).  Out-of-range rows / words are replaced by zeros (they then vanish
-    // from the XOR / mask).
-    uint4 xr[T::NLD], w0r[T::NLD], w1r[TERNARY ? T::NLD : 1];
-    auto fetch = [&](int kt) {
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // stage one K-tile: global -> registers -> (barrier) -> LDS.  Out-of-range rows / words
+        // are replaced by zeros (they then vanish from the XOR / mask).
+        uint4 xr[T::NLD], w0r[T::NLD], w1r[TERNARY ? T::NLD : 1];
 #pragma unroll
         for (int q = 0; q < T::NLD; ++q) {
             const int id = q * 256 + tid;
@@ -120,12 +118,6 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
             w0r[q] = v0;
             if constexpr (TERNARY) w1r[q] = v1;
         }
-    };
-    // (the ternary kernel stages three planes: the extra tile in flight would spill, so it keeps load-then-wait order)
-    constexpr bool PREFETCH = !TERNARY;
-    if (PREFETCH && ntiles > 0) fetch(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if constexpr (!PREFETCH) fetch(kt);
         if (kt > 0) __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int q = 0; q < T::NLD; ++q) {
@@ -137,7 +129,6 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
             if constexpr (TERNARY) *reinterpret_cast<uint4*>(W1l + wrow * S + c4 * 4) = w1r[q];
         }
         __syncthreads();
-        if (PREFETCH && kt + 1 < ntiles) fetch(kt + 1);
 
 #pragma unroll 1
         for (int kk = 0; kk < KT / 2; ++kk) {
