@@ -289,6 +289,31 @@ int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int
                         int64_t Cin, const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
                         qt_stream_t stream);
 
+/* ---- the same weight gradient, PIXEL-MAJOR (csrc/wgrad_pm.hip): operands stay [position][channel], a tap is a row offset,
+ * one workgroup accumulates all kh * kw taps of a 64 (co) x 64 / 32 (ci) tile and reads its MFMA fragments with the
+ * transposing LDS read.  Position space q = (y * N + n) * Wq + x as above.
+ *   qt_wgrad_pm_pack_grad_f32 : G3[(t * Qa + q) * Cp + co] = t-th term (hi / mid / lo) of the exact bf16 split of g; zero for
+ *                               x >= Wo, q >= Ho * N * Wq, co >= Cout.  Cp % 64 == 0, Qa % 32 == 0.
+ *   qt_wgrad_pm_pack_act_f32  : XP[q * Cp + ci] = bf16(xpad * x_scale) over Qx >= (H + 2 ph) * N * Wq rows (zero outside the
+ *                               image, past the pitch, in the tail rows and for ci >= Cin).  Cp % 32 == 0.
+ *   qt_wgrad_pm_f32           : part[((s * taps + tap) * Cpo + co) * Cpi + ci] = sum over the positions of slice s (Qa / nslice
+ *                               each, a multiple of 32) of g[q][co] * XP[q + r * kh_rows + c][ci], tap = r * kw + c.  XP must hold
+ *                               Qa + (kh - 1) * kh_rows + 48 rows.  (kh, kw) = (3, 3) with Cpi % 64 == 0 or (5, 5) with
+ *                               Cpi % 32 == 0; QT_ERR_UNSUPPORTED otherwise.
+ *   qt_wgrad_pm_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= out_scale * sum over slices, times the straight-through
+ *                               mask 1[|weight| <= ste_threshold] when weight != NULL. */
+int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                              int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
+                              qt_stream_t stream);
+int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
+                             float x_scale, uint16_t* XP, qt_stream_t stream);
+int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
+                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
+int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
+                           const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
+                           qt_stream_t stream);
+
 /* Y[M,N] = scale * (*scale_dev) * (Xc . Wc^T) + bias, Xc / Wc int8 code planes (ld in uint32 words).
  * scale_dev: optional DEVICE scalar (e.g. E = mean|W| computed on the device) so no host sync is
  * needed; NULL = 1.  max_abs_code bounds |x code * w code| (127 for +-1/0 weight codes, up to 127*127 for k-bit DoReFa

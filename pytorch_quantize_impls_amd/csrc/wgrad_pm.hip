@@ -1,0 +1,555 @@
+// Weight gradient of a stride-1 conv, PIXEL-MAJOR form (training path; the companion of wgrad.hip):
+//
+//     dW[co, ci, kh, kw] = sum_q  g[q, co] * xpad[q + kh * N * Wq + kw, ci]          q = (y * N + n) * Wq + x
+//
+// wgrad.hip runs this as one GEMM per tap over K-major (transposed) planes, which re-reads the gradient planes once per
+// tap and needs kw pre-shifted activation copies.  Here both operands stay in the order the tensors already have —
+// [position][channel], so a tap is a ROW offset — and ONE workgroup accumulates ALL kh * kw taps of a 64 (co) x TN (ci)
+// tile: per 32-position stage it loads the three exact bf16 planes of the gradient tile once and kh activation tiles of
+// 32 + kw - 1 rows, i.e. ~24 KB of LDS fill for ~1200 cycles of MFMA per wave — matrix-bound where the per-tap GEMM is
+// fill-bound.  The MFMA fragments (8 consecutive positions of one channel per lane) are read out of the [position][channel]
+// LDS tiles with ds_read_b64_tr_b16, the transposing LDS read (semantics: tools/ubench/tr_probe.hip — inside a 16-lane
+// group lane q addresses 4 consecutive channels of row q / 4, lane i receives channel i of the four rows).
+//
+// Work split: 8 waves = (64 / 32) x (TN / 32) output blocks x G tap groups (G = 8 / blocks); a wave owns one 32 x 32
+// (co x ci) block for the taps t = group, group + G, ...; the three gradient terms (hi / mid / lo) accumulate into the same
+// registers, so no row blocks have to be summed afterwards.  K is cut into slices (blockIdx.z); partial results
+// [slice][tap][64-row tiles...] are reduced by wgrad_pm_reduce_kernel, which applies the STE mask / scale as wgrad.hip does.
+#include "qt_common.h"
+
+namespace {
+
+typedef float pm_v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 pm_bf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pm_bf16_rn_bits(float f) {  // round-to-nearest-even, NaN kept quiet (as split_bf16.hip)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// ---- packers (HBM-bound, elementwise: no transposition) ------------------------------------------------------------
+// G3[t][q][Cp]: exact bf16 split of g at position q (zero where x >= Wo, q >= Ho * N * Wq, channel >= Cout)
+__global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh_,
+                                                           int64_t sw, int N, int Cout, int Ho, int Wo, int Wq, int Cp,
+                                                           int64_t Qa, uint16_t* __restrict__ G3) {
+    const int c8 = Cp >> 3;
+    const int64_t total = Qa * c8;
+    const int64_t row_elems = (int64_t)N * Wq;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = t / c8;
+        const int c0 = (int)(t - q * c8) << 3;
+        const int64_t y = q / row_elems, rem = q - y * row_elems;
+        const int n = (int)(rem / Wq), x = (int)(rem - (int64_t)n * Wq);
+        uint32_t h[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (y < Ho && x < Wo) {
+            const float* src = g + (int64_t)n * sn + y * sh_ + (int64_t)x * sw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (c0 + i >= Cout) break;
+                const float v = src[(int64_t)(c0 + i) * sc];
+                const uint32_t a = pm_bf16_rn_bits(v);
+                const float r1 = v - __uint_as_float(a << 16);
+                const uint32_t b = pm_bf16_rn_bits(r1);
+                const uint32_t c = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
+                const int s = (i & 1) * 16;
+                h[0][i >> 1] |= a << s;
+                h[1][i >> 1] |= b << s;
+                h[2][i >> 1] |= c << s;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            *reinterpret_cast<uint4*>(G3 + ((int64_t)s * Qa + q) * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
+    }
+}
+
+// XP[q][Cp]: bf16(x * x_scale) at padded position q = (y * N + n) * Wq + x over Hp rows (zero outside the image, past the
+// pitch, in the tail rows up to Qx and in channels >= Cin)
+__global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
+                                                          int64_t sw, int N, int Cin, int H, int W, int ph, int pw, int Wq,
+                                                          int Cp, int64_t Qx, float x_scale, uint16_t* __restrict__ XP) {
+    const int c8 = Cp >> 3;
+    const int64_t total = Qx * c8;
+    const int64_t row_elems = (int64_t)N * Wq;
+    const int Hp = H + 2 * ph;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = t / c8;
+        const int c0 = (int)(t - q * c8) << 3;
+        const int64_t y = q / row_elems, rem = q - y * row_elems;
+        const int n = (int)(rem / Wq), x = (int)(rem - (int64_t)n * Wq);
+        const int yy = (int)y - ph, xx = x - pw;
+        uint32_t h[4] = {0, 0, 0, 0};
+        if (y < Hp && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float* src = xin + (int64_t)n * sn + (int64_t)yy * sh_ + (int64_t)xx * sw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (c0 + i >= Cin) break;
+                h[i >> 1] |= pm_bf16_rn_bits(src[(int64_t)(c0 + i) * sc] * x_scale) << ((i & 1) * 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(XP + q * Cp + c0) = make_uint4(h[0], h[1], h[2], h[3]);
+    }
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+struct PmArgs {
+    const unsigned char* G3;   // [3][Qa][Cpo] bf16
+    const unsigned char* XP;   // [Qx][Cpi] bf16
+    float* part;               // [nslice][taps][Cpo][Cpi] fp32
+    long long Qa;              // positions per gradient plane (a multiple of 32 * nslice ... see launch)
+    long long kh_rows;         // N * Wq: position offset of one kernel row
+    long long slice_pos;       // positions per K slice (multiple of 32)
+    int Cpo, Cpi;
+    int tiles_co, tiles_ci, total;   // 64-row tiles, TN-column tiles, tiles_co * tiles_ci * nslice
+};
+
+constexpr int PM_KS = 32;       // positions per stage (two MFMA k-steps of 16)
+
+template <int TM, int TN, int KH, int KW>
+struct PmCfg {
+    static constexpr int T = KH * KW;
+    static constexpr int NH = TN / 32;                    // 32-channel sub-tiles of the activation tile
+    static constexpr int MB = TM / 32;                    // 32-channel sub-tiles of the gradient tile
+    static constexpr int MW = TM / 64;                    // 32 x 32 output blocks a wave owns per tap (stacked along co)
+    static constexpr int WB = 2 * NH;                     // wave positions in the tile: 2 (co halves) x NH
+    static constexpr int G = 8 / WB;                      // tap groups
+    static constexpr int MAXT = (T + G - 1) / G;          // taps per wave
+    // LDS image: 32-channel sub-tiles with a 64-byte row pitch — the four rows x 64 bytes a half-wave's transposing read
+    // touches are then 256 consecutive bytes (every bank once); a 128-byte pitch would put rows r and r + 2 on the same banks
+    static constexpr int XNEED = PM_KS + KW - 1;          // activation rows one stage reads per kernel row
+    static constexpr int XR = (XNEED + 15) / 16 * 16;     // rows reserved (whole 16-row DMA pieces; surplus lanes are masked off)
+    static constexpr int A_BYTES = 3 * MB * PM_KS * 64;   // gradient tile: 3 planes x MB sub-tiles x 32 rows
+    static constexpr int X_BYTES = KH * NH * XR * 64;
+    static constexpr int STAGE = A_BYTES + X_BYTES;
+    static constexpr int NST = 3;                         // ring depth: the DMA runs two stages ahead of the MFMAs
+    static constexpr int LDS = NST * STAGE;
+    // one stage = LDS-DMA pieces of 1 KiB (64 lanes x 16 bytes = 16 rows of one sub-tile), dealt round-robin to the 8 waves
+    static constexpr int A_PIECES = 3 * MB * 2;
+    static constexpr int XP_PER = XR / 16;
+    static constexpr int PIECES = A_PIECES + KH * NH * XP_PER;
+    static constexpr int NPW = (PIECES + 7) / 8;          // pieces per wave (the last round may be short)
+};
+
+// 64 lanes x 16 bytes, global -> LDS at the wave-uniform byte address lds_dst, no VGPR round trip.  Issued from asm so that
+// the compiler does not drain vmcnt in front of later LDS reads: the kernel counts its own outstanding pieces.
+__device__ __forceinline__ void pm_dma16(const unsigned char* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void pm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int KH, int KW>
+__global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
+    using C = PmCfg<TM, TN, KH, KW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = wave % C::WB, tg = wave / C::WB;
+    const int mg = wb & 1, nb = wb >> 1;
+    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2), so id
+    // -> (id % 8) * (grid / 8) + id / 8 puts a contiguous run of logical tiles on one XCD; logical order = ci tile fastest, then
+    // co tile, then K slice: the workgroups sharing a gradient tile (the larger operand) and a slice's activation rows sit
+    // behind the same L2 and move through the positions together
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= a.total) return;
+    const int ci_t = logical % a.tiles_ci, rest = logical / a.tiles_ci;
+    const int co_t = rest % a.tiles_co, slice = rest / a.tiles_co;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const long long q_begin = (long long)slice * a.slice_pos;
+    const int nstages = (int)(a.slice_pos / PM_KS);
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+    pm_v16f acc[C::MAXT][C::MW];
+#pragma unroll
+    for (int i = 0; i < C::MAXT; ++i)
+#pragma unroll
+        for (int j = 0; j < C::MW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // this wave's pieces: per-lane source address at stage 0, LDS offset inside a stage, bytes to advance per stage
+    const int prow = lane >> 2, pch = (lane & 3) * 16;
+    const unsigned char* psrc[C::NPW];
+    unsigned pdst[C::NPW];
+    bool pact[C::NPW];
+    const long long a_step = (long long)PM_KS * a.Cpo * 2, x_step = (long long)PM_KS * a.Cpi * 2;
+#pragma unroll
+    for (int j = 0; j < C::NPW; ++j) {
+        const int p = j * 8 + wave;
+        if (p < C::A_PIECES) {
+            const int t = p / (2 * C::MB), sub = (p >> 1) % C::MB, r16 = p & 1;
+            psrc[j] = a.G3 + (((long long)t * a.Qa + q_begin + r16 * 16 + prow) * a.Cpo + co0 + sub * 32) * 2 + pch;
+            pdst[j] = (unsigned)(((t * C::MB + sub) * PM_KS + r16 * 16) * 64);
+            pact[j] = true;
+        } else {
+            const int px = (p < C::PIECES ? p : C::A_PIECES) - C::A_PIECES;
+            const int sub = px / C::XP_PER, pr = px - sub * C::XP_PER;           // sub = kh * NH + h
+            const int kh = sub / C::NH, h = sub - kh * C::NH;
+            psrc[j] = a.XP + ((q_begin + (long long)kh * a.kh_rows + pr * 16 + prow) * a.Cpi + ci0 + h * 32) * 2 + pch;
+            pdst[j] = (unsigned)(C::A_BYTES + (sub * C::XR + pr * 16) * 64);
+            pact[j] = pr * 16 + prow < C::XNEED;                                 // rows past the ones a stage reads: lane masked off
+        }
+    }
+    const int n_mine = (C::PIECES - wave + 7) / 8;                               // pieces this wave issues per stage (wave-uniform)
+
+    auto issue_stage = [&](int s) {
+        const unsigned base = lds0 + (unsigned)((s % C::NST) * C::STAGE);
+#pragma unroll
+        for (int j = 0; j < C::NPW; ++j) {
+            const int p = j * 8 + wave;
+            if (j == C::NPW - 1 && p >= C::PIECES) break;
+            const unsigned char* src = psrc[j] + (long long)s * (p < C::A_PIECES ? a_step : x_step);
+            if (pact[j]) pm_dma16(src, base + pdst[j]);
+        }
+    };
+    // wait until at most `this wave's pieces of ONE stage` are outstanding (the DMA queue retires in order)
+    auto wait_one_stage_in_flight = [&]() {
+        if (n_mine == C::NPW) pm_wait_vm<C::NPW>();
+        else pm_wait_vm<C::NPW - 1>();
+    };
+
+    // fragment addressing (ds_read_b64_tr_b16): lane l, read r of a k-step: row = 8 (l >> 5) + 4 r + ((l & 15) >> 2),
+    // column (within the 32-channel sub-tile) = 16 ((l >> 4) & 1) + 4 (l & 3)
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const unsigned a_off = (unsigned)((mg * C::MW * PM_KS + frow) * 64 + fcol * 2);
+    const unsigned x_off = (unsigned)(C::A_BYTES + (nb * C::XR + frow) * 64 + fcol * 2);
+
+    if (nstages > 0) issue_stage(0);
+    if (nstages > 1) issue_stage(1);
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) wait_one_stage_in_flight();      // stage s landed (this wave's share) ...
+        else pm_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                         // ... and everybody's; everybody is also done reading stage s - 1,
+        if (s + 2 < nstages) issue_stage(s + 2);              // whose buffer takes stage s + 2
+        const unsigned sb = lds0 + (unsigned)((s % C::NST) * C::STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint2 af[C::MW][3][2], xf[2][2];
+            auto read_x = [&](int i, uint2 (&dst)[2]) {
+                const int tap = tg + i * C::G;
+                const int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
+                                 : "=v"(dst[r])
+                                 : "v"(sb + x_off + (unsigned)((kh * C::NH * C::XR + kw) * 64)), "n"((ks * 16 + r * 4) * 64)
+                                 : "memory");
+            };
+#pragma unroll
+            for (int j = 0; j < C::MW; ++j)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
+                                     : "=v"(af[j][t][r])
+                                     : "v"(sb + a_off), "n"(((t * C::MB + j) * PM_KS + ks * 16 + r * 4) * 64)
+                                     : "memory");
+            read_x(0, xf[0]);
+#pragma unroll
+            for (int i = 0; i < C::MAXT; ++i) {
+                const int tap = tg + i * C::G;
+                // only the last tap index can fall off the end (group tg > (T - 1) % G): everything before it is straight-line code
+                if ((C::G - 1) + i * C::G < C::T || tap < C::T) {
+                    const bool more = i + 1 < C::MAXT && ((C::G - 1) + (i + 1) * C::G < C::T || tap + C::G < C::T);
+                    // one tap ahead: its reads fly under this tap's MFMAs.  The fragment registers are operands of the wait so
+                    // that no MFMA reading them can be scheduled above it
+#define PM_WAIT(n)                                                                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)             \
+        asm volatile("" : "+v"(af[j_][t_][0]), "+v"(af[j_][t_][1]));                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(xf[i & 1][0]), "+v"(xf[i & 1][1])::"memory");                      \
+    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)             \
+        asm volatile("" : "+v"(af[j_][t_][0]), "+v"(af[j_][t_][1]))
+                    if (more) {
+                        read_x(i + 1, xf[(i + 1) & 1]);
+                        PM_WAIT(2);
+                    } else {
+                        PM_WAIT(0);
+                    }
+#undef PM_WAIT
+                    pm_bf8 bv;
+                    const uint4 bq = make_uint4(xf[i & 1][0].x, xf[i & 1][0].y, xf[i & 1][1].x, xf[i & 1][1].y);
+                    __builtin_memcpy(&bv, &bq, 16);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int j = 0; j < C::MW; ++j) {
+                            pm_bf8 av;
+                            const uint4 aq = make_uint4(af[j][t][0].x, af[j][t][0].y, af[j][t][1].x, af[j][t][1].y);
+                            __builtin_memcpy(&av, &aq, 16);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+
+    // partial result: part[slice][tap][co][ci]; accumulator register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+    const int lrow4 = 4 * (lane >> 5), col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < C::MAXT; ++i) {
+        const int tap = tg + i * C::G;
+        if (tap < C::T) {
+#pragma unroll
+            for (int j = 0; j < C::MW; ++j) {
+                float* dst = a.part + (((long long)slice * C::T + tap) * a.Cpo + co0 + (mg * C::MW + j) * 32) * a.Cpi + ci0 + nb * 32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2) + lrow4) * a.Cpi] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ---- the software-pipelined form for tiles of exactly 8 blocks (128 x 64): one wave = one 32 x 32 block, ALL taps ---------------
+// Every wave runs the same straight-line code: per stage 2 k-steps x T taps = 2 T "steps" of three MFMAs (the gradient's hi / mid
+// / lo terms) into the tap's accumulator.  The activation fragment of step j + 1 is read under the MFMAs of step j; the gradient
+// fragments of the next k-step are read two steps before they are needed — for the last k-step of a stage these come from the
+// NEXT stage's buffer, which is why the stage hand-over (vmcnt(0) for this wave's share of stage s + 1, the workgroup barrier, the
+// DMA issue for stage s + 2 into the buffer stage s - 1 used) sits three steps before the end of the stage instead of at its
+// end: no wave ever waits on LDS latency with an idle matrix pipe except in the prologue.
+template <int TM, int TN, int KH, int KW>
+__global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
+    using C = PmCfg<TM, TN, KH, KW>;
+    static_assert(C::MB * C::NH == 8, "one wave per 32 x 32 block");
+    constexpr int T = C::T, STEPS = 2 * T, HANDOVER = STEPS - 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mblk = wave % C::MB, nb = wave / C::MB;
+    const int per_xcd = (int)(gridDim.x >> 3);                                   // XCD-aware order, as wgrad_pm_kernel
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= a.total) return;
+    const int ci_t = logical % a.tiles_ci, rest = logical / a.tiles_ci;
+    const int co_t = rest % a.tiles_co, slice = rest / a.tiles_co;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const long long q_begin = (long long)slice * a.slice_pos;
+    const int nstages = (int)(a.slice_pos / PM_KS);
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+    pm_v16f acc[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int prow = lane >> 2, pch = (lane & 3) * 16;
+    const unsigned char* psrc[C::NPW];
+    unsigned pdst[C::NPW];
+    bool pact[C::NPW];
+    const long long a_step = (long long)PM_KS * a.Cpo * 2, x_step = (long long)PM_KS * a.Cpi * 2;
+#pragma unroll
+    for (int j = 0; j < C::NPW; ++j) {
+        const int p = j * 8 + wave;
+        if (p < C::A_PIECES) {
+            const int t = p / (2 * C::MB), sub = (p >> 1) % C::MB, r16 = p & 1;
+            psrc[j] = a.G3 + (((long long)t * a.Qa + q_begin + r16 * 16 + prow) * a.Cpo + co0 + sub * 32) * 2 + pch;
+            pdst[j] = (unsigned)(((t * C::MB + sub) * PM_KS + r16 * 16) * 64);
+            pact[j] = true;
+        } else {
+            const int px = (p < C::PIECES ? p : C::A_PIECES) - C::A_PIECES;
+            const int sub = px / C::XP_PER, pr = px - sub * C::XP_PER;
+            const int kh = sub / C::NH, h = sub - kh * C::NH;
+            psrc[j] = a.XP + ((q_begin + (long long)kh * a.kh_rows + pr * 16 + prow) * a.Cpi + ci0 + h * 32) * 2 + pch;
+            pdst[j] = (unsigned)(C::A_BYTES + (sub * C::XR + pr * 16) * 64);
+            pact[j] = pr * 16 + prow < C::XNEED;
+        }
+    }
+    auto issue_stage = [&](int s) {
+        const unsigned base = lds0 + (unsigned)((s % C::NST) * C::STAGE);
+#pragma unroll
+        for (int j = 0; j < C::NPW; ++j) {
+            const int p = j * 8 + wave;
+            if (j == C::NPW - 1 && p >= C::PIECES) break;
+            const unsigned char* src = psrc[j] + (long long)s * (p < C::A_PIECES ? a_step : x_step);
+            if (pact[j]) pm_dma16(src, base + pdst[j]);
+        }
+    };
+
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const unsigned a_off = (unsigned)((mblk * PM_KS + frow) * 64 + fcol * 2);
+    const unsigned x_off = (unsigned)(C::A_BYTES + (nb * C::XR + frow) * 64 + fcol * 2);
+
+    uint2 af[2][3][2], xf[2][2];
+#define PM_READ_A(base, ks, dst)                                                                                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[t_][r_]) : "v"((base) + a_off),                     \
+                     "n"((t_ * C::MB * PM_KS + (ks) * 16 + r_ * 4) * 64) : "memory")
+#define PM_READ_X(base, ks, tap, dst)                                                                                     \
+    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[r_]) : "v"((base) + x_off),                         \
+                     "n"(((((tap) / KW) * C::NH * C::XR + (tap) % KW) + (ks) * 16 + r_ * 4) * 64) : "memory")
+
+    if (nstages <= 0) return;
+    issue_stage(0);
+    if (nstages > 1) issue_stage(1);
+    pm_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    PM_READ_A(lds0, 0, af[0]);
+    PM_READ_X(lds0, 0, 0, xf[0]);
+    for (int s = 0; s < nstages; ++s) {
+        const unsigned sb = lds0 + (unsigned)((s % C::NST) * C::STAGE);
+        const unsigned sbn = lds0 + (unsigned)(((s + 1) % C::NST) * C::STAGE);
+        const bool has_next = s + 1 < nstages;
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+            const int ks = j / T, tap = j - ks * T;
+            if (j == HANDOVER && has_next) {
+                pm_wait_vm<0>();                                  // this wave's share of stage s + 1 (issued a whole stage ago)
+                __builtin_amdgcn_s_barrier();                     // everybody's; and everybody is past stage s - 1
+                if (s + 2 < nstages) issue_stage(s + 2);
+            }
+            // next step's activation fragment, then (two steps ahead of their first use) the next k-step's gradient fragments
+            int newer = 0;
+            if (j + 1 < STEPS) {
+                PM_READ_X(sb, (j + 1) / T, (j + 1) % T, xf[(j + 1) & 1]);
+                newer += 2;
+            } else if (has_next) {
+                PM_READ_X(sbn, 0, 0, xf[(j + 1) & 1]);
+                newer += 2;
+            }
+            if (tap == T - 3) {
+                if (ks == 0) {
+                    PM_READ_A(sb, 1, af[1]);
+                    newer += 6;
+                } else if (has_next) {
+                    PM_READ_A(sbn, 0, af[0]);
+                    newer += 6;
+                }
+            }
+            const bool a_prev = tap == T - 2;                     // the gradient reads issued one step ago may still be in flight
+            // LDS returns in order: everything older than the `newer` most recent reads has landed.  `newer` is a compile-time
+            // number on every path but the last stage, where the skipped prefetches make the wait stricter (never looser)
+            // (the fragment registers are operands of the wait so that no MFMA reading them can be scheduled above it)
+#define PM_WAIT(n)                                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                      \
+                 : "+v"(xf[j & 1][0]), "+v"(xf[j & 1][1]), "+v"(af[ks][0][0]), "+v"(af[ks][0][1]), "+v"(af[ks][1][0]),            \
+                   "+v"(af[ks][1][1]), "+v"(af[ks][2][0]), "+v"(af[ks][2][1])::"memory")
+            if (!has_next && (j + 1 >= STEPS || (tap >= T - 3 && ks == 1))) PM_WAIT(0);
+            else if (newer + (a_prev ? 6 : 0) == 8) PM_WAIT(8);
+            else PM_WAIT(2);
+#undef PM_WAIT
+            pm_bf8 bv;
+            const uint4 bq = make_uint4(xf[j & 1][0].x, xf[j & 1][0].y, xf[j & 1][1].x, xf[j & 1][1].y);
+            __builtin_memcpy(&bv, &bq, 16);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                pm_bf8 av;
+                const uint4 aq = make_uint4(af[ks][t][0].x, af[ks][t][0].y, af[ks][t][1].x, af[ks][t][1].y);
+                __builtin_memcpy(&av, &aq, 16);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+#undef PM_READ_A
+#undef PM_READ_X
+
+    const int lrow4 = 4 * (lane >> 5), col = lane & 31;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+        float* dst = a.part + (((long long)slice * T + tap) * a.Cpo + co0 + mblk * 32) * a.Cpi + ci0 + nb * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2) + lrow4) * a.Cpi] = acc[tap][r];
+    }
+}
+
+// one work item = one (co, ci, tap): sums the K slices, applies scale and the STE mask, writes / accumulates dW
+__global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int taps, int Cpo, int Cpi,
+                                                        int Cout, int Cin, const float* __restrict__ weight, float thr,
+                                                        float out_scale, int accumulate, float* __restrict__ dW) {
+    const int64_t total = (int64_t)taps * Cout * Cin;
+    const int64_t slice_elems = (int64_t)taps * Cpo * Cpi;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(t % Cin);
+        const int64_t r = t / Cin;
+        const int co = (int)(r % Cout), tap = (int)(r / Cout);
+        const float* p = part + ((int64_t)tap * Cpo + co) * Cpi + ci;
+        float s = 0.0f;
+        for (int sl = 0; sl < nslice; ++sl) s += p[sl * slice_elems];
+        s *= out_scale;
+        const int64_t o = ((int64_t)co * Cin + ci) * taps + tap;
+        if (weight && !(fabsf(weight[o]) <= thr)) s = 0.0f;
+        dW[o] = accumulate ? dW[o] + s : s;
+    }
+}
+
+template <int TM, int TN, int KH, int KW, bool FULL = false>
+int pm_launch(const PmArgs& a, int nslice, hipStream_t stream) {
+    using C = PmCfg<TM, TN, KH, KW>;
+    void (*kernel)(PmArgs) = wgrad_pm_kernel<TM, TN, KH, KW>;
+    if constexpr (FULL) kernel = wgrad_pm_full_kernel<TM, TN, KH, KW>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+        return QT_ERR_LAUNCH;
+    PmArgs b = a;
+    b.tiles_co = a.Cpo / TM;
+    b.tiles_ci = a.Cpi / TN;
+    const long long total = (long long)b.tiles_co * b.tiles_ci * nslice;
+    if (total > (1ll << 30)) return QT_ERR_UNSUPPORTED;
+    b.total = (int)total;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(512), C::LDS, stream, b);
+    return qt_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                              int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
+                              qt_stream_t stream) {
+    if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G3) return QT_ERR_INVALID_ARG;
+    if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G3)) return QT_ERR_ALIGNMENT;
+    if (N * Wq >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_grad_kernel, dim3(qt_stream_grid((Qa * (Cp >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       stride_n, stride_c, stride_h, stride_w, (int)N, (int)Cout, (int)Ho, (int)Wo, (int)Wq, (int)Cp, Qa, G3);
+    return qt_check_launch();
+}
+
+int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
+                             float x_scale, uint16_t* XP, qt_stream_t stream) {
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || !x || !XP) return QT_ERR_INVALID_ARG;
+    if (Wq < W + 2 * pw || Cp < Cin || (Cp & 31) || Qx < (H + 2 * ph) * N * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
+    if (N * Wq >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_act_kernel, dim3(qt_stream_grid((Qx * (Cp >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       stride_n, stride_c, stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp,
+                       Qx, x_scale, XP);
+    return qt_check_launch();
+}
+
+// part[nslice][kh * kw][Cpo][Cpi] = per-slice partial gradients; Qa = nslice * slice_pos, slice_pos % 32 == 0;
+// XP must hold (kh - 1) * kh_rows + Qa + 48 rows (kw - 1 are read).  Supported: (kh, kw) = (3, 3) with Cpi % 64 == 0, (5, 5) with Cpi % 32 == 0.
+int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
+                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream) {
+    if (!G3 || !XP || !part || Qa <= 0 || nslice <= 0 || nslice > 65535 || kh_rows <= 0) return QT_ERR_INVALID_ARG;
+    if ((Qa % (32 * nslice)) || (Cpo & 63) || !qt_aligned16(G3) || !qt_aligned16(XP) || !qt_aligned16(part)) return QT_ERR_ALIGNMENT;
+    PmArgs a;
+    a.G3 = reinterpret_cast<const unsigned char*>(G3);
+    a.XP = reinterpret_cast<const unsigned char*>(XP);
+    a.part = part; a.Qa = Qa; a.kh_rows = kh_rows; a.slice_pos = Qa / nslice; a.Cpo = (int)Cpo; a.Cpi = (int)Cpi;
+    hipStream_t s = (hipStream_t)stream;
+    if (kh == 3 && kw == 3 && !(Cpi & 63)) return (Cpo & 127) ? pm_launch<64, 64, 3, 3>(a, (int)nslice, s) : pm_launch<128, 64, 3, 3, true>(a, (int)nslice, s);
+    if (kh == 5 && kw == 5 && !(Cpi & 31)) return pm_launch<64, 32, 5, 5>(a, (int)nslice, s);
+    return QT_ERR_UNSUPPORTED;
+}
+
+int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
+                           const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
+                           qt_stream_t stream) {
+    if (!part || !dW || nslice <= 0 || taps <= 0 || Cout <= 0 || Cin <= 0 || Cpo < Cout || Cpi < Cin) return QT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pm_reduce_kernel, dim3(qt_stream_grid((taps * Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, (int)nslice, (int)taps, (int)Cpo, (int)Cpi, (int)Cout, (int)Cin, weight, ste_threshold, out_scale,
+                       accumulate, dW);
+    return qt_check_launch();
+}
+
+}  // extern "C"

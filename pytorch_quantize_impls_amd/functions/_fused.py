@@ -464,8 +464,12 @@ class QuantConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = None
             if mfma and ctx.x_is_pm1:     # +-1 activation x real gradient, contraction over the pixels
-                if ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
-                    # batched bf16 GEMMs over K-major planes; the STE mask of the weight quantiser is its epilogue
+                if ops.wgrad_pm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
+                    # pixel-major kernel: every tap of a tile in one workgroup; the STE mask of the weight quantiser is the
+                    # epilogue of its reduce step
+                    grad_weight = ops.conv2d_grad_weight_pm(input, grad_output, weight.shape[2:], padding, weight=weight)
+                if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
+                    # batched bf16 GEMMs over K-major planes (other kernel sizes)
                     grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, weight=weight)
                 if grad_weight is None:
                     gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
@@ -678,10 +682,12 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
                 grad_input = torch.nn.grad.conv2d_input(input.shape, sgn * E, go, stride=stride, padding=padding,
                                                         dilation=dilation, groups=groups)
         if ctx.needs_input_grad[1]:
-            if (mfma and ctx.x_levels is not None and ctx.x_levels <= 255
-                    and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation)):
+            if mfma and ctx.x_levels is not None and ctx.x_levels <= 255:
                 # UNscaled and un-masked, as upstream (_ignore_factor_op, identity STE): functions/dorefa_connect.py:66-79
-                grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
+                if ops.wgrad_pm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
+                    grad_weight = ops.conv2d_grad_weight_pm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
+                if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
+                    grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,

@@ -1553,6 +1553,7 @@ def conv2d_grad_weight_pm1(x_pm1: torch.Tensor, grad_output: torch.Tensor, kerne
 WGRAD_GEMM_BYTES = 6 << 30
 #: workgroups one weight-gradient launch aims for (K slices = this / (tiles x taps))
 WGRAD_WORKGROUPS = 1024
+WGRAD_PM_WORKGROUPS = 256
 
 
 def _round_up(v: int, m: int) -> int:
@@ -1647,6 +1648,79 @@ def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kern
             _lib.call("qt_bf16_gemm_taps", _p(Au), I(lda_use // 2), _p(Bu), I(ldb_use // 2), _p(part), I(ldc), I(M), I(Cin),
                       I(k_use), I(kh), I(kw), I(nslice), I(Cin * ldb_use * 2), I(cnt * Wq * 2), I(M * ldc), st)
             _lib.call("qt_wgrad_reduce_f32", _p(part), I(ldc), I(M * ldc), I(taps), I(nslice), I(Cout), I(Cin), _p(w),
+                      float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
+    return dW
+
+
+def wgrad_pm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
+    """Shapes the pixel-major weight-gradient kernel (csrc/wgrad_pm.hip) is built for: stride 1, un-dilated, 3 x 3 or 5 x 5."""
+    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    return sh == sw == 1 and dh == dw == 1 and (kh, kw) in ((3, 3), (5, 5)) and int(x_shape[1]) >= 32 and int(g_shape[1]) >= 32
+
+
+def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
+                          weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
+                          x_levels: float = 1.0, workgroups: int = 0):
+    """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
+    [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
+    the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs."""
+    _require(x_pm1, "input")
+    _require(grad_output, "grad_output")
+    kh, kw = (int(v) for v in kernel_hw)
+    ph, pw = _pairs(padding)
+    N, Cin, H, W = (int(v) for v in x_pm1.shape)
+    N2, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    if (N2 != N or Ho != H + 2 * ph - kh + 1 or Wo != W + 2 * pw - kw + 1 or Ho <= 0 or Wo <= 0 or N == 0
+            or (kh, kw) not in ((3, 3), (5, 5))):
+        return None
+    tn = 64 if kh == 3 else 32
+    Cpo, Cpi = _round_up(Cout, 64), _round_up(Cin, tn)
+    Wq, Hp, taps = W + 2 * pw, H + 2 * ph, kh * kw
+    tm = 128 if (kh == 3 and Cpo % 128 == 0) else 64                 # the kernel's own tile rule (qt_wgrad_pm_f32)
+    tiles = (Cpo // tm) * (Cpi // tn)
+    slots = workgroups or WGRAD_PM_WORKGROUPS                        # resident workgroups: one per CU (three-stage LDS ring)
+
+    def plan(nc):
+        ktot = Ho * nc * Wq
+        # K slices: the launch runs ceil(tiles * nslice / slots) rounds of ceil(ktot / nslice / 32) stages each
+        nslice = min(range(1, max(2, min(257, ktot // 256 + 1))),
+                     key=lambda ns: (-(-tiles * ns // slots) * -(-ktot // (ns * 32)), ns))
+        ks = _round_up(-(-ktot // nslice), 32)
+        qa = ks * nslice
+        qx = max(Hp * nc * Wq, qa + (kh - 1) * nc * Wq + 48)
+        nbytes = 3 * qa * Cpo * 2 + qx * Cpi * 2 + nslice * taps * Cpo * Cpi * 4
+        return nbytes <= WGRAD_GEMM_BYTES, nslice, qa, qx
+
+    nc = N
+    while nc > 1 and not plan(nc)[0]:
+        nc = (nc + 1) // 2
+    ok, nslice, qa, qx = plan(nc)
+    if not ok:
+        return None
+    dev = x_pm1.device
+    g, x = grad_output.detach(), x_pm1.detach()
+    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
+    G3 = torch.empty((3 * qa * Cpo,), dtype=torch.int16, device=dev)
+    XP = torch.empty((qx * Cpi,), dtype=torch.int16, device=dev)
+    part = torch.empty((nslice * taps * Cpo * Cpi,), dtype=torch.float32, device=dev)
+    w = None
+    if weight is not None:
+        w = _require(weight.detach(), "weight").contiguous()
+    I = int
+    st = _stream(dev)
+    with _on(dev):
+        for n0 in range(0, N, nc):
+            cnt = min(nc, N - n0)
+            gs, xs = g[n0:n0 + cnt], x[n0:n0 + cnt]
+            _, ns_u, qa_u, qx_u = plan(cnt) if cnt != nc else (True, nslice, qa, qx)
+            _lib.call("qt_wgrad_pm_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
+                      I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), st)
+            _lib.call("qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                      I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx_u), float(x_levels), _p(XP), st)
+            _lib.call("qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u), I(Cpo), I(Cpi), I(kh), I(kw), st)
+            _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
                       float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
     return dW
 

@@ -723,10 +723,14 @@ def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind
     finally:
         _fused.BWD_MFMA_MIN_MACS, ops.WEIGHT_GRAD_MAX_PIXELS = old_min, old_pix
     used_now = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items()}
-    # forward + grad_input on the implicit conv; grad_weight as the batched K-major GEMM (or the swapped conv)
-    gemm_route = ops.wgrad_gemm_applicable(xs.shape, y.shape, (k, k), 1, 1)
+    # forward + grad_input on the implicit conv; grad_weight on the pixel-major kernel (3 x 3 / 5 x 5), else as the batched
+    # K-major GEMM, else the swapped conv
+    pm_route = ops.wgrad_pm_applicable(xs.shape, y.shape, (k, k), 1, 1)
+    gemm_route = not pm_route and ops.wgrad_gemm_applicable(xs.shape, y.shape, (k, k), 1, 1)
+    assert pm_route
+    assert used_now.get("qt_wgrad_pm_f32", 0) == (1 if pm_route else 0)
     assert used_now.get("qt_bf16_gemm_taps", 0) == (1 if gemm_route else 0)
-    assert used_now.get("qt_conv2d_implicit", 0) >= (2 if gemm_route else 3)
+    assert used_now.get("qt_conv2d_implicit", 0) >= (2 if (gemm_route or pm_route) else 3)
     assert dict(_fused.LIBRARY_PATHS) == lib_before                                                 # no dense-library detour
     wq = (torch.where(conv.weight < 0, -1.0, 1.0) if kind == "binary" else ops.ternarize(conv.weight.detach())).double()
     gi = torch.nn.grad.conv2d_input(xs.shape, wq, gout.double(), padding=pd)
@@ -783,6 +787,60 @@ def test_weight_gradient_gemm_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
         assert norm_err(n(chunked), ref.cpu().numpy()) <= TOL
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,p,cl", [(3, 40, 70, 7, 9, 3, 1, False), (2, 33, 65, 6, 5, 5, 2, True),
+                                                    (1, 64, 64, 5, 5, 3, 0, True), (5, 96, 32, 9, 7, 5, 0, False),
+                                                    (17, 130, 200, 4, 4, 3, 1, True), (4, 64, 128, 19, 23, 3, 1, True),
+                                                    (9, 256, 384, 13, 13, 3, 1, True), (6, 64, 96, 27, 27, 5, 2, True)])
+def test_weight_gradient_pixel_major_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
+    """ops.conv2d_grad_weight_pm (csrc/wgrad_pm.hip: [position][channel] operands, every tap of a 64 / 128 x 64 / 32 tile in one
+    workgroup, transposing LDS reads, exact three-term bf16 split of the gradient) against torch.nn.grad.conv2d_weight in fp64:
+    all three kernel instances (128 x 64 pipelined, 64 x 64, 64 x 32 for 5 x 5), channel counts that need padding, both memory
+    formats, ternary activations, a gradient whose channels span six decades, the STE mask, DoReFa levels, and batch chunking
+    with a ragged last chunk."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(N * 1000 + Cin)
+    x = torch.randint(-1, 2, (N, Cin, H, W), generator=g, device=dev).float()             # -1 / 0 / +1
+    Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+    go = torch.randn((N, Cout, Ho, Wo), device=dev, generator=g) * torch.exp(torch.randn((1, Cout, 1, 1), device=dev, generator=g) * 3)
+    if cl:
+        x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g) * 0.8
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), go.double(), stride=1, padding=p)
+    per_channel = ref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-300)
+
+    def check(got, want):
+        assert got.shape == want.shape and got.dtype == torch.float32
+        assert float(((got.double() - want).abs() / per_channel).max()) <= TOL        # normalised PER OUTPUT CHANNEL
+
+    with used("qt_wgrad_pm_pack_grad_f32", "qt_wgrad_pm_pack_act_f32", "qt_wgrad_pm_f32", "qt_wgrad_pm_reduce_f32"):
+        got = ops.conv2d_grad_weight_pm(x, go, (k, k), p)
+    check(got, ref)
+    masked = ops.conv2d_grad_weight_pm(x, go, (k, k), p, weight=w)
+    check(masked, torch.where(w.abs() <= 1.001, ref, torch.zeros_like(ref)))
+    assert bool((masked[w.abs() > 1.001] == 0).all())
+    # k-bit DoReFa image: the codes enter the kernel, the result is scaled by fl(1 / n)
+    xq = torch.randint(0, 16, (N, Cin, H, W), generator=g, device=dev).float() / 15.0
+    refq = torch.nn.grad.conv2d_weight(xq.double(), (Cout, Cin, k, k), go.double(), stride=1, padding=p)
+    gq = ops.conv2d_grad_weight_pm(xq, go, (k, k), p, x_levels=15.0)
+    assert float(((gq.double() - refq).abs() / refq.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-300)).max()) <= TOL
+    # more K slices than the planner would pick, and one workgroup slot (a single slice)
+    for slots in (1, 4096):
+        check(ops.conv2d_grad_weight_pm(x, go, (k, k), p, workgroups=slots), ref)
+    if N > 2:
+        old = ops.WGRAD_GEMM_BYTES
+        try:       # a budget that admits ~2 images per launch: partial gradients are accumulated, the last chunk is ragged
+            Cpo, Cpi = (Cout + 63) // 64 * 64, (Cin + 63) // 64 * 64
+            per_img = 3 * Ho * (W + 2 * p) * Cpo * 2 + (H + 2 * p + k) * (W + 2 * p) * Cpi * 2
+            ops.WGRAD_GEMM_BYTES = 2 * per_img + 64 * k * k * Cpo * Cpi * 4 + (1 << 16)
+            chunked = ops.conv2d_grad_weight_pm(x, go, (k, k), p)
+        finally:
+            ops.WGRAD_GEMM_BYTES = old
+        if chunked is not None:
+            check(chunked, ref)
+    assert ops.conv2d_grad_weight_pm(x, go[:, :, :-1], (k, k), p) is None              # inconsistent shapes: not this route's
+    assert ops.conv2d_grad_weight_pm(x, go, (7, 7), p) is None
+
+
 def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
     """One whole training step of BinaryNet-AlexNet (packed forward, STE masks, grad_input / grad_weight of every conv and
     linear layer on the matrix cores) against the reference's op sequence in torch on the same device (torch.sign,
@@ -794,7 +852,7 @@ def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
         "bench_train_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_train_step.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with used("qt_bf16_gemm_taps", "qt_conv2d_implicit", "qt_nib_gemm"):
+    with used("qt_wgrad_pm_f32", "qt_conv2d_implicit", "qt_nib_gemm"):
         worst = mod.gradient_agreement(16)
     assert worst <= 2e-5, worst
 
@@ -817,7 +875,7 @@ def test_dorefa_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, 
     _fused.BWD_MFMA_MIN_MACS = 0
     lib_before = dict(_fused.LIBRARY_PATHS)
     try:
-        with used("qt_bf16_gemm_taps", "qt_conv2d_implicit"):
+        with used("qt_wgrad_pm_f32" if k == 3 else "qt_bf16_gemm_taps", "qt_conv2d_implicit"):
             y = conv(xq)
             gout = torch.randn_like(y)
             y.backward(gout)
