@@ -29,28 +29,49 @@ __device__ __forceinline__ uint32_t pm_bf16_rn_bits(float f) {  // round-to-near
     return u >> 16;
 }
 
-// ---- packers (HBM-bound, elementwise: no transposition) ------------------------------------------------------------
-// G3[t][q][Cp]: exact bf16 split of g at position q (zero where x >= Wo, q >= Ho * N * Wq, channel >= Cout)
+// ---- packers (HBM-bound, elementwise: no transposition) --------------------------------------------------------------
+// One workgroup per (row y, image n) = Wq consecutive positions; an item = 8 channels of one position (32 bytes of fp32 in,
+// 16 bytes of bf16 out per plane).  Channels-last sources (channel stride 1) put the channel chunks on adjacent lanes — reads and
+// writes are both contiguous; other layouts put adjacent x on adjacent lanes so that each of the eight channel reads is
+// coalesced.  All index arithmetic is 32-bit.
+__device__ __forceinline__ void pm_item(int item, int c8, int Wq, bool channel_fastest, int& x, int& c0) {
+    if (channel_fastest) {
+        x = item / c8;
+        c0 = (item - x * c8) << 3;
+    } else {
+        const int cc = item / Wq;
+        x = item - cc * Wq;
+        c0 = cc << 3;
+    }
+}
+
+// G3[t][q][Cp]: exact bf16 split of g at position q = (y * N + n) * Wq + x (zero where x >= Wo and for channels >= Cout)
 __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh_,
-                                                           int64_t sw, int N, int Cout, int Ho, int Wo, int Wq, int Cp,
-                                                           int64_t Qa, uint16_t* __restrict__ G3) {
-    const int c8 = Cp >> 3;
-    const int64_t total = Qa * c8;
-    const int64_t row_elems = (int64_t)N * Wq;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = t / c8;
-        const int c0 = (int)(t - q * c8) << 3;
-        const int64_t y = q / row_elems, rem = q - y * row_elems;
-        const int n = (int)(rem / Wq), x = (int)(rem - (int64_t)n * Wq);
+                                                           int64_t sw, int N, int Cout, int Wo, int Wq, int Cp, int64_t Qa,
+                                                           uint16_t* __restrict__ G3) {
+    const int c8 = Cp >> 3, items = Wq * c8;
+    const int y = blockIdx.x / N, n = blockIdx.x - y * N;
+    const float* row = g + (int64_t)n * sn + (int64_t)y * sh_;
+    uint16_t* out = G3 + (int64_t)blockIdx.x * Wq * Cp;
+    const bool cf = sc == 1;
+    for (int item = threadIdx.x; item < items; item += 256) {
+        int x, c0;
+        pm_item(item, c8, Wq, cf, x, c0);
         uint32_t h[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        if (y < Ho && x < Wo) {
-            const float* src = g + (int64_t)n * sn + y * sh_ + (int64_t)x * sw;
+        if (x < Wo) {
+            const float* src = row + (int64_t)x * sw + (int64_t)c0 * sc;
+            float v[8];
+            if (cf && c0 + 8 <= Cout && !((reinterpret_cast<uintptr_t>(src)) & 15)) {
+                const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = c0 + i < Cout ? src[(int64_t)i * sc] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (c0 + i >= Cout) break;
-                const float v = src[(int64_t)(c0 + i) * sc];
-                const uint32_t a = pm_bf16_rn_bits(v);
-                const float r1 = v - __uint_as_float(a << 16);
+                const uint32_t a = pm_bf16_rn_bits(v[i]);
+                const float r1 = v[i] - __uint_as_float(a << 16);
                 const uint32_t b = pm_bf16_rn_bits(r1);
                 const uint32_t c = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
                 const int s = (i & 1) * 16;
@@ -61,36 +82,48 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-            *reinterpret_cast<uint4*>(G3 + ((int64_t)s * Qa + q) * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
+            *reinterpret_cast<uint4*>(out + (int64_t)s * Qa * Cp + (int64_t)x * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
     }
 }
 
-// XP[q][Cp]: bf16(x * x_scale) at padded position q = (y * N + n) * Wq + x over Hp rows (zero outside the image, past the
-// pitch, in the tail rows up to Qx and in channels >= Cin)
+// XP[q][Cp]: bf16(x * x_scale) at padded position q = (y * N + n) * Wq + x over the H + 2 ph padded rows (zero outside the image,
+// past the pitch and in channels >= Cin)
 __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
                                                           int64_t sw, int N, int Cin, int H, int W, int ph, int pw, int Wq,
-                                                          int Cp, int64_t Qx, float x_scale, uint16_t* __restrict__ XP) {
-    const int c8 = Cp >> 3;
-    const int64_t total = Qx * c8;
-    const int64_t row_elems = (int64_t)N * Wq;
-    const int Hp = H + 2 * ph;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = t / c8;
-        const int c0 = (int)(t - q * c8) << 3;
-        const int64_t y = q / row_elems, rem = q - y * row_elems;
-        const int n = (int)(rem / Wq), x = (int)(rem - (int64_t)n * Wq);
-        const int yy = (int)y - ph, xx = x - pw;
+                                                          int Cp, float x_scale, uint16_t* __restrict__ XP) {
+    const int c8 = Cp >> 3, items = Wq * c8;
+    const int y = blockIdx.x / N, n = blockIdx.x - y * N;
+    const int yy = y - ph;
+    const bool row_ok = yy >= 0 && yy < H;
+    const float* row = xin + (int64_t)n * sn + (int64_t)yy * sh_;
+    uint16_t* out = XP + (int64_t)blockIdx.x * Wq * Cp;
+    const bool cf = sc == 1;
+    for (int item = threadIdx.x; item < items; item += 256) {
+        int x, c0;
+        pm_item(item, c8, Wq, cf, x, c0);
+        const int xx = x - pw;
         uint32_t h[4] = {0, 0, 0, 0};
-        if (y < Hp && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const float* src = xin + (int64_t)n * sn + (int64_t)yy * sh_ + (int64_t)xx * sw;
+        if (row_ok && xx >= 0 && xx < W) {
+            const float* src = row + (int64_t)xx * sw + (int64_t)c0 * sc;
+            float v[8];
+            if (cf && c0 + 8 <= Cin && !((reinterpret_cast<uintptr_t>(src)) & 15)) {
+                const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (c0 + i >= Cin) break;
-                h[i >> 1] |= pm_bf16_rn_bits(src[(int64_t)(c0 + i) * sc] * x_scale) << ((i & 1) * 16);
+                for (int i = 0; i < 8; ++i) v[i] = c0 + i < Cin ? src[(int64_t)i * sc] : 0.0f;
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i >> 1] |= pm_bf16_rn_bits(v[i] * x_scale) << ((i & 1) * 16);
         }
-        *reinterpret_cast<uint4*>(XP + q * Cp + c0) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(out + (int64_t)x * Cp + c0) = make_uint4(h[0], h[1], h[2], h[3]);
     }
+}
+
+// rows past the packed ones (the K-slice rounding of the gradient planes, the look-ahead rows of the activation plane)
+__global__ __launch_bounds__(256) void pm_zero_kernel(uint4* __restrict__ p, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
@@ -341,37 +374,54 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    // The DMA is issued by waves 0..3 only — one per SIMD: while it runs its ~50 scalar / DMA instructions after the hand-over
+    // barrier, the SIMD's other wave (4..7) keeps the matrix pipe busy, and the mid-stage position of the barrier gives the
+    // issuing wave most of a stage to catch up.  A piece = wave-uniform 64-bit base (SGPRs, advanced by scalar adds) + one of
+    // two per-lane byte offsets (row within the piece x row pitch + 16-byte chunk): no vector ALU work per piece.
+    constexpr int NPD = (C::PIECES + 3) / 4;                                     // pieces per issuing wave
+    const bool dma_wave = wave < 4;
     const int prow = lane >> 2, pch = (lane & 3) * 16;
-    const unsigned char* psrc[C::NPW];
-    unsigned pdst[C::NPW];
-    bool pact[C::NPW];
+    const unsigned voff_a = (unsigned)(prow * a.Cpo * 2 + pch), voff_x = (unsigned)(prow * a.Cpi * 2 + pch);
+    const bool x_tail_lane = 32 + prow < C::XNEED;                               // last piece of a sub-tile: rows 32.. of which XNEED - 32 are read
+    const unsigned char* pbase[NPD];
+    unsigned pdst[NPD];
     const long long a_step = (long long)PM_KS * a.Cpo * 2, x_step = (long long)PM_KS * a.Cpi * 2;
 #pragma unroll
-    for (int j = 0; j < C::NPW; ++j) {
-        const int p = j * 8 + wave;
+    for (int j = 0; j < NPD; ++j) {
+        const int p = j * 4 + (wave & 3);
         if (p < C::A_PIECES) {
             const int t = p / (2 * C::MB), sub = (p >> 1) % C::MB, r16 = p & 1;
-            psrc[j] = a.G3 + (((long long)t * a.Qa + q_begin + r16 * 16 + prow) * a.Cpo + co0 + sub * 32) * 2 + pch;
+            pbase[j] = a.G3 + (((long long)t * a.Qa + q_begin + r16 * 16) * a.Cpo + co0 + sub * 32) * 2;
             pdst[j] = (unsigned)(((t * C::MB + sub) * PM_KS + r16 * 16) * 64);
-            pact[j] = true;
         } else {
             const int px = (p < C::PIECES ? p : C::A_PIECES) - C::A_PIECES;
             const int sub = px / C::XP_PER, pr = px - sub * C::XP_PER;
             const int kh = sub / C::NH, h = sub - kh * C::NH;
-            psrc[j] = a.XP + ((q_begin + (long long)kh * a.kh_rows + pr * 16 + prow) * a.Cpi + ci0 + h * 32) * 2 + pch;
+            pbase[j] = a.XP + ((q_begin + (long long)kh * a.kh_rows + pr * 16) * a.Cpi + ci0 + h * 32) * 2;
             pdst[j] = (unsigned)(C::A_BYTES + (sub * C::XR + pr * 16) * 64);
-            pact[j] = pr * 16 + prow < C::XNEED;
         }
     }
+    static_assert(C::XP_PER == 3 && C::XNEED > 32 && C::XNEED <= 48, "the masked tail piece is the third of its sub-tile");
     auto issue_stage = [&](int s) {
         const unsigned base = lds0 + (unsigned)((s % C::NST) * C::STAGE);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
 #pragma unroll
-        for (int j = 0; j < C::NPW; ++j) {
-            const int p = j * 8 + wave;
-            if (j == C::NPW - 1 && p >= C::PIECES) break;
-            const unsigned char* src = psrc[j] + (long long)s * (p < C::A_PIECES ? a_step : x_step);
-            if (pact[j]) pm_dma16(src, base + pdst[j]);
+        for (int j = 0; j < NPD; ++j) {
+            const int p = j * 4 + (wave & 3);
+            if (j == NPD - 1 && p >= C::PIECES) break;
+            const bool is_a = p < C::A_PIECES;
+            const bool tail = !is_a && (p - C::A_PIECES) % C::XP_PER == C::XP_PER - 1;
+            const unsigned long long pb = (unsigned long long)pbase[j];
+            const unsigned long long pbu = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pb >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + pdst[j]);
+            if (!tail || x_tail_lane)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(is_a ? voff_a : voff_x), "s"(pbu), "s"(dst) : "memory");
+            pbase[j] += is_a ? a_step : x_step;
         }
+        asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory");
     };
 
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2);
@@ -390,8 +440,10 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
                      "n"(((((tap) / KW) * C::NH * C::XR + (tap) % KW) + (ks) * 16 + r_ * 4) * 64) : "memory")
 
     if (nstages <= 0) return;
-    issue_stage(0);
-    if (nstages > 1) issue_stage(1);
+    if (dma_wave) {
+        issue_stage(0);
+        if (nstages > 1) issue_stage(1);
+    }
     pm_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     PM_READ_A(lds0, 0, af[0]);
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
             if (j == HANDOVER && has_next) {
                 pm_wait_vm<0>();                                  // this wave's share of stage s + 1 (issued a whole stage ago)
                 __builtin_amdgcn_s_barrier();                     // everybody's; and everybody is past stage s - 1
-                if (s + 2 < nstages) issue_stage(s + 2);
+                if (dma_wave && s + 2 < nstages) issue_stage(s + 2);
             }
             // next step's activation fragment, then (two steps ahead of their first use) the next k-step's gradient fragments
             int newer = 0;
@@ -508,9 +560,13 @@ int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c
                               qt_stream_t stream) {
     if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G3) return QT_ERR_INVALID_ARG;
     if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G3)) return QT_ERR_ALIGNMENT;
-    if (N * Wq >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pm_pack_grad_kernel, dim3(qt_stream_grid((Qa * (Cp >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g,
-                       stride_n, stride_c, stride_h, stride_w, (int)N, (int)Cout, (int)Ho, (int)Wo, (int)Wq, (int)Cp, Qa, G3);
+    if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_grad_kernel, dim3((unsigned)(Ho * N)), dim3(256), 0, (hipStream_t)stream, g, stride_n, stride_c,
+                       stride_h, stride_w, (int)N, (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G3);
+    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
+    for (int t = 0; t < 3 && tail > 0; ++t)
+        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<uint4*>(G3 + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
     return qt_check_launch();
 }
 
@@ -518,11 +574,15 @@ int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c,
                              int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
                              float x_scale, uint16_t* XP, qt_stream_t stream) {
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || !x || !XP) return QT_ERR_INVALID_ARG;
-    if (Wq < W + 2 * pw || Cp < Cin || (Cp & 31) || Qx < (H + 2 * ph) * N * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
-    if (N * Wq >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pm_pack_act_kernel, dim3(qt_stream_grid((Qx * (Cp >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       stride_n, stride_c, stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp,
-                       Qx, x_scale, XP);
+    const int64_t rows = (H + 2 * ph) * N;
+    if (Wq < W + 2 * pw || Cp < Cin || (Cp & 31) || Qx < rows * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
+    if (rows >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_act_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c, stride_h,
+                       stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
+    const int64_t tail = (Qx - rows * Wq) * Cp * 2 / 16;
+    if (tail > 0)
+        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<uint4*>(XP + rows * Wq * Cp), tail);
     return qt_check_launch();
 }
 

@@ -1684,8 +1684,9 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
     def plan(nc):
         ktot = Ho * nc * Wq
         # K slices: the launch runs ceil(tiles * nslice / slots) rounds of ceil(ktot / nslice / 32) stages each
+        # (+ 24 stages' worth of prologue / partial-result write-out per round: few long slices beat many short ones)
         nslice = min(range(1, max(2, min(257, ktot // 256 + 1))),
-                     key=lambda ns: (-(-tiles * ns // slots) * -(-ktot // (ns * 32)), ns))
+                     key=lambda ns: (-(-tiles * ns // slots) * (-(-ktot // (ns * 32)) + 24), ns))
         ks = _round_up(-(-ktot // nslice), 32)
         qa = ks * nslice
         qx = max(Hp * nc * Wq, qa + (kh - 1) * nc * Wq + 48)
