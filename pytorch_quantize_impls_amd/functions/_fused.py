@@ -428,6 +428,14 @@ def packed_conv2d(layer, act, kind: str, epi=None):
 PACKED_FWD = {True: packed_linear, False: packed_conv2d}
 
 
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    """``t`` itself when it is dense in NCHW or channels-last order (the conv kernels take element strides), else an NCHW
+    copy.  A plain ``.contiguous()`` would transpose every channels-last gradient back to NCHW."""
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+        return t
+    return t.contiguous()
+
+
 class QuantConv2dFn(torch.autograd.Function):
     """Autograd node of BinConv2d / TerConv2d in training mode: forward F.conv2d(x, Q(W), b, ...)
     (layers/binary_layers.py:105); backward = what autograd derives from F.conv2d plus the STE mask
@@ -450,7 +458,7 @@ class QuantConv2dFn(torch.autograd.Function):
         input, weight, weight_q = ctx.saved_tensors
         stride, padding, dilation, groups = ctx.conv_args
         grad_input = grad_weight = grad_bias = None
-        go = grad_output.contiguous()
+        go = _dense(grad_output)
         mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
@@ -666,7 +674,7 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
         stride, padding, dilation, groups = ctx.conv_args
-        go = grad_output.contiguous()
+        go = _dense(grad_output)
         grad_input = grad_weight = grad_bias = None
         mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)

@@ -272,9 +272,20 @@ class BitPlanes:
 # elementwise
 # ----------------------------------------------------------------------------------------------
 
+def _storage_dense(t: torch.Tensor) -> bool:
+    """Dense in NCHW or channels-last order: an elementwise kernel can walk the storage as it lies (empty_like keeps the
+    strides), so a channels-last activation or gradient is not transposed to NCHW and back around every elementwise op."""
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
 def _unary(name: str, x: torch.Tensor, *extra) -> torch.Tensor:
-    x = _require(x, "input").contiguous()
+    x = _require(x, "input")
+    if not _storage_dense(x):
+        x = x.contiguous()
     y = torch.empty_like(x)
+    if y.stride() != x.stride():           # size-1 dimensions can leave the order ambiguous
+        x = x.contiguous()
+        y = torch.empty_like(x)
     with _on(x.device):
         _lib.call(name, _p(x), _p(y), int(x.numel()), *extra, _stream(x.device))
     return y
@@ -312,11 +323,19 @@ def ap2(x: torch.Tensor) -> torch.Tensor:
 
 
 def _binary(name: str, a: torch.Tensor, b: torch.Tensor, *extra) -> torch.Tensor:
-    a = _require(a, "a").contiguous()
-    b = _require(b, "b").contiguous()
+    a, b = _require(a, "a"), _require(b, "b")
     if a.shape != b.shape:
         raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    if not _storage_dense(a):
+        a = a.contiguous()
+    if b.stride() != a.stride():           # bring the second operand into the first one's storage order
+        b = b.contiguous(memory_format=torch.channels_last) if (a.dim() == 4 and not a.is_contiguous()) else b.contiguous()
+        if b.stride() != a.stride():       # size-1 dimensions leave the strides ambiguous: fall back to NCHW for both
+            a, b = a.contiguous(), b.contiguous()
     y = torch.empty_like(a)
+    if y.stride() != a.stride():
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
     with _on(a.device):
         _lib.call(name, _p(a), _p(b), _p(y), int(a.numel()), *extra, _stream(a.device))
     return y
