@@ -308,6 +308,12 @@ int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c
 int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                              int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
                              float x_scale, uint16_t* XP, qt_stream_t stream);
+/* Strided first layer over a real-valued image: XP[q * Cp + t * Cs8 + (c * s + dy) * s + dx] = t-th term of the exact bf16 split of
+ * xpad[n, c, Y s + dy - ph, X s + dx - pw], q = (Y * N + n) * Wq + X over Hs x Ws space-to-depth pixels; Cs8 = C s^2 rounded up
+ * to 8, Cp >= 3 Cs8.  The weight gradient of the s2d conv then has 3 Cs8 input channels whose three groups are summed. */
+int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                 int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw, int64_t Hs, int64_t Ws,
+                                 int64_t Wq, int64_t Cs8, int64_t Cp, int64_t Qx, uint16_t* XP, qt_stream_t stream);
 int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
                     int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,

@@ -120,6 +120,50 @@ __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restric
     }
 }
 
+// Strided first layer over a real-valued image (ops.conv2d_grad_weight_s2d): the stride-s conv is the stride-1 conv of the
+// space-to-depth image, and the image's exact bf16 split goes in as three channel groups —
+// XP[q][t * Cs8 + (c * s + dy) * s + dx] = term t (hi / mid / lo) of xpad[n, c, Y s + dy - ph, X s + dx - pw],
+// q = (Y * N + n) * Wq + X; zero outside the image, for X >= Ws, and in the channels between the groups' ends and Cp.
+__global__ __launch_bounds__(256) void pm_pack_act_s2d_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
+                                                              int64_t sw, int N, int C, int H, int W, int s, int ph, int pw,
+                                                              int Ws, int Wq, int Cs8, int Cp, uint16_t* __restrict__ XP) {
+    const int c8 = Cp >> 3, real8 = Cs8 >> 3, items = Wq * c8;
+    const int Y = blockIdx.x / N, n = blockIdx.x - Y * N;
+    const int Cs = C * s * s;
+    uint16_t* out = XP + (int64_t)blockIdx.x * Wq * Cp;
+    for (int item = threadIdx.x; item < items; item += 256) {
+        const int X = item / c8, chunk = item - X * c8;
+        if (chunk >= real8) {
+            if (chunk >= 3 * real8) *reinterpret_cast<uint4*>(out + (int64_t)X * Cp + chunk * 8) = make_uint4(0, 0, 0, 0);
+            continue;                                            // chunks [real8, 3 real8) are the mid / lo groups, written below
+        }
+        uint32_t h[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (X < Ws) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cc = chunk * 8 + i;
+                if (cc >= Cs) break;
+                const int c = cc / (s * s), r = cc - c * s * s;
+                const int dy = r / s, dx = r - dy * s;
+                const int yy = Y * s + dy - ph, xx = X * s + dx - pw;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const float v = xin[(int64_t)n * sn + (int64_t)c * sc + (int64_t)yy * sh_ + (int64_t)xx * sw];
+                const uint32_t a = pm_bf16_rn_bits(v);
+                const float r1 = v - __uint_as_float(a << 16);
+                const uint32_t b = pm_bf16_rn_bits(r1);
+                const uint32_t cbits = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
+                const int sft = (i & 1) * 16;
+                h[0][i >> 1] |= a << sft;
+                h[1][i >> 1] |= b << sft;
+                h[2][i >> 1] |= cbits << sft;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            *reinterpret_cast<uint4*>(out + (int64_t)X * Cp + t * Cs8 + chunk * 8) = make_uint4(h[t][0], h[t][1], h[t][2], h[t][3]);
+    }
+}
+
 // rows past the packed ones (the K-slice rounding of the gradient planes, the look-ahead rows of the activation plane)
 __global__ __launch_bounds__(256) void pm_zero_kernel(uint4* __restrict__ p, int64_t n16) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
@@ -579,6 +623,22 @@ int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c,
     if (rows >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pm_pack_act_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c, stride_h,
                        stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
+    const int64_t tail = (Qx - rows * Wq) * Cp * 2 / 16;
+    if (tail > 0)
+        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<uint4*>(XP + rows * Wq * Cp), tail);
+    return qt_check_launch();
+}
+
+int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                 int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw, int64_t Hs, int64_t Ws,
+                                 int64_t Wq, int64_t Cs8, int64_t Cp, int64_t Qx, uint16_t* XP, qt_stream_t stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || s <= 0 || ph < 0 || pw < 0 || Hs <= 0 || Ws <= 0 || !x || !XP) return QT_ERR_INVALID_ARG;
+    const int64_t rows = Hs * N;
+    if (Wq < Ws || (Cs8 & 7) || Cs8 < C * s * s || Cp < 3 * Cs8 || (Cp & 31) || Qx < rows * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
+    if (rows >= (1ll << 31) || Wq * Cp >= (1ll << 28) || H * s >= (1ll << 30) || W * s >= (1ll << 30)) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_act_s2d_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c, stride_h,
+                       stride_w, (int)N, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Ws, (int)Wq, (int)Cs8, (int)Cp, XP);
     const int64_t tail = (Qx - rows * Wq) * Cp * 2 / 16;
     if (tail > 0)
         hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

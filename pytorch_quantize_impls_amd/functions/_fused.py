@@ -481,6 +481,10 @@ class QuantConv2dFn(torch.autograd.Function):
                     grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, weight=weight)
                 if grad_weight is None:
                     gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
+            if (mfma and grad_weight is None and gw is None and not ctx.x_is_pm1
+                    and ops.wgrad_s2d_applicable(input.shape, weight.shape[2:], stride, dilation)):
+                # strided first layer over a real-valued image: space-to-depth + the pixel-major kernel
+                grad_weight = ops.conv2d_grad_weight_s2d(input, grad_output, weight.shape, stride, padding, weight=weight)
             if grad_weight is None:
                 if gw is None:
                     note_library_path(go, "conv grad_weight outside the matrix-core route")

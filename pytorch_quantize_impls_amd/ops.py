@@ -1678,21 +1678,12 @@ def wgrad_pm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
     return sh == sw == 1 and dh == dw == 1 and (kh, kw) in ((3, 3), (5, 5)) and int(x_shape[1]) >= 32 and int(g_shape[1]) >= 32
 
 
-def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
-                          weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
-                          x_levels: float = 1.0, workgroups: int = 0):
-    """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
-    [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
-    the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs."""
-    _require(x_pm1, "input")
-    _require(grad_output, "grad_output")
-    kh, kw = (int(v) for v in kernel_hw)
-    ph, pw = _pairs(padding)
-    N, Cin, H, W = (int(v) for v in x_pm1.shape)
-    N2, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
-    if (N2 != N or Ho != H + 2 * ph - kh + 1 or Wo != W + 2 * pw - kw + 1 or Ho <= 0 or Wo <= 0 or N == 0
-            or (kh, kw) not in ((3, 3), (5, 5))):
-        return None
+def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int):
+    """Pixel-major weight gradient for the position geometry ``geom`` = (N, Cin, H, W, kh, kw, ph, pw) of a stride-1 conv;
+    ``pack_act(n0, cnt, Wq, Cpi, Qx, XP, stream)`` writes the activation plane of images [n0, n0 + cnt).  Returns
+    [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget."""
+    N, Cin, H, W, kh, kw, ph, pw = geom
+    _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
     tn = 64 if kh == 3 else 32
     Cpo, Cpi = _round_up(Cout, 64), _round_up(Cin, tn)
     Wq, Hp, taps = W + 2 * pw, H + 2 * ph, kh * kw
@@ -1718,9 +1709,8 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
     ok, nslice, qa, qx = plan(nc)
     if not ok:
         return None
-    dev = x_pm1.device
-    g, x = grad_output.detach(), x_pm1.detach()
-    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    dev = grad_output.device
+    g = grad_output.detach()
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
     G3 = torch.empty((3 * qa * Cpo,), dtype=torch.int16, device=dev)
     XP = torch.empty((qx * Cpi,), dtype=torch.int16, device=dev)
@@ -1733,15 +1723,95 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
     with _on(dev):
         for n0 in range(0, N, nc):
             cnt = min(nc, N - n0)
-            gs, xs = g[n0:n0 + cnt], x[n0:n0 + cnt]
+            gs = g[n0:n0 + cnt]
             _, ns_u, qa_u, qx_u = plan(cnt) if cnt != nc else (True, nslice, qa, qx)
             _lib.call("qt_wgrad_pm_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
                       I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), st)
-            _lib.call("qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
-                      I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx_u), float(x_levels), _p(XP), st)
+            pack_act(n0, cnt, Wq, Cpi, qx_u, XP, st)
             _lib.call("qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u), I(Cpo), I(Cpi), I(kh), I(kw), st)
             _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
                       float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
+    return dW
+
+
+def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
+                          weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
+                          x_levels: float = 1.0, workgroups: int = 0):
+    """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
+    [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
+    the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs."""
+    _require(x_pm1, "input")
+    _require(grad_output, "grad_output")
+    kh, kw = (int(v) for v in kernel_hw)
+    ph, pw = _pairs(padding)
+    N, Cin, H, W = (int(v) for v in x_pm1.shape)
+    N2, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    if (N2 != N or Ho != H + 2 * ph - kh + 1 or Wo != W + 2 * pw - kw + 1 or Ho <= 0 or Wo <= 0 or N == 0
+            or (kh, kw) not in ((3, 3), (5, 5))):
+        return None
+    x = x_pm1.detach()
+    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    I = int
+
+    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st):
+        xs = x[n0:n0 + cnt]
+        _lib.call("qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                  I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx), float(x_levels), _p(XP), st)
+
+    return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups)
+
+
+def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
+    """A strided conv over a few REAL-VALUED input channels (the first layer: AlexNet's 3 -> 192, k 11, stride 4): its weight
+    gradient runs on the pixel-major kernel through the space-to-depth image (``conv2d_grad_weight_s2d``)."""
+    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    k2 = -(-kh // max(sh, 1))
+    return (sh == sw and sh > 1 and dh == dw == 1 and kh == kw and kh >= sh and k2 in (3, 5)
+            and 3 * int(x_shape[1]) * sh * sh <= 256)
+
+
+def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_shape, stride, padding,
+                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD):
+    """grad wrt the weight of a strided conv2d over a real-valued fp32 image with few channels.  The stride-s conv is the
+    stride-1 conv of the space-to-depth image ([N, C s^2, H / s, W / s], kernel ceil(k / s)) — the identity the forward uses
+    (``s2d_weight``) — so the gradient of the s2d weight comes from ``conv2d_grad_weight_pm`` and is folded back with
+    pixel_shuffle (the taps the rounding added are dropped).  The image is real-valued: its exact three-term bf16 split goes in
+    as 3 x C s^2 channels (every (gradient term, image term) product is exact in the fp32 accumulator; the three channel
+    groups are summed afterwards), which keeps fp32-GEMM accuracy.  Returns [Cout, C, k, k] fp32 or None."""
+    _require(x, "input")
+    _require(grad_output, "grad_output")
+    Cout, C, kh, kw = (int(v) for v in weight_shape)
+    (sh, sw), (ph, pw) = _pairs(stride), _pairs(padding)
+    if not wgrad_s2d_applicable(x.shape, (kh, kw), stride, 1):
+        return None
+    s = sh
+    k2 = -(-kh // s)
+    N, C2, H, W = (int(v) for v in x.shape)
+    N2, Co2, Ho, Wo = (int(v) for v in grad_output.shape)
+    if C2 != C or N2 != N or Co2 != Cout or Ho != (H + 2 * ph - kh) // s + 1 or Wo != (W + 2 * pw - kw) // s + 1:
+        return None
+    Hs, Ws = Ho + k2 - 1, Wo + k2 - 1
+    Cs = C * s * s
+    Cs8 = _round_up(Cs, 8)
+    xd = x.detach()
+    I = int
+
+    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st):
+        # space-to-depth gather + exact three-term split in one pass: XP[q][t * Cs8 + (c s + dy) s + dx] = term t of
+        # xpad[n, c, Y s + dy - ph, X s + dx - pw]
+        xs = xd[n0:n0 + cnt]
+        _lib.call("qt_wgrad_pm_pack_act_s2d_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                  I(cnt), I(C), I(H), I(W), I(s), I(ph), I(pw), I(Hs), I(Ws), I(Wq), I(Cs8), I(Cpi), I(qx), _p(XP), st)
+
+    dws = _wgrad_pm_run(grad_output, (N, 3 * Cs8, Hs, Ws, k2, k2, 0, 0), pack_act, None, ste_threshold, 1.0, 0)
+    if dws is None:
+        return None
+    dws = dws.view(Cout, 3, Cs8, k2, k2)[:, :, :Cs]
+    dws = (dws[:, 2] + dws[:, 1]) + dws[:, 0]
+    dW = torch.nn.functional.pixel_shuffle(dws, s)[:, :, :kh, :kw].contiguous()
+    if weight is not None:
+        dW = ste_mask(dW, weight.detach().contiguous(), ste_threshold)
     return dW
 
 

@@ -841,6 +841,41 @@ def test_weight_gradient_pixel_major_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
     assert ops.conv2d_grad_weight_pm(x, go, (7, 7), p) is None
 
 
+@pytest.mark.parametrize("N,C,H,W,Cout,k,s,p,cl", [(4, 3, 224, 224, 192, 11, 4, 2, True), (3, 3, 37, 45, 64, 11, 4, 2, False),
+                                                     (2, 1, 28, 28, 33, 5, 2, 2, False), (5, 3, 64, 64, 96, 9, 3, 0, True)])
+def test_weight_gradient_strided_first_layer_vs_fp64(dev, N, C, H, W, Cout, k, s, p, cl):
+    """ops.conv2d_grad_weight_s2d — the weight gradient of a strided conv over a REAL-valued image with few channels (AlexNet's
+    3 -> 192, k 11, stride 4): space-to-depth gather + exact three-term split of the image in one packer, the pixel-major kernel
+    on the ceil(k / s)-tap stride-1 form, pixel_shuffle back — against torch.nn.grad.conv2d_weight in fp64, directly and as the
+    backward of a training-mode BinConv2d (no library detour), incl. maps the stride does not divide."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    g = torch.Generator(device=dev)
+    g.manual_seed(N * 100 + k)
+    x = torch.randn((N, C, H, W), device=dev, generator=g) * 3
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    go = torch.randn((N, Cout, Ho, Wo), device=dev, generator=g)
+    if cl:
+        x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, C, k, k), go.double(), stride=s, padding=p)
+    with used("qt_wgrad_pm_pack_act_s2d_f32", "qt_wgrad_pm_f32"):
+        got = ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s, p)
+    assert norm_err(n(got), ref.cpu().numpy()) <= TOL
+    assert ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), 1, p) is None            # stride 1: not this route
+    conv = BinConv2d(C, Cout, k, stride=s, padding=p).to(dev)
+    conv.weight.data.uniform_(-1.3, 1.3)
+    old_min = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    try:
+        with used("qt_wgrad_pm_pack_act_s2d_f32"):
+            conv(x).backward(go)
+    finally:
+        _fused.BWD_MFMA_MIN_MACS = old_min
+    assert dict(_fused.LIBRARY_PATHS) == lib_before
+    refm = torch.where(conv.weight.detach().abs() > 1.001, torch.zeros_like(ref), ref)
+    assert norm_err(n(conv.weight.grad), refm.cpu().numpy()) <= TOL
+
+
 def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
     """One whole training step of BinaryNet-AlexNet (packed forward, STE masks, grad_input / grad_weight of every conv and
     linear layer on the matrix cores) against the reference's op sequence in torch on the same device (torch.sign,
