@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--c4-batch", type=int, default=256, help="C4 images per GPU (global with --strong; 0 = skip)")
     ap.add_argument("--c5-batch", type=int, default=256, help="C5 images per GPU (global with --strong, e.g. 2048; 0 = skip)")
     ap.add_argument("--extra-iters", type=int, default=10)
+    ap.add_argument("--train-batch", type=int, default=256, help="AlexNet-Bin training-step extra at N = 1 (0 = skip)")
     return ap.parse_args()
 
 
@@ -600,7 +601,41 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "fused": _net_line("c5", Bv, world, iters, el_f5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
                                {"argmax_agreement_with_unfused": agree5}),
             "global_batch": Bv * world}
+    # ---- training step: BinaryNet-AlexNet forward + backward at the headline batch, this backend vs the
+    # reference's op sequence through ROCm PyTorch on the same GPU (tools/bench_train_step.py holds both forms)
+    if args.train_batch and world == 1:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_train_step", os.path.join(ROOT, "tools", "bench_train_step.py"))
+        bts = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bts)
+        torch.manual_seed(0)
+        Bt = args.train_batch
+        mt = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+        xt = torch.randn(Bt, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+        tt = torch.randint(0, 10, (Bt,), device=dev)
+        before = dict(_fused_library_paths())
+        t_ours, loss_ours = bts.step_time(mt, mt, xt, tt)
+        lib_used = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
+        t_ref, loss_ref = bts.step_time(lambda t: bts.ref_forward(mt, t), mt, xt, tt, n=3)
+        out["n2_training_step_alexnet_bin"] = {
+            "workload": f"BinaryNet-AlexNet 3x224x224 batch {Bt}, training mode, forward + backward (nll loss), fp32 master weights, "
+                        "channels_last; no optimizer step (the reference's trainers are out of scope)",
+            "ms_per_step": t_ours, "images_per_s": Bt / t_ours * 1e3,
+            "reference_ops_on_gpu": {"ms_per_step": t_ref, "images_per_s": Bt / t_ref * 1e3,
+                                     "what": "torch.sign + F.conv2d / F.linear fp32 + the STE of functions/binary_connect.py:31-38 via autograd, "
+                                             "same model, same GPU"},
+            # real-valued pixels: conv1's fp32 rounding differs between the routes, a few signs flip behind the training-mode
+            # BatchNorm, so the two losses agree to ~1e-3 only; on +-1 pixels the forward passes are identical (the parity test)
+            "loss": loss_ours, "loss_reference_ops": loss_ref,
+            "dense_library_calls_in_the_steps": lib_used,
+            "gradient_parity": "tests/test_gpu_r2.py::test_alexnet_training_step_matches_the_reference_op_sequence (<= 2e-5 normalised)"}
+        del mt, xt
     return out
+
+
+def _fused_library_paths():
+    from pytorch_quantize_impls_amd.functions import _fused
+    return _fused.LIBRARY_PATHS
 
 
 def pmc_traffic(gemm_impl):

@@ -62,7 +62,7 @@ def step_time(fwd, model, x, target, n=5):
     for _ in range(n):
         loss = one()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3, float(loss)
+    return (time.perf_counter() - t0) / n * 1e3, float(loss.detach())
 
 
 def gradient_agreement(B: int = 16, seed: int = 0) -> float:
