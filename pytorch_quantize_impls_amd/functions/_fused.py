@@ -133,6 +133,16 @@ def _verdict(weight, tag, resolve):
     return d[tag], False
 
 
+def verdict_is_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]) -> bool:
+    """Did the detection for this (weight, activation shape) — run by the forward that just finished — say +-1?  Reads the
+    verdict store only (no device check): a forward that packed an un-tagged activation either verified it with a sync or
+    armed the device flag that poisons its output, so the backward may contract the same +-1 image."""
+    if weight is None:
+        return False
+    slot = _VERDICTS.get(id(weight))
+    return bool(slot is not None and slot[0]() is weight and slot[1].get(("pm1", tuple(input.shape[1:]))) is True)
+
+
 def detect_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]):
     """(treat as +-1?, device flag to fold into the bias or None) for an UN-TAGGED device activation."""
     ok, cached = _verdict(weight, ("pm1", tuple(input.shape[1:])), lambda: ops.is_pm1(input))
@@ -449,8 +459,12 @@ class QuantConv2dFn(torch.autograd.Function):
         # +-1 activation known without a device check (tag of a quantiser, or the layer's binary_input hint)?
         ctx.x_is_pm1 = bool(binary_input) or (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
                                               and packed.lookup(input, packed.NHWC) is not None)
-        return quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind,
-                                    weight_q=weight_q, binary_input=binary_input)
+        out = quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind,
+                                   weight_q=weight_q, binary_input=binary_input)
+        if not ctx.x_is_pm1 and binary_input is None and input.is_cuda and input.dim() == 4:
+            # un-tagged activation the forward detected as +-1 (e.g. behind a MaxPool2d): same knowledge for the backward
+            ctx.x_is_pm1 = verdict_is_pm1(input, weight)
+        return out
 
     @staticmethod
     def backward(ctx, grad_output):

@@ -1762,13 +1762,14 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
 
 
 def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
-    """A strided conv over a few REAL-VALUED input channels (the first layer: AlexNet's 3 -> 192, k 11, stride 4): its weight
-    gradient runs on the pixel-major kernel through the space-to-depth image (``conv2d_grad_weight_s2d``)."""
+    """A conv over a few REAL-VALUED input channels — strided (the first layer: AlexNet's 3 -> 192, k 11, stride 4) or stride 1
+    with <= 8 channels (VGG's 3 -> 64): its weight gradient runs on the pixel-major kernel through the space-to-depth image
+    (``conv2d_grad_weight_s2d``; s = 1 is just the three-term split of the image as channel groups)."""
     (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
     kh, kw = (int(v) for v in kernel_hw)
     k2 = -(-kh // max(sh, 1))
-    return (sh == sw and sh > 1 and dh == dw == 1 and kh == kw and kh >= sh and k2 in (3, 5)
-            and 3 * int(x_shape[1]) * sh * sh <= 256)
+    return (sh == sw and dh == dw == 1 and kh == kw and kh >= sh and k2 in (3, 5)
+            and (sh > 1 or int(x_shape[1]) <= 8) and 3 * int(x_shape[1]) * sh * sh <= 256)
 
 
 def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_shape, stride, padding,

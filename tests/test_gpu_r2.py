@@ -842,7 +842,8 @@ def test_weight_gradient_pixel_major_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
 
 
 @pytest.mark.parametrize("N,C,H,W,Cout,k,s,p,cl", [(4, 3, 224, 224, 192, 11, 4, 2, True), (3, 3, 37, 45, 64, 11, 4, 2, False),
-                                                     (2, 1, 28, 28, 33, 5, 2, 2, False), (5, 3, 64, 64, 96, 9, 3, 0, True)])
+                                                     (2, 1, 28, 28, 33, 5, 2, 2, False), (5, 3, 64, 64, 96, 9, 3, 0, True),
+                                                     (3, 3, 32, 40, 64, 3, 1, 1, True), (2, 8, 17, 19, 40, 5, 1, 2, False)])
 def test_weight_gradient_strided_first_layer_vs_fp64(dev, N, C, H, W, Cout, k, s, p, cl):
     """ops.conv2d_grad_weight_s2d — the weight gradient of a strided conv over a REAL-valued image with few channels (AlexNet's
     3 -> 192, k 11, stride 4): space-to-depth gather + exact three-term split of the image in one packer, the pixel-major kernel
@@ -860,7 +861,7 @@ def test_weight_gradient_strided_first_layer_vs_fp64(dev, N, C, H, W, Cout, k, s
     with used("qt_wgrad_pm_pack_act_s2d_f32", "qt_wgrad_pm_f32"):
         got = ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s, p)
     assert norm_err(n(got), ref.cpu().numpy()) <= TOL
-    assert ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), 1, p) is None            # stride 1: not this route
+    assert ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s + 1, p) is None        # shapes that do not belong together
     conv = BinConv2d(C, Cout, k, stride=s, padding=p).to(dev)
     conv.weight.data.uniform_(-1.3, 1.3)
     old_min = _fused.BWD_MFMA_MIN_MACS

@@ -84,7 +84,37 @@ def gradient_agreement(B: int = 16, seed: int = 0) -> float:
                if not (k.endswith(".bias") and ref[k].abs().max() < 1e-3 * top))
 
 
+def other_models(name):
+    """MODEL=vgg16 | resnet18: the C5 / C4 nets in training mode — this backend vs the same graph with the backward convs left to
+    MIOpen, the dense-library paths taken, and the per-step strided-copy count."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    if name == "vgg16":
+        B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+        model = bench_models.TernaryVGG16(num_classes=1000, image=224, fc=4096)
+        x = torch.randn(B, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+        target = torch.randint(0, 1000, (B,), device=dev)
+        fwd = lambda t: F.log_softmax(model(t), 1)
+    else:
+        B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+        model = bench_models.DorefaResNet18()
+        x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+        target = torch.randint(0, 10, (B,), device=dev)
+        fwd = lambda t: F.log_softmax(model(t), 1)
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    before = dict(_fused.LIBRARY_PATHS)
+    ta, la = step_time(fwd, model, x, target)
+    paths = {k: v - before.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != before.get(k, 0)}
+    _fused.BWD_CONV_MFMA = False
+    tb, lb = step_time(fwd, model, x, target)
+    _fused.BWD_CONV_MFMA = True
+    print(f"{name} training step, batch {B}: this backend {ta:.2f} ms ({B / ta * 1e3:.0f} img/s), with MIOpen backward convs {tb:.2f} ms; "
+          f"loss {la:.5f} / {lb:.5f}; dense-library paths in 7 steps: {paths}")
+
+
 def main():
+    if os.environ.get("MODEL", "alexnet") != "alexnet":
+        return other_models(os.environ["MODEL"])
     dev = torch.device("cuda:0")
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     torch.manual_seed(0)
