@@ -11,6 +11,6 @@ go = torch.randn((N, Cout, Ho, Ho), device=dev).contiguous(memory_format=torch.c
 ops.WGRAD_WORKGROUPS = int(os.environ.get('WG', '1024'))
 ops.WGRAD_PM_WORKGROUPS = int(os.environ.get('WGPM', str(ops.WGRAD_PM_WORKGROUPS)))
 fn = ops.conv2d_grad_weight_pm if os.environ.get('ROUTE', 'gemm') == 'pm' else ops.conv2d_grad_weight_gemm
-for _ in range(4):
+for _ in range(int(os.environ.get('ITERS', '12'))):
     fn(x, go, (k, k), p)
 torch.cuda.synchronize()
