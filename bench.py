@@ -630,6 +630,50 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "dense_library_calls_in_the_steps": lib_used,
             "gradient_parity": "tests/test_gpu_r2.py::test_alexnet_training_step_matches_the_reference_op_sequence (<= 2e-5 normalised)"}
         del mt, xt
+    elif args.train_batch and world > 1:
+        # data-parallel step, one process per GPU: per-GPU batch fixed (weak scaling), gradients averaged by the bucketed
+        # all-reduce of utils/data_parallel.py (RCCL over xGMI), overlapped with backward.  Never allowed to take the line down.
+        try:
+            import importlib.util
+            from pytorch_quantize_impls_amd.utils import GradientSynchronizer, broadcast_parameters
+            spec = importlib.util.spec_from_file_location("bench_train_step", os.path.join(ROOT, "tools", "bench_train_step.py"))
+            bts = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bts)
+            torch.manual_seed(0)
+            Bt = args.train_batch
+            mt = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+            broadcast_parameters(mt)
+            sync = GradientSynchronizer(mt.parameters())
+            xt = torch.randn(Bt, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+            tt = torch.randint(0, 10, (Bt,), device=dev)
+
+            def dp_step():
+                mt.zero_grad(set_to_none=True)
+                loss = torch.nn.functional.nll_loss(mt(xt), tt)
+                loss.backward()
+                sync.wait()
+                return loss
+            for _ in range(2):
+                dp_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dp_step()
+            torch.cuda.synchronize()
+            e = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            t_dp = float(e.item()) / 5 * 1e3
+            grad_bytes = sum(p.numel() * 4 for p in mt.parameters() if p.requires_grad)
+            out["n2_training_step_alexnet_bin"] = {
+                "workload": f"BinaryNet-AlexNet training step, data parallel over {world} GPUs, batch {Bt} per GPU, forward + backward + "
+                            f"bucketed gradient all-reduce (utils/data_parallel.GradientSynchronizer, backend {args.dist_backend}), no optimizer step",
+                "ms_per_step": t_dp, "images_per_s": Bt * world / t_dp * 1e3, "global_batch": Bt * world,
+                "gradient_bytes_per_step": grad_bytes, "buckets": len(sync.buckets)}
+            sync.remove()
+            del mt, xt
+        except Exception as exc:  # noqa: BLE001 — an extra must not void the headline measurement
+            out["n2_training_step_alexnet_bin"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 

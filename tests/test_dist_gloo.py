@@ -95,3 +95,83 @@ def test_ddp_gradients_average_over_ranks(tmp_path):
         want = gr if want is None else {k: (want[k] + gr[k]) / 2 for k in gr}
     for k in want:
         assert torch.allclose(g0[k], want[k], rtol=1e-5, atol=1e-6), k
+
+
+def _sync_worker(rank, world, port, out_dir):
+    """The path-owned gradient all-reduce (utils/data_parallel.py): bucketed, launched from post-accumulate hooks while
+    backward runs, one bucket per few parameters here so that several collectives are in flight."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_models
+    from pytorch_quantize_impls_amd.utils import GradientSynchronizer, broadcast_parameters, clamp_weights_
+    torch.manual_seed(100 + rank)                          # DIFFERENT initial replicas: the broadcast makes them equal
+    model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
+    broadcast_parameters(model, src=0)
+    sync = GradientSynchronizer(model.parameters(), bucket_bytes=256)
+    assert len(sync.buckets) >= 3
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 40, generator=g)
+    tgt = torch.randint(0, 5, (16,), generator=g)
+    lo, hi = rank * 8, (rank + 1) * 8
+    for step in range(2):                                  # two steps: the hooks re-arm
+        opt.zero_grad(set_to_none=(step == 1))
+        torch.nn.functional.nll_loss(model(x[lo:hi]), tgt[lo:hi]).backward()
+        sync.wait()
+        if step == 0:
+            torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"s{rank}.pt"))
+        opt.step()
+        clamp_weights_(model)
+    torch.save({k: p.detach().clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_world2(tmp_path):
+    """world_size 2 on CPU (gloo): identical replicas after the broadcast, every rank's gradients = the mean of the per-shard
+    gradients of rank 0's initial weights, weights stay identical and inside [-1, 1] after two optimiser steps + clamp."""
+    world = 2
+    mp.spawn(_sync_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import bench_models
+    g0, g1 = (torch.load(tmp_path / f"s{r}.pt") for r in range(world))
+    w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(world))
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.equal(w0[k], w1[k]), k
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 40, generator=gen)
+    tgt = torch.randint(0, 5, (16,), generator=gen)
+    want = None
+    for r in range(world):
+        torch.manual_seed(100)                             # rank 0's replica
+        model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
+        torch.nn.functional.nll_loss(model(x[r * 8:(r + 1) * 8]), tgt[r * 8:(r + 1) * 8]).backward()
+        gr = {k: p.grad for k, p in model.named_parameters()}
+        want = gr if want is None else {k: (want[k] + gr[k]) / 2 for k in gr}
+    for k in want:
+        assert torch.allclose(g0[k], want[k], rtol=1e-5, atol=1e-6), k
+    from pytorch_quantize_impls_amd.layers import LinearBin
+    torch.manual_seed(100)
+    ref_model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
+    for name, m in ref_model.named_modules():
+        if isinstance(m, LinearBin):
+            assert float(w0[name + ".weight"].abs().max()) <= 1.0
+
+
+def test_gradient_synchronizer_single_process_is_a_noop():
+    import bench_models
+    from pytorch_quantize_impls_amd.utils import GradientSynchronizer, clamp_weights_
+    model = bench_models.BinMLP(in_features=12, hidden=8, out_features=3)
+    sync = GradientSynchronizer(model.parameters())
+    x = torch.randn(4, 12)
+    torch.nn.functional.nll_loss(model(x), torch.tensor([0, 1, 2, 0])).backward()
+    before = {k: p.grad.clone() for k, p in model.named_parameters()}
+    sync.wait()
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, before[k])
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(5.0)
+    clamp_weights_(model)
+    from pytorch_quantize_impls_amd.layers import LinearBin
+    assert all(float(m.weight.abs().max()) <= 1.0 for m in model.modules() if isinstance(m, LinearBin))
