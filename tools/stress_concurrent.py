@@ -32,9 +32,23 @@ def run(iters: int = 60, verbose: bool = True) -> dict:
         xp, wp = ops.pack_linear_operands(x, w, kind, impl)
         return ops.packed_gemm(xp, wp, None, impl=impl)
 
+    # weight gradients on the pixel-major kernel (hand-counted vmcnt / lgkmcnt, mid-stage barrier): all three instances
+    gen = torch.Generator(device=dev).manual_seed(11)
+    wg = []
+    for (n_, ci, co, hw, k, p) in ((32, 256, 384, 13, 3, 1), (16, 64, 64, 56, 3, 1), (16, 96, 160, 27, 5, 2)):
+        xw = torch.where(torch.rand((n_, ci, hw, hw), device=dev, generator=gen) < 0.5, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+        gw = torch.randn((n_, co, hw, hw), device=dev, generator=gen).contiguous(memory_format=torch.channels_last)
+        wg.append((xw, gw, k, p))
+    ximg = torch.randn(16, 3, 224, 224, device=dev)
+    gimg = torch.randn(16, 192, 55, 55, device=dev).contiguous(memory_format=torch.channels_last)
+
     cases = {"c2 binary mfma": lambda: c2("binary", "mfma"), "c2 ternary mfma": lambda: c2("ternary", "mfma"),
              "c2 binary popcount": lambda: c2("binary", "valu"), "alexnet module graph": lambda: alex(xa),
-             "dorefa resnet18 module graph": lambda: res(xr)}
+             "dorefa resnet18 module graph": lambda: res(xr),
+             "grad_W 3x3 128x64 tile": lambda: ops.conv2d_grad_weight_pm(wg[0][0], wg[0][1], (3, 3), 1),
+             "grad_W 3x3 64x64 tile": lambda: ops.conv2d_grad_weight_pm(wg[1][0], wg[1][1], (3, 3), 1),
+             "grad_W 5x5": lambda: ops.conv2d_grad_weight_pm(wg[2][0], wg[2][1], (5, 5), 2),
+             "grad_W strided first layer": lambda: ops.conv2d_grad_weight_s2d(ximg, gimg, (192, 3, 11, 11), 4, 2)}
     side = torch.cuda.Stream(device=dev)
     big = torch.randn(8192, 8192, device=dev)
     bad = {k: 0 for k in cases}
