@@ -44,9 +44,28 @@ if os.path.exists(ks):
     print("## kernel-trace --stats (top kernels)\n")
     print("| kernel | calls | total us | avg us | % |")
     print("|---|---|---|---|---|")
-    for r in list(csv.DictReader(open(ks)))[:16]:
+    rows = list(csv.DictReader(open(ks)))
+
+    def row(r):
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | "
               f"{float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
+    for r in rows[:16]:
+        row(r)
+    # the headline step's own kernels and the training kernels, wherever they rank (the library's find-mode kernels of the
+    # reference-op legs crowd the top of the list)
+    must = ("nib_pack_pair_kernel", "wgrad_pm", "pm_pack", "pm_reduce")
+    print("\n## the C2 step's kernels and the weight-gradient kernels (same run)\n")
+    print("| kernel | calls | total us | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in rows:
+        n = r["Name"]
+        s_ = short(n)
+        is_c2_gemm = "mfma_gemm_kernel" in n and "ElemFp4" in n and s_.endswith("pipe=2>")
+        if is_c2_gemm or any(m in n for m in must):
+            if not (is_c2_gemm or "nib_pack_pair" in n):
+                s_ = n.replace("(anonymous namespace)::", "").replace("void ", "")
+                s_ = s_[:s_.index("(")] if "(" in s_ else s_
+            print(f"| {s_[:70]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
 print("\n## PMC (separate passes, per-dispatch averages)\n")
 print("| kernel | counter | dispatches | avg value | as bytes |")
 print("|---|---|---|---|---|")
