@@ -4,17 +4,21 @@
 //
 // wgrad.hip runs this as one GEMM per tap over K-major (transposed) planes, which re-reads the gradient planes once per
 // tap and needs kw pre-shifted activation copies.  Here both operands stay in the order the tensors already have —
-// [position][channel], so a tap is a ROW offset — and ONE workgroup accumulates ALL kh * kw taps of a 64 (co) x TN (ci)
-// tile: per 32-position stage it loads the three exact bf16 planes of the gradient tile once and kh activation tiles of
-// 32 + kw - 1 rows, i.e. ~24 KB of LDS fill for ~1200 cycles of MFMA per wave — matrix-bound where the per-tap GEMM is
-// fill-bound.  The MFMA fragments (8 consecutive positions of one channel per lane) are read out of the [position][channel]
-// LDS tiles with ds_read_b64_tr_b16, the transposing LDS read (semantics: tools/ubench/tr_probe.hip — inside a 16-lane
-// group lane q addresses 4 consecutive channels of row q / 4, lane i receives channel i of the four rows).
+// [position][channel], so a tap is a ROW offset — and ONE workgroup accumulates ALL kh * kw taps of its (co x ci) tile: per
+// 32-position stage it loads the three exact bf16 planes of the gradient tile once and kh activation tiles of 32 + kw - 1
+// rows (42 KB for 432 MFMAs on the 128 x 64 tile) — matrix-bound where the per-tap GEMM is fill-bound.  The MFMA fragments
+// (8 consecutive positions of one channel per lane) are read out of the [position][channel] LDS tiles with
+// ds_read_b64_tr_b16, the transposing LDS read (semantics: tools/ubench/tr_probe.hip — inside a 16-lane group lane q
+// addresses 4 consecutive channels of row q / 4, lane i receives channel i of the four rows).  The three gradient terms
+// (hi / mid / lo) accumulate into the same fp32 registers, so nothing has to be summed over terms afterwards.
 //
-// Work split: 8 waves = (64 / 32) x (TN / 32) output blocks x G tap groups (G = 8 / blocks); a wave owns one 32 x 32
-// (co x ci) block for the taps t = group, group + G, ...; the three gradient terms (hi / mid / lo) accumulate into the same
-// registers, so no row blocks have to be summed afterwards.  K is cut into slices (blockIdx.z); partial results
-// [slice][tap][64-row tiles...] are reduced by wgrad_pm_reduce_kernel, which applies the STE mask / scale as wgrad.hip does.
+// Two kernels share the layout (PmCfg), the LDS-DMA ring of three stages and the XCD-aware tile order:
+//   wgrad_pm_full_kernel<128, 64, 3, 3> : one wave per 32 x 32 block, every tap in that wave; straight-line, software-pipelined
+//                                         (fragments prefetched across a mid-stage hand-over).  3 x 3 convs with Cout % 128 == 0.
+//   wgrad_pm_kernel<TM, TN, KH, KW>     : waves = blocks x tap groups (a wave owns the taps t = group, group + G, ...); 64 x 64
+//                                         tiles for the other 3 x 3 convs, 64 x 32 for 5 x 5.
+// K (the positions) is cut into slices; the partial results [slice][tap][co][ci] are reduced by pm_reduce_kernel, which applies
+// the scale and the straight-through mask.  Measurements and the duty analysis: DESIGN.md section 1, profiles/r2_wgrad_pm.md.
 #include "qt_common.h"
 
 namespace {
