@@ -925,3 +925,62 @@ def test_dorefa_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, 
     gw = torch.nn.grad.conv2d_weight(xq.detach().double(), conv.weight.shape, gout.double(), padding=pd)
     assert norm_err(n(xq.grad), gi.cpu().numpy()) <= TOL
     assert norm_err(n(conv.weight.grad), gw.cpu().numpy()) <= TOL
+
+
+def test_elementwise_ops_keep_channels_last_storage(dev):
+    """The elementwise kernels walk dense storage as it lies: a channels-last activation / gradient comes back channels-last
+    (no NCHW round trip), with the same VALUES as the NCHW evaluation; mixed layouts and non-dense views still work."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn((5, 24, 7, 9), device=dev, generator=g) * 1.5
+    go = torch.randn((5, 24, 7, 9), device=dev, generator=g)
+    xcl, gcl = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    for fn in (ops.binarize, ops.ternarize, lambda t: ops.dorefa_quantize(t, 3), ops.ap2):
+        a, b = fn(x), fn(xcl)
+        assert b.is_contiguous(memory_format=torch.channels_last) and not b.is_contiguous()
+        assert a.is_contiguous() and torch.equal(a, b)
+    m_nchw = ops.ste_mask(go, x)
+    m_cl = ops.ste_mask(gcl, xcl)
+    assert m_cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(m_nchw, m_cl)
+    assert torch.equal(ops.ste_mask(gcl, x), m_nchw)                       # second operand brought into the first one's order
+    assert torch.equal(ops.ste_mask(go, xcl), m_nchw)
+    view = x[:, ::2]                                                       # not dense: copied, result still right
+    assert torch.equal(ops.binarize(view), ops.binarize(view.contiguous()))
+    one = torch.randn((4, 1, 6, 6), device=dev, generator=g)               # size-1 channel dim: ambiguous strides
+    assert torch.equal(ops.binarize(one.contiguous(memory_format=torch.channels_last)), ops.binarize(one))
+    # the module path: BinaryConnect's STE backward on a channels-last activation returns a channels-last gradient
+    xr = xcl.clone().requires_grad_(True)
+    BinaryConnectDeterministic.apply(xr).backward(gcl)
+    assert xr.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(xr.grad, torch.where(x.abs() > 1.001, torch.zeros_like(go), go))
+
+
+def test_conv_behind_maxpool_keeps_the_matrix_core_weight_gradient(dev):
+    """VGG pattern: BinaryConnect -> MaxPool2d -> TerConv2d.  The pool drops the quantiser's tag, the forward detects the +-1
+    activation (verdict store + device poison flag) and the backward reads the same verdict: weight gradient on the pixel-major
+    kernel, no dense-library detour, equal to the fp64 evaluation."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    torch.manual_seed(4)
+    conv = TerConv2d(64, 96, 3, padding=1).to(dev)
+    conv.weight.data.uniform_(-1.2, 1.2)
+    pool = torch.nn.MaxPool2d(2, 2)
+    xr = torch.randn(8, 64, 24, 24, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    old_min = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    try:
+        xin = pool(BinaryConnectDeterministic.apply(xr))
+        assert packed.lookup(xin, packed.NHWC) is None                     # the tag did not survive the pool
+        xin.retain_grad()
+        with used("qt_wgrad_pm_f32"):
+            y = conv(xin)
+            gout = torch.randn_like(y)
+            y.backward(gout)
+    finally:
+        _fused.BWD_MFMA_MIN_MACS = old_min
+    assert dict(_fused.LIBRARY_PATHS) == lib_before
+    gw = torch.nn.grad.conv2d_weight(xin.detach().double(), conv.weight.shape, gout.double(), padding=1)
+    gw = torch.where(conv.weight.detach().abs() > 1.001, torch.zeros_like(gw), gw)
+    assert norm_err(n(conv.weight.grad), gw.cpu().numpy()) <= TOL
+    wq = ops.ternarize(conv.weight.detach()).double()
+    gi = torch.nn.grad.conv2d_input(xin.shape, wq, gout.double(), padding=1)
+    assert norm_err(n(xin.grad), gi.cpu().numpy()) <= TOL
