@@ -305,6 +305,15 @@ int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int
 int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                               int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
                               qt_stream_t stream);
+/* qt_wgrad_pm_pack_grad_f32 for channels-last gradients (channel stride 1, Cp <= 2048) that also leaves the per-row channel sums
+ * bias_part[(y * N + n) * Cp + c] behind; qt_wgrad_pm_bias_reduce_f32 adds the rows: db[c] (+)= sum_rows bias_part[row][c], c < Cout —
+ * the conv's bias gradient without another pass over g.  Fixed summation order (no atomics).  bias_part must hold (Ho * N + 128) * Cp
+ * floats: the reduce uses the last 128 rows as scratch for its first pass. */
+int qt_wgrad_pm_pack_grad_bias_f32(const float* g, int64_t stride_n, int64_t stride_h, int64_t stride_w, int64_t N, int64_t Cout,
+                                   int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3, float* bias_part,
+                                   qt_stream_t stream);
+int qt_wgrad_pm_bias_reduce_f32(float* bias_part, int64_t rows, int64_t Cp, int64_t Cout, int accumulate, float* db,
+                                qt_stream_t stream);
 int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                              int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
                              float x_scale, uint16_t* XP, qt_stream_t stream);

@@ -90,6 +90,82 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
     }
 }
 
+// The same pack for channels-last gradients that ALSO leaves the bias gradient behind (grad_bias = sum of g over n, y, x — a
+// third pass over g otherwise): every thread keeps one fixed 8-channel chunk and walks the row's positions xl, xl + XPAR, ...,
+// so its eight running sums live in registers; the XPAR partial rows are added in a fixed order through LDS and the workgroup
+// writes bias_part[row][Cp].  Deterministic (no atomics): pm_bias_reduce_kernel adds the rows in a fixed order as well.
+__global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __restrict__ g, int64_t sn, int64_t sh_, int64_t sw, int N,
+                                                                int Cout, int Wo, int Wq, int Cp, int64_t Qa, uint16_t* __restrict__ G3,
+                                                                float* __restrict__ bias_part) {
+    __shared__ float red[2048];                              // [xpar][Cp] partial sums, xpar * Cp <= 256 * 8
+    const int c8 = Cp >> 3, xpar = 256 / c8;
+    const int y = blockIdx.x / N, n = blockIdx.x - y * N;
+    const float* row = g + (int64_t)n * sn + (int64_t)y * sh_;
+    uint16_t* out = G3 + (int64_t)blockIdx.x * Wq * Cp;
+    const int t = threadIdx.x, chunk = t % c8, xl = t / c8, c0 = chunk << 3;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (xl < xpar) {
+        for (int x = xl; x < Wq; x += xpar) {
+            uint32_t h[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            if (x < Wo) {
+                const float* src = row + (int64_t)x * sw + c0;
+                float v[8];
+                if (c0 + 8 <= Cout && !((reinterpret_cast<uintptr_t>(src)) & 15)) {
+                    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = c0 + i < Cout ? src[i] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] += v[i];
+                    const uint32_t a = pm_bf16_rn_bits(v[i]);
+                    const float r1 = v[i] - __uint_as_float(a << 16);
+                    const uint32_t b = pm_bf16_rn_bits(r1);
+                    const uint32_t c = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
+                    const int s = (i & 1) * 16;
+                    h[0][i >> 1] |= a << s;
+                    h[1][i >> 1] |= b << s;
+                    h[2][i >> 1] |= c << s;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                *reinterpret_cast<uint4*>(out + (int64_t)s * Qa * Cp + (int64_t)x * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[xl * Cp + c0 + i] = acc[i];
+    }
+    __syncthreads();
+    for (int c = t; c < Cp; c += 256) {
+        float s = red[c];
+        for (int j = 1; j < xpar; ++j) s += red[j * Cp + c];
+        bias_part[(int64_t)blockIdx.x * Cp + c] = s;
+    }
+}
+
+// out[seg][c] (+)= sum over the rows [seg * seg_len, (seg + 1) * seg_len) of in[row][Cp], c < climit: one workgroup per (32 channels,
+// segment), 8 row groups added in a fixed order.  Two passes (rows -> <= 128 segments -> 1) keep every pass wide enough for the chip.
+__global__ __launch_bounds__(256) void pm_bias_reduce_kernel(const float* __restrict__ in, int rows, int seg_len, int Cp, int climit,
+                                                             int accumulate, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * seg_len, r1 = min(rows, r0 + seg_len);
+    float s = 0.0f;
+    if (c < Cp)
+        for (int r = r0 + rg; r < r1; r += 8) s += in[(int64_t)r * Cp + c];
+    red[rg][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (rg == 0 && c < climit) {
+        float tot = red[0][threadIdx.x];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) tot += red[j][threadIdx.x];
+        float* o = out + (int64_t)blockIdx.y * Cp + c;
+        *o = accumulate ? *o + tot : tot;
+    }
+}
+
 // XP[q][Cp]: bf16(x * x_scale) at padded position q = (y * N + n) * Wq + x over the H + 2 ph padded rows (zero outside the image,
 // past the pitch and in channels >= Cin)
 __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
@@ -615,6 +691,40 @@ int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c
     for (int t = 0; t < 3 && tail > 0; ++t)
         hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<uint4*>(G3 + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
+    return qt_check_launch();
+}
+
+int qt_wgrad_pm_pack_grad_bias_f32(const float* g, int64_t stride_n, int64_t stride_h, int64_t stride_w, int64_t N, int64_t Cout,
+                                   int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3, float* bias_part,
+                                   qt_stream_t stream) {
+    if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G3 || !bias_part) return QT_ERR_INVALID_ARG;
+    if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G3)) return QT_ERR_ALIGNMENT;
+    if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28) || Cp > 2048) return QT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pm_pack_grad_bias_kernel, dim3((unsigned)(Ho * N)), dim3(256), 0, (hipStream_t)stream, g, stride_n, stride_h,
+                       stride_w, (int)N, (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G3, bias_part);
+    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
+    for (int t = 0; t < 3 && tail > 0; ++t)
+        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<uint4*>(G3 + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
+    return qt_check_launch();
+}
+
+int qt_wgrad_pm_bias_reduce_f32(float* bias_part, int64_t rows, int64_t Cp, int64_t Cout, int accumulate, float* db,
+                                qt_stream_t stream) {
+    if (!bias_part || !db || rows <= 0 || Cp <= 0 || Cout <= 0 || Cout > Cp || rows >= (1ll << 31)) return QT_ERR_INVALID_ARG;
+    const int64_t segs = rows >= 256 ? (rows / 128 < 128 ? rows / 128 : 128) : 1;
+    const float* in = bias_part;
+    int64_t in_rows = rows;
+    if (segs > 1) {      // first pass into the 128 scratch rows behind the partial sums
+        float* scratch = bias_part + rows * Cp;
+        const int64_t seg_len = (rows + segs - 1) / segs;
+        hipLaunchKernelGGL(pm_bias_reduce_kernel, dim3((unsigned)((Cp + 31) / 32), (unsigned)segs), dim3(256), 0, (hipStream_t)stream, in,
+                           (int)rows, (int)seg_len, (int)Cp, (int)Cp, 0, scratch);
+        in = scratch;
+        in_rows = segs;
+    }
+    hipLaunchKernelGGL(pm_bias_reduce_kernel, dim3((unsigned)((Cp + 31) / 32), 1u), dim3(256), 0, (hipStream_t)stream, in, (int)in_rows,
+                       (int)in_rows, (int)Cp, (int)Cout, accumulate, db);
     return qt_check_launch();
 }
 

@@ -483,13 +483,16 @@ class QuantConv2dFn(torch.autograd.Function):
                 note_library_path(go, "conv grad_input outside the matrix-core route")
                 grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
                                                         dilation=dilation, groups=groups)
+        want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        bias_by_product = []              # filled by the weight-gradient route when its gradient pack can sum the channels on the way
         if ctx.needs_input_grad[1]:
             gw = None
             if mfma and ctx.x_is_pm1:     # +-1 activation x real gradient, contraction over the pixels
                 if ops.wgrad_pm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
                     # pixel-major kernel: every tap of a tile in one workgroup; the STE mask of the weight quantiser is the
                     # epilogue of its reduce step
-                    grad_weight = ops.conv2d_grad_weight_pm(input, grad_output, weight.shape[2:], padding, weight=weight)
+                    grad_weight = ops.conv2d_grad_weight_pm(input, go, weight.shape[2:], padding, weight=weight,
+                                                            bias_grad=bias_by_product if want_bias else None)
                 if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
                     # batched bf16 GEMMs over K-major planes (other kernel sizes)
                     grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, weight=weight)
@@ -505,8 +508,8 @@ class QuantConv2dFn(torch.autograd.Function):
                     gw = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
                                                      dilation=dilation, groups=groups)
                 grad_weight = ste_mask(gw.contiguous(), weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = go.sum((0, 2, 3))
+        if want_bias:
+            grad_bias = bias_by_product[0] if bias_by_product else go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None, None, None, None
 
 

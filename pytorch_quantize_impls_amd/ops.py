@@ -1678,10 +1678,13 @@ def wgrad_pm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
     return sh == sw == 1 and dh == dw == 1 and (kh, kw) in ((3, 3), (5, 5)) and int(x_shape[1]) >= 32 and int(g_shape[1]) >= 32
 
 
-def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int):
+def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int,
+                  bias_grad: Optional[list] = None):
     """Pixel-major weight gradient for the position geometry ``geom`` = (N, Cin, H, W, kh, kw, ph, pw) of a stride-1 conv;
     ``pack_act(n0, cnt, Wq, Cpi, Qx, XP, stream)`` writes the activation plane of images [n0, n0 + cnt).  Returns
-    [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget."""
+    [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget.  ``bias_grad``: a list that receives the
+    conv's bias gradient (sum of the gradient over n, y, x) when the gradient pack can produce it on the way (channels-last
+    gradient, <= 2048 padded channels) — otherwise it stays empty and the caller reduces the gradient itself."""
     N, Cin, H, W, kh, kw, ph, pw = geom
     _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
     tn = 64 if kh == 3 else 32
@@ -1720,26 +1723,38 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
         w = _require(weight.detach(), "weight").contiguous()
     I = int
     st = _stream(dev)
+    want_bias = bias_grad is not None and g.stride(1) == 1 and Cpo <= 2048
+    if want_bias:
+        bias_part = torch.empty(((Ho * nc + 128) * Cpo,), dtype=torch.float32, device=dev)    # + the reduce's scratch rows
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
     with _on(dev):
         for n0 in range(0, N, nc):
             cnt = min(nc, N - n0)
             gs = g[n0:n0 + cnt]
             _, ns_u, qa_u, qx_u = plan(cnt) if cnt != nc else (True, nslice, qa, qx)
-            _lib.call("qt_wgrad_pm_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
-                      I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), st)
+            if want_bias:
+                _lib.call("qt_wgrad_pm_pack_grad_bias_f32", _p(gs), I(gs.stride(0)), I(gs.stride(2)), I(gs.stride(3)),
+                          I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), _p(bias_part), st)
+                _lib.call("qt_wgrad_pm_bias_reduce_f32", _p(bias_part), I(Ho * cnt), I(Cpo), I(Cout), int(n0 > 0), _p(db), st)
+            else:
+                _lib.call("qt_wgrad_pm_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
+                          I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), st)
             pack_act(n0, cnt, Wq, Cpi, qx_u, XP, st)
             _lib.call("qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u), I(Cpo), I(Cpi), I(kh), I(kw), st)
             _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
                       float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
+    if want_bias:
+        bias_grad.append(db)
     return dW
 
 
 def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
-                          x_levels: float = 1.0, workgroups: int = 0):
+                          x_levels: float = 1.0, workgroups: int = 0, bias_grad: Optional[list] = None):
     """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
     [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
-    the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs."""
+    the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs.
+    ``bias_grad``: see ``_wgrad_pm_run`` (the bias gradient as a by-product of the gradient pack)."""
     _require(x_pm1, "input")
     _require(grad_output, "grad_output")
     kh, kw = (int(v) for v in kernel_hw)
@@ -1758,7 +1773,7 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
         _lib.call("qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
                   I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx), float(x_levels), _p(XP), st)
 
-    return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups)
+    return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups, bias_grad)
 
 
 def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:

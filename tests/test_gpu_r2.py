@@ -837,6 +837,29 @@ def test_weight_gradient_pixel_major_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
             ops.WGRAD_GEMM_BYTES = old
         if chunked is not None:
             check(chunked, ref)
+    # the bias gradient as a by-product of the gradient pack (channels-last gradients only; fixed summation order)
+    got_db = []
+    check(ops.conv2d_grad_weight_pm(x, go, (k, k), p, bias_grad=got_db), ref)
+    if cl:
+        ref_db = go.double().sum((0, 2, 3))
+        assert len(got_db) == 1 and got_db[0].shape == (Cout,)
+        assert float(((got_db[0].double() - ref_db).abs() / go.double().abs().sum((0, 2, 3)).clamp_min(1e-300)).max()) <= 1e-6
+        again = []
+        ops.conv2d_grad_weight_pm(x, go, (k, k), p, bias_grad=again)
+        assert torch.equal(again[0], got_db[0])                                       # deterministic
+        if N > 2:
+            old = ops.WGRAD_GEMM_BYTES
+            try:
+                Cpo, Cpi = (Cout + 63) // 64 * 64, (Cin + 63) // 64 * 64
+                per_img = 3 * Ho * (W + 2 * p) * Cpo * 2 + (H + 2 * p + k) * (W + 2 * p) * Cpi * 2
+                ops.WGRAD_GEMM_BYTES = 2 * per_img + 64 * k * k * Cpo * Cpi * 4 + (1 << 16)
+                chunked_db = []
+                if ops.conv2d_grad_weight_pm(x, go, (k, k), p, bias_grad=chunked_db) is not None:
+                    assert float(((chunked_db[0].double() - ref_db).abs() / go.double().abs().sum((0, 2, 3)).clamp_min(1e-300)).max()) <= 1e-6
+            finally:
+                ops.WGRAD_GEMM_BYTES = old
+    else:
+        assert got_db == []                                                            # NCHW gradient: the caller reduces it
     assert ops.conv2d_grad_weight_pm(x, go[:, :, :-1], (k, k), p) is None              # inconsistent shapes: not this route's
     assert ops.conv2d_grad_weight_pm(x, go, (7, 7), p) is None
 
