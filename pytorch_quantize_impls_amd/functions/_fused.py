@@ -501,7 +501,8 @@ class QuantConv2dFn(torch.autograd.Function):
             if (mfma and grad_weight is None and gw is None and not ctx.x_is_pm1
                     and ops.wgrad_s2d_applicable(input.shape, weight.shape[2:], stride, dilation)):
                 # strided first layer over a real-valued image: space-to-depth + the pixel-major kernel
-                grad_weight = ops.conv2d_grad_weight_s2d(input, grad_output, weight.shape, stride, padding, weight=weight)
+                grad_weight = ops.conv2d_grad_weight_s2d(input, go, weight.shape, stride, padding, weight=weight,
+                                                         bias_grad=bias_by_product if want_bias else None)
             if grad_weight is None:
                 if gw is None:
                     note_library_path(go, "conv grad_weight outside the matrix-core route")

@@ -1788,7 +1788,8 @@ def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
 
 
 def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_shape, stride, padding,
-                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD):
+                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
+                           bias_grad: Optional[list] = None):
     """grad wrt the weight of a strided conv2d over a real-valued fp32 image with few channels.  The stride-s conv is the
     stride-1 conv of the space-to-depth image ([N, C s^2, H / s, W / s], kernel ceil(k / s)) — the identity the forward uses
     (``s2d_weight``) — so the gradient of the s2d weight comes from ``conv2d_grad_weight_pm`` and is folded back with
@@ -1820,7 +1821,7 @@ def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_sh
         _lib.call("qt_wgrad_pm_pack_act_s2d_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
                   I(cnt), I(C), I(H), I(W), I(s), I(ph), I(pw), I(Hs), I(Ws), I(Wq), I(Cs8), I(Cpi), I(qx), _p(XP), st)
 
-    dws = _wgrad_pm_run(grad_output, (N, 3 * Cs8, Hs, Ws, k2, k2, 0, 0), pack_act, None, ste_threshold, 1.0, 0)
+    dws = _wgrad_pm_run(grad_output, (N, 3 * Cs8, Hs, Ws, k2, k2, 0, 0), pack_act, None, ste_threshold, 1.0, 0, bias_grad)
     if dws is None:
         return None
     dws = dws.view(Cout, 3, Cs8, k2, k2)[:, :, :Cs]
