@@ -42,9 +42,10 @@ class GradientSynchronizer:
 
     Parameters are bucketed in REVERSE registration order (the order backward produces gradients in), ``bucket_bytes`` per
     bucket.  A parameter that received no gradient in a step is sent as zeros (every rank must issue the same collectives).
-    With a single process (or no initialised process group) ``wait`` is a no-op."""
+    With a single process (or no initialised process group) ``wait`` is a no-op.  ``overlap=False``: no hooks — every
+    bucket is launched by ``wait()`` itself, from the calling thread, after backward (same result, nothing hidden)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None, overlap: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         plist = [p for p in params if p.requires_grad]
@@ -63,7 +64,7 @@ class GradientSynchronizer:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._hooks = []
-        if self.world > 1:
+        if self.world > 1 and overlap:
             for b in self.buckets:
                 for p in b.params:
                     self._bucket_of[p] = b

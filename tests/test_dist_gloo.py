@@ -108,7 +108,7 @@ def _sync_worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)                          # DIFFERENT initial replicas: the broadcast makes them equal
     model = bench_models.BinMLP(in_features=40, hidden=32, out_features=5)
     broadcast_parameters(model, src=0)
-    sync = GradientSynchronizer(model.parameters(), bucket_bytes=256)
+    sync = GradientSynchronizer(model.parameters(), bucket_bytes=256, overlap=(os.environ.get("QT_SYNC_OVERLAP", "1") == "1"))
     assert len(sync.buckets) >= 3
     opt = torch.optim.SGD(model.parameters(), lr=0.5)
     g = torch.Generator().manual_seed(5)
@@ -125,6 +125,12 @@ def _sync_worker(rank, world, port, out_dir):
         clamp_weights_(model)
     torch.save({k: p.detach().clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"w{rank}.pt"))
     dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_world2_without_overlap(tmp_path, monkeypatch):
+    """The same protocol with every bucket launched by wait() (overlap=False, what bench.py --gpus N uses)."""
+    monkeypatch.setenv("QT_SYNC_OVERLAP", "0")
+    test_gradient_synchronizer_world2(tmp_path)
 
 
 def test_gradient_synchronizer_world2(tmp_path):
