@@ -1678,6 +1678,26 @@ def wgrad_pm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
     return sh == sw == 1 and dh == dw == 1 and (kh, kw) in ((3, 3), (5, 5)) and int(x_shape[1]) >= 32 and int(g_shape[1]) >= 32
 
 
+def wgrad_pm_plan(nc: int, Cout: int, Cin: int, H: int, W: int, Ho: int, kh: int, kw: int, ph: int, pw: int, slots: int):
+    """Launch plan of the pixel-major weight gradient for ``nc`` images: (fits the byte budget?, K slices, positions in the
+    gradient planes Qa = slices x slice length, rows of the activation plane Qx).  Host logic only (tests/test_wgrad_plan_cpu.py).
+    K slices: the launch runs ceil(tiles * nslice / slots) rounds of ceil(ktot / nslice / 32) stages each, plus 24 stages' worth
+    of prologue / partial-result write-out per round — few long slices beat many short ones; ties go to fewer slices."""
+    tn = 64 if kh == 3 else 32
+    Cpo, Cpi = _round_up(Cout, 64), _round_up(Cin, tn)
+    Wq, Hp, taps = W + 2 * pw, H + 2 * ph, kh * kw
+    tm = 128 if (kh == 3 and Cpo % 128 == 0) else 64                 # the kernel's own tile rule (qt_wgrad_pm_f32)
+    tiles = (Cpo // tm) * (Cpi // tn)
+    ktot = Ho * nc * Wq
+    nslice = min(range(1, max(2, min(257, ktot // 256 + 1))),
+                 key=lambda ns: (-(-tiles * ns // slots) * (-(-ktot // (ns * 32)) + 24), ns))
+    ks = _round_up(-(-ktot // nslice), 32)
+    qa = ks * nslice
+    qx = max(Hp * nc * Wq, qa + (kh - 1) * nc * Wq + 48)
+    nbytes = 3 * qa * Cpo * 2 + qx * Cpi * 2 + nslice * taps * Cpo * Cpi * 4
+    return nbytes <= WGRAD_GEMM_BYTES, nslice, qa, qx
+
+
 def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int,
                   bias_grad: Optional[list] = None):
     """Pixel-major weight gradient for the position geometry ``geom`` = (N, Cin, H, W, kh, kw, ph, pw) of a stride-1 conv;
@@ -1689,22 +1709,11 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
     tn = 64 if kh == 3 else 32
     Cpo, Cpi = _round_up(Cout, 64), _round_up(Cin, tn)
-    Wq, Hp, taps = W + 2 * pw, H + 2 * ph, kh * kw
-    tm = 128 if (kh == 3 and Cpo % 128 == 0) else 64                 # the kernel's own tile rule (qt_wgrad_pm_f32)
-    tiles = (Cpo // tm) * (Cpi // tn)
+    Wq, taps = W + 2 * pw, kh * kw
     slots = workgroups or WGRAD_PM_WORKGROUPS                        # resident workgroups: one per CU (three-stage LDS ring)
 
     def plan(nc):
-        ktot = Ho * nc * Wq
-        # K slices: the launch runs ceil(tiles * nslice / slots) rounds of ceil(ktot / nslice / 32) stages each
-        # (+ 24 stages' worth of prologue / partial-result write-out per round: few long slices beat many short ones)
-        nslice = min(range(1, max(2, min(257, ktot // 256 + 1))),
-                     key=lambda ns: (-(-tiles * ns // slots) * (-(-ktot // (ns * 32)) + 24), ns))
-        ks = _round_up(-(-ktot // nslice), 32)
-        qa = ks * nslice
-        qx = max(Hp * nc * Wq, qa + (kh - 1) * nc * Wq + 48)
-        nbytes = 3 * qa * Cpo * 2 + qx * Cpi * 2 + nslice * taps * Cpo * Cpi * 4
-        return nbytes <= WGRAD_GEMM_BYTES, nslice, qa, qx
+        return wgrad_pm_plan(nc, Cout, Cin, H, W, Ho, kh, kw, ph, pw, slots)
 
     nc = N
     while nc > 1 and not plan(nc)[0]:
