@@ -146,7 +146,13 @@ def main():
         step(record=(i % EVENT_EVERY == 0))
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
+        # every rank's own step time travels with the line, so a SCALE run is self-checking (a straggler or a rank that
+        # did no work shows up here); `ms_per_step` / `value` use the MAX over the ranks as the contract says
+        gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -166,30 +172,44 @@ def main():
     torch.cuda.synchronize()
     empty_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
 
+    # the same launch as a burst behind the pack kernel, one event pair around BURST launches, marker cost subtracted:
+    # per-launch time with only the ~1 us kernel-to-kernel hand-over on top of the kernel duration rocprofv3 reports
+    BURST = 50
+    xp_b, wp_b = ops.pack_linear_operands(x, w, "binary", gemm_impl)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.pack_linear_operands(x, w, "binary", gemm_impl)
+    b0.record()
+    for _ in range(BURST):
+        ops.packed_gemm(xp_b, wp_b, None, out=y, impl=gemm_impl)
+    b1.record()
+    torch.cuda.synchronize()
+    burst_ms = max(b0.elapsed_time(b1) - empty_ms, 0.0) / BURST
+
     # ---- roofline of the dominant kernel (the packed GEMM) ------------------------------------
     gemm_bytes = ops.packed_gemm_algorithmic_bytes(B, N, K, gemm_impl)  # DESIGN.md "Kernels"
+    timing = {"kernel_ms": burst_ms,
+              "kernel_ms_what": f"{BURST} launches back to back behind the pack kernel, one HIP-event pair around the burst, the "
+                                "cost of an empty event pair subtracted; agrees with the rocprofv3 --kernel-trace --stats average "
+                                "of this command (profiles/r3_bench_rocprof.md) to ~1 us; `achieved` and `frac` use THIS figure",
+              "kernel_ms_in_step_bracket": gemm_ms,
+              "kernel_ms_in_step_bracket_what": f"HIP-event pair around the single launch on every {EVENT_EVERY}th step of the timed "
+                                                "region; includes the marker packets / kernel boundary (~3-5 us)",
+              "event_pair_empty_ms": empty_ms}
     if gemm_impl == "mfma":
-        achieved = ops_per_step / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "fp4 MFMA packed GEMM", "achieved": achieved,
-                    "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_FP4_PEAK_TFLOPS,
-                    "traffic": None, "kernel_ms": gemm_ms,
-                    "kernel_ms_note": f"HIP-event bracket around the launch on every {EVENT_EVERY}th step of the timed region; "
-                                      "includes the marker packets / kernel boundary (~3-5 us): rocprofv3 kernel "
-                                      "duration is in profiles/",
-                    # an event pair around nothing, measured behind the same pack kernel: the bracket minus this is a LOWER
-                    # bound of the kernel time (part of the marker cost overlaps the kernel); rocprofv3's duration lies
-                    # between the two.  `frac` stays on the bracket (conservative).
-                    "event_pair_empty_ms": empty_ms,
-                    "kernel_ms_lower_bound": max(gemm_ms - empty_ms, 0.0),
+        achieved = ops_per_step / (burst_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "mfma_gemm_kernel<ElemFp4, 256x256, pipe=2> (fp4 MFMA packed GEMM)",
+                    "achieved": achieved, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_FP4_PEAK_TFLOPS,
+                    "frac_on_in_step_bracket": ops_per_step / (gemm_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                    "traffic": None, **timing,
                     "hbm_equiv": {"algorithmic_bytes": gemm_bytes,
-                                  "achieved_GBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9,
-                                  "frac_of_8TBs": gemm_bytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                  "achieved_GBs": gemm_bytes / (burst_ms * 1e-3) / 1e9,
+                                  "frac_of_8TBs": gemm_bytes / (burst_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     else:
-        achieved = gemm_bytes / (gemm_ms * 1e-3) / 1e9
-        valu = ops_per_step / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "hbm", "kernel": "xnor popcount GEMM (VALU)", "achieved": achieved,
+        achieved = gemm_bytes / (burst_ms * 1e-3) / 1e9
+        valu = ops_per_step / (burst_ms * 1e-3) / 1e12
+        roofline = {"bound": "hbm", "kernel": "popc_gemm_kernel (xnor popcount GEMM, VALU)", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel_ms": gemm_ms, "algorithmic_bytes": gemm_bytes,
+                    **timing, "algorithmic_bytes": gemm_bytes,
                     "note": "at this shape the popcount formulation is VALU-bound, not HBM-bound "
                             "(SURVEY.md 8d); the instruction ceiling is reported beside it",
                     "valu_ceiling": {"achieved_TOPS": valu, "peak_TOPS": VALU_PEAK_TOPS,
@@ -200,7 +220,10 @@ def main():
                             "achieved_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
                             "frac_of_8TBs": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
-    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(gemm_impl)
+    # HBM-side bytes per launch: counters cannot be read from inside the process, so this is QUOTED from the committed PMC
+    # passes of this same command (tools/collect_profiles.sh refreshes profiles/pmc_latest.json), not measured in this run
+    roofline["traffic"], src = pmc_traffic(gemm_impl)
+    roofline["traffic_source"] = None if src is None else f"quoted (not measured in this run): {src}"
 
     result = {
         "metric": "XNOR-popcount GEMM TOPS (LinearBin 4096x4096 forward, batch 4096 per GPU)",
@@ -211,9 +234,24 @@ def main():
         "data": "synthetic",
         "config": {"workload": "c2: LinearBin train-mode forward = sign+pack(x) + sign+pack(W) + packed GEMM",
                    "batch_per_gpu": B, "in_features": K, "out_features": N, "global_batch": B * world,
-                   "parallelism": f"batch-shard x{world}, no collective", "gemm_impl": gemm_impl},
+                   "parallelism": f"batch-shard x{world}, no collective", "gemm_impl": gemm_impl,
+                   # un-tagged inputs of the layer-level legs (AlexNet / C4 / C5) are checked for +-1 on the device; "verify" =
+                   # one 4-byte readback per un-tagged input per forward (functions/_fused.py); the C2 step itself packs
+                   # through ops.* and asks nothing
+                   "detect_mode": _fused.DETECT_MODE, "deferred_activations": "sign chains on (lazy.ENABLED), DoReFa code "
+                   "chains opt-in (lazy.DEFER_CODES; the C4 legs that use it say so)"},
         "roofline": roofline,
+        "per_rank_ms_per_step": per_rank_ms,
+        "dist": {"initialised": dist is not None, "backend": (dist.get_backend() if dist is not None else None),
+                 "world_size_seen_by_the_process_group": (dist.get_world_size() if dist is not None else 1),
+                 "devices": sorted({local_rank}) if dist is None else None,
+                 "scaling_measured": "this line is ONE point; the driver computes efficiency from the per-N lines. No N > 1 run "
+                                     "has been possible for this repo so far (1-GPU boxes): multi-GPU behaviour is unmeasured"},
     }
+    if dist is not None:
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}")
+        result["dist"]["devices"] = names
 
     # ---- the reference's own op sequence on THIS GPU (torch.sign + masked write + F.linear fp32 through ROCm PyTorch):
     # what the un-modified QuantTorch package gets here; per-rank work like the headline, a reported baseline only
@@ -322,15 +360,22 @@ def bench_alexnet(args, dev, dist, world, rank):
         ele, ye = timed(model)
     out["module_by_module_eager"] = {"images_per_s": world * B * args.alexnet_iters / ele,
                                      "ms_per_forward": ele / args.alexnet_iters * 1e3,
+                                     "same_logits_as_deferred": bool(torch.equal(ye, y)),
                                      "same_argmax_as_deferred": bool(torch.equal(ye.argmax(1), y.argmax(1)))}
     # same network fused for inference (layers.fused): every BinConv2d emits BatchNorm-threshold bits, MaxPool runs
     # on bits, FC blocks use the BN+Hardtanh+sign+pack kernel: no fp32 activation between binarised layers
-    fused = bench_models.FusedAlexNetBin(model)
+    fused = bench_models.FusedAlexNetBin(model, fold="device")
     elf, yf = timed(fused)
     out["fused"] = {"images_per_s": world * B * args.alexnet_iters / elf,
                     "ms_per_forward": elf / args.alexnet_iters * 1e3,
                     "same_logits_as_module_graph": bool(torch.equal(yf, y)),
-                    "same_argmax_as_unfused": bool(torch.equal(yf.argmax(1), ye.argmax(1)))}
+                    "same_logits_as_unfused": bool(torch.equal(yf, ye)),
+                    "bn_fold": "device (thresholds of this device's F.batch_norm: bit-identical to the module graph)"}
+    out["roofline"] = alexnet_roofline(model, fused, x, B)
+    floor = out["roofline"]["matrix_floor_ms"]
+    out["frac_of_matrix_floor"] = floor / out["ms_per_forward"]
+    out["module_by_module_eager"]["frac_of_matrix_floor"] = floor / out["module_by_module_eager"]["ms_per_forward"]
+    out["fused"]["frac_of_matrix_floor"] = floor / out["fused"]["ms_per_forward"]
     # SURVEY 8d asks for the train-mode form as well: the quantised layers in training mode (sign + pack of W on every
     # call, STE autograd nodes), BatchNorm kept on its running statistics for determinism
     from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
@@ -342,6 +387,7 @@ def bench_alexnet(args, dev, dist, world, rank):
         m.eval()
     out["train_mode_layers"] = {"images_per_s": world * B * args.alexnet_iters / elt,
                                 "ms_per_forward": elt / args.alexnet_iters * 1e3,
+                                "frac_of_matrix_floor": floor / (elt / args.alexnet_iters * 1e3),
                                 "same_logits_as_eval": bool(torch.equal(yt, ye))}
     # the reference's own op sequence (torch.sign + F.conv2d / F.linear fp32 + the torch modules) on THIS GPU: what the
     # un-modified QuantTorch package gets from ROCm PyTorch (MIOpen / hipBLASLt) for the same eval forward
@@ -405,6 +451,80 @@ def bench_alexnet(args, dev, dist, world, rank):
     return out
 
 
+BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md); fp16 has the same rate
+
+
+def alexnet_roofline(model, fused, x, B):
+    """Per-block roofline of the fused AlexNet forward, measured live: every block of the fused form (conv [+ pool] +
+    BatchNorm-threshold epilogue; FC + BatchNorm + sign) is run alone, 10 launches back to back inside one HIP-event pair.
+    ops = 2 * MACs of SURVEY Appendix A.1 (full taps, padding counted); peak = the matrix-core peak of the element type the
+    block's contraction runs in (conv1: real pixels, exact bf16 split -> bf16 peak; the other blocks: fp4); bytes = what the
+    packed path moves algorithmically (input plane + packed weights + output bits), against 8 TB/s.  The floor of the whole
+    forward = sum of ops / peak over the blocks; every leg of the 'alexnet' object is given as a fraction of it."""
+    from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
+    from pytorch_quantize_impls_amd.layers.fused import FusedConvPoolBnSign
+    blocks = list(fused.net.features.children()) + list(fused.net.classifier.children())
+    rows, floor_ms = [], 0.0
+    with torch.no_grad():
+        act = x
+        i = 0
+        feats = list(fused.net.features.children())
+        for bi, blk in enumerate(blocks):
+            if bi == len(feats):
+                act = act.flatten_hwc()
+            inp = act
+            for _ in range(3):
+                out_ = blk(inp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                out_ = blk(inp)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            act = out_
+            conv = blk.conv if isinstance(blk, FusedConvPoolBnSign) else (blk if isinstance(blk, LinearBin) else None)
+            if conv is None:
+                rows.append({"block": type(blk).__name__, "ms": ms})
+                continue
+            w = conv.weight
+            if isinstance(conv, BinConv2d):
+                N_, C_, H_, W_ = (int(v) for v in inp.shape)
+                from pytorch_quantize_impls_amd import ops as _ops
+                Ho, Wo = _ops.conv_out_hw(H_, W_, conv.kernel_size[0], conv.kernel_size[1], conv.stride, conv.padding, conv.dilation)
+                macs = float(N_ * Ho * Wo * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3])
+                real_in = bi == 0
+                in_bytes = N_ * C_ * H_ * W_ * (4.0 if real_in else 0.5)          # fp32 pixels / fp4 nibble plane
+                out_bytes = N_ * w.shape[0] * Ho * Wo / 8.0                          # threshold bits (before pooling)
+                name = f"conv{i + 1} {C_}->{w.shape[0]} k{conv.kernel_size[0]} s{conv.stride[0]} @{H_}"
+            else:
+                N_ = int(inp.shape[0])
+                macs = float(N_ * w.shape[0] * w.shape[1])
+                real_in = False
+                in_bytes = N_ * w.shape[1] / 8.0
+                out_bytes = N_ * w.shape[0] * 4.0
+                name = f"fc {w.shape[1]}->{w.shape[0]}"
+            i += 1
+            peak = BF16_PEAK_TFLOPS if real_in else MFMA_FP4_PEAK_TFLOPS
+            w_bytes = w.numel() * (2.0 if real_in else 0.5)
+            ops_ = 2.0 * macs
+            nbytes = in_bytes + w_bytes + out_bytes
+            floor_ms += ops_ / (peak * 1e12) * 1e3
+            rows.append({"block": name, "ms": ms, "ops": ops_, "achieved_TFLOPs": ops_ / (ms * 1e-3) / 1e12,
+                         "peak_TFLOPs": peak, "peak": "bf16 MFMA dense" if real_in else "fp4 MFMA dense",
+                         "frac": ops_ / (ms * 1e-3) / 1e12 / peak, "algorithmic_bytes_packed": nbytes,
+                         "frac_of_8TBs": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    timed_rows = [r for r in rows if "ops" in r]
+    dom = max(timed_rows, key=lambda r: r["ms"])
+    total = sum(r["ms"] for r in rows)
+    return {"what": alexnet_roofline.__doc__.split("\n")[0],
+            "bound": "mfma", "dominant_block": dom["block"], "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
+            "unit": "TFLOP/s", "frac": dom["frac"], "dominant_block_ms": dom["ms"], "sum_of_blocks_ms": total,
+            "matrix_floor_ms": floor_ms, "blocks": rows,
+            "kernel_names": "profiles/r3_bench_rocprof.md lists the kernels of each block (conv1: s2d_triple_rows_kernel + "
+                            "mfma_gemm_kernel<ElemBf16/ElemF16 conv> + pool_bits_kernel)"}
+
+
 def _layer_stats(model, x):
     """SURVEY.md 8(d) figures of one forward: ops = 2 * MACs and algorithmic bytes = 4 * (inputs + weights + outputs) summed
     over the quantised Linear / Conv2d layers (full taps, padding counted), from forward hooks on the un-fused model."""
@@ -430,15 +550,18 @@ def _layer_stats(model, x):
     return acc
 
 
-def _net_line(name, B, world, iters, el, stats, peak_tflops, peak_name, extra=None):
+def _net_line(name, B, world, iters, el, stats, peak_tflops, peak_name, extra=None, fp32_activations=False):
+    """``fp32_activations``: the leg really moves SURVEY 8(d)'s fp32 bytes (module by module); the fused / deferred legs keep
+    activations as bit / nibble / code planes, so an fp32-byte rate would be meaningless there (> 8 TB/s) and is not given."""
     ms = el / iters * 1e3
     ops_ = 2.0 * stats["macs"]
     d = {"images_per_s": world * B * iters / el, "batch_per_gpu": B, "ms_per_forward": ms,
-         "roofline": {"ops_per_forward": ops_, "algorithmic_bytes_fp32": stats["bytes"], "quantised_layers": stats["layers"],
+         "roofline": {"bound": "mfma", "ops_per_forward": ops_, "quantised_layers": stats["layers"],
                       "achieved_TFLOPs": ops_ / (ms * 1e-3) / 1e12, "peak_TFLOPs": peak_tflops, "peak": peak_name,
-                      "frac_of_matrix_peak": ops_ / (ms * 1e-3) / 1e12 / peak_tflops,
-                      "hbm_equiv_GBs": stats["bytes"] / (ms * 1e-3) / 1e9,
-                      "frac_of_8TBs": stats["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                      "frac_of_matrix_peak": ops_ / (ms * 1e-3) / 1e12 / peak_tflops}}
+    if fp32_activations:
+        d["roofline"].update({"algorithmic_bytes_fp32": stats["bytes"], "hbm_equiv_GBs": stats["bytes"] / (ms * 1e-3) / 1e9,
+                              "frac_of_8TBs": stats["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     if extra:
         d.update(extra)
     return d
@@ -539,30 +662,38 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         def eager4():
             with lazy.eager():
                 return m4(x4)
+        def deferred4():
+            with lazy.codes_deferred():          # opt-in since round 3 (lazy.DEFER_CODES): the code epilogue's BatchNorm
+                return m4(x4)                    # arithmetic is the ATen-CPU fold, not this device's F.batch_norm
         with torch.no_grad():
             ye4 = eager4()
             agree = float((f4(x4).argmax(1) == ye4.argmax(1)).float().mean())
-            agree_d = float((m4(x4).argmax(1) == ye4.argmax(1)).float().mean())
+            agree_d = float((deferred4().argmax(1) == ye4.argmax(1)).float().mean())
+            same_default = bool(torch.equal(m4(x4), ye4))
         el_u = timed(eager4)
-        el_d = timed(lambda: m4(x4), 2 * iters)
+        el_d = timed(deferred4, 2 * iters)
         el_f = timed(lambda: f4(x4), 2 * iters)
         # the deferred forward is ~1.7 ms of Python for < 1 ms of GPU work: replayed as a hipGraph (utils.graphed captures
         # the un-modified module; same kernels, no host work)
         from pytorch_quantize_impls_amd import utils
-        g4 = utils.graphed(m4, x4)
+        with lazy.codes_deferred():
+            g4 = utils.graphed(m4, x4)
         with torch.no_grad():
-            same_g = bool(torch.equal(g4(x4), m4(x4)))
+            same_g = bool(torch.equal(g4(x4), deferred4()))
         el_g = timed(lambda: g4(x4), 2 * iters)
         out["c4_dorefa_resnet18_w1a4"] = {
             # the un-modified module graph: DorefaConv2d layers return deferred activations, BatchNorm / shortcut add / ReLU /
             # nnDorefaQuant are recorded and run in the conv's code epilogue (lazy.py); the fp32 stem stays module by module
             "module_graph": _net_line("c4", Bc, world, 2 * iters, el_d, st4, 5000.0,
                                       "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
-                                      {"argmax_agreement_with_unfused": agree_d}),
+                                      {"argmax_agreement_with_unfused": agree_d,
+                                       "mode": "lazy.codes_deferred() (opt-in); the DEFAULT execution of the un-modified graph is "
+                                               "the 'unfused' leg", "default_equals_module_by_module": same_default}),
             "module_graph_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_g, st4, 5000.0,
                                                "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                                {"same_logits_as_module_graph": same_g}),
-            "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54"),
+            "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                 fp32_activations=True),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                {"argmax_agreement_with_unfused": agree}),
             "note": "launch / latency bound at 32 x 32 maps (SURVEY 8d): ~60 launches of 5-40 us each"}
@@ -577,13 +708,14 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         x5 = torch.randn((Bv, 3, 224, 224), device=dev).contiguous(memory_format=torch.channels_last)
         st5 = _layer_stats(m5, x5)
         from pytorch_quantize_impls_amd import lazy
-        f5 = FusedFeatureClassifier(m5.features, m5.classifier, (512, 7, 7))
+        f5 = FusedFeatureClassifier(m5.features, m5.classifier, (512, 7, 7), fold="device")
         with torch.no_grad():
             yf5, yd5 = f5(x5), m5(x5)
             with lazy.eager():
                 ye5 = m5(x5)
             agree5 = float((yf5.argmax(1) == ye5.argmax(1)).float().mean())
             same5 = bool(torch.equal(yf5, yd5))
+            same5e = bool(torch.equal(yd5, ye5))
             del yf5, yd5, ye5
 
         def eager5():
@@ -595,9 +727,9 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         out["c5_ternary_vgg16"] = {
             # the reference's module-by-module graph, un-modified; convs return deferred activations (lazy.py)
             "module_graph": _net_line("c5", Bv, world, iters, el_d5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
-                                      {"same_logits_as_fused_form": same5}),
+                                      {"same_logits_as_fused_form": same5, "same_logits_as_module_by_module": same5e}),
             # the same graph with deferral off: every module writes its fp32 output
-            "unfused": _net_line("c5", Bv, world, 3, el_u5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense"),
+            "unfused": _net_line("c5", Bv, world, 3, el_u5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense", fp32_activations=True),
             "fused": _net_line("c5", Bv, world, iters, el_f5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
                                {"argmax_agreement_with_unfused": agree5}),
             "global_batch": Bv * world}
@@ -632,7 +764,10 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         del mt, xt
     elif args.train_batch and world > 1:
         # data-parallel step, one process per GPU: per-GPU batch fixed (weak scaling), gradients averaged by the bucketed
-        # all-reduce of utils/data_parallel.py (RCCL over xGMI), overlapped with backward.  Never allowed to take the line down.
+        # all-reduce of utils/data_parallel.py (RCCL over xGMI) issued after backward (overlap=False, see below).  BatchNorm
+        # runs on PER-SHARD batch statistics (plain nn.BatchNorm2d, no SyncBatchNorm: SURVEY 8e "or per-shard stats"), so the
+        # step is the data-parallel step of the reference's modules, not the single-GPU step at the global batch.
+        # Never allowed to take the line down.
         try:
             import importlib.util
             from pytorch_quantize_impls_amd.utils import GradientSynchronizer, broadcast_parameters
@@ -670,7 +805,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                 "workload": f"BinaryNet-AlexNet training step, data parallel over {world} GPUs, batch {Bt} per GPU, forward + backward + "
                             f"bucketed gradient all-reduce after backward (utils/data_parallel.GradientSynchronizer(overlap=False), backend {args.dist_backend}), no optimizer step",
                 "ms_per_step": t_dp, "images_per_s": Bt * world / t_dp * 1e3, "global_batch": Bt * world,
-                "gradient_bytes_per_step": grad_bytes, "buckets": len(sync.buckets)}
+                "gradient_bytes_per_step": grad_bytes, "buckets": len(sync.buckets),
+                "batchnorm": "per-shard batch statistics (no cross-rank reduction of the statistics)"}
             sync.remove()
             del mt, xt
         except Exception as exc:  # noqa: BLE001 — an extra must not void the headline measurement

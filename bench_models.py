@@ -64,11 +64,11 @@ class FusedAlexNetBin(nn.Module):
     Shares the parameters of the model it was built from.  ``fuse_conv=False`` keeps fp32 conv outputs and fuses
     only the [MaxPool, BatchNorm, Hardtanh, BinaryConnect] runs (one kernel each)."""
 
-    def __init__(self, model: AlexNetBin, fuse_conv: bool = True):
+    def __init__(self, model: AlexNetBin, fuse_conv: bool = True, fold=None):
         super().__init__()
         from pytorch_quantize_impls_amd.layers import FusedFeatureClassifier
         assert not model.training, "fuse an eval-mode model"
-        self.net = FusedFeatureClassifier(model.features, model.classifieur, (256, 6, 6), fuse_conv=fuse_conv)
+        self.net = FusedFeatureClassifier(model.features, model.classifieur, (256, 6, 6), fuse_conv=fuse_conv, fold=fold)
 
     def forward(self, x):
         return self.net(x)

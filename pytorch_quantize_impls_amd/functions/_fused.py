@@ -14,6 +14,7 @@ CPU tensors: the same expression in torch (host logic; never used for a device t
 """
 from __future__ import annotations
 
+import threading
 import weakref
 from collections import Counter
 from typing import Optional
@@ -143,9 +144,25 @@ def verdict_is_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]) -> bool:
     return bool(slot is not None and slot[0]() is weight and slot[1].get(("pm1", tuple(input.shape[1:]))) is True)
 
 
+_LAST = threading.local()      # .pm1 = (data_ptr, shape, answer) of the detection that ran last in this thread
+
+
+def last_detection_said_pm1(input: torch.Tensor) -> bool:
+    """Did a detection run for exactly THIS activation since ``clear_last_detection()`` and answer +-1?  (The verdict store
+    is keyed by weight and shape: a forward that skipped the detection — DETECT_BINARY_INPUT switched off, a non-fp32
+    early return — must not inherit an older call's positive answer)"""
+    rec = getattr(_LAST, "pm1", None)
+    return rec is not None and rec == (input.data_ptr(), tuple(input.shape), True)
+
+
+def clear_last_detection() -> None:
+    _LAST.pm1 = None
+
+
 def detect_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]):
     """(treat as +-1?, device flag to fold into the bias or None) for an UN-TAGGED device activation."""
     ok, cached = _verdict(weight, ("pm1", tuple(input.shape[1:])), lambda: ops.is_pm1(input))
+    _LAST.pm1 = (input.data_ptr(), tuple(input.shape), bool(ok))
     if ok and cached:
         return True, ops.check_pm1(input)       # int32[1] on the device, non-zero = some element is not +-1; no sync
     return ok, None
@@ -459,11 +476,12 @@ class QuantConv2dFn(torch.autograd.Function):
         # +-1 activation known without a device check (tag of a quantiser, or the layer's binary_input hint)?
         ctx.x_is_pm1 = bool(binary_input) or (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
                                               and packed.lookup(input, packed.NHWC) is not None)
+        clear_last_detection()
         out = quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind,
                                    weight_q=weight_q, binary_input=binary_input)
         if not ctx.x_is_pm1 and binary_input is None and input.is_cuda and input.dim() == 4:
-            # un-tagged activation the forward detected as +-1 (e.g. behind a MaxPool2d): same knowledge for the backward
-            ctx.x_is_pm1 = verdict_is_pm1(input, weight)
+            # un-tagged activation THIS forward detected as +-1 (e.g. behind a MaxPool2d): same knowledge for the backward
+            ctx.x_is_pm1 = last_detection_said_pm1(input)
         return out
 
     @staticmethod

@@ -10,10 +10,18 @@ none of the intermediate fp32 tensors is materialised, and the next BinConv2d / 
 consumes the planes without re-reading anything.  Opt-in (``fuse_sequential``): the un-fused modules keep
 working exactly as in the reference.
 
-Numerics: BatchNorm is folded to x*alpha + beta with alpha = weight * (1/sqrt(var+eps)),
-beta = bias - mean*alpha — the fold ATen's own CPU kernel performs — evaluated with two fp32 roundings.
-A value within an ulp of the threshold can land on the other side of it than in a differently-ordered
-evaluation (MIOpen's, say); everything else is identical.
+Numerics — two folds (``fold=`` of the fused modules):
+
+  "reference"  x*alpha + beta with alpha = weight * (1/sqrt(var+eps)), beta = bias - mean*alpha — the fold ATen's own
+               CPU kernel performs — evaluated with two fp32 roundings (what oracle/ restates).  A value within an ulp of
+               the threshold can land on the other side of it than in a differently-ordered evaluation (MIOpen's
+               fma((x-mean)*rsqrt(var+eps), weight, bias), tools/probes/bn_eval_arith.py); everything else is identical.
+  "device"     the threshold of THIS device's own ``F.batch_norm``: eval BatchNorm is a monotone function of x per
+               channel, so [BatchNorm(x) < 0] == [x < theta_c] (or [x > theta_c] for a negative slope); theta_c is
+               found by bisection over the fp32 bit patterns on the function torch really evaluates (same dtype, rank
+               and memory format as the tensor the module graph would hand it), once per BatchNorm version.  The sign
+               planes then equal the module-by-module graph's bit for bit, whatever arithmetic the library uses.
+               Deferred activations (lazy.py) use this fold, so the un-modified graph gives the eager result exactly.
 """
 import torch
 
@@ -32,6 +40,75 @@ def fold_batchnorm(bn):
     return alpha.float().contiguous(), beta.float().contiguous()
 
 
+_BIG = 1.0e30     # no activation on this path comes near it (|accumulator| <= K)
+
+
+def _float_key(x):
+    """Monotone int64 key of fp32 values: key order == numeric order (-0.0 just below +0.0)."""
+    b = x.view(torch.int32).to(torch.int64)
+    return torch.where(b >= 0, b, -(b + (1 << 31)) - 1)
+
+
+def _key_float(k):
+    b = torch.where(k >= 0, k, (-k - 1) - (1 << 31))
+    return b.to(torch.int32).view(torch.float32)
+
+
+def device_sign_fold(bn, like_shape, channels_last: bool):
+    """(alpha', beta') with alpha' in {+1, -1, 0} such that, for every fp32 x of channel c (|x| < 1e30),
+
+        [ fl(x * alpha'_c + beta'_c) < 0 ]  ==  [ F.batch_norm(x)_c < 0 ]     as THIS device evaluates eval BatchNorm
+
+    ``like_shape`` / ``channels_last``: rank, (capped) extents and memory format of the tensor the module graph would
+    hand to F.batch_norm — the probe tensors have the same, so torch picks the same kernel family.  33 evaluations of
+    F.batch_norm on a [<=2, C, <=2, <=2] (or [<=2, C]) tensor; callers cache the result per BatchNorm version."""
+    import torch.nn.functional as F
+    rm, rv = bn.running_mean.detach(), bn.running_var.detach()
+    w = bn.weight.detach() if bn.affine else None
+    b = bn.bias.detach() if bn.affine else None
+    C, dev = int(rm.numel()), rm.device
+    if len(like_shape) == 2:
+        shape = (max(1, min(2, int(like_shape[0]))), C)
+    else:
+        shape = (max(1, min(2, int(like_shape[0]))), C, max(1, min(2, int(like_shape[2]))), max(1, min(2, int(like_shape[3]))))
+    fmt = torch.channels_last if (channels_last and len(shape) == 4) else torch.contiguous_format
+
+    def neg(v):
+        if len(shape) == 2:
+            y = F.batch_norm(v.unsqueeze(0).expand(shape).contiguous(), rm, rv, w, b, False, 0.0, bn.eps)[0]
+        else:
+            inp = v.view(1, C, 1, 1).expand(shape).contiguous(memory_format=fmt)
+            y = F.batch_norm(inp, rm, rv, w, b, False, 0.0, bn.eps)[0, :, 0, 0]
+        return y < 0
+
+    with torch.no_grad():
+        big = torch.full((C,), _BIG, dtype=torch.float32, device=dev)
+        n_lo, n_hi = neg(-big), neg(big)
+        dec = ~n_lo & n_hi                       # negative slope: negative for LARGE x
+        const_neg, const_pos = n_lo & n_hi, ~n_lo & ~n_hi
+        lo, hi = _float_key(-big), _float_key(big)          # g(lo) true, g(hi) false with g = neg xor dec
+        for _ in range(33):
+            mid = torch.div(lo + hi, 2, rounding_mode="floor")
+            g = neg(_key_float(mid)) ^ dec
+            lo = torch.where(g, mid, lo)
+            hi = torch.where(g, hi, mid)
+        one = torch.ones((C,), dtype=torch.float32, device=dev)
+        # rising: neg(x) <=> x < float(hi);  falling: neg(x) <=> x > float(lo)
+        alpha = torch.where(dec, -one, one)
+        beta = torch.where(dec, _key_float(lo), -_key_float(hi))
+        const = const_neg | const_pos
+        alpha = torch.where(const, torch.zeros_like(one), alpha)
+        beta = torch.where(const_neg, -one, torch.where(const_pos, one, beta))
+    return alpha.contiguous(), beta.contiguous()
+
+
+def _out_channels_last(x) -> bool:
+    """Memory format of the fp32 tensor a quantised conv returns for input ``x`` (functions/_fused.py: NCHW-contiguous
+    tensors get NCHW storage back, everything else — channels-last tensors, packed activations — NHWC storage)."""
+    return not (isinstance(x, torch.Tensor) and x.dim() == 4 and x.is_contiguous()
+                and not x.is_contiguous(memory_format=torch.channels_last))
+
+
 def _bn_key(bn):
     """Identity of a BatchNorm's parameters / statistics: (storage, version counter) of each tensor — load_state_dict(),
     copy_() and .to(device) change it, so a folded (alpha, beta) cached under it is never stale.  (Writes through
@@ -40,12 +117,19 @@ def _bn_key(bn):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
 
 
-def _folded_for(owner, attr, bn, device=None):
-    """fold_batchnorm(bn), cached on ``owner`` under ``attr`` for the current _bn_key."""
+def _folded_for(owner, attr, bn, device=None, fold="reference", like=None):
+    """fold_batchnorm(bn) — or, fold == "device", device_sign_fold(bn, *like) with like = (shape, channels_last) —
+    cached on ``owner`` under ``attr`` for the current _bn_key (and, for the device fold, the probe signature)."""
     key = _bn_key(bn)
+    if fold == "device":
+        shape, cl = like
+        sig = (len(shape), min(2, int(shape[0]))) + (tuple(min(2, int(v)) for v in shape[2:]) if len(shape) == 4 else ()) + (bool(cl),)
+        key = key + (sig,)
+    elif fold != "reference":
+        raise ValueError(f"fold must be 'reference' or 'device', got {fold!r}")
     cur = getattr(owner, attr, None)
     if cur is None or cur[0] != key or (device is not None and cur[1][0].device != device):
-        cur = (key, fold_batchnorm(bn))
+        cur = (key, device_sign_fold(bn, *like) if fold == "device" else fold_batchnorm(bn))
         setattr(owner, attr, cur)
     return cur[1]
 
@@ -53,8 +137,9 @@ def _folded_for(owner, attr, bn, device=None):
 class FusedPoolBnSign(torch.nn.Module):
     """[MaxPool2d(k, s)] + eval BatchNorm + [Hardtanh] + BinaryConnect(deterministic) -> PackedActivation."""
 
-    def __init__(self, bn, pool=None, flatten_hwc=False, pre_relu=False):
+    def __init__(self, bn, pool=None, flatten_hwc=False, pre_relu=False, fold=None):
         super().__init__()
+        self.fold = fold or DEFAULT_FOLD
         self.pre_relu = bool(pre_relu)     # ReLU between the pooling and the BatchNorm (MLPBin.py:42-44 pattern)
         if pool is not None:
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
@@ -79,7 +164,15 @@ class FusedPoolBnSign(torch.nn.Module):
         x = lazy.resolve(x)
         if not x.is_cuda:
             raise TypeError("FusedPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
-        alpha, beta = _folded_for(self, "_folded", self.bn, x.device)
+        like = None
+        if self.fold == "device":
+            if x.dim() == 4:
+                N, C, H, W = x.shape
+                like = ((N, C, (H - self.pool_k) // self.pool_s + 1, (W - self.pool_k) // self.pool_s + 1),
+                        x.is_contiguous(memory_format=torch.channels_last))
+            else:
+                like = (tuple(x.shape), False)
+        alpha, beta = _folded_for(self, "_folded", self.bn, x.device, self.fold, like)
         planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, alpha, beta, self.pool_k, self.pool_s,
                                                      pre_relu=self.pre_relu)
         if x.dim() == 2:
@@ -244,7 +337,7 @@ class FusedConvPoolBnSign(torch.nn.Module):
     evaluation order, see the module docstring) for NaN-free activations.  Input: a PackedActivation, or a
     real-valued device tensor (first layer; exact bf16-triple conv)."""
 
-    def __init__(self, conv, bn, pool=None, flatten_hwc=False):
+    def __init__(self, conv, bn, pool=None, flatten_hwc=False, fold=None):
         super().__init__()
         from .binary_layers import BinConv2d
         from .terner_layers import TerConv2d
@@ -258,7 +351,8 @@ class FusedConvPoolBnSign(torch.nn.Module):
             raise ValueError("only groups == 1, zero-padded convs can be fused")
         if not isinstance(bn, torch.nn.BatchNorm2d) or bn.num_features != conv.out_channels:
             raise ValueError("BatchNorm2d over the conv's output channels expected")
-        self._pool = FusedPoolBnSign(bn, pool)           # validates the pooling geometry, owns the fold cache
+        self._pool = FusedPoolBnSign(bn, pool, fold=fold)           # validates the pooling geometry, owns the fold cache
+        self.fold = self._pool.fold
         self.conv, self.bn = conv, bn
         self.flatten_hwc = flatten_hwc
         self._neg_alpha = None
@@ -281,7 +375,14 @@ class FusedConvPoolBnSign(torch.nn.Module):
         x = lazy.resolve(x)
         dev = conv.weight.device
         prev = fp._folded
-        epi = _folded_for(fp, "_folded", self.bn, dev)
+        like = None
+        if self.fold == "device":
+            # the tensor the module graph would hand to F.batch_norm: this conv's output, pooled
+            N, _, H, W = (int(v) for v in x.shape)
+            Ho, Wo = ops.conv_out_hw(H, W, conv.kernel_size[0], conv.kernel_size[1], conv.stride, conv.padding, conv.dilation)
+            like = ((N, conv.out_channels, (Ho - fp.pool_k) // fp.pool_s + 1, (Wo - fp.pool_k) // fp.pool_s + 1),
+                    _out_channels_last(x))
+        epi = _folded_for(fp, "_folded", self.bn, dev, self.fold, like)
         if fp._folded is not prev or self._neg_alpha is None:      # BatchNorm changed (or first call): derived data too
             self._neg_alpha = ops.neg_alpha_words(epi[0])
             self._thr = None
@@ -369,6 +470,10 @@ D2S_FIRST_LAYER = True
 #: real-valued 3x3 / stride-1 / padding-1 first layers with <= 5 channels run on the direct kernel (bf16 triple planes);
 #: takes precedence over the output-blocked form
 DIRECT_FIRST_LAYER = True
+#: BatchNorm fold of fused modules built without an explicit ``fold=`` (module docstring).  Blocks built by lazy.py for
+#: the un-modified module graph always use "device".
+DEFAULT_FOLD = "reference"
+
 #: fused conv blocks on +-1 activations use per-channel integer thresholds (ops.integer_thresholds) in the epilogue
 INTEGER_THRESHOLDS = True
 
@@ -410,12 +515,13 @@ def _is_det_binary_connect(m):
     return isinstance(m, _FunctionModule) and m.core is BinaryConnectDeterministic
 
 
-def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_pool: bool = False) -> torch.nn.Sequential:
+def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_pool: bool = False, fold=None) -> torch.nn.Sequential:
     """New nn.Sequential where every [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)] run is
     replaced by one FusedPoolBnSign (sharing the original BatchNorm's parameters).  With ``fuse_conv`` a
     BinConv2d / TerConv2d directly in front of such a run joins it (FusedConvPoolBnSign: the conv emits
     threshold bits, no fp32 activation is written at all).  With ``packed_pool`` a MaxPool2d that directly follows a
-    fused block (pool AFTER the sign, VGG style) becomes a PackedMaxPool on the bit planes."""
+    fused block (pool AFTER the sign, VGG style) becomes a PackedMaxPool on the bit planes.  ``fold``: the BatchNorm
+    fold of the fused blocks ("reference" | "device", module docstring; default DEFAULT_FOLD)."""
     from .binary_layers import BinConv2d
     from .terner_layers import TerConv2d
     mods = list(seq.children())
@@ -438,8 +544,8 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_po
                 j2 += 1
             if j2 < len(mods) and _is_det_binary_connect(mods[j2]):
                 try:
-                    out.append(FusedConvPoolBnSign(conv, bn, pool) if conv is not None
-                               else FusedPoolBnSign(bn, pool, pre_relu=pre_relu))
+                    out.append(FusedConvPoolBnSign(conv, bn, pool, fold=fold) if conv is not None
+                               else FusedPoolBnSign(bn, pool, pre_relu=pre_relu, fold=fold))
                     i = j2 + 1
                     if packed_pool and i < len(mods) and isinstance(mods[i], torch.nn.MaxPool2d) and (not bn.affine or bn.weight.dim() == 1) \
                             and isinstance(bn, torch.nn.BatchNorm2d):
@@ -486,7 +592,7 @@ class FusedFeatureClassifier(torch.nn.Module):
     modules it was built from (which must be in eval mode).  ``feat_chw`` = (C, H, W) of the feature map the
     classifier was trained on."""
 
-    def __init__(self, features: torch.nn.Sequential, classifier: torch.nn.Sequential, feat_chw, fuse_conv: bool = True):
+    def __init__(self, features: torch.nn.Sequential, classifier: torch.nn.Sequential, feat_chw, fuse_conv: bool = True, fold=None):
         super().__init__()
         from .binary_layers import LinearBin
         from .terner_layers import LinearTer
@@ -497,7 +603,7 @@ class FusedFeatureClassifier(torch.nn.Module):
             f, c = f + [c[0]], c[1:]
         if not c or not isinstance(c[0], (LinearBin, LinearTer)):
             raise ValueError("classifier must start with [BinaryConnect(deterministic),] LinearBin / LinearTer")
-        self.features = fuse_sequential(torch.nn.Sequential(*f), fuse_conv=fuse_conv, packed_pool=True)
+        self.features = fuse_sequential(torch.nn.Sequential(*f), fuse_conv=fuse_conv, packed_pool=True, fold=fold)
         tail = list(self.features.children())[-1] if len(self.features) else None
         if not isinstance(tail, (FusedConvPoolBnSign, FusedPoolBnSign, PackedMaxPool)):
             raise ValueError("features must end with BatchNorm2d [Hardtanh] (+ the classifier's BinaryConnect), or with "
@@ -511,7 +617,7 @@ class FusedFeatureClassifier(torch.nn.Module):
             fc1.bias.data.copy_(src.bias.data)
         fc1.eval()
         fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))      # already the quantised image
-        self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[1:]))
+        self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[1:]), fold=fold)
         self.eval()
 
     def train(self, mode: bool = True):

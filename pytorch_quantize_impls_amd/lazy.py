@@ -24,6 +24,11 @@ is pulled by the consumer:
     the tensor materialise: the conv runs through the layer's ordinary eval path and the recorded ops are replayed with
     the torch functions that were intercepted, so the caller gets what the module-by-module graph would have produced.
 
+Exactness: the fused sign chain takes its per-channel thresholds from this device's own ``F.batch_norm`` (bisection over
+the fp32 bit patterns, ``layers.fused.device_sign_fold``), so the bits — and everything computed from them — equal the
+module-by-module graph's exactly (tests assert ``torch.equal`` against ``lazy.eager()``).  The DoReFa code chain cannot be
+reduced to thresholds (a residual is added before the quantiser) and is therefore opt-in (``DEFER_CODES``).
+
 Nothing is deferred in training mode, with autograd enabled, on CPU tensors, for non-fp32 dtypes, grouped convs or
 non-zero padding modes.  ``lazy.ENABLED = False`` (or the ``eager()`` context manager) switches the mechanism off;
 ``lazy.STATS`` counts what happened (tests assert on it).
@@ -44,6 +49,13 @@ from . import ops, packed
 
 #: master switch (module-by-module execution when False)
 ENABLED = True
+#: DoReFa chains (DorefaConv2d -> BatchNorm -> [+ shortcut] -> ReLU -> nnDorefaQuant) are deferred only on request: the
+#: code epilogue needs BatchNorm's VALUE, not just its sign, and evaluates the ATen-CPU fold fl(fl(x*alpha)+beta) while
+#: this device's F.batch_norm evaluates fma((x-mean)*rsqrt(var+eps), weight, bias) (tools/probes/bn_eval_arith.py), so
+#: a code can differ by one level from the module-by-module graph where n*t sits within an ulp of a rounding boundary.
+#: The sign chains above do not have that problem (layers.fused fold="device": thresholds bisected on the device's own
+#: F.batch_norm — bit-identical to the eager graph), so they stay on by default.
+DEFER_CODES = False
 #: "deferred" convs that returned a LazyActivation, "fused" chains executed as fused blocks, "materialised" lazies that
 #: had to produce their fp32 value, "fallback:<func>" the functions that forced it
 STATS = collections.Counter()
@@ -65,6 +77,17 @@ def eager():
         yield
     finally:
         _tls.eager_depth -= 1
+
+
+@contextlib.contextmanager
+def codes_deferred(on: bool = True):
+    """Defer DoReFa code chains (``DEFER_CODES``) inside the block; process-wide, restores the previous setting."""
+    global DEFER_CODES
+    prev, DEFER_CODES = DEFER_CODES, bool(on)
+    try:
+        yield
+    finally:
+        DEFER_CODES = prev
 
 
 class _Node:
@@ -212,8 +235,9 @@ class _Node:
 
 
 def _stamp(*tensors):
-    """(tensor, storage pointer, version counter) of every real tensor among ``tensors`` (inference tensors track no
-    version counter and cannot be written in place outside inference mode: skipped)."""
+    """(tensor, storage pointer, version counter) of every real tensor among ``tensors``.  Inference tensors track no
+    version counter; layers whose producers are inference tensors are not deferred at all (``_untracked``), so the ones
+    skipped here are internal planes nobody else holds."""
     return tuple((t, t.data_ptr(), t._version) for t in tensors
                  if isinstance(t, torch.Tensor) and not isinstance(t, LazyActivation) and not t.is_inference())
 
@@ -305,7 +329,7 @@ def _fused_block(layer, bn, pool, flatten: bool, halo):
     blk = per.get(key)
     if blk is None:
         pm = torch.nn.MaxPool2d(pool[0], pool[1]) if pool is not None else None
-        blk = fused.FusedConvPoolBnSign(layer, _BnView(rm, rv, w, b, eps), pm, flatten_hwc=flatten)
+        blk = fused.FusedConvPoolBnSign(layer, _BnView(rm, rv, w, b, eps), pm, flatten_hwc=flatten, fold="device")
         blk.out_nib_halo = halo
         per[key] = blk
         while len(per) > _MAX_BLOCKS_PER_LAYER:
@@ -372,7 +396,18 @@ class LazyActivation(torch.Tensor):
                 return fast(*args)
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
-        STATS["fallback:" + getattr(func, "__name__", str(func))] += 1
+        name = getattr(func, "__name__", str(func))
+        STATS["fallback:" + name] += 1
+        if _writes_in_place(name) and args and isinstance(args[0], LazyActivation):
+            # x.op_(...) on a deferred activation outside the grammar: the module-by-module value, mutated — but in a
+            # private copy (the cached value of this node may be the parent of chains recorded earlier), and the wrapper
+            # moves on to a constant node holding the result, as the tensor an in-place op returns would
+            self_ = args[0]
+            v = self_._qt.materialise().clone()
+            rest, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (tuple(args[1:]), kwargs))
+            func(v, *rest, **kwargs)
+            self_._qt = _const_node(v)
+            return self_
         args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs))
         return func(*args, **kwargs)
 
@@ -381,6 +416,23 @@ class LazyActivation(torch.Tensor):
         # safety net: an ATen op reached the dispatcher with a deferred activation (C++ callers, autograd internals)
         args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs or {}))
         return func(*args, **kwargs)
+
+
+def _writes_in_place(name: str) -> bool:
+    return (name.endswith("_") and not name.endswith("__")) or (name.startswith("__i") and name.endswith("__")
+                                                                 and name not in ("__int__", "__index__", "__invert__"))
+
+
+def _const_node(value: torch.Tensor) -> _Node:
+    """A node that only holds a computed value (nothing can be recorded on it: every handler declines)."""
+    n = _Node.__new__(_Node)
+    n.parent = n.op = n.layer = n.input = None
+    n.kind, n.shape, n.value, n.packed_cache = "const", tuple(int(v) for v in value.shape), value, None
+    n.pool = n.pool2 = n.add = n.quant = n.chw = None
+    n.bn = n.hardtanh = n.flat = True          # "already there": pool / BatchNorm / Hardtanh / flatten handlers decline
+    n.signed = n.relu = n.captured = False
+    n.stamp, n.device = (), value.device
+    return n
 
 
 _T = torch.Tensor
@@ -471,7 +523,7 @@ def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, trai
         if (type(t) is LazyActivation or t.device != n.device or t.dtype != torch.float32 or t.dim() != 1
                 or t.numel() != C):
             return NotImplemented
-    if (weight is None) != (bias is None):
+    if (weight is None) != (bias is None) or _untracked(running_mean, running_var, weight, bias):
         return NotImplemented
     return _wrap(_Node(n, ("bn", running_mean, running_var, weight, bias, float(eps)), n.shape))
 
@@ -526,7 +578,7 @@ def _residual_ok(main: _Node, other) -> bool:
             return True
         return o.bn is not None and o.parent is not None and o.parent.parent is None       # exactly conv -> BatchNorm
     return (isinstance(other, torch.Tensor) and other.device == main.input.device and other.dtype == torch.float32
-            and tuple(other.shape) == main.shape and not other.requires_grad)
+            and tuple(other.shape) == main.shape and not other.requires_grad and not other.is_inference())
 
 
 def _mainline(n: _Node) -> bool:
@@ -623,7 +675,7 @@ def sign(x: LazyActivation):
     """BinaryConnect (deterministic) of a deferred activation: recorded if the chain allows it, else None (the caller
     then binarises the materialised value)."""
     n = x._qt
-    if n.kind == "dorefa":
+    if n.kind in ("dorefa", "const"):
         return None
     if n.signed:
         return x                     # sign(+-1) == itself
@@ -647,6 +699,12 @@ def _no_autograd(layer) -> bool:
     return not torch.is_grad_enabled()
 
 
+def _untracked(*tensors) -> bool:
+    """An inference tensor among the producers: it has no version counter, so a write in place between the deferral and
+    the use (possible inside ``torch.inference_mode()``) could not be detected — such a layer runs eagerly instead."""
+    return any(isinstance(t, torch.Tensor) and not isinstance(t, LazyActivation) and t.is_inference() for t in tensors)
+
+
 def _conv_can_defer(layer, input) -> bool:
     if layer.training or not _no_autograd(layer) or layer.groups != 1 or layer.padding_mode != "zeros" \
             or isinstance(layer.padding, str):
@@ -659,6 +717,8 @@ def _conv_can_defer(layer, input) -> bool:
     else:
         ok = (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
               and input.numel() > 0)
+    if _untracked(input, w, layer.bias):
+        return False
     return ok and int(input.shape[1]) == layer.in_channels and layer._eval_on_grid()
 
 
@@ -690,6 +750,8 @@ def _dorefa_can_defer(layer, input) -> bool:
     w = layer.weight
     if not w.is_cuda or w.dtype != torch.float32 or not isinstance(input, packed.CodeActivation) or len(input.shape) != 4:
         return False
+    if _untracked(w, layer.bias):
+        return False
     return int(input.shape[1]) == layer.in_channels and layer._eval_on_grid()
 
 
@@ -712,7 +774,8 @@ def dorefa_conv_forward(layer, input):
                 act = n.force(pad)
         input = act if act is not None else n.materialise()
     tagged = None
-    if enabled() and not isinstance(input, packed.CodeActivation) and isinstance(input, torch.Tensor) and input.is_cuda \
+    defer = enabled() and DEFER_CODES
+    if defer and not isinstance(input, packed.CodeActivation) and isinstance(input, torch.Tensor) and input.is_cuda \
             and input.dtype == torch.float32 and input.dim() == 4 and not torch.is_grad_enabled() and not layer.training \
             and layer.bit_width == 1:
         codes = packed.lookup_codes(input, packed.NHWC)
@@ -721,7 +784,7 @@ def dorefa_conv_forward(layer, input):
             cand = packed.CodeActivation(codes, (N, C, H, W))
             if _dorefa_can_defer(layer, cand):
                 tagged, input = input, cand
-    if enabled() and _dorefa_can_defer(layer, input):
+    if defer and _dorefa_can_defer(layer, input):
         N, C, H, W = (int(v) for v in input.shape)
         kh, kw = layer.kernel_size
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)

@@ -1654,6 +1654,7 @@ def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kern
             xs = x[n0:n0 + cnt]
             if cnt != nc:                                     # ragged last chunk: its own (smaller) position space
                 ok2, ks2, lda2, ldb2 = plan(cnt)
+                assert lda2 <= lda and ldb2 <= ldb      # nslice is fixed here, so the plan is monotone in the chunk size
                 Au = A.view(-1)[:M * lda2].view(M, lda2)
                 Bu = B.view(-1)[:kw * Cin * ldb2].view(kw, Cin, ldb2)
                 k_use, lda_use, ldb_use = ks2, lda2, ldb2
@@ -1721,12 +1722,16 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     ok, nslice, qa, qx = plan(nc)
     if not ok:
         return None
+    # the plan is not monotone in the chunk size (a ragged last chunk can ask for MORE slices or a longer plane than the
+    # full chunks: 64 -> 64 3x3 at 32^2, 13 images: 50 slices, 12 images: 51): size every buffer for both plans
+    tail = plan(N % nc) if N % nc else (True, nslice, qa, qx)
+    ns_m, qa_m, qx_m = max(nslice, tail[1]), max(qa, tail[2]), max(qx, tail[3])
     dev = grad_output.device
     g = grad_output.detach()
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
-    G3 = torch.empty((3 * qa * Cpo,), dtype=torch.int16, device=dev)
-    XP = torch.empty((qx * Cpi,), dtype=torch.int16, device=dev)
-    part = torch.empty((nslice * taps * Cpo * Cpi,), dtype=torch.float32, device=dev)
+    G3 = torch.empty((3 * qa_m * Cpo,), dtype=torch.int16, device=dev)
+    XP = torch.empty((qx_m * Cpi,), dtype=torch.int16, device=dev)
+    part = torch.empty((ns_m * taps * Cpo * Cpi,), dtype=torch.float32, device=dev)
     w = None
     if weight is not None:
         w = _require(weight.detach(), "weight").contiguous()
@@ -1740,7 +1745,8 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
         for n0 in range(0, N, nc):
             cnt = min(nc, N - n0)
             gs = g[n0:n0 + cnt]
-            _, ns_u, qa_u, qx_u = plan(cnt) if cnt != nc else (True, nslice, qa, qx)
+            _, ns_u, qa_u, qx_u = tail if cnt != nc else (True, nslice, qa, qx)
+            assert ns_u <= ns_m and qa_u <= qa_m and qx_u <= qx_m
             if want_bias:
                 _lib.call("qt_wgrad_pm_pack_grad_bias_f32", _p(gs), I(gs.stride(0)), I(gs.stride(2)), I(gs.stride(3)),
                           I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), _p(bias_part), st)

@@ -43,7 +43,15 @@ class GradientSynchronizer:
     Parameters are bucketed in REVERSE registration order (the order backward produces gradients in), ``bucket_bytes`` per
     bucket.  A parameter that received no gradient in a step is sent as zeros (every rank must issue the same collectives).
     With a single process (or no initialised process group) ``wait`` is a no-op.  ``overlap=False``: no hooks — every
-    bucket is launched by ``wait()`` itself, from the calling thread, after backward (same result, nothing hidden)."""
+    bucket is launched by ``wait()`` itself, from the calling thread, after backward (same result, nothing hidden).
+
+    Contract: every rank constructs it over the SAME parameter list, and every ``backward()`` is followed by one
+    ``wait()`` before the next backward (no gradient accumulation across backwards: accumulate locally with
+    ``overlap=False`` and call ``wait()`` once).  Collectives are issued strictly in bucket order on every rank — a
+    bucket whose gradients are complete waits for the buckets before it, and whatever has not started when ``wait()`` is
+    called (parameters without a gradient this step) is launched there, in order — so ranks that differ in WHICH
+    parameters received gradients still issue the same sequence of all-reduces.  A second backward before ``wait()``
+    raises instead of silently averaging a stale gradient."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None, overlap: bool = True):
         self.group = group
@@ -64,6 +72,7 @@ class GradientSynchronizer:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._hooks = []
+        self._next = 0                      # index of the first bucket whose all-reduce has not been issued
         if self.world > 1 and overlap:
             for b in self.buckets:
                 for p in b.params:
@@ -84,17 +93,22 @@ class GradientSynchronizer:
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
+        if b.work is not None or b.pending <= 0:
+            raise RuntimeError("GradientSynchronizer: a gradient arrived for a bucket that is already reduced / complete — "
+                               "a second backward() ran before wait() (for gradient accumulation use overlap=False)")
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        # strictly in bucket order: start every complete bucket at the head of the line, stop at the first incomplete one
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def wait(self):
         """Blocks until every bucket is reduced and writes the means back into ``.grad``; re-arms for the next backward."""
         if self.world == 1:
             return
-        for b in self.buckets:
-            if b.work is None:            # some parameter of the bucket got no gradient this step
-                self._launch(b)
+        for b in self.buckets[self._next:]:      # not started by the hooks (a parameter without a gradient, or overlap=False)
+            self._launch(b)
+        self._next = 0
         for b in self.buckets:
             b.work.wait()
             b.flat.div_(self.world)

@@ -181,3 +181,91 @@ def test_gradient_synchronizer_single_process_is_a_noop():
     clamp_weights_(model)
     from pytorch_quantize_impls_amd.layers import LinearBin
     assert all(float(m.weight.abs().max()) <= 1.0 for m in model.modules() if isinstance(m, LinearBin))
+
+
+def _order_worker(rank, world, port, out_dir):
+    """Ranks that differ in WHICH parameters receive gradients: rank 1 never uses the last layer's second head.
+    Every rank must still issue the same all-reduces in the same order; and a second backward before wait() must raise."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorch_quantize_impls_amd.layers import LinearBin
+    from pytorch_quantize_impls_amd.utils import GradientSynchronizer
+    torch.manual_seed(3)
+    trunk, head_a, head_b = LinearBin(20, 16), LinearBin(16, 4), LinearBin(16, 4)
+    params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    sync = GradientSynchronizer(params, bucket_bytes=64, overlap=True)        # one bucket per parameter
+    assert len(sync.buckets) == 6
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 20, generator=g)[rank * 4:(rank + 1) * 4]
+    h = trunk(x)
+    loss = head_a(h).sum() + (head_b(h).sum() if rank == 0 else 0.0)         # head_b: no gradient on rank 1
+    loss.backward()
+    sync.wait()
+    torch.save({"trunk": trunk.weight.grad.clone(), "a": head_a.weight.grad.clone(), "b": head_b.weight.grad.clone()},
+               os.path.join(out_dir, f"o{rank}.pt"))
+    # second backward before wait(): an error, not a stale average
+    h = trunk(x)
+    head_a(h).sum().backward()
+    raised = False
+    try:
+        head_a(trunk(x)).sum().backward()
+    except RuntimeError as e:
+        raised = "second backward" in str(e)
+    assert raised
+    dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_launch_order_with_unused_parameters(tmp_path):
+    world = 2
+    mp.spawn(_order_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    o0, o1 = (torch.load(tmp_path / f"o{r}.pt") for r in range(world))
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    from pytorch_quantize_impls_amd.layers import LinearBin
+    torch.manual_seed(3)
+    trunk, head_a, head_b = LinearBin(20, 16), LinearBin(16, 4), LinearBin(16, 4)
+    g = torch.Generator().manual_seed(9)
+    xs = torch.randn(8, 20, generator=g)
+    h0 = trunk(xs[:4])
+    (head_a(h0).sum() + head_b(h0).sum()).backward()
+    gb = head_b.weight.grad.clone() / 2          # rank 1 contributed zeros
+    assert torch.allclose(o0["b"], gb, rtol=1e-5, atol=1e-6)
+
+
+def _strong_worker(rank, world, port, out_dir):
+    """bench.py --strong on C5's shape: the GLOBAL batch is fixed and cut into world contiguous shards; planes are replicated,
+    nothing but the timing barrier crosses ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_models
+    from pytorch_quantize_impls_amd import synth
+    torch.manual_seed(11)                                   # replicated weights
+    m = bench_models.TernaryVGG16(num_classes=10, image=32, fc=64)
+    bench_models.randomize_bn(m, 2)
+    m.eval()
+    G = 8
+    x = torch.from_numpy(synth.pm1(21, (G, 3, 32, 32)))    # +-1 pixels: every layer is exact integer arithmetic
+    per = G // world
+    with torch.no_grad():
+        y = m(x[rank * per:(rank + 1) * per])
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"v{rank}.npy"), y.numpy())
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_c5_shards_concatenate_to_the_global_batch(tmp_path):
+    world = 2
+    mp.spawn(_strong_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import bench_models
+    from pytorch_quantize_impls_amd import synth
+    torch.manual_seed(11)
+    m = bench_models.TernaryVGG16(num_classes=10, image=32, fc=64)
+    bench_models.randomize_bn(m, 2)
+    m.eval()
+    x = torch.from_numpy(synth.pm1(21, (8, 3, 32, 32)))
+    with torch.no_grad():
+        full = m(x).numpy()
+    got = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)], 0)
+    assert np.array_equal(got, full)

@@ -59,3 +59,16 @@ def test_route_applicability_rules():
     assert not ops.wgrad_s2d_applicable((4, 64, 32, 32), (3, 3), 1, 1)             # stride 1 with many channels: not a first layer
     assert not ops.wgrad_s2d_applicable((4, 3, 32, 32), (3, 3), 1, 2)
     assert not ops.wgrad_s2d_applicable((4, 8, 64, 64), (11, 11), 4, 1)            # 3 * 8 * 16 channels > 256
+
+
+def test_plan_is_not_monotone_in_the_chunk_size_so_buffers_cover_both_plans():
+    """a ragged last chunk re-plans; 64 -> 64 3x3 at 32^2 with 13 images per chunk asks for 50 slices, the
+    12-image tail for 51.  ops._wgrad_pm_run sizes G3 / XP / part for the maximum of the two plans (asserted there); here:
+    the counter-example exists, i.e. sizing by the full-chunk plan alone would be an out-of-bounds write."""
+    full = ops.wgrad_pm_plan(13, 64, 64, 32, 32, 32, 3, 3, 1, 1, 256)
+    tail = ops.wgrad_pm_plan(12, 64, 64, 32, 32, 32, 3, 3, 1, 1, 256)
+    assert full[0] and tail[0]
+    assert tail[1] > full[1]
+    import inspect
+    src = inspect.getsource(ops._wgrad_pm_run)
+    assert "max(nslice, tail[1])" in src and "max(qa, tail[2])" in src and "max(qx, tail[3])" in src
