@@ -514,7 +514,12 @@ class QuantConv2dFn(torch.autograd.Function):
                 if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
                     # batched bf16 GEMMs over K-major planes (other kernel sizes)
                     grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, weight=weight)
-                if grad_weight is None:
+                if grad_weight is None and ops.wgrad_strided_applicable(input.shape, go.shape, weight.shape[2:], stride, padding,
+                                                                        dilation):
+                    # strided convs (ResNet stage transitions): 1x1 -> GEMM over the sub-sampled positions, 3x3 -> the
+                    # pixel-major kernel on the space-to-depth image; STE mask below
+                    gw = ops.conv2d_grad_weight_strided(input, go, weight.shape[2:], stride, padding)
+                if grad_weight is None and gw is None:
                     gw = ops.conv2d_grad_weight_pm1(input, go, weight.shape[2:], stride, padding, dilation)
             if (mfma and grad_weight is None and gw is None and not ctx.x_is_pm1
                     and ops.wgrad_s2d_applicable(input.shape, weight.shape[2:], stride, dilation)):
@@ -736,12 +741,156 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
                     grad_weight = ops.conv2d_grad_weight_pm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
                 if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
                     grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
+                if grad_weight is None and ops.wgrad_strided_applicable(input.shape, go.shape, weight.shape[2:], stride, padding,
+                                                                        dilation):
+                    grad_weight = ops.conv2d_grad_weight_strided(input, go, weight.shape[2:], stride, padding,
+                                                                 x_levels=ctx.x_levels)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
                                                           dilation=dilation, groups=groups)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = go.sum((0, 2, 3))
+        return grad_input, grad_weight, grad_bias, None
+
+
+def _weight_levels(weight_q: torch.Tensor, bit_width: int) -> torch.Tensor:
+    """Integer levels c = rint((2^k - 1) * w_q) of a k-bit DoReFa weight image (odd integers, |c| <= 2^k - 1 <= 127: exact
+    in bf16 and in int8), as an fp32 tensor shaped like w_q."""
+    return torch.round(weight_q.detach() * float((1 << int(bit_width)) - 1))
+
+
+def _act_levels(t: torch.Tensor, layout):
+    """n = 2^k - 1 of a k-bit DoReFa activation that carries valid int8 codes (the tag nnDorefaQuant leaves), else None."""
+    if t.is_cuda and t.dtype == torch.float32:
+        codes = packed.lookup_codes(t, layout)
+        if codes is not None and codes.K == t.shape[1 if layout is packed.NHWC else -1]:
+            n = float((1 << int(codes.bit_width)) - 1)
+            return n if n <= 255 else None
+    return None
+
+
+class DorefaWkConv2dFn(torch.autograd.Function):
+    """Training-mode DorefaConv2d(bit_width = k), 2 <= k <= 7: conv2d(x, w_q, b) for the quantised image w_q the layer's
+    weight_op produced (layers/dorefa_layers.py:77-82, functions/dorefa_connect.py:99-111); the gradient w.r.t. w_q flows on
+    into weight_op's own autograd graph (tanh and its normalisation), exactly as in the reference.
+
+    w_q = c / n_w with odd integer levels c, so every contraction has one operand that is exact in bf16 / int8:
+      forward   activation with int8 codes (nnDorefaQuant tag): (1 / (n_a n_w)) * sum q c on the int8 matrix cores
+                (dorefa_wk_conv_forward); real-valued activation: (1 / n_w) * the exact-split conv with the level image;
+      grad_x    (1 / n_w) * the exact-split conv of the gradient with the flipped level image (any square stride);
+      grad_w_q  activation codes x exact-split gradient on the pixel-major / K-major / strided weight-gradient routes."""
+
+    @staticmethod
+    def forward(ctx, input, weight_q, bias, bit_width, conv_args):
+        stride, padding, dilation, groups = conv_args
+        ctx.has_bias, ctx.conv_args, ctx.bit_width = bias is not None, conv_args, int(bit_width)
+        ctx.save_for_backward(input, weight_q)
+        ctx.x_levels = _act_levels(input, packed.NHWC) if input.dim() == 4 else None
+        y = None
+        ok = groups == 1 and not isinstance(padding, str) and input.dim() == 4 and input.dtype == torch.float32
+        if ok and ctx.x_levels is not None:
+            wc = ops.pack_conv_weight_dorefa_codes(weight_q.detach(), bit_width)
+            y = dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width, wc)
+        if y is None and ok and FLOAT_PATH == "bf16x3" and input.numel() > 0:
+            N_, _, H, W = input.shape
+            Ho, Wo = ops.conv_out_hw(H, W, int(weight_q.shape[2]), int(weight_q.shape[3]), stride, padding, dilation)
+            y2 = ops.float_conv2d(input.detach(), _weight_levels(weight_q, bit_width), "raw", None, stride, padding, dilation)
+            y2 = y2 * _inv_levels(bit_width)
+            if bias is not None:
+                y2 = y2 + bias.detach()
+            y = y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)
+            if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous()
+        if y is None:
+            note_library_path(input, "k-bit DoReFa conv outside the level routes")
+            y = F.conv2d(input, weight_q, bias, stride, padding, dilation, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight_q = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        go = _dense(grad_output)
+        k = ctx.bit_width
+        grad_input = grad_weight = grad_bias = None
+        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight_q[0].numel() >= BWD_MFMA_MIN_MACS)
+        if ctx.needs_input_grad[0]:
+            if mfma:
+                grad_input = ops.conv2d_grad_input_q(input.shape, _weight_levels(weight_q, k), go, stride, padding, dilation,
+                                                     kind="raw")
+                if grad_input is not None:
+                    grad_input = grad_input * _inv_levels(k)
+            if grad_input is None:
+                note_library_path(go, "conv grad_input outside the matrix-core route")
+                grad_input = torch.nn.grad.conv2d_input(input.shape, weight_q, go, stride=stride, padding=padding,
+                                                        dilation=dilation, groups=groups)
+        if ctx.needs_input_grad[1]:
+            ksz = weight_q.shape[2:]
+            if mfma and ctx.x_levels is not None:
+                if ops.wgrad_pm_applicable(input.shape, go.shape, ksz, stride, dilation):
+                    grad_weight = ops.conv2d_grad_weight_pm(input, go, ksz, padding, x_levels=ctx.x_levels)
+                if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, ksz, stride, dilation):
+                    grad_weight = ops.conv2d_grad_weight_gemm(input, go, ksz, padding, x_levels=ctx.x_levels)
+                if grad_weight is None and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
+                    grad_weight = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=ctx.x_levels)
+            if grad_weight is None:
+                note_library_path(go, "conv grad_weight outside the matrix-core route")
+                grad_weight = torch.nn.grad.conv2d_weight(input, weight_q.shape, go, stride=stride, padding=padding,
+                                                          dilation=dilation, groups=groups)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = go.sum((0, 2, 3))
+        return grad_input, grad_weight, grad_bias, None, None
+
+
+class DorefaWkLinearFn(torch.autograd.Function):
+    """Training-mode LinearDorefa(bit_width = k), 2 <= k <= 7; see DorefaWkConv2dFn (layers/dorefa_layers.py:41-45)."""
+
+    @staticmethod
+    def forward(ctx, input, weight_q, bias, bit_width):
+        ctx.has_bias, ctx.bit_width = bias is not None, int(bit_width)
+        ctx.save_for_backward(input, weight_q)
+        ctx.x_levels = _act_levels(input, packed.ROWS_LAST)
+        y = None
+        if input.dtype == torch.float32 and ctx.x_levels is not None:
+            wc = ops.dorefa_weight_codes(weight_q.detach(), bit_width)
+            y = dorefa_wk_linear_forward(input, weight_q, bias, bit_width, wc)
+        if y is None and input.dtype == torch.float32 and FLOAT_PATH == "bf16x3" and input.numel() > 0:
+            y = ops.float_linear(input.detach(), _weight_levels(weight_q, bit_width), "raw") * _inv_levels(bit_width)
+            if bias is not None:
+                y = y + bias.detach()
+        if y is None:
+            note_library_path(input, "k-bit DoReFa linear outside the level routes")
+            y = F.linear(input, weight_q, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight_q = ctx.saved_tensors
+        k = ctx.bit_width
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        x2 = input.reshape(-1, input.shape[-1])
+        grad_input = grad_weight = grad_bias = None
+        big = (g2.is_cuda and g2.dtype == torch.float32
+               and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
+        if ctx.needs_input_grad[0]:
+            if big:        # real gradient x integer levels
+                lv = _weight_levels(weight_q, k)
+                grad_input = (ops.float_linear(g2.contiguous(), lv.t().contiguous(), "raw") * _inv_levels(k)).view(input.shape)
+            else:
+                note_library_path(g2, "small backward GEMM (launch-bound either way)")
+                grad_input = g2.mm(weight_q).view(input.shape)
+        if ctx.needs_input_grad[1]:
+            if big and ctx.x_levels is not None:   # g^T . x with x = codes / n_a
+                xc = torch.round(x2.detach() * ctx.x_levels)
+                inv_a = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(ctx.x_levels, dtype=torch.float32))
+                grad_weight = ops.float_linear(g2.t().contiguous(), xc.t().contiguous(), "raw") * inv_a
+            else:
+                note_library_path(g2, "backward GEMM with two real operands")
+                grad_weight = g2.t().mm(x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = g2.sum(0)
         return grad_input, grad_weight, grad_bias, None
 
 

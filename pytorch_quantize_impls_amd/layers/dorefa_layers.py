@@ -67,6 +67,12 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
             if y is not None:
                 return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
+        if (input.is_cuda and self.training and 2 <= self.bit_width <= 7 and input.dtype == torch.float32
+                and self.weight.dtype == torch.float32):
+            # WkAk training: level image x codes / exact split on the matrix cores, forward and both gradients
+            return _fused.DorefaWkLinearFn.apply(input, w, self.bias, self.bit_width)
+        if input.is_cuda:
+            _fused.note_library_path(input, "DoReFa linear with bit_width 8 / 32, a non-fp32 dtype, or autograd in eval mode")
         return torch.nn.functional.linear(input, w, self.bias)
 
 
@@ -140,4 +146,9 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
             if y is not None:
                 return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
+        if (input.is_cuda and self.training and 2 <= self.bit_width <= 7 and input.dtype == torch.float32
+                and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"):
+            return _fused.DorefaWkConv2dFn.apply(input, w, self.bias, self.bit_width, args)
+        if input.is_cuda:
+            _fused.note_library_path(input, "DoReFa conv with bit_width 8 / 32, groups, a non-fp32 dtype, or autograd in eval mode")
         return torch.nn.functional.conv2d(input, w, self.bias, *args)

@@ -1489,17 +1489,96 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
 #            "weight" under the kernel's 1 MiB K limit and give the launch enough tiles, partial results added in fp32.
 # Reference expressions: functions/binary_connect.py:141-143 (torch.nn.grad.conv2d_input / conv2d_weight).
 
-def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation):
-    """grad wrt the input of conv2d(x, weight_q) for a +-1 / 0 weight_q; None when the shape is outside the route
-    (stride / dilation != 1, padding > k - 1): the caller uses torch.nn.grad.conv2d_input."""
+def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation,
+                        kind: str = "sign"):
+    """grad wrt the input of conv2d(x, weight_q) for a weight_q that is exact in bf16 — +-1 / 0 (``kind`` "sign") or integer
+    levels (``kind`` "raw": the k-bit DoReFa levels c = n * w_q, the caller scales by 1 / n): the forward's exact-split conv
+    of the gradient with the flipped, transposed weight.  Stride 1 directly; stride s > 1 (square, un-dilated — the
+    3x3 / stride-2 and 1x1 / stride-2 convs of the reference's ResNets, models/Resnet/Resnet_bin.py:20-33) through the
+    zero-dilated gradient: g_d[.., s y, s x] = g[.., y, x], zeros elsewhere and ``H + 2p - k - (Ho - 1) s`` rows / columns of
+    zeros appended, which turns conv_transpose(g, W, stride s) into the stride-1 conv above (3/4 of its products are with the
+    inserted zeros; these layers are the small ones).  None when the shape is outside the route (dilation != 1,
+    padding > k - 1, non-square stride): the caller uses torch.nn.grad.conv2d_input."""
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Cout, Cin, kh, kw = (int(v) for v in weight_q.shape)
-    if (sh, sw, dh, dw) != (1, 1, 1, 1) or ph > kh - 1 or pw > kw - 1:
+    if (dh, dw) != (1, 1) or sh != sw or sh < 1 or ph > kh - 1 or pw > kw - 1:
         return None
     N, C, H, W = (int(v) for v in input_shape)
+    g = grad_output
+    if sh > 1:
+        s = sh
+        _, _, Ho, Wo = (int(v) for v in g.shape)
+        eh, ew = H + 2 * ph - kh - (Ho - 1) * s, W + 2 * pw - kw - (Wo - 1) * s
+        if not (0 <= eh < s and 0 <= ew < s):
+            return None
+        gd = torch.zeros((N, (Ho - 1) * s + 1 + eh, (Wo - 1) * s + 1 + ew, Cout), dtype=g.dtype, device=g.device)   # NHWC
+        gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = g.permute(0, 2, 3, 1)
+        g = gd.permute(0, 3, 1, 2)
     wT = weight_q.detach().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, kh, kw]
-    y2 = float_conv2d(grad_output, wT, "sign", None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+    y2 = float_conv2d(g, wT, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
     return y2.view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+def wgrad_strided_applicable(x_shape, g_shape, kernel_hw, stride, padding, dilation) -> bool:
+    """Strided convs whose weight gradient runs on this backend's kernels (``conv2d_grad_weight_strided``): square stride
+    s > 1, un-dilated, and either 1x1 / padding 0 or a kernel whose taps fall on offsets {-1, 0, +1} of the space-to-depth
+    image (k <= s + 1 with padding 1, e.g. 3x3 / stride 2 / padding 1) with H, W multiples of s and >= 32 channels after
+    the space-to-depth step."""
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    if sh != sw or sh <= 1 or (dh, dw) != (1, 1) or kh != kw or ph != pw:
+        return False
+    N, Cin, H, W = (int(v) for v in x_shape)
+    if kh == 1 and ph == 0:
+        return True
+    s = sh
+    if H % s or W % s or ph != 1 or kh > s + 1 or kh < 2:
+        return False
+    if int(g_shape[2]) != H // s or int(g_shape[3]) != W // s:
+        return False
+    return Cin * s * s >= 32 and int(g_shape[1]) >= 32
+
+
+def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kernel_hw, stride, padding,
+                               x_levels: float = 1.0, bias_grad: Optional[list] = None):
+    """grad wrt the weight of a STRIDED conv2d(x, Q(W)) for an activation that is exact in bf16 (+-1 / 0, or a k-bit DoReFa
+    image q / n with ``x_levels`` = n); un-masked (the caller applies the quantiser's STE).  See ``wgrad_strided_applicable``.
+
+      * 1x1, padding 0: dW[co, ci] = sum_pos g[pos, co] x[s pos, ci] — the sub-sampled activation against the gradient, one
+        exact-split GEMM over the positions (qt_bf16_gemm);
+      * k x k, padding 1, k <= s + 1: tap i sits at t = i - 1 = s u + a of the input, i.e. at offset u in {-1, 0} (k = s + 1:
+        {-1, 0}) of phase a of the space-to-depth image (H/s x W/s, Cin s^2 channels).  The stride-1 3x3 pixel-major kernel
+        (csrc/wgrad_pm.hip) on that image gives dW'[co, (ci, a_h, a_w), u_h + 1, u_w + 1]; the k^2 real taps are gathered
+        from it (the u = +1 row / column is computed and dropped)."""
+    _require(x, "input")
+    _require(grad_output, "grad_output")
+    s = _pairs(stride)[0]
+    kh, kw = (int(v) for v in kernel_hw)
+    p = _pairs(padding)[0]
+    N, Cin, H, W = (int(v) for v in x.shape)
+    _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    inv = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    if kh == 1:
+        xs = x.detach()[:, :, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s]
+        x2 = xs.permute(1, 0, 2, 3).reshape(Cin, -1)                             # [Cin, P]  (gather copy)
+        if x_levels != 1.0:
+            x2 = torch.round(x2 * float(x_levels))                              # the integer codes: exact in bf16 (<= 255)
+        g2 = grad_output.detach().permute(1, 0, 2, 3).reshape(Cout, -1)          # [Cout, P]
+        dW = bf16_gemm(split_bf16x3(g2.contiguous()), weight_bf16x3(x2.contiguous(), "raw"))
+        if inv != 1.0:
+            dW = dW * inv
+        return dW.view(Cout, Cin, 1, 1)
+    xs2d = torch.nn.functional.pixel_unshuffle(x.detach(), s)                    # [N, Cin s^2, H/s, W/s], channel = (ci, a_h, a_w)
+    dWp = conv2d_grad_weight_pm(xs2d, grad_output, (3, 3), 1, weight=None, x_levels=x_levels, bias_grad=bias_grad)
+    if dWp is None:
+        return None
+    dWp = dWp.view(Cout, Cin, s, s, 3, 3)
+    ua = [((i - p) // s, (i - p) % s) for i in range(kh)]                        # floor division: t = s u + a, 0 <= a < s
+    dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
+    for i, (ui, ai) in enumerate(ua):
+        for j, (uj, aj) in enumerate(ua):
+            dW[:, :, i, j] = dWp[:, :, ai, aj, ui + 1, uj + 1]
+    return dW
 
 
 #: largest output map (Ho * Wo) for which the weight gradient takes the matrix-core route (see conv2d_grad_weight_pm1)

@@ -1,0 +1,213 @@
+"""Round-3 GPU parity: the training-path routes VERDICT r2 listed as missing.
+
+  * strided convs (the 3x3 / stride-2 and 1x1 / stride-2 convs of models/Resnet/Resnet_bin.py:20-33): grad_input through the
+    zero-dilated gradient, grad_weight through the space-to-depth image / the sub-sampled GEMM, against fp64 of
+    torch.nn.grad.conv2d_input / conv2d_weight (functions/binary_connect.py:141-143);
+  * DoReFa layers with k-bit weights in TRAINING mode (layers/dorefa_layers.py:41-45,77-82, functions/dorefa_connect.py:99-111):
+    forward and every gradient against the fp64 evaluation of the reference expression, no dense-library call;
+  * the DoReFa ResNet-18 training step (W1A4 and W3A4) without a dense-library path.
+
+Float tails: max|a-b| / max|b| <= 1e-5."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import norm_err
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import _lib, ops  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic, nnDorefaQuant, _fused  # noqa: E402
+from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d, DorefaConv2d, LinearDorefa  # noqa: E402
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture()
+def all_shapes_on_the_routes():
+    """The routes are dispatched from 2^27 MACs on; the tests exercise them at every shape."""
+    old = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    yield
+    _fused.BWD_MFMA_MIN_MACS = old
+
+
+# ---- strided convs: grad_input ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,s,p,cl", [(4, 64, 128, 32, 32, 3, 2, 1, True), (4, 64, 128, 32, 32, 1, 2, 0, True),
+                                                      (3, 24, 40, 15, 17, 3, 2, 1, False), (2, 16, 8, 14, 9, 1, 2, 0, True),
+                                                      (2, 8, 12, 19, 20, 3, 3, 1, True), (3, 32, 32, 16, 16, 5, 2, 2, False),
+                                                      (2, 256, 512, 8, 8, 3, 2, 1, True)])
+@pytest.mark.parametrize("kind", ["sign", "raw"])
+def test_strided_grad_input_vs_fp64(dev, N, Cin, Cout, H, W, k, s, p, cl, kind):
+    g = torch.Generator(device=dev).manual_seed(N * 100 + Cin + k)
+    if kind == "sign":
+        wq = torch.randint(-1, 2, (Cout, Cin, k, k), generator=g, device=dev).float()
+    else:       # odd integer levels of a 3-bit DoReFa weight
+        wq = (2 * torch.randint(0, 8, (Cout, Cin, k, k), generator=g, device=dev) - 7).float()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    go = torch.randn((N, Cout, Ho, Wo), device=dev, generator=g)
+    if cl:
+        go = go.contiguous(memory_format=torch.channels_last)
+    before = dict(_lib.call_counts)
+    got = ops.conv2d_grad_input_q((N, Cin, H, W), wq, go, s, p, 1, kind=kind)
+    assert got is not None and _lib.call_counts["qt_conv2d_implicit"] > before.get("qt_conv2d_implicit", 0)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), wq.double(), go.double(), stride=s, padding=p)
+    assert norm_err(n(got), n(ref)) <= TOL
+
+
+# ---- strided convs: grad_weight -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,s,p,cl", [(8, 64, 128, 32, 3, 2, 1, True), (8, 64, 128, 32, 1, 2, 0, True),
+                                                    (5, 16, 40, 16, 3, 2, 1, False), (3, 128, 256, 16, 3, 2, 1, True),
+                                                    (4, 256, 512, 8, 1, 2, 0, True), (3, 12, 36, 9, 1, 3, 0, False),
+                                                    (2, 8, 32, 12, 4, 3, 1, True)])
+@pytest.mark.parametrize("levels", [1.0, 15.0])
+def test_strided_grad_weight_vs_fp64(dev, N, Cin, Cout, H, k, s, p, cl, levels):
+    g = torch.Generator(device=dev).manual_seed(N * 100 + Cin + k)
+    if levels == 1.0:
+        x = torch.randint(-1, 2, (N, Cin, H, H), generator=g, device=dev).float()
+    else:       # a 4-bit DoReFa image q / 15 exactly as the quantiser forms it
+        x = nnDorefaQuant(4)(torch.rand((N, Cin, H, H), generator=g, device=dev) * 1.5).detach()
+    Ho = (H + 2 * p - k) // s + 1
+    go = torch.randn((N, Cout, Ho, Ho), device=dev, generator=g)
+    if cl:
+        x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    assert ops.wgrad_strided_applicable(x.shape, go.shape, (k, k), s, p, 1)
+    got = ops.conv2d_grad_weight_strided(x, go, (k, k), s, p, x_levels=levels)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), go.double(), stride=s, padding=p)
+    assert got is not None and norm_err(n(got), n(ref)) <= TOL
+
+
+def test_strided_route_applicability_rules():
+    x, gsh = (8, 64, 32, 32), (8, 128, 16, 16)
+    assert ops.wgrad_strided_applicable(x, gsh, (3, 3), 2, 1, 1) and ops.wgrad_strided_applicable(x, gsh, (1, 1), 2, 0, 1)
+    assert not ops.wgrad_strided_applicable(x, gsh, (3, 3), 1, 1, 1)            # stride 1: the pixel-major route itself
+    assert not ops.wgrad_strided_applicable(x, gsh, (3, 3), 2, 1, 2)            # dilated
+    assert not ops.wgrad_strided_applicable(x, gsh, (5, 5), 2, 1, 1)            # taps beyond offsets {-1, 0} of the s2d image
+    assert not ops.wgrad_strided_applicable((8, 64, 31, 31), gsh, (3, 3), 2, 1, 1)   # odd extent
+    assert not ops.wgrad_strided_applicable((8, 4, 32, 32), gsh, (3, 3), 2, 1, 1)    # too few channels for a tile
+
+
+@pytest.mark.parametrize("cls,k,s,p", [(BinConv2d, 3, 2, 1), (TerConv2d, 1, 2, 0), (BinConv2d, 1, 2, 0), (TerConv2d, 3, 2, 1)])
+def test_strided_binarised_conv_backward_has_no_library_path(dev, all_shapes_on_the_routes, cls, k, s, p):
+    """Training-mode BinConv2d / TerConv2d with stride 2 on a BinaryConnect-tagged activation (ResNet_bin stage transition):
+    forward, grad_input, grad_weight (with the quantiser's STE mask) and grad_bias on this backend's kernels."""
+    torch.manual_seed(k + s)
+    conv = cls(64, 128, k, stride=s, padding=p).to(dev)
+    conv.weight.data.uniform_(-1.3, 1.3)
+    xr = torch.randn(6, 64, 32, 32, device=dev, requires_grad=True)
+    xs = BinaryConnectDeterministic.apply(xr.contiguous(memory_format=torch.channels_last))
+    xs.retain_grad()
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = conv(xs)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    assert dict(_fused.LIBRARY_PATHS) == lib_before, _fused.LIBRARY_PATHS
+    wq = (torch.where(conv.weight < 0, -1.0, 1.0) if cls is BinConv2d else ops.ternarize(conv.weight.detach())).double()
+    gi = torch.nn.grad.conv2d_input(xs.shape, wq, gout.double(), stride=s, padding=p)
+    gw = torch.nn.grad.conv2d_weight(xs.detach().double(), conv.weight.shape, gout.double(), stride=s, padding=p)
+    gw = torch.where(conv.weight.detach().abs() > 1.001, torch.zeros_like(gw), gw)
+    assert norm_err(n(xs.grad), n(gi)) <= TOL
+    assert norm_err(n(conv.weight.grad), n(gw)) <= TOL
+    assert norm_err(n(conv.bias.grad), n(gout.double().sum((0, 2, 3)))) <= TOL
+
+
+# ---- DoReFa, k-bit weights, training mode --------------------------------------------------------------------------------
+
+def _fp64_layer_grads(layer, x, gout):
+    """Forward + gradients of the reference expression F.conv2d / F.linear(x, weight_op(W), b) in fp64 on the CPU."""
+    ref = copy.deepcopy(layer).cpu().double().train()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    w = ref.weight_op.forward(ref.weight)
+    if isinstance(ref, torch.nn.Conv2d):
+        y = torch.nn.functional.conv2d(xr, w, ref.bias, ref.stride, ref.padding, ref.dilation, ref.groups)
+    else:
+        y = torch.nn.functional.linear(xr, w, ref.bias)
+    y.backward(gout.detach().cpu().double())
+    return y.detach(), xr.grad, ref.weight.grad, (ref.bias.grad if ref.bias is not None else None)
+
+
+@pytest.mark.parametrize("k_w", [2, 3, 4, 7])
+@pytest.mark.parametrize("coded", [True, False])
+@pytest.mark.parametrize("Cin,Cout,ksz,s,p,H", [(64, 64, 3, 1, 1, 16), (64, 128, 3, 2, 1, 16), (64, 128, 1, 2, 0, 16)])
+def test_dorefa_kbit_conv_training_vs_fp64(dev, all_shapes_on_the_routes, k_w, coded, Cin, Cout, ksz, s, p, H):
+    torch.manual_seed(k_w * 10 + Cin + ksz)
+    conv = DorefaConv2d(Cin, Cout, ksz, stride=s, padding=p, bias=True, bit_width=k_w).to(dev).train()
+    conv.weight.data.normal_(0, 0.7)
+    raw = (torch.rand(6, Cin, H, H, device=dev) * 1.4).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = nnDorefaQuant(4)(raw) if coded else raw * 1.0
+    x.retain_grad()
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    before = dict(_lib.call_counts)
+    y = conv(x)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    lib_now = {k: v - lib_before.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != lib_before.get(k, 0)}
+    if coded:
+        assert not lib_now, lib_now                                  # forward, grad_x and grad_W on this backend's kernels
+        assert _lib.call_counts["qt_conv2d_implicit"] - before.get("qt_conv2d_implicit", 0) >= 2
+    else:                                                            # a real activation: only grad_W has two real operands
+        assert set(lib_now) <= {"conv grad_weight outside the matrix-core route"}, lib_now
+    ry, rgx, rgw, rgb = _fp64_layer_grads(conv, x, gout)
+    assert norm_err(n(y), n(ry)) <= TOL
+    assert norm_err(n(x.grad), n(rgx)) <= TOL
+    assert norm_err(n(conv.weight.grad), n(rgw)) <= 2 * TOL        # through tanh / max|tanh| of the weight quantiser in fp32
+    assert norm_err(n(conv.bias.grad), n(rgb)) <= TOL
+
+
+@pytest.mark.parametrize("k_w", [2, 3, 5])
+@pytest.mark.parametrize("coded", [True, False])
+def test_dorefa_kbit_linear_training_vs_fp64(dev, all_shapes_on_the_routes, k_w, coded):
+    torch.manual_seed(k_w)
+    lin = LinearDorefa(300, 70, bias=True, bit_width=k_w).to(dev).train()
+    lin.weight.data.normal_(0, 0.7)
+    raw = (torch.rand(96, 300, device=dev) * 1.3).requires_grad_(True)
+    x = nnDorefaQuant(3)(raw) if coded else raw * 1.0
+    x.retain_grad()
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = lin(x)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    lib_now = {k: v - lib_before.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != lib_before.get(k, 0)}
+    if coded:
+        assert not lib_now, lib_now
+    ry, rgx, rgw, rgb = _fp64_layer_grads(lin, x, gout)
+    assert norm_err(n(y), n(ry)) <= TOL
+    assert norm_err(n(x.grad), n(rgx)) <= TOL
+    assert norm_err(n(lin.weight.grad), n(rgw)) <= 2 * TOL
+    assert norm_err(n(lin.bias.grad), n(rgb)) <= TOL
+
+
+@pytest.mark.parametrize("w_bits", [1, 3])
+def test_dorefa_resnet18_training_step_runs_on_this_backend(dev, w_bits):
+    """C4's network in TRAINING mode, batch 64: forward + backward of every DorefaConv2d (stride-1 and stride-2 3x3, 1x1
+    stride-2 shortcuts) without a dense-library contraction.  The first-layer stem and the classifier head are plain
+    nn.Conv2d / nn.Linear in the reference too (models/samples/ResNet_Dorefa.py) and are not this path's."""
+    import bench_models
+    torch.manual_seed(4)
+    m = bench_models.DorefaResNet18(w_bits=w_bits, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    m = m.to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(64, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 10, (64,), device=dev)
+    _fused.LIBRARY_PATHS.clear()
+    loss = torch.nn.functional.cross_entropy(m(x), t)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+    for name, p_ in m.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), name
