@@ -544,7 +544,8 @@ def _dorefa_w1_scale(weight: torch.Tensor, prequantized: bool) -> torch.Tensor:
     return weight.detach().abs().amax() if prequantized else weight.detach().abs().mean()
 
 
-def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None, scale=None):
+def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None, scale=None,
+                             route: Optional[list] = None):
     """LinearDorefa(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:41-45):
     y = x . (sign(W)*E)^T + b.  If the activation carries k-bit DoReFa codes (nnDorefaQuant output)
     the contraction runs on the int8 matrix cores: y = (E/n) * sum q*s + b; otherwise the dense GEMM
@@ -565,15 +566,29 @@ def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_cod
         if ok:
             wc = weight_codes if weight_codes is not None else ops.weight_codes(weight.detach().reshape(N, -1))
             y = ops.i8_gemm(codes, wc, codes.inv_n, poison_bias(bias, flag, N, input.device), scale_dev=E)
+            if route is not None:
+                route.append("codes")
             return y.view(*input.shape[:-1], N)
+    if FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+        # no usable int8 codes: exact bf16 split of the activation x sign(W) on the bf16 matrix cores, E and bias after
+        y = ops.float_linear(input.detach(), weight.detach(), "binary") * E
+        if bias is not None:
+            y = y + bias.detach()
+        if route is not None:
+            route.append("split")
+        return y
     wq = weight if prequantized else quantize_weight_f32(weight.detach(), "binary") * E
     note_library_path(input, "DoReFa activation without usable int8 codes")
+    if route is not None:
+        route.append("library")
     return F.linear(input, wq, bias)
 
 
 def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, weight_codes=None,
-                           padding_mode: str = "zeros", scale=None, epi=None):
-    """DorefaConv2d(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:77-82)."""
+                           padding_mode: str = "zeros", scale=None, epi=None, route: Optional[list] = None):
+    """DorefaConv2d(bit_width=1).forward on a device tensor (layers/dorefa_layers.py:77-82).  ``route``: a list that
+    receives "codes" (int8 matrix cores on the activation's codes), "split" (exact bf16 split of a real-valued — or
+    int8-overflowing — activation x sign(W), scaled by E) or "library"."""
     stride, padding, dilation, groups = conv_args
     E = scale if scale is not None else _dorefa_w1_scale(weight, prequantized)
     if isinstance(input, packed.CodeActivation):
@@ -616,9 +631,29 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
                                   poison_bias(bias, flag, int(weight.shape[0]), input.device), stride, padding,
                                   dilation, scale_dev=E)
             Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+            if route is not None:
+                route.append("codes")
             return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
+    if (FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0 and groups == 1
+            and padding_mode == "zeros" and not isinstance(padding, str)):
+        # no int8 codes (an un-quantised input, or the un-clamped quantiser left the int8 range): the activation is a real
+        # number for the matrix cores — exact bf16 split x sign(W), E and the bias applied to the result
+        N_, _, H, W = input.shape
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        y2 = ops.float_conv2d(input.detach(), weight.detach(), "binary", None, stride, padding, dilation) * E
+        if bias is not None:
+            y2 = y2 + bias.detach()
+        y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+        if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous()
+        if route is not None:
+            route.append("split")
+        return y
     wq = weight if prequantized else quantize_weight_f32(weight.detach(), "binary") * E
     note_library_path(input, "DoReFa activation without usable int8 codes")
+    if route is not None:
+        route.append("library")
     return F.conv2d(input, wq, bias, stride, padding, dilation, groups)
 
 
@@ -673,27 +708,58 @@ def dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width: int, wei
     return y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
 
 
+def _levels_grad_weight_linear(g2, x2, x_levels, codes_fit: bool):
+    """g2^T . x2 for a k-bit image x2 = q / n: codes (or their 256-digits when they left int8) as the exact bf16 operand."""
+    inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    q = torch.round(x2.detach() * float(x_levels))
+    gT = ops.split_bf16x3(g2.t().contiguous())
+    if codes_fit:
+        return ops.bf16_gemm(gT, ops.weight_bf16x3(q.t().contiguous(), "raw")) * inv
+    if float(q.abs().amax()) >= 65536.0:
+        return None
+    hi = torch.floor(q * (1.0 / 256.0))
+    lo = q - hi * 256.0
+    return (ops.bf16_gemm(gT, ops.weight_bf16x3(hi.t().contiguous(), "raw")) * 256.0
+            + ops.bf16_gemm(gT, ops.weight_bf16x3(lo.t().contiguous(), "raw"))) * inv
+
+
 class DorefaW1LinearFn(torch.autograd.Function):
     """Training-mode LinearDorefa(bit_width=1): forward above; backward as autograd derives it from
     F.linear(x, _ignore_factor_op(sign(W), E), b): grad_x = g . (sign(W) E), grad_W = g^T . x passed
-    through UNscaled (functions/dorefa_connect.py:66-79) with the identity STE of the quantiser."""
+    through UNscaled (functions/dorefa_connect.py:66-79) with the identity STE of the quantiser.  From 2^27 MACs on both
+    GEMMs run on the bf16 matrix cores (g split exactly, sign(W) / the activation's codes as the exact operand)."""
 
     @staticmethod
     def forward(ctx, input, weight, bias):
         ctx.has_bias = bias is not None
         ctx.save_for_backward(input, weight)
-        return dorefa_w1_linear_forward(input, weight, bias, prequantized=False)
+        ctx.x_levels = _act_levels(input, packed.ROWS_LAST) if input.dim() >= 2 else None
+        route = []
+        y = dorefa_w1_linear_forward(input, weight, bias, prequantized=False, route=route)
+        ctx.codes_fit = route == ["codes"]
+        return y
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        x2 = input.reshape(-1, input.shape[-1])
         grad_input = grad_weight = grad_bias = None
+        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
-            wq = quantize_weight_f32(weight, "binary") * weight.abs().mean()
-            grad_input = g2.mm(wq).view(input.shape)
+            sgn = quantize_weight_f32(weight, "binary")
+            E = weight.abs().mean()
+            if big:
+                grad_input = (ops.float_linear(g2.contiguous(), sgn.t().contiguous(), "sign") * E).view(input.shape)
+            else:
+                grad_input = g2.mm(sgn * E).view(input.shape)
         if ctx.needs_input_grad[1]:
-            grad_weight = g2.t().mm(input.reshape(-1, input.shape[-1]))
+            if big and ctx.x_levels is not None:
+                grad_weight = _levels_grad_weight_linear(g2, x2, ctx.x_levels, ctx.codes_fit)
+            if grad_weight is None:
+                if big:
+                    note_library_path(g2, "backward GEMM with two real operands")
+                grad_weight = g2.t().mm(x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)
         return grad_input, grad_weight, grad_bias
@@ -713,7 +779,10 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
             codes = packed.lookup_codes(input, packed.NHWC)
             if codes is not None and codes.K == input.shape[1]:
                 ctx.x_levels = float((1 << int(codes.bit_width)) - 1)
-        return dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False)
+        route = []
+        y = dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False, route=route)
+        ctx.codes_fit = route == ["codes"]
+        return y
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -737,14 +806,8 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if mfma and ctx.x_levels is not None and ctx.x_levels <= 255:
                 # UNscaled and un-masked, as upstream (_ignore_factor_op, identity STE): functions/dorefa_connect.py:66-79
-                if ops.wgrad_pm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
-                    grad_weight = ops.conv2d_grad_weight_pm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
-                if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, weight.shape[2:], stride, dilation):
-                    grad_weight = ops.conv2d_grad_weight_gemm(input, grad_output, weight.shape[2:], padding, x_levels=ctx.x_levels)
-                if grad_weight is None and ops.wgrad_strided_applicable(input.shape, go.shape, weight.shape[2:], stride, padding,
-                                                                        dilation):
-                    grad_weight = ops.conv2d_grad_weight_strided(input, go, weight.shape[2:], stride, padding,
-                                                                 x_levels=ctx.x_levels)
+                grad_weight = dorefa_conv_grad_weight(input, go, weight.shape[2:], stride, padding, dilation, ctx.x_levels,
+                                                      ctx.codes_fit)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
@@ -770,6 +833,37 @@ def _act_levels(t: torch.Tensor, layout):
     return None
 
 
+def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels: float, codes_fit: bool):
+    """grad wrt the (quantised) weight of a DoReFa conv whose activation is a k-bit image q / n (n = ``x_levels``): the
+    integer codes q are exact in bf16 while |q| <= 256, so the contraction runs on the weight-gradient routes (pixel-major,
+    K-major, strided) with the gradient split exactly.  ``codes_fit`` False — the un-clamped quantiser left the int8 range
+    (functions/dorefa_connect.py:11-25 has no clamp) —: q = 256 hi + lo with both digits exact in bf16, two passes,
+    256 GW(hi) + GW(lo); |q| >= 2^16 (or no route for the shape): None, the caller uses the library."""
+    def run(xt, levels):
+        gw = None
+        if ops.wgrad_pm_applicable(xt.shape, go.shape, ksz, stride, dilation):
+            gw = ops.conv2d_grad_weight_pm(xt, go, ksz, padding, x_levels=levels)
+        if gw is None and ops.wgrad_gemm_applicable(xt.shape, go.shape, ksz, stride, dilation):
+            gw = ops.conv2d_grad_weight_gemm(xt, go, ksz, padding, x_levels=levels)
+        if gw is None and ops.wgrad_strided_applicable(xt.shape, go.shape, ksz, stride, padding, dilation):
+            gw = ops.conv2d_grad_weight_strided(xt, go, ksz, stride, padding, x_levels=levels)
+        return gw
+
+    if codes_fit:
+        return run(input, x_levels)
+    q = torch.round(input.detach() * float(x_levels))
+    if float(q.abs().amax()) >= 65536.0:
+        return None
+    hi = torch.floor(q * (1.0 / 256.0))
+    lo = q - hi * 256.0
+    g_hi = run(hi, 1.0)
+    if g_hi is None:
+        return None
+    g_lo = run(lo, 1.0)
+    inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    return (g_hi * 256.0 + g_lo) * inv
+
+
 class DorefaWkConv2dFn(torch.autograd.Function):
     """Training-mode DorefaConv2d(bit_width = k), 2 <= k <= 7: conv2d(x, w_q, b) for the quantised image w_q the layer's
     weight_op produced (layers/dorefa_layers.py:77-82, functions/dorefa_connect.py:99-111); the gradient w.r.t. w_q flows on
@@ -792,6 +886,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         if ok and ctx.x_levels is not None:
             wc = ops.pack_conv_weight_dorefa_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width, wc)
+        ctx.codes_fit = y is not None            # the int8 route ran: every |code| <= 127
         if y is None and ok and FLOAT_PATH == "bf16x3" and input.numel() > 0:
             N_, _, H, W = input.shape
             Ho, Wo = ops.conv_out_hw(H, W, int(weight_q.shape[2]), int(weight_q.shape[3]), stride, padding, dilation)
@@ -829,12 +924,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ksz = weight_q.shape[2:]
             if mfma and ctx.x_levels is not None:
-                if ops.wgrad_pm_applicable(input.shape, go.shape, ksz, stride, dilation):
-                    grad_weight = ops.conv2d_grad_weight_pm(input, go, ksz, padding, x_levels=ctx.x_levels)
-                if grad_weight is None and ops.wgrad_gemm_applicable(input.shape, go.shape, ksz, stride, dilation):
-                    grad_weight = ops.conv2d_grad_weight_gemm(input, go, ksz, padding, x_levels=ctx.x_levels)
-                if grad_weight is None and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
-                    grad_weight = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=ctx.x_levels)
+                grad_weight = dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, ctx.x_levels, ctx.codes_fit)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight_q.shape, go, stride=stride, padding=padding,
@@ -856,6 +946,7 @@ class DorefaWkLinearFn(torch.autograd.Function):
         if input.dtype == torch.float32 and ctx.x_levels is not None:
             wc = ops.dorefa_weight_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_linear_forward(input, weight_q, bias, bit_width, wc)
+        ctx.codes_fit = y is not None
         if y is None and input.dtype == torch.float32 and FLOAT_PATH == "bf16x3" and input.numel() > 0:
             y = ops.float_linear(input.detach(), _weight_levels(weight_q, bit_width), "raw") * _inv_levels(bit_width)
             if bias is not None:
@@ -879,15 +970,13 @@ class DorefaWkLinearFn(torch.autograd.Function):
                 lv = _weight_levels(weight_q, k)
                 grad_input = (ops.float_linear(g2.contiguous(), lv.t().contiguous(), "raw") * _inv_levels(k)).view(input.shape)
             else:
-                note_library_path(g2, "small backward GEMM (launch-bound either way)")
                 grad_input = g2.mm(weight_q).view(input.shape)
         if ctx.needs_input_grad[1]:
             if big and ctx.x_levels is not None:   # g^T . x with x = codes / n_a
-                xc = torch.round(x2.detach() * ctx.x_levels)
-                inv_a = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(ctx.x_levels, dtype=torch.float32))
-                grad_weight = ops.float_linear(g2.t().contiguous(), xc.t().contiguous(), "raw") * inv_a
-            else:
-                note_library_path(g2, "backward GEMM with two real operands")
+                grad_weight = _levels_grad_weight_linear(g2, x2, ctx.x_levels, ctx.codes_fit)
+            if grad_weight is None:
+                if big:
+                    note_library_path(g2, "backward GEMM with two real operands")
                 grad_weight = g2.t().mm(x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)

@@ -191,6 +191,32 @@ def test_dorefa_kbit_linear_training_vs_fp64(dev, all_shapes_on_the_routes, k_w,
     assert norm_err(n(lin.bias.grad), n(rgb)) <= TOL
 
 
+@pytest.mark.parametrize("k_w", [1, 3])
+@pytest.mark.parametrize("ksz,s,p", [(3, 1, 1), (3, 2, 1), (1, 2, 0)])
+def test_dorefa_training_with_codes_beyond_int8_vs_fp64(dev, all_shapes_on_the_routes, k_w, ksz, s, p):
+    """The reference's quantiser does not clamp (functions/dorefa_connect.py:11-25): relu(bn(x)) + shortcut reaches values
+    whose 4-bit codes exceed 127 (even 256).  Forward then takes the exact-split route, the weight gradient contracts the
+    two base-256 digits of the codes — still no dense-library call, still the fp64 result."""
+    torch.manual_seed(k_w + ksz + s)
+    conv = DorefaConv2d(64, 96, ksz, stride=s, padding=p, bias=True, bit_width=k_w).to(dev).train()
+    conv.weight.data.normal_(0, 0.7)
+    raw = (torch.rand(5, 64, 16, 16, device=dev) * 40.0).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = nnDorefaQuant(4)(raw)                     # codes up to 600
+    x.retain_grad()
+    assert float(x.max()) * 15 > 300
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = conv(x)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    lib_now = {k: v - lib_before.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != lib_before.get(k, 0)}
+    assert not lib_now, lib_now
+    ry, rgx, rgw, rgb = _fp64_layer_grads(conv, x, gout)
+    assert norm_err(n(y), n(ry)) <= TOL
+    assert norm_err(n(x.grad), n(rgx)) <= TOL
+    assert norm_err(n(conv.weight.grad), n(rgw)) <= 2 * TOL
+    assert norm_err(n(conv.bias.grad), n(rgb)) <= TOL
+
+
 @pytest.mark.parametrize("w_bits", [1, 3])
 def test_dorefa_resnet18_training_step_runs_on_this_backend(dev, w_bits):
     """C4's network in TRAINING mode, batch 64: forward + backward of every DorefaConv2d (stride-1 and stride-2 3x3, 1x1
