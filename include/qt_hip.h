@@ -382,6 +382,28 @@ int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, i
                            int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s,
                            int64_t ph, int64_t pw, qt_stream_t stream);
 
+/* ---- fp16 pair planes: the two-term form of the same path (round 3; csrc/split_f16.hip) -------------------------------------
+ * Replaces the same F.linear / F.conv2d call sites as the bf16 triple planes (layers/binary_layers.py:44,105 with a real-valued
+ * input: models/Alexnet/Alexnet_Bin.py:13, and the backward convs of functions/binary_connect.py:141-143) at 2/3 of the matrix
+ * work: x / s = hi + lo (fp16, 2 x 11 significand bits) with s a per-tensor power of two chosen on the device,
+ * |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|); weights (+-1 / 0 / integer levels) exact in fp16, replicated twice.
+ *   qt_f16x2_scale_f32     : scale2[0] = s = 2^k with max(|*mn|, |*mx|) / s in [2^14, 2^15) (1 for an all-zero or non-finite
+ *                            tensor), scale2[1] = 1 / s.  mn / mx: device scalars (torch.aminmax); no host sync.
+ *   qt_f16x2_pack_f32      : mode 0: slots (2k, 2k+1) of a row = (hi, lo) of x[k] * scale2[1] (scale2 NULL: 1); modes 1..4:
+ *                            safeSign / ternary / torch.sign / raw weight value as fp16, twice.  ld_bytes >= 4 K, multiple
+ *                            of 16 (128 for GEMM operands), pad = 0.
+ *   qt_f16x2_s2d_pack_f32  : the space-to-depth gather of qt_bf16x3_s2d_pack_f32 with pairs instead of triples.
+ *   qt_f16_gemm            : Y[M,N] = scale * (*scale_dev) * Xh . Wh^T (+ bias) over K fp16 elements per row (K = 2 * features);
+ *                            ld in uint32 words.  Conv: qt_conv2d_implicit* with elem = 3 and scale_dev = &scale2[0]. */
+int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream);
+int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes, int64_t rows,
+                      int64_t K, int mode, qt_stream_t stream);
+int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2, uint16_t* out,
+                          int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw,
+                          qt_stream_t stream);
+int qt_f16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias, float scale,
+                const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
+
 /* Y[M,N] = Xh . Wh^T (+ bias) over K bf16 elements per row (K = 3 * features for triple planes);
  * ld in uint32 words. */
 int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,
@@ -428,7 +450,7 @@ int qt_im2col_words(const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t 
 
 /* Implicit-GEMM form of the same conv: no im2col matrix is materialised — the GEMM kernel's LDS-DMA
  * gathers 16-byte pixel chunks straight from the NHWC plane P (zero page for padding taps).
- * elem: 0 = fp4 nibble planes (scale ignored), 1 = int8 code planes (Y = scale * (*scale_dev) * acc),
+ * elem: 0 = fp4 nibble planes (scale ignored), 1 = int8 code planes (Y = scale * (*scale_dev) * acc), 3 = fp16 pair planes (same scaling),
  * 2 = bf16 triple planes.  Wmat: [Cout][ldwp] words, row = kh*kw taps x Cw words, ldwp % 32 == 0.
  * Y: NHWC [N*Ho*Wo][ldy] fp32. */
 int qt_conv2d_implicit(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,

@@ -194,6 +194,27 @@ struct ElemBf16 {
     __device__ __forceinline__ static float out(float v, float scale, float bias) { return v + bias; }
 };
 
+// fp16 operands (round 3, "pair planes"): the same idea with TWO terms.  An fp32 activation divided by a power-of-two
+// scale s (per tensor: max|x| / s in [2^14, 2^15), so that nothing overflows fp16 and the low term stays a normal number for
+// everything within 2^-17 of the maximum) is hi = fp16(x / s), lo = fp16(x / s - hi): 2 x 11 significand bits, i.e.
+// |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|).  Weights are +-1 / 0 / small integers (exact in fp16) replicated twice.
+// v_mfma_f32_32x32x16_f16 runs at the bf16 rate, products are exact, accumulation is fp32; the epilogue multiplies by s
+// (exact).  Two thirds of the MFMA work and of the operand bytes of the three-term bf16 route, at a normalised error two
+// orders inside the 1e-5 bar for real-valued inputs ("two-term split").
+struct ElemF16 {
+    using acc_t = v16f;
+    static constexpr bool CODE_EPI = false;
+    __device__ __forceinline__ static int kbytes(int K) { return 2 * K; }
+    __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+    }
+    __device__ __forceinline__ static float out(float v, float scale, float bias) { return v * scale + bias; }
+};
+
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
 //   4 = no LDS fragment reads, 5 = (ping-pong) per-segment cycle stamps + wall-clock phase stamps written over Y, 6 = phase stamps only.
@@ -1300,6 +1321,13 @@ int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t l
     return dispatch_gemm<ElemBf16>(0, Xh, ldxp, Wh, ldwp, bias, 1.0f, nullptr, Y, ldy, M, N, K, stream);
 }
 
+int qt_f16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias, float scale,
+                const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream) {
+    const int rc = check_common(Xh, ldxp, Wh, ldwp, Y, ldy, M, N, K, (K + 1) / 2);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    return dispatch_gemm<ElemF16>(0, Xh, ldxp, Wh, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
+}
+
 int qt_bf16_gemm_taps(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, float* Y, int64_t ldy,
                       int64_t M, int64_t N, int64_t K, int64_t tap_rows, int64_t tap_cols, int64_t nslice,
                       int64_t w_copy_bytes, int64_t w_row_bytes, int64_t y_stride, qt_stream_t stream) {
@@ -1347,7 +1375,7 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
 // AlexNet conv2 302 -> 275 us; other widths: double-buffered, equal or faster there), 1 = double-buffered, 2 = ping-pong,
 // 4 = automatic without the un-padded fast path; 3 = stamped 384x192 ping-pong, only in -DQT_PROFILING_VARIANTS builds
 
-// elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes.  epi.alpha != nullptr:
+// elem: 0 = fp4 nibble planes, 1 = int8 code planes, 2 = bf16 (triple) planes, 3 = fp16 (pair) planes.  epi.alpha != nullptr:
 // Y is the threshold-bit plane and ldy its row stride in words.
 static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
@@ -1362,7 +1390,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 #endif
     if (hy < 0 || hx < 0 || ((hy | hx) && (ph > hy || pw > hx))) return QT_ERR_INVALID_ARG;
     if (Nimg < 0 || H <= 0 || W <= 0 || Cw <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 ||
-        dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 2)
+        dw <= 0 || ph < 0 || pw < 0 || Cout < 0 || elem < 0 || elem > 3)
         return QT_ERR_INVALID_ARG;
     const int64_t Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
     if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
@@ -1455,6 +1483,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     } while (0)
     if (elem == 0) QT_CONV(ElemFp4);
     if (elem == 1) QT_CONV(ElemI8);
+    if (elem == 3) QT_CONV(ElemF16);
     QT_CONV(ElemBf16);
 #undef QT_CONV
 #undef QT_CONV_STAMPS
@@ -1484,7 +1513,7 @@ int qt_conv2d_implicit_bits(int elem, const uint32_t* P, int64_t Nimg, int64_t H
                             const float* scale_dev, const float* alpha, const float* beta, const float* thr,
                             uint32_t* neg_plane, int64_t ldb, int64_t Cout, qt_stream_t stream) {
     if (!alpha || !beta) return QT_ERR_INVALID_ARG;
-    if (thr && elem == 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
+    if (thr && elem >= 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
     if (ldb & 3) return QT_ERR_ALIGNMENT;
     EpiArgs epi;
     epi.alpha = alpha;
@@ -1501,7 +1530,7 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t Nimg, int64_t H,
                            uint32_t* nib_plane, int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w,
                            int64_t d2s_cout, qt_stream_t stream) {
     if (!alpha || !beta) return QT_ERR_INVALID_ARG;
-    if (thr && elem == 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
+    if (thr && elem >= 2) return QT_ERR_INVALID_ARG;       // integer thresholds need integer accumulators
     if (out_halo_h < 0 || out_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_INVALID_ARG;
     if ((ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
     if (d2s_cout < 0 || (d2s_cout && (d2s_cout % 32 || Cout != 4 * d2s_cout))) return QT_ERR_INVALID_ARG;

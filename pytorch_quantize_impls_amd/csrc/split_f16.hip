@@ -1,0 +1,219 @@
+// fp16 "pair planes": the two-term form of the real-valued-activation path (include/qt_hip.h, round 3).
+//   activations: x / s = hi + lo + e with hi = fp16_rn(x / s), lo = fp16_rn(x / s - hi); s = 2^k is a PER-TENSOR scale chosen
+//     on the device (qt_f16x2_scale_f32) so that max|x| / s lies in [2^14, 2^15): nothing overflows fp16 (max 65504), the
+//     division is exact, x / s - hi is exact in fp32 (it has at most 13 significant bits), and lo is a normal fp16 number for
+//     every |x| >= 2^-17 max|x| (below that it is rounded on the subnormal grid 2^-24).  Hence
+//         |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|)                                  (2 x 11 significand bits)
+//     stored as consecutive pairs: fp16 slot 2k + t of a row is term t of x[k].
+//   weights: a value that is exact in fp16 — the quantised q in {-1, 0, +1} (safeSign / ternary / torch.sign) or an integer
+//     level |q| <= 2048 ("raw": k-bit DoReFa levels) — replicated twice.
+// An fp16 MFMA GEMM (v_mfma_f32_32x32x16_f16, exact products, fp32 accumulate) over 2K of these planes, times s, equals the
+// fp32 GEMM of x with the quantised weight to the bound above: normalised error ~1e-7, two orders inside the 1e-5 bar of
+// SURVEY 8(d) for real-valued inputs, at 2/3 of the matrix work and operand bytes of the exact three-term bf16 route
+// (split_bf16.hip), which stays selectable.  HBM-bound elementwise kernels: 4 B in, 4 B out per element.
+#include "qt_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t f16_bits(float f) {
+    const _Float16 h = (_Float16)f;            // v_cvt_f16_f32: round to nearest even, subnormals kept
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+    const unsigned short u = (unsigned short)b;
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+// (hi | lo << 16) of v (already divided by the scale)
+__device__ __forceinline__ uint32_t split2(float v) {
+    const uint32_t hi = f16_bits(v);
+    const uint32_t lo = f16_bits(v - f16_bits_to_f32(hi));
+    return hi | (lo << 16);
+}
+
+__global__ void scale_kernel(const float* __restrict__ mn, const float* __restrict__ mx, float* __restrict__ scale2) {
+    const float a = fmaxf(fabsf(*mn), fabsf(*mx));
+    float s = 1.0f;
+    if (a > 0.0f && a < __builtin_huge_valf()) {
+        int e;
+        frexpf(a, &e);                          // a = m 2^e, m in [0.5, 1): floor(log2 a) = e - 1
+        int k = e - 15;                         // a / 2^k in [2^14, 2^15)
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        s = ldexpf(1.0f, k);
+    }
+    scale2[0] = s;
+    scale2[1] = 1.0f / s;                       // exact: a power of two
+}
+
+// mode 0 = activation split (x * scale2[1]), 1 = safeSign weight, 2 = ternary weight, 3 = torch.sign weight, 4 = raw weight
+template <int MODE>
+__global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale2,
+                                                   uint32_t* __restrict__ out, int64_t ld_words, int64_t rows, int64_t K) {
+    const float inv = (MODE == 0 && scale2) ? scale2[1] : 1.0f;
+    const int64_t quads = ld_words / 4;                      // one work item = 4 elements = 8 fp16 = 16 B
+    const int64_t total = rows * quads;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / quads, q = t - row * quads;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t k = q * 4 + e;
+            if (k >= K) continue;
+            const float v = x[row * ldx + k];
+            if (MODE == 0) {
+                w[e] = split2(v * inv);
+            } else {
+                float qv;
+                if (MODE == 1) qv = qt_safe_sign(v);
+                else if (MODE == 2) qv = qt_ternarize(v);
+                else if (MODE == 3) qv = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+                else qv = v;
+                const uint32_t b = f16_bits(qv);
+                w[e] = b | (b << 16);
+            }
+        }
+        reinterpret_cast<uint4*>(out + row * ld_words)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Space-to-depth gather + split (see split_bf16.hip: s2d_triple_kernel / s2d_triple_rows_kernel for the geometry):
+// pixel (n, Y, X) of the output plane holds, for e = (c*s + dy)*s + dx, the pair of x[n, c, s*Y + dy - ph, s*X + dx - pw] / scale.
+__global__ __launch_bounds__(256) void s2d_pair_kernel(const float* __restrict__ x, int64_t sN, int64_t sC, int64_t sH,
+                                                       int64_t sW, const float* __restrict__ scale2,
+                                                       uint32_t* __restrict__ out, int64_t ld_words, int64_t N, int C, int H,
+                                                       int W, int s, int ph, int pw, int Hs, int Ws) {
+    const float inv = scale2 ? scale2[1] : 1.0f;
+    const int E = C * s * s;
+    const int64_t quads = ld_words / 4;
+    const int64_t total = N * Hs * Ws * quads;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / quads, q = t - pix * quads;
+        const int64_t n = pix / ((int64_t)Hs * Ws);
+        const int rem = (int)(pix - n * Hs * Ws);
+        const int Y = rem / Ws, X = rem - Y * Ws;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = (int)q * 4 + j;
+            if (e >= E) continue;
+            const int c = e / (s * s), r = e - c * s * s, dy = r / s, dx = r - dy * s;
+            const int hh = s * Y + dy - ph, ww = s * X + dx - pw;
+            float v = 0.0f;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = x[n * sN + c * sC + hh * sH + ww * sW];
+            w[j] = split2(v * inv);
+        }
+        reinterpret_cast<uint4*>(out + pix * ld_words)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// channels-last images: one workgroup per output row (n, Y); the s input rows go through LDS with full-line loads, the
+// output row leaves as coalesced 16-byte stores (4 elements x 2 terms each)
+__global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restrict__ x, int64_t sN, int64_t sH,
+                                                            const float* __restrict__ scale2, uint32_t* __restrict__ out,
+                                                            int64_t ld_words, int C, int H, int W, int s, int ph, int pw,
+                                                            int Hs, int Ws, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2d_smem[];
+    const float inv = scale2 ? scale2[1] : 1.0f;
+    const int E = C * s * s, rowf = W * C, rowf4 = (rowf + 3) & ~3;
+    float* rows = reinterpret_cast<float*>(s2d_smem);                     // [s][rowf4]
+    int* lut_off = reinterpret_cast<int*>(rows + (size_t)s * rowf4);      // [E] dy*rowf4 + (dx - pw)*C + c
+    int* lut_dx = lut_off + E;                                            // [E] dx - pw
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / Hs, Y = blockIdx.x - n * Hs;
+    for (int e = tid; e < E; e += 256) {
+        const int c = e / (s * s), r = e - c * s * s, dy = r / s, dx = r - dy * s;
+        lut_off[e] = dy * rowf4 + (dx - pw) * C + c;
+        lut_dx[e] = dx - pw;
+    }
+    for (int dy = 0; dy < s; ++dy) {
+        const int hh = s * Y + dy - ph;
+        const bool ok = hh >= 0 && hh < H;
+        const float* src = x + (int64_t)n * sN + (int64_t)(ok ? hh : 0) * sH;
+        float* dst = rows + dy * rowf4;
+        if (vec_ok) {
+            for (int i = tid * 4; i < rowf; i += 1024)
+                *reinterpret_cast<float4*>(dst + i) = ok ? *reinterpret_cast<const float4*>(src + i) : make_float4(0, 0, 0, 0);
+        } else {
+            for (int i = tid; i < rowf; i += 256) dst[i] = ok ? src[i] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int quads = (int)(ld_words >> 2), total = Ws * quads;
+    uint4* orow = reinterpret_cast<uint4*>(out + ((int64_t)blockIdx.x * Ws) * ld_words);
+    for (int q = tid; q < total; q += 256) {
+        const int X = q / quads, cq = q - X * quads;
+        const int base = s * X * C, wx = s * X;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = cq * 4 + j;
+            float v = 0.0f;
+            if (e < E) {
+                const int ww = wx + lut_dx[e];
+                if ((unsigned)ww < (unsigned)W) v = rows[lut_off[e] + base];
+            }
+            w[j] = split2(v * inv);
+        }
+        orow[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream) {
+    if (!mn || !mx || !scale2) return QT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, mn, mx, scale2);
+    return qt_check_launch();
+}
+
+extern "C" int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes,
+                                 int64_t rows, int64_t K, int mode, qt_stream_t stream) {
+    if (rows < 0 || K < 0 || ldx < K || mode < 0 || mode > 4) return QT_ERR_INVALID_ARG;
+    if (rows == 0) return QT_OK;
+    if (!out || (!x && K > 0)) return QT_ERR_INVALID_ARG;
+    if (ld_bytes < 4 * K || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (ld_bytes == 0) return QT_OK;
+    const int64_t ld_words = ld_bytes / 4;
+    const int grid = qt_stream_grid((rows * (ld_words / 4) + 255) / 256);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+#define QT_LAUNCH(M) hipLaunchKernelGGL((pair_kernel<M>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, scale2, o, ld_words, rows, K)
+    switch (mode) {
+        case 0: QT_LAUNCH(0); break;
+        case 1: QT_LAUNCH(1); break;
+        case 2: QT_LAUNCH(2); break;
+        case 3: QT_LAUNCH(3); break;
+        default: QT_LAUNCH(4); break;
+    }
+#undef QT_LAUNCH
+    return qt_check_launch();
+}
+
+extern "C" int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2,
+                                     uint16_t* out, int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s,
+                                     int64_t ph, int64_t pw, qt_stream_t stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || s < 1 || ph < 0 || pw < 0) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!x || !out) return QT_ERR_INVALID_ARG;
+    const int64_t E = C * s * s;
+    if (ld_bytes < 4 * E || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (H > 32767 || W > 32767 || E > 4096) return QT_ERR_UNSUPPORTED;
+    const int64_t Hs = (H + 2 * ph + s - 1) / s, Ws = (W + 2 * pw + s - 1) / s;
+    const int64_t ld_words = ld_bytes / 4;
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    const int64_t rowf4 = (W * C + 3) & ~3ll;
+    const int64_t lds = s * rowf4 * 4 + E * 8;
+    if (sC == 1 && sW == C && lds <= 60 * 1024 && N * Hs < (1ll << 31) && sH >= W * C) {
+        const int vec_ok = ((W * C) % 4 == 0) && qt_aligned16(x) && (sH % 4 == 0) && (sN % 4 == 0);
+        hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, (hipStream_t)stream, x, sN, sH,
+                           scale2, o, ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok);
+        return qt_check_launch();
+    }
+    const int64_t total = N * Hs * Ws * (ld_words / 4);
+    const int grid = qt_stream_grid((total + 255) / 256);
+    hipLaunchKernelGGL(s2d_pair_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, sN, sC, sH, sW, scale2, o, ld_words, N,
+                       (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws);
+    return qt_check_launch();
+}

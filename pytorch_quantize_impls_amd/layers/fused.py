@@ -413,8 +413,8 @@ class FusedConvPoolBnSign(torch.nn.Module):
                                                           conv.padding, conv.dilation)):
                 # real-valued 3x3 / stride-1 / padding-1 first layer: direct kernel on the padded bf16-triple plane
                 N, C, H, W = (int(v) for v in x.shape)
-                px, _ = ops.s2d_triple_pack(x, 1, 1)
-                wtr = conv._conv_triples("plain")
+                px, _ = ops.s2d_triple_pack(x, 1, 1, terms=3)            # the direct kernel reads bf16 triple pixels
+                wtr = conv._conv_triples("plain", terms=3)
                 e2 = ops.NibEpilogue(epi[0], epi[1], (1, 1)) if (nib_out and not pooled) else epi
                 planes = ops.conv3x3_direct_nib(px, N, C, H, W, wtr, conv.bias, e2)
                 shape = (N, conv.out_channels, H, W)
@@ -455,7 +455,7 @@ class FusedConvPoolBnSign(torch.nn.Module):
         def build(_w2):
             ws = ops.s2d_weight(ops.d2s_first_layer_weight(conv.weight.detach()), 2)        # [4*Cout, 4*C, 2, 2]
             return tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")                  # zeros stay zeros
-        ws_shape, wtr = conv._eval_planes(build, key="conv_bf16x3_d2s")
+        ws_shape, wtr = conv._eval_planes(build, key=f"conv_split{ops.split_terms()}_d2s")
         px, (Hs, Ws) = ops.s2d_triple_pack(x, 2, 1)
         alpha, beta = (t.repeat(4) for t in affine)
         bias = conv.bias.detach().repeat(4) if conv.bias is not None else None

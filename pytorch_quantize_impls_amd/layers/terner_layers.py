@@ -93,18 +93,20 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def _weight_on_grid(self, w):
         return ((w == 0) | (w.abs() == 1)).all()
 
-    def _conv_triples(self, form):
-        """Cached bf16 triple image of the eval-mode (already quantised) weight for real-valued inputs:
-        'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the space-to-depth form."""
+    def _conv_triples(self, form, terms=None):
+        """Cached split image (bf16 triples / fp16 pairs, ops.FLOAT_SPLIT or ``terms``) of the eval-mode (already quantised)
+        weight for real-valued inputs: 'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the
+        space-to-depth form."""
         ops = _fused.ops
+        terms = ops.split_terms(terms)
         if form == "plain":
-            return self._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x3(self.weight.detach(), "ternary"),
-                                     key="conv_bf16x3")
+            return self._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x3(self.weight.detach(), "ternary", terms=terms),
+                                     key=f"conv_split{terms}")
 
         def build(_w2):
             ws = ops.s2d_weight(self.weight.detach(), self.stride[0])
-            return tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign")
-        return self._eval_planes(build, key="conv_bf16x3_s2d")
+            return tuple(ws.shape), ops.pack_conv_weight_bf16x3(ws, "sign", terms=terms)
+        return self._eval_planes(build, key=f"conv_split{terms}_s2d")
 
     def forward(self, input):
         """See BinConv2d.forward: eval mode without autograd on a HIP device returns a deferred activation."""

@@ -169,7 +169,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         rows = N * (zs * Ho + 2 * ohy) * (zs * Wo + 2 * ohx)
         plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)     # the launch writes every word, border included
         with _on(dev):
-            thr = _check_bias(epi.thr, Cout, dev) if (epi.thr is not None and elem != 2) else None
+            thr = _check_bias(epi.thr, Cout, dev) if (epi.thr is not None and elem < 2) else None
             _lib.call("qt_conv2d_implicit_nib", *head, _p(alpha), _p(beta), _p(thr), _p(plane), I(ldn), I(Cout), I(ohy),
                       I(ohx), I(d2s), _stream(dev))
         return NibPlanes(words=plane, rows=rows, K=Cpix)
@@ -184,7 +184,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         return y
     if epi is not None:
         alpha, beta = (_require(t, nm).contiguous() for t, nm in zip(epi[:2], ("alpha", "beta")))
-        thr = _check_bias(epi[2], Cout, dev) if (len(epi) > 2 and epi[2] is not None and elem != 2) else None
+        thr = _check_bias(epi[2], Cout, dev) if (len(epi) > 2 and epi[2] is not None and elem < 2) else None
         if alpha.numel() != Cout or beta.numel() != Cout:
             raise ValueError(f"alpha/beta must have {Cout} entries")
         ldb = packed_ld(Cout)
@@ -1250,19 +1250,53 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
 
 _TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3, "raw": 4}
 
+#: How a real-valued fp32 operand is split for the matrix cores:
+#:   "f16x2"  two fp16 terms of x / s, s a per-tensor power of two found on the device (csrc/split_f16.hip):
+#:            |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|); 2/3 of the MFMA work and operand bytes of the exact route;
+#:   "bf16x3" three bf16 terms, exact (csrc/split_bf16.hip).
+#: Both meet the 1e-5 normalised bar of SURVEY 8(d) for real-valued inputs ("two-term split"); routes
+#: whose kernels only exist for triples (direct 3x3 first layer, swapped-conv weight gradient, XNOR alpha folding) pass
+#: terms=3 explicitly.
+FLOAT_SPLIT = "f16x2"
 
-def triple_ld_bytes(K: int, granule: int = 128) -> int:
-    """Row stride in bytes of a bf16 triple plane holding K features (6 bytes each)."""
-    return max(granule, (6 * int(K) + granule - 1) // granule * granule)
+
+@contextlib.contextmanager
+def float_split(mode: str):
+    """Run the enclosed real-valued contractions with FLOAT_SPLIT = ``mode`` (process-wide; restores the previous mode)."""
+    global FLOAT_SPLIT
+    if mode not in ("f16x2", "bf16x3"):
+        raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
+    prev, FLOAT_SPLIT = FLOAT_SPLIT, mode
+    try:
+        yield
+    finally:
+        FLOAT_SPLIT = prev
+
+
+def split_terms(terms: Optional[int] = None) -> int:
+    if terms is not None:
+        return int(terms)
+    if FLOAT_SPLIT not in ("f16x2", "bf16x3"):
+        raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {FLOAT_SPLIT!r}")
+    return 2 if FLOAT_SPLIT == "f16x2" else 3
+
+
+def triple_ld_bytes(K: int, granule: int = 128, terms: int = 3) -> int:
+    """Row stride in bytes of a bf16 triple (terms = 3: 6 bytes per feature) or fp16 pair (terms = 2: 4 bytes) plane."""
+    return max(granule, (2 * int(terms) * int(K) + granule - 1) // granule * granule)
 
 
 @dataclass
 class TriplePlanes:
-    """bf16 triple image of a [rows, K] fp32 matrix: int16 tensor [rows, ld_bytes/2]; element 3k+s is
-    term s of x[k] = hi + mid + lo (activations) or the quantised weight value replicated (weights)."""
+    """Split image of a [rows, K] fp32 matrix for the bf16 / fp16 matrix cores: int16 tensor [rows, ld_bytes/2].
+    terms = 3: bf16, element 3k+t is term t of x[k] = hi + mid + lo (activations) or the quantised weight value replicated
+    (weights).  terms = 2: fp16, element 2k+t is term t of x[k] / scale[0] (activations; ``scale`` = device fp32 [s, 1/s])
+    or the weight value replicated twice."""
     data: torch.Tensor
     rows: int
     K: int
+    terms: int = 3
+    scale: Optional[torch.Tensor] = None
 
     @property
     def ld_words(self) -> int:
@@ -1272,13 +1306,37 @@ class TriplePlanes:
     def device(self):
         return self.data.device
 
+    @property
+    def elem(self) -> int:
+        """Element code of the conv / GEMM entry points: 2 = bf16 triples, 3 = fp16 pairs."""
+        return 2 if self.terms == 3 else 3
 
-def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_bytes: Optional[int]) -> TriplePlanes:
+
+def pow2_scale(x: torch.Tensor) -> torch.Tensor:
+    """Device fp32 [s, 1 / s] with s = 2^k and max|x| / s in [2^14, 2^15) (qt_f16x2_scale_f32): one reduction pass over x
+    (torch.aminmax), no host sync."""
+    mn, mx = torch.aminmax(x.detach())
+    out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _lib.call("qt_f16x2_scale_f32", _p(mn), _p(mx), _p(out), _stream(x.device))
+    return out
+
+
+def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_bytes: Optional[int],
+                 terms: Optional[int] = None, scale: Optional[torch.Tensor] = None) -> TriplePlanes:
     _require(x, "input")
     x2 = _as_rows(x)
     rows, K = int(x2.shape[0]), int(x2.shape[1])
-    ld = triple_ld_bytes(K) if ld_bytes is None else int(ld_bytes)
+    terms = 3 if alpha is not None else split_terms(terms)        # the per-feature alpha is folded by the triple kernel only
+    ld = triple_ld_bytes(K, terms=terms) if ld_bytes is None else int(ld_bytes)
     out = torch.empty((rows, ld // 2), dtype=torch.int16, device=x.device)
+    if terms == 2:
+        if mode == 0 and scale is None:
+            scale = pow2_scale(x2)
+        with _on(x.device):
+            _lib.call("qt_f16x2_pack_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(K, 1)),
+                      _p(scale if mode == 0 else None), _p(out), int(ld), int(rows), int(K), int(mode), _stream(x.device))
+        return TriplePlanes(data=out, rows=rows, K=K, terms=2, scale=scale if mode == 0 else None)
     if alpha is not None:
         alpha = _require(alpha, "alpha").contiguous().view(-1)
         if alpha.numel() != K:
@@ -1290,14 +1348,17 @@ def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_b
     return TriplePlanes(data=out, rows=rows, K=K)
 
 
-def split_bf16x3(x: torch.Tensor, alpha: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None) -> TriplePlanes:
-    """Exact hi/mid/lo bf16 split of an fp32 activation (optionally of x * alpha[k])."""
-    return _triple_pack(x, 0, alpha, ld_bytes)
+def split_bf16x3(x: torch.Tensor, alpha: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None,
+                 terms: Optional[int] = None) -> TriplePlanes:
+    """Split of an fp32 activation (optionally of x * alpha[k]) for the matrix cores: exact hi / mid / lo bf16 triples, or
+    (terms = 2 / FLOAT_SPLIT = "f16x2") scaled fp16 pairs."""
+    return _triple_pack(x, 0, alpha, ld_bytes, terms)
 
 
-def weight_bf16x3(w2d: torch.Tensor, kind: str, ld_bytes: Optional[int] = None) -> TriplePlanes:
-    """bf16 triples of the quantised weight: kind 'binary' (safeSign), 'ternary', 'sign' (torch.sign)."""
-    return _triple_pack(w2d, _TRIPLE_MODES[kind], None, ld_bytes)
+def weight_bf16x3(w2d: torch.Tensor, kind: str, ld_bytes: Optional[int] = None, terms: Optional[int] = None) -> TriplePlanes:
+    """Replicated image of the quantised weight: kind 'binary' (safeSign), 'ternary', 'sign' (torch.sign), 'raw' (the value
+    itself; exact for the integer levels it is used with), as bf16 x 3 or fp16 x 2."""
+    return _triple_pack(w2d, _TRIPLE_MODES[kind], None, ld_bytes, terms)
 
 
 def bf16_gemm(x: TriplePlanes, w: TriplePlanes, bias: Optional[torch.Tensor] = None,
@@ -1309,10 +1370,17 @@ def bf16_gemm(x: TriplePlanes, w: TriplePlanes, bias: Optional[torch.Tensor] = N
     bias = _check_bias(bias, N, dev)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if x.terms != w.terms:
+        raise ValueError(f"operand planes disagree: {x.terms}-term activation vs {w.terms}-term weight")
     with _on(dev):
-        _lib.call("qt_bf16_gemm", _p(x.data), int(x.ld_words), _p(w.data), int(w.ld_words),
-                  _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)), int(M),
-                  int(N), int(3 * x.K), _stream(dev))
+        if x.terms == 2:
+            _lib.call("qt_f16_gemm", _p(x.data), int(x.ld_words), _p(w.data), int(w.ld_words), _p(bias), 1.0,
+                      _p(x.scale[0:1] if x.scale is not None else None), _p(out),
+                      int(out.stride(0) if M > 1 else max(N, 1)), int(M), int(N), int(2 * x.K), _stream(dev))
+        else:
+            _lib.call("qt_bf16_gemm", _p(x.data), int(x.ld_words), _p(w.data), int(w.ld_words),
+                      _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)), int(M),
+                      int(N), int(3 * x.K), _stream(dev))
     return out
 
 
@@ -1387,18 +1455,21 @@ def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, al
     """y = x . Q(weight)^T (+ bias) for REAL-valued x: Q in {safeSign, ternary, torch.sign}; ``alpha``
     (per input feature) multiplies x first (XNORDense).  fp32-GEMM accuracy on the bf16 matrix cores."""
     N = weight.shape[0]
-    wt = weight_triples if weight_triples is not None else weight_bf16x3(weight.reshape(N, -1), kind)
-    y = bf16_gemm(split_bf16x3(x, alpha), wt, bias)
+    xp = split_bf16x3(x, alpha)
+    wt = weight_triples if (weight_triples is not None and weight_triples.terms == xp.terms) else \
+        weight_bf16x3(weight.reshape(N, -1), kind, terms=xp.terms)
+    y = bf16_gemm(xp, wt, bias)
     return y.view(*x.shape[:-1], N)
 
 
-def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str) -> TriplePlanes:
-    """[Cout, Cin, kh, kw] -> triple plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 6*Cin bytes rounded to 16)."""
+def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int] = None) -> TriplePlanes:
+    """[Cout, Cin, kh, kw] -> triple / pair plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 6*Cin or 4*Cin bytes rounded to 16)."""
     _require(weight, "weight")
     Cout, Cin, kh, kw = (int(v) for v in weight.shape)
-    Cb = triple_ld_bytes(Cin, 16)
+    terms = split_terms(terms)
+    Cb = triple_ld_bytes(Cin, 16, terms)
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
-    taps = weight_bf16x3(wt, kind, ld_bytes=Cb)
+    taps = weight_bf16x3(wt, kind, ld_bytes=Cb, terms=terms)
     kbytes = kh * kw * Cb
     ld = max(128, (kbytes + 127) // 128 * 128)
     data = taps.data.view(Cout, kbytes // 2)
@@ -1406,21 +1477,28 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str) -> TriplePlanes:
         padded = torch.zeros((Cout, ld // 2), dtype=torch.int16, device=weight.device)
         padded[:, :kbytes // 2] = data
         data = padded
-    return TriplePlanes(data=data, rows=Cout, K=kbytes // 6)   # K only used for consistency checks
+    return TriplePlanes(data=data, rows=Cout, K=kbytes // (2 * terms), terms=terms)   # K only used for consistency checks
 
 
-def s2d_triple_pack(x: torch.Tensor, s: int, padding) -> Tuple[TriplePlanes, Tuple[int, int]]:
-    """Space-to-depth gather + exact bf16 split of [N, C, H, W] (any storage) in one kernel.
+def s2d_triple_pack(x: torch.Tensor, s: int, padding, terms: Optional[int] = None) -> Tuple[TriplePlanes, Tuple[int, int]]:
+    """Space-to-depth gather + split (exact bf16 triples, or scaled fp16 pairs) of [N, C, H, W] (any storage) in one kernel.
     Returns (pixel planes with rows = N*Hs*Ws and K = C*s*s, (Hs, Ws))."""
     _require(x, "input")
     N, C, H, W = (int(v) for v in x.shape)
     ph, pw = _pairs(padding)
     Hs, Ws = (H + 2 * ph + s - 1) // s, (W + 2 * pw + s - 1) // s
     E = C * s * s
-    ld = triple_ld_bytes(E, 16)
+    terms = split_terms(terms)
+    ld = triple_ld_bytes(E, 16, terms)
     out = torch.empty((N * Hs * Ws, ld // 2), dtype=torch.int16, device=x.device)
     I = int
     sN, sC, sH, sW = (int(v) for v in x.stride())
+    if terms == 2:
+        scale = pow2_scale(x)
+        with _on(x.device):
+            _lib.call("qt_f16x2_s2d_pack_f32", _p(x), I(sN), I(sC), I(sH), I(sW), _p(scale), _p(out), I(ld), I(N), I(C), I(H),
+                      I(W), I(int(s)), I(ph), I(pw), _stream(x.device))
+        return TriplePlanes(data=out, rows=N * Hs * Ws, K=E, terms=2, scale=scale), (Hs, Ws)
     with _on(x.device):
         _lib.call("qt_bf16x3_s2d_pack_f32", _p(x), I(sN), I(sC), I(sH), I(sW), _p(out), I(ld), I(N), I(C), I(H),
                   I(W), I(int(s)), I(ph), I(pw), _stream(x.device))
@@ -1441,25 +1519,31 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     Cout, _, kh, kw = (int(v) for v in weight.shape)
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-    Cb = triple_ld_bytes(C, 16)
+    terms = pixels.terms if pixels is not None else split_terms(None)
+    Cb = triple_ld_bytes(C, 16, terms)
     if pixels is None:
         nhwc = x.permute(0, 2, 3, 1)
         if not nhwc.is_contiguous():
             nhwc = nhwc.contiguous()
-        px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb)
+        px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb, terms=terms)
     else:
         px = pixels
         x = pixels.data
         if pixels.rows != N * H * W or int(pixels.data.shape[0]) < N * H * W:
             raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
-    wt = weight_triples if weight_triples is not None else pack_conv_weight_bf16x3(weight, kind)
+    if weight_triples is not None and weight_triples.terms == terms:
+        wt = weight_triples
+    else:
+        if weight.device.type == "meta":
+            raise ValueError(f"cached weight planes have {weight_triples.terms} terms, the pixel planes {terms}")
+        wt = pack_conv_weight_bf16x3(weight, kind, terms=terms)
     Cw, ldA = Cb // 4, wt.ld_words
     M = N * Ho * Wo
     dev = x.device
     bias = _check_bias(bias, Cout, dev)
     if CONV_IMPLICIT:
-        y = _conv_implicit(2, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
-                           1.0, None, Cout, epi=epi)
+        y = _conv_implicit(px.elem, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
+                           1.0, (px.scale[0:1] if px.scale is not None else None), Cout, epi=epi)
         if y is not None:
             return y
     if epi is not None:
@@ -1474,8 +1558,13 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
         with _on(dev):
             _lib.call("qt_im2col_words", _p(px.data), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw),
                       I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
-            _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
-                      I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
+            if terms == 2:
+                _lib.call("qt_f16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), 1.0,
+                          _p(px.scale[0:1] if px.scale is not None else None), _p(y[m0:m0 + cnt]), I(Cout), I(cnt), I(Cout),
+                          I(kel), _stream(dev))
+            else:
+                _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
+                          I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
     return y
 
 
@@ -1630,9 +1719,9 @@ def conv2d_grad_weight_pm1(x_pm1: torch.Tensor, grad_output: torch.Tensor, kerne
             xs = torch.cat([xs, torch.zeros((nc - cnt,) + tuple(xs.shape[1:]), device=dev)], 0)
             gs = torch.cat([gs, torch.zeros((nc - cnt,) + tuple(gs.shape[1:]), device=dev)], 0)
         xt = xs.permute(1, 2, 3, 0).contiguous().view(Cin * H * W, nc)          # "pixels" (ci, h, w) x "channels" n
-        px = weight_bf16x3(xt, "sign", ld_bytes=Cb)                              # +-1 / 0 replicated three times
+        px = weight_bf16x3(xt, "sign", ld_bytes=Cb, terms=3)                     # +-1 / 0 replicated three times
         gt = gs.permute(1, 2, 3, 0).contiguous().view(Cout * Ho * Wo, nc)
-        tr = split_bf16x3(gt, ld_bytes=Cb)                                       # exact hi / mid / lo of the gradient
+        tr = split_bf16x3(gt, ld_bytes=Cb, terms=3)                              # exact hi / mid / lo of the gradient
         data = tr.data.view(Cout, kbytes // 2)
         if ld != kbytes:
             padded = torch.zeros((Cout, ld // 2), dtype=torch.int16, device=dev)
@@ -1759,6 +1848,18 @@ def wgrad_pm_applicable(x_shape, g_shape, kernel_hw, stride, dilation) -> bool:
 
 
 def wgrad_pm_plan(nc: int, Cout: int, Cin: int, H: int, W: int, Ho: int, kh: int, kw: int, ph: int, pw: int, slots: int):
+    """Memoised front of ``_wgrad_pm_plan`` (the slice search walks up to 256 candidates in Python: ~100 us per call, twenty
+    times per ResNet training step); the byte budget is part of the key because tests change it."""
+    return _wgrad_pm_plan_cached(int(nc), int(Cout), int(Cin), int(H), int(W), int(Ho), int(kh), int(kw), int(ph), int(pw),
+                                 int(slots), int(WGRAD_GEMM_BYTES))
+
+
+@functools.lru_cache(maxsize=4096)
+def _wgrad_pm_plan_cached(nc, Cout, Cin, H, W, Ho, kh, kw, ph, pw, slots, budget):
+    return _wgrad_pm_plan(nc, Cout, Cin, H, W, Ho, kh, kw, ph, pw, slots)
+
+
+def _wgrad_pm_plan(nc: int, Cout: int, Cin: int, H: int, W: int, Ho: int, kh: int, kw: int, ph: int, pw: int, slots: int):
     """Launch plan of the pixel-major weight gradient for ``nc`` images: (fits the byte budget?, K slices, positions in the
     gradient planes Qa = slices x slice length, rows of the activation plane Qx).  Host logic only (tests/test_wgrad_plan_cpu.py).
     K slices: the launch runs ceil(tiles * nslice / slots) rounds of ceil(ktot / nslice / 32) stages each, plus 24 stages' worth

@@ -47,6 +47,15 @@ def oracle():
     return O
 
 
+@pytest.fixture()
+def exact_split():
+    """Tests that pin the EXACT three-term bf16 route of real-valued operands (kernel names, bit-level layout); the default
+    since round 3 is the two-term fp16 split (ops.FLOAT_SPLIT = "f16x2", covered by tests/test_gpu_r3.py)."""
+    from pytorch_quantize_impls_amd import ops
+    with ops.float_split("bf16x3"):
+        yield
+
+
 def same(a, b):
     """Bitwise-style equality for fp32 arrays, treating NaN == NaN."""
     a = np.asarray(a)

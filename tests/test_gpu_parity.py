@@ -510,6 +510,7 @@ def test_c2_full_size_properties(dev):
     assert torch.equal(yt[idx][:, jdx].to(torch.float64), xs[idx].to(torch.float64) @ wt[jdx].t())
 
 
+@pytest.mark.usefixtures("exact_split")
 def test_alexnet_bin_layerwise(dev):
     """Every binarised layer of AlexNet-Bin on the GPU against the same layer on
     the CPU, fed with the CPU model's own intermediate activations (so a sign flip near a BN threshold
@@ -707,6 +708,7 @@ def test_fused_alexnet_matches_unfused(dev):
 
 # ---- real-valued activations: exact bf16 triple split + bf16 MFMA GEMM -----------------------------------------
 
+@pytest.mark.usefixtures("exact_split")
 def test_bf16x3_split_is_exact(dev):
     x = np.concatenate([synth.normal(1, (5000,)) * 3, synth.uniform(2, (5000,), -1e-3, 1e-3),
                         np.array([0.0, -0.0, 1.0, -1.0, 3.14159274, 1e-20, -1e20, 65504.0, 1.0000001], np.float32)])
@@ -727,6 +729,7 @@ def test_bf16x3_split_is_exact(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 7, 31), (130, 70, 363), (300, 260, 1000), (257, 129, 4096), (1024, 1024, 784)])
+@pytest.mark.usefixtures("exact_split")
 def test_float_linear_bf16x3_vs_fp64(dev, M, N, K):
     x = synth.normal(M + K, (M, K)) * 2.0
     w = synth.uniform(N + K, (N, K), -1.5, 1.5)
@@ -742,6 +745,7 @@ def test_float_linear_bf16x3_vs_fp64(dev, M, N, K):
     assert norm_err(ya, refa) <= TOL
 
 
+@pytest.mark.usefixtures("exact_split")
 def test_float_conv_bf16x3_vs_fp64(dev):
     gen = torch.Generator(device=dev)
     gen.manual_seed(21)
@@ -764,6 +768,7 @@ def test_float_conv_bf16x3_vs_fp64(dev):
         assert norm_err(n(y), n(ref)) <= TOL
 
 
+@pytest.mark.usefixtures("exact_split")
 def test_strided_first_layer_conv_s2d_vs_fp64(dev):
     """BinConv2d on real pixels with stride > 1 goes through the space-to-depth form; same numbers."""
     from pytorch_quantize_impls_amd.functions import _fused
@@ -935,6 +940,7 @@ def test_conv_ping_pong_kernels_equal_double_buffered(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("exact_split")
 def test_s2d_triple_pack_row_staged_kernel_equals_generic(dev):
     """Channels-last images take the LDS-staged kernel, NCHW storage the generic gather: identical planes
     (incl. zero padding rows/columns, ragged sizes, the non-vectorisable W*C % 4 != 0 case)."""
@@ -1018,6 +1024,7 @@ def test_dorefa_wk_ak_inference_on_int8_matrix_cores(dev, oracle, kw_bits, ka_bi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cls", ["bin", "ter"])
+@pytest.mark.usefixtures("exact_split")
 def test_linear_backward_on_bf16_matrix_cores_vs_fp64(dev, cls):
     """Large training-mode LinearBin / LinearTer: grad_x = g . Q(W) and grad_W = (g^T . x) * STE mask run through the
     exact-split bf16 GEMM (x is a tagged +-1 activation); compare with the fp64 evaluation."""

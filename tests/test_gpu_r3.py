@@ -237,3 +237,115 @@ def test_dorefa_resnet18_training_step_runs_on_this_backend(dev, w_bits):
     assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
     for name, p_ in m.named_parameters():
         assert p_.grad is not None and torch.isfinite(p_.grad).all(), name
+
+
+# ---- two-term fp16 split of real-valued operands (ops.FLOAT_SPLIT = "f16x2", csrc/split_f16.hip) ---------------------------
+
+def _decode_pairs(tp, K):
+    raw = n(tp.data).view(np.float16)[:, :2 * K].astype(np.float64).reshape(tp.rows, K, 2)
+    s = n(tp.scale).astype(np.float64)
+    return raw, s
+
+
+def test_f16x2_split_meets_its_stated_bound(dev):
+    """x / s = hi + lo with s a power of two, max|x| / s in [2^14, 2^15):  |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|)."""
+    from pytorch_quantize_impls_amd import synth
+    for seed, spread in ((1, 1.0), (2, 1e-6), (3, 1e6)):
+        x = np.concatenate([synth.normal(seed, (6000,)) * 3 * spread, synth.uniform(seed + 10, (3000,), -1e-4, 1e-4) * spread,
+                            (synth.normal(seed + 20, (1000,)) * spread * 10.0 ** synth.uniform(seed + 30, (1000,), -6, 0)),
+                            np.array([0.0, -0.0, 1.0, -1.0, 3.14159274, 1.0000001], np.float32) * spread]).astype(np.float32)
+        x = x.reshape(2, -1)
+        K = x.shape[1]
+        before = dict(_lib.call_counts)
+        with ops.float_split("f16x2"):
+            tp = ops.split_bf16x3(torch.from_numpy(x).to(dev))
+        assert tp.terms == 2 and tp.elem == 3 and _lib.call_counts["qt_f16x2_pack_f32"] > before.get("qt_f16x2_pack_f32", 0)
+        terms, s = _decode_pairs(tp, K)
+        amax = float(np.abs(x).max())
+        assert s[0] * s[1] == 1.0 and np.log2(s[0]) == np.floor(np.log2(s[0])) and 2.0 ** 14 <= amax / s[0] < 2.0 ** 15
+        rec = terms.sum(2) * s[0]
+        err = np.abs(rec - x.astype(np.float64))
+        bound = np.maximum(2.0 ** -22 * np.abs(x.astype(np.float64)), 2.0 ** -39 * amax)
+        assert (err <= bound).all(), float((err / bound).max())
+        assert not n(tp.data)[:, 2 * K:].any()                                     # zero pad
+    w = synth.uniform(3, (4, 37), -1.5, 1.5)
+    w[0, 0] = 0.0
+    for kind, q in (("binary", np.where(w < 0, -1.0, 1.0)), ("sign", np.sign(w)),
+                    ("ternary", np.where(w >= 0.5, 1.0, np.where(w < -0.5, -1.0, 0.0)))):
+        wt = ops.weight_bf16x3(torch.from_numpy(w).to(dev), kind, terms=2)
+        vals = n(wt.data).view(np.float16)[:, :2 * 37].astype(np.float32).reshape(4, 37, 2)
+        assert np.array_equal(vals, np.repeat(q[:, :, None], 2, 2).astype(np.float32)), kind
+    lv = torch.from_numpy((2 * np.arange(0, 128) - 127).astype(np.float32).reshape(1, -1)).to(dev)     # 7-bit DoReFa levels
+    raw = n(ops.weight_bf16x3(lv, "raw", terms=2).data).view(np.float16)[:, :256].astype(np.float32).reshape(1, 128, 2)
+    assert np.array_equal(raw[..., 0], n(lv)) and np.array_equal(raw[..., 1], n(lv))
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 7, 31), (130, 70, 363), (300, 260, 1000), (257, 129, 4096)])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_float_linear_both_splits_vs_fp64(dev, M, N, K, mode):
+    from pytorch_quantize_impls_amd import synth
+    x = synth.normal(M + K, (M, K)) * 2.0
+    x[:, ::7] *= 1e-4                                            # columns spanning four decades
+    w = synth.uniform(N + K, (N, K), -1.5, 1.5)
+    b = synth.normal(N, (N,))
+    q = np.where(w < 0, -1.0, 1.0)
+    with ops.float_split(mode):
+        y = n(ops.float_linear(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), "binary", torch.from_numpy(b).to(dev)))
+    ref = x.astype(np.float64) @ q.T + b
+    assert norm_err(y, ref) <= (2e-6 if mode == "f16x2" else TOL), norm_err(y, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,s,p,cl", [(4, 3, 192, 224, 11, 4, 2, True), (3, 3, 64, 33, 3, 1, 1, False),
+                                                    (2, 16, 40, 19, 5, 2, 2, True), (2, 64, 96, 14, 3, 1, 1, True)])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_real_input_conv_both_splits_vs_fp64(dev, N, Cin, Cout, H, k, s, p, cl, mode):
+    """BinConv2d on a REAL-valued image (the first layer: models/Alexnet/Alexnet_Bin.py:13) — space-to-depth and plain
+    routes, both splits, against fp64 of F.conv2d(x, safeSign(W), b)."""
+    torch.manual_seed(Cin + Cout + k)
+    conv = BinConv2d(Cin, Cout, k, stride=s, padding=p).to(dev).eval()
+    conv.binary_input = False
+    x = torch.randn(N, Cin, H, H, device=dev) * 2.0
+    x[:, :, ::3] *= 1e-3
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    from pytorch_quantize_impls_amd import lazy
+    before = dict(_lib.call_counts)
+    with torch.no_grad(), lazy.eager(), ops.float_split(mode):
+        y = conv(x)
+    pk = "qt_f16x2" if mode == "f16x2" else "qt_bf16x3"
+    assert any(k2.startswith(pk) and v > before.get(k2, 0) for k2, v in _lib.call_counts.items()), mode
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), s, p)
+    assert norm_err(n(y), n(ref)) <= (2e-6 if mode == "f16x2" else TOL), norm_err(n(y), n(ref))
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_gradient_conv_with_channels_spanning_six_decades(dev, mode):
+    """grad_x of a binarised conv (functions/binary_connect.py:141-143) for a gradient whose channels span six decades: the
+    per-tensor fp16 scale loses the small channels' low bits, but only relative to the LARGE ones — the normalised error
+    stays inside 1e-5 (and the exact three-term route stays selectable)."""
+    g_ = torch.Generator(device=dev).manual_seed(3)
+    Cout, Cin = 96, 64
+    wq = torch.randint(-1, 2, (Cout, Cin, 3, 3), generator=g_, device=dev).float()
+    go = torch.randn((4, Cout, 20, 20), device=dev, generator=g_)
+    go = (go * (10.0 ** torch.linspace(-6, 0, Cout, device=dev)).view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
+    with ops.float_split(mode):
+        got = ops.conv2d_grad_input_q((4, Cin, 20, 20), wq, go, 1, 1, 1)
+    ref = torch.nn.grad.conv2d_input((4, Cin, 20, 20), wq.double(), go.double(), padding=1)
+    assert norm_err(n(got), n(ref)) <= (2e-6 if mode == "f16x2" else TOL)
+
+
+def test_alexnet_first_block_bits_do_not_depend_on_the_epilogue_in_f16x2_mode(dev):
+    """Fused conv1 block (threshold-bit epilogue on the fp16-pair conv) == sign(BatchNorm(pool(conv1(x)))) of the same
+    route's fp32 output, bit for bit (the epilogue forms exactly the value the conv would have stored)."""
+    import bench_models
+    from pytorch_quantize_impls_amd import lazy
+    torch.manual_seed(0)
+    m = bench_models.AlexNetBin(num_classes=10)
+    bench_models.randomize_bn(m, 0)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(8, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad(), ops.float_split("f16x2"):
+        y = m(x)
+        with lazy.eager():
+            e = m(x)
+    assert torch.equal(y, e)
