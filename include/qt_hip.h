@@ -394,8 +394,13 @@ int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, i
  *                            of 16 (128 for GEMM operands), pad = 0.
  *   qt_f16x2_s2d_pack_f32  : the space-to-depth gather of qt_bf16x3_s2d_pack_f32 with pairs instead of triples.
  *   qt_f16_gemm            : Y[M,N] = scale * (*scale_dev) * Xh . Wh^T (+ bias) over K fp16 elements per row (K = 2 * features);
- *                            ld in uint32 words.  Conv: qt_conv2d_implicit* with elem = 3 and scale_dev = &scale2[0]. */
+ *                            ld in uint32 words.  Conv: qt_conv2d_implicit* with elem = 3 and scale_dev = &scale2[0].
+ *   qt_f16x2_absmax_scale_f32 : the same scale2 from the tensor itself: max|x| over n DENSE fp32 values (any order) at the HBM
+ *                            rate (per-workgroup partial maxima, then a one-workgroup fold; no atomics); work = scratch of
+ *                            qt_f16x2_absmax_work_words() uint32 (contents irrelevant).  x 16-byte aligned. */
+int64_t qt_f16x2_absmax_work_words(void);
 int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream);
+int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* work, float* scale2, qt_stream_t stream);
 int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes, int64_t rows,
                       int64_t K, int mode, qt_stream_t stream);
 int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2, uint16_t* out,

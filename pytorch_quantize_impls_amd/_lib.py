@@ -100,6 +100,8 @@ SIGNATURES = {
     "qt_bf16x3_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_bf16x6_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_f16x2_scale_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p]),
+    "qt_f16x2_absmax_work_words": (_c_i64, []),
+    "qt_f16x2_absmax_scale_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
     "qt_f16x2_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_f16x2_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -34,8 +34,7 @@ __device__ __forceinline__ uint32_t split2(float v) {
     return hi | (lo << 16);
 }
 
-__global__ void scale_kernel(const float* __restrict__ mn, const float* __restrict__ mx, float* __restrict__ scale2) {
-    const float a = fmaxf(fabsf(*mn), fabsf(*mx));
+__device__ __forceinline__ void write_scale(float a, float* __restrict__ scale2) {
     float s = 1.0f;
     if (a > 0.0f && a < __builtin_huge_valf()) {
         int e;
@@ -45,7 +44,52 @@ __global__ void scale_kernel(const float* __restrict__ mn, const float* __restri
         s = ldexpf(1.0f, k);
     }
     scale2[0] = s;
-    scale2[1] = 1.0f / s;                       // exact: a power of two
+    scale2[1] = 1.0f / s;
+}
+
+__global__ void scale_kernel(const float* __restrict__ mn, const float* __restrict__ mx, float* __restrict__ scale2) {
+    write_scale(fmaxf(fabsf(*mn), fabsf(*mx)), scale2);
+}
+
+// max|x| over a dense tensor at the HBM rate: every workgroup writes the maximum of its share (the bit pattern of |x|:
+// non-negative floats order like unsigned integers, NaN above everything) to part[blockIdx]; a second, one-workgroup launch
+// folds the partials and writes scale2.  (One launch with a device-scope atomicMax per workgroup was 85 us for 154 MB: 2048
+// same-address atomics serialise at ~40 ns each across the XCDs.)
+__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ part) {
+    unsigned m = 0;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#define QT_FOLD(v) m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, \
+            max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)))
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per lane
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        QT_FOLD(a); QT_FOLD(b); QT_FOLD(c); QT_FOLD(d);
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = x4[i];
+        QT_FOLD(a);
+    }
+#undef QT_FOLD
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_final_kernel(const unsigned* __restrict__ part, int nparts, float* __restrict__ scale2) {
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = max(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) write_scale(__uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3]))), scale2);
 }
 
 // mode 0 = activation split (x * scale2[1]), 1 = safeSign weight, 2 = ternary weight, 3 = torch.sign weight, 4 = raw weight
@@ -166,6 +210,17 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
 extern "C" int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream) {
     if (!mn || !mx || !scale2) return QT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, mn, mx, scale2);
+    return qt_check_launch();
+}
+
+extern "C" int64_t qt_f16x2_absmax_work_words() { return 2048; }
+
+extern "C" int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* work, float* scale2, qt_stream_t stream) {
+    if (n < 0 || !work || !scale2 || (n > 0 && !x)) return QT_ERR_INVALID_ARG;
+    if (!qt_aligned16(x)) return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid(((n >> 2) + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, work);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, work, grid, scale2);
     return qt_check_launch();
 }
 

@@ -1315,8 +1315,16 @@ class TriplePlanes:
 def pow2_scale(x: torch.Tensor) -> torch.Tensor:
     """Device fp32 [s, 1 / s] with s = 2^k and max|x| / s in [2^14, 2^15) (qt_f16x2_scale_f32): one reduction pass over x
     (torch.aminmax), no host sync."""
-    mn, mx = torch.aminmax(x.detach())
+    x = x.detach()
     out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    if _storage_dense(x) and x.data_ptr() % 16 == 0:
+        # dense storage in any dimension order: max|x| at the HBM rate and the scale in one launch (torch.aminmax runs at
+        # ~1.2 TB/s: 128 us for AlexNet's 154 MB input batch against 26 us)
+        work = torch.empty((2048,), dtype=torch.int32, device=x.device)        # qt_f16x2_absmax_work_words()
+        with _on(x.device):
+            _lib.call("qt_f16x2_absmax_scale_f32", _p(x), int(x.numel()), _p(work), _p(out), _stream(x.device))
+        return out
+    mn, mx = torch.aminmax(x)
     with _on(x.device):
         _lib.call("qt_f16x2_scale_f32", _p(mn), _p(mx), _p(out), _stream(x.device))
     return out

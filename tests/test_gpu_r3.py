@@ -349,3 +349,107 @@ def test_alexnet_first_block_bits_do_not_depend_on_the_epilogue_in_f16x2_mode(de
         with lazy.eager():
             e = m(x)
     assert torch.equal(y, e)
+
+
+# ---- reference digests / fp64 vectors for the shapes whose only comparator was the same device's library -----------------
+
+@pytest.fixture(scope="module")
+def hashes_r3():
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes_r3.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.fixture(scope="module")
+def golden_r3():
+    import os
+    from conftest import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "golden_r3_v1.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("case", ["terconv_c5_128_256_56", "terconv_c5_512_512_14", "binconv_c4_64_128_32_s2",
+                                  "binconv_c4_64_128_32_1x1s2", "binconv_c4_256_512_8_s2"])
+def test_config_size_convs_reproduce_the_reference_digest(dev, hashes_r3, case):
+    """TerConv2d at the two remaining VGG channel classes, BinConv2d at the ResNet stage transitions (3x3 / stride 2 and the
+    1x1 / stride 2 shortcut): SHA-256 of the int32 result the REFERENCE layer produced on the same +-1 input
+    (tests/golden/make_golden_r3.py), train and eval mode, tagged and un-tagged input."""
+    import hashlib
+    from pytorch_quantize_impls_amd import lazy, synth
+    h = hashes_r3[case]
+    x = synth.pm1(h["x_seed"], (h["B"], h["Cin"], h["H"], h["H"]))
+    w = synth.uniform(h["w_seed"], (h["Cout"], h["Cin"], h["k"], h["k"]), h["w_lo"], h["w_hi"])
+    cls = TerConv2d if case.startswith("terconv") else BinConv2d
+    conv = cls(h["Cin"], h["Cout"], h["k"], stride=h["stride"], padding=h["pad"]).to(dev)
+    wd = torch.from_numpy(w).to(dev)
+    conv.bias.data.zero_()
+    for tagged in (False, True):
+        xd = torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last)
+        if tagged:
+            xd = BinaryConnectDeterministic.apply(xd)
+        for training in (True, False):
+            conv.train(True)
+            conv.weight.data.copy_(wd)
+            conv.train(training)
+            before = dict(_lib.call_counts)
+            with torch.no_grad():
+                y = lazy.resolve(conv(xd))
+            assert _lib.call_counts["qt_conv2d_implicit"] > before.get("qt_conv2d_implicit", 0)
+            yi = n(y.contiguous()).astype(np.int32)
+            assert hashlib.sha256(np.ascontiguousarray(yi).tobytes()).hexdigest() == h["sha256_int32"], (tagged, training)
+            assert float(y.double().sum()) == h["sum"]
+
+
+@pytest.mark.parametrize("case", ["w1a4_core_c4_64_128_32_s2", "w1a4_core_c4_64_128_32_1x1s2"])
+def test_strided_w1a4_integer_core_reproduces_the_reference_digest(dev, hashes_r3, case):
+    """4-bit activation codes x sign weights on the int8 matrix cores with unit scale at the strided C4 shapes."""
+    import hashlib
+    from pytorch_quantize_impls_amd import synth
+    h = hashes_r3[case]
+    B, C, H, k, s, p = h["B"], h["Cin"], h["H"], h["k"], h["stride"], h["pad"]
+    codes = np.floor(synth.uniform(h["x_seed"], (B, C, H, H), 0.0, 16.0)).clip(0, 15).astype(np.float32)
+    w = synth.uniform(h["w_seed"], (h["Cout"], C, k, k), h["w_lo"], h["w_hi"])
+    xq = (torch.from_numpy(codes).to(dev) / 15.0).contiguous(memory_format=torch.channels_last)
+    px, _ = ops.dorefa_codes(xq.permute(0, 2, 3, 1).reshape(B * H * H, C), 4, want_f32=False, ld_bytes=ops.code_ld_bytes(C, 16))
+    wp = ops.pack_conv_weight_codes(torch.from_numpy(w).to(dev))
+    y2 = ops.conv2d_codes(px, (B, C, H, H), wp, (k, k), 1.0, None, s, p, 1)
+    Ho = (H + 2 * p - k) // s + 1
+    y = y2.view(B, Ho, Ho, h["Cout"]).permute(0, 3, 1, 2).contiguous()
+    assert hashlib.sha256(np.ascontiguousarray(n(y).astype(np.int32)).tobytes()).hexdigest() == h["sha256_int32"]
+
+
+def test_strided_binconv_backward_vs_reference_fp64_vectors(dev, all_shapes_on_the_routes, golden_r3):
+    """G15: forward + every gradient of a training-mode strided BinConv2d against the fp64 autograd of the REFERENCE layer."""
+    for name in golden_r3["g15_cases"]:
+        Cin, Cout, H, k, s, p = (int(v) for v in golden_r3[f"g15_{name}_geom"])
+        t = {kk: torch.from_numpy(golden_r3[f"g15_{name}_{kk}"]).to(dev) for kk in ("x", "w", "b", "go")}
+        conv = BinConv2d(Cin, Cout, k, stride=s, padding=p).to(dev).train()
+        conv.weight.data.copy_(t["w"])
+        conv.bias.data.copy_(t["b"])
+        xr = t["x"].contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        xs = BinaryConnectDeterministic.apply(xr)
+        xs.retain_grad()
+        lib_before = dict(_fused.LIBRARY_PATHS)
+        y = conv(xs)
+        y.backward(t["go"])
+        assert dict(_fused.LIBRARY_PATHS) == lib_before
+        assert norm_err(n(y), golden_r3[f"g15_{name}_y"]) <= TOL
+        assert norm_err(n(xs.grad), golden_r3[f"g15_{name}_gx"]) <= TOL
+        assert norm_err(n(conv.weight.grad), golden_r3[f"g15_{name}_gw"]) <= TOL
+        assert norm_err(n(conv.bias.grad), golden_r3[f"g15_{name}_gb"]) <= TOL
+
+
+def test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence(dev):
+    """the whole-step comparator is the FP64 evaluation of the reference's op sequence (CPU), at 1e-5 —
+    and the device's fp32 library run of the same sequence is measured against it too, so it is visible which side a
+    difference comes from."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_train_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_train_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ours, fp32_lib = mod.gradient_agreement_fp64(4)
+    print(f"worst normalised gradient difference vs fp64: this backend {ours:.2e}, fp32 library ops {fp32_lib:.2e}")
+    assert ours <= TOL, (ours, fp32_lib)

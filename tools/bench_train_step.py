@@ -84,6 +84,32 @@ def gradient_agreement(B: int = 16, seed: int = 0) -> float:
                if not (k.endswith(".bias") and ref[k].abs().max() < 1e-3 * top))
 
 
+def gradient_agreement_fp64(B: int = 4, seed: int = 0):
+    """(worst normalised difference of this backend's parameter gradients, of the fp32 reference op sequence's on this device)
+    against the FP64 evaluation of the reference op sequence on the CPU, for one AlexNet-Bin training step on +-1 pixels:
+    the comparator is neither this backend nor the device's fp32 library (VERDICT r2, weak #2)."""
+    import copy
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    model = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.where(torch.randn(B, 3, 224, 224, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    target = torch.randint(0, 10, (B,), device=dev)
+    ref = copy.deepcopy(model).cpu().double().train()
+    ref.zero_grad(set_to_none=True)
+    F.nll_loss(ref_forward(ref, x.cpu().double()), target.cpu()).backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    worst = []
+    for fwd in (model, lambda t: ref_forward(model, t)):
+        m2 = copy.deepcopy(model)                       # BatchNorm running statistics must not move between the two runs
+        m2.zero_grad(set_to_none=True)
+        F.nll_loss((m2 if fwd is model else (lambda t: ref_forward(m2, t)))(x), target).backward()
+        got = {k: p.grad.double().cpu() for k, p in m2.named_parameters()}
+        top = max(float(g.abs().max()) for g in want.values())
+        worst.append(max(float((got[k] - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in got
+                         if not (k.endswith(".bias") and want[k].abs().max() < 1e-3 * top)))
+    return tuple(worst)
+
+
 def other_models(name):
     """MODEL=vgg16 | resnet18: the C5 / C4 nets in training mode — this backend vs the same graph with the backward convs left to
     MIOpen, the dense-library paths taken, and the per-step strided-copy count."""
@@ -97,7 +123,7 @@ def other_models(name):
         fwd = lambda t: F.log_softmax(model(t), 1)
     else:
         B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-        model = bench_models.DorefaResNet18()
+        model = bench_models.DorefaResNet18(w_bits=int(os.environ.get("W_BITS", "1")), a_bits=4)
         x = torch.randn(B, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
         target = torch.randint(0, 10, (B,), device=dev)
         fwd = lambda t: F.log_softmax(model(t), 1)
