@@ -218,3 +218,20 @@ class TernaryVGG16(nn.Module):
     def forward(self, x):
         x = self.features(x)
         return self.classifier(x.reshape(x.size(0), -1))
+
+
+class TrainFusedAlexNetBin(nn.Module):
+    """AlexNetBin for TRAINING with every [MaxPool2d?, BatchNorm, Hardtanh, BinaryConnect] run as one FusedTrainPoolBnSign
+    (layers.fuse_sequential_training): shares all parameters / buffers with ``model``.  The BinaryConnect that opens the
+    classifier is applied before the flatten (sign commutes with a reshape), so the last feature block is fused too."""
+
+    def __init__(self, model: AlexNetBin):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import fuse_sequential_training
+        f, c = list(model.features.children()), list(model.classifieur.children())
+        self.features = fuse_sequential_training(nn.Sequential(*f, c[0]))
+        self.classifieur = fuse_sequential_training(nn.Sequential(*c[1:]))
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifieur(x.reshape(x.size(0), 256 * 6 * 6))

@@ -409,6 +409,28 @@ int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, in
 int qt_f16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias, float scale,
                 const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
 
+/* ---- training-mode chain between two binarised layers (csrc/train_chain.hip, round 3) -------------------------------------
+ * [MaxPool2d(k, s)] -> BatchNorm (BATCH statistics) -> [Hardtanh(lo, hi)] -> BinaryConnectDeterministic, forward and backward:
+ * replaces F.max_pool2d / F.batch_norm(training=True) / F.hardtanh and their autograd backwards in
+ * models/Alexnet/Alexnet_Bin.py:13-17, benchmark/BinaryNet/MLPBin.py:42-44 (torch / MIOpen kernels in the module graph), and
+ * the STE of functions/binary_connect.py:31-38.  x: NHWC fp32 [N][H][W][C] (a [N, C] matrix: H = W = 1); pooled rows
+ * R = N * Ho * Wo, Ho = (H - k) / s + 1 (no padding, floor mode; k = 1: no pooling, p and idx unused / NULL).
+ *   forward : p[R][C] pooled values, idx[R][C] int8 argmax (first maximum in scan order), mean[C], invstd[C] (biased variance,
+ *             two passes), running statistics updated in place (NULL: skipped; unbiased variance, as torch), sgn[R][C] = +-1 of
+ *             clamp(((p - mean) * invstd) * gamma + beta, lo, hi) (no Hardtanh: lo = -inf, hi = +inf; gamma / beta NULL: 1 / 0).
+ *             partial: scratch of qt_train_chain_partial_floats(R, C) floats.
+ *   backward: g[R][C] = dL/dsgn -> dgamma[C], dbeta[C], gp[R][C] = dL/dp, and (k > 1) gx[N][H][W][C] = dL/dx by a gather over
+ *             the windows that contain each pixel (no atomics).  p_or_x: p (k > 1) or x (k = 1) of the forward. */
+int64_t qt_train_chain_partial_floats(int64_t R, int64_t C);
+int qt_pool_bn_sign_train_f32(const float* x, int64_t N, int64_t H, int64_t W, int64_t C, int64_t k, int64_t s,
+                              const float* gamma, const float* beta, float eps, float momentum, float ht_lo, float ht_hi,
+                              float* running_mean, float* running_var, float* p, int8_t* idx, float* mean, float* invstd,
+                              float* partial, float* sgn, qt_stream_t stream);
+int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p_or_x, const int8_t* idx, int64_t N, int64_t H, int64_t W,
+                                       int64_t C, int64_t k, int64_t s, const float* gamma, const float* beta,
+                                       const float* mean, const float* invstd, float ht_lo, float ht_hi, float ste_threshold,
+                                       float* partial, float* dgamma, float* dbeta, float* gp, float* gx, qt_stream_t stream);
+
 /* Y[M,N] = Xh . Wh^T (+ bias) over K bf16 elements per row (K = 3 * features for triple planes);
  * ld in uint32 words. */
 int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,

@@ -511,6 +511,103 @@ class PackedMaxPool(torch.nn.Module):
         return packed.PackedActivation(planes, (N, C, Ho, Wo))
 
 
+class _TrainPoolBnSignFn(torch.autograd.Function):
+    """[MaxPool2d] -> BatchNorm (batch statistics) -> [Hardtanh] -> BinaryConnectDeterministic as one autograd node on this
+    backend's kernels (ops.pool_bn_sign_train / _backward); see FusedTrainPoolBnSign."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, k, s, lo, hi):
+        out, saved = ops.pool_bn_sign_train(x, gamma, beta, running_mean, running_var, eps, momentum, k, s, (lo, hi))
+        ctx.saved_chain, ctx.ht = saved, (lo, hi)
+        ctx.save_for_backward(gamma, beta)
+        ctx.x_nchw = x.dim() == 4 and x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)
+        # the sign planes ride along like BinaryConnect's (the next binarised layer takes them without a detection pass)
+        if out.dim() == 4:
+            planes, _ = ops.sign_pack(out.permute(0, 2, 3, 1))
+            out = packed.attach(out, planes, packed.NHWC)
+        else:
+            planes, _ = ops.sign_pack(out)
+            out = packed.attach(out, planes, packed.ROWS_LAST)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gamma, beta = ctx.saved_tensors
+        gx, dgamma, dbeta = ops.pool_bn_sign_train_backward(grad_out, ctx.saved_chain, gamma, beta, ctx.ht)
+        if ctx.x_nchw:
+            gx = gx.contiguous()
+        return (gx, dgamma if gamma is not None else None, dbeta if beta is not None else None) + (None,) * 8
+
+
+class FusedTrainPoolBnSign(torch.nn.Module):
+    """TRAINING-mode form of [MaxPool2d(k, s)] -> BatchNorm{1,2}d -> [Hardtanh] -> BinaryConnect(deterministic), the chain
+    between two binarised layers (models/Alexnet/Alexnet_Bin.py:13-17, benchmark/BinaryNet/MLPBin.py:42-44): forward (pooling
+    with its argmax, batch statistics in two passes, running-statistics update, normalise + clamp + sign) and backward (STE
+    of the sign, Hardtanh mask, BatchNorm backward, max-pool gather) on this backend's kernels (csrc/train_chain.hip) instead
+    of torch's max_pool2d / MIOpen's batch_norm / hardtanh and their autograd backwards.  Shares the BatchNorm module (its
+    parameters and buffers ARE the model's).  CPU tensors, eval mode, momentum=None or untracked statistics: the module chain
+    itself.  Opt-in: ``fuse_sequential_training``."""
+
+    def __init__(self, bn, pool=None, hardtanh=None):
+        super().__init__()
+        self.bn, self.pool, self.hardtanh = bn, pool, hardtanh
+        self.sign = _FunctionModule(BinaryConnectDeterministic)
+        self.pool_k = self.pool_s = 1
+        if pool is not None:
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            st = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+            pad = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+            dil = pool.dilation if isinstance(pool.dilation, int) else pool.dilation[0]
+            if pad != 0 or dil != 1 or pool.ceil_mode or pool.return_indices:
+                raise ValueError("only un-padded, un-dilated, floor-mode MaxPool2d can be fused")
+            self.pool_k, self.pool_s = int(k), int(st)
+
+    def forward(self, x):
+        x = lazy.resolve(x)
+        bn = self.bn
+        fast = (self.training and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 4)
+                and bn.momentum is not None and bn.track_running_stats and x.shape[0] * (x[0, 0].numel()) > 1
+                and (self.pool is None or x.dim() == 4))
+        if not fast:
+            h = self.pool(x) if self.pool is not None else x
+            h = bn(h)
+            if self.hardtanh is not None:
+                h = self.hardtanh(h)
+            return self.sign(h)
+        lo, hi = ((float(self.hardtanh.min_val), float(self.hardtanh.max_val)) if self.hardtanh is not None
+                  else (-float("inf"), float("inf")))
+        out = _TrainPoolBnSignFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean,
+                                       bn.running_var, float(bn.eps), float(bn.momentum), self.pool_k, self.pool_s, lo, hi)
+        bn.num_batches_tracked.add_(1)
+        return out
+
+
+def fuse_sequential_training(seq: torch.nn.Sequential) -> torch.nn.Sequential:
+    """New nn.Sequential (sharing every module of ``seq``) where each [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)]
+    run is one FusedTrainPoolBnSign: the training step then runs no torch / MIOpen pooling, BatchNorm or Hardtanh kernel
+    between binarised layers, forward or backward."""
+    mods = list(seq.children())
+    out, i = [], 0
+    while i < len(mods):
+        j, pool = i, None
+        if isinstance(mods[j], torch.nn.MaxPool2d):
+            pool, j = mods[j], j + 1
+        if j < len(mods) and isinstance(mods[j], (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            bn, j2, ht = mods[j], j + 1, None
+            if j2 < len(mods) and isinstance(mods[j2], torch.nn.Hardtanh):
+                ht, j2 = mods[j2], j2 + 1
+            if j2 < len(mods) and _is_det_binary_connect(mods[j2]):
+                try:
+                    out.append(FusedTrainPoolBnSign(bn, pool, ht))
+                    i = j2 + 1
+                    continue
+                except ValueError:
+                    pass
+        out.append(mods[i])
+        i += 1
+    return torch.nn.Sequential(*out)
+
+
 def _is_det_binary_connect(m):
     return isinstance(m, _FunctionModule) and m.core is BinaryConnectDeterministic
 

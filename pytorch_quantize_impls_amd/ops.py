@@ -1576,6 +1576,72 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     return y
 
 
+# ---- training-mode chain [MaxPool] -> BatchNorm(batch stats) -> [Hardtanh] -> sign (csrc/train_chain.hip) --------------------------
+
+def _rows_view(x: torch.Tensor):
+    """(NHWC-contiguous view of a 4-D tensor | the [N, C] matrix itself, N, H, W, C)."""
+    if x.dim() == 4:
+        nhwc = x.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+        N, H, W, C = (int(v) for v in nhwc.shape)
+        return nhwc, N, H, W, C
+    if x.dim() == 2:
+        x2 = x.contiguous()
+        return x2, int(x2.shape[0]), 1, 1, int(x2.shape[1])
+    raise ValueError("the training chain takes [N, C, H, W] or [N, C] tensors")
+
+
+def pool_bn_sign_train(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, momentum: float,
+                       pool_k: int = 1, pool_s: int = 1, ht=(-float("inf"), float("inf"))):
+    """Forward of the training chain on a device fp32 tensor.  Returns (sign image shaped like the pooled tensor — NHWC storage
+    for 4-D inputs —, saved = (p_or_x, idx, mean, invstd, geometry) for ``pool_bn_sign_train_backward``).  The running
+    statistics are updated in place."""
+    _require(x, "input")
+    xs, N, H, W, C = _rows_view(x.detach())
+    k, s = int(pool_k), int(pool_s)
+    if H < k or W < k:
+        raise ValueError("pooling window larger than the map")
+    Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+    R = N * Ho * Wo
+    dev = x.device
+    p = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=dev) if k > 1 else None
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.int8, device=dev) if k > 1 else None
+    mean = torch.empty((C,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+    partial = torch.empty((int(_lib.load().qt_train_chain_partial_floats(R, C)),), dtype=torch.float32, device=dev)
+    sgn = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=dev)
+    g_ = _check_bias(gamma.detach() if gamma is not None else None, C, dev)
+    b_ = _check_bias(beta.detach() if beta is not None else None, C, dev)
+    with _on(dev):
+        _lib.call("qt_pool_bn_sign_train_f32", _p(xs), N, H, W, C, k, s, _p(g_), _p(b_), float(eps), float(momentum),
+                  float(ht[0]), float(ht[1]), _p(running_mean), _p(running_var), _p(p), _p(idx), _p(mean), _p(invstd),
+                  _p(partial), _p(sgn), _stream(dev))
+    out = sgn.permute(0, 3, 1, 2) if x.dim() == 4 else sgn.view(N, C)
+    return out, (p if k > 1 else xs, idx, mean, invstd, (N, H, W, C, k, s))
+
+
+def pool_bn_sign_train_backward(grad_out: torch.Tensor, saved, gamma, beta, ht, ste_threshold: float = STE_THRESHOLD):
+    """(grad wrt the chain's input [shaped / laid out like it], dgamma, dbeta)."""
+    p_or_x, idx, mean, invstd, (N, H, W, C, k, s) = saved
+    g, _, Ho, Wo, _ = _rows_view(_require(grad_out, "grad_output"))
+    dev = g.device
+    R = N * Ho * Wo
+    partial = torch.empty((int(_lib.load().qt_train_chain_partial_floats(R, C)),), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+    gp = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=dev)
+    gx = torch.empty((N, H, W, C), dtype=torch.float32, device=dev) if k > 1 else None
+    g_ = _check_bias(gamma.detach() if gamma is not None else None, C, dev)
+    b_ = _check_bias(beta.detach() if beta is not None else None, C, dev)
+    with _on(dev):
+        _lib.call("qt_pool_bn_sign_train_backward_f32", _p(g), _p(p_or_x), _p(idx), N, H, W, C, k, s, _p(g_), _p(b_), _p(mean),
+                  _p(invstd), float(ht[0]), float(ht[1]), float(ste_threshold), _p(partial), _p(dgamma), _p(dbeta), _p(gp),
+                  _p(gx), _stream(dev))
+    gin = gx if k > 1 else gp
+    return (gin.permute(0, 3, 1, 2) if grad_out.dim() == 4 else gin.view(N, C)), dgamma, dbeta
+
+
 # ---- backward of a quantised conv on the bf16 matrix cores (SURVEY 8f n2) ----------------------------------------------
 # Both gradients of conv2d(x, Q(W)) have one +-1 / 0 operand, so the exact-split route of the forward applies:
 #   grad_x = conv2d(g, flip(Q(W))^T, padding k-1-p)                 (stride 1): real g x quantised weight, the forward kernel

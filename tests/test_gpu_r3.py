@@ -453,3 +453,107 @@ def test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence(dev):
     ours, fp32_lib = mod.gradient_agreement_fp64(4)
     print(f"worst normalised gradient difference vs fp64: this backend {ours:.2e}, fp32 library ops {fp32_lib:.2e}")
     assert ours <= TOL, (ours, fp32_lib)
+
+
+# ---- training-mode chain [MaxPool] -> BatchNorm(batch stats) -> [Hardtanh] -> sign on this backend's kernels --------------------
+
+@pytest.mark.parametrize("shape,pool,ht,cl", [((8, 192, 27, 27), (3, 2), True, True), ((4, 96, 13, 13), None, True, True),
+                                               ((3, 40, 9, 11), (2, 2), False, False), ((64, 300), None, True, False),
+                                               ((5, 33, 7, 7), (3, 1), True, True), ((2, 8, 6, 6), (2, 2), True, True)])
+def test_training_chain_vs_fp64_of_the_module_chain(dev, shape, pool, ht, cl):
+    """layers.FusedTrainPoolBnSign against the reference's module chain MaxPool2d -> BatchNorm -> Hardtanh -> BinaryConnect
+    (models/Alexnet/Alexnet_Bin.py:13-17) evaluated in fp64 on the CPU: the +-1 output, the gradient w.r.t. the input,
+    dgamma / dbeta, and the running statistics."""
+    import copy
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    from pytorch_quantize_impls_amd.layers import FusedTrainPoolBnSign
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    bn = (torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d)(C, eps=1e-4, momentum=0.15)
+    with torch.no_grad():
+        bn.weight.uniform_(0.3, 1.5)
+        bn.weight[::3] *= -1.0
+        bn.bias.normal_(0, 0.4)
+    pm = torch.nn.MaxPool2d(*pool) if pool else None
+    hm = torch.nn.Hardtanh() if ht else None
+    ref_bn = copy.deepcopy(bn).double().train()
+    mod = FusedTrainPoolBnSign(bn.to(dev), pm, hm).train()
+    x = torch.randn(shape) * 1.7 + 0.3
+    xd = x.to(dev)
+    if cl and len(shape) == 4:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_(True)
+    before = dict(_lib.call_counts)
+    y = mod(xd)
+    assert _lib.call_counts["qt_pool_bn_sign_train_f32"] > before.get("qt_pool_bn_sign_train_f32", 0)
+    gout = torch.randn(y.shape)
+    y.backward(gout.to(dev))
+    assert _lib.call_counts["qt_pool_bn_sign_train_backward_f32"] > before.get("qt_pool_bn_sign_train_backward_f32", 0)
+    xr = x.double().requires_grad_(True)
+    h = pm(xr) if pm else xr
+    h = ref_bn(h)
+    if hm:
+        h = hm(h)
+    yr = BinaryConnect()(h)
+    yr.backward(gout.double())
+    assert torch.equal(y.detach().cpu().double(), yr.detach())
+    assert norm_err(n(xd.grad), n(xr.grad)) <= TOL
+    assert norm_err(n(bn.weight.grad), n(ref_bn.weight.grad)) <= TOL
+    assert norm_err(n(bn.bias.grad), n(ref_bn.bias.grad)) <= TOL
+    assert norm_err(n(bn.running_mean), n(ref_bn.running_mean)) <= 1e-6
+    assert norm_err(n(bn.running_var), n(ref_bn.running_var)) <= 1e-6
+    assert int(bn.num_batches_tracked) == 1
+    # the +-1 output carries its sign planes like BinaryConnect's
+    from pytorch_quantize_impls_amd import packed
+    assert packed.lookup(y, packed.NHWC if len(shape) == 4 else packed.ROWS_LAST) is not None
+
+
+def test_training_chain_pool_ties_route_the_gradient_like_torch(dev):
+    """Conv outputs of +-1 nets are integers: equal maxima inside a window are the rule.  The gradient goes to the FIRST
+    maximum in scan order (torch's max_pool2d rule on CPU and GPU)."""
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    from pytorch_quantize_impls_amd.layers import FusedTrainPoolBnSign
+    torch.manual_seed(0)
+    x = torch.randint(-3, 4, (4, 32, 9, 9)).float()
+    bn = torch.nn.BatchNorm2d(32)
+    import copy
+    ref_bn = copy.deepcopy(bn).double()
+    mod = FusedTrainPoolBnSign(bn.to(dev), torch.nn.MaxPool2d(3, 2), torch.nn.Hardtanh()).train()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = mod(xd)
+    gout = torch.randn(y.shape)
+    y.backward(gout.to(dev))
+    xr = x.double().requires_grad_(True)
+    yr = BinaryConnect()(torch.nn.functional.hardtanh(ref_bn(torch.nn.functional.max_pool2d(xr, 3, 2))))
+    yr.backward(gout.double())
+    assert torch.equal(y.detach().cpu().double(), yr.detach())
+    assert norm_err(n(xd.grad), n(xr.grad)) <= TOL
+
+
+def test_alexnet_training_step_with_the_fused_training_chain(dev):
+    """bench_models.TrainFusedAlexNetBin (every pool / BatchNorm / Hardtanh / sign run on csrc/train_chain.hip) against the
+    un-fused module graph on the same device, +-1 pixels: same loss, same parameter gradients to the float tail."""
+    import bench_models
+    torch.manual_seed(0)
+    model = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
+    fused = bench_models.TrainFusedAlexNetBin(model)
+    x = torch.where(torch.randn(8, 3, 224, 224, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 10, (8,), device=dev)
+    import copy
+    state = copy.deepcopy(model.state_dict())
+    grads = []
+    for net in (model, fused):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        _fused.LIBRARY_PATHS.clear()
+        loss = torch.nn.functional.nll_loss(net(x), t)
+        loss.backward()
+        grads.append((float(loss), {k: p_.grad.clone() for k, p_ in model.named_parameters()}))
+    assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+    (l0, g0), (l1, g1) = grads
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    top = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        if k.endswith(".bias") and float(g0[k].abs().max()) < 1e-3 * top:
+            continue          # a bias in front of a training-mode BatchNorm: mathematically zero gradient, rounding noise
+        assert norm_err(n(g1[k]), n(g0[k])) <= 2e-5, k
