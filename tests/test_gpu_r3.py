@@ -531,29 +531,37 @@ def test_training_chain_pool_ties_route_the_gradient_like_torch(dev):
 
 
 def test_alexnet_training_step_with_the_fused_training_chain(dev):
-    """bench_models.TrainFusedAlexNetBin (every pool / BatchNorm / Hardtanh / sign run on csrc/train_chain.hip) against the
-    un-fused module graph on the same device, +-1 pixels: same loss, same parameter gradients to the float tail."""
+    """bench_models.TrainFusedAlexNetBin (every pool / BatchNorm / Hardtanh / sign run on csrc/train_chain.hip) against the FP64
+    evaluation of the reference's op sequence on the CPU, +-1 pixels: same loss, every parameter gradient within 1e-5.
+    (The same device's un-fused fp32 graph is NOT the comparator: with integer conv sums and beta = 0 a value can sit exactly on
+    BatchNorm's mean, and MIOpen's fp32 mean then lands it on either side — one such element of 73 728 flips in this very
+    configuration, tools/probes/train_chain_debug.py; the two-pass double-folded statistics here reproduce the exact tie.)"""
+    import copy
+    import importlib.util
+    import os
     import bench_models
+    spec = importlib.util.spec_from_file_location(
+        "bench_train_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_train_step.py"))
+    bts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bts)
     torch.manual_seed(0)
     model = bench_models.AlexNetBin().to(dev).to(memory_format=torch.channels_last).train()
-    fused = bench_models.TrainFusedAlexNetBin(model)
     x = torch.where(torch.randn(8, 3, 224, 224, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
     t = torch.randint(0, 10, (8,), device=dev)
-    import copy
-    state = copy.deepcopy(model.state_dict())
-    grads = []
-    for net in (model, fused):
-        model.load_state_dict(state)
-        model.zero_grad(set_to_none=True)
-        _fused.LIBRARY_PATHS.clear()
-        loss = torch.nn.functional.nll_loss(net(x), t)
-        loss.backward()
-        grads.append((float(loss), {k: p_.grad.clone() for k, p_ in model.named_parameters()}))
+    ref = copy.deepcopy(model).cpu().double().train()
+    loss_ref = torch.nn.functional.nll_loss(bts.ref_forward(ref, x.cpu().double()), t.cpu())
+    loss_ref.backward()
+    want = {k: p_.grad for k, p_ in ref.named_parameters()}
+    fused = bench_models.TrainFusedAlexNetBin(model)
+    _fused.LIBRARY_PATHS.clear()
+    before = dict(_lib.call_counts)
+    loss = torch.nn.functional.nll_loss(fused(x), t)
+    loss.backward()
     assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
-    (l0, g0), (l1, g1) = grads
-    assert abs(l0 - l1) <= 1e-5 * abs(l0)
-    top = max(float(v.abs().max()) for v in g0.values())
-    for k in g0:
-        if k.endswith(".bias") and float(g0[k].abs().max()) < 1e-3 * top:
+    assert _lib.call_counts["qt_pool_bn_sign_train_f32"] - before.get("qt_pool_bn_sign_train_f32", 0) == 7       # 5 conv + 2 FC blocks
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
+    top = max(float(v.abs().max()) for v in want.values())
+    for k, p_ in model.named_parameters():
+        if k.endswith(".bias") and float(want[k].abs().max()) < 1e-3 * top:
             continue          # a bias in front of a training-mode BatchNorm: mathematically zero gradient, rounding noise
-        assert norm_err(n(g1[k]), n(g0[k])) <= 2e-5, k
+        assert norm_err(n(p_.grad), n(want[k])) <= TOL, k
