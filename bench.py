@@ -748,11 +748,18 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         before = dict(_fused_library_paths())
         t_ours, loss_ours = bts.step_time(mt, mt, xt, tt)
         lib_used = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
+        # the same step with every [MaxPool, BatchNorm, Hardtanh, BinaryConnect] run on this backend's training-chain kernels
+        # (layers.fuse_sequential_training: opt-in, shares the parameters) instead of torch / MIOpen
+        mf = bench_models.TrainFusedAlexNetBin(mt)
+        t_fused, loss_fused = bts.step_time(mf, mt, xt, tt)
         t_ref, loss_ref = bts.step_time(lambda t: bts.ref_forward(mt, t), mt, xt, tt, n=3)
         out["n2_training_step_alexnet_bin"] = {
             "workload": f"BinaryNet-AlexNet 3x224x224 batch {Bt}, training mode, forward + backward (nll loss), fp32 master weights, "
                         "channels_last; no optimizer step (the reference's trainers are out of scope)",
             "ms_per_step": t_ours, "images_per_s": Bt / t_ours * 1e3,
+            "with_fused_training_chain": {"ms_per_step": t_fused, "images_per_s": Bt / t_fused * 1e3, "loss": loss_fused,
+                                          "what": "bench_models.TrainFusedAlexNetBin: pooling / BatchNorm(batch statistics) / Hardtanh / "
+                                                  "sign forward + backward on csrc/train_chain.hip (opt-in fuse_sequential_training)"},
             "reference_ops_on_gpu": {"ms_per_step": t_ref, "images_per_s": Bt / t_ref * 1e3,
                                      "what": "torch.sign + F.conv2d / F.linear fp32 + the STE of functions/binary_connect.py:31-38 via autograd, "
                                              "same model, same GPU"},
@@ -760,7 +767,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             # BatchNorm, so the two losses agree to ~1e-3 only; on +-1 pixels the forward passes are identical (the parity test)
             "loss": loss_ours, "loss_reference_ops": loss_ref,
             "dense_library_calls_in_the_steps": lib_used,
-            "gradient_parity": "tests/test_gpu_r2.py::test_alexnet_training_step_matches_the_reference_op_sequence (<= 2e-5 normalised)"}
+            "gradient_parity": "tests/test_gpu_r3.py::test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence and "
+                               "::test_alexnet_training_step_with_the_fused_training_chain (<= 1e-5 normalised vs fp64 on the CPU)"}
         del mt, xt
     elif args.train_batch and world > 1:
         # data-parallel step, one process per GPU: per-GPU batch fixed (weak scaling), gradients averaged by the bucketed

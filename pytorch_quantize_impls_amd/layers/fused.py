@@ -567,6 +567,7 @@ class FusedTrainPoolBnSign(torch.nn.Module):
         bn = self.bn
         fast = (self.training and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 4)
                 and bn.momentum is not None and bn.track_running_stats and x.shape[0] * (x[0, 0].numel()) > 1
+                and x.shape[1] % 4 == 0
                 and (self.pool is None or x.dim() == 4))
         if not fast:
             h = self.pool(x) if self.pool is not None else x
