@@ -238,8 +238,8 @@ def main():
                    # un-tagged inputs of the layer-level legs (AlexNet / C4 / C5) are checked for +-1 on the device; "verify" =
                    # one 4-byte readback per un-tagged input per forward (functions/_fused.py); the C2 step itself packs
                    # through ops.* and asks nothing
-                   "detect_mode": _fused.DETECT_MODE, "deferred_activations": "sign chains on (lazy.ENABLED), DoReFa code "
-                   "chains opt-in (lazy.DEFER_CODES; the C4 legs that use it say so)"},
+                   "detect_mode": _fused.DETECT_MODE, "deferred_activations": "on (lazy.ENABLED, lazy.DEFER_CODES): bit-identical "
+                   "to the module-by-module graph on this device"},
         "roofline": roofline,
         "per_rank_ms_per_step": per_rank_ms,
         "dist": {"initialised": dist is not None, "backend": (dist.get_backend() if dist is not None else None),
@@ -657,17 +657,18 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         x4 = torch.randn((Bc, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
         st4 = _layer_stats(m4, x4)
         from pytorch_quantize_impls_amd import lazy
-        f4 = bench_models.FusedDorefaResNet18(m4)
+        f4 = bench_models.FusedDorefaResNet18(m4, fold="device")
 
         def eager4():
             with lazy.eager():
                 return m4(x4)
         def deferred4():
-            with lazy.codes_deferred():          # opt-in since round 3 (lazy.DEFER_CODES): the code epilogue's BatchNorm
-                return m4(x4)                    # arithmetic is the ATen-CPU fold, not this device's F.batch_norm
+            return m4(x4)
         with torch.no_grad():
             ye4 = eager4()
-            agree = float((f4(x4).argmax(1) == ye4.argmax(1)).float().mean())
+            yf4 = f4(x4)
+            agree = float((yf4.argmax(1) == ye4.argmax(1)).float().mean())
+            same_fused = bool(torch.equal(yf4, ye4))
             agree_d = float((deferred4().argmax(1) == ye4.argmax(1)).float().mean())
             same_default = bool(torch.equal(m4(x4), ye4))
         el_u = timed(eager4)
@@ -676,8 +677,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         # the deferred forward is ~1.7 ms of Python for < 1 ms of GPU work: replayed as a hipGraph (utils.graphed captures
         # the un-modified module; same kernels, no host work)
         from pytorch_quantize_impls_amd import utils
-        with lazy.codes_deferred():
-            g4 = utils.graphed(m4, x4)
+        g4 = utils.graphed(m4, x4)
         with torch.no_grad():
             same_g = bool(torch.equal(g4(x4), deferred4()))
         el_g = timed(lambda: g4(x4), 2 * iters)
@@ -687,15 +687,16 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "module_graph": _net_line("c4", Bc, world, 2 * iters, el_d, st4, 5000.0,
                                       "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                       {"argmax_agreement_with_unfused": agree_d,
-                                       "mode": "lazy.codes_deferred() (opt-in); the DEFAULT execution of the un-modified graph is "
-                                               "the 'unfused' leg", "default_equals_module_by_module": same_default}),
+                                       "same_logits_as_module_by_module": same_default,
+                                       "bn_arithmetic": "this device's eval-mode F.batch_norm, emulated and verified "
+                                                        "(layers.fused.device_bn_fold)"}),
             "module_graph_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_g, st4, 5000.0,
                                                "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                                {"same_logits_as_module_graph": same_g}),
             "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                  fp32_activations=True),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
-                               {"argmax_agreement_with_unfused": agree}),
+                               {"argmax_agreement_with_unfused": agree, "same_logits_as_module_by_module": same_fused}),
             "note": "launch / latency bound at 32 x 32 maps (SURVEY 8d): ~60 launches of 5-40 us each"}
     # ---- C5: ternary VGG-16, 3 x 224 x 224 (2048 over 8 GPUs = 256 per GPU)
     if args.c5_batch > 0:

@@ -155,18 +155,18 @@ class _FusedDorefaBlock(nn.Module):
     """Inference form of _DorefaBlock: activations between the DorefaConv2d layers exist only as int8 code planes
     (layers.FusedBnDorefaQuant folds BatchNorm + shortcut add + ReLU + quantiser into one pass per conv output)."""
 
-    def __init__(self, blk: _DorefaBlock, a_bits: int, fuse_conv: bool = True, halo: int = 1):
+    def __init__(self, blk: _DorefaBlock, a_bits: int, fuse_conv: bool = True, halo: int = 1, fold=None):
         super().__init__()
         from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant, FusedDorefaConvBnQuant
         self.fuse_conv = fuse_conv
         if fuse_conv:       # the whole tail in the conv epilogue: no fp32 conv output at all
             # every consumer is a 3x3 conv with padding 1 (or the 1x1 shortcut): planes carry a 1-pixel zero halo
-            self.c1 = FusedDorefaConvBnQuant(blk.conv1, blk.bn1, a_bits, out_halo=halo)
-            self.c2 = FusedDorefaConvBnQuant(blk.conv2, blk.bn2, a_bits, out_halo=halo)
+            self.c1 = FusedDorefaConvBnQuant(blk.conv1, blk.bn1, a_bits, out_halo=halo, fold=fold)
+            self.c2 = FusedDorefaConvBnQuant(blk.conv2, blk.bn2, a_bits, out_halo=halo, fold=fold)
         else:               # fp32 conv output + one fused elementwise pass
             self.conv1, self.conv2 = blk.conv1, blk.conv2
-            self.q1 = FusedBnDorefaQuant(blk.bn1, a_bits)
-            self.q2 = FusedBnDorefaQuant(blk.bn2, a_bits)
+            self.q1 = FusedBnDorefaQuant(blk.bn1, a_bits, fold=fold)
+            self.q2 = FusedBnDorefaQuant(blk.bn2, a_bits, fold=fold)
         self.sc_conv, self.sc_bn = (blk.shortcut[0], blk.shortcut[1]) if blk.shortcut is not None else (None, None)
 
     def forward(self, act):
@@ -179,13 +179,13 @@ class _FusedDorefaBlock(nn.Module):
 class FusedDorefaResNet18(nn.Module):
     """Inference form of an eval-mode DorefaResNet18 (shares its parameters)."""
 
-    def __init__(self, model: DorefaResNet18, a_bits: int = 4, fuse_conv: bool = True, halo: int = 1):
+    def __init__(self, model: DorefaResNet18, a_bits: int = 4, fuse_conv: bool = True, halo: int = 1, fold=None):
         super().__init__()
         from pytorch_quantize_impls_amd.layers import FusedBnDorefaQuant
         assert not model.training, "fuse an eval-mode model"
         self.stem, self.linear = model.stem, model.linear
-        self.q0 = FusedBnDorefaQuant(model.bn, a_bits, out_halo=halo if fuse_conv else 0)
-        self.blocks = nn.Sequential(*[_FusedDorefaBlock(b, a_bits, fuse_conv, halo) for b in model.blocks])
+        self.q0 = FusedBnDorefaQuant(model.bn, a_bits, out_halo=halo if fuse_conv else 0, fold=fold)
+        self.blocks = nn.Sequential(*[_FusedDorefaBlock(b, a_bits, fuse_conv, halo, fold) for b in model.blocks])
 
     def forward(self, x):
         out = self.blocks(self.q0(self.stem(x))).float()

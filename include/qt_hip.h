@@ -242,12 +242,16 @@ int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_b
  * relu == 2: ReLU BEFORE the BatchNorm instead (x = max(x, 0) first: the Linear -> ReLU -> BatchNorm -> quant order of
  * models/FullNet/DorefaMNIST.py:46-48), no ReLU after.
  * codes <- q as int8 (pad bytes of the 16-byte rows zero), y_f32 (may be NULL) <- fl(fl(1/(2^k-1)) * q).
- * *overflow is OR-ed with 1 if any |q| > 127 or NaN (code written as 0), as qt_dorefa_codes_i8. */
+ * *overflow is OR-ed with 1 if any |q| > 127 or NaN (code written as 0), as qt_dorefa_codes_i8.
+ * bn_stats != NULL (round 3, "device" BatchNorm arithmetic): bn_stats = [mean[C] | rs[C]], alpha = the BatchNorm weight,
+ * beta = its bias, and  t = fma(fl(fl(x - mean[c]) * rs[c]), weight[c], bias[c])  — bit for bit what eval-mode
+ * F.batch_norm evaluates on this device when rs is read back from its kernel (tools/probes/bn_eval_emulation.py); the un-modified
+ * module graph then equals its module-by-module execution exactly.  res_bn_stats: the same for the fp32 residual's BatchNorm. */
 int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
                               const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
                               const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
                               int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
-                              int32_t* overflow, qt_stream_t stream);
+                              int32_t* overflow, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream);
 
 /* MaxPool2d(pool_k, pool_s) (no padding, floor mode) on an NHWC int8 DoReFa code plane: the reference pools after the
  * quantiser (models/samples/AlexNet_Dorefa.py:38-41) and fl(inv_n * code) is monotone in the code, so the max over
@@ -572,7 +576,8 @@ int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, int64_t W, 
  * [N][H + 2*halo_h][W + 2*halo_w][C]: the zero padding of a conv that reads it is then physical and the conv runs
  * the un-padded kernels (no per-tap bounds checks).  in_halo_*: halo of P (needs ph <= in_halo_h, pw <= in_halo_w;
  * QT_ERR_UNSUPPORTED when the plane exceeds 4 GiB); out_halo_*: halo of `codes` — the launch writes
- * the interior pixels and the zero border (every byte of the plane); res_halo_*: halo of `res_codes`. */
+ * the interior pixels and the zero border (every byte of the plane); res_halo_*: halo of `res_codes`.
+ * bn_stats / res_bn_stats: the device BatchNorm arithmetic of qt_affine_dorefa_codes_i8 ([mean | rs], alpha / beta = weight / bias). */
 int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                              int64_t dw, const uint32_t* Wmat, int64_t ldw, const float* bias, float scale,
@@ -581,7 +586,7 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t N, int64_t H, 
                              int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
                              int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
                              int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
-                             int64_t res_halo_w, qt_stream_t stream);
+                             int64_t res_halo_w, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream);
 
 /* qt_conv2d_implicit reading a halo plane P [N][H + 2*halo_h][W + 2*halo_w][Cw] (see qt_conv2d_implicit_codes):
  * fp32 output as qt_conv2d_implicit.  ph <= halo_h, pw <= halo_w. */

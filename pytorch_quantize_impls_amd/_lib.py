@@ -90,7 +90,7 @@ SIGNATURES = {
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "qt_affine_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
-                                           _c_int, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
+                                           _c_int, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p]),
     "qt_weight_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_i8_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                             _c_i64, _c_i64, _c_p]),
@@ -116,7 +116,7 @@ SIGNATURES = {
     "qt_conv2d_implicit_codes": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
                                                                           _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
                                                                           _c_int, _c_int, _c_p, _c_i64, _c_i64, _c_p]
-                                 + [_c_i64] * 6 + [_c_p]),
+                                 + [_c_i64] * 6 + [_c_p, _c_p, _c_p]),
     "qt_conv2d_implicit_halo": (_c_int, [_c_int, _c_p] + [_c_i64] * 14 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64,
                                                                           _c_i64, _c_p]),
     "qt_conv2d_implicit_nib": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,

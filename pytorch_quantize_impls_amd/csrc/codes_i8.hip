@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
     const float* __restrict__ rf, int64_t ldr, const float* __restrict__ ralpha, const float* __restrict__ rbeta,
     const int8_t* __restrict__ rc, int64_t ldrc, float rscale, int relu, int8_t* __restrict__ codes, int64_t ldc,
     float* __restrict__ yf, int64_t ldy, int64_t rows, int64_t C, float n, float inv_n,
-    int32_t* __restrict__ overflow, int vec) {
+    int32_t* __restrict__ overflow, int vec, const float* __restrict__ bn_stats, const float* __restrict__ rbn_stats) {
     const int64_t slots_per_row = ldc / 4;
     const int64_t total = rows * slots_per_row;
     int bad = 0;
@@ -105,10 +105,15 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
             int q = 0;
             if (k0 + e < C) {
                 const float x0 = (relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];          // ReLU in front of the BatchNorm
-                float t = __fadd_rn(__fmul_rn(x0, alpha[k0 + e]), beta[k0 + e]);
+                // folded form: fl(fl(x * alpha) + beta).  Device form (bn_stats = [mean | rs], alpha = weight, beta = bias):
+                // fma(fl(fl(x - mean) * rs), weight, bias) — the expression this device's eval-mode F.batch_norm evaluates
+                float t = bn_stats ? __fmaf_rn(__fmul_rn(__fsub_rn(x0, bn_stats[k0 + e]), bn_stats[C + k0 + e]), alpha[k0 + e], beta[k0 + e])
+                                   : __fadd_rn(__fmul_rn(x0, alpha[k0 + e]), beta[k0 + e]);
                 if (rf) {
                     float u = r[e];
-                    if (ralpha) u = __fadd_rn(__fmul_rn(u, ralpha[k0 + e]), rbeta[k0 + e]);
+                    if (ralpha)
+                        u = rbn_stats ? __fmaf_rn(__fmul_rn(__fsub_rn(u, rbn_stats[k0 + e]), rbn_stats[C + k0 + e]), ralpha[k0 + e], rbeta[k0 + e])
+                                      : __fadd_rn(__fmul_rn(u, ralpha[k0 + e]), rbeta[k0 + e]);
                     t = __fadd_rn(t, u);
                 }
                 if (rc) t = __fadd_rn(t, __fmul_rn(rscale, (float)(int8_t)(rword >> (8 * e))));
@@ -137,11 +142,12 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
                               const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
                               const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
                               int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
-                              int32_t* overflow, qt_stream_t stream) {
+                              int32_t* overflow, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream) {
     if (rows < 0 || C < 0 || ldx < C || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (rows == 0) return QT_OK;
     if (!codes || !overflow || !alpha || !beta || (!x && C > 0) || (y_f32 && ldy < C)) return QT_ERR_INVALID_ARG;
     if ((res_f32 && ldr < C) || (!res_alpha != !res_beta) || (res_alpha && !res_f32)) return QT_ERR_INVALID_ARG;
+    if (res_bn_stats && !res_alpha) return QT_ERR_INVALID_ARG;
     if (ldc_bytes < C || (ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
     if (res_codes && (ldrc_bytes < ((C + 3) & ~(int64_t)3) || (ldrc_bytes & 3) || ((uintptr_t)res_codes & 3)))
         return QT_ERR_ALIGNMENT;
@@ -151,7 +157,7 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
     const int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
     hipLaunchKernelGGL(affine_codes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, beta,
                        res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes, ldc_bytes,
-                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec);
+                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec, bn_stats, res_bn_stats);
     return qt_check_launch();
 }
 

@@ -113,6 +113,10 @@ struct EpiArgs {
     // ops.integer_thresholds).  One compare per accumulator register instead of add + multiply + compare — the
     // "BatchNorm + sign collapses to a per-channel integer threshold on the popcount" of SURVEY 8f n1.
     const float* thr = nullptr;
+    // code epilogue with the DEVICE's BatchNorm arithmetic: bn_stats = [mean | rs] (alpha / beta then hold weight / bias):
+    //   t = fma(fl(fl(x - mean) * rs), weight, bias)      what eval-mode F.batch_norm evaluates on this device; rbn_stats: residual's
+    const float* bn_stats = nullptr;
+    const float* rbn_stats = nullptr;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
 
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             const int nb = n0 + (wave_n * C::TNW + b) * 32;
             const float bv = (bias && nb + lrow < N) ? bias[nb + lrow] : 0.0f;
             const int n = nb + (lane & 7) * 4;
-            float al[4], be[4], ral[4], rbe[4];
+            float al[4], be[4], ral[4], rbe[4], mu[4], rs[4], rmu[4], rrs[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool in = n + e < N;
@@ -692,6 +696,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 be[e] = in ? epi.beta[n + e] : 0.0f;
                 ral[e] = (in && epi.ralpha) ? epi.ralpha[n + e] : 1.0f;
                 rbe[e] = (in && epi.ralpha) ? epi.rbeta[n + e] : 0.0f;
+                mu[e] = (in && epi.bn_stats) ? epi.bn_stats[n + e] : 0.0f;
+                rs[e] = (in && epi.bn_stats) ? epi.bn_stats[N + n + e] : 1.0f;
+                rmu[e] = (in && epi.rbn_stats) ? epi.rbn_stats[n + e] : 0.0f;
+                rrs[e] = (in && epi.rbn_stats) ? epi.rbn_stats[N + n + e] : 1.0f;
             }
 #pragma unroll
             for (int a = 0; a < C::TMW; ++a) {
@@ -730,8 +738,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             int q = 0;
                             if (n + e < N) {
                                 const float x0 = (epi.relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];   // ReLU before the BatchNorm
-                                float t = x0 * al[e] + be[e];            // two roundings (-ffp-contract=off)
-                                if (epi.res_f32) t = t + (epi.ralpha ? u[e] * ral[e] + rbe[e] : u[e]);
+                                // folded: two roundings (-ffp-contract=off); device form: fma(fl(fl(x - mean) * rs), weight, bias)
+                                float t = epi.bn_stats ? __builtin_fmaf((x0 - mu[e]) * rs[e], al[e], be[e]) : x0 * al[e] + be[e];
+                                if (epi.res_f32)
+                                    t = t + (epi.ralpha ? (epi.rbn_stats ? __builtin_fmaf((u[e] - rmu[e]) * rrs[e], ral[e], rbe[e])
+                                                                          : u[e] * ral[e] + rbe[e])
+                                                        : u[e]);
                                 if (epi.res_codes) t = t + epi.rscale * (float)(int8_t)(rword >> (8 * e));
                                 if (epi.relu == 1) t = t < 0.0f ? 0.0f : t;
                                 const float qf = rintf(epi.levels * t);
@@ -1556,7 +1568,8 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
                              int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
                              int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
                              int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
-                             int64_t res_halo_w, qt_stream_t stream) {
+                             int64_t res_halo_w, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream) {
+    if (res_bn_stats && !res_alpha) return QT_ERR_INVALID_ARG;
     if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (out_halo_h < 0 || out_halo_w < 0 || res_halo_h < 0 || res_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64 ||
         res_halo_h > 64 || res_halo_w > 64 || ((res_halo_h | res_halo_w) && !res_codes))
@@ -1584,6 +1597,8 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
     epi.ohx = (int)out_halo_w;
     epi.rhy = (int)res_halo_h;
     epi.rhx = (int)res_halo_w;
+    epi.bn_stats = bn_stats;
+    epi.rbn_stats = res_bn_stats;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi, in_halo_h,
                               in_halo_w);

@@ -102,6 +102,45 @@ def device_sign_fold(bn, like_shape, channels_last: bool):
     return alpha.contiguous(), beta.contiguous()
 
 
+def device_bn_fold(bn, like_shape, channels_last: bool):
+    """(weight, bias, stats) with stats = fp32 [mean | rs] such that, for every fp32 x of channel c,
+
+        fma(fl(fl(x - mean_c) * rs_c), weight_c, bias_c)  ==  F.batch_norm(x)_c      bit for bit on THIS device
+
+    rs is read back from the device's own eval-mode kernel (F.batch_norm(1, mean 0, running_var, weight 1, bias 0) = rs):
+    the library's reciprocal square root is not the correctly rounded one (tools/probes/bn_eval_emulation.py: 100 % bit
+    agreement with the read-back value, 91-94 % with torch.rsqrt).  The emulation is VERIFIED against F.batch_norm on a
+    probe (512 values per channel around and far from zero, same rank / memory format as the real tensor); a mismatch —
+    another library version, another kernel family — raises ValueError, which sends a deferred chain to its eager path."""
+    import torch.nn.functional as F
+    rm, rv = bn.running_mean.detach(), bn.running_var.detach()
+    C, dev = int(rm.numel()), rm.device
+    one, zero = torch.ones((C,), dtype=torch.float32, device=dev), torch.zeros((C,), dtype=torch.float32, device=dev)
+    w = bn.weight.detach().float() if bn.affine else one
+    b = bn.bias.detach().float() if bn.affine else zero
+    if len(like_shape) != 4:
+        raise ValueError("the device BatchNorm arithmetic is probed for 4-D activations")
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    n_, h_, w_ = max(1, min(2, int(like_shape[0]))), max(1, min(2, int(like_shape[2]))), max(1, min(2, int(like_shape[3])))
+    with torch.no_grad():
+        ones = torch.ones((n_, C, h_, w_), dtype=torch.float32, device=dev).contiguous(memory_format=fmt)
+        rs = F.batch_norm(ones, zero, rv, one, zero, False, 0.0, bn.eps)[0, :, 0, 0].contiguous()
+        g = torch.Generator(device=dev).manual_seed(1234)
+        probe = torch.randn((8, C, 8, 8), generator=g, device=dev) * (torch.sqrt(rv + bn.eps) * 3).view(1, C, 1, 1) + rm.view(1, C, 1, 1)
+        probe[:, :, ::2] *= 17.0
+        probe = probe.contiguous(memory_format=fmt)
+        want = F.batch_norm(probe, rm, rv, w if bn.affine else None, b if bn.affine else None, False, 0.0, bn.eps)
+        # the fma formed in fp64 from the fp32 intermediate: the product of two fp32 values is exact in fp64, so rounding the
+        # fp64 sum to fp32 once is the fused multiply-add (up to double rounding, which the equality below would expose)
+        t32 = ((probe - rm.view(1, C, 1, 1)) * rs.view(1, C, 1, 1))
+        got = (t32.double() * w.double().view(1, C, 1, 1) + b.double().view(1, C, 1, 1)).float()
+        if not torch.equal(got, want):
+            raise ValueError("eval-mode F.batch_norm of this device is not fma((x - mean) * rs, weight, bias): "
+                             f"{int((got != want).sum())} of {want.numel()} probe values differ")
+    stats = torch.cat([rm.float(), rs]).contiguous()
+    return w.contiguous(), b.contiguous(), stats
+
+
 def _out_channels_last(x) -> bool:
     """Memory format of the fp32 tensor a quantised conv returns for input ``x`` (functions/_fused.py: NCHW-contiguous
     tensors get NCHW storage back, everything else — channels-last tensors, packed activations — NHWC storage)."""
@@ -130,6 +169,20 @@ def _folded_for(owner, attr, bn, device=None, fold="reference", like=None):
     cur = getattr(owner, attr, None)
     if cur is None or cur[0] != key or (device is not None and cur[1][0].device != device):
         cur = (key, device_sign_fold(bn, *like) if fold == "device" else fold_batchnorm(bn))
+        setattr(owner, attr, cur)
+    return cur[1]
+
+
+def _code_fold_for(owner, attr, bn, fold, like):
+    """BatchNorm parameters of a DoReFa code epilogue, cached like ``_folded_for``: (alpha, beta) of the ATen-CPU fold
+    ("reference") or (weight, bias, [mean | rs]) of this device's own arithmetic ("device": ``device_bn_fold``)."""
+    if fold != "device":
+        return _folded_for(owner, attr, bn)
+    shape, cl = like
+    key = _bn_key(bn) + (("codes", len(shape), bool(cl)),)
+    cur = getattr(owner, attr, None)
+    if cur is None or cur[0] != key:
+        cur = (key, device_bn_fold(bn, shape, cl))
         setattr(owner, attr, cur)
     return cur[1]
 
@@ -198,10 +251,11 @@ class FusedBnDorefaQuant(torch.nn.Module):
     (oracle.affine_relu_dorefa_codes).  The quantiser is unclamped like the reference's, so codes may leave int8:
     the kernel raises a device flag shared along the chain and ``CodeActivation.check()/float()`` raises."""
 
-    def __init__(self, bn, bit_width: int, relu=True, out_halo=0):
+    def __init__(self, bn, bit_width: int, relu=True, out_halo=0, fold=None):
         super().__init__()
         if not 2 <= int(bit_width) <= 8:
             raise ValueError("code planes exist for 2 <= bit_width <= 8")
+        self.fold = fold or DEFAULT_FOLD
         self.bn, self.bit_width, self.relu = bn, int(bit_width), ops.relu_mode(relu)
         # out_halo: zero border for the consuming conv's padding (see FusedDorefaConvBnQuant); made here by one
         # qt_pad_pixel_plane pass over the code plane
@@ -215,8 +269,10 @@ class FusedBnDorefaQuant(torch.nn.Module):
     def forward(self, x, residual=None, residual_bn=None):
         if self.bn.training:
             raise RuntimeError("FusedBnDorefaQuant folds running statistics: call .eval() first")
-        alpha, beta = _folded_for(self, "_folded", self.bn)
         x, residual = lazy.resolve(x), lazy.resolve(residual)
+        like = (tuple(x.shape), x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)) if self.fold == "device" else None
+        folded = _code_fold_for(self, "_folded", self.bn, self.fold, like)
+        alpha, beta, stats = folded[0], folded[1], (folded[2] if len(folded) > 2 else None)
         if x.dim() == 4:
             N, C, H, W = x.shape
             x2 = x.permute(0, 2, 3, 1)
@@ -240,10 +296,13 @@ class FusedBnDorefaQuant(torch.nn.Module):
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(x2.shape)
             if residual_bn is not None:
-                res_affine = _folded_for(self, "_folded_res", residual_bn)
+                rlike = (tuple(residual.shape), residual.dim() == 4 and residual.is_contiguous(memory_format=torch.channels_last)) \
+                    if self.fold == "device" else None
+                res_affine = _code_fold_for(self, "_folded_res", residual_bn, self.fold, rlike)
         codes, _ = ops.affine_dorefa_codes(x2, alpha, beta, self.bit_width, self.relu, res_f32, res_affine, res_codes,
                                            overflow=flag,
-                                           ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None)
+                                           ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None,
+                                           bn_stats=stats)
         if x.dim() == 4 and any(self.out_halo):
             N, C, H, W = x.shape
             hy, hx = self.out_halo
@@ -262,10 +321,11 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
 
     forward(act, residual=None, residual_bn=None): residual over the conv's OUTPUT pixels, as FusedBnDorefaQuant."""
 
-    def __init__(self, conv, bn, bit_width: int, relu=True, out_halo=0):
+    def __init__(self, conv, bn, bit_width: int, relu=True, out_halo=0, fold=None):
         super().__init__()
         if getattr(conv, "bit_width", None) != 1 or conv.groups != 1 or conv.padding_mode != "zeros":
             raise ValueError("FusedDorefaConvBnQuant takes an un-grouped, zero-padded DorefaConv2d(bit_width=1)")
+        self.fold = fold or DEFAULT_FOLD
         self.conv, self.bn, self.bit_width, self.relu = conv, bn, int(bit_width), ops.relu_mode(relu)
         # out_halo = the padding of the conv(s) that consume this activation: the epilogue writes into a plane with
         # that zero border, so they run the un-padded kernels (a residual CodeActivation may carry any halo)
@@ -281,15 +341,22 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
             raise RuntimeError("FusedDorefaConvBnQuant is an inference form: call .eval() first")
         if not isinstance(act, packed.CodeActivation):
             raise TypeError("FusedDorefaConvBnQuant consumes a CodeActivation (FusedBnDorefaQuant output)")
-        alpha, beta = _folded_for(self, "_folded", self.bn)
-        epi = ops.CodeEpilogue(alpha, beta, self.bit_width, self.relu, out_halo=self.out_halo)
+        # the tensor the module graph hands to F.batch_norm is this conv's fp32 output: channels-last for a code-plane input
+        N_, _, H_, W_ = act.shape
+        Ho_, Wo_ = ops.conv_out_hw(H_, W_, conv.kernel_size[0], conv.kernel_size[1], conv.stride, conv.padding, conv.dilation)
+        like = ((N_, conv.out_channels, Ho_, Wo_), True) if self.fold == "device" else None
+        folded = _code_fold_for(self, "_folded", self.bn, self.fold, like)
+        epi = ops.CodeEpilogue(folded[0], folded[1], self.bit_width, self.relu, out_halo=self.out_halo,
+                               bn_stats=folded[2] if len(folded) > 2 else None)
         if isinstance(residual, packed.CodeActivation):
             epi.res_codes, epi.res_halo = residual.codes, residual.halo
         elif residual is not None:
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
             if residual_bn is not None:
-                epi.res_affine = _folded_for(self, "_folded_res", residual_bn)
+                rlike = (tuple(residual.shape), residual.dim() == 4 and residual.is_contiguous(memory_format=torch.channels_last)) \
+                    if self.fold == "device" else None
+                epi.res_affine = _code_fold_for(self, "_folded_res", residual_bn, self.fold, rlike)
         from ..functions import _fused
         wc = conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(conv.weight.detach()), key="conv_i8")
         E = conv._eval_planes(lambda w2: w2.abs().amax(), key="E")

@@ -27,7 +27,8 @@ is pulled by the consumer:
 Exactness: the fused sign chain takes its per-channel thresholds from this device's own ``F.batch_norm`` (bisection over
 the fp32 bit patterns, ``layers.fused.device_sign_fold``), so the bits — and everything computed from them — equal the
 module-by-module graph's exactly (tests assert ``torch.equal`` against ``lazy.eager()``).  The DoReFa code chain cannot be
-reduced to thresholds (a residual is added before the quantiser) and is therefore opt-in (``DEFER_CODES``).
+reduced to thresholds (a residual is added before the quantiser): its epilogue evaluates BatchNorm in this device's own
+arithmetic instead, verified on a probe (``layers.fused.device_bn_fold``).
 
 Nothing is deferred in training mode, with autograd enabled, on CPU tensors, for non-fp32 dtypes, grouped convs or
 non-zero padding modes.  ``lazy.ENABLED = False`` (or the ``eager()`` context manager) switches the mechanism off;
@@ -49,13 +50,13 @@ from . import ops, packed
 
 #: master switch (module-by-module execution when False)
 ENABLED = True
-#: DoReFa chains (DorefaConv2d -> BatchNorm -> [+ shortcut] -> ReLU -> nnDorefaQuant) are deferred only on request: the
-#: code epilogue needs BatchNorm's VALUE, not just its sign, and evaluates the ATen-CPU fold fl(fl(x*alpha)+beta) while
-#: this device's F.batch_norm evaluates fma((x-mean)*rsqrt(var+eps), weight, bias) (tools/probes/bn_eval_arith.py), so
-#: a code can differ by one level from the module-by-module graph where n*t sits within an ulp of a rounding boundary.
-#: The sign chains above do not have that problem (layers.fused fold="device": thresholds bisected on the device's own
-#: F.batch_norm — bit-identical to the eager graph), so they stay on by default.
-DEFER_CODES = False
+#: DoReFa chains (DorefaConv2d -> BatchNorm -> [+ shortcut] -> ReLU -> nnDorefaQuant) need BatchNorm's VALUE, not just its
+#: sign.  Their fused blocks therefore evaluate BatchNorm exactly as this device's eval-mode F.batch_norm does —
+#: fma(fl(fl(x - mean) * rs), weight, bias) with rs read back from the library's own kernel — and verify that emulation against
+#: F.batch_norm on a probe when a block is built (layers.fused.device_bn_fold; a mismatch sends the chain to its eager path).
+#: The codes then equal the module-by-module graph's bit for bit (tests/test_gpu_lazy.py: torch.equal).  False: DoReFa
+#: convs are never deferred.
+DEFER_CODES = True
 #: "deferred" convs that returned a LazyActivation, "fused" chains executed as fused blocks, "materialised" lazies that
 #: had to produce their fp32 value, "fallback:<func>" the functions that forced it
 STATS = collections.Counter()
@@ -348,7 +349,7 @@ def _code_block(layer, bn, bit_width, relu, halo):
         per = _BLOCKS[layer] = collections.OrderedDict()
     blk = per.get(key)
     if blk is None:
-        blk = fused.FusedDorefaConvBnQuant(layer, _BnView(rm, rv, w, b, eps), bit_width, relu=relu, out_halo=halo)
+        blk = fused.FusedDorefaConvBnQuant(layer, _BnView(rm, rv, w, b, eps), bit_width, relu=relu, out_halo=halo, fold="device")
         per[key] = blk
         while len(per) > _MAX_BLOCKS_PER_LAYER:
             per.popitem(last=False)

@@ -60,6 +60,9 @@ class CodeEpilogue:
     res_codes: Optional["CodePlanes"] = None
     overflow: Optional[torch.Tensor] = None
     out_halo: tuple = (0, 0)        # zero border (pixels) of the produced plane: [N][Ho + 2hy][Wo + 2hx][ld]
+    # "device" BatchNorm arithmetic (layers.fused.device_bn_fold): bn_stats = fp32 [mean | rs] (2 C values), alpha / beta then
+    # hold the BatchNorm weight / bias; a 3-tuple res_affine = (weight, bias, stats) does the same for the residual's BatchNorm
+    bn_stats: Optional[torch.Tensor] = None
     res_halo: tuple = (0, 0)        # halo of the residual code plane
 
 
@@ -127,7 +130,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
         if not 2 <= int(epi.bit_width) <= 8:
             raise ValueError("int8 code planes exist for 2 <= bit_width <= 8")
-        rf, ra, rb, rc, ldr, ldrc, rscale = None, None, None, None, 0, 0, 0.0
+        rf, ra, rb, rc, ldr, ldrc, rscale, rstats = None, None, None, None, 0, 0, 0.0, None
         if epi.res_f32 is not None:
             rf = _require(epi.res_f32, "residual")
             if tuple(rf.shape) != (M, Cout) or (Cout > 1 and rf.stride(1) != 1):
@@ -135,8 +138,17 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
             ldr = rf.stride(0) if M > 1 else max(Cout, 1)
             if epi.res_affine is not None:
                 ra, rb = _check_bias(epi.res_affine[0], Cout, dev), _check_bias(epi.res_affine[1], Cout, dev)
+                if len(epi.res_affine) > 2 and epi.res_affine[2] is not None:
+                    rstats = _require(epi.res_affine[2], "res_bn_stats").contiguous()
+                    if rstats.numel() != 2 * Cout:
+                        raise ValueError("res_bn_stats must hold [mean | rs] of the residual's BatchNorm")
         elif epi.res_affine is not None:
             raise ValueError("res_affine needs res_f32")
+        stats = None
+        if epi.bn_stats is not None:
+            stats = _require(epi.bn_stats, "bn_stats").contiguous()
+            if stats.numel() != 2 * Cout:
+                raise ValueError("bn_stats must hold [mean | rs]: 2 * Cout values")
         ohy, ohx = (int(v) for v in epi.out_halo)
         rhy, rhx = (int(v) for v in epi.res_halo)
         Mo = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
@@ -153,7 +165,7 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
             _lib.call("qt_conv2d_implicit_codes", *head, _p(alpha), _p(beta), _p(rf), I(ldr), _p(ra), _p(rb), _p(rc),
                       I(ldrc), float(rscale), relu_mode(epi.relu),
                       int(int(epi.bit_width)), _p(codes), I(ldc), I(Cout), _p(flag), I(hy), I(hx), I(ohy),
-                      I(ohx), I(rhy), I(rhx), _stream(dev))
+                      I(ohx), I(rhy), I(rhx), _p(stats), _p(rstats), _stream(dev))
         inv_n = inv_levels(epi.bit_width)
         return CodePlanes(codes=codes, rows=Mo, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
     if isinstance(epi, NibEpilogue):
@@ -817,12 +829,14 @@ def dorefa_codes(x: torch.Tensor, bit_width: int, want_f32: bool = True, ld_byte
 def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, bit_width: int, relu: bool = True,
                         res_f32: Optional[torch.Tensor] = None, res_affine=None,
                         res_codes: Optional[CodePlanes] = None, want_f32: bool = False,
-                        overflow: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None):
+                        overflow: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None,
+                        bn_stats: Optional[torch.Tensor] = None):
     """Fused eval BatchNorm (folded alpha, beta) [+ residual] [-> ReLU] -> k-bit DoReFa quantiser over a
     [rows, C] fp32 matrix (a conv output viewed as pixels x channels): returns (CodePlanes, fp32 image or None).
     ``res_f32``: fp32 [rows, C] residual, optionally with its own folded BatchNorm ``res_affine`` = (alpha, beta);
     ``res_codes``: residual held as DoReFa codes (value inv_n * code).  ``overflow``: device int32 flag to OR into
-    (a fresh one is made when None)."""
+    (a fresh one is made when None).  ``bn_stats`` = [mean | rs]: the device's BatchNorm arithmetic with alpha / beta =
+    weight / bias (qt_affine_dorefa_codes_i8); a 3-tuple ``res_affine`` = (weight, bias, stats) likewise for the residual."""
     _require(x2, "input")
     if x2.dim() != 2 or x2.dtype != torch.float32 or (x2.shape[1] > 1 and x2.stride(1) != 1):
         raise ValueError("affine_dorefa_codes takes a [rows, C] fp32 matrix with unit channel stride")
@@ -831,7 +845,7 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
     rows, C = int(x2.shape[0]), int(x2.shape[1])
     dev = x2.device
     alpha, beta = _check_bias(alpha, C, dev), _check_bias(beta, C, dev)
-    ra = rb = None
+    ra = rb = rstats = None
     ldr = 0
     if res_f32 is not None:
         if tuple(res_f32.shape) != (rows, C) or res_f32.dtype != torch.float32 or (C > 1 and res_f32.stride(1) != 1):
@@ -839,8 +853,16 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
         ldr = res_f32.stride(0) if rows > 1 else max(C, 1)
         if res_affine is not None:
             ra, rb = _check_bias(res_affine[0], C, dev), _check_bias(res_affine[1], C, dev)
+            if len(res_affine) > 2 and res_affine[2] is not None:
+                rstats = _require(res_affine[2], "res_bn_stats").contiguous()
+                if rstats.numel() != 2 * C:
+                    raise ValueError("res_bn_stats must hold [mean | rs] of the residual's BatchNorm")
     elif res_affine is not None:
         raise ValueError("res_affine needs res_f32")
+    if bn_stats is not None:
+        bn_stats = _require(bn_stats, "bn_stats").contiguous()
+        if bn_stats.numel() != 2 * C:
+            raise ValueError("bn_stats must hold [mean | rs]: 2 * C values")
     rscale, ldrc = 0.0, 0
     if res_codes is not None:
         if res_codes.rows != rows or res_codes.K != C:
@@ -855,7 +877,7 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
         _lib.call("qt_affine_dorefa_codes_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
                   _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
                   float(rscale), relu_mode(relu), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
-                  int(int(bit_width)), _p(flag), _stream(dev))
+                  int(int(bit_width)), _p(flag), _p(bn_stats), _p(rstats), _stream(dev))
     inv_n = inv_levels(bit_width)
     return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
 
