@@ -247,6 +247,12 @@ int qt_dorefa_codes_i8(const float* x, int64_t ldx, int8_t* codes, int64_t ldc_b
  * beta = its bias, and  t = fma(fl(fl(x - mean[c]) * rs[c]), weight[c], bias[c])  — bit for bit what eval-mode
  * F.batch_norm evaluates on this device when rs is read back from its kernel (tools/probes/bn_eval_emulation.py); the un-modified
  * module graph then equals its module-by-module execution exactly.  res_bn_stats: the same for the fp32 residual's BatchNorm. */
+/* Eval-mode BatchNorm of an fp32 [rows][C] matrix in the device's arithmetic (bn_stats = [mean | rs], see above):
+ * y = fma(fl(fl(x - mean[c]) * rs[c]), weight[c], bias[c]) — replaces F.batch_norm on the conv -> BatchNorm shortcut branch of
+ * models/samples/ResNet_Dorefa.py when the block runs fused.  C % 4 == 0, 16-byte aligned rows. */
+int qt_bn_eval_device_f32(const float* x, int64_t ldx, const float* weight, const float* bias, const float* bn_stats, float* y,
+                          int64_t ldy, int64_t rows, int64_t C, qt_stream_t stream);
+
 int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
                               const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
                               const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,

@@ -114,9 +114,9 @@ struct EpiArgs {
     // "BatchNorm + sign collapses to a per-channel integer threshold on the popcount" of SURVEY 8f n1.
     const float* thr = nullptr;
     // code epilogue with the DEVICE's BatchNorm arithmetic: bn_stats = [mean | rs] (alpha / beta then hold weight / bias):
-    //   t = fma(fl(fl(x - mean) * rs), weight, bias)      what eval-mode F.batch_norm evaluates on this device; rbn_stats: residual's
+    //   t = fma(fl(fl(x - mean) * rs), weight, bias)      what eval-mode F.batch_norm evaluates on this device (an fp32 residual
+    //   that has its own BatchNorm arrives already normalised: the caller applies F.batch_norm itself)
     const float* bn_stats = nullptr;
-    const float* rbn_stats = nullptr;
     unsigned long long magic_hw = 0, magic_w = 0;   // ceil(2^64 / (Ho*Wo)), ceil(2^64 / Wo) (0: divisor 1)
 };
 
@@ -247,7 +247,10 @@ struct GemmCfg {
                   "DMA pieces divide evenly over the waves (asm-DMA pipelines: W pieces may wrap)");
 };
 
-template <class C>
+// DEVBN: the code epilogue in the device's BatchNorm arithmetic (EpiArgs::bn_stats) — a separate instantiation (int8 conv
+// configurations only) so that the folded-form kernels keep their register budget: with both forms in one kernel the 16 extra
+// per-channel registers pushed the 3-workgroups-per-CU tiles from 16 to 88 B of scratch per lane (fused C4 0.78 -> 1.1 ms).
+template <class C, bool DEVBN = false>
 __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kernel(
     const uint32_t* __restrict__ X, int64_t ldx, const uint32_t* __restrict__ W, int64_t ldw,
     const float* __restrict__ bias, float scale, const float* __restrict__ scale_dev,
@@ -688,18 +691,21 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             const int nb = n0 + (wave_n * C::TNW + b) * 32;
             const float bv = (bias && nb + lrow < N) ? bias[nb + lrow] : 0.0f;
             const int n = nb + (lane & 7) * 4;
-            float al[4], be[4], ral[4], rbe[4], mu[4], rs[4], rmu[4], rrs[4];
+            // per-channel epilogue constants of the lane's 4 channels, hoisted out of the row loops: folded form (alpha, beta,
+            // residual alpha / beta), device form (weight, bias, mean, rs) — 16 registers either way
+            float al[4], be[4], ral[4], rbe[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool in = n + e < N;
                 al[e] = in ? epi.alpha[n + e] : 0.0f;
                 be[e] = in ? epi.beta[n + e] : 0.0f;
-                ral[e] = (in && epi.ralpha) ? epi.ralpha[n + e] : 1.0f;
-                rbe[e] = (in && epi.ralpha) ? epi.rbeta[n + e] : 0.0f;
-                mu[e] = (in && epi.bn_stats) ? epi.bn_stats[n + e] : 0.0f;
-                rs[e] = (in && epi.bn_stats) ? epi.bn_stats[N + n + e] : 1.0f;
-                rmu[e] = (in && epi.rbn_stats) ? epi.rbn_stats[n + e] : 0.0f;
-                rrs[e] = (in && epi.rbn_stats) ? epi.rbn_stats[N + n + e] : 1.0f;
+                if constexpr (DEVBN) {      // ral = mean, rbe = rs
+                    ral[e] = in ? epi.bn_stats[n + e] : 0.0f;
+                    rbe[e] = in ? epi.bn_stats[N + n + e] : 1.0f;
+                } else {
+                    ral[e] = (in && epi.ralpha) ? epi.ralpha[n + e] : 1.0f;
+                    rbe[e] = (in && epi.ralpha) ? epi.rbeta[n + e] : 0.0f;
+                }
             }
 #pragma unroll
             for (int a = 0; a < C::TMW; ++a) {
@@ -739,11 +745,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             if (n + e < N) {
                                 const float x0 = (epi.relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];   // ReLU before the BatchNorm
                                 // folded: two roundings (-ffp-contract=off); device form: fma(fl(fl(x - mean) * rs), weight, bias)
-                                float t = epi.bn_stats ? __builtin_fmaf((x0 - mu[e]) * rs[e], al[e], be[e]) : x0 * al[e] + be[e];
-                                if (epi.res_f32)
-                                    t = t + (epi.ralpha ? (epi.rbn_stats ? __builtin_fmaf((u[e] - rmu[e]) * rrs[e], ral[e], rbe[e])
-                                                                          : u[e] * ral[e] + rbe[e])
-                                                        : u[e]);
+                                float t;
+                                if constexpr (DEVBN) t = __builtin_fmaf((x0 - ral[e]) * rbe[e], al[e], be[e]);
+                                else t = x0 * al[e] + be[e];
+                                if (epi.res_f32) t = t + ((!DEVBN && epi.ralpha) ? u[e] * ral[e] + rbe[e] : u[e]);
                                 if (epi.res_codes) t = t + epi.rscale * (float)(int8_t)(rword >> (8 * e));
                                 if (epi.relu == 1) t = t < 0.0f ? 0.0f : t;
                                 const float qf = rintf(epi.levels * t);
@@ -945,6 +950,16 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
     const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0);
     if (lds_bytes > 160 * 1024) return QT_ERR_UNSUPPORTED;
+    if constexpr (C::E::CODE_EPI && C::CONV) {
+        if (epi.mode == 2 && epi.bn_stats) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+                return QT_ERR_LAUNCH;
+            hipLaunchKernelGGL((mfma_gemm_kernel<C, true>), dim3(grid, 1), dim3(C::NTHREADS), lds_bytes, (hipStream_t)stream, Xn,
+                               ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy, (int)M, (int)N, (int)K, cg, epi);
+            return qt_check_launch();
+        }
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
         return QT_ERR_LAUNCH;
@@ -1569,7 +1584,7 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
                              int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t in_halo_h,
                              int64_t in_halo_w, int64_t out_halo_h, int64_t out_halo_w, int64_t res_halo_h,
                              int64_t res_halo_w, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream) {
-    if (res_bn_stats && !res_alpha) return QT_ERR_INVALID_ARG;
+    if (res_bn_stats || (bn_stats && res_alpha)) return QT_ERR_UNSUPPORTED;   // device form: the residual arrives normalised
     if (!alpha || !beta || !overflow || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (out_halo_h < 0 || out_halo_w < 0 || res_halo_h < 0 || res_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64 ||
         res_halo_h > 64 || res_halo_w > 64 || ((res_halo_h | res_halo_w) && !res_codes))
@@ -1598,7 +1613,6 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
     epi.rhy = (int)res_halo_h;
     epi.rhx = (int)res_halo_w;
     epi.bn_stats = bn_stats;
-    epi.rbn_stats = res_bn_stats;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi, in_halo_h,
                               in_halo_w);

@@ -353,10 +353,23 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
         elif residual is not None:
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
-            if residual_bn is not None:
-                rlike = (tuple(residual.shape), residual.dim() == 4 and residual.is_contiguous(memory_format=torch.channels_last)) \
-                    if self.fold == "device" else None
-                epi.res_affine = _code_fold_for(self, "_folded_res", residual_bn, self.fold, rlike)
+            if residual_bn is not None and self.fold == "device":
+                # device arithmetic: the shortcut's BatchNorm runs as its own elementwise pass in the same (verified) expression;
+                # the conv epilogue then adds a plain fp32 residual and carries no second set of per-channel registers
+                rlike = (tuple(residual.shape), residual.dim() == 4 and residual.is_contiguous(memory_format=torch.channels_last))
+                rw, rb, rstats = _code_fold_for(self, "_folded_res", residual_bn, "device", rlike)
+                r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
+                r2 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
+                if r2.shape[1] % 4 == 0:
+                    epi.res_f32 = ops.bn_eval_device(r2, rw, rb, rstats)
+                else:
+                    rb_ = residual_bn
+                    rn = torch.nn.functional.batch_norm(residual, rb_.running_mean, rb_.running_var, rb_.weight if rb_.affine else None,
+                                                        rb_.bias if rb_.affine else None, False, 0.0, rb_.eps)
+                    rn = rn.permute(0, 2, 3, 1) if rn.dim() == 4 else rn
+                    epi.res_f32 = (rn if rn.is_contiguous() else rn.contiguous()).view(-1, rn.shape[-1])
+            elif residual_bn is not None:
+                epi.res_affine = _folded_for(self, "_folded_res", residual_bn)
         from ..functions import _fused
         wc = conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(conv.weight.detach()), key="conv_i8")
         E = conv._eval_planes(lambda w2: w2.abs().amax(), key="E")

@@ -882,6 +882,20 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
     return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
 
 
+def bn_eval_device(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, bn_stats: torch.Tensor) -> torch.Tensor:
+    """Eval-mode BatchNorm of an fp32 [rows, C] matrix in the device's arithmetic (qt_bn_eval_device_f32; layers.fused.device_bn_fold
+    supplies weight, bias and bn_stats = [mean | rs] and verifies the expression against F.batch_norm)."""
+    _require(x2, "input")
+    rows, C = int(x2.shape[0]), int(x2.shape[1])
+    if x2.dim() != 2 or (C > 1 and x2.stride(1) != 1):
+        raise ValueError("bn_eval_device takes a [rows, C] fp32 matrix with unit channel stride")
+    y = torch.empty((rows, C), dtype=torch.float32, device=x2.device)
+    with _on(x2.device):
+        _lib.call("qt_bn_eval_device_f32", _p(x2), int(x2.stride(0) if rows > 1 else max(C, 1)), _p(_require(weight, "weight")),
+                  _p(_require(bias, "bias")), _p(_require(bn_stats, "bn_stats")), _p(y), int(C), int(rows), int(C), _stream(x2.device))
+    return y
+
+
 def pool_codes(codes: CodePlanes, N: int, H: int, W: int, pool_k: int, pool_s: int, out_halo=(0, 0)) -> CodePlanes:
     """MaxPool2d(pool_k, pool_s) on an NHWC code plane [N*H*W, ld] -> [N*(Ho+2hy)*(Wo+2hx), ld] (max of codes =
     code of the max: the quantised value is monotone in its code)."""

@@ -12,7 +12,7 @@ m4 = m4.to(dev).to(memory_format=torch.channels_last).eval()
 x4 = torch.randn((256, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
 for m in m4.modules():
     if isinstance(m, torch.nn.BatchNorm2d): m.running_var.mul_(4.0)
-net = bench_models.FusedDorefaResNet18(m4) if os.environ.get("FUSED", "0") == "1" else m4
+net = bench_models.FusedDorefaResNet18(m4, fold=os.environ.get("FOLD") or None) if os.environ.get("FUSED", "0") == "1" else m4
 with torch.no_grad():
     for _ in range(int(os.environ.get("ITERS", "13"))): net(x4)
 torch.cuda.synchronize()

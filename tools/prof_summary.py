@@ -17,7 +17,8 @@ d = sys.argv[1]
 ours = ("mfma_gemm_kernel", "pool_affine_sign_pack_kernel", "triple_kernel", "codes_kernel", "im2col_words_kernel",
         "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_pair_kernel", "bits_to_nib_pad_kernel", "s2d_triple_rows_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
         "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
-        "check_pm1_kernel", "pool_bits_kernel", "affine_codes_kernel", "pool_codes_kernel", "zero_halo_kernel", "pad_pixel_plane_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
+        "check_pm1_kernel", "pair_kernel", "s2d_pair_rows_kernel", "absmax_part_kernel", "absmax_final_kernel", "pool_sum_kernel",
+        "sqdev_kernel", "fold_kernel", "finalize_kernel", "norm_sign_kernel", "bwd_sum_kernel", "bwd_dx_kernel", "pool_bwd_kernel", "pool_bits_kernel", "affine_codes_kernel", "pool_codes_kernel", "zero_halo_kernel", "pad_pixel_plane_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
 
 
 import re
