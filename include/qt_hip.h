@@ -335,6 +335,18 @@ int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t strid
                                  int64_t Wq, int64_t Cs8, int64_t Cp, int64_t Qx, uint16_t* XP, qt_stream_t stream);
 int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
                     int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
+/* Round 3: the same weight gradient with the gradient as TWO fp16 planes of g / s (s = scale2[0], a per-tensor power of two:
+ * qt_f16x2_absmax_scale_f32) and the activation plane in fp16 — 2/3 of the MFMAs and of the gradient bytes, bound in
+ * csrc/split_f16.hip.  bias_part may be NULL (then any gradient strides are accepted).  The reduced result is multiplied by
+ * scale2[0] by the caller. */
+int qt_wgrad_pm_pack_grad_f16x2(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, const float* scale2,
+                                uint16_t* G2, float* bias_part, qt_stream_t stream);
+int qt_wgrad_pm_pack_act_f16(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
+                             float x_scale, uint16_t* XP, qt_stream_t stream);
+int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
+                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
                            const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
                            qt_stream_t stream);

@@ -25,6 +25,7 @@ namespace {
 
 typedef float pm_v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 pm_bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pm_h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint32_t pm_bf16_rn_bits(float f) {  // round-to-nearest-even, NaN kept quiet (as split_bf16.hip)
     uint32_t u = __float_as_uint(f);
@@ -32,6 +33,37 @@ __device__ __forceinline__ uint32_t pm_bf16_rn_bits(float f) {  // round-to-near
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+
+// Round 3: the gradient goes in as NP planes — 3 exact bf16 terms (v_mfma_f32_32x32x16_bf16), or 2 fp16 terms of g / s with a
+// per-tensor power-of-two scale s (v_mfma_f32_32x32x16_f16; csrc/split_f16.hip has the bound): 2/3 of the MFMAs, of the gradient
+// bytes and of the LDS fill.  The activation plane holds the same +-1 / 0 / small-integer values in the matching 16-bit format.
+__device__ __forceinline__ uint32_t pm_f16_bits(float f) {
+    const _Float16 h = (_Float16)f;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ float pm_f16_to_f32(uint32_t b) {
+    const unsigned short u = (unsigned short)b;
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+// the NP 16-bit terms of v (NP == 2: v already divided by the scale)
+template <int NP>
+__device__ __forceinline__ void pm_split(float v, uint32_t (&t)[3]) {
+    if constexpr (NP == 3) {
+        t[0] = pm_bf16_rn_bits(v);
+        const float r1 = v - __uint_as_float(t[0] << 16);
+        t[1] = pm_bf16_rn_bits(r1);
+        t[2] = pm_bf16_rn_bits(r1 - __uint_as_float(t[1] << 16));
+    } else {
+        t[0] = pm_f16_bits(v);
+        t[1] = pm_f16_bits(v - pm_f16_to_f32(t[0]));
+        t[2] = 0;
+    }
+}
+
 
 // ---- packers (HBM-bound, elementwise: no transposition) --------------------------------------------------------------
 // One workgroup per (row y, image n) = Wq consecutive positions; an item = 8 channels of one position (32 bytes of fp32 in,
@@ -50,9 +82,11 @@ __device__ __forceinline__ void pm_item(int item, int c8, int Wq, bool channel_f
 }
 
 // G3[t][q][Cp]: exact bf16 split of g at position q = (y * N + n) * Wq + x (zero where x >= Wo and for channels >= Cout)
+template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh_,
                                                            int64_t sw, int N, int Cout, int Wo, int Wq, int Cp, int64_t Qa,
-                                                           uint16_t* __restrict__ G3) {
+                                                           uint16_t* __restrict__ G3, const float* __restrict__ scale2) {
+    const float inv = (NP == 2 && scale2) ? scale2[1] : 1.0f;
     const int c8 = Cp >> 3, items = Wq * c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
     const float* row = g + (int64_t)n * sn + (int64_t)y * sh_;
@@ -74,18 +108,16 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const uint32_t a = pm_bf16_rn_bits(v[i]);
-                const float r1 = v[i] - __uint_as_float(a << 16);
-                const uint32_t b = pm_bf16_rn_bits(r1);
-                const uint32_t c = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
+                uint32_t t[3];
+                pm_split<NP>(v[i] * inv, t);
                 const int s = (i & 1) * 16;
-                h[0][i >> 1] |= a << s;
-                h[1][i >> 1] |= b << s;
-                h[2][i >> 1] |= c << s;
+                h[0][i >> 1] |= t[0] << s;
+                h[1][i >> 1] |= t[1] << s;
+                h[2][i >> 1] |= t[2] << s;
             }
         }
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NP; ++s)
             *reinterpret_cast<uint4*>(out + (int64_t)s * Qa * Cp + (int64_t)x * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
     }
 }
@@ -94,9 +126,11 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
 // third pass over g otherwise): every thread keeps one fixed 8-channel chunk and walks the row's positions xl, xl + XPAR, ...,
 // so its eight running sums live in registers; the XPAR partial rows are added in a fixed order through LDS and the workgroup
 // writes bias_part[row][Cp].  Deterministic (no atomics): pm_bias_reduce_kernel adds the rows in a fixed order as well.
+template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __restrict__ g, int64_t sn, int64_t sh_, int64_t sw, int N,
                                                                 int Cout, int Wo, int Wq, int Cp, int64_t Qa, uint16_t* __restrict__ G3,
-                                                                float* __restrict__ bias_part) {
+                                                                float* __restrict__ bias_part, const float* __restrict__ scale2) {
+    const float inv = (NP == 2 && scale2) ? scale2[1] : 1.0f;
     __shared__ float red[2048];                              // [xpar][Cp] partial sums, xpar * Cp <= 256 * 8
     const int c8 = Cp >> 3, xpar = 256 / c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
@@ -120,18 +154,16 @@ __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __r
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     acc[i] += v[i];
-                    const uint32_t a = pm_bf16_rn_bits(v[i]);
-                    const float r1 = v[i] - __uint_as_float(a << 16);
-                    const uint32_t b = pm_bf16_rn_bits(r1);
-                    const uint32_t c = pm_bf16_rn_bits(r1 - __uint_as_float(b << 16));
+                    uint32_t t3[3];
+                    pm_split<NP>(v[i] * inv, t3);
                     const int s = (i & 1) * 16;
-                    h[0][i >> 1] |= a << s;
-                    h[1][i >> 1] |= b << s;
-                    h[2][i >> 1] |= c << s;
+                    h[0][i >> 1] |= t3[0] << s;
+                    h[1][i >> 1] |= t3[1] << s;
+                    h[2][i >> 1] |= t3[2] << s;
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NP; ++s)
                 *reinterpret_cast<uint4*>(out + (int64_t)s * Qa * Cp + (int64_t)x * Cp + c0) = make_uint4(h[s][0], h[s][1], h[s][2], h[s][3]);
         }
 #pragma unroll
@@ -168,6 +200,7 @@ __global__ __launch_bounds__(256) void pm_bias_reduce_kernel(const float* __rest
 
 // XP[q][Cp]: bf16(x * x_scale) at padded position q = (y * N + n) * Wq + x over the H + 2 ph padded rows (zero outside the image,
 // past the pitch and in channels >= Cin)
+template <bool F16>
 __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
                                                           int64_t sw, int N, int Cin, int H, int W, int ph, int pw, int Wq,
                                                           int Cp, float x_scale, uint16_t* __restrict__ XP) {
@@ -194,7 +227,7 @@ __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restric
                 for (int i = 0; i < 8; ++i) v[i] = c0 + i < Cin ? src[(int64_t)i * sc] : 0.0f;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) h[i >> 1] |= pm_bf16_rn_bits(v[i] * x_scale) << ((i & 1) * 16);
+            for (int i = 0; i < 8; ++i) h[i >> 1] |= (F16 ? pm_f16_bits(v[i] * x_scale) : pm_bf16_rn_bits(v[i] * x_scale)) << ((i & 1) * 16);
         }
         *reinterpret_cast<uint4*>(out + (int64_t)x * Cp + c0) = make_uint4(h[0], h[1], h[2], h[3]);
     }
@@ -264,7 +297,7 @@ struct PmArgs {
 
 constexpr int PM_KS = 32;       // positions per stage (two MFMA k-steps of 16)
 
-template <int TM, int TN, int KH, int KW>
+template <int TM, int TN, int KH, int KW, int NP = 3>
 struct PmCfg {
     static constexpr int T = KH * KW;
     static constexpr int NH = TN / 32;                    // 32-channel sub-tiles of the activation tile
@@ -277,13 +310,13 @@ struct PmCfg {
     // touches are then 256 consecutive bytes (every bank once); a 128-byte pitch would put rows r and r + 2 on the same banks
     static constexpr int XNEED = PM_KS + KW - 1;          // activation rows one stage reads per kernel row
     static constexpr int XR = (XNEED + 15) / 16 * 16;     // rows reserved (whole 16-row DMA pieces; surplus lanes are masked off)
-    static constexpr int A_BYTES = 3 * MB * PM_KS * 64;   // gradient tile: 3 planes x MB sub-tiles x 32 rows
+    static constexpr int A_BYTES = NP * MB * PM_KS * 64;  // gradient tile: NP planes x MB sub-tiles x 32 rows
     static constexpr int X_BYTES = KH * NH * XR * 64;
     static constexpr int STAGE = A_BYTES + X_BYTES;
     static constexpr int NST = 3;                         // ring depth: the DMA runs two stages ahead of the MFMAs
     static constexpr int LDS = NST * STAGE;
     // one stage = LDS-DMA pieces of 1 KiB (64 lanes x 16 bytes = 16 rows of one sub-tile), dealt round-robin to the 8 waves
-    static constexpr int A_PIECES = 3 * MB * 2;
+    static constexpr int A_PIECES = NP * MB * 2;
     static constexpr int XP_PER = XR / 16;
     static constexpr int PIECES = A_PIECES + KH * NH * XP_PER;
     static constexpr int NPW = (PIECES + 7) / 8;          // pieces per wave (the last round may be short)
@@ -299,12 +332,27 @@ __device__ __forceinline__ void pm_dma16(const unsigned char* src, unsigned lds_
                  : "memory");
 }
 
+template <int NP>
+__device__ __forceinline__ pm_v16f pm_mfma(const uint4& aq, const uint4& bq, pm_v16f c) {
+    if constexpr (NP == 3) {
+        pm_bf8 av, bv;
+        __builtin_memcpy(&av, &aq, 16);
+        __builtin_memcpy(&bv, &bq, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    } else {
+        pm_h8 av, bv;
+        __builtin_memcpy(&av, &aq, 16);
+        __builtin_memcpy(&bv, &bq, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void pm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int TN, int KH, int KW>
+template <int TM, int TN, int KH, int KW, int NP>
 __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
-    using C = PmCfg<TM, TN, KH, KW>;
+    using C = PmCfg<TM, TN, KH, KW, NP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,7 +438,7 @@ __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
         const unsigned sb = lds0 + (unsigned)((s % C::NST) * C::STAGE);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint2 af[C::MW][3][2], xf[2][2];
+            uint2 af[C::MW][NP][2], xf[2][2];
             auto read_x = [&](int i, uint2 (&dst)[2]) {
                 const int tap = tg + i * C::G;
                 const int kh = tap / KW, kw = tap - kh * KW;
@@ -404,7 +452,7 @@ __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
 #pragma unroll
             for (int j = 0; j < C::MW; ++j)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < NP; ++t)
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
                         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
@@ -421,10 +469,10 @@ __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
                     // one tap ahead: its reads fly under this tap's MFMAs.  The fragment registers are operands of the wait so
                     // that no MFMA reading them can be scheduled above it
 #define PM_WAIT(n)                                                                                                     \
-    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)             \
+    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < NP; ++t_)            \
         asm volatile("" : "+v"(af[j_][t_][0]), "+v"(af[j_][t_][1]));                                                   \
     asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(xf[i & 1][0]), "+v"(xf[i & 1][1])::"memory");                      \
-    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)             \
+    _Pragma("unroll") for (int j_ = 0; j_ < C::MW; ++j_) _Pragma("unroll") for (int t_ = 0; t_ < NP; ++t_)            \
         asm volatile("" : "+v"(af[j_][t_][0]), "+v"(af[j_][t_][1]))
                     if (more) {
                         read_x(i + 1, xf[(i + 1) & 1]);
@@ -433,17 +481,13 @@ __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
                         PM_WAIT(0);
                     }
 #undef PM_WAIT
-                    pm_bf8 bv;
                     const uint4 bq = make_uint4(xf[i & 1][0].x, xf[i & 1][0].y, xf[i & 1][1].x, xf[i & 1][1].y);
-                    __builtin_memcpy(&bv, &bq, 16);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                    for (int t = 0; t < NP; ++t)
 #pragma unroll
                         for (int j = 0; j < C::MW; ++j) {
-                            pm_bf8 av;
                             const uint4 aq = make_uint4(af[j][t][0].x, af[j][t][0].y, af[j][t][1].x, af[j][t][1].y);
-                            __builtin_memcpy(&av, &aq, 16);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                            acc[i][j] = pm_mfma<NP>(aq, bq, acc[i][j]);
                         }
                 }
             }
@@ -473,9 +517,9 @@ __global__ __launch_bounds__(512) void wgrad_pm_kernel(PmArgs a) {
 // NEXT stage's buffer, which is why the stage hand-over (vmcnt(0) for this wave's share of stage s + 1, the workgroup barrier, the
 // DMA issue for stage s + 2 into the buffer stage s - 1 used) sits three steps before the end of the stage instead of at its
 // end: no wave ever waits on LDS latency with an idle matrix pipe except in the prologue.
-template <int TM, int TN, int KH, int KW>
+template <int TM, int TN, int KH, int KW, int NP>
 __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
-    using C = PmCfg<TM, TN, KH, KW>;
+    using C = PmCfg<TM, TN, KH, KW, NP>;
     static_assert(C::MB * C::NH == 8, "one wave per 32 x 32 block");
     constexpr int T = C::T, STEPS = 2 * T, HANDOVER = STEPS - 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -553,9 +597,9 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
     const unsigned a_off = (unsigned)((mblk * PM_KS + frow) * 64 + fcol * 2);
     const unsigned x_off = (unsigned)(C::A_BYTES + (nb * C::XR + frow) * 64 + fcol * 2);
 
-    uint2 af[2][3][2], xf[2][2];
+    uint2 af[2][NP][2], xf[2][2];
 #define PM_READ_A(base, ks, dst)                                                                                          \
-    _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                   \
+    _Pragma("unroll") for (int t_ = 0; t_ < NP; ++t_) _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                  \
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[t_][r_]) : "v"((base) + a_off),                     \
                      "n"((t_ * C::MB * PM_KS + (ks) * 16 + r_ * 4) * 64) : "memory")
 #define PM_READ_X(base, ks, tap, dst)                                                                                     \
@@ -596,10 +640,10 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
             if (tap == T - 3) {
                 if (ks == 0) {
                     PM_READ_A(sb, 1, af[1]);
-                    newer += 6;
+                    newer += 2 * NP;
                 } else if (has_next) {
                     PM_READ_A(sbn, 0, af[0]);
-                    newer += 6;
+                    newer += 2 * NP;
                 }
             }
             const bool a_prev = tap == T - 2;                     // the gradient reads issued one step ago may still be in flight
@@ -607,22 +651,27 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
             // number on every path but the last stage, where the skipped prefetches make the wait stricter (never looser)
             // (the fragment registers are operands of the wait so that no MFMA reading them can be scheduled above it)
 #define PM_WAIT(n)                                                                                                                \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                      \
-                 : "+v"(xf[j & 1][0]), "+v"(xf[j & 1][1]), "+v"(af[ks][0][0]), "+v"(af[ks][0][1]), "+v"(af[ks][1][0]),            \
-                   "+v"(af[ks][1][1]), "+v"(af[ks][2][0]), "+v"(af[ks][2][1])::"memory")
+    do {                                                                                                                          \
+        if constexpr (NP == 3)                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                              \
+                         : "+v"(xf[j & 1][0]), "+v"(xf[j & 1][1]), "+v"(af[ks][0][0]), "+v"(af[ks][0][1]), "+v"(af[ks][1][0]),    \
+                           "+v"(af[ks][1][1]), "+v"(af[ks][NP - 1][0]), "+v"(af[ks][NP - 1][1])::"memory");                       \
+        else                                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                              \
+                         : "+v"(xf[j & 1][0]), "+v"(xf[j & 1][1]), "+v"(af[ks][0][0]), "+v"(af[ks][0][1]), "+v"(af[ks][1][0]),    \
+                           "+v"(af[ks][1][1])::"memory");                                                                         \
+    } while (0)
+            // (the counts: 2 activation fragment reads per step, 2 NP gradient fragment reads per k-step)
             if (!has_next && (j + 1 >= STEPS || (tap >= T - 3 && ks == 1))) PM_WAIT(0);
-            else if (newer + (a_prev ? 6 : 0) == 8) PM_WAIT(8);
-            else PM_WAIT(2);
+            else if (newer + (a_prev ? 2 * NP : 0) == 2 + 2 * NP) {
+                if constexpr (NP == 3) PM_WAIT(8); else PM_WAIT(6);
+            } else PM_WAIT(2);
 #undef PM_WAIT
-            pm_bf8 bv;
             const uint4 bq = make_uint4(xf[j & 1][0].x, xf[j & 1][0].y, xf[j & 1][1].x, xf[j & 1][1].y);
-            __builtin_memcpy(&bv, &bq, 16);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                pm_bf8 av;
+            for (int t = 0; t < NP; ++t) {
                 const uint4 aq = make_uint4(af[ks][t][0].x, af[ks][t][0].y, af[ks][t][1].x, af[ks][t][1].y);
-                __builtin_memcpy(&av, &aq, 16);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
+                acc[tap] = pm_mfma<NP>(aq, bq, acc[tap]);
             }
         }
     }
@@ -658,11 +707,11 @@ __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict_
     }
 }
 
-template <int TM, int TN, int KH, int KW, bool FULL = false>
+template <int TM, int TN, int KH, int KW, int NP, bool FULL = false>
 int pm_launch(const PmArgs& a, int nslice, hipStream_t stream) {
-    using C = PmCfg<TM, TN, KH, KW>;
-    void (*kernel)(PmArgs) = wgrad_pm_kernel<TM, TN, KH, KW>;
-    if constexpr (FULL) kernel = wgrad_pm_full_kernel<TM, TN, KH, KW>;
+    using C = PmCfg<TM, TN, KH, KW, NP>;
+    void (*kernel)(PmArgs) = wgrad_pm_kernel<TM, TN, KH, KW, NP>;
+    if constexpr (FULL) kernel = wgrad_pm_full_kernel<TM, TN, KH, KW, NP>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
         return QT_ERR_LAUNCH;
     PmArgs b = a;
@@ -679,34 +728,54 @@ int pm_launch(const PmArgs& a, int nslice, hipStream_t stream) {
 
 extern "C" {
 
+static int pm_pack_grad_impl(int np, const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                            int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G, float* bias_part,
+                            const float* scale2, qt_stream_t stream) {
+    if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G || (np == 2 && !scale2)) return QT_ERR_INVALID_ARG;
+    if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G)) return QT_ERR_ALIGNMENT;
+    if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28) || (bias_part && Cp > 2048)) return QT_ERR_UNSUPPORTED;
+    if (bias_part && stride_c != 1) return QT_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)(Ho * N));
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_part) {
+        if (np == 2)
+            hipLaunchKernelGGL(pm_pack_grad_bias_kernel<2>, grid, dim3(256), 0, st, g, stride_n, stride_h, stride_w, (int)N, (int)Cout,
+                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2);
+        else
+            hipLaunchKernelGGL(pm_pack_grad_bias_kernel<3>, grid, dim3(256), 0, st, g, stride_n, stride_h, stride_w, (int)N, (int)Cout,
+                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2);
+    } else {
+        if (np == 2)
+            hipLaunchKernelGGL(pm_pack_grad_kernel<2>, grid, dim3(256), 0, st, g, stride_n, stride_c, stride_h, stride_w, (int)N,
+                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2);
+        else
+            hipLaunchKernelGGL(pm_pack_grad_kernel<3>, grid, dim3(256), 0, st, g, stride_n, stride_c, stride_h, stride_w, (int)N,
+                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2);
+    }
+    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
+    for (int t = 0; t < np && tail > 0; ++t)
+        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<uint4*>(G + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
+    return qt_check_launch();
+}
+
 int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                               int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
                               qt_stream_t stream) {
-    if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G3) return QT_ERR_INVALID_ARG;
-    if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G3)) return QT_ERR_ALIGNMENT;
-    if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pm_pack_grad_kernel, dim3((unsigned)(Ho * N)), dim3(256), 0, (hipStream_t)stream, g, stride_n, stride_c,
-                       stride_h, stride_w, (int)N, (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G3);
-    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
-    for (int t = 0; t < 3 && tail > 0; ++t)
-        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<uint4*>(G3 + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
-    return qt_check_launch();
+    return pm_pack_grad_impl(3, g, stride_n, stride_c, stride_h, stride_w, N, Cout, Ho, Wo, Wq, Cp, Qa, G3, nullptr, nullptr, stream);
 }
 
 int qt_wgrad_pm_pack_grad_bias_f32(const float* g, int64_t stride_n, int64_t stride_h, int64_t stride_w, int64_t N, int64_t Cout,
                                    int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3, float* bias_part,
                                    qt_stream_t stream) {
-    if (N <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !g || !G3 || !bias_part) return QT_ERR_INVALID_ARG;
-    if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G3)) return QT_ERR_ALIGNMENT;
-    if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28) || Cp > 2048) return QT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pm_pack_grad_bias_kernel, dim3((unsigned)(Ho * N)), dim3(256), 0, (hipStream_t)stream, g, stride_n, stride_h,
-                       stride_w, (int)N, (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G3, bias_part);
-    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
-    for (int t = 0; t < 3 && tail > 0; ++t)
-        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<uint4*>(G3 + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
-    return qt_check_launch();
+    if (!bias_part) return QT_ERR_INVALID_ARG;
+    return pm_pack_grad_impl(3, g, stride_n, 1, stride_h, stride_w, N, Cout, Ho, Wo, Wq, Cp, Qa, G3, bias_part, nullptr, stream);
+}
+
+int qt_wgrad_pm_pack_grad_f16x2(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, const float* scale2,
+                                uint16_t* G2, float* bias_part, qt_stream_t stream) {
+    return pm_pack_grad_impl(2, g, stride_n, stride_c, stride_h, stride_w, N, Cout, Ho, Wo, Wq, Cp, Qa, G2, bias_part, scale2, stream);
 }
 
 int qt_wgrad_pm_bias_reduce_f32(float* bias_part, int64_t rows, int64_t Cp, int64_t Cout, int accumulate, float* db,
@@ -728,20 +797,36 @@ int qt_wgrad_pm_bias_reduce_f32(float* bias_part, int64_t rows, int64_t Cp, int6
     return qt_check_launch();
 }
 
-int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
-                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
-                             float x_scale, uint16_t* XP, qt_stream_t stream) {
+static int pm_pack_act_impl(bool f16, const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                           int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx, float x_scale,
+                           uint16_t* XP, qt_stream_t stream) {
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || !x || !XP) return QT_ERR_INVALID_ARG;
     const int64_t rows = (H + 2 * ph) * N;
     if (Wq < W + 2 * pw || Cp < Cin || (Cp & 31) || Qx < rows * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
     if (rows >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pm_pack_act_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c, stride_h,
-                       stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
+    if (f16)
+        hipLaunchKernelGGL(pm_pack_act_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
+                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
+    else
+        hipLaunchKernelGGL(pm_pack_act_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
+                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
     const int64_t tail = (Qx - rows * Wq) * Cp * 2 / 16;
     if (tail > 0)
         hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<uint4*>(XP + rows * Wq * Cp), tail);
     return qt_check_launch();
+}
+
+int qt_wgrad_pm_pack_act_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
+                             float x_scale, uint16_t* XP, qt_stream_t stream) {
+    return pm_pack_act_impl(false, x, stride_n, stride_c, stride_h, stride_w, N, Cin, H, W, ph, pw, Wq, Cp, Qx, x_scale, XP, stream);
+}
+
+int qt_wgrad_pm_pack_act_f16(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                             int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
+                             float x_scale, uint16_t* XP, qt_stream_t stream) {
+    return pm_pack_act_impl(true, x, stride_n, stride_c, stride_h, stride_w, N, Cin, H, W, ph, pw, Wq, Cp, Qx, x_scale, XP, stream);
 }
 
 int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
@@ -762,18 +847,34 @@ int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t strid
 
 // part[nslice][kh * kw][Cpo][Cpi] = per-slice partial gradients; Qa = nslice * slice_pos, slice_pos % 32 == 0;
 // XP must hold (kh - 1) * kh_rows + Qa + 48 rows (kw - 1 are read).  Supported: (kh, kw) = (3, 3) with Cpi % 64 == 0, (5, 5) with Cpi % 32 == 0.
-int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
-                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream) {
-    if (!G3 || !XP || !part || Qa <= 0 || nslice <= 0 || nslice > 65535 || kh_rows <= 0) return QT_ERR_INVALID_ARG;
-    if ((Qa % (32 * nslice)) || (Cpo & 63) || !qt_aligned16(G3) || !qt_aligned16(XP) || !qt_aligned16(part)) return QT_ERR_ALIGNMENT;
+static int pm_run(int np, const uint16_t* G, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice, int64_t Cpo,
+                  int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream) {
+    if (!G || !XP || !part || Qa <= 0 || nslice <= 0 || nslice > 65535 || kh_rows <= 0) return QT_ERR_INVALID_ARG;
+    if ((Qa % (32 * nslice)) || (Cpo & 63) || !qt_aligned16(G) || !qt_aligned16(XP) || !qt_aligned16(part)) return QT_ERR_ALIGNMENT;
     PmArgs a;
-    a.G3 = reinterpret_cast<const unsigned char*>(G3);
+    a.G3 = reinterpret_cast<const unsigned char*>(G);
     a.XP = reinterpret_cast<const unsigned char*>(XP);
     a.part = part; a.Qa = Qa; a.kh_rows = kh_rows; a.slice_pos = Qa / nslice; a.Cpo = (int)Cpo; a.Cpi = (int)Cpi;
     hipStream_t s = (hipStream_t)stream;
-    if (kh == 3 && kw == 3 && !(Cpi & 63)) return (Cpo & 127) ? pm_launch<64, 64, 3, 3>(a, (int)nslice, s) : pm_launch<128, 64, 3, 3, true>(a, (int)nslice, s);
-    if (kh == 5 && kw == 5 && !(Cpi & 31)) return pm_launch<64, 32, 5, 5>(a, (int)nslice, s);
+    const int ns = (int)nslice;
+    if (kh == 3 && kw == 3 && !(Cpi & 63)) {
+        if (np == 3) return (Cpo & 127) ? pm_launch<64, 64, 3, 3, 3>(a, ns, s) : pm_launch<128, 64, 3, 3, 3, true>(a, ns, s);
+        return (Cpo & 127) ? pm_launch<64, 64, 3, 3, 2>(a, ns, s) : pm_launch<128, 64, 3, 3, 2, true>(a, ns, s);
+    }
+    if (kh == 5 && kw == 5 && !(Cpi & 31)) return np == 3 ? pm_launch<64, 32, 5, 5, 3>(a, ns, s) : pm_launch<64, 32, 5, 5, 2>(a, ns, s);
     return QT_ERR_UNSUPPORTED;
+}
+
+int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
+                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream) {
+    return pm_run(3, G3, XP, part, Qa, kh_rows, nslice, Cpo, Cpi, kh, kw, stream);
+}
+
+// the same contraction over TWO fp16 gradient planes (qt_wgrad_pm_pack_grad_f16x2) and an fp16 activation plane
+// (qt_wgrad_pm_pack_act_f16); the caller multiplies the reduced result by scale2[0]
+int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
+                    int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream) {
+    return pm_run(2, G2, XP, part, Qa, kh_rows, nslice, Cpo, Cpi, kh, kw, stream);
 }
 
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,

@@ -1990,12 +1990,14 @@ def _wgrad_pm_plan(nc: int, Cout: int, Cin: int, H: int, W: int, Ho: int, kh: in
 
 
 def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int,
-                  bias_grad: Optional[list] = None):
+                  bias_grad: Optional[list] = None, terms: int = 3):
     """Pixel-major weight gradient for the position geometry ``geom`` = (N, Cin, H, W, kh, kw, ph, pw) of a stride-1 conv;
-    ``pack_act(n0, cnt, Wq, Cpi, Qx, XP, stream)`` writes the activation plane of images [n0, n0 + cnt).  Returns
-    [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget.  ``bias_grad``: a list that receives the
-    conv's bias gradient (sum of the gradient over n, y, x) when the gradient pack can produce it on the way (channels-last
-    gradient, <= 2048 padded channels) — otherwise it stays empty and the caller reduces the gradient itself."""
+    ``pack_act(n0, cnt, Wq, Cpi, Qx, XP, stream, f16)`` writes the activation plane of images [n0, n0 + cnt) (bf16, or fp16 when
+    ``f16``).  Returns [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget.  ``bias_grad``: a list that
+    receives the conv's bias gradient (sum of the gradient over n, y, x) when the gradient pack can produce it on the way
+    (channels-last gradient, <= 2048 padded channels) — otherwise it stays empty and the caller reduces the gradient itself.
+    ``terms``: 3 = the gradient as three exact bf16 planes; 2 = two fp16 planes of g / s with the per-tensor power-of-two
+    scale of FLOAT_SPLIT = "f16x2" (the result is multiplied by s at the end; the STE mask only zeroes entries)."""
     N, Cin, H, W, kh, kw, ph, pw = geom
     _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
     tn = 64 if kh == 3 else 32
@@ -2018,8 +2020,10 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     ns_m, qa_m, qx_m = max(nslice, tail[1]), max(qa, tail[2]), max(qx, tail[3])
     dev = grad_output.device
     g = grad_output.detach()
+    two = int(terms) == 2
+    scale2 = pow2_scale(g) if two else None
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
-    G3 = torch.empty((3 * qa_m * Cpo,), dtype=torch.int16, device=dev)
+    G3 = torch.empty(((2 if two else 3) * qa_m * Cpo,), dtype=torch.int16, device=dev)
     XP = torch.empty((qx_m * Cpi,), dtype=torch.int16, device=dev)
     part = torch.empty((ns_m * taps * Cpo * Cpi,), dtype=torch.float32, device=dev)
     w = None
@@ -2028,6 +2032,7 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     I = int
     st = _stream(dev)
     want_bias = bias_grad is not None and g.stride(1) == 1 and Cpo <= 2048
+    bias_part = db = None
     if want_bias:
         bias_part = torch.empty(((Ho * nc + 128) * Cpo,), dtype=torch.float32, device=dev)    # + the reduce's scratch rows
         db = torch.empty((Cout,), dtype=torch.float32, device=dev)
@@ -2037,17 +2042,24 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
             gs = g[n0:n0 + cnt]
             _, ns_u, qa_u, qx_u = tail if cnt != nc else (True, nslice, qa, qx)
             assert ns_u <= ns_m and qa_u <= qa_m and qx_u <= qx_m
-            if want_bias:
+            if two:
+                _lib.call("qt_wgrad_pm_pack_grad_f16x2", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
+                          I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(scale2), _p(G3), _p(bias_part), st)
+            elif want_bias:
                 _lib.call("qt_wgrad_pm_pack_grad_bias_f32", _p(gs), I(gs.stride(0)), I(gs.stride(2)), I(gs.stride(3)),
                           I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), _p(bias_part), st)
-                _lib.call("qt_wgrad_pm_bias_reduce_f32", _p(bias_part), I(Ho * cnt), I(Cpo), I(Cout), int(n0 > 0), _p(db), st)
             else:
                 _lib.call("qt_wgrad_pm_pack_grad_f32", _p(gs), I(gs.stride(0)), I(gs.stride(1)), I(gs.stride(2)), I(gs.stride(3)),
                           I(cnt), I(Cout), I(Ho), I(Wo), I(Wq), I(Cpo), I(qa_u), _p(G3), st)
-            pack_act(n0, cnt, Wq, Cpi, qx_u, XP, st)
-            _lib.call("qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u), I(Cpo), I(Cpi), I(kh), I(kw), st)
+            if want_bias:
+                _lib.call("qt_wgrad_pm_bias_reduce_f32", _p(bias_part), I(Ho * cnt), I(Cpo), I(Cout), int(n0 > 0), _p(db), st)
+            pack_act(n0, cnt, Wq, Cpi, qx_u, XP, st, two)
+            _lib.call("qt_wgrad_pm_f16" if two else "qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u),
+                      I(Cpo), I(Cpi), I(kh), I(kw), st)
             _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
                       float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
+    if two:
+        dW = dW * scale2[0]
     if want_bias:
         bias_grad.append(db)
     return dW
@@ -2055,11 +2067,13 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
 
 def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
-                          x_levels: float = 1.0, workgroups: int = 0, bias_grad: Optional[list] = None):
+                          x_levels: float = 1.0, workgroups: int = 0, bias_grad: Optional[list] = None,
+                          terms: Optional[int] = None):
     """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
     [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
     the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs.
-    ``bias_grad``: see ``_wgrad_pm_run`` (the bias gradient as a by-product of the gradient pack)."""
+    ``bias_grad``: see ``_wgrad_pm_run`` (the bias gradient as a by-product of the gradient pack).  ``terms``: how the
+    real-valued gradient is split (default: FLOAT_SPLIT — two fp16 terms, or three exact bf16 terms)."""
     _require(x_pm1, "input")
     _require(grad_output, "grad_output")
     kh, kw = (int(v) for v in kernel_hw)
@@ -2073,12 +2087,14 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
     out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
     I = int
 
-    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st):
+    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st, f16=False):
         xs = x[n0:n0 + cnt]
-        _lib.call("qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
-                  I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx), float(x_levels), _p(XP), st)
+        _lib.call("qt_wgrad_pm_pack_act_f16" if f16 else "qt_wgrad_pm_pack_act_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)),
+                  I(xs.stride(2)), I(xs.stride(3)), I(cnt), I(Cin), I(H), I(W), I(ph), I(pw), I(Wq), I(Cpi), I(qx), float(x_levels),
+                  _p(XP), st)
 
-    return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups, bias_grad)
+    return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups,
+                         bias_grad, terms=split_terms(terms))
 
 
 def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
@@ -2119,7 +2135,8 @@ def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_sh
     xd = x.detach()
     I = int
 
-    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st):
+    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st, f16=False):
+        # (the first-layer route keeps the exact three-term bf16 form: the image's terms are channel groups of the activation plane)
         # space-to-depth gather + exact three-term split in one pass: XP[q][t * Cs8 + (c s + dy) s + dx] = term t of
         # xpad[n, c, Y s + dy - ph, X s + dx - pw]
         xs = xd[n0:n0 + cnt]

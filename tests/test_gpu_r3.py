@@ -568,3 +568,52 @@ def test_alexnet_training_step_with_the_fused_training_chain(dev):
         if k.endswith(".bias") and float(want[k].abs().max()) < 1e-3 * top:
             continue          # a bias in front of a training-mode BatchNorm: mathematically zero gradient, rounding noise
         assert norm_err(n(p_.grad), n(want[k])) <= TOL, k
+
+
+# ---- pixel-major weight gradient with the gradient as two fp16 planes ----------------------------------------------------------
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,p,cl", [(3, 64, 128, 13, 13, 3, 1, True), (2, 96, 160, 27, 27, 5, 2, True),
+                                                    (4, 64, 64, 20, 17, 3, 1, False), (5, 70, 40, 9, 11, 3, 0, True),
+                                                    (2, 33, 65, 6, 5, 5, 2, True), (7, 128, 256, 8, 8, 3, 1, True)])
+@pytest.mark.parametrize("terms", [2, 3])
+def test_weight_gradient_pixel_major_both_splits_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl, terms):
+    """ops.conv2d_grad_weight_pm with the gradient in two fp16 planes (per-tensor power-of-two scale) and in three exact bf16
+    planes against torch.nn.grad.conv2d_weight in fp64: +-1 / 0 activations and 4-bit codes, the STE mask, the bias by-product,
+    a gradient whose channels span six decades, chunked batches with a ragged tail."""
+    g_ = torch.Generator(device=dev).manual_seed(N * 1000 + Cin + k)
+    x = torch.randint(-1, 2, (N, Cin, H, W), generator=g_, device=dev).float()
+    Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+    go = torch.randn((N, Cout, Ho, Wo), device=dev, generator=g_)
+    go = go * (10.0 ** torch.linspace(-6, 0, Cout, device=dev)).view(1, -1, 1, 1)
+    if cl:
+        x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g_) * 0.8
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), go.double(), stride=1, padding=p)
+    before = dict(_lib.call_counts)
+    bias = []
+    got = ops.conv2d_grad_weight_pm(x, go, (k, k), p, weight=w, bias_grad=bias, terms=terms)
+    kern = "qt_wgrad_pm_f16" if terms == 2 else "qt_wgrad_pm_f32"
+    assert _lib.call_counts[kern] > before.get(kern, 0)
+    refm = torch.where(w.abs() <= 1.001, ref, torch.zeros_like(ref))
+    assert norm_err(n(got), n(refm)) <= (2e-6 if terms == 2 else TOL)
+    # per output channel as well: the per-tensor scale must not wipe out the small channels beyond the stated bound
+    per = ((got.double() - refm).abs().amax((1, 2, 3)) / (refm.abs().amax((1, 2, 3)) + 1e-300)).cpu().numpy()
+    scale = (refm.abs().amax((1, 2, 3)) / refm.abs().max()).cpu().numpy()
+    assert (per <= np.maximum(1e-5, 2.0 ** -38 / np.maximum(scale, 1e-30) * 64)).all()
+    if bias:
+        assert norm_err(n(bias[0]), n(go.double().sum((0, 2, 3)))) <= TOL
+    xq = nnDorefaQuant(4)(torch.rand((N, Cin, H, W), generator=g_, device=dev) * 1.2).detach()
+    if cl:
+        xq = xq.contiguous(memory_format=torch.channels_last)
+    gq = ops.conv2d_grad_weight_pm(xq, go, (k, k), p, x_levels=15.0, terms=terms)
+    refq = torch.nn.grad.conv2d_weight(xq.double(), (Cout, Cin, k, k), go.double(), stride=1, padding=p)
+    assert norm_err(n(gq), n(refq)) <= (2e-6 if terms == 2 else TOL)
+    old = ops.WGRAD_GEMM_BYTES
+    try:       # chunked batches (ragged tail): partial gradients accumulate under ONE scale
+        ops.WGRAD_GEMM_BYTES = max(1 << 16, (3 * Ho * (W + 2 * p) * 2 * max(Cout, 64) * 2 + (H + 2 * p) * (W + 2 * p) * 2 * max(Cin, 64) * 2) * 2
+                                   + 64 * k * k * max(Cout, 64) * max(Cin, 64) * 4)
+        ch = ops.conv2d_grad_weight_pm(x, go, (k, k), p, terms=terms)
+    finally:
+        ops.WGRAD_GEMM_BYTES = old
+    if ch is not None:
+        assert norm_err(n(ch), n(ref)) <= (2e-6 if terms == 2 else TOL)
