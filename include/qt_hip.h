@@ -310,8 +310,8 @@ int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int
  *                               each, a multiple of 32) of g[q][co] * XP[q + r * kh_rows + c][ci], tap = r * kw + c.  XP must hold
  *                               Qa + (kh - 1) * kh_rows + 48 rows.  (kh, kw) = (3, 3) with Cpi % 64 == 0 or (5, 5) with
  *                               Cpi % 32 == 0; QT_ERR_UNSUPPORTED otherwise.
- *   qt_wgrad_pm_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= out_scale * sum over slices, times the straight-through
- *                               mask 1[|weight| <= ste_threshold] when weight != NULL. */
+ *   qt_wgrad_pm_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= out_scale * row_scale[co] * sum over slices (row_scale NULL:
+ *                               1), times the straight-through mask 1[|weight| <= ste_threshold] when weight != NULL. */
 int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                               int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
                               qt_stream_t stream);
@@ -335,21 +335,22 @@ int qt_wgrad_pm_pack_act_s2d_f32(const float* x, int64_t stride_n, int64_t strid
                                  int64_t Wq, int64_t Cs8, int64_t Cp, int64_t Qx, uint16_t* XP, qt_stream_t stream);
 int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
                     int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
-/* Round 3: the same weight gradient with the gradient as TWO fp16 planes of g / s (s = scale2[0], a per-tensor power of two:
- * qt_f16x2_absmax_scale_f32) and the activation plane in fp16 — 2/3 of the MFMAs and of the gradient bytes, bound in
- * csrc/split_f16.hip.  bias_part may be NULL (then any gradient strides are accepted).  The reduced result is multiplied by
- * scale2[0] by the caller. */
+int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
+                           const float* weight, float ste_threshold, float out_scale, const float* row_scale, int accumulate,
+                           float* dW, qt_stream_t stream);
+/* Round 3: the same weight gradient with the gradient as TWO fp16 planes of g[.., c] / s[c] and the activation plane in fp16 —
+ * 2/3 of the MFMAs and of the gradient bytes, bound in csrc/split_f16.hip.  scale2c = [s[0..Cp) | 1 / s[0..Cp)]: PER-CHANNEL
+ * powers of two from qt_f16x2_absmax_scale_ch_f32 (a row of dW only sees its own gradient channel, so every row keeps the
+ * bound relative to that channel's maximum — a gradient whose channels span many decades loses nothing).  bias_part may be
+ * NULL (then any gradient strides are accepted).  qt_wgrad_pm_reduce_f32 takes row_scale = scale2c. */
 int qt_wgrad_pm_pack_grad_f16x2(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
-                                int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, const float* scale2,
+                                int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, const float* scale2c,
                                 uint16_t* G2, float* bias_part, qt_stream_t stream);
 int qt_wgrad_pm_pack_act_f16(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                              int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
                              float x_scale, uint16_t* XP, qt_stream_t stream);
 int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t Qa, int64_t kh_rows, int64_t nslice,
                     int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
-int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
-                           const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
-                           qt_stream_t stream);
 
 /* Y[M,N] = scale * (*scale_dev) * (Xc . Wc^T) + bias, Xc / Wc int8 code planes (ld in uint32 words).
  * scale_dev: optional DEVICE scalar (e.g. E = mean|W| computed on the device) so no host sync is
@@ -419,8 +420,15 @@ int qt_bf16x3_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, i
  *                            ld in uint32 words.  Conv: qt_conv2d_implicit* with elem = 3 and scale_dev = &scale2[0].
  *   qt_f16x2_absmax_scale_f32 : the same scale2 from the tensor itself: max|x| over n DENSE fp32 values (any order) at the HBM
  *                            rate (per-workgroup partial maxima, then a one-workgroup fold; no atomics); work = scratch of
- *                            qt_f16x2_absmax_work_words() uint32 (contents irrelevant).  x 16-byte aligned. */
+ *                            qt_f16x2_absmax_work_words() uint32 (contents irrelevant).  x 16-byte aligned.
+ *   qt_f16x2_absmax_scale_ch_f32 : PER-CHANNEL scales of an [N, C, H, W] tensor given by its strides: scale2c[c] = s[c] from
+ *                            max|g[:, c]|, scale2c[Cp + c] = 1 / s[c] (1 for C <= c < Cp).  Dense channels-last tensors are
+ *                            reduced at the HBM rate (row-walking workgroups, partial maxima, one fold); any other layout
+ *                            works, slower.  work = qt_f16x2_absmax_ch_work_words(C) uint32 of scratch. */
 int64_t qt_f16x2_absmax_work_words(void);
+int64_t qt_f16x2_absmax_ch_work_words(int64_t C);
+int qt_f16x2_absmax_scale_ch_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                 int64_t C, int64_t H, int64_t W, int64_t Cp, uint32_t* work, float* scale2c, qt_stream_t stream);
 int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream);
 int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* work, float* scale2, qt_stream_t stream);
 int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes, int64_t rows,

@@ -87,7 +87,7 @@ SIGNATURES = {
     "qt_wgrad_pm_pack_act_f16": (_c_int, [_c_p] + [_c_i64] * 13 + [_c_f32, _c_p, _c_p]),
     "qt_wgrad_pm_f16": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 7 + [_c_p]),
     "qt_wgrad_pm_f32": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 7 + [_c_p]),
-    "qt_wgrad_pm_reduce_f32": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_f32, _c_f32, _c_int, _c_p, _c_p]),
+    "qt_wgrad_pm_reduce_f32": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_f32, _c_f32, _c_p, _c_int, _c_p, _c_p]),
     "qt_nib_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
@@ -106,6 +106,8 @@ SIGNATURES = {
     "qt_f16x2_scale_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p]),
     "qt_f16x2_absmax_work_words": (_c_i64, []),
     "qt_f16x2_absmax_scale_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "qt_f16x2_absmax_ch_work_words": (_c_i64, [_c_i64]),
+    "qt_f16x2_absmax_scale_ch_f32": (_c_int, [_c_p] + [_c_i64] * 9 + [_c_p, _c_p, _c_p]),
     "qt_f16x2_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_f16x2_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

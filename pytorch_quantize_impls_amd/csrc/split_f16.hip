@@ -92,6 +92,95 @@ __global__ __launch_bounds__(256) void absmax_final_kernel(const unsigned* __res
     if (threadIdx.x == 0) write_scale(__uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3]))), scale2);
 }
 
+// ---- per-CHANNEL scales (the weight gradient: one output row of dW per gradient channel) -------------------------------------
+// A weight-gradient row only sees ITS channel of the gradient, so a per-tensor scale would cost the channels far below the
+// tensor's maximum their low bits (2^-39 max|g| absolute, per element); with s[c] chosen from max|g[:, c]| every row keeps
+// the bound relative to its own channel, like an fp32 GEMM.  scale2c = [s[0..Cp) | 1 / s[0..Cp)] (1 for padding channels).
+//
+// channels-last, dense: the gradient is a [P][C] matrix.  A workgroup = rpb rows x cw channel groups (VEC channels each, cw =
+// min(C / VEC, 256)); it walks rows bx * rpb + lr, + gridDim.x * rpb, ... (whole contiguous rows when cw covers the row), folds
+// its rpb partial rows through LDS and writes part[bx][C].
+template <int VEC>
+__global__ __launch_bounds__(256) void absmax_ch_rows_kernel(const float* __restrict__ g, int64_t P, int C, int cw, int rpb,
+                                                             unsigned* __restrict__ part) {
+    __shared__ unsigned sm[256 * VEC];
+    const int tid = threadIdx.x, lr = tid / cw, lq = tid - lr * cw;
+    const int cq = C / VEC, q = blockIdx.y * cw + lq;
+    unsigned m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = 0;
+    if (lr < rpb && q < cq) {
+        const int64_t step = (int64_t)gridDim.x * rpb;
+        int64_t r = (int64_t)blockIdx.x * rpb + lr;
+        if constexpr (VEC == 4) {
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+#define QT_FOLD4(v) do { m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu); m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu); \
+                         m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu); m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu); } while (0)
+            for (; r + 3 * step < P; r += 4 * step) {
+                const float4 a = g4[r * cq + q], b = g4[(r + step) * cq + q], c = g4[(r + 2 * step) * cq + q], d = g4[(r + 3 * step) * cq + q];
+                QT_FOLD4(a); QT_FOLD4(b); QT_FOLD4(c); QT_FOLD4(d);
+            }
+            for (; r < P; r += step) {
+                const float4 a = g4[r * cq + q];
+                QT_FOLD4(a);
+            }
+#undef QT_FOLD4
+        } else {
+            for (; r < P; r += step) m[0] = max(m[0], __float_as_uint(g[r * C + q]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sm[tid * VEC + e] = m[e];
+    __syncthreads();
+    if (lr == 0 && q < cq) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            unsigned t = m[e];
+            for (int j = 1; j < rpb; ++j) t = max(t, sm[(j * cw + lq) * VEC + e]);
+            part[(int64_t)blockIdx.x * C + q * VEC + e] = t;
+        }
+    }
+}
+
+// any other layout: workgroup (c, j) walks images j, j + gridDim.y, ... of channel c
+__global__ __launch_bounds__(256) void absmax_ch_strided_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh,
+                                                                int64_t sw, int N, int C, int H, int W, unsigned* __restrict__ part) {
+    const int c = blockIdx.x;
+    unsigned m = 0;
+    const int hw = H * W;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* base = g + (int64_t)n * sn + (int64_t)c * sc;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            const int y = i / W, x = i - y * W;
+            m = max(m, __float_as_uint(base[(int64_t)y * sh + (int64_t)x * sw]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh4[4];
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * C + c] = max(max(sh4[0], sh4[1]), max(sh4[2], sh4[3]));
+}
+
+// part[nparts][C] -> scale2c[2 Cp]: 64 channels x 4 row groups per workgroup
+__global__ __launch_bounds__(256) void absmax_ch_final_kernel(const unsigned* __restrict__ part, int nparts, int C, int Cp,
+                                                              float* __restrict__ scale2c) {
+    __shared__ unsigned sm[4][64];
+    const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + lc;
+    unsigned m = 0;
+    if (c < C)
+        for (int r = rg; r < nparts; r += 4) m = max(m, part[(int64_t)r * C + c]);
+    sm[rg][lc] = m;
+    __syncthreads();
+    if (rg == 0 && c < Cp) {
+        float pair[2] = {1.0f, 1.0f};
+        if (c < C) write_scale(__uint_as_float(max(max(sm[0][lc], sm[1][lc]), max(sm[2][lc], sm[3][lc]))), pair);
+        scale2c[c] = pair[0];
+        scale2c[Cp + c] = pair[1];
+    }
+}
+
 // mode 0 = activation split (x * scale2[1]), 1 = safeSign weight, 2 = ternary weight, 3 = torch.sign weight, 4 = raw weight
 template <int MODE>
 __global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale2,
@@ -221,6 +310,35 @@ extern "C" int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* wo
     const int grid = qt_stream_grid(((n >> 2) + 255) / 256 + 1, 2048);
     hipLaunchKernelGGL(absmax_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, work);
     hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, work, grid, scale2);
+    return qt_check_launch();
+}
+
+extern "C" int64_t qt_f16x2_absmax_ch_work_words(int64_t C) { return 512 * (C > 0 ? C : 1); }
+
+extern "C" int qt_f16x2_absmax_scale_ch_f32(const float* g, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C,
+                                            int64_t H, int64_t W, int64_t Cp, uint32_t* work, float* scale2c, qt_stream_t stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || !g || !work || !scale2c) return QT_ERR_INVALID_ARG;
+    if (C > (1 << 20) || H * W >= (1ll << 31) || N >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int nparts;
+    const int64_t P = N * H * W;
+    if (sc == 1 && sw == C && sh == W * C && sn == H * W * C) {
+        const bool v4 = !(C & 3) && qt_aligned16(g);
+        const int cq = (int)(v4 ? C / 4 : C);
+        const int cw = cq < 256 ? cq : 256, rpb = 256 / cw;
+        const int gy = (cq + cw - 1) / cw;
+        int64_t gx = (P + rpb - 1) / rpb;
+        const int64_t cap = gy >= 512 ? 1 : 512 / gy;
+        if (gx > cap) gx = cap;
+        nparts = (int)gx;
+        if (v4) hipLaunchKernelGGL((absmax_ch_rows_kernel<4>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, g, P, (int)C, cw, rpb, work);
+        else hipLaunchKernelGGL((absmax_ch_rows_kernel<1>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, g, P, (int)C, cw, rpb, work);
+    } else {
+        nparts = (int)(N < 16 ? N : 16);
+        hipLaunchKernelGGL(absmax_ch_strided_kernel, dim3((unsigned)C, (unsigned)nparts), dim3(256), 0, st, g, sn, sc, sh, sw, (int)N,
+                           (int)C, (int)H, (int)W, work);
+    }
+    hipLaunchKernelGGL(absmax_ch_final_kernel, dim3((unsigned)((Cp + 63) / 64)), dim3(256), 0, st, work, nparts, (int)C, (int)Cp, scale2c);
     return qt_check_launch();
 }
 

@@ -86,7 +86,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh_,
                                                            int64_t sw, int N, int Cout, int Wo, int Wq, int Cp, int64_t Qa,
                                                            uint16_t* __restrict__ G3, const float* __restrict__ scale2) {
-    const float inv = (NP == 2 && scale2) ? scale2[1] : 1.0f;
+    const float* inv = NP == 2 ? scale2 + Cp : nullptr;               // 1 / s[c], per channel (split_f16.hip)
     const int c8 = Cp >> 3, items = Wq * c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
     const float* row = g + (int64_t)n * sn + (int64_t)y * sh_;
@@ -106,10 +106,14 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = c0 + i < Cout ? src[(int64_t)i * sc] : 0.0f;
             }
+            if constexpr (NP == 2) {
+                const float4 il = *reinterpret_cast<const float4*>(inv + c0), ih = *reinterpret_cast<const float4*>(inv + c0 + 4);
+                v[0] *= il.x; v[1] *= il.y; v[2] *= il.z; v[3] *= il.w; v[4] *= ih.x; v[5] *= ih.y; v[6] *= ih.z; v[7] *= ih.w;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 uint32_t t[3];
-                pm_split<NP>(v[i] * inv, t);
+                pm_split<NP>(v[i], t);
                 const int s = (i & 1) * 16;
                 h[0][i >> 1] |= t[0] << s;
                 h[1][i >> 1] |= t[1] << s;
@@ -130,7 +134,6 @@ template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __restrict__ g, int64_t sn, int64_t sh_, int64_t sw, int N,
                                                                 int Cout, int Wo, int Wq, int Cp, int64_t Qa, uint16_t* __restrict__ G3,
                                                                 float* __restrict__ bias_part, const float* __restrict__ scale2) {
-    const float inv = (NP == 2 && scale2) ? scale2[1] : 1.0f;
     __shared__ float red[2048];                              // [xpar][Cp] partial sums, xpar * Cp <= 256 * 8
     const int c8 = Cp >> 3, xpar = 256 / c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
@@ -138,6 +141,13 @@ __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __r
     uint16_t* out = G3 + (int64_t)blockIdx.x * Wq * Cp;
     const int t = threadIdx.x, chunk = t % c8, xl = t / c8, c0 = chunk << 3;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float inv[8] = {1, 1, 1, 1, 1, 1, 1, 1};                          // NP == 2: 1 / s[c] of this thread's eight channels
+    if constexpr (NP == 2) {
+        if (xl < xpar) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) inv[i] = scale2[Cp + c0 + i];
+        }
+    }
     if (xl < xpar) {
         for (int x = xl; x < Wq; x += xpar) {
             uint32_t h[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __r
                 for (int i = 0; i < 8; ++i) {
                     acc[i] += v[i];
                     uint32_t t3[3];
-                    pm_split<NP>(v[i] * inv, t3);
+                    pm_split<NP>(NP == 2 ? v[i] * inv[i] : v[i], t3);
                     const int s = (i & 1) * 16;
                     h[0][i >> 1] |= t3[0] << s;
                     h[1][i >> 1] |= t3[1] << s;
@@ -690,7 +700,8 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
 // one work item = one (co, ci, tap): sums the K slices, applies scale and the STE mask, writes / accumulates dW
 __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int taps, int Cpo, int Cpi,
                                                         int Cout, int Cin, const float* __restrict__ weight, float thr,
-                                                        float out_scale, int accumulate, float* __restrict__ dW) {
+                                                        float out_scale, const float* __restrict__ row_scale, int accumulate,
+                                                        float* __restrict__ dW) {
     const int64_t total = (int64_t)taps * Cout * Cin;
     const int64_t slice_elems = (int64_t)taps * Cpo * Cpi;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict_
         float s = 0.0f;
         for (int sl = 0; sl < nslice; ++sl) s += p[sl * slice_elems];
         s *= out_scale;
+        if (row_scale) s *= row_scale[co];                           // the two-plane gradient's per-channel power of two
         const int64_t o = ((int64_t)co * Cin + ci) * taps + tap;
         if (weight && !(fabsf(weight[o]) <= thr)) s = 0.0f;
         dW[o] = accumulate ? dW[o] + s : s;
@@ -878,12 +890,12 @@ int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t
 }
 
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
-                           const float* weight, float ste_threshold, float out_scale, int accumulate, float* dW,
-                           qt_stream_t stream) {
+                           const float* weight, float ste_threshold, float out_scale, const float* row_scale, int accumulate,
+                           float* dW, qt_stream_t stream) {
     if (!part || !dW || nslice <= 0 || taps <= 0 || Cout <= 0 || Cin <= 0 || Cpo < Cout || Cpi < Cin) return QT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(pm_reduce_kernel, dim3(qt_stream_grid((taps * Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        part, (int)nslice, (int)taps, (int)Cpo, (int)Cpi, (int)Cout, (int)Cin, weight, ste_threshold, out_scale,
-                       accumulate, dW);
+                       row_scale, accumulate, dW);
     return qt_check_launch();
 }
 

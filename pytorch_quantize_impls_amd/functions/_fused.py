@@ -712,14 +712,15 @@ def _levels_grad_weight_linear(g2, x2, x_levels, codes_fit: bool):
     """g2^T . x2 for a k-bit image x2 = q / n: codes (or their 256-digits when they left int8) as the exact bf16 operand."""
     inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
     q = torch.round(x2.detach() * float(x_levels))
-    gT = ops.split_bf16x3(g2.t().contiguous())
+    # three exact bf16 terms: a row of g2^T is ONE output feature's gradient (the two-term form's scale is per tensor)
+    gT = ops.split_bf16x3(g2.t().contiguous(), terms=3)
     if codes_fit:
-        return ops.bf16_gemm(gT, ops.weight_bf16x3(q.t().contiguous(), "raw")) * inv
+        return ops.bf16_gemm(gT, ops.weight_bf16x3(q.t().contiguous(), "raw", terms=3)) * inv
     hi = torch.floor(q * (1.0 / 256.0))
     lo = q - hi * 256.0
     bad = torch.where(hi.abs().amax() >= 256.0, float("nan"), 0.0)
-    return (ops.bf16_gemm(gT, ops.weight_bf16x3(hi.t().contiguous(), "raw")) * 256.0
-            + ops.bf16_gemm(gT, ops.weight_bf16x3(lo.t().contiguous(), "raw"))) * inv + bad
+    return (ops.bf16_gemm(gT, ops.weight_bf16x3(hi.t().contiguous(), "raw", terms=3)) * 256.0
+            + ops.bf16_gemm(gT, ops.weight_bf16x3(lo.t().contiguous(), "raw", terms=3))) * inv + bad
 
 
 class DorefaW1LinearFn(torch.autograd.Function):
@@ -994,12 +995,12 @@ BWD_MFMA_MIN_MACS = 1 << 27
 BWD_CONV_MFMA = True
 
 
-def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor) -> torch.Tensor:
-    """a [M, J] (real) @ b_pm1 [J, K] (entries in {-1, 0, +1}) -> [M, K] fp32."""
+def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor, terms=None) -> torch.Tensor:
+    """a [M, J] (real) @ b_pm1 [J, K] (entries in {-1, 0, +1}) -> [M, K] fp32.  ``terms``: split of a (ops.float_linear)."""
     M, J = a.shape
     K = b_pm1.shape[1]
     if a.is_cuda and a.dtype == torch.float32 and M * J * K >= BWD_MFMA_MIN_MACS:
-        return ops.float_linear(a.contiguous(), b_pm1.t().contiguous(), "sign")
+        return ops.float_linear(a.contiguous(), b_pm1.t().contiguous(), "sign", terms=terms)
     return a.mm(b_pm1)
 
 
@@ -1035,7 +1036,8 @@ class QuantLinearFn(torch.autograd.Function):
             grad_input = pm1_matmul(g2, wq).view(input.shape)
         if ctx.needs_input_grad[1]:
             x2 = input.reshape(-1, input.shape[-1])
-            gw = pm1_matmul(g2.t(), x2) if ctx.x_is_pm1 else g2.t().mm(x2)
+            # (rows of g2^T are output features: the exact three-term split, not the per-tensor-scaled two-term one)
+            gw = pm1_matmul(g2.t(), x2, terms=3) if ctx.x_is_pm1 else g2.t().mm(x2)
             grad_weight = ste_mask(gw, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)

@@ -1495,11 +1495,12 @@ def real_conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=1, padd
 
 
 def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, alpha=None,
-                 weight_triples: Optional[TriplePlanes] = None) -> torch.Tensor:
+                 weight_triples: Optional[TriplePlanes] = None, terms: Optional[int] = None) -> torch.Tensor:
     """y = x . Q(weight)^T (+ bias) for REAL-valued x: Q in {safeSign, ternary, torch.sign}; ``alpha``
-    (per input feature) multiplies x first (XNORDense).  fp32-GEMM accuracy on the bf16 matrix cores."""
+    (per input feature) multiplies x first (XNORDense).  fp32-GEMM accuracy on the bf16 matrix cores.  ``terms``: the split
+    of x (default FLOAT_SPLIT; 3 = exact, for an x whose ROWS are separate quantities of very different magnitude)."""
     N = weight.shape[0]
-    xp = split_bf16x3(x, alpha)
+    xp = split_bf16x3(x, alpha, terms=terms)
     wt = weight_triples if (weight_triples is not None and weight_triples.terms == xp.terms) else \
         weight_bf16x3(weight.reshape(N, -1), kind, terms=xp.terms)
     y = bf16_gemm(xp, wt, bias)
@@ -1763,7 +1764,8 @@ def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kerne
         if x_levels != 1.0:
             x2 = torch.round(x2 * float(x_levels))                              # the integer codes: exact in bf16 (<= 255)
         g2 = grad_output.detach().permute(1, 0, 2, 3).reshape(Cout, -1)          # [Cout, P]
-        dW = bf16_gemm(split_bf16x3(g2.contiguous()), weight_bf16x3(x2.contiguous(), "raw"))
+        # (three exact bf16 terms: a row of this GEMM is ONE gradient channel — the two-term form's per-tensor scale is not for it)
+        dW = bf16_gemm(split_bf16x3(g2.contiguous(), terms=3), weight_bf16x3(x2.contiguous(), "raw", terms=3))
         if inv != 1.0:
             dW = dW * inv
         return dW.view(Cout, Cin, 1, 1)
@@ -1996,8 +1998,8 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     ``f16``).  Returns [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget.  ``bias_grad``: a list that
     receives the conv's bias gradient (sum of the gradient over n, y, x) when the gradient pack can produce it on the way
     (channels-last gradient, <= 2048 padded channels) — otherwise it stays empty and the caller reduces the gradient itself.
-    ``terms``: 3 = the gradient as three exact bf16 planes; 2 = two fp16 planes of g / s with the per-tensor power-of-two
-    scale of FLOAT_SPLIT = "f16x2" (the result is multiplied by s at the end; the STE mask only zeroes entries)."""
+    ``terms``: 3 = the gradient as three exact bf16 planes; 2 = two fp16 planes of g[:, c] / s[c] with PER-CHANNEL powers of
+    two s[c] (the reduce multiplies row c of the result by s[c]; the STE mask only zeroes entries)."""
     N, Cin, H, W, kh, kw, ph, pw = geom
     _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
     tn = 64 if kh == 3 else 32
@@ -2021,7 +2023,13 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
     dev = grad_output.device
     g = grad_output.detach()
     two = int(terms) == 2
-    scale2 = pow2_scale(g) if two else None
+    scale2 = None
+    if two:       # per-channel powers of two: a row of dW sees one gradient channel only (csrc/split_f16.hip)
+        scale2 = torch.empty((2 * Cpo,), dtype=torch.float32, device=dev)
+        work = torch.empty((int(_lib.load().qt_f16x2_absmax_ch_work_words(Cout)),), dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.call("qt_f16x2_absmax_scale_ch_f32", _p(g), int(g.stride(0)), int(g.stride(1)), int(g.stride(2)), int(g.stride(3)),
+                      int(N), int(Cout), int(Ho), int(Wo), int(Cpo), _p(work), _p(scale2), _stream(dev))
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
     G3 = torch.empty(((2 if two else 3) * qa_m * Cpo,), dtype=torch.int16, device=dev)
     XP = torch.empty((qx_m * Cpi,), dtype=torch.int16, device=dev)
@@ -2057,9 +2065,7 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
             _lib.call("qt_wgrad_pm_f16" if two else "qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u),
                       I(Cpo), I(Cpi), I(kh), I(kw), st)
             _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
-                      float(ste_threshold), float(out_scale), int(n0 > 0), _p(dW), st)
-    if two:
-        dW = dW * scale2[0]
+                      float(ste_threshold), float(out_scale), _p(scale2), int(n0 > 0), _p(dW), st)
     if want_bias:
         bias_grad.append(db)
     return dW

@@ -44,6 +44,16 @@ def n(t):
     return t.detach().cpu().numpy()
 
 
+_PM_F16 = {"qt_wgrad_pm_f32": "qt_wgrad_pm_f16", "qt_wgrad_pm_pack_grad_f32": "qt_wgrad_pm_pack_grad_f16x2",
+           "qt_wgrad_pm_pack_act_f32": "qt_wgrad_pm_pack_act_f16"}
+
+
+def pm_entry(name):
+    """The pixel-major weight-gradient entry the configured split dispatches for a quantised activation: three bf16 planes
+    (ops.FLOAT_SPLIT == 'bf16x3') or two fp16 planes ('f16x2', the default since round 3)."""
+    return _PM_F16.get(name, name) if ops.split_terms() == 2 else name
+
+
 class used:
     def __init__(self, *names):
         self.names = names
@@ -728,7 +738,7 @@ def test_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, B, kind
     pm_route = ops.wgrad_pm_applicable(xs.shape, y.shape, (k, k), 1, 1)
     gemm_route = not pm_route and ops.wgrad_gemm_applicable(xs.shape, y.shape, (k, k), 1, 1)
     assert pm_route
-    assert used_now.get("qt_wgrad_pm_f32", 0) == (1 if pm_route else 0)
+    assert used_now.get(pm_entry("qt_wgrad_pm_f32"), 0) == (1 if pm_route else 0)
     assert used_now.get("qt_bf16_gemm_taps", 0) == (1 if gemm_route else 0)
     assert used_now.get("qt_conv2d_implicit", 0) >= (2 if (gemm_route or pm_route) else 3)
     assert dict(_fused.LIBRARY_PATHS) == lib_before                                                 # no dense-library detour
@@ -812,7 +822,8 @@ def test_weight_gradient_pixel_major_vs_fp64(dev, N, Cin, Cout, H, W, k, p, cl):
         assert got.shape == want.shape and got.dtype == torch.float32
         assert float(((got.double() - want).abs() / per_channel).max()) <= TOL        # normalised PER OUTPUT CHANNEL
 
-    with used("qt_wgrad_pm_pack_grad_f32", "qt_wgrad_pm_pack_act_f32", "qt_wgrad_pm_f32", "qt_wgrad_pm_reduce_f32"):
+    with used(pm_entry("qt_wgrad_pm_pack_grad_f32"), pm_entry("qt_wgrad_pm_pack_act_f32"), pm_entry("qt_wgrad_pm_f32"),
+              "qt_wgrad_pm_reduce_f32"):
         got = ops.conv2d_grad_weight_pm(x, go, (k, k), p)
     check(got, ref)
     masked = ops.conv2d_grad_weight_pm(x, go, (k, k), p, weight=w)
@@ -911,7 +922,7 @@ def test_alexnet_training_step_matches_the_reference_op_sequence(dev):
         "bench_train_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_train_step.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with used("qt_wgrad_pm_f32", "qt_conv2d_implicit", "qt_nib_gemm"):
+    with used(pm_entry("qt_wgrad_pm_f32"), "qt_conv2d_implicit", "qt_nib_gemm"):
         worst = mod.gradient_agreement(16)
     assert worst <= 2e-5, worst
 
@@ -934,7 +945,7 @@ def test_dorefa_conv_backward_on_matrix_cores_vs_fp64(dev, Cin, Cout, k, pd, H, 
     _fused.BWD_MFMA_MIN_MACS = 0
     lib_before = dict(_fused.LIBRARY_PATHS)
     try:
-        with used("qt_wgrad_pm_f32" if k == 3 else "qt_bf16_gemm_taps", "qt_conv2d_implicit"):
+        with used(pm_entry("qt_wgrad_pm_f32") if k == 3 else "qt_bf16_gemm_taps", "qt_conv2d_implicit"):
             y = conv(xq)
             gout = torch.randn_like(y)
             y.backward(gout)
@@ -994,7 +1005,7 @@ def test_conv_behind_maxpool_keeps_the_matrix_core_weight_gradient(dev):
         xin = pool(BinaryConnectDeterministic.apply(xr))
         assert packed.lookup(xin, packed.NHWC) is None                     # the tag did not survive the pool
         xin.retain_grad()
-        with used("qt_wgrad_pm_f32"):
+        with used(pm_entry("qt_wgrad_pm_f32")):
             y = conv(xin)
             gout = torch.randn_like(y)
             y.backward(gout)
