@@ -163,19 +163,25 @@ __global__ __launch_bounds__(256) void absmax_ch_strided_kernel(const float* __r
     if (threadIdx.x == 0) part[(int64_t)blockIdx.y * C + c] = max(max(sh4[0], sh4[1]), max(sh4[2], sh4[3]));
 }
 
-// part[nparts][C] -> scale2c[2 Cp]: 64 channels x 4 row groups per workgroup
-__global__ __launch_bounds__(256) void absmax_ch_final_kernel(const unsigned* __restrict__ part, int nparts, int C, int Cp,
-                                                              float* __restrict__ scale2c) {
-    __shared__ unsigned sm[4][64];
+// part[nparts][C] -> scale2c[2 Cp]: 64 channels x 16 row groups per workgroup (a thread folds nparts / 16 <= 32 partials)
+__global__ __launch_bounds__(1024) void absmax_ch_final_kernel(const unsigned* __restrict__ part, int nparts, int C, int Cp,
+                                                               float* __restrict__ scale2c) {
+    __shared__ unsigned sm[16][64];
     const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + lc;
     unsigned m = 0;
-    if (c < C)
-        for (int r = rg; r < nparts; r += 4) m = max(m, part[(int64_t)r * C + c]);
+    if (c < C) {
+#pragma unroll 8
+        for (int r = rg; r < nparts; r += 16) m = max(m, part[(int64_t)r * C + c]);
+    }
     sm[rg][lc] = m;
     __syncthreads();
     if (rg == 0 && c < Cp) {
         float pair[2] = {1.0f, 1.0f};
-        if (c < C) write_scale(__uint_as_float(max(max(sm[0][lc], sm[1][lc]), max(sm[2][lc], sm[3][lc]))), pair);
+        if (c < C) {
+#pragma unroll
+            for (int j = 1; j < 16; ++j) m = max(m, sm[j][lc]);
+            write_scale(__uint_as_float(m), pair);
+        }
         scale2c[c] = pair[0];
         scale2c[Cp + c] = pair[1];
     }
@@ -338,7 +344,7 @@ extern "C" int qt_f16x2_absmax_scale_ch_f32(const float* g, int64_t sn, int64_t 
         hipLaunchKernelGGL(absmax_ch_strided_kernel, dim3((unsigned)C, (unsigned)nparts), dim3(256), 0, st, g, sn, sc, sh, sw, (int)N,
                            (int)C, (int)H, (int)W, work);
     }
-    hipLaunchKernelGGL(absmax_ch_final_kernel, dim3((unsigned)((Cp + 63) / 64)), dim3(256), 0, st, work, nparts, (int)C, (int)Cp, scale2c);
+    hipLaunchKernelGGL(absmax_ch_final_kernel, dim3((unsigned)((Cp + 63) / 64)), dim3(1024), 0, st, work, nparts, (int)C, (int)Cp, scale2c);
     return qt_check_launch();
 }
 

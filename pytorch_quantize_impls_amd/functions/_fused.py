@@ -641,9 +641,8 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
         N_, _, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-        y2 = ops.float_conv2d(input.detach(), weight.detach(), "binary", None, stride, padding, dilation) * E
-        if bias is not None:
-            y2 = y2 + bias.detach()
+        y2 = ops.float_conv2d(input.detach(), weight.detach(), "binary", bias.detach() if bias is not None else None, stride,
+                              padding, dilation, out_scale_dev=E)
         y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
         if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous()
@@ -780,7 +779,8 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
             if codes is not None and codes.K == input.shape[1]:
                 ctx.x_levels = float((1 << int(codes.bit_width)) - 1)
         route = []
-        y = dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False, route=route)
+        ctx.E = _dorefa_w1_scale(weight, False) if input.is_cuda else None     # mean|W|: the backward scales grad_x by it again
+        y = dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False, route=route, scale=ctx.E)
         ctx.codes_fit = route == ["codes"]
         return y
 
@@ -794,11 +794,9 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
             sgn = quantize_weight_f32(weight, "binary")
-            E = weight.abs().mean()
+            E = ctx.E if ctx.E is not None else weight.abs().mean()
             if mfma:     # g * (sign(W) E) = E * (g * sign(W)): the exact-split conv on the flipped +-1 weight, scaled after
-                grad_input = ops.conv2d_grad_input_q(input.shape, sgn, go, stride, padding, dilation)
-                if grad_input is not None:
-                    grad_input = grad_input * E
+                grad_input = ops.conv2d_grad_input_q(input.shape, sgn, go, stride, padding, dilation, out_scale_dev=E)
             if grad_input is None:
                 note_library_path(go, "conv grad_input outside the matrix-core route")
                 grad_input = torch.nn.grad.conv2d_input(input.shape, sgn * E, go, stride=stride, padding=padding,
@@ -891,10 +889,9 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         if y is None and ok and FLOAT_PATH == "bf16x3" and input.numel() > 0:
             N_, _, H, W = input.shape
             Ho, Wo = ops.conv_out_hw(H, W, int(weight_q.shape[2]), int(weight_q.shape[3]), stride, padding, dilation)
-            y2 = ops.float_conv2d(input.detach(), _weight_levels(weight_q, bit_width), "raw", None, stride, padding, dilation)
-            y2 = y2 * _inv_levels(bit_width)
-            if bias is not None:
-                y2 = y2 + bias.detach()
+            y2 = ops.float_conv2d(input.detach(), _weight_levels(weight_q, bit_width), "raw",
+                                  bias.detach() if bias is not None else None, stride, padding, dilation,
+                                  out_scale=_inv_levels(bit_width))
             y = y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous()
@@ -915,9 +912,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if mfma:
                 grad_input = ops.conv2d_grad_input_q(input.shape, _weight_levels(weight_q, k), go, stride, padding, dilation,
-                                                     kind="raw")
-                if grad_input is not None:
-                    grad_input = grad_input * _inv_levels(k)
+                                                     kind="raw", out_scale=_inv_levels(k))
             if grad_input is None:
                 note_library_path(go, "conv grad_input outside the matrix-core route")
                 grad_input = torch.nn.grad.conv2d_input(input.shape, weight_q, go, stride=stride, padding=padding,

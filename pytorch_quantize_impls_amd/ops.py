@@ -1552,10 +1552,12 @@ def s2d_triple_pack(x: torch.Tensor, s: int, padding, terms: Optional[int] = Non
 
 def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0,
                  dilation=1, weight_triples: Optional[TriplePlanes] = None, pixels: Optional[TriplePlanes] = None,
-                 in_shape=None, epi=None):
+                 in_shape=None, epi=None, out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None):
     """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
     implicit-GEMM conv on the bf16 matrix cores.  ``pixels``/``in_shape``: pre-built pixel planes (e.g. from
-    s2d_triple_pack) instead of x.  Returns NHWC [N*Ho*Wo, Cout]."""
+    s2d_triple_pack) instead of x.  ``out_scale`` (host float) / ``out_scale_dev`` (one-element device tensor, e.g. DoReFa's
+    E = mean|W|): multiply the contraction in the kernel's epilogue, before the bias — no extra pass over the result.
+    Returns NHWC [N*Ho*Wo, Cout]."""
     if pixels is None:
         _require(x, "input")
         N, C, H, W = (int(v) for v in x.shape)
@@ -1586,9 +1588,13 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     M = N * Ho * Wo
     dev = x.device
     bias = _check_bias(bias, Cout, dev)
+    sdev = px.scale[0:1] if px.scale is not None else None
+    if out_scale_dev is not None:
+        osd = _require(out_scale_dev.detach(), "out_scale_dev").reshape(1)
+        sdev = osd if sdev is None else sdev * osd                     # (the split's scale is a power of two: exact)
     if CONV_IMPLICIT:
         y = _conv_implicit(px.elem, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
-                           1.0, (px.scale[0:1] if px.scale is not None else None), Cout, epi=epi)
+                           float(out_scale), sdev, Cout, epi=epi)
         if y is not None:
             return y
     if epi is not None:
@@ -1604,12 +1610,16 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
             _lib.call("qt_im2col_words", _p(px.data), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw),
                       I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
             if terms == 2:
-                _lib.call("qt_f16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), 1.0,
-                          _p(px.scale[0:1] if px.scale is not None else None), _p(y[m0:m0 + cnt]), I(Cout), I(cnt), I(Cout),
-                          I(kel), _stream(dev))
+                _lib.call("qt_f16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), float(out_scale),
+                          _p(sdev), _p(y[m0:m0 + cnt]), I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
             else:
-                _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias), _p(y[m0:m0 + cnt]),
-                          I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
+                plain = sdev is None and float(out_scale) == 1.0
+                _lib.call("qt_bf16_gemm", _p(A), I(ldA), _p(wt.data), I(wt.ld_words), _p(bias if plain else None),
+                          _p(y[m0:m0 + cnt]), I(Cout), I(cnt), I(Cout), I(kel), _stream(dev))
+    if terms != 2 and not (sdev is None and float(out_scale) == 1.0):
+        y = y * (float(out_scale) if sdev is None else sdev * float(out_scale))
+        if bias is not None:
+            y = y + bias
     return y
 
 
@@ -1690,15 +1700,16 @@ def pool_bn_sign_train_backward(grad_out: torch.Tensor, saved, gamma, beta, ht, 
 # Reference expressions: functions/binary_connect.py:141-143 (torch.nn.grad.conv2d_input / conv2d_weight).
 
 def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation,
-                        kind: str = "sign"):
+                        kind: str = "sign", out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None):
     """grad wrt the input of conv2d(x, weight_q) for a weight_q that is exact in bf16 — +-1 / 0 (``kind`` "sign") or integer
     levels (``kind`` "raw": the k-bit DoReFa levels c = n * w_q, the caller scales by 1 / n): the forward's exact-split conv
     of the gradient with the flipped, transposed weight.  Stride 1 directly; stride s > 1 (square, un-dilated — the
     3x3 / stride-2 and 1x1 / stride-2 convs of the reference's ResNets, models/Resnet/Resnet_bin.py:20-33) through the
     zero-dilated gradient: g_d[.., s y, s x] = g[.., y, x], zeros elsewhere and ``H + 2p - k - (Ho - 1) s`` rows / columns of
     zeros appended, which turns conv_transpose(g, W, stride s) into the stride-1 conv above (3/4 of its products are with the
-    inserted zeros; these layers are the small ones).  None when the shape is outside the route (dilation != 1,
-    padding > k - 1, non-square stride): the caller uses torch.nn.grad.conv2d_input."""
+    inserted zeros; these layers are the small ones).  ``out_scale`` / ``out_scale_dev``: see ``float_conv2d`` (1 / n of the
+    levels, DoReFa's E).  None when the shape is outside the route (dilation != 1, padding > k - 1, non-square stride): the
+    caller uses torch.nn.grad.conv2d_input."""
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Cout, Cin, kh, kw = (int(v) for v in weight_q.shape)
     if (dh, dw) != (1, 1) or sh != sw or sh < 1 or ph > kh - 1 or pw > kw - 1:
@@ -1715,7 +1726,7 @@ def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.
         gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = g.permute(0, 2, 3, 1)
         g = gd.permute(0, 3, 1, 2)
     wT = weight_q.detach().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, kh, kw]
-    y2 = float_conv2d(g, wT, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+    y2 = float_conv2d(g, wT, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1, out_scale=out_scale, out_scale_dev=out_scale_dev)
     return y2.view(N, H, W, C).permute(0, 3, 1, 2)
 
 
