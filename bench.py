@@ -771,6 +771,35 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "gradient_parity": "tests/test_gpu_r3.py::test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence and "
                                "::test_alexnet_training_step_with_the_fused_training_chain (<= 1e-5 normalised vs fp64 on the CPU)"}
         del mt, xt
+        # C4's network in training mode (models/Resnet/Resnet_bin.py:63-97 shapes: 3 x 32 x 32): the module graph (DorefaConv2d
+        # forward / backward on this backend, BatchNorm / relu / add are torch's and MIOpen's) and the form with every
+        # BatchNorm [+ shortcut] -> ReLU -> quantiser run as one FusedTrainBnActQuant node (csrc/train_chain.hip)
+        try:
+            torch.manual_seed(0)
+            mr = bench_models.DorefaResNet18(w_bits=1, a_bits=4).to(dev).to(memory_format=torch.channels_last).train()
+            xr = torch.randn(Bt, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+            before = dict(_fused_library_paths())
+            lsm = lambda net: (lambda t: torch.nn.functional.log_softmax(net(t), 1))      # noqa: E731
+            t_r, loss_r = bts.step_time(lsm(mr), mr, xr, tt, n=10)
+            t_rf, loss_rf = bts.step_time(lsm(bench_models.TrainFusedDorefaResNet18(mr)), mr, xr, tt, n=10)
+            lib_r = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
+            out["n2_training_step_dorefa_resnet18_w1a4"] = {
+                "workload": f"DoReFa ResNet-18 W1A4 3x32x32 batch {Bt}, training mode, forward + backward (nll loss), channels_last; "
+                            "fp32 stem conv and classifier are torch's, as in the reference",
+                "ms_per_step": t_r, "images_per_s": Bt / t_r * 1e3, "loss": loss_r,
+                "with_fused_training_chain": {"ms_per_step": t_rf, "images_per_s": Bt / t_rf * 1e3, "loss": loss_rf,
+                                              "what": "bench_models.TrainFusedDorefaResNet18: BatchNorm(batch statistics) + shortcut add + "
+                                                      "ReLU + k-bit quantiser forward + backward as one node per conv "
+                                                      "(layers.FusedTrainBnActQuant, opt-in)"},
+                "dense_library_calls_in_the_steps": lib_r,
+                "note": "many small launches (3 x 32 x 32 maps): ~1100 kernels per step in the module graph; "
+                        "tools/probes/train_resnet_prof.py has the per-kernel split",
+                "gradient_parity": "tests/test_gpu_r3.py::test_dorefa_kbit_conv_training_vs_fp64, "
+                                   "::test_dorefa_training_chain_vs_fp64_of_the_module_chain (<= 1e-5 normalised vs fp64), "
+                                   "::test_dorefa_resnet18_training_step_with_the_fused_training_chain"}
+            del mr, xr
+        except Exception as exc:        # never take the line down
+            out["n2_training_step_dorefa_resnet18_w1a4"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif args.train_batch and world > 1:
         # data-parallel step, one process per GPU: per-GPU batch fixed (weak scaling), gradients averaged by the bucketed
         # all-reduce of utils/data_parallel.py (RCCL over xGMI) issued after backward (overlap=False, see below).  BatchNorm

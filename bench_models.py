@@ -235,3 +235,37 @@ class TrainFusedAlexNetBin(nn.Module):
     def forward(self, x):
         x = self.features(x)
         return self.classifieur(x.reshape(x.size(0), 256 * 6 * 6))
+
+
+class _TrainFusedDorefaBlock(nn.Module):
+    """_DorefaBlock for TRAINING with BatchNorm (+ shortcut add + ReLU + quantiser) behind every conv as one
+    layers.FusedTrainBnActQuant node (shares the block's convs and BatchNorm modules)."""
+
+    def __init__(self, blk: _DorefaBlock, a_bits: int):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import FusedTrainBnActQuant
+        self.conv1, self.conv2 = blk.conv1, blk.conv2
+        self.q1 = FusedTrainBnActQuant(blk.bn1, a_bits, relu=True)
+        self.q2 = FusedTrainBnActQuant(blk.bn2, a_bits, relu=True)
+        self.sc_conv = blk.shortcut[0] if blk.shortcut is not None else None
+        self.sc_bn = FusedTrainBnActQuant(blk.shortcut[1]) if blk.shortcut is not None else None
+
+    def forward(self, x):
+        res = x if self.sc_conv is None else self.sc_bn(self.sc_conv(x))
+        return self.q2(self.conv2(self.q1(self.conv1(x))), residual=res)
+
+
+class TrainFusedDorefaResNet18(nn.Module):
+    """DorefaResNet18 for TRAINING on the fused BatchNorm chains (shares all parameters / buffers with ``model``)."""
+
+    def __init__(self, model: DorefaResNet18, a_bits: int = 4):
+        super().__init__()
+        from pytorch_quantize_impls_amd.layers import FusedTrainBnActQuant
+        self.stem, self.linear = model.stem, model.linear
+        self.q0 = FusedTrainBnActQuant(model.bn, a_bits, relu=True)
+        self.blocks = nn.Sequential(*[_TrainFusedDorefaBlock(b, a_bits) for b in model.blocks])
+
+    def forward(self, x):
+        out = self.blocks(self.q0(self.stem(x)))
+        out = torch.nn.functional.avg_pool2d(out, 4)
+        return self.linear(out.reshape(out.size(0), -1))

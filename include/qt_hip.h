@@ -461,6 +461,21 @@ int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p_or_x, cons
                                        const float* mean, const float* invstd, float ht_lo, float ht_hi, float ste_threshold,
                                        float* partial, float* dgamma, float* dbeta, float* gp, float* gx, qt_stream_t stream);
 
+/* Training-mode form of the chain between two DoReFa layers (reference: models/Resnet/Resnet_bin.py:63-97 —
+ * conv -> BatchNorm2d (batch statistics) [+ shortcut] -> ReLU -> nnDorefaQuant; functions/dorefa_connect.py:28-45 identity STE),
+ * over channels-last fp32 pixels x[R][C], C % 4 == 0.
+ *   qt_bn_train_stats_f32        : stats2 = [mean[C] | invstd[C]] (biased variance, two passes, folded in double) + the running
+ *                                  statistics update (NULL: skipped).  The forward's second half is qt_affine_dorefa_codes_i8 with
+ *                                  alpha / beta = BatchNorm weight / bias and bn_stats = stats2 (codes, fp32 image, residual, ReLU).
+ *   qt_bn_act_train_backward_f32 : t = fma((x - mean) * invstd, gamma, beta) + res (res NULL: 0); g_t = g * 1[t > 0] when relu,
+ *                                  else g; dgamma = sum g_t xhat, dbeta = sum g_t, gx = gamma invstd (g_t - dbeta / R -
+ *                                  xhat dgamma / R), gres (optional) = g_t.  partial: qt_train_chain_partial_floats(R, C) floats. */
+int qt_bn_train_stats_f32(const float* x, int64_t R, int64_t C, float eps, float momentum, float* running_mean,
+                          float* running_var, float* stats2, float* partial, qt_stream_t stream);
+int qt_bn_act_train_backward_f32(const float* g, const float* x, const float* res, int64_t R, int64_t C, const float* gamma,
+                                 const float* beta, const float* stats2, int relu, float* partial, float* dgamma, float* dbeta,
+                                 float* gx, float* gres, qt_stream_t stream);
+
 /* Y[M,N] = Xh . Wh^T (+ bias) over K bf16 elements per row (K = 3 * features for triple planes);
  * ld in uint32 words. */
 int qt_bf16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias,

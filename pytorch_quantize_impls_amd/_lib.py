@@ -112,6 +112,8 @@ SIGNATURES = {
     "qt_f16x2_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_train_chain_partial_floats": (_c_i64, [_c_i64, _c_i64]),
+    "qt_bn_train_stats_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_f32, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "qt_bn_act_train_backward_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_int] + [_c_p] * 6),
     "qt_pool_bn_sign_train_f32": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p, _c_f32, _c_f32, _c_f32, _c_f32] + [_c_p] * 9),
     "qt_pool_bn_sign_train_backward_f32": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 6 + [_c_p] * 4 + [_c_f32] * 3 + [_c_p] * 6),
     "qt_bf16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -136,6 +136,15 @@ __global__ __launch_bounds__(1024) void fold_kernel(const float* __restrict__ pa
     if (threadIdx.y == 0 && c < C) out[c] = (float)(s * scale);
 }
 
+// two folds in one launch (dbeta and dgamma of a backward): blockIdx.y picks the pair
+__global__ __launch_bounds__(1024) void fold2_kernel(const float* __restrict__ part_a, const float* __restrict__ part_b, int nblk, int C,
+                                                     float* __restrict__ out_a, float* __restrict__ out_b) {
+    __shared__ double sh[TC_FY][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const double s = fold_partials(blockIdx.y ? part_b : part_a, nblk, C, c, sh);
+    if (threadIdx.y == 0 && c < C) (blockIdx.y ? out_b : out_a)[c] = (float)s;
+}
+
 // var partials -> invstd, running statistics
 __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict__ part, int nblk, int C, double R, float eps,
                                                         float momentum, const float* __restrict__ mean, float* __restrict__ invstd,
@@ -273,6 +282,73 @@ __global__ __launch_bounds__(1024) void pool_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- DoReFa chain: BatchNorm (batch statistics) [+ residual] [-> ReLU] -> nnDorefaQuant (identity STE) ------------------------------
+// (models/Resnet/Resnet_bin.py:63-97: every block of the reference's DoReFa ResNets.)  Forward = the statistics launches above
+// + the code epilogue pass (csrc/codes_i8.hip: qt_affine_dorefa_codes_i8 with bn_stats = [mean | invstd]); backward of
+//     t = fma((x - mean) * invstd, gamma, beta) [+ res] ;  out = quant(relu(t))          (the forward pass's own expression)
+//     g_t = g * 1[t > 0] (ReLU; the quantiser's STE is the identity) ;  g_res = g_t ;  BatchNorm backward on g_t as above.
+__device__ __forceinline__ float act_gt(float g, float v, float mu, float is, float ga, float be, float res, int relu) {
+    const float t = __fadd_rn(__fmaf_rn(__fmul_rn(__fsub_rn(v, mu), is), ga, be), res);
+    return (relu && !(t > 0.0f)) ? 0.0f : g;
+}
+
+__global__ __launch_bounds__(1024) void act_bwd_sum_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ res, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu, float* __restrict__ part_b,
+                                                          float* __restrict__ part_g, int64_t R, int C, int rows_per_block) {
+    __shared__ float4 sh[TC_TY][TC_TX];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    for (int c0 = 0; c0 < C; c0 += 4 * TC_TX) {
+        const int c = c0 + 4 * threadIdx.x;
+        const bool live = c < C;
+        float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+        if (live) {
+            const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4_or(gamma ? gamma + c : nullptr, 1.0f),
+                         be = ld4_or(beta ? beta + c : nullptr, 0.0f);
+            for (int64_t r = r0 + threadIdx.y; r < r1; r += TC_TY) {
+                const float4 v = ld4(x + r * C + c), gv = ld4(g + r * C + c), rv = ld4_or(res ? res + r * C + c : nullptr, 0.0f);
+                const float gx_ = act_gt(gv.x, v.x, mu.x, is.x, ga.x, be.x, rv.x, relu), gy_ = act_gt(gv.y, v.y, mu.y, is.y, ga.y, be.y, rv.y, relu),
+                            gz_ = act_gt(gv.z, v.z, mu.z, is.z, ga.z, be.z, rv.z, relu), gw_ = act_gt(gv.w, v.w, mu.w, is.w, ga.w, be.w, rv.w, relu);
+                sb.x += gx_; sb.y += gy_; sb.z += gz_; sb.w += gw_;
+                sg.x += gx_ * ((v.x - mu.x) * is.x); sg.y += gy_ * ((v.y - mu.y) * is.y);
+                sg.z += gz_ * ((v.z - mu.z) * is.z); sg.w += gw_ * ((v.w - mu.w) * is.w);
+            }
+        }
+        fold_rows_store(sb, part_b + (int64_t)blockIdx.x * C + (live ? c : 0), sh, live);
+        fold_rows_store(sg, part_g + (int64_t)blockIdx.x * C + (live ? c : 0), sh, live);
+    }
+}
+
+__global__ __launch_bounds__(1024) void act_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ res, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                         const float* __restrict__ dbeta, int relu, float invR,
+                                                         float* __restrict__ gx, float* __restrict__ gres, int64_t R, int C,
+                                                         int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    for (int c = 4 * threadIdx.x; c < C; c += 4 * TC_TX) {
+        const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4_or(gamma ? gamma + c : nullptr, 1.0f),
+                     be = ld4_or(beta ? beta + c : nullptr, 0.0f), dg = ld4(dgamma + c), db = ld4(dbeta + c);
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += TC_TY) {
+            const float4 v = ld4(x + r * C + c), gv = ld4(g + r * C + c), rv = ld4_or(res ? res + r * C + c : nullptr, 0.0f);
+            float4 gt;
+            gt.x = act_gt(gv.x, v.x, mu.x, is.x, ga.x, be.x, rv.x, relu); gt.y = act_gt(gv.y, v.y, mu.y, is.y, ga.y, be.y, rv.y, relu);
+            gt.z = act_gt(gv.z, v.z, mu.z, is.z, ga.z, be.z, rv.z, relu); gt.w = act_gt(gv.w, v.w, mu.w, is.w, ga.w, be.w, rv.w, relu);
+            if (gres) *reinterpret_cast<float4*>(gres + r * C + c) = gt;
+            float4 o;
+            o.x = ga.x * is.x * (gt.x - db.x * invR - (v.x - mu.x) * is.x * dg.x * invR);
+            o.y = ga.y * is.y * (gt.y - db.y * invR - (v.y - mu.y) * is.y * dg.y * invR);
+            o.z = ga.z * is.z * (gt.z - db.z * invR - (v.z - mu.z) * is.z * dg.z * invR);
+            o.w = ga.w * is.w * (gt.w - db.w * invR - (v.w - mu.w) * is.w * dg.w * invR);
+            *reinterpret_cast<float4*>(gx + r * C + c) = o;
+        }
+    }
+}
+
 int rows_per_block_for(int64_t R, int* nblk) {
     int64_t rpb = (R + 511) / 512;                          // ~512 workgroups of 1024 threads: few partials to fold
     if (rpb < TC_TY) rpb = TC_TY;
@@ -334,8 +410,7 @@ extern "C" int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p
     hipLaunchKernelGGL(bwd_sum_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, p_or_x, g, mean, invstd, gamma, beta, ht_lo, ht_hi, ste_threshold,
                        part_b, part_g, R, (int)C, rpb);
     const int cg = (int)((C + 63) / 64);
-    hipLaunchKernelGGL(fold_kernel, dim3(cg), dim3(64, TC_FY), 0, st, part_b, nblk, (int)C, 1.0, dbeta);
-    hipLaunchKernelGGL(fold_kernel, dim3(cg), dim3(64, TC_FY), 0, st, part_g, nblk, (int)C, 1.0, dgamma);
+    hipLaunchKernelGGL(fold2_kernel, dim3(cg, 2), dim3(64, TC_FY), 0, st, part_b, part_g, nblk, (int)C, dbeta, dgamma);
     hipLaunchKernelGGL(bwd_dx_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, p_or_x, g, mean, invstd, gamma, beta, dgamma, dbeta, ht_lo,
                        ht_hi, ste_threshold, (float)(1.0 / (double)R), gp, R, (int)C, rpb);
     if (k > 1) {
@@ -344,5 +419,51 @@ extern "C" int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p
         hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk_x), dim3(TC_TX, TC_TY), 0, st, gp, idx, gx, N * H * W, (int)H, (int)W, (int)C,
                            (int)k, (int)s, Ho, Wo, rpb_x);
     }
+    return qt_check_launch();
+}
+
+// Batch statistics of an fp32 [R][C] matrix (channels-last pixels x channels): mean, invstd = 1 / sqrt(var + eps) (biased variance,
+// two passes, partials folded in double) and the running-statistics update of nn.BatchNorm2d.train().  stats2 = [mean | invstd]
+// (the layout the code epilogue's bn_stats takes).
+extern "C" int qt_bn_train_stats_f32(const float* x, int64_t R, int64_t C, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* stats2, float* partial, qt_stream_t stream) {
+    if (R <= 0 || C <= 0 || !x || !stats2 || !partial) return QT_ERR_INVALID_ARG;
+    if (R * C >= (1ll << 40) || C > (1 << 24)) return QT_ERR_UNSUPPORTED;
+    if ((C & 3) || !qt_aligned16(x)) return QT_ERR_ALIGNMENT;
+    int nblk;
+    const int rpb = rows_per_block_for(R, &nblk);
+    hipStream_t st = (hipStream_t)stream;
+    float* mean = stats2;
+    float* invstd = stats2 + C;
+    hipLaunchKernelGGL(pool_sum_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, x, (float*)nullptr, (int8_t*)nullptr, partial, R, 1, 1,
+                       (int)C, 1, 1, 1, 1, rpb);
+    const int cg = (int)((C + 63) / 64);
+    hipLaunchKernelGGL(fold_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, 1.0 / (double)R, mean);
+    hipLaunchKernelGGL(sqdev_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, x, mean, partial, R, (int)C, rpb);
+    hipLaunchKernelGGL(finalize_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, (double)R, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+    return qt_check_launch();
+}
+
+// Backward of out = quant(relu?(BatchNorm_train(x) [+ res])) w.r.t. x, gamma, beta and res (see act_gt above): gx[R][C], dgamma[C],
+// dbeta[C] and, when gres != NULL, gres[R][C] = g * 1[t > 0] (the gradient that flows on into the shortcut branch).
+extern "C" int qt_bn_act_train_backward_f32(const float* g, const float* x, const float* res, int64_t R, int64_t C, const float* gamma,
+                                            const float* beta, const float* stats2, int relu, float* partial, float* dgamma,
+                                            float* dbeta, float* gx, float* gres, qt_stream_t stream) {
+    if (R <= 0 || C <= 0 || !g || !x || !stats2 || !partial || !dgamma || !dbeta || !gx) return QT_ERR_INVALID_ARG;
+    if (C & 3) return QT_ERR_ALIGNMENT;
+    int nblk;
+    const int rpb = rows_per_block_for(R, &nblk);
+    hipStream_t st = (hipStream_t)stream;
+    const float* mean = stats2;
+    const float* invstd = stats2 + C;
+    float* part_b = partial;
+    float* part_g = partial + (int64_t)nblk * C;
+    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, x, g, res, mean, invstd, gamma, beta, relu, part_b, part_g,
+                       R, (int)C, rpb);
+    const int cg = (int)((C + 63) / 64);
+    hipLaunchKernelGGL(fold2_kernel, dim3(cg, 2), dim3(64, TC_FY), 0, st, part_b, part_g, nblk, (int)C, dbeta, dgamma);
+    hipLaunchKernelGGL(act_bwd_dx_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, x, g, res, mean, invstd, gamma, beta, dgamma, dbeta, relu,
+                       (float)(1.0 / (double)R), gx, gres, R, (int)C, rpb);
     return qt_check_launch();
 }

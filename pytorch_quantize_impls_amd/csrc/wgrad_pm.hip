@@ -697,25 +697,36 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
     }
 }
 
-// one work item = one (co, ci, tap): sums the K slices, applies scale and the STE mask, writes / accumulates dW
-__global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int taps, int Cpo, int Cpi,
+// one work item = one (co, ci) with all its taps: sums the K slices (reads coalesced along ci), applies the scales and the STE
+// mask, writes / accumulates the T consecutive values dW[co][ci][0..T) (one (co, ci, tap) per thread scattered 4-byte writes
+// 4 T bytes apart: 37 us for a 512 x 512 x 9 layer, twice what the bytes need)
+template <int T>
+__global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int Cpo, int Cpi,
                                                         int Cout, int Cin, const float* __restrict__ weight, float thr,
                                                         float out_scale, const float* __restrict__ row_scale, int accumulate,
                                                         float* __restrict__ dW) {
-    const int64_t total = (int64_t)taps * Cout * Cin;
-    const int64_t slice_elems = (int64_t)taps * Cpo * Cpi;
+    const int64_t total = (int64_t)Cout * Cin;
+    const int64_t tap_elems = (int64_t)Cpo * Cpi, slice_elems = (int64_t)T * tap_elems;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(t % Cin);
-        const int64_t r = t / Cin;
-        const int co = (int)(r % Cout), tap = (int)(r / Cout);
-        const float* p = part + ((int64_t)tap * Cpo + co) * Cpi + ci;
-        float s = 0.0f;
-        for (int sl = 0; sl < nslice; ++sl) s += p[sl * slice_elems];
-        s *= out_scale;
-        if (row_scale) s *= row_scale[co];                           // the two-plane gradient's per-channel power of two
-        const int64_t o = ((int64_t)co * Cin + ci) * taps + tap;
-        if (weight && !(fabsf(weight[o]) <= thr)) s = 0.0f;
-        dW[o] = accumulate ? dW[o] + s : s;
+        const int ci = (int)(t % Cin), co = (int)(t / Cin);
+        const float* p = part + (int64_t)co * Cpi + ci;
+        float acc[T];
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) acc[tap] = 0.0f;
+        for (int sl = 0; sl < nslice; ++sl) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) acc[tap] += p[sl * slice_elems + tap * tap_elems];
+        }
+        const float rs = row_scale ? row_scale[co] : 1.0f;          // the two-plane gradient's per-channel power of two
+        float* o = dW + t * T;
+        const float* w = weight ? weight + t * T : nullptr;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            float v = acc[tap] * out_scale;
+            if (row_scale) v *= rs;
+            if (w && !(fabsf(w[tap]) <= thr)) v = 0.0f;
+            o[tap] = accumulate ? o[tap] + v : v;
+        }
     }
 }
 
@@ -893,9 +904,14 @@ int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int6
                            const float* weight, float ste_threshold, float out_scale, const float* row_scale, int accumulate,
                            float* dW, qt_stream_t stream) {
     if (!part || !dW || nslice <= 0 || taps <= 0 || Cout <= 0 || Cin <= 0 || Cpo < Cout || Cpi < Cin) return QT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(pm_reduce_kernel, dim3(qt_stream_grid((taps * Cout * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       part, (int)nslice, (int)taps, (int)Cpo, (int)Cpi, (int)Cout, (int)Cin, weight, ste_threshold, out_scale,
-                       row_scale, accumulate, dW);
+    if (taps != 9 && taps != 25) return QT_ERR_UNSUPPORTED;       // the kernels this reduce serves: 3 x 3 and 5 x 5
+    const dim3 grid(qt_stream_grid((Cout * Cin + 255) / 256));
+    if (taps == 9)
+        hipLaunchKernelGGL((pm_reduce_kernel<9>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
+                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW);
+    else
+        hipLaunchKernelGGL((pm_reduce_kernel<25>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
+                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW);
     return qt_check_launch();
 }
 

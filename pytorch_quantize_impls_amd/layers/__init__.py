@@ -6,5 +6,5 @@ from .terner_layers import LinearTer, TerConv2d
 from .xnor_layers import LinearXNOR, XNORConv2d
 from .log_lin_layers import LinearQuant, QuantConv2d
 from .common import QLayer
-from .fused import (FusedTrainPoolBnSign, fuse_sequential_training, CodeMaxPool, FusedBnDorefaQuant, FusedDorefaConvBnQuant, FusedPoolBnSign, FusedConvPoolBnSign, FusedFeatureClassifier, PackedMaxPool, fuse_sequential, fold_batchnorm,
+from .fused import (FusedTrainPoolBnSign, FusedTrainBnActQuant, fuse_sequential_training, CodeMaxPool, FusedBnDorefaQuant, FusedDorefaConvBnQuant, FusedPoolBnSign, FusedConvPoolBnSign, FusedFeatureClassifier, PackedMaxPool, fuse_sequential, fold_batchnorm,
                     permute_fc_weight_hwc)

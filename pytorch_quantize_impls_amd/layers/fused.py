@@ -663,6 +663,89 @@ class FusedTrainPoolBnSign(torch.nn.Module):
         return out
 
 
+class _TrainBnActQuantFn(torch.autograd.Function):
+    """BatchNorm (batch statistics) [+ residual] [-> ReLU] [-> nnDorefaQuant(k)] as one autograd node on this backend's kernels
+    (ops.bn_train_stats + ops.affine_dorefa_codes / bn_eval_device forward, ops.bn_act_train_backward); see FusedTrainBnActQuant."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu, bits):
+        xs, stats2 = ops.bn_train_stats(x, running_mean, running_var, eps, momentum)
+        C = int(x.shape[1])
+        x2 = xs.view(-1, C)
+        dev = x.device
+        g_ = gamma.detach() if gamma is not None else torch.ones((C,), dtype=torch.float32, device=dev)
+        b_ = beta.detach() if beta is not None else torch.zeros((C,), dtype=torch.float32, device=dev)
+        rs = None
+        if res is not None:
+            rs = ops._rows_view(res.detach())[0]
+        four = x.dim() == 4
+        if bits:
+            cp, y = ops.affine_dorefa_codes(x2, g_, b_, bits, relu=bool(relu), res_f32=rs.view(-1, C) if rs is not None else None,
+                                            want_f32=True, ld_bytes=ops.code_ld_bytes(C, 16) if four else None, bn_stats=stats2)
+        else:
+            y = ops.bn_eval_device(x2, g_, b_, stats2)
+        ctx.saved_chain = (xs, rs, stats2)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(gamma, beta)
+        ctx.x_nchw = four and x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)
+        if four:
+            N, _, H, W = x.shape
+            out = y.view(N, H, W, C).permute(0, 3, 1, 2)
+            return packed.attach_codes(out, cp, packed.NHWC) if bits else out
+        out = y.view(x.shape)
+        return packed.attach_codes(out, cp, packed.ROWS_LAST) if bits else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gamma, beta = ctx.saved_tensors
+        xs, rs, stats2 = ctx.saved_chain
+        want_res = rs is not None and ctx.needs_input_grad[1]
+        gx, dgamma, dbeta, gres = ops.bn_act_train_backward(grad_out, xs, rs, gamma, beta, stats2, ctx.relu, want_res)
+        if ctx.x_nchw:
+            gx = gx.contiguous()
+            gres = gres.contiguous() if gres is not None else None
+        return (gx, gres, dgamma if gamma is not None else None, dbeta if beta is not None else None) + (None,) * 6
+
+
+class FusedTrainBnActQuant(torch.nn.Module):
+    """TRAINING-mode form of BatchNorm{1,2}d [+ residual] [-> ReLU] [-> nnDorefaQuant(k)] — what the reference puts behind every
+    DorefaConv2d of its ResNets (models/Resnet/Resnet_bin.py:63-97; identity STE of the quantiser,
+    functions/dorefa_connect.py:28-45) — as one autograd node: batch statistics (two passes, folded in double) and the
+    running-statistics update, then ONE pass that normalises, adds the shortcut, applies ReLU and the un-clamped k-bit
+    quantiser and writes both the fp32 image and the int8 codes the next DoReFa layer contracts; backward = ReLU mask,
+    BatchNorm backward and the shortcut's gradient in two passes (csrc/train_chain.hip) — instead of MIOpen's BatchNorm
+    forward / backward, torch's add / relu / threshold_backward and the separate quantiser pass.  ``a_bits`` 0: no quantiser
+    (plain BatchNorm, e.g. the shortcut branch's — then without ReLU / residual).  Shares the BatchNorm module.  CPU tensors,
+    eval mode, C % 4 != 0, momentum=None or untracked statistics: the module chain itself."""
+
+    def __init__(self, bn, a_bits: int = 0, relu: bool = False):
+        super().__init__()
+        from ..functions import nnDorefaQuant
+        self.bn, self.a_bits, self.relu = bn, int(a_bits), bool(relu)
+        self.quant = nnDorefaQuant(self.a_bits) if self.a_bits else None
+        if self.a_bits and not 2 <= self.a_bits <= 8:
+            raise ValueError("the fused chain writes int8 codes: 2 <= a_bits <= 8 (or 0: no quantiser)")
+
+    def forward(self, x, residual=None):
+        x = lazy.resolve(x)
+        bn = self.bn
+        fast = (self.training and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 4)
+                and bn.momentum is not None and bn.track_running_stats and x.shape[0] * (x[0, 0].numel()) > 1
+                and x.shape[1] % 4 == 0 and (self.a_bits or (residual is None and not self.relu))
+                and (residual is None or (residual.shape == x.shape and residual.dtype == torch.float32 and residual.is_cuda)))
+        if not fast:
+            h = bn(x)
+            if residual is not None:
+                h = h + residual
+            if self.relu:
+                h = torch.relu(h)
+            return self.quant(h) if self.quant is not None else h
+        out = _TrainBnActQuantFn.apply(x, residual, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                                       bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), self.relu, self.a_bits)
+        bn.num_batches_tracked.add_(1)
+        return out
+
+
 def fuse_sequential_training(seq: torch.nn.Sequential) -> torch.nn.Sequential:
     """New nn.Sequential (sharing every module of ``seq``) where each [MaxPool2d?, BatchNorm, Hardtanh?, BinaryConnect(det)]
     run is one FusedTrainPoolBnSign: the training step then runs no torch / MIOpen pooling, BatchNorm or Hardtanh kernel

@@ -1689,6 +1689,44 @@ def pool_bn_sign_train_backward(grad_out: torch.Tensor, saved, gamma, beta, ht, 
     return (gin.permute(0, 3, 1, 2) if grad_out.dim() == 4 else gin.view(N, C)), dgamma, dbeta
 
 
+# ---- training-mode chain BatchNorm(batch stats) [+ residual] [-> ReLU] [-> nnDorefaQuant] (csrc/train_chain.hip, codes_i8.hip) -----
+
+def bn_train_stats(x: torch.Tensor, running_mean, running_var, eps: float, momentum: float):
+    """Batch statistics of a device fp32 [N, C, H, W] / [N, C] tensor: returns (NHWC view of x, stats2 = [mean | invstd]); the
+    running statistics (None: skipped) are updated in place like nn.BatchNorm2d.train() does."""
+    _require(x, "input")
+    xs, N, H, W, C = _rows_view(x.detach())
+    R = N * H * W
+    dev = x.device
+    stats2 = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+    partial = torch.empty((int(_lib.load().qt_train_chain_partial_floats(R, C)),), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.call("qt_bn_train_stats_f32", _p(xs), R, C, float(eps), float(momentum), _p(running_mean), _p(running_var),
+                  _p(stats2), _p(partial), _stream(dev))
+    return xs, stats2
+
+
+def bn_act_train_backward(grad_out: torch.Tensor, xs: torch.Tensor, res, gamma, beta, stats2: torch.Tensor, relu: bool,
+                          want_res_grad: bool):
+    """Backward of quant(relu?(BatchNorm_train(x) + res)) (identity STE): (gx shaped like grad_out, dgamma, dbeta, gres or None).
+    ``xs`` / ``res``: the forward's NHWC (or [N, C]) views."""
+    g, N, H, W, C = _rows_view(_require(grad_out, "grad_output"))
+    dev = g.device
+    R = N * H * W
+    partial = torch.empty((int(_lib.load().qt_train_chain_partial_floats(R, C)),), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+    gx = torch.empty_like(g)
+    gres = torch.empty_like(g) if want_res_grad else None
+    g_ = _check_bias(gamma.detach() if gamma is not None else None, C, dev)
+    b_ = _check_bias(beta.detach() if beta is not None else None, C, dev)
+    with _on(dev):
+        _lib.call("qt_bn_act_train_backward_f32", _p(g), _p(xs), _p(res), R, C, _p(g_), _p(b_), _p(stats2), int(bool(relu)),
+                  _p(partial), _p(dgamma), _p(dbeta), _p(gx), _p(gres), _stream(dev))
+    shape = (lambda t: t.permute(0, 3, 1, 2)) if grad_out.dim() == 4 else (lambda t: t.view(N, C))
+    return shape(gx), dgamma, dbeta, (shape(gres) if gres is not None else None)
+
+
 # ---- backward of a quantised conv on the bf16 matrix cores (SURVEY 8f n2) ----------------------------------------------
 # Both gradients of conv2d(x, Q(W)) have one +-1 / 0 operand, so the exact-split route of the forward applies:
 #   grad_x = conv2d(g, flip(Q(W))^T, padding k-1-p)                 (stride 1): real g x quantised weight, the forward kernel
@@ -1771,6 +1809,11 @@ def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kerne
     inv = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
     if kh == 1:
         xs = x.detach()[:, :, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s]
+        # the sub-sampled activation (a strided VIEW: the packers take strides) against the gradient is a stride-1 1x1 weight
+        # gradient: the K-major route cuts its long contraction (N Ho Wo positions, few output tiles) into K slices
+        dW = conv2d_grad_weight_gemm(xs, grad_output, (1, 1), 0, x_levels=x_levels)
+        if dW is not None:
+            return dW
         x2 = xs.permute(1, 0, 2, 3).reshape(Cin, -1)                             # [Cin, P]  (gather copy)
         if x_levels != 1.0:
             x2 = torch.round(x2 * float(x_levels))                              # the integer codes: exact in bf16 (<= 255)

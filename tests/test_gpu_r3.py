@@ -649,3 +649,127 @@ def test_per_channel_scales_of_the_two_plane_gradient(dev, N, C, H, W, cl):
                 assert s[c] == 1.0, (c, amax[c], s[c])
             else:
                 assert 2.0 ** 14 <= amax[c] / s[c] < 2.0 ** 15, (c, amax[c], s[c])
+
+
+# ---- training-mode chain BatchNorm(batch stats) [+ shortcut] -> ReLU -> nnDorefaQuant on this backend's kernels ------------------
+
+@pytest.mark.parametrize("shape,bits,relu,res,cl", [((8, 64, 16, 16), 4, True, True, True), ((4, 128, 8, 8), 4, True, False, True),
+                                                     ((3, 36, 9, 11), 2, True, True, False), ((64, 300), 4, True, False, False),
+                                                     ((6, 256, 4, 4), 0, False, False, True), ((5, 40, 7, 7), 8, False, True, True)])
+def test_dorefa_training_chain_vs_fp64_of_the_module_chain(dev, shape, bits, relu, res, cl):
+    """layers.FusedTrainBnActQuant against the reference's module chain BatchNorm2d (batch statistics) [+ shortcut] -> ReLU ->
+    nnDorefaQuant (models/Resnet/Resnet_bin.py:63-97, functions/dorefa_connect.py:28-45) evaluated in fp64 on the CPU: the
+    quantised image (a value within rounding distance of a quantiser boundary may land on the neighbouring level: counted and
+    bounded), the gradients w.r.t. the input, the shortcut, gamma / beta, the running statistics and the int8 codes the output
+    carries."""
+    import copy
+    from pytorch_quantize_impls_amd import packed
+    from pytorch_quantize_impls_amd.layers import FusedTrainBnActQuant
+    torch.manual_seed(sum(shape) + bits)
+    C = shape[1]
+    bn = (torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d)(C, eps=1e-4, momentum=0.15)
+    with torch.no_grad():
+        bn.weight.uniform_(0.3, 1.5)
+        bn.weight[::3] *= -1.0
+        bn.bias.normal_(0, 0.4)
+    ref_bn = copy.deepcopy(bn).double().train()
+    mod = FusedTrainBnActQuant(bn.to(dev), bits, relu=relu).train()
+    x = torch.randn(shape) * 1.7 + 0.3
+    r = torch.randn(shape) * 0.8 if res else None
+    xd = x.to(dev)
+    rd = r.to(dev) if res else None
+    if cl and len(shape) == 4:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+        rd = rd.contiguous(memory_format=torch.channels_last) if res else None
+    xd.requires_grad_(True)
+    if res:
+        rd.requires_grad_(True)
+    before = dict(_lib.call_counts)
+    y = mod(xd, residual=rd)
+    assert _lib.call_counts["qt_bn_train_stats_f32"] > before.get("qt_bn_train_stats_f32", 0)
+    gout = torch.randn(y.shape)
+    y.backward(gout.to(dev))
+    assert _lib.call_counts["qt_bn_act_train_backward_f32"] > before.get("qt_bn_act_train_backward_f32", 0)
+    xr = x.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    h = ref_bn(xr)
+    if res:
+        h = h + rr
+    if relu:
+        h = torch.relu(h)
+    nlev = float((1 << bits) - 1) if bits else 0.0
+    hq = (torch.round(h * nlev) / nlev).detach() + (h - h.detach()) if bits else h          # identity STE
+    hq.backward(gout.double())
+    got = y.detach().cpu().double()
+    if bits:
+        off = (got - hq.detach()).abs()
+        assert float(off.max()) <= 1.0 / nlev + 1e-6                                          # at most the neighbouring level
+        flipped = off > 1e-6
+        assert int(flipped.sum()) <= max(2, got.numel() // 20000), int(flipped.sum())
+        dist = ((h.detach() * nlev) - torch.floor(h.detach() * nlev) - 0.5).abs()             # distance to the rounding boundary
+        assert float(dist[flipped].max() if flipped.any() else 0.0) <= 1e-4
+        tag = packed.lookup_codes(y, packed.NHWC if len(shape) == 4 else packed.ROWS_LAST)
+        assert tag is not None and tag.bit_width == bits
+        codes = tag.codes[:, :C].cpu().double().view(*( (shape[0], shape[2], shape[3], C) if len(shape) == 4 else shape))
+        want_codes = torch.round(got * nlev)
+        if len(shape) == 4:
+            want_codes = want_codes.permute(0, 2, 3, 1)
+        ok = want_codes.abs() <= 127
+        assert torch.equal(codes[ok], want_codes[ok])
+    else:
+        assert norm_err(n(got), n(hq.detach())) <= 1e-6
+    assert norm_err(n(xd.grad), n(xr.grad)) <= TOL
+    if res:
+        assert norm_err(n(rd.grad), n(rr.grad)) <= TOL
+    assert norm_err(n(bn.weight.grad), n(ref_bn.weight.grad)) <= TOL
+    assert norm_err(n(bn.bias.grad), n(ref_bn.bias.grad)) <= TOL
+    assert norm_err(n(bn.running_mean), n(ref_bn.running_mean)) <= 1e-6
+    assert norm_err(n(bn.running_var), n(ref_bn.running_var)) <= 1e-6
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("w_bits", [1, 3])
+def test_dorefa_resnet18_training_step_with_the_fused_training_chain(dev, w_bits):
+    """bench_models.TrainFusedDorefaResNet18 (BatchNorm + shortcut add + ReLU + quantiser of every block as one
+    FusedTrainBnActQuant node) against the module graph of the same parameters on the same input: no MIOpen BatchNorm / torch
+    relu / add kernel between the DoReFa layers, no dense-library contraction, the same loss to 1e-3.  Gradients: a 4-bit net
+    follows every code that lands on the other side of a rounding boundary, so the yardstick is the module graph ITSELF on an
+    input moved by one part in 10^6 (cosine ~0.85 per parameter at this depth; tools/probes/train_resnet_fused_agreement.py) —
+    the fused chain has to agree with the module graph at least that well, and to 0.999 at the classifier."""
+    import copy
+    import bench_models
+    torch.manual_seed(4)
+    m = bench_models.DorefaResNet18(w_bits=w_bits, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    m = m.to(dev).to(memory_format=torch.channels_last).train()
+    m2, m3 = copy.deepcopy(m), copy.deepcopy(m)
+    x = torch.randn(64, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 10, (64,), device=dev)
+    loss_ref = torch.nn.functional.cross_entropy(m2(x), t)
+    loss_ref.backward()
+    torch.nn.functional.cross_entropy(m3(x * (1.0 + 1e-6)), t).backward()
+    fused = bench_models.TrainFusedDorefaResNet18(m)
+    _fused.LIBRARY_PATHS.clear()
+    before = dict(_lib.call_counts)
+    loss = torch.nn.functional.cross_entropy(fused(x), t)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+    assert _lib.call_counts["qt_bn_train_stats_f32"] - before.get("qt_bn_train_stats_f32", 0) == 20     # stem + 16 convs + 3 shortcuts
+    assert _lib.call_counts["qt_bn_act_train_backward_f32"] - before.get("qt_bn_act_train_backward_f32", 0) == 20
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-3 * abs(float(loss_ref.detach()))
+
+    def cos(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+    for (k, p_), (_, q_), (_, r_) in zip(m.named_parameters(), m2.named_parameters(), m3.named_parameters()):
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+        if float(q_.grad.norm()) <= 1e-6 * q_.grad.numel() ** 0.5:
+            continue
+        floor = cos(q_.grad, r_.grad)
+        assert cos(p_.grad, q_.grad) >= min(0.999, floor - 0.02), (k, cos(p_.grad, q_.grad), floor)
+    assert cos(m.linear.weight.grad, m2.linear.weight.grad) >= 0.999
+    for (k, b1), (_, b2), (_, b3) in zip(m.named_buffers(), m2.named_buffers(), m3.named_buffers()):
+        if b1.dtype == torch.float32:       # running statistics: same yardstick (flipped codes upstream move the batch moments a little)
+            assert norm_err(n(b1), n(b2)) <= max(1e-5, 3.0 * norm_err(n(b3), n(b2))), k

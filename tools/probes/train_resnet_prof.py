@@ -9,8 +9,9 @@ model = bench_models.DorefaResNet18(w_bits=int(os.environ.get("W_BITS", "1")), a
 x = torch.randn(256, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
 t = torch.randint(0, 10, (256,), device=dev)
 _fused.DETECT_MODE = "remember"
+net = bench_models.TrainFusedDorefaResNet18(model) if os.environ.get("FUSED") else model
 for _ in range(int(os.environ.get("STEPS", "8"))):
     model.zero_grad(set_to_none=True)
-    F.nll_loss(F.log_softmax(model(x), 1), t).backward()
+    F.nll_loss(F.log_softmax(net(x), 1), t).backward()
 torch.cuda.synchronize()
 print("library paths:", dict(_fused.LIBRARY_PATHS))

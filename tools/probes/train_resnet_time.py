@@ -8,10 +8,15 @@ model = bench_models.DorefaResNet18(w_bits=1, a_bits=4).to(dev).to(memory_format
 x = torch.randn(256, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
 t = torch.randint(0, 10, (256,), device=dev)
 _fused.DETECT_MODE = "remember"
+if os.environ.get("FUSED"):
+    net = bench_models.TrainFusedDorefaResNet18(model)
+    model_fwd = net
+else:
+    model_fwd = model
 for i in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     model.zero_grad(set_to_none=True)
-    F.nll_loss(F.log_softmax(model(x), 1), t).backward()
+    F.nll_loss(F.log_softmax(model_fwd(x), 1), t).backward()
     torch.cuda.synchronize(); print(i, round((time.perf_counter() - t0) * 1e3, 2), "ms", flush=True)
 # the stem alone
 stem = model.stem
