@@ -999,6 +999,10 @@ template <class E> using Conv256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, 1>;
 template <class E> using Conv128 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 128, 1>;
 template <class E> using Conv64 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 128, 1>;
 template <class E> using Conv192 = GemmCfg<E, 4, 2, 2, 3, 1, 0, 128, 1>;
+// small maps with padding (the late stages of a CIFAR ResNet: M = 16384 / 4096 output pixels): the 256-row tiles above leave
+// most CUs idle — 128x128 tiles (wave 64x32) quadruple the workgroups; 64x64 with 512-byte stages below 64 big tiles
+template <class E> using Conv128x128 = GemmCfg<E, 2, 4, 2, 1, 1, 0, 128, 1>;
+template <class E> using ConvSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 1>;
 
 // ... and on un-padded / physically padded planes (CONV_ = 2)
 template <class E> using ConvV256 = GemmCfg<E, 2, 4, 4, 2, 1, 0, 128, 2>;
@@ -1495,6 +1499,17 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
             return launch_cfg<ConvV64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi);                 \
         }                                                                                                       \
         QT_CONV_STAMPS(E)                                                                                       \
+        if (g_conv_force == 5 && !epi.alpha && epi.mode == 0)                                                   \
+            return launch_cfg<Conv128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        if (g_conv_force == 6 && !epi.alpha && epi.mode == 0 && kwords * 4 >= 2048 && !(ldwp & 127))            \
+            return launch_cfg<ConvSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        if (g_conv_force == 0 && !epi.alpha && epi.mode == 0 && ((M + 255) / 256) * ((Cout + tn - 1) / tn) < 200) {     \
+            /* small maps: fewer 256-row tiles than CUs (tools/bench_conv_small_maps.py: 256 ch @ 8x8 137 -> 83 us,  */ \
+            /* 512 ch @ 4x4 239 -> 102 us incl. the operand split; same accumulation order, bit-identical results)   */ \
+            if (((M + 127) / 128) * ((Cout + 127) / 128) < 200 && kwords * 4 >= 2048 && !(ldwp & 127))          \
+                return launch_cfg<ConvSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            return launch_cfg<Conv128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        }                                                                                                       \
         if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
             return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
         if (g_conv_force == 2) {                                                                                \
@@ -1521,7 +1536,7 @@ int qt_conv2d_implicit_variant(int variant, int elem, const uint32_t* P, int64_t
                                int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh,
                                int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
                                const float* scale_dev, float* Y, int64_t ldy, int64_t Cout, qt_stream_t stream) {
-    if (variant < 0 || variant > 4) return QT_ERR_INVALID_ARG;
+    if (variant < 0 || variant > 6) return QT_ERR_INVALID_ARG;
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, Y, ldy, Cout, stream, EpiArgs{}, 0, 0, variant);
 }
