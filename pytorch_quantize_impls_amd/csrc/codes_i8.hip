@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void codes_kernel(const float* __restrict__ x,
                     const float r = rintf(n * v[e]);
                     q4[e] = r;
                     // NaN / inf / out-of-range codes cannot be represented: flag them
-                    if (!(r >= -127.0f && r <= 127.0f)) { bad = 1; q = 0; } else q = (int)r;
+                    // (bit 1: beyond +-2047 as well — no longer exact in an fp16 plane either, see the training weight gradient)
+                    if (!(r >= -127.0f && r <= 127.0f)) { bad |= (r >= -2047.0f && r <= 2047.0f) ? 1 : 3; q = 0; } else q = (int)r;
                 }
             }
             word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void codes_kernel(const float* __restrict__ x,
                 if (k0 + e < K) yf[row * ldy + k0 + e] = inv_n * q4[e];   // fl(fl(1/n) * r), as _quantize
         }
     }
-    if (!WEIGHT && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+    if (!WEIGHT && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, __any(bad & 2) ? 3 : 1);
 }
 
 // Eval-mode BatchNorm of an fp32 [rows][C] matrix in the DEVICE's arithmetic, y = fma(fl(fl(x - mean) * rs), weight, bias) with
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
                 if (relu == 1) t = t < 0.0f ? 0.0f : t;             // NaN stays NaN (flagged below)
                 const float q_ = rintf(__fmul_rn(n, t));
                 q4[e] = q_;
-                if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad = 1; q = 0; } else q = (int)q_;
+                if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad |= (q_ >= -2047.0f && q_ <= 2047.0f) ? 1 : 3; q = 0; } else q = (int)q_;
             }
             word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
         }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
                 if (k0 + e < C) yf[row * ldy + k0 + e] = inv_n * q4[e];
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, __any(bad & 2) ? 3 : 1);
 }
 
 }  // namespace

@@ -773,11 +773,12 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(input, weight)
         # k-bit activation with valid int8 codes (the tag nnDorefaQuant leaves): its image is codes / (2^k - 1), so the
         # weight gradient can contract the integer codes on the bf16 matrix cores
-        ctx.x_levels = None
+        ctx.x_levels, ctx.code_flag = None, None
         if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4:
             codes = packed.lookup_codes(input, packed.NHWC)
             if codes is not None and codes.K == input.shape[1]:
                 ctx.x_levels = float((1 << int(codes.bit_width)) - 1)
+                ctx.code_flag = codes.overflow
         route = []
         ctx.E = _dorefa_w1_scale(weight, False) if input.is_cuda else None     # mean|W|: the backward scales grad_x by it again
         y = dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized=False, route=route, scale=ctx.E)
@@ -805,7 +806,7 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
             if mfma and ctx.x_levels is not None and ctx.x_levels <= 255:
                 # UNscaled and un-masked, as upstream (_ignore_factor_op, identity STE): functions/dorefa_connect.py:66-79
                 grad_weight = dorefa_conv_grad_weight(input, go, weight.shape[2:], stride, padding, dilation, ctx.x_levels,
-                                                      ctx.codes_fit)
+                                                      ctx.codes_fit, ctx.code_flag)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
@@ -831,12 +832,16 @@ def _act_levels(t: torch.Tensor, layout):
     return None
 
 
-def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels: float, codes_fit: bool):
+def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels: float, codes_fit: bool, code_flag=None):
     """grad wrt the (quantised) weight of a DoReFa conv whose activation is a k-bit image q / n (n = ``x_levels``): the
     integer codes q are exact in bf16 while |q| <= 256, so the contraction runs on the weight-gradient routes (pixel-major,
-    K-major, strided) with the gradient split exactly.  ``codes_fit`` False — the un-clamped quantiser left the int8 range
-    (functions/dorefa_connect.py:11-25 has no clamp) —: q = 256 hi + lo with both digits exact in bf16, two passes,
-    256 GW(hi) + GW(lo); |q| >= 2^16 (or no route for the shape): None, the caller uses the library."""
+    K-major, strided) with the split gradient.  ``codes_fit`` False — the un-clamped quantiser left the int8 range
+    (functions/dorefa_connect.py:11-25 has no clamp):
+      * pixel-major routes with the two-plane gradient: their activation plane is fp16, where |q| <= 2048 is still exact — one
+        pass as before; ``code_flag`` (the quantiser's device flag, bit 1 = a code beyond +-2047) poisons the result with NaN
+        instead of a host sync for a case that does not occur (an activation beyond 136 at 4 bits);
+      * otherwise q = 256 hi + lo with both digits exact in bf16, two passes, 256 GW(hi) + GW(lo), NaN from |q| >= 2^16.
+    No route for the shape: None, the caller uses the library."""
     def run(xt, levels):
         gw = None
         if ops.wgrad_pm_applicable(xt.shape, go.shape, ksz, stride, dilation):
@@ -849,6 +854,14 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
 
     if codes_fit:
         return run(input, x_levels)
+    if code_flag is not None and ops.split_terms() == 2:
+        gw = None
+        if ops.wgrad_pm_applicable(input.shape, go.shape, ksz, stride, dilation):
+            gw = ops.conv2d_grad_weight_pm(input, go, ksz, padding, x_levels=x_levels, terms=2)
+        elif int(ksz[0]) > 1 and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
+            gw = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=x_levels)     # the pixel-major kernel too
+        if gw is not None:
+            return gw + torch.where((code_flag.reshape(()) & 2) != 0, float("nan"), 0.0)
     q = torch.round(input.detach() * float(x_levels))
     hi = torch.floor(q * (1.0 / 256.0))
     lo = q - hi * 256.0
@@ -880,6 +893,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         ctx.has_bias, ctx.conv_args, ctx.bit_width = bias is not None, conv_args, int(bit_width)
         ctx.save_for_backward(input, weight_q)
         ctx.x_levels = _act_levels(input, packed.NHWC) if input.dim() == 4 else None
+        ctx.code_flag = packed.lookup_codes(input, packed.NHWC).overflow if ctx.x_levels is not None else None
         y = None
         ok = groups == 1 and not isinstance(padding, str) and input.dim() == 4 and input.dtype == torch.float32
         if ok and ctx.x_levels is not None:
@@ -920,7 +934,8 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ksz = weight_q.shape[2:]
             if mfma and ctx.x_levels is not None:
-                grad_weight = dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, ctx.x_levels, ctx.codes_fit)
+                grad_weight = dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, ctx.x_levels, ctx.codes_fit,
+                                                      ctx.code_flag)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight_q.shape, go, stride=stride, padding=padding,

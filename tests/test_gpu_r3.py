@@ -773,3 +773,30 @@ def test_dorefa_resnet18_training_step_with_the_fused_training_chain(dev, w_bits
     for (k, b1), (_, b2), (_, b3) in zip(m.named_buffers(), m2.named_buffers(), m3.named_buffers()):
         if b1.dtype == torch.float32:       # running statistics: same yardstick (flipped codes upstream move the batch moments a little)
             assert norm_err(n(b1), n(b2)) <= max(1e-5, 3.0 * norm_err(n(b3), n(b2))), k
+
+
+def test_dorefa_training_codes_beyond_the_fp16_plane_are_flagged_not_wrong(dev, all_shapes_on_the_routes):
+    """Codes beyond +-2047 (a 4-bit activation beyond 136) are not exact in the pixel-major kernel's fp16 activation plane any
+    more: the quantiser's device flag (bit 1) turns the weight gradient of that route into NaN — never a silently wrong number —
+    while the forward and grad_x (exact-split routes) stay right; with the exact three-term split selected the base-256 digits
+    still give the fp64 result (up to 2^16)."""
+    from pytorch_quantize_impls_amd import packed
+    torch.manual_seed(5)
+    conv = DorefaConv2d(64, 96, 3, padding=1, bias=True, bit_width=1).to(dev).train()
+    raw = (torch.rand(4, 64, 12, 12, device=dev) * 200.0).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = nnDorefaQuant(4)(raw)
+    assert float(x.detach().max()) * 15 > 2100
+    assert int(packed.lookup_codes(x, packed.NHWC).overflow.item()) == 3
+    y = conv(x)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    ry, rgx, rgw, _ = _fp64_layer_grads(conv, x, gout)
+    assert norm_err(n(y), n(ry)) <= TOL and norm_err(n(raw.grad), n(rgx)) <= TOL
+    assert torch.isnan(conv.weight.grad).all()
+    conv.zero_grad()
+    with ops.float_split("bf16x3"):
+        y2 = conv(x)
+        y2.backward(gout)
+    assert norm_err(n(conv.weight.grad), n(rgw)) <= 2 * TOL
+    small = nnDorefaQuant(4)((torch.rand(4, 64, 12, 12, device=dev) * 100.0).contiguous(memory_format=torch.channels_last))
+    assert int(packed.lookup_codes(small, packed.NHWC).overflow.item()) == 1          # beyond int8, inside the fp16 plane
