@@ -994,6 +994,40 @@ class DorefaWkLinearFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None
 
 
+def grouped_quant_conv(layer, input, kind: str, quant_op):
+    """BinConv2d / TerConv2d with ``groups`` > 1 (layers/binary_layers.py:59-60,103-106 hand ``groups`` to F.conv2d): group g is
+    an independent conv of its channel slice with its rows of the weight, and the element-wise quantisers (safeSign, the fixed
+    ternary thresholds) commute with slicing — so every group runs on the groups == 1 routes of this backend, forward and
+    backward, and the results are concatenated.  Returns None when the case is not this path's (eval mode with autograd, a
+    weight off the quantiser's grid): the caller continues with its general code."""
+    G = int(layer.groups)
+    cin, cout = int(input.shape[1]) // G, int(layer.weight.shape[0]) // G
+    args = (layer.stride, layer.padding, layer.dilation, 1)
+    if not layer.training:
+        if torch.is_grad_enabled() and (input.requires_grad or layer.weight.requires_grad):
+            return None
+        if not layer._eval_on_grid():
+            return None
+    wq_full = None
+    if layer.training and not layer.deterministic:
+        wq_full = quant_op.apply(layer.weight.detach())          # ONE stochastic draw for the whole weight, as upstream
+    cl = input.is_contiguous(memory_format=torch.channels_last) and not input.is_contiguous()
+    # a +-1 tag of the whole activation (BinaryConnect's sign planes) holds for every channel slice
+    known_pm1 = True if (layer.binary_input or packed.lookup(input, packed.NHWC) is not None) else layer.binary_input
+    ys = []
+    for g in range(G):
+        xg = input[:, g * cin:(g + 1) * cin]
+        xg = xg.contiguous(memory_format=torch.channels_last) if cl else xg.contiguous()
+        wg = layer.weight[g * cout:(g + 1) * cout]
+        bg = layer.bias[g * cout:(g + 1) * cout] if layer.bias is not None else None
+        if layer.training:
+            wq = wq_full[g * cout:(g + 1) * cout] if wq_full is not None else None
+            ys.append(QuantConv2dFn.apply(xg, wg, bg, kind, wq, known_pm1, args))
+        else:
+            ys.append(quant_conv2d_forward(xg, wg, bg, *args, kind, weight_q=wg, binary_input=known_pm1, padding_mode="zeros"))
+    return torch.cat(ys, 1)
+
+
 #: backward GEMMs with one +-1/0 operand (grad_x = g . Q(W); grad_W = g^T . x for +-1 activations) run on the bf16
 #: matrix cores from this many multiply-accumulates on: the real operand is split exactly into bf16 triples, the
 #: +-1/0 operand is exact in bf16, accumulation is fp32 — fp32-GEMM accuracy at ~2.5x the fp32 library's speed

@@ -150,6 +150,10 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
             w = self.bin_op.apply(self.weight) if self.training else self.weight
             return torch.nn.functional.conv2d(input, w, self.bias, self.stride, self.padding,
                                               self.dilation, self.groups)
+        if self.groups > 1 and self.padding_mode == "zeros" and input.dim() == 4 and not isinstance(self.padding, str):
+            y = _fused.grouped_quant_conv(self, input, "binary", self.bin_op)       # every group on the groups == 1 routes
+            if y is not None:
+                return y
         args = (self.stride, self.padding, self.dilation, self.groups)
         if self.training:
             wq = None if self.deterministic else self.bin_op.apply(self.weight.detach())

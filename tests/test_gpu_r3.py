@@ -800,3 +800,48 @@ def test_dorefa_training_codes_beyond_the_fp16_plane_are_flagged_not_wrong(dev, 
     assert norm_err(n(conv.weight.grad), n(rgw)) <= 2 * TOL
     small = nnDorefaQuant(4)((torch.rand(4, 64, 12, 12, device=dev) * 100.0).contiguous(memory_format=torch.channels_last))
     assert int(packed.lookup_codes(small, packed.NHWC).overflow.item()) == 1          # beyond int8, inside the fp16 plane
+
+
+# ---- grouped binarised convs (VERDICT r2 missing #5) ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cls_name,groups,Cin,Cout,k,s,p,pm1", [("BinConv2d", 2, 128, 192, 3, 1, 1, True), ("TerConv2d", 4, 128, 128, 3, 1, 1, True),
+                                                                 ("BinConv2d", 2, 64, 64, 3, 2, 1, True), ("TerConv2d", 2, 6, 64, 5, 1, 2, False),
+                                                                 ("BinConv2d", 32, 64, 64, 3, 1, 1, True)])      # 2-channel groups
+def test_grouped_binarised_conv_runs_group_by_group_on_this_backend(dev, all_shapes_on_the_routes, cls_name, groups, Cin, Cout, k, s, p, pm1):
+    """BinConv2d / TerConv2d with groups > 1 (layers/binary_layers.py:59-60,103-106): training-mode forward + backward and the
+    eval-mode forward against the fp64 evaluation of F.conv2d(x, Q(W), b, groups=G) and the quantiser's STE — every group on the
+    groups == 1 routes, no dense-library call while a group keeps >= 32 channels (the weight-gradient kernels' tile floor; the
+    2-channel groups of the last case are still right, their weight gradient is counted in LIBRARY_PATHS)."""
+    from pytorch_quantize_impls_amd import layers as L
+    from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic
+    torch.manual_seed(groups + Cin)
+    conv = getattr(L, cls_name)(Cin, Cout, k, stride=s, padding=p, groups=groups).to(dev).train()
+    conv.weight.data.uniform_(-1.3, 1.3)
+    raw = torch.randn(6, Cin, 14, 14, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = BinaryConnectDeterministic.apply(raw) if pm1 else raw * 1.0
+    x.retain_grad()
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = conv(x)
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    if min(Cin, Cout) // groups >= 32 or not pm1:
+        assert dict(_fused.LIBRARY_PATHS) == lib_before
+    else:
+        assert set(_fused.LIBRARY_PATHS) - set(lib_before) <= {"conv grad_weight outside the matrix-core route"}
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    w = conv.weight.detach().double().cpu()
+    wq = (torch.where(w < 0, -torch.ones_like(w), torch.ones_like(w)) if cls_name == "BinConv2d"
+          else ops.ternarize(conv.weight.detach()).double().cpu()).requires_grad_(True)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wq, conv.bias.detach().double().cpu(), s, p, 1, groups)
+    yr.backward(gout.double().cpu())
+    assert norm_err(n(y), n(yr)) <= TOL
+    assert norm_err(n(x.grad), n(xr.grad)) <= TOL
+    gw = torch.where(w.abs() <= 1.001, wq.grad, torch.zeros_like(wq.grad))            # STE of the quantiser
+    assert norm_err(n(conv.weight.grad), n(gw)) <= TOL
+    conv.eval()
+    with torch.no_grad():
+        ye = conv(x.detach())
+        ye = ye if type(ye) is torch.Tensor else ye * 1.0
+    assert dict(_fused.LIBRARY_PATHS) == lib_before
+    assert norm_err(n(ye), n(yr)) <= TOL

@@ -10,9 +10,10 @@ model = bench_models.DorefaResNet18(w_bits=1, a_bits=4).to(dev).to(memory_format
 x = torch.randn(256, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
 t = torch.randint(0, 10, (256,), device=dev)
 _fused.DETECT_MODE = "remember"
+net = bench_models.TrainFusedDorefaResNet18(model) if os.environ.get("FUSED") else model
 def step():
     model.zero_grad(set_to_none=True)
-    F.nll_loss(F.log_softmax(model(x), 1), t).backward()
+    F.nll_loss(F.log_softmax(net(x), 1), t).backward()
 for _ in range(4): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
