@@ -845,3 +845,45 @@ def test_grouped_binarised_conv_runs_group_by_group_on_this_backend(dev, all_sha
         ye = ye if type(ye) is torch.Tensor else ye * 1.0
     assert dict(_fused.LIBRARY_PATHS) == lib_before
     assert norm_err(n(ye), n(yr)) <= TOL
+
+
+# ---- small-map tile rule of the padded implicit-GEMM convs -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["f16x2", "bf16x3", "int8", "fp4"])
+def test_small_map_conv_tiles_equal_the_standard_tiles(dev, kind):
+    """Padded convs with fewer 256-row tiles than CUs run 128x128 (qt_conv2d_implicit_variant 5) or 64x64 / 512-byte-stage
+    (variant 6) tiles since round 3 (csrc/mfma_gemm.hip: Conv128x128, ConvSkinny); same accumulation order, so the result must
+    equal the standard double-buffered tiles (variant 1) and the dispatcher's choice (0) bit for bit — for every operand kind
+    (two fp16 planes, three bf16 planes, int8 codes, fp4 nibbles), at shapes on both sides of the rule."""
+    from pytorch_quantize_impls_amd.layers import BinConv2d
+    torch.manual_seed(11)
+    shapes = [(8, 256, 8, 256, 3, 1), (16, 512, 4, 512, 3, 1), (4, 64, 12, 96, 3, 1), (2, 128, 9, 130, 5, 2), (64, 128, 16, 128, 3, 1)]
+    before = _lib.call_counts["qt_conv2d_implicit_variant"]
+    try:
+        for (B, C, H, Co, k, p) in shapes:
+            outs = []
+            if kind in ("f16x2", "bf16x3"):
+                x = torch.randn(B, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+                w = torch.randn(Co, C, k, k, device=dev)
+                with ops.float_split(kind):
+                    for v in (0, 1, 5, 6):
+                        ops.CONV_VARIANT = v
+                        outs.append(ops.float_conv2d(x, w, "binary", None, 1, p, 1).clone())
+            elif kind == "int8":
+                xq = nnDorefaQuant(4)((torch.rand(B, C, H, H, device=dev) * 1.2).contiguous(memory_format=torch.channels_last))
+                conv = DorefaConv2d(C, Co, k, padding=p, bias=True, bit_width=1).to(dev).train()
+                for v in (0, 1, 5, 6):
+                    ops.CONV_VARIANT = v
+                    with torch.no_grad():
+                        outs.append(conv(xq).clone())
+            else:
+                conv = BinConv2d(C, Co, k, padding=p).to(dev).train()
+                x = torch.where(torch.randn(B, C, H, H, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+                for v in (0, 1, 5, 6):
+                    ops.CONV_VARIANT = v
+                    with torch.no_grad():
+                        outs.append(conv(x).clone())
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (kind, B, C, H, Co, k)
+        assert _lib.call_counts["qt_conv2d_implicit_variant"] - before >= 3 * len(shapes)      # the variants did run
+    finally:
+        ops.CONV_VARIANT = 0
