@@ -681,6 +681,19 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         with torch.no_grad():
             same_g = bool(torch.equal(g4(x4), deferred4()))
         el_g = timed(lambda: g4(x4), 2 * iters)
+        # ... and the opt-in fused form the same way (its eager time is host-bound as well: ~60 launches)
+        fused_graph = {}
+        try:
+            gf4 = utils.graphed(f4, x4)
+            with torch.no_grad():
+                same_gf = bool(torch.equal(gf4(x4), yf4))
+            el_gf = timed(lambda: gf4(x4), 2 * iters)
+            fused_graph = {"fused_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_gf, st4, 5000.0,
+                                                       "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                                       {"same_logits_as_fused": same_gf})}
+            del gf4
+        except Exception as exc:
+            fused_graph = {"fused_hipgraph": {"error": f"{type(exc).__name__}: {exc}"}}
         out["c4_dorefa_resnet18_w1a4"] = {
             # the un-modified module graph: DorefaConv2d layers return deferred activations, BatchNorm / shortcut add / ReLU /
             # nnDorefaQuant are recorded and run in the conv's code epilogue (lazy.py); the fp32 stem stays module by module
@@ -697,6 +710,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                  fp32_activations=True),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                {"argmax_agreement_with_unfused": agree, "same_logits_as_module_by_module": same_fused}),
+            **fused_graph,
             "note": "launch / latency bound at 32 x 32 maps (SURVEY 8d): ~60 launches of 5-40 us each"}
     # ---- C5: ternary VGG-16, 3 x 224 x 224 (2048 over 8 GPUs = 256 per GPU)
     if args.c5_batch > 0:
@@ -794,34 +808,19 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                 t_m, _ = bts.step_time(lsm(mr), mr, xr, tt, n=10)
                 t_f, _ = bts.step_time(lsm(fused_r), mr, xr, tt, n=10)
                 remembered = {"module_graph_ms_per_step": t_m, "fused_chain_ms_per_step": t_f}
-                for p_ in mr.parameters():
-                    p_.grad = torch.zeros_like(p_)
-
-                def one_step():
-                    mr.zero_grad(set_to_none=False)
-                    loss_ = torch.nn.functional.nll_loss(lsm(fused_r)(xr), tt)
-                    loss_.backward()
-                    return loss_
-                side = torch.cuda.Stream()
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        one_step()
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side):
-                        loss_g = one_step()
-                torch.cuda.synchronize()
+                from pytorch_quantize_impls_amd import utils as _utils
+                gstep = _utils.GraphedTrainStep(fused_r, lambda o_, t_: torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(o_, 1), t_),
+                                                xr, tt)
                 for _ in range(2):
-                    graph.replay()
+                    loss_g = gstep(xr, tt)
                 torch.cuda.synchronize()
                 t0g = time.perf_counter()
                 for _ in range(10):
-                    graph.replay()
+                    loss_g = gstep(xr, tt)
                 torch.cuda.synchronize()
                 remembered["fused_chain_as_hipgraph_ms_per_step"] = (time.perf_counter() - t0g) / 10 * 1e3
                 remembered["hipgraph_loss"] = float(loss_g.detach())
-                del graph
+                del gstep
             except Exception as exc:
                 remembered["error"] = f"{type(exc).__name__}: {exc}"
             finally:
@@ -835,7 +834,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                                       "ReLU + k-bit quantiser forward + backward as one node per conv "
                                                       "(layers.FusedTrainBnActQuant, opt-in)"},
                 "with_remembered_range_verdicts": dict(remembered, what="_fused.DETECT_MODE = 'remember': no host sync per layer for "
-                                                       "'do these codes fit int8?'; hipGraph = forward + backward captured once, replayed"),
+                                                       "'do these codes fit int8?'; hipGraph = utils.GraphedTrainStep (forward + loss + backward captured once; every replay copies the batch in)"),
                 "dense_library_calls_in_the_steps": lib_r,
                 "note": "many small launches (3 x 32 x 32 maps): ~1100 kernels per step in the module graph; "
                         "tools/probes/train_resnet_prof.py has the per-kernel split",

@@ -887,3 +887,69 @@ def test_small_map_conv_tiles_equal_the_standard_tiles(dev, kind):
         assert _lib.call_counts["qt_conv2d_implicit_variant"] - before >= 3 * len(shapes)      # the variants did run
     finally:
         ops.CONV_VARIANT = 0
+
+
+# ---- a whole training step as one hipGraph -----------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("which", ["resnet18", "resnet18_fused", "alexnet"])
+def test_graphed_train_step_replays_the_eager_step(dev, which):
+    """utils.GraphedTrainStep: forward + loss + backward captured once, replayed on a NEW batch — the loss and the parameter
+    gradients are the eager step's on that batch, a second replay reproduces the first bit for bit, BatchNorm's running statistics
+    keep advancing, and no host synchronisation is needed inside (range verdicts remembered for the capture only)."""
+    import copy
+    import bench_models
+    from pytorch_quantize_impls_amd import utils
+    torch.manual_seed(12)
+    if which == "alexnet":
+        model = bench_models.AlexNetBin()
+        shape, fwd = (8, 3, 224, 224), (lambda m: m)
+        loss_fn = lambda out, t: torch.nn.functional.nll_loss(out, t)                          # noqa: E731
+    else:
+        model = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+        shape = (32, 3, 32, 32)
+        fwd = (lambda m: bench_models.TrainFusedDorefaResNet18(m)) if which.endswith("fused") else (lambda m: m)
+        loss_fn = lambda out, t: torch.nn.functional.cross_entropy(out, t)                     # noqa: E731
+    bench_models.randomize_bn(model, 5)
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    eager = copy.deepcopy(model)
+    x0 = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    x1 = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    t0, t1 = torch.randint(0, 10, (shape[0],), device=dev), torch.randint(0, 10, (shape[0],), device=dev)
+    mode_before = _fused.DETECT_MODE
+    net = fwd(model)
+
+    class _Wrap(torch.nn.Module):             # the step sees ONE module whose parameters are the model's
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return self.net(x)
+
+    step = utils.GraphedTrainStep(_Wrap(), loss_fn, x0, t0)
+    assert _fused.DETECT_MODE == mode_before
+    rm_before = {k: b.clone() for k, b in model.named_buffers() if k.endswith("running_mean")}
+    loss = step(x1, t1).clone()
+    grads = {k: p_.grad.clone() for k, p_ in model.named_parameters()}
+    prev = _fused.DETECT_MODE
+    _fused.DETECT_MODE = "remember"
+    try:
+        loss_e = loss_fn(fwd(eager)(x1), t1)
+        loss_e.backward()
+    finally:
+        _fused.DETECT_MODE = prev
+    # torch's own kernels in the step (the fp32 stem conv, MIOpen's BatchNorm) may pick other algorithms under capture, and a
+    # quantised net follows every flipped code: the same loss to 1e-3, gradients that point the same way, the classifier's to 1e-3
+    assert abs(float(loss) - float(loss_e)) <= 1e-3 * abs(float(loss_e))
+    last = [k for k, _ in eager.named_parameters()][-2]
+    for k, p_ in eager.named_parameters():
+        a, b = grads[k].double().flatten(), p_.grad.double().flatten()
+        if float(b.norm()) <= 1e-6 * b.numel() ** 0.5:
+            continue
+        c = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+        assert c >= (0.999 if k == last else 0.8), (k, c)
+    assert any(not torch.equal(rm_before[k], b) for k, b in model.named_buffers() if k in rm_before)
+    loss_again = step(x1, t1)
+    assert torch.equal(loss_again, loss)                                                       # replay is reproducible
+    with pytest.raises(ValueError):
+        step(x1[:4], t1[:4])
