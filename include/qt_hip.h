@@ -346,6 +346,13 @@ int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int6
 int qt_wgrad_pm_pack_grad_f16x2(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                                 int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, const float* scale2c,
                                 uint16_t* G2, float* bias_part, qt_stream_t stream);
+/* qt_wgrad_pm_pack_act_s2d_f32 with the image as two fp16 terms of x / scale2[0] (qt_f16x2_absmax_scale_f32) in two channel
+ * groups, XP[q][t * Cs8 + e], Cp >= 2 * Cs8: the activation plane of qt_wgrad_pm_f16 for a strided real-valued first layer; the
+ * caller adds the two channel groups of the result and multiplies by scale2[0]. */
+int qt_wgrad_pm_pack_act_s2d_f16x2(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
+                                   int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw, int64_t Hs, int64_t Ws,
+                                   int64_t Wq, int64_t Cs8, int64_t Cp, int64_t Qx, const float* scale2, uint16_t* XP,
+                                   qt_stream_t stream);
 int qt_wgrad_pm_pack_act_f16(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                              int64_t Cin, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Wq, int64_t Cp, int64_t Qx,
                              float x_scale, uint16_t* XP, qt_stream_t stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "qt_wgrad_pm_bias_reduce_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "qt_wgrad_pm_pack_act_f32": (_c_int, [_c_p] + [_c_i64] * 13 + [_c_f32, _c_p, _c_p]),
     "qt_wgrad_pm_pack_act_s2d_f32": (_c_int, [_c_p] + [_c_i64] * 17 + [_c_p, _c_p]),
+    "qt_wgrad_pm_pack_act_s2d_f16x2": (_c_int, [_c_p] + [_c_i64] * 17 + [_c_p, _c_p, _c_p]),
     "qt_wgrad_pm_pack_grad_f16x2": (_c_int, [_c_p] + [_c_i64] * 11 + [_c_p, _c_p, _c_p, _c_p]),
     "qt_wgrad_pm_pack_act_f16": (_c_int, [_c_p] + [_c_i64] * 13 + [_c_f32, _c_p, _c_p]),
     "qt_wgrad_pm_f16": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 7 + [_c_p]),

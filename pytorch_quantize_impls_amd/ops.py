@@ -2170,13 +2170,14 @@ def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
 
 def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_shape, stride, padding,
                            weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
-                           bias_grad: Optional[list] = None):
+                           bias_grad: Optional[list] = None, terms: Optional[int] = None):
     """grad wrt the weight of a strided conv2d over a real-valued fp32 image with few channels.  The stride-s conv is the
     stride-1 conv of the space-to-depth image ([N, C s^2, H / s, W / s], kernel ceil(k / s)) — the identity the forward uses
     (``s2d_weight``) — so the gradient of the s2d weight comes from ``conv2d_grad_weight_pm`` and is folded back with
-    pixel_shuffle (the taps the rounding added are dropped).  The image is real-valued: its exact three-term bf16 split goes in
-    as 3 x C s^2 channels (every (gradient term, image term) product is exact in the fp32 accumulator; the three channel
-    groups are summed afterwards), which keeps fp32-GEMM accuracy.  Returns [Cout, C, k, k] fp32 or None."""
+    pixel_shuffle (the taps the rounding added are dropped).  The image is real-valued: its split goes in as channel groups —
+    three exact bf16 terms (3 x C s^2 channels), or, with the two-term form (``terms`` = 2 / FLOAT_SPLIT = "f16x2", the
+    default), two fp16 terms of x / s (2 x C s^2 channels, per-tensor power-of-two s) against the two-plane gradient; the
+    groups are summed afterwards.  Returns [Cout, C, k, k] fp32 or None."""
     _require(x, "input")
     _require(grad_output, "grad_output")
     Cout, C, kh, kw = (int(v) for v in weight_shape)
@@ -2195,19 +2196,31 @@ def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_sh
     xd = x.detach()
     I = int
 
-    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st, f16=False):
-        # (the first-layer route keeps the exact three-term bf16 form: the image's terms are channel groups of the activation plane)
-        # space-to-depth gather + exact three-term split in one pass: XP[q][t * Cs8 + (c s + dy) s + dx] = term t of
-        # xpad[n, c, Y s + dy - ph, X s + dx - pw]
-        xs = xd[n0:n0 + cnt]
-        _lib.call("qt_wgrad_pm_pack_act_s2d_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
-                  I(cnt), I(C), I(H), I(W), I(s), I(ph), I(pw), I(Hs), I(Ws), I(Wq), I(Cs8), I(Cpi), I(qx), _p(XP), st)
+    nt = split_terms(terms)
+    x_scale = pow2_scale(xd) if nt == 2 else None        # the image's per-tensor power of two (two fp16 terms of x / s)
 
-    dws = _wgrad_pm_run(grad_output, (N, 3 * Cs8, Hs, Ws, k2, k2, 0, 0), pack_act, None, ste_threshold, 1.0, 0, bias_grad)
+    def pack_act(n0, cnt, Wq, Cpi, qx, XP, st, f16=False):
+        # space-to-depth gather + split in one pass: XP[q][t * Cs8 + (c s + dy) s + dx] = term t of
+        # xpad[n, c, Y s + dy - ph, X s + dx - pw] — the image's terms (three exact bf16, or two fp16 of x / s) are channel
+        # groups of the activation plane
+        xs = xd[n0:n0 + cnt]
+        if nt == 2:
+            _lib.call("qt_wgrad_pm_pack_act_s2d_f16x2", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                      I(cnt), I(C), I(H), I(W), I(s), I(ph), I(pw), I(Hs), I(Ws), I(Wq), I(Cs8), I(Cpi), I(qx), _p(x_scale),
+                      _p(XP), st)
+        else:
+            _lib.call("qt_wgrad_pm_pack_act_s2d_f32", _p(xs), I(xs.stride(0)), I(xs.stride(1)), I(xs.stride(2)), I(xs.stride(3)),
+                      I(cnt), I(C), I(H), I(W), I(s), I(ph), I(pw), I(Hs), I(Ws), I(Wq), I(Cs8), I(Cpi), I(qx), _p(XP), st)
+
+    dws = _wgrad_pm_run(grad_output, (N, nt * Cs8, Hs, Ws, k2, k2, 0, 0), pack_act, None, ste_threshold, 1.0, 0, bias_grad,
+                        terms=nt)
     if dws is None:
         return None
-    dws = dws.view(Cout, 3, Cs8, k2, k2)[:, :, :Cs]
-    dws = (dws[:, 2] + dws[:, 1]) + dws[:, 0]
+    dws = dws.view(Cout, nt, Cs8, k2, k2)[:, :, :Cs]
+    if nt == 2:
+        dws = (dws[:, 1] + dws[:, 0]) * x_scale[0]
+    else:
+        dws = (dws[:, 2] + dws[:, 1]) + dws[:, 0]
     dW = torch.nn.functional.pixel_shuffle(dws, s)[:, :, :kh, :kw].contiguous()
     if weight is not None:
         dW = ste_mask(dW, weight.detach().contiguous(), ste_threshold)

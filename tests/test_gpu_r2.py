@@ -45,7 +45,7 @@ def n(t):
 
 
 _PM_F16 = {"qt_wgrad_pm_f32": "qt_wgrad_pm_f16", "qt_wgrad_pm_pack_grad_f32": "qt_wgrad_pm_pack_grad_f16x2",
-           "qt_wgrad_pm_pack_act_f32": "qt_wgrad_pm_pack_act_f16"}
+           "qt_wgrad_pm_pack_act_f32": "qt_wgrad_pm_pack_act_f16", "qt_wgrad_pm_pack_act_s2d_f32": "qt_wgrad_pm_pack_act_s2d_f16x2"}
 
 
 def pm_entry(name):
@@ -892,8 +892,10 @@ def test_weight_gradient_strided_first_layer_vs_fp64(dev, N, C, H, W, Cout, k, s
     if cl:
         x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
     ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, C, k, k), go.double(), stride=s, padding=p)
-    with used("qt_wgrad_pm_pack_act_s2d_f32", "qt_wgrad_pm_f32"):
+    with used(pm_entry("qt_wgrad_pm_pack_act_s2d_f32"), pm_entry("qt_wgrad_pm_f32")):
         got = ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s, p)
+    with used("qt_wgrad_pm_pack_act_s2d_f32", "qt_wgrad_pm_f32"):               # the exact three-term form stays selectable
+        assert norm_err(n(ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s, p, terms=3)), ref.cpu().numpy()) <= TOL
     assert norm_err(n(got), ref.cpu().numpy()) <= TOL
     assert ops.conv2d_grad_weight_s2d(x, go, (Cout, C, k, k), s + 1, p) is None        # shapes that do not belong together
     conv = BinConv2d(C, Cout, k, stride=s, padding=p).to(dev)
@@ -902,7 +904,7 @@ def test_weight_gradient_strided_first_layer_vs_fp64(dev, N, C, H, W, Cout, k, s
     _fused.BWD_MFMA_MIN_MACS = 0
     lib_before = dict(_fused.LIBRARY_PATHS)
     try:
-        with used("qt_wgrad_pm_pack_act_s2d_f32"):
+        with used(pm_entry("qt_wgrad_pm_pack_act_s2d_f32")):
             conv(x).backward(go)
     finally:
         _fused.BWD_MFMA_MIN_MACS = old_min
