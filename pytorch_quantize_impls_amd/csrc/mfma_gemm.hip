@@ -1018,6 +1018,9 @@ template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
 // for M <= 4096, and beyond that while the standard tiling leaves CUs idle (< 256 tiles) and the weight re-reads of the
 // small row tiles ((M / 64) x the weight matrix through L2) stay under 256 MB
 template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
+// ... and 128x128 tiles where those already give every CU a workgroup (M = 16384 pixels x 256 channels: 256 tiles): half the
+// L2 -> LDS traffic of the 64x64 tiles, which is what bounds these layers
+template <class E> using ConvV128x128 = GemmCfg<E, 2, 4, 2, 1, 1, 0, 128, 2>;
 #ifdef QT_PROFILING_VARIANTS
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling builds only
 #endif
@@ -1478,8 +1481,11 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         if (valid && g_conv_force != 4 && g_conv_force != 3) {                                                  \
             if (g_conv_force == 0 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout &&                  \
                 (M <= 4096 || (((M + 255) / 256) * ((Cout + tn - 1) / tn) < 256 &&                              \
-                               (M / 64) * Cout * kwords * 4 <= (256ll << 20))))                                 \
+                               (M / 64) * Cout * kwords * 4 <= (256ll << 20)))) {                               \
+                if (M > 4096 && ((M + 127) / 128) * ((Cout + 127) / 128) >= 200)                               \
+                    return launch_cfg<ConvV128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 return launch_cfg<ConvVSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            }                                                                                                   \
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
             /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
             if (g_conv_force == 0 && tn == 256 && kwords * 4 <= 1024)                                           \
