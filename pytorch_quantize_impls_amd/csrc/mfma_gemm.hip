@@ -1021,6 +1021,8 @@ template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
 // ... and 128x128 tiles where those already give every CU a workgroup (M = 16384 pixels x 256 channels: 256 tiles): half the
 // L2 -> LDS traffic of the 64x64 tiles, which is what bounds these layers
 template <class E> using ConvV128x128 = GemmCfg<E, 2, 4, 2, 1, 1, 0, 128, 2>;
+// ... and 128x64 tiles (256-byte stages, the skinny GEMM's shape) where THOSE fill the chip (M = 4096 pixels x 512 channels)
+template <class E> using ConvV128x64 = GemmCfg<E, 4, 2, 1, 1, 1, 0, 256, 2>;
 #ifdef QT_PROFILING_VARIANTS
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling builds only
 #endif
@@ -1484,6 +1486,8 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                                (M / 64) * Cout * kwords * 4 <= (256ll << 20)))) {                               \
                 if (M > 4096 && ((M + 127) / 128) * ((Cout + 127) / 128) >= 200)                               \
                     return launch_cfg<ConvV128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                if (((M + 127) / 128) * ((Cout + 63) / 64) >= 200)   /* 512 ch @ 4x4: 128x64 tiles, 256-byte stages */ \
+                    return launch_cfg<ConvV128x64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 return launch_cfg<ConvVSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             }                                                                                                   \
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
