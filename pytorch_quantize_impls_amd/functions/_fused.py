@@ -494,11 +494,13 @@ class QuantConv2dFn(torch.autograd.Function):
         mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
-            wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
-            if mfma:     # real gradient x +-1 / 0 weight: the forward's exact-split conv on flipped weights
-                grad_input = ops.conv2d_grad_input_q(input.shape, wq, go, stride, padding, dilation)
+            if mfma:     # real gradient x +-1 / 0 weight: the forward's exact-split conv on flipped weights (the deterministic
+                #          quantiser runs inside the operand pack; a stochastic draw was saved)
+                grad_input = (ops.conv2d_grad_input_q(input.shape, weight_q, go, stride, padding, dilation) if weight_q is not None
+                              else ops.conv2d_grad_input_q(input.shape, weight, go, stride, padding, dilation, kind=ctx.kind))
             if grad_input is None:
                 note_library_path(go, "conv grad_input outside the matrix-core route")
+                wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
                 grad_input = torch.nn.grad.conv2d_input(input.shape, wq, go, stride=stride, padding=padding,
                                                         dilation=dilation, groups=groups)
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
@@ -794,12 +796,13 @@ class DorefaW1Conv2dFn(torch.autograd.Function):
         mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
-            sgn = quantize_weight_f32(weight, "binary")
             E = ctx.E if ctx.E is not None else weight.abs().mean()
             if mfma:     # g * (sign(W) E) = E * (g * sign(W)): the exact-split conv on the flipped +-1 weight, scaled after
-                grad_input = ops.conv2d_grad_input_q(input.shape, sgn, go, stride, padding, dilation, out_scale_dev=E)
+                grad_input = ops.conv2d_grad_input_q(input.shape, weight, go, stride, padding, dilation, kind="binary",
+                                                     out_scale_dev=E)
             if grad_input is None:
                 note_library_path(go, "conv grad_input outside the matrix-core route")
+                sgn = quantize_weight_f32(weight, "binary")
                 grad_input = torch.nn.grad.conv2d_input(input.shape, sgn * E, go, stride=stride, padding=padding,
                                                         dilation=dilation, groups=groups)
         if ctx.needs_input_grad[1]:

@@ -1507,11 +1507,27 @@ def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, al
     return y.view(*x.shape[:-1], N)
 
 
-def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int] = None) -> TriplePlanes:
-    """[Cout, Cin, kh, kw] -> triple / pair plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 6*Cin or 4*Cin bytes rounded to 16)."""
+def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int] = None, transpose_flip: bool = False) -> TriplePlanes:
+    """[Cout, Cin, kh, kw] -> triple / pair plane [Cout, kh*kw*Cb/2] (tap-major; Cb = 6*Cin or 4*Cin bytes rounded to 16).
+    ``transpose_flip``: the operand of grad_x instead — the plane of weight.flip(2, 3).transpose(0, 1), [Cin, kh*kw*Cb'/2].
+    The fp16 pair form comes from ONE kernel that reads the weight where it lies (qt_f16x2_pack_conv_weight_f32: quantiser,
+    flip / transpose, tap-major layout and row padding)."""
     _require(weight, "weight")
-    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
     terms = split_terms(terms)
+    if terms == 2 and weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() > 0:
+        Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+        rows, chans = (Cin, Cout) if transpose_flip else (Cout, Cin)
+        Cb = triple_ld_bytes(chans, 16, 2)
+        kbytes = kh * kw * Cb
+        ld = max(128, (kbytes + 127) // 128 * 128)
+        data = torch.empty((rows, ld // 2), dtype=torch.int16, device=weight.device)
+        with _on(weight.device):
+            _lib.call("qt_f16x2_pack_conv_weight_f32", _p(weight), Cout, Cin, kh, kw, int(_TRIPLE_MODES[kind]), int(bool(transpose_flip)),
+                      _p(data), int(ld), _stream(weight.device))
+        return TriplePlanes(data=data, rows=rows, K=kbytes // 4, terms=2)
+    if transpose_flip:
+        weight = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
     Cb = triple_ld_bytes(Cin, 16, terms)
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
     taps = weight_bf16x3(wt, kind, ld_bytes=Cb, terms=terms)
@@ -1739,8 +1755,9 @@ def bn_act_train_backward(grad_out: torch.Tensor, xs: torch.Tensor, res, gamma, 
 
 def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation,
                         kind: str = "sign", out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None):
-    """grad wrt the input of conv2d(x, weight_q) for a weight_q that is exact in bf16 — +-1 / 0 (``kind`` "sign") or integer
-    levels (``kind`` "raw": the k-bit DoReFa levels c = n * w_q, the caller scales by 1 / n): the forward's exact-split conv
+    """grad wrt the input of conv2d(x, Q(weight_q)): ``weight_q`` already quantised — +-1 / 0 (``kind`` "sign") or integer
+    levels (``kind`` "raw": the k-bit DoReFa levels c = n * w_q, the caller scales by 1 / n) — or the latent weight with its
+    quantiser (``kind`` "binary" / "ternary": applied inside the operand pack): the forward's exact-split conv
     of the gradient with the flipped, transposed weight.  Stride 1 directly; stride s > 1 (square, un-dilated — the
     3x3 / stride-2 and 1x1 / stride-2 convs of the reference's ResNets, models/Resnet/Resnet_bin.py:20-33) through the
     zero-dilated gradient: g_d[.., s y, s x] = g[.., y, x], zeros elsewhere and ``H + 2p - k - (Ho - 1) s`` rows / columns of
@@ -1763,8 +1780,11 @@ def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.
         gd = torch.zeros((N, (Ho - 1) * s + 1 + eh, (Wo - 1) * s + 1 + ew, Cout), dtype=g.dtype, device=g.device)   # NHWC
         gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = g.permute(0, 2, 3, 1)
         g = gd.permute(0, 3, 1, 2)
-    wT = weight_q.detach().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, kh, kw]
-    y2 = float_conv2d(g, wT, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1, out_scale=out_scale, out_scale_dev=out_scale_dev)
+    # the flipped, transposed weight [Cin, Cout, kh, kw] only ever exists as the conv's packed operand
+    wt = pack_conv_weight_bf16x3(weight_q.detach().contiguous(), kind, transpose_flip=True)
+    shape_t = torch.empty((Cin, Cout, kh, kw), dtype=torch.float32, device="meta")
+    y2 = float_conv2d(g, shape_t, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1, weight_triples=wt, out_scale=out_scale,
+                      out_scale_dev=out_scale_dev)
     return y2.view(N, H, W, C).permute(0, 3, 1, 2)
 
 

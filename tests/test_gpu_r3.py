@@ -953,3 +953,27 @@ def test_graphed_train_step_replays_the_eager_step(dev, which):
     assert torch.equal(loss_again, loss)                                                       # replay is reproducible
     with pytest.raises(ValueError):
         step(x1[:4], t1[:4])
+
+
+@pytest.mark.parametrize("Cout,Cin,k", [(64, 64, 3), (96, 33, 5), (40, 130, 1), (192, 3, 11)])
+@pytest.mark.parametrize("kind", ["binary", "ternary", "sign", "raw"])
+def test_conv_weight_pair_plane_in_one_kernel_equals_the_composed_form(dev, Cout, Cin, k, kind):
+    """qt_f16x2_pack_conv_weight_f32 (quantiser + [flip / transpose] + tap-major layout + row padding in one pass over the weight where
+    it lies) against the composition it replaces: permute -> contiguous -> qt_f16x2_pack_f32 -> zero-padded rows, for the forward
+    operand and for grad_x's flipped, transposed operand; odd channel counts exercise the 16-byte tap granule."""
+    torch.manual_seed(Cout + Cin + k)
+    w = torch.randn(Cout, Cin, k, k, device=dev) * 0.8
+    if kind == "raw":
+        w = torch.round(w * 5)
+    for tf in (False, True):
+        src = w.flip(2, 3).transpose(0, 1).contiguous() if tf else w
+        rows, chans = int(src.shape[0]), int(src.shape[1])
+        Cb = ops.triple_ld_bytes(chans, 16, 2)
+        taps = ops.weight_bf16x3(src.permute(0, 2, 3, 1).contiguous().view(rows * k * k, chans), kind, ld_bytes=Cb, terms=2)
+        want = taps.data.view(rows, k * k * Cb // 2)
+        before = _lib.call_counts["qt_f16x2_pack_conv_weight_f32"]
+        got = ops.pack_conv_weight_bf16x3(w, kind, terms=2, transpose_flip=tf)
+        assert _lib.call_counts["qt_f16x2_pack_conv_weight_f32"] == before + 1
+        assert got.rows == rows and got.terms == 2 and got.data.shape[1] % 64 == 0
+        assert torch.equal(got.data[:, :want.shape[1]], want)
+        assert not bool(got.data[:, want.shape[1]:].any())                       # padding is zero
