@@ -270,6 +270,11 @@ int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, in
 /* Weight codes: ternary == 0: safeSign(w) as +1/-1 ; ternary != 0: TernaryConnect codes {-1,0,+1}. */
 int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,
                        int64_t K, int ternary, qt_stream_t stream);
+/* The conv weight [Cout][Cin][kh][kw] (fp32, contiguous) as the int8 operand of qt_conv2d_implicit*(elem = 1) in one pass: codes of
+ * safeSign / ternary, tap-major, Cin rounded to 16 bytes per tap, rows zero-padded to ldc_bytes (layers/dorefa_layers.py:77-82's
+ * weight_op for 1-bit weights, without the permute / pad copies). */
+int qt_pack_conv_weight_codes_i8(const float* w, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int ternary, int8_t* codes,
+                                 int64_t ldc_bytes, qt_stream_t stream);
 
 /* ---- weight gradient of a stride-1 conv with +-1 / 0 activations (training; replaces torch.nn.grad.conv2d_weight behind
  * layers/binary_layers.py:105, functions/binary_connect.py:141-143) -------------------------------------------------------

@@ -985,10 +985,16 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
     _require(weight, "weight")
     Cout, Cin, kh, kw = (int(v) for v in weight.shape)
     Cb = code_ld_bytes(Cin, 16)
-    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
-    taps = weight_codes(wt, ternary, ld_bytes=Cb)
     kbytes = kh * kw * Cb
     ld = code_ld_bytes(kbytes, 512 if kbytes >= 2048 else 128)      # whole 512-byte stages for long K (skinny conv tiles)
+    if weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() > 0:
+        codes = torch.empty((Cout, ld), dtype=torch.int8, device=weight.device)
+        with _on(weight.device):                                    # one pass over the weight where it lies
+            _lib.call("qt_pack_conv_weight_codes_i8", _p(weight), Cout, Cin, kh, kw, int(bool(ternary)), _p(codes), int(ld),
+                      _stream(weight.device))
+        return CodePlanes(codes=codes, rows=Cout, K=kbytes)
+    wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
+    taps = weight_codes(wt, ternary, ld_bytes=Cb)
     codes = taps.codes.view(Cout, kbytes)
     if ld != kbytes:
         padded = torch.zeros((Cout, ld), dtype=torch.int8, device=weight.device)

@@ -977,3 +977,21 @@ def test_conv_weight_pair_plane_in_one_kernel_equals_the_composed_form(dev, Cout
         assert got.rows == rows and got.terms == 2 and got.data.shape[1] % 64 == 0
         assert torch.equal(got.data[:, :want.shape[1]], want)
         assert not bool(got.data[:, want.shape[1]:].any())                       # padding is zero
+
+
+@pytest.mark.parametrize("Cout,Cin,k", [(64, 64, 3), (96, 33, 5), (40, 130, 1), (512, 512, 3)])
+@pytest.mark.parametrize("ternary", [False, True])
+def test_conv_weight_code_plane_in_one_kernel_equals_the_composed_form(dev, Cout, Cin, k, ternary):
+    """qt_pack_conv_weight_codes_i8 against the composition it replaces (permute -> contiguous -> qt_weight_codes_i8 -> zero-padded
+    rows): same bytes, zero padding between the taps' channel granules and behind the row."""
+    torch.manual_seed(Cout + Cin + k)
+    w = torch.randn(Cout, Cin, k, k, device=dev) * 0.8
+    Cb = ops.code_ld_bytes(Cin, 16)
+    taps = ops.weight_codes(w.permute(0, 2, 3, 1).contiguous().view(Cout * k * k, Cin), ternary, ld_bytes=Cb)
+    want = taps.codes.view(Cout, k * k * Cb)
+    before = _lib.call_counts["qt_pack_conv_weight_codes_i8"]
+    got = ops.pack_conv_weight_codes(w, ternary)
+    assert _lib.call_counts["qt_pack_conv_weight_codes_i8"] == before + 1
+    assert got.rows == Cout and got.K == k * k * Cb
+    assert torch.equal(got.codes[:, :want.shape[1]], want)
+    assert not bool(got.codes[:, want.shape[1]:].any())
