@@ -91,6 +91,10 @@ int qt_ternarize_stochastic_f32(const float* x, const float* z, float* y, int64_
  * functions/binary_connect.py:31-38,64-71; functions/terner_connect.py:29-34,58-63. */
 int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, float thr,
                     qt_stream_t stream);
+/* out[i] = x[i] (x NULL: 0), or NaN for every i when (*flag & mask) != 0: folds a DEVICE range flag (codes beyond int8 / beyond the
+ * fp16 plane, a remembered +-1 verdict that no longer holds) into a bias or a gradient without a host synchronisation — a broken
+ * assumption yields NaN, never a plausible wrong number. */
+int qt_poison_f32(const float* x, const int32_t* flag, int32_t mask, float* out, int64_t n, qt_stream_t stream);
 
 /* DoReFa k-bit quantiser: k==1 -> safeSign; k==32 -> copy; else
  * y = fl(fl(1/n) * rint(n*x)), n = 2^k - 1, round-half-even, NO clamp.

@@ -43,6 +43,7 @@ SIGNATURES = {
     "qt_ternarize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "qt_ternarize_stochastic_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p]),
     "qt_ste_mask_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_f32, _c_p]),
+    "qt_poison_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_i64, _c_p]),
     "qt_dorefa_quantize_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     "qt_xnor_weight_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_shift_batch_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64,

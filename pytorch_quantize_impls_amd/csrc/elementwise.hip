@@ -136,6 +136,17 @@ int launch_binary(const float* a, const float* b, float* y, int64_t n, qt_stream
 
 }  // namespace
 
+namespace {
+// out[i] = (x ? x[i] : 0) and NaN instead when (*flag & mask) != 0: how a device-side range flag (the un-clamped DoReFa
+// quantiser left int8 / the fp16 plane; an un-tagged activation was not +-1 after all) reaches a result without a host sync
+__global__ __launch_bounds__(256) void poison_kernel(const float* __restrict__ x, const int32_t* __restrict__ flag, int32_t mask,
+                                                     float* __restrict__ out, int64_t n) {
+    const bool bad = (*flag & mask) != 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bad ? __builtin_nanf("") : (x ? x[i] : 0.0f);
+}
+}  // namespace
+
 extern "C" {
 
 int qt_binarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream) {
@@ -191,6 +202,13 @@ int qt_ternarize_stochastic_f32(const float* x, const float* z, float* y, int64_
 int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, float thr,
                     qt_stream_t stream) {
     return launch_binary(gout, x, gin, n, stream, Op2SteMask{thr});
+}
+
+int qt_poison_f32(const float* x, const int32_t* flag, int32_t mask, float* out, int64_t n, qt_stream_t stream) {
+    if (n < 0 || !flag || (n > 0 && !out)) return QT_ERR_INVALID_ARG;
+    if (n == 0) return QT_OK;
+    hipLaunchKernelGGL(poison_kernel, dim3(qt_stream_grid((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, flag, mask, out, n);
+    return qt_check_launch();
 }
 
 }  // extern "C"

@@ -179,9 +179,11 @@ def codes_route(codes, weight: Optional[torch.Tensor]):
 
 
 def poison_bias(bias: Optional[torch.Tensor], flag: Optional[torch.Tensor], n: int, device) -> Optional[torch.Tensor]:
-    """bias (+ NaN if the device flag is raised): three tiny launches instead of a host sync."""
+    """bias (+ NaN if the device flag is raised): one tiny launch instead of a host sync."""
     if flag is None:
         return bias
+    if flag.dtype == torch.int32 and flag.is_cuda:
+        return ops.poison(bias.detach() if bias is not None else None, flag, -1, n)
     nanv = torch.where(flag.reshape(()) != 0, float("nan"), 0.0)
     base = bias.detach() if bias is not None else torch.zeros((n,), dtype=torch.float32, device=device)
     return base + nanv
@@ -864,7 +866,8 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
         elif int(ksz[0]) > 1 and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
             gw = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=x_levels)     # the pixel-major kernel too
         if gw is not None:
-            return gw + torch.where((code_flag.reshape(()) & 2) != 0, float("nan"), 0.0)
+            return ops.poison(gw, code_flag, 2) if code_flag.dtype == torch.int32 else \
+                gw + torch.where((code_flag.reshape(()) & 2) != 0, float("nan"), 0.0)
     q = torch.round(input.detach() * float(x_levels))
     hi = torch.floor(q * (1.0 / 256.0))
     lo = q - hi * 256.0

@@ -1711,6 +1711,21 @@ def pool_bn_sign_train_backward(grad_out: torch.Tensor, saved, gamma, beta, ht, 
     return (gin.permute(0, 3, 1, 2) if grad_out.dim() == 4 else gin.view(N, C)), dgamma, dbeta
 
 
+def poison(x: Optional[torch.Tensor], flag: torch.Tensor, mask: int = -1, n: Optional[int] = None) -> torch.Tensor:
+    """x (or n zeros), turned into NaN when ``flag & mask`` is set on the device (qt_poison_f32): one launch, no host sync."""
+    _require(flag, "flag", torch.int32)
+    if x is not None:
+        x = _require(x, "input").contiguous()
+        out = torch.empty_like(x)
+        cnt = x.numel()
+    else:
+        out = torch.empty((int(n),), dtype=torch.float32, device=flag.device)
+        cnt = int(n)
+    with _on(flag.device):
+        _lib.call("qt_poison_f32", _p(x), _p(flag), int(mask), _p(out), cnt, _stream(flag.device))
+    return out
+
+
 # ---- training-mode chain BatchNorm(batch stats) [+ residual] [-> ReLU] [-> nnDorefaQuant] (csrc/train_chain.hip, codes_i8.hip) -----
 
 def bn_train_stats(x: torch.Tensor, running_mean, running_var, eps: float, momentum: float):

@@ -42,7 +42,9 @@ def main():
             m(x)
         pr.disable()
         torch.cuda.synchronize()
-        pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get("TOP", "28")))
+        if os.environ.get("CUM"):
+            pstats.Stats(pr).sort_stats("cumtime").print_stats(int(os.environ.get("TOP", "28")))
         print(dict(lazy.STATS))
 
 
