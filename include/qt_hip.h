@@ -274,11 +274,11 @@ int qt_pool_codes_i8(const int8_t* in_plane, int64_t N, int64_t H, int64_t W, in
 /* Weight codes: ternary == 0: safeSign(w) as +1/-1 ; ternary != 0: TernaryConnect codes {-1,0,+1}. */
 int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_bytes, int64_t rows,
                        int64_t K, int ternary, qt_stream_t stream);
-/* The conv weight [Cout][Cin][kh][kw] (fp32, contiguous) as the int8 operand of qt_conv2d_implicit*(elem = 1) in one pass: codes of
+/* The conv weight [Cout][Cin][kh][kw] (fp32, given by its element strides) as the int8 operand of qt_conv2d_implicit*(elem = 1) in one pass: codes of
  * safeSign / ternary, tap-major, Cin rounded to 16 bytes per tap, rows zero-padded to ldc_bytes (layers/dorefa_layers.py:77-82's
  * weight_op for 1-bit weights, without the permute / pad copies). */
-int qt_pack_conv_weight_codes_i8(const float* w, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int ternary, int8_t* codes,
-                                 int64_t ldc_bytes, qt_stream_t stream);
+int qt_pack_conv_weight_codes_i8(const float* w, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, int64_t Cout,
+                                 int64_t Cin, int64_t kh, int64_t kw, int ternary, int8_t* codes, int64_t ldc_bytes, qt_stream_t stream);
 
 /* ---- weight gradient of a stride-1 conv with +-1 / 0 activations (training; replaces torch.nn.grad.conv2d_weight behind
  * layers/binary_layers.py:105, functions/binary_connect.py:141-143) -------------------------------------------------------
@@ -452,12 +452,13 @@ int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t
 int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2, uint16_t* out,
                           int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw,
                           qt_stream_t stream);
-/* The conv weight [Cout][Cin][kh][kw] (fp32, contiguous) as the fp16 pair-plane operand of qt_conv2d_implicit(elem = 3): quantised
+/* The conv weight [Cout][Cin][kh][kw] (fp32, given by its element strides: contiguous or channels-last) as the fp16 pair-plane operand of qt_conv2d_implicit(elem = 3): quantised
  * by `mode` (1 safeSign, 2 ternary, 3 torch.sign, 4 raw) and replicated twice, rows tap-major with 16-byte tap granules, padded with
  * zeros to ld_bytes (a multiple of 128).  transpose_flip = 1: the operand of grad_x — rows = Cin, channels = Cout, taps flipped
  * (torch.nn.grad.conv2d_input's conv_transpose as a conv; functions/binary_connect.py:141). */
-int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int mode, int transpose_flip,
-                                  uint16_t* out, int64_t ld_bytes, qt_stream_t stream);
+int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, int64_t Cout,
+                                  int64_t Cin, int64_t kh, int64_t kw, int mode, int transpose_flip, uint16_t* out, int64_t ld_bytes,
+                                  qt_stream_t stream);
 int qt_f16_gemm(const uint32_t* Xh, int64_t ldxp, const uint32_t* Wh, int64_t ldwp, const float* bias, float scale,
                 const float* scale_dev, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
 

@@ -93,7 +93,7 @@ SIGNATURES = {
     "qt_nib_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
-    "qt_pack_conv_weight_codes_i8": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p]),
+    "qt_pack_conv_weight_codes_i8": (_c_int, [_c_p] + [_c_i64] * 8 + [_c_int, _c_p, _c_i64, _c_p]),
     "qt_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "qt_bn_eval_device_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_affine_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
@@ -112,7 +112,7 @@ SIGNATURES = {
     "qt_f16x2_absmax_ch_work_words": (_c_i64, [_c_i64]),
     "qt_f16x2_absmax_scale_ch_f32": (_c_int, [_c_p] + [_c_i64] * 9 + [_c_p, _c_p, _c_p]),
     "qt_f16x2_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
-    "qt_f16x2_pack_conv_weight_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_i64, _c_p]),
+    "qt_f16x2_pack_conv_weight_f32": (_c_int, [_c_p] + [_c_i64] * 8 + [_c_int, _c_int, _c_p, _c_i64, _c_p]),
     "qt_f16x2_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_train_chain_partial_floats": (_c_i64, [_c_i64, _c_i64]),

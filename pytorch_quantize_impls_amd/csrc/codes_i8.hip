@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
 // The conv weight [Cout][Cin][kh][kw] as the int8 operand of the code-plane convs in one pass: row co, tap (i, j), channel ci
 // hold safeSign / ternary of w[co][ci][i][j]; taps are cb bytes apart (Cin rounded to 16), the row is zero-padded to ldc bytes.
 // One thread = one 4-byte word of the output row.  (Was: permute copy, pack, zero fill, padded copy.)
-__global__ __launch_bounds__(256) void conv_weight_codes_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int ternary,
+__global__ __launch_bounds__(256) void conv_weight_codes_kernel(const float* __restrict__ w, int64_t so, int64_t si, int64_t sh, int64_t sw,
+                                                                int Cout, int Cin, int taps, int kw, int ternary,
                                                                 int8_t* __restrict__ codes, int64_t ldc, int cb) {
     const int64_t words_per_row = ldc / 4, total = (int64_t)Cout * words_per_row;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(256) void conv_weight_codes_kernel(const float* __r
         const int tap = byte0 / cb, c0 = byte0 - tap * cb;
         uint32_t word = 0;
         if (tap < taps) {
+            const int i = tap / kw, j = tap - i * kw;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ci = c0 + e;
                 if (ci >= Cin) break;
-                const float v = w[((int64_t)co * Cin + ci) * taps + tap];
+                const float v = w[co * so + ci * si + i * sh + j * sw];
                 const int q = (int)(ternary ? qt_ternarize(v) : qt_safe_sign(v));
                 word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
             }
@@ -253,14 +255,15 @@ int qt_weight_codes_i8(const float* w, int64_t ldw, int8_t* codes, int64_t ldc_b
     return qt_check_launch();
 }
 
-int qt_pack_conv_weight_codes_i8(const float* w, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int ternary, int8_t* codes,
-                                 int64_t ldc_bytes, qt_stream_t stream) {
+int qt_pack_conv_weight_codes_i8(const float* w, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, int64_t Cout,
+                                 int64_t Cin, int64_t kh, int64_t kw, int ternary, int8_t* codes, int64_t ldc_bytes, qt_stream_t stream) {
     if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || !w || !codes) return QT_ERR_INVALID_ARG;
     const int64_t cb = (Cin + 15) / 16 * 16;
     if (ldc_bytes < kh * kw * cb || (ldc_bytes & 15) || !qt_aligned16(codes)) return QT_ERR_ALIGNMENT;
     if (Cout * Cin * kh * kw >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(conv_weight_codes_kernel, dim3(qt_stream_grid((Cout * (ldc_bytes / 4) + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, (int)Cout, (int)Cin, (int)(kh * kw), ternary, codes, ldc_bytes, (int)cb);
+                       (hipStream_t)stream, w, stride_o, stride_i, stride_h, stride_w, (int)Cout, (int)Cin, (int)(kh * kw), (int)kw, ternary, codes,
+                       ldc_bytes, (int)cb);
     return qt_check_launch();
 }
 

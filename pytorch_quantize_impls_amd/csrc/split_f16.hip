@@ -301,15 +301,16 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
 }
 
 
-// The conv weight as the GEMM operand of the pair-plane convs, straight from its [Cout][Cin][kh][kw] storage: row r, tap (i, j),
+// The conv weight as the GEMM operand of the pair-plane convs, straight from its [Cout][Cin][kh][kw] storage (any strides: contiguous
+// or channels-last): row r, tap (i, j),
 // channel c hold q(w[...]) twice (fp16), q = the quantiser of `mode` (1 safeSign, 2 ternary, 3 torch.sign, 4 the value itself):
 //   forward operand  (transpose_flip = 0): rows = Cout, channels = Cin:  w[r][c][i][j]
 //   grad_x operand   (transpose_flip = 1): rows = Cin, channels = Cout: w[c][r][kh-1-i][kw-1-j]   (flipped, transposed weight)
 // Row layout as ops.pack_conv_weight_bf16x3 builds it: tap-major, Cb = 4 * channels bytes rounded to 16 per tap, the row padded
 // with zeros to ld_bytes.  (Was: quantise, flip, transpose copy, permute copy, pack — five launches and three copies per conv.)
-__global__ __launch_bounds__(256) void conv_weight_pair_kernel(const float* __restrict__ w, int Cout, int Cin, int kh, int kw, int mode,
-                                                               int transpose_flip, uint32_t* __restrict__ out, int64_t ld_words,
-                                                               int cb_words) {
+__global__ __launch_bounds__(256) void conv_weight_pair_kernel(const float* __restrict__ w, int64_t so, int64_t si, int64_t sh, int64_t sw,
+                                                               int Cout, int Cin, int kh, int kw, int mode, int transpose_flip,
+                                                               uint32_t* __restrict__ out, int64_t ld_words, int cb_words) {
     const int rows = transpose_flip ? Cin : Cout, chans = transpose_flip ? Cout : Cin, taps = kh * kw;
     const int64_t total = (int64_t)rows * ld_words;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256) void conv_weight_pair_kernel(const float* __re
         uint32_t v = 0;
         if (tap < taps && c < chans) {
             const int i = tap / kw, j = tap - i * kw;
-            const float x = transpose_flip ? w[(((int64_t)c * Cin + r) * kh + (kh - 1 - i)) * kw + (kw - 1 - j)]
-                                           : w[(((int64_t)r * Cin + c) * kh + i) * kw + j];
+            const float x = transpose_flip ? w[c * so + r * si + (kh - 1 - i) * sh + (kw - 1 - j) * sw]
+                                           : w[r * so + c * si + i * sh + j * sw];
             float q;
             if (mode == 1) q = qt_safe_sign(x);
             else if (mode == 2) q = qt_ternarize(x);
@@ -429,8 +430,9 @@ extern "C" int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int
     return qt_check_launch();
 }
 
-extern "C" int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int mode,
-                                             int transpose_flip, uint16_t* out, int64_t ld_bytes, qt_stream_t stream) {
+extern "C" int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w,
+                                             int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int mode, int transpose_flip,
+                                             uint16_t* out, int64_t ld_bytes, qt_stream_t stream) {
     if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || mode < 1 || mode > 4 || !w || !out) return QT_ERR_INVALID_ARG;
     const int64_t rows = transpose_flip ? Cin : Cout, chans = transpose_flip ? Cout : Cin;
     const int64_t cb = (4 * chans + 15) / 16 * 16;             // bytes per tap (fp16 pairs, 16-byte granule)
@@ -438,7 +440,7 @@ extern "C" int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t Cout, int64
     if (Cout * Cin * kh * kw >= (1ll << 31) || rows * ld_bytes >= (1ll << 33)) return QT_ERR_UNSUPPORTED;
     const int64_t ld_words = ld_bytes / 4;
     hipLaunchKernelGGL(conv_weight_pair_kernel, dim3(qt_stream_grid((rows * ld_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (int)Cout, (int)Cin, (int)kh, (int)kw, mode, transpose_flip, reinterpret_cast<uint32_t*>(out), ld_words,
-                       (int)(cb / 4));
+                       stride_o, stride_i, stride_h, stride_w, (int)Cout, (int)Cin, (int)kh, (int)kw, mode, transpose_flip,
+                       reinterpret_cast<uint32_t*>(out), ld_words, (int)(cb / 4));
     return qt_check_launch();
 }

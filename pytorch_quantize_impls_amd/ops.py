@@ -987,10 +987,11 @@ def pack_conv_weight_codes(weight: torch.Tensor, ternary: bool = False) -> CodeP
     Cb = code_ld_bytes(Cin, 16)
     kbytes = kh * kw * Cb
     ld = code_ld_bytes(kbytes, 512 if kbytes >= 2048 else 128)      # whole 512-byte stages for long K (skinny conv tiles)
-    if weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() > 0:
+    if weight.dtype == torch.float32 and weight.numel() > 0:
         codes = torch.empty((Cout, ld), dtype=torch.int8, device=weight.device)
-        with _on(weight.device):                                    # one pass over the weight where it lies
-            _lib.call("qt_pack_conv_weight_codes_i8", _p(weight), Cout, Cin, kh, kw, int(bool(ternary)), _p(codes), int(ld),
+        with _on(weight.device):                                    # one pass over the weight where it lies (any strides)
+            _lib.call("qt_pack_conv_weight_codes_i8", _p(weight), *(int(v) for v in weight.stride()), Cout, Cin, kh, kw,
+                      int(bool(ternary)), _p(codes), int(ld),
                       _stream(weight.device))
         return CodePlanes(codes=codes, rows=Cout, K=kbytes)
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)
@@ -1520,7 +1521,7 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int
     flip / transpose, tap-major layout and row padding)."""
     _require(weight, "weight")
     terms = split_terms(terms)
-    if terms == 2 and weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() > 0:
+    if terms == 2 and weight.dtype == torch.float32 and weight.dim() == 4 and weight.numel() > 0:
         Cout, Cin, kh, kw = (int(v) for v in weight.shape)
         rows, chans = (Cin, Cout) if transpose_flip else (Cout, Cin)
         Cb = triple_ld_bytes(chans, 16, 2)
@@ -1528,7 +1529,8 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int
         ld = max(128, (kbytes + 127) // 128 * 128)
         data = torch.empty((rows, ld // 2), dtype=torch.int16, device=weight.device)
         with _on(weight.device):
-            _lib.call("qt_f16x2_pack_conv_weight_f32", _p(weight), Cout, Cin, kh, kw, int(_TRIPLE_MODES[kind]), int(bool(transpose_flip)),
+            _lib.call("qt_f16x2_pack_conv_weight_f32", _p(weight), *(int(v) for v in weight.stride()), Cout, Cin, kh, kw,
+                      int(_TRIPLE_MODES[kind]), int(bool(transpose_flip)),
                       _p(data), int(ld), _stream(weight.device))
         return TriplePlanes(data=data, rows=rows, K=kbytes // 4, terms=2)
     if transpose_flip:
@@ -1802,7 +1804,7 @@ def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.
         gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = g.permute(0, 2, 3, 1)
         g = gd.permute(0, 3, 1, 2)
     # the flipped, transposed weight [Cin, Cout, kh, kw] only ever exists as the conv's packed operand
-    wt = pack_conv_weight_bf16x3(weight_q.detach().contiguous(), kind, transpose_flip=True)
+    wt = pack_conv_weight_bf16x3(weight_q.detach(), kind, transpose_flip=True)
     shape_t = torch.empty((Cin, Cout, kh, kw), dtype=torch.float32, device="meta")
     y2 = float_conv2d(g, shape_t, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1, weight_triples=wt, out_scale=out_scale,
                       out_scale_dev=out_scale_dev)

@@ -971,12 +971,13 @@ def test_conv_weight_pair_plane_in_one_kernel_equals_the_composed_form(dev, Cout
         Cb = ops.triple_ld_bytes(chans, 16, 2)
         taps = ops.weight_bf16x3(src.permute(0, 2, 3, 1).contiguous().view(rows * k * k, chans), kind, ld_bytes=Cb, terms=2)
         want = taps.data.view(rows, k * k * Cb // 2)
-        before = _lib.call_counts["qt_f16x2_pack_conv_weight_f32"]
-        got = ops.pack_conv_weight_bf16x3(w, kind, terms=2, transpose_flip=tf)
-        assert _lib.call_counts["qt_f16x2_pack_conv_weight_f32"] == before + 1
-        assert got.rows == rows and got.terms == 2 and got.data.shape[1] % 64 == 0
-        assert torch.equal(got.data[:, :want.shape[1]], want)
-        assert not bool(got.data[:, want.shape[1]:].any())                       # padding is zero
+        for wsrc in (w, w.contiguous(memory_format=torch.channels_last)):      # the weight of a channels_last model is strided so
+            before = _lib.call_counts["qt_f16x2_pack_conv_weight_f32"]
+            got = ops.pack_conv_weight_bf16x3(wsrc, kind, terms=2, transpose_flip=tf)
+            assert _lib.call_counts["qt_f16x2_pack_conv_weight_f32"] == before + 1
+            assert got.rows == rows and got.terms == 2 and got.data.shape[1] % 64 == 0
+            assert torch.equal(got.data[:, :want.shape[1]], want)
+            assert not bool(got.data[:, want.shape[1]:].any())                   # padding is zero
 
 
 @pytest.mark.parametrize("Cout,Cin,k", [(64, 64, 3), (96, 33, 5), (40, 130, 1), (512, 512, 3)])
@@ -989,9 +990,10 @@ def test_conv_weight_code_plane_in_one_kernel_equals_the_composed_form(dev, Cout
     Cb = ops.code_ld_bytes(Cin, 16)
     taps = ops.weight_codes(w.permute(0, 2, 3, 1).contiguous().view(Cout * k * k, Cin), ternary, ld_bytes=Cb)
     want = taps.codes.view(Cout, k * k * Cb)
-    before = _lib.call_counts["qt_pack_conv_weight_codes_i8"]
-    got = ops.pack_conv_weight_codes(w, ternary)
-    assert _lib.call_counts["qt_pack_conv_weight_codes_i8"] == before + 1
-    assert got.rows == Cout and got.K == k * k * Cb
-    assert torch.equal(got.codes[:, :want.shape[1]], want)
-    assert not bool(got.codes[:, want.shape[1]:].any())
+    for wsrc in (w, w.contiguous(memory_format=torch.channels_last)):
+        before = _lib.call_counts["qt_pack_conv_weight_codes_i8"]
+        got = ops.pack_conv_weight_codes(wsrc, ternary)
+        assert _lib.call_counts["qt_pack_conv_weight_codes_i8"] == before + 1
+        assert got.rows == Cout and got.K == k * k * Cb
+        assert torch.equal(got.codes[:, :want.shape[1]], want)
+        assert not bool(got.codes[:, want.shape[1]:].any())
