@@ -989,6 +989,7 @@ template <class E> using PP64 = GemmCfg<E, 4, 2, 2, 1, 2, 0, 64, false>;
 template <class E> using ConvPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 1>;
 template <class E> using ConvPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 1>;   // 384x192 tile: wave tile 96x96, 6 reads per 9 MFMAs
 template <class E> using ConvPP128 = GemmCfg<E, 2, 4, 4, 1, 2, 0, 64, 1>;
+template <class E> using ConvPP256x192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, 1>;   // 256x192 ping-pong (the GEMM's PP192 as a conv)
 #ifdef QT_PROFILING_VARIANTS
 template <class E> using ConvPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 1>;   // profiling builds only (conv variant 3)
 #endif
@@ -1522,6 +1523,13 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
         }                                                                                                       \
         if (g_conv_force == 0 && tn == 192 && prefer_384_rows(M, Cout))                                         \
             return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        /* long K (>= 2 KiB per output row), wide tiles: the ping-pong main loop beats the double-buffered one on the   */ \
+        /* padded convs too (tools/bench_grad_input_variants.py: grad_x 512 ch @ 28x28 0.532 -> 0.485 ms, 768 -> 1152   */ \
+        /* @ 13x13 1.34 -> 1.25); the 384-row tile only where its rounds pay (above), else 256 rows                     */ \
+        if (g_conv_force == 0 && kwords * 4 >= 2048) {                                                          \
+            if (tn == 256) return launch_cfg<ConvPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (tn == 192) return launch_cfg<ConvPP256x192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+        }                                                                                                       \
         if (g_conv_force == 2) {                                                                                \
             if (tn == 256) return launch_cfg<ConvPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 192) return launch_cfg<ConvPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
