@@ -1072,8 +1072,13 @@ class QuantLinearFn(torch.autograd.Function):
         # +-1 activation known without a device check (tag of a quantiser, or the layer's binary_input hint)?
         ctx.x_is_pm1 = bool(binary_input) or (input.is_cuda and input.dtype == torch.float32
                                               and packed.lookup(input, packed.ROWS_LAST) is not None)
-        return quant_linear_forward(input, weight, bias, kind, weight_q=weight_q,
-                                    binary_input=binary_input)
+        clear_last_detection()
+        out = quant_linear_forward(input, weight, bias, kind, weight_q=weight_q, binary_input=binary_input)
+        if not ctx.x_is_pm1 and binary_input is None and input.is_cuda:
+            # un-tagged activation THIS forward detected as +-1 (a reshaped / flattened sign image): the backward's g^T . x then
+            # runs on the matrix cores as well instead of the dense library
+            ctx.x_is_pm1 = last_detection_said_pm1(input)
+        return out
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -1087,7 +1092,12 @@ class QuantLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             x2 = input.reshape(-1, input.shape[-1])
             # (rows of g2^T are output features: the exact three-term split, not the per-tensor-scaled two-term one)
-            gw = pm1_matmul(g2.t(), x2, terms=3) if ctx.x_is_pm1 else g2.t().mm(x2)
+            if ctx.x_is_pm1:
+                gw = pm1_matmul(g2.t(), x2, terms=3)
+            else:
+                if g2.is_cuda and g2.dtype == torch.float32 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS:
+                    note_library_path(g2, "backward GEMM with two real operands")
+                gw = g2.t().mm(x2)
             grad_weight = ste_mask(gw, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)
