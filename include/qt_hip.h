@@ -319,8 +319,10 @@ int qt_wgrad_reduce_f32(const float* partial, int64_t ldc, int64_t z_stride, int
  *                               each, a multiple of 32) of g[q][co] * XP[q + r * kh_rows + c][ci], tap = r * kw + c.  XP must hold
  *                               Qa + (kh - 1) * kh_rows + 48 rows.  (kh, kw) = (3, 3) with Cpi % 64 == 0 or (5, 5) with
  *                               Cpi % 32 == 0; QT_ERR_UNSUPPORTED otherwise.
- *   qt_wgrad_pm_reduce_f32    : dW[(co * Cin + ci) * taps + tap] (+)= out_scale * row_scale[co] * sum over slices (row_scale NULL:
- *                               1), times the straight-through mask 1[|weight| <= ste_threshold] when weight != NULL. */
+ *   qt_wgrad_pm_reduce_f32    : dW[co, ci, i, j] (+)= out_scale * row_scale[co] * sum over slices (row_scale NULL: 1), times the
+ *                               straight-through mask 1[|weight| <= ste_threshold] when weight != NULL; dW and weight are addressed
+ *                               by ONE set of element strides (contiguous: (Cin taps, taps, kw, 1); or the channels-last
+ *                               strides of a channels_last model's parameter). */
 int qt_wgrad_pm_pack_grad_f32(const float* g, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N,
                               int64_t Cout, int64_t Ho, int64_t Wo, int64_t Wq, int64_t Cp, int64_t Qa, uint16_t* G3,
                               qt_stream_t stream);
@@ -346,7 +348,7 @@ int qt_wgrad_pm_f32(const uint16_t* G3, const uint16_t* XP, float* part, int64_t
                     int64_t Cpo, int64_t Cpi, int64_t kh, int64_t kw, qt_stream_t stream);
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
                            const float* weight, float ste_threshold, float out_scale, const float* row_scale, int accumulate,
-                           float* dW, qt_stream_t stream);
+                           float* dW, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, qt_stream_t stream);
 /* Round 3: the same weight gradient with the gradient as TWO fp16 planes of g[.., c] / s[c] and the activation plane in fp16 —
  * 2/3 of the MFMAs and of the gradient bytes, bound in csrc/split_f16.hip.  scale2c = [s[0..Cp) | 1 / s[0..Cp)]: PER-CHANNEL
  * powers of two from qt_f16x2_absmax_scale_ch_f32 (a row of dW only sees its own gradient channel, so every row keeps the

@@ -792,11 +792,11 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
 // one work item = one (co, ci) with all its taps: sums the K slices (reads coalesced along ci), applies the scales and the STE
 // mask, writes / accumulates the T consecutive values dW[co][ci][0..T) (one (co, ci, tap) per thread scattered 4-byte writes
 // 4 T bytes apart: 37 us for a 512 x 512 x 9 layer, twice what the bytes need)
-template <int T>
+template <int T, int KW>
 __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int Cpo, int Cpi,
                                                         int Cout, int Cin, const float* __restrict__ weight, float thr,
                                                         float out_scale, const float* __restrict__ row_scale, int accumulate,
-                                                        float* __restrict__ dW) {
+                                                        float* __restrict__ dW, int64_t so, int64_t si, int64_t sh, int64_t sw) {
     const int64_t total = (int64_t)Cout * Cin;
     const int64_t tap_elems = (int64_t)Cpo * Cpi, slice_elems = (int64_t)T * tap_elems;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -810,14 +810,15 @@ __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict_
             for (int tap = 0; tap < T; ++tap) acc[tap] += p[sl * slice_elems + tap * tap_elems];
         }
         const float rs = row_scale ? row_scale[co] : 1.0f;          // the two-plane gradient's per-channel power of two
-        float* o = dW + t * T;
-        const float* w = weight ? weight + t * T : nullptr;
+        // dW and the weight share ONE set of element strides (contiguous, or channels-last like the parameter of a channels_last model)
+        const int64_t base = co * so + ci * si;
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
+            const int64_t o = base + (tap / KW) * sh + (tap % KW) * sw;
             float v = acc[tap] * out_scale;
             if (row_scale) v *= rs;
-            if (w && !(fabsf(w[tap]) <= thr)) v = 0.0f;
-            o[tap] = accumulate ? o[tap] + v : v;
+            if (weight && !(fabsf(weight[o]) <= thr)) v = 0.0f;
+            dW[o] = accumulate ? dW[o] + v : v;
         }
     }
 }
@@ -1022,16 +1023,18 @@ int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t
 
 int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int64_t Cpo, int64_t Cpi, int64_t Cout, int64_t Cin,
                            const float* weight, float ste_threshold, float out_scale, const float* row_scale, int accumulate,
-                           float* dW, qt_stream_t stream) {
+                           float* dW, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, qt_stream_t stream) {
     if (!part || !dW || nslice <= 0 || taps <= 0 || Cout <= 0 || Cin <= 0 || Cpo < Cout || Cpi < Cin) return QT_ERR_INVALID_ARG;
     if (taps != 9 && taps != 25) return QT_ERR_UNSUPPORTED;       // the kernels this reduce serves: 3 x 3 and 5 x 5
     const dim3 grid(qt_stream_grid((Cout * Cin + 255) / 256));
     if (taps == 9)
-        hipLaunchKernelGGL((pm_reduce_kernel<9>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
-                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW);
+        hipLaunchKernelGGL((pm_reduce_kernel<9, 3>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
+                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW, stride_o, stride_i, stride_h,
+                           stride_w);
     else
-        hipLaunchKernelGGL((pm_reduce_kernel<25>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
-                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW);
+        hipLaunchKernelGGL((pm_reduce_kernel<25, 5>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
+                           (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW, stride_o, stride_i, stride_h,
+                           stride_w);
     return qt_check_launch();
 }
 

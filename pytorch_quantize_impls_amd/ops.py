@@ -2127,13 +2127,18 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
         with _on(dev):
             _lib.call("qt_f16x2_absmax_scale_ch_f32", _p(g), int(g.stride(0)), int(g.stride(1)), int(g.stride(2)), int(g.stride(3)),
                       int(N), int(Cout), int(Ho), int(Wo), int(Cpo), _p(work), _p(scale2), _stream(dev))
-    dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
+    # the result takes the weight's own layout (a channels_last model keeps channels-last parameters): no contiguous() copy of
+    # the weight for the STE mask, no re-layout when autograd accumulates the gradient
+    w = None
+    if weight is not None:
+        w = _require(weight.detach(), "weight")
+        if tuple(w.shape) != (Cout, Cin, kh, kw) or not (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)):
+            w = w.contiguous()
+    dW = torch.empty_like(w) if w is not None else torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
+    dws = tuple(int(v) for v in dW.stride())
     G3 = torch.empty(((2 if two else 3) * qa_m * Cpo,), dtype=torch.int16, device=dev)
     XP = torch.empty((qx_m * Cpi,), dtype=torch.int16, device=dev)
     part = torch.empty((ns_m * taps * Cpo * Cpi,), dtype=torch.float32, device=dev)
-    w = None
-    if weight is not None:
-        w = _require(weight.detach(), "weight").contiguous()
     I = int
     st = _stream(dev)
     want_bias = bias_grad is not None and g.stride(1) == 1 and Cpo <= 2048
@@ -2162,7 +2167,7 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
             _lib.call("qt_wgrad_pm_f16" if two else "qt_wgrad_pm_f32", _p(G3), _p(XP), _p(part), I(qa_u), I(cnt * Wq), I(ns_u),
                       I(Cpo), I(Cpi), I(kh), I(kw), st)
             _lib.call("qt_wgrad_pm_reduce_f32", _p(part), I(ns_u), I(taps), I(Cpo), I(Cpi), I(Cout), I(Cin), _p(w),
-                      float(ste_threshold), float(out_scale), _p(scale2), int(n0 > 0), _p(dW), st)
+                      float(ste_threshold), float(out_scale), _p(scale2), int(n0 > 0), _p(dW), *dws, st)
     if want_bias:
         bias_grad.append(db)
     return dW

@@ -997,3 +997,17 @@ def test_conv_weight_code_plane_in_one_kernel_equals_the_composed_form(dev, Cout
         assert got.rows == Cout and got.K == k * k * Cb
         assert torch.equal(got.codes[:, :want.shape[1]], want)
         assert not bool(got.codes[:, want.shape[1]:].any())
+
+
+def test_weight_gradient_takes_the_layout_of_a_channels_last_parameter(dev):
+    """The pixel-major reduce addresses dW and the STE mask's weight by the parameter's own strides: a channels_last model's
+    (channels-last) weight is neither copied to contiguous nor is its gradient re-laid-out by autograd — same values."""
+    torch.manual_seed(3)
+    x = torch.where(torch.randn(4, 64, 12, 12, device=dev) < 0, -1.0, 1.0).contiguous(memory_format=torch.channels_last)
+    go = torch.randn(4, 96, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(96, 64, 3, 3, device=dev) * 0.8
+    a = ops.conv2d_grad_weight_pm(x, go, (3, 3), 1, weight=w)
+    b = ops.conv2d_grad_weight_pm(x, go, (3, 3), 1, weight=w.contiguous(memory_format=torch.channels_last))
+    assert a.is_contiguous() and b.is_contiguous(memory_format=torch.channels_last) and not b.is_contiguous()
+    assert torch.equal(a, b)
+    assert bool((b[w.abs() > 1.001] == 0).all()) and bool((b != 0).any())

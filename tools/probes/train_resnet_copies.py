@@ -6,14 +6,15 @@ from pytorch_quantize_impls_amd.functions import _fused
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = bench_models.DorefaResNet18(w_bits=1, a_bits=4).to(dev).to(memory_format=torch.channels_last).train()
-x = torch.randn(256, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+alex = os.environ.get("MODEL") == "alexnet"
+model = (bench_models.AlexNetBin() if alex else bench_models.DorefaResNet18(w_bits=1, a_bits=4)).to(dev).to(memory_format=torch.channels_last).train()
+x = torch.randn(*((256, 3, 224, 224) if alex else (256, 3, 32, 32)), device=dev).contiguous(memory_format=torch.channels_last)
 t = torch.randint(0, 10, (256,), device=dev)
 _fused.DETECT_MODE = "remember"
-net = bench_models.TrainFusedDorefaResNet18(model) if os.environ.get("FUSED") else model
+net = ((bench_models.TrainFusedAlexNetBin if alex else bench_models.TrainFusedDorefaResNet18)(model)) if os.environ.get("FUSED") else model
 def step():
     model.zero_grad(set_to_none=True)
-    F.nll_loss(F.log_softmax(net(x), 1), t).backward()
+    F.nll_loss(net(x) if alex else F.log_softmax(net(x), 1), t).backward()
 for _ in range(4): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
