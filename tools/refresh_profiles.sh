@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run HERE after `gpurun -- 'bash tools/collect_profiles.sh <tag>'` (+ the four training-step traces, see below) merged its output
+# into gpurun_out/: condenses the raw rocprofv3 CSVs into the summaries committed under profiles/.
+#   training-step traces (on the GPU box, cwd /tmp, TMPDIR=/tmp):
+#     [FUSED=1] rocprofv3 --kernel-trace --stats -d gpurun_out/tr_{rn,ax}_{mod,fused} -o t --output-format csv -- python tools/probes/train_{resnet,chain}_prof.py
+TAG=${1:-r3}
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd "$R"
+python tools/prof_summary.py gpurun_out/$TAG > profiles/${TAG}_bench_rocprof.md
+cp gpurun_out/$TAG/bench_line.json profiles/${TAG}_bench_line.json
+cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
+for c in c4 c5; do
+  { echo "# rocprofv3 --kernel-trace --stats of the $c line of bench.py's extra object (tools/collect_profiles.sh $TAG): name, calls, total us, avg us"
+    echo '```'; python tools/kstats.py gpurun_out/$TAG/kt_$c | sort -k3 -n -r | head -70; echo '```'; } > profiles/${TAG}_${c}_rocprof.md
+done
+if [ -d gpurun_out/tr_rn_mod ]; then
+  { echo "# Training steps, batch 256, per-kernel-class split (round 3, final state)"; echo
+    echo "\`rocprofv3 --kernel-trace --stats -- python tools/probes/train_resnet_prof.py\` (DoReFa ResNet-18 W1A4, 3x32x32, 8 steps; \`FUSED=1\`: bench_models.TrainFusedDorefaResNet18)"
+    echo "and \`tools/probes/train_chain_prof.py\` (BinaryNet-AlexNet, 3x224x224, 6 steps; \`FUSED=1\`: TrainFusedAlexNetBin), condensed by \`tools/probes/kcat.py <dir> <steps> <top>\`:"
+    echo "kernel time per step by class, then the top kernels (us per step, launches per step).  Under the profiler the fp32 stem conv of the"
+    echo "ResNet (torch / MIOpen, not this path's) runs MIOpen's naive fallback kernels in its first calls; that class is listed and excluded from the totals."
+    for n in rn_mod:8:"ResNet-18, module graph" rn_fused:8:"ResNet-18, fused training chain" ax_mod:6:"AlexNet-Bin, module graph" ax_fused:6:"AlexNet-Bin, fused training chain"; do
+      d=${n%%:*}; r=${n#*:}; st=${r%%:*}; t=${r#*:}
+      echo; echo "## $t"; echo '```'; python tools/probes/kcat.py gpurun_out/tr_$d $st 24; echo '```'
+    done; } > profiles/${TAG}_train_steps_rocprof.md
+fi
+grep -n "tile 256x256, pipe=2> |" profiles/${TAG}_bench_rocprof.md | head -3
