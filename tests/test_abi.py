@@ -62,3 +62,22 @@ def test_cpu_tensor_is_rejected_loudly():
         ops.binarize(torch.zeros(4))
     with pytest.raises(TypeError):
         ops.sign_pack(torch.zeros(2, 32))
+
+
+def test_the_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure (its header says so): no module of the shipped package imports, loads or executes anything
+    from it — checked on the sources and on sys.modules after importing every sub-package."""
+    import importlib
+    import pathlib
+    import re
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1] / "pytorch_quantize_impls_amd"
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|[\"']oracle[\"'/\\]|_ref[/\\]", re.M)      # imports and path literals
+    for f in root.rglob("*.py"):
+        assert not pat.search(f.read_text()), f
+    before = {m for m in sys.modules if m == "oracle" or m.startswith("oracle.")}
+    for name in ("pytorch_quantize_impls_amd", "pytorch_quantize_impls_amd.functions", "pytorch_quantize_impls_amd.layers",
+                 "pytorch_quantize_impls_amd.utils", "pytorch_quantize_impls_amd.lazy", "pytorch_quantize_impls_amd.ops"):
+        importlib.import_module(name)
+    after = {m for m in sys.modules if m == "oracle" or m.startswith("oracle.")}
+    assert after == before
