@@ -180,8 +180,9 @@ int qt_xnor_gemm(const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t l
                  qt_stream_t stream);
 
 /* The same two GEMMs with the kernel chosen by the caller (tests / tuning; no process state involved):
- * variant 0 = automatic (skinny weight-streaming kernel for small M or N, 128x128-tile kernel otherwise),
- * 1 = tiled, 2 = skinny. */
+ * variant 0 = automatic (streaming kernel — K along the lanes, DPP wavefront reduction — when min(M, N) <= 32; skinny
+ * lane-per-batch-row kernel for other small M or N; 128x128-tile kernel otherwise),
+ * 1 = tiled, 2 = skinny, 3 = streaming (QT_ERR_UNSUPPORTED unless min(M, N) <= 32). */
 int qt_xnor_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Ws, int64_t ldwp,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
 int qt_tern_gemm_variant(int variant, const uint32_t* Xs, int64_t ldxp, const uint32_t* Wmask, const uint32_t* Wsign,

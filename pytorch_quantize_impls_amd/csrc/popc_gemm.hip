@@ -25,6 +25,9 @@
 int qt_launch_popc_skinny(bool ternary, const uint32_t* Xs, int64_t ldx, const uint32_t* W0,
                           const uint32_t* W1, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                           int64_t M, int64_t N, int64_t K, qt_stream_t stream);  // popc_skinny.hip
+bool qt_popc_stream_applicable(int64_t M, int64_t N);                             // popc_stream.hip
+int qt_launch_popc_stream(bool ternary, const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const uint32_t* W1, int64_t ldw,
+                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, qt_stream_t stream);
 
 namespace {
 
@@ -195,12 +198,13 @@ __global__ __launch_bounds__(256, 4) void popc_gemm_kernel(
     }
 }
 
-// variant: 0 = automatic, 1 = 128x128-tile kernel, 2 = skinny (weight-streaming) kernel
+// variant: 0 = automatic, 1 = 128x128-tile kernel, 2 = skinny (lane <-> batch row) kernel, 3 = streaming kernel (K along the
+// lanes + DPP wavefront reduction; min(M, N) <= 32 only)
 template <bool TERNARY>
 int launch_popc_gemm(int variant, const uint32_t* Xs, int64_t ldx, const uint32_t* W0, const uint32_t* W1,
                      int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N,
                      int64_t K, qt_stream_t stream) {
-    if (variant < 0 || variant > 2) return QT_ERR_INVALID_ARG;
+    if (variant < 0 || variant > 3) return QT_ERR_INVALID_ARG;
     if (M < 0 || N < 0 || K < 0) return QT_ERR_INVALID_ARG;
     if (M == 0 || N == 0) return QT_OK;
     if (!Y || ldy < N) return QT_ERR_INVALID_ARG;
@@ -211,6 +215,10 @@ int launch_popc_gemm(int variant, const uint32_t* Xs, int64_t ldx, const uint32_
     if ((ldx & 3) || (ldw & 3)) return QT_ERR_ALIGNMENT;
     if (K > 0 && (!qt_aligned16(Xs) || !qt_aligned16(W0) || (TERNARY && !qt_aligned16(W1))))
         return QT_ERR_ALIGNMENT;
+    // one operand with a handful of rows (batch <= 32, or a classifier head): K along the lanes, every packed word read once
+    if (variant == 3 && !qt_popc_stream_applicable(M, N)) return QT_ERR_UNSUPPORTED;
+    if (variant == 3 || (variant == 0 && qt_popc_stream_applicable(M, N)))
+        return qt_launch_popc_stream(TERNARY, Xs, ldx, W0, W1, ldw, bias, Y, ldy, M, N, K, stream);
     // weight-streaming regime: few batch rows or few output features -> the tiled kernel would leave
     // most CUs idle (tiles = ceil(M/128)*ceil(N/128) << 256) while the skinny kernel spreads N over waves
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);

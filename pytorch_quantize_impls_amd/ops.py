@@ -561,7 +561,7 @@ def _check_bias(bias, N, device):
     return bias
 
 
-#: kernel variants handed to the library as ARGUMENTS (tests / tuning; 0 = automatic): popcount GEMM 1 = tiled, 2 = skinny;
+#: kernel variants handed to the library as ARGUMENTS (tests / tuning; 0 = automatic): popcount GEMM 1 = tiled, 2 = skinny, 3 = streaming (min(M, N) <= 32);
 #: plain implicit conv 1 = double-buffered, 2 = ping-pong, 4 = no un-padded fast path
 POPC_VARIANT = 0
 CONV_VARIANT = 0
@@ -2339,6 +2339,12 @@ MFMA_MIN_OPS_LONG_K, MFMA_LONG_K, MFMA_MIN_OPS = 8.0e9, 2048, 3.0e10
 def select_gemm_impl(requested: str, M: int, N: int, K: int) -> str:
     """'auto' -> the faster formulation for the shape (both are bit-exact)."""
     if requested == "auto":
+        # a handful of rows on one side (batch <= 8: small-batch serving; <= 32 output features: classifier heads): the
+        # streaming popcount kernel reads every packed word once with K along the lanes (csrc/popc_stream.hip) — 1 x 4096 x 9216
+        # 3.1 us, 8 x 4096 x 9216 7.5 us, 256 x 10 x 4096 3.6 us against 11.4 / 11.9 / 10.0 us for bits -> nibbles + the
+        # skinny matrix-core configuration (tools/bench_popc_stream.py); from batch 16 on the matrix cores win
+        if 1 <= M <= 8 or 1 <= N <= 32:
+            return "valu"
         ops_ = 2.0 * M * N * K
         big = (ops_ >= MFMA_MIN_OPS or (ops_ >= MFMA_MIN_OPS_LONG_K and K >= MFMA_LONG_K)) and K < (1 << 24)
         # skinny, long-K products (FC layers at batch <= 256): the 64x64 / 512-byte-stage matrix-core configuration beats
