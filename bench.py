@@ -425,9 +425,15 @@ def bench_alexnet(args, dev, dist, world, rank):
                 te, tg = lat(lambda: model(xs)), lat(lambda: gm(xs))
                 with lazy.eager():
                     tm = lat(lambda: model(xs))
+                # utils.auto_graphed: the wrapper a serving loop would use — eager on the first call with a signature,
+                # captured on the second, replayed (input copied in, output copied out) from then on
+                am = utils.auto_graphed(model)
+                same_a = bool(torch.equal(am(xs), want)) and bool(torch.equal(am(xs), want))
+                ta = lat(lambda: am(xs))
             serving[f"batch_{sb}"] = {"eager_ms": te, "module_by_module_eager_ms": tm, "hipgraph_ms": tg,
-                                      "hipgraph_images_per_s": sb / tg * 1e3, "same_logits": same}
-            del gm
+                                      "hipgraph_images_per_s": sb / tg * 1e3, "same_logits": same,
+                                      "auto_graphed_ms": ta, "auto_graphed_same_logits": same_a, "auto_graphed_replays": am.replays}
+            del gm, am
         out["serving_small_batch"] = serving
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = B                       # the same batch as the GPU leg (one forward = ~1 s on the box's host)
@@ -644,6 +650,45 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         tail["norm_err_vs_cpu_port_512_rows"] = float((y_b[rows].cpu() - ref).abs().max() / ref.abs().max())
     out["c2_bias_tail"] = tail
 
+    # ---- the XNOR-popcount GEMM where it IS HBM-bound (north_star's named formulation): a handful of rows on one side, the packed
+    # weight planes streamed once (csrc/popc_stream.hip: K along the lanes, DPP wavefront reduction).  Per call inside a captured
+    # hipGraph of 20 calls (no launch gaps); bytes = 1-bit operands + the fp32 result (SURVEY 8d bytes_packed).
+    try:
+        rows_s = []
+        with torch.no_grad():
+            for (Ms, Ns, Ks) in [(1, 4096, 4096), (1, 4096, 9216), (8, 4096, 9216), (1, 16384, 16384), (256, 10, 4096)]:
+                gs = torch.Generator(device=dev)
+                gs.manual_seed(Ms + Ns + Ks)
+                xs_ = torch.randn((Ms, Ks), device=dev, generator=gs)
+                ws_ = torch.randn((Ns, Ks), device=dev, generator=gs)
+                xps, wps = ops.sign_pack(xs_)[0], ops.sign_pack(ws_)[0]
+                ys_ = torch.empty((Ms, Ns), device=dev)
+                fn = lambda: ops.xnor_gemm(xps, wps, out=ys_)     # noqa: E731
+                fn()
+                exact = bool(torch.equal(ys_, torch.nn.functional.linear(torch.where(xs_ < 0, -1.0, 1.0).double(),
+                                                                         torch.where(ws_ < 0, -1.0, 1.0).double()).float()))
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    fn()
+                    with torch.cuda.graph(gr, stream=side):
+                        for _ in range(20):
+                            fn()
+                torch.cuda.current_stream().wait_stream(side)
+                t_s = timed(gr.replay, 20) / (20 * 20)
+                byt = (Ms + Ns) * Ks / 8.0 + 4.0 * Ms * Ns
+                rows_s.append({"M": Ms, "N": Ns, "K": Ks, "us": t_s * 1e6, "bytes": byt, "GBs": byt / t_s / 1e9,
+                               "frac_of_8TBs": byt / t_s / 1e9 / HBM_PEAK_GBS, "bit_exact_vs_fp64_of_the_reference_ops": exact})
+        out["popcount_gemm_hbm_regime"] = {
+            "kernel": "popc_stream_kernel (xor + v_bcnt accumulate, lanes along K, DPP reduction)", "bound": "hbm",
+            "peak_GBs": HBM_PEAK_GBS, "shapes": rows_s,
+            "what": "LinearBin / classifier-head forward on pre-packed 1-bit planes at batch <= 32 or <= 32 output features; per "
+                    "call inside a hipGraph of 20 calls; small shapes are launch-latency bound (~2.5 us floor), 1 x 16384 x 16384 "
+                    "streams 33.5 MB of weight bits"}
+    except Exception as e:                                        # an extra: it may not void the headline
+        out["popcount_gemm_hbm_regime"] = {"error": repr(e)}
+
     # ---- C4: DoReFa ResNet-18 W1A4, 3 x 32 x 32
     if args.c4_batch > 0:
         Bc = args.c4_batch
@@ -681,6 +726,10 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         with torch.no_grad():
             same_g = bool(torch.equal(g4(x4), deferred4()))
         el_g = timed(lambda: g4(x4), 2 * iters)
+        a4 = utils.auto_graphed(m4)                      # "auto-capture a hipGraph on the second identical call"
+        with torch.no_grad():
+            same_a4 = bool(torch.equal(a4(x4), deferred4())) and bool(torch.equal(a4(x4), deferred4()))
+        el_a = timed(lambda: a4(x4), 2 * iters)
         # ... and the opt-in fused form the same way (its eager time is host-bound as well: ~60 launches)
         fused_graph = {}
         try:
@@ -706,6 +755,11 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "module_graph_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_g, st4, 5000.0,
                                                "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                                {"same_logits_as_module_graph": same_g}),
+            "module_graph_auto_graphed": _net_line("c4", Bc, world, 2 * iters, el_a, st4, 5000.0,
+                                                   "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                                   {"same_logits_as_module_graph": same_a4, "replays": a4.replays,
+                                                    "what": "utils.auto_graphed(model): eager first call, captured on the second, "
+                                                            "replayed after (input copied in, logits copied out)"}),
             "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                  fp32_activations=True),
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",

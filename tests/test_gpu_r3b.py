@@ -102,3 +102,41 @@ def test_streaming_kernel_refuses_shapes_with_two_large_dimensions(dev):
     wp = ops.sign_pack(torch.ones((33, 64), device=dev))[0]
     with pytest.raises(Exception):
         _forced(3, lambda: ops.xnor_gemm(xp, wp))
+
+
+# ---- utils.auto_graphed: the un-modified model with its inference forwards replayed as hipGraphs ---------------------------------
+
+def test_auto_graphed_replays_the_unmodified_model_and_follows_weight_updates(dev):
+    import copy, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench_models
+    from pytorch_quantize_impls_amd import utils
+    torch.manual_seed(3)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    auto = utils.auto_graphed(model)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    xs = [torch.randn((2, 3, 224, 224), device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for _ in range(4)]
+    with torch.no_grad():
+        want = [model(x).clone() for x in xs]
+        got = [auto(x) for x in xs]
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+        assert auto.replays == 3 and auto.eager_calls == 1            # first call eager, captured on the second
+        # another signature starts eagerly again, the first one keeps replaying
+        x8 = torch.randn((8, 3, 224, 224), device=dev, generator=gen).contiguous(memory_format=torch.channels_last)
+        assert torch.equal(auto(x8), model(x8)) and auto.eager_calls == 2
+        assert torch.equal(auto(xs[0]), want[0]) and auto.replays == 4
+        # a weight update (load_state_dict bumps the version counters) drops the graphs: results follow the new weights
+        sd = copy.deepcopy(model.state_dict())
+        for k in sd:
+            if k.endswith("bias") and sd[k].dtype == torch.float32:
+                sd[k] = sd[k] + 0.25
+        model.load_state_dict(sd)
+        new = model(xs[1]).clone()
+        assert not torch.equal(new, want[1])
+        assert torch.equal(auto(xs[1]), new) and torch.equal(auto(xs[1]), new) and torch.equal(auto(xs[2]), model(xs[2]))
+    # autograd enabled / training mode: the eager module
+    before = auto.eager_calls
+    y = auto(xs[0])
+    assert auto.eager_calls == before + 1 and torch.equal(y.detach(), model(xs[0]).detach())
