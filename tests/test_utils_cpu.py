@@ -138,3 +138,30 @@ def test_packing_ratio_on_a_realistic_layer():
     assert st["layers"]["0"]["sign"].shape == (512, 32) and st["layers"]["1"]["mask"].shape == (512, 32)
     w_bytes = 512 * 1024 * 4   # per layer
     assert packed_state_nbytes(st) - 2 * 512 * 4 == w_bytes // 32 + w_bytes // 16   # 1 bit + 2 bits per weight
+
+
+def test_auto_graphed_host_logic_on_cpu():
+    """utils.auto_graphed keeps everything that cannot be replayed on the eager module: CPU tensors, training mode, autograd."""
+    from pytorch_quantize_impls_amd.utils import AutoGraphed, auto_graphed
+    m = binary_net_convert(float_net()).eval()
+    a = auto_graphed(m, capture_after=2, max_graphs=3)
+    assert isinstance(a, AutoGraphed) and a.module is m and (a.capture_after, a.max_graphs) == (2, 3)
+    x = torch.randn(2, 3, 6, 6)
+    with torch.no_grad():
+        ref = m(x)
+        for _ in range(4):
+            assert torch.equal(a(x), ref)
+    assert a.replays == 0 and a.eager_calls == 4 and not a._graphs          # a CPU tensor is never captured
+    y = a(x)                                                                 # autograd enabled: the module itself
+    assert y.requires_grad and a.eager_calls == 5
+    a.train()
+    assert m.training and a(x).requires_grad
+    # the state signature follows version counters and storage; reset() forgets everything
+    a.eval()
+    s0 = a._state_sig()
+    with torch.no_grad():
+        next(m.parameters()).add_(1.0)
+    assert a._state_sig() != s0
+    a._seen[("k",)] = 3
+    a.reset()
+    assert not a._seen and a._state is None

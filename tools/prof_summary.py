@@ -18,7 +18,7 @@ ours = ("mfma_gemm_kernel", "pool_affine_sign_pack_kernel", "triple_kernel", "co
         "col_abs_mean_kernel", "sign_scale_kernel", "nib_gemm_kernel", "nib_pack_vec_kernel", "nib_pack_pair_kernel", "bits_to_nib_pad_kernel", "s2d_triple_rows_kernel", "nib_pack_scalar_kernel", "popc_gemm_kernel",
         "pack_vec_kernel", "pack_wave_kernel", "bits_to_nib_kernel", "unary_kernel", "binary_kernel",
         "check_pm1_kernel", "pair_kernel", "s2d_pair_rows_kernel", "absmax_part_kernel", "absmax_final_kernel", "pool_sum_kernel",
-        "sqdev_kernel", "fold_kernel", "finalize_kernel", "norm_sign_kernel", "bwd_sum_kernel", "bwd_dx_kernel", "pool_bwd_kernel", "wgrad_pack", "wgrad_reduce_kernel", "pm_zero_kernel", "pm_bias_reduce_kernel", "pm_pack_act", "pm_pack_grad", "wgrad_pm_kernel", "wgrad_pm_full_kernel", "pm_reduce_kernel", "bn_eval_device_kernel", "absmax_ch_final_kernel", "absmax_ch_strided_kernel", "absmax_ch_rows_kernel", "fold2_kernel", "act_bwd_dx_kernel", "act_bwd_sum_kernel", "pool_bits_kernel", "affine_codes_kernel", "pool_codes_kernel", "zero_halo_kernel", "pad_pixel_plane_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "conv", "im2col")
+        "sqdev_kernel", "fold_kernel", "finalize_kernel", "norm_sign_kernel", "bwd_sum_kernel", "bwd_dx_kernel", "pool_bwd_kernel", "wgrad_pack", "wgrad_reduce_kernel", "pm_zero_kernel", "pm_bias_reduce_kernel", "pm_pack_act", "pm_pack_grad", "wgrad_pm_kernel", "wgrad_pm_full_kernel", "pm_reduce_kernel", "bn_eval_device_kernel", "absmax_ch_final_kernel", "absmax_ch_strided_kernel", "absmax_ch_rows_kernel", "fold2_kernel", "act_bwd_dx_kernel", "act_bwd_sum_kernel", "pool_bits_kernel", "affine_codes_kernel", "pool_codes_kernel", "zero_halo_kernel", "pad_pixel_plane_kernel", "s2d_triple_kernel", "popc_skinny_kernel", "popc_stream_kernel", "conv", "im2col")
 
 
 import re
