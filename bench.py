@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--alexnet-batch", type=int, default=256, help="images per GPU (0 = skip)")
     ap.add_argument("--alexnet-iters", type=int, default=10)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (smoke tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (and run the data-parallel training extra) even with ONE rank: exercises "
+                         "the RCCL init / barrier / all-reduce path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test only: every rank uses cuda:0 (exercise the N>1 code path on a 1-GPU box)")
     ap.add_argument("--strong", action="store_true",
@@ -87,9 +90,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                   # --force-dist without a launcher
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=dev)
         else:
@@ -144,8 +151,10 @@ def main():
     # stream time per step (tools/bench_step_overheads.py), which would otherwise be billed to `value`.
     for i in range(args.steps):
         step(record=(i % EVENT_EVERY == 0))
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0        # this rank's K steps are complete; the MAX over the ranks is taken below
+    sync_all()                                # closing barrier + synchronize of the bracket (its own latency — ~0.3 ms for an RCCL
+    #                                           barrier, measured with --force-dist — is not K steps of work and is not billed)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         # every rank's own step time travels with the line, so a SCALE run is self-checking (a straggler or a rank that
@@ -817,7 +826,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "global_batch": Bv * world}
     # ---- training step: BinaryNet-AlexNet forward + backward at the headline batch, this backend vs the
     # reference's op sequence through ROCm PyTorch on the same GPU (tools/bench_train_step.py holds both forms)
-    if args.train_batch and world == 1:
+    if args.train_batch and world == 1 and dist is None:
         import importlib.util
         spec = importlib.util.spec_from_file_location("bench_train_step", os.path.join(ROOT, "tools", "bench_train_step.py"))
         bts = importlib.util.module_from_spec(spec)
@@ -911,7 +920,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             del mr, xr
         except Exception as exc:        # never take the line down
             out["n2_training_step_dorefa_resnet18_w1a4"] = {"error": f"{type(exc).__name__}: {exc}"}
-    elif args.train_batch and world > 1:
+    elif args.train_batch and dist is not None:
         # data-parallel step, one process per GPU: per-GPU batch fixed (weak scaling), gradients averaged by the bucketed
         # all-reduce of utils/data_parallel.py (RCCL over xGMI) issued after backward (overlap=False, see below).  BatchNorm
         # runs on PER-SHARD batch statistics (plain nn.BatchNorm2d, no SyncBatchNorm: SURVEY 8e "or per-shard stats"), so the
