@@ -1014,6 +1014,7 @@ template <class E> using ConvVPP256 = GemmCfg<E, 2, 4, 4, 2, 2, 0, 64, 2>;
 template <class E> using ConvV64x2 = GemmCfg<E, 4, 2, 2, 1, 1, 0, 64, 2, 3>;    // 256x64 tile, 64-byte stages, 3 workgroups / CU
 template <class E> using ConvV128x2 = GemmCfg<E, 2, 4, 4, 1, 1, 0, 64, 2, 2>;   // 256x128 tile, same
 template <class E> using ConvVPP192 = GemmCfg<E, 4, 2, 3, 3, 2, 0, 64, 2>;
+template <class E> using ConvVPP256x192 = GemmCfg<E, 4, 2, 2, 3, 2, 0, 64, 2>;   // 256x192 ping-pong on un-padded / physically padded planes
 // small M (small-batch inference, late layers of small images): few tiles and a long, latency-bound K loop — 64x64 tiles
 // with 512-byte stages, as the skinny GEMM configuration (weight rows must be padded to whole 512-byte stages).  Taken
 // for M <= 4096, and beyond that while the standard tiling leaves CUs idle (< 256 tiles) and the weight re-reads of the
@@ -1499,6 +1500,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                 if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
                     return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 if (tn == 256) return launch_cfg<ConvVPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                /* 192-wide tiles whose 384-row form wastes a round (576 -> 1152 @ 13x13): 256x192 ping-pong for long K */ \
+                if (tn == 192 && g_conv_force == 0 && kwords * 4 >= 2048)                                         \
+                    return launch_cfg<ConvVPP256x192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             }                                                                                                   \
             if (g_conv_force == 0 && tn == 64 && kwords * 4 <= 1024)                                            \
                 return launch_cfg<ConvV64x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \

@@ -15,8 +15,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/pmc_fetch" -o bench --output-fo
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/pmc_write" -o bench --output-format csv -- $C2 > "$O/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$O/pmc_l2" -o bench --output-format csv -- $C2 > "$O/pmc_l2.log" 2>&1
 # the other configs of the bench line's "extra" object, one kernel-stats pass each (C4: DoReFa ResNet-18, C5: ternary VGG-16)
-C4="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --alexnet-batch 0 --c5-batch 0"
-C5="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --alexnet-batch 0 --c4-batch 0"
+C4="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --alexnet-batch 0 --c5-batch 0 --train-batch 0"
+C5="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --alexnet-batch 0 --c4-batch 0 --train-batch 0"
 rocprofv3 --kernel-trace --stats -d "$O/kt_c4" -o bench --output-format csv -- $C4 > "$O/kt_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$O/kt_c5" -o bench --output-format csv -- $C5 > "$O/kt_c5.log" 2>&1
 for s in kt_c4 kt_c5; do find "$O/$s" -mindepth 2 -name "*.csv" -exec mv {} "$O/$s/" \; ; rm -f "$O/$s/bench_kernel_trace.csv"; done

@@ -11,7 +11,10 @@ cp gpurun_out/$TAG/bench_line.json profiles/${TAG}_bench_line.json
 cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 for c in c4 c5; do
   { echo "# rocprofv3 --kernel-trace --stats of the $c line of bench.py's extra object (tools/collect_profiles.sh $TAG): name, calls, total us, avg us"
-    echo '```'; python tools/kstats.py gpurun_out/$TAG/kt_$c | sort -k3 -n -r | head -70; echo '```'; } > profiles/${TAG}_${c}_rocprof.md
+    echo "# (the command times the fused form, the un-modified module graph, the module-by-module eager graph and the reference's op sequence on the GPU:"
+    echo "#  MIOpen / torch kernels belong to the last two)"
+    echo; echo "## kernels of libqt_hip.so"; echo '```'; python tools/kstats.py gpurun_out/$TAG/kt_$c --own | head -45; echo '```'
+    echo; echo "## all kernels"; echo '```'; python tools/kstats.py gpurun_out/$TAG/kt_$c | head -40; echo '```'; } > profiles/${TAG}_${c}_rocprof.md
 done
 if [ -d gpurun_out/tr_rn_mod ]; then
   { echo "# Training steps, batch 256, per-kernel-class split (round 3, final state)"; echo
