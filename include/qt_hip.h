@@ -455,6 +455,17 @@ int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t
 int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2, uint16_t* out,
                           int64_t ld_bytes, int64_t N, int64_t C, int64_t H, int64_t W, int64_t s, int64_t ph, int64_t pw,
                           qt_stream_t stream);
+/* The same plane WITHOUT a separate max|x| pass over the image (channels-last images only, else QT_ERR_UNSUPPORTED): the image is
+ * packed with the fixed power-of-two scale `spec_scale` while max|x| is folded on the way (work = qt_f16x2_s2d_spec_work_words(N, H,
+ * s, ph) uint32 of scratch); a one-workgroup launch then decides: max|x| / spec_scale in [2^8, 2^16) (or max|x| = 0) -> scale2 =
+ * [spec_scale, 1 / spec_scale], *redo = 0 and the plane stands, with |x - s (hi + lo)| <= max(2^-22 |x|, 2^-33 max|x|); otherwise
+ * scale2 = the exact-binade scale of qt_f16x2_absmax_scale_f32, *redo = 1, and a third launch (which returns at once when *redo = 0)
+ * rewrites the plane with it.  No host synchronisation; the consumer reads the scale from scale2 on the device.  Replaces the
+ * operand preparation of the first layer's F.conv2d on real pixels (models/Alexnet/Alexnet_Bin.py:13, layers/binary_layers.py:105). */
+int64_t qt_f16x2_s2d_spec_work_words(int64_t N, int64_t H, int64_t s, int64_t ph);
+int qt_f16x2_s2d_pack_spec_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, float spec_scale, uint32_t* work,
+                               float* scale2, int* redo, uint16_t* out, int64_t ld_bytes, int64_t N, int64_t C, int64_t H,
+                               int64_t W, int64_t s, int64_t ph, int64_t pw, qt_stream_t stream);
 /* The conv weight [Cout][Cin][kh][kw] (fp32, given by its element strides: contiguous or channels-last) as the fp16 pair-plane operand of qt_conv2d_implicit(elem = 3): quantised
  * by `mode` (1 safeSign, 2 ternary, 3 torch.sign, 4 raw) and replicated twice, rows tap-major with 16-byte tap granules, padded with
  * zeros to ld_bytes (a multiple of 128).  transpose_flip = 1: the operand of grad_x — rows = Cin, channels = Cout, taps flipped

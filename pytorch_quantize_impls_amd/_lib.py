@@ -114,6 +114,9 @@ SIGNATURES = {
     "qt_f16x2_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_f16x2_pack_conv_weight_f32": (_c_int, [_c_p] + [_c_i64] * 8 + [_c_int, _c_int, _c_p, _c_i64, _c_p]),
     "qt_f16x2_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
+    "qt_f16x2_s2d_spec_work_words": (_c_i64, [_c_i64] * 4),
+    "qt_f16x2_s2d_pack_spec_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_i64] + [_c_i64] * 7
+                                   + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_train_chain_partial_floats": (_c_i64, [_c_i64, _c_i64]),
     "qt_bn_train_stats_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_f32, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_p]),

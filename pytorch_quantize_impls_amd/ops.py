@@ -1549,6 +1549,11 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int
     return TriplePlanes(data=data, rows=Cout, K=kbytes // (2 * terms), terms=terms)   # K only used for consistency checks
 
 
+#: fixed power-of-two scale the first layer's space-to-depth pack speculates with (None / 0: always the separate max|x| pass).
+#: 2^-11 is admissible for max|x| in [2^-3, 2^5): unit-variance and [0, 1] images; anything else is repacked on the device.
+S2D_SPEC_SCALE: Optional[float] = 2.0 ** -11
+
+
 def s2d_triple_pack(x: torch.Tensor, s: int, padding, terms: Optional[int] = None) -> Tuple[TriplePlanes, Tuple[int, int]]:
     """Space-to-depth gather + split (exact bf16 triples, or scaled fp16 pairs) of [N, C, H, W] (any storage) in one kernel.
     Returns (pixel planes with rows = N*Hs*Ws and K = C*s*s, (Hs, Ws))."""
@@ -1563,6 +1568,17 @@ def s2d_triple_pack(x: torch.Tensor, s: int, padding, terms: Optional[int] = Non
     I = int
     sN, sC, sH, sW = (int(v) for v in x.stride())
     if terms == 2:
+        rowf4 = (W * C + 3) & ~3
+        if (S2D_SPEC_SCALE and sC == 1 and sW == C and sH >= W * C and int(s) * rowf4 * 4 + E * 8 <= 60 * 1024
+                and N * Hs < (1 << 31) and N > 0):
+            # channels-last image: packed with a fixed scale while max|x| is folded on the way; the device decides whether the
+            # plane stands or is rewritten with the exact-binade scale (csrc/split_f16.hip): no separate pass over the image
+            scale = torch.empty((2,), dtype=torch.float32, device=x.device)
+            work = torch.empty((N * Hs + 1,), dtype=torch.int32, device=x.device)        # [partial maxima | redo flag]
+            with _on(x.device):
+                _lib.call("qt_f16x2_s2d_pack_spec_f32", _p(x), I(sN), I(sC), I(sH), I(sW), float(S2D_SPEC_SCALE), _p(work), _p(scale),
+                          _p(work[N * Hs:]), _p(out), I(ld), I(N), I(C), I(H), I(W), I(int(s)), I(ph), I(pw), _stream(x.device))
+            return TriplePlanes(data=out, rows=N * Hs * Ws, K=E, terms=2, scale=scale), (Hs, Ws)
         scale = pow2_scale(x)
         with _on(x.device):
             _lib.call("qt_f16x2_s2d_pack_f32", _p(x), I(sN), I(sC), I(sH), I(sW), _p(scale), _p(out), I(ld), I(N), I(C), I(H),

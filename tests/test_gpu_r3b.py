@@ -18,30 +18,70 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("N,C,H,W,s,pad", [(2, 3, 224, 224, 4, 2), (3, 3, 30, 34, 4, 2), (2, 3, 17, 22, 4, 0), (1, 3, 9, 10, 4, (3, 4)),
-                                           (5, 3, 4, 2, 4, (0, 2)),
-                                           (2, 3, 31, 33, 4, 2), (2, 3, 32, 32, 4, 1), (2, 4, 32, 32, 4, 2), (2, 3, 32, 32, 2, 2)])
-def test_f16x2_s2d_pack_row_staged_kernel_equals_generic(dev, N, C, H, W, s, pad):
-    gen = torch.Generator(device=dev).manual_seed(N * 1000 + H * 10 + W)
-    x = torch.randn((N, C, H, W), device=dev, generator=gen) * 3.0
-    x[0, 0, 0, 0] = 37.5                                    # the per-tensor scale is not 1
-    xl = x.contiguous(memory_format=torch.channels_last)
-    before = _lib.call_counts.get("qt_f16x2_s2d_pack_f32", 0)
-    a, hw_a = ops.s2d_triple_pack(xl, s, pad, terms=2)
-    b, hw_b = ops.s2d_triple_pack(x.contiguous(), s, pad, terms=2)
-    assert _lib.call_counts.get("qt_f16x2_s2d_pack_f32", 0) == before + 2
-    assert hw_a == hw_b and a.data.shape == b.data.shape and a.terms == b.terms == 2
-    assert torch.equal(a.scale, b.scale)
-    assert torch.equal(a.data, b.data), (N, C, H, W, s, pad)
-    # and the planes mean what the header says: s * (hi + lo) reproduces the image to 2^-22 relative
+def _check_planes(a, x, N, C, H, W, s, pad, floor_exp):
+    """The plane means what the header says: a.scale[0] * (hi + lo) reproduces the space-to-depth image to
+    max(2^-22 |x|, 2^floor_exp max|x|)."""
+    dev = x.device
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    Hs, Ws = hw_a
+    Hs, Ws = (H + 2 * ph + s - 1) // s, (W + 2 * pw + s - 1) // s
     xp = torch.zeros((N, C, Hs * s, Ws * s), device=dev, dtype=torch.float64)
     xp[:, :, ph:ph + H, pw:pw + W] = x.double()
     ref = xp.view(N, C, Hs, s, Ws, s).permute(0, 2, 4, 1, 3, 5).reshape(N * Hs * Ws, C * s * s)
     pairs = a.data.view(torch.float16).double().view(N * Hs * Ws, -1, 2)[:, :C * s * s]
     got = (pairs[..., 0] + pairs[..., 1]) * float(a.scale[0])
-    assert float((got - ref).abs().max()) <= 2.0 ** -22 * float(ref.abs().max())
+    amax = float(ref.abs().max())
+    bound = torch.maximum(2.0 ** -22 * ref.abs(), torch.full_like(ref, 2.0 ** floor_exp * amax))
+    assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound.clamp_min(1e-300)).max())
+    assert float(a.scale[0]) * float(a.scale[1]) == 1.0
+
+
+@pytest.mark.parametrize("N,C,H,W,s,pad", [(2, 3, 224, 224, 4, 2), (3, 3, 30, 34, 4, 2), (2, 3, 17, 22, 4, 0), (1, 3, 9, 10, 4, (3, 4)),
+                                           (5, 3, 4, 2, 4, (0, 2)),
+                                           (2, 3, 31, 33, 4, 2), (2, 3, 32, 32, 4, 1), (2, 4, 32, 32, 4, 2), (2, 3, 32, 32, 2, 2)])
+@pytest.mark.parametrize("amp", [3.0, 40.0, 1e-4, 3e5])
+def test_f16x2_s2d_pack_channels_last_vs_generic(dev, N, C, H, W, s, pad, amp):
+    """Channels-last images take the speculative row-staging pack (fixed scale 2^-11 unless max|x| falls outside [2^-3, 2^5): then
+    the device rewrites the plane with the exact-binade scale); NCHW storage takes max|x| pass + generic gather.  Same scale ->
+    identical planes; either way the plane meets its bound."""
+    gen = torch.Generator(device=dev).manual_seed(N * 1000 + H * 10 + W)
+    x = torch.randn((N, C, H, W), device=dev, generator=gen).clamp_(-4, 4) * (amp / 4.0)
+    x[0, 0, 0, 0] = amp                                     # max|x| = amp exactly
+    xl = x.contiguous(memory_format=torch.channels_last)
+    before = dict(_lib.call_counts)
+    a, hw_a = ops.s2d_triple_pack(xl, s, pad, terms=2)
+    b, hw_b = ops.s2d_triple_pack(x.contiguous(), s, pad, terms=2)
+    assert _lib.call_counts["qt_f16x2_s2d_pack_spec_f32"] == before.get("qt_f16x2_s2d_pack_spec_f32", 0) + 1
+    assert _lib.call_counts["qt_f16x2_s2d_pack_f32"] == before.get("qt_f16x2_s2d_pack_f32", 0) + 1
+    assert hw_a == hw_b and a.data.shape == b.data.shape and a.terms == b.terms == 2
+    in_window = 2.0 ** -3 <= amp < 2.0 ** 5
+    assert float(a.scale[0]) == (2.0 ** -11 if in_window else float(b.scale[0]))
+    assert 2.0 ** 14 <= amp / float(b.scale[0]) < 2.0 ** 15
+    if not in_window:
+        assert torch.equal(a.data, b.data), (N, C, H, W, s, pad)
+    _check_planes(a, x, N, C, H, W, s, pad, -33)
+    _check_planes(b, x, N, C, H, W, s, pad, -39)
+    # the speculation switched off: the two-pass form, identical to the generic kernel's planes
+    old = ops.S2D_SPEC_SCALE
+    ops.S2D_SPEC_SCALE = None
+    try:
+        c, _ = ops.s2d_triple_pack(xl, s, pad, terms=2)
+    finally:
+        ops.S2D_SPEC_SCALE = old
+    assert torch.equal(c.data, b.data) and torch.equal(c.scale, b.scale)
+
+
+def test_f16x2_s2d_speculative_pack_corner_images(dev):
+    """All-zero images keep the fixed scale (nothing to represent); a NaN / inf anywhere makes the device fall back to scale 1,
+    like the max|x| pass does; both without a host round trip."""
+    z = torch.zeros((2, 3, 16, 16), device=dev).contiguous(memory_format=torch.channels_last)
+    a, _ = ops.s2d_triple_pack(z, 4, 2, terms=2)
+    assert float(a.scale[0]) == 2.0 ** -11 and not bool(a.data.any())
+    for bad in (float("nan"), float("inf")):
+        x = torch.randn((2, 3, 16, 16), device=dev)
+        x[1, 2, 3, 4] = bad
+        a, _ = ops.s2d_triple_pack(x.contiguous(memory_format=torch.channels_last), 4, 2, terms=2)
+        b, _ = ops.s2d_triple_pack(x.contiguous(), 4, 2, terms=2)
+        assert float(a.scale[0]) == float(b.scale[0]) == 1.0 and torch.equal(a.data, b.data)
 
 
 # ---- streaming popcount GEMM (csrc/popc_stream.hip): K along the lanes + DPP wavefront reduction -------------------------------
