@@ -4,7 +4,8 @@
 //     division is exact, x / s - hi is exact in fp32 (it has at most 13 significant bits), and lo is a normal fp16 number for
 //     every |x| >= 2^-17 max|x| (below that it is rounded on the subnormal grid 2^-24).  Hence
 //         |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 max|x|)                                  (2 x 11 significand bits)
-//     stored as consecutive pairs: fp16 slot 2k + t of a row is term t of x[k].
+//     stored as consecutive pairs: fp16 slot 2k + t of a row is term t of x[k].  (The speculative first-layer pack below may keep
+//     a FIXED scale with max|x| / s anywhere in [2^8, 2^16): the floor term is then 2^-33 max|x|.)
 //   weights: a value that is exact in fp16 — the quantised q in {-1, 0, +1} (safeSign / ternary / torch.sign) or an integer
 //     level |q| <= 2048 ("raw": k-bit DoReFa levels) — replicated twice.
 // An fp16 MFMA GEMM (v_mfma_f32_32x32x16_f16, exact products, fp32 accumulate) over 2K of these planes, times s, equals the
