@@ -97,17 +97,20 @@ __global__ __launch_bounds__(256) void absmax_final_kernel(const unsigned* __res
 // [2^8, 2^16) (nothing overflows fp16; the subnormal grid 2^-24 s0 of the low term is <= 2^-32 a, i.e. the split's error is
 // max(2^-22 |x|, 2^-33 max|x|)), or when a == 0: then scale2 = [s0, 1 / s0] and *redo = 0.  Otherwise scale2 is the exact-binade
 // scale of write_scale and *redo = 1: the repack launch behind this one rewrites the plane with it.
-__global__ __launch_bounds__(256) void spec_final_kernel(const unsigned* __restrict__ part, int nparts, float spec_inv,
-                                                         float* __restrict__ scale2, int* __restrict__ redo) {
+__global__ __launch_bounds__(1024) void spec_final_kernel(const unsigned* __restrict__ part, int nparts, float spec_inv,
+                                                          float* __restrict__ scale2, int* __restrict__ redo) {
     unsigned m = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) m = max(m, part[i]);
+    for (int i = threadIdx.x; i < nparts; i += 1024) m = max(m, part[i]);       // AlexNet: 14592 partials, 15 per thread
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    __shared__ unsigned sh[4];
+    __shared__ unsigned sh[16];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float a = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+        unsigned mm = sh[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mm = max(mm, sh[j]);
+        const float a = __uint_as_float(mm);
         const float r = a * spec_inv;                                     // exact: spec_inv is a power of two
         const bool ok = a == 0.0f || (r >= 256.0f && r < 65536.0f);      // NaN / inf: not ok
         if (ok) {
@@ -511,7 +514,7 @@ extern "C" int qt_f16x2_s2d_pack_spec_f32(const float* x, int64_t sN, int64_t sC
     hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, st, x, sN, sH, (const float*)nullptr, o,
                        ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok, spec_inv, work,
                        (const int*)nullptr);
-    hipLaunchKernelGGL(spec_final_kernel, dim3(1), dim3(256), 0, st, work, (int)(N * Hs), spec_inv, scale2, redo);
+    hipLaunchKernelGGL(spec_final_kernel, dim3(1), dim3(1024), 0, st, work, (int)(N * Hs), spec_inv, scale2, redo);
     hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, st, x, sN, sH, (const float*)scale2, o,
                        ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok, 0.0f,
                        (unsigned*)nullptr, (const int*)redo);
