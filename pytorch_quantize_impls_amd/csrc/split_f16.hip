@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
                                                             const float* __restrict__ scale2, uint32_t* __restrict__ out,
                                                             int64_t ld_words, int C, int H, int W, int s, int ph, int pw,
                                                             int Hs, int Ws, int vec_ok, float spec_inv,
-                                                            unsigned* __restrict__ part, const int* __restrict__ run_if) {
+                                                            unsigned* __restrict__ part, const int* __restrict__ run_if, int nrows_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s2d_smem[];
     if (run_if && *run_if == 0) return;                                   // uniform, before any barrier
     const float inv = spec_inv != 0.0f ? spec_inv : (scale2 ? scale2[1] : 1.0f);
@@ -300,12 +300,16 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
     int* lut_off = reinterpret_cast<int*>(rows + (size_t)s * rowf4);      // [E] dy*rowf4 + (dx - pw)*C + c
     int* lut_dx = lut_off + E;                                            // [E] dx - pw
     const int tid = threadIdx.x;
-    const int n = blockIdx.x / Hs, Y = blockIdx.x - n * Hs;
     for (int e = tid; e < E; e += 256) {
         const int c = e / (s * s), r = e - c * s * s, dy = r / s, dx = r - dy * s;
         lut_off[e] = dy * rowf4 + (dx - pw) * C + c;
         lut_dx[e] = dx - pw;
     }
+    // one output row (n, Y) per workgroup when the grid covers nrows_out; the repack launch uses a small grid (its workgroups
+    // normally return above: 14592 empty workgroups cost ~8 us, 1024 cost ~2) and walks the rows
+    for (int blk = blockIdx.x; blk < nrows_out; blk += gridDim.x) {
+    const int n = blk / Hs, Y = blk - n * Hs;
+    amax = 0;
     for (int dy = 0; dy < s; ++dy) {
         const int hh = s * Y + dy - ph;
         const bool ok = hh >= 0 && hh < H;
@@ -332,11 +336,11 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
         __shared__ unsigned wmax[4];
         if ((tid & 63) == 0) wmax[tid >> 6] = amax;
         __syncthreads();
-        if (tid == 0) part[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (tid == 0) part[blk] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     }
     __syncthreads();
     const int quads = (int)(ld_words >> 2), total = Ws * quads;
-    uint4* orow = reinterpret_cast<uint4*>(out + ((int64_t)blockIdx.x * Ws) * ld_words);
+    uint4* orow = reinterpret_cast<uint4*>(out + ((int64_t)blk * Ws) * ld_words);
     for (int q = tid; q < total; q += 256) {
         const int X = q / quads, cq = q - X * quads;
         const int base = s * X * C, wx = s * X;
@@ -352,6 +356,8 @@ __global__ __launch_bounds__(256) void s2d_pair_rows_kernel(const float* __restr
             w[j] = split2(v * inv);
         }
         orow[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();                                                      // the staged rows (and wmax) are re-used by the next row
     }
 }
 
@@ -476,7 +482,7 @@ extern "C" int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int
         const int vec_ok = ((W * C) % 4 == 0) && qt_aligned16(x) && (sH % 4 == 0) && (sN % 4 == 0);
         hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, (hipStream_t)stream, x, sN, sH,
                            scale2, o, ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok, 0.0f,
-                           (unsigned*)nullptr, (const int*)nullptr);
+                           (unsigned*)nullptr, (const int*)nullptr, (int)(N * Hs));
         return qt_check_launch();
     }
     const int64_t total = N * Hs * Ws * (ld_words / 4);
@@ -513,11 +519,12 @@ extern "C" int qt_f16x2_s2d_pack_spec_f32(const float* x, int64_t sN, int64_t sC
     const float spec_inv = 1.0f / spec_scale;
     hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, st, x, sN, sH, (const float*)nullptr, o,
                        ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok, spec_inv, work,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (int)(N * Hs));
     hipLaunchKernelGGL(spec_final_kernel, dim3(1), dim3(1024), 0, st, work, (int)(N * Hs), spec_inv, scale2, redo);
-    hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)(N * Hs)), dim3(256), (size_t)lds, st, x, sN, sH, (const float*)scale2, o,
+    const int64_t rgrid = N * Hs < 1024 ? N * Hs : 1024;
+    hipLaunchKernelGGL(s2d_pair_rows_kernel, dim3((unsigned)rgrid), dim3(256), (size_t)lds, st, x, sN, sH, (const float*)scale2, o,
                        ld_words, (int)C, (int)H, (int)W, (int)s, (int)ph, (int)pw, (int)Hs, (int)Ws, vec_ok, 0.0f,
-                       (unsigned*)nullptr, (const int*)redo);
+                       (unsigned*)nullptr, (const int*)redo, (int)(N * Hs));
     return qt_check_launch();
 }
 

@@ -36,7 +36,7 @@ def _check_planes(a, x, N, C, H, W, s, pad, floor_exp):
 
 
 @pytest.mark.parametrize("N,C,H,W,s,pad", [(2, 3, 224, 224, 4, 2), (3, 3, 30, 34, 4, 2), (2, 3, 17, 22, 4, 0), (1, 3, 9, 10, 4, (3, 4)),
-                                           (5, 3, 4, 2, 4, (0, 2)),
+                                           (5, 3, 4, 2, 4, (0, 2)), (40, 3, 112, 112, 4, 2),      # 1160 rows: the repack launch walks rows
                                            (2, 3, 31, 33, 4, 2), (2, 3, 32, 32, 4, 1), (2, 4, 32, 32, 4, 2), (2, 3, 32, 32, 2, 2)])
 @pytest.mark.parametrize("amp", [3.0, 40.0, 1e-4, 3e5])
 def test_f16x2_s2d_pack_channels_last_vs_generic(dev, N, C, H, W, s, pad, amp):
