@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--c5-batch", type=int, default=256, help="C5 images per GPU (global with --strong, e.g. 2048; 0 = skip)")
     ap.add_argument("--extra-iters", type=int, default=10)
     ap.add_argument("--train-batch", type=int, default=256, help="AlexNet-Bin training-step extra at N = 1 (0 = skip)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up (self-launch when no launcher is around), meet in the barrier / MAX reduction the "
+                         "timed region uses and print the 'dist' object: runs without a GPU (tests/test_dist_gloo.py)")
     return ap.parse_args()
 
 
@@ -81,8 +84,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with "
-                     f"--nproc-per-node {args.gpus}")
+            # no launcher around this process: re-execute under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1)
+            # — `python bench.py --gpus 8` alone is a complete command; rank 0 of the child job prints the single JSON line
+            return self_launch(args.gpus)
+        sys.exit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE): pass --gpus {world}")
+    if args.launch_check:
+        return launch_check(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     if args.share_device:
@@ -159,8 +166,10 @@ def main():
     if dist is not None:
         # every rank's own step time travels with the line, so a SCALE run is self-checking (a straggler or a rank that
         # did no work shows up here); `ms_per_step` / `value` use the MAX over the ranks as the contract says
-        gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        # (gloo gathers host tensors only; the smoke-test backend keeps this one on the CPU)
+        gdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        gathered = [torch.zeros(1, device=gdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed], device=gdev, dtype=torch.float64))
         per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -316,6 +325,53 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(nproc: int):
+    """`python bench.py --gpus N` without a launcher: run this same command line as N ranks of one node under
+    torch.distributed.run (what the driver does by hand), inherit stdout / stderr, and exit with the job's status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:       # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or nproc) // nproc)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args, world: int, rank: int):
+    """--launch-check: the rendezvous, barrier and MAX reduction of the timed region with no device work (host tensors, so the
+    gloo backend serves it on a machine without a GPU); rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    backend = args.dist_backend if (args.dist_backend != "nccl" or torch.cuda.is_available()) else "gloo"
+    if backend == "nccl":
+        lr = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+        tdev = torch.device("cuda", lr)
+    else:
+        dist.init_process_group(backend)
+        tdev = torch.device("cpu")
+    dist.barrier()
+    tt = torch.tensor([float(rank + 1)], device=tdev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, os.getpid()))
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": args.gpus,
+                          "dist": {"initialised": True, "backend": dist.get_backend(),
+                                   "world_size_seen_by_the_process_group": dist.get_world_size(),
+                                   "max_over_ranks": float(tt.item()), "ranks": sorted(r for r, _ in ranks),
+                                   "distinct_processes": len({p for _, p in ranks})}}))
+    dist.destroy_process_group()
 
 
 def bench_alexnet(args, dev, dist, world, rank):

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void absmax_final_kernel(const unsigned* __res
 }
 
 // Fold of the speculative pack's partial maxima: a = max|x|.  The fixed scale s0 = 1 / spec_inv is ADMISSIBLE when a / s0 lies in
-// [2^8, 2^16) (nothing overflows fp16; the subnormal grid 2^-24 s0 of the low term is <= 2^-32 a, i.e. the split's error is
+// [2^8, 2^15) (nothing overflows fp16 — its largest finite value is 65504 and v_cvt_f16_f32 rounds anything >= 65520 to inf,
+// so the window stops at write_scale's own target binade [2^14, 2^15) instead of 2^16; the subnormal grid 2^-24 s0 of the low term is <= 2^-32 a, i.e. the split's error is
 // max(2^-22 |x|, 2^-33 max|x|)), or when a == 0: then scale2 = [s0, 1 / s0] and *redo = 0.  Otherwise scale2 is the exact-binade
 // scale of write_scale and *redo = 1: the repack launch behind this one rewrites the plane with it.
 __global__ __launch_bounds__(1024) void spec_final_kernel(const unsigned* __restrict__ part, int nparts, float spec_inv,
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(1024) void spec_final_kernel(const unsigned* __rest
         for (int j = 1; j < 16; ++j) mm = max(mm, sh[j]);
         const float a = __uint_as_float(mm);
         const float r = a * spec_inv;                                     // exact: spec_inv is a power of two
-        const bool ok = a == 0.0f || (r >= 256.0f && r < 65536.0f);      // NaN / inf: not ok
+        const bool ok = a == 0.0f || (r >= 256.0f && r < 32768.0f);      // NaN / inf: not ok
         if (ok) {
             scale2[0] = 1.0f / spec_inv;
             scale2[1] = spec_inv;

@@ -1550,7 +1550,8 @@ def pack_conv_weight_bf16x3(weight: torch.Tensor, kind: str, terms: Optional[int
 
 
 #: fixed power-of-two scale the first layer's space-to-depth pack speculates with (None / 0: always the separate max|x| pass).
-#: 2^-11 is admissible for max|x| in [2^-3, 2^5): unit-variance and [0, 1] images; anything else is repacked on the device.
+#: 2^-11 is admissible for max|x| in [2^-3, 2^4) (max|x| / s in [2^8, 2^15): below fp16's overflow with a binade to spare):
+#: unit-variance and [0, 1] images; anything else is repacked on the device.
 S2D_SPEC_SCALE: Optional[float] = 2.0 ** -11
 
 

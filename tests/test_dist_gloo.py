@@ -269,3 +269,26 @@ def test_strong_scaling_c5_shards_concatenate_to_the_global_batch(tmp_path):
         full = m(x).numpy()
     got = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)], 0)
     assert np.array_equal(got, full)
+
+
+def _run_bench(*flags, timeout=600):
+    """`python bench.py <flags>` as a user types it — no launcher around it; returns the JSON lines of its stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_self_launches_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset re-executes itself under torch.distributed.run: two
+    distinct processes meet in the barrier / MAX reduction of the timed region and rank 0 alone prints ONE line."""
+    lines = _run_bench("--gpus", "2", "--dist-backend", "gloo", "--launch-check")
+    assert len(lines) == 1
+    d = lines[0]["dist"]
+    assert d["world_size_seen_by_the_process_group"] == 2 and d["ranks"] == [0, 1] and d["distinct_processes"] == 2
+    assert d["max_over_ranks"] == 2.0 and lines[0]["n_gpus"] == 2
