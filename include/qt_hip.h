@@ -208,6 +208,11 @@ int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64
 int qt_ternary_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp,
                             int64_t rows, int64_t K, qt_stream_t stream);
 
+/* nibble plane of torch.sign(x): 0 (and NaN) -> 0x0 — the sign image of the XNOR-Net weight quantiser, which keeps W == 0 at 0
+ * (functions/xnor_connect.py:112-113, 140-141). */
+int qt_sign0_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp, int64_t rows, int64_t K,
+                          qt_stream_t stream);
+
 /* Both operands of one LinearBin / LinearTer forward (layers/binary_layers.py:44: F.linear(x, bin_op(W), b) on a
  * +-1 activation that is not packed yet) in ONE launch: x -> safeSign nibble plane, w -> safeSign (w_ternary = 0)
  * or ternary (1) nibble plane.  Same formats and contracts as the two single-operand entries. */
@@ -611,6 +616,50 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, in
                            const float* scale_dev, const float* alpha, const float* beta, const float* thr,
                            uint32_t* nib_plane, int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w,
                            int64_t d2s_cout, qt_stream_t stream);
+
+/* ---- per-tap scaled convs: the XNOR-Net family (functions/xnor_connect.py:135-169, layers/xnor_layers.py:36-69) ----------------
+ * XNORConv2d computes conv2d(x, sign(W) * alpha) with alpha = mean(|W|, dim = [0, 1], keepdim) -> [1, 1, kh, kw]: one scale per
+ * filter TAP (xnor_connect.py:140-145).  With the implicit GEMM's tap-major K order
+ *     y[m, n] = sum_t alpha_t * D_t[m, n],    D_t = sum over the input channels of tap t      (exact integer for +-1 activations)
+ * is evaluated in Horner form on the accumulators: at the boundary in front of tap t they are multiplied by
+ * rho_t = alpha_{t-1} / alpha_t, the taps' MFMAs keep accumulating onto them, and the epilogue multiplies by alpha_{T-1}: one
+ * matrix-core pass over the sign planes (the six bf16 passes of a real x real conv otherwise), 2 (T - 1 - t) extra fp32 roundings
+ * on tap t's term.  This is the `qt_xnor_conv2d_taps` of SURVEY 8(b).
+ *
+ * qt_xnor_tap_prep_f32: alpha and the Horner tables of a conv weight viewed as row-major [R = Cout * Cin, taps = kh * kw].
+ *   w != NULL, alpha_in == NULL: alpha[t] = mean_r |w[r, t]| (deterministic two-stage reduction; `work` =
+ *       qt_xnor_tap_prep_work_floats(R, taps) floats), written to `alpha` (optional) — training mode, xnor_connect.py:140;
+ *   alpha_in != NULL: the scales are given (eval mode: the weight already holds sign(W) * alpha, layers/xnor_layers.py:54-61).
+ *   tables [2 * (taps + 1)]: [1, rho_1 .. rho_{T-1}, a'_{T-1}] for the forward tap order, then the same for the REVERSED tap order
+ *   (the gradient w.r.t. the input convolves with the flipped kernel, xnor_connect.py:154-155).  a' = alpha with zeros replaced
+ *   by the preceding non-zero scale (a tap with alpha == 0 has all-zero weights, D_t = 0).  taps <= 1024. */
+int64_t qt_xnor_tap_prep_work_floats(int64_t R, int64_t taps);
+int qt_xnor_tap_prep_f32(const float* w, int64_t R, int64_t taps, const float* alpha_in, float* work, float* alpha,
+                         float* tables, qt_stream_t stream);
+
+/* qt_conv2d_implicit with per-tap scaling: Y = (scale * scale_dev) * sum_t alpha_t D_t + bias.  elem 0: fp4 nibble planes (+-1
+ * activations x sign(W), zeros for W == 0 as torch.sign gives); elem 3: fp16 pair planes (a real-valued operand, e.g. the
+ * gradient, against the replicated +-1 / 0 weight).  tap_rho: one (taps + 1)-entry table of qt_xnor_tap_prep_f32.  A tap must be
+ * a whole number of 32-byte MFMA k-steps: Cw % 8 == 0 (channels padded to 64 for fp4, to 8 for fp16 pairs), else
+ * QT_ERR_ALIGNMENT.  Everything else as qt_conv2d_implicit. */
+int qt_conv2d_implicit_taps(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw,
+                            int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat,
+                            int64_t ldw, const float* bias, float scale, const float* scale_dev, const float* tap_rho, float* Y,
+                            int64_t ldy, int64_t Cout, qt_stream_t stream);
+
+/* ... with the threshold-bit epilogue of qt_conv2d_implicit_bits (float form: the accumulators are not integers), */
+int qt_conv2d_implicit_taps_bits(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw,
+                                 int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat,
+                                 int64_t ldw, const float* bias, float scale, const float* scale_dev, const float* tap_rho,
+                                 const float* alpha, const float* beta, uint32_t* neg_plane, int64_t ldb, int64_t Cout,
+                                 qt_stream_t stream);
+
+/* ... and with the sign bits written as the next conv's nibble pixel plane (qt_conv2d_implicit_nib without depth-to-space). */
+int qt_conv2d_implicit_taps_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw,
+                                int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat,
+                                int64_t ldw, const float* bias, float scale, const float* scale_dev, const float* tap_rho,
+                                const float* alpha, const float* beta, uint32_t* nib_plane, int64_t ldn, int64_t Cout,
+                                int64_t out_halo_h, int64_t out_halo_w, qt_stream_t stream);
 
 /* Direct form of the 3x3 / stride 1 / padding 1 conv of a +-1 activation for few channels at large spatial size
  * (VGG / ResNet early layers), where the implicit-GEMM gather of qt_conv2d_implicit_* is bound by L2 traffic (each

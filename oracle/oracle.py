@@ -325,15 +325,89 @@ def dorefa_weight(weight, k):
 def xnor_dense_weight(weight):
     """XNORDense forward weight: sign(W)*mean(|W|, DIM=0, keepdim) (functions/xnor_connect.py:112-113)."""
     w = np.asarray(weight, dtype=np.float32)
-    mean = np.mean(np.abs(w), axis=0, keepdims=True, dtype=np.float32)
+    # (float64 accumulation, rounded once: numpy's float32 reduction over an outer axis is a plain running sum — 4e-6 off at 4096
+    # rows — where torch's cascade sum stays within an ulp of this)
+    mean = np.mean(np.abs(w), axis=0, keepdims=True, dtype=np.float64).astype(np.float32)
     return np.sign(w).astype(np.float32) * mean
 
 
 def xnor_conv_weight(weight, dim=(0, 1)):
     """XNORConv2d forward weight: sign(W)*mean(|W|, dim, keepdim) (functions/xnor_connect.py:140-141)."""
     w = np.asarray(weight, dtype=np.float32)
-    mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True, dtype=np.float32)
+    mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True, dtype=np.float64).astype(np.float32)     # see xnor_dense_weight
     return np.sign(w).astype(np.float32) * mean
+
+
+# ---- XNOR-Net layers: forward and the reference's hand-written backward (functions/xnor_connect.py:93-169) ---------------------
+# Restated in float64 numpy (the contractions as per-tap BLAS products); used by the tests only, at sizes that finish in seconds.
+
+def conv2d_input_f64(in_shape, wq, g, stride=1, padding=0, dilation=1):
+    """torch.nn.grad.conv2d_input (groups = 1) in float64: gx[n, c, ho s - p + i d, wo s - p + j d] += g[n, o, ho, wo] wq[o, c, i, j]."""
+    Nb, Cin, H, W = (int(v) for v in in_shape)
+    wq = np.asarray(wq, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    Cout, _, kh, kw = wq.shape
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    _, _, Ho, Wo = g.shape
+    gp = np.zeros((Nb, Cin, H + 2 * ph, W + 2 * pw), dtype=np.float64)
+    g2 = g.transpose(0, 2, 3, 1).reshape(-1, Cout)                          # [n ho wo, o]
+    for i in range(kh):
+        for j in range(kw):
+            t = (g2 @ wq[:, :, i, j]).reshape(Nb, Ho, Wo, Cin).transpose(0, 3, 1, 2)
+            gp[:, :, i * dh:i * dh + sh * (Ho - 1) + 1:sh, j * dw:j * dw + sw * (Wo - 1) + 1:sw] += t
+    return gp[:, :, ph:ph + H, pw:pw + W]
+
+
+def conv2d_weight_f64(x, w_shape, g, stride=1, padding=0, dilation=1):
+    """torch.nn.grad.conv2d_weight (groups = 1) in float64."""
+    x = np.asarray(x, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    Cout, Cin, kh, kw = (int(v) for v in w_shape)
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Nb, _, Ho, Wo = g.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    g2 = g.transpose(1, 0, 2, 3).reshape(Cout, -1)                          # [o, n ho wo]
+    gw = np.empty((Cout, Cin, kh, kw), dtype=np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            xs = xp[:, :, i * dh:i * dh + sh * (Ho - 1) + 1:sh, j * dw:j * dw + sw * (Wo - 1) + 1:sw]
+            gw[:, :, i, j] = g2 @ xs.transpose(0, 2, 3, 1).reshape(-1, Cin)
+    return gw
+
+
+def xnor_conv2d_forward(x, weight, bias=None, stride=1, padding=1, dilation=1, dim=(0, 1)):
+    """XNORConv2d forward (functions/xnor_connect.py:139-146; quant_input False as the layer hard-codes, layers/xnor_layers.py:49)."""
+    return conv2d(x, xnor_conv_weight(weight, dim), bias, stride, padding, dilation)
+
+
+def xnor_conv2d_backward(g, x, weight, stride=1, padding=1, dilation=1, dim=(0, 1)):
+    """XNORConv2d backward (functions/xnor_connect.py:149-168) in float64: (grad_input, grad_weight, grad_bias).  The weight
+    gradient mixes ``dim`` (the saved mean) with the module-global DIM = 0 (the second term's reduction), as upstream."""
+    w = np.asarray(weight, dtype=np.float64)
+    sgn = np.sign(w)
+    mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True)
+    gx = conv2d_input_f64(np.shape(x), sgn * mean, g, stride, padding, dilation)
+    gt = conv2d_weight_f64(x, w.shape, g, stride, padding, dilation)
+    gw = mean * gt + sgn * np.mean(gt * sgn, axis=0, keepdims=True)
+    gb = np.asarray(g, dtype=np.float64).sum((0, 2, 3))
+    return gx, gw, gb
+
+
+def xnor_dense_forward(x, weight, bias=None):
+    """XNORDense forward (functions/xnor_connect.py:110-116)."""
+    return linear(x, xnor_dense_weight(weight), bias)
+
+
+def xnor_dense_backward(g, x, weight):
+    """XNORDense backward (functions/xnor_connect.py:118-131) in float64: (grad_input, grad_weight, grad_bias)."""
+    w = np.asarray(weight, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    sgn = np.sign(w)
+    mean = np.mean(np.abs(w), axis=0, keepdims=True)
+    gx = g @ (sgn * mean)
+    gt = g.T @ np.asarray(x, dtype=np.float64)
+    gw = mean * gt + sgn * np.mean(gt * sgn, axis=0, keepdims=True)
+    return gx, gw, g.sum(0)
 
 
 def shift_batch(x, mean, var, weight, bias, eps):

@@ -257,16 +257,17 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
     return F.linear(input, wq, bias)
 
 
-def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool], weight: Optional[torch.Tensor] = None):
+def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool], weight: Optional[torch.Tensor] = None, ld_fn=None):
     """(NHWC nibble pixel plane of a device activation that is (treated as) exactly +-1 else None, device flag to fold
-    into the bias or None)."""
+    into the bias or None).  ``ld_fn``: words per pixel as a function of the channel count (default ops.pixel_ld_nib)."""
     if input.dtype != torch.float32 or input.dim() != 4 or input.numel() == 0:
         return None, None
+    ld_fn = ld_fn or ops.pixel_ld_nib
     tagged = packed.lookup(input, packed.NHWC)
     if tagged is not None:
         N, C, H, W = input.shape
         if tagged.K == C and tagged.rows == N * H * W:
-            return ops.bits_to_nib(tagged, ld=ops.pixel_ld_nib(C)), None
+            return ops.bits_to_nib(tagged, ld=ld_fn(C)), None
     if binary_input is False:
         return None, None
     flag = None
@@ -276,7 +277,7 @@ def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool], weight: Opt
         ok, flag = detect_pm1(input, weight)
         if not ok:
             return None, None
-    return ops.pack_pixels_nib(input), flag
+    return ops.pack_pixels_nib(input, ld=ld_fn(int(input.shape[1]))), flag
 
 
 def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups, kind: str,
@@ -539,6 +540,62 @@ class QuantConv2dFn(torch.autograd.Function):
         if want_bias:
             grad_bias = bias_by_product[0] if bias_by_product else go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None, None, None, None
+
+
+def pm1_conv_grad_weight(input, go, weight_shape, stride, padding, dilation, bias_by_product=None):
+    """UN-masked grad wrt the weight of conv2d(x, .) for a +-1 / 0 activation x on this backend's weight-gradient routes
+    (pixel-major kernel, K-major batched GEMMs, strided forms, swapped conv); None when no route takes the shape.  The callers
+    apply their quantiser's backward to it (STE mask: QuantConv2dFn; the XNOR-Net combination: xnor_connect.py:158-159)."""
+    ksz = weight_shape[2:]
+    gw = None
+    if ops.wgrad_pm_applicable(input.shape, go.shape, ksz, stride, dilation):
+        gw = ops.conv2d_grad_weight_pm(input, go, ksz, padding, weight=None, bias_grad=bias_by_product)
+    if gw is None and ops.wgrad_gemm_applicable(input.shape, go.shape, ksz, stride, dilation):
+        gw = ops.conv2d_grad_weight_gemm(input, go, ksz, padding, weight=None)
+    if gw is None and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
+        gw = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding)
+    if gw is None:
+        gw = ops.conv2d_grad_weight_pm1(input, go, ksz, stride, padding, dilation)
+    return gw
+
+
+# ---- XNOR-Net family (functions/xnor_connect.py:93-169, layers/xnor_layers.py) ------------------------------------------------------
+
+def xnor_conv_fast_applicable(input, weight, dim, groups, padding) -> bool:
+    """The per-tap scaled route: device fp32 NCHW input, groups == 1, numeric zero padding, and the scale reduced over exactly the
+    first two weight dimensions (``dim`` = [0, 1], the default of the layer, the converter and the function: one alpha per tap)."""
+    return (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+            and input.numel() > 0 and weight.dtype == torch.float32 and weight.dim() == 4 and groups == 1
+            and not isinstance(padding, str) and not isinstance(dim, int) and sorted(int(d) for d in dim) == [0, 1])
+
+
+def xnor_conv2d_forward(input, weight, bias, stride, padding, dilation, binary_input=None, planes=None, epi=None):
+    """conv2d(x, sign(W) * alpha[1, 1, kh, kw]) for a +-1 activation on the fp4 matrix cores with per-tap scaling
+    (qt_conv2d_implicit_taps).  ``planes`` = (weight nibble planes, TapScales) cached by an eval-mode layer.
+    Returns (result, TapScales, pixel words per channel) with result = the NHWC fp32 matrix [N*Ho*Wo, Cout] (or the epilogue's
+    planes), or None when the activation is not +-1 / the shape is outside the kernel's limits (the caller takes the real x real
+    route)."""
+    px, flag = _pixel_planes(input, binary_input, weight, ld_fn=ops.pixel_ld_nib_taps)
+    if px is None:
+        return None
+    if planes is not None:
+        wp, taps = planes
+    else:
+        taps = ops.xnor_tap_prep(weight)
+        wp = ops.pack_conv_weight_nib(weight.detach(), "sign", cw=px.ld)
+    N, C, H, W = (int(v) for v in input.shape)
+    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    b = poison_bias(bias.detach() if bias is not None else None, flag, int(weight.shape[0]), input.device)
+    y2 = ops.conv2d_nib_taps(px, (N, C, H, W), wp, (kh, kw), taps.fwd, b, stride, padding, dilation, epi=epi)
+    if y2 is None:
+        return None
+    return y2, taps
+
+
+def xnor_weight_grad(gw: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor, reduce_dim=0) -> torch.Tensor:
+    """mean * gw + sign(W) * mean(gw * sign(W), DIM, keepdim) (functions/xnor_connect.py:126-127, 158-159; DIM = 0 upstream)."""
+    sgn = torch.sign(weight)
+    return mean * gw + sgn * torch.mean(gw * sgn, reduce_dim, keepdim=True)
 
 
 def _dorefa_w1_scale(weight: torch.Tensor, prequantized: bool) -> torch.Tensor:

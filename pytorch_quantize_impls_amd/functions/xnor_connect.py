@@ -8,7 +8,8 @@ The reference module is unfinished upstream; observable numerics are reproduced,
 """
 import torch
 
-from .. import ops
+from .. import ops, packed
+from . import _fused
 from .common import front
 
 DIM = 0
@@ -76,16 +77,26 @@ def xnor_weight(weight, dims):
 
 
 def XNORDense(dim=[0, 1]):
-    """XNOR dense op; ``dim`` is accepted and ignored like upstream (xnor_connect.py:93-132)."""
+    """XNOR dense op; ``dim`` is accepted and ignored like upstream (xnor_connect.py:93-132).
+
+    Device fp32 tensors: forward = the split GEMM of x * alpha[k] against sign(W) on the matrix cores; backward (:118-131) on the
+    same routes — grad_input = (g . sign(W)) * alpha[k] (the per-column scale commutes with the contraction over n),
+    grad_weight from g^T . x with the +-1 activation as the exact operand (two real operands: the dense library, counted in
+    _fused.LIBRARY_PATHS) and the XNOR-Net combination mean * gw + sign(W) * mean(gw * sign(W), DIM)."""
 
     class _XNORDense(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
+            ctx.x_is_pm1 = False
             if input.is_cuda and input.dtype == torch.float32 and weight.dim() == 2 and input.numel() > 0:
                 # alpha on the device (qt_xnor_weight_f32), folded into the activation split; sign(W) on
                 # the bf16 matrix cores: fl(x*alpha) * (+-1) is the product fl(x * (+-alpha)) exactly
                 _, mean = ops.xnor_weight(weight.detach(), 1)
                 ctx.save_for_backward(input, weight, mean, bias)
+                if input.dim() == 2:
+                    ctx.x_is_pm1 = packed.lookup(input, packed.ROWS_LAST) is not None
+                    if not ctx.x_is_pm1 and _fused.DETECT_BINARY_INPUT:
+                        ctx.x_is_pm1 = bool(_fused.detect_pm1(input, weight)[0])
                 return ops.float_linear(input, weight.detach(), "sign", bias, alpha=mean.view(-1))
             weight_q, mean = xnor_weight(weight, DIM)
             ctx.save_for_backward(input, weight, mean, bias)
@@ -96,11 +107,21 @@ def XNORDense(dim=[0, 1]):
             input, weight, mean, bias = ctx.saved_tensors
             sgn = torch.sign(weight)
             grad_input = grad_weight = grad_bias = None
+            hip = grad_output.is_cuda and grad_output.dtype == torch.float32 and grad_output.dim() == 2 and input.dim() == 2
+            g2 = grad_output.contiguous() if hip else grad_output
             if ctx.needs_input_grad[0]:
-                grad_input = grad_output.mm(sgn * mean)
+                if hip:
+                    grad_input = _fused.pm1_matmul(g2, sgn) * mean          # g . (sign(W) * alpha[k]) = (g . sign(W)) * alpha[k]
+                else:
+                    grad_input = grad_output.mm(sgn * mean)
             if ctx.needs_input_grad[1]:
-                gw = grad_output.t().mm(input)
-                grad_weight = mean * gw + sgn * torch.mean(gw * sgn, DIM, keepdim=True)
+                if hip and ctx.x_is_pm1:
+                    gw = _fused.pm1_matmul(g2.t(), input, terms=3)          # rows of g^T are output features: the exact split
+                else:
+                    if hip and g2.shape[0] * g2.shape[1] * input.shape[1] >= _fused.BWD_MFMA_MIN_MACS:
+                        _fused.note_library_path(g2, "backward GEMM with two real operands")
+                    gw = grad_output.t().mm(input)
+                grad_weight = _fused.xnor_weight_grad(gw, weight, mean, DIM)
             if bias is not None and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum(0)
             return grad_input, grad_weight, grad_bias
@@ -109,11 +130,36 @@ def XNORDense(dim=[0, 1]):
 
 
 def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, groups=1):
-    """XNOR conv op (xnor_connect.py:135-169)."""
+    """XNOR conv op (xnor_connect.py:135-169).
+
+    Device fp32 tensors with ``dim`` = [0, 1] (one alpha per filter tap), groups == 1:
+      * +-1 activation (tag of a BinaryConnect, or detected on the device): one fp4 matrix-core pass over the sign planes with the
+        taps' alphas applied on the accumulators (qt_conv2d_implicit_taps) — y = sum_taps alpha[i, j] * (integer dot over Cin);
+      * real-valued activation (the first layer): six-term bf16 planes of x and of sign(W) * alpha (fp32-GEMM accuracy);
+      * backward: grad_input = the split gradient against the flipped sign(W) with the flipped alphas per tap (stride 1),
+        grad_weight = the +-1 weight-gradient routes (pixel-major / K-major / strided) + the XNOR-Net combination (:158-159).
+    Whatever has no route here runs the reference expression on the dense library and is counted (_fused.LIBRARY_PATHS)."""
 
     class _XNORConv2d(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
+            ctx.x_is_pm1, ctx.taps = False, None
+            fast = (not quant_input) and _fused.xnor_conv_fast_applicable(input, weight, dim, groups, padding)
+            if fast:
+                known = True if packed.lookup(input, packed.NHWC) is not None else None
+                _fused.clear_last_detection()
+                out = _fused.xnor_conv2d_forward(input, weight, bias, stride, padding, dilation, binary_input=known)
+                if out is not None:
+                    y2, taps = out
+                    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+                    ctx.x_is_pm1, ctx.taps = True, taps
+                    ctx.save_for_backward(input, weight, taps.alpha.view(1, 1, kh, kw), bias)
+                    N_, _, H, W = input.shape
+                    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+                    y = y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+                    if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                        y = y.contiguous()
+                    return y
             weight_b, mean_weight = xnor_weight(weight, dim)
             if quant_input:
                 input = torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
@@ -130,24 +176,41 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
                     if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                         y = y.contiguous()
                     return y
+            _fused.note_library_path(input, "XNOR conv outside the matrix-core routes")
             return torch.nn.functional.conv2d(input, weight_b, bias=bias, stride=stride,
                                               padding=padding, dilation=dilation, groups=groups)
 
         @staticmethod
         def backward(ctx, grad_output):
             input, weight, mean, bias = ctx.saved_tensors
-            sgn = torch.sign(weight)
+            sgn = None
             grad_input = grad_weight = grad_bias = None
+            go = _fused._dense(grad_output)
+            mfma = (_fused.BWD_CONV_MFMA and ctx.x_is_pm1 and go.is_cuda and go.dtype == torch.float32 and groups == 1
+                    and not isinstance(padding, str))
             if ctx.needs_input_grad[0]:
-                grad_input = torch.nn.grad.conv2d_input(input.size(), sgn * mean, grad_output,
-                                                        stride=stride, padding=padding,
-                                                        dilation=dilation, groups=groups)
+                if mfma:
+                    grad_input = ops.conv2d_grad_input_taps(input.shape, weight, go, ctx.taps.bwd, stride, padding, dilation)
+                if grad_input is None:
+                    _fused.note_library_path(go, "conv grad_input outside the matrix-core route")
+                    sgn = torch.sign(weight)
+                    grad_input = torch.nn.grad.conv2d_input(input.size(), sgn * mean, grad_output,
+                                                            stride=stride, padding=padding,
+                                                            dilation=dilation, groups=groups)
+            want_bias = bias is not None and ctx.needs_input_grad[2]
+            by_product = []
             if ctx.needs_input_grad[1]:
-                gw = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output, stride=stride,
-                                                 padding=padding, dilation=dilation, groups=groups)
-                grad_weight = mean * gw + sgn * torch.mean(gw * sgn, DIM, keepdim=True)
-            if bias is not None and ctx.needs_input_grad[2]:
-                grad_bias = grad_output.sum((0, 2, 3))
+                gw = None
+                if mfma:
+                    gw = _fused.pm1_conv_grad_weight(input, go, weight.shape, stride, padding, dilation,
+                                                     by_product if want_bias else None)
+                if gw is None:
+                    _fused.note_library_path(go, "conv grad_weight outside the matrix-core route")
+                    gw = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output, stride=stride,
+                                                     padding=padding, dilation=dilation, groups=groups)
+                grad_weight = _fused.xnor_weight_grad(gw, weight, mean, DIM)
+            if want_bias:
+                grad_bias = by_product[0] if by_product else grad_output.sum((0, 2, 3))
             if bias is not None:
                 return grad_input, grad_weight, grad_bias
             return grad_input, grad_weight

@@ -5,7 +5,7 @@ its ``dim`` / forces quant_input=False (:47-49).  Numerics are reproduced; the c
 using the stored ``self.dim`` (documented in DESIGN.md)."""
 import torch
 
-from ..functions import xnor_connect
+from ..functions import xnor_connect, _fused
 from .common import QLayer, EvalSwapMixin
 
 
@@ -57,5 +57,34 @@ class XNORConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
     def clamp(self):
         pass
 
+    def _weight_on_grid(self, w):
+        # sign(W) * alpha[1, 1, kh, kw]: per tap every entry is 0 or +-(the tap's largest magnitude)
+        a = w.abs()
+        top = a.amax((0, 1), keepdim=True)
+        return ((a == 0) | (a == top)).all()
+
+    def _taps_planes(self):
+        """Cached operands of the eval-mode weight for the per-tap scaled conv: (nibble planes of sign(W), TapScales)."""
+        ops = _fused.ops
+        cw = ops.pixel_ld_nib_taps(self.in_channels)
+        return self._eval_planes(lambda _w2: (ops.pack_conv_weight_nib(self.weight.detach(), "sign", cw=cw),
+                                              ops.xnor_tap_prep(self.weight)), key="conv_taps")
+
     def forward(self, input):
+        if (not self.training and not torch.is_grad_enabled()
+                and _fused.xnor_conv_fast_applicable(input, self.weight, self.dim, self.groups, self.padding)
+                and self.padding_mode == "zeros"):
+            # eval mode: the weight holds sign(W) * alpha and the op quantises it again like upstream (a fixed point: the
+            # scales of the image are its own magnitudes); the packed operands are cached per weight version
+            known = True if _fused.packed.lookup(input, _fused.packed.NHWC) is not None else None
+            out = _fused.xnor_conv2d_forward(input, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                             binary_input=known, planes=self._taps_planes())
+            if out is not None:
+                ops = _fused.ops
+                N_, _, H, W = input.shape
+                Ho, Wo = ops.conv_out_hw(H, W, self.kernel_size[0], self.kernel_size[1], self.stride, self.padding, self.dilation)
+                y = out[0].view(N_, Ho, Wo, self.out_channels).permute(0, 3, 1, 2)
+                if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous()
+                return y
         return self.conv_op.apply(input, self.weight, self.bias)

@@ -708,6 +708,11 @@ def ternary_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
     return _nib_pack("qt_ternary_pack_nib_f32", x, ld)
 
 
+def sign0_pack_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
+    """Nibble plane of torch.sign(x) (0 stays 0): the sign image of the XNOR-Net weight quantiser (xnor_connect.py:141)."""
+    return _nib_pack("qt_sign0_pack_nib_f32", x, ld)
+
+
 def bits_to_nib(planes: BitPlanes, ld: Optional[int] = None) -> NibPlanes:
     """Expand 1-bit planes (sign, or mask + sign) to the nibble plane the MFMA GEMM consumes."""
     ld = packed_ld_nib(planes.K) if ld is None else int(ld)
@@ -1079,14 +1084,15 @@ def conv_out_hw(H, W, kh, kw, stride, padding, dilation):
     return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
 
 
-def pack_conv_weight_nib(weight: torch.Tensor, kind: str) -> NibPlanes:
+def pack_conv_weight_nib(weight: torch.Tensor, kind: str, cw: Optional[int] = None) -> NibPlanes:
     """[Cout, Cin, kh, kw] fp32 -> nibble plane [Cout, kh*kw*Cw] (tap-major, channels inside a tap,
-    Cw words per tap = pixel_ld_nib(Cin)), row stride padded to a whole GEMM stage."""
+    Cw words per tap = pixel_ld_nib(Cin), or ``cw``), row stride padded to a whole GEMM stage.  ``kind``: "binary" (safeSign),
+    "ternary", or "sign" (torch.sign: the XNOR-Net weight image)."""
     _require(weight, "weight")
     Cout, Cin, kh, kw = (int(v) for v in weight.shape)
-    Cw = pixel_ld_nib(Cin)
+    Cw = pixel_ld_nib(Cin) if cw is None else int(cw)
     wt = weight.permute(0, 2, 3, 1).contiguous().view(Cout * kh * kw, Cin)   # plumbing (weights are small)
-    taps = sign_pack_nib(wt, ld=Cw) if kind == "binary" else ternary_pack_nib(wt, ld=Cw)
+    taps = {"binary": sign_pack_nib, "ternary": ternary_pack_nib, "sign": sign0_pack_nib}[kind](wt, ld=Cw)
     kwords = kh * kw * Cw
     ld = max(32, (kwords + 127) // 128 * 128 if kwords * 4 >= 2048 else (kwords + 31) // 32 * 32)   # whole 512-byte stages for long K
     words = taps.words.view(Cout, kwords)
@@ -1097,14 +1103,14 @@ def pack_conv_weight_nib(weight: torch.Tensor, kind: str) -> NibPlanes:
     return NibPlanes(words=words, rows=Cout, K=kwords * 8)
 
 
-def pack_pixels_nib(x: torch.Tensor) -> NibPlanes:
-    """+-1 activation [N, C, H, W] (any memory format) -> NHWC nibble pixel plane [N*H*W, Cw]."""
+def pack_pixels_nib(x: torch.Tensor, ld: Optional[int] = None) -> NibPlanes:
+    """+-1 activation [N, C, H, W] (any memory format) -> NHWC nibble pixel plane [N*H*W, Cw] (Cw = pixel_ld_nib(C) or ``ld``)."""
     _require(x, "input")
     N, C, H, W = (int(v) for v in x.shape)
     nhwc = x.permute(0, 2, 3, 1)
     if not nhwc.is_contiguous():
         nhwc = nhwc.contiguous()          # NCHW storage: one transpose copy (plumbing)
-    return sign_pack_nib(nhwc.view(N * H * W, C), ld=pixel_ld_nib(C))
+    return sign_pack_nib(nhwc.view(N * H * W, C), ld=pixel_ld_nib(C) if ld is None else int(ld))
 
 
 
@@ -1285,6 +1291,121 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
                       I(sw), I(ph), I(pw), I(dh), I(dw), _p(A), I(ldA), I(m0), I(cnt), _stream(dev))
         nib_gemm(NibPlanes(words=A[:cnt], rows=cnt, K=wplanes.K), wplanes, bias, out=y[m0:m0 + cnt])
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# per-tap scaled convs: the XNOR-Net family (csrc/conv_taps.hip)
+# ----------------------------------------------------------------------------------------------
+
+def pixel_ld_nib_taps(C: int) -> int:
+    """Words per pixel of a nibble pixel plane that feeds a per-tap scaled conv: a tap must be whole 32-byte MFMA k-steps, so
+    ceil(C / 8) rounded up to 8 words (64 channels)."""
+    return max(8, ((int(C) + 7) // 8 + 7) // 8 * 8)
+
+
+@dataclass
+class TapScales:
+    """Per-tap scales of an XNOR-Net conv weight (alpha = mean(|W|, [0, 1]) -> [kh * kw], functions/xnor_connect.py:140) and the
+    Horner tables the kernels read (qt_xnor_tap_prep_f32): ``tables`` = [forward (taps + 1) | flipped (taps + 1)]."""
+    alpha: torch.Tensor
+    tables: torch.Tensor
+    taps: int
+
+    @property
+    def fwd(self) -> torch.Tensor:
+        return self.tables[:self.taps + 1]
+
+    @property
+    def bwd(self) -> torch.Tensor:
+        return self.tables[self.taps + 1:]
+
+
+def xnor_tap_prep(weight: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None) -> TapScales:
+    """alpha[kh * kw] of a conv weight [Cout, Cin, kh, kw] (mean of |W| over the first two dimensions) and its Horner tables, on
+    the device without a host round trip.  ``alpha`` given (eval mode: the weight already holds sign(W) * alpha): tables only."""
+    if alpha is not None:
+        a = _require(alpha.detach(), "alpha").contiguous().view(-1)
+        T = int(a.numel())
+        tables = torch.empty((2 * (T + 1),), dtype=torch.float32, device=a.device)
+        with _on(a.device):
+            _lib.call("qt_xnor_tap_prep_f32", None, 0, T, _p(a), None, None, _p(tables), _stream(a.device))
+        return TapScales(alpha=a, tables=tables, taps=T)
+    w = _require(weight.detach(), "weight").contiguous()
+    Cout, Cin, kh, kw = (int(v) for v in w.shape)
+    R, T = Cout * Cin, kh * kw
+    if T > 1024 or R == 0:
+        raise ValueError("xnor_tap_prep: at most 1024 taps and a non-empty weight")
+    work = torch.empty((max(1, int(_lib.load().qt_xnor_tap_prep_work_floats(R, T))),), dtype=torch.float32, device=w.device)
+    a = torch.empty((T,), dtype=torch.float32, device=w.device)
+    tables = torch.empty((2 * (T + 1),), dtype=torch.float32, device=w.device)
+    with _on(w.device):
+        _lib.call("qt_xnor_tap_prep_f32", _p(w), R, T, None, _p(work), _p(a), _p(tables), _stream(w.device))
+    return TapScales(alpha=a, tables=tables, taps=T)
+
+
+def _conv_taps(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, geom, wmat: torch.Tensor, ldw_words: int, bias,
+               scale: float, scale_dev, tap_rho: torch.Tensor, Cout: int, epi=None):
+    """qt_conv2d_implicit_taps (fp32 result), _bits (``epi`` = (alpha, beta)) or _nib (a NibEpilogue); None when the shape is
+    outside the kernel's limits."""
+    (sh, sw), (ph, pw), (dh, dw) = geom
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    M = N * Ho * Wo
+    if (M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or ldw_words % 32 or Cw % 8
+            or H * W * Cw * 4 >= (1 << 31) or Cout * ldw_words * 4 >= (1 << 31)):
+        return None
+    dev = pixels_words.device
+    rho = _require(tap_rho, "tap_rho")
+    if rho.numel() != kh * kw + 1 or not rho.is_contiguous():
+        raise ValueError(f"tap_rho must hold kh * kw + 1 = {kh * kw + 1} contiguous entries")
+    I = int
+    head = (int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw),
+            I(dh), I(dw), _p(wmat), I(ldw_words), _p(bias), float(float(scale)),
+            _p(_require(scale_dev, "scale_dev").reshape(1) if scale_dev is not None else None), _p(rho))
+    if isinstance(epi, NibEpilogue):
+        if epi.d2s_cout:
+            raise ValueError("the depth-to-space epilogue does not exist for per-tap scaled convs")
+        alpha, beta = _check_bias(epi.alpha, Cout, dev), _check_bias(epi.beta, Cout, dev)
+        ohy, ohx = (int(v) for v in epi.out_halo)
+        ldn = pixel_ld_nib(Cout)
+        rows = N * (Ho + 2 * ohy) * (Wo + 2 * ohx)
+        plane = torch.empty((rows, ldn), dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv2d_implicit_taps_nib", *head, _p(alpha), _p(beta), _p(plane), I(ldn), I(Cout), I(ohy), I(ohx),
+                      _stream(dev))
+        return NibPlanes(words=plane, rows=rows, K=Cout)
+    if epi is not None:
+        alpha, beta = _check_bias(epi[0], Cout, dev), _check_bias(epi[1], Cout, dev)
+        ldb = packed_ld(Cout)
+        plane = torch.empty((M, ldb), dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv2d_implicit_taps_bits", *head, _p(alpha), _p(beta), _p(plane), I(ldb), I(Cout), _stream(dev))
+        return BitPlanes(sign=plane, rows=M, K=Cout)
+    y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.call("qt_conv2d_implicit_taps", *head, _p(y), I(Cout), I(Cout), _stream(dev))
+    return y
+
+
+def conv2d_nib_taps(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, tap_rho: torch.Tensor, bias=None, stride=1,
+                    padding=0, dilation=1, epi=None):
+    """XNORConv2d on packed operands (functions/xnor_connect.py:145 for +-1 activations): NHWC nibble pixel plane of the
+    activation (row stride pixel_ld_nib_taps(C)) x nibble plane of sign(W) (pack_conv_weight_nib(w, "sign", cw = that stride)),
+    alpha per tap through ``tap_rho`` (TapScales.fwd).  Returns the NHWC result [N*Ho*Wo, Cout] fp32 (or the epilogue's
+    planes), None when the shape is outside the kernel's limits."""
+    N, C, H, W = (int(v) for v in in_shape)
+    kh, kw = kernel_hw
+    Cw = pixels.ld
+    if pixels.rows != N * H * W or int(pixels.words.shape[0]) < N * H * W:
+        raise ValueError(f"pixel plane holds {pixels.rows} pixels, in_shape {tuple(in_shape)} needs {N * H * W}")
+    if Cw % 8:
+        raise ValueError("per-tap scaled convs take pixel planes with whole 32-byte taps (pixel_ld_nib_taps)")
+    if wplanes.K != kh * kw * Cw * 8:
+        raise ValueError("weight planes do not match the activation's channel packing")
+    Cout = wplanes.rows
+    bias = _check_bias(bias, Cout, pixels.device)
+    return _conv_taps(0, pixels.words, N, H, W, Cw, kh, kw, (_pairs(stride), _pairs(padding), _pairs(dilation)), wplanes.words,
+                      wplanes.ld, bias, 1.0, None, tap_rho, Cout, epi=epi)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1825,6 +1946,32 @@ def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.
     shape_t = torch.empty((Cin, Cout, kh, kw), dtype=torch.float32, device="meta")
     y2 = float_conv2d(g, shape_t, kind, None, 1, (kh - 1 - ph, kw - 1 - pw), 1, weight_triples=wt, out_scale=out_scale,
                       out_scale_dev=out_scale_dev)
+    return y2.view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+def conv2d_grad_input_taps(input_shape, weight: torch.Tensor, grad_output: torch.Tensor, tap_rho_flipped: torch.Tensor, stride,
+                           padding, dilation):
+    """grad wrt the input of an XNOR-Net conv, conv2d(x, sign(W) * alpha[1, 1, kh, kw]) (functions/xnor_connect.py:154-155):
+    the two-term fp16 split of the gradient against the flipped, transposed sign(W) on the fp16 matrix cores, alpha applied per
+    (flipped) tap on the accumulators (qt_conv2d_implicit_taps, elem 3; ``tap_rho_flipped`` = TapScales.bwd).  Stride 1,
+    un-dilated, padding <= k - 1, Cout % 8 == 0 (a tap of the pair plane = whole 32-byte k-steps); None otherwise."""
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    if (sh, sw) != (1, 1) or (dh, dw) != (1, 1) or ph > kh - 1 or pw > kw - 1 or Cout % 8:
+        return None
+    N, C, H, W = (int(v) for v in input_shape)
+    g = _require(grad_output, "grad_output")
+    _, _, Ho, Wo = (int(v) for v in g.shape)
+    wt = pack_conv_weight_bf16x3(weight.detach(), "sign", terms=2, transpose_flip=True)        # [Cin, kh*kw*Cb/2] fp16 pairs
+    Cb = triple_ld_bytes(Cout, 16, 2)
+    nhwc = g.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    px = split_bf16x3(nhwc.view(N * Ho * Wo, Cout), ld_bytes=Cb, terms=2)
+    y2 = _conv_taps(3, px.data, N, Ho, Wo, Cb // 4, kh, kw, ((1, 1), (kh - 1 - ph, kw - 1 - pw), (1, 1)), wt.data, wt.ld_words,
+                    None, 1.0, px.scale[0:1], tap_rho_flipped, Cin)
+    if y2 is None:
+        return None
     return y2.view(N, H, W, C).permute(0, 3, 1, 2)
 
 

@@ -1,0 +1,295 @@
+"""Round-4 GPU parity: the XNOR-Net family on its own kernels (VERDICT r3 "next" item 1).
+
+  * qt_conv2d_implicit_taps — conv2d(x, sign(W) * alpha[1, 1, kh, kw]) for +-1 activations as ONE fp4 matrix-core pass with the taps'
+    alphas applied on the accumulators (functions/xnor_connect.py:135-146, layers/xnor_layers.py:36-69):
+      - bit-exact against the digests of the REFERENCE layer on power-of-two-per-tap weights at the AlexNet conv2 / conv3 / conv5
+        shapes (tests/golden/make_golden_r4.py G16): tap order, tap boundaries, padding, factor table;
+      - <= 1e-5 (normalised) against the fp64 evaluation of the reference FUNCTIONS, forward and backward (G17);
+      - <= 1e-5 against the oracle at ragged shapes, every tile configuration, taps whose alpha is 0;
+  * the backward of XNORConv2d / XNORDense on the matrix-core routes, no dense-library call (_fused.LIBRARY_PATHS);
+  * qt_xnor_tap_prep_f32 (alpha + Horner tables) against numpy."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, norm_err
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import _lib, ops, synth  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic, _fused, xnor_connect  # noqa: E402
+from pytorch_quantize_impls_amd.layers import XNORConv2d, LinearXNOR  # noqa: E402
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def g4():
+    return np.load(os.path.join(GOLDEN_DIR, "golden_r4_v1.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def h4():
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes_r4.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.fixture()
+def all_shapes_on_the_routes():
+    old = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    yield
+    _fused.BWD_MFMA_MIN_MACS = old
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+def t32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+# ---- alpha + Horner tables ---------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("Cout,Cin,k", [(576, 192, 5), (1152, 576, 3), (7, 3, 11), (5, 4, 1), (64, 64, 7), (3, 2, 32)])
+def test_tap_prep_vs_numpy(dev, Cout, Cin, k):
+    w = synth.normal(Cout + k, (Cout, Cin, k, k), 0.1)
+    if k >= 3:
+        w[:, :, 1, 1] = 0.0                      # a tap whose alpha is 0: inherits its predecessor's scale
+        w[:, :, 0, 0] = 0.0                      # ... a leading one: the first non-zero scale
+    ts = ops.xnor_tap_prep(t32(w, dev))
+    T = k * k
+    alpha = np.abs(w.astype(np.float64)).mean((0, 1)).reshape(-1)
+    assert np.abs(n(ts.alpha).astype(np.float64) - alpha).max() <= 3e-7 * alpha.max()
+    a32 = n(ts.alpha)
+    for tab, order in ((n(ts.fwd), a32), (n(ts.bwd), a32[::-1])):
+        nz = order[order != 0]
+        eff, prev = [], (nz[0] if nz.size else np.float32(1))
+        for v in order:
+            prev = v if v != 0 else prev
+            eff.append(prev)
+        eff = np.asarray(eff, dtype=np.float32)
+        assert tab.shape == (T + 1,) and tab[0] == 1.0 and tab[T] == eff[-1]
+        assert np.array_equal(tab[1:T], eff[:-1] / eff[1:])
+    # eval mode: the scales are given (the weight already holds sign(W) * alpha)
+    ts2 = ops.xnor_tap_prep(alpha=ts.alpha)
+    assert torch.equal(ts2.tables, ts.tables)
+
+
+# ---- the reference layer's digests (bit-exact) ---------------------------------------------------------------------------------------
+
+def _pow2_weight(c):
+    s = synth.pm1(c["w_seed"], (c["Cout"], c["Cin"], c["k"], c["k"]))
+    return (s * np.exp2(np.asarray(c["tap_exponents"], dtype=np.float32))[None, None]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["xnorconv_conv2", "xnorconv_conv3", "xnorconv_conv5", "xnorconv_odd_96_72_9_s2"])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_xnor_conv_layer_reference_digest(dev, h4, name, channels_last, mode):
+    c = h4[name]
+    x = t32(synth.pm1(c["x_seed"], (c["B"], c["Cin"], c["H"], c["H"])), dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    conv = XNORConv2d(c["Cin"], c["Cout"], c["k"], stride=c["stride"], padding=c["pad"]).to(dev)
+    conv.weight.data.copy_(t32(_pow2_weight(c), dev))
+    conv.bias.data.zero_()
+    if mode == "eval":
+        conv.eval()
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        y = conv(BinaryConnectDeterministic.apply(x))
+    assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
+    a = np.ascontiguousarray(n(y.contiguous()), dtype=np.float32)
+    assert a.shape[1] == c["Cout"]
+    assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32"], (float(a.astype(np.float64).sum()), c["sum"])
+
+
+# ---- the reference functions in fp64: forward + backward ----------------------------------------------------------------------------
+
+def _sampled_err(g4, name, key, full):
+    want = g4[f"g17_{name}_{key}"]
+    mx, st = g4[f"g17_{name}_{key}_max"]
+    got = n(full.contiguous()).astype(np.float64).reshape(-1)[::int(st)]
+    assert got.shape == want.shape
+    return float(np.abs(got - want).max() / mx)
+
+
+@pytest.mark.parametrize("name", ["conv2", "conv3", "conv5", "odd_96_72_9_s2"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_xnor_conv_function_vs_reference_fp64(dev, g4, name, channels_last, all_shapes_on_the_routes):
+    B, Cin, Cout, H, k, s, p, seed = (int(v) for v in g4[f"g17_{name}_geom"])
+    x = t32(synth.pm1(seed, (B, Cin, H, H)), dev)
+    w = synth.normal(seed + 1, (Cout, Cin, k, k), 0.05)
+    w[0, 0, 0, 0] = 0.0
+    w = t32(w, dev).requires_grad_(True)
+    b = t32(synth.normal(seed + 2, (Cout,)), dev).requires_grad_(True)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    xs = BinaryConnectDeterministic.apply(x.requires_grad_(True))
+    xs.retain_grad()
+    op = xnor_connect.XNORConv2d([0, 1], False, s, p, 1, 1)
+    _fused.LIBRARY_PATHS.clear()
+    before = dict(_lib.call_counts)
+    y = op.apply(xs, w, b)
+    assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
+    assert _sampled_err(g4, name, "y", y) <= TOL
+    go = t32(synth.normal(seed + 3, tuple(y.shape)), dev)
+    if channels_last:
+        go = go.contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    assert _sampled_err(g4, name, "gw", w.grad) <= TOL
+    assert _sampled_err(g4, name, "gb", b.grad) <= TOL
+    assert _sampled_err(g4, name, "gx", xs.grad) <= TOL
+    if s == 1:          # strided grad_input has no per-tap route (only the real-valued first layer is strided in the reference's models)
+        assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+        assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 2
+
+
+@pytest.mark.parametrize("name", ["fc1", "fc3", "fc_odd"])
+def test_xnor_dense_function_vs_reference_fp64(dev, g4, name, all_shapes_on_the_routes):
+    B, K, N, seed = (int(v) for v in g4[f"g17_{name}_geom"])
+    x = t32(synth.pm1(seed, (B, K)), dev)
+    w = synth.normal(seed + 1, (N, K), 0.05)
+    w[0, 0] = 0.0
+    w = t32(w, dev).requires_grad_(True)
+    b = t32(synth.normal(seed + 2, (N,)), dev).requires_grad_(True)
+    xs = BinaryConnectDeterministic.apply(x.requires_grad_(True))
+    xs.retain_grad()
+    _fused.LIBRARY_PATHS.clear()
+    y = xnor_connect.XNORDense([0, 1]).apply(xs, w, b)
+    assert _sampled_err(g4, name, "y", y) <= TOL
+    y.backward(t32(synth.normal(seed + 3, tuple(y.shape)), dev))
+    for key, t in (("gx", xs.grad), ("gw", w.grad), ("gb", b.grad)):
+        assert _sampled_err(g4, name, key, t) <= TOL, key
+    assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+
+
+# ---- ragged shapes / every tile configuration / zero taps, against the oracle ------------------------------------------------------
+
+TAPS_SHAPES = [
+    # N, Cin, Cout, H, W, k, s, p          tile the dispatch takes (csrc/conv_taps.hip)
+    (2, 64, 64, 9, 11, 3, 1, 1),            # 64-wide, padded: Conv64
+    (2, 64, 64, 12, 10, 3, 1, 0),           # ... un-padded: ConvV64
+    (3, 40, 128, 14, 14, 3, 1, 1),          # channels padded 40 -> 64; 128-wide
+    (2, 130, 200, 8, 9, 3, 1, 0),           # 130 -> 192 channels (3 k-steps per tap), 192-wide + ragged column tile, un-padded
+    (2, 192, 192, 13, 13, 5, 1, 2),         # 25 taps
+    (1, 64, 256, 30, 30, 1, 1, 0),          # one tap: no factor at all; 256 -> 128-wide tiles
+    (2, 128, 96, 10, 10, 7, 2, 3),          # 49 taps, stride 2
+    (1, 256, 512, 6, 6, 3, 1, 1),           # small M, long K: skinny tiles
+    (1, 512, 512, 4, 4, 3, 1, 0),           # ... un-padded: ConvVSkinny
+    (8, 256, 256, 8, 8, 3, 1, 0),           # M = 288 .. un-padded small-M rules
+    (70, 256, 384, 8, 8, 3, 1, 0),          # M = 2520
+    (2, 64, 72, 21, 5, 3, (2, 1), (1, 0)),  # anisotropic stride / padding
+    (2, 64, 64, 11, 11, 3, 1, 1, 2),        # dilation 2
+]
+
+
+@pytest.mark.parametrize("shape", TAPS_SHAPES)
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_xnor_conv_vs_oracle(dev, oracle, shape, with_bias):
+    N, Cin, Cout, H, W, k, s, p = shape[:8]
+    d = shape[8] if len(shape) > 8 else 1
+    seed = N * 1000 + Cin * 7 + Cout + k
+    x = synth.pm1(seed, (N, Cin, H, W))
+    w = synth.normal(seed + 1, (Cout, Cin, k, k), 0.3)
+    w[w == 0] = 0.1
+    if k >= 3:
+        w[:, :, 0, 1] = 0.0                    # a tap with alpha == 0 (all its weights zero)
+        w[1, 0, 2, 2] = 0.0                    # a lone zero weight: torch.sign keeps it at 0
+    b = synth.normal(seed + 2, (Cout,)) if with_bias else None
+    conv = XNORConv2d(Cin, Cout, k, stride=s, padding=p, dilation=d, bias=with_bias).to(dev)
+    conv.weight.data.copy_(t32(w, dev))
+    if with_bias:
+        conv.bias.data.copy_(t32(b, dev))
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        y = conv(BinaryConnectDeterministic.apply(t32(x, dev)))
+    assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
+    want = oracle.xnor_conv2d_forward(x, w, b, s, p, d)
+    assert norm_err(n(y), want) <= TOL
+
+
+def test_xnor_conv_untagged_pm1_input_is_detected(dev, oracle):
+    """+-1 activation WITHOUT a quantiser's tag (e.g. behind a MaxPool): detected on the device, same route."""
+    x = synth.pm1(5, (2, 64, 8, 8))
+    w = synth.normal(6, (64, 64, 3, 3), 0.2)
+    conv = XNORConv2d(64, 64, 3, padding=1, bias=False).to(dev)
+    conv.weight.data.copy_(t32(w, dev))
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        y = conv(t32(x, dev))
+        yr = conv(t32(x, dev) * 0.75)                   # a real-valued input: the six-term route
+    assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
+    assert norm_err(n(y), oracle.xnor_conv2d_forward(x, w, None, 1, 1)) <= TOL
+    assert norm_err(n(yr), oracle.xnor_conv2d_forward(x * 0.75, w, None, 1, 1)) <= TOL
+
+
+def test_xnor_layers_training_step_without_the_dense_library(dev, all_shapes_on_the_routes):
+    """conv -> flatten -> linear, one SGD-less step: every gradient against the fp64 evaluation of the same graph built from the
+    reference expressions, and no hipBLASLt / MIOpen call on the way."""
+    torch.manual_seed(3)
+    conv = XNORConv2d(64, 64, 3, padding=1).to(dev)
+    fc = LinearXNOR(64 * 6 * 6, 24).to(dev)
+    x = torch.randn((4, 64, 6, 6), device=dev)
+    _fused.LIBRARY_PATHS.clear()
+    h = BinaryConnectDeterministic.apply(conv(BinaryConnectDeterministic.apply(x)))
+    y = fc(h.reshape(4, -1))
+    y.square().sum().backward()
+    assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
+
+    def ref():
+        cw, cb = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+        fw, fb = fc.weight.detach().double().requires_grad_(True), fc.bias.detach().double().requires_grad_(True)
+        xs = torch.where(x.double() < 0, -1.0, 1.0)
+        a = cw.abs().mean((0, 1), keepdim=True)
+        h0 = torch.nn.functional.conv2d(xs, _XnorW.apply(cw, a, 0), cb, padding=1)
+        hs = _Ste.apply(h0)
+        a2 = fw.abs().mean(0, keepdim=True)
+        yy = torch.nn.functional.linear(hs.reshape(4, -1), _XnorW.apply(fw, a2, 0), fb)
+        yy.square().sum().backward()
+        return yy, cw.grad, cb.grad, fw.grad, fb.grad
+
+    yy, gcw, gcb, gfw, gfb = ref()
+    assert norm_err(n(y), n(yy)) <= TOL
+    for got, want in ((conv.weight.grad, gcw), (conv.bias.grad, gcb), (fc.weight.grad, gfw), (fc.bias.grad, gfb)):
+        assert norm_err(n(got), n(want)) <= TOL
+
+
+class _XnorW(torch.autograd.Function):
+    """sign(W) * alpha with the reference's hand-written weight gradient (xnor_connect.py:126-127, 158-159)."""
+
+    @staticmethod
+    def forward(ctx, w, alpha, dim0):
+        ctx.save_for_backward(w, alpha)
+        ctx.dim0 = dim0
+        return torch.sign(w) * alpha
+
+    @staticmethod
+    def backward(ctx, g):
+        w, alpha = ctx.saved_tensors
+        sgn = torch.sign(w)
+        return alpha * g + sgn * torch.mean(g * sgn, ctx.dim0, keepdim=True), None, None
+
+
+class _Ste(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.where(x < 0, -1.0, 1.0).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * (x.abs() <= 1.001).to(g.dtype)
