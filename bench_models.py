@@ -58,6 +58,57 @@ class AlexNetBin(nn.Module):
         return self.classifieur(x)
 
 
+class AlexNetFloat(nn.Module):
+    """The AlexNetBin topology (models/Alexnet/Alexnet_Bin.py:12-54) written with plain nn.Conv2d / nn.Linear: the float network
+    the reference's converters take (utils/convertor.py:40-58 replace exactly these two classes)."""
+
+    def __init__(self, num_classes=10, coef=3):
+        super().__init__()
+        c = coef
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64 * c, kernel_size=11, stride=4, padding=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(64 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            nn.Conv2d(64 * c, 192 * c, kernel_size=5, padding=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(192 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            nn.Conv2d(192 * c, 384 * c, kernel_size=3, padding=1),
+            nn.BatchNorm2d(384 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            nn.Conv2d(384 * c, 256 * c, kernel_size=3, padding=1),
+            nn.BatchNorm2d(256 * c), nn.Hardtanh(inplace=True), BinaryConnect(stochastic=False),
+
+            nn.Conv2d(256 * c, 256, kernel_size=3, padding=1),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.BatchNorm2d(256), nn.Hardtanh(inplace=True),
+        )
+        self.classifieur = nn.Sequential(
+            BinaryConnect(stochastic=False), nn.Linear(256 * 6 * 6, 4096),
+            nn.BatchNorm1d(4096), nn.Hardtanh(inplace=True),
+            BinaryConnect(stochastic=False), nn.Linear(4096, 4096),
+            nn.BatchNorm1d(4096), nn.Hardtanh(inplace=True),
+            BinaryConnect(stochastic=False), nn.Linear(4096, num_classes),
+            nn.LogSoftmax(dim=1),
+        )
+
+    def forward(self, x):
+        x = self.features(x)
+        x = x.reshape(x.size(0), 256 * 6 * 6)
+        return self.classifieur(x)
+
+
+def alexnet_xnor(num_classes=10, coef=3):
+    """BASELINE config 3 in its XNOR-Net flavour: ``xnor_net_convert`` of the float topology — XNORConv2d(dim=[0, 1])
+    / LinearXNOR everywhere (utils/convertor.py:54-58; fresh layers, weights are not copied, like upstream).  The first layer
+    sees real pixels: its ``binary_input`` hint is set like AlexNetBin's."""
+    from pytorch_quantize_impls_amd.utils import xnor_net_convert
+    net = xnor_net_convert(AlexNetFloat(num_classes, coef))
+    net.features[0].binary_input = False
+    return net
+
+
 class FusedAlexNetBin(nn.Module):
     """Inference form of an (eval-mode) AlexNetBin (layers.FusedFeatureClassifier): every BinConv2d emits
     BatchNorm-threshold bits, MaxPool runs on bits, activations between binarised layers exist only as bit planes.

@@ -86,8 +86,12 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
 #define QT_TAPS(...) return launch_cfg<__VA_ARGS__>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi)
     // Tile widths: the in-place multiply needs the accumulators in VALU-addressable registers next to the fragments, so the
     // 144- / 128-register wave tiles of the un-scaled conv (384x192, 256x256) would spill; widest here: 256x192 (96 registers).
-    int tn = pick_tile_n(Cout);
-    if (tn == 256) tn = 128;
+    int tn = 192;
+    {
+        int64_t best = (Cout + 191) / 192 * 192;
+        for (int c : {128, 64})
+            if ((Cout + c - 1) / c * c < best) { tn = c; best = (Cout + c - 1) / c * c; }
+    }
     const int64_t tiles = ((M + 255) / 256) * ((Cout + tn - 1) / tn);
     const bool long_k = kwords * 4 >= 2048 && !(ldwp & 127);
     if (valid) {

@@ -42,7 +42,46 @@ __global__ __launch_bounds__(256) void sign_scale_kernel(const float* __restrict
     }
 }
 
+// LinearXNOR on a PACKED +-1 activation (eval-mode inference: the activation exists only as sign bits): the operand of the fp16
+// matrix-core GEMM is x[b, k] * alpha[k] = +-alpha[k] as a two-term fp16 pair — the (hi, lo) pair of alpha[k] / s, prepared once
+// per weight version, with both signs flipped where the bit says -1 (exact).  One thread = one 32-bit word of a bit-plane row ->
+// 32 pairs (128 bytes).
+__global__ __launch_bounds__(256) void bits_alpha_pairs_kernel(const uint32_t* __restrict__ bits, int64_t ldb,
+                                                               const uint32_t* __restrict__ apair, uint32_t* __restrict__ out,
+                                                               int64_t ldo_words, int64_t rows, int64_t K) {
+    const int64_t wpr = ldo_words / 32;            // 32-pair groups per output row (row stride is a multiple of 128 bytes)
+    const int64_t total = rows * wpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / wpr, g = i - r * wpr;
+        const uint32_t w = g < ldb ? bits[r * ldb + g] : 0u;
+        uint4* o = reinterpret_cast<uint4*>(out + r * ldo_words + g * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint32_t v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t k = g * 32 + q * 4 + e;
+                const uint32_t a = k < K ? apair[k] : 0u;                       // (hi | lo << 16) of alpha[k] / s
+                v[e] = ((w >> (q * 4 + e)) & 1u) ? (a ^ 0x80008000u) : a;       // -1: flip both sign bits
+            }
+            o[q] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out,
+                                         int64_t ld_bytes, int64_t rows, int64_t K, qt_stream_t stream) {
+    if (rows < 0 || K < 0) return QT_ERR_INVALID_ARG;
+    if (rows == 0 || K == 0) return QT_OK;
+    if (!bits || !alpha_pairs || !out || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
+    if ((ld_bytes & 127) || ld_bytes < 4 * K || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid((rows * (ld_bytes / 128) + 255) / 256);
+    hipLaunchKernelGGL(bits_alpha_pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, ldb, alpha_pairs, out,
+                       ld_bytes / 4, rows, K);
+    return qt_check_launch();
+}
 
 extern "C" int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int64_t ldq,
                                   int64_t R, int64_t C, qt_stream_t stream) {

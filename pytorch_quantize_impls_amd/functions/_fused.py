@@ -425,6 +425,8 @@ def packed_conv2d(layer, act, kind: str, epi=None):
         raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
     if layer.groups != 1 or layer.padding_mode != "zeros":
         raise ValueError("packed conv needs groups == 1 and zero padding")
+    if kind == "xnor":
+        return packed_xnor_conv2d(layer, act, epi)
     N, C, H, W = act.shape
     wp = layer._eval_planes(lambda _w2: ops.pack_conv_weight_nib(layer.weight.detach(), kind), key="conv_nib")
     kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
@@ -452,6 +454,57 @@ def packed_conv2d(layer, act, kind: str, epi=None):
     if epi is not None:
         return y2, (N, int(layer.weight.shape[0]), Ho, Wo)
     return y2.view(N, Ho, Wo, layer.weight.shape[0]).permute(0, 3, 1, 2)
+
+
+def packed_xnor_conv2d(layer, act, epi=None):
+    """Eval-mode XNORConv2d on a PackedActivation: the per-tap scaled fp4 conv (ops.conv2d_nib_taps) on the activation's nibble
+    plane — the producer's own (zero halo = this conv's padding, un-padded kernel) when its pixel stride is whole 32-byte taps,
+    else expanded from the bit planes with the padding made physical.  Same returns as packed_conv2d."""
+    N, C, H, W = act.shape
+    wp, taps = layer._taps_planes()
+    kh, kw = int(layer.weight.shape[2]), int(layer.weight.shape[3])
+    ph, pw = ops._pairs(layer.padding)
+    Cw = ops.pixel_ld_nib_taps(C)
+    if act.nib is not None:
+        if act.halo != (ph, pw):
+            raise ValueError(f"activation carries a {act.halo} halo, this conv pads {(ph, pw)}: re-link the fused modules")
+        px = act.nib
+        if px.ld != Cw:       # channels not a multiple of 64: widen the pixel stride to whole 32-byte taps (zero nibbles)
+            wide = torch.zeros((int(px.words.shape[0]), Cw), dtype=torch.int32, device=px.device)
+            wide[:, :px.ld] = px.words
+            px = ops.NibPlanes(words=wide, rows=px.rows, K=px.K)
+    else:
+        px = ops.bits_to_nib_pad(act.planes, N, H, W, (ph, pw), ld=Cw)
+    y2 = ops.conv2d_nib_taps(px, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), taps.fwd, layer.bias, layer.stride, 0,
+                             layer.dilation, epi=epi)
+    if y2 is None:
+        raise ValueError("XNOR conv outside the per-tap kernel's limits")
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, layer.stride, layer.padding, layer.dilation)
+    if epi is not None:
+        return y2, (N, int(layer.weight.shape[0]), Ho, Wo)
+    return y2.view(N, Ho, Wo, layer.weight.shape[0]).permute(0, 3, 1, 2)
+
+
+def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
+    """Eval-mode LinearXNOR on a PackedActivation (row planes): y = (x * alpha) . sign(W)^T + b (xnor_connect.py:112-115) with
+    x * alpha = +-alpha[k] built from the sign bits as two-term fp16 pairs (qt_bits_alpha_pairs_f16x2) against the replicated
+    sign(W) on the fp16 matrix cores.  ``hwc``: see packed_linear (weight columns and alpha permuted alike)."""
+    if layer.training:
+        raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
+    N = layer.weight.shape[0]
+    K = act.planes.K
+    if K != layer.weight.shape[1]:
+        raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
+
+    def build(w2):
+        if hwc is not None:
+            from ..layers.fused import permute_fc_weight_hwc
+            w2 = permute_fc_weight_hwc(w2, *(int(v) for v in hwc))
+        _, alpha = ops.xnor_weight(w2.contiguous(), 1)                       # alpha[1, K] of the (already quantised) image
+        return ops.weight_bf16x3(w2, "sign", terms=2), ops.alpha_pairs(alpha.view(-1))
+    wt, ap = layer._eval_planes(build, key=("xnor_pairs",) + (tuple(int(v) for v in hwc) if hwc is not None else ()))
+    y = ops.bf16_gemm(ops.bits_alpha_pairs(act.planes, ap), wt, layer.bias)
+    return y.view(*act.shape[:-1], N)
 
 
 #: dispatch used by the layers' forward for PackedActivation inputs: [is_linear] -> function

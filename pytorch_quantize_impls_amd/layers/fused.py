@@ -421,12 +421,15 @@ class FusedConvPoolBnSign(torch.nn.Module):
         super().__init__()
         from .binary_layers import BinConv2d
         from .terner_layers import TerConv2d
+        from .xnor_layers import XNORConv2d
         if isinstance(conv, BinConv2d):
             self.kind = "binary"
         elif isinstance(conv, TerConv2d):
             self.kind = "ternary"
+        elif isinstance(conv, XNORConv2d) and conv._qt_can_defer:
+            self.kind = "xnor"           # per-tap scaled conv (real-valued accumulators: float-form threshold epilogue)
         else:
-            raise ValueError("FusedConvPoolBnSign fuses BinConv2d / TerConv2d only")
+            raise ValueError("FusedConvPoolBnSign fuses BinConv2d / TerConv2d / XNORConv2d(dim=[0, 1]) only")
         if conv.groups != 1 or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
             raise ValueError("only groups == 1, zero-padded convs can be fused")
         if not isinstance(bn, torch.nn.BatchNorm2d) or bn.num_features != conv.out_channels:
@@ -472,10 +475,11 @@ class FusedConvPoolBnSign(torch.nn.Module):
             # +-1 activations x +-1 / 0 weights: the accumulator is an exact integer, so BatchNorm + sign is one integer
             # threshold per channel (found once, by bisection on the kernel's own fp32 expression)
             bkey = None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version)
-            if INTEGER_THRESHOLDS and (self._thr is None or self._thr[0] != bkey or self._thr[1].device != dev):
+            int_thr = INTEGER_THRESHOLDS and self.kind != "xnor"
+            if int_thr and (self._thr is None or self._thr[0] != bkey or self._thr[1].device != dev):
                 kmax = conv.in_channels * conv.kernel_size[0] * conv.kernel_size[1]
                 self._thr = (bkey, ops.integer_thresholds(conv.bias, epi[0], epi[1], kmax))
-            thr = self._thr[1] if INTEGER_THRESHOLDS else None
+            thr = self._thr[1] if int_thr else None
             epi = (epi[0], epi[1], thr)
             if nib_out and not pooled:
                 epi = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo, thr=thr)
@@ -485,9 +489,15 @@ class FusedConvPoolBnSign(torch.nn.Module):
         else:
             if not (isinstance(x, torch.Tensor) and x.is_cuda):
                 raise TypeError("FusedConvPoolBnSign runs on a HIP device only (use the un-fused modules on CPU)")
-            wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
             planes = shape = None
-            if (DIRECT_FIRST_LAYER and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
+            if self.kind == "xnor":
+                planes, shape = self._xnor_real_input(x, epi, nib_out and not pooled)
+                wp = None
+            else:
+                wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
+            if planes is not None:
+                pass
+            elif (DIRECT_FIRST_LAYER and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
                     and (not nib_out or pooled or tuple(self.out_nib_halo) == (1, 1))
                     and ops.direct_first_layer_applicable(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride,
                                                           conv.padding, conv.dilation)):
@@ -522,6 +532,29 @@ class FusedConvPoolBnSign(torch.nn.Module):
         act = packed.PackedActivation(planes, (N, Cout, Ho, Wo))
         return act.flatten_hwc() if self.flatten_hwc else act
 
+
+    def _xnor_real_input(self, x, epi, nib_out: bool):
+        """XNORConv2d on a device tensor inside a fused stack: a +-1 tensor (tagged / detected) takes the per-tap scaled conv, a
+        real-valued one (the first layer) the real x real conv on six-term bf16 planes, both with the threshold epilogue."""
+        from ..functions import _fused
+        conv = self.conv
+        N, C, H, W = (int(v) for v in x.shape)
+        kh, kw = conv.kernel_size
+        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, conv.stride, conv.padding, conv.dilation)
+        shape = (N, conv.out_channels, Ho, Wo)
+        e2 = ops.NibEpilogue(epi[0], epi[1], self.out_nib_halo) if nib_out else (epi[0], epi[1])
+        known = True if packed.lookup(x, packed.NHWC) is not None else conv.binary_input
+        out = None
+        if known is not False:
+            out = _fused.xnor_conv2d_forward(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation,
+                                             binary_input=known, planes=conv._taps_planes(), epi=e2)
+        if out is not None:
+            return out[0], shape
+        wt = conv._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x6(conv.weight.detach()), key="conv_bf16x6")
+        y = ops.real_conv2d(x, conv.weight.detach(), conv.bias, conv.stride, conv.padding, conv.dilation, weight_planes=wt, epi=e2)
+        if y is None:
+            raise ValueError("XNOR conv outside the implicit kernel's limits")
+        return y, shape
 
     def _first_layer_d2s(self, x, affine):
         """Real-valued 3x3 / stride-1 / padding-1 first layer in its 2x2 output-blocked form (ops.d2s_first_layer_weight):

@@ -6,6 +6,7 @@ using the stored ``self.dim`` (documented in DESIGN.md)."""
 import torch
 
 from ..functions import xnor_connect, _fused
+from .. import lazy
 from .common import QLayer, EvalSwapMixin
 
 
@@ -28,7 +29,17 @@ class LinearXNOR(EvalSwapMixin, torch.nn.Linear, QLayer):
         # ``dim`` says, so the eval image uses the same reduction to stay consistent with it
         return xnor_connect.xnor_weight(self.weight, xnor_connect.DIM)[0]
 
+    def _weight_on_grid(self, w):
+        # sign(W) * alpha[1, K]: per input feature every entry is 0 or +-(the column's largest magnitude)
+        a = w.abs()
+        return ((a == 0) | (a == a.amax(0, keepdim=True))).all()
+
     def forward(self, input):
+        return lazy.linear_forward(self, input, "xnor")
+
+    def _forward_impl(self, input):
+        if isinstance(input, _fused.packed.PackedActivation):
+            return _fused.packed_xnor_linear(self, input)
         return self.lin_op.apply(input, self.weight, self.bias)
 
 
@@ -50,6 +61,7 @@ class XNORConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         # upstream hard-codes quant_input=False here (xnor_layers.py:49); reproduced
         self.conv_op = xnor_connect.XNORConv2d(dim, False, self.stride, self.padding,
                                                self.dilation, self.groups)
+        self.binary_input = None        # like BinConv2d: None = detect +-1 activations, True / False = the caller's word
 
     def _quantized_weight_for_eval(self):
         return xnor_connect.xnor_weight(self.weight, self.dim)[0]
@@ -70,7 +82,18 @@ class XNORConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         return self._eval_planes(lambda _w2: (ops.pack_conv_weight_nib(self.weight.detach(), "sign", cw=cw),
                                               ops.xnor_tap_prep(self.weight)), key="conv_taps")
 
+    @property
+    def _qt_can_defer(self) -> bool:
+        """The fused / deferred inference chain runs the per-tap scaled conv: one alpha per filter tap (dim = [0, 1])."""
+        d = self.dim
+        return not isinstance(d, int) and sorted(int(v) for v in d) == [0, 1]
+
     def forward(self, input):
+        return lazy.conv_forward(self, input, "xnor")
+
+    def _forward_impl(self, input):
+        if isinstance(input, _fused.packed.PackedActivation):
+            return _fused.packed_xnor_conv2d(self, input)
         if (not self.training and not torch.is_grad_enabled()
                 and _fused.xnor_conv_fast_applicable(input, self.weight, self.dim, self.groups, self.padding)
                 and self.padding_mode == "zeros"):

@@ -708,7 +708,7 @@ def _untracked(*tensors) -> bool:
 
 def _conv_can_defer(layer, input) -> bool:
     if layer.training or not _no_autograd(layer) or layer.groups != 1 or layer.padding_mode != "zeros" \
-            or isinstance(layer.padding, str):
+            or isinstance(layer.padding, str) or not getattr(layer, "_qt_can_defer", True):
         return False
     w = layer.weight
     if not w.is_cuda or w.dtype != torch.float32:
@@ -819,6 +819,8 @@ def linear_forward(layer, input, kind: str):
             act = n.force()
             if act is not None:
                 from .functions import _fused
+                if kind == "xnor":
+                    return _fused.packed_xnor_linear(layer, act, hwc=n.chw)
                 return _fused.packed_linear(layer, act, kind, hwc=n.chw)
         input = n.materialise()
     return layer._forward_impl(input)

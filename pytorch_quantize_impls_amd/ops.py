@@ -1408,6 +1408,26 @@ def conv2d_nib_taps(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, 
                       wplanes.ld, bias, 1.0, None, tap_rho, Cout, epi=epi)
 
 
+def alpha_pairs(alpha: torch.Tensor) -> "TriplePlanes":
+    """Two-term fp16 pair image of a per-feature scale row alpha[K] (LinearXNOR, xnor_connect.py:112): TriplePlanes [1, K] with
+    its power-of-two scale, the table qt_bits_alpha_pairs_f16x2 reads."""
+    a = _require(alpha.detach(), "alpha").contiguous().view(1, -1)
+    return split_bf16x3(a, terms=2)
+
+
+def bits_alpha_pairs(planes: BitPlanes, apairs: "TriplePlanes") -> "TriplePlanes":
+    """fp16 pair plane of x[b, k] * alpha[k] for a packed +-1 activation (row bit planes): the pairs of alpha with the
+    activation's signs (qt_bits_alpha_pairs_f16x2)."""
+    if planes.mask is not None or planes.K != apairs.K:
+        raise ValueError("bits_alpha_pairs takes sign-only row planes and the pair image of a [K] scale row")
+    ld = triple_ld_bytes(planes.K, terms=2)
+    out = torch.empty((planes.rows, ld // 2), dtype=torch.int16, device=planes.device)
+    with _on(planes.device):
+        _lib.call("qt_bits_alpha_pairs_f16x2", _p(planes.sign), int(planes.ld), _p(apairs.data), _p(out), int(ld),
+                  int(planes.rows), int(planes.K), _stream(planes.device))
+    return TriplePlanes(data=out, rows=planes.rows, K=planes.K, terms=2, scale=apairs.scale)
+
+
 # ----------------------------------------------------------------------------------------------
 # real-valued activation x quantised weight: exact bf16 triples + bf16 MFMA GEMM
 # ----------------------------------------------------------------------------------------------
@@ -1603,7 +1623,7 @@ def pack_conv_weight_bf16x6(weight: torch.Tensor) -> TriplePlanes:
 
 
 def real_conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=1, padding=0, dilation=1,
-                weight_planes: Optional[TriplePlanes] = None) -> Optional[torch.Tensor]:
+                weight_planes: Optional[TriplePlanes] = None, epi=None) -> Optional[torch.Tensor]:
     """conv2d(x, weight) for REAL x and REAL weight (groups = 1, zero padding) as an implicit GEMM over six-term
     planes on the bf16 matrix cores.  Returns the NHWC result [N*Ho*Wo, Cout], or None if the shape is outside the
     implicit kernel's limits (caller falls back to the dense library)."""
@@ -1619,7 +1639,7 @@ def real_conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=1, padd
     wt = weight_planes if weight_planes is not None else pack_conv_weight_bf16x6(weight)
     bias = _check_bias(bias, Cout, x.device)
     return _conv_implicit(2, px.data, N, H, W, Cb // 4, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, wt.ld_words,
-                          bias, 1.0, None, Cout)
+                          bias, 1.0, None, Cout, epi=epi)
 
 
 def float_linear(x: torch.Tensor, weight: torch.Tensor, kind: str, bias=None, alpha=None,
