@@ -109,9 +109,9 @@ def test_xnor_conv_layer_reference_digest(dev, h4, name, channels_last, mode):
         conv.eval()
     before = dict(_lib.call_counts)
     with torch.no_grad():
-        y = conv(BinaryConnectDeterministic.apply(x))
+        y = conv(BinaryConnectDeterministic.apply(x))              # (eval mode: a deferred activation until it is used)
+        a = np.ascontiguousarray(n(y.contiguous()), dtype=np.float32)
     assert _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
-    a = np.ascontiguousarray(n(y.contiguous()), dtype=np.float32)
     assert a.shape[1] == c["Cout"]
     assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32"], (float(a.astype(np.float64).sum()), c["sum"])
 
@@ -351,8 +351,8 @@ def test_xnor_alexnet_eager_graph_vs_the_oracle_chain(dev, oracle):
         h.remove()
     assert len(seen) == 8
     for mod, xin, out in seen:
-        w = n(mod.weight.org if hasattr(mod.weight, "org") else mod.weight)       # the real weight (eval mode holds the image)
-        b = n(mod.bias)
+        w = n(mod.weight)            # eval mode: the quantised image, which the op quantises again like upstream (a fixed point
+        b = n(mod.bias)              # unless a weight is exactly zero)
         if isinstance(mod, XNORConv2d):
             want = oracle.xnor_conv2d_forward(n(xin.contiguous()), w, b, mod.stride, mod.padding, mod.dilation)
         else:
@@ -375,5 +375,7 @@ def test_linear_xnor_on_packed_bits_vs_oracle(dev, oracle, B, K, N):
     with torch.no_grad():
         y = lin(packed.PackedActivation(planes, (B, K)))
         y2 = lin(BinaryConnectDeterministic.apply(t32(x, dev)))
-    want = oracle.xnor_dense_forward(x, w, b)
+    # eval mode: the weight holds sign(W) * alpha and the op quantises it AGAIN, like upstream (layers/xnor_layers.py:24-33 +
+    # xnor_connect.py:112): a column with an exact zero gets alpha * (N - 1) / N the second time
+    want = oracle.xnor_dense_forward(x, oracle.xnor_dense_weight(w), b)
     assert norm_err(n(y), want) <= TOL and norm_err(n(y2), want) <= TOL
