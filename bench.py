@@ -466,6 +466,7 @@ def bench_alexnet(args, dev, dist, world, rank):
                                    "ms_per_forward": elr / args.alexnet_iters * 1e3,
                                    "same_argmax_as_module_by_module": bool(torch.equal(yr.argmax(1), ye.argmax(1))),
                                    "what": "oracle/torch_port.sequential_forward: the reference's eval-mode ops in torch on the device"}
+    out["xnor_flavour"] = bench_alexnet_xnor(args, dev, world, timed, x, out)
     # small-batch serving: the un-modified module graph at batch 1 / 8 / 32, eager (host-bound: ~25 Python-driven launches)
     # and replayed as a hipGraph captured from the same model (utils.graphed; per-rank latencies, no aggregation)
     if not args.no_extras:
@@ -522,6 +523,51 @@ def bench_alexnet(args, dev, dist, world, rank):
     return out
 
 
+def bench_alexnet_xnor(args, dev, world, timed, x, bin_out):
+    """The XNOR-Net flavour BASELINE config 3 is named after: utils.xnor_net_convert of the same topology —
+    XNORConv2d(dim = [0, 1]) / LinearXNOR (layers/xnor_layers.py, functions/xnor_connect.py:93-169).  Behind a BinaryConnect every
+    conv is  sum_taps alpha[i, j] * (integer dot over Cin): one fp4 matrix-core pass with the taps' alphas applied on the
+    accumulators (csrc/conv_taps.hip); the first layer (real pixels x real sign(W) * alpha) runs on six-term bf16 planes."""
+    import bench_models
+    from pytorch_quantize_impls_amd import lazy
+    from pytorch_quantize_impls_amd.layers import XNORConv2d, LinearXNOR, FusedFeatureClassifier
+    from pytorch_quantize_impls_amd.functions import _fused
+    B = args.alexnet_batch
+    torch.manual_seed(4321)
+    xm = bench_models.alexnet_xnor()
+    for mod in xm.modules():            # the converter hands out fresh layers: give them weights of a trained-looking scale
+        if isinstance(mod, (XNORConv2d, LinearXNOR)):
+            mod.weight.data.normal_(0, 0.05)
+            mod.bias.data.zero_()
+    bench_models.randomize_bn(xm)
+    xm = xm.to(dev).to(memory_format=torch.channels_last).eval()
+    before = dict(_fused.LIBRARY_PATHS)
+    lazy.STATS.clear()
+    el, y = timed(xm)
+    stats = dict(lazy.STATS)
+    iters = args.alexnet_iters
+    out = {"what": bench_alexnet_xnor.__doc__.split("\n")[0],
+           "images_per_s": world * B * iters / el, "ms_per_forward": el / iters * 1e3, "batch_per_gpu": B,
+           "mode": "eval, channels_last, the un-modified module graph (deferred activations), best of 3 runs",
+           "deferred_convs_per_forward": stats.get("deferred", 0) / max(1, 3 + 3 * iters), "materialised": stats.get("materialised", 0),
+           "finite": bool(torch.isfinite(y).all()),
+           "vs_binarynet_flavour": (el / iters * 1e3) / bin_out["ms_per_forward"]}
+    with lazy.eager():
+        ele, ye = timed(xm)
+    out["module_by_module_eager"] = {"images_per_s": world * B * iters / ele, "ms_per_forward": ele / iters * 1e3,
+                                     "same_logits_as_deferred": bool(torch.equal(ye, y))}
+    fused = FusedFeatureClassifier(xm.features, xm.classifieur, (256, 6, 6), fold="device")
+    elf, yf = timed(fused)
+    out["fused"] = {"images_per_s": world * B * iters / elf, "ms_per_forward": elf / iters * 1e3,
+                    "same_logits_as_module_graph": bool(torch.equal(yf, y)),
+                    "vs_binarynet_flavour_fused": (elf / iters * 1e3) / bin_out["fused"]["ms_per_forward"]}
+    out["roofline"] = alexnet_roofline(xm, fused, x, B)
+    out["dense_library_calls"] = {k: v - before.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != before.get(k, 0)}
+    out["parity"] = ("tests/test_gpu_r4.py: reference digests (power-of-two-per-tap weights, bit-exact), fp64 vectors of the reference "
+                     "functions forward + backward <= 1e-5, deferred graph == module-by-module graph (torch.equal)")
+    return out
+
+
 BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA (MI355X_MICROARCH.md); fp16 has the same rate
 
 
@@ -532,14 +578,16 @@ def alexnet_roofline(model, fused, x, B):
     block's contraction runs in (conv1: real pixels, exact bf16 split -> bf16 peak; the other blocks: fp4); bytes = what the
     packed path moves algorithmically (input plane + packed weights + output bits), against 8 TB/s.  The floor of the whole
     forward = sum of ops / peak over the blocks; every leg of the 'alexnet' object is given as a fraction of it."""
-    from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
+    from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin, XNORConv2d, LinearXNOR
     from pytorch_quantize_impls_amd.layers.fused import FusedConvPoolBnSign
-    blocks = list(fused.net.features.children()) + list(fused.net.classifier.children())
+    BinConv2d, LinearBin = (BinConv2d, XNORConv2d), (LinearBin, LinearXNOR)        # both flavours of config 3
+    net = fused.net if hasattr(fused, "net") else fused
+    blocks = list(net.features.children()) + list(net.classifier.children())
     rows, floor_ms = [], 0.0
     with torch.no_grad():
         act = x
         i = 0
-        feats = list(fused.net.features.children())
+        feats = list(net.features.children())
         for bi, blk in enumerate(blocks):
             if bi == len(feats):
                 act = act.flatten_hwc()
@@ -917,6 +965,32 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "gradient_parity": "tests/test_gpu_r3.py::test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence and "
                                "::test_alexnet_training_step_with_the_fused_training_chain (<= 1e-5 normalised vs fp64 on the CPU)"}
         del mt, xt
+        # the XNOR-Net flavour in training mode: per-tap scaled forward, grad_input on the flipped taps, grad_weight on the +-1
+        # weight-gradient routes + the XNOR-Net combination (functions/xnor_connect.py:149-168); never takes the line down
+        try:
+            from pytorch_quantize_impls_amd.layers import XNORConv2d as _XC, LinearXNOR as _XL
+            torch.manual_seed(0)
+            mx = bench_models.alexnet_xnor()
+            for mod in mx.modules():
+                if isinstance(mod, (_XC, _XL)):
+                    mod.weight.data.normal_(0, 0.05)
+                    mod.bias.data.zero_()
+            mx = mx.to(dev).to(memory_format=torch.channels_last).train()
+            xt = torch.randn(Bt, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+            before = dict(_fused_library_paths())
+            t_x, loss_x = bts.step_time(mx, mx, xt, tt)
+            lib_x = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
+            out["n2_training_step_alexnet_xnor"] = {
+                "workload": f"XNOR-Net AlexNet (xnor_net_convert of the config-3 topology) 3x224x224 batch {Bt}, training mode, forward + "
+                            "backward (nll loss), channels_last, un-modified module graph",
+                "ms_per_step": t_x, "images_per_s": Bt / t_x * 1e3, "loss": loss_x,
+                "vs_binarynet_flavour_step": t_x / t_ours,
+                "dense_library_calls_in_the_steps": lib_x,
+                "gradient_parity": "tests/test_gpu_r4.py::test_xnor_conv_function_vs_reference_fp64 / test_xnor_dense_function_vs_reference_fp64 "
+                                   "(<= 1e-5 vs the fp64 evaluation of the reference functions)"}
+            del mx, xt
+        except Exception as exc:
+            out["n2_training_step_alexnet_xnor"] = {"error": f"{type(exc).__name__}: {exc}"}
         # C4's network in training mode (models/Resnet/Resnet_bin.py:63-97 shapes: 3 x 32 x 32): the module graph (DorefaConv2d
         # forward / backward on this backend, BatchNorm / relu / add are torch's and MIOpen's) and the form with every
         # BatchNorm [+ shortcut] -> ReLU -> quantiser run as one FusedTrainBnActQuant node (csrc/train_chain.hip)

@@ -612,6 +612,112 @@ def pm1_conv_grad_weight(input, go, weight_shape, stride, padding, dilation, bia
     return gw
 
 
+# ---- backward of the functional (fused Function) forms ------------------------------------------------------------------------------
+# BinaryDense / BinaryConv2d() / TernaryDense / TernaryConv2d() / QuantDense / QuantConv2d / XNORDense / XNORConv2d write their
+# backward by hand (functions/binary_connect.py:100-112,133-146, terner_connect.py:97-152, dorefa_connect.py:140-199,
+# xnor_connect.py:118-168): two contractions per layer.  These helpers are the ONLY place a dense-library call (hipBLASLt GEMM,
+# MIOpen backward conv) can come from, and every such call on a device tensor is counted in LIBRARY_PATHS — the functions
+# themselves contain no `.mm(` / `torch.nn.grad.` (tests/test_layers_cpu.py greps for it).
+
+def lib_mm(a: torch.Tensor, b: torch.Tensor, reason: str = "backward GEMM on the dense library") -> torch.Tensor:
+    """a @ b on the dense library: host tensors (the reference expression itself), non-fp32 device tensors; counted for device
+    tensors."""
+    note_library_path(a, reason)
+    return a.mm(b)
+
+
+def lib_conv2d_input(input_shape, weight_q, grad_output, stride, padding, dilation, groups, reason="conv grad_input outside the matrix-core route"):
+    note_library_path(grad_output, reason)
+    return torch.nn.grad.conv2d_input(input_shape, weight_q, grad_output, stride=stride, padding=padding, dilation=dilation,
+                                      groups=groups)
+
+
+def lib_conv2d_weight(input, weight_shape, grad_output, stride, padding, dilation, groups, reason="conv grad_weight outside the matrix-core route"):
+    note_library_path(grad_output, reason)
+    return torch.nn.grad.conv2d_weight(input, weight_shape, grad_output, stride=stride, padding=padding, dilation=dilation,
+                                       groups=groups)
+
+
+def _hip2d(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.numel() > 0 for t in ts)
+
+
+def known_pm1(input: torch.Tensor, weight: Optional[torch.Tensor], layout) -> bool:
+    """Is this device activation exactly +-1?  The tag of a quantiser (BinaryConnect) answers without a device check; otherwise
+    the detection the layers use (one read of the tensor; negative verdicts are remembered per weight)."""
+    if not (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and input.numel() > 0):
+        return False
+    if packed.lookup(input, layout) is not None:
+        return True
+    return bool(DETECT_BINARY_INPUT and detect_pm1(input, weight)[0])
+
+
+def real_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [M, J] @ b [J, K] for two REAL device matrices on the bf16 matrix cores (six-term planes, fp32-GEMM accuracy); host /
+    non-fp32 tensors: the library."""
+    if _hip2d(a, b):
+        return ops.real_linear(a.contiguous(), b.t().contiguous())
+    return lib_mm(a, b)
+
+
+def dense_grad_input(grad_output: torch.Tensor, weight_q: torch.Tensor, pm1: bool) -> torch.Tensor:
+    """g . weight_q for the quantised image the forward multiplied with: +-1 / 0 images (``pm1``) through the exact split of g
+    against the replicated image, real-valued images (DoReFa levels, sign(W) * E) through the six-term real x real route."""
+    if _hip2d(grad_output, weight_q):
+        g2 = grad_output.contiguous()
+        if pm1:
+            return ops.float_linear(g2, weight_q.t().contiguous(), "sign")
+        return ops.real_linear(g2, weight_q.t().contiguous())
+    return lib_mm(grad_output, weight_q)
+
+
+def dense_grad_weight(grad_output: torch.Tensor, input: torch.Tensor, x_is_pm1: bool) -> torch.Tensor:
+    """g^T . x: a +-1 activation is the exact operand (rows of g^T are output features: three exact bf16 terms); two real operands
+    take the six-term route."""
+    if _hip2d(grad_output, input):
+        gt = grad_output.t().contiguous()
+        if x_is_pm1:
+            return ops.float_linear(gt, input.t().contiguous(), "sign", terms=3)
+        return ops.real_linear(gt, input.t().contiguous())
+    return lib_mm(grad_output.t(), input)
+
+
+def conv_grad_input(input_shape, weight_q, grad_output, stride, padding, dilation, groups, kind="raw", out_scale=1.0,
+                    out_scale_dev=None):
+    """grad wrt the input of conv2d(x, weight_q) for an image that is exact in fp16 / bf16 (``kind`` "sign" / "binary" /
+    "ternary": +-1 / 0; "raw": small integers or multiples of 1/2, the caller scales) on ops.conv2d_grad_input_q; anything else
+    (groups, dilation, a real-valued image) on the library, counted."""
+    go = _dense(grad_output)
+    if (BWD_CONV_MFMA and kind is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
+            and not isinstance(padding, str) and go.numel() > 0):
+        gx = ops.conv2d_grad_input_q(input_shape, weight_q, go, stride, padding, dilation, kind=kind, out_scale=out_scale,
+                                     out_scale_dev=out_scale_dev)
+        if gx is not None:
+            return gx
+    wq = weight_q
+    if kind in ("binary", "ternary"):
+        wq = quantize_weight_f32(weight_q, kind)
+    if out_scale_dev is not None or out_scale != 1.0:
+        wq = wq * (float(out_scale) if out_scale_dev is None else out_scale_dev * float(out_scale))
+    return lib_conv2d_input(input_shape, wq, grad_output, stride, padding, dilation, groups)
+
+
+def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation, groups, x_is_pm1: bool, bias_by_product=None):
+    """UN-masked grad wrt the weight of conv2d(x, .): +-1 activations on the weight-gradient routes, a real-valued image with few
+    channels (first layers) through the space-to-depth form; anything else on the library, counted."""
+    go = _dense(grad_output)
+    if (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+            and go.numel() > 0 and input.dtype == torch.float32):
+        gw = None
+        if x_is_pm1:
+            gw = pm1_conv_grad_weight(input, go, weight_shape, stride, padding, dilation, bias_by_product)
+        elif ops.wgrad_s2d_applicable(input.shape, weight_shape[2:], stride, dilation):
+            gw = ops.conv2d_grad_weight_s2d(input, go, weight_shape, stride, padding, weight=None, bias_grad=bias_by_product)
+        if gw is not None:
+            return gw
+    return lib_conv2d_weight(input, weight_shape, grad_output, stride, padding, dilation, groups)
+
+
 # ---- XNOR-Net family (functions/xnor_connect.py:93-169, layers/xnor_layers.py) ------------------------------------------------------
 
 def xnor_conv_fast_applicable(input, weight, dim, groups, padding) -> bool:
@@ -858,21 +964,19 @@ class DorefaW1LinearFn(torch.autograd.Function):
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         x2 = input.reshape(-1, input.shape[-1])
         grad_input = grad_weight = grad_bias = None
-        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
+        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
             sgn = quantize_weight_f32(weight, "binary")
             E = weight.abs().mean()
             if big:
                 grad_input = (ops.float_linear(g2.contiguous(), sgn.t().contiguous(), "sign") * E).view(input.shape)
             else:
-                grad_input = g2.mm(sgn * E).view(input.shape)
+                grad_input = lib_mm(g2, sgn * E).view(input.shape)
         if ctx.needs_input_grad[1]:
             if big and ctx.x_levels is not None:
                 grad_weight = _levels_grad_weight_linear(g2, x2, ctx.x_levels, ctx.codes_fit)
             if grad_weight is None:
-                if big:
-                    note_library_path(g2, "backward GEMM with two real operands")
-                grad_weight = g2.t().mm(x2)
+                grad_weight = real_matmul(g2.t(), x2) if big else lib_mm(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)
         return grad_input, grad_weight, grad_bias
@@ -1090,21 +1194,19 @@ class DorefaWkLinearFn(torch.autograd.Function):
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         x2 = input.reshape(-1, input.shape[-1])
         grad_input = grad_weight = grad_bias = None
-        big = (g2.is_cuda and g2.dtype == torch.float32
+        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0
                and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
             if big:        # real gradient x integer levels
                 lv = _weight_levels(weight_q, k)
                 grad_input = (ops.float_linear(g2.contiguous(), lv.t().contiguous(), "raw") * _inv_levels(k)).view(input.shape)
             else:
-                grad_input = g2.mm(weight_q).view(input.shape)
+                grad_input = lib_mm(g2, weight_q).view(input.shape)
         if ctx.needs_input_grad[1]:
             if big and ctx.x_levels is not None:   # g^T . x with x = codes / n_a
                 grad_weight = _levels_grad_weight_linear(g2, x2, ctx.x_levels, ctx.codes_fit)
             if grad_weight is None:
-                if big:
-                    note_library_path(g2, "backward GEMM with two real operands")
-                grad_weight = g2.t().mm(x2)
+                grad_weight = real_matmul(g2.t(), x2) if big else lib_mm(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)
         return grad_input, grad_weight, grad_bias, None
@@ -1148,7 +1250,7 @@ def grouped_quant_conv(layer, input, kind: str, quant_op):
 #: matrix cores from this many multiply-accumulates on: the real operand is split exactly into bf16 triples, the
 #: +-1/0 operand is exact in bf16, accumulation is fp32 — fp32-GEMM accuracy at ~2.5x the fp32 library's speed
 #: (4096^3: 0.51 vs 1.03 ms per GEMM incl. transposes and splits, max error 1.6e-6 vs 3.0e-6 of fp64; tools/bench_backward.py).  Below it the dense library is used (launch-bound either way).
-BWD_MFMA_MIN_MACS = 1 << 27
+BWD_MFMA_MIN_MACS = 0          # (round 4: every size on the own routes; 1 << 27 was the measured break-even against hipBLASLt)
 
 
 #: backward convs with a +-1 / 0 operand on the bf16 matrix cores (ops.conv2d_grad_input_q / conv2d_grad_weight_pm1)
@@ -1159,9 +1261,9 @@ def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor, terms=None) -> torch.Tensor
     """a [M, J] (real) @ b_pm1 [J, K] (entries in {-1, 0, +1}) -> [M, K] fp32.  ``terms``: split of a (ops.float_linear)."""
     M, J = a.shape
     K = b_pm1.shape[1]
-    if a.is_cuda and a.dtype == torch.float32 and M * J * K >= BWD_MFMA_MIN_MACS:
+    if a.is_cuda and a.dtype == torch.float32 and M * J * K >= BWD_MFMA_MIN_MACS and a.numel() > 0 and b_pm1.numel() > 0:
         return ops.float_linear(a.contiguous(), b_pm1.t().contiguous(), "sign", terms=terms)
-    return a.mm(b_pm1)
+    return lib_mm(a, b_pm1, "backward GEMM below BWD_MFMA_MIN_MACS / non-fp32")
 
 
 class QuantLinearFn(torch.autograd.Function):
@@ -1205,9 +1307,7 @@ class QuantLinearFn(torch.autograd.Function):
             if ctx.x_is_pm1:
                 gw = pm1_matmul(g2.t(), x2, terms=3)
             else:
-                if g2.is_cuda and g2.dtype == torch.float32 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS:
-                    note_library_path(g2, "backward GEMM with two real operands")
-                gw = g2.t().mm(x2)
+                gw = real_matmul(g2.t(), x2)          # two real operands (a real-valued first layer): six-term planes
             grad_weight = ste_mask(gw, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)

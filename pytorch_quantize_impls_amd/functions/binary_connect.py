@@ -84,51 +84,56 @@ def BinaryConnect(stochastic=False):
 
 
 class BinaryDense(torch.autograd.Function):
-    """y = x . sign(W)^T + b with a plain (un-masked) backward (binary_connect.py:86-112)."""
+    """y = x . sign(W)^T + b with a plain (un-masked) backward (binary_connect.py:86-112).  Device fp32 tensors: both backward
+    contractions on this backend's matrix-core routes (_fused.dense_grad_input / dense_grad_weight)."""
 
     @staticmethod
     def forward(ctx, input, weight, bias=None):
         ctx.save_for_backward(input, weight, bias)
-        return _fused.quant_linear_forward(input, weight, bias, kind="binary")
+        _fused.clear_last_detection()
+        out = _fused.quant_linear_forward(input, weight, bias, kind="binary")
+        ctx.x_is_pm1 = bool(input.is_cuda and input.dim() == 2 and (_fused.packed.lookup(input, _fused.packed.ROWS_LAST) is not None
+                                                                    or _fused.last_detection_said_pm1(input)))
+        return out
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight, bias = ctx.saved_tensors
-        weight_b = safeSign(weight)
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            grad_input = grad_output.mm(weight_b)
+            grad_input = _fused.dense_grad_input(grad_output, safeSign(weight), pm1=True)
         if ctx.needs_input_grad[1]:
-            grad_weight = grad_output.t().mm(input)
+            grad_weight = _fused.dense_grad_weight(grad_output, input, ctx.x_is_pm1)
         if bias is not None and ctx.needs_input_grad[2]:
             grad_bias = grad_output.sum(0)
         return grad_input, grad_weight, grad_bias
 
 
 def BinaryConv2d(stride=1, padding=1, dilation=1, groups=1):
-    """DEPRECATED functional conv with binarised weight (binary_connect.py:116-153)."""
+    """DEPRECATED functional conv with binarised weight (binary_connect.py:116-153); backward on the matrix-core conv routes."""
     _warnings.warn("Deprecated conv op ! Use layers.BinConv2d.", DeprecationWarning, stacklevel=2)
 
     class _BinaryConv2d(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             ctx.save_for_backward(input, weight, bias)
-            return _fused.quant_conv2d_forward(input, weight, bias, stride, padding, dilation,
-                                               groups, kind="binary")
+            _fused.clear_last_detection()
+            out = _fused.quant_conv2d_forward(input, weight, bias, stride, padding, dilation,
+                                              groups, kind="binary")
+            ctx.x_is_pm1 = bool(input.is_cuda and input.dim() == 4 and (_fused.packed.lookup(input, _fused.packed.NHWC) is not None
+                                                                        or _fused.last_detection_said_pm1(input)))
+            return out
 
         @staticmethod
         def backward(ctx, grad_output):
             input, weight, bias = ctx.saved_tensors
-            weight_b = safeSign(weight)
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                grad_input = torch.nn.grad.conv2d_input(input.size(), weight_b, grad_output,
-                                                        stride=stride, padding=padding,
-                                                        dilation=dilation, groups=groups)
+                grad_input = _fused.conv_grad_input(input.size(), weight, grad_output, stride, padding, dilation, groups,
+                                                    kind="binary")
             if ctx.needs_input_grad[1]:
-                grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output,
-                                                          stride=stride, padding=padding,
-                                                          dilation=dilation, groups=groups)
+                grad_weight = _fused.conv_grad_weight(input, weight.shape, grad_output, stride, padding, dilation, groups,
+                                                      ctx.x_is_pm1)
             if bias is not None and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum((0, 2, 3))
             if bias is not None:

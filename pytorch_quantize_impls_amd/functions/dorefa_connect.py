@@ -130,9 +130,10 @@ def QuantDense(bit_width=3):
             input, weight, weight_q, max_abs, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                grad_input = grad_output.mm(weight_q)
+                grad_input = _fused.dense_grad_input(grad_output, weight_q, pm1=False)
             if ctx.needs_input_grad[1]:
-                grad_weight = grad_output.t().mm(input)
+                x_pm1 = input.dim() == 2 and _fused.packed.lookup(input, _fused.packed.ROWS_LAST) is not None
+                grad_weight = _fused.dense_grad_weight(grad_output, input, x_pm1)
                 if 1 < bit_width < 32:
                     grad_weight = grad_weight * (1 - torch.pow(torch.tanh(weight), 2)) / max_abs
             if bias is not None and ctx.needs_input_grad[2]:
@@ -165,13 +166,20 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
             input, weight, weight_q, max_weight, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                grad_input = torch.nn.grad.conv2d_input(input.size(), weight_q, grad_output,
-                                                        stride=stride, padding=padding,
-                                                        dilation=dilation, groups=groups)
+                if 1 < bit_width <= 7:      # odd integer levels / (2^k - 1): the levels are the exact operand, 1 / n after
+                    n_w = float((1 << bit_width) - 1)
+                    grad_input = _fused.conv_grad_input(input.size(), torch.round(weight_q.detach() * n_w), grad_output, stride,
+                                                        padding, dilation, groups, kind="raw",
+                                                        out_scale=_fused._inv_levels(bit_width))
+                elif bit_width == 1:        # sign(W) * E
+                    grad_input = _fused.conv_grad_input(input.size(), weight, grad_output, stride, padding, dilation, groups,
+                                                        kind="binary", out_scale_dev=torch.mean(torch.abs(weight)).detach())
+                else:
+                    grad_input = _fused.conv_grad_input(input.size(), weight_q, grad_output, stride, padding, dilation, groups,
+                                                        kind=None)
             if ctx.needs_input_grad[1]:
-                grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output,
-                                                          stride=stride, padding=padding,
-                                                          dilation=dilation, groups=groups)
+                x_pm1 = input.dim() == 4 and _fused.packed.lookup(input, _fused.packed.NHWC) is not None
+                grad_weight = _fused.conv_grad_weight(input, weight.shape, grad_output, stride, padding, dilation, groups, x_pm1)
                 if 1 < bit_width < 32:
                     grad_weight = grad_weight * (1 - torch.pow(torch.tanh(weight), 2)) / torch.tanh(max_weight)
             if bias is not None and ctx.needs_input_grad[2]:

@@ -66,13 +66,16 @@ def _functional_ternary_weight(weight, stochastic):
 
 
 def TernaryDense(stochastic=False):
-    """Functional ternary linear op (terner_connect.py:78-108)."""
+    """Functional ternary linear op (terner_connect.py:78-108).  The image is real-valued (w = +-0.5 stays +-0.5, the stochastic
+    branch gives {0, +-2}): forward and both backward contractions on the six-term real x real route for device tensors
+    (a +-1 activation is the exact operand of the weight gradient)."""
 
     class _TernaryDense(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)
             ctx.save_for_backward(input, weight, weight_t, bias)
+            ctx.x_is_pm1 = input.dim() == 2 and _fused.known_pm1(input, weight, _fused.packed.ROWS_LAST)
             return _fused.real_weight_linear(input, weight_t, bias)
 
         @staticmethod
@@ -80,9 +83,9 @@ def TernaryDense(stochastic=False):
             input, weight, weight_t, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                grad_input = grad_output.mm(weight_t)
+                grad_input = _fused.dense_grad_input(grad_output, weight_t, pm1=False)
             if ctx.needs_input_grad[1]:
-                grad_weight = grad_output.t().mm(input)
+                grad_weight = _fused.dense_grad_weight(grad_output, input, ctx.x_is_pm1)
             if bias is not None and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum(0)
             return grad_input, grad_weight, grad_bias
@@ -91,7 +94,9 @@ def TernaryDense(stochastic=False):
 
 
 def TernaryConv2d(stochastic=True, stride=1, padding=1, dilation=1, groups=1):
-    """DEPRECATED functional ternary conv (terner_connect.py:113-153)."""
+    """DEPRECATED functional ternary conv (terner_connect.py:113-153).  Backward: the image's entries are multiples of 1/2 (exact
+    in fp16), so grad_input is the split gradient against the flipped image (kind "raw"); grad_weight on the +-1 routes when the
+    activation is +-1."""
     warnings.warn("Deprecated conv op ! Use layers.TerConv2d.", DeprecationWarning, stacklevel=2)
 
     class _TernaryConv2d(torch.autograd.Function):
@@ -99,6 +104,7 @@ def TernaryConv2d(stochastic=True, stride=1, padding=1, dilation=1, groups=1):
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)
             ctx.save_for_backward(input, weight, weight_t, bias)
+            ctx.x_is_pm1 = input.dim() == 4 and _fused.known_pm1(input, weight, _fused.packed.NHWC)
             return _fused.real_weight_conv2d(input, weight_t, bias, stride, padding, dilation, groups)
 
         @staticmethod
@@ -106,13 +112,11 @@ def TernaryConv2d(stochastic=True, stride=1, padding=1, dilation=1, groups=1):
             input, weight, weight_t, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                grad_input = torch.nn.grad.conv2d_input(input.size(), weight_t, grad_output,
-                                                        stride=stride, padding=padding,
-                                                        dilation=dilation, groups=groups)
+                grad_input = _fused.conv_grad_input(input.size(), weight_t, grad_output, stride, padding, dilation, groups,
+                                                    kind="raw")
             if ctx.needs_input_grad[1]:
-                grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output,
-                                                          stride=stride, padding=padding,
-                                                          dilation=dilation, groups=groups)
+                grad_weight = _fused.conv_grad_weight(input, weight.shape, grad_output, stride, padding, dilation, groups,
+                                                      ctx.x_is_pm1)
             if bias is not None and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum((0, 2, 3))
             if bias is not None:

@@ -111,16 +111,11 @@ def XNORDense(dim=[0, 1]):
             g2 = grad_output.contiguous() if hip else grad_output
             if ctx.needs_input_grad[0]:
                 if hip:
-                    grad_input = _fused.pm1_matmul(g2, sgn) * mean          # g . (sign(W) * alpha[k]) = (g . sign(W)) * alpha[k]
+                    grad_input = _fused.dense_grad_input(g2, sgn, pm1=True) * mean     # g . (sign(W) * alpha[k]) = (g . sign(W)) * alpha[k]
                 else:
-                    grad_input = grad_output.mm(sgn * mean)
+                    grad_input = _fused.lib_mm(grad_output, sgn * mean)
             if ctx.needs_input_grad[1]:
-                if hip and ctx.x_is_pm1:
-                    gw = _fused.pm1_matmul(g2.t(), input, terms=3)          # rows of g^T are output features: the exact split
-                else:
-                    if hip and g2.shape[0] * g2.shape[1] * input.shape[1] >= _fused.BWD_MFMA_MIN_MACS:
-                        _fused.note_library_path(g2, "backward GEMM with two real operands")
-                    gw = grad_output.t().mm(input)
+                gw = _fused.dense_grad_weight(grad_output, input, ctx.x_is_pm1)        # +-1 x: the exact operand; else six-term
                 grad_weight = _fused.xnor_weight_grad(gw, weight, mean, DIM)
             if bias is not None and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum(0)
@@ -183,7 +178,6 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
         @staticmethod
         def backward(ctx, grad_output):
             input, weight, mean, bias = ctx.saved_tensors
-            sgn = None
             grad_input = grad_weight = grad_bias = None
             go = _fused._dense(grad_output)
             mfma = (_fused.BWD_CONV_MFMA and ctx.x_is_pm1 and go.is_cuda and go.dtype == torch.float32 and groups == 1
@@ -192,22 +186,13 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
                 if mfma:
                     grad_input = ops.conv2d_grad_input_taps(input.shape, weight, go, ctx.taps.bwd, stride, padding, dilation)
                 if grad_input is None:
-                    _fused.note_library_path(go, "conv grad_input outside the matrix-core route")
-                    sgn = torch.sign(weight)
-                    grad_input = torch.nn.grad.conv2d_input(input.size(), sgn * mean, grad_output,
-                                                            stride=stride, padding=padding,
-                                                            dilation=dilation, groups=groups)
+                    grad_input = _fused.lib_conv2d_input(input.size(), torch.sign(weight) * mean, grad_output, stride, padding,
+                                                         dilation, groups)
             want_bias = bias is not None and ctx.needs_input_grad[2]
             by_product = []
             if ctx.needs_input_grad[1]:
-                gw = None
-                if mfma:
-                    gw = _fused.pm1_conv_grad_weight(input, go, weight.shape, stride, padding, dilation,
-                                                     by_product if want_bias else None)
-                if gw is None:
-                    _fused.note_library_path(go, "conv grad_weight outside the matrix-core route")
-                    gw = torch.nn.grad.conv2d_weight(input, weight.shape, grad_output, stride=stride,
-                                                     padding=padding, dilation=dilation, groups=groups)
+                gw = _fused.conv_grad_weight(input, weight.shape, grad_output, stride, padding, dilation, groups, ctx.x_is_pm1,
+                                             by_product if want_bias else None)
                 grad_weight = _fused.xnor_weight_grad(gw, weight, mean, DIM)
             if want_bias:
                 grad_bias = by_product[0] if by_product else grad_output.sum((0, 2, 3))

@@ -818,12 +818,13 @@ def fuse_sequential(seq: torch.nn.Sequential, fuse_conv: bool = False, packed_po
     fold of the fused blocks ("reference" | "device", module docstring; default DEFAULT_FOLD)."""
     from .binary_layers import BinConv2d
     from .terner_layers import TerConv2d
+    from .xnor_layers import XNORConv2d
     mods = list(seq.children())
     out, i = [], 0
     while i < len(mods):
         j = i
         conv = None
-        if fuse_conv and isinstance(mods[j], (BinConv2d, TerConv2d)) and j + 1 < len(mods):
+        if fuse_conv and isinstance(mods[j], (BinConv2d, TerConv2d, XNORConv2d)) and j + 1 < len(mods):
             conv, j = mods[j], j + 1
         pool = None
         if isinstance(mods[j], torch.nn.MaxPool2d):
@@ -890,13 +891,14 @@ class FusedFeatureClassifier(torch.nn.Module):
         super().__init__()
         from .binary_layers import LinearBin
         from .terner_layers import LinearTer
+        from .xnor_layers import LinearXNOR
         if any(m.training for m in (features, classifier)):
             raise ValueError("fuse eval-mode modules")
         f, c = list(features.children()), list(classifier.children())
         if c and _is_det_binary_connect(c[0]):
             f, c = f + [c[0]], c[1:]
-        if not c or not isinstance(c[0], (LinearBin, LinearTer)):
-            raise ValueError("classifier must start with [BinaryConnect(deterministic),] LinearBin / LinearTer")
+        if not c or not isinstance(c[0], (LinearBin, LinearTer, LinearXNOR)):
+            raise ValueError("classifier must start with [BinaryConnect(deterministic),] LinearBin / LinearTer / LinearXNOR")
         self.features = fuse_sequential(torch.nn.Sequential(*f), fuse_conv=fuse_conv, packed_pool=True, fold=fold)
         tail = list(self.features.children())[-1] if len(self.features) else None
         if not isinstance(tail, (FusedConvPoolBnSign, FusedPoolBnSign, PackedMaxPool)):

@@ -651,8 +651,11 @@ def test_xnor_layers_golden(dev, golden):
         layer.weight.data.copy_(g(golden[f"g4_conv_{name}_w"], dev))
         if has_b:
             layer.bias.data.copy_(g(golden[f"g4_conv_{name}_b"], dev))
-        with used("qt_xnor_weight_f32"):
-            y = layer(g(golden[f"g4_conv_{name}_x"], dev))
+        before = dict(_lib.call_counts)
+        y = layer(g(golden[f"g4_conv_{name}_x"], dev))
+        # real-valued input: alpha + sign(W) * alpha image (qt_xnor_weight_f32), six-term conv; +-1 input: alpha + Horner
+        # tables (qt_xnor_tap_prep_f32), per-tap scaled fp4 conv (round 4)
+        assert sum(_lib.call_counts[k] - before.get(k, 0) for k in ("qt_xnor_weight_f32", "qt_xnor_tap_prep_f32")) > 0
         assert norm_err(n(y), golden[f"g4_conv_{name}_xnor_y"]) <= TOL, name
 
 

@@ -382,3 +382,24 @@ def test_output_blocked_first_layer_weight_is_the_same_conv():
     assert ops.d2s_first_layer_applicable(3, 64, (3, 3), 1, 1, 1, 224, 224)
     assert not ops.d2s_first_layer_applicable(3, 64, (3, 3), 1, 1, 1, 223, 224)      # odd size: no 2x2 blocking
     assert not ops.d2s_first_layer_applicable(3, 48, (3, 3), 1, 1, 1, 224, 224)      # channel groups of 32 in the epilogue
+
+
+def test_no_bare_dense_library_call_in_the_functional_forms():
+    """every hipBLASLt / MIOpen call a backward can make goes through functions/_fused.py, where it is counted
+    (LIBRARY_PATHS); the Function classes themselves contain no `.mm(` / `torch.nn.grad.` / F.linear-on-a-device-tensor shortcut."""
+    import glob
+    import os
+    import re
+    import pytorch_quantize_impls_amd.functions as F_
+    root = os.path.dirname(F_.__file__)
+    bad = []
+    for path in sorted(glob.glob(os.path.join(root, "*.py"))):
+        if os.path.basename(path) == "_fused.py":
+            continue
+        text = open(path, encoding="utf-8").read()
+        code = "\n".join(ln.split("#", 1)[0] for ln in text.split("\n"))        # comments stripped (docstrings cite upstream lines)
+        code = re.sub(r'"""(.|\n)*?"""', "", code)
+        for pat in (r"\.mm\(", r"torch\.nn\.grad\."):
+            for m in re.finditer(pat, code):
+                bad.append((os.path.basename(path), m.group(0)))
+    assert not bad, bad
