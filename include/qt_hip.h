@@ -135,9 +135,12 @@ int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int
 /* LinearXNOR on a packed +-1 activation (layers/xnor_layers.py:8-33 in eval mode behind the fused inference chain): the operand
  * x[b, k] * alpha[k] of y = (x * alpha) . sign(W)^T (functions/xnor_connect.py:112-115) as two-term fp16 pairs, from the
  * activation's SIGN BITS and the pair image of alpha / s (alpha_pairs[k] = hi | lo << 16; qt_f16x2_pack_f32 of the [1, K] scale
- * row): out[r][k] = bit ? -pair[k] : pair[k] (exact).  out: [rows][ld_bytes], ld_bytes % 128 == 0, pad pairs zero. */
+ * row): out[r][k] = bit ? -pair[k] : pair[k] (exact).  out: [rows][ld_bytes], ld_bytes % 128 == 0, pad pairs zero.
+ * perm_C > 0 (perm_C * perm_HW == K): the bit rows hold a feature map flattened in (h, w, c) order (what the fused conv blocks hand
+ * over) while k counts in the NCHW order c * HW + hw of the module graph's reshape: feature k reads bit (k % HW) * C + k / HW, so
+ * the GEMM sums in the module graph's order (bit-identical results for the two executions of a model). */
 int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out, int64_t ld_bytes,
-                              int64_t rows, int64_t K, qt_stream_t stream);
+                              int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW, qt_stream_t stream);
 
 /* XNOR-Net ACTIVATION quantiser on a row-major [R, C] tensor (_quantOpXnor / nnQuantXnor / QuantXnor,
  * functions/xnor_connect.py:17-66):  y = sign(x) * mean(x, dim)  with torch.sign (0 -> 0) and the SIGNED mean the

@@ -46,14 +46,29 @@ __global__ __launch_bounds__(256) void sign_scale_kernel(const float* __restrict
 // matrix-core GEMM is x[b, k] * alpha[k] = +-alpha[k] as a two-term fp16 pair — the (hi, lo) pair of alpha[k] / s, prepared once
 // per weight version, with both signs flipped where the bit says -1 (exact).  One thread = one 32-bit word of a bit-plane row ->
 // 32 pairs (128 bytes).
+// perm_C > 0: the bit rows are a feature map flattened in (h, w, c) order (PackedActivation.flatten_hwc: bit hw * C + c) while the
+// layer — and the pair table — count features in the NCHW order c * HW + hw the module graph flattens in: output feature k reads bit
+// (k % HW) * C + k / HW, so the GEMM contracts in the same order, on the same operands, as for the un-packed activation (the two
+// executions of a model then agree bit for bit; a real-valued sum depends on its order).
 __global__ __launch_bounds__(256) void bits_alpha_pairs_kernel(const uint32_t* __restrict__ bits, int64_t ldb,
                                                                const uint32_t* __restrict__ apair, uint32_t* __restrict__ out,
-                                                               int64_t ldo_words, int64_t rows, int64_t K) {
+                                                               int64_t ldo_words, int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW) {
     const int64_t wpr = ldo_words / 32;            // 32-pair groups per output row (row stride is a multiple of 128 bytes)
     const int64_t total = rows * wpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / wpr, g = i - r * wpr;
-        const uint32_t w = g < ldb ? bits[r * ldb + g] : 0u;
+        uint32_t w = 0u;
+        if (perm_C > 0) {
+            for (int e = 0; e < 32; ++e) {
+                const int64_t k = g * 32 + e;
+                if (k < K) {
+                    const int64_t c = k / perm_HW, hw = k - c * perm_HW, b = hw * perm_C + c;
+                    w |= ((bits[r * ldb + (b >> 5)] >> (b & 31)) & 1u) << e;
+                }
+            }
+        } else if (g < ldb) {
+            w = bits[r * ldb + g];
+        }
         uint4* o = reinterpret_cast<uint4*>(out + r * ldo_words + g * 32);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -72,14 +87,15 @@ __global__ __launch_bounds__(256) void bits_alpha_pairs_kernel(const uint32_t* _
 }  // namespace
 
 extern "C" int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out,
-                                         int64_t ld_bytes, int64_t rows, int64_t K, qt_stream_t stream) {
-    if (rows < 0 || K < 0) return QT_ERR_INVALID_ARG;
+                                         int64_t ld_bytes, int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW,
+                                         qt_stream_t stream) {
+    if (rows < 0 || K < 0 || perm_C < 0 || perm_HW < 0 || (perm_C > 0 && perm_C * perm_HW != K)) return QT_ERR_INVALID_ARG;
     if (rows == 0 || K == 0) return QT_OK;
     if (!bits || !alpha_pairs || !out || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
     if ((ld_bytes & 127) || ld_bytes < 4 * K || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
     const int grid = qt_stream_grid((rows * (ld_bytes / 128) + 255) / 256);
     hipLaunchKernelGGL(bits_alpha_pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, ldb, alpha_pairs, out,
-                       ld_bytes / 4, rows, K);
+                       ld_bytes / 4, rows, K, perm_C, perm_HW);
     return qt_check_launch();
 }
 

@@ -488,7 +488,8 @@ def packed_xnor_conv2d(layer, act, epi=None):
 def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
     """Eval-mode LinearXNOR on a PackedActivation (row planes): y = (x * alpha) . sign(W)^T + b (xnor_connect.py:112-115) with
     x * alpha = +-alpha[k] built from the sign bits as two-term fp16 pairs (qt_bits_alpha_pairs_f16x2) against the replicated
-    sign(W) on the fp16 matrix cores.  ``hwc``: see packed_linear (weight columns and alpha permuted alike)."""
+    sign(W) on the fp16 matrix cores.  ``hwc`` = (C, H, W): the rows are a feature map flattened in (h, w, c) order; the pair
+    kernel reads the bits in the weight's own NCHW order, so the sum runs in the module graph's order (bit-identical logits)."""
     if layer.training:
         raise RuntimeError("PackedActivation inputs are an inference feature: call .eval() first")
     N = layer.weight.shape[0]
@@ -496,15 +497,20 @@ def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
     if K != layer.weight.shape[1]:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
 
-    def build(w2):
-        if hwc is not None:
-            from ..layers.fused import permute_fc_weight_hwc
-            w2 = permute_fc_weight_hwc(w2, *(int(v) for v in hwc))
-        _, alpha = ops.xnor_weight(w2.contiguous(), 1)                       # alpha[1, K] of the (already quantised) image
-        return ops.weight_bf16x3(w2, "sign", terms=2), ops.alpha_pairs(alpha.view(-1))
-    wt, ap = layer._eval_planes(build, key=("xnor_pairs",) + (tuple(int(v) for v in hwc) if hwc is not None else ()))
-    y = ops.bf16_gemm(ops.bits_alpha_pairs(act.planes, ap), wt, layer.bias)
+    wt, ap = xnor_linear_operands(layer)
+    y = ops.bf16_gemm(ops.bits_alpha_pairs(act.planes, ap, hwc=hwc), wt, layer.bias)
     return y.view(*act.shape[:-1], N)
+
+
+def xnor_linear_operands(layer=None, weight=None):
+    """(fp16 pair planes of sign(W), pair image of alpha[K] = mean(|W|, 0)) of a LinearXNOR weight: cached per weight version
+    for an eval-mode ``layer``, built on the spot for a training-mode ``weight``."""
+    def build(w2):
+        _, alpha = ops.xnor_weight(w2.contiguous(), 1)                       # alpha[1, K] (eval: of the already quantised image)
+        return ops.weight_bf16x3(w2, "sign", terms=2), ops.alpha_pairs(alpha.view(-1))
+    if layer is not None:
+        return layer._eval_planes(build, key="xnor_pairs")
+    return build(weight.detach())
 
 
 #: dispatch used by the layers' forward for PackedActivation inputs: [is_linear] -> function

@@ -94,7 +94,13 @@ def XNORDense(dim=[0, 1]):
                 _, mean = ops.xnor_weight(weight.detach(), 1)
                 ctx.save_for_backward(input, weight, mean, bias)
                 if input.dim() == 2:
-                    ctx.x_is_pm1 = packed.lookup(input, packed.ROWS_LAST) is not None
+                    planes = packed.lookup(input, packed.ROWS_LAST)
+                    ctx.x_is_pm1 = planes is not None
+                    if planes is not None and planes.K == weight.shape[1] and planes.rows == input.shape[0]:
+                        # +-1 activation with its sign planes: x * alpha = +-alpha[k] as two-term fp16 pairs built from the
+                        # bits (the operands of the eval-mode / packed path: one arithmetic for every execution of a layer)
+                        wt, ap = _fused.xnor_linear_operands(weight=weight)
+                        return ops.bf16_gemm(ops.bits_alpha_pairs(planes, ap), wt, bias.detach() if bias is not None else None)
                     if not ctx.x_is_pm1 and _fused.DETECT_BINARY_INPUT:
                         ctx.x_is_pm1 = bool(_fused.detect_pm1(input, weight)[0])
                 return ops.float_linear(input, weight.detach(), "sign", bias, alpha=mean.view(-1))

@@ -550,7 +550,10 @@ class FusedConvPoolBnSign(torch.nn.Module):
                                              binary_input=known, planes=conv._taps_planes(), epi=e2)
         if out is not None:
             return out[0], shape
-        wt = conv._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x6(conv.weight.detach()), key="conv_bf16x6")
+        # the op quantises the eval image AGAIN (sign(w) * mean|w| of values that are already +-alpha: the fp32 mean of n equal
+        # numbers is not that number to the last bit), like upstream and like the layer's own forward: same image, same bits
+        wt = conv._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x6(ops.xnor_weight(conv.weight.detach(), 2)[0]),
+                               key="conv_bf16x6")
         y = ops.real_conv2d(x, conv.weight.detach(), conv.bias, conv.stride, conv.padding, conv.dilation, weight_planes=wt, epi=e2)
         if y is None:
             raise ValueError("XNOR conv outside the implicit kernel's limits")
@@ -908,11 +911,16 @@ class FusedFeatureClassifier(torch.nn.Module):
         src = c[0]
         if src.in_features != C * H * W:
             raise ValueError(f"classifier expects {src.in_features} features, feat_chw gives {C * H * W}")
-        fc1 = type(src)(src.in_features, src.out_features, bias=src.bias is not None).to(src.weight.device)
-        if src.bias is not None:
-            fc1.bias.data.copy_(src.bias.data)
-        fc1.eval()
-        fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))      # already the quantised image
+        if isinstance(src, LinearXNOR):
+            # a real-valued sum depends on its order: the XNOR layer keeps its own weight and reads the (h, w, c)-flattened bits in
+            # NCHW order instead (PackedActivation.hwc -> qt_bits_alpha_pairs_f16x2), bit-identical to the module graph
+            fc1 = src
+        else:
+            fc1 = type(src)(src.in_features, src.out_features, bias=src.bias is not None).to(src.weight.device)
+            if src.bias is not None:
+                fc1.bias.data.copy_(src.bias.data)
+            fc1.eval()
+            fc1.weight.data.copy_(permute_fc_weight_hwc(src.weight.data, C, H, W))      # already the quantised image
         self.classifier = fuse_sequential(torch.nn.Sequential(fc1, *c[1:]), fold=fold)
         self.eval()
 

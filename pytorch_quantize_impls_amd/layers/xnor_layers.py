@@ -39,7 +39,14 @@ class LinearXNOR(EvalSwapMixin, torch.nn.Linear, QLayer):
 
     def _forward_impl(self, input):
         if isinstance(input, _fused.packed.PackedActivation):
-            return _fused.packed_xnor_linear(self, input)
+            return _fused.packed_xnor_linear(self, input, hwc=input.hwc)
+        if (not self.training and not torch.is_grad_enabled() and isinstance(input, torch.Tensor) and input.is_cuda
+                and input.dtype == torch.float32 and input.dim() == 2 and input.numel() > 0):
+            # eval mode, +-1 activation carrying its sign planes (BinaryConnect's tag): the same operands and the same GEMM as
+            # for a packed activation (cached per weight version) — the module-by-module and the deferred execution agree bit for bit
+            planes = _fused.packed.lookup(input, _fused.packed.ROWS_LAST)
+            if planes is not None and planes.K == self.in_features and planes.rows == input.shape[0] and self._eval_on_grid():
+                return _fused.packed_xnor_linear(self, _fused.packed.PackedActivation(planes, tuple(input.shape)))
         return self.lin_op.apply(input, self.weight, self.bias)
 
 

@@ -1415,16 +1415,18 @@ def alpha_pairs(alpha: torch.Tensor) -> "TriplePlanes":
     return split_bf16x3(a, terms=2)
 
 
-def bits_alpha_pairs(planes: BitPlanes, apairs: "TriplePlanes") -> "TriplePlanes":
+def bits_alpha_pairs(planes: BitPlanes, apairs: "TriplePlanes", hwc=None) -> "TriplePlanes":
     """fp16 pair plane of x[b, k] * alpha[k] for a packed +-1 activation (row bit planes): the pairs of alpha with the
-    activation's signs (qt_bits_alpha_pairs_f16x2)."""
+    activation's signs (qt_bits_alpha_pairs_f16x2).  ``hwc`` = (C, H, W): the bit rows are a feature map flattened in (h, w, c)
+    order; the pairs come out in the NCHW order the layer's weight (and ``apairs``) count in."""
     if planes.mask is not None or planes.K != apairs.K:
         raise ValueError("bits_alpha_pairs takes sign-only row planes and the pair image of a [K] scale row")
+    pc, phw = (int(hwc[0]), int(hwc[1]) * int(hwc[2])) if hwc is not None else (0, 0)
     ld = triple_ld_bytes(planes.K, terms=2)
     out = torch.empty((planes.rows, ld // 2), dtype=torch.int16, device=planes.device)
     with _on(planes.device):
         _lib.call("qt_bits_alpha_pairs_f16x2", _p(planes.sign), int(planes.ld), _p(apairs.data), _p(out), int(ld),
-                  int(planes.rows), int(planes.K), _stream(planes.device))
+                  int(planes.rows), int(planes.K), pc, phw, _stream(planes.device))
     return TriplePlanes(data=out, rows=planes.rows, K=planes.K, terms=2, scale=apairs.scale)
 
 

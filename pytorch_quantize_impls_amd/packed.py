@@ -80,6 +80,7 @@ class PackedActivation:
         self.nib = nib
         self.halo = tuple(int(v) for v in halo)
         self.shape = tuple(int(v) for v in shape)
+        self.hwc = None               # (C, H, W) when the rows are a feature map flattened in (h, w, c) order (flatten_hwc)
 
     @property
     def device(self):
@@ -101,7 +102,9 @@ class PackedActivation:
         if self.planes.ld * 32 != C:
             raise ValueError("flatten_hwc needs C to be a multiple of 128 (unpadded 16-byte pixel rows)")
         words = self.planes.sign.view(N, H * W * self.planes.ld)
-        return PackedActivation(BitPlanes(sign=words, rows=N, K=H * W * C), (N, H * W * C))
+        flat = PackedActivation(BitPlanes(sign=words, rows=N, K=H * W * C), (N, H * W * C))
+        flat.hwc = (C, H, W)          # the feature order of the rows, for consumers that count features in NCHW order
+        return flat
 
 
 class CodeActivation:

@@ -317,7 +317,7 @@ def test_xnor_alexnet_module_graph_runs_the_tap_kernels_and_equals_the_eager_gra
     BatchNorm / Hardtanh / BinaryConnect modules behind it (per-tap scaled conv with the threshold epilogue, LinearXNOR on the
     packed bits); the logits equal the module-by-module evaluation BIT FOR BIT (device thresholds on the same fp32 conv values)."""
     m = _alexnet_xnor(dev)
-    x = torch.randn(8, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(64, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
     _fused.LIBRARY_PATHS.clear()
     with torch.no_grad():
         before = dict(_lib.call_counts)
@@ -329,10 +329,15 @@ def test_xnor_alexnet_module_graph_runs_the_tap_kernels_and_equals_the_eager_gra
             e = m(x)
     assert stats.get("deferred") == 5 and stats.get("fused") == 5 and not stats.get("materialised"), stats
     assert used.get("qt_conv2d_implicit_taps_bits", 0) + used.get("qt_conv2d_implicit_taps_nib", 0) == 4, used
-    assert used.get("qt_bits_alpha_pairs_f16x2", 0) == 1, used            # fc1 on the packed bits of the last block
+    assert used.get("qt_bits_alpha_pairs_f16x2", 0) == 3, used            # the three LinearXNOR layers on sign bits
     assert not _fused.LIBRARY_PATHS, dict(_fused.LIBRARY_PATHS)
     assert torch.isfinite(y).all()
     assert torch.equal(y, e)
+    # ... and the explicit fused form (its first classifier layer reads the (h, w, c)-flattened bits in the weight's NCHW order)
+    from pytorch_quantize_impls_amd.layers import FusedFeatureClassifier
+    with torch.no_grad():
+        f = FusedFeatureClassifier(m.features, m.classifieur, (256, 6, 6), fold="device")(x)
+    assert torch.equal(f, y)
 
 
 def test_xnor_alexnet_eager_graph_vs_the_oracle_chain(dev, oracle):
