@@ -627,6 +627,31 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, in
                            uint32_t* nib_plane, int64_t ldn, int64_t Cout, int64_t out_halo_h, int64_t out_halo_w,
                            int64_t d2s_cout, qt_stream_t stream);
 
+/* ---- direct first-layer conv (csrc/conv_first_direct.hip) ---------------------------------------------------------------------------
+ * conv2d(x, Q(W), bias, stride S, padding (PH, PW)) for a REAL-valued fp32 image with a few channels (C <= Cp <= 8) and a large /
+ * strided kernel — the first layer of the reference's CNNs (models/Alexnet/Alexnet_Bin.py:13: 3 -> 192, 11 x 11, stride 4, padding 2;
+ * layers/binary_layers.py:103-106, terner_layers.py:89-92, functions/xnor_connect.py:139-146).  x: [N, C, H, W] with element strides
+ * (sn, sc, sh, sw) — NCHW or channels-last storage, read where it lies.  A workgroup loads the input patch of its <= 128 output
+ * pixels once, splits it into two fp16 terms of x / s with the TILE's power-of-two s (|x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 tile
+ * max)) and contracts K = (ky, kx, c) on the fp16 matrix cores by stride addressing of the patch: no space-to-depth plane, no
+ * operand pack pass.  Weights, packed once by the caller ([k-step][2][Coutp][8 fp16], k = ky-row chunks of ceil(KW * Cp / 8) * 8
+ * elements in (kx, c) order, zero padded; Coutp = Cout rounded up to 32):
+ *   w_lo == NULL: +-1 / 0 (or small-integer) weights, exact in fp16 (BinConv2d / TerConv2d): w_hi alone;
+ *   w_lo != NULL: real-valued weights (XNOR-Net's sign(W) * alpha) as w / (w_scale * w_scale_dev[0]) = w_hi + w_lo (three
+ *                 products per element: hi whi + lo whi + hi wlo).
+ * S * Cp % 4 == 0 (QT_ERR_ALIGNMENT otherwise: pad the channel count).  y: fp32 NHWC [N * Ho * Wo][ldy]. */
+int qt_conv_first_direct_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp, const uint32_t* w_hi,
+                             const uint32_t* w_lo, float w_scale, const float* w_scale_dev, int64_t Cout, int64_t Coutp,
+                             const float* bias, float* y, int64_t ldy, qt_stream_t stream);
+
+/* ... with the BatchNorm-threshold bit epilogue of qt_conv2d_implicit_bits (float form): neg_plane [N * Ho * Wo][ldb words]. */
+int qt_conv_first_direct_bits_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H,
+                                  int64_t W, int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp,
+                                  const uint32_t* w_hi, const uint32_t* w_lo, float w_scale, const float* w_scale_dev, int64_t Cout,
+                                  int64_t Coutp, const float* bias, const float* alpha, const float* beta, uint32_t* neg_plane,
+                                  int64_t ldb, qt_stream_t stream);
+
 /* ---- per-tap scaled convs: the XNOR-Net family (functions/xnor_connect.py:135-169, layers/xnor_layers.py:36-69) ----------------
  * XNORConv2d computes conv2d(x, sign(W) * alpha) with alpha = mean(|W|, dim = [0, 1], keepdim) -> [1, 1, kh, kw]: one scale per
  * filter TAP (xnor_connect.py:140-145).  With the implicit GEMM's tap-major K order

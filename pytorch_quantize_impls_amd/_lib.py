@@ -148,6 +148,9 @@ SIGNATURES = {
     "qt_pad_pixel_plane": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p]),
     "qt_bits_to_nib_pad": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64] + [_c_i64] * 6 + [_c_p]),
     "qt_im2col_words": (_c_int, [_c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_conv_first_direct_f32": (_c_int, [_c_p] + [_c_i64] * 14 + [_c_p, _c_p, _c_f32, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p]),
+    "qt_conv_first_direct_bits_f32": (_c_int, [_c_p] + [_c_i64] * 14 + [_c_p, _c_p, _c_f32, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p,
+                                               _c_i64, _c_p]),
     "qt_bits_alpha_pairs_f16x2": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_xnor_tap_prep_work_floats": (_c_i64, [_c_i64, _c_i64]),
     "qt_xnor_tap_prep_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),

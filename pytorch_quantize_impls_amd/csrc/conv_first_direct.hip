@@ -1,0 +1,350 @@
+// Direct first-layer conv: a real-valued fp32 image with a few channels against a quantised weight, strided, large kernel
+// (AlexNet conv1: 3 -> 192, 11 x 11, stride 4, padding 2 — models/Alexnet/Alexnet_Bin.py:13; BinConv2d / TerConv2d / XNORConv2d,
+// layers/binary_layers.py:103-106, terner_layers.py:89-92, functions/xnor_connect.py:139-146).
+//
+// The implicit-GEMM route pays for this layer three times: a space-to-depth pack pass that writes and re-reads a 154 MB fp16
+// plane, a K loop whose every output row gathers 1.7 KB into LDS (LDS-fill bound), and weight rows replicated per split term.
+// Here a workgroup owns TOY x TOX output pixels (<= 128) x up to 192 output channels:
+//   * the (TOY-1) s + kh  x  (TOX-1) s + kw  pixel PATCH of the fp32 image is read from HBM once (every loaded pixel feeds
+//     ~ (kh / s)(kw / s) outputs x all channels), its max|x| is folded on the way and the patch goes to LDS as two fp16 planes
+//     hi = fp16(x / s), lo = fp16(x / s - hi) with the TILE's own power-of-two s (max|x| / s in [2^14, 2^15)): no global max|x|
+//     pass, no speculation, |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 tilemax);
+//   * K = (ky, kx, c): for a fixed ky the kw * C values an output pixel needs are CONTIGUOUS in its patch row (NHWC, c fastest), so
+//     the A fragment of v_mfma_f32_32x32x16_f16 (8 consecutive k per lane) is one 16-byte run of the LDS patch at
+//     ((oy s + ky) RS + ox s C + 8 cc) — stride addressing replaces the space-to-depth plane; a ky row is ceil(kw C / 8)
+//     chunks (AlexNet: 33 -> 40 elements), chunks of consecutive ky rows pair up into k-steps (28 instead of 33);
+//   * the weight fragments come straight from global memory (L2) in the packed order [k-step][half][channel][8 fp16] — 16 bytes per
+//     lane, lane-contiguous — prefetched one k-step ahead; +-1 / 0 weights are ONE fragment shared by the hi and lo terms of the
+//     image (no replicated rows), real-valued weights (XNOR-Net: sign(W) * alpha) two fragments w / sw = whi + wlo and the three
+//     products hi whi + lo whi + hi wlo;
+//   * 4 waves, each 2 (m) x 3 (n) accumulator tiles of 32 x 32; two workgroups per CU overlap each other's patch prologue.
+// Epilogues: fp32 NHWC (+ bias), or the BatchNorm-threshold bits of the fused inference chain (qt_conv2d_implicit_bits' float form).
+#include "qt_common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct FirstArgs {
+    const float* x;
+    int64_t sn, sc, sh, sw;            // element strides of x [N, C, H, W] (any storage order)
+    int N, C, H, W, KH, KW, S, PH, PW, Ho, Wo;
+    int Cp;                            // channels per pixel in the LDS patch (C, or padded so that S * Cp % 4 == 0)
+    int CPK;                           // 16-byte chunks per ky row = ceil(KW * Cp / 8)
+    int NCH, NKS;                      // chunks = KH * CPK, k-steps = ceil(NCH / 2)
+    int TOY, TOX, tiles_y, tiles_x;
+    int PR, PCE, RS;                   // patch rows, real elements per patch row (PC * Cp), LDS row stride in elements (% 4 == 0)
+    unsigned m_ppr, m_cp, m_tox, m_cpk; // floor(2^32 / d) + 1 for d = RS / 2, Cp, TOX, CPK: q / d == __umulhi(q, m) for q < 2^16 (d > 1)
+    const uint4* whi;                  // [NKS][2][Coutp] 16-byte chunks
+    const uint4* wlo;                  // real-valued weights only
+    float wscale;                      // weights were divided by this power of two before the fp16 split (1 for +-1 / 0)
+    const float* wscale_dev;           // ... or by this device-resident one (times wscale): no host round trip for a training-mode weight
+    int Cout, Coutp;
+    const float* bias;
+    float* y;                          // fp32 NHWC [N, Ho, Wo, ldy]   (alpha == nullptr)
+    int64_t ldy;
+    const float* alpha;                // threshold epilogue: bit = fl(fl(v * alpha) + beta) < 0  ->  bits[(n, oy, ox)][ldb words]
+    const float* beta;
+    uint32_t* bits;
+    int64_t ldb;
+};
+
+__device__ __forceinline__ int divm(int q, unsigned magic, int d) { return d == 1 ? q : (int)__umulhi((unsigned)q, magic); }
+
+__device__ __forceinline__ v16f mfma16(const uint4& a, const uint4& b, v16f c) {
+    h8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+}
+
+// REALW: the weight is real-valued (two fp16 terms); otherwise +-1 / 0 (one fragment)
+template <bool REALW>
+__global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, lrow = lane & 31;
+    const int tpi = a.tiles_y * a.tiles_x;
+    const int img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int oy0 = ty * a.TOY, ox0 = tx * a.TOX;
+    const int iy0 = oy0 * a.S - a.PH, ix0 = ox0 * a.S - a.PW;          // patch origin in the image (may be negative: padding)
+    const int plane_bytes = a.PR * a.RS * 2;
+    _Float16* hi = reinterpret_cast<_Float16*>(smem);
+    _Float16* lo = reinterpret_cast<_Float16*>(smem + plane_bytes);
+    float* red = reinterpret_cast<float*>(smem + 2 * plane_bytes);      // 4 partial maxima + the tile's scale
+
+    // ---- patch: HBM -> registers (pairs of consecutive elements of a patch row), max|x| on the way -------------------------------
+    constexpr int MAXP = 20;                     // pairs per thread (host: PR * RS / 2 <= 256 * MAXP)
+    const int ppr = a.RS >> 1;                   // pairs per LDS row
+    const int npairs = a.PR * ppr;
+    float v0[MAXP], v1[MAXP];
+    unsigned mx = 0;
+    const float* xi = a.x + (int64_t)img * a.sn;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = tid + i * 256;
+        float f0 = 0.0f, f1 = 0.0f;
+        if (p < npairs) {
+            const int r = divm(p, a.m_ppr, ppr), e = (p - r * ppr) * 2;
+            const int iy = iy0 + r;
+            if ((unsigned)iy < (unsigned)a.H) {
+                const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
+                int px1 = px0, c1 = c0 + 1;
+                if (c1 == a.Cp) { c1 = 0; ++px1; }
+                const int ixa = ix0 + px0, ixb = ix0 + px1;
+                const float* row = xi + (int64_t)iy * a.sh;
+                if (e < a.PCE && c0 < a.C && (unsigned)ixa < (unsigned)a.W) f0 = row[(int64_t)ixa * a.sw + (int64_t)c0 * a.sc];
+                if (e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W) f1 = row[(int64_t)ixb * a.sw + (int64_t)c1 * a.sc];
+            }
+        }
+        v0[i] = f0;
+        v1[i] = f1;
+        mx = max(mx, max(__float_as_uint(f0) & 0x7fffffffu, __float_as_uint(f1) & 0x7fffffffu));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if (lane == 0) red[wave] = __uint_as_float(mx);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned m = max(max(__float_as_uint(red[0]), __float_as_uint(red[1])), max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+        // s = 2^(e - 14) with e the exponent of max|x|: max|x| / s in [2^14, 2^15).  max|x| == 0 / subnormal, inf, NaN: s = 1 (an
+        // inf / NaN pixel then poisons its outputs through fp16 inf / NaN, as it does in the reference's fp32 conv)
+        const int eb = (int)(m >> 23);
+        float s = 1.0f;
+        if (eb > 0 && eb < 255) {
+            int se = eb - 14;                                  // biased exponent of s
+            se = se < 1 ? 1 : (se > 254 ? 254 : se);
+            s = __uint_as_float((unsigned)se << 23);
+        }
+        red[4] = s;
+        red[5] = 1.0f / s;                                     // exact (power of two within the normal range)
+    }
+    __syncthreads();
+    const float sx = red[4], isx = red[5];
+    uint32_t* hi32 = reinterpret_cast<uint32_t*>(hi);
+    uint32_t* lo32 = reinterpret_cast<uint32_t*>(lo);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = tid + i * 256;
+        if (p < npairs) {
+            const float t0 = v0[i] * isx, t1 = v1[i] * isx;
+            const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+            const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
+            uint16_t b0, b1, c0, c1;
+            __builtin_memcpy(&b0, &h0, 2); __builtin_memcpy(&b1, &h1, 2);
+            __builtin_memcpy(&c0, &l0, 2); __builtin_memcpy(&c1, &l1, 2);
+            hi32[p] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+            lo32[p] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop ---------------------------------------------------------------------------------------------------------------
+    const int mg = wave >> 1, ng = wave & 1;                   // this wave: m-tiles 2 mg, 2 mg + 1; n-tiles 3 ng .. 3 ng + 2
+    const int npix = a.TOY * a.TOX;
+    int abase[2];                                              // byte offset of the pixel's run start (ky = 0, chunk 0) in a plane
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int j = min((mg * 2 + mt) * 32 + lrow, npix - 1);
+        const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+        abase[mt] = ((oyl * a.S) * a.RS + oxl * a.S * a.Cp) * 2;
+    }
+    const int nt0 = blockIdx.y * 6 + ng * 3;                   // first of this wave's three 32-channel tiles
+    bool ntv[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) ntv[t] = (nt0 + t) * 32 < a.Coutp;
+    v16f acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
+
+    auto load_w = [&](int s, uint4 (&wh)[3], uint4 (&wl)[3]) {
+        const int64_t base = ((int64_t)s * 2 + half) * a.Coutp + (int64_t)nt0 * 32 + lrow;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (ntv[t]) {
+                wh[t] = a.whi[base + t * 32];
+                if constexpr (REALW) wl[t] = a.wlo[base + t * 32];
+            }
+        }
+    };
+    uint4 wh[3], wl[3], whn[3], wln[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wh[t] = wl[t] = whn[t] = wln[t] = make_uint4(0, 0, 0, 0);
+    load_w(0, wh, wl);
+    const unsigned char* hib = reinterpret_cast<const unsigned char*>(hi);
+    const unsigned char* lob = reinterpret_cast<const unsigned char*>(lo);
+    for (int s = 0; s < a.NKS; ++s) {
+        if (s + 1 < a.NKS) load_w(s + 1, whn, wln);
+        // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one (odd chunk count) re-read the last
+        // chunk — their weights are zero
+        const int q = min(2 * s + half, a.NCH - 1);
+        const int ky = divm(q, a.m_cpk, a.CPK), cc = q - ky * a.CPK;
+        const int koff = (ky * a.RS + cc * 8) * 2;
+        uint4 ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const uint2 h0 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff);
+            const uint2 h1 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff + 8);
+            const uint2 l0 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff);
+            const uint2 l1 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff + 8);
+            ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (ntv[t]) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][t] = mfma16(ah[mt], wh[t], acc[mt][t]);
+                    acc[mt][t] = mfma16(al[mt], wh[t], acc[mt][t]);
+                    if constexpr (REALW) acc[mt][t] = mfma16(ah[mt], wl[t], acc[mt][t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { wh[t] = whn[t]; wl[t] = wln[t]; }
+    }
+
+    // ---- epilogue: lane owns channel n = tile * 32 + lrow, rows (r & 3) + 8 (r >> 2) + 4 half of each 32-pixel tile ---------------
+    const float oscale = sx * (a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (!ntv[t]) continue;
+        const int n = (nt0 + t) * 32 + lrow;
+        const bool nin = n < a.Cout;
+        const float bv = (a.bias && nin) ? a.bias[n] : 0.0f;
+        const float al_ = (a.alpha && nin) ? a.alpha[n] : 0.0f, nbe = (a.alpha && nin) ? -a.beta[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int jb = (mg * 2 + mt) * 32;
+            if (a.alpha) {
+                uint32_t myword = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][t][r] * oscale + bv;
+                    const unsigned long long mask = __ballot(v * al_ < nbe);      // channels >= Cout: 0 < 0 -> bit 0
+                    const int R = (r & 3) + 8 * (r >> 2);
+                    if (lane == R) myword = (uint32_t)mask;
+                    if (lane == R + 4) myword = (uint32_t)(mask >> 32);
+                }
+                const int j = jb + lane;                                           // lanes 0 .. 31: one pixel each
+                if (lane < 32 && j < npix) {
+                    const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+                    const int oy = oy0 + oyl, ox = ox0 + oxl;
+                    if (oy < a.Ho && ox < a.Wo) {
+                        uint32_t* row = a.bits + (((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldb;
+                        row[nt0 + t] = myword;
+                        // the row's pad words (ldb rounds ceil(Cout / 32) up): written once, by the tile that holds the last channels
+                        if ((nt0 + t + 1) * 32 >= a.Coutp)
+                            for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
+                    }
+                }
+            } else if (nin) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (j < npix) {
+                        const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+                        const int oy = oy0 + oyl, ox = ox0 + oxl;
+                        if (oy < a.Ho && ox < a.Wo)
+                            a.y[(((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldy + n] = acc[mt][t][r] * oscale + bv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H, int64_t W,
+                      int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp, const uint32_t* whi, const uint32_t* wlo,
+                      float wscale, const float* wscale_dev, int64_t Cout, int64_t Coutp, const float* bias, float* y, int64_t ldy,
+                      const float* alpha, const float* beta, uint32_t* bits, int64_t ldb, qt_stream_t stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || S <= 0 || PH < 0 || PW < 0 || Cout < 0 || Cp < C)
+        return QT_ERR_INVALID_ARG;
+    const int64_t Ho = (H + 2 * PH - KH) / S + 1, Wo = (W + 2 * PW - KW) / S + 1;
+    if (Ho <= 0 || Wo <= 0) return QT_ERR_INVALID_ARG;
+    if (N == 0 || Cout == 0) return QT_OK;
+    if (!x || !whi || (Coutp & 31) || Coutp < Cout || !qt_aligned16(whi) || (wlo && !qt_aligned16(wlo))) return QT_ERR_INVALID_ARG;
+    if (alpha ? (!beta || !bits || ldb < (Cout + 31) / 32) : (!y || ldy < Cout)) return QT_ERR_INVALID_ARG;
+    if ((S * Cp) & 3) return QT_ERR_ALIGNMENT;                        // a pixel's run starts on an 8-byte LDS boundary
+    if (Cp > 8 || KW * Cp > 256 || KH > 64 || N * Ho * Wo > INT32_MAX || H > 32767 || W > 32767) return QT_ERR_UNSUPPORTED;
+    FirstArgs a;
+    a.x = x; a.sn = sn; a.sc = sc; a.sh = sh; a.sw = sw;
+    a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W; a.KH = (int)KH; a.KW = (int)KW; a.S = (int)S; a.PH = (int)PH; a.PW = (int)PW;
+    a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cp = (int)Cp;
+    a.CPK = (int)((KW * Cp + 7) / 8);
+    a.NCH = (int)(KH * a.CPK);
+    a.NKS = (a.NCH + 1) / 2;
+    // output tile: <= 128 pixels, as square as the map allows, sized to waste the fewest padded pixels
+    int best_ty = 1, best_tx = 1;
+    double best = 1e30;
+    for (int ty = 1; ty <= 128; ++ty)
+        for (int tx = 1; tx * ty <= 128; ++tx) {
+            if (tx * ty < 64 && tx * ty < Ho * Wo) continue;
+            const int64_t pr = (int64_t)(ty - 1) * S + KH, pce = ((int64_t)(tx - 1) * S + KW) * Cp;
+            const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.CPK * 8) + 3) / 4 * 4;
+            if (pr * rs / 2 > 256 * 20 || 2 * pr * rs * 2 + 64 > 72 * 1024) continue;
+            const int64_t tiles = ((Ho + ty - 1) / ty) * ((Wo + tx - 1) / tx);
+            // cost: MFMA work (128 rows per tile whatever it holds) + the patch it loads (halo re-reads)
+            const double cost = (double)tiles * (128.0 * a.NKS * 16 + 0.25 * (double)(pr * rs));
+            if (cost < best) { best = cost; best_ty = ty; best_tx = tx; }
+        }
+    if (best > 1e29) return QT_ERR_UNSUPPORTED;
+    a.TOY = best_ty; a.TOX = best_tx;
+    a.tiles_y = (int)((Ho + a.TOY - 1) / a.TOY); a.tiles_x = (int)((Wo + a.TOX - 1) / a.TOX);
+    a.PR = (a.TOY - 1) * a.S + a.KH;
+    a.PCE = ((a.TOX - 1) * a.S + a.KW) * a.Cp;
+    a.RS = (std::max(a.PCE, (a.TOX - 1) * a.S * a.Cp + a.CPK * 8) + 3) / 4 * 4;
+    auto magic = [](int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; };
+    a.m_ppr = magic(a.RS / 2); a.m_cp = magic(a.Cp); a.m_tox = magic(a.TOX); a.m_cpk = magic(a.CPK);
+    a.whi = reinterpret_cast<const uint4*>(whi);
+    a.wlo = reinterpret_cast<const uint4*>(wlo);
+    a.wscale = wscale;
+    a.wscale_dev = wscale_dev;
+    a.Cout = (int)Cout; a.Coutp = (int)Coutp;
+    a.bias = bias; a.y = y; a.ldy = ldy; a.alpha = alpha; a.beta = beta; a.bits = bits; a.ldb = ldb;
+    const int64_t nblk = N * a.tiles_y * a.tiles_x;
+    if (nblk > INT32_MAX) return QT_ERR_UNSUPPORTED;
+    const int lds = 2 * a.PR * a.RS * 2 + 64;
+    const dim3 grid((unsigned)nblk, (unsigned)((Coutp + 191) / 192));
+    if (wlo) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv_first_direct_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv_first_direct_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
+    return qt_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_conv_first_direct_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp, const uint32_t* w_hi,
+                             const uint32_t* w_lo, float w_scale, const float* w_scale_dev, int64_t Cout, int64_t Coutp,
+                             const float* bias, float* y, int64_t ldy, qt_stream_t stream) {
+    return first_direct_impl(x, sn, sc, sh, sw, N, C, H, W, KH, KW, S, PH, PW, Cp, w_hi, w_lo, w_scale, w_scale_dev, Cout, Coutp, bias,
+                             y, ldy, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int qt_conv_first_direct_bits_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H,
+                                  int64_t W, int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp,
+                                  const uint32_t* w_hi, const uint32_t* w_lo, float w_scale, const float* w_scale_dev, int64_t Cout,
+                                  int64_t Coutp, const float* bias, const float* alpha, const float* beta, uint32_t* neg_plane,
+                                  int64_t ldb, qt_stream_t stream) {
+    if (!alpha || !beta) return QT_ERR_INVALID_ARG;
+    return first_direct_impl(x, sn, sc, sh, sw, N, C, H, W, KH, KW, S, PH, PW, Cp, w_hi, w_lo, w_scale, w_scale_dev, Cout, Coutp, bias,
+                             nullptr, 0, alpha, beta, neg_plane, ldb, stream);
+}
+
+}  // extern "C"

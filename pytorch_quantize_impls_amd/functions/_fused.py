@@ -318,6 +318,25 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
         N, C, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        if ops.first_direct_applicable(C, (kh, kw), stride, padding, dilation):
+            # strided few-channel first layer (AlexNet conv1): the direct kernel reads the fp32 image where it lies, splits its
+            # patch in registers and contracts by stride addressing — no operand pack pass, no space-to-depth plane
+            fw = weight_triples_fn("first_direct") if weight_triples_fn is not None else None
+            if fw is None:
+                wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+                fw = ops.pack_first_layer_weight(wq, ops._pairs(stride)[0])
+            nib_epi = epi if isinstance(epi, ops.NibEpilogue) else None
+            y2 = ops.conv_first_direct(input, fw, bias, stride, padding,
+                                       epi=(nib_epi.alpha, nib_epi.beta) if nib_epi is not None else (epi[:2] if epi is not None else None))
+            if y2 is not None:
+                if epi is not None:
+                    if nib_epi is not None:
+                        y2 = ops.bits_to_nib_pad(y2, N, Ho, Wo, nib_epi.out_halo, ld=ops.pixel_ld_nib(y2.K))
+                    return y2, (N, int(weight.shape[0]), Ho, Wo)
+                y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+                if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous()
+                return y
         if USE_S2D and ops.s2d_applicable(C, kh, kw, stride, dilation, padding):
             # strided few-channel conv (conv1) == stride-1 conv on the space-to-depth image; the gather and
             # the exact bf16 split are one kernel, the transformed weight is cached by eval-mode layers

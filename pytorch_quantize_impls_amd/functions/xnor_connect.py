@@ -167,9 +167,15 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
             ctx.save_for_backward(input, weight, mean_weight, bias)
             if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0
                     and groups == 1 and not isinstance(padding, str)):
-                # sign(W) * alpha[kh, kw] is a REAL weight: six-term bf16 planes, implicit-GEMM conv on the
-                # matrix cores (fp32-GEMM accuracy); the result keeps the input's memory format
-                y2 = ops.real_conv2d(input, weight_b.detach(), bias, stride, padding, dilation)
+                # sign(W) * alpha[kh, kw] is a REAL weight.  A strided few-channel image (the first layer): the direct kernel with
+                # two-term fp16 weights (three products per element); anything else: six-term bf16 planes, implicit-GEMM conv on
+                # the matrix cores (fp32-GEMM accuracy).  The result keeps the input's memory format
+                y2 = None
+                if ops.first_direct_applicable(int(input.shape[1]), weight.shape[2:], stride, padding, dilation):
+                    fw = ops.pack_first_layer_weight(weight_b, ops._pairs(stride)[0], real=True)
+                    y2 = ops.conv_first_direct(input, fw, bias, stride, padding)
+                if y2 is None:
+                    y2 = ops.real_conv2d(input, weight_b.detach(), bias, stride, padding, dilation)
                 if y2 is not None:
                     N_, _, H, W = input.shape
                     Ho, Wo = ops.conv_out_hw(H, W, weight.shape[2], weight.shape[3], stride, padding, dilation)

@@ -552,9 +552,17 @@ class FusedConvPoolBnSign(torch.nn.Module):
             return out[0], shape
         # the op quantises the eval image AGAIN (sign(w) * mean|w| of values that are already +-alpha: the fp32 mean of n equal
         # numbers is not that number to the last bit), like upstream and like the layer's own forward: same image, same bits
-        wt = conv._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x6(ops.xnor_weight(conv.weight.detach(), 2)[0]),
-                               key="conv_bf16x6")
-        y = ops.real_conv2d(x, conv.weight.detach(), conv.bias, conv.stride, conv.padding, conv.dilation, weight_planes=wt, epi=e2)
+        y = None
+        if ops.first_direct_applicable(C, (kh, kw), conv.stride, conv.padding, conv.dilation):
+            fw = conv._eval_planes(lambda _w2: ops.pack_first_layer_weight(ops.xnor_weight(conv.weight.detach(), 2)[0],
+                                                                           conv.stride[0], real=True), key="first_direct_real")
+            y = ops.conv_first_direct(x, fw, conv.bias, conv.stride, conv.padding, epi=(epi[0], epi[1]))
+            if y is not None and nib_out:
+                y = ops.bits_to_nib_pad(y, N, Ho, Wo, self.out_nib_halo, ld=ops.pixel_ld_nib(y.K))
+        if y is None:
+            wt = conv._eval_planes(lambda _w2: ops.pack_conv_weight_bf16x6(ops.xnor_weight(conv.weight.detach(), 2)[0]),
+                                   key="conv_bf16x6")
+            y = ops.real_conv2d(x, conv.weight.detach(), conv.bias, conv.stride, conv.padding, conv.dilation, weight_planes=wt, epi=e2)
         if y is None:
             raise ValueError("XNOR conv outside the implicit kernel's limits")
         return y, shape

@@ -2461,6 +2461,103 @@ def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_sh
     return dW
 
 
+# ---- direct first-layer conv (csrc/conv_first_direct.hip) ---------------------------------------------------------------------------
+
+#: strided few-channel first layers (AlexNet's 3 -> 192, 11 x 11, stride 4) run on the direct kernel: the fp32 image is read once,
+#: split in registers and contracted by stride addressing of an LDS patch (False: the space-to-depth pack + implicit GEMM of round 3)
+FIRST_DIRECT = True
+
+
+@dataclass
+class FirstLayerWeights:
+    """Packed weight of the direct first-layer conv: fp16 chunks [k-steps][2][Coutp][8] (int16 storage), ``lo`` / ``scale_dev`` for
+    real-valued weights (w / scale = hi + lo), geometry the planes were built for."""
+    hi: torch.Tensor
+    lo: Optional[torch.Tensor]
+    scale_dev: Optional[torch.Tensor]
+    Cout: int
+    Coutp: int
+    Cp: int
+    kernel_hw: tuple
+
+
+def first_direct_cp(C: int, S: int) -> int:
+    """Channels per pixel of the kernel's LDS patch: the smallest Cp >= C with S * Cp % 4 == 0 (8-byte aligned pixel runs)."""
+    cp = int(C)
+    while (int(S) * cp) % 4:
+        cp += 1
+    return cp
+
+
+def first_direct_applicable(C: int, kernel_hw, stride, padding, dilation) -> bool:
+    (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
+    kh, kw = (int(v) for v in kernel_hw)
+    if not (FIRST_DIRECT and sh == sw and sh >= 2 and (dh, dw) == (1, 1) and not isinstance(padding, str) and kh >= sh and kw >= sw):
+        return False
+    cp = first_direct_cp(C, sh)
+    return int(C) <= 4 and cp <= 8 and kw * cp <= 256 and kh <= 64
+
+
+def pack_first_layer_weight(wq: torch.Tensor, stride: int, real: bool = False) -> FirstLayerWeights:
+    """[Cout, C, kh, kw] QUANTISED weight image (fp32) -> the direct kernel's fragment order.  ``real``: the values are not exact in
+    fp16 (XNOR-Net's sign(W) * alpha): two fp16 terms of w / s with the tensor's power-of-two s (max|w| / s in [2^14, 2^15)), found on
+    the device.  Weights are tiny: plain torch ops, cached by eval-mode layers."""
+    wq = _require(wq.detach(), "weight")
+    Cout, C, kh, kw = (int(v) for v in wq.shape)
+    Cp = first_direct_cp(C, stride)
+    cpk = (kw * Cp + 7) // 8
+    nch = kh * cpk
+    nks = (nch + 1) // 2
+    Coutp = (Cout + 31) // 32 * 32
+    F = torch.nn.functional
+    scale = None
+    if real:
+        _, e = torch.frexp(wq.abs().amax())                      # max = m 2^e, m in [0.5, 1): max / 2^(e - 15) in [2^14, 2^15)
+        scale = torch.ldexp(torch.ones((), dtype=torch.float32, device=wq.device), e - 15).reshape(1)
+        wq = wq / scale
+
+    def frag(t):                                                # [Cout, C, kh, kw] fp32 -> [nks, 2, Coutp, 8] fp16
+        t = F.pad(t.permute(0, 2, 3, 1), (0, Cp - C)).reshape(Cout, kh, kw * Cp)
+        t = F.pad(t, (0, cpk * 8 - kw * Cp)).reshape(Cout, nch * 8)
+        t = F.pad(t, (0, nks * 16 - nch * 8, 0, Coutp - Cout)).reshape(Coutp, nks, 2, 8)
+        return t.permute(1, 2, 0, 3).contiguous()
+    hi = frag(wq).to(torch.float16)
+    lo = None
+    if real:
+        lo = frag(wq).sub_(hi.float()).to(torch.float16).view(torch.int16)
+    return FirstLayerWeights(hi=hi.view(torch.int16), lo=lo, scale_dev=scale, Cout=Cout, Coutp=Coutp, Cp=Cp, kernel_hw=(kh, kw))
+
+
+def conv_first_direct(x: torch.Tensor, fw: FirstLayerWeights, bias=None, stride=1, padding=0, epi=None):
+    """Direct first-layer conv of a real-valued [N, C, H, W] fp32 image (any storage order).  Returns the NHWC result
+    [N*Ho*Wo, Cout] fp32, or with ``epi`` = (alpha, beta) the BitPlanes of the BatchNorm-threshold bits; None when the shape is
+    outside the kernel's limits."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    kh, kw = fw.kernel_hw
+    s = _pairs(stride)[0]
+    ph, pw = _pairs(padding)
+    Ho, Wo = (H + 2 * ph - kh) // s + 1, (W + 2 * pw - kw) // s + 1
+    if Ho <= 0 or Wo <= 0 or N * Ho * Wo >= (1 << 31) or H > 32767 or W > 32767 or N == 0:
+        return None
+    dev = x.device
+    bias = _check_bias(bias, fw.Cout, dev)
+    sN, sC, sH, sW = (int(v) for v in x.stride())
+    head = (_p(x), sN, sC, sH, sW, N, C, H, W, kh, kw, s, ph, pw, int(fw.Cp), _p(fw.hi), _p(fw.lo), 1.0, _p(fw.scale_dev),
+            int(fw.Cout), int(fw.Coutp), _p(bias))
+    if epi is not None:
+        alpha, beta = _check_bias(epi[0], fw.Cout, dev), _check_bias(epi[1], fw.Cout, dev)
+        ldb = packed_ld(fw.Cout)
+        plane = torch.empty((N * Ho * Wo, ldb), dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv_first_direct_bits_f32", *head, _p(alpha), _p(beta), _p(plane), int(ldb), _stream(dev))
+        return BitPlanes(sign=plane, rows=N * Ho * Wo, K=fw.Cout)
+    y = torch.empty((N * Ho * Wo, fw.Cout), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.call("qt_conv_first_direct_f32", *head, _p(y), int(fw.Cout), _stream(dev))
+    return y
+
+
 def s2d_applicable(C: int, kh: int, kw: int, stride, dilation, padding=0) -> bool:
     """Strided first-layer style convs (few input channels) are re-expressed as stride-1 convs on the
     space-to-depth image: no padding waste in the pixel planes and ~(k/ceil(k/s)s)^2 of the K bytes.  With stride 1

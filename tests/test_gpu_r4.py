@@ -384,3 +384,76 @@ def test_linear_xnor_on_packed_bits_vs_oracle(dev, oracle, B, K, N):
     # xnor_connect.py:112): a column with an exact zero gets alpha * (N - 1) / N the second time
     want = oracle.xnor_dense_forward(x, oracle.xnor_dense_weight(w), b)
     assert norm_err(n(y), want) <= TOL and norm_err(n(y2), want) <= TOL
+
+
+# ---- direct first-layer conv (csrc/conv_first_direct.hip) ----------------------------------------------------------------------------
+
+FIRST_SHAPES = [
+    # N, C, H, W, Cout, k, s, p
+    (2, 3, 224, 224, 192, 11, 4, 2),        # AlexNet conv1 (models/Alexnet/Alexnet_Bin.py:13)
+    (3, 3, 67, 45, 72, 11, 4, 2),           # ragged map, channel tail (72 = 2 tiles + 8)
+    (2, 3, 30, 34, 200, 7, 2, 3),           # stride 2: channels padded 3 -> 4 in the patch; two channel blocks (grid.y = 2)
+    (2, 1, 28, 28, 40, 5, 2, 0),            # one channel, no padding
+    (1, 4, 33, 31, 64, 8, 4, 1),            # 4 channels, even kernel
+    (2, 3, 19, 19, 24, 5, 3, 2),            # stride 3 (Cp = 4)
+    (5, 2, 16, 40, 33, 4, 4, 0),            # kernel == stride
+]
+
+
+@pytest.mark.parametrize("shape", FIRST_SHAPES)
+@pytest.mark.parametrize("kind", ["binary", "ternary", "xnor"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_first_layer_direct_conv_vs_oracle(dev, oracle, shape, kind, channels_last):
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d
+    N, C, H, W, Cout, k, s, p = shape
+    seed = N * 100 + H + Cout
+    x = synth.normal(seed, (N, C, H, W)) * 2.0
+    x[0, 0, :3, :3] *= 37.0                          # a tile whose range differs from its neighbours' (per-tile scale)
+    w = synth.uniform(seed + 1, (Cout, C, k, k), -1.3, 1.3)
+    b = synth.normal(seed + 2, (Cout,))
+    cls = {"binary": BinConv2d, "ternary": TerConv2d, "xnor": XNORConv2d}[kind]
+    conv = cls(C, Cout, k, stride=s, padding=p).to(dev)
+    conv.weight.data.copy_(t32(w, dev))
+    conv.bias.data.copy_(t32(b, dev))
+    conv.binary_input = False
+    xd = t32(x, dev)
+    if channels_last:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    want = {"binary": lambda: oracle.bin_conv2d_forward(x, w, b, s, p), "ternary": lambda: oracle.ter_conv2d_forward(x, w, b, s, p),
+            "xnor": lambda: oracle.xnor_conv2d_forward(x, w, b, s, p)}[kind]()
+    for mode in ("train", "eval"):
+        conv.train(mode == "train")
+        before = dict(_lib.call_counts)
+        with torch.no_grad(), lazy.eager():
+            y = conv(xd)
+        assert _lib.call_counts["qt_conv_first_direct_f32"] == before.get("qt_conv_first_direct_f32", 0) + 1, mode
+        assert tuple(y.shape) == want.shape
+        assert norm_err(n(y), want) <= TOL, (mode, norm_err(n(y), want))
+
+
+def test_first_layer_direct_conv_threshold_bits_equal_the_unfused_chain(dev):
+    """conv1 -> MaxPool -> BatchNorm -> Hardtanh -> BinaryConnect deferred (direct kernel with the threshold epilogue + pooling on
+    bits) against the same modules run one by one: identical sign planes."""
+    from pytorch_quantize_impls_amd.layers import BinConv2d
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    torch.manual_seed(5)
+    for cls in (BinConv2d, XNORConv2d):
+        conv = cls(3, 192, 11, stride=4, padding=2).to(dev)
+        conv.weight.data.normal_(0, 0.3)
+        conv.binary_input = False
+        bn = torch.nn.BatchNorm2d(192).to(dev)
+        bn.running_mean.normal_(0, 3.0)
+        bn.running_var.uniform_(5, 50)
+        bn.weight.data.normal_(0, 1.0)
+        seq = torch.nn.Sequential(conv, torch.nn.MaxPool2d(3, 2), bn, torch.nn.Hardtanh(), BinaryConnect()).eval()
+        x = torch.randn(6, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+        before = dict(_lib.call_counts)
+        with torch.no_grad():
+            d = seq(x)
+            assert isinstance(d, lazy.LazyActivation)
+            bits = d._qt.force().planes.sign.clone()
+            with lazy.eager():
+                e = seq(x)
+        assert _lib.call_counts["qt_conv_first_direct_bits_f32"] == before.get("qt_conv_first_direct_bits_f32", 0) + 1
+        want = ops.sign_pack(e.permute(0, 2, 3, 1).contiguous())[0].sign
+        assert torch.equal(bits, want), cls.__name__
