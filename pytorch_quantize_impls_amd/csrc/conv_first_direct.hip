@@ -19,6 +19,7 @@
 //     products hi whi + lo whi + hi wlo;
 //   * 4 waves, each 2 (m) x 3 (n) accumulator tiles of 32 x 32; two workgroups per CU overlap each other's patch prologue.
 // Epilogues: fp32 NHWC (+ bias), or the BatchNorm-threshold bits of the fused inference chain (qt_conv2d_implicit_bits' float form).
+#include <cstdlib>
 #include "qt_common.h"
 
 namespace {
@@ -32,7 +33,7 @@ struct FirstArgs {
     int N, C, H, W, KH, KW, S, PH, PW, Ho, Wo;
     int Cp;                            // channels per pixel in the LDS patch (C, or padded so that S * Cp % 4 == 0)
     int CPK;                           // 16-byte chunks per ky row = ceil(KW * Cp / 8)
-    int NCH, NKS;                      // chunks = KH * CPK, k-steps = ceil(NCH / 2)
+    int NCH, NKS;                      // chunks = KH * CPK, k-steps = ceil(NCH / 2) rounded up to 4
     int TOY, TOX, tiles_y, tiles_x;
     int PR, PCE, RS;                   // patch rows, real elements per patch row (PC * Cp), LDS row stride in elements (% 4 == 0)
     unsigned m_ppr, m_cp, m_tox, m_cpk; // floor(2^32 / d) + 1 for d = RS / 2, Cp, TOX, CPK: q / d == __umulhi(q, m) for q < 2^16 (d > 1)
@@ -48,6 +49,7 @@ struct FirstArgs {
     const float* beta;
     uint32_t* bits;
     int64_t ldb;
+    int step_r, step_pc, rows_dense;    // patch loader: 256 / (RS / 2), 256 % (RS / 2); channels-last image read as float2 spans
 };
 
 __device__ __forceinline__ int divm(int q, unsigned magic, int d) { return d == 1 ? q : (int)__umulhi((unsigned)q, magic); }
@@ -59,89 +61,139 @@ __device__ __forceinline__ v16f mfma16(const uint4& a, const uint4& b, v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
-// REALW: the weight is real-valued (two fp16 terms); otherwise +-1 / 0 (one fragment)
-template <bool REALW>
+// REALW: the weight is real-valued (two fp16 terms); otherwise +-1 / 0 (one fragment).  MAXP: pairs of patch elements a thread holds.
+//
+// Persistent workgroups (two per CU), tiles b, b + G, b + 2G, ...: the patch of the NEXT tile is requested from HBM into
+// registers before the MFMA loop of the current tile starts and is converted / written to the other LDS patch buffer after it, so a
+// workgroup's HBM latency and its split arithmetic sit under MFMA time (its own and the co-resident workgroup's) instead of in
+// front of it — with one tile per workgroup the two workgroups of a CU run their prologues, loops and epilogues in lockstep.
+template <bool REALW, int MAXP>
 __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, lrow = lane & 31;
     const int tpi = a.tiles_y * a.tiles_x;
-    const int img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-    const int oy0 = ty * a.TOY, ox0 = tx * a.TOX;
-    const int iy0 = oy0 * a.S - a.PH, ix0 = ox0 * a.S - a.PW;          // patch origin in the image (may be negative: padding)
+    const int ntiles = a.N * tpi;
     const int plane_bytes = a.PR * a.RS * 2;
-    _Float16* hi = reinterpret_cast<_Float16*>(smem);
-    _Float16* lo = reinterpret_cast<_Float16*>(smem + plane_bytes);
-    float* red = reinterpret_cast<float*>(smem + 2 * plane_bytes);      // 4 partial maxima + the tile's scale
-
-    // ---- patch: HBM -> registers (pairs of consecutive elements of a patch row), max|x| on the way -------------------------------
-    constexpr int MAXP = 20;                     // pairs per thread (host: PR * RS / 2 <= 256 * MAXP)
+    const int buf_bytes = 2 * plane_bytes;                                   // [hi plane | lo plane]
+    float* red = reinterpret_cast<float*>(smem + 2 * buf_bytes);           // per buffer: 4 partial maxima, scale, 1 / scale
     const int ppr = a.RS >> 1;                   // pairs per LDS row
     const int npairs = a.PR * ppr;
-    float v0[MAXP], v1[MAXP];
-    unsigned mx = 0;
-    const float* xi = a.x + (int64_t)img * a.sn;
+
+    float v0[MAXP], v1[MAXP];                    // the patch in flight: pairs p = tid + 256 i of consecutive elements of a patch row
+    const int r_first = divm(tid, a.m_ppr, ppr), pc_first = tid - r_first * ppr;
+
+    auto tile_origin = [&](int tile, int& img, int& oy0, int& ox0) __attribute__((always_inline)) {
+        img = tile / tpi;
+        const int trem = tile - img * tpi;
+        const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+        oy0 = ty * a.TOY;
+        ox0 = tx * a.TOX;
+    };
+
+    // ---- patch: HBM -> registers ---------------------------------------------------------------------------------------------------
+    auto issue_patch = [&](int tile) __attribute__((always_inline)) {
+        int img, oy0, ox0;
+        tile_origin(tile, img, oy0, ox0);
+        const int iy0 = oy0 * a.S - a.PH, ix0 = ox0 * a.S - a.PW;          // patch origin in the image (may be negative: padding)
+        const float* xi = a.x + (int64_t)img * a.sn;
+        int r = r_first, pc = pc_first, tid_t = tid;
+        asm volatile("" : "+v"(r), "+v"(pc), "+v"(tid_t));      // per tile opaque: the 16 (row, column) pairs are loop-invariant (see the epilogue)
+        if (a.rows_dense) {
+            // channels-last image, no channel padding: a patch row is ONE contiguous span of the image row, starting at element
+            // ix0 * C (even: 8-byte aligned float2 loads); spans are clipped against the row for the zero padding
+            const int g0 = ix0 * a.C, gend = a.W * a.C;
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int p = tid + i * 256;
-        float f0 = 0.0f, f1 = 0.0f;
-        if (p < npairs) {
-            const int r = divm(p, a.m_ppr, ppr), e = (p - r * ppr) * 2;
-            const int iy = iy0 + r;
-            if ((unsigned)iy < (unsigned)a.H) {
-                const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
-                int px1 = px0, c1 = c0 + 1;
-                if (c1 == a.Cp) { c1 = 0; ++px1; }
-                const int ixa = ix0 + px0, ixb = ix0 + px1;
-                const float* row = xi + (int64_t)iy * a.sh;
-                if (e < a.PCE && c0 < a.C && (unsigned)ixa < (unsigned)a.W) f0 = row[(int64_t)ixa * a.sw + (int64_t)c0 * a.sc];
-                if (e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W) f1 = row[(int64_t)ixb * a.sw + (int64_t)c1 * a.sc];
+            for (int i = 0; i < MAXP; ++i) {
+                float f0 = 0.0f, f1 = 0.0f;
+                if (tid_t + i * 256 < npairs) {
+                    const int iy = iy0 + r, e = 2 * pc, g = g0 + e;
+                    if ((unsigned)iy < (unsigned)a.H && e < a.PCE) {
+                        const float* row = xi + (int64_t)iy * a.sh;
+                        if (g >= 0 && g + 1 < gend && e + 1 < a.PCE) {
+                            const float2 v = *reinterpret_cast<const float2*>(row + g);
+                            f0 = v.x;
+                            f1 = v.y;
+                        } else {
+                            if (g >= 0 && g < gend) f0 = row[g];
+                            if (g + 1 >= 0 && g + 1 < gend && e + 1 < a.PCE) f1 = row[g + 1];
+                        }
+                    }
+                }
+                v0[i] = f0;
+                v1[i] = f1;
+                r += a.step_r;
+                pc += a.step_pc;
+                if (pc >= ppr) { pc -= ppr; ++r; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                float f0 = 0.0f, f1 = 0.0f;
+                if (tid_t + i * 256 < npairs) {
+                    const int e = 2 * pc;
+                    const int iy = iy0 + r;
+                    if ((unsigned)iy < (unsigned)a.H) {
+                        const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
+                        int px1 = px0, c1 = c0 + 1;
+                        if (c1 == a.Cp) { c1 = 0; ++px1; }
+                        const int ixa = ix0 + px0, ixb = ix0 + px1;
+                        const float* row = xi + (int64_t)iy * a.sh;
+                        if (e < a.PCE && c0 < a.C && (unsigned)ixa < (unsigned)a.W) f0 = row[(int64_t)ixa * a.sw + (int64_t)c0 * a.sc];
+                        if (e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W) f1 = row[(int64_t)ixb * a.sw + (int64_t)c1 * a.sc];
+                    }
+                }
+                v0[i] = f0;
+                v1[i] = f1;
+                r += a.step_r;
+                pc += a.step_pc;
+                if (pc >= ppr) { pc -= ppr; ++r; }
             }
         }
-        v0[i] = f0;
-        v1[i] = f1;
-        mx = max(mx, max(__float_as_uint(f0) & 0x7fffffffu, __float_as_uint(f1) & 0x7fffffffu));
-    }
+    };
+
+    // ---- registers -> two fp16 planes in LDS buffer `buf` with the tile's power-of-two scale (two barriers) -----------------------
+    auto finish_patch = [&](int buf) __attribute__((always_inline)) {
+        unsigned mx = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    if (lane == 0) red[wave] = __uint_as_float(mx);
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned m = max(max(__float_as_uint(red[0]), __float_as_uint(red[1])), max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+        for (int i = 0; i < MAXP; ++i) mx = max(mx, max(__float_as_uint(v0[i]) & 0x7fffffffu, __float_as_uint(v1[i]) & 0x7fffffffu));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        float* rb = red + buf * 8;
+        if (lane == 0) rb[wave] = __uint_as_float(mx);
+        __syncthreads();           // every wave is past the MFMA loop that read this buffer's predecessor; partial maxima visible
         // s = 2^(e - 14) with e the exponent of max|x|: max|x| / s in [2^14, 2^15).  max|x| == 0 / subnormal, inf, NaN: s = 1 (an
         // inf / NaN pixel then poisons its outputs through fp16 inf / NaN, as it does in the reference's fp32 conv)
+        const unsigned m = max(max(__float_as_uint(rb[0]), __float_as_uint(rb[1])), max(__float_as_uint(rb[2]), __float_as_uint(rb[3])));
         const int eb = (int)(m >> 23);
-        float s = 1.0f;
+        float sc = 1.0f;
         if (eb > 0 && eb < 255) {
             int se = eb - 14;                                  // biased exponent of s
             se = se < 1 ? 1 : (se > 254 ? 254 : se);
-            s = __uint_as_float((unsigned)se << 23);
+            sc = __uint_as_float((unsigned)se << 23);
         }
-        red[4] = s;
-        red[5] = 1.0f / s;                                     // exact (power of two within the normal range)
-    }
-    __syncthreads();
-    const float sx = red[4], isx = red[5];
-    uint32_t* hi32 = reinterpret_cast<uint32_t*>(hi);
-    uint32_t* lo32 = reinterpret_cast<uint32_t*>(lo);
+        const float isx = 1.0f / sc;                           // exact (power of two within the normal range)
+        if (tid == 0) rb[4] = sc;
+        uint32_t* hi32 = reinterpret_cast<uint32_t*>(smem + buf * buf_bytes);
+        uint32_t* lo32 = reinterpret_cast<uint32_t*>(smem + buf * buf_bytes + plane_bytes);
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int p = tid + i * 256;
-        if (p < npairs) {
-            const float t0 = v0[i] * isx, t1 = v1[i] * isx;
-            const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
-            const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
-            uint16_t b0, b1, c0, c1;
-            __builtin_memcpy(&b0, &h0, 2); __builtin_memcpy(&b1, &h1, 2);
-            __builtin_memcpy(&c0, &l0, 2); __builtin_memcpy(&c1, &l1, 2);
-            hi32[p] = (uint32_t)b0 | ((uint32_t)b1 << 16);
-            lo32[p] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = tid + i * 256;
+            if (p < npairs) {
+                const float t0 = v0[i] * isx, t1 = v1[i] * isx;
+                const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+                const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
+                uint16_t b0, b1, c0, c1;
+                __builtin_memcpy(&b0, &h0, 2); __builtin_memcpy(&b1, &h1, 2);
+                __builtin_memcpy(&c0, &l0, 2); __builtin_memcpy(&c1, &l1, 2);
+                hi32[p] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+                lo32[p] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+    };
 
-    // ---- main loop ---------------------------------------------------------------------------------------------------------------
+    // ---- per-wave constants of the MFMA loop -----------------------------------------------------------------------------------------
     const int mg = wave >> 1, ng = wave & 1;                   // this wave: m-tiles 2 mg, 2 mg + 1; n-tiles 3 ng .. 3 ng + 2
     const int npix = a.TOY * a.TOX;
     int abase[2];                                              // byte offset of the pixel's run start (ky = 0, chunk 0) in a plane
@@ -152,112 +204,149 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         abase[mt] = ((oyl * a.S) * a.RS + oxl * a.S * a.Cp) * 2;
     }
     const int nt0 = blockIdx.y * 6 + ng * 3;                   // first of this wave's three 32-channel tiles
-    bool ntv[3];
+    // (branch-free main loop: a wave whose channel tiles lie past Coutp computes on the last valid tile's fragments and drops the
+    // result; the k-step count is a multiple of 4 — zero k-steps appended by the weight pack — and loads past the end re-read the
+    // last k-step.  With conditionals in the loop hipcc puts s_waitcnt vmcnt(0) in front of every MFMA group: the whole L2
+    // latency of the prefetch just issued, per k-step.)
+    const int ntl = a.Coutp / 32 - 1;
+    int64_t wbase[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) ntv[t] = (nt0 + t) * 32 < a.Coutp;
-    v16f acc[2][3];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
-
-    auto load_w = [&](int s, uint4 (&wh)[3], uint4 (&wl)[3]) {
-        const int64_t base = ((int64_t)s * 2 + half) * a.Coutp + (int64_t)nt0 * 32 + lrow;
+    for (int t = 0; t < 3; ++t) wbase[t] = (int64_t)half * a.Coutp + (int64_t)min(nt0 + t, ntl) * 32 + lrow;
+    const int64_t wstep = 2 * (int64_t)a.Coutp;                 // 16-byte chunks per k-step
+    auto load_w = [&](int s, uint4 (&wh)[3], uint4 (&wl)[3]) __attribute__((always_inline)) {
+        const int64_t o = (int64_t)min(s, a.NKS - 1) * wstep;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            if (ntv[t]) {
-                wh[t] = a.whi[base + t * 32];
-                if constexpr (REALW) wl[t] = a.wlo[base + t * 32];
-            }
+            wh[t] = a.whi[o + wbase[t]];
+            if constexpr (REALW) wl[t] = a.wlo[o + wbase[t]];
         }
     };
-    uint4 wh[3], wl[3], whn[3], wln[3];
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;                                // uniform
+    int buf = 0;
+    issue_patch(tile);
+    finish_patch(0);
+    while (true) {
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;                       // uniform
+        if (more) issue_patch(next);                           // in flight across the MFMA loop below
+
+        const unsigned char* hib = smem + buf * buf_bytes;
+        const unsigned char* lob = hib + plane_bytes;
+        auto load_a = [&](int s, uint4 (&ah)[2], uint4 (&al)[2]) __attribute__((always_inline)) {
+            // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one re-read the last chunk (zero weights)
+            const int q = min(2 * s + half, a.NCH - 1);
+            const int ky = divm(q, a.m_cpk, a.CPK), cc = q - ky * a.CPK;
+            const int koff = (ky * a.RS + cc * 8) * 2;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) wh[t] = wl[t] = whn[t] = wln[t] = make_uint4(0, 0, 0, 0);
-    load_w(0, wh, wl);
-    const unsigned char* hib = reinterpret_cast<const unsigned char*>(hi);
-    const unsigned char* lob = reinterpret_cast<const unsigned char*>(lo);
-    for (int s = 0; s < a.NKS; ++s) {
-        if (s + 1 < a.NKS) load_w(s + 1, whn, wln);
-        // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one (odd chunk count) re-read the last
-        // chunk — their weights are zero
-        const int q = min(2 * s + half, a.NCH - 1);
-        const int ky = divm(q, a.m_cpk, a.CPK), cc = q - ky * a.CPK;
-        const int koff = (ky * a.RS + cc * 8) * 2;
-        uint4 ah[2], al[2];
+            for (int mt = 0; mt < 2; ++mt) {
+                const uint2 h0 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff);
+                const uint2 h1 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff + 8);
+                const uint2 l0 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff);
+                const uint2 l1 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff + 8);
+                ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        };
+        v16f acc[2][3];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const uint2 h0 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff);
-            const uint2 h1 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff + 8);
-            const uint2 l0 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff);
-            const uint2 l1 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff + 8);
-            ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
+        // software pipeline: the weight fragments of k-step s + WD (L2 latency ~ 2-3 k-steps of MFMA time) and the patch fragments
+        // of k-step s + 1 (LDS latency) are requested before the MFMAs of k-step s issue; rings indexed by the unrolled position
+        constexpr int WD = 1, RING = 2;                          // (the unrolled group of 4 k-steps must be a multiple of the ring)
+        static_assert(4 % RING == 0, "ring slots are indexed by the unrolled position");
+        uint4 wh[RING][3], wl[RING][3], ah[2][2], al[2][2];
+#pragma unroll
+        for (int u = 0; u < WD; ++u) load_w(u, wh[u], wl[u]);
+        load_a(0, ah[0], al[0]);
+        for (int s0 = 0; s0 < a.NKS; s0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u;
+                load_w(s + WD, wh[(u + WD) % RING], wl[(u + WD) % RING]);
+                load_a(s + 1, ah[(u + 1) & 1], al[(u + 1) & 1]);
+                // one term at a time over the six accumulator tiles: two MFMAs on the same accumulator are never adjacent
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wh[u % RING][t], acc[mt][t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(al[u & 1][mt], wh[u % RING][t], acc[mt][t]);
+                if constexpr (REALW) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wl[u % RING][t], acc[mt][t]);
+                }
+            }
         }
+
+        // ---- epilogue: lane owns channel n = tile * 32 + lrow, rows (r & 3) + 8 (r >> 2) + 4 half of each 32-pixel tile ------------
+        // (the lane's coordinates are made opaque per tile: everything below that depends only on them — 32 pixel offsets, the
+        // channel constants — is loop-invariant, and hipcc otherwise hoists it out of the tile loop into 200 spilled registers)
+        int lane_t = lane, half_t = half, lrow_t = lrow;
+        asm volatile("" : "+v"(lane_t), "+v"(half_t), "+v"(lrow_t));
+        int img, oy0, ox0;
+        tile_origin(tile, img, oy0, ox0);
+        const float sx = red[buf * 8 + 4];
+        const float oscale = sx * (a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            if (ntv[t]) {
+            if ((nt0 + t) * 32 >= a.Coutp) continue;
+            const int n = (nt0 + t) * 32 + lrow_t;
+            const bool nin = n < a.Cout;
+            const float bv = (a.bias && nin) ? a.bias[n] : 0.0f;
+            const float al_ = (a.alpha && nin) ? a.alpha[n] : 0.0f, nbe = (a.alpha && nin) ? -a.beta[n] : 0.0f;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[mt][t] = mfma16(ah[mt], wh[t], acc[mt][t]);
-                    acc[mt][t] = mfma16(al[mt], wh[t], acc[mt][t]);
-                    if constexpr (REALW) acc[mt][t] = mfma16(ah[mt], wl[t], acc[mt][t]);
-                }
-            }
-        }
+            for (int mt = 0; mt < 2; ++mt) {
+                const int jb = (mg * 2 + mt) * 32;
+                if (a.alpha) {
+                    uint32_t myword = 0;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { wh[t] = whn[t]; wl[t] = wln[t]; }
-    }
-
-    // ---- epilogue: lane owns channel n = tile * 32 + lrow, rows (r & 3) + 8 (r >> 2) + 4 half of each 32-pixel tile ---------------
-    const float oscale = sx * (a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        if (!ntv[t]) continue;
-        const int n = (nt0 + t) * 32 + lrow;
-        const bool nin = n < a.Cout;
-        const float bv = (a.bias && nin) ? a.bias[n] : 0.0f;
-        const float al_ = (a.alpha && nin) ? a.alpha[n] : 0.0f, nbe = (a.alpha && nin) ? -a.beta[n] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int jb = (mg * 2 + mt) * 32;
-            if (a.alpha) {
-                uint32_t myword = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[mt][t][r] * oscale + bv;
-                    const unsigned long long mask = __ballot(v * al_ < nbe);      // channels >= Cout: 0 < 0 -> bit 0
-                    const int R = (r & 3) + 8 * (r >> 2);
-                    if (lane == R) myword = (uint32_t)mask;
-                    if (lane == R + 4) myword = (uint32_t)(mask >> 32);
-                }
-                const int j = jb + lane;                                           // lanes 0 .. 31: one pixel each
-                if (lane < 32 && j < npix) {
-                    const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
-                    const int oy = oy0 + oyl, ox = ox0 + oxl;
-                    if (oy < a.Ho && ox < a.Wo) {
-                        uint32_t* row = a.bits + (((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldb;
-                        row[nt0 + t] = myword;
-                        // the row's pad words (ldb rounds ceil(Cout / 32) up): written once, by the tile that holds the last channels
-                        if ((nt0 + t + 1) * 32 >= a.Coutp)
-                            for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[mt][t][r] * oscale + bv;
+                        const unsigned long long mask = __ballot(v * al_ < nbe);      // channels >= Cout: 0 < 0 -> bit 0
+                        const int R = (r & 3) + 8 * (r >> 2);
+                        if (lane_t == R) myword = (uint32_t)mask;
+                        if (lane_t == R + 4) myword = (uint32_t)(mask >> 32);
                     }
-                }
-            } else if (nin) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (j < npix) {
+                    const int j = jb + lane_t;                                          // lanes 0 .. 31: one pixel each
+                    if (lane_t < 32 && j < npix) {
                         const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
                         const int oy = oy0 + oyl, ox = ox0 + oxl;
-                        if (oy < a.Ho && ox < a.Wo)
-                            a.y[(((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldy + n] = acc[mt][t][r] * oscale + bv;
+                        if (oy < a.Ho && ox < a.Wo) {
+                            uint32_t* row = a.bits + (((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldb;
+                            row[nt0 + t] = myword;
+                            // the row's pad words (ldb rounds ceil(Cout / 32) up): written once, by the tile that holds the last channels
+                            if ((nt0 + t + 1) * 32 >= a.Coutp)
+                                for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
+                        }
+                    }
+                } else if (nin) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * half_t;
+                        if (j < npix) {
+                            const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+                            const int oy = oy0 + oyl, ox = ox0 + oxl;
+                            if (oy < a.Ho && ox < a.Wo)
+                                a.y[(((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldy + n] = acc[mt][t][r] * oscale + bv;
+                        }
                     }
                 }
             }
         }
+        if (!more) break;
+        finish_patch(buf ^ 1);
+        tile = next;
+        buf ^= 1;
     }
 }
 
@@ -280,7 +369,7 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cp = (int)Cp;
     a.CPK = (int)((KW * Cp + 7) / 8);
     a.NCH = (int)(KH * a.CPK);
-    a.NKS = (a.NCH + 1) / 2;
+    a.NKS = ((a.NCH + 1) / 2 + 3) / 4 * 4;           // whole groups of 4 k-steps (the weight pack appends zero k-steps)
     // output tile: <= 128 pixels, as square as the map allows, sized to waste the fewest padded pixels
     int best_ty = 1, best_tx = 1;
     double best = 1e30;
@@ -289,7 +378,7 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
             if (tx * ty < 64 && tx * ty < Ho * Wo) continue;
             const int64_t pr = (int64_t)(ty - 1) * S + KH, pce = ((int64_t)(tx - 1) * S + KW) * Cp;
             const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.CPK * 8) + 3) / 4 * 4;
-            if (pr * rs / 2 > 256 * 20 || 2 * pr * rs * 2 + 64 > 72 * 1024) continue;
+            if (pr * rs / 2 > 256 * 20 || 2 * (2 * pr * rs * 2) + 64 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
             const int64_t tiles = ((Ho + ty - 1) / ty) * ((Wo + tx - 1) / tx);
             // cost: MFMA work (128 rows per tile whatever it holds) + the patch it loads (halo re-reads)
             const double cost = (double)tiles * (128.0 * a.NKS * 16 + 0.25 * (double)(pr * rs));
@@ -308,20 +397,30 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.wscale = wscale;
     a.wscale_dev = wscale_dev;
     a.Cout = (int)Cout; a.Coutp = (int)Coutp;
+    a.step_r = 256 / (a.RS / 2); a.step_pc = 256 % (a.RS / 2);
+    // float2 spans: dense channels-last rows, no channel padding, every patch row starts on an even element of an 8-byte aligned row
+    a.rows_dense = (sc == 1 && sw == C && Cp == C && !(sh & 1) && !(sn & 1) && !((a.TOX * S * C) & 1) && !((PW * C) & 1) &&
+                    (reinterpret_cast<uintptr_t>(x) & 7) == 0) ? 1 : 0;
     a.bias = bias; a.y = y; a.ldy = ldy; a.alpha = alpha; a.beta = beta; a.bits = bits; a.ldb = ldb;
-    const int64_t nblk = N * a.tiles_y * a.tiles_x;
-    if (nblk > INT32_MAX) return QT_ERR_UNSUPPORTED;
-    const int lds = 2 * a.PR * a.RS * 2 + 64;
-    const dim3 grid((unsigned)nblk, (unsigned)((Coutp + 191) / 192));
+    const int64_t ntiles = N * a.tiles_y * a.tiles_x;
+    if (ntiles > INT32_MAX) return QT_ERR_UNSUPPORTED;
+    const int lds = 2 * (2 * a.PR * a.RS * 2) + 64;                   // two patch buffers (hi + lo planes each) + the scales
+    const int npairs = a.PR * (a.RS / 2);
+    const unsigned ny = (unsigned)((Coutp + 191) / 192);
+    // persistent workgroups: two per CU (256 CUs), shared between the channel blocks
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, std::max<int64_t>(1, 512 / ny)), ny);
+#define QT_FIRST_LAUNCH(REALW, MAXP)                                                                                          \
+    do {                                                                                                                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<REALW, MAXP>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;          \
+        hipLaunchKernelGGL((conv_first_direct_kernel<REALW, MAXP>), grid, dim3(256), lds, (hipStream_t)stream, a);            \
+    } while (0)
     if (wlo) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_first_direct_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+        if (npairs <= 256 * 16) QT_FIRST_LAUNCH(true, 16); else QT_FIRST_LAUNCH(true, 20);
     } else {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_first_direct_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+        if (npairs <= 256 * 16) QT_FIRST_LAUNCH(false, 16); else QT_FIRST_LAUNCH(false, 20);
     }
+#undef QT_FIRST_LAUNCH
     return qt_check_launch();
 }
 

@@ -2507,7 +2507,7 @@ def pack_first_layer_weight(wq: torch.Tensor, stride: int, real: bool = False) -
     Cp = first_direct_cp(C, stride)
     cpk = (kw * Cp + 7) // 8
     nch = kh * cpk
-    nks = (nch + 1) // 2
+    nks = ((nch + 1) // 2 + 3) // 4 * 4            # whole groups of 4 k-steps (the kernel's unrolled pipeline); zero padded
     Coutp = (Cout + 31) // 32 * 32
     F = torch.nn.functional
     scale = None

@@ -54,6 +54,15 @@ def main():
                 with lazy.eager():
                     t_f32 = timed(lambda: conv(x))
                 t_blk = timed(lambda: block(x)._qt.force())
+            if direct:     # the kernel alone, threshold epilogue / fp32 epilogue
+                from pytorch_quantize_impls_amd.layers.fused import fold_batchnorm
+                al, be = fold_batchnorm(bn)
+                if name == "bin":
+                    fw = ops.pack_first_layer_weight(conv.weight.detach(), 4)
+                else:
+                    fw = ops.pack_first_layer_weight(ops.xnor_weight(conv.weight.detach(), 2)[0], 4, real=True)
+                row["kernel_bits_us"] = timed(lambda: ops.conv_first_direct(x, fw, conv.bias, 4, 2, epi=(al, be)))
+                row["kernel_fp32_us"] = timed(lambda: ops.conv_first_direct(x, fw, conv.bias, 4, 2))
             tag = "direct" if direct else "r3_route"
             row[tag] = {"fp32_out_us": t_f32, "fused_block_us": t_blk,
                         "fused_block_frac_f16_peak_2term": 2 * 2 * macs / (t_blk * 1e-6) / 2.5e15}
