@@ -36,6 +36,8 @@ struct FirstArgs {
     int NCH, NKS;                      // chunks = KH * CPK, k-steps = ceil(NCH / 2) rounded up to 4
     int TOY, TOX, tiles_y, tiles_x;
     int PR, PCE, RS;                   // patch rows, real elements per patch row (PC * Cp), LDS row stride in elements (% 4 == 0)
+    unsigned long long m64_tpi;        // ceil(2^64 / tiles per image)
+    unsigned m_tx;                     // magic of tiles_x
     unsigned m_ppr, m_cp, m_tox, m_cpk; // floor(2^32 / d) + 1 for d = RS / 2, Cp, TOX, CPK: q / d == __umulhi(q, m) for q < 2^16 (d > 1)
     const uint4* whi;                  // [NKS][2][Coutp] 16-byte chunks
     const uint4* wlo;                  // real-valued weights only
@@ -67,7 +69,7 @@ __device__ __forceinline__ v16f mfma16(const uint4& a, const uint4& b, v16f c) {
 // registers before the MFMA loop of the current tile starts and is converted / written to the other LDS patch buffer after it, so a
 // workgroup's HBM latency and its split arithmetic sit under MFMA time (its own and the co-resident workgroup's) instead of in
 // front of it — with one tile per workgroup the two workgroups of a CU run their prologues, loops and epilogues in lockstep.
-template <bool REALW, int MAXP>
+template <bool REALW, bool BITS, int MAXP>
 __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,15 +80,20 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     const int buf_bytes = 2 * plane_bytes;                                   // [hi plane | lo plane]
     float* red = reinterpret_cast<float*>(smem + 2 * buf_bytes);           // per buffer: 4 partial maxima, scale, 1 / scale
     const int ppr = a.RS >> 1;                   // pairs per LDS row
-    const int npairs = a.PR * ppr;
 
-    float v0[MAXP], v1[MAXP];                    // the patch in flight: pairs p = tid + 256 i of consecutive elements of a patch row
-    const int r_first = divm(tid, a.m_ppr, ppr), pc_first = tid - r_first * ppr;
+    // the patch in flight: a thread owns ONE pair column pc (two consecutive elements of a patch row) and walks the rows
+    // rr, rr + rpp, ... (rpp = 256 / ppr rows per pass): everything that depends on the column — bounds against the image row and the
+    // real patch width, the float2 alignment case — is evaluated once per tile, a pass costs a row check, one address and one load
+    float v0[MAXP], v1[MAXP];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int rpp = a.step_r;                                   // rows per pass
+    const int rr0 = divm(tid, a.m_ppr, ppr), pc0 = tid - rr0 * ppr;
 
     auto tile_origin = [&](int tile, int& img, int& oy0, int& ox0) __attribute__((always_inline)) {
-        img = tile / tpi;
+        img = tpi == 1 ? tile : (int)__umul64hi((unsigned long long)(unsigned)tile, a.m64_tpi);     // exact for 32-bit numerators
         const int trem = tile - img * tpi;
-        const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+        const int ty = divm(trem, a.m_tx, a.tiles_x), tx = trem - ty * a.tiles_x;
         oy0 = ty * a.TOY;
         ox0 = tx * a.TOX;
     };
@@ -97,58 +104,49 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         tile_origin(tile, img, oy0, ox0);
         const int iy0 = oy0 * a.S - a.PH, ix0 = ox0 * a.S - a.PW;          // patch origin in the image (may be negative: padding)
         const float* xi = a.x + (int64_t)img * a.sn;
-        int r = r_first, pc = pc_first, tid_t = tid;
-        asm volatile("" : "+v"(r), "+v"(pc), "+v"(tid_t));      // per tile opaque: the 16 (row, column) pairs are loop-invariant (see the epilogue)
+        int rr = rr0, pc = pc0;
+        asm volatile("" : "+v"(rr), "+v"(pc));      // opaque per tile: what follows is loop-invariant and would be hoisted into spills
+        const int e = 2 * pc;
+        const bool act = rr < rpp && e < a.PCE;
+        int64_t off0 = 0, off1 = 0;                 // element offsets of the pair within an image row
+        bool ok0 = false, ok1 = false, vec = false;
         if (a.rows_dense) {
-            // channels-last image, no channel padding: a patch row is ONE contiguous span of the image row, starting at element
+            // channels-last image, no channel padding: a patch row is ONE contiguous span of the image row starting at element
             // ix0 * C (even: 8-byte aligned float2 loads); spans are clipped against the row for the zero padding
-            const int g0 = ix0 * a.C, gend = a.W * a.C;
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) {
-                float f0 = 0.0f, f1 = 0.0f;
-                if (tid_t + i * 256 < npairs) {
-                    const int iy = iy0 + r, e = 2 * pc, g = g0 + e;
-                    if ((unsigned)iy < (unsigned)a.H && e < a.PCE) {
-                        const float* row = xi + (int64_t)iy * a.sh;
-                        if (g >= 0 && g + 1 < gend && e + 1 < a.PCE) {
-                            const float2 v = *reinterpret_cast<const float2*>(row + g);
-                            f0 = v.x;
-                            f1 = v.y;
-                        } else {
-                            if (g >= 0 && g < gend) f0 = row[g];
-                            if (g + 1 >= 0 && g + 1 < gend && e + 1 < a.PCE) f1 = row[g + 1];
-                        }
-                    }
-                }
-                v0[i] = f0;
-                v1[i] = f1;
-                r += a.step_r;
-                pc += a.step_pc;
-                if (pc >= ppr) { pc -= ppr; ++r; }
-            }
+            const int g = ix0 * a.C + e, gend = a.W * a.C;
+            ok0 = act && g >= 0 && g < gend;
+            ok1 = act && g + 1 >= 0 && g + 1 < gend && e + 1 < a.PCE;
+            vec = ok0 && ok1;
+            off0 = g;
+            off1 = g + 1;
         } else {
+            const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
+            int px1 = px0, c1 = c0 + 1;
+            if (c1 == a.Cp) { c1 = 0; ++px1; }
+            const int ixa = ix0 + px0, ixb = ix0 + px1;
+            ok0 = act && c0 < a.C && (unsigned)ixa < (unsigned)a.W;
+            ok1 = act && e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W;
+            off0 = (int64_t)ixa * a.sw + (int64_t)c0 * a.sc;
+            off1 = (int64_t)ixb * a.sw + (int64_t)c1 * a.sc;
+        }
+        const float* p0 = xi + off0;
+        const float* p1 = xi + off1;
 #pragma unroll
-            for (int i = 0; i < MAXP; ++i) {
-                float f0 = 0.0f, f1 = 0.0f;
-                if (tid_t + i * 256 < npairs) {
-                    const int e = 2 * pc;
-                    const int iy = iy0 + r;
-                    if ((unsigned)iy < (unsigned)a.H) {
-                        const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
-                        int px1 = px0, c1 = c0 + 1;
-                        if (c1 == a.Cp) { c1 = 0; ++px1; }
-                        const int ixa = ix0 + px0, ixb = ix0 + px1;
-                        const float* row = xi + (int64_t)iy * a.sh;
-                        if (e < a.PCE && c0 < a.C && (unsigned)ixa < (unsigned)a.W) f0 = row[(int64_t)ixa * a.sw + (int64_t)c0 * a.sc];
-                        if (e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W) f1 = row[(int64_t)ixb * a.sw + (int64_t)c1 * a.sc];
-                    }
-                }
-                v0[i] = f0;
-                v1[i] = f1;
-                r += a.step_r;
-                pc += a.step_pc;
-                if (pc >= ppr) { pc -= ppr; ++r; }
+        for (int i = 0; i < MAXP; ++i) {
+            const int r = rr + i * rpp, iy = iy0 + r;
+            const bool rok = r < a.PR && (unsigned)iy < (unsigned)a.H;
+            const int64_t ro = (int64_t)iy * a.sh;
+            float f0 = 0.0f, f1 = 0.0f;
+            if (rok && vec) {
+                const float2 v = *reinterpret_cast<const float2*>(p0 + ro);
+                f0 = v.x;
+                f1 = v.y;
+            } else if (rok) {
+                if (ok0) f0 = p0[ro];
+                if (ok1) f1 = p1[ro];
             }
+            v0[i] = f0;
+            v1[i] = f1;
         }
     };
 
@@ -174,20 +172,23 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         }
         const float isx = 1.0f / sc;                           // exact (power of two within the normal range)
         if (tid == 0) rb[4] = sc;
-        uint32_t* hi32 = reinterpret_cast<uint32_t*>(smem + buf * buf_bytes);
-        uint32_t* lo32 = reinterpret_cast<uint32_t*>(smem + buf * buf_bytes + plane_bytes);
+        h2* hi2 = reinterpret_cast<h2*>(smem + buf * buf_bytes);
+        h2* lo2 = reinterpret_cast<h2*>(smem + buf * buf_bytes + plane_bytes);
+        int rr = rr0, pc = pc0;
+        asm volatile("" : "+v"(rr), "+v"(pc));
+        if (rr < rpp) {
+            int p = rr * ppr + pc;
+            const int dp = rpp * ppr;
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int p = tid + i * 256;
-            if (p < npairs) {
-                const float t0 = v0[i] * isx, t1 = v1[i] * isx;
-                const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
-                const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
-                uint16_t b0, b1, c0, c1;
-                __builtin_memcpy(&b0, &h0, 2); __builtin_memcpy(&b1, &h1, 2);
-                __builtin_memcpy(&c0, &l0, 2); __builtin_memcpy(&c1, &l1, 2);
-                hi32[p] = (uint32_t)b0 | ((uint32_t)b1 << 16);
-                lo32[p] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+            for (int i = 0; i < MAXP; ++i) {
+                if (rr + i * rpp < a.PR) {
+                    const f2 t = (f2){v0[i], v1[i]} * isx;
+                    const h2 h = __builtin_convertvector(t, h2);
+                    const h2 l = __builtin_convertvector(t - __builtin_convertvector(h, f2), h2);
+                    hi2[p] = h;
+                    lo2[p] = l;
+                }
+                p += dp;
             }
         }
         __syncthreads();
@@ -222,15 +223,25 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;                                // uniform
-    int buf = 0;
-    issue_patch(tile);
-    finish_patch(0);
+    // per-channel epilogue constants of this lane's three channels: loaded once per (persistent) workgroup
+    float e_bv[3], e_al[3], e_nbe[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (nt0 + t) * 32 + lrow;
+        const bool nin = n < a.Cout;
+        e_bv[t] = (a.bias && nin) ? a.bias[n] : 0.0f;
+        e_al[t] = (BITS && nin) ? a.alpha[n] : 0.0f;
+        e_nbe[t] = (BITS && nin) ? -a.beta[n] : 0.0f;
+    }
+    const float wsc = a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale;
+    // rotated tile loop — every phase exists ONCE in the code (the unrolled patch passes and the unrolled epilogue are large; inlined
+    // twice, with both epilogues, the kernel was ~70 KB of instructions and ran out of the instruction cache: every phase, loads or
+    // not, took 4-8x its instruction count):   [request patch of `load_tile`]  [MFMA loop + epilogue of `tile`]  [patch -> LDS]
+    int load_tile = blockIdx.x, tile = -1, buf = 0;
     while (true) {
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;                       // uniform
-        if (more) issue_patch(next);                           // in flight across the MFMA loop below
+        const bool more = load_tile < ntiles;                  // uniform
+        if (more) issue_patch(load_tile);                      // in flight across the MFMA loop below
+        if (tile >= 0) {
 
         const unsigned char* hib = smem + buf * buf_bytes;
         const unsigned char* lob = hib + plane_bytes;
@@ -296,26 +307,28 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         int img, oy0, ox0;
         tile_origin(tile, img, oy0, ox0);
         const float sx = red[buf * 8 + 4];
-        const float oscale = sx * (a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale);
+        const float oscale = sx * wsc;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if ((nt0 + t) * 32 >= a.Coutp) continue;
             const int n = (nt0 + t) * 32 + lrow_t;
             const bool nin = n < a.Cout;
-            const float bv = (a.bias && nin) ? a.bias[n] : 0.0f;
-            const float al_ = (a.alpha && nin) ? a.alpha[n] : 0.0f, nbe = (a.alpha && nin) ? -a.beta[n] : 0.0f;
+            const float bv = e_bv[t], al_ = e_al[t], nbe = e_nbe[t];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int jb = (mg * 2 + mt) * 32;
-                if (a.alpha) {
+                if constexpr (BITS) {
                     uint32_t myword = 0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[mt][t][r] * oscale + bv;
                         const unsigned long long mask = __ballot(v * al_ < nbe);      // channels >= Cout: 0 < 0 -> bit 0
                         const int R = (r & 3) + 8 * (r >> 2);
-                        if (lane_t == R) myword = (uint32_t)mask;
-                        if (lane_t == R + 4) myword = (uint32_t)(mask >> 32);
+                        // v_writelane: the two halves of the (scalar) ballot straight into lanes R and R + 4
+                        // (gfx950 does not interlock a VALU-written SGPR read by the next VALU and the hazard recogniser does not look
+                        // inside inline asm: the s_nop covers v_cmp -> first write; the writes are chained through myword)
+                        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
                     }
                     const int j = jb + lane_t;                                          // lanes 0 .. 31: one pixel each
                     if (lane_t < 32 && j < npix) {
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
                                 for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
                         }
                     }
-                } else if (nin) {
+                } else {
+                  if (nin) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * half_t;
@@ -340,13 +354,17 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
                                 a.y[(((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldy + n] = acc[mt][t][r] * oscale + bv;
                         }
                     }
+                  }
                 }
             }
         }
+        }
         if (!more) break;
-        finish_patch(buf ^ 1);
-        tile = next;
-        buf ^= 1;
+        const int nb = tile >= 0 ? (buf ^ 1) : 0;
+        finish_patch(nb);
+        tile = load_tile;
+        load_tile += gridDim.x;
+        buf = nb;
     }
 }
 
@@ -378,7 +396,8 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
             if (tx * ty < 64 && tx * ty < Ho * Wo) continue;
             const int64_t pr = (int64_t)(ty - 1) * S + KH, pce = ((int64_t)(tx - 1) * S + KW) * Cp;
             const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.CPK * 8) + 3) / 4 * 4;
-            if (pr * rs / 2 > 256 * 20 || 2 * (2 * pr * rs * 2) + 64 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
+            if (rs / 2 > 256 || (pr + 256 / (rs / 2) - 1) / (256 / (rs / 2)) > 18) continue;          // <= 18 row passes of the patch loader
+            if (2 * (2 * pr * rs * 2) + 64 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
             const int64_t tiles = ((Ho + ty - 1) / ty) * ((Wo + tx - 1) / tx);
             // cost: MFMA work (128 rows per tile whatever it holds) + the patch it loads (halo re-reads)
             const double cost = (double)tiles * (128.0 * a.NKS * 16 + 0.25 * (double)(pr * rs));
@@ -391,13 +410,15 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.PCE = ((a.TOX - 1) * a.S + a.KW) * a.Cp;
     a.RS = (std::max(a.PCE, (a.TOX - 1) * a.S * a.Cp + a.CPK * 8) + 3) / 4 * 4;
     auto magic = [](int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; };
+    a.m_tx = magic(a.tiles_x);
+    { const unsigned long long d = (unsigned long long)a.tiles_y * a.tiles_x; a.m64_tpi = d > 1 ? ~0ull / d + 1 : 0; }
     a.m_ppr = magic(a.RS / 2); a.m_cp = magic(a.Cp); a.m_tox = magic(a.TOX); a.m_cpk = magic(a.CPK);
     a.whi = reinterpret_cast<const uint4*>(whi);
     a.wlo = reinterpret_cast<const uint4*>(wlo);
     a.wscale = wscale;
     a.wscale_dev = wscale_dev;
     a.Cout = (int)Cout; a.Coutp = (int)Coutp;
-    a.step_r = 256 / (a.RS / 2); a.step_pc = 256 % (a.RS / 2);
+    a.step_r = 256 / (a.RS / 2); a.step_pc = 0;          // rows of the patch one pass of the loader covers
     // float2 spans: dense channels-last rows, no channel padding, every patch row starts on an even element of an 8-byte aligned row
     a.rows_dense = (sc == 1 && sw == C && Cp == C && !(sh & 1) && !(sn & 1) && !((a.TOX * S * C) & 1) && !((PW * C) & 1) &&
                     (reinterpret_cast<uintptr_t>(x) & 7) == 0) ? 1 : 0;
@@ -405,21 +426,17 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     const int64_t ntiles = N * a.tiles_y * a.tiles_x;
     if (ntiles > INT32_MAX) return QT_ERR_UNSUPPORTED;
     const int lds = 2 * (2 * a.PR * a.RS * 2) + 64;                   // two patch buffers (hi + lo planes each) + the scales
-    const int npairs = a.PR * (a.RS / 2);
     const unsigned ny = (unsigned)((Coutp + 191) / 192);
     // persistent workgroups: two per CU (256 CUs), shared between the channel blocks
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, std::max<int64_t>(1, 512 / ny)), ny);
-#define QT_FIRST_LAUNCH(REALW, MAXP)                                                                                          \
+#define QT_FIRST_LAUNCH(REALW, BITS, MAXP)                                                                                          \
     do {                                                                                                                      \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<REALW, MAXP>),                         \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<REALW, BITS, MAXP>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;          \
-        hipLaunchKernelGGL((conv_first_direct_kernel<REALW, MAXP>), grid, dim3(256), lds, (hipStream_t)stream, a);            \
+        hipLaunchKernelGGL((conv_first_direct_kernel<REALW, BITS, MAXP>), grid, dim3(256), lds, (hipStream_t)stream, a);            \
     } while (0)
-    if (wlo) {
-        if (npairs <= 256 * 16) QT_FIRST_LAUNCH(true, 16); else QT_FIRST_LAUNCH(true, 20);
-    } else {
-        if (npairs <= 256 * 16) QT_FIRST_LAUNCH(false, 16); else QT_FIRST_LAUNCH(false, 20);
-    }
+    if (wlo) { if (alpha) QT_FIRST_LAUNCH(true, true, 18); else QT_FIRST_LAUNCH(true, false, 18); }
+    else { if (alpha) QT_FIRST_LAUNCH(false, true, 18); else QT_FIRST_LAUNCH(false, false, 18); }
 #undef QT_FIRST_LAUNCH
     return qt_check_launch();
 }

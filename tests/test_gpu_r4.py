@@ -426,9 +426,18 @@ def test_first_layer_direct_conv_vs_oracle(dev, oracle, shape, kind, channels_la
         before = dict(_lib.call_counts)
         with torch.no_grad(), lazy.eager():
             y = conv(xd)
-        assert _lib.call_counts["qt_conv_first_direct_f32"] == before.get("qt_conv_first_direct_f32", 0) + 1, mode
+        # (+-1 / 0 weights with fp32 output stay on the space-to-depth route, which is faster there; the kernel's fp32 epilogue is
+        # exercised through ops below for every kind)
+        if kind == "xnor":
+            assert _lib.call_counts["qt_conv_first_direct_f32"] == before.get("qt_conv_first_direct_f32", 0) + 1, mode
         assert tuple(y.shape) == want.shape
         assert norm_err(n(y), want) <= TOL, (mode, norm_err(n(y), want))
+    if kind != "xnor":
+        wq = {"binary": oracle.safe_sign, "ternary": oracle.ternarize}[kind](w)
+        fw = ops.pack_first_layer_weight(t32(wq, dev), s)
+        y2 = ops.conv_first_direct(xd, fw, t32(b, dev), s, p)
+        Ho, Wo = want.shape[2], want.shape[3]
+        assert norm_err(n(y2.view(N, Ho, Wo, Cout).permute(0, 3, 1, 2)), want) <= TOL
 
 
 def test_first_layer_direct_conv_threshold_bits_equal_the_unfused_chain(dev):
