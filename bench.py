@@ -215,7 +215,7 @@ def main():
               "event_pair_empty_ms": empty_ms}
     if gemm_impl == "mfma":
         achieved = ops_per_step / (burst_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "mfma_gemm_kernel<ElemFp4, 256x256, pipe=2> (fp4 MFMA packed GEMM)",
+        roofline = {"bound": "mfma", "kernel": ops.nib_gemm_kernel_name(B, N, K) + " (fp4 MFMA packed GEMM; name from the library's own dispatch)",
                     "achieved": achieved, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_FP4_PEAK_TFLOPS,
                     "frac_on_in_step_bracket": ops_per_step / (gemm_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                     "traffic": None, **timing,
@@ -256,7 +256,10 @@ def main():
                    # un-tagged inputs of the layer-level legs (AlexNet / C4 / C5) are checked for +-1 on the device; "verify" =
                    # one 4-byte readback per un-tagged input per forward (functions/_fused.py); the C2 step itself packs
                    # through ops.* and asks nothing
-                   "detect_mode": _fused.DETECT_MODE, "deferred_activations": "on (lazy.ENABLED, lazy.DEFER_CODES): bit-identical "
+                   "detect_mode": _fused.DETECT_MODE, "float_split": ops.FLOAT_SPLIT,
+                   "legs": "every leg of this line runs with detect_mode and float_split above unless its own object says otherwise "
+                           "(with_remembered_range_verdicts: detect_mode 'remember'; Lin/Log layers: bf16x3); real-valued first layers: "
+                           "AlexNet conv1 on the direct kernel (per-tile two-term fp16 split), VGG conv1 on bf16 triples", "deferred_activations": "on (lazy.ENABLED, lazy.DEFER_CODES): bit-identical "
                    "to the module-by-module graph on this device"},
         "roofline": roofline,
         "per_rank_ms_per_step": per_rank_ms,
@@ -498,7 +501,8 @@ def bench_alexnet(args, dev, dist, world, rank):
                 ta = lat(lambda: am(xs))
             serving[f"batch_{sb}"] = {"eager_ms": te, "module_by_module_eager_ms": tm, "hipgraph_ms": tg,
                                       "hipgraph_images_per_s": sb / tg * 1e3, "same_logits": same,
-                                      "auto_graphed_ms": ta, "auto_graphed_same_logits": same_a, "auto_graphed_replays": am.replays}
+                                      "auto_graphed_ms": ta, "auto_graphed_same_logits": same_a, "auto_graphed_replays": am.replays,
+                                      "auto_graphed_capture_failures": dict(am.capture_failures)}
             del gm, am
         out["serving_small_batch"] = serving
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -883,7 +887,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                                {"same_logits_as_module_graph": same_g}),
             "module_graph_auto_graphed": _net_line("c4", Bc, world, 2 * iters, el_a, st4, 5000.0,
                                                    "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
-                                                   {"same_logits_as_module_graph": same_a4, "replays": a4.replays,
+                                                   {"same_logits_as_module_graph": same_a4, "replays": a4.replays, "capture_failures": dict(a4.capture_failures),
                                                     "what": "utils.auto_graphed(model): eager first call, captured on the second, "
                                                             "replayed after (input copied in, logits copied out)"}),
             "unfused": _net_line("c4", Bc, world, iters, el_u, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",

@@ -230,6 +230,10 @@ int qt_pack_pair_nib_f32(const float* x, int64_t ldx, uint32_t* x_plane, int64_t
                          const float* w, int64_t ldw, uint32_t* w_plane, int64_t ldwp, int64_t rows_w,
                          int64_t K, int w_ternary, qt_stream_t stream);
 
+/* Name of the kernel configuration qt_nib_gemm's automatic dispatch launches for (M, N, K) with these row strides — written to
+ * out[cap] (bench.py quotes it in roofline.kernel, so the record names the kernel that ran). */
+int qt_nib_gemm_describe(int64_t M, int64_t N, int64_t K, int64_t ldxp, int64_t ldwp, char* out, int cap);
+
 /* Y[M,N] = Xn . Wn^T (+ bias): replaces the same F.linear call sites as qt_xnor_gemm /
  * qt_tern_gemm (binary and ternary weights share this entry point: zero is a nibble value). */
 int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp,

@@ -91,6 +91,7 @@ SIGNATURES = {
     "qt_wgrad_pm_f16": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 7 + [_c_p]),
     "qt_wgrad_pm_f32": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 7 + [_c_p]),
     "qt_wgrad_pm_reduce_f32": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_f32, _c_f32, _c_p, _c_int, _c_p] + [_c_i64] * 4 + [_c_p]),
+    "qt_nib_gemm_describe": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_char_p, _c_int]),
     "qt_nib_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_p]),
     "qt_bits_to_nib": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -46,6 +46,7 @@
 // Profiling-only variants (ABL_ != 0) exist only in -DQT_PROFILING_VARIANTS builds (qt_nib_gemm_variant 161-166,
 // qt_conv2d_implicit_variant 3); the product library does not contain them.
 
+#include <cstdio>
 #include "mfma_gemm_kernel.h"
 
 namespace {
@@ -343,6 +344,23 @@ int qt_nib_gemm_variant(int variant, const uint32_t* Xn, int64_t ldxp, const uin
     if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
     if (K >= (1 << 24)) return QT_ERR_UNSUPPORTED;  // fp32-exact bound of the accumulator
     return dispatch_gemm<ElemFp4>(variant, Xn, ldxp, Wn, ldwp, bias, 1.0f, nullptr, Y, ldy, M, N, K, stream);
+}
+
+int qt_nib_gemm_describe(int64_t M, int64_t N, int64_t K, int64_t ldxp, int64_t ldwp, char* out, int cap) {
+    // the tile configuration dispatch_gemm's automatic rule (variant 0) launches for this shape: "<kernel><element, tile, pipeline>"
+    if (!out || cap < 2 || M <= 0 || N <= 0 || K < 0) return QT_ERR_INVALID_ARG;
+    const bool pipe_ok = !(ldxp & 31) && !(ldwp & 31) && M * ldxp * 4 < (1ll << 31) && N * ldwp * 4 < (1ll << 31);
+    const int tn = pick_tile_n_gemm(M, N);
+    const char* cfg;
+    if (pipe_ok && M <= 256 && !((ldxp | ldwp) & 127)) cfg = "64x64, 512-byte stages, pipe=1";
+    else if (pipe_ok && M <= 512 && !((ldxp | ldwp) & 63)) cfg = "128x64, 256-byte stages, pipe=1";
+    else if (pipe_ok && tn == 256) cfg = "256x256, pipe=2 (ping-pong)";
+    else if (pipe_ok && tn == 192) cfg = prefer_384_rows(M, N) ? "384x192, pipe=2 (ping-pong)" : "256x192, pipe=2 (ping-pong)";
+    else if (pipe_ok && tn == 128) cfg = "256x128, pipe=2 (ping-pong)";
+    else if (pipe_ok) cfg = "256x64, pipe=1";
+    else cfg = tn == 256 ? "256x256, pipe=0" : tn == 192 ? "256x192, pipe=0" : tn == 128 ? "256x128, pipe=0" : "256x64, pipe=0";
+    snprintf(out, (size_t)cap, "mfma_gemm_kernel<ElemFp4, %s>", cfg);
+    return QT_OK;
 }
 
 int qt_nib_gemm(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldwp, const float* bias,

@@ -2700,6 +2700,17 @@ def packed_gemm(x, w, bias=None, out=None, impl: str = "valu") -> torch.Tensor:
     raise NotImplementedError(impl)
 
 
+def nib_gemm_kernel_name(M: int, N: int, K: int) -> str:
+    """The kernel configuration nib_gemm's automatic dispatch takes for this shape (qt_nib_gemm_describe)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    ld = packed_ld_nib(K)
+    rc = _lib.load().qt_nib_gemm_describe(int(M), int(N), int(K), ld, ld, buf, 128)
+    if rc != 0:
+        raise _lib.QtStatusError(f"qt_nib_gemm_describe failed: {_lib.strerror(rc)}")
+    return buf.value.decode()
+
+
 def packed_gemm_algorithmic_bytes(M: int, N: int, K: int, impl: str = "valu", planes_w: int = 1,
                                   bias: bool = False) -> float:
     """Algorithmic HBM bytes of ONE packed-GEMM launch (DESIGN.md 'Kernels'): every operand read

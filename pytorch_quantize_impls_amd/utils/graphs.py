@@ -67,6 +67,10 @@ class AutoGraphed(torch.nn.Module):
         self.capture_after, self.max_graphs, self.clone_output = int(capture_after), int(max_graphs), bool(clone_output)
         self._graphs, self._seen, self._state = {}, {}, None
         self.replays = self.eager_calls = 0
+        #: captures that failed, by reason ("ExceptionType: message" -> count): such a signature stays eager — VISIBLY (a genuine
+        #: bug inside a captured forward must not turn into a silent performance regression); ``strict=True`` re-raises instead
+        self.capture_failures = {}
+        self.strict = False
 
     def _state_sig(self):
         # version counter + storage of every parameter and buffer (optimizer steps, load_state_dict, copy_, .to()); writes through
@@ -81,8 +85,10 @@ class AutoGraphed(torch.nn.Module):
         self._state = None
 
     def forward(self, x):
-        ok = (isinstance(x, torch.Tensor) and x.is_cuda and not torch.is_grad_enabled() and not self.module.training
-              and not torch.cuda.is_current_stream_capturing())
+        # (a submodule left in train() — BatchNorm fine-tuning, stochastic quantisers — would be captured once and replayed with
+        # frozen behaviour: every module has to be in eval mode, not just the root)
+        ok = (isinstance(x, torch.Tensor) and x.is_cuda and not torch.is_grad_enabled()
+              and not any(m.training for m in self.module.modules()) and not torch.cuda.is_current_stream_capturing())
         if not ok:
             self.eager_calls += 1
             return self.module(x)
@@ -101,8 +107,12 @@ class AutoGraphed(torch.nn.Module):
                 return self.module(x)
             try:
                 g = GraphedModule(self.module, x, warmup=1)
-            except Exception:                           # a host synchronisation inside the forward: stay eager for this signature
-                torch.cuda.synchronize(x.device)
+            except Exception as exc:                    # e.g. a host synchronisation inside the forward: stay eager for this signature,
+                torch.cuda.synchronize(x.device)        # and say so (capture_failures; bench.py prints it)
+                if self.strict:
+                    raise
+                reason = f"{type(exc).__name__}: {str(exc).splitlines()[0][:160] if str(exc) else ''}"
+                self.capture_failures[reason] = self.capture_failures.get(reason, 0) + 1
                 g = None
             self._graphs[key] = g
             self._state = self._state_sig()             # the warm-up forwards may have built caches, never written parameters
