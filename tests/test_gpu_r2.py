@@ -386,11 +386,32 @@ def test_c5_fused_vgg16_layerwise_at_224(dev):
             cur, prev, ci = want, blk, ci + 1
         # classifier: fused FC blocks on the flattened planes vs the host modules
         flat_in = _as_input(cur, None, dev).flatten_hwc()
-        y_gpu = fused.classifier(flat_in).cpu()
-        y_cpu = model.classifier(cur.reshape(N, -1))
+        # block by block like the features: the FC sums are exact integers (+ bias), the BatchNorm1d -> Hardtanh -> sign blocks may
+        # differ from the host modules only at ties (counted; |BatchNorm output| <= 1e-5 of its mean magnitude), and the device's
+        # bits are carried forward on both sides, so the logits are compared on identical activations
+        from pytorch_quantize_impls_amd.layers import FusedPoolBnSign
+        cmods = list(model.classifier.children())
+        h_cpu, h_gpu, ci, flips = cur.reshape(N, -1), flat_in, 0, 0
+        for blk in fused.classifier.children():
+            if isinstance(blk, FusedPoolBnSign):
+                v = cmods[ci](h_cpu)                                   # BatchNorm1d on the host
+                ci += 3                                                # (BatchNorm1d, Hardtanh, BinaryConnect)
+                out = blk(h_gpu)
+                words = out.planes.sign.cpu().numpy().view(np.uint32)
+                bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(N, -1)[:, :v.shape[1]]
+                got = torch.from_numpy(np.where(bits == 1, -1.0, 1.0).astype(np.float32))
+                diff = got != torch.where(v < 0, -1.0, 1.0)
+                flips += int(diff.sum())
+                assert not diff.any() or float(v[diff].abs().max()) <= 1e-5 * float(v.abs().mean()), "a flip that is not a tie"
+                h_cpu, h_gpu = got, out
+            else:
+                y_cpu, y_gpu = cmods[ci](h_cpu), blk(h_gpu).cpu()
+                ci += 1
+                assert norm_err(y_gpu.numpy(), y_cpu.numpy()) <= 1e-5
+                h_cpu, h_gpu = y_cpu, blk(h_gpu)
+        assert ci == len(cmods) and flips <= 4, flips
     used_ = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
     assert used_.get("qt_conv3x3_direct_nib", 0) >= 3, used_        # conv1 (real input), conv2, conv3 take the direct kernel
-    assert norm_err(y_gpu.numpy(), y_cpu.numpy()) <= 0.02, norm_err(y_gpu.numpy(), y_cpu.numpy())   # BatchNorm1d ties in two FC blocks
 
 
 def test_c3_fused_alexnet_layerwise(dev):
