@@ -318,9 +318,11 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
         N, C, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-        if epi is not None and ops.first_direct_applicable(C, (kh, kw), stride, padding, dilation):
-            # (fp32 output keeps the space-to-depth route: the direct kernel's fp32 store tail makes it ~100 us slower there at AlexNet
-            # conv1, tools/bench_conv1.py; with the threshold epilogue the two are level and the direct kernel needs no 154 MB plane)
+        if ops.first_direct_applicable(C, (kh, kw), stride, padding, dilation):
+            # (both epilogues on ONE route: the threshold bits of the fused / deferred chain must come from the very accumulators
+            # the fp32 output of the module-by-module execution shows, or the two executions differ at ties.  The kernel's fp32
+            # store tail makes the module-by-module conv1 ~100 us slower than the space-to-depth route at AlexNet's shape — not the
+            # inference path: tools/bench_conv1.py)
             # strided few-channel first layer (AlexNet conv1): the direct kernel reads the fp32 image where it lies, splits its
             # patch in registers and contracts by stride addressing — no operand pack pass, no space-to-depth plane
             fw = weight_triples_fn("first_direct") if weight_triples_fn is not None else None

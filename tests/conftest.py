@@ -69,3 +69,14 @@ def norm_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+@pytest.fixture()
+def s2d_first_layer():
+    """Tests that pin the round-3 route of strided real-valued first layers (space-to-depth pack + implicit GEMM: kernel names,
+    both float splits); since round 4 such layers take the direct kernel (ops.FIRST_DIRECT, tests/test_gpu_r4.py)."""
+    from pytorch_quantize_impls_amd import ops
+    prev = ops.FIRST_DIRECT
+    ops.FIRST_DIRECT = False
+    yield
+    ops.FIRST_DIRECT = prev

@@ -545,11 +545,12 @@ def test_alexnet_bin_layerwise(dev):
     for name, (xin, yout) in captured.items():
         binary = bool(((xin == 1) | (xin == -1)).all())
         packed_entries = ("qt_nib_gemm", "qt_xnor_gemm", "qt_conv2d_implicit")
-        float_before = _lib.call_counts["qt_bf16x3_pack_f32"]
+        float_entries = ("qt_bf16x3_pack_f32", "qt_conv_first_direct_f32")   # real-valued input: split + implicit GEMM, or (strided
+        float_before = sum(_lib.call_counts[k] for k in float_entries)        # first layers since round 4) the direct kernel
         before = sum(_lib.call_counts[k] for k in packed_entries)
         with torch.no_grad():
             y = lazy.resolve(gmods[name](xin.to(dev)))
-        ran_float = _lib.call_counts["qt_bf16x3_pack_f32"] > float_before   # real-valued input: bf16x3 path
+        ran_float = sum(_lib.call_counts[k] for k in float_entries) > float_before
         ran_packed = sum(_lib.call_counts[k] for k in packed_entries) > before and not ran_float
         assert ran_packed == binary, name                   # only features.0 sees real pixels ...
         assert ran_float == (not binary), name              # ... and it takes the bf16x3 path, not a library
@@ -780,7 +781,7 @@ def test_float_conv_bf16x3_vs_fp64(dev):
 
 
 @pytest.mark.usefixtures("exact_split")
-def test_strided_first_layer_conv_s2d_vs_fp64(dev):
+def test_strided_first_layer_conv_s2d_vs_fp64(dev, s2d_first_layer):
     """BinConv2d on real pixels with stride > 1 goes through the space-to-depth form; same numbers."""
     from pytorch_quantize_impls_amd.functions import _fused
     gen = torch.Generator(device=dev)
@@ -905,9 +906,15 @@ def test_fused_first_layer_conv_bits_match_fp32_route(dev):
         bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 30); bn.weight.data.normal_(); bn.bias.data.normal_()
         mp = torch.nn.MaxPool2d(*pool) if pool else None
         x = torch.randn((2, Cin, HW, HW), device=dev).contiguous(memory_format=torch.channels_last)
-        with torch.no_grad(), used("qt_conv2d_implicit_bits"):
+        before = dict(_lib.call_counts)
+        with torch.no_grad():
             act = FusedConvPoolBnSign(conv, bn, mp)(x)
             ref = FusedPoolBnSign(bn, mp)(conv(x))
+        # strided first layers: the direct kernel (round 4), both epilogues; stride 1: the implicit GEMM on bf16 triples
+        ran = {k_: _lib.call_counts[k_] - before.get(k_, 0) for k_ in ("qt_conv2d_implicit_bits", "qt_conv_first_direct_bits_f32",
+                                                                      "qt_conv2d_implicit", "qt_conv_first_direct_f32")}
+        assert (ran["qt_conv_first_direct_bits_f32"] == 1 and ran["qt_conv_first_direct_f32"] == 1) if st > 1 else \
+            (ran["qt_conv2d_implicit_bits"] == 1 and ran["qt_conv2d_implicit"] == 1), ran
         assert act.shape == ref.shape and torch.equal(act.planes.sign, ref.planes.sign)
 
 
@@ -929,7 +936,7 @@ def test_fused_alexnet_conv_bits_equals_fp32_fusion(dev):
 
 
 @pytest.mark.gpu
-def test_conv_ping_pong_kernels_equal_double_buffered(dev):
+def test_conv_ping_pong_kernels_equal_double_buffered(dev, s2d_first_layer):
     """qt_conv2d_implicit_variant(2): the ping-pong main loop (ring of 4 64-byte stages, wrapped W pieces for the
     192- and 64-wide tiles) must reproduce the double-buffered conv kernels (variant 1) and the automatic choice bit for
     bit, all four tile widths."""
@@ -1131,7 +1138,7 @@ def test_fuzz_packed_gemm_vs_oracle(dev, oracle):
 
 
 @pytest.mark.gpu
-def test_fuzz_real_input_conv_vs_fp64(dev):
+def test_fuzz_real_input_conv_vs_fp64(dev, s2d_first_layer):
     """First-layer style convs on real-valued inputs (exact bf16-triple route; space-to-depth form when strided)."""
     rng = np.random.default_rng(4242)
     from pytorch_quantize_impls_amd.layers import TerConv2d

@@ -298,7 +298,7 @@ def test_float_linear_both_splits_vs_fp64(dev, M, N, K, mode):
 @pytest.mark.parametrize("N,Cin,Cout,H,k,s,p,cl", [(4, 3, 192, 224, 11, 4, 2, True), (3, 3, 64, 33, 3, 1, 1, False),
                                                     (2, 16, 40, 19, 5, 2, 2, True), (2, 64, 96, 14, 3, 1, 1, True)])
 @pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
-def test_real_input_conv_both_splits_vs_fp64(dev, N, Cin, Cout, H, k, s, p, cl, mode):
+def test_real_input_conv_both_splits_vs_fp64(dev, N, Cin, Cout, H, k, s, p, cl, mode, s2d_first_layer):
     """BinConv2d on a REAL-valued image (the first layer: models/Alexnet/Alexnet_Bin.py:13) — space-to-depth and plain
     routes, both splits, against fp64 of F.conv2d(x, safeSign(W), b)."""
     torch.manual_seed(Cin + Cout + k)

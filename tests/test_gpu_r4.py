@@ -426,10 +426,7 @@ def test_first_layer_direct_conv_vs_oracle(dev, oracle, shape, kind, channels_la
         before = dict(_lib.call_counts)
         with torch.no_grad(), lazy.eager():
             y = conv(xd)
-        # (+-1 / 0 weights with fp32 output stay on the space-to-depth route, which is faster there; the kernel's fp32 epilogue is
-        # exercised through ops below for every kind)
-        if kind == "xnor":
-            assert _lib.call_counts["qt_conv_first_direct_f32"] == before.get("qt_conv_first_direct_f32", 0) + 1, mode
+        assert _lib.call_counts["qt_conv_first_direct_f32"] == before.get("qt_conv_first_direct_f32", 0) + 1, mode
         assert tuple(y.shape) == want.shape
         assert norm_err(n(y), want) <= TOL, (mode, norm_err(n(y), want))
     if kind != "xnor":
