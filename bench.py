@@ -945,8 +945,13 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         xt = torch.randn(Bt, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
         tt = torch.randint(0, 10, (Bt,), device=dev)
         before = dict(_fused_library_paths())
+        from pytorch_quantize_impls_amd import lazy_train
+        lazy_train.STATS.clear()
         t_ours, loss_ours = bts.step_time(mt, mt, xt, tt)
+        chain_stats = {k: v for k, v in lazy_train.STATS.items() if k.startswith(("fused:", "replayed:"))}
         lib_used = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
+        with lazy_train.eager():         # every module by itself: torch / MIOpen pooling, BatchNorm, Hardtanh between the layers
+            t_mbm, loss_mbm = bts.step_time(mt, mt, xt, tt)
         # the same step with every [MaxPool, BatchNorm, Hardtanh, BinaryConnect] run on this backend's training-chain kernels
         # (layers.fuse_sequential_training: opt-in, shares the parameters) instead of torch / MIOpen
         mf = bench_models.TrainFusedAlexNetBin(mt)
@@ -956,6 +961,11 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "workload": f"BinaryNet-AlexNet 3x224x224 batch {Bt}, training mode, forward + backward (nll loss), fp32 master weights, "
                         "channels_last; no optimizer step (the reference's trainers are out of scope)",
             "ms_per_step": t_ours, "images_per_s": Bt / t_ours * 1e3,
+            "what": "the un-modified module graph: the [MaxPool, BatchNorm, Hardtanh, BinaryConnect] runs between the layers reach the "
+                    "fused training nodes by themselves (lazy_train.py)",
+            "recorded_chains_all_timed_steps": chain_stats,
+            "module_by_module": {"ms_per_step": t_mbm, "images_per_s": Bt / t_mbm * 1e3, "loss": loss_mbm,
+                                 "what": "with lazy_train.eager(): torch / MIOpen pooling, BatchNorm, Hardtanh kernels between the layers"},
             "with_fused_training_chain": {"ms_per_step": t_fused, "images_per_s": Bt / t_fused * 1e3, "loss": loss_fused,
                                           "what": "bench_models.TrainFusedAlexNetBin: pooling / BatchNorm(batch statistics) / Hardtanh / "
                                                   "sign forward + backward on csrc/train_chain.hip (opt-in fuse_sequential_training)"},
@@ -1005,6 +1015,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             before = dict(_fused_library_paths())
             lsm = lambda net: (lambda t: torch.nn.functional.log_softmax(net(t), 1))      # noqa: E731
             t_r, loss_r = bts.step_time(lsm(mr), mr, xr, tt, n=10)
+            with lazy_train.eager():
+                t_rm, loss_rm = bts.step_time(lsm(mr), mr, xr, tt, n=10)
             t_rf, loss_rf = bts.step_time(lsm(bench_models.TrainFusedDorefaResNet18(mr)), mr, xr, tt, n=10)
             lib_r = {k: v - before.get(k, 0) for k, v in _fused_library_paths().items() if v != before.get(k, 0)}
             # serving-style: range verdicts remembered (no host sync per layer; a broken assumption gives NaN, never a wrong
@@ -1039,6 +1051,10 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                 "workload": f"DoReFa ResNet-18 W1A4 3x32x32 batch {Bt}, training mode, forward + backward (nll loss), channels_last; "
                             "fp32 stem conv and classifier are torch's, as in the reference",
                 "ms_per_step": t_r, "images_per_s": Bt / t_r * 1e3, "loss": loss_r,
+                "what": "the un-modified module graph: BatchNorm [+ shortcut] [-> ReLU] -> nnDorefaQuant behind every DorefaConv2d reaches the "
+                        "fused training node by itself (lazy_train.py); the fp32 stem's BatchNorm stays MIOpen's",
+                "module_by_module": {"ms_per_step": t_rm, "images_per_s": Bt / t_rm * 1e3, "loss": loss_rm,
+                                     "what": "with lazy_train.eager(): MIOpen BatchNorm, torch add / relu, separate quantiser pass"},
                 "with_fused_training_chain": {"ms_per_step": t_rf, "images_per_s": Bt / t_rf * 1e3, "loss": loss_rf,
                                               "what": "bench_models.TrainFusedDorefaResNet18: BatchNorm(batch statistics) + shortcut add + "
                                                       "ReLU + k-bit quantiser forward + backward as one node per conv "

@@ -7,7 +7,7 @@ import warnings as _warnings
 
 import torch
 
-from .. import ops, packed, lazy
+from .. import ops, packed, lazy, lazy_train
 from .common import front, safeSign, ste_mask
 from . import _fused
 
@@ -41,6 +41,11 @@ class BinaryConnectDeterministic(torch.autograd.Function):
             if out is not None:
                 return out
             input = input.value()
+        elif type(input) in lazy_train._DEFERRED:
+            out = lazy_train.sign(input)
+            if out is not None:
+                return out
+            input = lazy_train.resolve(input)
         return super().apply(input)
 
     @staticmethod

@@ -1,7 +1,7 @@
 """Shared pieces of the STE function family (reference: QuantTorch/functions/common.py)."""
 import torch
 
-from .. import ops, lazy
+from .. import ops, lazy, lazy_train
 
 
 def safeSign(tensor: torch.Tensor) -> torch.Tensor:
@@ -34,6 +34,16 @@ class _FunctionModule(torch.nn.Module):
             if out is not None:
                 return out
             x = x.value()
+        elif type(x) in lazy_train._DEFERRED:
+            # training mode: the recorded [pool] -> BatchNorm -> ... chain runs as one autograd node (lazy_train.py)
+            out = None
+            if getattr(self.core, "_qt_records_sign", False):
+                out = lazy_train.sign(x)
+            elif getattr(self.core, "_qt_quant_bits", None) is not None:
+                out = lazy_train.quant(x, self.core._qt_quant_bits)
+            if out is not None:
+                return out
+            x = lazy_train.resolve(x)
         return self.core.apply(x)
 
 

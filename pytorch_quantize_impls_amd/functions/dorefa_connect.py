@@ -3,7 +3,7 @@ import warnings
 
 import torch
 
-from .. import ops, packed, lazy
+from .. import ops, packed, lazy, lazy_train
 from .common import front, safeSign
 from . import _fused
 
@@ -45,6 +45,11 @@ def _make_quant_function(bit_width):
                 if out is not None:
                     return out
                 input = input.value()
+            elif type(input) in lazy_train._DEFERRED:
+                out = lazy_train.quant(input, bit_width)
+                if out is not None:
+                    return out
+                input = lazy_train.resolve(input)
             return super().apply(input)
 
         @staticmethod

@@ -2,7 +2,7 @@
 import torch
 
 from ..functions import dorefa_connect, _fused
-from .. import lazy
+from .. import lazy, lazy_train
 from ..packed import CodeActivation as _CodeActivation
 from .common import QLayer, EvalSwapMixin
 
@@ -40,7 +40,9 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
 
     def forward(self, input):
-        input = lazy.resolve(input)
+        return lazy_train.wrap(self, self._forward_impl(lazy.resolve(input)))
+
+    def _forward_impl(self, input):
         if isinstance(input, _CodeActivation) and (self.training or self.bit_width != 1):
             raise RuntimeError("CodeActivation inputs are an inference feature of 1-bit-weight DoReFa layers: "
                                "call .eval() first (k-bit weights: pass input.float())")

@@ -771,7 +771,7 @@ class FusedTrainBnActQuant(torch.nn.Module):
             raise ValueError("the fused chain writes int8 codes: 2 <= a_bits <= 8 (or 0: no quantiser)")
 
     def forward(self, x, residual=None):
-        x = lazy.resolve(x)
+        x, residual = lazy.resolve(x), lazy.resolve(residual)
         bn = self.bn
         fast = (self.training and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 4)
                 and bn.momentum is not None and bn.track_running_stats and x.shape[0] * (x[0, 0].numel()) > 1

@@ -7,6 +7,7 @@ binary net): fp32-GEMM accuracy, and for Log weights this IS the shift-add GEMM 
 """
 import torch
 
+from .. import lazy
 from ..functions import _fused, log_lin_connect
 from .common import EvalSwapMixin, QLayer
 
@@ -48,6 +49,7 @@ class LinearQuant(_WeightInit, EvalSwapMixin, torch.nn.Linear, QLayer):
         self.weight_op = log_lin_connect.nnQuant(dtype=dtype, fsr=fsr, bit_width=bit_width, with_sign=True, lin_back=True)
 
     def forward(self, input):
+        input = lazy.resolve(input)
         wq = self.weight_op.forward(self.weight)
         if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and _exact_in_bf16(self.qdtype, self.bit_width)
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
@@ -78,6 +80,7 @@ class QuantConv2d(_WeightInit, EvalSwapMixin, torch.nn.Conv2d, QLayer):
         self.weight_op = log_lin_connect.nnQuant(dtype=dtype, fsr=fsr, bit_width=bit_width, with_sign=True, lin_back=True)
 
     def forward(self, input):
+        input = lazy.resolve(input)
         wq = self.weight_op.forward(self.weight) if self.training else self.weight
         if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and input.dim() == 4
                 and self.groups == 1 and self.padding_mode == "zeros" and not isinstance(self.padding, str)

@@ -46,7 +46,7 @@ import torch
 import torch.nn.functional as F
 from torch.utils._pytree import tree_map_only
 
-from . import ops, packed
+from . import lazy_train, ops, packed
 
 #: master switch (module-by-module execution when False)
 ENABLED = True
@@ -472,7 +472,11 @@ def _wrap(node: _Node, device=None) -> LazyActivation:
 def resolve(x):
     """``x`` itself, or the fp32 tensor a deferred activation stands for (entry guard of every consumer that does not
     take part in the fused chain)."""
-    return x._qt.materialise() if isinstance(x, LazyActivation) else x
+    if isinstance(x, LazyActivation):
+        return x._qt.materialise()
+    if type(x) in lazy_train._DEFERRED:
+        return lazy_train.resolve(x)
+    return x
 
 
 # ---- recording handlers ----------------------------------------------------------------------------------------------
@@ -741,7 +745,9 @@ def conv_forward(layer, input, kind: str):
             STATS["deferred"] += 1
             return _wrap(_Node(None, None, (N, int(layer.out_channels), int(Ho), int(Wo)), layer=layer, kind=kind,
                                input=input))
-    return layer._forward_impl(input)
+    if type(input) in lazy_train._DEFERRED:
+        input = lazy_train.resolve(input)
+    return lazy_train.wrap(layer, layer._forward_impl(input))
 
 
 def _dorefa_can_defer(layer, input) -> bool:
@@ -794,7 +800,9 @@ def dorefa_conv_forward(layer, input):
             node = _Node(None, None, (N, int(layer.out_channels), int(Ho), int(Wo)), layer=layer, kind="dorefa", input=input)
             node.stamp += _stamp(tagged)          # the fp32 tensor whose code tag is being used
             return _wrap(node)
-    return layer._forward_impl(tagged if tagged is not None else input)
+    if type(input) in lazy_train._DEFERRED:
+        input = lazy_train.resolve(input)
+    return lazy_train.wrap(layer, layer._forward_impl(tagged if tagged is not None else input))
 
 
 class _CodeShapeOnly(packed.CodeActivation):
@@ -823,4 +831,6 @@ def linear_forward(layer, input, kind: str):
                     return _fused.packed_xnor_linear(layer, act, hwc=n.chw)
                 return _fused.packed_linear(layer, act, kind, hwc=n.chw)
         input = n.materialise()
-    return layer._forward_impl(input)
+    if type(input) in lazy_train._DEFERRED:
+        input = lazy_train.resolve(input)
+    return lazy_train.wrap(layer, layer._forward_impl(input))

@@ -745,9 +745,11 @@ def test_dorefa_resnet18_training_step_with_the_fused_training_chain(dev, w_bits
     m2, m3 = copy.deepcopy(m), copy.deepcopy(m)
     x = torch.randn(64, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
     t = torch.randint(0, 10, (64,), device=dev)
-    loss_ref = torch.nn.functional.cross_entropy(m2(x), t)
-    loss_ref.backward()
-    torch.nn.functional.cross_entropy(m3(x * (1.0 + 1e-6)), t).backward()
+    from pytorch_quantize_impls_amd import lazy_train
+    with lazy_train.eager():          # the yardstick is the module-by-module graph (MIOpen BatchNorm, torch add / relu)
+        loss_ref = torch.nn.functional.cross_entropy(m2(x), t)
+        loss_ref.backward()
+        torch.nn.functional.cross_entropy(m3(x * (1.0 + 1e-6)), t).backward()
     fused = bench_models.TrainFusedDorefaResNet18(m)
     _fused.LIBRARY_PATHS.clear()
     before = dict(_lib.call_counts)

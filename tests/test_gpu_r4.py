@@ -463,3 +463,144 @@ def test_first_layer_direct_conv_threshold_bits_equal_the_unfused_chain(dev):
         assert _lib.call_counts["qt_conv_first_direct_bits_f32"] == before.get("qt_conv_first_direct_bits_f32", 0) + 1
         want = ops.sign_pack(e.permute(0, 2, 3, 1).contiguous())[0].sign
         assert torch.equal(bits, want), cls.__name__
+
+
+# ---- un-modified TRAINING graphs reach the fused training nodes (lazy_train.py) --------------------------------
+
+def _train_step(net, model, x, t, loss_fn):
+    model.zero_grad(set_to_none=True)
+    loss = loss_fn(net(x), t)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone()
+
+
+def _assert_same_step(m_a, m_b, loss_a, loss_b, library=()):
+    """``library``: parameters whose gradient comes from the dense library (the fp32 stem conv: MIOpen's weight gradient adds
+    with atomics, two runs of the SAME graph differ in the last bit — tools/probes/lazy_train_dbg.py)."""
+    assert torch.equal(loss_a, loss_b), (float(loss_a), float(loss_b))
+    for (k, p), (_, q_) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert (p.grad is None) == (q_.grad is None), k
+        if p.grad is not None and k in library:
+            assert norm_err(n(p.grad), n(q_.grad)) <= TOL, k
+        elif p.grad is not None:
+            assert torch.equal(p.grad, q_.grad), k
+    for (k, p), (_, q_) in zip(m_a.named_buffers(), m_b.named_buffers()):
+        assert torch.equal(p, q_), k
+
+
+def test_alexnet_module_graph_trains_on_the_fused_chain_by_itself(dev):
+    """bench_models.AlexNetBin, un-modified, in training mode: every [MaxPool2d, BatchNorm, Hardtanh, BinaryConnect] run (and the
+    reshape in front of the classifier's BinaryConnect) is recorded by lazy_train.py and runs as the SAME autograd node as the
+    explicit TrainFusedAlexNetBin form — loss, every gradient and every BatchNorm buffer bit for bit — with no torch / MIOpen
+    pooling, BatchNorm or Hardtanh kernel in the step (7 fused nodes, nothing replayed); ``lazy_train.eager()`` restores the
+    module-by-module step."""
+    import copy
+    import bench_models
+    from pytorch_quantize_impls_amd import lazy_train
+    torch.manual_seed(21)
+    model = bench_models.AlexNetBin()
+    bench_models.randomize_bn(model, 2)
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    twin = copy.deepcopy(model)
+    x = torch.randn(16, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 10, (16,), device=dev)
+    lazy_train.STATS.clear()
+    before = dict(_lib.call_counts)
+    la = _train_step(model, model, x, t, torch.nn.functional.nll_loss)
+    assert _lib.call_counts["qt_pool_bn_sign_train_f32"] - before.get("qt_pool_bn_sign_train_f32", 0) == 7
+    assert lazy_train.STATS["fused:sign"] == 7 and not any(k.startswith("replayed") for k in lazy_train.STATS), dict(lazy_train.STATS)
+    lb = _train_step(bench_models.TrainFusedAlexNetBin(twin), twin, x, t, torch.nn.functional.nll_loss)
+    _assert_same_step(model, twin, la, lb)
+    # the profiler's view: no MIOpen BatchNorm / torch pooling kernel in the un-modified step
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        _train_step(model, model, x, t, torch.nn.functional.nll_loss)
+    names = [e.key for e in prof.key_averages()]
+    assert not [k for k in names if "atch" in k and "orm" in k and "qt_" not in k], names
+    assert not [k for k in names if "max_pool" in k.lower() and "qt_" not in k], names
+    # switched off: the module-by-module step (MIOpen's BatchNorm: same loss to rounding, not bit for bit)
+    before = dict(_lib.call_counts)
+    with lazy_train.eager():
+        lc = _train_step(twin, twin, x, t, torch.nn.functional.nll_loss)
+    assert _lib.call_counts["qt_pool_bn_sign_train_f32"] == before.get("qt_pool_bn_sign_train_f32", 0)
+    assert abs(float(lc) - float(la)) <= 5e-2 * abs(float(la))
+
+
+class _ModuleStem(torch.nn.Module):
+    def __init__(self, bn, quant):
+        super().__init__()
+        self.bn, self.quant = bn, quant
+
+    def forward(self, x):
+        return self.quant(torch.relu(self.bn(x)))
+
+
+@pytest.mark.parametrize("w_bits", [1, 3])
+def test_dorefa_resnet_module_graph_trains_on_the_fused_chain_by_itself(dev, w_bits):
+    """bench_models.DorefaResNet18, un-modified, in training mode: BatchNorm [+ shortcut] -> ReLU -> nnDorefaQuant behind each of the
+    16 DorefaConv2d runs as one _TrainBnActQuantFn node and the 3 shortcut BatchNorms as its quantiser-less form — the step of
+    TrainFusedDorefaResNet18 bit for bit (with the fp32 stem's BatchNorm left to MIOpen in both, the one chain that does not
+    start at a quantised layer)."""
+    import copy
+    import bench_models
+    from pytorch_quantize_impls_amd import lazy_train
+    torch.manual_seed(22)
+    m = bench_models.DorefaResNet18(w_bits=w_bits, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    m = m.to(dev).to(memory_format=torch.channels_last).train()
+    twin = copy.deepcopy(m)
+    x = torch.randn(32, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 10, (32,), device=dev)
+    lazy_train.STATS.clear()
+    before = dict(_lib.call_counts)
+    la = _train_step(m, m, x, t, torch.nn.functional.cross_entropy)
+    assert _lib.call_counts["qt_bn_train_stats_f32"] - before.get("qt_bn_train_stats_f32", 0) == 19      # 16 convs + 3 shortcuts
+    assert _lib.call_counts["qt_bn_act_train_backward_f32"] - before.get("qt_bn_act_train_backward_f32", 0) == 19
+    assert lazy_train.STATS["fused:quant"] == 16 and lazy_train.STATS["replayed:bn"] == 3, dict(lazy_train.STATS)
+    explicit = bench_models.TrainFusedDorefaResNet18(twin)
+    explicit.q0 = _ModuleStem(twin.bn, twin.quant)
+    lb = _train_step(explicit, twin, x, t, torch.nn.functional.cross_entropy)
+    _assert_same_step(m, twin, la, lb, library=("stem.weight",))
+
+
+def test_training_chain_outside_the_grammar_is_the_module_chain(dev):
+    """Recorded calls whose consumer is not BinaryConnect / nnDorefaQuant: BatchNorm by the quantiser-less node (fp64 parity like
+    the fused forms), the rest by torch on the real tensor; a BatchNorm on C % 4 != 0 channels, ceil-mode pooling, an eval-mode
+    BatchNorm and dropout are not recorded at all; the last layer's output is the real tensor for C++ callers."""
+    from pytorch_quantize_impls_amd import lazy_train
+    from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin
+    torch.manual_seed(23)
+    conv = BinConv2d(16, 24, 3, padding=1).to(dev).train()
+    bn = torch.nn.BatchNorm2d(24).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    x = torch.where(torch.randn(6, 16, 9, 9, device=dev) < 0, -1.0, 1.0)
+    out = conv(x)
+    assert type(out) is lazy_train.TrainOut
+    (g,) = torch.autograd.grad(out.sum(), conv.weight)                   # C++ entry: the ordinary tensor and graph
+    assert torch.isfinite(g).all()
+    h = bn(conv(x))
+    assert type(h) is lazy_train.TrainChain
+    y = torch.tanh(h)
+    rbn = torch.nn.BatchNorm2d(24).double().train()
+    rbn.load_state_dict({k: v.double().cpu() if v.is_floating_point() else v.cpu() for k, v in bn.state_dict().items()
+                         if k != "num_batches_tracked"}, strict=False)
+    rbn.running_mean.zero_()
+    rbn.running_var.fill_(1.0)
+    with lazy_train.eager():
+        ref = torch.tanh(rbn(conv(x).double().cpu()))
+    assert norm_err(n(y), n(ref)) <= TOL
+    assert norm_err(n(bn.running_mean), n(rbn.running_mean)) <= 1e-6 and int(bn.num_batches_tracked) == 1
+    # not recorded
+    bn6 = torch.nn.BatchNorm2d(6).to(dev).train()
+    assert type(bn6(BinConv2d(16, 6, 3).to(dev).train()(x))) is torch.Tensor
+    assert type(torch.nn.functional.max_pool2d(conv(x), 2, 2, ceil_mode=True)) is torch.Tensor
+    assert type(bn.eval()(conv(x))) is torch.Tensor
+    assert type(torch.nn.functional.dropout(conv(x), 0.5, True)) is torch.Tensor
+    lin = LinearBin(32, 10).to(dev).train()
+    o = lin(torch.randn(4, 32, device=dev))
+    loss = torch.nn.functional.cross_entropy(o, torch.randint(0, 10, (4,), device=dev))
+    loss.backward()
+    assert lin.weight.grad is not None and type(loss) is torch.Tensor
