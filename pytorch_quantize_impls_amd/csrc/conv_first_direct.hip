@@ -22,6 +22,18 @@
 #include <cstdlib>
 #include "qt_common.h"
 
+#ifdef QT_PROFILING_VARIANTS
+// profiling builds only (tools/probes/stamps_conv1.py): shader-clock cycles wave 0 of every workgroup spends per phase, summed
+__device__ unsigned long long qt_first_stamps[40];
+#define QT_FS_DECL unsigned long long fs_t = clock64(), fs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QT_FS(i) do { const unsigned long long t_ = clock64(); fs_acc[i] += t_ - fs_t; fs_t = t_; } while (0)
+#define QT_FS_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&qt_first_stamps[(threadIdx.x >> 6) * 8 + i_], fs_acc[i_]); if (threadIdx.x == 0) atomicAdd(&qt_first_stamps[32], 1ull); } } while (0)
+#else
+#define QT_FS_DECL
+#define QT_FS(i)
+#define QT_FS_FLUSH
+#endif
+
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -74,11 +86,16 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, lrow = lane & 31;
+    QT_FS_DECL;
     const int tpi = a.tiles_y * a.tiles_x;
     const int ntiles = a.N * tpi;
     const int plane_bytes = a.PR * a.RS * 2;
     const int buf_bytes = 2 * plane_bytes;                                   // [hi plane | lo plane]
     float* red = reinterpret_cast<float*>(smem + 2 * buf_bytes);           // per buffer: 4 partial maxima, scale, 1 / scale
+    // fp32 epilogue: per patch buffer, the byte offset of each of the tile's 128 pixels within its image's output plane
+    // ((oy Wo + ox) ldy 4; OOB for pixels past the tile / the map) — written with the patch, read as 16-byte runs by the epilogue
+    int* otab = reinterpret_cast<int*>(smem + 2 * buf_bytes + 64);
+    constexpr int OOB = 0x40000000;                              // two of them add up to 2^31: still past any buffer extent
     const int ppr = a.RS >> 1;                   // pairs per LDS row
 
     // the patch in flight: a thread owns ONE pair column pc (two consecutive elements of a patch row) and walks the rows
@@ -108,50 +125,69 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         asm volatile("" : "+v"(rr), "+v"(pc));      // opaque per tile: what follows is loop-invariant and would be hoisted into spills
         const int e = 2 * pc;
         const bool act = rr < rpp && e < a.PCE;
-        int64_t off0 = 0, off1 = 0;                 // element offsets of the pair within an image row
-        bool ok0 = false, ok1 = false, vec = false;
         if (a.rows_dense) {
             // channels-last image, no channel padding: a patch row is ONE contiguous span of the image row starting at element
-            // ix0 * C (even: 8-byte aligned float2 loads); spans are clipped against the row for the zero padding
-            const int g = ix0 * a.C + e, gend = a.W * a.C;
-            ok0 = act && g >= 0 && g < gend;
-            ok1 = act && g + 1 >= 0 && g + 1 < gend && e + 1 < a.PCE;
-            vec = ok0 && ok1;
-            off0 = g;
-            off1 = g + 1;
+            // ix0 * C + e, e even — 8-byte aligned pairs, and a pair lies inside the image row or outside it as a whole (row length
+            // W * C and ix0 * C are even).  The image is a BUFFER: a pair outside the row / the image / the patch gets an offset past
+            // the buffer's extent and the bounds check returns zeros — one load per pass for every lane, no branch, no mask kept
+            // across the MFMA loop.  (With a conditional scalar path in the loop, ONE lane holding the odd last element of a patch
+            // row made its whole wave execute both paths in every pass.)
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xi), 0, a.H * (int)a.sh * 4, 0x00020000);
+            const int g = ix0 * a.C + e;
+            const int cb = (act && g >= 0 && g < a.W * a.C) ? g * 4 : OOB;
+            const int rb4 = (int)a.sh * 4;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int r = rr + i * rpp, iy = iy0 + r;
+                const bool rok = r < a.PR && (unsigned)iy < (unsigned)a.H;
+                const u2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, rok ? cb + iy * rb4 : OOB, 0, 0);
+                v0[i] = __uint_as_float(v.x);
+                v1[i] = __uint_as_float(v.y);
+            }
         } else {
+            // any layout: two scalar loads per pass from clamped (valid) addresses, zeroed by a select
             const int px0 = divm(e, a.m_cp, a.Cp), c0 = e - px0 * a.Cp;
             int px1 = px0, c1 = c0 + 1;
             if (c1 == a.Cp) { c1 = 0; ++px1; }
             const int ixa = ix0 + px0, ixb = ix0 + px1;
-            ok0 = act && c0 < a.C && (unsigned)ixa < (unsigned)a.W;
-            ok1 = act && e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W;
-            off0 = (int64_t)ixa * a.sw + (int64_t)c0 * a.sc;
-            off1 = (int64_t)ixb * a.sw + (int64_t)c1 * a.sc;
-        }
-        const float* p0 = xi + off0;
-        const float* p1 = xi + off1;
+            const bool ok0 = act && c0 < a.C && (unsigned)ixa < (unsigned)a.W;
+            const bool ok1 = act && e + 1 < a.PCE && c1 < a.C && (unsigned)ixb < (unsigned)a.W;
+            const float* p0 = xi + (ok0 ? (int64_t)ixa * a.sw + (int64_t)c0 * a.sc : 0);
+            const float* p1 = xi + (ok1 ? (int64_t)ixb * a.sw + (int64_t)c1 * a.sc : 0);
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int r = rr + i * rpp, iy = iy0 + r;
-            const bool rok = r < a.PR && (unsigned)iy < (unsigned)a.H;
-            const int64_t ro = (int64_t)iy * a.sh;
-            float f0 = 0.0f, f1 = 0.0f;
-            if (rok && vec) {
-                const float2 v = *reinterpret_cast<const float2*>(p0 + ro);
-                f0 = v.x;
-                f1 = v.y;
-            } else if (rok) {
-                if (ok0) f0 = p0[ro];
-                if (ok1) f1 = p1[ro];
+            for (int i = 0; i < MAXP; ++i) {
+                const int r = rr + i * rpp, iy = iy0 + r;
+                const bool rok = r < a.PR && (unsigned)iy < (unsigned)a.H;
+                const int64_t ro = (int64_t)(rok ? iy : 0) * a.sh;
+                const float f0 = p0[ro], f1 = p1[ro];
+                v0[i] = (rok && ok0) ? f0 : 0.0f;
+                v1[i] = (rok && ok1) ? f1 : 0.0f;
             }
-            v0[i] = f0;
-            v1[i] = f1;
         }
     };
 
     // ---- registers -> two fp16 planes in LDS buffer `buf` with the tile's power-of-two scale (two barriers) -----------------------
-    auto finish_patch = [&](int buf) __attribute__((always_inline)) {
+    auto finish_patch = [&](int buf, int tile_in) __attribute__((always_inline)) {
+        if constexpr (!BITS) {
+            int j = tid;
+            asm volatile("" : "+v"(j));
+            if (j < 128) {
+                int img, oy0, ox0;
+                tile_origin(tile_in, img, oy0, ox0);
+                const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+                const int oy = oy0 + oyl, ox = ox0 + oxl;
+                const bool ok = j < a.TOY * a.TOX && oy < a.Ho && ox < a.Wo;
+                otab[buf * 128 + j] = ok ? (int)(((int64_t)oy * a.Wo + ox) * a.ldy * 4) : OOB;
+            }
+        }
+        {   // the element past an odd patch row: the dense loader fetched image data there
+            int pc = pc0;
+            asm volatile("" : "+v"(pc));
+            const bool tail = 2 * pc + 1 >= a.PCE;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) v1[i] = tail ? 0.0f : v1[i];
+        }
         unsigned mx = 0;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) mx = max(mx, max(__float_as_uint(v0[i]) & 0x7fffffffu, __float_as_uint(v1[i]) & 0x7fffffffu));
@@ -159,9 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
         float* rb = red + buf * 8;
         if (lane == 0) rb[wave] = __uint_as_float(mx);
+        QT_FS(4);
         __syncthreads();           // every wave is past the MFMA loop that read this buffer's predecessor; partial maxima visible
         // s = 2^(e - 14) with e the exponent of max|x|: max|x| / s in [2^14, 2^15).  max|x| == 0 / subnormal, inf, NaN: s = 1 (an
         // inf / NaN pixel then poisons its outputs through fp16 inf / NaN, as it does in the reference's fp32 conv)
+        QT_FS(5);
         const unsigned m = max(max(__float_as_uint(rb[0]), __float_as_uint(rb[1])), max(__float_as_uint(rb[2]), __float_as_uint(rb[3])));
         const int eb = (int)(m >> 23);
         float sc = 1.0f;
@@ -191,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
                 p += dp;
             }
         }
+        QT_FS(6);
         __syncthreads();
+        QT_FS(7);
     };
 
     // ---- per-wave constants of the MFMA loop -----------------------------------------------------------------------------------------
@@ -210,28 +250,77 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     // last k-step.  With conditionals in the loop hipcc puts s_waitcnt vmcnt(0) in front of every MFMA group: the whole L2
     // latency of the prefetch just issued, per k-step.)
     const int ntl = a.Coutp / 32 - 1;
-    int64_t wbase[3];
+    // the weight planes are BUFFERS: per-lane byte offset of the lane's chunk within a k-step (constant), k-step offset in an SGPR —
+    // no vector address arithmetic in the loop
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    int wbase[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) wbase[t] = (int64_t)half * a.Coutp + (int64_t)min(nt0 + t, ntl) * 32 + lrow;
-    const int64_t wstep = 2 * (int64_t)a.Coutp;                 // 16-byte chunks per k-step
+    for (int t = 0; t < 3; ++t) wbase[t] = (half * a.Coutp + min(nt0 + t, ntl) * 32 + lrow) * 16;
+    const int wstep = 2 * a.Coutp * 16;                        // bytes per k-step
+    const int wextent = a.NKS * wstep;
+    const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.whi), 0, wextent, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t wlr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(REALW ? a.wlo : a.whi), 0, wextent, 0x00020000);
     auto load_w = [&](int s, uint4 (&wh)[3], uint4 (&wl)[3]) __attribute__((always_inline)) {
-        const int64_t o = (int64_t)min(s, a.NKS - 1) * wstep;
+        const int o = min(s, a.NKS - 1) * wstep;                // uniform
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            wh[t] = a.whi[o + wbase[t]];
-            if constexpr (REALW) wl[t] = a.wlo[o + wbase[t]];
+            const u4v h = __builtin_amdgcn_raw_buffer_load_b128(whr, wbase[t], o, 0);
+            wh[t] = make_uint4(h.x, h.y, h.z, h.w);
+            if constexpr (REALW) {
+                const u4v l = __builtin_amdgcn_raw_buffer_load_b128(wlr, wbase[t], o, 0);
+                wl[t] = make_uint4(l.x, l.y, l.z, l.w);
+            }
         }
     };
 
     // per-channel epilogue constants of this lane's three channels: loaded once per (persistent) workgroup
-    float e_bv[3], e_al[3], e_nbe[3];
+    float e_bv[3];
+    int e_co[3];                                               // fp32 epilogue: byte offset of the lane's channel within a pixel, or OOB
+    // threshold epilogue: bit = fl(fl(fl(u) + bias) * alpha) < -beta with u = acc * oscale, oscale a power of two (u exact).  The
+    // left side is monotone in u, so per channel the test IS a comparison of u with one fp32 threshold theta — found once per
+    // workgroup by bisection over the ordered fp32 values WITH the epilogue's own arithmetic (exact by construction, NaN and the
+    // infinities included), rescaled per tile by the exact 1 / oscale: one compare per value instead of mul, add, mul, compare.
+    //   alpha > 0: bit <=> u < theta;   alpha < 0: bit <=> u > theta' <=> -u < -theta' (e_sg flips the sign of u, e_th = -theta');
+    //   alpha == 0 / NaN: the left side is +-0 / NaN for every finite u — the bit is the constant (0 < -beta): theta = +-inf
+    float e_th[3];
+    unsigned e_sg[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (nt0 + t) * 32 + lrow;
         const bool nin = n < a.Cout;
+        e_co[t] = nin ? n * 4 : OOB;
         e_bv[t] = (a.bias && nin) ? a.bias[n] : 0.0f;
-        e_al[t] = (BITS && nin) ? a.alpha[n] : 0.0f;
-        e_nbe[t] = (BITS && nin) ? -a.beta[n] : 0.0f;
+        e_th[t] = 0.0f;
+        e_sg[t] = 0u;
+        if constexpr (BITS) {
+            const float al = nin ? a.alpha[n] : 0.0f, nbe = nin ? -a.beta[n] : 0.0f, bv = e_bv[t];
+            auto key2f = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+            auto pred = [&](unsigned k) { const float u = key2f(k); const float v = u + bv; return v * al < nbe; };
+            const unsigned klo = 0x007fffffu, khi = 0xff800000u;          // keys of -inf, +inf
+            if (!(al > 0.0f) && !(al < 0.0f)) {
+                e_th[t] = (0.0f < nbe) ? __uint_as_float(0x7f800000u) : __uint_as_float(0xff800000u);
+            } else if (al > 0.0f) {                                     // first key whose bit is 0 (the bit of +inf is 0)
+                unsigned lo = klo, hi = khi;
+                while (lo < hi) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    if (!pred(mid)) hi = mid; else lo = mid + 1;
+                }
+                e_th[t] = key2f(lo);
+            } else {                                                    // first key whose bit is 1 (the bit of -inf is 0); none: never
+                e_sg[t] = 0x80000000u;
+                if (!pred(khi)) {
+                    e_th[t] = __uint_as_float(0xff800000u);            // -u < -inf: never
+                } else {
+                    unsigned lo = klo, hi = khi;
+                    while (lo < hi) {
+                        const unsigned mid = lo + ((hi - lo) >> 1);
+                        if (pred(mid)) hi = mid; else lo = mid + 1;
+                    }
+                    e_th[t] = -key2f(lo - 1);                           // theta' = the last value whose bit is 0
+                }
+            }
+        }
     }
     const float wsc = a.wscale_dev ? a.wscale * *a.wscale_dev : a.wscale;
     // rotated tile loop — every phase exists ONCE in the code (the unrolled patch passes and the unrolled epilogue are large; inlined
@@ -241,21 +330,34 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     while (true) {
         const bool more = load_tile < ntiles;                  // uniform
         if (more) issue_patch(load_tile);                      // in flight across the MFMA loop below
+        QT_FS(0);
         if (tile >= 0) {
 
-        const unsigned char* hib = smem + buf * buf_bytes;
-        const unsigned char* lob = hib + plane_bytes;
+        // LDS byte address of this lane's pixel runs in the two planes (per tile)
+        const unsigned char* ahb[2];
+        const unsigned char* alb[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            ahb[mt] = smem + buf * buf_bytes + abase[mt];
+            alb[mt] = ahb[mt] + plane_bytes;
+        }
         auto load_a = [&](int s, uint4 (&ah)[2], uint4 (&al)[2]) __attribute__((always_inline)) {
-            // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one re-read the last chunk (zero weights)
-            const int q = min(2 * s + half, a.NCH - 1);
-            const int ky = divm(q, a.m_cpk, a.CPK), cc = q - ky * a.CPK;
-            const int koff = (ky * a.RS + cc * 8) * 2;
+            // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one re-read the last chunk (zero
+            // weights).  Both halves' offsets are computed on the scalar unit (s is uniform), a lane picks its own: one vector
+            // instruction per k-step instead of a division chain
+            const int q0 = min(2 * s, a.NCH - 1), q1 = min(2 * s + 1, a.NCH - 1);
+            int ky0 = (int)(((unsigned long long)(unsigned)q0 * a.m_cpk) >> 32), ky1 = (int)(((unsigned long long)(unsigned)q1 * a.m_cpk) >> 32);
+            ky0 = a.CPK == 1 ? q0 : ky0;                         // (the magic of 1 is 0) — selects, not branches
+            ky1 = a.CPK == 1 ? q1 : ky1;
+            const int k0 = (ky0 * a.RS + (q0 - ky0 * a.CPK) * 8) * 2;
+            const int k1 = (ky1 * a.RS + (q1 - ky1 * a.CPK) * 8) * 2;
+            const int koff = half ? k1 : k0;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const uint2 h0 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff);
-                const uint2 h1 = *reinterpret_cast<const uint2*>(hib + abase[mt] + koff + 8);
-                const uint2 l0 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff);
-                const uint2 l1 = *reinterpret_cast<const uint2*>(lob + abase[mt] + koff + 8);
+                const uint2 h0 = *reinterpret_cast<const uint2*>(ahb[mt] + koff);
+                const uint2 h1 = *reinterpret_cast<const uint2*>(ahb[mt] + koff + 8);
+                const uint2 l0 = *reinterpret_cast<const uint2*>(alb[mt] + koff);
+                const uint2 l1 = *reinterpret_cast<const uint2*>(alb[mt] + koff + 8);
                 ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
                 al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
@@ -275,12 +377,14 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
 #pragma unroll
         for (int u = 0; u < WD; ++u) load_w(u, wh[u], wl[u]);
         load_a(0, ah[0], al[0]);
+        QT_FS(1);
         for (int s0 = 0; s0 < a.NKS; s0 += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int s = s0 + u;
                 load_w(s + WD, wh[(u + WD) % RING], wl[(u + WD) % RING]);
                 load_a(s + 1, ah[(u + 1) & 1], al[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this k-step's MFMAs, not after them
                 // one term at a time over the six accumulator tiles: two MFMAs on the same accumulator are never adjacent
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
@@ -299,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
             }
         }
 
+        QT_FS(2);
         // ---- epilogue: lane owns channel n = tile * 32 + lrow, rows (r & 3) + 8 (r >> 2) + 4 half of each 32-pixel tile ------------
         // (the lane's coordinates are made opaque per tile: everything below that depends only on them — 32 pixel offsets, the
         // channel constants — is loop-invariant, and hipcc otherwise hoists it out of the tile loop into 200 spilled registers)
@@ -308,27 +413,39 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         tile_origin(tile, img, oy0, ox0);
         const float sx = red[buf * 8 + 4];
         const float oscale = sx * wsc;
+        [[maybe_unused]] const float inv_os = 1.0f / oscale;
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t yrsrc;
+        if constexpr (!BITS)
+            yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + (int64_t)img * a.Ho * a.Wo * a.ldy, 0,
+                                                      (int)((int64_t)a.Ho * a.Wo * a.ldy * 4), 0x00020000);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if ((nt0 + t) * 32 >= a.Coutp) continue;
-            const int n = (nt0 + t) * 32 + lrow_t;
-            const bool nin = n < a.Cout;
-            const float bv = e_bv[t], al_ = e_al[t], nbe = e_nbe[t];
+            const float bv = e_bv[t];
+            [[maybe_unused]] const float thr = e_th[t] * inv_os;     // exact (power of two) unless it leaves the normal range
+            [[maybe_unused]] const unsigned sg = e_sg[t];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int jb = (mg * 2 + mt) * 32;
                 if constexpr (BITS) {
                     uint32_t myword = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[mt][t][r] * oscale + bv;
-                        const unsigned long long mask = __ballot(v * al_ < nbe);      // channels >= Cout: 0 < 0 -> bit 0
-                        const int R = (r & 3) + 8 * (r >> 2);
-                        // v_writelane: the two halves of the (scalar) ballot straight into lanes R and R + 4
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned long long m[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            m[q] = __ballot(__uint_as_float(__float_as_uint(acc[mt][t][4 * g + q]) ^ sg) < thr);    // channels >= Cout: 0
+                        // v_writelane: the two halves of each (scalar) ballot straight into lanes R and R + 4, R = q + 8 g
                         // (gfx950 does not interlock a VALU-written SGPR read by the next VALU and the hazard recogniser does not look
-                        // inside inline asm: the s_nop covers v_cmp -> first write; the writes are chained through myword)
-                        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
+                        // inside inline asm: the s_nop covers the last v_cmp -> first write; the writes are chained through myword)
+                        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %9+4\n\t"
+                            "v_writelane_b32 %0, %3, %9+1\n\tv_writelane_b32 %0, %4, %9+5\n\t"
+                            "v_writelane_b32 %0, %5, %9+2\n\tv_writelane_b32 %0, %6, %9+6\n\t"
+                            "v_writelane_b32 %0, %7, %9+3\n\tv_writelane_b32 %0, %8, %9+7"
+                            : "+v"(myword)
+                            : "s"((uint32_t)m[0]), "s"((uint32_t)(m[0] >> 32)), "s"((uint32_t)m[1]), "s"((uint32_t)(m[1] >> 32)),
+                              "s"((uint32_t)m[2]), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)m[3]), "s"((uint32_t)(m[3] >> 32)),
+                              "n"(8 * g));
                     }
                     const int j = jb + lane_t;                                          // lanes 0 .. 31: one pixel each
                     if (lane_t < 32 && j < npix) {
@@ -343,29 +460,31 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
                         }
                     }
                 } else {
-                  if (nin) {
+                    // buffer stores: voffset = pixel offset (LDS table, four consecutive pixels per 16-byte read) + this lane's channel;
+                    // pixels past the map / channels past Cout carry OOB and are dropped by the bounds check of the buffer
+                    // (no per-value index arithmetic, no branches)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * half_t;
-                        if (j < npix) {
-                            const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
-                            const int oy = oy0 + oyl, ox = ox0 + oxl;
-                            if (oy < a.Ho && ox < a.Wo)
-                                a.y[(((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldy + n] = acc[mt][t][r] * oscale + bv;
-                        }
+                    for (int g = 0; g < 4; ++g) {
+                        const int4 o4 = *reinterpret_cast<const int4*>(otab + buf * 128 + jb + 8 * g + 4 * half_t);
+                        const int oq[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][t][4 * g + q] * oscale + bv), yrsrc,
+                                                                  oq[q] + e_co[t], 0, 0);
                     }
-                  }
                 }
             }
         }
         }
+        QT_FS(3);
         if (!more) break;
         const int nb = tile >= 0 ? (buf ^ 1) : 0;
-        finish_patch(nb);
+        finish_patch(nb, load_tile);
         tile = load_tile;
         load_tile += gridDim.x;
         buf = nb;
     }
+    QT_FS_FLUSH;
 }
 
 int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H, int64_t W,
@@ -381,6 +500,7 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     if (alpha ? (!beta || !bits || ldb < (Cout + 31) / 32) : (!y || ldy < Cout)) return QT_ERR_INVALID_ARG;
     if ((S * Cp) & 3) return QT_ERR_ALIGNMENT;                        // a pixel's run starts on an 8-byte LDS boundary
     if (Cp > 8 || KW * Cp > 256 || KH > 64 || N * Ho * Wo > INT32_MAX || H > 32767 || W > 32767) return QT_ERR_UNSUPPORTED;
+    if (!alpha && Ho * Wo * ldy * 4 >= (1ll << 30)) return QT_ERR_UNSUPPORTED;      // one image's output plane is a buffer (32-bit offsets)
     FirstArgs a;
     a.x = x; a.sn = sn; a.sc = sc; a.sh = sh; a.sw = sw;
     a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W; a.KH = (int)KH; a.KW = (int)KW; a.S = (int)S; a.PH = (int)PH; a.PW = (int)PW;
@@ -397,7 +517,7 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
             const int64_t pr = (int64_t)(ty - 1) * S + KH, pce = ((int64_t)(tx - 1) * S + KW) * Cp;
             const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.CPK * 8) + 3) / 4 * 4;
             if (rs / 2 > 256 || (pr + 256 / (rs / 2) - 1) / (256 / (rs / 2)) > 18) continue;          // <= 18 row passes of the patch loader
-            if (2 * (2 * pr * rs * 2) + 64 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
+            if (2 * (2 * pr * rs * 2) + 64 + 1024 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
             const int64_t tiles = ((Ho + ty - 1) / ty) * ((Wo + tx - 1) / tx);
             // cost: MFMA work (128 rows per tile whatever it holds) + the patch it loads (halo re-reads)
             const double cost = (double)tiles * (128.0 * a.NKS * 16 + 0.25 * (double)(pr * rs));
@@ -420,12 +540,12 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.Cout = (int)Cout; a.Coutp = (int)Coutp;
     a.step_r = 256 / (a.RS / 2); a.step_pc = 0;          // rows of the patch one pass of the loader covers
     // float2 spans: dense channels-last rows, no channel padding, every patch row starts on an even element of an 8-byte aligned row
-    a.rows_dense = (sc == 1 && sw == C && Cp == C && !(sh & 1) && !(sn & 1) && !((a.TOX * S * C) & 1) && !((PW * C) & 1) &&
+    a.rows_dense = (sc == 1 && sw == C && Cp == C && !(sh & 1) && !(sn & 1) && !((a.TOX * S * C) & 1) && !((PW * C) & 1) && H * sh * 4 < (1ll << 30) &&
                     (reinterpret_cast<uintptr_t>(x) & 7) == 0) ? 1 : 0;
     a.bias = bias; a.y = y; a.ldy = ldy; a.alpha = alpha; a.beta = beta; a.bits = bits; a.ldb = ldb;
     const int64_t ntiles = N * a.tiles_y * a.tiles_x;
     if (ntiles > INT32_MAX) return QT_ERR_UNSUPPORTED;
-    const int lds = 2 * (2 * a.PR * a.RS * 2) + 64;                   // two patch buffers (hi + lo planes each) + the scales
+    const int lds = 2 * (2 * a.PR * a.RS * 2) + 64 + 1024;            // two patch buffers (hi + lo planes each) + the scales + pixel offsets
     const unsigned ny = (unsigned)((Coutp + 191) / 192);
     // persistent workgroups: two per CU (256 CUs), shared between the channel blocks
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, std::max<int64_t>(1, 512 / ny)), ny);
@@ -444,6 +564,17 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
 }  // namespace
 
 extern "C" {
+
+#ifdef QT_PROFILING_VARIANTS
+int qt_first_stamps_fetch(unsigned long long* host40, int reset) {
+    if (hipMemcpyFromSymbol(host40, HIP_SYMBOL(qt_first_stamps), 40 * sizeof(unsigned long long)) != hipSuccess) return QT_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[40] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(qt_first_stamps), z, sizeof(z)) != hipSuccess) return QT_ERR_LAUNCH;
+    }
+    return QT_OK;
+}
+#endif
 
 int qt_conv_first_direct_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int64_t N, int64_t C, int64_t H,
                              int64_t W, int64_t KH, int64_t KW, int64_t S, int64_t PH, int64_t PW, int64_t Cp, const uint32_t* w_hi,

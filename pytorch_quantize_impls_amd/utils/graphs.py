@@ -88,7 +88,7 @@ class AutoGraphed(torch.nn.Module):
         # (a submodule left in train() — BatchNorm fine-tuning, stochastic quantisers — would be captured once and replayed with
         # frozen behaviour: every module has to be in eval mode, not just the root)
         ok = (isinstance(x, torch.Tensor) and x.is_cuda and not torch.is_grad_enabled()
-              and not any(m.training for m in self.module.modules()) and not torch.cuda.is_current_stream_capturing())
+              and not _any_training(self.module) and not torch.cuda.is_current_stream_capturing())
         if not ok:
             self.eager_calls += 1
             return self.module(x)
@@ -122,6 +122,18 @@ class AutoGraphed(torch.nn.Module):
         self.replays += 1
         out = g(x)
         return tree_map_only(torch.Tensor, torch.clone, out) if self.clone_output else out
+
+
+def _any_training(module: torch.nn.Module) -> bool:
+    """A module of the tree is in training mode.  The quantised layers' own children (``weight_op``: the weight quantiser as a
+    module) are not looked at: the reference's train() / eval() of those layers sets the flag of the layer alone
+    (layers/binary_layers.py:30-40 — kept, layers/common.py), so they read ``training`` for ever and never act on it."""
+    from ..layers.common import EvalSwapMixin
+    if module.training:
+        return True
+    if isinstance(module, EvalSwapMixin):
+        return False
+    return any(_any_training(c) for c in module.children())
 
 
 def auto_graphed(module: torch.nn.Module, **kw) -> AutoGraphed:

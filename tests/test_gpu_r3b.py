@@ -183,6 +183,24 @@ def test_auto_graphed_replays_the_unmodified_model_and_follows_weight_updates(de
     assert auto.eager_calls == before + 1 and torch.equal(y.detach(), model(xs[0]).detach())
 
 
+def test_auto_graphed_replays_the_dorefa_resnet(dev):
+    """DoReFa layers keep a ``weight_op`` child whose training flag never changes (upstream's train() / eval()): the eval-mode
+    ResNet-18 is still recognised as replayable, and the replayed logits are the module graph's."""
+    import bench_models
+    from pytorch_quantize_impls_amd import utils
+    torch.manual_seed(5)
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m, 4)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    auto = utils.auto_graphed(m)
+    x = torch.randn(32, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = m(x).clone()
+        for _ in range(4):
+            assert torch.equal(auto(x), want)
+    assert auto.replays == 3 and not auto.capture_failures, (auto.replays, auto.capture_failures)
+
+
 def test_bench_two_ranks_self_launched_on_one_device():
     """The whole N > 1 code path of bench.py on a 1-GPU box: `python bench.py --gpus 2 --share-device` with no launcher around it
     self-launches two ranks (gloo rendezvous, both on cuda:0), each runs its batch shard, rank 0 prints the single JSON line."""

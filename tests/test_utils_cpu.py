@@ -165,3 +165,20 @@ def test_auto_graphed_host_logic_on_cpu():
     a._seen[("k",)] = 3
     a.reset()
     assert not a._seen and a._state is None
+
+
+def test_auto_graphed_training_check_ignores_the_layers_own_children():
+    """The quantised layers' train() / eval() set the flag of the layer alone, like upstream (layers/binary_layers.py:30-40): a
+    DoReFa layer's ``weight_op`` child reads training=True for ever.  AutoGraphed's "every module in eval mode" test looks at
+    the layers and at everything around them (BatchNorm, Dropout, function modules), not inside the layers."""
+    import bench_models
+    from pytorch_quantize_impls_amd.utils.graphs import _any_training
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4).eval()
+    assert any(mod.training for mod in m.modules())            # the weight_op children
+    assert not _any_training(m)
+    m.blocks[3].bn2.train()
+    assert _any_training(m)
+    m.eval()
+    m.blocks[5].conv1.train()
+    assert _any_training(m)
+    assert not _any_training(m.eval()) and _any_training(m.train())
