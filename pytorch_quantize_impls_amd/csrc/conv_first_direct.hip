@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     // workgroup by bisection over the ordered fp32 values WITH the epilogue's own arithmetic (exact by construction, NaN and the
     // infinities included), rescaled per tile by the exact 1 / oscale: one compare per value instead of mul, add, mul, compare.
     //   alpha > 0: bit <=> u < theta;   alpha < 0: bit <=> u > theta' <=> -u < -theta' (e_sg flips the sign of u, e_th = -theta');
-    //   alpha == 0 / NaN: the left side is +-0 / NaN for every finite u — the bit is the constant (0 < -beta): theta = +-inf
+    //   alpha == 0: the left side is +-0 for every finite u — the bit is the constant (0 < -beta): theta = +-inf;  alpha NaN: never
     float e_th[3];
     unsigned e_sg[3];
 #pragma unroll
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
             auto pred = [&](unsigned k) { const float u = key2f(k); const float v = u + bv; return v * al < nbe; };
             const unsigned klo = 0x007fffffu, khi = 0xff800000u;          // keys of -inf, +inf
             if (!(al > 0.0f) && !(al < 0.0f)) {
-                e_th[t] = (0.0f < nbe) ? __uint_as_float(0x7f800000u) : __uint_as_float(0xff800000u);
+                // alpha == 0: +-0 < -beta for every finite u;  alpha NaN: never
+                e_th[t] = (al == 0.0f && 0.0f < nbe) ? __uint_as_float(0x7f800000u) : __uint_as_float(0xff800000u);
             } else if (al > 0.0f) {                                     // first key whose bit is 0 (the bit of +inf is 0)
                 unsigned lo = klo, hi = khi;
                 while (lo < hi) {

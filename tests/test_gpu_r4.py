@@ -465,6 +465,53 @@ def test_first_layer_direct_conv_threshold_bits_equal_the_unfused_chain(dev):
         assert torch.equal(bits, want), cls.__name__
 
 
+@pytest.mark.parametrize("real", [False, True])
+def test_first_layer_threshold_epilogue_is_the_float_formula_bit_for_bit(dev, real):
+    """The threshold epilogue compares the raw accumulator with ONE per-channel fp32 threshold (found in the kernel by bisection with
+    the epilogue's own arithmetic) instead of evaluating  fl(fl(y * alpha) + beta) < 0  per value, y = the fp32 route's output.  The
+    bits must be that formula's on y for every kind of channel: alpha > 0, alpha < 0, alpha == 0 (either sign of beta), beta == 0
+    with zero bias (ties at +-0), huge / tiny alpha, infinite beta, NaN beta — and for pixels that are +-inf or NaN (both sides
+    poisoned the same way), on tiles whose power-of-two scales differ by 2^60."""
+    torch.manual_seed(31 + real)
+    N, C, H, W, Cout, k, s_, p_ = 3, 3, 67, 75, 96, 11, 4, 2
+    x = torch.randn(N, C, H, W, device=dev)
+    x[0] *= 2.0 ** 40
+    x[1] *= 2.0 ** -30
+    x[2, :, :20, :20] = torch.round(x[2, :, :20, :20] * 4) / 4          # exact sums: accumulators that hit thresholds exactly
+    x[2, 1, 40, 40] = float("inf")
+    x[2, 2, 60, 10] = float("nan")
+    x[2, 0, 5, 70] = float("-inf")
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, C, k, k, device=dev).sign()
+    if real:
+        w = w * torch.rand(1, 1, k, k, device=dev) * 0.1
+    fw = ops.pack_first_layer_weight(w, s_, real=real)
+    bias = torch.randn(Cout, device=dev)
+    bias[::5] = 0.0
+    alpha = torch.randn(Cout, device=dev)
+    beta = torch.randn(Cout, device=dev) * 3.0
+    alpha[1::8] = 0.0
+    beta[1::16] = -beta[1::16].abs()
+    beta[2::10] = 0.0
+    alpha[3] = 1e30
+    alpha[4] = -1e-30
+    alpha[6] = 1e-42                                    # subnormal
+    beta[7] = float("inf")
+    beta[8] = float("-inf")
+    beta[9] = float("nan")
+    alpha[11] = float("nan")
+    y = ops.conv_first_direct(x, fw, bias, s_, p_)
+    bits = ops.conv_first_direct(x, fw, bias, s_, p_, epi=(alpha, beta)).sign
+    want_neg = (y * alpha + beta) < 0                   # torch evaluates mul then add in fp32, like the fp32 route + the fold
+    got_neg = torch.zeros_like(want_neg)
+    for c in range(Cout):
+        got_neg[:, c] = ((bits[:, c // 32] >> (c % 32)) & 1).bool()
+    bad = (got_neg != want_neg).nonzero()
+    assert bad.numel() == 0, (bad[:10].tolist(), [float(y[i, c]) for i, c in bad[:10].tolist()])
+    assert bool(want_neg.any()) and bool((~want_neg).any())
+    assert (bits[:, Cout // 32:] == 0).all()
+
+
 # ---- un-modified TRAINING graphs reach the fused training nodes (lazy_train.py; VERDICT r3 item 6) --------------------------------
 
 def _train_step(net, model, x, t, loss_fn):
