@@ -208,7 +208,7 @@ def main():
     timing = {"kernel_ms": burst_ms,
               "kernel_ms_what": f"{BURST} launches back to back behind the pack kernel, one HIP-event pair around the burst, the "
                                 "cost of an empty event pair subtracted; agrees with the rocprofv3 --kernel-trace --stats average "
-                                "of this command (profiles/r3_bench_rocprof.md) to ~1 us; `achieved` and `frac` use THIS figure",
+                                "of this command (profiles/r4_bench_rocprof.md: 36.4 us) to ~1 us; `achieved` and `frac` use THIS figure",
               "kernel_ms_in_step_bracket": gemm_ms,
               "kernel_ms_in_step_bracket_what": f"HIP-event pair around the single launch on every {EVENT_EVERY}th step of the timed "
                                                 "region; includes the marker packets / kernel boundary (~3-5 us)",
@@ -256,7 +256,7 @@ def main():
                    # un-tagged inputs of the layer-level legs (AlexNet / C4 / C5) are checked for +-1 on the device; "verify" =
                    # one 4-byte readback per un-tagged input per forward (functions/_fused.py); the C2 step itself packs
                    # through ops.* and asks nothing
-                   "detect_mode": _fused.DETECT_MODE, "float_split": ops.FLOAT_SPLIT,
+                   "detect_mode": _fused.DETECT_MODE, "float_split": ops.current_float_split(),
                    "legs": "every leg of this line runs with detect_mode and float_split above unless its own object says otherwise "
                            "(with_remembered_range_verdicts: detect_mode 'remember'; Lin/Log layers: bf16x3); real-valued first layers: "
                            "AlexNet conv1 on the direct kernel (per-tile two-term fp16 split), VGG conv1 on bf16 triples", "deferred_activations": "on (lazy.ENABLED, lazy.DEFER_CODES): bit-identical "
@@ -644,8 +644,9 @@ def alexnet_roofline(model, fused, x, B):
             "bound": "mfma", "dominant_block": dom["block"], "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
             "unit": "TFLOP/s", "frac": dom["frac"], "dominant_block_ms": dom["ms"], "sum_of_blocks_ms": total,
             "matrix_floor_ms": floor_ms, "blocks": rows,
-            "kernel_names": "profiles/r3_bench_rocprof.md lists the kernels of each block (conv1: s2d_triple_rows_kernel + "
-                            "mfma_gemm_kernel<ElemBf16/ElemF16 conv> + pool_bits_kernel)"}
+            "kernel_names": "profiles/r4_bench_kernel_stats.csv lists the kernels of each block (conv1: conv_first_direct_kernel<real weights?, "
+                            "threshold bits, 18> + pool_bits_kernel; conv2-5: mfma_gemm_kernel<ElemFp4 conv-valid, bits epilogue> (XNOR flavour: "
+                            "<ElemFp4Taps>) [+ pool_bits_kernel]; fc: mfma_gemm_kernel<ElemFp4 skinny> (XNOR flavour: bits_alpha_pairs_kernel + <ElemF16 skinny>))"}
 
 
 def _layer_stats(model, x):

@@ -1261,6 +1261,14 @@ def grouped_quant_conv(layer, input, kind: str, quant_op):
     cl = input.is_contiguous(memory_format=torch.channels_last) and not input.is_contiguous()
     # a +-1 tag of the whole activation (BinaryConnect's sign planes) holds for every channel slice
     known_pm1 = True if (layer.binary_input or packed.lookup(input, packed.NHWC) is not None) else layer.binary_input
+    flag = None
+    if (known_pm1 is None and DETECT_BINARY_INPUT and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+            and input.numel() > 0):
+        # un-tagged activation, no hint: ONE detection on the whole activation, remembered under the layer's own weight (the
+        # per-group weight views are fresh tensors on every call: verdicts keyed on them die with them — a host sync per group
+        # per call, and nothing for DETECT_MODE = "remember" to remember)
+        ok, flag = detect_pm1(input, layer.weight)
+        known_pm1 = bool(ok)
     ys = []
     for g in range(G):
         xg = input[:, g * cin:(g + 1) * cin]
@@ -1272,7 +1280,10 @@ def grouped_quant_conv(layer, input, kind: str, quant_op):
             ys.append(QuantConv2dFn.apply(xg, wg, bg, kind, wq, known_pm1, args))
         else:
             ys.append(quant_conv2d_forward(xg, wg, bg, *args, kind, weight_q=wg, binary_input=known_pm1, padding_mode="zeros"))
-    return torch.cat(ys, 1)
+    out = torch.cat(ys, 1)
+    if flag is not None:          # a remembered "+-1" verdict: the device flag of THIS activation turns a wrong assumption into NaN
+        out = out + torch.where(flag.reshape(()) != 0, float("nan"), 0.0).to(out.dtype)
+    return out
 
 
 #: backward GEMMs with one +-1/0 operand (grad_x = g . Q(W); grad_W = g^T . x for +-1 activations) run on the bf16

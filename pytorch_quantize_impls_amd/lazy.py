@@ -399,6 +399,14 @@ class LazyActivation(torch.Tensor):
                 return func(*args, **kwargs)
         name = getattr(func, "__name__", str(func))
         STATS["fallback:" + name] += 1
+        out_kw = kwargs.get("out")
+        if isinstance(out_kw, LazyActivation):
+            # func(..., out=deferred): the result replaces what the wrapper stood for — computed into a fresh tensor (the cached
+            # value of the old node may be the parent of chains recorded earlier), the wrapper moves on to a constant node
+            rest = {k: v for k, v in kwargs.items() if k != "out"}
+            a2, rest = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (tuple(args), rest))
+            out_kw._qt = _const_node(func(*a2, **rest))
+            return out_kw
         if _writes_in_place(name) and args and isinstance(args[0], LazyActivation):
             # x.op_(...) on a deferred activation outside the grammar: the module-by-module value, mutated — but in a
             # private copy (the cached value of this node may be the parent of chains recorded earlier), and the wrapper
@@ -420,8 +428,8 @@ class LazyActivation(torch.Tensor):
 
 
 def _writes_in_place(name: str) -> bool:
-    return (name.endswith("_") and not name.endswith("__")) or (name.startswith("__i") and name.endswith("__")
-                                                                 and name not in ("__int__", "__index__", "__invert__"))
+    return (name.endswith("_") and not name.endswith("__")) or name == "__setitem__" or (
+        name.startswith("__i") and name.endswith("__") and name not in ("__int__", "__index__", "__invert__"))
 
 
 def _const_node(value: torch.Tensor) -> _Node:

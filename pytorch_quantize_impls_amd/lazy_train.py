@@ -238,8 +238,8 @@ def _torch_function(func, types, args, kwargs):
 
 
 def _writes_in_place(name: str) -> bool:
-    return (name.endswith("_") and not name.endswith("__")) or (name.startswith("__i") and name.endswith("__")
-                                                                 and name not in ("__int__", "__index__", "__invert__"))
+    return (name.endswith("_") and not name.endswith("__")) or name == "__setitem__" or (
+        name.startswith("__i") and name.endswith("__") and name not in ("__int__", "__index__", "__invert__"))
 
 
 def _square(v):

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import contextlib
 import functools
+import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -1446,25 +1447,35 @@ _TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3, "raw": 4}
 FLOAT_SPLIT = "f16x2"
 
 
+_float_split_local = threading.local()          # float_split() overrides are per THREAD: concurrent forwards do not interleave
+
+
+def current_float_split() -> str:
+    """The split in force for the calling thread: the innermost ``with float_split(...)`` of THIS thread, else FLOAT_SPLIT."""
+    return getattr(_float_split_local, "mode", None) or FLOAT_SPLIT
+
+
 @contextlib.contextmanager
 def float_split(mode: str):
-    """Run the enclosed real-valued contractions with FLOAT_SPLIT = ``mode`` (process-wide; restores the previous mode)."""
-    global FLOAT_SPLIT
+    """Run the enclosed real-valued contractions with the split ``mode`` — for the calling thread only (the Lin / Log layers switch
+    to the exact route inside their forward: with a process-wide switch, two serving threads would restore each other's mode)."""
     if mode not in ("f16x2", "bf16x3"):
         raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
-    prev, FLOAT_SPLIT = FLOAT_SPLIT, mode
+    prev = getattr(_float_split_local, "mode", None)
+    _float_split_local.mode = mode
     try:
         yield
     finally:
-        FLOAT_SPLIT = prev
+        _float_split_local.mode = prev
 
 
 def split_terms(terms: Optional[int] = None) -> int:
     if terms is not None:
         return int(terms)
-    if FLOAT_SPLIT not in ("f16x2", "bf16x3"):
-        raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {FLOAT_SPLIT!r}")
-    return 2 if FLOAT_SPLIT == "f16x2" else 3
+    mode = current_float_split()
+    if mode not in ("f16x2", "bf16x3"):
+        raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
+    return 2 if mode == "f16x2" else 3
 
 
 def triple_ld_bytes(K: int, granule: int = 128, terms: int = 3) -> int:

@@ -250,6 +250,35 @@ def test_same_deferred_activation_used_twice(dev):
     assert torch.equal(y1, e1) and torch.equal(y2, e2)
 
 
+def test_writes_into_a_deferred_activation_go_to_a_private_copy(dev):
+    """``act[mask] = v``, ``act.mul_(2)`` and ``torch.add(a, b, out=act)`` on a deferred activation: the wrapper moves on to the
+    written result, a chain recorded on the activation BEFORE the write still replays from the unwritten value."""
+    conv = BinConv2d(32, 48, 3, padding=1).to(dev).eval()
+    bn = nn.BatchNorm2d(48).to(dev).eval()
+    bn.running_var.uniform_(0.5, 4.0)
+    x = _pm1((2, 32, 9, 9), dev)
+    with torch.no_grad():
+        with lazy.eager():
+            e = conv(x)
+            e_bn = bn(e)
+        for kind in ("setitem", "mul_", "out"):
+            t = conv(x)
+            assert isinstance(t, lazy.LazyActivation)
+            later = bn(t)                         # recorded before the write
+            want = e.clone()
+            if kind == "setitem":
+                t[:, :3] = 7.0
+                want[:, :3] = 7.0
+            elif kind == "mul_":
+                t.mul_(2.0)
+                want.mul_(2.0)
+            else:
+                torch.add(e, 1.0, out=t)
+                want = e + 1.0
+            assert torch.equal(t + 0, want), kind
+            assert torch.equal(later + 0, e_bn), kind
+
+
 def test_module_graph_in_a_hipgraph(dev):
     from pytorch_quantize_impls_amd import utils
     m = _alexnet(dev, 5)

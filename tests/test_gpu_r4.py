@@ -465,6 +465,37 @@ def test_first_layer_direct_conv_threshold_bits_equal_the_unfused_chain(dev):
         assert torch.equal(bits, want), cls.__name__
 
 
+# ---- batch-256 digests of the reference layers (tests/golden/make_golden_r4b.py G18) -----------------------------
+
+@pytest.mark.parametrize("name", ["c3_binconv3_b256", "c5_terconv_b256"])
+@pytest.mark.parametrize("mode", ["eval_deferred", "eval_eager", "train"])
+def test_conv_layers_reproduce_the_reference_digest_at_batch_256(dev, name, mode):
+    """BinConv2d at AlexNet's conv3 and TerConv2d at VGG-16's last block, the configs' own batch of 256, +-1 inputs: the SHA-256 of
+    the fp32 result is the reference layer's (exact integer sums) — through the deferred inference graph (materialised), the
+    module-by-module eval path and the training-mode forward, channels-last storage."""
+    from pytorch_quantize_impls_amd import lazy
+    from pytorch_quantize_impls_amd.layers import BinConv2d, TerConv2d
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes_r4b.json")) as fh:
+        c = json.load(fh)["cases"][name]
+    B, Cin, Cout, H, k = c["B"], c["Cin"], c["Cout"], c["H"], c["k"]
+    conv = {"BinConv2d": BinConv2d, "TerConv2d": TerConv2d}[c["layer"]](Cin, Cout, k, stride=c["stride"], padding=c["pad"]).to(dev)
+    conv.weight.data.copy_(t32(synth.uniform(c["w_seed"], (Cout, Cin, k, k), -1.0, 1.0), dev))
+    conv.bias.data.copy_(t32(np.round(synth.normal(c["b_seed"], (Cout,)) * 4), dev))
+    x = t32(synth.pm1(c["x_seed"], (B, Cin, H, H)), dev).contiguous(memory_format=torch.channels_last)
+    conv.train(mode == "train")
+    with torch.no_grad():
+        if mode == "eval_deferred":
+            y = conv(x)
+            assert isinstance(y, lazy.LazyActivation)
+            y = y.value()
+        else:
+            with lazy.eager():
+                y = conv(x)
+    a = np.ascontiguousarray(y.detach().float().contiguous().cpu().numpy(), dtype=np.float32)
+    assert a.shape == (B, Cout, H, H)
+    assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32_nchw"], (float(a.astype(np.float64).sum()), c["sum"])
+
+
 @pytest.mark.parametrize("real", [False, True])
 def test_first_layer_threshold_epilogue_is_the_float_formula_bit_for_bit(dev, real):
     """The threshold epilogue compares the raw accumulator with ONE per-channel fp32 threshold (found in the kernel by bisection with

@@ -17,13 +17,16 @@ for c in c4 c5; do
     echo; echo "## all kernels"; echo '```'; python tools/kstats.py gpurun_out/$TAG/kt_$c | head -40; echo '```'; } > profiles/${TAG}_${c}_rocprof.md
 done
 if [ -d gpurun_out/tr_rn_mod ]; then
-  { echo "# Training steps, batch 256, per-kernel-class split (round 3, final state)"; echo
+  { echo "# Training steps, batch 256, per-kernel-class split ($TAG)"; echo
     echo "\`rocprofv3 --kernel-trace --stats -- python tools/probes/train_resnet_prof.py\` (DoReFa ResNet-18 W1A4, 3x32x32, 8 steps; \`FUSED=1\`: bench_models.TrainFusedDorefaResNet18)"
     echo "and \`tools/probes/train_chain_prof.py\` (BinaryNet-AlexNet, 3x224x224, 6 steps; \`FUSED=1\`: TrainFusedAlexNetBin), condensed by \`tools/probes/kcat.py <dir> <steps> <top>\`:"
     echo "kernel time per step by class, then the top kernels (us per step, launches per step).  Under the profiler the fp32 stem conv of the"
     echo "ResNet (torch / MIOpen, not this path's) runs MIOpen's naive fallback kernels in its first calls; that class is listed and excluded from the totals."
-    for n in rn_mod:8:"ResNet-18, module graph" rn_fused:8:"ResNet-18, fused training chain" ax_mod:6:"AlexNet-Bin, module graph" ax_fused:6:"AlexNet-Bin, fused training chain"; do
+    echo "Since round 4 the un-modified module graph reaches the fused training nodes by itself (lazy_train.py): 'module graph' below IS the fused chain"
+    echo "(no MIOpen BatchNorm / torch pooling kernel between the layers; the ResNet's fp32 stem BatchNorm is the one MIOpen BatchNorm left)."
+    for n in rn_mod:8:"ResNet-18, un-modified module graph" rn_fused:8:"ResNet-18, explicit TrainFused form" ax_mod:6:"AlexNet-Bin, un-modified module graph" ax_fused:6:"AlexNet-Bin, explicit TrainFused form"; do
       d=${n%%:*}; r=${n#*:}; st=${r%%:*}; t=${r#*:}
+      [ -d gpurun_out/tr_$d ] || continue
       echo; echo "## $t"; echo '```'; python tools/probes/kcat.py gpurun_out/tr_$d $st 24; echo '```'
     done; } > profiles/${TAG}_train_steps_rocprof.md
 fi
