@@ -956,6 +956,43 @@ def dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width: int, wei
     return y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
 
 
+#: k-bit DoReFa weights whose integer levels c = (2^k - 1) w_q (odd, |c| <= 2^k - 1) are exact in BOTH split formats (bf16: 8
+#: significant bits, fp16: 11): the level image is the exact operand of the real-activation routes up to this bit width
+LEVEL_MAX_BITS = 8
+#: ... and fit the int8 matrix cores (|c| <= 127) up to this one
+LEVEL_INT8_BITS = 7
+
+
+def dorefa_levels_conv_forward(input, weight_q, bias, conv_args, bit_width: int, level_planes=None):
+    """conv2d(x, w_q, b) for a k-bit DoReFa weight image w_q = c / n_w (2 <= k <= LEVEL_MAX_BITS) and ANY fp32 activation —
+    real-valued, or a k-bit image whose codes left the int8 range, or 8-bit weights whose levels do not fit int8: the split
+    activation x the exact level image on the matrix cores, 1 / n_w and the bias in the epilogue
+    (layers/dorefa_layers.py:77-82).  Returns None outside the route's limits (groups, padding mode, empty)."""
+    stride, padding, dilation, groups = conv_args
+    if not (input.is_cuda and input.dim() == 4 and input.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+            and input.numel() > 0 and 2 <= int(bit_width) <= LEVEL_MAX_BITS):
+        return None
+    N_, _, H, W = input.shape
+    Ho, Wo = ops.conv_out_hw(H, W, int(weight_q.shape[2]), int(weight_q.shape[3]), stride, padding, dilation)
+    y2 = ops.float_conv2d(input.detach(), _weight_levels(weight_q, bit_width), "raw",
+                          bias.detach() if bias is not None else None, stride, padding, dilation,
+                          weight_triples=level_planes, out_scale=_inv_levels(bit_width))
+    y = y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)
+    if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous()
+    return y
+
+
+def dorefa_levels_linear_forward(input, weight_q, bias, bit_width: int, level_planes=None):
+    """The dense twin of dorefa_levels_conv_forward (layers/dorefa_layers.py:41-45)."""
+    if not (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and 2 <= int(bit_width) <= LEVEL_MAX_BITS):
+        return None
+    y = ops.float_linear(input.detach(), _weight_levels(weight_q, bit_width), "raw", weight_triples=level_planes) * _inv_levels(bit_width)
+    if bias is not None:
+        y = y + bias.detach()
+    return y
+
+
 def _levels_grad_weight_linear(g2, x2, x_levels, codes_fit: bool):
     """g2^T . x2 for a k-bit image x2 = q / n: codes (or their 256-digits when they left int8) as the exact bf16 operand."""
     inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
@@ -1126,13 +1163,14 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
 
 
 class DorefaWkConv2dFn(torch.autograd.Function):
-    """Training-mode DorefaConv2d(bit_width = k), 2 <= k <= 7: conv2d(x, w_q, b) for the quantised image w_q the layer's
+    """Training-mode DorefaConv2d(bit_width = k), 2 <= k <= 8: conv2d(x, w_q, b) for the quantised image w_q the layer's
     weight_op produced (layers/dorefa_layers.py:77-82, functions/dorefa_connect.py:99-111); the gradient w.r.t. w_q flows on
     into weight_op's own autograd graph (tanh and its normalisation), exactly as in the reference.
 
     w_q = c / n_w with odd integer levels c, so every contraction has one operand that is exact in bf16 / int8:
-      forward   activation with int8 codes (nnDorefaQuant tag): (1 / (n_a n_w)) * sum q c on the int8 matrix cores
-                (dorefa_wk_conv_forward); real-valued activation: (1 / n_w) * the exact-split conv with the level image;
+      forward   activation with int8 codes (nnDorefaQuant tag) and k <= 7: (1 / (n_a n_w)) * sum q c on the int8 matrix cores
+                (dorefa_wk_conv_forward); real-valued activation, codes beyond int8, or k = 8 (|c| <= 255 does not fit int8 but
+                is exact in bf16 / fp16): (1 / n_w) * the split conv with the level image (dorefa_levels_conv_forward);
       grad_x    (1 / n_w) * the exact-split conv of the gradient with the flipped level image (any square stride);
       grad_w_q  activation codes x exact-split gradient on the pixel-major / K-major / strided weight-gradient routes."""
 
@@ -1145,19 +1183,12 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         ctx.code_flag = packed.lookup_codes(input, packed.NHWC).overflow if ctx.x_levels is not None else None
         y = None
         ok = groups == 1 and not isinstance(padding, str) and input.dim() == 4 and input.dtype == torch.float32
-        if ok and ctx.x_levels is not None:
+        if ok and ctx.x_levels is not None and bit_width <= LEVEL_INT8_BITS:
             wc = ops.pack_conv_weight_dorefa_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width, wc)
         ctx.codes_fit = y is not None            # the int8 route ran: every |code| <= 127
-        if y is None and ok and FLOAT_PATH == "bf16x3" and input.numel() > 0:
-            N_, _, H, W = input.shape
-            Ho, Wo = ops.conv_out_hw(H, W, int(weight_q.shape[2]), int(weight_q.shape[3]), stride, padding, dilation)
-            y2 = ops.float_conv2d(input.detach(), _weight_levels(weight_q, bit_width), "raw",
-                                  bias.detach() if bias is not None else None, stride, padding, dilation,
-                                  out_scale=_inv_levels(bit_width))
-            y = y2.view(N_, Ho, Wo, weight_q.shape[0]).permute(0, 3, 1, 2)
-            if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
-                y = y.contiguous()
+        if y is None and ok and FLOAT_PATH == "bf16x3":
+            y = dorefa_levels_conv_forward(input, weight_q, bias, conv_args, bit_width)
         if y is None:
             note_library_path(input, "k-bit DoReFa conv outside the level routes")
             y = F.conv2d(input, weight_q, bias, stride, padding, dilation, groups)
@@ -1195,7 +1226,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
 
 
 class DorefaWkLinearFn(torch.autograd.Function):
-    """Training-mode LinearDorefa(bit_width = k), 2 <= k <= 7; see DorefaWkConv2dFn (layers/dorefa_layers.py:41-45)."""
+    """Training-mode LinearDorefa(bit_width = k), 2 <= k <= 8; see DorefaWkConv2dFn (layers/dorefa_layers.py:41-45)."""
 
     @staticmethod
     def forward(ctx, input, weight_q, bias, bit_width):
@@ -1203,14 +1234,12 @@ class DorefaWkLinearFn(torch.autograd.Function):
         ctx.save_for_backward(input, weight_q)
         ctx.x_levels = _act_levels(input, packed.ROWS_LAST)
         y = None
-        if input.dtype == torch.float32 and ctx.x_levels is not None:
+        if input.dtype == torch.float32 and ctx.x_levels is not None and bit_width <= LEVEL_INT8_BITS:
             wc = ops.dorefa_weight_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_linear_forward(input, weight_q, bias, bit_width, wc)
         ctx.codes_fit = y is not None
-        if y is None and input.dtype == torch.float32 and FLOAT_PATH == "bf16x3" and input.numel() > 0:
-            y = ops.float_linear(input.detach(), _weight_levels(weight_q, bit_width), "raw") * _inv_levels(bit_width)
-            if bias is not None:
-                y = y + bias.detach()
+        if y is None and FLOAT_PATH == "bf16x3":
+            y = dorefa_levels_linear_forward(input, weight_q, bias, bit_width)
         if y is None:
             note_library_path(input, "k-bit DoReFa linear outside the level routes")
             y = F.linear(input, weight_q, bias)
@@ -1238,6 +1267,73 @@ class DorefaWkLinearFn(torch.autograd.Function):
                 grad_weight = real_matmul(g2.t(), x2) if big else lib_mm(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g2.sum(0)
+        return grad_input, grad_weight, grad_bias, None
+
+
+class RealLinearFn(torch.autograd.Function):
+    """F.linear(x, W, b) for two REAL fp32 device operands on the matrix cores (six-term bf16 planes, fp32-GEMM accuracy), forward
+    and both gradients: LinearDorefa(bit_width = 32), whose weight quantiser is the identity (functions/dorefa_connect.py:100-101,
+    layers/dorefa_layers.py:41-45) — the layer is an un-quantised nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias):
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(input, weight)
+        x2 = input.reshape(-1, input.shape[-1])
+        y = ops.real_linear(x2.detach().contiguous(), weight.detach(), bias.detach() if bias is not None else None)
+        return y.view(*input.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        x2 = input.reshape(-1, input.shape[-1])
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = real_matmul(g2, weight).view(input.shape)
+        if ctx.needs_input_grad[1]:
+            grad_weight = real_matmul(g2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = g2.sum(0)
+        return grad_input, grad_weight, grad_bias
+
+
+class RealConv2dFn(torch.autograd.Function):
+    """F.conv2d(x, W, b) for two REAL fp32 device operands (groups == 1, zero padding): DorefaConv2d(bit_width = 32).  Forward and
+    — for stride 1, dilation 1 — grad_x (the conv of the gradient with the flipped, transposed weight) on the six-term implicit
+    GEMM; grad_W of two real operands stays on the library unless the first-layer form applies (counted)."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, conv_args):
+        stride, padding, dilation, groups = conv_args
+        ctx.has_bias, ctx.conv_args = bias is not None, conv_args
+        ctx.save_for_backward(input, weight)
+        return real_weight_conv2d(input, weight, bias, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        go = _dense(grad_output)
+        grad_input = grad_weight = grad_bias = None
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        (sh, sw), (ph, pw), (dh, dw) = ops._pairs(stride), ops._pairs(padding), ops._pairs(dilation)
+        if ctx.needs_input_grad[0]:
+            if (go.is_cuda and go.dtype == torch.float32 and go.numel() > 0 and (sh, sw, dh, dw) == (1, 1, 1, 1)
+                    and ph <= kh - 1 and pw <= kw - 1):
+                wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+                y2 = ops.real_conv2d(go, wt, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+                if y2 is not None:
+                    N_, C, H, W = input.shape
+                    grad_input = y2.view(N_, H, W, C).permute(0, 3, 1, 2)
+                    if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                        grad_input = grad_input.contiguous()
+            if grad_input is None:
+                grad_input = lib_conv2d_input(input.shape, weight, go, stride, padding, dilation, groups)
+        if ctx.needs_input_grad[1]:
+            grad_weight = conv_grad_weight(input, weight.shape, go, stride, padding, dilation, groups, x_is_pm1=False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None
 
 

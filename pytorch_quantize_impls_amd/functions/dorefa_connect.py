@@ -171,7 +171,7 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
             input, weight, weight_q, max_weight, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if ctx.needs_input_grad[0]:
-                if 1 < bit_width <= 7:      # odd integer levels / (2^k - 1): the levels are the exact operand, 1 / n after
+                if 1 < bit_width <= _fused.LEVEL_MAX_BITS:      # odd integer levels / (2^k - 1): the levels are the exact operand, 1 / n after
                     n_w = float((1 << bit_width) - 1)
                     grad_input = _fused.conv_grad_input(input.size(), torch.round(weight_q.detach() * n_w), grad_output, stride,
                                                         padding, dilation, groups, kind="raw",

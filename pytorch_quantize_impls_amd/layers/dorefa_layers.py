@@ -61,20 +61,34 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
                 wc = self._eval_planes(lambda w2: _fused.ops.weight_codes(w2), key="i8")
                 E = self._eval_planes(lambda w2: w2.abs().amax(), key="E")      # |w| == E everywhere after eval()
                 return _fused.dorefa_w1_linear_forward(input, self.weight, self.bias, True, wc, scale=E)
-        if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
+        if (input.is_cuda and 2 <= self.bit_width <= _fused.LEVEL_INT8_BITS and input.dtype == torch.float32 and not self.training
                 and self.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             # WkAk inference: integer weight levels x activation codes on the int8 matrix cores
             wc = self._eval_planes(lambda w2: _fused.ops.dorefa_weight_codes(w2, self.bit_width), key="i8k")
             y = _fused.dorefa_wk_linear_forward(input, self.weight, self.bias, self.bit_width, wc)
             if y is not None:
                 return y
+        if (input.is_cuda and 2 <= self.bit_width <= _fused.LEVEL_MAX_BITS and input.dtype == torch.float32 and not self.training
+                and self.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
+            # no usable int8 codes (real-valued input, codes beyond int8) or 8-bit weights (|level| <= 255): split activation x
+            # the exact level image
+            terms = _fused.ops.split_terms()
+            lp = self._eval_planes(lambda w2: _fused.ops.weight_bf16x3(_fused._weight_levels(w2, self.bit_width), "raw", terms=terms),
+                                   key=f"levels{terms}")
+            y = _fused.dorefa_levels_linear_forward(input, self.weight, self.bias, self.bit_width, lp)
+            if y is not None:
+                return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
-        if (input.is_cuda and self.training and 2 <= self.bit_width <= 7 and input.dtype == torch.float32
+        if (input.is_cuda and self.training and 2 <= self.bit_width <= _fused.LEVEL_MAX_BITS and input.dtype == torch.float32
                 and self.weight.dtype == torch.float32):
             # WkAk training: level image x codes / exact split on the matrix cores, forward and both gradients
             return _fused.DorefaWkLinearFn.apply(input, w, self.bias, self.bit_width)
+        if (input.is_cuda and self.bit_width == 32 and input.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and input.numel() > 0 and input.dim() >= 2):
+            # the identity quantiser (functions/dorefa_connect.py:19-20, 100-101): two real operands, six-term planes
+            return _fused.RealLinearFn.apply(input, w, self.bias)
         if input.is_cuda:
-            _fused.note_library_path(input, "DoReFa linear with bit_width 8 / 32, a non-fp32 dtype, or autograd in eval mode")
+            _fused.note_library_path(input, "DoReFa linear with 8 < bit_width < 32, a non-fp32 dtype, or autograd in eval mode with k-bit weights")
         return torch.nn.functional.linear(input, w, self.bias)
 
 
@@ -139,7 +153,7 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                 E = self._eval_planes(lambda w2: w2.abs().amax(), key="E")      # |w| == E everywhere after eval()
                 return _fused.dorefa_w1_conv_forward(input, self.weight, self.bias, args, True, wc,
                                                      self.padding_mode, scale=E)
-        if (input.is_cuda and 2 <= self.bit_width <= 7 and input.dtype == torch.float32 and not self.training
+        if (input.is_cuda and 2 <= self.bit_width <= _fused.LEVEL_INT8_BITS and input.dtype == torch.float32 and not self.training
                 and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             wc = self._eval_planes(
@@ -147,10 +161,25 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
             y = _fused.dorefa_wk_conv_forward(input, self.weight, self.bias, args, self.bit_width, wc, self.padding_mode)
             if y is not None:
                 return y
+        if (input.is_cuda and 2 <= self.bit_width <= _fused.LEVEL_MAX_BITS and input.dtype == torch.float32 and not self.training
+                and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"
+                and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
+            # no usable int8 codes, or 8-bit weights: split activation x the exact level image (see LinearDorefa)
+            terms = _fused.ops.split_terms()
+            lp = self._eval_planes(
+                lambda _w2: _fused.ops.pack_conv_weight_bf16x3(_fused._weight_levels(self.weight, self.bit_width), "raw", terms=terms),
+                key=f"conv_levels{terms}")
+            y = _fused.dorefa_levels_conv_forward(input, self.weight, self.bias, args, self.bit_width, lp)
+            if y is not None:
+                return y
         w = self.weight_op.forward(self.weight) if self.training else self.weight
-        if (input.is_cuda and self.training and 2 <= self.bit_width <= 7 and input.dtype == torch.float32
+        if (input.is_cuda and self.training and 2 <= self.bit_width <= _fused.LEVEL_MAX_BITS and input.dtype == torch.float32
                 and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"):
             return _fused.DorefaWkConv2dFn.apply(input, w, self.bias, self.bit_width, args)
+        if (input.is_cuda and self.bit_width == 32 and input.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and input.dim() == 4 and input.numel() > 0 and self.groups == 1 and self.padding_mode == "zeros"
+                and not isinstance(self.padding, str)):
+            return _fused.RealConv2dFn.apply(input, w, self.bias, args)
         if input.is_cuda:
-            _fused.note_library_path(input, "DoReFa conv with bit_width 8 / 32, groups, a non-fp32 dtype, or autograd in eval mode")
+            _fused.note_library_path(input, "DoReFa conv with 8 < bit_width < 32, groups, a non-fp32 dtype, or autograd in eval mode with k-bit weights")
         return torch.nn.functional.conv2d(input, w, self.bias, *args)

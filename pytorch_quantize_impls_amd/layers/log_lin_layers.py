@@ -54,10 +54,9 @@ class LinearQuant(_WeightInit, EvalSwapMixin, torch.nn.Linear, QLayer):
         if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and _exact_in_bf16(self.qdtype, self.bit_width)
                 and not (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad))):
             # Lin / Log levels are exact in bf16 (fp32's exponent range), not necessarily in fp16: the exact three-term route
-            with _fused.ops.float_split("bf16x3"):
-                wt = None if self.training else self._eval_planes(
-                    lambda w2: _fused.ops.weight_bf16x3(w2, "raw", terms=3), key="bf16x3_raw")
-                return _fused.ops.float_linear(input, wq.detach(), "raw", self.bias, weight_triples=wt)
+            wt = None if self.training else self._eval_planes(
+                lambda w2: _fused.ops.weight_bf16x3(w2, "raw", terms=3), key="bf16x3_raw")
+            return _fused.ops.float_linear(input, wq.detach(), "raw", self.bias, weight_triples=wt, terms=3)
         return torch.nn.functional.linear(input, wq, self.bias)
 
 
@@ -90,9 +89,9 @@ class QuantConv2d(_WeightInit, EvalSwapMixin, torch.nn.Conv2d, QLayer):
                 lambda _w2: _fused.ops.pack_conv_weight_bf16x3(self.weight.detach(), "raw", terms=3), key="conv_bf16x3_raw")
             N, C, H, W = input.shape
             kh, kw = int(self.weight.shape[2]), int(self.weight.shape[3])
-            with _fused.ops.float_split("bf16x3"):      # levels exact in bf16, not necessarily in fp16
-                y2 = _fused.ops.float_conv2d(input, wq.detach(), "raw", self.bias, self.stride, self.padding, self.dilation,
-                                             weight_triples=wt)
+            # levels exact in bf16, not necessarily in fp16: the exact three-term route, named explicitly
+            y2 = _fused.ops.float_conv2d(input, wq.detach(), "raw", self.bias, self.stride, self.padding, self.dilation,
+                                         weight_triples=wt, terms=3)
             Ho, Wo = _fused.ops.conv_out_hw(H, W, kh, kw, self.stride, self.padding, self.dilation)
             y = y2.view(N, Ho, Wo, self.weight.shape[0]).permute(0, 3, 1, 2)
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):

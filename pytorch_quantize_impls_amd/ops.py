@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import contextlib
 import functools
-import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -1447,26 +1446,27 @@ _TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3, "raw": 4}
 FLOAT_SPLIT = "f16x2"
 
 
-_float_split_local = threading.local()          # float_split() overrides are per THREAD: concurrent forwards do not interleave
-
-
 def current_float_split() -> str:
-    """The split in force for the calling thread: the innermost ``with float_split(...)`` of THIS thread, else FLOAT_SPLIT."""
-    return getattr(_float_split_local, "mode", None) or FLOAT_SPLIT
+    """The split in force: the innermost ``with float_split(...)``, else the default FLOAT_SPLIT."""
+    return FLOAT_SPLIT
 
 
 @contextlib.contextmanager
 def float_split(mode: str):
-    """Run the enclosed real-valued contractions with the split ``mode`` — for the calling thread only (the Lin / Log layers switch
-    to the exact route inside their forward: with a process-wide switch, two serving threads would restore each other's mode)."""
+    """Run the enclosed real-valued contractions with the split ``mode``.  PROCESS-WIDE on purpose: the backward of an autograd
+    graph runs on the engine's own thread, which must see the mode its forward was built under (a thread-local override is
+    invisible there — the exact-split tests then ran their backward GEMMs on the default route).  It is a switch for tools and
+    tests, not for concurrent serving threads: library code never flips it — layers that need the exact route pass ``terms=3``
+    to float_linear / float_conv2d explicitly (Lin / Log layers)."""
+    global FLOAT_SPLIT
     if mode not in ("f16x2", "bf16x3"):
         raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
-    prev = getattr(_float_split_local, "mode", None)
-    _float_split_local.mode = mode
+    prev = FLOAT_SPLIT
+    FLOAT_SPLIT = mode
     try:
         yield
     finally:
-        _float_split_local.mode = prev
+        FLOAT_SPLIT = prev
 
 
 def split_terms(terms: Optional[int] = None) -> int:
@@ -1747,12 +1747,13 @@ def s2d_triple_pack(x: torch.Tensor, s: int, padding, terms: Optional[int] = Non
 
 def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bias=None, stride=1, padding=0,
                  dilation=1, weight_triples: Optional[TriplePlanes] = None, pixels: Optional[TriplePlanes] = None,
-                 in_shape=None, epi=None, out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None):
+                 in_shape=None, epi=None, out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None,
+                 terms: Optional[int] = None):
     """conv2d(x, Q(weight)) for REAL-valued x (groups = 1, zero padding): NHWC bf16 triple pixel planes ->
     implicit-GEMM conv on the bf16 matrix cores.  ``pixels``/``in_shape``: pre-built pixel planes (e.g. from
     s2d_triple_pack) instead of x.  ``out_scale`` (host float) / ``out_scale_dev`` (one-element device tensor, e.g. DoReFa's
     E = mean|W|): multiply the contraction in the kernel's epilogue, before the bias — no extra pass over the result.
-    Returns NHWC [N*Ho*Wo, Cout]."""
+    ``terms``: the split of x (default FLOAT_SPLIT; 3 = the exact bf16 route).  Returns NHWC [N*Ho*Wo, Cout]."""
     if pixels is None:
         _require(x, "input")
         N, C, H, W = (int(v) for v in x.shape)
@@ -1761,7 +1762,7 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     Cout, _, kh, kw = (int(v) for v in weight.shape)
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
-    terms = pixels.terms if pixels is not None else split_terms(None)
+    terms = pixels.terms if pixels is not None else split_terms(terms)
     Cb = triple_ld_bytes(C, 16, terms)
     if pixels is None:
         nhwc = x.permute(0, 2, 3, 1)
