@@ -142,6 +142,18 @@ int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int
 int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out, int64_t ld_bytes,
                               int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW, qt_stream_t stream);
 
+/* LinearXNOR on a packed +-1 activation, INTEGER form (replaces the fp16 pair operand above wherever alpha is finite): alpha in
+ * fixed point, A[k] = rint(alpha[k] / s) < 2^21 as three 7-bit digits (digit_table[k] = d0 | d1 << 8 | d2 << 16, A = d0 2^14 +
+ * d1 2^7 + d2), out = three stacked int8 planes [3 * rows][ld_bytes] with out[j * rows + r][k] = +-d_j[k] by the activation's
+ * sign bit (ld_bytes % 32 == 0, pad zero; perm_C / perm_HW as above).  The three planes meet sign(W)'s int8 codes in ONE
+ * qt_i8_gemm / qt_i8_gemm_splitk launch (exact integer partial sums) and qt_digit_reduce_f32 forms
+ *     Y[b][n] = fp32(s * (2^14 S0 + 2^7 S1 + S2)) + bias[n],   S_j = sum_z partial[z * slice_stride + (j * rows + b) * ldp + n]
+ * in fp64 (exact; one rounding before the bias).  functions/xnor_connect.py:112-115. */
+int qt_bits_alpha_digits_i8(const uint32_t* bits, int64_t ldb, const uint32_t* digit_table, int8_t* out, int64_t ld_bytes,
+                            int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW, qt_stream_t stream);
+int qt_digit_reduce_f32(const float* partial, int64_t ldp, int64_t slice_stride, int64_t nslice, const float* scale_dev,
+                        const float* bias, float* Y, int64_t ldy, int64_t rows, int64_t N, qt_stream_t stream);
+
 /* XNOR-Net ACTIVATION quantiser on a row-major [R, C] tensor (_quantOpXnor / nnQuantXnor / QuantXnor,
  * functions/xnor_connect.py:17-66):  y = sign(x) * mean(x, dim)  with torch.sign (0 -> 0) and the SIGNED mean the
  * reference computes (:21-28).  dim = 1: mean[R] per row; dim = 0: mean[C] per column; dim = -1: mean[1] over all
@@ -398,6 +410,13 @@ int qt_wgrad_pm_f16(const uint16_t* G2, const uint16_t* XP, float* part, int64_t
 int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, const float* bias,
                float scale, const float* scale_dev, int64_t max_abs_code, float* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t K, qt_stream_t stream);
+
+/* Split-K form of qt_i8_gemm for skinny problems (few row tiles, long K): slice z (blockIdx.y) contracts bytes
+ * [z * kslice, (z + 1) * kslice) of every row (kslice % 64 == 0; both planes hold nslice * kslice zero-padded bytes per row,
+ * row strides % 128 bytes == 0) and writes its exact integer partial sums as fp32 — no scale, no bias — to Y + z * y_stride
+ * (127 * K < 2^24).  Used by the digit-plane form of LinearXNOR (layers/xnor_layers.py:8-33). */
+int qt_i8_gemm_splitk(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, float* Y, int64_t ldy, int64_t M, int64_t N,
+                      int64_t kslice, int64_t nslice, int64_t y_stride, qt_stream_t stream);
 
 /* Fused inference epilogue between binarised layers:
  *   [MaxPool2d(pool_k, pool_s, no padding, floor)] -> BatchNorm(eval) -> Hardtanh -> BinaryConnect -> pack

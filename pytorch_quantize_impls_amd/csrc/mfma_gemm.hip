@@ -424,6 +424,33 @@ int qt_i8_gemm(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldw
     return dispatch_gemm<ElemI8>(0, Xc, ldxp, Wc, ldwp, bias, scale, scale_dev, Y, ldy, M, N, K, stream);
 }
 
+// Split-K form of qt_i8_gemm for skinny problems (few row tiles, long K: the digit-plane GEMM of LinearXNOR at batch 256):
+// blockIdx.y = K slice, slice z contracts bytes [z * kslice, (z + 1) * kslice) of every row and writes its exact integer partial
+// sums (as fp32, no scale, no bias) to Y + z * y_stride — 256 x 256 tiles keep the operand bytes per MAC low, the slices fill the
+// CUs the few tiles leave idle.  The planes must hold nslice * kslice bytes per row (zero padded).
+int qt_i8_gemm_splitk(const uint32_t* Xc, int64_t ldxp, const uint32_t* Wc, int64_t ldwp, float* Y, int64_t ldy, int64_t M, int64_t N,
+                      int64_t kslice, int64_t nslice, int64_t y_stride, qt_stream_t stream) {
+    const int rc = check_common(Xc, ldxp, Wc, ldwp, Y, ldy, M, N, kslice * nslice, (kslice * nslice + 3) / 4);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    if (nslice < 1 || nslice > 65535 || kslice <= 0 || (kslice & 63)) return QT_ERR_ALIGNMENT;          // whole 64-byte stages per slice
+    if (127 * kslice * nslice >= (1ll << 24)) return QT_ERR_UNSUPPORTED;                                 // partial sums exact in fp32
+    if (y_stride < M * ldy || (ldy & 3) || !qt_aligned16(Y) || (y_stride & 3)) return QT_ERR_ALIGNMENT;
+    if ((ldxp & 31) || (ldwp & 31) || M * ldxp * 4 >= (1ll << 31) || N * ldwp * 4 >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    ConvArgs cg{};
+    cg.H = 1;
+    cg.z_nslice = (int)nslice;
+    cg.z_kw = 1;
+    cg.z_kslice_bytes = kslice;
+    cg.z_y_stride = y_stride;
+#define QT_GOZ(...) return launch_cfg<__VA_ARGS__>(Xc, ldxp, Wc, ldwp, nullptr, 1.0f, nullptr, Y, ldy, M, N, kslice, stream, cg)
+    const int tn = pick_tile_n(N);
+    if (tn == 256) QT_GOZ(PP256<ElemI8>);
+    if (tn == 192) QT_GOZ(PP192<ElemI8>);
+    if (tn == 128) QT_GOZ(PP128<ElemI8>);
+    QT_GOZ(PP64<ElemI8>);
+#undef QT_GOZ
+}
+
 // conv kernel variant (an ARGUMENT of qt_conv2d_implicit_variant; every other entry point passes 0): 0 = automatic
 // (192-wide tiles: ping-pong on a 384x192 tile, whose 96x96 wave tiles keep the load segment under the compute segment:
 // AlexNet conv2 302 -> 275 us; other widths: double-buffered, equal or faster there), 1 = double-buffered, 2 = ping-pong,

@@ -21,7 +21,7 @@ struct ConvArgs {
     int cpp;                       // 16-byte chunks per pixel
     int kbytes;                    // K bytes per (virtual) im2col row
     unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
-    // GEMM mode, bf16 only (qt_bf16_gemm_taps): a launch of blockIdx.y = tap * z_nslice + slice problems of one shape —
+    // GEMM mode, bf16 (qt_bf16_gemm_taps) and int8 (qt_i8_gemm_splitk: one tap, K slices only): a launch of blockIdx.y = tap * z_nslice + slice problems of one shape —
     // X and W advance by z_kslice_bytes per slice along K, W additionally by the tap's offset (tap = row * z_kw + col:
     // col * z_w_copy_bytes + row * z_w_row_bytes), Y by z_y_stride floats per problem.  z_nslice == 0: a plain launch.
     int z_nslice = 0, z_kw = 1;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     const int64_t ldx_b = ldx * 4, ldw_b = ldw * 4;  // row strides in bytes
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
-    if constexpr (!C::CONV && std::is_same<E, ElemBf16>::value) {
+    if constexpr (!C::CONV && (std::is_same<E, ElemBf16>::value || std::is_same<E, ElemI8>::value)) {   // (int8: split-K, one tap)
         if (cg.z_nslice > 0) {
             // dispatch order: taps fastest, so the workgroups running at the same time walk the SAME K slice of X (and
             // shifted views of the same W rows): one HBM read serves all taps through the L2s / MALL

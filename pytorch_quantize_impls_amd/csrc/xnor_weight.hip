@@ -84,6 +84,86 @@ __global__ __launch_bounds__(256) void bits_alpha_pairs_kernel(const uint32_t* _
     }
 }
 
+
+// ---- LinearXNOR on a packed +-1 activation, integer form -------------------------------------------------------------------------
+// y[b, n] = sum_k x[b, k] alpha[k] s[n, k]  (x = +-1 bits, s = sign(W) in {-1, 0, +1}, alpha[k] = mean_n |W[n, k]| >= 0).  The fp16
+// pair route treats +-alpha[k] as a real operand: 4 bytes per weight (the sign replicated for both terms) and 2 fp16 products
+// per MAC.  Here alpha is FIXED POINT: A[k] = rint(alpha[k] / s), s a power of two with max A < 2^21, cut into three 7-bit digits
+// A = d0 2^14 + d1 2^7 + d2 (0 <= d <= 127), so that x[b, k] d_j[k] is an int8 and
+//     y[b, n] = s (2^14 P0 + 2^7 P1 + P2)[b, n],    P_j = (x d_j) . s^T     three EXACT integer GEMMs on the int8 matrix cores
+// sharing one weight operand of 1 byte per weight (stacked along M: rows [j * rows + b]); the partial sums are exact integers
+// whatever the summation order (tile shape, K split), so every execution of a model gives the same bits.  Error: alpha rounded
+// to 2^-22 of max alpha (the fp16 pair: 2^-22 of each alpha; alpha is a mean over the output features — its entries are of one
+// magnitude), the combination in fp64 rounds once.
+//
+// One thread = one 32-bit word of a bit-plane row -> 32 bytes of each of the three digit planes.  digit table: d0 | d1 << 8 |
+// d2 << 16 per feature (zero past K).  perm_C > 0: see bits_alpha_pairs_kernel.
+__global__ __launch_bounds__(256) void bits_alpha_digits_kernel(const uint32_t* __restrict__ bits, int64_t ldb,
+                                                                const uint32_t* __restrict__ dtab, int8_t* __restrict__ out,
+                                                                int64_t ldo, int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW) {
+    const int64_t wpr = ldo / 32;                  // 32-feature groups per output row
+    const int64_t total = rows * wpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / wpr, g = i - r * wpr;
+        uint32_t w = 0u;
+        if (perm_C > 0) {
+            for (int e = 0; e < 32; ++e) {
+                const int64_t k = g * 32 + e;
+                if (k < K) {
+                    const int64_t c = k / perm_HW, hw = k - c * perm_HW, b = hw * perm_C + c;
+                    w |= ((bits[r * ldb + (b >> 5)] >> (b & 31)) & 1u) << e;
+                }
+            }
+        } else if (g < ldb) {
+            w = bits[r * ldb + g];
+        }
+        uint32_t o[3][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint32_t v[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t k = g * 32 + q * 4 + e;
+                const uint32_t t = k < K ? dtab[k] : 0u;
+                const bool neg = (w >> (q * 4 + e)) & 1u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int d = (int)((t >> (8 * j)) & 0xffu);
+                    v[j] |= (uint32_t)(uint8_t)(int8_t)(neg ? -d : d) << (8 * e);
+                }
+            }
+            o[0][q] = v[0]; o[1][q] = v[1]; o[2][q] = v[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)j * rows + r) * ldo + g * 32);
+            dst[0] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            dst[1] = make_uint4(o[j][4], o[j][5], o[j][6], o[j][7]);
+        }
+    }
+}
+
+// y[b, n] = fp32(s * (2^14 S0 + 2^7 S1 + S2)) + bias[n],  S_j = sum over the K slices of P[z][j * rows + b][n]: the slice sums are
+// exact integers below 2^24 (fp32 adds are exact), the combination is exact in fp64 (< 2^38), s is a power of two: ONE rounding
+// before the bias, as if the whole dot product had been formed exactly.
+__global__ __launch_bounds__(256) void digit_reduce_kernel(const float* __restrict__ P, int64_t ldp, int64_t slice_stride, int nslice,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t N) {
+    const int64_t total = rows * N;
+    const double s = (double)scale[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / N, n = i - b * N;
+        float S[3] = {0.0f, 0.0f, 0.0f};
+        for (int z = 0; z < nslice; ++z) {
+            const float* p = P + (int64_t)z * slice_stride + b * ldp + n;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) S[j] += p[(int64_t)j * rows * ldp];
+        }
+        const double t = (double)S[0] * 16384.0 + (double)S[1] * 128.0 + (double)S[2];
+        Y[b * ldy + n] = (float)(t * s) + (bias ? bias[n] : 0.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out,
@@ -110,5 +190,28 @@ extern "C" int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, flo
         hipLaunchKernelGGL(sign_scale_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, ldw, alpha,
                            wq, ldq, R, C);
     }
+    return qt_check_launch();
+}
+
+extern "C" int qt_bits_alpha_digits_i8(const uint32_t* bits, int64_t ldb, const uint32_t* digit_table, int8_t* out, int64_t ld_bytes,
+                                       int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW, qt_stream_t stream) {
+    if (rows < 0 || K < 0 || perm_C < 0 || perm_HW < 0 || (perm_C > 0 && perm_C * perm_HW != K)) return QT_ERR_INVALID_ARG;
+    if (rows == 0 || K == 0) return QT_OK;
+    if (!bits || !digit_table || !out || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
+    if ((ld_bytes & 31) || ld_bytes < K || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid((rows * (ld_bytes / 32) + 255) / 256);
+    hipLaunchKernelGGL(bits_alpha_digits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, ldb, digit_table, out, ld_bytes,
+                       rows, K, perm_C, perm_HW);
+    return qt_check_launch();
+}
+
+extern "C" int qt_digit_reduce_f32(const float* partial, int64_t ldp, int64_t slice_stride, int64_t nslice, const float* scale_dev,
+                                   const float* bias, float* Y, int64_t ldy, int64_t rows, int64_t N, qt_stream_t stream) {
+    if (rows < 0 || N < 0 || nslice < 1 || nslice > 65535 || ldp < N || ldy < N || slice_stride < 3 * rows * ldp) return QT_ERR_INVALID_ARG;
+    if (rows == 0 || N == 0) return QT_OK;
+    if (!partial || !scale_dev || !Y) return QT_ERR_INVALID_ARG;
+    const int grid = qt_stream_grid((rows * N + 255) / 256);
+    hipLaunchKernelGGL(digit_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, ldp, slice_stride, (int)nslice,
+                       scale_dev, bias, Y, ldy, rows, N);
     return qt_check_launch();
 }

@@ -520,9 +520,33 @@ def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
     if K != layer.weight.shape[1]:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
 
-    wt, ap = xnor_linear_operands(layer)
-    y = ops.bf16_gemm(ops.bits_alpha_pairs(act.planes, ap, hwc=hwc), wt, layer.bias)
+    dg = xnor_linear_digits(layer) if XNOR_LINEAR_DIGITS else None
+    if dg is not None:
+        # integer form: alpha as three 7-bit digits against the int8 codes of sign(W) — exact partial sums, 1 byte per weight
+        y = ops.xnor_digit_linear(act.planes, dg[1], dg[0], layer.bias, hwc=hwc)
+    else:
+        wt, ap = xnor_linear_operands(layer)
+        y = ops.bf16_gemm(ops.bits_alpha_pairs(act.planes, ap, hwc=hwc), wt, layer.bias)
     return y.view(*act.shape[:-1], N)
+
+
+#: LinearXNOR on packed +-1 activations: True = the digit-plane int8 form (ops.xnor_digit_linear), False = fp16 pairs of +-alpha
+XNOR_LINEAR_DIGITS = True
+
+
+def xnor_linear_digits(layer):
+    """(int8 codes of sign(W), digit table of alpha[K] = mean(|W|, 0)) of an eval-mode LinearXNOR weight, cached per weight
+    version; None when alpha has a non-finite entry or K is beyond the exact range (the pair route then reproduces the NaN / inf
+    the reference would produce)."""
+    def build(w2):
+        if 127 * ops.code_ld_bytes(int(w2.shape[1])) >= (1 << 24):
+            return None
+        _, alpha = ops.xnor_weight(w2.contiguous(), 1)
+        dg = ops.alpha_digits(alpha.view(-1))
+        if dg is None:
+            return None
+        return ops.weight_codes(torch.sign(w2), ternary=True), dg         # torch.sign: 0 -> 0 (xnor_connect.py:113)
+    return layer._eval_planes(build, key="xnor_digits")
 
 
 def xnor_linear_operands(layer=None, weight=None):

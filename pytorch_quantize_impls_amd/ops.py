@@ -1430,6 +1430,91 @@ def bits_alpha_pairs(planes: BitPlanes, apairs: "TriplePlanes", hwc=None) -> "Tr
     return TriplePlanes(data=out, rows=planes.rows, K=planes.K, terms=2, scale=apairs.scale)
 
 
+@dataclass
+class AlphaDigits:
+    """Fixed-point image of a per-feature scale row alpha[K] >= 0 (LinearXNOR, functions/xnor_connect.py:112):
+    A[k] = rint(alpha[k] / s) < 2^21 as three 7-bit digits, table[k] = d0 | d1 << 8 | d2 << 16 with A = d0 2^14 + d1 2^7 + d2
+    (int32 [K]); ``scale`` = the power of two s as a device fp32 [1]."""
+    table: torch.Tensor
+    scale: torch.Tensor
+    K: int
+
+
+def alpha_digits(alpha: torch.Tensor) -> Optional[AlphaDigits]:
+    """The digit table of a scale row, or None when alpha has a non-finite entry (one host sync; once per weight version)."""
+    a = _require(alpha.detach(), "alpha").contiguous().view(-1)
+    mx = a.amax() if a.numel() else a.new_zeros(())
+    _, e = torch.frexp(mx)                                   # max < 2^e
+    s = torch.ldexp(torch.ones_like(mx), e - 21)             # max / s < 2^21
+    s = torch.where((mx > 0) & (s > 0), s, torch.ones_like(mx))
+    q = a / s
+    if not bool(torch.isfinite(q).all().item()) or bool((a < 0).any().item()):
+        return None
+    A = torch.clamp(torch.round(q), 0, float((1 << 21) - 1)).to(torch.int32)
+    table = (A >> 14) | (((A >> 7) & 127) << 8) | ((A & 127) << 16)
+    return AlphaDigits(table=table.contiguous(), scale=s.reshape(1).to(torch.float32).contiguous(), K=int(a.numel()))
+
+
+def _pick_tile_n(N: int) -> int:
+    """csrc/mfma_gemm_kernel.h pick_tile_n: the tile width (256 / 192 / 128 / 64) with the fewest padded columns."""
+    best, best_pad = 256, (N + 255) // 256 * 256
+    for c in (192, 128, 64):
+        pad = (N + c - 1) // c * c
+        if pad < best_pad:
+            best, best_pad = c, pad
+    return best
+
+
+def splitk_plan(M: int, N: int, ld_bytes: int, min_slice_bytes: int = 512, workgroups: int = 256):
+    """(kslice, nslice) for qt_i8_gemm_splitk: the largest number of equal K slices (whole 64-byte stages, at least
+    ``min_slice_bytes`` each, dividing the padded row) whose workgroups still fit one round of the chip."""
+    tiles = ((M + 255) // 256) * ((N + _pick_tile_n(N) - 1) // _pick_tile_n(N))
+    units = max(1, ld_bytes // 64)
+    best = 1
+    for d in range(1, units + 1):
+        if units % d == 0 and tiles * d <= workgroups and (units // d) * 64 >= min_slice_bytes:
+            best = d
+    return (units // best) * 64, best
+
+
+def bits_alpha_digits(planes: BitPlanes, digits: AlphaDigits, hwc=None, ld_bytes: Optional[int] = None) -> CodePlanes:
+    """Three stacked int8 planes [3 * rows, ld] of x[b, k] * d_j[k] for a packed +-1 activation (qt_bits_alpha_digits_i8)."""
+    if planes.mask is not None or planes.K != digits.K:
+        raise ValueError("bits_alpha_digits takes sign-only row planes and the digit table of a [K] scale row")
+    pc, phw = (int(hwc[0]), int(hwc[1]) * int(hwc[2])) if hwc is not None else (0, 0)
+    ld = code_ld_bytes(planes.K) if ld_bytes is None else int(ld_bytes)
+    out = torch.empty((3 * planes.rows, ld), dtype=torch.int8, device=planes.device)
+    with _on(planes.device):
+        _lib.call("qt_bits_alpha_digits_i8", _p(planes.sign), int(planes.ld), _p(digits.table), _p(out), int(ld),
+                  int(planes.rows), int(planes.K), pc, phw, _stream(planes.device))
+    return CodePlanes(codes=out, rows=3 * planes.rows, K=planes.K)
+
+
+def xnor_digit_linear(planes: BitPlanes, digits: AlphaDigits, wcodes: CodePlanes, bias: Optional[torch.Tensor] = None,
+                      hwc=None) -> torch.Tensor:
+    """y = (x * alpha) . sign(W)^T + b for a packed +-1 activation x (functions/xnor_connect.py:112-115) in the integer form:
+    digit planes of alpha against the int8 codes of sign(W) in one split-K int8 GEMM (exact partial sums), combined in fp64."""
+    rows, K, N = planes.rows, planes.K, wcodes.rows
+    if wcodes.K != K:
+        raise ValueError(f"K mismatch: activations {K} vs weights {wcodes.K}")
+    dev = planes.device
+    bias = _check_bias(bias, N, dev)
+    ld = int(wcodes.codes.shape[1])
+    if 127 * ld >= (1 << 24) or (ld & 127):
+        raise ValueError("digit-plane GEMM: K beyond the exact fp32 range of the partial sums, or an unpadded weight plane")
+    x3 = bits_alpha_digits(planes, digits, hwc=hwc, ld_bytes=ld)
+    kslice, nslice = splitk_plan(3 * rows, N, ld)
+    ldp = (N + 3) // 4 * 4
+    part = torch.empty((nslice, 3 * rows, ldp), dtype=torch.float32, device=dev)
+    y = torch.empty((rows, N), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.call("qt_i8_gemm_splitk", _p(x3.codes), int(ld // 4), _p(wcodes.codes), int(ld // 4), _p(part), int(ldp), int(3 * rows),
+                  int(N), int(kslice), int(nslice), int(3 * rows * ldp), _stream(dev))
+        _lib.call("qt_digit_reduce_f32", _p(part), int(ldp), int(3 * rows * ldp), int(nslice), _p(digits.scale), _p(bias), _p(y),
+                  int(N), int(rows), int(N), _stream(dev))
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # real-valued activation x quantised weight: exact bf16 triples + bf16 MFMA GEMM
 # ----------------------------------------------------------------------------------------------

@@ -180,3 +180,97 @@ def test_dorefa_32bit_layers_vs_fp64(dev, training):
         assert norm_err(n(x.grad), n(rgx)) <= TOL
         assert norm_err(n(layer.weight.grad), n(rgw)) <= TOL
         assert norm_err(n(layer.bias.grad), n(rgb)) <= TOL
+
+
+# ---- LinearXNOR on packed +-1 activations: the digit-plane int8 form ------------------------------------------------------------------
+
+import numpy as np  # noqa: E402
+from pytorch_quantize_impls_amd import ops, packed  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnectDeterministic  # noqa: E402
+from pytorch_quantize_impls_amd.layers import LinearXNOR  # noqa: E402
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 4096, 9216), (768, 10, 4096), (15, 7, 100), (300, 1000, 1024), (256, 192, 64)])
+def test_i8_gemm_splitk_partial_sums_are_exact(dev, M, N, K):
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    ld = ops.code_ld_bytes(K)
+    x = torch.zeros((M, ld), dtype=torch.int8, device=dev)
+    w = torch.zeros((N, ld), dtype=torch.int8, device=dev)
+    x[:, :K] = torch.randint(-127, 128, (M, K), device=dev, generator=g, dtype=torch.int32).to(torch.int8)
+    w[:, :K] = torch.randint(-1, 2, (N, K), device=dev, generator=g, dtype=torch.int32).to(torch.int8)
+    kslice, nslice = ops.splitk_plan(M, N, ld)
+    assert kslice * nslice == ld and kslice % 64 == 0
+    ldp = (N + 3) // 4 * 4
+    part = torch.full((nslice, M, ldp), float("nan"), dtype=torch.float32, device=dev)
+    _lib.call("qt_i8_gemm_splitk", x.data_ptr(), ld // 4, w.data_ptr(), ld // 4, part.data_ptr(), ldp, M, N, kslice, nslice, M * ldp,
+              torch.cuda.current_stream().cuda_stream)
+    got = part[:, :, :N].double().sum(0)
+    want = x[:, :K].double() @ w[:, :K].double().t()
+    assert torch.equal(got, want)
+    for z in range(nslice):                                     # every slice holds ITS bytes of K, nothing else
+        k0, k1 = z * kslice, min(K, (z + 1) * kslice)
+        wz = x[:, k0:k1].double() @ w[:, k0:k1].double().t() if k1 > k0 else torch.zeros_like(want)
+        assert torch.equal(part[z, :, :N].double(), wz)
+
+
+def _xnor_linear_fp64(x_pm1, w, bias):
+    """functions/xnor_connect.py:112-115 in fp64: alpha = mean(|W|, 0, keepdim), y = x . (sign(W) * alpha)^T + b — applied to
+    the weight the layer HOLDS: in eval mode that is the quantised image, which the op quantises again like upstream (with an
+    all-zero output feature alpha shrinks by (N - 1) / N the second time)."""
+    w64 = w.double().cpu()
+    wq = torch.sign(w64) * w64.abs().mean(0, keepdim=True)
+    y = x_pm1.double().cpu() @ wq.t()
+    return y + bias.double().cpu() if bias is not None else y
+
+
+@pytest.mark.parametrize("rows,N,K,hwc", [(256, 4096, 9216, (256, 6, 6)), (256, 4096, 4096, None), (256, 10, 4096, None),
+                                          (5, 7, 100, None), (33, 70, 96, (6, 4, 4)), (64, 1000, 4096, None)])
+def test_xnor_digit_linear_vs_fp64_and_vs_the_pair_route(dev, rows, N, K, hwc):
+    torch.manual_seed(rows + N + K)
+    lin = LinearXNOR(K, N, bias=True).to(dev)
+    lin.weight.data.normal_(0, 0.05)
+    lin.weight.data[:, 3] = 0.0                                  # a feature whose alpha is 0
+    lin.weight.data[1, :] = 0.0                                  # an output feature of zeros: sign(0) = 0
+    lin.bias.data.normal_(0, 1.0)
+    lin.eval()
+    x = BinaryConnectDeterministic.apply(torch.randn(rows, K, device=dev))
+    planes = packed.lookup(x, packed.ROWS_LAST)
+    assert planes is not None
+    if hwc is not None:
+        # the fused chain hands the features over in (h, w, c) order; the layer counts them in (c, h, w) order
+        C, H, W = hwc
+        xh = x.view(rows, C, H, W).permute(0, 2, 3, 1).reshape(rows, K).contiguous()
+        planes = ops.sign_pack(xh)[0]
+    act = packed.PackedActivation(planes, (rows, K))
+    before = dict(_lib.call_counts)
+    with torch.no_grad():
+        y = _fused.packed_xnor_linear(lin, act, hwc=hwc)
+        y2 = _fused.packed_xnor_linear(lin, act, hwc=hwc)
+    assert _lib.call_counts["qt_i8_gemm_splitk"] - before.get("qt_i8_gemm_splitk", 0) == 2
+    assert torch.equal(y, y2)
+    ref = _xnor_linear_fp64(x, lin.weight.detach(), lin.bias)
+    assert norm_err(n(y), n(ref)) <= TOL, norm_err(n(y), n(ref))
+    old = _fused.XNOR_LINEAR_DIGITS
+    try:
+        _fused.XNOR_LINEAR_DIGITS = False
+        with torch.no_grad():
+            yp = _fused.packed_xnor_linear(lin, act, hwc=hwc)
+    finally:
+        _fused.XNOR_LINEAR_DIGITS = old
+    assert norm_err(n(y), n(yp)) <= TOL
+    # the module-by-module execution (fp32 activation carrying its sign planes) takes the same operands: same bits
+    if hwc is None:
+        with torch.no_grad():
+            assert torch.equal(lin(x), y)
+
+
+def test_xnor_digit_linear_falls_back_on_non_finite_alpha(dev):
+    lin = LinearXNOR(128, 16, bias=False).to(dev)
+    lin.weight.data.normal_(0, 0.05)
+    lin.weight.data[2, 5] = float("inf")
+    lin.eval()
+    assert _fused.xnor_linear_digits(lin) is None
+    x = BinaryConnectDeterministic.apply(torch.randn(8, 128, device=dev))
+    with torch.no_grad():
+        y = lin(x)
+    assert not bool(torch.isfinite(y).all())                    # the reference's inf / NaN come through the pair route
