@@ -96,50 +96,42 @@ __global__ __launch_bounds__(256) void bits_alpha_pairs_kernel(const uint32_t* _
 // to 2^-22 of max alpha (the fp16 pair: 2^-22 of each alpha; alpha is a mean over the output features — its entries are of one
 // magnitude), the combination in fp64 rounds once.
 //
-// One thread = one 32-bit word of a bit-plane row -> 32 bytes of each of the three digit planes.  digit table: d0 | d1 << 8 |
-// d2 << 16 per feature (zero past K).  perm_C > 0: see bits_alpha_pairs_kernel.
+// One thread = four consecutive features of one row: one 16-byte read of the digit table (d0 | d1 << 8 | d2 << 16 per feature, zero
+// from K up to the padded row length), four sign bits, one dword of each of the three digit planes — table reads and plane
+// writes are lane-contiguous.  perm_C > 0: see bits_alpha_pairs_kernel.
 __global__ __launch_bounds__(256) void bits_alpha_digits_kernel(const uint32_t* __restrict__ bits, int64_t ldb,
-                                                                const uint32_t* __restrict__ dtab, int8_t* __restrict__ out,
-                                                                int64_t ldo, int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW) {
-    const int64_t wpr = ldo / 32;                  // 32-feature groups per output row
-    const int64_t total = rows * wpr;
+                                                                const uint4* __restrict__ dtab4, uint32_t* __restrict__ out,
+                                                                int64_t ldo_words, int64_t rows, int64_t K, int64_t perm_C, int64_t perm_HW) {
+    const int64_t total = rows * ldo_words;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / wpr, g = i - r * wpr;
-        uint32_t w = 0u;
+        const int64_t r = i / ldo_words, q = i - r * ldo_words, k0 = q * 4;
+        const uint4 t4 = dtab4[q];
+        uint32_t nib = 0u;                            // bit e: feature k0 + e is -1
         if (perm_C > 0) {
-            for (int e = 0; e < 32; ++e) {
-                const int64_t k = g * 32 + e;
-                if (k < K) {
-                    const int64_t c = k / perm_HW, hw = k - c * perm_HW, b = hw * perm_C + c;
-                    w |= ((bits[r * ldb + (b >> 5)] >> (b & 31)) & 1u) << e;
-                }
-            }
-        } else if (g < ldb) {
-            w = bits[r * ldb + g];
-        }
-        uint32_t o[3][8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint32_t v[3] = {0u, 0u, 0u};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int64_t k = g * 32 + q * 4 + e;
-                const uint32_t t = k < K ? dtab[k] : 0u;
-                const bool neg = (w >> (q * 4 + e)) & 1u;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int d = (int)((t >> (8 * j)) & 0xffu);
-                    v[j] |= (uint32_t)(uint8_t)(int8_t)(neg ? -d : d) << (8 * e);
+                const int64_t k = k0 + e;
+                if (k < K) {
+                    const int64_t c = k / perm_HW, hw = k - c * perm_HW, b = hw * perm_C + c;
+                    nib |= ((bits[r * ldb + (b >> 5)] >> (b & 31)) & 1u) << e;
                 }
             }
-            o[0][q] = v[0]; o[1][q] = v[1]; o[2][q] = v[2];
+        } else if ((k0 >> 5) < ldb) {
+            nib = (bits[r * ldb + (k0 >> 5)] >> (k0 & 31)) & 0xFu;
+        }
+        const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+        uint32_t v[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool neg = (nib >> e) & 1u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int d = (int)((t[e] >> (8 * j)) & 0xffu);
+                v[j] |= (uint32_t)(uint8_t)(int8_t)(neg ? -d : d) << (8 * e);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)j * rows + r) * ldo + g * 32);
-            dst[0] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
-            dst[1] = make_uint4(o[j][4], o[j][5], o[j][6], o[j][7]);
-        }
+        for (int j = 0; j < 3; ++j) out[((int64_t)j * rows + r) * ldo_words + q] = v[j];
     }
 }
 
@@ -198,10 +190,10 @@ extern "C" int qt_bits_alpha_digits_i8(const uint32_t* bits, int64_t ldb, const 
     if (rows < 0 || K < 0 || perm_C < 0 || perm_HW < 0 || (perm_C > 0 && perm_C * perm_HW != K)) return QT_ERR_INVALID_ARG;
     if (rows == 0 || K == 0) return QT_OK;
     if (!bits || !digit_table || !out || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
-    if ((ld_bytes & 31) || ld_bytes < K || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
-    const int grid = qt_stream_grid((rows * (ld_bytes / 32) + 255) / 256);
-    hipLaunchKernelGGL(bits_alpha_digits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, ldb, digit_table, out, ld_bytes,
-                       rows, K, perm_C, perm_HW);
+    if ((ld_bytes & 31) || ld_bytes < K || !qt_aligned16(out) || !qt_aligned16(digit_table)) return QT_ERR_ALIGNMENT;
+    const int grid = qt_stream_grid((rows * (ld_bytes / 4) + 255) / 256);
+    hipLaunchKernelGGL(bits_alpha_digits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, ldb,
+                       reinterpret_cast<const uint4*>(digit_table), reinterpret_cast<uint32_t*>(out), ld_bytes / 4, rows, K, perm_C, perm_HW);
     return qt_check_launch();
 }
 

@@ -1434,7 +1434,7 @@ def bits_alpha_pairs(planes: BitPlanes, apairs: "TriplePlanes", hwc=None) -> "Tr
 class AlphaDigits:
     """Fixed-point image of a per-feature scale row alpha[K] >= 0 (LinearXNOR, functions/xnor_connect.py:112):
     A[k] = rint(alpha[k] / s) < 2^21 as three 7-bit digits, table[k] = d0 | d1 << 8 | d2 << 16 with A = d0 2^14 + d1 2^7 + d2
-    (int32 [K]); ``scale`` = the power of two s as a device fp32 [1]."""
+    (int32, one entry per byte of a padded code-plane row, zero from K on); ``scale`` = the power of two s as a device fp32 [1]."""
     table: torch.Tensor
     scale: torch.Tensor
     K: int
@@ -1451,8 +1451,9 @@ def alpha_digits(alpha: torch.Tensor) -> Optional[AlphaDigits]:
     if not bool(torch.isfinite(q).all().item()) or bool((a < 0).any().item()):
         return None
     A = torch.clamp(torch.round(q), 0, float((1 << 21) - 1)).to(torch.int32)
-    table = (A >> 14) | (((A >> 7) & 127) << 8) | ((A & 127) << 16)
-    return AlphaDigits(table=table.contiguous(), scale=s.reshape(1).to(torch.float32).contiguous(), K=int(a.numel()))
+    table = torch.zeros((code_ld_bytes(int(a.numel())),), dtype=torch.int32, device=a.device)      # zero up to the padded row length
+    table[:a.numel()] = (A >> 14) | (((A >> 7) & 127) << 8) | ((A & 127) << 16)
+    return AlphaDigits(table=table, scale=s.reshape(1).to(torch.float32).contiguous(), K=int(a.numel()))
 
 
 def _pick_tile_n(N: int) -> int:
@@ -1483,6 +1484,8 @@ def bits_alpha_digits(planes: BitPlanes, digits: AlphaDigits, hwc=None, ld_bytes
         raise ValueError("bits_alpha_digits takes sign-only row planes and the digit table of a [K] scale row")
     pc, phw = (int(hwc[0]), int(hwc[1]) * int(hwc[2])) if hwc is not None else (0, 0)
     ld = code_ld_bytes(planes.K) if ld_bytes is None else int(ld_bytes)
+    if digits.table.numel() < ld:
+        raise ValueError(f"digit table holds {digits.table.numel()} entries, the planes' rows {ld}")
     out = torch.empty((3 * planes.rows, ld), dtype=torch.int8, device=planes.device)
     with _on(planes.device):
         _lib.call("qt_bits_alpha_digits_i8", _p(planes.sign), int(planes.ld), _p(digits.table), _p(out), int(ld),
