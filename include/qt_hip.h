@@ -657,8 +657,8 @@ int qt_conv2d_implicit_nib(int elem, const uint32_t* P, int64_t N, int64_t H, in
  * (sn, sc, sh, sw) — NCHW or channels-last storage, read where it lies.  A workgroup loads the input patch of its <= 128 output
  * pixels once, splits it into two fp16 terms of x / s with the TILE's power-of-two s (|x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 tile
  * max)) and contracts K = (ky, kx, c) on the fp16 matrix cores by stride addressing of the patch: no space-to-depth plane, no
- * operand pack pass.  Weights, packed once by the caller ([k-step][2][Coutp][8 fp16], k = ky-row chunks of ceil(KW * Cp / 8) * 8
- * elements in (kx, c) order, zero padded; k-steps = ceil(KH * chunks / 2) rounded up to a multiple of 4; Coutp = Cout rounded up to 32):
+ * operand pack pass.  Weights, packed once by the caller ([k-step][2][Coutp][8 fp16]; the k axis strings the KH kernel rows together, each
+ * ceil(KW * Cp / 4) * 4 elements in (kx, c) order, zero padded; k-steps = ceil(k / 16), the last one zero-filled; Coutp = Cout rounded up to 32):
  *   w_lo == NULL: +-1 / 0 (or small-integer) weights, exact in fp16 (BinConv2d / TerConv2d): w_hi alone;
  *   w_lo != NULL: real-valued weights (XNOR-Net's sign(W) * alpha) as w / (w_scale * w_scale_dev[0]) = w_hi + w_lo (three
  *                 products per element: hi whi + lo whi + hi wlo).

@@ -10,9 +10,10 @@
 //     hi = fp16(x / s), lo = fp16(x / s - hi) with the TILE's own power-of-two s (max|x| / s in [2^14, 2^15)): no global max|x|
 //     pass, no speculation, |x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 tilemax);
 //   * K = (ky, kx, c): for a fixed ky the kw * C values an output pixel needs are CONTIGUOUS in its patch row (NHWC, c fastest), so
-//     the A fragment of v_mfma_f32_32x32x16_f16 (8 consecutive k per lane) is one 16-byte run of the LDS patch at
-//     ((oy s + ky) RS + ox s C + 8 cc) — stride addressing replaces the space-to-depth plane; a ky row is ceil(kw C / 8)
-//     chunks (AlexNet: 33 -> 40 elements), chunks of consecutive ky rows pair up into k-steps (28 instead of 33);
+//     the A fragment of v_mfma_f32_32x32x16_f16 (8 consecutive k per lane) is TWO 8-byte runs (4 k each) of the LDS patch at
+//     ((oy s + ky) RS + ox s C + 4 g) — stride addressing replaces the space-to-depth plane; a ky row is ceil(kw C / 4)
+//     groups of 4 (AlexNet: 33 -> 36 elements; with 16-byte runs it was 40), the groups of all ky rows are strung together
+//     four to a k-step (25 k-steps; 28 with 16-byte runs, 36 on the space-to-depth route);
 //   * the weight fragments come straight from global memory (L2) in the packed order [k-step][half][channel][8 fp16] — 16 bytes per
 //     lane, lane-contiguous — prefetched one k-step ahead; +-1 / 0 weights are ONE fragment shared by the hi and lo terms of the
 //     image (no replicated rows), real-valued weights (XNOR-Net: sign(W) * alpha) two fragments w / sw = whi + wlo and the three
@@ -20,6 +21,7 @@
 //   * 4 waves, each 2 (m) x 3 (n) accumulator tiles of 32 x 32; two workgroups per CU overlap each other's patch prologue.
 // Epilogues: fp32 NHWC (+ bias), or the BatchNorm-threshold bits of the fused inference chain (qt_conv2d_implicit_bits' float form).
 #include <cstdlib>
+#include <type_traits>
 #include "qt_common.h"
 
 #ifdef QT_PROFILING_VARIANTS
@@ -44,13 +46,13 @@ struct FirstArgs {
     int64_t sn, sc, sh, sw;            // element strides of x [N, C, H, W] (any storage order)
     int N, C, H, W, KH, KW, S, PH, PW, Ho, Wo;
     int Cp;                            // channels per pixel in the LDS patch (C, or padded so that S * Cp % 4 == 0)
-    int CPK;                           // 16-byte chunks per ky row = ceil(KW * Cp / 8)
-    int NCH, NKS;                      // chunks = KH * CPK, k-steps = ceil(NCH / 2) rounded up to 4
+    int G4;                            // 8-byte groups (4 k) per ky row = ceil(KW * Cp / 4)
+    int NG4, NKS;                      // groups = KH * G4, k-steps = ceil(NG4 / 4)
     int TOY, TOX, tiles_y, tiles_x;
     int PR, PCE, RS;                   // patch rows, real elements per patch row (PC * Cp), LDS row stride in elements (% 4 == 0)
     unsigned long long m64_tpi;        // ceil(2^64 / tiles per image)
     unsigned m_tx;                     // magic of tiles_x
-    unsigned m_ppr, m_cp, m_tox, m_cpk; // floor(2^32 / d) + 1 for d = RS / 2, Cp, TOX, CPK: q / d == __umulhi(q, m) for q < 2^16 (d > 1)
+    unsigned m_ppr, m_cp, m_tox, m_g4;  // floor(2^32 / d) + 1 for d = RS / 2, Cp, TOX, G4: q / d == __umulhi(q, m) for q < 2^16 (d > 1)
     const uint4* whi;                  // [NKS][2][Coutp] 16-byte chunks
     const uint4* wlo;                  // real-valued weights only
     float wscale;                      // weights were divided by this power of two before the fp16 split (1 for +-1 / 0)
@@ -95,6 +97,20 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
     // fp32 epilogue: per patch buffer, the byte offset of each of the tile's 128 pixels within its image's output plane
     // ((oy Wo + ox) ldy 4; OOB for pixels past the tile / the map) — written with the patch, read as 16-byte runs by the epilogue
     int* otab = reinterpret_cast<int*>(smem + 2 * buf_bytes + 64);
+    // per (k-step, lane half): the byte offsets of the half's two 8-byte groups within a pixel's patch (ky RS + 4 g) 2 — filled once
+    // per workgroup (the tile loop's first barriers order it before the first read), read one k-step ahead by the MFMA loop:
+    // the scalar division chain it replaces was 51 SALU instructions per k-step
+    int2* ktab = reinterpret_cast<int2*>(smem + 2 * buf_bytes + 64 + 1024);
+    for (int i = tid; i < 2 * a.NKS; i += 256) {
+        int o2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = min(4 * (i >> 1) + 2 * (i & 1) + j, a.NG4 - 1);        // groups past the last one re-read it (zero weights)
+            const int ky = divm(g, a.m_g4, a.G4);
+            o2[j] = (ky * a.RS + (g - ky * a.G4) * 4) * 2;
+        }
+        ktab[i] = make_int2(o2[0], o2[1]);
+    }
     constexpr int OOB = 0x40000000;                              // two of them add up to 2^31: still past any buffer extent
     const int ppr = a.RS >> 1;                   // pairs per LDS row
 
@@ -135,15 +151,21 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
             typedef unsigned u2 __attribute__((ext_vector_type(2)));
             const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xi), 0, a.H * (int)a.sh * 4, 0x00020000);
             const int g = ix0 * a.C + e;
-            const int cb = (act && g >= 0 && g < a.W * a.C) ? g * 4 : OOB;
+            // ... and the image ROWS too: the offset of row iy is cb + iy * rb4 as an unsigned number — rows above the image wrap
+            // past 2^31, rows below it land at or past the extent (H * rb4 < 2^30), an invalid column starts from COLOOB, which
+            // stays past the extent for every row of the patch.  One add per pass; only the rows past the PATCH (r >= PR) are
+            // masked, and those passes are the last ones
+            constexpr int COLOOB = 0x60000000;
             const int rb4 = (int)a.sh * 4;
+            int off = ((act && g >= 0 && g < a.W * a.C) ? g * 4 : COLOOB) + (iy0 + rr) * rb4;
+            const int step = rpp * rb4;
+            const int rlim = a.PR - rr;                      // pass i is inside the patch iff i * rpp < rlim
 #pragma unroll
             for (int i = 0; i < MAXP; ++i) {
-                const int r = rr + i * rpp, iy = iy0 + r;
-                const bool rok = r < a.PR && (unsigned)iy < (unsigned)a.H;
-                const u2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, rok ? cb + iy * rb4 : OOB, 0, 0);
+                const u2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, i * rpp < rlim ? off : COLOOB, 0, 0);
                 v0[i] = __uint_as_float(v.x);
                 v1[i] = __uint_as_float(v.y);
+                off += step;
             }
         } else {
             // any layout: two scalar loads per pass from clamped (valid) addresses, zeroed by a select
@@ -342,67 +364,68 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
             ahb[mt] = smem + buf * buf_bytes + abase[mt];
             alb[mt] = ahb[mt] + plane_bytes;
         }
-        auto load_a = [&](int s, uint4 (&ah)[2], uint4 (&al)[2]) __attribute__((always_inline)) {
-            // this lane's chunk of the k-step: q = 2 s + half -> (ky, cc); chunks past the last one re-read the last chunk (zero
-            // weights).  Both halves' offsets are computed on the scalar unit (s is uniform), a lane picks its own: one vector
-            // instruction per k-step instead of a division chain
-            const int q0 = min(2 * s, a.NCH - 1), q1 = min(2 * s + 1, a.NCH - 1);
-            int ky0 = (int)(((unsigned long long)(unsigned)q0 * a.m_cpk) >> 32), ky1 = (int)(((unsigned long long)(unsigned)q1 * a.m_cpk) >> 32);
-            ky0 = a.CPK == 1 ? q0 : ky0;                         // (the magic of 1 is 0) — selects, not branches
-            ky1 = a.CPK == 1 ? q1 : ky1;
-            const int k0 = (ky0 * a.RS + (q0 - ky0 * a.CPK) * 8) * 2;
-            const int k1 = (ky1 * a.RS + (q1 - ky1 * a.CPK) * 8) * 2;
-            const int koff = half ? k1 : k0;
+        // A fragments of one k-step: the lane half's two groups at the table's offsets (k2 = ktab[2 s + half])
+        auto load_a = [&](const int2 k2, uint4 (&ah)[2], uint4 (&al)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const uint2 h0 = *reinterpret_cast<const uint2*>(ahb[mt] + koff);
-                const uint2 h1 = *reinterpret_cast<const uint2*>(ahb[mt] + koff + 8);
-                const uint2 l0 = *reinterpret_cast<const uint2*>(alb[mt] + koff);
-                const uint2 l1 = *reinterpret_cast<const uint2*>(alb[mt] + koff + 8);
+                const uint2 h0 = *reinterpret_cast<const uint2*>(ahb[mt] + k2.x);
+                const uint2 h1 = *reinterpret_cast<const uint2*>(ahb[mt] + k2.y);
+                const uint2 l0 = *reinterpret_cast<const uint2*>(alb[mt] + k2.x);
+                const uint2 l1 = *reinterpret_cast<const uint2*>(alb[mt] + k2.y);
                 ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
                 al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         };
+        const int2* ktl = ktab + half;
+        auto koffs = [&](int s) __attribute__((always_inline)) { return ktl[2 * min(s, a.NKS - 1)]; };
         v16f acc[2][3];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
-        // software pipeline: the weight fragments of k-step s + WD (L2 latency ~ 2-3 k-steps of MFMA time) and the patch fragments
-        // of k-step s + 1 (LDS latency) are requested before the MFMAs of k-step s issue; rings indexed by the unrolled position
-        constexpr int WD = 1, RING = 2;                          // (the unrolled group of 4 k-steps must be a multiple of the ring)
-        static_assert(4 % RING == 0, "ring slots are indexed by the unrolled position");
+        // software pipeline: the weight fragments of k-step s + WD (L2 latency ~ 2-3 k-steps of MFMA time), the patch fragments of
+        // k-step s + 1 (LDS latency) and the offset pair of k-step s + 2 are requested before the MFMAs of k-step s issue; rings
+        // indexed by the k-step's parity (a compile-time constant at every call site)
+        constexpr int WD = 1, RING = 2;
         uint4 wh[RING][3], wl[RING][3], ah[2][2], al[2][2];
 #pragma unroll
         for (int u = 0; u < WD; ++u) load_w(u, wh[u], wl[u]);
-        load_a(0, ah[0], al[0]);
+        load_a(koffs(0), ah[0], al[0]);
+        int2 kq = koffs(1);
         QT_FS(1);
-        for (int s0 = 0; s0 < a.NKS; s0 += 4) {
+        // FIRST: the k-step that starts the tile — its MFMAs take a zero C operand instead of 96 zeroed accumulator registers
+        auto kstep = [&](int s, auto uc, auto firstc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            constexpr bool FIRST = decltype(firstc)::value;
+            load_w(s + WD, wh[(u + WD) % RING], wl[(u + WD) % RING]);
+            load_a(kq, ah[(u + 1) & 1], al[(u + 1) & 1]);
+            kq = koffs(s + 2);
+            __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this k-step's MFMAs, not after them
+            // one term at a time over the six accumulator tiles: two MFMAs on the same accumulator are never adjacent
+            v16f zero;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = s0 + u;
-                load_w(s + WD, wh[(u + WD) % RING], wl[(u + WD) % RING]);
-                load_a(s + 1, ah[(u + 1) & 1], al[(u + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);               // the requests go out BEFORE this k-step's MFMAs, not after them
-                // one term at a time over the six accumulator tiles: two MFMAs on the same accumulator are never adjacent
+            for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wh[u % RING][t], FIRST ? zero : acc[mt][t]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(al[u & 1][mt], wh[u % RING][t], acc[mt][t]);
+            if constexpr (REALW) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wh[u % RING][t], acc[mt][t]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(al[u & 1][mt], wh[u % RING][t], acc[mt][t]);
-                if constexpr (REALW) {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wl[u % RING][t], acc[mt][t]);
-                }
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma16(ah[u & 1][mt], wl[u % RING][t], acc[mt][t]);
             }
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        // k-step 0, then pairs (the ring positions alternate), an even count's last k-step peeled: no zero k-steps appended
+        kstep(0, P0{}, std::true_type{});
+        int s0 = 1;
+        for (; s0 + 1 < a.NKS; s0 += 2) {
+            kstep(s0, P1{}, std::false_type{});
+            kstep(s0 + 1, P0{}, std::false_type{});
         }
+        if (s0 < a.NKS) kstep(s0, P1{}, std::false_type{});
 
         QT_FS(2);
         // ---- epilogue: lane owns channel n = tile * 32 + lrow, rows (r & 3) + 8 (r >> 2) + 4 half of each 32-pixel tile ------------
@@ -419,6 +442,19 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
         if constexpr (!BITS)
             yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + (int64_t)img * a.Ho * a.Wo * a.ldy, 0,
                                                       (int)((int64_t)a.Ho * a.Wo * a.ldy * 4), 0x00020000);
+        // threshold bits: lanes 0 .. 31 store one pixel's word per (m-tile, channel tile) — the pixel's row of the bit plane is the same
+        // for the three channel tiles: found once per m-tile (it was recomputed per store: 25 of the epilogue's ~95 VALU instructions per
+        // accumulator tile)
+        [[maybe_unused]] uint32_t* brow[2] = {nullptr, nullptr};
+        if constexpr (BITS) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int j = (mg * 2 + mt) * 32 + lane_t;
+                const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
+                const int oy = oy0 + oyl, ox = ox0 + oxl;
+                if (lane_t < 32 && j < npix && oy < a.Ho && ox < a.Wo) brow[mt] = a.bits + (((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldb;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if ((nt0 + t) * 32 >= a.Coutp) continue;
@@ -448,17 +484,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_direct_kernel(FirstArgs a) 
                               "s"((uint32_t)m[2]), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)m[3]), "s"((uint32_t)(m[3] >> 32)),
                               "n"(8 * g));
                     }
-                    const int j = jb + lane_t;                                          // lanes 0 .. 31: one pixel each
-                    if (lane_t < 32 && j < npix) {
-                        const int oyl = divm(j, a.m_tox, a.TOX), oxl = j - oyl * a.TOX;
-                        const int oy = oy0 + oyl, ox = ox0 + oxl;
-                        if (oy < a.Ho && ox < a.Wo) {
-                            uint32_t* row = a.bits + (((int64_t)img * a.Ho + oy) * a.Wo + ox) * a.ldb;
-                            row[nt0 + t] = myword;
-                            // the row's pad words (ldb rounds ceil(Cout / 32) up): written once, by the tile that holds the last channels
-                            if ((nt0 + t + 1) * 32 >= a.Coutp)
-                                for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
-                        }
+                    if (uint32_t* row = brow[mt]) {                                     // lanes 0 .. 31: one pixel each
+                        row[nt0 + t] = myword;
+                        // the row's pad words (ldb rounds ceil(Cout / 32) up): written once, by the tile that holds the last channels
+                        if ((nt0 + t + 1) * 32 >= a.Coutp)
+                            for (int wc = nt0 + t + 1; wc < a.ldb; ++wc) row[wc] = 0u;
                     }
                 } else {
                     // buffer stores: voffset = pixel offset (LDS table, four consecutive pixels per 16-byte read) + this lane's channel;
@@ -506,9 +536,9 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.x = x; a.sn = sn; a.sc = sc; a.sh = sh; a.sw = sw;
     a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W; a.KH = (int)KH; a.KW = (int)KW; a.S = (int)S; a.PH = (int)PH; a.PW = (int)PW;
     a.Ho = (int)Ho; a.Wo = (int)Wo; a.Cp = (int)Cp;
-    a.CPK = (int)((KW * Cp + 7) / 8);
-    a.NCH = (int)(KH * a.CPK);
-    a.NKS = ((a.NCH + 1) / 2 + 3) / 4 * 4;           // whole groups of 4 k-steps (the weight pack appends zero k-steps)
+    a.G4 = (int)((KW * Cp + 3) / 4);
+    a.NG4 = (int)(KH * a.G4);
+    a.NKS = (a.NG4 + 3) / 4;                          // (the weight pack zero-fills the last k-step)
     // output tile: <= 128 pixels, as square as the map allows, sized to waste the fewest padded pixels
     int best_ty = 1, best_tx = 1;
     double best = 1e30;
@@ -516,9 +546,9 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
         for (int tx = 1; tx * ty <= 128; ++tx) {
             if (tx * ty < 64 && tx * ty < Ho * Wo) continue;
             const int64_t pr = (int64_t)(ty - 1) * S + KH, pce = ((int64_t)(tx - 1) * S + KW) * Cp;
-            const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.CPK * 8) + 3) / 4 * 4;
+            const int64_t rs = (std::max<int64_t>(pce, (int64_t)(tx - 1) * S * Cp + a.G4 * 4) + 3) / 4 * 4;
             if (rs / 2 > 256 || (pr + 256 / (rs / 2) - 1) / (256 / (rs / 2)) > 18) continue;          // <= 18 row passes of the patch loader
-            if (2 * (2 * pr * rs * 2) + 64 + 1024 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
+            if (2 * (2 * pr * rs * 2) + 64 + 1024 + a.NKS * 16 > 76 * 1024) continue;     // two patch buffers, two workgroups per CU
             const int64_t tiles = ((Ho + ty - 1) / ty) * ((Wo + tx - 1) / tx);
             // cost: MFMA work (128 rows per tile whatever it holds) + the patch it loads (halo re-reads)
             const double cost = (double)tiles * (128.0 * a.NKS * 16 + 0.25 * (double)(pr * rs));
@@ -529,11 +559,11 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.tiles_y = (int)((Ho + a.TOY - 1) / a.TOY); a.tiles_x = (int)((Wo + a.TOX - 1) / a.TOX);
     a.PR = (a.TOY - 1) * a.S + a.KH;
     a.PCE = ((a.TOX - 1) * a.S + a.KW) * a.Cp;
-    a.RS = (std::max(a.PCE, (a.TOX - 1) * a.S * a.Cp + a.CPK * 8) + 3) / 4 * 4;
+    a.RS = (std::max(a.PCE, (a.TOX - 1) * a.S * a.Cp + a.G4 * 4) + 3) / 4 * 4;
     auto magic = [](int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; };
     a.m_tx = magic(a.tiles_x);
     { const unsigned long long d = (unsigned long long)a.tiles_y * a.tiles_x; a.m64_tpi = d > 1 ? ~0ull / d + 1 : 0; }
-    a.m_ppr = magic(a.RS / 2); a.m_cp = magic(a.Cp); a.m_tox = magic(a.TOX); a.m_cpk = magic(a.CPK);
+    a.m_ppr = magic(a.RS / 2); a.m_cp = magic(a.Cp); a.m_tox = magic(a.TOX); a.m_g4 = magic(a.G4);
     a.whi = reinterpret_cast<const uint4*>(whi);
     a.wlo = reinterpret_cast<const uint4*>(wlo);
     a.wscale = wscale;
@@ -546,7 +576,7 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     a.bias = bias; a.y = y; a.ldy = ldy; a.alpha = alpha; a.beta = beta; a.bits = bits; a.ldb = ldb;
     const int64_t ntiles = N * a.tiles_y * a.tiles_x;
     if (ntiles > INT32_MAX) return QT_ERR_UNSUPPORTED;
-    const int lds = 2 * (2 * a.PR * a.RS * 2) + 64 + 1024;            // two patch buffers (hi + lo planes each) + the scales + pixel offsets
+    const int lds = 2 * (2 * a.PR * a.RS * 2) + 64 + 1024 + a.NKS * 16;   // two patch buffers (hi + lo planes each) + the scales + pixel offsets + k-step offsets
     const unsigned ny = (unsigned)((Coutp + 191) / 192);
     // persistent workgroups: two per CU (256 CUs), shared between the channel blocks
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, std::max<int64_t>(1, 512 / ny)), ny);

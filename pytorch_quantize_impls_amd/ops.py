@@ -2605,9 +2605,9 @@ def pack_first_layer_weight(wq: torch.Tensor, stride: int, real: bool = False) -
     wq = _require(wq.detach(), "weight")
     Cout, C, kh, kw = (int(v) for v in wq.shape)
     Cp = first_direct_cp(C, stride)
-    cpk = (kw * Cp + 7) // 8
-    nch = kh * cpk
-    nks = ((nch + 1) // 2 + 3) // 4 * 4            # whole groups of 4 k-steps (the kernel's unrolled pipeline); zero padded
+    g4 = (kw * Cp + 3) // 4                        # 8-byte groups (4 k) per kernel row
+    ng4 = kh * g4
+    nks = (ng4 + 3) // 4                           # k-steps of 16 (the last one zero-filled)
     Coutp = (Cout + 31) // 32 * 32
     F = torch.nn.functional
     scale = None
@@ -2618,8 +2618,8 @@ def pack_first_layer_weight(wq: torch.Tensor, stride: int, real: bool = False) -
 
     def frag(t):                                                # [Cout, C, kh, kw] fp32 -> [nks, 2, Coutp, 8] fp16
         t = F.pad(t.permute(0, 2, 3, 1), (0, Cp - C)).reshape(Cout, kh, kw * Cp)
-        t = F.pad(t, (0, cpk * 8 - kw * Cp)).reshape(Cout, nch * 8)
-        t = F.pad(t, (0, nks * 16 - nch * 8, 0, Coutp - Cout)).reshape(Coutp, nks, 2, 8)
+        t = F.pad(t, (0, g4 * 4 - kw * Cp)).reshape(Cout, ng4 * 4)
+        t = F.pad(t, (0, nks * 16 - ng4 * 4, 0, Coutp - Cout)).reshape(Coutp, nks, 2, 8)
         return t.permute(1, 2, 0, 3).contiguous()
     hi = frag(wq).to(torch.float16)
     lo = None
