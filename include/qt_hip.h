@@ -154,6 +154,14 @@ int qt_bits_alpha_digits_i8(const uint32_t* bits, int64_t ldb, const uint32_t* d
 int qt_digit_reduce_f32(const float* partial, int64_t ldp, int64_t slice_stride, int64_t nslice, const float* scale_dev,
                         const float* bias, float* Y, int64_t ldy, int64_t rows, int64_t N, qt_stream_t stream);
 
+/* The digit route for small heads (N of a few outputs: the classifier layer) in ONE launch, straight from the sign bits:
+ * Y[b][n] = fp32(s * sum_k x[b, k] A[k] W[n][k]) + bias[n] with the exact integer sum (A from digit_table, W = int8 codes of
+ * sign(W), [N][ldw_bytes], zero past K) — bit-identical to qt_bits_alpha_digits_i8 + qt_i8_gemm_splitk + qt_digit_reduce_f32.
+ * K < 2^16. */
+int qt_xnor_head_i8(const uint32_t* bits, int64_t ldb, const uint32_t* digit_table, const int8_t* wcodes, int64_t ldw_bytes,
+                    const float* scale_dev, const float* bias, float* Y, int64_t ldy, int64_t rows, int64_t N, int64_t K,
+                    int64_t perm_C, int64_t perm_HW, qt_stream_t stream);
+
 /* XNOR-Net ACTIVATION quantiser on a row-major [R, C] tensor (_quantOpXnor / nnQuantXnor / QuantXnor,
  * functions/xnor_connect.py:17-66):  y = sign(x) * mean(x, dim)  with torch.sign (0 -> 0) and the SIGNED mean the
  * reference computes (:21-28).  dim = 1: mean[R] per row; dim = 0: mean[C] per column; dim = -1: mean[1] over all

@@ -154,6 +154,7 @@ SIGNATURES = {
                                                _c_i64, _c_p]),
     "qt_bits_alpha_pairs_f16x2": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_bits_alpha_digits_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_xnor_head_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_digit_reduce_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_i8_gemm_splitk": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_xnor_tap_prep_work_floats": (_c_i64, [_c_i64, _c_i64]),

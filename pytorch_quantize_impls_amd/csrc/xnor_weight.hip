@@ -156,6 +156,65 @@ __global__ __launch_bounds__(256) void digit_reduce_kernel(const float* __restri
     }
 }
 
+
+// Small heads (N <= 32 outputs: the classifier layer): the same exact integer sum_k x[b, k] A[k] s[n, k] straight from the sign bits —
+// one wave per (row, 8 outputs), lane = 4 consecutive features per step (one dword of each weight row's int8 codes, one 16-byte read
+// of the digit table), |lane partial| < 2^21 K / 64 in int32, the wave's total in fp64 (exact), then the digit route's own last
+// step fp32(total * s) + bias: BIT-IDENTICAL to the split-K GEMM + qt_digit_reduce_f32, without three launches whose tiles are
+// empty at N = 10 (29 -> 6 us at 256 x 10 x 4096).
+__global__ __launch_bounds__(256) void xnor_head_kernel(const uint32_t* __restrict__ bits, int64_t ldb, const uint4* __restrict__ dtab4,
+                                                        const uint32_t* __restrict__ wc, int64_t ldw_words, const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                        int64_t N, int64_t K, int64_t perm_C, int64_t perm_HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = blockIdx.y * 8;
+    if (r >= rows) return;
+    const int64_t kq = (K + 3) / 4;                  // groups of 4 features (table / weight rows are zero past K)
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t* wrow[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wrow[j] = wc + (int64_t)min((int64_t)(n0 + j), N - 1) * ldw_words;
+    for (int64_t q = lane; q < kq; q += 64) {
+        const int64_t k0 = q * 4;
+        const uint4 t4 = dtab4[q];
+        uint32_t nib = 0u;
+        if (perm_C > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t k = k0 + e;
+                if (k < K) {
+                    const int64_t c = k / perm_HW, hw = k - c * perm_HW, b = hw * perm_C + c;
+                    nib |= ((bits[r * ldb + (b >> 5)] >> (b & 31)) & 1u) << e;
+                }
+            }
+        } else {
+            nib = (bits[r * ldb + (k0 >> 5)] >> (k0 & 31)) & 0xFu;
+        }
+        const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+        int xa[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int A = (int)(((t[e] & 0xffu) << 14) | (((t[e] >> 8) & 0xffu) << 7) | ((t[e] >> 16) & 0xffu));
+            xa[e] = ((nib >> e) & 1u) ? -A : A;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w4 = wrow[j][q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] += xa[e] * (int)(int8_t)(w4 >> (8 * e));
+        }
+    }
+    const double s = (double)scale[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double v = (double)acc[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && n0 + j < N) Y[r * ldy + n0 + j] = (float)(v * s) + (bias ? bias[n0 + j] : 0.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_bits_alpha_pairs_f16x2(const uint32_t* bits, int64_t ldb, const uint32_t* alpha_pairs, uint32_t* out,
@@ -205,5 +264,19 @@ extern "C" int qt_digit_reduce_f32(const float* partial, int64_t ldp, int64_t sl
     const int grid = qt_stream_grid((rows * N + 255) / 256);
     hipLaunchKernelGGL(digit_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, ldp, slice_stride, (int)nslice,
                        scale_dev, bias, Y, ldy, rows, N);
+    return qt_check_launch();
+}
+
+extern "C" int qt_xnor_head_i8(const uint32_t* bits, int64_t ldb, const uint32_t* digit_table, const int8_t* wcodes, int64_t ldw_bytes,
+                               const float* scale_dev, const float* bias, float* Y, int64_t ldy, int64_t rows, int64_t N, int64_t K,
+                               int64_t perm_C, int64_t perm_HW, qt_stream_t stream) {
+    if (rows < 0 || N < 0 || K < 0 || perm_C < 0 || perm_HW < 0 || (perm_C > 0 && perm_C * perm_HW != K) || ldy < N) return QT_ERR_INVALID_ARG;
+    if (rows == 0 || N == 0) return QT_OK;
+    if (!bits || !digit_table || !wcodes || !scale_dev || !Y || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
+    if ((ldw_bytes & 15) || ldw_bytes < (K + 3) / 4 * 4 || !qt_aligned16(wcodes) || !qt_aligned16(digit_table)) return QT_ERR_ALIGNMENT;
+    if (K >= (1ll << 16) || N > 65535 * 8) return QT_ERR_UNSUPPORTED;                  // lane partial < 2^21 * K / 64 < 2^31
+    hipLaunchKernelGGL(xnor_head_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)((N + 7) / 8)), dim3(256), 0, (hipStream_t)stream, bits,
+                       ldb, reinterpret_cast<const uint4*>(digit_table), reinterpret_cast<const uint32_t*>(wcodes), ldw_bytes / 4, scale_dev,
+                       bias, Y, ldy, rows, N, K, perm_C, perm_HW);
     return qt_check_launch();
 }

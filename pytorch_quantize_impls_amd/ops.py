@@ -1493,6 +1493,10 @@ def bits_alpha_digits(planes: BitPlanes, digits: AlphaDigits, hwc=None, ld_bytes
     return CodePlanes(codes=out, rows=3 * planes.rows, K=planes.K)
 
 
+#: output features up to which LinearXNOR's digit route runs as one streaming launch (qt_xnor_head_i8) instead of the split-K GEMM
+XNOR_HEAD_MAX_N = 32
+
+
 def xnor_digit_linear(planes: BitPlanes, digits: AlphaDigits, wcodes: CodePlanes, bias: Optional[torch.Tensor] = None,
                       hwc=None) -> torch.Tensor:
     """y = (x * alpha) . sign(W)^T + b for a packed +-1 activation x (functions/xnor_connect.py:112-115) in the integer form:
@@ -1505,6 +1509,14 @@ def xnor_digit_linear(planes: BitPlanes, digits: AlphaDigits, wcodes: CodePlanes
     ld = int(wcodes.codes.shape[1])
     if 127 * ld >= (1 << 24) or (ld & 127):
         raise ValueError("digit-plane GEMM: K beyond the exact fp32 range of the partial sums, or an unpadded weight plane")
+    if N <= XNOR_HEAD_MAX_N and K < (1 << 16):
+        # classifier heads: the same exact integer sum in one launch from the sign bits (bit-identical to the GEMM form below)
+        pc, phw = (int(hwc[0]), int(hwc[1]) * int(hwc[2])) if hwc is not None else (0, 0)
+        y = torch.empty((rows, N), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("qt_xnor_head_i8", _p(planes.sign), int(planes.ld), _p(digits.table), _p(wcodes.codes), int(ld), _p(digits.scale),
+                      _p(bias), _p(y), int(N), int(rows), int(N), int(K), pc, phw, _stream(dev))
+        return y
     x3 = bits_alpha_digits(planes, digits, hwc=hwc, ld_bytes=ld)
     kslice, nslice = splitk_plan(3 * rows, N, ld)
     ldp = (N + 3) // 4 * 4

@@ -224,7 +224,8 @@ def _xnor_linear_fp64(x_pm1, w, bias):
 
 
 @pytest.mark.parametrize("rows,N,K,hwc", [(256, 4096, 9216, (256, 6, 6)), (256, 4096, 4096, None), (256, 10, 4096, None),
-                                          (5, 7, 100, None), (33, 70, 96, (6, 4, 4)), (64, 1000, 4096, None)])
+                                          (5, 7, 100, None), (33, 70, 96, (6, 4, 4)), (64, 1000, 4096, None), (3, 32, 9216, (256, 6, 6)),
+                                          (130, 17, 1030, None)])
 def test_xnor_digit_linear_vs_fp64_and_vs_the_pair_route(dev, rows, N, K, hwc):
     torch.manual_seed(rows + N + K)
     lin = LinearXNOR(K, N, bias=True).to(dev)
@@ -246,8 +247,18 @@ def test_xnor_digit_linear_vs_fp64_and_vs_the_pair_route(dev, rows, N, K, hwc):
     with torch.no_grad():
         y = _fused.packed_xnor_linear(lin, act, hwc=hwc)
         y2 = _fused.packed_xnor_linear(lin, act, hwc=hwc)
-    assert _lib.call_counts["qt_i8_gemm_splitk"] - before.get("qt_i8_gemm_splitk", 0) == 2
+    route = "qt_xnor_head_i8" if N <= ops.XNOR_HEAD_MAX_N else "qt_i8_gemm_splitk"
+    assert _lib.call_counts[route] - before.get(route, 0) == 2
     assert torch.equal(y, y2)
+    if N <= ops.XNOR_HEAD_MAX_N:          # the one-launch head form and the split-K GEMM form: the same exact integer sum, the same bits
+        old_n = ops.XNOR_HEAD_MAX_N
+        try:
+            ops.XNOR_HEAD_MAX_N = 0
+            with torch.no_grad():
+                yg = _fused.packed_xnor_linear(lin, act, hwc=hwc)
+        finally:
+            ops.XNOR_HEAD_MAX_N = old_n
+        assert torch.equal(y, yg)
     ref = _xnor_linear_fp64(x, lin.weight.detach(), lin.bias)
     assert norm_err(n(y), n(ref)) <= TOL, norm_err(n(y), n(ref))
     old = _fused.XNOR_LINEAR_DIGITS
