@@ -521,6 +521,8 @@ def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
 
     dg = xnor_linear_digits(layer) if XNOR_LINEAR_DIGITS else None
+    if dg is not None and 3 * act.planes.rows * int(dg[0].codes.shape[1]) >= (1 << 31):
+        dg = None                                               # the stacked digit planes pass the GEMM's 32-bit operand offsets
     if dg is not None:
         # integer form: alpha as three 7-bit digits against the int8 codes of sign(W) — exact partial sums, 1 byte per weight
         y = ops.xnor_digit_linear(act.planes, dg[1], dg[0], layer.bias, hwc=hwc)

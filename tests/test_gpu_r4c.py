@@ -285,3 +285,73 @@ def test_xnor_digit_linear_falls_back_on_non_finite_alpha(dev):
     with torch.no_grad():
         y = lin(x)
     assert not bool(torch.isfinite(y).all())                    # the reference's inf / NaN come through the pair route
+
+
+# ---- reference digests of LinearXNOR at the classifier shapes (tests/golden/make_golden_r4c.py G19) -----------------------------------
+
+import hashlib  # noqa: E402
+import json  # noqa: E402
+import os  # noqa: E402
+
+from conftest import GOLDEN_DIR  # noqa: E402
+from pytorch_quantize_impls_amd import synth  # noqa: E402
+
+
+def _g19_operands(seed, B, K, N):
+    """The operands make_golden_r4c.py fed the reference: x +-1, |W[n, k]| = 2^e[k], bias multiples of 1/4."""
+    x = synth.pm1(seed, (B, K))
+    e = np.floor(synth.uniform(seed + 1, (K,), -6.0, -2.0)).astype(np.int32)
+    sgn = synth.pm1(seed + 2, (N, K))
+    w = (sgn * np.exp2(e.astype(np.float32))[None, :]).astype(np.float32)
+    b = (np.round(synth.normal(seed + 3, (N,)) * 4) / 4).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize("name", ["xnor_fc1_b256", "xnor_fc2_b256", "xnor_fc3_b256", "xnor_fc_ragged"])
+@pytest.mark.parametrize("route", ["eval_digits", "eval_digits_gemm_only", "eval_packed_hwc", "eval_pairs", "train"])
+def test_linear_xnor_reproduces_the_reference_digest(dev, name, route):
+    """alpha[k] a power of two per input feature: the reference's fp32 result is exact whatever the summation order, and its SHA-256
+    must come out of every route of this backend — the digit-plane int8 GEMM, the one-launch head, the fp16 pair route (eval and
+    training-mode forward), and the packed activation whose bits arrive in (h, w, c) order."""
+    with open(os.path.join(GOLDEN_DIR, "golden_hashes_r4c.json")) as fh:
+        c = json.load(fh)["cases"][name]
+    B, K, N = c["B"], c["K"], c["N"]
+    x, w, b = _g19_operands(c["seed"], B, K, N)
+    lin = LinearXNOR(K, N, bias=True).to(dev)
+    lin.weight.data.copy_(torch.from_numpy(w))
+    lin.bias.data.copy_(torch.from_numpy(b))
+    xt = BinaryConnectDeterministic.apply(torch.from_numpy(x).to(dev))
+    old_d, old_n = _fused.XNOR_LINEAR_DIGITS, ops.XNOR_HEAD_MAX_N
+    before = dict(_lib.call_counts)
+    try:
+        if route == "train":
+            lin.train()
+            with torch.no_grad():
+                y = lin(xt)
+        else:
+            lin.eval()
+            assert torch.equal(lin.weight.detach().cpu(), torch.from_numpy(w))       # sign(W) * alpha == W: the image is a fixed point
+            _fused.XNOR_LINEAR_DIGITS = route != "eval_pairs"
+            if route == "eval_digits_gemm_only":
+                ops.XNOR_HEAD_MAX_N = 0
+            with torch.no_grad():
+                if route == "eval_packed_hwc":
+                    if K != 9216:
+                        pytest.skip("the (h, w, c) hand-over is fc1's")
+                    xh = xt.view(B, 256, 6, 6).permute(0, 2, 3, 1).reshape(B, K).contiguous()
+                    act = packed.PackedActivation(ops.sign_pack(xh)[0], (B, K))
+                    y = _fused.packed_xnor_linear(lin, act, hwc=(256, 6, 6))
+                else:
+                    y = lin(xt)
+    finally:
+        _fused.XNOR_LINEAR_DIGITS, ops.XNOR_HEAD_MAX_N = old_d, old_n
+    used = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v != before.get(k, 0)}
+    if route in ("eval_digits", "eval_packed_hwc"):
+        assert used.get("qt_xnor_head_i8" if N <= 32 else "qt_i8_gemm_splitk", 0) == 1, used
+    elif route == "eval_digits_gemm_only":
+        assert used.get("qt_i8_gemm_splitk", 0) == 1 and "qt_xnor_head_i8" not in used, used
+    else:
+        assert used.get("qt_bits_alpha_pairs_f16x2", 0) == 1 and "qt_i8_gemm_splitk" not in used, used
+    a = np.ascontiguousarray(y.detach().float().cpu().numpy(), dtype=np.float32)
+    assert a.shape == (B, N)
+    assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32"], (float(a.astype(np.float64).sum()), c["sum"])
