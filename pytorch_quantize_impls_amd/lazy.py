@@ -57,6 +57,11 @@ ENABLED = True
 #: The codes then equal the module-by-module graph's bit for bit (tests/test_gpu_lazy.py: torch.equal).  False: DoReFa
 #: convs are never deferred.
 DEFER_CODES = True
+#: the [B, N] result of an eval-mode LinearBin / LinearTer / LinearXNOR is handed out as a deferred activation as well — already
+#: COMPUTED (the GEMM ran), but BatchNorm1d -> [Hardtanh] -> BinaryConnect recorded on it run as ONE pass over it (FusedPoolBnSign
+#: with this device's own BatchNorm thresholds: the bits of the module chain) instead of three launches; any other use reads the
+#: value.  The classifier of an un-modified AlexNet then executes like the explicit fused form.
+DEFER_DENSE = True
 #: "deferred" convs that returned a LazyActivation, "fused" chains executed as fused blocks, "materialised" lazies that
 #: had to produce their fp32 value, "fallback:<func>" the functions that forced it
 STATS = collections.Counter()
@@ -208,6 +213,8 @@ class _Node:
         quantised chain (int8 code plane, ``halo`` = zero border).  None if this chain cannot run fused."""
         if self.kind == "dorefa":
             return self._force_codes(halo)
+        if self.kind == "dense":
+            return self._force_dense()
         if not self.signed or self.bn is None:
             return None
         if self.flat:
@@ -398,7 +405,8 @@ class LazyActivation(torch.Tensor):
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
         name = getattr(func, "__name__", str(func))
-        STATS["fallback:" + name] += 1
+        if not (args and isinstance(args[0], LazyActivation) and args[0]._qt.value is not None):
+            STATS["fallback:" + name] += 1            # (a use of an already computed value — dense / constant nodes — forces nothing)
         out_kw = kwargs.get("out")
         if isinstance(out_kw, LazyActivation):
             # func(..., out=deferred): the result replaces what the wrapper stood for — computed into a fresh tensor (the cached
@@ -442,6 +450,57 @@ def _const_node(value: torch.Tensor) -> _Node:
     n.signed = n.relu = n.captured = False
     n.stamp, n.device = (), value.device
     return n
+
+
+def _dense_node(value: torch.Tensor) -> _Node:
+    """Root that holds the computed [B, N] result of a quantised Linear layer: BatchNorm1d, Hardtanh and BinaryConnect can be
+    recorded on it (kind "dense"); everything else reads the value."""
+    n = _const_node(value)
+    n.kind = "dense"
+    n.bn = n.hardtanh = None                  # still to come; flat stays True: pooling / flatten handlers decline
+    n.stamp = _stamp(value)
+    n.captured = value.is_cuda and torch.cuda.is_current_stream_capturing()
+    return n
+
+
+_DENSE_BLOCKS = collections.OrderedDict()     # BatchNorm tensors' ids -> FusedPoolBnSign (its fold is re-validated per call)
+
+
+def _force_dense(self):
+    """PackedActivation (row planes) of a recorded Linear -> BatchNorm1d -> [Hardtanh] -> BinaryConnect chain: one pass over the
+    layer's fp32 result with this device's BatchNorm thresholds."""
+    if not self.signed or self.bn is None:
+        return None
+    if self.packed_cache is None:
+        self.packed_cache = {}
+    if None in self.packed_cache:
+        return self.packed_cache[None]
+    self.check_unmodified()
+    from .layers import fused
+    rm, rv, w, b, eps = self.bn
+    key = (id(rm), id(rv), id(w), id(b), eps)
+    blk = _DENSE_BLOCKS.get(key)
+    if blk is None:
+        blk = _DENSE_BLOCKS[key] = fused.FusedPoolBnSign(_BnView(rm, rv, w, b, eps), fold="device")
+        while len(_DENSE_BLOCKS) > 64:
+            _DENSE_BLOCKS.popitem(last=False)
+    else:
+        _DENSE_BLOCKS.move_to_end(key)
+    root = self
+    while root.parent is not None:
+        root = root.parent
+    try:
+        with torch.no_grad():
+            act = blk(root.value)
+    except ValueError:
+        act = None
+    if act is not None:
+        STATS["dense_fused"] += 1
+    self.packed_cache[None] = act
+    return act
+
+
+_Node._force_dense = _force_dense
 
 
 _T = torch.Tensor
@@ -527,7 +586,10 @@ def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, trai
     if not isinstance(input, LazyActivation) or training or running_mean is None or running_var is None:
         return NotImplemented
     n = input._qt
-    if n.bn is not None or n.flat or len(n.shape) != 4 or n.add is not None:
+    if n.kind == "dense":
+        if n.bn is not None or len(n.shape) != 2:
+            return NotImplemented
+    elif n.bn is not None or n.flat or len(n.shape) != 4 or n.add is not None:
         return NotImplemented
     C = n.shape[1]
     for t in (running_mean, running_var, weight, bias):
@@ -825,9 +887,19 @@ class _ShapeOnly(packed.PackedActivation):
         self.shape = tuple(shape)
 
 
+def _dense_result(layer, y):
+    """``y`` as a deferred activation that BatchNorm1d -> [Hardtanh] -> BinaryConnect can be recorded on (DEFER_DENSE)."""
+    if (DEFER_DENSE and enabled() and type(y) is torch.Tensor and y.dim() == 2 and y.is_cuda and y.dtype == torch.float32
+            and not y.requires_grad and not layer.training and _no_autograd(layer) and not _untracked(y)):
+        STATS["dense_deferred"] += 1
+        return _wrap(_dense_node(y))
+    return y
+
+
 def linear_forward(layer, input, kind: str):
-    """forward() of LinearBin / LinearTer: a flattened, binarised deferred activation arrives as row planes in (h, w, c)
-    order and meets the weight with its columns permuted to that order (cached per weight version)."""
+    """forward() of LinearBin / LinearTer / LinearXNOR: a flattened, binarised deferred activation arrives as row planes in
+    (h, w, c) order and meets the weight with its columns permuted to that order (cached per weight version).  In eval mode without
+    autograd the result goes out as a "dense" deferred activation (DEFER_DENSE)."""
     if isinstance(input, LazyActivation):
         n = input._qt
         if (n.signed and n.flat and not layer.training and _no_autograd(layer) and layer.weight.is_cuda
@@ -836,9 +908,9 @@ def linear_forward(layer, input, kind: str):
             if act is not None:
                 from .functions import _fused
                 if kind == "xnor":
-                    return _fused.packed_xnor_linear(layer, act, hwc=n.chw)
-                return _fused.packed_linear(layer, act, kind, hwc=n.chw)
+                    return _dense_result(layer, _fused.packed_xnor_linear(layer, act, hwc=n.chw))
+                return _dense_result(layer, _fused.packed_linear(layer, act, kind, hwc=n.chw))
         input = n.materialise()
     if type(input) in lazy_train._DEFERRED:
         input = lazy_train.resolve(input)
-    return lazy_train.wrap(layer, layer._forward_impl(input))
+    return _dense_result(layer, lazy_train.wrap(layer, layer._forward_impl(input)))

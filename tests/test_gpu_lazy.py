@@ -55,7 +55,8 @@ def test_alexnet_module_graph_runs_fused_and_equals_the_fused_form(dev):
         y = m(x)
         with lazy.eager():
             e = m(x)
-    assert type(y) is torch.Tensor and type(e) is torch.Tensor          # the classifier's LinearBin returns real tensors
+    assert type(y) is torch.Tensor and type(e) is torch.Tensor          # LogSoftmax reads the last LinearBin's (computed) result
+    assert lazy.STATS["dense_deferred"] == 3 and lazy.STATS["dense_fused"] == 2, lazy.STATS   # BatchNorm1d / Hardtanh / sign: one pass
     assert torch.equal(y, ref)                                          # same kernels, same bits
     assert lazy.STATS["deferred"] == 5 and lazy.STATS["fused"] == 5 and lazy.STATS["materialised"] == 0, lazy.STATS
     assert not any(k.startswith("fallback") for k in lazy.STATS), lazy.STATS
@@ -140,7 +141,9 @@ def test_chain_feeding_a_second_conv_and_a_linear(dev):
         y = fc(torch.flatten(b(a(x)), 1))
         y2 = fc(nn.Flatten()(b(a(x))))
         y3 = fc(b(a(x)).view(3, -1))
-    assert type(y) is torch.Tensor
+    # an eval-mode LinearBin hands its (computed) result out as a "dense" deferred activation: BatchNorm1d -> Hardtanh -> BinaryConnect
+    # would be recorded on it, anything else reads the value
+    assert type(y) is lazy.LazyActivation and y._qt.kind == "dense" and type(y.value()) is torch.Tensor
     assert torch.equal(y, e) and torch.equal(y2, e) and torch.equal(y3, e)      # +-1 / 0 operands: exact integers
     assert lazy.STATS["fused"] == 6 and lazy.STATS["materialised"] == 0, lazy.STATS
 
@@ -454,3 +457,51 @@ def test_fuzz_random_stacks_deferred_equals_fuse_sequential(dev, seed):
     assert lazy.STATS["fused"] >= 1
     assert torch.equal(got, ref), (seed, lazy.STATS)
     assert torch.equal(got, e), (seed, float((got - e).abs().max()))      # the eager graph on this device, bit for bit
+
+
+# ---- dense roots: Linear -> BatchNorm1d -> [Hardtanh] -> BinaryConnect as one pass (lazy.DEFER_DENSE) -------------------------------------
+
+@pytest.mark.parametrize("cls_name", ["LinearBin", "LinearTer", "LinearXNOR"])
+@pytest.mark.parametrize("hardtanh,width", [(True, 256), (False, 256), (True, 257)])
+def test_linear_bn_sign_chain_runs_as_one_pass_and_equals_the_module_chain(dev, cls_name, hardtanh, width):
+    """The classifier pattern of the BinaryNet models (models/Alexnet/Alexnet_Bin.py:40-54, benchmark/BinaryNet/MLPBin.py): the fp32 result
+    of an eval-mode quantised Linear is handed out deferred; BatchNorm1d -> [Hardtanh] -> BinaryConnect recorded on it run as ONE
+    launch with this device's own BatchNorm thresholds and feed the next layer's packed GEMM — the same bits and the same logits as
+    the module-by-module execution; a use outside the grammar reads the value."""
+    from pytorch_quantize_impls_amd import layers as L
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    torch.manual_seed(5)
+    cls = getattr(L, cls_name)
+    mods = [BinaryConnect(), cls(300, width), nn.BatchNorm1d(width)] + ([nn.Hardtanh()] if hardtanh else []) + [BinaryConnect(), cls(width, 40)]
+    seq = nn.Sequential(*mods).to(dev)
+    bn = seq[2]
+    bn.running_mean.normal_(0, 3.0)
+    bn.running_var.uniform_(0.5, 2.0)
+    bn.weight.data.normal_(0, 1.0)                      # negative slopes included
+    bn.bias.data.normal_(0, 1.0)
+    for m in seq:
+        if isinstance(m, cls):
+            m.weight.data.normal_(0, 0.3)
+    seq.eval()
+    x = torch.randn(64, 300, device=dev)
+    with torch.no_grad():
+        with lazy.eager():
+            e = seq(x)
+            e_mid = seq[:-1](x)
+        lazy.STATS.clear()
+        before = dict(_lib.call_counts)
+        y = seq(x)
+        mid = seq[:-1](x)
+    assert type(y) is lazy.LazyActivation and y._qt.kind == "dense"
+    if width % 4 == 0:
+        assert lazy.STATS["dense_fused"] == 1 and lazy.STATS["materialised"] == 0, lazy.STATS       # (`mid` was recorded, never used)
+        assert _lib.call_counts["qt_pool_affine_sign_pack_nhwc"] - before.get("qt_pool_affine_sign_pack_nhwc", 0) == 1
+    else:                                 # a width the one-pass kernel does not take (C % 4): the recorded chain runs module by module
+        assert lazy.STATS["dense_fused"] == 0 and lazy.STATS["materialised"] > 0, lazy.STATS
+    assert torch.equal(y, e)
+    assert torch.equal(mid.value(), e_mid)                # the recorded chain's own value: sign(hardtanh(BatchNorm(.)))
+    # outside the grammar: the value is simply there
+    with torch.no_grad():
+        z = seq[1](BinaryConnect()(x))
+        assert torch.equal(z + 1.0, seq[1]._forward_impl(BinaryConnect()(x)) + 1.0)
+        assert type(torch.relu(z)) is torch.Tensor
