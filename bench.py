@@ -531,7 +531,8 @@ def bench_alexnet_xnor(args, dev, world, timed, x, bin_out):
     """The XNOR-Net flavour BASELINE config 3 is named after: utils.xnor_net_convert of the same topology —
     XNORConv2d(dim = [0, 1]) / LinearXNOR (layers/xnor_layers.py, functions/xnor_connect.py:93-169).  Behind a BinaryConnect every
     conv is  sum_taps alpha[i, j] * (integer dot over Cin): one fp4 matrix-core pass with the taps' alphas applied on the
-    accumulators (csrc/conv_taps.hip); the first layer (real pixels x real sign(W) * alpha) runs on six-term bf16 planes."""
+    accumulators (csrc/conv_taps.hip); the first layer (real pixels x real sign(W) * alpha) runs on the direct first-layer kernel with
+    two-term fp16 weights; LinearXNOR on packed bits runs in integer form (alpha as three 7-bit digits, one split-K int8 GEMM)."""
     import bench_models
     from pytorch_quantize_impls_amd import lazy
     from pytorch_quantize_impls_amd.layers import XNORConv2d, LinearXNOR, FusedFeatureClassifier
@@ -644,9 +645,9 @@ def alexnet_roofline(model, fused, x, B):
             "bound": "mfma", "dominant_block": dom["block"], "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
             "unit": "TFLOP/s", "frac": dom["frac"], "dominant_block_ms": dom["ms"], "sum_of_blocks_ms": total,
             "matrix_floor_ms": floor_ms, "blocks": rows,
-            "kernel_names": "profiles/r4_bench_kernel_stats.csv lists the kernels of each block (conv1: conv_first_direct_kernel<real weights?, "
+            "kernel_names": "profiles/r4b_bench_kernel_stats.csv lists the kernels of each block (conv1: conv_first_direct_kernel<real weights?, "
                             "threshold bits, 18> + pool_bits_kernel; conv2-5: mfma_gemm_kernel<ElemFp4 conv-valid, bits epilogue> (XNOR flavour: "
-                            "<ElemFp4Taps>) [+ pool_bits_kernel]; fc: mfma_gemm_kernel<ElemFp4 skinny> (XNOR flavour: bits_alpha_pairs_kernel + <ElemF16 skinny>))"}
+                            "<ElemFp4Taps>) [+ pool_bits_kernel]; fc: mfma_gemm_kernel<ElemFp4 skinny> (XNOR flavour: bits_alpha_digits_kernel + mfma_gemm_kernel<ElemI8, 256x256, split-K> + digit_reduce_kernel; 10-way head: xnor_head_kernel))"}
 
 
 def _layer_stats(model, x):
