@@ -19,7 +19,7 @@ for _ in range(4): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-want = sys.argv[1:] or ["aten::copy_", "aten::mul", "aten::add", "aten::add_", "aten::contiguous", "aten::clone"]
+want = sys.argv[1:] or ["aten::copy_", "aten::mul", "aten::add", "aten::add_", "aten::contiguous", "aten::clone", "aten::abs", "aten::mean", "aten::fill_", "aten::zero_", "aten::zeros", "aten::mul_"]
 rows = []
 for e in prof.events():
     if e.name in want and e.device_time > 0:
@@ -28,7 +28,7 @@ for e in prof.events():
 import collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for d, n, s, st in rows:
-    st = s
-    agg[(n, st)][0] += d; agg[(n, st)][1] += 1
+    key = s if os.environ.get("BY") == "shape" else st
+    agg[(n, key)][0] += d; agg[(n, key)][1] += 1
 for (n, st), (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{d:9.1f} us {c:4d}x {n:18s} {st}")
