@@ -355,3 +355,46 @@ def test_linear_xnor_reproduces_the_reference_digest(dev, name, route):
     a = np.ascontiguousarray(y.detach().float().cpu().numpy(), dtype=np.float32)
     assert a.shape == (B, N)
     assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32"], (float(a.astype(np.float64).sum()), c["sum"])
+
+
+# ---- fp64 vectors of the REFERENCE's 8- / 32-bit DoReFa layers (tests/golden/make_golden_r4d.py G20) ----------------------------------
+
+@pytest.fixture(scope="module")
+def g20():
+    return np.load(os.path.join(GOLDEN_DIR, "golden_r4d_v1.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["conv8_s1_codes", "conv8_s2_real", "conv8_1x1_codes", "lin8_codes", "lin8_real", "conv32_s1", "lin32"])
+def test_dorefa_8_and_32_bit_layers_vs_reference_fp64_vectors(dev, g20, all_shapes_on_the_routes, name):
+    """Forward, grad_input, grad_weight and grad_bias of this backend's training-mode layers against the reference's own layers run in
+    double precision (layers/dorefa_layers.py:11-82): <= 1e-5 normalised (2e-5 for the weight gradient through tanh / max|tanh|)."""
+    g = {k: g20[f"g20_{name}_{k}"] for k in ("x", "w", "b", "go", "y", "gx", "gw", "gb", "geom")}
+    geom = [int(v) for v in g["geom"]]
+    bits, coded = geom[-2], bool(geom[-1])
+    if name.startswith("conv"):
+        B, Cin, Cout, H, k, s, p = geom[:7]
+        layer = DorefaConv2d(Cin, Cout, k, stride=s, padding=p, bias=True, bit_width=bits)
+    else:
+        B, K, N = geom[:3]
+        layer = LinearDorefa(K, N, bias=True, bit_width=bits)
+    layer = layer.to(dev).train()
+    layer.weight.data.copy_(torch.from_numpy(g["w"]))
+    layer.bias.data.copy_(torch.from_numpy(g["b"]))
+    raw = torch.from_numpy(g["x"]).to(dev)
+    if raw.dim() == 4:
+        raw = raw.contiguous(memory_format=torch.channels_last)
+    raw.requires_grad_(True)
+    x = nnDorefaQuant(4)(raw) if coded else raw * 1.0        # the stored activation IS a 4-bit image: the quantiser reproduces it
+    if coded:
+        assert torch.equal(x.detach().cpu(), torch.from_numpy(g["x"]))
+    x.retain_grad()
+    lib_before = dict(_fused.LIBRARY_PATHS)
+    y = layer(x)
+    y.backward(torch.from_numpy(g["go"]).to(dev))
+    lib_now = _lib_delta(lib_before)
+    allowed = set() if (coded or not name.startswith("conv")) else {"conv grad_weight outside the matrix-core route"}
+    assert set(lib_now) <= allowed, lib_now
+    assert norm_err(n(y), g["y"]) <= TOL
+    assert norm_err(n(x.grad), g["gx"]) <= TOL
+    assert norm_err(n(layer.weight.grad), g["gw"]) <= 2 * TOL
+    assert norm_err(n(layer.bias.grad), g["gb"]) <= TOL
