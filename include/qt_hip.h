@@ -743,6 +743,16 @@ int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int64_t H, int
                           const uint32_t* Wmat, int64_t ldw, const float* bias, const float* alpha, const float* beta, uint32_t* out,
                           int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream);
 
+/* The real-valued 3 x 3 / stride 1 / padding 1 first layer (<= 4 channels) on fp16 PAIR planes (round 4): P = the halo-1 plane
+ * qt_f16x2_s2d_pack_f32 / _spec_f32 write for s = 1, padding 1 (16 bytes per pixel: [hi, lo] of each channel of x / scale),
+ * scale_dev = that plane's power-of-two scale, Wmat = the tap-major pair rows of qt_f16x2_pack_conv_weight_f32 (16 bytes per
+ * tap, ldw words per output channel).  Same outputs as qt_conv3x3_direct_nib (threshold bits, or the next conv's halo-1 nibble
+ * plane); the two lane halves of one MFMA take two taps (5 MFMAs per 32 x 32 block instead of 9).  Replaces the
+ * F.conv2d(x, ter_op(W)) of layers/terner_layers.py:89-92 / binary_layers.py:103-106 for VGG-style first layers. */
+int qt_conv3x3_direct_pairs(const uint32_t* P, int64_t N, int64_t H, int64_t W, const uint32_t* Wmat, int64_t ldw,
+                            const float* bias, const float* scale_dev, const float* alpha, const float* beta, uint32_t* out,
+                            int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream);
+
 /* The direct 3x3 kernel for DoReFa int8 code planes with the code epilogue of qt_conv2d_implicit_codes (same arithmetic,
  * bit-identical): P, codes and (optional) res_codes are planes with a 1-pixel halo of identical geometry,
  * [N][H+2][W+2][.]; every byte of `codes` is written, the halo as zeros.  Cw = 16 words (64 input channels), Cout <= 64,

@@ -152,6 +152,7 @@ SIGNATURES = {
     "qt_conv_first_direct_f32": (_c_int, [_c_p] + [_c_i64] * 14 + [_c_p, _c_p, _c_f32, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p]),
     "qt_conv_first_direct_bits_f32": (_c_int, [_c_p] + [_c_i64] * 14 + [_c_p, _c_p, _c_f32, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p,
                                                _c_i64, _c_p]),
+    "qt_conv3x3_direct_pairs": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_bits_alpha_pairs_f16x2": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_bits_alpha_digits_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_xnor_head_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

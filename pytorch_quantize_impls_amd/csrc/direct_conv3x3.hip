@@ -49,6 +49,17 @@ __device__ __forceinline__ d3_v16f d3_mfma_bf16(const uint4& a, const uint4& b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
 }
 
+// fp16 pair planes (real-valued first layers, two terms: x / s = hi + lo, weights +-1 / 0 replicated twice; round 4): a pixel of
+// <= 4 channels is ONE 16-byte chunk, so the two lane halves of v_mfma_f32_32x32x16_f16 (K 0..7 from lanes 0..31, 8..15 from lanes
+// 32..63) take two different TAPS: 5 MFMAs cover the 9 taps (+ one zero slot) where the triple form needs 9
+__device__ __forceinline__ d3_v16f d3_mfma_f16(const uint4& a, const uint4& b, d3_v16f c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+}
+
 // int8 code planes (DoReFa activations x +-1 weight codes): v_mfma_i32_32x32x32_i8, 16 bytes = 16 K elements per lane
 typedef int d3_v4i __attribute__((ext_vector_type(4)));
 typedef int d3_v16i __attribute__((ext_vector_type(16)));
@@ -91,7 +102,8 @@ constexpr int D3_TM = 256, D3_RUN = D3_TM + 2;
 template <int CPP, int TNW, int WN, int OCC, int EL>
 __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     constexpr int NT = 256 * WN;
-    constexpr bool I8 = EL == 1, BF16 = EL == 2;
+    constexpr bool I8 = EL == 1, BF16 = EL == 2, F16 = EL == 3;
+    static_assert(!F16 || CPP == 1, "fp16 pair pixels are one 16-byte chunk");
     using acc_t = typename std::conditional<I8, d3_v16i, d3_v16f>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WROW = 9 * CPP * 16 + 16;        // + 16: consecutive rows land on different bank groups
@@ -110,6 +122,18 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
         if (row < g.Cout) v = *reinterpret_cast<const uint4*>(g.Wm + (long long)row * g.ldw + c * 16);
         *reinterpret_cast<uint4*>(wl + row * WROW + c * 16) = v;
     }
+    if constexpr (F16) {     // the row's 16 pad bytes are tap slot 9 (the odd tap's partner): zero weights
+        for (int row = tid; row < TNW * WN * 32; row += NT) *reinterpret_cast<uint4*>(wl + row * WROW + 9 * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // fp16 pairs: this lane half's tap of pair p = 2 p + lhalf -> byte offset of its run / column in the patch, of its slot in a weight row
+    [[maybe_unused]] int tpo[5], two[5];
+#pragma unroll
+    for (int p_ = 0; p_ < 5; ++p_) {
+        const int tap = 2 * p_ + lhalf, tc = tap > 8 ? 8 : tap;          // slot 9 reads tap 8's pixel against zero weights
+        tpo[p_] = ((tc / 3) * D3_RUN + tc % 3) * 16;
+        two[p_] = tap * 16;
+    }
+    [[maybe_unused]] const float sc16 = (F16 && g.scale_dev) ? *g.scale_dev : 1.0f;       // power-of-two scale of the pair plane
     float al[TNW], nbe[TNW], bv[TNW];
 #pragma unroll
     for (int b = 0; b < TNW; ++b) {
@@ -118,6 +142,48 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
         al[b] = in ? g.alpha[n] : 0.0f;
         nbe[b] = in ? -g.beta[n] : 0.0f;
         bv[b] = (in && g.bias) ? g.bias[n] : 0.0f;
+    }
+    // threshold epilogue as ONE compare per value: bit = fl(fl(u + bias) * alpha) < -beta is monotone in u (u = the accumulator, times
+    // the pair plane's power-of-two scale), so per channel it IS a comparison of u with one fp32 threshold — found once per
+    // (persistent) workgroup by bisection over the ordered fp32 values WITH the epilogue's own arithmetic (exact by construction,
+    // infinities and alpha <= 0 / NaN included; the scheme of csrc/conv_first_direct.hip).  alpha < 0: the bit is u > theta', tested
+    // as -u < -theta' (e_sg flips the sign of u).  Was: add, multiply, compare per accumulator register
+    [[maybe_unused]] float e_th[TNW];
+    [[maybe_unused]] unsigned e_sg[TNW];
+    if constexpr (!I8) {
+#pragma unroll
+        for (int b = 0; b < TNW; ++b) {
+            const float alv = al[b], nbv = nbe[b], bvv = bv[b];
+            e_th[b] = 0.0f;
+            e_sg[b] = 0u;
+            auto key2f = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+            auto pred = [&](unsigned k) { const float u = key2f(k); const float v = u + bvv; return v * alv < nbv; };
+            const unsigned klo = 0x007fffffu, khi = 0xff800000u;          // keys of -inf, +inf
+            if (!(alv > 0.0f) && !(alv < 0.0f)) {
+                // alpha == 0: +-0 < -beta for every finite u;  alpha NaN: never
+                e_th[b] = (alv == 0.0f && 0.0f < nbv) ? __uint_as_float(0x7f800000u) : __uint_as_float(0xff800000u);
+            } else if (alv > 0.0f) {                                      // first key whose bit is 0 (the bit of +inf is 0)
+                unsigned lo = klo, hi = khi;
+                while (lo < hi) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    if (!pred(mid)) hi = mid; else lo = mid + 1;
+                }
+                e_th[b] = key2f(lo);
+            } else {                                                      // first key whose bit is 1 (the bit of -inf is 0); none: never
+                e_sg[b] = 0x80000000u;
+                if (!pred(khi)) {
+                    e_th[b] = __uint_as_float(0xff800000u);
+                } else {
+                    unsigned lo = klo, hi = khi;
+                    while (lo < hi) {
+                        const unsigned mid = lo + ((hi - lo) >> 1);
+                        if (pred(mid)) hi = mid; else lo = mid + 1;
+                    }
+                    e_th[b] = -key2f(lo - 1);
+                }
+            }
+            if constexpr (F16) e_th[b] *= 1.0f / sc16;                    // u = acc * s, s a power of two: compare acc with theta / s (exact)
+        }
     }
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const unsigned plane = (unsigned)(g.Hp * g.Wp);
@@ -164,6 +230,22 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
             for (int b = 0; b < TNW; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+        if constexpr (F16) {
+#pragma unroll
+            for (int p_ = 0; p_ < 5; ++p_) {
+                uint4 xf[2], wf[TNW];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    xf[a] = *reinterpret_cast<const uint4*>(patch + (wave * 64 + a * 32 + lrow) * 16 + tpo[p_]);
+#pragma unroll
+                for (int b = 0; b < TNW; ++b)
+                    wf[b] = *reinterpret_cast<const uint4*>(wl + ((wave_n * TNW + b) * 32 + lrow) * WROW + two[p_]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b) acc[a][b] = d3_mfma_f16(xf[a], wf[b], acc[a][b]);
+            }
+        } else
         // one kernel row at a time: a fully unrolled tap loop lets the scheduler hoist all 36 fragment reads (198 VGPRs,
         // 2 waves per SIMD); rolled over i it keeps 12 in flight
 #pragma unroll 1
@@ -289,8 +371,7 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                     uint32_t myword = 0;
     #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float t = acc[a][b][r] + bv[b];
-                        const unsigned long long mask = __ballot(t * al[b] < nbe[b]);
+                        const unsigned long long mask = __ballot(__uint_as_float(__float_as_uint(acc[a][b][r]) ^ e_sg[b]) < e_th[b]);
                         const int R = (r & 3) + 8 * (r >> 2);
                         // gfx950 does not interlock a VALU-written SGPR read by the next VALU: see mfma_gemm.hip
                         asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
@@ -360,11 +441,42 @@ extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int
     g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldo; g.out_bits = out_bits ? 1 : 0;
     g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;     // divisors >= 9: ceil(2^64 / d)
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
+    g.scale = 1.0f; g.scale_dev = nullptr; g.rscale = 0.0f; g.levels = 0.0f; g.res_codes = nullptr; g.ldrc = 0; g.relu = 0;
+    g.overflow = nullptr;
     hipStream_t s = (hipStream_t)stream;
     // LDS per workgroup: 44 / 64 KB (64 input channels), 87 / 125 KB (128)
     if (elem == 2) return Cout <= 64 ? d3_launch<2, 2, 1, 3, 2>(g, 3, s) : d3_launch<2, 4, 1, 2, 2>(g, 2, s);
     if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3>(g, 3, s) : d3_launch<2, 4, 1, 2>(g, 2, s);
     return Cout <= 64 ? d3_launch<4, 1, 2, 2>(g, 1, s) : d3_launch<4, 2, 2, 2>(g, 1, s);
+}
+
+// The real-valued first layer on fp16 PAIR planes (two terms: P = the halo-1 plane of qt_f16x2_s2d_pack*_f32(s = 1, padding 1), 16
+// bytes per pixel = up to 4 channels x [hi, lo]; scale_dev = the plane's power-of-two scale; Wmat = qt_f16x2_pack_conv_weight_f32's
+// tap-major rows, 16 bytes per tap): the two lane halves of one MFMA take two taps, 5 MFMAs per position block instead of 9, half
+// the plane bytes of the triple form (elem = 2 above) at the two-term bound max(2^-22 |x|, 2^-39 max|x|).
+extern "C" int qt_conv3x3_direct_pairs(const uint32_t* P, int64_t N, int64_t H, int64_t W, const uint32_t* Wmat, int64_t ldw,
+                                       const float* bias, const float* scale_dev, const float* alpha, const float* beta,
+                                       uint32_t* out, int64_t ldo, int64_t Cout, int out_bits, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Cout <= 0 || ldo <= 0) return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!P || !Wmat || !alpha || !beta || !out || !scale_dev) return QT_ERR_INVALID_ARG;
+    if (Cout > 128) return QT_ERR_UNSUPPORTED;
+    if (ldw < 9 * 4 || (ldw & 3) || !qt_aligned16(P) || !qt_aligned16(Wmat) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    if (out_bits ? (ldo < (Cout + 31) / 32) : (ldo != (Cout + 31) / 32 * 4)) return QT_ERR_INVALID_ARG;
+    if (H + 2 > 32767 || W + 2 > 32767 || N * (H + 2) * (W + 2) > (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    D3Args g;
+    g.P = reinterpret_cast<const unsigned char*>(P);
+    g.Wm = reinterpret_cast<const unsigned char*>(Wmat);
+    g.bias = bias; g.alpha = alpha; g.beta = beta; g.out = out;
+    g.H = (int)H; g.W = (int)W; g.Hp = (int)H + 2; g.Wp = (int)W + 2;
+    g.total = N * (int64_t)g.Hp * g.Wp;
+    g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldo; g.out_bits = out_bits ? 1 : 0;
+    g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;
+    g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
+    g.scale = 1.0f; g.scale_dev = scale_dev; g.rscale = 0.0f; g.levels = 0.0f; g.res_codes = nullptr; g.ldrc = 0; g.relu = 0;
+    g.overflow = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    return Cout <= 64 ? d3_launch<1, 2, 1, 3, 3>(g, 3, s) : d3_launch<1, 4, 1, 2, 3>(g, 2, s);
 }
 
 // The same direct kernel for DoReFa int8 code planes with the code epilogue of qt_conv2d_implicit_codes: P and codes are

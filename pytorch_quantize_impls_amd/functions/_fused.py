@@ -541,7 +541,8 @@ def xnor_linear_digits(layer):
     version; None when alpha has a non-finite entry or K is beyond the exact range (the pair route then reproduces the NaN / inf
     the reference would produce)."""
     def build(w2):
-        if 127 * ops.code_ld_bytes(int(w2.shape[1])) >= (1 << 24):
+        ld = ops.code_ld_bytes(int(w2.shape[1]))
+        if 127 * ld >= (1 << 24) or int(w2.shape[0]) * ld >= (1 << 31):       # exact fp32 partial sums; 32-bit operand offsets
             return None
         _, alpha = ops.xnor_weight(w2.contiguous(), 1)
         dg = ops.alpha_digits(alpha.view(-1))

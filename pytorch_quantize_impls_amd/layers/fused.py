@@ -503,8 +503,9 @@ class FusedConvPoolBnSign(torch.nn.Module):
                                                           conv.padding, conv.dilation)):
                 # real-valued 3x3 / stride-1 / padding-1 first layer: direct kernel on the padded bf16-triple plane
                 N, C, H, W = (int(v) for v in x.shape)
-                px, _ = ops.s2d_triple_pack(x, 1, 1, terms=3)            # the direct kernel reads bf16 triple pixels
-                wtr = conv._conv_triples("plain", terms=3)
+                terms = ops.direct_first_layer_terms(C)               # fp16 pair pixels (two taps per MFMA), or exact bf16 triples
+                px, _ = ops.s2d_triple_pack(x, 1, 1, terms=terms)
+                wtr = conv._conv_triples("plain", terms=terms)
                 e2 = ops.NibEpilogue(epi[0], epi[1], (1, 1)) if (nib_out and not pooled) else epi
                 planes = ops.conv3x3_direct_nib(px, N, C, H, W, wtr, conv.bias, e2)
                 shape = (N, conv.out_channels, H, W)

@@ -1156,11 +1156,14 @@ def conv3x3_direct_nib(pixels, N: int, C: int, H: int, W: int, wplanes, bias, ep
     ``epi`` = (alpha, beta[, thr]) or the halo-1 NibPlanes of the next conv for a NibEpilogue.  ``pixels`` / ``wplanes``:
     NibPlanes (+-1 activations) or TriplePlanes (real-valued first layer, <= 5 channels)."""
     real = isinstance(pixels, TriplePlanes)
+    pairs = real and pixels.terms == 2
     if real:
-        Cw = triple_ld_bytes(C, 16) // 4
+        Cw = triple_ld_bytes(C, 16, pixels.terms) // 4
         words, ldw_words, Cout = pixels.data, wplanes.ld_words, wplanes.rows
-        if Cw != 8 or int(pixels.data.shape[1]) * 2 != Cw * 4 or ldw_words < 9 * Cw:
-            raise ValueError("direct first-layer conv expects 32-byte triple pixels (<= 5 channels)")
+        if Cw != (4 if pairs else 8) or int(pixels.data.shape[1]) * 2 != Cw * 4 or ldw_words < 9 * Cw or wplanes.terms != pixels.terms:
+            raise ValueError("direct first-layer conv expects 32-byte triple pixels (<= 5 channels) or 16-byte pair pixels (<= 4)")
+        if pairs and pixels.scale is None:
+            raise ValueError("fp16 pair planes carry their power-of-two scale")
         wwords = wplanes.data
     else:
         Cw = pixel_ld_nib(C)
@@ -1182,9 +1185,13 @@ def conv3x3_direct_nib(pixels, N: int, C: int, H: int, W: int, wplanes, bias, ep
         ldo = packed_ld(Cout)
         out = torch.empty((N * H * W, ldo), dtype=torch.int32, device=dev)
     with _on(dev):
-        _lib.call("qt_conv3x3_direct_nib", 2 if real else 0, _p(words), int(N), int(H), int(W), int(Cw), _p(wwords),
-                  int(ldw_words), _p(bias), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1,
-                  _stream(dev))
+        if pairs:
+            _lib.call("qt_conv3x3_direct_pairs", _p(words), int(N), int(H), int(W), _p(wwords), int(ldw_words), _p(bias),
+                      _p(pixels.scale[0:1]), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1, _stream(dev))
+        else:
+            _lib.call("qt_conv3x3_direct_nib", 2 if real else 0, _p(words), int(N), int(H), int(W), int(Cw), _p(wwords),
+                      int(ldw_words), _p(bias), _p(alpha), _p(beta), _p(out), int(ldo), int(Cout), 0 if nib_out else 1,
+                      _stream(dev))
     if nib_out:
         return NibPlanes(words=out, rows=int(out.shape[0]), K=Cout)
     return BitPlanes(sign=out, rows=N * H * W, K=Cout)
@@ -1231,6 +1238,12 @@ def conv3x3_direct_codes(pixels: CodePlanes, N: int, C: int, H: int, W: int, wpl
                   _p(flag), _stream(dev))
     return CodePlanes(codes=codes, rows=rows, K=Cout, inv_n=inv_levels(epi.bit_width), bit_width=int(epi.bit_width),
                       overflow=flag)
+
+
+def direct_first_layer_terms(Cin: int) -> int:
+    """Split of the image the direct 3x3 first-layer kernel runs with: fp16 pairs (16-byte pixels: <= 4 channels, the two lane halves
+    of an MFMA take two taps) when FLOAT_SPLIT allows two terms, else the exact bf16 triples (32-byte pixels: <= 5 channels)."""
+    return 2 if (split_terms(None) == 2 and int(Cin) <= 4) else 3
 
 
 def direct_first_layer_applicable(Cin: int, Cout: int, kernel_hw, stride, padding, dilation) -> bool:

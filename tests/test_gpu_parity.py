@@ -1404,12 +1404,13 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
     blk.out_nib_halo = (1, 1)
     x_exact = g(np.round(synth.normal(47, (N, Cin, H, W)) * 16) / 8, dev).contiguous(memory_format=torch.channels_last)
     x_gauss = g(synth.normal(48, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
-    # third form: the direct 3x3 kernel on the padded bf16-triple plane (what the fused stacks use by default)
+    # third form: the direct 3x3 kernel on the padded pair / triple plane (what the fused stacks use by default)
     monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", True)
     before = dict(_lib.call_counts)
     with torch.no_grad():
         direct = (blk(x_exact), blk(x_gauss))
-    assert _lib.call_counts["qt_conv3x3_direct_nib"] - before.get("qt_conv3x3_direct_nib", 0) == 2
+    ran = sum(_lib.call_counts.get(k, 0) - before.get(k, 0) for k in ("qt_conv3x3_direct_nib", "qt_conv3x3_direct_pairs"))
+    assert ran == 2          # (fp16 pair pixels by default since round 4: qt_conv3x3_direct_pairs; bf16 triples: _nib with elem = 2)
     monkeypatch.setattr(fused_mod, "DIRECT_FIRST_LAYER", False)
     outs = {}
     for flag in (True, False):

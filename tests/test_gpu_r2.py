@@ -298,20 +298,22 @@ def test_direct_first_layer_vs_oracle_chain(dev, oracle):
     bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
     bn.running_mean.copy_(g(synth.normal(34, (Cout,)), dev)); bn.running_var.copy_(g(synth.uniform(35, (Cout,), 2, 30), dev))
     bn.weight.data.copy_(g(synth.normal(36, (Cout,)), dev)); bn.bias.data.copy_(g(synth.normal(37, (Cout,)), dev))
-    blk = FusedConvPoolBnSign(conv, bn)
-    with torch.no_grad(), used("qt_conv3x3_direct_nib"):
-        act = blk(g(x, dev).contiguous(memory_format=torch.channels_last))
     alpha, beta = (n(t) for t in fold_batchnorm(bn))
     wq = oracle.ternarize(w)
-    got = _decode(act).numpy()
-    for img in (0, N - 1):
-        yconv = oracle.conv2d(x[img:img + 1], wq, n(conv.bias), 1, 1)[0].astype(np.float64)
-        v = yconv * alpha.astype(np.float64)[:, None, None] + beta.astype(np.float64)[:, None, None]
-        want = np.where(v < 0, -1.0, 1.0)
-        diff = got[img] != want
-        scale = np.abs(v).mean()
-        assert diff.mean() <= 1e-4, diff.mean()
-        assert np.all(np.abs(v[diff]) <= 1e-5 * scale), float(np.abs(v[diff]).max() / scale)   # ties only
+    # both splits of the image: fp16 pair pixels (the default since round 4: two taps per MFMA) and the exact bf16 triples
+    for mode, entry in (("f16x2", "qt_conv3x3_direct_pairs"), ("bf16x3", "qt_conv3x3_direct_nib")):
+        blk = FusedConvPoolBnSign(conv, bn)
+        with torch.no_grad(), ops.float_split(mode), used(entry):
+            act = blk(g(x, dev).contiguous(memory_format=torch.channels_last))
+        got = _decode(act).numpy()
+        for img in (0, N - 1):
+            yconv = oracle.conv2d(x[img:img + 1], wq, n(conv.bias), 1, 1)[0].astype(np.float64)
+            v = yconv * alpha.astype(np.float64)[:, None, None] + beta.astype(np.float64)[:, None, None]
+            want = np.where(v < 0, -1.0, 1.0)
+            diff = got[img] != want
+            scale = np.abs(v).mean()
+            assert diff.mean() <= 1e-4, (mode, diff.mean())
+            assert np.all(np.abs(v[diff]) <= 1e-5 * scale), (mode, float(np.abs(v[diff]).max() / scale))   # ties only
 
 
 # ---- fused networks, layer by layer at the configured image size ----------------------------------------------------
@@ -411,7 +413,7 @@ def test_c5_fused_vgg16_layerwise_at_224(dev):
                 h_cpu, h_gpu = y_cpu, blk(h_gpu)
         assert ci == len(cmods) and flips <= 4, flips
     used_ = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
-    assert used_.get("qt_conv3x3_direct_nib", 0) >= 3, used_        # conv1 (real input), conv2, conv3 take the direct kernel
+    assert used_.get("qt_conv3x3_direct_nib", 0) + used_.get("qt_conv3x3_direct_pairs", 0) >= 3, used_    # conv1 (real input), conv2, conv3 take the direct kernel
 
 
 def test_c3_fused_alexnet_layerwise(dev):
