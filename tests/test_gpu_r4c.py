@@ -398,3 +398,42 @@ def test_dorefa_8_and_32_bit_layers_vs_reference_fp64_vectors(dev, g20, all_shap
     assert norm_err(n(x.grad), g["gx"]) <= TOL
     assert norm_err(n(layer.weight.grad), g["gw"]) <= 2 * TOL
     assert norm_err(n(layer.bias.grad), g["gb"]) <= TOL
+
+
+# ---- seeded geometry fuzz of the direct first-layer kernel (K axis in 8-byte groups, odd k-step counts, LDS offset table) ------------------
+
+def test_first_layer_direct_conv_geometry_fuzz(dev):
+    """40 random strided few-channel geometries (kernel 2 .. 11, stride 2 .. 4, 1 .. 4 channels, ragged maps, both storage orders,
+    +-1 / 0 and real-valued weights, fp32 and threshold-bit epilogues) against the fp64 conv on the CPU: <= 1e-5 normalised; the
+    threshold bits equal the float formula on the fp32 route's own output."""
+    rng = np.random.default_rng(20260930)
+    done = 0
+    for _ in range(200):
+        C = int(rng.integers(1, 5)); s = int(rng.integers(2, 5)); k = int(rng.integers(s, 12)); p = int(rng.integers(0, 4))
+        H = int(rng.integers(k + 2, 60)); W = int(rng.integers(k + 2, 60)); N = int(rng.integers(1, 4)); Cout = int(rng.choice([5, 32, 40, 64, 96, 200]))
+        if not ops.first_direct_applicable(C, (k, k), s, p, 1) or (H + 2 * p - k) // s + 1 <= 0 or (W + 2 * p - k) // s + 1 <= 0:
+            continue
+        real = bool(rng.integers(0, 2))
+        x = torch.randn(N, C, H, W, device=dev) * float(rng.choice([0.01, 1.0, 300.0]))
+        if rng.integers(0, 2):
+            x = x.contiguous(memory_format=torch.channels_last)
+        w = torch.randint(-1, 2, (Cout, C, k, k), device=dev).float()
+        if real:
+            w = w * (0.02 + torch.rand(1, 1, k, k, device=dev))                  # sign(W) * alpha[tap]
+        b = torch.randn(Cout, device=dev)
+        fw = ops.pack_first_layer_weight(w, s, real=real)
+        y = ops.conv_first_direct(x, fw, b, s, p)
+        if y is None:
+            continue
+        ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), s, p)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        got = y.view(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+        assert norm_err(n(got), n(ref)) <= TOL, (C, s, k, p, H, W, Cout, real, norm_err(n(got), n(ref)))
+        al, be = torch.randn(Cout, device=dev), torch.randn(Cout, device=dev)
+        bits = ops.conv_first_direct(x, fw, b, s, p, epi=(al, be))
+        want = ops.sign_pack(((y * al + be)).contiguous())[0]                 # the float formula fl(fl(v * alpha) + beta) < 0 on the fp32 route
+        assert torch.equal(bits.sign[:, :want.sign.shape[1]], want.sign), (C, s, k, p, H, W, Cout, real)
+        done += 1
+        if done == 40:
+            break
+    assert done >= 25, done
