@@ -505,3 +505,23 @@ def test_linear_bn_sign_chain_runs_as_one_pass_and_equals_the_module_chain(dev, 
         z = seq[1](BinaryConnect()(x))
         assert torch.equal(z + 1.0, seq[1]._forward_impl(BinaryConnect()(x)) + 1.0)
         assert type(torch.relu(z)) is torch.Tensor
+
+
+def test_graph_capture_of_a_model_that_ends_in_a_quantised_linear(dev):
+    """The last layer's dense deferred activation is resolved inside the captured region (utils.graphed / utils.auto_graphed):
+    replays return the eager logits."""
+    from pytorch_quantize_impls_amd import utils
+    torch.manual_seed(3)
+    seq = nn.Sequential(BinaryConnect(), LinearBin(256, 128), nn.BatchNorm1d(128), nn.Hardtanh(), BinaryConnect(), LinearBin(128, 10)).to(dev)
+    seq[2].running_mean.normal_(0, 2.0)
+    seq.eval()
+    x = torch.randn(32, 256, device=dev)
+    with torch.no_grad():
+        with lazy.eager():
+            e = seq(x)
+        assert type(seq(x)) is lazy.LazyActivation
+        g = utils.graphed(seq, x)
+        assert type(g(x)) is torch.Tensor and torch.equal(g(x), e)
+        a = utils.auto_graphed(seq)
+        for _ in range(3):
+            assert torch.equal(a(x), e)
