@@ -42,9 +42,25 @@ def run(iters: int = 60, verbose: bool = True) -> dict:
     ximg = torch.randn(16, 3, 224, 224, device=dev)
     gimg = torch.randn(16, 192, 55, 55, device=dev).contiguous(memory_format=torch.channels_last)
 
-    cases = {"c2 binary mfma": lambda: c2("binary", "mfma"), "c2 ternary mfma": lambda: c2("ternary", "mfma"),
-             "c2 binary popcount": lambda: c2("binary", "valu"), "alexnet module graph": lambda: alex(xa),
-             "dorefa resnet18 module graph": lambda: res(xr),
+    # round 4: XNOR-Net AlexNet (per-tap conv, direct first layer with real-valued weights, digit-plane split-K int8 GEMM + head
+    # kernel) and the first blocks of the ternary VGG-16 (first layer on fp16 pair pixels)
+    from pytorch_quantize_impls_amd.layers import XNORConv2d, LinearXNOR
+    axn = bench_models.alexnet_xnor()
+    for mod in axn.modules():
+        if isinstance(mod, (XNORConv2d, LinearXNOR)):
+            mod.weight.data.normal_(0, 0.05)
+    bench_models.randomize_bn(axn, seed=7)
+    axn = axn.to(dev).to(memory_format=torch.channels_last).eval()
+    vgg = bench_models.TernaryVGG16(num_classes=100, image=64, fc=512)
+    bench_models.randomize_bn(vgg, seed=5)
+    vgg = vgg.to(dev).to(memory_format=torch.channels_last).eval()
+    vgg.features[0].binary_input = False
+    xv = torch.randn(32, 3, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+
+    cases = {"xnor alexnet module graph": lambda: axn(xa) * 1.0, "ternary vgg16 module graph": lambda: vgg(xv) * 1.0,
+             "c2 binary mfma": lambda: c2("binary", "mfma"), "c2 ternary mfma": lambda: c2("ternary", "mfma"),
+             "c2 binary popcount": lambda: c2("binary", "valu"), "alexnet module graph": lambda: alex(xa) * 1.0,
+             "dorefa resnet18 module graph": lambda: res(xr) * 1.0,
              "grad_W 3x3 128x64 tile": lambda: ops.conv2d_grad_weight_pm(wg[0][0], wg[0][1], (3, 3), 1),
              "grad_W 3x3 64x64 tile": lambda: ops.conv2d_grad_weight_pm(wg[1][0], wg[1][1], (3, 3), 1),
              "grad_W 5x5": lambda: ops.conv2d_grad_weight_pm(wg[2][0], wg[2][1], (5, 5), 2),
