@@ -405,8 +405,15 @@ class LazyActivation(torch.Tensor):
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
         name = getattr(func, "__name__", str(func))
-        if not (args and isinstance(args[0], LazyActivation) and args[0]._qt.value is not None):
-            STATS["fallback:" + name] += 1            # (a use of an already computed value — dense / constant nodes — forces nothing)
+        if args and isinstance(args[0], LazyActivation) and args[0]._qt.value is not None:
+            # a use of an already computed value (dense / constant nodes) forces nothing; the common shape — the activation first, no
+            # other deferred operand, not an in-place / out= form — skips the generic argument walk (log_softmax on the last layer)
+            if (not _writes_in_place(name) and "out" not in kwargs
+                    and not any(isinstance(a, LazyActivation) for a in args[1:])
+                    and not any(isinstance(v, LazyActivation) for v in kwargs.values())):
+                return func(args[0]._qt.value, *args[1:], **kwargs)
+        else:
+            STATS["fallback:" + name] += 1
         out_kw = kwargs.get("out")
         if isinstance(out_kw, LazyActivation):
             # func(..., out=deferred): the result replaces what the wrapper stood for — computed into a fresh tensor (the cached
