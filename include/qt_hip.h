@@ -127,7 +127,8 @@ int qt_shift_batch_f32(const float* x, int64_t ldx, const float* running_mean, c
 
 /* XNOR-Net weight quantiser over a row-major [R, C] view of the weight:
  * alpha[c] = mean_r |w[r,c]| ;  wq[r,c] = sign(w[r,c]) * alpha[c]  (torch.sign: 0 -> 0).  wq may be NULL
- * (alpha only).  XNORDense: R = N, C = K (functions/xnor_connect.py:112-113, global DIM = 0);
+ * (alpha only; with a separate wq buffer tall matrices use it as scratch for chunked partial sums).  XNORDense: R = N, C = K
+ * (functions/xnor_connect.py:112-113, global DIM = 0);
  * XNORConv2d(dim=[0,1]): R = Cout*Cin, C = kh*kw (functions/xnor_connect.py:140-141). */
 int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, float* wq, int64_t ldq, int64_t R,
                        int64_t C, qt_stream_t stream);

@@ -26,6 +26,33 @@ __global__ __launch_bounds__(256) void col_abs_mean_kernel(const float* __restri
     if (ty == 0 && c < C) alpha[c] = (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]) / (float)R;
 }
 
+// The same column sums for TALL matrices (XNORConv2d: R = Cout * Cin rows, C = kh * kw columns — one 64-column strip walked
+// 110 592 rows on ONE workgroup: 8.8 ms for AlexNet conv2): rows cut into chunks of 256, one workgroup per (strip, chunk) writes its
+// partial sums, a second launch adds the chunks of a column in ascending order (deterministic) and divides by R.  The partials
+// live in the caller's wq buffer (R * C floats, overwritten by sign_scale_kernel afterwards): no workspace argument.
+__global__ __launch_bounds__(256) void col_abs_part_kernel(const float* __restrict__ w, int64_t ldw, float* __restrict__ part, int64_t R,
+                                                           int64_t C, int64_t rows_per_chunk) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < R ? r0 + rows_per_chunk : R;
+    float acc = 0.0f;
+    if (c < C)
+        for (int64_t r = r0 + ty; r < r1; r += 4) acc += fabsf(w[r * ldw + c]);
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+}
+
+__global__ __launch_bounds__(256) void col_abs_final_kernel(const float* __restrict__ part, float* __restrict__ alpha, int64_t chunks,
+                                                            int64_t R, int64_t C) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.0f;
+    for (int64_t k = 0; k < chunks; ++k) acc += part[k * C + c];
+    alpha[c] = acc / (float)R;
+}
+
 __device__ __forceinline__ float torch_sign(float x) {
     return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : x);  // +-0 -> +-0, NaN -> NaN (times alpha stays NaN)
 }
@@ -234,8 +261,16 @@ extern "C" int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, flo
                                   int64_t R, int64_t C, qt_stream_t stream) {
     if (R <= 0 || C <= 0) return (R == 0 || C == 0) ? QT_OK : QT_ERR_INVALID_ARG;
     if (!w || !alpha || ldw < C || (wq && ldq < C)) return QT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(col_abs_mean_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, w, ldw, alpha, R, C);
+    const int64_t strips = (C + 63) / 64;
+    if (wq && wq != w && ldq == C && R >= 2048 && strips * 4 <= 256 && (R + 255) / 256 <= 65535) {
+        // tall and narrow: chunked partial sums through the wq buffer (see col_abs_part_kernel)
+        const int64_t chunks = (R + 255) / 256;
+        hipLaunchKernelGGL(col_abs_part_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, w, ldw, wq, R,
+                           C, (int64_t)256);
+        hipLaunchKernelGGL(col_abs_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wq, alpha, chunks, R, C);
+    } else {
+        hipLaunchKernelGGL(col_abs_mean_kernel, dim3((unsigned)strips), dim3(256), 0, (hipStream_t)stream, w, ldw, alpha, R, C);
+    }
     if (wq) {
         const int grid = qt_stream_grid((R * C + 1023) / 1024);
         hipLaunchKernelGGL(sign_scale_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, ldw, alpha,
