@@ -439,6 +439,13 @@ int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t 
                                   int64_t pool_k, int64_t pool_s, const float* alpha, const float* beta,
                                   uint32_t* sign_plane, int64_t ldp, int pre_relu, qt_stream_t stream);
 
+/* The same pass writing, beside the sign plane, the fp4 NIBBLE row plane the next layer's matrix-core GEMM consumes ([N*Ho*Wo][ldn
+ * words], +1 = 0x2, -1 = 0xA, features >= C zero; ldn >= 4 * ldp, % 4 == 0): the Linear -> BatchNorm1d -> Hardtanh -> BinaryConnect ->
+ * Linear chain of the classifiers (models/Alexnet/Alexnet_Bin.py:40-54) without a separate bits -> nibbles launch. */
+int qt_pool_affine_sign_pack_nib_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C, int64_t pool_k, int64_t pool_s,
+                                      const float* alpha, const float* beta, uint32_t* sign_plane, int64_t ldp, uint32_t* nib_plane,
+                                      int64_t ldn, int pre_relu, qt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Real-valued activation x quantised weight (first layer of every model, XNOR-Net layers, the general
  * case of LinearBin/LinearTer/BinConv2d/TerConv2d.forward: layers/binary_layers.py:44,105 with an

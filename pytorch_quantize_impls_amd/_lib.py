@@ -105,6 +105,8 @@ SIGNATURES = {
                             _c_i64, _c_i64, _c_p]),
     "qt_pool_affine_sign_pack_nhwc": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
                                                _c_p, _c_i64, _c_int, _c_p]),
+    "qt_pool_affine_sign_pack_nib_nhwc": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
+                                                   _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p]),
     "qt_bf16x3_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_bf16x3_s2d_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64] + [_c_i64] * 7 + [_c_p]),
     "qt_bf16x6_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),

@@ -22,10 +22,18 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t pas_spread8(uint32_t b) {      // the 8 bits of a byte to bit 0 of 8 nibbles
+    uint32_t t = b & 0xFFu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t;
+}
+
 __global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
     const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta,
     uint32_t* __restrict__ plane, int64_t ldp, int64_t N, int H, int W, int C, int pk, int ps, int Ho,
-    int Wo, int pre_relu) {
+    int Wo, int pre_relu, uint32_t* __restrict__ nibplane, int64_t ldn) {
     const int64_t slots_per_pixel = ldp * 8;  // float4 slots per output pixel incl. pad (pad -> bit 0)
     const int64_t total = N * Ho * Wo * slots_per_pixel;  // multiple of 32 (ldp % 4 == 0)
     const int c4max = C / 4;
@@ -62,7 +70,25 @@ __global__ __launch_bounds__(256) void pool_affine_sign_pack_kernel(
                   (qt_neg_bit(m.z * a.z + b.z) << 2) | (qt_neg_bit(m.w * a.w + b.w) << 3);
         }
         const uint32_t word = or_reduce8(nib << (4 * lane8));
-        if (lane8 == 0) plane[pix * ldp + (slot >> 3)] = word;
+        if (lane8 == 0) {
+            const int wi = slot >> 3;
+            plane[pix * ldp + wi] = word;
+            if (nibplane) {
+                // ... and the same signs as the fp4 operand row of the NEXT layer's matrix-core GEMM (+1 = 0x2, -1 = 0xA, features
+                // >= C = 0): the consumer's separate bits -> nibbles pass (one more launch per FC layer) is gone
+                const int left = C - wi * 32;
+                const uint32_t mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
+                uint4 o;
+                o.x = (pas_spread8(mw) << 1) | (pas_spread8(word) << 3);
+                o.y = (pas_spread8(mw >> 8) << 1) | (pas_spread8(word >> 8) << 3);
+                o.z = (pas_spread8(mw >> 16) << 1) | (pas_spread8(word >> 16) << 3);
+                o.w = (pas_spread8(mw >> 24) << 1) | (pas_spread8(word >> 24) << 3);
+                uint32_t* row = nibplane + pix * ldn;
+                *reinterpret_cast<uint4*>(row + wi * 4) = o;
+                if (wi == ldp - 1)                                  // the row's tail past the bit plane's words
+                    for (int64_t t = ldp * 4; t < ldn; t += 4) *reinterpret_cast<uint4*>(row + t) = make_uint4(0, 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -236,11 +262,11 @@ extern "C" int qt_pool_bits(const uint32_t* in_plane, int64_t N, int64_t H, int6
     return qt_check_launch();
 }
 
-extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
-                                             int64_t pool_k, int64_t pool_s, const float* alpha,
-                                             const float* beta, uint32_t* sign_plane, int64_t ldp,
-                                             int pre_relu, qt_stream_t stream) {
+static int pool_affine_sign_pack_impl(const float* x, int64_t N, int64_t H, int64_t W, int64_t C, int64_t pool_k, int64_t pool_s,
+                                      const float* alpha, const float* beta, uint32_t* sign_plane, int64_t ldp, uint32_t* nib_plane,
+                                      int64_t ldn, int pre_relu, qt_stream_t stream) {
     if (N < 0 || H <= 0 || W <= 0 || C <= 0 || pool_k < 1 || pool_s < 1) return QT_ERR_INVALID_ARG;
+    if (nib_plane && (ldn < 4 * ldp || (ldn & 3) || !qt_aligned16(nib_plane))) return QT_ERR_ALIGNMENT;
     if (pool_k > H || pool_k > W) return QT_ERR_INVALID_ARG;
     if (N == 0) return QT_OK;
     if (!x || !alpha || !beta || !sign_plane) return QT_ERR_INVALID_ARG;
@@ -253,6 +279,20 @@ extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t 
     const int grid = qt_stream_grid((total + 255) / 256);
     hipLaunchKernelGGL(pool_affine_sign_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, alpha,
                        beta, sign_plane, ldp, N, (int)H, (int)W, (int)C, (int)pool_k, (int)pool_s, (int)Ho,
-                       (int)Wo, pre_relu ? 1 : 0);
+                       (int)Wo, pre_relu ? 1 : 0, nib_plane, ldn);
     return qt_check_launch();
+}
+
+extern "C" int qt_pool_affine_sign_pack_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C,
+                                             int64_t pool_k, int64_t pool_s, const float* alpha,
+                                             const float* beta, uint32_t* sign_plane, int64_t ldp,
+                                             int pre_relu, qt_stream_t stream) {
+    return pool_affine_sign_pack_impl(x, N, H, W, C, pool_k, pool_s, alpha, beta, sign_plane, ldp, nullptr, 0, pre_relu, stream);
+}
+
+extern "C" int qt_pool_affine_sign_pack_nib_nhwc(const float* x, int64_t N, int64_t H, int64_t W, int64_t C, int64_t pool_k,
+                                                 int64_t pool_s, const float* alpha, const float* beta, uint32_t* sign_plane,
+                                                 int64_t ldp, uint32_t* nib_plane, int64_t ldn, int pre_relu, qt_stream_t stream) {
+    if (!nib_plane) return QT_ERR_INVALID_ARG;
+    return pool_affine_sign_pack_impl(x, N, H, W, C, pool_k, pool_s, alpha, beta, sign_plane, ldp, nib_plane, ldn, pre_relu, stream);
 }

@@ -226,8 +226,10 @@ class FusedPoolBnSign(torch.nn.Module):
             else:
                 like = (tuple(x.shape), False)
         alpha, beta = _folded_for(self, "_folded", self.bn, x.device, self.fold, like)
-        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, alpha, beta, self.pool_k, self.pool_s,
-                                                     pre_relu=self.pre_relu)
+        # rows of a classifier (2-D): the next quantised Linear takes them on the matrix cores from batch 33 on (ops.select_gemm_impl)
+        # — its fp4 nibble operand comes out of this same launch
+        planes, (Ho, Wo) = ops.pool_affine_sign_pack(x, alpha, beta, self.pool_k, self.pool_s, pre_relu=self.pre_relu,
+                                                     want_nib=x.dim() == 2 and x.shape[0] > 32)
         if x.dim() == 2:
             return packed.PackedActivation(planes, (x.shape[0], x.shape[1]))
         act = packed.PackedActivation(planes, (x.shape[0], x.shape[1], Ho, Wo))

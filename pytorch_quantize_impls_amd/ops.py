@@ -266,6 +266,8 @@ class BitPlanes:
     rows: int
     K: int
     mask: Optional[torch.Tensor] = None
+    #: the same rows as the matrix-core GEMM's fp4 nibble operand, when the producer wrote it in the same pass (NibPlanes)
+    nib: Optional[object] = None
 
     @property
     def ld(self) -> int:
@@ -497,10 +499,11 @@ def ternary_pack(x: torch.Tensor) -> BitPlanes:
 
 
 def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor, pool_k: int = 1,
-                          pool_s: int = 1, pre_relu: bool = False):
+                          pool_s: int = 1, pre_relu: bool = False, want_nib: bool = False):
     """Fused [MaxPool2d(pool_k, pool_s)] -> eval-BatchNorm (x*alpha+beta) -> Hardtanh -> sign -> bit-pack.
     x: [N, C, H, W] fp32 (channels_last storage is used as-is, NCHW storage is transposed once) or
-    [N, C].  Returns (BitPlanes with rows = N*Ho*Wo, K = C; (Ho, Wo))."""
+    [N, C].  Returns (BitPlanes with rows = N*Ho*Wo, K = C; (Ho, Wo)).  ``want_nib``: the planes also carry the fp4 nibble rows
+    of the same signs (``.nib``), written by the same launch — what the next layer's matrix-core GEMM consumes."""
     _require(x, "input")
     if x.dim() == 2:
         N, C = (int(v) for v in x.shape)
@@ -519,11 +522,19 @@ def pool_affine_sign_pack(x: torch.Tensor, alpha: torch.Tensor, beta: torch.Tens
     alpha = _require(alpha, "alpha").contiguous()
     beta = _require(beta, "beta").contiguous()
     I = int
+    nib = None
     with _on(x.device):
-        _lib.call("qt_pool_affine_sign_pack_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)),
-                  I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), int(1 if pre_relu else 0),
-                  _stream(x.device))
-    return BitPlanes(sign=plane, rows=N * Ho * Wo, K=C), (Ho, Wo)
+        if want_nib:
+            ldn = packed_ld_nib(C)
+            words = torch.empty((N * Ho * Wo, ldn), dtype=torch.int32, device=x.device)
+            _lib.call("qt_pool_affine_sign_pack_nib_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)), I(int(pool_s)),
+                      _p(alpha), _p(beta), _p(plane), I(ld), _p(words), I(ldn), int(1 if pre_relu else 0), _stream(x.device))
+            nib = NibPlanes(words=words, rows=N * Ho * Wo, K=C)
+        else:
+            _lib.call("qt_pool_affine_sign_pack_nhwc", _p(nhwc), I(N), I(H), I(W), I(C), I(int(pool_k)),
+                      I(int(pool_s)), _p(alpha), _p(beta), _p(plane), I(ld), int(1 if pre_relu else 0),
+                      _stream(x.device))
+    return BitPlanes(sign=plane, rows=N * Ho * Wo, K=C, nib=nib), (Ho, Wo)
 
 
 def check_pm1(x: torch.Tensor, limit: Optional[int] = None) -> torch.Tensor:
@@ -2814,6 +2825,8 @@ def to_impl(planes, impl: str):
         raise TypeError("nibble planes cannot feed the popcount GEMM")
     if isinstance(planes, NibPlanes):
         return planes
+    if getattr(planes, "nib", None) is not None:      # written by the producer's own pass (pool_affine_sign_pack(want_nib=True))
+        return planes.nib
     return bits_to_nib(planes)
 
 

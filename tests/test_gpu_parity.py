@@ -1955,7 +1955,7 @@ def test_fused_relu_bn_sign_mlp_pattern(dev):
     fused = fuse_sequential(seq)
     assert isinstance(fused[1], FusedPoolBnSign) and fused[1].pre_relu and len(fused) == 3
     x = torch.randn((64, 200), device=dev).sign()
-    with torch.no_grad(), used("qt_pool_affine_sign_pack_nhwc"):
+    with torch.no_grad(), used("qt_pool_affine_sign_pack_nib_nhwc"):         # (batch 64: the pass also writes the next GEMM's nibble rows)
         yf = fused(x)
         h = seq[0](x)
         act = fused[1](h)

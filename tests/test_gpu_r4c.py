@@ -437,3 +437,19 @@ def test_first_layer_direct_conv_geometry_fuzz(dev):
         if done == 40:
             break
     assert done >= 25, done
+
+
+# ---- BatchNorm / sign / pack pass that also writes the next GEMM's nibble rows ---------------------------------------------------------
+
+@pytest.mark.parametrize("rows,C", [(256, 4096), (64, 36), (33, 100), (40, 256), (7, 1000)])
+def test_pool_affine_sign_pack_nib_rows_equal_the_separate_expansion(dev, rows, C):
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device=dev)
+    al, be = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    plain, _ = ops.pool_affine_sign_pack(x, al, be)
+    both, _ = ops.pool_affine_sign_pack(x, al, be, want_nib=True)
+    assert plain.nib is None and both.nib is not None
+    assert torch.equal(plain.sign, both.sign)
+    want = ops.bits_to_nib(plain)
+    assert both.nib.words.shape == want.words.shape and torch.equal(both.nib.words, want.words)
+    assert ops.to_impl(both, "mfma") is both.nib
