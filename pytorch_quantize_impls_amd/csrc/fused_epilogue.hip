@@ -11,6 +11,7 @@
 // Layout: x is NHWC fp32 [N][H][W][C] (C % 4 == 0), out is the NHWC pixel bit plane [N*Ho*Wo][ldp].
 // One work item = 4 consecutive channels of one output pixel; 8 adjacent lanes = one 32-channel word.
 // HBM-bound: algorithmic bytes = 4*N*H*W*C (read) + N*Ho*Wo*C/8 (write).
+#include <algorithm>
 #include "qt_common.h"
 
 namespace {
@@ -171,6 +172,61 @@ __global__ __launch_bounds__(256) void pool_bits_nib_kernel(const uint32_t* __re
     }
 }
 
+// The same with 16-byte accesses: one thread = FOUR words (128 channels) of one output pixel — a window tap is one dwordx4 load
+// instead of four dword loads scattered over four lanes, the four nibble groups are four dwordx4 stores (AlexNet's two pools
+// between the convs: 15 -> ~9 us each).  Needs 16-byte aligned bit rows (ld % 4 == 0, aligned base): the entry point checks.
+__global__ __launch_bounds__(256) void pool_bits_nib_vec_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                const uint32_t* __restrict__ neg_alpha, int64_t ld, int64_t ldn,
+                                                                int64_t N, int H, int W, int pk, int ps, int Ho, int Wo, int hy, int hx,
+                                                                int C) {
+    // grid: x over (output column, word group) of one output row, y over the N * (Ho + 2 hy) output rows (walked with a stride
+    // when they exceed the grid): 32-bit index arithmetic only — the 64-bit divisions of a flat index cost more than the loads
+    const unsigned g4 = (unsigned)(ld / 4);
+    const int Hop = Ho + 2 * hy, Wop = Wo + 2 * hx;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (unsigned)Wop * g4) return;
+    const unsigned wop = t / g4;
+    const int q = (int)(t - wop * g4);
+    if ((int64_t)q * 16 >= ldn) return;                            // bit-plane pad words past the nibble row
+    const int wo = (int)wop - hx;
+    const int64_t nrows = N * Hop;
+    for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const int64_t n = row / Hop;
+        const int ho = (int)(row - n * Hop) - hy;
+        const int64_t pix = row * Wop + wop;
+        const bool inside = (unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo;
+        uint4 all = make_uint4(~0u, ~0u, ~0u, ~0u), any = make_uint4(0, 0, 0, 0);
+        if (inside) {
+            const uint32_t* base = in + ((n * H + (int64_t)ho * ps) * W + (int64_t)wo * ps) * ld + q * 4;
+            for (int a = 0; a < pk; ++a)
+                for (int b = 0; b < pk; ++b) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(base + ((int64_t)a * W + b) * ld);
+                    all.x &= v.x; all.y &= v.y; all.z &= v.z; all.w &= v.w;
+                    any.x |= v.x; any.y |= v.y; any.z |= v.z; any.w |= v.w;
+                }
+        }
+        const uint4 na = *reinterpret_cast<const uint4*>(neg_alpha + q * 4);
+        const uint32_t al[4] = {all.x, all.y, all.z, all.w}, an[4] = {any.x, any.y, any.z, any.w}, nv[4] = {na.x, na.y, na.z, na.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int w = q * 4 + e;
+            if ((int64_t)w * 4 >= ldn) break;
+            uint32_t sw = 0, mw = 0;
+            if (inside) {
+                const int left = C - w * 32;
+                mw = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? ((1u << left) - 1u) : 0u);
+                sw = ((al[e] & ~nv[e]) | (an[e] & nv[e])) & mw;
+            }
+            uint4 o;
+            o.x = (fe_spread8(mw) << 1) | (fe_spread8(sw) << 3);
+            o.y = (fe_spread8(mw >> 8) << 1) | (fe_spread8(sw >> 8) << 3);
+            o.z = (fe_spread8(mw >> 16) << 1) | (fe_spread8(sw >> 16) << 3);
+            o.w = (fe_spread8(mw >> 24) << 1) | (fe_spread8(sw >> 24) << 3);
+            *reinterpret_cast<uint4*>(out + pix * ldn + w * 4) = o;
+        }
+    }
+}
+
 // MaxPool2d(k, s) on an int8 DoReFa code plane (the reference pools AFTER the quantiser,
 // models/samples/AlexNet_Dorefa.py:38-41: x = quant(relu(bn(conv))); x = pool(x)).  value = fl(inv_n * code) is
 // monotone in the code, so the max of the codes IS the code of the max: bit-identical to pooling the fp32 image.
@@ -220,6 +276,15 @@ extern "C" int qt_pool_bits_nib(const uint32_t* in_plane, int64_t N, int64_t H, 
     if ((ld & 3) || (ldn & 3) || !qt_aligned16(nib_plane)) return QT_ERR_ALIGNMENT;
     if (H > 32767 || W > 32767 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_UNSUPPORTED;
     const int64_t Ho = (H - pool_k) / pool_s + 1, Wo = (W - pool_k) / pool_s + 1;
+    if (qt_aligned16(in_plane) && qt_aligned16(neg_alpha) && ldn <= 4 * ld) {     // (ldn <= 4 ld: every nibble group has its bit word)
+        const int64_t rows_out = N * (Ho + 2 * out_halo_h);
+        const int64_t per_row = (Wo + 2 * out_halo_w) * (ld / 4);
+        const unsigned bs = per_row <= 64 ? 64u : (per_row <= 128 ? 128u : 256u);          // a row of a small map fills one wave
+        const dim3 gridv((unsigned)((per_row + bs - 1) / bs), (unsigned)std::min<int64_t>(rows_out, 65535));
+        hipLaunchKernelGGL(pool_bits_nib_vec_kernel, gridv, dim3(bs), 0, (hipStream_t)stream, in_plane, nib_plane, neg_alpha, ld,
+                           ldn, N, (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo, (int)out_halo_h, (int)out_halo_w, (int)C);
+        return qt_check_launch();
+    }
     const int grid = qt_stream_grid((N * (Ho + 2 * out_halo_h) * (Wo + 2 * out_halo_w) * (ldn / 4) + 255) / 256);
     hipLaunchKernelGGL(pool_bits_nib_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in_plane, nib_plane,
                        neg_alpha, ld, ldn, N, (int)H, (int)W, (int)pool_k, (int)pool_s, (int)Ho, (int)Wo,
