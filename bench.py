@@ -208,7 +208,7 @@ def main():
     timing = {"kernel_ms": burst_ms,
               "kernel_ms_what": f"{BURST} launches back to back behind the pack kernel, one HIP-event pair around the burst, the "
                                 "cost of an empty event pair subtracted; agrees with the rocprofv3 --kernel-trace --stats average "
-                                "of this command (profiles/r4c_bench_rocprof.md: 36.9 us) to ~1 us; `achieved` and `frac` use THIS figure",
+                                "of this command (profiles/r4c_bench_rocprof.md: 35.8 us) to ~1 us; `achieved` and `frac` use THIS figure",
               "kernel_ms_in_step_bracket": gemm_ms,
               "kernel_ms_in_step_bracket_what": f"HIP-event pair around the single launch on every {EVENT_EVERY}th step of the timed "
                                                 "region; includes the marker packets / kernel boundary (~3-5 us)",
