@@ -1466,7 +1466,10 @@ class AlphaDigits:
 
 def alpha_digits(alpha: torch.Tensor) -> Optional[AlphaDigits]:
     """The digit table of a scale row, or None when alpha has a non-finite entry (one host sync; once per weight version)."""
-    a = _require(alpha.detach(), "alpha").contiguous().view(-1)
+    a = alpha.detach()                               # (plain tensor arithmetic on K values: any device)
+    if a.dtype != torch.float32:
+        raise TypeError(f"alpha: expected dtype torch.float32, got {a.dtype}")
+    a = a.contiguous().view(-1)
     mx = a.amax() if a.numel() else a.new_zeros(())
     _, e = torch.frexp(mx)                                   # max < 2^e
     s = torch.ldexp(torch.ones_like(mx), e - 21)             # max / s < 2^21
