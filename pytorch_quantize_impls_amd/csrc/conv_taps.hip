@@ -84,12 +84,14 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
                   float* Y, int64_t ldy, int64_t M, int64_t Cout, int64_t K, int64_t kwords, bool valid, qt_stream_t stream,
                   const ConvArgs& cg, const EpiArgs& epi) {
 #define QT_TAPS(...) return launch_cfg<__VA_ARGS__>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi)
-    // Tile widths: the in-place multiply needs the accumulators in VALU-addressable registers next to the fragments, so the
-    // 144- / 128-register wave tiles of the un-scaled conv (384x192, 256x256) would spill; widest here: 256x192 (96 registers).
-    int tn = 192;
+    // Tile widths: the in-place multiply needs the accumulators in VALU-addressable registers next to the fragments (a wave of an
+    // 8-wave workgroup owns 256 registers, arch + acc together).  256x256 (128 accumulator registers) fits its MAIN LOOP in them —
+    // the ~80 spilled dwords are prologue / epilogue values — and is what Cout = 768 / 256 want (AlexNet conv4: 163 -> 137 us,
+    // conv5: 60 -> 41 us against 256x192 / 256x128 tiles); the 144-register 384x192 tile of the un-scaled conv does not.
+    int tn = 256;
     {
-        int64_t best = (Cout + 191) / 192 * 192;
-        for (int c : {128, 64})
+        int64_t best = (Cout + 255) / 256 * 256;
+        for (int c : {192, 128, 64})
             if ((Cout + c - 1) / c * c < best) { tn = c; best = (Cout + c - 1) / c * c; }
     }
     const int64_t tiles = ((M + 255) / 256) * ((Cout + tn - 1) / tn);
@@ -101,6 +103,7 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
             if (((M + 127) / 128) * ((Cout + 63) / 64) >= 200) QT_TAPS(ConvV128x64<E>);
             QT_TAPS(ConvVSkinny<E>);
         }
+        if (tn == 256) QT_TAPS(ConvVPP256<E>);
         if (tn == 192) QT_TAPS(ConvVPP256x192<E>);
         if (tn == 128) QT_TAPS(ConvVPP128<E>);
         QT_TAPS(ConvV64<E>);
@@ -109,6 +112,7 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
         if (((M + 127) / 128) * ((Cout + 127) / 128) < 200 && long_k) QT_TAPS(ConvSkinny<E>);
         QT_TAPS(Conv128x128<E>);
     }
+    if (tn == 256) QT_TAPS(ConvPP256<E>);
     if (tn == 192) QT_TAPS(ConvPP256x192<E>);
     if (tn == 128) QT_TAPS(ConvPP128<E>);
     QT_TAPS(Conv64<E>);

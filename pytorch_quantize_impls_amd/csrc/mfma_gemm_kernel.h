@@ -347,7 +347,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // one MFMA k-step of the wave tile; at a tap boundary (E::TAPS) the accumulators are scaled first, in place.  (Interleaving
     // the packed multiplies of tile i + 1 with the MFMA of tile i — sched_group_barrier — was measured equal, AlexNet conv2 338 vs
     // 335 us, and makes the compiler alternate between two accumulator register sets: 253 VGPRs instead of 208.)
-    auto k_step = [&](uint4 (&xf)[C::TMW], uint4 (&wf)[C::TNW]) {
+    // tap_boundary() = the bookkeeping in front of ONE k-step; k_step() = boundary + MFMAs.  The ping-pong loop calls the two
+    // separately: the boundary in front of a stage's FIRST k-step is processed in the wave's LOAD segment (its accumulators are
+    // idle there and the matrix pipe belongs to its SIMD partner), only a boundary between the two k-steps of a stage sits in the
+    // compute segment.
+    auto tap_boundary = [&]() {
         if constexpr (E::TAPS) {
             if (tap_left == 0) {
 #pragma unroll
@@ -360,6 +364,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             }
             --tap_left;
         }
+    };
+    auto k_step = [&](uint4 (&xf)[C::TMW], uint4 (&wf)[C::TNW]) {
+        tap_boundary();
         mfma_step(xf, wf);
     };
 
@@ -540,8 +547,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     m0_restore(m0_keep);
                     if constexpr (C::VALID) tap_next = tap_table[min(s + 1 + AHEAD, nstages - 1) * CH + lchunk];
                     if constexpr (C::ABL == 5 && issue) dbg_ts[2] = stamp_now();
+                    tap_boundary();
                     asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(tap_next) : "n"(2 * NP) : "memory");
                 } else {
+                    tap_boundary();
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
                 if constexpr (C::ABL == 5 && issue) dbg_ts[3] = stamp_now();
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (C::ABL == 5 && issue) dbg_ts[4] = stamp_now();
-                k_step(xf0, wf0);
+                mfma_step(xf0, wf0);              // its boundary: processed in the load segment above
                 k_step(xf1, wf1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (C::ABL == 5 && issue) dbg_ts[5] = stamp_now();
