@@ -193,16 +193,19 @@ __global__ __launch_bounds__(256) void xnor_head_kernel(const uint32_t* __restri
                                                         const uint32_t* __restrict__ wc, int64_t ldw_words, const float* __restrict__ scale,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t rows,
                                                         int64_t N, int64_t K, int64_t perm_C, int64_t perm_HW) {
+    // workgroup = (one row, 8 outputs): its 4 waves stride the feature groups together (a wave per row walked K in 16 dependent
+    // round trips on half the CUs: 20.8 us at AlexNet's head; this form: 4 trips on all of them)
+    __shared__ double part[4][8];
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r = blockIdx.x;
     const int n0 = blockIdx.y * 8;
-    if (r >= rows) return;
     const int64_t kq = (K + 3) / 4;                  // groups of 4 features (table / weight rows are zero past K)
     int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t* wrow[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wrow[j] = wc + (int64_t)min((int64_t)(n0 + j), N - 1) * ldw_words;
-    for (int64_t q = lane; q < kq; q += 64) {
+#pragma unroll 2
+    for (int64_t q = threadIdx.x; q < kq; q += 256) {
         const int64_t k0 = q * 4;
         const uint4 t4 = dtab4[q];
         uint32_t nib = 0u;
@@ -238,7 +241,13 @@ __global__ __launch_bounds__(256) void xnor_head_kernel(const uint32_t* __restri
         double v = (double)acc[j];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0 && n0 + j < N) Y[r * ldy + n0 + j] = (float)(v * s) + (bias ? bias[n0 + j] : 0.0f);
+        if (lane == 0) part[threadIdx.x >> 6][j] = v;           // integers below 2^53: any summation order gives the same double
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && n0 + threadIdx.x < N) {
+        const int j = threadIdx.x;
+        const double v = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        Y[r * ldy + n0 + j] = (float)(v * s) + (bias ? bias[n0 + j] : 0.0f);
     }
 }
 
@@ -310,7 +319,7 @@ extern "C" int qt_xnor_head_i8(const uint32_t* bits, int64_t ldb, const uint32_t
     if (!bits || !digit_table || !wcodes || !scale_dev || !Y || ldb < (K + 31) / 32) return QT_ERR_INVALID_ARG;
     if ((ldw_bytes & 15) || ldw_bytes < (K + 3) / 4 * 4 || !qt_aligned16(wcodes) || !qt_aligned16(digit_table)) return QT_ERR_ALIGNMENT;
     if (K >= (1ll << 16) || N > 65535 * 8) return QT_ERR_UNSUPPORTED;                  // lane partial < 2^21 * K / 64 < 2^31
-    hipLaunchKernelGGL(xnor_head_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)((N + 7) / 8)), dim3(256), 0, (hipStream_t)stream, bits,
+    hipLaunchKernelGGL(xnor_head_kernel, dim3((unsigned)rows, (unsigned)((N + 7) / 8)), dim3(256), 0, (hipStream_t)stream, bits,
                        ldb, reinterpret_cast<const uint4*>(digit_table), reinterpret_cast<const uint32_t*>(wcodes), ldw_bytes / 4, scale_dev,
                        bias, Y, ldy, rows, N, K, perm_C, perm_HW);
     return qt_check_launch();
