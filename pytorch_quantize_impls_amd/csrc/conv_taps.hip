@@ -104,6 +104,7 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
             QT_TAPS(ConvVSkinny<E>);
         }
         if (tn == 256) QT_TAPS(ConvVPP256<E>);
+        if (tn == 192 && prefer_384_rows(M, Cout)) QT_TAPS(ConvVPP192<E>);
         if (tn == 192) QT_TAPS(ConvVPP256x192<E>);
         if (tn == 128) QT_TAPS(ConvVPP128<E>);
         QT_TAPS(ConvV64<E>);
@@ -113,6 +114,7 @@ int dispatch_taps(const uint32_t* P, const uint32_t* Wmat, int64_t ldwp, const f
         QT_TAPS(Conv128x128<E>);
     }
     if (tn == 256) QT_TAPS(ConvPP256<E>);
+    if (tn == 192 && prefer_384_rows(M, Cout)) QT_TAPS(ConvPP192<E>);
     if (tn == 192) QT_TAPS(ConvPP256x192<E>);
     if (tn == 128) QT_TAPS(ConvPP128<E>);
     QT_TAPS(Conv64<E>);
