@@ -208,7 +208,7 @@ def main():
     timing = {"kernel_ms": burst_ms,
               "kernel_ms_what": f"{BURST} launches back to back behind the pack kernel, one HIP-event pair around the burst, the "
                                 "cost of an empty event pair subtracted; agrees with the rocprofv3 --kernel-trace --stats average "
-                                "of this command (profiles/r4c_bench_rocprof.md: 35.8 us) to ~1 us; `achieved` and `frac` use THIS figure",
+                                "of this command (profiles/r4d_bench_rocprof.md: 36.9 us) to ~1.5 us; `achieved` and `frac` use THIS figure",
               "kernel_ms_in_step_bracket": gemm_ms,
               "kernel_ms_in_step_bracket_what": f"HIP-event pair around the single launch on every {EVENT_EVERY}th step of the timed "
                                                 "region; includes the marker packets / kernel boundary (~3-5 us)",
@@ -645,7 +645,7 @@ def alexnet_roofline(model, fused, x, B):
             "bound": "mfma", "dominant_block": dom["block"], "achieved": dom["achieved_TFLOPs"], "peak": dom["peak_TFLOPs"],
             "unit": "TFLOP/s", "frac": dom["frac"], "dominant_block_ms": dom["ms"], "sum_of_blocks_ms": total,
             "matrix_floor_ms": floor_ms, "blocks": rows,
-            "kernel_names": "profiles/r4c_bench_kernel_stats.csv lists the kernels of each block (conv1: conv_first_direct_kernel<real weights?, "
+            "kernel_names": "profiles/r4d_bench_kernel_stats.csv lists the kernels of each block (conv1: conv_first_direct_kernel<real weights?, "
                             "threshold bits, 18> + pool_bits_kernel; conv2-5: mfma_gemm_kernel<ElemFp4 conv-valid, bits epilogue> (XNOR flavour: "
                             "<ElemFp4Taps>) [+ pool_bits_kernel]; fc: mfma_gemm_kernel<ElemFp4 skinny> (XNOR flavour: bits_alpha_digits_kernel + mfma_gemm_kernel<ElemI8, 256x256, split-K> + digit_reduce_kernel; 10-way head: xnor_head_kernel))"}
 
