@@ -453,3 +453,34 @@ def test_pool_affine_sign_pack_nib_rows_equal_the_separate_expansion(dev, rows, 
     want = ops.bits_to_nib(plain)
     assert both.nib.words.shape == want.words.shape and torch.equal(both.nib.words, want.words)
     assert ops.to_impl(both, "mfma") is both.nib
+
+
+# ---- per-tap scaled conv on the un-scaled conv's wide tiles (end of round 4: csrc/conv_taps.hip dispatch_taps) -----------------------
+
+@pytest.mark.parametrize("Cin,Cout,H,k,p,B,tile", [
+    (64, 256, 30, 3, 1, 64, "256x256"),        # M = 57 600: 225 tiles -> ConvPP256 / ConvVPP256
+    (128, 768, 13, 3, 1, 256, "256x256"),      # AlexNet conv4's widths (two k-steps per tap)
+    (64, 576, 27, 5, 2, 128, "384x192"),       # M = 93 312: the 384-row tile's rounds pay (prefer_384_rows)
+    (192, 576, 14, 3, 1, 96, "256x192"),       # three k-steps per tap: boundaries alternate between stage start and mid-stage
+])
+def test_xnor_taps_conv_on_the_wide_tiles_vs_fp64(dev, Cin, Cout, H, k, p, B, tile):
+    """XNORConv2d's integer-per-tap core (functions/xnor_connect.py:140-159: alpha = mean(|W|, [0, 1]) per tap) at sizes that take the
+    256x256 / 384x192 / 256x192 ping-pong tiles, padded and on the physically padded plane (un-padded kernels): the two executions
+    are bit-identical, and <= 1e-5 normalised against the fp64 evaluation of conv2d(x, sign(W) * alpha)."""
+    from pytorch_quantize_impls_amd import ops
+    g = torch.Generator(device=dev).manual_seed(Cin + Cout + k)
+    x = torch.randn((B, Cin, H, H), device=dev, generator=g).sign_().contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g) * 0.05
+    px = ops.pack_pixels_nib(x, ld=ops.pixel_ld_nib_taps(Cin))
+    ws = ops.pack_conv_weight_nib(w, "sign", cw=px.ld)
+    ts = ops.xnor_tap_prep(w)
+    y0 = ops.conv2d_nib_taps(px, (B, Cin, H, H), ws, (k, k), ts.fwd, None, 1, p, 1)
+    xp = torch.nn.functional.pad(x, (p, p, p, p)).contiguous(memory_format=torch.channels_last)
+    pxp = ops.pack_pixels_nib(xp, ld=ops.pixel_ld_nib_taps(Cin))
+    v = pxp.words.view(B, H + 2 * p, H + 2 * p, -1)
+    v[:, :p] = 0; v[:, -p:] = 0; v[:, :, :p] = 0; v[:, :, -p:] = 0          # padding pixels are fp4 zeros, not +1
+    y1 = ops.conv2d_nib_taps(pxp, (B, Cin, H + 2 * p, H + 2 * p), ws, (k, k), ts.fwd, None, 1, 0, 1)
+    assert torch.equal(y0, y1), tile
+    alpha = w.double().abs().mean(dim=(0, 1))
+    ref = torch.nn.functional.conv2d(x.double(), torch.sign(w).double() * alpha[None, None], None, 1, p)
+    assert norm_err(n(y0), n(ref.permute(0, 2, 3, 1).reshape(-1, Cout))) <= TOL, tile          # the kernel's result is NHWC rows
