@@ -484,3 +484,32 @@ def test_xnor_taps_conv_on_the_wide_tiles_vs_fp64(dev, Cin, Cout, H, k, p, B, ti
     alpha = w.double().abs().mean(dim=(0, 1))
     ref = torch.nn.functional.conv2d(x.double(), torch.sign(w).double() * alpha[None, None], None, 1, p)
     assert norm_err(n(y0), n(ref.permute(0, 2, 3, 1).reshape(-1, Cout))) <= TOL, tile          # the kernel's result is NHWC rows
+
+
+@pytest.mark.parametrize("Cin,Cout,H,k,p,B", [(64, 256, 30, 3, 1, 64), (128, 768, 13, 3, 1, 256), (64, 576, 27, 5, 2, 128)])
+def test_xnor_taps_conv_wide_tile_epilogues_equal_the_float_predicate(dev, Cin, Cout, H, k, p, B):
+    """The threshold-bit and nibble-plane epilogues of the wide tiles (their epilogue code is where the compiler's spills sit):
+    bit = [(y + b) * alpha + beta < 0] evaluated on the fp32 result of the same conv, word for word; the nibble plane is the bit
+    plane expanded (qt_bits_to_nib_pad) with its zero halo."""
+    from pytorch_quantize_impls_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3 * Cin + Cout + k)
+    x = torch.randn((B, Cin, H, H), device=dev, generator=g).sign_().contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g) * 0.05
+    bias = torch.randn((Cout,), device=dev, generator=g) * 0.3
+    px = ops.pack_pixels_nib(x, ld=ops.pixel_ld_nib_taps(Cin))
+    ws = ops.pack_conv_weight_nib(w, "sign", cw=px.ld)
+    ts = ops.xnor_tap_prep(w)
+    args = (px, (B, Cin, H, H), ws, (k, k), ts.fwd, bias, 1, p, 1)
+    y = ops.conv2d_nib_taps(*args)
+    al = torch.rand((Cout,), device=dev, generator=g) * 2 - 1                      # negative BatchNorm slopes included
+    be = (torch.rand((Cout,), device=dev, generator=g) * 2 - 1) * float(y.abs().mean())
+    bits = ops.conv2d_nib_taps(*args, epi=(al, be))
+    want = ops.sign_pack(torch.where(y * al < -be, -1.0, 1.0).contiguous())[0]
+    nw = (Cout + 31) // 32
+    M = B * H * H
+    assert torch.equal(bits.sign.view(M, -1)[:, :nw], want.sign.view(M, -1)[:, :nw])
+    frac = float((y * al < -be).float().mean())
+    assert 0.2 < frac < 0.8                                                           # a real threshold, not all-0 / all-1 planes
+    nib = ops.conv2d_nib_taps(*args, epi=ops.NibEpilogue(al, be, (1, 1)))
+    want_n = ops.bits_to_nib_pad(bits, B, H, H, (1, 1), ld=ops.pixel_ld_nib(Cout))
+    assert nib.rows == want_n.rows and torch.equal(nib.words, want_n.words)
