@@ -513,3 +513,20 @@ def test_xnor_taps_conv_wide_tile_epilogues_equal_the_float_predicate(dev, Cin, 
     nib = ops.conv2d_nib_taps(*args, epi=ops.NibEpilogue(al, be, (1, 1)))
     want_n = ops.bits_to_nib_pad(bits, B, H, H, (1, 1), ld=ops.pixel_ld_nib(Cout))
     assert nib.rows == want_n.rows and torch.equal(nib.words, want_n.words)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,k,p,B", [(256, 64, 30, 3, 1, 64), (576, 64, 27, 5, 2, 128)])
+def test_xnor_grad_input_on_the_wide_tiles_vs_fp64(dev, Cin, Cout, H, k, p, B):
+    """grad_x of an XNOR-Net conv (functions/xnor_connect.py:154-155) at sizes whose transposed conv takes the 256x256 / 384x192
+    tiles of the fp16-pair per-tap kernel: <= 1e-5 normalised against the fp64 conv2d_input of sign(W) * alpha."""
+    from pytorch_quantize_impls_amd import ops
+    g = torch.Generator(device=dev).manual_seed(Cin + 7 * Cout + k)
+    w = torch.randn((Cout, Cin, k, k), device=dev, generator=g) * 0.05
+    gout = torch.randn((B, Cout, H, H), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    ts = ops.xnor_tap_prep(w)
+    before = dict(_lib.call_counts)
+    gx = ops.conv2d_grad_input_taps((B, Cin, H, H), w, gout, ts.bwd, 1, p, 1)
+    assert gx is not None and _lib.call_counts["qt_conv2d_implicit_taps"] == before.get("qt_conv2d_implicit_taps", 0) + 1
+    alpha = w.double().abs().mean(dim=(0, 1))
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, H), torch.sign(w).double() * alpha[None, None], gout.double(), 1, p)
+    assert norm_err(n(gx), n(ref)) <= TOL
