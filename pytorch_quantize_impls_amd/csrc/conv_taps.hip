@@ -13,30 +13,11 @@
 // Entry points (include/qt_hip.h): qt_conv2d_implicit_taps (fp32 result), qt_conv2d_implicit_taps_bits / _nib (inference
 // fusion: BatchNorm-threshold bits, or the next conv's nibble plane), qt_xnor_tap_prep_f32 (alpha + the Horner tables of a weight).
 #include "mfma_gemm_kernel.h"
+#include "xnor_alpha.h"
 
 namespace {
 
-// ---- alpha[c] = mean_r |W[r, c]| for a row-major [R, C] view with FEW columns (C = kh * kw <= 1024) -------------------------------
-// Thread t of a workgroup owns column t % C and rows t / C, t / C + rpp, ... of the workgroup's row range (rpp = 1024 / C rows per
-// pass: one pass reads rpp * C consecutive floats); partial column sums per workgroup -> work[blk][C]; the final kernel adds them
-// in a fixed order (deterministic) and writes alpha and both Horner tables.
-__global__ __launch_bounds__(1024) void tap_abs_partial_kernel(const float* __restrict__ w, int64_t R, int C, int64_t rows_per_blk,
-                                                               float* __restrict__ work) {
-    __shared__ float sm[1024];
-    const int t = threadIdx.x, rpp = 1024 / C, c = t % C, r0 = t / C;
-    float acc = 0.0f;
-    if (r0 < rpp) {
-        const int64_t rb = (int64_t)blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
-        for (int64_t r = rb + r0; r < re; r += rpp) acc += fabsf(w[r * C + c]);
-    }
-    sm[t] = acc;
-    __syncthreads();
-    if (t < C) {
-        float s = 0.0f;
-        for (int j = 0; j < rpp; ++j) s += sm[j * C + t];
-        work[(int64_t)blockIdx.x * C + t] = s;
-    }
-}
+// ---- alpha[c] = mean_r |W[r, c]|: the shared column-sum order of xnor_alpha.h (tap_abs_partial_kernel + tap_alpha_final) ----
 
 // tables[0 .. T]      forward  : [1, rho_1 .. rho_{T-1}, a'_{T-1}],   rho_t = a'_{t-1} / a'_t
 // tables[T+1 .. 2T+1] flipped  : the same for the reversed tap order (grad_x convolves with the flipped kernel)
@@ -49,11 +30,7 @@ __global__ __launch_bounds__(1024) void tap_tables_kernel(const float* __restric
     if (t < T) {
         float s;
         if (alpha_in) s = alpha_in[t];
-        else {
-            s = 0.0f;
-            for (int b = 0; b < nblk; ++b) s += work[(int64_t)b * T + t];
-            s /= rows;
-        }
+        else s = tap_alpha_final(work, nblk, T, t, rows);
         a[t] = s;
         if (alpha) alpha[t] = s;
     }
@@ -188,9 +165,7 @@ int qt_conv2d_implicit_taps_nib(int elem, const uint32_t* P, int64_t Nimg, int64
 
 int64_t qt_xnor_tap_prep_work_floats(int64_t R, int64_t taps) {
     if (R <= 0 || taps <= 0 || taps > 1024) return 0;
-    const int64_t rpp = 1024 / taps;
-    const int64_t nblk = std::min<int64_t>(512, (R + rpp * 8 - 1) / (rpp * 8));
-    return nblk * taps;
+    return (int64_t)tap_alpha_blocks(R, taps, nullptr) * taps;
 }
 
 int qt_xnor_tap_prep_f32(const float* w, int64_t R, int64_t taps, const float* alpha_in, float* work, float* alpha,
@@ -199,9 +174,8 @@ int qt_xnor_tap_prep_f32(const float* w, int64_t R, int64_t taps, const float* a
     int nblk = 0;
     if (!alpha_in) {
         if (!w || R <= 0 || !work) return QT_ERR_INVALID_ARG;
-        const int64_t rpp = 1024 / taps;
-        nblk = (int)std::min<int64_t>(512, (R + rpp * 8 - 1) / (rpp * 8));
-        const int64_t rows_per_blk = ((R + nblk - 1) / nblk + rpp - 1) / rpp * rpp;
+        int64_t rows_per_blk = 0;
+        nblk = tap_alpha_blocks(R, taps, &rows_per_blk);
         hipLaunchKernelGGL(tap_abs_partial_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, w, R, (int)taps, rows_per_blk, work);
     }
     hipLaunchKernelGGL(tap_tables_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, work, nblk, (float)R,

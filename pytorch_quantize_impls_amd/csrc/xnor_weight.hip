@@ -6,6 +6,7 @@
 // C = kh*kw), followed by sign(w) * alpha[c] with torch.sign semantics (0 -> 0, NaN -> NaN).
 // HBM-bound, weights only (small): two passes over W.
 #include "qt_common.h"
+#include "xnor_alpha.h"
 
 namespace {
 
@@ -51,6 +52,13 @@ __global__ __launch_bounds__(256) void col_abs_final_kernel(const float* __restr
     float acc = 0.0f;
     for (int64_t k = 0; k < chunks; ++k) acc += part[k * C + c];
     alpha[c] = acc / (float)R;
+}
+
+// closing step of xnor_alpha.h's order for FEW columns (XNORConv2d weights): the alpha bits of qt_xnor_tap_prep_f32
+__global__ __launch_bounds__(1024) void tap_alpha_final_kernel(const float* __restrict__ work, int nblk, float rows, int T,
+                                                               float* __restrict__ alpha) {
+    const int t = threadIdx.x;
+    if (t < T) alpha[t] = tap_alpha_final(work, nblk, T, t, rows);
 }
 
 __device__ __forceinline__ float torch_sign(float x) {
@@ -277,7 +285,14 @@ extern "C" int qt_xnor_weight_f32(const float* w, int64_t ldw, float* alpha, flo
     if (R <= 0 || C <= 0) return (R == 0 || C == 0) ? QT_OK : QT_ERR_INVALID_ARG;
     if (!w || !alpha || ldw < C || (wq && ldq < C)) return QT_ERR_INVALID_ARG;
     const int64_t strips = (C + 63) / 64;
-    if (wq && wq != w && ldq == C && R >= 2048 && strips * 4 <= 256 && (R + 255) / 256 <= 65535) {
+    if (wq && wq != w && ldw == C && ldq == C && C <= 1024 && R >= 1 && tap_alpha_blocks(R, C, nullptr) <= R) {
+        // few contiguous columns (an XNORConv2d weight: R = Cout * Cin, C = kh * kw): the column-sum order qt_xnor_tap_prep_f32
+        // uses (xnor_alpha.h), partials through the wq buffer — the image's alpha and the TapScales' alpha are the same bits
+        int64_t rows_per_blk = 0;
+        const int nblk = tap_alpha_blocks(R, C, &rows_per_blk);
+        hipLaunchKernelGGL(tap_abs_partial_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, w, R, (int)C, rows_per_blk, wq);
+        hipLaunchKernelGGL(tap_alpha_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, wq, nblk, (float)R, (int)C, alpha);
+    } else if (wq && wq != w && ldq == C && R >= 2048 && strips * 4 <= 256 && (R + 255) / 256 <= 65535) {
         // tall and narrow: chunked partial sums through the wq buffer (see col_abs_part_kernel)
         const int64_t chunks = (R + 255) / 256;
         hipLaunchKernelGGL(col_abs_part_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, w, ldw, wq, R,

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, packed
+from .common import QtFunction
 
 #: When True (default) an un-tagged device activation is checked on the device for being exactly
 #: +-1 before the packed path is taken (costs one read of the activation and one host sync).
@@ -575,7 +576,7 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-class QuantConv2dFn(torch.autograd.Function):
+class QuantConv2dFn(QtFunction):
     """Autograd node of BinConv2d / TerConv2d in training mode: forward F.conv2d(x, Q(W), b, ...)
     (layers/binary_layers.py:105); backward = what autograd derives from F.conv2d plus the STE mask
     of the weight quantiser."""
@@ -1035,7 +1036,7 @@ def _levels_grad_weight_linear(g2, x2, x_levels, codes_fit: bool):
             + ops.bf16_gemm(gT, ops.weight_bf16x3(lo.t().contiguous(), "raw", terms=3))) * inv + bad
 
 
-class DorefaW1LinearFn(torch.autograd.Function):
+class DorefaW1LinearFn(QtFunction):
     """Training-mode LinearDorefa(bit_width=1): forward above; backward as autograd derives it from
     F.linear(x, _ignore_factor_op(sign(W), E), b): grad_x = g . (sign(W) E), grad_W = g^T . x passed
     through UNscaled (functions/dorefa_connect.py:66-79) with the identity STE of the quantiser.  From 2^27 MACs on both
@@ -1075,7 +1076,7 @@ class DorefaW1LinearFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias
 
 
-class DorefaW1Conv2dFn(torch.autograd.Function):
+class DorefaW1Conv2dFn(QtFunction):
     """Training-mode DorefaConv2d(bit_width=1); see DorefaW1LinearFn."""
 
     @staticmethod
@@ -1189,7 +1190,7 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
     return (g_hi * 256.0 + g_lo) * inv + bad
 
 
-class DorefaWkConv2dFn(torch.autograd.Function):
+class DorefaWkConv2dFn(QtFunction):
     """Training-mode DorefaConv2d(bit_width = k), 2 <= k <= 8: conv2d(x, w_q, b) for the quantised image w_q the layer's
     weight_op produced (layers/dorefa_layers.py:77-82, functions/dorefa_connect.py:99-111); the gradient w.r.t. w_q flows on
     into weight_op's own autograd graph (tanh and its normalisation), exactly as in the reference.
@@ -1252,7 +1253,7 @@ class DorefaWkConv2dFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None, None
 
 
-class DorefaWkLinearFn(torch.autograd.Function):
+class DorefaWkLinearFn(QtFunction):
     """Training-mode LinearDorefa(bit_width = k), 2 <= k <= 8; see DorefaWkConv2dFn (layers/dorefa_layers.py:41-45)."""
 
     @staticmethod
@@ -1297,7 +1298,7 @@ class DorefaWkLinearFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None
 
 
-class RealLinearFn(torch.autograd.Function):
+class RealLinearFn(QtFunction):
     """F.linear(x, W, b) for two REAL fp32 device operands on the matrix cores (six-term bf16 planes, fp32-GEMM accuracy), forward
     and both gradients: LinearDorefa(bit_width = 32), whose weight quantiser is the identity (functions/dorefa_connect.py:100-101,
     layers/dorefa_layers.py:41-45) — the layer is an un-quantised nn.Linear."""
@@ -1325,7 +1326,7 @@ class RealLinearFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias
 
 
-class RealConv2dFn(torch.autograd.Function):
+class RealConv2dFn(QtFunction):
     """F.conv2d(x, W, b) for two REAL fp32 device operands (groups == 1, zero padding): DorefaConv2d(bit_width = 32).  Forward and
     — for stride 1, dilation 1 — grad_x (the conv of the gradient with the flipped, transposed weight) on the six-term implicit
     GEMM; grad_W of two real operands stays on the library unless the first-layer form applies (counted)."""
@@ -1429,7 +1430,7 @@ def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor, terms=None) -> torch.Tensor
     return lib_mm(a, b_pm1, "backward GEMM below BWD_MFMA_MIN_MACS / non-fp32")
 
 
-class QuantLinearFn(torch.autograd.Function):
+class QuantLinearFn(QtFunction):
     """Autograd node of LinearBin / LinearTer in training mode.
 
     forward : F.linear(x, Q(W), b)                         layers/binary_layers.py:44

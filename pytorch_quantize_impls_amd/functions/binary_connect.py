@@ -8,7 +8,7 @@ import warnings as _warnings
 import torch
 
 from .. import ops, packed, lazy, lazy_train
-from .common import front, safeSign, ste_mask
+from .common import QtFunction, front, safeSign, ste_mask
 from . import _fused
 
 _warnings.simplefilter("always", DeprecationWarning)
@@ -30,7 +30,7 @@ def _binarize_and_tag(input: torch.Tensor) -> torch.Tensor:
     return safeSign(input)
 
 
-class BinaryConnectDeterministic(torch.autograd.Function):
+class BinaryConnectDeterministic(QtFunction):
     """r_b = sign(r) (0 -> +1); d r_b / d r = 1_{|r| <= 1}  (binary_connect.py:14-38)."""
     _qt_records_sign = True      # on a deferred conv chain (lazy.py) the op is recorded, not executed
 
@@ -59,7 +59,7 @@ class BinaryConnectDeterministic(torch.autograd.Function):
         return ste_mask(grad_output, input)
 
 
-class BinaryConnectStochastic(torch.autograd.Function):
+class BinaryConnectStochastic(QtFunction):
     """r_b = +1 with probability hardsigmoid(r), else -1; same STE backward
     (binary_connect.py:42-71).  The uniforms come from torch.rand_like, as in the reference."""
 
@@ -88,7 +88,7 @@ def BinaryConnect(stochastic=False):
     return front(BinaryConnectStochastic if stochastic else BinaryConnectDeterministic)
 
 
-class BinaryDense(torch.autograd.Function):
+class BinaryDense(QtFunction):
     """y = x . sign(W)^T + b with a plain (un-masked) backward (binary_connect.py:86-112).  Device fp32 tensors: both backward
     contractions on this backend's matrix-core routes (_fused.dense_grad_input / dense_grad_weight)."""
 
@@ -118,7 +118,7 @@ def BinaryConv2d(stride=1, padding=1, dilation=1, groups=1):
     """DEPRECATED functional conv with binarised weight (binary_connect.py:116-153); backward on the matrix-core conv routes."""
     _warnings.warn("Deprecated conv op ! Use layers.BinConv2d.", DeprecationWarning, stacklevel=2)
 
-    class _BinaryConv2d(torch.autograd.Function):
+    class _BinaryConv2d(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             ctx.save_for_backward(input, weight, bias)
@@ -155,7 +155,7 @@ def AP2(x):
     return safeSign(x) * torch.pow(torch.full_like(x, 2.0), torch.round(torch.log2(torch.abs(x))))
 
 
-class ShiftBatch(torch.autograd.Function):
+class ShiftBatch(QtFunction):
     """Shift-based batch-norm primitive (binary_connect.py:173-214).  Device fp32 tensors whose statistics / affine
     tensors broadcast over the leading dimension (how ShiftNormBatch1d / 2d call it): one HIP kernel
     (qt_shift_batch_f32); anything else: the torch expression."""

@@ -17,6 +17,23 @@ def safeSign(tensor: torch.Tensor) -> torch.Tensor:
     return torch.where(tensor < 0, -one, one)
 
 
+class QtFunction(torch.autograd.Function):
+    """Base of every autograd.Function of this package.  ``Function.apply`` bypasses ``__torch_function__``, so a deferred
+    activation (the storage-less stand-in of a recorded training-mode [pool] -> BatchNorm -> ... chain, lazy_train.py; a deferred
+    inference chain, lazy.py) handed to ``apply`` would enter ``forward`` as a no-grad leaf and cut the graph to everything
+    upstream.  Every ``apply`` therefore swaps deferred arguments for their ordinary tensors first; subclasses that can FUSE
+    the chain instead (BinaryConnectDeterministic, nnDorefaQuant's Function) override ``apply`` and end here."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        args = lazy_train.resolve_args(args)
+        for a in args:
+            if isinstance(a, lazy.LazyActivation):
+                args = tuple(b.value() if isinstance(b, lazy.LazyActivation) else b for b in args)
+                break
+        return super().apply(*args, **kwargs)
+
+
 class _FunctionModule(torch.nn.Module):
     """nn.Module that applies an autograd.Function class (what front()/front2() hand out)."""
 

@@ -4,7 +4,7 @@ import warnings
 import torch
 
 from .. import ops, packed, lazy, lazy_train
-from .common import front, safeSign
+from .common import QtFunction, front, safeSign
 from . import _fused
 
 warnings.simplefilter("always", DeprecationWarning)
@@ -35,7 +35,7 @@ def _quantize(x, bit_width=3):
 
 
 def _make_quant_function(bit_width):
-    class _Quant(torch.autograd.Function):
+    class _Quant(QtFunction):
         _qt_quant_bits = bit_width          # on a deferred DorefaConv2d chain (lazy.py) the quantiser is recorded
 
         @classmethod
@@ -73,7 +73,7 @@ def DorefaQuant(x, bit_width=3):
     return _make_quant_function(bit_width).apply(x)
 
 
-class _ignore_factor_op(torch.autograd.Function):
+class _ignore_factor_op(QtFunction):
     """forward x*c ; backward passes the gradient through UNscaled (dorefa_connect.py:66-79)."""
 
     @staticmethod
@@ -116,7 +116,7 @@ def QuantDense(bit_width=3):
     """DEPRECATED functional dense op with explicit tanh-derivative backward
     (dorefa_connect.py:116-155)."""
 
-    class _QuantDense(torch.autograd.Function):
+    class _QuantDense(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             max_abs = torch.max(torch.abs(torch.tanh(weight)))
@@ -152,7 +152,7 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
     """DEPRECATED functional conv op; normalises by tanh(max|W|) (dorefa_connect.py:158-199)."""
     warnings.warn("Deprecated conv op ! Use layers.DorefaConv2d.", DeprecationWarning, stacklevel=2)
 
-    class _QuantConv2d(torch.autograd.Function):
+    class _QuantConv2d(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             max_weight = torch.max(torch.abs(weight))

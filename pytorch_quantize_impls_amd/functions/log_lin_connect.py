@@ -9,7 +9,7 @@ sign(g) * clamp(round(g/step)*step, 0, 2^fsr) (note: negative g therefore yields
 import torch
 
 from .. import ops
-from .common import front
+from .common import QtFunction, front
 
 
 def _is_dev(t):
@@ -40,7 +40,7 @@ def LogQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
     """autograd.Function class: forward [sign(x) *] 2^clamp(round(log2|x|), fsr - 2^bit_width, fsr); backward the
     identity (lin_back) or the same quantiser applied to the gradient, signed (log_lin_connect.py:9-41)."""
 
-    class _LogQuant(torch.autograd.Function):
+    class _LogQuant(QtFunction):
         @staticmethod
         def forward(ctx, input):
             if _is_dev(input) and _kernel_takes(fsr, bit_width, True):
@@ -62,7 +62,7 @@ def LinQuant(fsr=7, bit_width=3, with_sign=True, lin_back=True):
     """autograd.Function class: forward [sign(x) *] clamp(round(|x| / step) * step, 0, 2^fsr), step = 2^(fsr - bit_width)
     (bit_width 32: identity); backward the identity (lin_back) or the quantised gradient (log_lin_connect.py:43-80)."""
 
-    class _LinQuant(torch.autograd.Function):
+    class _LinQuant(QtFunction):
         @staticmethod
         def forward(ctx, input):
             if bit_width == 32:

@@ -4,13 +4,13 @@ import warnings
 import torch
 
 from .. import ops
-from .common import front, safeSign, ste_mask
+from .common import QtFunction, front, safeSign, ste_mask
 from . import _fused
 
 warnings.simplefilter("always", DeprecationWarning)
 
 
-class TernaryConnectDeterministic(torch.autograd.Function):
+class TernaryConnectDeterministic(QtFunction):
     """x_t = +1 if x >= 0.5 ; -1 if x < -0.5 ; else 0   (written in the reference as
     (s + safeSign(x - 0.5 s))/2, terner_connect.py:24-27); d x_t/d x = 1_{|x| <= 1}."""
 
@@ -33,7 +33,7 @@ def stochastic_ternarize(input: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return s - s * (z > torch.abs(input)).to(input.dtype)
 
 
-class TernaryConnectStochastic(torch.autograd.Function):
+class TernaryConnectStochastic(QtFunction):
     """x_t = sign(x) with probability |x|, else 0 (terner_connect.py:37-63)."""
 
     @staticmethod
@@ -70,7 +70,7 @@ def TernaryDense(stochastic=False):
     branch gives {0, +-2}): forward and both backward contractions on the six-term real x real route for device tensors
     (a +-1 activation is the exact operand of the weight gradient)."""
 
-    class _TernaryDense(torch.autograd.Function):
+    class _TernaryDense(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)
@@ -99,7 +99,7 @@ def TernaryConv2d(stochastic=True, stride=1, padding=1, dilation=1, groups=1):
     activation is +-1."""
     warnings.warn("Deprecated conv op ! Use layers.TerConv2d.", DeprecationWarning, stacklevel=2)
 
-    class _TernaryConv2d(torch.autograd.Function):
+    class _TernaryConv2d(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             weight_t = _functional_ternary_weight(weight, stochastic)

@@ -10,13 +10,13 @@ import torch
 
 from .. import ops, packed
 from . import _fused
-from .common import front
+from .common import QtFunction, front
 
 DIM = 0
 
 
 def _quantOpXnor(dim=1):
-    class _QuantXNOR(torch.autograd.Function):
+    class _QuantXNOR(QtFunction):
         @staticmethod
         def forward(ctx, input):
             if input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and input.numel() > 0:
@@ -84,7 +84,7 @@ def XNORDense(dim=[0, 1]):
     grad_weight from g^T . x with the +-1 activation as the exact operand (two real operands: the dense library, counted in
     _fused.LIBRARY_PATHS) and the XNOR-Net combination mean * gw + sign(W) * mean(gw * sign(W), DIM)."""
 
-    class _XNORDense(torch.autograd.Function):
+    class _XNORDense(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             ctx.x_is_pm1 = False
@@ -141,7 +141,7 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
         grad_weight = the +-1 weight-gradient routes (pixel-major / K-major / strided) + the XNOR-Net combination (:158-159).
     Whatever has no route here runs the reference expression on the dense library and is counted (_fused.LIBRARY_PATHS)."""
 
-    class _XNORConv2d(torch.autograd.Function):
+    class _XNORConv2d(QtFunction):
         @staticmethod
         def forward(ctx, input, weight, bias=None):
             ctx.x_is_pm1, ctx.taps = False, None

@@ -26,7 +26,7 @@ Numerics — two folds (``fold=`` of the fused modules):
 import torch
 
 from .. import ops, packed, lazy
-from ..functions.common import _FunctionModule
+from ..functions.common import QtFunction, _FunctionModule
 from ..functions.binary_connect import BinaryConnectDeterministic
 
 
@@ -638,7 +638,7 @@ class PackedMaxPool(torch.nn.Module):
         return packed.PackedActivation(planes, (N, C, Ho, Wo))
 
 
-class _TrainPoolBnSignFn(torch.autograd.Function):
+class _TrainPoolBnSignFn(QtFunction):
     """[MaxPool2d] -> BatchNorm (batch statistics) -> [Hardtanh] -> BinaryConnectDeterministic as one autograd node on this
     backend's kernels (ops.pool_bn_sign_train / _backward); see FusedTrainPoolBnSign."""
 
@@ -710,7 +710,7 @@ class FusedTrainPoolBnSign(torch.nn.Module):
         return out
 
 
-class _TrainBnActQuantFn(torch.autograd.Function):
+class _TrainBnActQuantFn(QtFunction):
     """BatchNorm (batch statistics) [+ residual] [-> ReLU] [-> nnDorefaQuant(k)] as one autograd node on this backend's kernels
     (ops.bn_train_stats + ops.affine_dorefa_codes / bn_eval_device forward, ops.bn_act_train_backward); see FusedTrainBnActQuant."""
 

@@ -420,14 +420,20 @@ class LazyActivation(torch.Tensor):
             # value of the old node may be the parent of chains recorded earlier), the wrapper moves on to a constant node
             rest = {k: v for k, v in kwargs.items() if k != "out"}
             a2, rest = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (tuple(args), rest))
-            out_kw._qt = _const_node(func(*a2, **rest))
+            own = _own_storage(out_kw)
+            if own is not None:                 # a LazyDense IS its memory: the result is written there (C++ readers see it)
+                func(*a2, out=own, **rest)
+                out_kw._qt = _const_node(own)
+            else:
+                out_kw._qt = _const_node(func(*a2, **rest))
             return out_kw
         if _writes_in_place(name) and args and isinstance(args[0], LazyActivation):
             # x.op_(...) on a deferred activation outside the grammar: the module-by-module value, mutated — but in a
             # private copy (the cached value of this node may be the parent of chains recorded earlier), and the wrapper
             # moves on to a constant node holding the result, as the tensor an in-place op returns would
             self_ = args[0]
-            v = self_._qt.materialise().clone()
+            own = _own_storage(self_)
+            v = own if own is not None else self_._qt.materialise().clone()
             rest, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (tuple(args[1:]), kwargs))
             func(v, *rest, **kwargs)
             self_._qt = _const_node(v)
@@ -439,6 +445,45 @@ class LazyActivation(torch.Tensor):
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
         # safety net: an ATen op reached the dispatcher with a deferred activation (C++ callers, autograd internals)
         args, kwargs = tree_map_only(LazyActivation, lambda t: t._qt.materialise(), (args, kwargs or {}))
+        return func(*args, **kwargs)
+
+
+def _own_storage(t):
+    """For a LazyDense about to be overwritten (in-place op / out=): its own memory as a plain tensor, after the node that
+    chains recorded earlier hang on has been given a private copy of the old value; None for storage-less activations."""
+    if type(t) is not LazyDense:
+        return None
+    with torch._C.DisableTorchFunctionSubclass():
+        own = t.as_subclass(torch.Tensor)
+    node = t._qt
+    if node.value is not None and node.value.data_ptr() == own.data_ptr():
+        node.value = own.clone()
+        if node.kind == "dense":
+            node.stamp = _stamp(node.value)          # chains recorded on the node now read (and version-check) the copy
+    return own
+
+
+class LazyDense(LazyActivation):
+    """The COMPUTED [B, N] result of an eval-mode quantised Linear layer (DEFER_DENSE): the real tensor — same storage, made
+    with ``as_subclass`` — that can still record BatchNorm1d -> [Hardtanh] -> BinaryConnect.  Unlike a storage-less
+    LazyActivation it is an ordinary tensor to everything that bypasses ``__torch_function__`` (torch.distributed collectives,
+    C++ extensions, pickling / torch.save): a model's final logits travel as plain memory."""
+
+    @staticmethod
+    def __new__(cls, node: _Node, device=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            t = node.value.as_subclass(cls)
+        t._qt = node
+        return t
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def plain(t):
+            v = t._qt.value
+            if v is None:                                  # the wrapper moved on (in-place op outside the grammar)
+                v = t._qt.materialise()
+            return v
+        args, kwargs = tree_map_only(LazyActivation, plain, (args, kwargs or {}))
         return func(*args, **kwargs)
 
 
@@ -899,7 +944,7 @@ def _dense_result(layer, y):
     if (DEFER_DENSE and enabled() and type(y) is torch.Tensor and y.dim() == 2 and y.is_cuda and y.dtype == torch.float32
             and not y.requires_grad and not layer.training and _no_autograd(layer) and not _untracked(y)):
         STATS["dense_deferred"] += 1
-        return _wrap(_dense_node(y))
+        return LazyDense(_dense_node(y))
     return y
 
 

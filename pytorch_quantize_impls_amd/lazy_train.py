@@ -108,7 +108,7 @@ class _Step:
         elif kind == "hardtanh":
             h = F.hardtanh(h, self.op[1], self.op[2])
         elif kind == "add":
-            h = h + resolve(self.op[1])
+            h = h + _resolve_operand(self.op[1])
         elif kind == "relu":
             h = torch.relu(h)
         elif kind == "flat":
@@ -116,6 +116,11 @@ class _Step:
         STATS["replayed:" + kind] += 1
         self.value = h
         return h
+
+
+def _resolve_operand(o):
+    """A recorded residual operand: an immutable _Step (deferred when recorded) or an ordinary tensor."""
+    return o.materialise() if type(o) is _Step else resolve(o)
 
 
 def _batch_norm(h, step):
@@ -143,8 +148,13 @@ class TrainChain(torch.Tensor):
     @staticmethod
     def __new__(cls, step: _Step):
         base = step.base
-        t = torch.Tensor._make_wrapper_subclass(cls, step.shape, dtype=torch.float32, device=base.device, requires_grad=False)
+        # requires_grad=True + the hook below: an autograd.Function this package cannot see (Function.apply bypasses
+        # __torch_function__) takes the stand-in as a graph LEAF; its backward then reaches _foreign_function_grad and fails
+        # loudly instead of silently cutting the graph to the BatchNorm and every layer upstream.
+        t = torch.Tensor._make_wrapper_subclass(cls, step.shape, dtype=torch.float32, device=base.device, requires_grad=True)
         t._qt = step
+        with torch._C.DisableTorchFunctionSubclass():
+            t.register_hook(_foreign_function_grad)
         return t
 
     def value(self) -> torch.Tensor:
@@ -161,6 +171,23 @@ class TrainChain(torch.Tensor):
 
 
 _DEFERRED = (TrainOut, TrainChain)
+
+
+def _foreign_function_grad(grad):
+    raise RuntimeError(
+        "pytorch_quantize_impls_amd.lazy_train: a gradient arrived at the stand-in of a deferred training-mode "
+        "[pool] -> BatchNorm -> ... chain.  A torch.autograd.Function outside this package consumed the stand-in through "
+        "Function.apply (which bypasses __torch_function__), so its backward cannot reach the BatchNorm.  Pass "
+        "lazy_train.resolve(x) to that Function, derive it from functions.common.QtFunction, or run the step under "
+        "`with lazy_train.eager():`.")
+
+
+def resolve_args(args):
+    """Function.apply arguments with every deferred training activation replaced by its ordinary tensor."""
+    for a in args:
+        if type(a) in _DEFERRED:
+            return tuple(resolve(b) for b in args)
+    return args
 
 
 def _step_of(t) -> _Step:
@@ -224,7 +251,9 @@ def _torch_function(func, types, args, kwargs):
         if _writes_in_place(name):
             # x.op_(...) outside the grammar on a stand-in: the replayed value, mutated; the stand-in moves on to the result
             self_ = args[0]
-            v = self_._qt.materialise()
+            # a private copy: the step's cached value may be the parent of chains recorded earlier (a = y + r; y.mul_(2)),
+            # which must replay on the un-mutated tensor, as eager computed them before the mutation (lazy.py does the same)
+            v = self_._qt.materialise().clone()
             rest, kwargs = tree_map_only(TrainChain, resolve, (tuple(args[1:]), kwargs))
             with torch._C.DisableTorchFunctionSubclass():
                 res = func(v, *rest, **kwargs)
@@ -345,7 +374,9 @@ def _h_add(a, b, *, alpha=1, out=None, _inplace=False):
         main, other = b, a
     else:
         return NotImplemented
-    child = _Step(main._qt, ("add", other), main._qt.shape)
+    # a deferred residual is captured as its CURRENT (immutable) step: a later shortcut.relu_() / shortcut += ... rebinds the
+    # stand-in's _qt and must not change what this already-recorded add resolves to
+    child = _Step(main._qt, ("add", _step_of(other) if type(other) in _DEFERRED else other), main._qt.shape)
     if _inplace:
         a._qt = child
         return a
@@ -439,7 +470,7 @@ def quant(x, bit_width: int):
         return None
     from .layers.fused import _TrainBnActQuantFn
     _, rm, rv, w, b, momentum, eps = n.bn
-    res = resolve(n.add[1]) if n.add is not None else None
+    res = _resolve_operand(n.add[1]) if n.add is not None else None
     out = _TrainBnActQuantFn.apply(n.base, res, w, b, rm, rv, eps, momentum, n.relu, int(bit_width))
     n._mark_fused()
     STATS["fused:quant"] += 1

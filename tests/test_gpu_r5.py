@@ -1,0 +1,133 @@
+"""Round-5 GPU tests, part a: the ADVICE r4 items.
+
+  * every package autograd.Function keeps the graph to a deferred training-mode BatchNorm chain (Function.apply bypasses
+    __torch_function__; lazy_train.resolve_args in functions.common.QtFunction.apply), a foreign Function fails loudly;
+  * the computed result of an eval-mode quantised Linear layer (DEFER_DENSE) is real memory (lazy.LazyDense);
+  * ONE alpha per XNORConv2d weight: qt_xnor_weight_f32 (eval image / real-input route) and qt_xnor_tap_prep_f32 (+-1 routes)
+    sum the columns in the same order (csrc/xnor_alpha.h)."""
+import copy
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_quantize_impls_amd import lazy, lazy_train, ops  # noqa: E402
+from pytorch_quantize_impls_amd.functions import BinaryConnect, binary_connect, terner_connect, xnor_connect, log_lin_connect  # noqa: E402
+from pytorch_quantize_impls_amd.layers import BinConv2d, LinearBin, XNORConv2d  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _grads(consume, dev, eager, seed=5):
+    torch.manual_seed(seed)
+    conv = BinConv2d(16, 32, 3, padding=1).to(dev).train()
+    bn = torch.nn.BatchNorm2d(32).to(dev).train()
+    x = torch.randn(4, 16, 8, 8, device=dev).sign().requires_grad_(True)
+    torch.manual_seed(seed + 1)
+    if eager:
+        with lazy_train.eager():
+            y = consume(bn(conv(x)))
+    else:
+        h = bn(conv(x))
+        assert type(h) is lazy_train.TrainChain
+        y = consume(h)
+    assert y.grad_fn is not None
+    g = torch.arange(y.numel(), dtype=torch.float32, device=dev).reshape(y.shape) / y.numel()
+    (y * g).sum().backward()
+    return y.detach(), conv.weight.grad, bn.weight.grad, bn.bias.grad, x.grad
+
+
+@pytest.mark.parametrize("name", ["bin_stochastic", "ter_det", "quant_xnor", "lin_quant", "binary_dense"])
+def test_package_functions_keep_the_graph_to_a_deferred_training_chain(dev, name):
+    w = torch.randn(6, 32 * 8 * 8, device=dev)
+    consume = {
+        "bin_stochastic": lambda h: binary_connect.BinaryConnectStochastic.apply(h),
+        "ter_det": lambda h: terner_connect.TernaryConnectDeterministic.apply(h),
+        "quant_xnor": lambda h: xnor_connect.QuantXnor(h.reshape(4, -1), 1),
+        "lin_quant": lambda h: log_lin_connect.Quant(h, "lin", bit_width=4),
+        "binary_dense": lambda h: binary_connect.BinaryDense.apply(h.reshape(4, -1), w, None),
+    }[name]
+    a = _grads(consume, dev, eager=False)
+    b = _grads(consume, dev, eager=True)
+    assert torch.equal(a[0], b[0])
+    for u, v in zip(a[1:], b[1:]):
+        assert u is not None and v is not None
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), name
+
+
+def test_a_foreign_function_on_a_deferred_training_chain_fails_loudly(dev):
+    class Sq(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            ctx.save_for_backward(t)
+            return t * t
+
+        @staticmethod
+        def backward(ctx, g):
+            return 2 * ctx.saved_tensors[0] * g
+
+    with pytest.raises(RuntimeError, match="lazy_train.resolve"):
+        _grads(lambda h: Sq.apply(h), dev, eager=False)
+    a = _grads(lambda h: Sq.apply(lazy_train.resolve(h)), dev, eager=False)
+    b = _grads(lambda h: Sq.apply(h), dev, eager=True)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max()))
+
+
+def test_dense_deferred_result_is_real_memory(dev):
+    torch.manual_seed(0)
+    lin = LinearBin(256, 64).to(dev).eval()
+    bn = torch.nn.BatchNorm1d(64).to(dev).eval()
+    bn.running_mean.normal_()
+    x = torch.randn(32, 256, device=dev).sign()
+    with torch.no_grad():
+        with lazy.eager():
+            want = lin(x)
+            want_bits = BinaryConnect()(torch.nn.functional.hardtanh(bn(want)))
+        y = lin(BinaryConnect()(x))
+        assert type(y) is lazy.LazyDense and isinstance(y, lazy.LazyActivation)
+        # an ordinary tensor to everything that bypasses __torch_function__
+        with torch._C.DisableTorchFunctionSubclass():
+            plain = y.as_subclass(torch.Tensor)
+        assert plain.data_ptr() != 0 and torch.equal(plain, want)
+        buf = io.BytesIO()
+        torch.save(y, buf)
+        buf.seek(0)
+        assert torch.equal(torch.load(buf, weights_only=False).to(dev), want)
+        # still records BatchNorm1d -> Hardtanh -> BinaryConnect
+        got = BinaryConnect()(torch.nn.functional.hardtanh(bn(y)))
+        assert torch.equal(lazy.resolve(got), want_bits)
+        # chain recorded first, then an in-place op on the result: the chain reads the un-mutated value, the tensor's own
+        # memory holds the mutated one
+        y = lin(BinaryConnect()(x))
+        rec = bn(y)
+        y.mul_(2.0)
+        with torch._C.DisableTorchFunctionSubclass():
+            plain = y.as_subclass(torch.Tensor)
+        assert torch.equal(plain, want * 2.0) and torch.equal(y + 0, want * 2.0)
+        assert torch.equal(lazy.resolve(BinaryConnect()(torch.nn.functional.hardtanh(rec))), want_bits)
+
+
+@pytest.mark.parametrize("shape", [(576, 192, 5, 5), (192, 3, 11, 11), (24, 8, 3, 3), (5, 3, 1, 1), (7, 5, 3, 2)])
+def test_one_alpha_per_xnor_conv_weight(dev, shape):
+    torch.manual_seed(sum(shape))
+    w = torch.randn(shape, device=dev) * 0.05
+    wq, alpha = ops.xnor_weight(w, 2)
+    taps = ops.xnor_tap_prep(w)
+    assert torch.equal(alpha.reshape(-1), taps.alpha)                      # the same bits on every route
+    ref = w.double().abs().mean((0, 1)).reshape(-1)
+    assert float((alpha.reshape(-1).double() - ref).abs().max() / ref.abs().max()) <= 1e-6
+    assert torch.equal(wq, torch.sign(w) * alpha)
+    # the layer: eval image and TapScales agree too
+    Cout, Cin, kh, kw = shape
+    layer = XNORConv2d(Cin, Cout, (kh, kw), padding=kh // 2).to(dev)
+    layer.weight.data.copy_(w)
+    layer.eval()
+    img_alpha = layer.weight.detach().abs().amax((0, 1)).reshape(-1)
+    assert torch.equal(img_alpha, taps.alpha)

@@ -158,3 +158,117 @@ def test_in_place_forms_and_the_residual_on_either_side(nodes):
         with lazy_train.eager():
             y2 = nnDorefaQuant(4)(torch.relu(bn2(conv(x)) + r))
         assert torch.equal(y, y2), form
+
+
+def _upstream_grads(consume, seed=5):
+    """Gradients of conv weight / BatchNorm affine / input for  consume(bn(conv(x)))  with the recording on and off."""
+    res = []
+    for eager in (False, True):
+        torch.manual_seed(seed)
+        conv, bn = BinConv2d(8, 8, 3, padding=1).train(), torch.nn.BatchNorm2d(8).train()
+        x = torch.randn(2, 8, 6, 6, requires_grad=True)
+        torch.manual_seed(seed + 1)                    # the stochastic ops draw the same uniforms both times
+        if eager:
+            with lazy_train.eager():
+                y = consume(bn(conv(x)))
+        else:
+            h = bn(conv(x))
+            assert type(h) is lazy_train.TrainChain
+            y = consume(h)
+        assert type(y) is torch.Tensor and y.grad_fn is not None
+        (y * torch.arange(y.numel(), dtype=torch.float32).reshape(y.shape)).sum().backward()
+        res.append((y.detach(), conv.weight.grad, bn.weight.grad, bn.bias.grad, x.grad))
+    return res
+
+
+@pytest.mark.parametrize("name", ["bin_stochastic", "ter_det", "ter_stochastic", "quant_xnor", "lin_quant", "log_quant",
+                                  "dorefa_quant_fn", "binary_dense", "xnor_dense"])
+def test_every_package_function_keeps_the_graph_to_the_batchnorm(nodes, name):
+    """Function.apply bypasses __torch_function__; a stand-in handed to any package Function other than
+    BinaryConnectDeterministic / nnDorefaQuant used to enter forward as a no-grad leaf (grads upstream silently None)."""
+    from pytorch_quantize_impls_amd import functions as Fn
+    from pytorch_quantize_impls_amd.functions import binary_connect, terner_connect, xnor_connect, log_lin_connect, dorefa_connect
+    w = torch.randn(5, 8 * 6 * 6)
+    consume = {
+        "bin_stochastic": lambda h: binary_connect.BinaryConnectStochastic.apply(h),
+        "ter_det": lambda h: terner_connect.TernaryConnectDeterministic.apply(h),
+        "ter_stochastic": lambda h: terner_connect.TernaryConnectStochastic.apply(h),
+        "quant_xnor": lambda h: xnor_connect.QuantXnor(h.reshape(2, -1), 1),
+        "lin_quant": lambda h: log_lin_connect.Quant(h, "lin", bit_width=4),
+        "log_quant": lambda h: log_lin_connect.Quant(h, "log", bit_width=4),
+        "dorefa_quant_fn": lambda h: dorefa_connect.DorefaQuant(h, 3),
+        "binary_dense": lambda h: binary_connect.BinaryDense.apply(h.reshape(2, -1), w, None),
+        "xnor_dense": lambda h: xnor_connect.XNORDense().apply(h.reshape(2, -1), w, None),
+    }[name]
+    (y, gw, gbw, gbb, gx), (y2, gw2, gbw2, gbb2, gx2) = _upstream_grads(consume)
+    assert torch.equal(y, y2)
+    for a, b in ((gw, gw2), (gbw, gbw2), (gbb, gbb2), (gx, gx2)):
+        assert a is not None and b is not None, name
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), name
+
+
+def test_a_foreign_function_consuming_a_stand_in_fails_loudly(nodes):
+    class Sq(torch.autograd.Function):                 # a user Function: not derived from QtFunction
+        @staticmethod
+        def forward(ctx, t):
+            ctx.save_for_backward(t)
+            return t * t
+
+        @staticmethod
+        def backward(ctx, g):
+            t, = ctx.saved_tensors
+            return 2 * t * g
+
+    torch.manual_seed(7)
+    conv, bn = BinConv2d(8, 8, 3, padding=1).train(), torch.nn.BatchNorm2d(8).train()
+    x = torch.randn(2, 8, 6, 6)
+    y = Sq.apply(bn(conv(x)))
+    assert y.requires_grad                           # the stand-in is a graph leaf now, not a constant
+    with pytest.raises(RuntimeError, match="lazy_train.resolve"):
+        y.sum().backward()
+    # the two documented ways out
+    y = Sq.apply(lazy_train.resolve(bn(conv(x))))
+    y.sum().backward()
+    g = conv.weight.grad.clone()
+    conv.weight.grad = None
+    with lazy_train.eager():
+        Sq.apply(bn(conv(x))).sum().backward()
+    assert torch.allclose(conv.weight.grad, g, rtol=1e-4, atol=1e-6)
+
+
+def test_in_place_op_outside_the_grammar_does_not_touch_recorded_parents(nodes):
+    """a = y + r recorded, then y.mul_(2): `a` must replay on the un-mutated y (eager computed it before)."""
+    torch.manual_seed(8)
+    conv, bn = BinConv2d(8, 8, 3, padding=1).train(), torch.nn.BatchNorm2d(8).train()
+    bn2 = copy.deepcopy(bn)
+    x, r = torch.randn(2, 8, 6, 6), torch.randn(2, 8, 6, 6)
+    y = bn(conv(x))
+    yv = torch.sigmoid(y)                              # forces (and caches) the BatchNorm value
+    a = y + r                                          # recorded on the cached step
+    y.mul_(2.0)                                        # out of grammar, in place
+    with lazy_train.eager():
+        y2 = bn2(conv(x))
+        yv2 = torch.sigmoid(y2)
+        a2 = y2 + r
+        y2 = y2 * 2.0
+    assert torch.equal(yv, yv2)
+    assert torch.allclose(lazy_train.resolve(a) if type(a) is lazy_train.TrainChain else a, a2, atol=1e-6)
+    assert torch.allclose(lazy_train.resolve(y), y2, atol=1e-6)
+
+
+def test_recorded_add_keeps_the_residual_it_saw(nodes):
+    """out = bn2(c2) + shortcut recorded; a later shortcut.relu_() must not change what the add resolves to."""
+    torch.manual_seed(9)
+    conv = DorefaConv2d(8, 8, 3, padding=1, bias=False, bit_width=1).train()
+    conv_s = DorefaConv2d(8, 8, 1, bias=False, bit_width=1).train()
+    bn, bn_s = torch.nn.BatchNorm2d(8).train(), torch.nn.BatchNorm2d(8).train()
+    bnc, bn_sc = copy.deepcopy(bn), copy.deepcopy(bn_s)
+    x = torch.rand(2, 8, 5, 5)
+    short = bn_s(conv_s(x))
+    out = bn(conv(x)) + short
+    short.relu_()                                      # rebinds the stand-in after the add was recorded
+    got = torch.sigmoid(out)
+    with lazy_train.eager():
+        s2 = bn_sc(conv_s(x))
+        want = torch.sigmoid(bnc(conv(x)) + s2)
+    assert torch.allclose(got, want, atol=1e-6)
