@@ -375,14 +375,29 @@ def conv2d_weight_f64(x, w_shape, g, stride=1, padding=0, dilation=1):
     return gw
 
 
-def xnor_conv2d_forward(x, weight, bias=None, stride=1, padding=1, dilation=1, dim=(0, 1)):
-    """XNORConv2d forward (functions/xnor_connect.py:139-146; quant_input False as the layer hard-codes, layers/xnor_layers.py:49)."""
+def xnor_input_quant(x, dtype=np.float32):
+    """The input quantiser of XNORConv2d(quant_input=True): sign(x) * mean(|x|, 1, keepdim) (functions/xnor_connect.py:142-143;
+    torch.sign: an exact zero stays zero; the mean runs over the channel dimension of an NCHW tensor -> one scale per pixel)."""
+    x = np.asarray(x, dtype=dtype)
+    mean = np.mean(np.abs(x), axis=1, keepdims=True, dtype=np.float64).astype(dtype)        # see xnor_dense_weight
+    return np.sign(x).astype(dtype) * mean
+
+
+def xnor_conv2d_forward(x, weight, bias=None, stride=1, padding=1, dilation=1, dim=(0, 1), quant_input=False):
+    """XNORConv2d forward (functions/xnor_connect.py:139-146; quant_input False as the layer hard-codes, layers/xnor_layers.py:49;
+    True: the function's own switch, :142-143)."""
+    if quant_input:
+        x = xnor_input_quant(x)
     return conv2d(x, xnor_conv_weight(weight, dim), bias, stride, padding, dilation)
 
 
-def xnor_conv2d_backward(g, x, weight, stride=1, padding=1, dilation=1, dim=(0, 1)):
+def xnor_conv2d_backward(g, x, weight, stride=1, padding=1, dilation=1, dim=(0, 1), quant_input=False):
     """XNORConv2d backward (functions/xnor_connect.py:149-168) in float64: (grad_input, grad_weight, grad_bias).  The weight
-    gradient mixes ``dim`` (the saved mean) with the module-global DIM = 0 (the second term's reduction), as upstream."""
+    gradient mixes ``dim`` (the saved mean) with the module-global DIM = 0 (the second term's reduction), as upstream.
+    quant_input: backward sees the QUANTISED input (it is what forward saved, :144), and grad_input is the plain conv2d_input
+    (straight through the input quantiser: upstream's "TODO backprob input quant", :136)."""
+    if quant_input:
+        x = xnor_input_quant(x, np.float64)
     w = np.asarray(weight, dtype=np.float64)
     sgn = np.sign(w)
     mean = np.mean(np.abs(w), axis=tuple(dim), keepdims=True)

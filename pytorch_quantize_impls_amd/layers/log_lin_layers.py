@@ -57,6 +57,7 @@ class LinearQuant(_WeightInit, EvalSwapMixin, torch.nn.Linear, QLayer):
             wt = None if self.training else self._eval_planes(
                 lambda w2: _fused.ops.weight_bf16x3(w2, "raw", terms=3), key="bf16x3_raw")
             return _fused.ops.float_linear(input, wq.detach(), "raw", self.bias, weight_triples=wt, terms=3)
+        _fused.note_library_path(input, "Lin/Log linear: autograd, a non-fp32 dtype or levels beyond bf16")
         return torch.nn.functional.linear(input, wq, self.bias)
 
 
@@ -97,4 +98,5 @@ class QuantConv2d(_WeightInit, EvalSwapMixin, torch.nn.Conv2d, QLayer):
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous()
             return y
+        _fused.note_library_path(input, "Lin/Log conv: autograd, groups, a non-fp32 dtype or levels beyond bf16")
         return torch.nn.functional.conv2d(input, wq, self.bias, self.stride, self.padding, self.dilation, self.groups)

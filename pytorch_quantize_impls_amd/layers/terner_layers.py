@@ -133,6 +133,11 @@ class TerConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
                                               self.binary_input, args)
         # eval: weight already holds the quantised image; its packed planes are cached
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            # eval-mode forward under autograd: the training node on the stored image (see _eval_linear)
+            if self.padding_mode == "zeros" and not isinstance(self.padding, str) and self._eval_on_grid():
+                return _fused.QuantConv2dFn.apply(input, self.weight, self.bias, "ternary", self.weight.detach(),
+                                                  self.binary_input, args)
+            _fused.note_library_path(input, "eval-mode conv forward under autograd (off-grid weight / non-zero padding mode)")
             return torch.nn.functional.conv2d(input, self.weight, self.bias, *args)
         if not self._eval_on_grid():
             _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")

@@ -647,7 +647,7 @@ def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, trai
     for t in (running_mean, running_var, weight, bias):
         if t is None:
             continue
-        if (type(t) is LazyActivation or t.device != n.device or t.dtype != torch.float32 or t.dim() != 1
+        if (isinstance(t, LazyActivation) or t.device != n.device or t.dtype != torch.float32 or t.dim() != 1
                 or t.numel() != C):
             return NotImplemented
     if (weight is None) != (bias is None) or _untracked(running_mean, running_var, weight, bias):

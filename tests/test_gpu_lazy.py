@@ -143,7 +143,7 @@ def test_chain_feeding_a_second_conv_and_a_linear(dev):
         y3 = fc(b(a(x)).view(3, -1))
     # an eval-mode LinearBin hands its (computed) result out as a "dense" deferred activation: BatchNorm1d -> Hardtanh -> BinaryConnect
     # would be recorded on it, anything else reads the value
-    assert type(y) is lazy.LazyActivation and y._qt.kind == "dense" and type(y.value()) is torch.Tensor
+    assert type(y) is lazy.LazyDense and y._qt.kind == "dense" and type(y.value()) is torch.Tensor
     assert torch.equal(y, e) and torch.equal(y2, e) and torch.equal(y3, e)      # +-1 / 0 operands: exact integers
     assert lazy.STATS["fused"] == 6 and lazy.STATS["materialised"] == 0, lazy.STATS
 
@@ -492,7 +492,7 @@ def test_linear_bn_sign_chain_runs_as_one_pass_and_equals_the_module_chain(dev, 
         before = dict(_lib.call_counts)
         y = seq(x)
         mid = seq[:-1](x)
-    assert type(y) is lazy.LazyActivation and y._qt.kind == "dense"
+    assert type(y) is lazy.LazyDense and y._qt.kind == "dense"
     if width % 4 == 0:
         assert lazy.STATS["dense_fused"] == 1 and lazy.STATS["materialised"] == 0, lazy.STATS       # (`mid` was recorded, never used)
         one_pass = sum(_lib.call_counts.get(k, 0) - before.get(k, 0)
@@ -521,7 +521,7 @@ def test_graph_capture_of_a_model_that_ends_in_a_quantised_linear(dev):
     with torch.no_grad():
         with lazy.eager():
             e = seq(x)
-        assert type(seq(x)) is lazy.LazyActivation
+        assert type(seq(x)) is lazy.LazyDense
         g = utils.graphed(seq, x)
         assert type(g(x)) is torch.Tensor and torch.equal(g(x), e)
         a = utils.auto_graphed(seq)

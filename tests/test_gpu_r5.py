@@ -55,7 +55,10 @@ def test_package_functions_keep_the_graph_to_a_deferred_training_chain(dev, name
     }[name]
     a = _grads(consume, dev, eager=False)
     b = _grads(consume, dev, eager=True)
-    assert torch.equal(a[0], b[0])
+    if name != "bin_stochastic":          # (rand_like follows the memory layout of its argument: different draws; the gradients
+        #                                    do not depend on the draw — backward is the STE mask of the saved input)
+        # the replayed BatchNorm is this backend's statistics kernel, the eager one MIOpen's: last-bit differences
+        assert float((a[0] - b[0]).abs().max()) <= 1e-5 * max(1.0, float(b[0].abs().max())), name
     for u, v in zip(a[1:], b[1:]):
         assert u is not None and v is not None
         assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), name
@@ -131,3 +134,45 @@ def test_one_alpha_per_xnor_conv_weight(dev, shape):
     layer.eval()
     img_alpha = layer.weight.detach().abs().amax((0, 1)).reshape(-1)
     assert torch.equal(img_alpha, taps.alpha)
+
+
+# ---- eval-mode forward with autograd enabled (model.eval(); model(x) without no_grad) ---------------------------
+
+@pytest.mark.parametrize("family", ["binary", "ternary"])
+def test_eval_mode_forward_under_autograd_runs_on_the_own_kernels(dev, family):
+    from pytorch_quantize_impls_amd import _lib
+    from pytorch_quantize_impls_amd.functions import _fused
+    from pytorch_quantize_impls_amd.layers import LinearTer, TerConv2d
+    Lin, Conv = (LinearBin, BinConv2d) if family == "binary" else (LinearTer, TerConv2d)
+    torch.manual_seed(11)
+    conv = Conv(32, 64, 3, padding=1).to(dev)
+    lin = Lin(64 * 6 * 6, 24).to(dev)
+    if family == "ternary":
+        conv.weight.data.uniform_(-1, 1)
+        lin.weight.data.uniform_(-1, 1)
+    conv.eval(), lin.eval()
+    x = torch.randn(8, 32, 6, 6, device=dev).sign().requires_grad_(True)
+    before_lib = dict(_fused.LIBRARY_PATHS)
+    before = dict(_lib.call_counts)
+    y = lin(conv(x).flatten(1))                                   # autograd enabled: the parameters require grad
+    assert type(y) is torch.Tensor and y.grad_fn is not None
+    g = torch.randn_like(y)
+    y.backward(g)
+    moved = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v != before.get(k, 0)}
+    assert any(k.startswith(("qt_conv2d_implicit", "qt_nib_gemm", "qt_xnor_gemm", "qt_tern_gemm")) for k in moved), moved
+    assert {k: v - before_lib.get(k, 0) for k, v in _fused.LIBRARY_PATHS.items() if v != before_lib.get(k, 0)} == {}
+    # the reference expression in fp64 on the stored images
+    wc, wl = conv.weight.detach().double().cpu(), lin.weight.detach().double().cpu()
+    wc.requires_grad_(True), wl.requires_grad_(True)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.linear(torch.nn.functional.conv2d(xr, wc, conv.bias.detach().double().cpu(), padding=1).flatten(1), wl,
+                                    lin.bias.detach().double().cpu())
+    yr.backward(g.double().cpu())
+    for got, want in ((y, yr), (x.grad, xr.grad), (conv.weight.grad, wc.grad), (lin.weight.grad, wl.grad)):
+        assert float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()) <= 1e-5
+    # an off-grid weight (a float checkpoint loaded after .eval()) under autograd: the dense expression, counted
+    lin.weight.data.normal_()
+    lin.reset_quant_cache()
+    before_lib = dict(_fused.LIBRARY_PATHS)
+    lin(torch.randn(4, 64 * 6 * 6, device=dev).sign().requires_grad_(True))
+    assert sum(_fused.LIBRARY_PATHS.values()) == sum(before_lib.values()) + 1

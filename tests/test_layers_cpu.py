@@ -403,3 +403,26 @@ def test_no_bare_dense_library_call_in_the_functional_forms():
             for m in re.finditer(pat, code):
                 bad.append((os.path.basename(path), m.group(0)))
     assert not bad, bad
+
+
+def test_every_dense_library_call_of_the_layers_is_counted():
+    """a layer that falls back to F.linear / F.conv2d on a device tensor says so (note_library_path within the
+    three code lines above the call), so _fused.LIBRARY_PATHS sees every hipBLASLt / MIOpen forward the layers can make."""
+    import glob
+    import os
+    import re
+    import pytorch_quantize_impls_amd.layers as L_
+    root = os.path.dirname(L_.__file__)
+    bad, seen = [], 0
+    for path in sorted(glob.glob(os.path.join(root, "*.py"))):
+        text = open(path, encoding="utf-8").read()
+        text = re.sub(r'"""(.|\n)*?"""', lambda m: "\n" * m.group(0).count("\n"), text)       # docstrings cite upstream lines
+        lines = [ln.split("#", 1)[0].rstrip() for ln in text.split("\n")]
+        code = [(i, ln) for i, ln in enumerate(lines) if ln.strip()]
+        for j, (i, ln) in enumerate(code):
+            if re.search(r"(functional|\bF)\.(linear|conv2d)\(", ln):
+                seen += 1
+                before = " ".join(c for _, c in code[max(0, j - 3):j])
+                if "note_library_path" not in before:
+                    bad.append((os.path.basename(path), i + 1))
+    assert seen >= 10 and not bad, bad
