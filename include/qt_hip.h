@@ -174,6 +174,14 @@ int qt_xnor_act_f32(const float* x, int64_t ldx, float* mean, float* work, float
 int qt_xnor_act_backward_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* mean, float* gmean,
                              float* work, float* gin, int64_t ldi, int64_t R, int64_t C, int dim, qt_stream_t stream);
 
+/* Input quantiser of XNORConv2d(quant_input = True) (functions/xnor_connect.py:142-143):
+ *   y[n, c, h, w] = sign(x[n, c, h, w]) * mean_c |x[n, :, h, w]|        torch.sign (0 -> 0, NaN -> NaN), one scale per pixel.
+ * x: logical [N, C, H, W] fp32 with ELEMENT strides (sn, sc, sh, sw) (contiguous NCHW or channels-last); y: the same logical
+ * tensor written densely in NHWC memory order [N][H][W][C] — the layout the per-tap scaled conv's operand pack and the
+ * weight-gradient routes read (backward sees this quantised tensor, :144). */
+int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int64_t N, int64_t C,
+                            int64_t H, int64_t W, qt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bit-pack kernels (fp32 -> packed planes).  rows x K fp32 (row stride ldx) ->
  * rows x ldp uint32 (only the first ceil(K/32) words of a row carry data, the rest are 0).

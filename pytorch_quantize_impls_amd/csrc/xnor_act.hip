@@ -129,6 +129,53 @@ int check_args(const float* x, int64_t ldx, const float* mean, const float* work
     return QT_OK;
 }
 
+
+// ---- input quantiser of XNORConv2d(quant_input=True): y = sign(x) * mean(|x|, channel dim) per pixel ---------------------------------
+// (functions/xnor_connect.py:142-143; torch.sign: +-0 -> +-0, NaN -> NaN).  x: logical [N, C, H, W] with element strides
+// (sn, sc, sh, sw); y: the same logical tensor written in NHWC memory order (what the per-tap scaled conv's operand pack and
+// the weight-gradient routes read).  HBM-bound: one read of x (the second walk of a pixel's channels hits L1 / L2), one write.
+//   channels-last input (sc == 1): G = 4 .. 64 lanes share a pixel (lanes along the channels: coalesced), butterfly sum;
+//   NCHW input: one thread per pixel (lanes along w: every channel's read is coalesced), the NHWC writes are strided.
+template <int G>
+__global__ __launch_bounds__(256) void xnor_input_quant_cl_kernel(const float* __restrict__ x, int64_t sn, int64_t sh, int64_t sw,
+                                                                  float* __restrict__ y, int64_t P, int C, int H, int W) {
+    const int sub = threadIdx.x % G;
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, ngroups = (int64_t)gridDim.x * blockDim.x / G;
+    const float inv_note = (float)C;
+    for (int64_t p = gid; p < P; p += ngroups) {
+        const int64_t n = p / ((int64_t)H * W), r = p - n * (int64_t)H * W;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const float* px = x + n * sn + h * sh + w * sw;
+        float acc = 0.0f;
+        for (int c = sub; c < C; c += G) acc += fabsf(px[c]);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+        const float a = acc / inv_note;
+        float* py = y + p * C;
+        for (int c = sub; c < C; c += G) {
+            const float v = px[c];
+            py[c] = (v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v)) * a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void xnor_input_quant_strided_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh,
+                                                                       int64_t sw, float* __restrict__ y, int64_t P, int C, int H, int W) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = p / ((int64_t)H * W), r = p - n * (int64_t)H * W;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const float* px = x + n * sn + h * sh + w * sw;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc += fabsf(px[c * sc]);
+        const float a = acc / (float)C;
+        float* py = y + p * C;
+        for (int c = 0; c < C; ++c) {
+            const float v = px[c * sc];
+            py[c] = (v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v)) * a;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -154,6 +201,32 @@ int qt_xnor_act_backward_f32(const float* g, int64_t ldg, const float* x, int64_
     launch_mean<true>(x, ldx, g, ldg, gmean, work, R, C, dim, (hipStream_t)stream);
     hipLaunchKernelGGL((xnor_scale_kernel<true>), dim3(qt_stream_grid((R * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, g, ldg, mean, gmean, gin, ldi, R, C, dim);
+    return qt_check_launch();
+}
+
+int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int64_t N, int64_t C,
+                            int64_t H, int64_t W, qt_stream_t stream) {
+    if (N < 0 || C < 0 || H < 0 || W < 0) return QT_ERR_INVALID_ARG;
+    const int64_t P = N * H * W;
+    if (P == 0 || C == 0) return QT_OK;
+    if (!x || !y || C > (1 << 24) || H > (1 << 24) || W > (1 << 24)) return QT_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (sc == 1) {
+        const int G = C >= 48 ? 64 : C >= 24 ? 32 : C >= 12 ? 16 : C >= 6 ? 8 : 4;
+        const int grid = qt_stream_grid((P * G + 255) / 256);
+#define QT_XIQ(g) hipLaunchKernelGGL((xnor_input_quant_cl_kernel<g>), dim3(grid), dim3(256), 0, st, x, sn, sh, sw, y, P, (int)C, (int)H, (int)W)
+        switch (G) {
+            case 64: QT_XIQ(64); break;
+            case 32: QT_XIQ(32); break;
+            case 16: QT_XIQ(16); break;
+            case 8: QT_XIQ(8); break;
+            default: QT_XIQ(4); break;
+        }
+#undef QT_XIQ
+    } else {
+        hipLaunchKernelGGL(xnor_input_quant_strided_kernel, dim3(qt_stream_grid((P + 255) / 256)), dim3(256), 0, st, x, sn, sc, sh, sw,
+                           y, P, (int)C, (int)H, (int)W);
+    }
     return qt_check_launch();
 }
 

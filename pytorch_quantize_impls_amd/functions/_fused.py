@@ -759,7 +759,8 @@ def conv_grad_input(input_shape, weight_q, grad_output, stride, padding, dilatio
     return lib_conv2d_input(input_shape, wq, grad_output, stride, padding, dilation, groups)
 
 
-def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation, groups, x_is_pm1: bool, bias_by_product=None):
+def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation, groups, x_is_pm1: bool, bias_by_product=None,
+                     real_any_channels: bool = False):
     """UN-masked grad wrt the weight of conv2d(x, .): +-1 activations on the weight-gradient routes, a real-valued image with few
     channels (first layers) through the space-to-depth form; anything else on the library, counted."""
     go = _dense(grad_output)
@@ -770,6 +771,9 @@ def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation
             gw = pm1_conv_grad_weight(input, go, weight_shape, stride, padding, dilation, bias_by_product)
         elif ops.wgrad_s2d_applicable(input.shape, weight_shape[2:], stride, dilation):
             gw = ops.conv2d_grad_weight_s2d(input, go, weight_shape, stride, padding, weight=None, bias_grad=bias_by_product)
+        elif real_any_channels and ops.wgrad_s2d_applicable(input.shape, weight_shape[2:], stride, dilation, True):
+            gw = ops.conv2d_grad_weight_s2d(input, go, weight_shape, stride, padding, weight=None, bias_grad=bias_by_product,
+                                            any_channels=True)
         if gw is not None:
             return gw
     return lib_conv2d_weight(input, weight_shape, grad_output, stride, padding, dilation, groups)

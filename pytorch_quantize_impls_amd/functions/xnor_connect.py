@@ -161,9 +161,24 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
                     if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                         y = y.contiguous()
                     return y
-            weight_b, mean_weight = xnor_weight(weight, dim)
             if quant_input:
-                input = torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
+                # both operands binarised (:142-143): x -> sign(x) * mean(|x|, 1) per pixel, one pass; backward sees this
+                # quantised tensor (:144).  With one alpha per tap it is a REAL activation against sign(W): the two-term fp16
+                # split on the per-tap scaled conv (alpha on the accumulators), not the six-term real x real conv
+                on_dev = input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0
+                input = ops.xnor_input_quant(input) if on_dev else torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
+                if (on_dev and _fused.xnor_conv_fast_applicable(input, weight, dim, groups, padding)
+                        and int(weight.shape[1]) % 8 == 0 and weight.is_cuda):
+                    taps = ops.xnor_tap_prep(weight)
+                    y2 = ops.conv2d_real_taps(input, weight, taps.fwd, bias, stride, padding, dilation)
+                    if y2 is not None:
+                        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+                        ctx.taps = taps                                   # grad_input: the flipped taps, like the +-1 route
+                        ctx.save_for_backward(input, weight, taps.alpha.view(1, 1, kh, kw), bias)
+                        N_, _, H, W = input.shape
+                        Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+                        return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+            weight_b, mean_weight = xnor_weight(weight, dim)
             ctx.save_for_backward(input, weight, mean_weight, bias)
             if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0
                     and groups == 1 and not isinstance(padding, str)):
@@ -192,7 +207,7 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
             input, weight, mean, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             go = _fused._dense(grad_output)
-            mfma = (_fused.BWD_CONV_MFMA and ctx.x_is_pm1 and go.is_cuda and go.dtype == torch.float32 and groups == 1
+            mfma = (_fused.BWD_CONV_MFMA and ctx.taps is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
                     and not isinstance(padding, str))
             if ctx.needs_input_grad[0]:
                 if mfma:
@@ -203,8 +218,10 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
             want_bias = bias is not None and ctx.needs_input_grad[2]
             by_product = []
             if ctx.needs_input_grad[1]:
+                # (quant_input: the saved input is the quantised, real-valued one — its terms go in as channel groups of the
+                #  pixel-major weight-gradient kernel)
                 gw = _fused.conv_grad_weight(input, weight.shape, grad_output, stride, padding, dilation, groups, ctx.x_is_pm1,
-                                             by_product if want_bias else None)
+                                             by_product if want_bias else None, real_any_channels=quant_input)
                 grad_weight = _fused.xnor_weight_grad(gw, weight, mean, DIM)
             if want_bias:
                 grad_bias = by_product[0] if by_product else grad_output.sum((0, 2, 3))

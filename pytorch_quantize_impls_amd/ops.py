@@ -386,6 +386,22 @@ def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
     return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
 
 
+def xnor_input_quant(x: torch.Tensor) -> torch.Tensor:
+    """Input quantiser of XNORConv2d(quant_input=True): sign(x) * mean(|x|, 1, keepdim) (functions/xnor_connect.py:142-143) for an
+    NCHW or channels-last fp32 tensor, one pass (qt_xnor_input_quant_f32).  The result is the same logical [N, C, H, W] tensor in
+    channels-last memory (its NHWC matrix is what the conv's operand pack and the weight-gradient routes read)."""
+    x = _require(x, "input")
+    if x.dim() != 4:
+        raise ValueError("xnor_input_quant takes a [N, C, H, W] tensor")
+    N, C, H, W = (int(v) for v in x.shape)
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    if x.numel():
+        sn, sc, sh, sw = (int(v) for v in x.stride())
+        with _on(x.device):
+            _lib.call("qt_xnor_input_quant_f32", _p(x), sn, sc, sh, sw, _p(y), N, C, H, W, _stream(x.device))
+    return y.permute(0, 3, 1, 2)
+
+
 def shift_batch(x: torch.Tensor, running_mean, running_var, weight, bias, eps: float, want_saved: bool = True):
     """ShiftBatch.forward on the device (qt_shift_batch_f32): x [N, ...], the four statistic / affine tensors hold one
     entry per element of x[0] (broadcast over N).  Returns (y, norm_inputs or None, sqrtvar or None)."""
@@ -1430,6 +1446,29 @@ def conv2d_nib_taps(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, 
     bias = _check_bias(bias, Cout, pixels.device)
     return _conv_taps(0, pixels.words, N, H, W, Cw, kh, kw, (_pairs(stride), _pairs(padding), _pairs(dilation)), wplanes.words,
                       wplanes.ld, bias, 1.0, None, tap_rho, Cout, epi=epi)
+
+
+def conv2d_real_taps(x: torch.Tensor, weight: torch.Tensor, tap_rho: torch.Tensor, bias=None, stride=1, padding=0, dilation=1,
+                     weight_planes: Optional["TriplePlanes"] = None):
+    """conv2d(x, sign(W) * alpha[1, 1, kh, kw]) for a REAL-valued x (XNORConv2d with quant_input=True: x = sign(.) * per-pixel
+    scale, functions/xnor_connect.py:142-145): the two-term fp16 split of x against the +-1 / 0 image of sign(W) on the fp16 matrix
+    cores, alpha applied per tap on the accumulators (qt_conv2d_implicit_taps, elem 3; ``tap_rho`` = TapScales.fwd) — two fp16
+    passes instead of the six bf16 passes of a real x real conv.  Cin % 8 == 0 (a tap of the pair plane = whole 32-byte k-steps).
+    Returns the NHWC result [N*Ho*Wo, Cout], or None when the shape is outside the kernel's limits."""
+    _require(x, "input")
+    Cout, Cin, kh, kw = (int(v) for v in weight.shape)
+    N, C, H, W = (int(v) for v in x.shape)
+    if C != Cin or Cin % 8 or x.numel() == 0:
+        return None
+    Cb = triple_ld_bytes(Cin, 16, 2)
+    nhwc = x.detach().permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    px = split_bf16x3(nhwc.view(N * H * W, Cin), ld_bytes=Cb, terms=2)
+    wt = weight_planes if weight_planes is not None else pack_conv_weight_bf16x3(weight.detach(), "sign", terms=2)
+    bias = _check_bias(bias, Cout, x.device)
+    return _conv_taps(3, px.data, N, H, W, Cb // 4, kh, kw, (_pairs(stride), _pairs(padding), _pairs(dilation)), wt.data, wt.ld_words,
+                      bias, 1.0, px.scale[0:1], tap_rho, Cout)
 
 
 def alpha_pairs(alpha: torch.Tensor) -> "TriplePlanes":
@@ -2530,21 +2569,26 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
                          bias_grad, terms=split_terms(terms))
 
 
-def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation) -> bool:
+def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation, any_channels: bool = False) -> bool:
     """A conv over a few REAL-VALUED input channels — strided (the first layer: AlexNet's 3 -> 192, k 11, stride 4) or stride 1
     with <= 8 channels (VGG's 3 -> 64): its weight gradient runs on the pixel-major kernel through the space-to-depth image
     (``conv2d_grad_weight_s2d``; s = 1 is just the three-term split of the image as channel groups)."""
     (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
     kh, kw = (int(v) for v in kernel_hw)
     k2 = -(-kh // max(sh, 1))
+    if any_channels:
+        # a real-valued activation with MANY channels (XNORConv2d with quant_input=True: sign(x) * per-pixel scale): stride 1 only,
+        # the two / three terms of the image as channel groups of the same kernel (the plan decides whether the planes fit)
+        return sh == sw == 1 and dh == dw == 1 and kh == kw and kh in (3, 5)
     return (sh == sw and dh == dw == 1 and kh == kw and kh >= sh and k2 in (3, 5)
             and (sh > 1 or int(x_shape[1]) <= 8) and 3 * int(x_shape[1]) * sh * sh <= 256)
 
 
 def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_shape, stride, padding,
                            weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
-                           bias_grad: Optional[list] = None, terms: Optional[int] = None):
-    """grad wrt the weight of a strided conv2d over a real-valued fp32 image with few channels.  The stride-s conv is the
+                           bias_grad: Optional[list] = None, terms: Optional[int] = None, any_channels: bool = False):
+    """grad wrt the weight of a strided conv2d over a real-valued fp32 image with few channels (``any_channels``: a stride-1
+    3 x 3 / 5 x 5 conv over a real-valued activation of any width).  The stride-s conv is the
     stride-1 conv of the space-to-depth image ([N, C s^2, H / s, W / s], kernel ceil(k / s)) — the identity the forward uses
     (``s2d_weight``) — so the gradient of the s2d weight comes from ``conv2d_grad_weight_pm`` and is folded back with
     pixel_shuffle (the taps the rounding added are dropped).  The image is real-valued: its split goes in as channel groups —
@@ -2555,7 +2599,7 @@ def conv2d_grad_weight_s2d(x: torch.Tensor, grad_output: torch.Tensor, weight_sh
     _require(grad_output, "grad_output")
     Cout, C, kh, kw = (int(v) for v in weight_shape)
     (sh, sw), (ph, pw) = _pairs(stride), _pairs(padding)
-    if not wgrad_s2d_applicable(x.shape, (kh, kw), stride, 1):
+    if not wgrad_s2d_applicable(x.shape, (kh, kw), stride, 1, any_channels):
         return None
     s = sh
     k2 = -(-kh // s)
