@@ -774,9 +774,36 @@ def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation
         elif real_any_channels and ops.wgrad_s2d_applicable(input.shape, weight_shape[2:], stride, dilation, True):
             gw = ops.conv2d_grad_weight_s2d(input, go, weight_shape, stride, padding, weight=None, bias_grad=bias_by_product,
                                             any_channels=True)
+        if gw is None and real_any_channels:
+            gw = real_conv_grad_weight_taps(input, go, weight_shape, stride, padding, dilation)
         if gw is not None:
             return gw
     return lib_conv2d_weight(input, weight_shape, grad_output, stride, padding, dilation, groups)
+
+
+def real_conv_grad_weight_taps(input, go, weight_shape, stride, padding, dilation):
+    """grad wrt the weight of conv2d(x, .) for two REAL operands of any geometry (groups == 1), one six-term real x real GEMM per
+    filter tap on the bf16 matrix cores:  dW[:, :, i, j] = G^T . X_ij  with G [n ho wo, Cout] the gradient and X_ij [n ho wo, Cin] the
+    tap-shifted, strided view of the zero-padded input.  The general fallback of the real-valued layers (DoReFa at 8 < k <= 32, the
+    quantised input of XNORConv2d) where the pixel-major kernel's geometry (stride 1, 3 x 3 / 5 x 5) does not apply: kh * kw launches
+    of K = N Ho Wo, fp32-GEMM accuracy, no dense library.  None for host tensors / empty operands."""
+    if not (go.is_cuda and input.is_cuda and go.dtype == torch.float32 and input.dtype == torch.float32 and go.numel() > 0
+            and input.numel() > 0):
+        return None
+    Cout, Cin, kh, kw = (int(v) for v in weight_shape)
+    (sh, sw), (ph, pw), (dh, dw) = ops._pairs(stride), ops._pairs(padding), ops._pairs(dilation)
+    N_, _, Ho, Wo = (int(v) for v in go.shape)
+    x = input.detach()
+    if ph or pw:
+        x = F.pad(x, (pw, pw, ph, ph))
+    g2t = go.detach().permute(1, 0, 2, 3).reshape(Cout, -1).contiguous()                 # [Cout, n ho wo]
+    gw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=go.device)
+    for i in range(kh):
+        for j in range(kw):
+            xs = x[:, :, i * dh:i * dh + sh * (Ho - 1) + 1:sh, j * dw:j * dw + sw * (Wo - 1) + 1:sw]
+            x2t = xs.permute(1, 0, 2, 3).reshape(Cin, -1).contiguous()                   # [Cin, n ho wo]
+            gw[:, :, i, j] = ops.real_linear(g2t, x2t)                                    # G^T . X_ij  = g2t . x2t^T
+    return gw
 
 
 # ---- XNOR-Net family (functions/xnor_connect.py:93-169, layers/xnor_layers.py) ------------------------------------------------------
@@ -1333,7 +1360,8 @@ class RealLinearFn(QtFunction):
 class RealConv2dFn(QtFunction):
     """F.conv2d(x, W, b) for two REAL fp32 device operands (groups == 1, zero padding): DorefaConv2d(bit_width = 32).  Forward and
     — for stride 1, dilation 1 — grad_x (the conv of the gradient with the flipped, transposed weight) on the six-term implicit
-    GEMM; grad_W of two real operands stays on the library unless the first-layer form applies (counted)."""
+    GEMM; grad_W on the pixel-major kernel (stride 1, 3 x 3 / 5 x 5: the image's terms as channel groups) or one six-term GEMM per
+    filter tap (real_conv_grad_weight_taps)."""
 
     @staticmethod
     def forward(ctx, input, weight, bias, conv_args):
@@ -1351,10 +1379,11 @@ class RealConv2dFn(QtFunction):
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         (sh, sw), (ph, pw), (dh, dw) = ops._pairs(stride), ops._pairs(padding), ops._pairs(dilation)
         if ctx.needs_input_grad[0]:
-            if (go.is_cuda and go.dtype == torch.float32 and go.numel() > 0 and (sh, sw, dh, dw) == (1, 1, 1, 1)
+            if (go.is_cuda and go.dtype == torch.float32 and go.numel() > 0 and sh == sw and (dh, dw) == (1, 1)
                     and ph <= kh - 1 and pw <= kw - 1):
                 wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
-                y2 = ops.real_conv2d(go, wt, None, 1, (kh - 1 - ph, kw - 1 - pw), 1)
+                gd = go if sh == 1 else ops.zero_dilated_gradient(go, input.shape, (kh, kw), sh, (ph, pw))   # stride s: conv_transpose
+                y2 = ops.real_conv2d(gd, wt, None, 1, (kh - 1 - ph, kw - 1 - pw), 1) if gd is not None else None
                 if y2 is not None:
                     N_, C, H, W = input.shape
                     grad_input = y2.view(N_, H, W, C).permute(0, 3, 1, 2)
@@ -1363,7 +1392,8 @@ class RealConv2dFn(QtFunction):
             if grad_input is None:
                 grad_input = lib_conv2d_input(input.shape, weight, go, stride, padding, dilation, groups)
         if ctx.needs_input_grad[1]:
-            grad_weight = conv_grad_weight(input, weight.shape, go, stride, padding, dilation, groups, x_is_pm1=False)
+            grad_weight = conv_grad_weight(input, weight.shape, go, stride, padding, dilation, groups, x_is_pm1=False,
+                                           real_any_channels=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = go.sum((0, 2, 3))
         return grad_input, grad_weight, grad_bias, None

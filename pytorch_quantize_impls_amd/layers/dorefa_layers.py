@@ -32,7 +32,9 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         k = int(self.bit_width)
         if k == 1:                      # sign(W) * E: every magnitude equals the scale
             return (w.abs() == w.abs().amax()).all()
-        if k >= 32:
+        if k > _fused.LEVEL_MAX_BITS:
+            # 2^k - 1 levels beyond fp32's reach to verify (and the identity at k = 32): these widths run the real x real
+            # routes, which multiply by whatever ``weight`` holds — like upstream — and need no grid guarantee
             return torch.ones((), dtype=torch.bool, device=w.device)
         n = float((1 << k) - 1)         # levels (2 q - n) / n: n * w is an integer of the parity of n, |.| <= n
         c = w * n
@@ -83,12 +85,16 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
                 and self.weight.dtype == torch.float32):
             # WkAk training: level image x codes / exact split on the matrix cores, forward and both gradients
             return _fused.DorefaWkLinearFn.apply(input, w, self.bias, self.bit_width)
-        if (input.is_cuda and self.bit_width == 32 and input.dtype == torch.float32 and self.weight.dtype == torch.float32
-                and input.numel() > 0 and input.dim() >= 2):
-            # the identity quantiser (functions/dorefa_connect.py:19-20, 100-101): two real operands, six-term planes
+        if (input.is_cuda and input.dtype == torch.float32 and self.weight.dtype == torch.float32 and input.numel() > 0
+                and input.dim() >= 2):
+            # two real operands on the six-term planes (fp32-GEMM accuracy), forward and both gradients:
+            #   bit_width = 32: the identity quantiser (functions/dorefa_connect.py:19-20, 100-101);
+            #   8 < bit_width < 32: 2^k - 1 levels are past the exact level images (functions/dorefa_connect.py:21-25 accepts any
+            #     k) — the quantised weight is a real tensor like any other, its straight-through backward is weight_op's;
+            #   eval mode under autograd (any k): F.linear on the stored image is the reference expression
             return _fused.RealLinearFn.apply(input, w, self.bias)
         if input.is_cuda:
-            _fused.note_library_path(input, "DoReFa linear with 8 < bit_width < 32, a non-fp32 dtype, or autograd in eval mode with k-bit weights")
+            _fused.note_library_path(input, "DoReFa linear in a non-fp32 dtype")
         return torch.nn.functional.linear(input, w, self.bias)
 
 
@@ -117,7 +123,9 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         k = int(self.bit_width)
         if k == 1:                      # sign(W) * E: every magnitude equals the scale
             return (w.abs() == w.abs().amax()).all()
-        if k >= 32:
+        if k > _fused.LEVEL_MAX_BITS:
+            # 2^k - 1 levels beyond fp32's reach to verify (and the identity at k = 32): these widths run the real x real
+            # routes, which multiply by whatever ``weight`` holds — like upstream — and need no grid guarantee
             return torch.ones((), dtype=torch.bool, device=w.device)
         n = float((1 << k) - 1)         # levels (2 q - n) / n: n * w is an integer of the parity of n, |.| <= n
         c = w * n
@@ -176,10 +184,11 @@ class DorefaConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         if (input.is_cuda and self.training and 2 <= self.bit_width <= _fused.LEVEL_MAX_BITS and input.dtype == torch.float32
                 and self.weight.dtype == torch.float32 and self.groups == 1 and self.padding_mode == "zeros"):
             return _fused.DorefaWkConv2dFn.apply(input, w, self.bias, self.bit_width, args)
-        if (input.is_cuda and self.bit_width == 32 and input.dtype == torch.float32 and self.weight.dtype == torch.float32
+        if (input.is_cuda and input.dtype == torch.float32 and self.weight.dtype == torch.float32
                 and input.dim() == 4 and input.numel() > 0 and self.groups == 1 and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str)):
+            # real x real on the six-term planes: bit_width = 32, 8 < bit_width < 32, eval mode under autograd (see LinearDorefa)
             return _fused.RealConv2dFn.apply(input, w, self.bias, args)
         if input.is_cuda:
-            _fused.note_library_path(input, "DoReFa conv with 8 < bit_width < 32, groups, a non-fp32 dtype, or autograd in eval mode with k-bit weights")
+            _fused.note_library_path(input, "DoReFa conv with groups, a non-zero padding mode or a non-fp32 dtype")
         return torch.nn.functional.conv2d(input, w, self.bias, *args)

@@ -2114,6 +2114,23 @@ def bn_act_train_backward(grad_out: torch.Tensor, xs: torch.Tensor, res, gamma, 
 #            "weight" under the kernel's 1 MiB K limit and give the launch enough tiles, partial results added in fp32.
 # Reference expressions: functions/binary_connect.py:141-143 (torch.nn.grad.conv2d_input / conv2d_weight).
 
+def zero_dilated_gradient(grad_output: torch.Tensor, input_shape, kernel_hw, stride: int, padding):
+    """The gradient of a stride-s conv (square stride, un-dilated) as the operand of the equivalent STRIDE-1 transposed conv:
+    g_d[.., s y, s x] = g[.., y, x], zeros elsewhere, with ``H + 2p - k - (Ho - 1) s`` rows / columns of zeros appended (the input
+    rows the strided windows never reached).  Logical NCHW over NHWC memory.  None when the shapes do not belong together."""
+    s = int(stride)
+    kh, kw = (int(v) for v in kernel_hw)
+    ph, pw = _pairs(padding)
+    N, C, H, W = (int(v) for v in input_shape)
+    _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
+    eh, ew = H + 2 * ph - kh - (Ho - 1) * s, W + 2 * pw - kw - (Wo - 1) * s
+    if not (0 <= eh < s and 0 <= ew < s):
+        return None
+    gd = torch.zeros((N, (Ho - 1) * s + 1 + eh, (Wo - 1) * s + 1 + ew, Cout), dtype=grad_output.dtype, device=grad_output.device)
+    gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = grad_output.permute(0, 2, 3, 1)
+    return gd.permute(0, 3, 1, 2)
+
+
 def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.Tensor, stride, padding, dilation,
                         kind: str = "sign", out_scale: float = 1.0, out_scale_dev: Optional[torch.Tensor] = None):
     """grad wrt the input of conv2d(x, Q(weight_q)): ``weight_q`` already quantised — +-1 / 0 (``kind`` "sign") or integer
@@ -2133,14 +2150,9 @@ def conv2d_grad_input_q(input_shape, weight_q: torch.Tensor, grad_output: torch.
     N, C, H, W = (int(v) for v in input_shape)
     g = grad_output
     if sh > 1:
-        s = sh
-        _, _, Ho, Wo = (int(v) for v in g.shape)
-        eh, ew = H + 2 * ph - kh - (Ho - 1) * s, W + 2 * pw - kw - (Wo - 1) * s
-        if not (0 <= eh < s and 0 <= ew < s):
+        g = zero_dilated_gradient(g, input_shape, (kh, kw), sh, (ph, pw))
+        if g is None:
             return None
-        gd = torch.zeros((N, (Ho - 1) * s + 1 + eh, (Wo - 1) * s + 1 + ew, Cout), dtype=g.dtype, device=g.device)   # NHWC
-        gd[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s, :] = g.permute(0, 2, 3, 1)
-        g = gd.permute(0, 3, 1, 2)
     # the flipped, transposed weight [Cin, Cout, kh, kw] only ever exists as the conv's packed operand
     wt = pack_conv_weight_bf16x3(weight_q.detach(), kind, transpose_flip=True)
     shape_t = torch.empty((Cin, Cout, kh, kw), dtype=torch.float32, device="meta")
@@ -2153,14 +2165,19 @@ def conv2d_grad_input_taps(input_shape, weight: torch.Tensor, grad_output: torch
                            padding, dilation):
     """grad wrt the input of an XNOR-Net conv, conv2d(x, sign(W) * alpha[1, 1, kh, kw]) (functions/xnor_connect.py:154-155):
     the two-term fp16 split of the gradient against the flipped, transposed sign(W) on the fp16 matrix cores, alpha applied per
-    (flipped) tap on the accumulators (qt_conv2d_implicit_taps, elem 3; ``tap_rho_flipped`` = TapScales.bwd).  Stride 1,
-    un-dilated, padding <= k - 1, Cout % 8 == 0 (a tap of the pair plane = whole 32-byte k-steps); None otherwise."""
+    (flipped) tap on the accumulators (qt_conv2d_implicit_taps, elem 3; ``tap_rho_flipped`` = TapScales.bwd).  Square stride
+    (s > 1 through the zero-dilated gradient), un-dilated, padding <= k - 1, Cout % 8 == 0 (a tap of the pair plane = whole 32-byte
+    k-steps); None otherwise."""
     (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
     Cout, Cin, kh, kw = (int(v) for v in weight.shape)
-    if (sh, sw) != (1, 1) or (dh, dw) != (1, 1) or ph > kh - 1 or pw > kw - 1 or Cout % 8:
+    if sh != sw or sh < 1 or (dh, dw) != (1, 1) or ph > kh - 1 or pw > kw - 1 or Cout % 8:
         return None
     N, C, H, W = (int(v) for v in input_shape)
     g = _require(grad_output, "grad_output")
+    if sh > 1:                                     # square stride: the zero-dilated gradient (see conv2d_grad_input_q)
+        g = zero_dilated_gradient(g, input_shape, (kh, kw), sh, (ph, pw))
+        if g is None:
+            return None
     _, _, Ho, Wo = (int(v) for v in g.shape)
     wt = pack_conv_weight_bf16x3(weight.detach(), "sign", terms=2, transpose_flip=True)        # [Cin, kh*kw*Cb/2] fp16 pairs
     Cb = triple_ld_bytes(Cout, 16, 2)

@@ -79,3 +79,28 @@ def test_input_quantiser_keeps_zeros_and_scales_per_pixel(oracle):
     q = oracle.xnor_input_quant(x)
     a0, a1 = np.float32(2.0 / 3.0), np.float32(2.0)
     assert np.array_equal(q, np.array([[[[a0, -a1]], [[0.0, a1]], [[-a0, 0.0]]]], dtype=np.float32))
+
+
+# ---- G23: DoReFa layers at 8 < bit_width < 32 (tests/golden/make_golden_r5b.py) -----------------------------------------------------
+
+G23 = ["conv12_s1_codes", "conv16_s2_real", "conv16_s1_codes", "lin12_real", "lin16_codes", "lin9_codes"]
+
+
+@pytest.mark.parametrize("name", G23)
+def test_oracle_dorefa_9_to_16_bit_forward_vs_reference_fp64(oracle, name):
+    """The oracle's nnQuantWeight + conv2d / linear (functions/dorefa_connect.py:99-111, layers/dorefa_layers.py:41-45, 77-82) against the
+    reference's own layers run in double precision: the weights sit away from the rounding boundaries, so the fp32 quantiser picks
+    the reference's levels (checked: n * w_q is an odd-parity integer grid point within 2^-24 n)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "golden_r5b_v1.npz"), allow_pickle=False)
+    x, w, b, want = (g[f"g23_{name}_{k}"] for k in ("x", "w", "b", "y"))
+    geom = [int(v) for v in g[f"g23_{name}_geom"]]
+    bits = geom[-2]
+    wq = oracle.dorefa_weight(w, bits)
+    n = float((1 << bits) - 1)
+    lv = np.round(wq.astype(np.float64) * n)
+    assert np.abs(wq.astype(np.float64) * n - lv).max() < 0.02 and np.all(np.mod(lv + n, 2) == 0) and np.abs(lv).max() == n
+    if name.startswith("conv"):
+        y = oracle.conv2d(x, wq, b, geom[5], geom[6])
+    else:
+        y = oracle.linear(x, wq, b)
+    assert np.abs(y.astype(np.float64) - want).max() <= 1e-5 * np.abs(want).max()
