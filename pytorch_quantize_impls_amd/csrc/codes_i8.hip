@@ -88,6 +88,67 @@ __global__ __launch_bounds__(256) void bn_eval_device_kernel(const float* __rest
 //     [-> ReLU] -> nnDorefaQuant(k): q = rint(n * t)   (functions/dorefa_connect.py:24-25, unclamped)
 // written as the next layer's int8 code plane (and, on request, the fp32 image fl(fl(1/n) * q)).
 // One thread = 4 consecutive channels; per element 4 B in (+ 4 B or 1 B residual), 1 B out: HBM-bound.
+// Per-channel constants of one thread's 4 channels (loaded once per thread on the fixed-slot path).
+struct AffineConsts {
+    float al[4], be[4], mean[4], rs[4], ral[4], rbe[4], rmean[4], rrs[4];
+};
+
+__device__ __forceinline__ void affine_load_consts(AffineConsts& c, int64_t k0, int64_t C, const float* __restrict__ alpha,
+                                                   const float* __restrict__ beta, const float* __restrict__ ralpha,
+                                                   const float* __restrict__ rbeta, const float* __restrict__ bn_stats,
+                                                   const float* __restrict__ rbn_stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool in = k0 + e < C;
+        c.al[e] = in ? alpha[k0 + e] : 0.0f;
+        c.be[e] = in ? beta[k0 + e] : 0.0f;
+        c.mean[e] = (in && bn_stats) ? bn_stats[k0 + e] : 0.0f;
+        c.rs[e] = (in && bn_stats) ? bn_stats[C + k0 + e] : 1.0f;
+        c.ral[e] = (in && ralpha) ? ralpha[k0 + e] : 1.0f;
+        c.rbe[e] = (in && ralpha) ? rbeta[k0 + e] : 0.0f;
+        c.rmean[e] = (in && rbn_stats) ? rbn_stats[k0 + e] : 0.0f;
+        c.rrs[e] = (in && rbn_stats) ? rbn_stats[C + k0 + e] : 1.0f;
+    }
+}
+
+// one output dword (4 channels of one row): the arithmetic of the header comment, every rounding spelled out
+__device__ __forceinline__ uint32_t affine_codes_word(const float (&v)[4], const float (&r)[4], uint32_t rword, const AffineConsts& c,
+                                                      int nvalid, bool devbn, bool has_rf, bool has_ralpha, bool rdevbn, bool has_rc,
+                                                      float rscale, int relu, float n, float (&q4)[4], int& bad) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int q = 0;
+        q4[e] = 0.0f;
+        if (e < nvalid) {
+            const float x0 = (relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];          // ReLU in front of the BatchNorm
+            // folded form: fl(fl(x * alpha) + beta).  Device form (bn_stats = [mean | rs], alpha = weight, beta = bias):
+            // fma(fl(fl(x - mean) * rs), weight, bias) — the expression this device's eval-mode F.batch_norm evaluates
+            float t = devbn ? __fmaf_rn(__fmul_rn(__fsub_rn(x0, c.mean[e]), c.rs[e]), c.al[e], c.be[e])
+                            : __fadd_rn(__fmul_rn(x0, c.al[e]), c.be[e]);
+            if (has_rf) {
+                float u = r[e];
+                if (has_ralpha)
+                    u = rdevbn ? __fmaf_rn(__fmul_rn(__fsub_rn(u, c.rmean[e]), c.rrs[e]), c.ral[e], c.rbe[e])
+                               : __fadd_rn(__fmul_rn(u, c.ral[e]), c.rbe[e]);
+                t = __fadd_rn(t, u);
+            }
+            if (has_rc) t = __fadd_rn(t, __fmul_rn(rscale, (float)(int8_t)(rword >> (8 * e))));
+            if (relu == 1) t = t < 0.0f ? 0.0f : t;             // NaN stays NaN (flagged below)
+            const float q_ = rintf(__fmul_rn(n, t));
+            q4[e] = q_;
+            if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad |= (q_ >= -2047.0f && q_ <= 2047.0f) ? 1 : 3; q = 0; } else q = (int)q_;
+        }
+        word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
+    }
+    return word;
+}
+
+// FIXED: the launch's thread count is a multiple of the slots per row, so a thread keeps its 4 channels for its whole
+// grid-stride walk: the per-channel constants are loaded once, the row index advances by a constant (no 64-bit division per
+// element — 180 VALU instructions per dword and 1.2 TB/s before, profiles/r5_c4_pmc.md), and two rows are in flight per
+// iteration.  Otherwise: the general walk (slot recomputed per element).
+template <bool FIXED>
 __global__ __launch_bounds__(256) void affine_codes_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ rf, int64_t ldr, const float* __restrict__ ralpha, const float* __restrict__ rbeta,
@@ -95,18 +156,16 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
     float* __restrict__ yf, int64_t ldy, int64_t rows, int64_t C, float n, float inv_n,
     int32_t* __restrict__ overflow, int vec, const float* __restrict__ bn_stats, const float* __restrict__ rbn_stats) {
     const int64_t slots_per_row = ldc / 4;
-    const int64_t total = rows * slots_per_row;
     int bad = 0;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
-         s += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
-        const int64_t k0 = slot * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool full = k0 + 3 < C;
+    const bool devbn = bn_stats != nullptr, has_rf = rf != nullptr, has_ralpha = ralpha != nullptr, rdevbn = rbn_stats != nullptr,
+               has_rc = rc != nullptr;
+    auto load4 = [&](int64_t row, int64_t k0, bool full, float (&v)[4], float (&r)[4], uint32_t& rword) {
+        v[0] = v[1] = v[2] = v[3] = 0.0f;
+        r[0] = r[1] = r[2] = r[3] = 0.0f;
         if (vec && full) {
             const float4 t = *reinterpret_cast<const float4*>(x + row * ldx + k0);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            if (rf) {
+            if (has_rf) {
                 const float4 u = *reinterpret_cast<const float4*>(rf + row * ldr + k0);
                 r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
             }
@@ -115,42 +174,57 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
             for (int e = 0; e < 4; ++e)
                 if (k0 + e < C) {
                     v[e] = x[row * ldx + k0 + e];
-                    if (rf) r[e] = rf[row * ldr + k0 + e];
+                    if (has_rf) r[e] = rf[row * ldr + k0 + e];
                 }
         }
-        uint32_t rword = 0;
-        if (rc) rword = *reinterpret_cast<const uint32_t*>(rc + row * ldrc + k0);   // plane rows are 16-byte padded
-        uint32_t word = 0;
-        float q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int q = 0;
-            if (k0 + e < C) {
-                const float x0 = (relu == 2 && v[e] < 0.0f) ? 0.0f : v[e];          // ReLU in front of the BatchNorm
-                // folded form: fl(fl(x * alpha) + beta).  Device form (bn_stats = [mean | rs], alpha = weight, beta = bias):
-                // fma(fl(fl(x - mean) * rs), weight, bias) — the expression this device's eval-mode F.batch_norm evaluates
-                float t = bn_stats ? __fmaf_rn(__fmul_rn(__fsub_rn(x0, bn_stats[k0 + e]), bn_stats[C + k0 + e]), alpha[k0 + e], beta[k0 + e])
-                                   : __fadd_rn(__fmul_rn(x0, alpha[k0 + e]), beta[k0 + e]);
-                if (rf) {
-                    float u = r[e];
-                    if (ralpha)
-                        u = rbn_stats ? __fmaf_rn(__fmul_rn(__fsub_rn(u, rbn_stats[k0 + e]), rbn_stats[C + k0 + e]), ralpha[k0 + e], rbeta[k0 + e])
-                                      : __fadd_rn(__fmul_rn(u, ralpha[k0 + e]), rbeta[k0 + e]);
-                    t = __fadd_rn(t, u);
-                }
-                if (rc) t = __fadd_rn(t, __fmul_rn(rscale, (float)(int8_t)(rword >> (8 * e))));
-                if (relu == 1) t = t < 0.0f ? 0.0f : t;             // NaN stays NaN (flagged below)
-                const float q_ = rintf(__fmul_rn(n, t));
-                q4[e] = q_;
-                if (!(q_ >= -127.0f && q_ <= 127.0f)) { bad |= (q_ >= -2047.0f && q_ <= 2047.0f) ? 1 : 3; q = 0; } else q = (int)q_;
-            }
-            word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
-        }
+        rword = has_rc ? *reinterpret_cast<const uint32_t*>(rc + row * ldrc + k0) : 0u;   // plane rows are 16-byte padded
+    };
+    auto store4 = [&](int64_t row, int64_t k0, uint32_t word, const float (&q4)[4]) {
         *reinterpret_cast<uint32_t*>(codes + row * ldc + k0) = word;
         if (yf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (k0 + e < C) yf[row * ldy + k0 + e] = inv_n * q4[e];
+        }
+    };
+    if constexpr (FIXED) {
+        const unsigned spr = (unsigned)slots_per_row, nthreads = gridDim.x * blockDim.x;
+        const unsigned s0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned slot = s0 % spr;
+        const int64_t drow = nthreads / spr, k0 = (int64_t)slot * 4;
+        const bool full = k0 + 3 < C;
+        const int nvalid = (int)(C - k0 < 0 ? 0 : (C - k0 > 4 ? 4 : C - k0));
+        AffineConsts c;
+        affine_load_consts(c, k0, C, alpha, beta, ralpha, rbeta, bn_stats, rbn_stats);
+        int64_t row = s0 / spr;
+        for (; row + drow < rows; row += 2 * drow) {          // two rows in flight
+            float v0[4], r0[4], v1[4], r1[4], q0[4], q1[4];
+            uint32_t w0, w1;
+            load4(row, k0, full, v0, r0, w0);
+            load4(row + drow, k0, full, v1, r1, w1);
+            const uint32_t o0 = affine_codes_word(v0, r0, w0, c, nvalid, devbn, has_rf, has_ralpha, rdevbn, has_rc, rscale, relu, n, q0, bad);
+            const uint32_t o1 = affine_codes_word(v1, r1, w1, c, nvalid, devbn, has_rf, has_ralpha, rdevbn, has_rc, rscale, relu, n, q1, bad);
+            store4(row, k0, o0, q0);
+            store4(row + drow, k0, o1, q1);
+        }
+        if (row < rows) {
+            float v0[4], r0[4], q0[4];
+            uint32_t w0;
+            load4(row, k0, full, v0, r0, w0);
+            store4(row, k0, affine_codes_word(v0, r0, w0, c, nvalid, devbn, has_rf, has_ralpha, rdevbn, has_rc, rscale, relu, n, q0, bad), q0);
+        }
+    } else {
+        const int64_t total = rows * slots_per_row;
+        for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
+            const int64_t k0 = slot * 4;
+            const int nvalid = (int)(C - k0 < 0 ? 0 : (C - k0 > 4 ? 4 : C - k0));
+            AffineConsts c;
+            affine_load_consts(c, k0, C, alpha, beta, ralpha, rbeta, bn_stats, rbn_stats);
+            float v0[4], r0[4], q0[4];
+            uint32_t w0;
+            load4(row, k0, k0 + 3 < C, v0, r0, w0);
+            store4(row, k0, affine_codes_word(v0, r0, w0, c, nvalid, devbn, has_rf, has_ralpha, rdevbn, has_rc, rscale, relu, n, q0, bad), q0);
         }
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, __any(bad & 2) ? 3 : 1);
@@ -218,10 +292,20 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
     if (ldc_bytes == 0) return QT_OK;
     const float n = (float)((1 << bit_width) - 1);
     const int vec = qt_aligned16(x) && (ldx % 4 == 0) && (!res_f32 || (qt_aligned16(res_f32) && ldr % 4 == 0));
-    const int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
-    hipLaunchKernelGGL(affine_codes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, beta,
-                       res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes, ldc_bytes,
-                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec, bn_stats, res_bn_stats);
+    int grid = qt_stream_grid((rows * (ldc_bytes / 4) + 255) / 256);
+    // fixed-slot walk: a thread count that is a multiple of the slots per row (grid rounded DOWN to a multiple of
+    // spr / gcd(spr, 256) blocks — the grid-stride loop covers the rest); rows * spr < 2^32 for its 32-bit slot arithmetic
+    const int64_t spr = ldc_bytes / 4;
+    int64_t g = 256, t = spr;
+    while (t) { const int64_t r_ = g % t; g = t; t = r_; }
+    const int64_t unit = spr / g;                              // blocks per whole number of rows
+    const bool fixed = unit <= grid && spr <= (1 << 20) && rows * spr < (1ll << 32);
+    if (fixed) grid = (int)(grid / unit * unit);
+#define QT_AFFINE(F) hipLaunchKernelGGL((affine_codes_kernel<F>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, beta, \
+                       res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes, ldc_bytes,                  \
+                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec, bn_stats, res_bn_stats)
+    if (fixed) QT_AFFINE(true); else QT_AFFINE(false);
+#undef QT_AFFINE
     return qt_check_launch();
 }
 

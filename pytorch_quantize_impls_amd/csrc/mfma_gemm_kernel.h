@@ -21,6 +21,10 @@ struct ConvArgs {
     int cpp;                       // 16-byte chunks per pixel
     int kbytes;                    // K bytes per (virtual) im2col row
     unsigned magic_cpp, magic_kw;  // floor(2^32/d)+1: q/d == __umulhi(q, magic) for q < 2^16 (d > 1)
+    // log2(Ho * Wo), log2(Wo) when both are powers of two (-1 otherwise): output row m -> (image, ho, wo) by shifts and masks
+    // instead of integer divisions (prologue) / 64-bit magic multiplies (halo-plane epilogues) — quarter-rate VALU work that
+    // bounds the short small-N launches of the 32 x 32 .. 4 x 4 maps (profiles/r5_c4_pmc.md)
+    int sh_hw = -1, sh_w = -1;
     // GEMM mode, bf16 (qt_bf16_gemm_taps) and int8 (qt_i8_gemm_splitk: one tap, K slices only): a launch of blockIdx.y = tap * z_nslice + slice problems of one shape —
     // X and W advance by z_kslice_bytes per slice along K, W additionally by the tap's offset (tap = row * z_kw + col:
     // col * z_w_copy_bytes + row * z_w_row_bytes), Y by z_y_stride floats per problem.  z_nslice == 0: a plain launch.
@@ -396,8 +400,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             if constexpr (C::CONV) {
                 const int m = min(m0 + row, M - 1);
                 const int hw = cg.Ho * cg.Wo;
-                const int n = m / hw, rem = m - n * hw;
-                const int ho = rem / cg.Wo, wo = rem - ho * cg.Wo;
+                int n, ho, wo;
+                if (cg.sh_w >= 0) {                     // wave-uniform: power-of-two maps
+                    n = m >> cg.sh_hw;
+                    const int rem = m & (hw - 1);
+                    ho = rem >> cg.sh_w;
+                    wo = rem & (cg.Wo - 1);
+                } else {
+                    n = m / hw;
+                    const int rem = m - n * hw;
+                    ho = rem / cg.Wo;
+                    wo = rem - ho * cg.Wo;
+                }
                 ch0[j] = ho * cg.sh - cg.ph;
                 cw0[j] = wo * cg.sw - cg.pw;
                 // byte address of chunk 0 of the window's top-left pixel (may lie before the plane: only
@@ -703,10 +717,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 orow[a][i] = rrow[a][i] = m;
                 if (halo && m < M) {
                     const unsigned um = (unsigned)m;
-                    const unsigned img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
-                    const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
-                    const unsigned ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
-                    const unsigned wo = rem - ho * (unsigned)cg.Wo;
+                    unsigned img, ho, wo;
+                    if (cg.sh_w >= 0) {                 // wave-uniform: power-of-two maps
+                        img = um >> cg.sh_hw;
+                        const unsigned rem = um & (unsigned)(cg.Ho * cg.Wo - 1);
+                        ho = rem >> cg.sh_w;
+                        wo = rem & (unsigned)(cg.Wo - 1);
+                    } else {
+                        img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
+                        const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
+                        ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
+                        wo = rem - ho * (unsigned)cg.Wo;
+                    }
                     orow[a][i] = (int)((img * (unsigned)(cg.Ho + 2 * epi.ohy) + ho + epi.ohy) * (unsigned)(cg.Wo + 2 * epi.ohx) + wo + epi.ohx);
                     rrow[a][i] = (int)((img * (unsigned)(cg.Ho + 2 * epi.rhy) + ho + epi.rhy) * (unsigned)(cg.Wo + 2 * epi.rhx) + wo + epi.rhx);
                 }
@@ -858,10 +880,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                         int orow = m;
                         if (epi.ohy | epi.ohx | epi.d2s_cout) {
                             const unsigned um = (unsigned)m;
-                            const unsigned img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
-                            const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
-                            const unsigned ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
-                            const unsigned wo = rem - ho * (unsigned)cg.Wo;
+                            unsigned img, ho, wo;
+                            if (cg.sh_w >= 0) {
+                                img = um >> cg.sh_hw;
+                                const unsigned rem = um & (unsigned)(cg.Ho * cg.Wo - 1);
+                                ho = rem >> cg.sh_w;
+                                wo = rem & (unsigned)(cg.Wo - 1);
+                            } else {
+                                img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
+                                const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
+                                ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
+                                wo = rem - ho * (unsigned)cg.Wo;
+                            }
                             const unsigned zs = epi.d2s_cout ? 2u : 1u;
                             const unsigned oh = zs * ho + (unsigned)(dyx >> 1), ow = zs * wo + (unsigned)(dyx & 1);
                             orow = (int)((img * (zs * (unsigned)cg.Ho + 2u * (unsigned)epi.ohy) + oh + (unsigned)epi.ohy) *
@@ -1129,6 +1159,11 @@ static int conv_prepare(int elem, const uint32_t*& P, int64_t Nimg, int64_t H, i
     cg.kbytes = (int)(kwords * 4);
     cg.magic_cpp = cg.cpp > 1 ? (unsigned)((1ull << 32) / (unsigned)cg.cpp + 1) : 0;
     cg.magic_kw = kw > 1 ? (unsigned)((1ull << 32) / (unsigned)kw + 1) : 0;
+    cg.sh_hw = cg.sh_w = -1;
+    if (((Ho * Wo) & (Ho * Wo - 1)) == 0 && (Wo & (Wo - 1)) == 0) {
+        cg.sh_hw = __builtin_ctzll((unsigned long long)(Ho * Wo));
+        cg.sh_w = __builtin_ctzll((unsigned long long)Wo);
+    }
     // un-padded conv on a plane < 4 GiB: every tap of every window is in bounds -> 32-bit offsets, no checks
     valid = ph == 0 && pw == 0 && Nimg * H * W * Cw * 4 < (1ll << 32) && kwords * 4 <= 32768;
     if (hy | hx) {
