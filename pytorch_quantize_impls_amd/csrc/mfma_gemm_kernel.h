@@ -733,6 +733,82 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     rrow[a][i] = (int)((img * (unsigned)(cg.Ho + 2 * epi.rhy) + ho + epi.rhy) * (unsigned)(cg.Wo + 2 * epi.rhx) + wo + epi.rhx);
                 }
             }
+        if constexpr (DEVBN) {
+            // Straight-line form of the common case — whole column tiles (every channel of the lane's dword exists), no conv bias,
+            // no fp32 residual, ReLU (if any) behind the BatchNorm: the residual kind and the ReLU are template flags of the body,
+            // so the per-element chain is 10 (13 with a code residual) VALU instructions with no per-element scalar branch.  The
+            // general form below spends ~2x that on its wave-uniform-but-unknown-at-compile-time conditions, and these short
+            // small-N launches are VALU-issue bound in their epilogue (profiles/r5_c4_pmc.md).  Same roundings, same codes.
+            const bool fast = !bias && !epi.res_f32 && epi.relu != 2 && (N & 3) == 0 && n0 + C::TN <= N;
+            if (fast) {
+                int badf = 0;
+                const float levels = epi.levels, rscale = epi.rscale;
+                auto body = [&](auto rc_tag, auto relu_tag) {
+                    constexpr bool RC = decltype(rc_tag)::value, RELU = decltype(relu_tag)::value;
+#pragma unroll
+                    for (int b = 0; b < C::TNW; ++b) {
+                        const int nb = n0 + (wave_n * C::TNW + b) * 32;
+                        const int n = nb + (lane & 7) * 4;
+                        float al[4], be[4], mean[4], rs[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            al[e] = epi.alpha[n + e];
+                            be[e] = epi.beta[n + e];
+                            mean[e] = epi.bn_stats[n + e];
+                            rs[e] = epi.bn_stats[N + n + e];
+                        }
+#pragma unroll
+                        for (int a = 0; a < C::TMW; ++a) {
+                            const int mb = m0 + (wave_m * C::TMW + a) * 32;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = (float)acc[a][b][r] * scale;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = i * 8 + (lane >> 3);
+                                const float4 v4 = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
+                                if (mb + row < M) {
+                                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                                    uint32_t rword = 0;
+                                    if constexpr (RC)
+                                        rword = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)rrow[a][i] * epi.ldrc + n);
+                                    uint32_t word = 0;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = __builtin_fmaf((v[e] - mean[e]) * rs[e], al[e], be[e]);
+                                        if constexpr (RC) t = t + rscale * (float)(int8_t)(rword >> (8 * e));
+                                        if constexpr (RELU) t = t < 0.0f ? 0.0f : t;
+                                        const float qf = rintf(levels * t);
+                                        const bool ok = __builtin_fabsf(qf) <= 127.0f;       // NaN -> false
+                                        const int q = ok ? (int)qf : 0;
+                                        badf |= ok ? 0 : 1;
+                                        word |= (uint32_t)(uint8_t)(int8_t)q << (8 * e);
+                                    }
+                                    *reinterpret_cast<uint32_t*>(Q + (int64_t)orow[a][i] * ldy + n) = word;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            if (!halo && b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && mb + lane < M)
+                                for (int c = n0 + C::TN; c < ldy; c += 4)
+                                    *reinterpret_cast<uint32_t*>(Q + (int64_t)(mb + lane) * ldy + c) = 0u;
+                        }
+                    }
+                };
+                if (epi.res_codes) {
+                    if (epi.relu == 1) body(std::true_type{}, std::true_type{});
+                    else body(std::true_type{}, std::false_type{});
+                } else {
+                    if (epi.relu == 1) body(std::false_type{}, std::true_type{});
+                    else body(std::false_type{}, std::false_type{});
+                }
+                if (__any(badf) && lane == 0) atomicOr(epi.overflow, 1);
+                return;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < C::TNW; ++b) {
             const int nb = n0 + (wave_n * C::TNW + b) * 32;
