@@ -295,6 +295,14 @@ int launch_nib_pack(const float* x, int64_t ldx, uint32_t* out, int64_t ldp, int
 
 }  // namespace
 
+// code_conv3x3.hip
+int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                        int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp, const float* bias, float scale,
+                        const float* scale_dev, const float* alpha, const float* beta, const float* res_f32, const float* res_alpha,
+                        const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
+                        int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t ihy, int64_t ihx, int64_t ohy, int64_t ohx,
+                        int64_t rhy, int64_t rhx, const float* bn_stats, qt_stream_t stream);
+
 extern "C" {
 
 int qt_sign_pack_nib_f32(const float* x, int64_t ldx, uint32_t* nib_plane, int64_t ldp, int64_t rows,
@@ -659,6 +667,13 @@ int qt_conv2d_implicit_codes(int elem, const uint32_t* P, int64_t Nimg, int64_t 
     epi.rhy = (int)res_halo_h;
     epi.rhx = (int)res_halo_w;
     epi.bn_stats = bn_stats;
+    {   // small-channel 3 x 3 / stride 1 layers: the persistent direct kernel (code_conv3x3.hip), bit-identical codes
+        const int rc = qt_code_conv3x3_try(P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale, scale_dev, alpha,
+                                           beta, res_f32, res_alpha, res_codes, ldrc_bytes, res_scale, relu, bit_width, codes, ldc_bytes,
+                                           Cout, overflow, in_halo_h, in_halo_w, out_halo_h, out_halo_w, res_halo_h, res_halo_w, bn_stats,
+                                           stream);
+        if (rc != QT_ERR_UNSUPPORTED) return rc;
+    }
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, reinterpret_cast<float*>(codes), ldc_bytes, Cout, stream, epi, in_halo_h,
                               in_halo_w);

@@ -344,3 +344,52 @@ def test_dorefa_9_to_16_bit_layers_vs_reference_fp64_vectors(dev, name, mode):
     finally:
         _fused.BWD_MFMA_MIN_MACS = old
     assert _lib_delta(lib_before) == {}
+
+
+# ---- the persistent direct 3 x 3 code conv (csrc/code_conv3x3.hip) == the implicit-GEMM route, bit for bit ---------------------------
+
+_C3_SNIPPET = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+import bench_models
+from pytorch_quantize_impls_amd import lazy
+torch.manual_seed(4)
+m4 = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+bench_models.randomize_bn(m4, seed=3)
+for m in m4.modules():
+    if isinstance(m, torch.nn.BatchNorm2d):
+        m.running_var.mul_(4.0)
+dev = torch.device("cuda:0")
+m4 = m4.to(dev).to(memory_format=torch.channels_last).eval()
+f4 = bench_models.FusedDorefaResNet18(m4, fold="device")
+out = []
+for B in (8, 24, 256):
+    x = torch.randn((B, 3, 32, 32), device=dev, generator=torch.Generator(device=dev).manual_seed(B)).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = f4(x)
+        with lazy.eager():
+            ye = m4(x)
+    out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest() + ":" + str(bool(torch.equal(y, ye))))
+print("RESULT", " ".join(out))
+"""
+
+
+def test_direct_code_conv3x3_equals_the_implicit_gemm_route(dev):
+    """The fused DoReFa ResNet-18 forward (stage-1 / stage-2 stride-1 convs on the persistent direct kernel) gives the same logits,
+    bit for bit, as with the kernel switched off (QT_NO_CODE_CONV3X3: every conv on the implicit-GEMM kernel) and as the
+    module-by-module graph; batches 8 / 24 / 256 (whole 128-pixel tiles, ragged tile counts per workgroup)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for off in (False, True):
+        env = dict(os.environ)
+        env.pop("QT_NO_CODE_CONV3X3", None)
+        if off:
+            env["QT_NO_CODE_CONV3X3"] = "1"
+        p = subprocess.run([sys.executable, "-c", _C3_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0]
+        res[off] = line.split()[1:]
+    assert res[False] == res[True], res
+    assert all(r.endswith(":True") for r in res[False]), res
