@@ -1098,6 +1098,10 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         mf = bench_models.TrainFusedAlexNetBin(mt)
         t_fused, loss_fused = bts.step_time(mf, mt, xt, tt)
         t_ref, loss_ref = bts.step_time(lambda t: bts.ref_forward(mt, t), mt, xt, tt, n=3)
+        try:
+            ties = bts.tie_report(mt, xt, tt)
+        except Exception as exc:  # noqa: BLE001 — an extra must not void the headline measurement
+            ties = {"error": f"{type(exc).__name__}: {exc}"}
         out["n2_training_step_alexnet_bin"] = {
             "workload": f"BinaryNet-AlexNet 3x224x224 batch {Bt}, training mode, forward + backward (nll loss), fp32 master weights, "
                         "channels_last; no optimizer step (the reference's trainers are out of scope)",
@@ -1116,6 +1120,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             # real-valued pixels: conv1's fp32 rounding differs between the routes, a few signs flip behind the training-mode
             # BatchNorm, so the two losses agree to ~1e-3 only; on +-1 pixels the forward passes are identical (the parity test)
             "loss": loss_ours, "loss_reference_ops": loss_ref,
+            # the gap between the two losses, explained: sign flips at the activation quantisers (tools/bench_train_step.tie_report)
+            "first_step_ties": ties,
             "dense_library_calls_in_the_steps": lib_used,
             "gradient_parity": "tests/test_gpu_r3.py::test_alexnet_training_step_vs_fp64_of_the_reference_op_sequence and "
                                "::test_alexnet_training_step_with_the_fused_training_chain (<= 1e-5 normalised vs fp64 on the CPU)"}

@@ -65,6 +65,63 @@ def step_time(fwd, model, x, target, n=5):
     return (time.perf_counter() - t0) / n * 1e3, float(loss.detach())
 
 
+def tie_report(model, x, target):
+    """Why the loss of this backend's step and of the reference op sequence differ on real-valued pixels: the
+    two conv1 routes round differently in fp32, so behind the training-mode BatchNorm a few activations sit on the other side of
+    BinaryConnect's boundary (sign ties), and every flip moves the integer sums downstream by whole steps.  Forward only: the
+    reference op sequence records the output of every activation quantiser; this backend's forward then runs with those outputs
+    FORCED in (forward hooks on the BinaryConnect modules), counting the elements that differed.  With the reference's codes forced
+    the two losses must agree to the float tail; the flip count is the whole explanation of the gap."""
+    from pytorch_quantize_impls_amd.functions.common import _FunctionModule
+    rec = []
+    orig = _RefSign.apply
+
+    def run(seq, h, act):
+        for m in seq:
+            name = type(m).__name__
+            if name == "BinConv2d":
+                h = F.conv2d(h, orig(m.weight), m.bias, m.stride, m.padding)
+            elif name == "LinearBin":
+                h = F.linear(h, orig(m.weight), m.bias)
+            elif name == "_FunctionModule":
+                h = orig(h)
+                act(h)
+            else:
+                h = m(h)
+        return h
+
+    was = {m: m.momentum for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)}
+    for m in was:
+        m.momentum = 0.0                                    # the report does not move the running statistics
+    try:
+        with torch.no_grad():
+            h = run(model.features, x, lambda t: rec.append(t.detach()))
+            loss_ref = float(F.nll_loss(run(model.classifieur, h.reshape(h.size(0), 256 * 6 * 6), lambda t: rec.append(t.detach())), target))
+            it = iter(rec)
+            stats = {"flips": 0, "elements": 0}
+
+            def force(mod, inp, out):
+                forced = next(it)
+                o = torch.as_tensor(out).detach()
+                stats["elements"] += o.numel()
+                stats["flips"] += int((forced.reshape(o.shape) != o).sum())
+                return forced.reshape(o.shape).to(o.dtype)
+            hooks = [m.register_forward_hook(force) for m in model.modules() if isinstance(m, _FunctionModule)]
+            try:
+                loss_forced = float(F.nll_loss(model(x), target))
+            finally:
+                for hk in hooks:
+                    hk.remove()
+            loss_free = float(F.nll_loss(model(x), target))
+    finally:
+        for m, mom in was.items():
+            m.momentum = mom
+    return {"sign_flips_vs_reference_ops": stats["flips"], "activation_elements": stats["elements"],
+            "loss_reference_ops": loss_ref, "loss_with_the_reference_codes_forced": loss_forced, "loss_unforced": loss_free,
+            "rel_gap_forced": abs(loss_forced - loss_ref) / max(abs(loss_ref), 1e-30),
+            "rel_gap_unforced": abs(loss_free - loss_ref) / max(abs(loss_ref), 1e-30)}
+
+
 def gradient_agreement(B: int = 16, seed: int = 0) -> float:
     """Worst normalised difference between this backend's parameter gradients and the reference op sequence's for one
     AlexNet-Bin training step on +-1 pixels (identical forward passes); zero-gradient biases excluded."""
