@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import collections
 import contextlib
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -36,15 +37,23 @@ ENABLED = True
 STATS = collections.Counter()
 
 
+_tls = threading.local()
+
+
+def enabled() -> bool:
+    """Recording is on: the master switch ``ENABLED`` and no ``eager()`` block open in THIS thread."""
+    return ENABLED and not getattr(_tls, "eager_depth", 0)
+
+
 @contextlib.contextmanager
 def eager():
-    """Module-by-module training inside the block (torch / MIOpen pooling, BatchNorm, Hardtanh, add, ReLU kernels)."""
-    global ENABLED
-    old, ENABLED = ENABLED, False
+    """Module-by-module training inside the block (torch / MIOpen pooling, BatchNorm, Hardtanh, add, ReLU kernels).  Thread-local,
+    like lazy.eager(): two training threads of one process do not switch each other's recording off."""
+    _tls.eager_depth = getattr(_tls, "eager_depth", 0) + 1
     try:
         yield
     finally:
-        ENABLED = old
+        _tls.eager_depth -= 1
 
 
 class _Step:
@@ -214,7 +223,7 @@ def resolve(x):
 
 def wrap(layer, out):
     """What a quantised layer returns in training mode: ``out`` itself unless the chain behind it can be fused."""
-    if (ENABLED and layer.training and torch.is_grad_enabled() and type(out) is torch.Tensor and out.is_cuda
+    if (enabled() and layer.training and torch.is_grad_enabled() and type(out) is torch.Tensor and out.is_cuda
             and out.dtype == torch.float32 and out.dim() in (2, 4) and out.requires_grad and out.numel() > 0):
         STATS["wrapped"] += 1
         return out.as_subclass(TrainOut)
@@ -280,7 +289,7 @@ def _square(v):
 
 
 def _deferred(x) -> bool:
-    return ENABLED and type(x) in _DEFERRED
+    return enabled() and type(x) in _DEFERRED
 
 
 def _h_max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
@@ -317,7 +326,7 @@ def _h_batch_norm(input, running_mean, running_var, weight=None, bias=None, trai
 
 
 def _h_hardtanh(input, min_val=-1.0, max_val=1.0, inplace=False):
-    if type(input) is not TrainChain or not ENABLED:
+    if type(input) is not TrainChain or not enabled():
         return NotImplemented
     n = input._qt
     if n.bn is None or n.ht is not None or n.add is not None or n.relu or n.flat is not None or not (min_val < 0 < max_val):
@@ -334,7 +343,7 @@ def _h_hardtanh_(input, min_val=-1.0, max_val=1.0):
 
 
 def _h_relu(input, inplace=False):
-    if type(input) is not TrainChain or not ENABLED:
+    if type(input) is not TrainChain or not enabled():
         return NotImplemented
     n = input._qt
     if n.bn is None or n.pool is not None or n.ht is not None or n.relu or n.flat is not None:
@@ -366,7 +375,7 @@ def _residual_ok(main: _Step, other) -> bool:
 
 
 def _h_add(a, b, *, alpha=1, out=None, _inplace=False):
-    if alpha != 1 or out is not None or not ENABLED:
+    if alpha != 1 or out is not None or not enabled():
         return NotImplemented
     if _mainline(a) and _residual_ok(a._qt, b):
         main, other = a, b
@@ -411,7 +420,7 @@ def _as_flat(input):
 
 
 def _h_reshape(input, *shape):
-    if type(input) is not TrainChain or not ENABLED:
+    if type(input) is not TrainChain or not enabled():
         return NotImplemented
     if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
         shape = tuple(shape[0])
@@ -419,7 +428,7 @@ def _h_reshape(input, *shape):
 
 
 def _h_flatten(input, start_dim=0, end_dim=-1):
-    if type(input) is not TrainChain or not ENABLED:
+    if type(input) is not TrainChain or not enabled():
         return NotImplemented
     n = input._qt
     if len(n.shape) == 4 and start_dim == 1 and end_dim in (-1, 3) and _flat_ok(n, (n.shape[0], -1)):
@@ -444,7 +453,7 @@ _HANDLERS = {
 def sign(x):
     """BinaryConnect(deterministic) of a deferred training activation: the fused node when the recorded chain is
     [pool] -> BatchNorm -> [Hardtanh] -> [flatten], else None (the caller binarises ``resolve(x)``)."""
-    if type(x) is not TrainChain or not ENABLED:
+    if type(x) is not TrainChain or not enabled():
         return None
     n = x._qt
     if n.bn is None or n.add is not None or n.relu or not n._untouched():
@@ -462,7 +471,7 @@ def sign(x):
 def quant(x, bit_width: int):
     """nnDorefaQuant(k) of a deferred training activation: the fused node when the recorded chain is
     BatchNorm -> [+ shortcut] -> [ReLU] and 2 <= k <= 8, else None."""
-    if type(x) is not TrainChain or not ENABLED:
+    if type(x) is not TrainChain or not enabled():
         return None
     n = x._qt
     if (n.bn is None or n.pool is not None or n.ht is not None or n.flat is not None or not 2 <= int(bit_width) <= 8

@@ -8,6 +8,7 @@ A CPU tensor is a programming error here (``TypeError``) — there is no fallbac
 from __future__ import annotations
 
 import contextlib
+import threading
 import functools
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -1612,27 +1613,36 @@ _TRIPLE_MODES = {"binary": 1, "ternary": 2, "sign": 3, "raw": 4}
 FLOAT_SPLIT = "f16x2"
 
 
+_split_tls = threading.local()
+
+
 def current_float_split() -> str:
-    """The split in force: the innermost ``with float_split(...)``, else the default FLOAT_SPLIT."""
-    return FLOAT_SPLIT
+    """The split in force in THIS thread: the innermost ``with float_split(...)``, else the default FLOAT_SPLIT."""
+    return getattr(_split_tls, "mode", None) or FLOAT_SPLIT
+
+
+def float_split_override() -> Optional[str]:
+    """The mode an enclosing ``with float_split(...)`` of this thread set, or None (what QtFunction.forward captures)."""
+    return getattr(_split_tls, "mode", None)
 
 
 @contextlib.contextmanager
-def float_split(mode: str):
-    """Run the enclosed real-valued contractions with the split ``mode``.  PROCESS-WIDE on purpose: the backward of an autograd
-    graph runs on the engine's own thread, which must see the mode its forward was built under (a thread-local override is
-    invisible there — the exact-split tests then ran their backward GEMMs on the default route).  It is a switch for tools and
-    tests, not for concurrent serving threads: library code never flips it — layers that need the exact route pass ``terms=3``
-    to float_linear / float_conv2d explicitly (Lin / Log layers)."""
-    global FLOAT_SPLIT
-    if mode not in ("f16x2", "bf16x3"):
+def float_split(mode: Optional[str]):
+    """Run the enclosed real-valued contractions with the split ``mode`` ("f16x2" | "bf16x3"; None = leave as is).  THREAD-LOCAL:
+    two serving threads (one process, one stream per device: SURVEY 8e) can hold different modes at the same time without seeing
+    each other's.  The backward of an autograd graph runs on the engine's own thread, which cannot see the forward thread's
+    override — so every autograd.Function of the package records the override at forward time and re-opens it around its backward
+    (functions.common.QtFunction), i.e. a graph is differentiated under the mode it was built under.  Library code never opens a
+    scope: layers that need the exact route pass ``terms=3`` to float_linear / float_conv2d explicitly (Lin / Log layers)."""
+    if mode is not None and mode not in ("f16x2", "bf16x3"):
         raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
-    prev = FLOAT_SPLIT
-    FLOAT_SPLIT = mode
+    prev = getattr(_split_tls, "mode", None)
+    if mode is not None:
+        _split_tls.mode = mode
     try:
         yield
     finally:
-        FLOAT_SPLIT = prev
+        _split_tls.mode = prev
 
 
 def split_terms(terms: Optional[int] = None) -> int:

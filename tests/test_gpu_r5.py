@@ -393,3 +393,64 @@ def test_direct_code_conv3x3_equals_the_implicit_gemm_route(dev):
         res[off] = line.split()[1:]
     assert res[False] == res[True], res
     assert all(r.endswith(":True") for r in res[False]), res
+
+
+# ---- thread-local switches: float_split / lazy_train.eager do not leak between threads; backward keeps the forward's mode
+
+def test_float_split_is_thread_local_and_follows_the_graph_into_backward(dev):
+    import threading
+    from pytorch_quantize_impls_amd import _lib
+    torch.manual_seed(0)
+    x = torch.randn(64, 200, device=dev)
+    w = torch.randn(48, 200, device=dev)
+    with ops.float_split("bf16x3"):
+        ref3 = ops.float_linear(x, w, "binary")
+    ref2 = ops.float_linear(x, w, "binary")
+    assert ops.current_float_split() == "f16x2"
+    want = torch.nn.functional.linear(x.double(), torch.where(w < 0, -1.0, 1.0).double()).float()
+    assert torch.equal(ref3, want)                        # the three-term split is exact for +-1 weights
+    errs = []
+
+    def worker(mode, ref, n=200):
+        try:
+            for _ in range(n):
+                if mode is None:
+                    assert ops.current_float_split() == "f16x2"
+                    y = ops.float_linear(x, w, "binary")
+                else:
+                    with ops.float_split(mode):
+                        assert ops.current_float_split() == mode
+                        y = ops.float_linear(x, w, "binary")
+                if not torch.equal(y, ref):
+                    errs.append(mode)
+                    return
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+    ts = [threading.Thread(target=worker, args=("bf16x3", ref3)), threading.Thread(target=worker, args=(None, ref2)),
+          threading.Thread(target=worker, args=("bf16x3", ref3)), threading.Thread(target=worker, args=(None, ref2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    # backward runs on the autograd engine's thread: it re-opens the mode the forward was recorded under
+    lin = LinearBin(200, 48).to(dev).train()
+    xin = (x * 3.0).requires_grad_(True)                  # real-valued input: the float routes
+    with ops.float_split("bf16x3"):
+        y = lin(xin)
+    before = dict(_lib.call_counts)
+    y.sum().backward()                                    # outside the scope
+    moved = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v != before.get(k, 0)}
+    assert not any(k.startswith("qt_f16x2") for k in moved), moved
+    assert any(k.startswith(("qt_bf16x3", "qt_bf16x6", "qt_bf16_gemm")) for k in moved), moved
+    # and lazy_train.eager() of one thread does not switch another thread's recording off
+    flags = {}
+
+    def probe():
+        flags["other"] = lazy_train.enabled()
+    with lazy_train.eager():
+        t = threading.Thread(target=probe)
+        t.start()
+        t.join()
+        flags["mine"] = lazy_train.enabled()
+    assert flags == {"other": True, "mine": False}

@@ -45,7 +45,7 @@ def nodes(monkeypatch):
             return nnDorefaQuant(bits)(h)
 
     def wrap(layer, out):
-        if lazy_train.ENABLED and layer.training and torch.is_grad_enabled() and type(out) is torch.Tensor and out.requires_grad:
+        if lazy_train.enabled() and layer.training and torch.is_grad_enabled() and type(out) is torch.Tensor and out.requires_grad:
             return out.as_subclass(lazy_train.TrainOut)
         return out
 

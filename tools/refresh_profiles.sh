@@ -31,3 +31,33 @@ if [ -d gpurun_out/tr_rn_mod ]; then
     done; } > profiles/${TAG}_train_steps_rocprof.md
 fi
 grep -n "tile 256x256, pipe=2> |" profiles/${TAG}_bench_rocprof.md | head -3
+# profiles/pmc_latest.json: what bench.py quotes as roofline.traffic / rocprof_avg_us (counters cannot be read from inside the
+# process): the C2 GEMM's and the pack kernel's per-launch averages of THIS collection
+python - "$TAG" <<'PY'
+import json, re, sys
+tag = sys.argv[1]
+md = open(f"profiles/{tag}_bench_rocprof.md").read()
+cur = json.load(open("profiles/pmc_latest.json"))
+def pmc(kernel_pat, counter):
+    m = re.search(r"\| " + kernel_pat + r"[^|]*\| " + counter + r" \| \d+ \| ([0-9.]+) \|", md)
+    return float(m.group(1)) if m else None
+def avg(kernel_pat):
+    m = re.search(r"\| " + kernel_pat + r"[^|]*\| \d+ \| [0-9.]+ \| ([0-9.]+) \|", md)
+    return float(m.group(1)) if m else None
+g = {"FETCH_SIZE_KiB": pmc(r"mfma_gemm_kernel<ElemFp4, tile 256x256, pipe=2>", "FETCH_SIZE"),
+     "WRITE_SIZE_KiB": pmc(r"mfma_gemm_kernel<ElemFp4, tile 256x256, pipe=2>", "WRITE_SIZE"),
+     "rocprof_avg_us": avg(r"mfma_gemm_kernel<ElemFp4, tile 256x256, pipe=2>")}
+p = {"FETCH_SIZE_KiB": pmc(r"nib_pack_pair_kernel", "FETCH_SIZE"), "WRITE_SIZE_KiB": pmc(r"nib_pack_pair_kernel", "WRITE_SIZE"),
+     "rocprof_avg_us": avg(r"nib_pack_pair_kernel")}
+if all(v is not None for v in g.values()):
+    cur["kernels"]["mfma_gemm_kernel"] = g
+    if all(v is not None for v in p.values()):
+        cur["kernels"]["nib_pack_pair_kernel"] = p
+    cur["source"] = (f"profiles/{tag}_bench_rocprof.md (rocprofv3 --kernel-trace --stats of the default bench command; --kernel-trace --pmc FETCH_SIZE / "
+                     f"--pmc WRITE_SIZE passes of `python bench.py --steps 40 --warmup 10 --no-cpu-baseline --alexnet-batch 0 --no-extras`, "
+                     f"tools/collect_profiles.sh {tag})")
+    json.dump(cur, open("profiles/pmc_latest.json", "w"))
+    print("pmc_latest.json <-", tag, g)
+else:
+    print("pmc_latest.json unchanged: counters not found in", tag, g)
+PY
