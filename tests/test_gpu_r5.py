@@ -408,7 +408,8 @@ def test_float_split_is_thread_local_and_follows_the_graph_into_backward(dev):
     ref2 = ops.float_linear(x, w, "binary")
     assert ops.current_float_split() == "f16x2"
     want = torch.nn.functional.linear(x.double(), torch.where(w < 0, -1.0, 1.0).double()).float()
-    assert torch.equal(ref3, want)                        # the three-term split is exact for +-1 weights
+    assert float((ref3 - want).abs().max() / want.abs().max()) <= 1e-6      # exact products, fp32 accumulation
+    assert float((ref2 - want).abs().max() / want.abs().max()) <= 1e-5
     errs = []
 
     def worker(mode, ref, n=200):
