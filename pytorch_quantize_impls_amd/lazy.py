@@ -274,6 +274,19 @@ def _force_codes(self, halo=None):
                         res, res_bn = o.parent.materialise(), _bn_view(blk, o.bn)
                 else:
                     res = other
+                    # an fp32 residual that carries the int8 codes of the quantiser that produced it (the identity shortcut of the
+                    # FIRST block of a ResNet: the stem's nnDorefaQuant output, which is also where this chain's codes started —
+                    # same range flag): join as codes, 1 byte per element and the straight-line epilogue instead of 4 bytes and
+                    # the general one (87 -> ~24 us for the 64 -> 64 conv at 32 x 32, batch 256).  fl(inv_n * q) is what the
+                    # quantiser wrote into the fp32 image and what the code path adds: the same bits
+                    tag = packed.lookup_codes(other, packed.NHWC) if (isinstance(other, torch.Tensor) and other.dim() == 4
+                                                                      and other.dtype == torch.float32) else None
+                    inp = self.input
+                    if (tag is not None and isinstance(inp, packed.CodeActivation) and tag.overflow is not None
+                            and tag.overflow is inp.codes.overflow and tag.K == int(other.shape[1])
+                            and tag.rows == int(other.shape[0]) * int(other.shape[2]) * int(other.shape[3])):
+                        res = packed.CodeActivation(tag, tuple(int(v) for v in other.shape))
+                        STATS["residual_as_codes"] += 1
                 if res is None:
                     raise ValueError("residual cannot join the fused chain")
             act = blk(self.input, residual=res, residual_bn=res_bn)
