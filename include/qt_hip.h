@@ -174,6 +174,13 @@ int qt_xnor_act_f32(const float* x, int64_t ldx, float* mean, float* work, float
 int qt_xnor_act_backward_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* mean, float* gmean,
                              float* work, float* gin, int64_t ldi, int64_t R, int64_t C, int dim, qt_stream_t stream);
 
+/* Diagnostic: launches of the persistent direct 3 x 3 code conv (csrc/code_conv3x3.hip) since the library was loaded.
+ * qt_conv2d_implicit_codes takes that kernel for 3 x 3 / stride 1 / padding 1 layers with 64 or 128 input channels, Cout % 64 == 0
+ * and power-of-two maps (models/Resnet/Resnet_bin.py:63-97 stages 1 and 2), bit-identical to its implicit-GEMM route; tests use the
+ * counter to assert which route ran.  Setting the environment variable QT_NO_CODE_CONV3X3 (read per call) keeps every conv on the
+ * implicit-GEMM kernel. */
+int64_t qt_code_conv3x3_launch_count(void);
+
 /* Input quantiser of XNORConv2d(quant_input = True) (functions/xnor_connect.py:142-143):
  *   y[n, c, h, w] = sign(x[n, c, h, w]) * mean_c |x[n, :, h, w]|        torch.sign (0 -> 0, NaN -> NaN), one scale per pixel.
  * x: logical [N, C, H, W] fp32 with ELEMENT strides (sn, sc, sh, sw) (contiguous NCHW or channels-last); y: the same logical

@@ -15,6 +15,7 @@
 // plane): the same roundings in the same order, so the codes are bit-identical to the implicit-GEMM route (integer sums are
 // order-independent).  Whatever does not meet the conditions of qt_code_conv3x3_try stays on the implicit-GEMM kernel.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "qt_common.h"
@@ -336,6 +337,8 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
         c3_zero_border(a.Q, a.ldq / 16, a.Nimg, a.H, a.W, a.ohy, a.ohx, (int)blockIdx.x, (int)gridDim.x);
 }
 
+std::atomic<long long> c3_launches{0};
+
 int c3_log2(int64_t v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctzll((unsigned long long)v) : -1; }
 
 }  // namespace
@@ -347,8 +350,7 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
                         const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int bit_width, int8_t* codes,
                         int64_t ldc_bytes, int64_t Cout, int32_t* overflow, int64_t ihy, int64_t ihx, int64_t ohy, int64_t ohx,
                         int64_t rhy, int64_t rhx, const float* bn_stats, qt_stream_t stream) {
-    static const bool off = getenv("QT_NO_CODE_CONV3X3") != nullptr;       // A/B switch for tools (tools/time_c4.py)
-    if (off) return QT_ERR_UNSUPPORTED;
+    if (getenv("QT_NO_CODE_CONV3X3")) return QT_ERR_UNSUPPORTED;          // A/B switch for tools and tests (read per call)
     const int64_t CB = Cw * 4;
     if (kh != 3 || kw != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || dh != 1 || dw != 1 || ihy < 1 || ihx < 1) return QT_ERR_UNSUPPORTED;
     if ((CB != 64 && CB != 128) || Cout <= 0 || (Cout & 63) || ldc_bytes != Cout || ldwp * 4 < 9 * CB) return QT_ERR_UNSUPPORTED;
@@ -391,7 +393,8 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     // MODE 0: the compute waves issue the next patch's DMA themselves; MODE 2: a fifth (loader) wave does.  Measured per launch
     // (tools/probes/c3_modes.sh, batch 256): 64 -> 64 @ 32 x 32: 22.8 / 29.4 us, 128 -> 128 @ 16 x 16: 23.8 / 22.4 us
     // (implicit-GEMM kernel: 29.0 / 24.2 us).  QT_C3_MODE overrides (tools only; 1 / 3 / 4 exist in profiling builds).
-    static const int forced = getenv("QT_C3_MODE") ? atoi(getenv("QT_C3_MODE")) : -1;
+    const char* fm = getenv("QT_C3_MODE");
+    const int forced = fm ? atoi(fm) : -1;
     const int mode = forced >= 0 ? forced : (CB == 64 ? 0 : 2);
 #define QT_C3(CBV, MD)                                                                                                              \
     do {                                                                                                                            \
@@ -414,5 +417,8 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
         if (mode == 2) QT_C3(128, 2); else QT_C3(128, 0);
     }
 #undef QT_C3
+    c3_launches.fetch_add(1, std::memory_order_relaxed);
     return qt_check_launch();
 }
+
+extern "C" int64_t qt_code_conv3x3_launch_count(void) { return (int64_t)c3_launches.load(std::memory_order_relaxed); }

@@ -455,3 +455,55 @@ def test_float_split_is_thread_local_and_follows_the_graph_into_backward(dev):
         t.join()
         flags["mine"] = lazy_train.enabled()
     assert flags == {"other": True, "mine": False}
+
+
+def test_direct_code_conv3x3_geometry_fuzz(dev):
+    """Seeded geometries of FusedBnDorefaQuant -> FusedDorefaConvBnQuant (fold="device"): channels 64 / 128, Cout 64 / 128 / 192,
+    power-of-two maps 4 .. 64 (tiles inside an image, whole images per tile, ragged tile counts per workgroup), halos 0 / 1 on
+    the output, with / without a code residual and ReLU, bit widths 2 .. 4: the code planes of the persistent direct kernel equal
+    those of the implicit-GEMM kernel byte for byte (the switch QT_NO_CODE_CONV3X3 is read per call)."""
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant
+    from pytorch_quantize_impls_amd import _lib
+    count = _lib.load().qt_code_conv3x3_launch_count
+    rng = np.random.default_rng(20260930)
+    done = 0
+    for it in range(24):
+        Cin = int(rng.choice([64, 128])); Cout = int(rng.choice([64, 128, 192]))
+        H = int(rng.choice([4, 8, 16, 32])); W = int(rng.choice([4, 8, 16, 32, 64])); N = int(rng.choice([1, 2, 3, 8, 16, 33]))
+        if (N * H * W) % 128:
+            N = int(np.ceil(N * H * W / 128) * 128 // (H * W)) or 1
+            if (N * H * W) % 128:
+                continue
+        bits = int(rng.choice([2, 3, 4])); relu = bool(rng.integers(0, 2)); use_res = bool(rng.integers(0, 2)) and Cin == Cout
+        oh = int(rng.integers(0, 2))
+        torch.manual_seed(1000 + it)
+        bn0 = torch.nn.BatchNorm2d(Cin).to(dev).eval()
+        bn0.running_mean.normal_(); bn0.running_var.uniform_(0.5, 2.0); bn0.weight.data.normal_(); bn0.bias.data.normal_()
+        conv = DorefaConv2d(Cin, Cout, 3, padding=1, bias=False, bit_width=1).to(dev)
+        conv.weight.data.normal_(0, 0.05)
+        conv.eval()
+        bn = torch.nn.BatchNorm2d(Cout).to(dev).eval()
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(); bn.bias.data.normal_(0, 0.3)
+        x = torch.rand(N, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        head = FusedBnDorefaQuant(bn0, bits, relu=True, out_halo=1, fold="device")
+        blk = FusedDorefaConvBnQuant(conv, bn, bits, relu=relu, out_halo=oh, fold="device")
+        outs = []
+        with torch.no_grad():
+            for off in (False, True):
+                if off:
+                    os.environ["QT_NO_CODE_CONV3X3"] = "1"
+                else:
+                    os.environ.pop("QT_NO_CODE_CONV3X3", None)
+                try:
+                    act = head(x)
+                    c0 = int(count())
+                    y = blk(act, residual=act if use_res else None)
+                    assert int(count()) - c0 == (0 if off else 1), "route"
+                    outs.append((y.without_halo().codes.codes.clone(), y.codes.codes.clone(), int(y.codes.overflow.item())))
+                finally:
+                    os.environ.pop("QT_NO_CODE_CONV3X3", None)
+        assert torch.equal(outs[0][0], outs[1][0]), (Cin, Cout, H, W, N, bits, relu, use_res, oh)
+        assert torch.equal(outs[0][1], outs[1][1]), "halo border differs"
+        assert outs[0][2] == outs[1][2]
+        done += 1
+    assert done >= 16
