@@ -185,9 +185,21 @@ int64_t qt_code_conv3x3_launch_count(void);
  *   y[n, c, h, w] = sign(x[n, c, h, w]) * mean_c |x[n, :, h, w]|        torch.sign (0 -> 0, NaN -> NaN), one scale per pixel.
  * x: logical [N, C, H, W] fp32 with ELEMENT strides (sn, sc, sh, sw) (contiguous NCHW or channels-last); y: the same logical
  * tensor written densely in NHWC memory order [N][H][W][C] — the layout the per-tap scaled conv's operand pack and the
- * weight-gradient routes read (backward sees this quantised tensor, :144). */
-int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int64_t N, int64_t C,
-                            int64_t H, int64_t W, qt_stream_t stream);
+ * weight-gradient routes read (backward sees this quantised tensor, :144).
+ * a_plane (optional, like y): the scale plane A[N][H][W] itself — the per-(row, tap) factor of qt_conv2d_implicit_taps_rows. */
+int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, float* a_plane, int64_t N,
+                            int64_t C, int64_t H, int64_t W, qt_stream_t stream);
+
+/* XNORConv2d(quant_input = True) at the fp4 rate (functions/xnor_connect.py:142-145):
+ *   y[m, co] = sum_t alpha_t * A[pixel(m, t)] * (integer dot of sign(x) and sign(W) over tap t's channels)  (+ bias)
+ * P: fp4 nibble pixel plane of torch.sign(x) (+1 = 0x2, -1 = 0xA, 0 = 0x0; qt_sign0_pack_nib_f32), UN-padded [Nimg][H][W][Cw words],
+ * Cw % 8 == 0; Wmat: nibble plane of sign(W), tap-major; tap_rho: the forward table of qt_xnor_tap_prep_f32; a_plane: A[Nimg][H][W]
+ * (qt_xnor_input_quant_f32).  The Horner factor of a tap boundary is formed per output row from a_plane inside the kernel
+ * (ElemFp4TapsRows, csrc/mfma_gemm_kernel.h).  kh * kw <= 48 (the per-row table lives in LDS); QT_ERR_UNSUPPORTED beyond. */
+int qt_conv2d_implicit_taps_rows(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw, int64_t sh,
+                                 int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp,
+                                 const float* bias, const float* tap_rho, const float* a_plane, float* Y, int64_t ldy, int64_t Cout,
+                                 qt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bit-pack kernels (fp32 -> packed planes).  rows x K fp32 (row stride ldx) ->

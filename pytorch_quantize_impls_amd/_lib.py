@@ -53,7 +53,8 @@ SIGNATURES = {
     "qt_xnor_act_backward_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int,
                                           _c_p]),
     "qt_code_conv3x3_launch_count": (_c_i64, []),
-    "qt_xnor_input_quant_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_xnor_input_quant_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "qt_conv2d_implicit_taps_rows": (_c_int, [_c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "qt_sign_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_ternary_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_check_pm1_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p]),

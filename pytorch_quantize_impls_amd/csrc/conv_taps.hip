@@ -163,6 +163,31 @@ int qt_conv2d_implicit_taps_nib(int elem, const uint32_t* P, int64_t Nimg, int64
                           reinterpret_cast<float*>(nib_plane), ldn, Cout, stream, epi);
 }
 
+int qt_conv2d_implicit_taps_rows(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw, int64_t kh, int64_t kw, int64_t sh,
+                                 int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp,
+                                 const float* bias, const float* tap_rho, const float* a_plane, float* Y, int64_t ldy, int64_t Cout,
+                                 qt_stream_t stream) {
+    if (!tap_rho || !a_plane) return QT_ERR_INVALID_ARG;
+    if (Cw <= 0 || (Cw & 7)) return QT_ERR_ALIGNMENT;
+    if (kh * kw > 48) return QT_ERR_UNSUPPORTED;                  // (kh kw + 1) x 256 floats of LDS beside the stage buffers
+    ConvArgs cg;
+    EpiArgs epi;
+    bool valid;
+    int64_t M, K, kwords;
+    const int rc = conv_prepare(0, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, Y, ldy, Cout, epi, 0, 0, cg, valid, M,
+                                K, kwords);
+    if (rc != QT_OK) return rc > 0 ? QT_OK : rc;
+    epi.tap_rho = tap_rho;
+    epi.tap_ksteps = (int)(Cw / 8);
+    epi.ntaps = (int)(kh * kw);
+    epi.row_A = a_plane;
+    epi.aH = (int)H; epi.aW = (int)W; epi.aph = (int)ph; epi.apw = (int)pw;
+    // 256 x 128 tiles, double-buffered 128-byte stages, bounds-checked taps (the per-row factors need the accumulators in
+    // VALU-addressable registers next to 16 factor registers: the 64-register accumulator tile)
+    // (the 256 x 128 ping-pong tile measured slower here: AlexNet conv2 810 vs 752 us for the whole function, conv4 463 vs 444)
+    return launch_cfg<Conv128<ElemFp4TapsRows>>(P, 0, Wmat, ldwp, bias, 1.0f, nullptr, Y, ldy, M, Cout, K, stream, cg, epi);
+}
+
 int64_t qt_xnor_tap_prep_work_floats(int64_t R, int64_t taps) {
     if (R <= 0 || taps <= 0 || taps > 1024) return 0;
     return (int64_t)tap_alpha_blocks(R, taps, nullptr) * taps;

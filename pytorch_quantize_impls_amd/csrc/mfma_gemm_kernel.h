@@ -82,6 +82,9 @@ struct EpiArgs {
     // per-tap scaling (E::TAPS kernels only; see ElemFp4Taps): [1, rho_1 .. rho_{T-1}, alpha_{T-1}], MFMA k-steps per tap, T
     const float* tap_rho = nullptr;
     int tap_ksteps = 0, ntaps = 0;
+    // ElemFp4TapsRows only: per-pixel scale plane A [Nimg][aH][aW] of the conv's (logical, un-padded) input and its padding
+    const float* row_A = nullptr;
+    int aH = 0, aW = 0, aph = 0, apw = 0;
 };
 
 // spread the 8 bits of a byte to bit 0 of 8 nibbles
@@ -203,6 +206,17 @@ struct ElemFp4Taps : ElemFp4 {
 struct ElemF16Taps : ElemF16 {      // real-valued operand (grad_x of an XNOR conv: split gradient x flipped sign(W), alpha per tap)
     static constexpr bool TAPS = true;
 };
+// XNORConv2d(quant_input = True) (functions/xnor_connect.py:142-145): the activation is sign(x) * A with A = mean_c |x| PER PIXEL, so
+//     y[m, co] = sum_t alpha_t A[pixel(m, t)] D_t[m, co]        (D_t: the integer dot of sign(x) and sign(W) over tap t's channels)
+// — the Horner factor of a tap boundary becomes one per accumulator ROW:  F_t[m] = rho_t * a'_{t-1}[m] / a'_t[m]  (a' = A along the
+// row's taps with zeros — padding, all-zero pixels: their D_t is 0 — replaced by the previous non-zero entry), a table of
+// (T + 1) x TM floats in LDS filled once per tile from the A plane (EpiArgs::row_A); entry 0 holds a'_{T-1}[m] for the epilogue.
+// One fp4 pass like the +-1 conv instead of two fp16 passes over the real-valued x_q.
+struct ElemFp4TapsRows : ElemFp4Taps {
+    static constexpr bool ROWS = true;
+};
+template <class E, class = void> struct elem_rows : std::false_type {};
+template <class E> struct elem_rows<E, std::void_t<decltype(E::ROWS)>> : std::bool_constant<E::ROWS> {};
 
 // Workgroup = WM x WN waves (8 waves); wave tile = (TMW*32) m-rows x (TNW*32) n-rows.
 //   ABL (profiling only; results wrong unless 0): 1 = no MFMA, 2 = no DMA, 3 = epilogue only,
@@ -348,6 +362,43 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         rho_lds = r;
         if (epi.ntaps > 1) { tap_left = epi.tap_ksteps; tap_mul = r[1]; }
     }
+    [[maybe_unused]] const float* ftab = nullptr;            // ROWS: [ntaps + 1][TM] row factors (entry 0: the epilogue's)
+    if constexpr (elem_rows<E>::value) {
+        float* f = const_cast<float*>(rho_lds) + ((epi.ntaps + 1 + 3) & ~3);
+        const int T = epi.ntaps;
+        if (tid < C::TM) {
+            const int m = min(m0 + tid, M - 1);
+            const int hw = cg.Ho * cg.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / cg.Wo, wo = rem - ho * cg.Wo;
+            const float* Ap = epi.row_A + (int64_t)n * epi.aH * epi.aW;
+            const int h0 = ho * cg.sh - epi.aph, w0 = wo * cg.sw - epi.apw;
+            auto a_of = [&](int t) -> float {
+                const int i = t / cg.kw, j = t - i * cg.kw;
+                const int hi = h0 + i * cg.dh, wi = w0 + j * cg.dw;
+                return ((unsigned)hi < (unsigned)epi.aH && (unsigned)wi < (unsigned)epi.aW) ? Ap[hi * epi.aW + wi] : 0.0f;
+            };
+            // pass 1: the T scales of the row's window, independent loads (row t + 1 of the table holds a_t for now)
+#pragma unroll 5
+            for (int t = 0; t < T; ++t) f[(t + 1) * C::TM + tid] = a_of(t);
+            // pass 2 (this thread's own column of the table): zeros inherit, ratios in place — row t is written after it was read
+            float first = 1.0f;
+            for (int t = 0; t < T; ++t) {
+                const float v = f[(t + 1) * C::TM + tid];
+                if (v != 0.0f) { first = v; break; }
+            }
+            float prev = first;
+            for (int t = 0; t < T; ++t) {
+                float v = f[(t + 1) * C::TM + tid];
+                if (!(v != 0.0f)) v = prev;            // zero: any factor is right (D_t = 0); NaN compares unequal and is kept
+                if (t > 0) f[t * C::TM + tid] = rho_lds[t] * (prev / v);
+                prev = v;
+            }
+            f[tid] = prev;
+        }
+        __syncthreads();
+        ftab = f;
+    }
     // one MFMA k-step of the wave tile; at a tap boundary (E::TAPS) the accumulators are scaled first, in place.  (Interleaving
     // the packed multiplies of tile i + 1 with the MFMA of tile i — sched_group_barrier — was measured equal, AlexNet conv2 338 vs
     // 335 us, and makes the compiler alternate between two accumulator register sets: 253 VGPRs instead of 208.)
@@ -358,10 +409,31 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     auto tap_boundary = [&]() {
         if constexpr (E::TAPS) {
             if (tap_left == 0) {
+                if constexpr (elem_rows<E>::value) {
+                    // one factor per accumulator row: register r of the lane is row (r & 3) + 8 (r >> 2) + 4 lhalf of the block
+                    const float* ft = ftab + (tap_idx + 1) * C::TM + 4 * lhalf;
 #pragma unroll
-                for (int a = 0; a < C::TMW; ++a)
+                    for (int a = 0; a < C::TMW; ++a) {
+                        float4 f4[4];
 #pragma unroll
-                    for (int b = 0; b < C::TNW; ++b) acc[a][b] *= tap_mul;
+                        for (int j = 0; j < 4; ++j)
+                            f4[j] = *reinterpret_cast<const float4*>(ft + (wave_m * C::TMW + a) * 32 + 8 * j);
+#pragma unroll
+                        for (int b = 0; b < C::TNW; ++b)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                acc[a][b][4 * j + 0] *= f4[j].x;
+                                acc[a][b][4 * j + 1] *= f4[j].y;
+                                acc[a][b][4 * j + 2] *= f4[j].z;
+                                acc[a][b][4 * j + 3] *= f4[j].w;
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < C::TMW; ++a)
+#pragma unroll
+                        for (int b = 0; b < C::TNW; ++b) acc[a][b] *= tap_mul;
+                }
                 ++tap_idx;
                 tap_left = tap_idx + 1 < epi.ntaps ? epi.tap_ksteps : 0x3fffffff;
                 tap_mul = rho_lds[min(tap_idx + 1, epi.ntaps - 1)];
@@ -691,6 +763,24 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 
     if (scale_dev) scale *= *scale_dev;   // device-resident factor (e.g. DoReFa's E = mean|W|): no host sync
     if constexpr (E::TAPS) scale *= epi.tap_rho[epi.ntaps];   // alpha of the last tap closes the Horner form
+    if constexpr (elem_rows<E>::value) {                      // ... and the last tap's per-pixel scale, per accumulator row
+        const float* ft = ftab + 4 * lhalf;
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 f4 = *reinterpret_cast<const float4*>(ft + (wave_m * C::TMW + a) * 32 + 8 * j);
+#pragma unroll
+                for (int b = 0; b < C::TNW; ++b) {
+                    acc[a][b][4 * j + 0] *= f4.x;
+                    acc[a][b][4 * j + 1] *= f4.y;
+                    acc[a][b][4 * j + 2] *= f4.z;
+                    acc[a][b][4 * j + 3] *= f4.w;
+                }
+            }
+        }
+        __syncthreads();      // every wave has read its factors: the stage buffers' neighbourhood may become transpose patches
+    }
     // ---- epilogue: D[row = m][col = n]; lane owns column n, rows m = mb + (r&3) + 8*(r>>2) + 4*lhalf ---
     // The store tail is store-ISSUE bound (1024 dword wave-stores per CU: 13 us of a 41 us kernel at
     // 4096^3, tools/pp_stamps.py), so each 32x32 tile is transposed through a wave-private 4 KiB LDS
@@ -1080,7 +1170,8 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
     // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
     const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0) +
-                          (C::E::TAPS ? (epi.ntaps + 1 + 3) / 4 * 16 : 0);      // E::TAPS: + the per-tap factor table
+                          (C::E::TAPS ? (epi.ntaps + 1 + 3) / 4 * 16 : 0) +      // E::TAPS: + the per-tap factor table
+                          (elem_rows<typename C::E>::value ? (epi.ntaps + 1) * C::TM * 4 : 0);   // ROWS: + the per-row factor table
     if (lds_bytes > 160 * 1024) return QT_ERR_UNSUPPORTED;
     if constexpr (C::E::CODE_EPI && C::CONV) {
         if (epi.mode == 2 && epi.bn_stats) {

@@ -138,7 +138,8 @@ int check_args(const float* x, int64_t ldx, const float* mean, const float* work
 //   NCHW input: one thread per pixel (lanes along w: every channel's read is coalesced), the NHWC writes are strided.
 template <int G>
 __global__ __launch_bounds__(256) void xnor_input_quant_cl_kernel(const float* __restrict__ x, int64_t sn, int64_t sh, int64_t sw,
-                                                                  float* __restrict__ y, int64_t P, int C, int H, int W) {
+                                                                  float* __restrict__ y, float* __restrict__ aplane, int64_t P, int C,
+                                                                  int H, int W) {
     const int sub = threadIdx.x % G;
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, ngroups = (int64_t)gridDim.x * blockDim.x / G;
     const float inv_note = (float)C;
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(256) void xnor_input_quant_cl_kernel(const float* _
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
         const float a = acc / inv_note;
+        if (aplane && sub == 0) aplane[p] = a;
+        if (!y) continue;
         float* py = y + p * C;
         for (int c = sub; c < C; c += G) {
             const float v = px[c];
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(256) void xnor_input_quant_cl_kernel(const float* _
 }
 
 __global__ __launch_bounds__(256) void xnor_input_quant_strided_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh,
-                                                                       int64_t sw, float* __restrict__ y, int64_t P, int C, int H, int W) {
+                                                                       int64_t sw, float* __restrict__ y, float* __restrict__ aplane,
+                                                                       int64_t P, int C, int H, int W) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = p / ((int64_t)H * W), r = p - n * (int64_t)H * W;
         const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(256) void xnor_input_quant_strided_kernel(const flo
         float acc = 0.0f;
         for (int c = 0; c < C; ++c) acc += fabsf(px[c * sc]);
         const float a = acc / (float)C;
+        if (aplane) aplane[p] = a;
+        if (!y) continue;
         float* py = y + p * C;
         for (int c = 0; c < C; ++c) {
             const float v = px[c * sc];
@@ -204,17 +210,17 @@ int qt_xnor_act_backward_f32(const float* g, int64_t ldg, const float* x, int64_
     return qt_check_launch();
 }
 
-int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int64_t N, int64_t C,
-                            int64_t H, int64_t W, qt_stream_t stream) {
+int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, float* a_plane, int64_t N,
+                            int64_t C, int64_t H, int64_t W, qt_stream_t stream) {
     if (N < 0 || C < 0 || H < 0 || W < 0) return QT_ERR_INVALID_ARG;
     const int64_t P = N * H * W;
     if (P == 0 || C == 0) return QT_OK;
-    if (!x || !y || C > (1 << 24) || H > (1 << 24) || W > (1 << 24)) return QT_ERR_INVALID_ARG;
+    if (!x || (!y && !a_plane) || C > (1 << 24) || H > (1 << 24) || W > (1 << 24)) return QT_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (sc == 1) {
         const int G = C >= 48 ? 64 : C >= 24 ? 32 : C >= 12 ? 16 : C >= 6 ? 8 : 4;
         const int grid = qt_stream_grid((P * G + 255) / 256);
-#define QT_XIQ(g) hipLaunchKernelGGL((xnor_input_quant_cl_kernel<g>), dim3(grid), dim3(256), 0, st, x, sn, sh, sw, y, P, (int)C, (int)H, (int)W)
+#define QT_XIQ(g) hipLaunchKernelGGL((xnor_input_quant_cl_kernel<g>), dim3(grid), dim3(256), 0, st, x, sn, sh, sw, y, a_plane, P, (int)C, (int)H, (int)W)
         switch (G) {
             case 64: QT_XIQ(64); break;
             case 32: QT_XIQ(32); break;
@@ -225,7 +231,7 @@ int qt_xnor_input_quant_f32(const float* x, int64_t sn, int64_t sc, int64_t sh, 
 #undef QT_XIQ
     } else {
         hipLaunchKernelGGL(xnor_input_quant_strided_kernel, dim3(qt_stream_grid((P + 255) / 256)), dim3(256), 0, st, x, sn, sc, sh, sw,
-                           y, P, (int)C, (int)H, (int)W);
+                           y, a_plane, P, (int)C, (int)H, (int)W);
     }
     return qt_check_launch();
 }

@@ -162,22 +162,38 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
                         y = y.contiguous()
                     return y
             if quant_input:
-                # both operands binarised (:142-143): x -> sign(x) * mean(|x|, 1) per pixel, one pass; backward sees this
-                # quantised tensor (:144).  With one alpha per tap it is a REAL activation against sign(W): the two-term fp16
-                # split on the per-tap scaled conv (alpha on the accumulators), not the six-term real x real conv
+                # both operands binarised (:142-143): x -> sign(x) * mean(|x|, 1) per pixel; backward sees this quantised tensor
+                # (:144).  With one alpha per tap the conv is  sum_t alpha_t A[pixel(m, t)] D_t[m, co]  (D_t: integer dot of the two
+                # sign planes over tap t): ONE fp4 matrix-core pass with a per-(row, tap) factor on the accumulators
+                # (qt_conv2d_implicit_taps_rows); kernels beyond 48 taps: the two-term fp16 split of the quantised image x sign(W)
                 on_dev = input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0
-                input = ops.xnor_input_quant(input) if on_dev else torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
-                if (on_dev and _fused.xnor_conv_fast_applicable(input, weight, dim, groups, padding)
-                        and int(weight.shape[1]) % 8 == 0 and weight.is_cuda):
+                raw = input
+                need_image = (not on_dev) or any(ctx.needs_input_grad[:2])
+                a_plane = None
+                if on_dev:
+                    input, a_plane = ops.xnor_input_quant(raw, want_image=need_image, want_scale=True)
+                else:
+                    input = torch.sign(input) * torch.mean(torch.abs(input), 1, keepdim=True)
+                if on_dev and _fused.xnor_conv_fast_applicable(raw, weight, dim, groups, padding) and weight.is_cuda:
+                    kh, kw = int(weight.shape[2]), int(weight.shape[3])
                     taps = ops.xnor_tap_prep(weight)
-                    y2 = ops.conv2d_real_taps(input, weight, taps.fwd, bias, stride, padding, dilation)
+                    y2 = None
+                    if kh * kw <= 48:
+                        wp = ops.pack_conv_weight_nib(weight.detach(), "sign", cw=ops.pixel_ld_nib_taps(int(weight.shape[1])))
+                        y2 = ops.conv2d_nib_taps_rows(raw, a_plane, wp, (kh, kw), taps.fwd, bias, stride, padding, dilation)
+                    if y2 is None and int(weight.shape[1]) % 8 == 0:
+                        if input is None:
+                            input = ops.xnor_input_quant(raw)
+                        y2 = ops.conv2d_real_taps(input, weight, taps.fwd, bias, stride, padding, dilation)
                     if y2 is not None:
-                        kh, kw = int(weight.shape[2]), int(weight.shape[3])
                         ctx.taps = taps                                   # grad_input: the flipped taps, like the +-1 route
-                        ctx.save_for_backward(input, weight, taps.alpha.view(1, 1, kh, kw), bias)
-                        N_, _, H, W = input.shape
+                        if need_image:
+                            ctx.save_for_backward(input, weight, taps.alpha.view(1, 1, kh, kw), bias)
+                        N_, _, H, W = raw.shape
                         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
                         return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+                if input is None:
+                    input = ops.xnor_input_quant(raw)
             weight_b, mean_weight = xnor_weight(weight, dim)
             ctx.save_for_backward(input, weight, mean_weight, bias)
             if (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0

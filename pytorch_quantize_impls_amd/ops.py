@@ -387,20 +387,57 @@ def xnor_weight(w: torch.Tensor, lead_dims: int = 1):
     return wq, alpha.view((1,) * lead_dims + tuple(w.shape[lead_dims:]))
 
 
-def xnor_input_quant(x: torch.Tensor) -> torch.Tensor:
+def xnor_input_quant(x: torch.Tensor, want_image: bool = True, want_scale: bool = False):
     """Input quantiser of XNORConv2d(quant_input=True): sign(x) * mean(|x|, 1, keepdim) (functions/xnor_connect.py:142-143) for an
-    NCHW or channels-last fp32 tensor, one pass (qt_xnor_input_quant_f32).  The result is the same logical [N, C, H, W] tensor in
-    channels-last memory (its NHWC matrix is what the conv's operand pack and the weight-gradient routes read)."""
+    NCHW or channels-last fp32 tensor, one pass (qt_xnor_input_quant_f32).  The image is the same logical [N, C, H, W] tensor in
+    channels-last memory (its NHWC matrix is what the conv's operand pack and the weight-gradient routes read); ``want_scale``:
+    also (or only) the per-pixel scale plane A [N, H, W].  Returns the image, or (image or None, A)."""
     x = _require(x, "input")
     if x.dim() != 4:
         raise ValueError("xnor_input_quant takes a [N, C, H, W] tensor")
     N, C, H, W = (int(v) for v in x.shape)
-    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device) if want_image else None
+    a = torch.empty((N, H, W), dtype=torch.float32, device=x.device) if want_scale else None
     if x.numel():
         sn, sc, sh, sw = (int(v) for v in x.stride())
         with _on(x.device):
-            _lib.call("qt_xnor_input_quant_f32", _p(x), sn, sc, sh, sw, _p(y), N, C, H, W, _stream(x.device))
-    return y.permute(0, 3, 1, 2)
+            _lib.call("qt_xnor_input_quant_f32", _p(x), sn, sc, sh, sw, _p(y), _p(a), N, C, H, W, _stream(x.device))
+    img = y.permute(0, 3, 1, 2) if y is not None else None
+    return (img, a) if want_scale else img
+
+
+def conv2d_nib_taps_rows(x: torch.Tensor, a_plane: torch.Tensor, wplanes: "NibPlanes", kernel_hw, tap_rho: torch.Tensor, bias=None,
+                         stride=1, padding=0, dilation=1):
+    """XNORConv2d(quant_input=True) at the fp4 rate: sign(x) as an fp4 nibble pixel plane (0 stays 0) against the nibble plane of
+    sign(W), alpha per tap AND the per-pixel scale ``a_plane`` [N, H, W] applied on the accumulators, one factor per output row and
+    tap (qt_conv2d_implicit_taps_rows).  Returns the NHWC result [N*Ho*Wo, Cout] or None outside the kernel's limits."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    kh, kw = (int(v) for v in kernel_hw)
+    (sh, sw), (ph, pw), (dh, dw) = _pairs(stride), _pairs(padding), _pairs(dilation)
+    if kh * kw > 48 or x.numel() == 0:
+        return None
+    Cw = pixel_ld_nib_taps(C)
+    if wplanes.K != kh * kw * Cw * 8:
+        raise ValueError("weight planes do not match the activation's channel packing")
+    nhwc = x.detach().permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    px = sign0_pack_nib(nhwc.view(N * H * W, C), ld=Cw)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    M, Cout = N * Ho * Wo, wplanes.rows
+    if (M >= (1 << 31) or kh * kw * Cw * 4 >= (1 << 20) or H > 32767 or W > 32767 or wplanes.ld % 32
+            or H * W * Cw * 4 >= (1 << 31) or Cout * wplanes.ld * 4 >= (1 << 31)):
+        return None
+    bias = _check_bias(bias, Cout, x.device)
+    rho = _require(tap_rho, "tap_rho")
+    a = _require(a_plane, "a_plane").contiguous()
+    y = torch.empty((M, Cout), dtype=torch.float32, device=x.device)
+    I = int
+    with _on(x.device):
+        _lib.call("qt_conv2d_implicit_taps_rows", _p(px.words), I(N), I(H), I(W), I(Cw), I(kh), I(kw), I(sh), I(sw), I(ph), I(pw), I(dh),
+                  I(dw), _p(wplanes.words), I(wplanes.ld), _p(bias), _p(rho), _p(a), _p(y), I(Cout), I(Cout), _stream(x.device))
+    return y
 
 
 def shift_batch(x: torch.Tensor, running_mean, running_var, weight, bias, eps: float, want_saved: bool = True):

@@ -240,7 +240,7 @@ def test_xnor_conv_quant_input_reference_digest(dev, name):
         got = np.ascontiguousarray(y.cpu().numpy(), dtype=np.float32)
         assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256_f32"], fmt
     assert _lib_delta(before) == {}
-    assert _lib.call_counts["qt_conv2d_implicit_taps"] == calls.get("qt_conv2d_implicit_taps", 0) + 2
+    assert _lib.call_counts["qt_conv2d_implicit_taps_rows"] == calls.get("qt_conv2d_implicit_taps_rows", 0) + 2     # the fp4-rate route
     assert _lib.call_counts["qt_xnor_input_quant_f32"] == calls.get("qt_xnor_input_quant_f32", 0) + 2
 
 
@@ -274,9 +274,12 @@ def test_xnor_conv_quant_input_vs_reference_fp64(dev, g5, name):
 def test_xnor_conv_quant_input_vs_oracle_seeded(dev, oracle):
     from pytorch_quantize_impls_amd import synth
     for seed, (B, Cin, Cout, H, k, s, p) in enumerate(((3, 64, 40, 12, 3, 1, 1), (2, 32, 48, 9, 5, 1, 2), (2, 16, 24, 11, 3, 2, 0),
-                                                       (1, 8, 8, 5, 1, 1, 0))):
+                                                       (1, 8, 8, 5, 1, 1, 0), (2, 3, 32, 19, 5, 2, 2), (2, 20, 130, 10, 3, 1, 2),
+                                                       (5, 96, 200, 7, 3, 1, 1), (1, 7, 9, 6, 6, 1, 3))):
         x = synth.normal(900 + seed, (B, Cin, H, H))
         x.reshape(-1)[::41] = 0.0
+        x[:, :, 1::4, 2::3] = 0.0                      # whole pixels of zeros: their scale is 0 (the row factor inherits)
+        x[0, :, :2, :] = 0.0                           # ... and whole windows of them
         w = synth.normal(950 + seed, (Cout, Cin, k, k), 0.1)
         b = synth.normal(980 + seed, (Cout,))
         want = oracle.xnor_conv2d_forward(x, w, b, s, p, quant_input=True)
