@@ -90,7 +90,8 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
     unsigned char* Wl = smem;
     // (patch buffer b lives at smem + TN * WROW + b * patch_bytes_max: always addressed as an offset from ``smem`` itself — a
     //  pointer picked from an array by a run-time index loses its LDS address space and its reads become flat loads)
-    float* Tall = reinterpret_cast<float*>(smem + TN * WROW + 2 * patch_bytes_max);
+    // MODE 5: ONE patch buffer, the transpose patches alias it (dead after the main loop): 49 KiB per workgroup -> 3 per CU
+    float* Tall = reinterpret_cast<float*>(smem + TN * WROW + (MODE == 5 ? 0 : 2 * patch_bytes_max));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
                     cur ^= 1;
                     continue;
                 }
-            } else {
+            } else if constexpr (MODE != 5) {
                 if (nxt < a.tiles_m) issue_patch(nxt, cur ^ 1, 0, 256);
             }
             // plane rows of this lane's 4 output pixels (pixel m = m0 + 32 wave + 8 i + (lane >> 3)) and the residual's code words,
@@ -261,6 +262,10 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
             }
 
             if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (MODE == 5) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the residual words
+                __syncthreads();                                           // every wave is done reading the patch: it becomes T
+            }
             // ---- code epilogue (the straight-line form of mfma_gemm_kernel.h, mode 2, device BatchNorm arithmetic) ---------
             auto body = [&](auto rc_tag, auto relu_tag) {
                 constexpr bool RC = decltype(rc_tag)::value, RELU = decltype(relu_tag)::value;
@@ -328,6 +333,15 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
             // the barrier joins the four waves' shares of the next patch (each waited for its own above) and tells that every
             // wave is done reading the current one
             if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (MODE == 5) {
+                __syncthreads();                                           // the transpose patches are dead: the buffer may be refilled
+                if (nxt < a.tiles_m) {
+                    issue_patch(nxt, 0, 0, 256);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // exposed per workgroup; two other workgroups of the CU run meanwhile
+                }
+                __syncthreads();
+                continue;
+            }
             __syncthreads();
             cur ^= 1;
         }
@@ -368,7 +382,14 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     const int64_t tiles_m = (rows_total + RT - 1) / RT, tiles_n = Cout / 64;
     const int64_t patch_rows = RT <= H ? RT + 2 : (RT / H) * Hp;
     const int64_t patch_bytes = (patch_rows * Wp * CB + 255) / 256 * 256;
-    const int64_t lds = 64 * 9 * CB + 2 * patch_bytes + 4 * 4096;
+    const char* fm0 = getenv("QT_C3_MODE");
+#ifdef QT_PROFILING_VARIANTS
+    const bool single = fm0 && atoi(fm0) == 5;                                  // profiling builds: the single-buffer variant
+#else
+    const bool single = false;
+    (void)fm0;
+#endif
+    const int64_t lds = single ? 64 * 9 * CB + std::max<int64_t>(patch_bytes, 4 * 4096) : 64 * 9 * CB + 2 * patch_bytes + 4 * 4096;
     if (lds > 160 * 1024 || tiles_m * tiles_n > (1 << 30)) return QT_ERR_UNSUPPORTED;
     C3Args a;
     a.P = reinterpret_cast<const unsigned char*>(P);
@@ -386,7 +407,8 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     a.Q = codes; a.ldq = (int)ldc_bytes; a.ohy = (int)ohy; a.ohx = (int)ohx;
     a.overflow = overflow;
     // persistent grid: as many workgroups as stay resident (LDS-bound), a multiple of the column tiles
-    const int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds));
+    int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds));
+    if (const char* pc = getenv("QT_C3_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(pc)));     // tools: occupancy experiments
     int64_t grid = std::min<int64_t>(tiles_m * tiles_n, 256ll * per_cu);
     grid = std::max<int64_t>(tiles_n, grid / tiles_n * tiles_n);
     hipStream_t st = (hipStream_t)stream;
@@ -405,9 +427,10 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
                            (int)patch_bytes);                                                                                       \
     } while (0)
 #ifdef QT_PROFILING_VARIANTS
-    if (mode == 1 || mode == 3 || mode == 4) {     // ablations: wait at the tile end / no main loop / no epilogue (results wrong for 3, 4)
-        if (CB == 64) { if (mode == 1) QT_C3(64, 1); else if (mode == 3) QT_C3(64, 3); else QT_C3(64, 4); }
-        else { if (mode == 1) QT_C3(128, 1); else if (mode == 3) QT_C3(128, 3); else QT_C3(128, 4); }
+    if (mode == 1 || mode == 3 || mode == 4 || mode == 5) {     // ablations: wait at the tile end / no main loop / no epilogue (results
+        // wrong for 3, 4) / ONE patch buffer with the transpose patches aliased on it, 3 workgroups per CU (26.3 vs 23.4 us: slower)
+        if (CB == 64) { if (mode == 1) QT_C3(64, 1); else if (mode == 3) QT_C3(64, 3); else if (mode == 4) QT_C3(64, 4); else QT_C3(64, 5); }
+        else { if (mode == 1) QT_C3(128, 1); else if (mode == 3) QT_C3(128, 3); else if (mode == 4) QT_C3(128, 4); else QT_C3(128, 5); }
         return qt_check_launch();
     }
 #endif
