@@ -929,11 +929,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                                                              torch.where(ws_ < 0, -1.0, 1.0).double()).float()))
                     exact_what = "fp64 of sign(x) . sign(W)^T"
                 else:                                        # fp64 weights would take 34 GB: the tiled popcount kernel instead
-                    ops.POPC_VARIANT = 1
-                    try:
-                        exact = bool(torch.equal(ys_.clone(), ops.xnor_gemm(xps, wps)))
-                    finally:
-                        ops.POPC_VARIANT = 0
+                    exact = bool(torch.equal(ys_.clone(), ops.xnor_gemm(xps, wps, variant=1)))
                     exact_what = "the tiled popcount kernel (itself oracle-tested)"
                 del xs_, ws_
                 side = torch.cuda.Stream()
@@ -1072,6 +1068,9 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "unfused": _net_line("c5", Bv, world, 3, el_u5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense", fp32_activations=True),
             "fused": _net_line("c5", Bv, world, iters, el_f5, st5, MFMA_FP4_PEAK_TFLOPS, "fp4 MFMA 10 PF dense",
                                {"argmax_agreement_with_unfused": agree5}),
+            "parity": "every conv / FC shape of the net exact against the device dense conv at full 224 x 224 geometry (batch 2 - 64) and the "
+                      "last block against a batch-256 reference digest (tests/test_gpu_configs.py, test_gpu_r4.py); the whole net against the "
+                      "oracle chain at 64 x 64 inputs; here: deferred == fused == module-by-module logits (torch.equal) at full size",
             "global_batch": Bv * world}
     # ---- training step: BinaryNet-AlexNet forward + backward at the headline batch, this backend vs the
     # reference's op sequence through ROCm PyTorch on the same GPU (tools/bench_train_step.py holds both forms)

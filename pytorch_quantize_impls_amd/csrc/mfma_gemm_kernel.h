@@ -829,7 +829,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             // so the per-element chain is 10 (13 with a code residual) VALU instructions with no per-element scalar branch.  The
             // general form below spends ~2x that on its wave-uniform-but-unknown-at-compile-time conditions, and these short
             // small-N launches are VALU-issue bound in their epilogue (profiles/r5_c4_pmc.md).  Same roundings, same codes.
-            const bool fast = !bias && !epi.res_f32 && epi.relu != 2 && (N & 3) == 0 && n0 + C::TN <= N;
+            // (whole ROW tiles too: a bounds branch per row group puts every group in its own basic block, and the waitcnt pass then
+            //  drains the previous group's code store before each group's first use of a residual word — profiles/r5_c4_direct_conv.md)
+            const bool fast = !bias && !epi.res_f32 && epi.relu != 2 && (N & 3) == 0 && n0 + C::TN <= N && m0 + C::TM <= M;
             if (fast) {
                 int badf = 0;
                 const float levels = epi.levels, rscale = epi.rscale;
@@ -847,6 +849,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             mean[e] = epi.bn_stats[n + e];
                             rs[e] = epi.bn_stats[N + n + e];
                         }
+                        // the residual words of this column block, all requested up front
+                        uint32_t rwd[C::TMW][4];
+#pragma unroll
+                        for (int a = 0; a < C::TMW; ++a)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                rwd[a][i] = 0;
+                                if constexpr (RC) rwd[a][i] = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)rrow[a][i] * epi.ldrc + n);
+                            }
 #pragma unroll
                         for (int a = 0; a < C::TMW; ++a) {
                             const int mb = m0 + (wave_m * C::TMW + a) * 32;
@@ -860,11 +871,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                             for (int i = 0; i < 4; ++i) {
                                 const int row = i * 8 + (lane >> 3);
                                 const float4 v4 = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
-                                if (mb + row < M) {
+                                {
                                     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                                    uint32_t rword = 0;
-                                    if constexpr (RC)
-                                        rword = *reinterpret_cast<const uint32_t*>(epi.res_codes + (int64_t)rrow[a][i] * epi.ldrc + n);
+                                    const uint32_t rword = rwd[a][i];
                                     uint32_t word = 0;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {

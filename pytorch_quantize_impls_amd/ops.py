@@ -633,8 +633,9 @@ CONV_VARIANT = 0
 
 
 def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) for +-1 operands given as sign planes."""
+              out: Optional[torch.Tensor] = None, variant: Optional[int] = None) -> torch.Tensor:
+    """Y[M,N] = sum_k x[m,k]*w[n,k] (+ bias) for +-1 operands given as sign planes.  ``variant``: force one of the popcount kernels
+    (1 = tiled, 2 = skinny, 3 = streaming) for this call; default: the library's own choice (POPC_VARIANT, a tools-only default)."""
     if x.K != w.K:
         raise ValueError(f"K mismatch: activations {x.K} vs weights {w.K}")
     if x.is_ternary or w.is_ternary:
@@ -647,8 +648,9 @@ def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     with _on(dev):
         args = (_p(x.sign), int(x.ld), _p(w.sign), int(w.ld), _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)),
                 int(M), int(N), int(K), _stream(dev))
-        if POPC_VARIANT:
-            _lib.call("qt_xnor_gemm_variant", int(POPC_VARIANT), *args)
+        v = POPC_VARIANT if variant is None else int(variant)
+        if v:
+            _lib.call("qt_xnor_gemm_variant", int(v), *args)
         else:
             _lib.call("qt_xnor_gemm", *args)
     return out
