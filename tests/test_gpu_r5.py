@@ -510,3 +510,33 @@ def test_direct_code_conv3x3_geometry_fuzz(dev):
         assert outs[0][2] == outs[1][2]
         done += 1
     assert done >= 16
+
+
+@pytest.mark.parametrize("bits", [1, 3, 8])
+def test_dorefa_eval_mode_forward_under_autograd(dev, bits):
+    """DoReFa layers in eval mode with autograd on (parameters require grad): F.linear / F.conv2d on the stored image is the reference
+    expression (layers/dorefa_layers.py:45,81); forward + input / weight gradients vs fp64, no dense-library call."""
+    from pytorch_quantize_impls_amd.functions import _fused
+    from pytorch_quantize_impls_amd.layers import DorefaConv2d, LinearDorefa
+    torch.manual_seed(20 + bits)
+    conv = DorefaConv2d(16, 24, 3, padding=1, bit_width=bits).to(dev)
+    lin = LinearDorefa(24 * 5 * 5, 10, bit_width=bits).to(dev)
+    conv.eval(), lin.eval()
+    x = torch.rand(6, 16, 5, 5, device=dev).requires_grad_(True)
+    old = _fused.BWD_MFMA_MIN_MACS
+    _fused.BWD_MFMA_MIN_MACS = 0
+    before = dict(_fused.LIBRARY_PATHS)
+    try:
+        y = lin(conv(x).flatten(1))
+        g = torch.randn_like(y)
+        y.backward(g)
+    finally:
+        _fused.BWD_MFMA_MIN_MACS = old
+    assert _lib_delta(before) == {}
+    wc, wl = conv.weight.detach().double().cpu().requires_grad_(True), lin.weight.detach().double().cpu().requires_grad_(True)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.linear(torch.nn.functional.conv2d(xr, wc, conv.bias.detach().double().cpu(), padding=1).flatten(1), wl,
+                                    lin.bias.detach().double().cpu())
+    yr.backward(g.double().cpu())
+    for got, want in ((y, yr), (x.grad, xr.grad), (conv.weight.grad, wc.grad), (lin.weight.grad, wl.grad)):
+        assert float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()) <= 1e-5
