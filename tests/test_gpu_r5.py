@@ -282,12 +282,13 @@ def test_xnor_conv_quant_input_vs_oracle_seeded(dev, oracle):
         x[0, :, :2, :] = 0.0                           # ... and whole windows of them
         w = synth.normal(950 + seed, (Cout, Cin, k, k), 0.1)
         b = synth.normal(980 + seed, (Cout,))
-        want = oracle.xnor_conv2d_forward(x, w, b, s, p, quant_input=True)
-        op = xnor_connect.XNORConv2d([0, 1], True, s, p, 1, 1)
-        with torch.no_grad():
-            got = op.apply(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
-        assert got.shape == want.shape
-        assert float(np.abs(got - want).max() / np.abs(want).max()) <= 1e-5, (B, Cin, Cout, H, k, s, p)
+        for dil in ((1, 2) if seed in (0, 5) else (1,)):
+            want = oracle.xnor_conv2d_forward(x, w, b, s, p, dil, quant_input=True)
+            op = xnor_connect.XNORConv2d([0, 1], True, s, p, dil, 1)
+            with torch.no_grad():
+                got = op.apply(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+            assert got.shape == want.shape
+            assert float(np.abs(got - want).max() / np.abs(want).max()) <= 1e-5, (B, Cin, Cout, H, k, s, p, dil)
 
 
 # ---- DoReFa layers at 8 < bit_width < 32 (VERDICT r4 missing #3; G23) ------------------------------------------------------------------
