@@ -49,6 +49,7 @@ struct C3Args {
     int8_t* Q;
     int ldq, ohy, ohx;
     int32_t* overflow;
+    int no_xcd_order;           // tools: plain workgroup order (A/B)
 };
 
 // LDS chunk swizzle: 16-byte chunk c of pixel / weight row q lands on chunk c ^ x(q) of its CB-byte record, so that the 16 lanes
@@ -97,10 +98,14 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void code_conv3x3_kernel(con
 
     const int ntiles = a.tiles_m * a.tiles_n;
     // persistent walk: workgroup b takes column tile b % tiles_n and the row tiles b / tiles_n, + gridDim / tiles_n, ...
-    const int tile_n = blockIdx.x % a.tiles_n;
+    // XCD-aware order (speed only): workgroup b is observed to run on XCD b % 8, so XCD x takes a CONTIGUOUS range of the walk's
+    // slots — neighbouring row tiles share two of their patch rows, which then meet in one L2
+    int slot = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && !a.no_xcd_order) slot = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile_n = slot % a.tiles_n;
     const int n0 = tile_n * TN;
     const int mstep = gridDim.x / a.tiles_n;          // the host launches a multiple of tiles_n workgroups
-    int tm = blockIdx.x / a.tiles_n;
+    int tm = slot / a.tiles_n;
 
     if (tm < a.tiles_m) {
         // ---- weights of this column tile, once: slot s = 16 bytes; row n = s / (9 CPP), tap t, physical chunk c' -------------
@@ -406,6 +411,7 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     a.res_codes = res_codes; a.ldrc = (int)ldrc_bytes; a.rhy = (int)rhy; a.rhx = (int)rhx;
     a.Q = codes; a.ldq = (int)ldc_bytes; a.ohy = (int)ohy; a.ohx = (int)ohx;
     a.overflow = overflow;
+    a.no_xcd_order = getenv("QT_C3_PLAIN_ORDER") ? 1 : 0;
     // persistent grid: as many workgroups as stay resident (LDS-bound), a multiple of the column tiles
     int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds));
     if (const char* pc = getenv("QT_C3_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(pc)));     // tools: occupancy experiments
