@@ -1070,7 +1070,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                {"argmax_agreement_with_unfused": agree5}),
             "parity": "every conv / FC shape of the net exact against the device dense conv at full 224 x 224 geometry (batch 2 - 64) and the "
                       "last block against a batch-256 reference digest (tests/test_gpu_configs.py, test_gpu_r4.py); the whole net against the "
-                      "oracle chain at 64 x 64 inputs; here: deferred == fused == module-by-module logits (torch.equal) at full size",
+                      "CPU execution at 64 x 64 and at the full 224 x 224 geometry (sign ties counted, logits <= 1e-5 with the codes "
+                      "forced); here: deferred == fused == module-by-module logits (torch.equal) at full size",
             "global_batch": Bv * world}
     # ---- training step: BinaryNet-AlexNet forward + backward at the headline batch, this backend vs the
     # reference's op sequence through ROCm PyTorch on the same GPU (tools/bench_train_step.py holds both forms)
