@@ -258,7 +258,7 @@ def main():
                    # un-tagged inputs of the layer-level legs (AlexNet / C4 / C5) are checked for +-1 on the device; "verify" =
                    # one 4-byte readback per un-tagged input per forward (functions/_fused.py); the C2 step itself packs
                    # through ops.* and asks nothing
-                   "detect_mode": _fused.DETECT_MODE, "float_split": ops.current_float_split(),
+                   "detect_mode": _fused.detect_mode(), "float_split": ops.current_float_split(),
                    "legs": "every leg of this line runs with detect_mode and float_split above unless its own object says otherwise "
                            "(with_remembered_range_verdicts: detect_mode 'remember'; Lin/Log layers: bf16x3); real-valued first layers: "
                            "AlexNet conv1 on the direct kernel (per-tile two-term fp16 split), VGG conv1 on bf16 triples", "deferred_activations": "on (lazy.ENABLED, lazy.DEFER_CODES): bit-identical "
@@ -1170,12 +1170,11 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             # number) — eager, and the whole forward + backward captured once as a hipGraph and replayed
             from pytorch_quantize_impls_amd.functions import _fused as _ff
             remembered = {}
-            prev_mode = _ff.DETECT_MODE
             try:
-                _ff.DETECT_MODE = "remember"
-                fused_r = bench_models.TrainFusedDorefaResNet18(mr)
-                t_m, _ = bts.step_time(lsm(mr), mr, xr, tt, n=10)
-                t_f, _ = bts.step_time(lsm(fused_r), mr, xr, tt, n=10)
+                with _ff.detect_scope("remember"):        # thread-local; the Functions carry it into their backward
+                    fused_r = bench_models.TrainFusedDorefaResNet18(mr)
+                    t_m, _ = bts.step_time(lsm(mr), mr, xr, tt, n=10)
+                    t_f, _ = bts.step_time(lsm(fused_r), mr, xr, tt, n=10)
                 remembered = {"module_graph_ms_per_step": t_m, "fused_chain_ms_per_step": t_f}
                 from pytorch_quantize_impls_amd import utils as _utils
                 gstep = _utils.GraphedTrainStep(fused_r, lambda o_, t_: torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(o_, 1), t_),
@@ -1192,8 +1191,6 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                 del gstep
             except Exception as exc:
                 remembered["error"] = f"{type(exc).__name__}: {exc}"
-            finally:
-                _ff.DETECT_MODE = prev_mode
             out["n2_training_step_dorefa_resnet18_w1a4"] = {
                 "workload": f"DoReFa ResNet-18 W1A4 3x32x32 batch {Bt}, training mode, forward + backward (nll loss), channels_last; "
                             "fp32 stem conv and classifier are torch's, as in the reference",
@@ -1206,7 +1203,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
                                               "what": "bench_models.TrainFusedDorefaResNet18: BatchNorm(batch statistics) + shortcut add + "
                                                       "ReLU + k-bit quantiser forward + backward as one node per conv "
                                                       "(layers.FusedTrainBnActQuant, opt-in)"},
-                "with_remembered_range_verdicts": dict(remembered, what="_fused.DETECT_MODE = 'remember': no host sync per layer for "
+                "with_remembered_range_verdicts": dict(remembered, what="_fused.detect_scope('remember'): no host sync per layer for "
                                                        "'do these codes fit int8?'; hipGraph = utils.GraphedTrainStep (forward + loss + backward captured once; every replay copies the batch in)"),
                 "dense_library_calls_in_the_steps": lib_r,
                 "note": "many small launches (3 x 32 x 32 maps): ~1100 kernels per step in the module graph; "

@@ -14,6 +14,7 @@ CPU tensors: the same expression in torch (host logic; never used for a device t
 """
 from __future__ import annotations
 
+import contextlib
 import threading
 import weakref
 from collections import Counter
@@ -100,6 +101,34 @@ def pack_weight(weight_2d: torch.Tensor, kind: str, impl: str = "valu"):
 # Activations that carry a tag from their quantiser (BinaryConnect, nnDorefaQuant: packed.py) never get here for the
 # +-1 question.
 DETECT_MODE = "verify"
+_detect_tls = threading.local()
+
+
+def detect_mode() -> str:
+    """The detection mode in force in THIS thread: the innermost ``detect_scope(...)``, else the module default DETECT_MODE."""
+    return getattr(_detect_tls, "mode", None) or DETECT_MODE
+
+
+def detect_mode_override() -> Optional[str]:
+    return getattr(_detect_tls, "mode", None)
+
+
+@contextlib.contextmanager
+def detect_scope(mode: Optional[str]):
+    """``with detect_scope("remember"):`` — thread-local like ops.float_split: a capturing thread (utils.GraphedTrainStep) does not
+    change what a serving thread beside it asks the device; autograd Functions re-open the forward's scope around their backward
+    (functions.common.QtFunction), which runs on the engine's thread.  None = leave as is."""
+    if mode is not None and mode not in ("verify", "remember"):
+        raise ValueError(f"DETECT_MODE must be 'verify' or 'remember', got {mode!r}")
+    prev = getattr(_detect_tls, "mode", None)
+    if mode is not None:
+        _detect_tls.mode = mode
+    try:
+        yield
+    finally:
+        _detect_tls.mode = prev
+
+
 _VERDICTS = {}     # id(weight tensor) -> (weak reference to it, {(question, shape): bool}); tensors compare element-wise, so
 #                    they cannot key a WeakKeyDictionary
 #: "sync": decisions that needed a host sync; "cached": decisions taken from a remembered verdict (tests assert on it)
@@ -116,8 +145,9 @@ def reset_detection(weight: Optional[torch.Tensor] = None) -> None:
 
 def _verdict(weight, tag, resolve):
     """(answer, trusted-from-cache)"""
-    if DETECT_MODE not in ("verify", "remember"):
-        raise ValueError(f"DETECT_MODE must be 'verify' or 'remember', got {DETECT_MODE!r}")
+    mode = detect_mode()
+    if mode not in ("verify", "remember"):
+        raise ValueError(f"DETECT_MODE must be 'verify' or 'remember', got {mode!r}")
     if weight is None:
         DETECT_STATS["sync"] += 1
         return bool(resolve()), False
@@ -127,7 +157,7 @@ def _verdict(weight, tag, resolve):
         slot = (weakref.ref(weight, lambda _r, k=key: _VERDICTS.pop(k, None)), {})
         _VERDICTS[key] = slot
     d = slot[1]
-    if tag in d and (d[tag] is False or DETECT_MODE == "remember"):
+    if tag in d and (d[tag] is False or mode == "remember"):
         DETECT_STATS["cached"] += 1
         return d[tag], True
     d[tag] = bool(resolve())

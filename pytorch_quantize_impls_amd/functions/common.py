@@ -25,22 +25,25 @@ class QtFunction(torch.autograd.Function):
     the chain instead (BinaryConnectDeterministic, nnDorefaQuant's Function) override ``apply`` and end here."""
 
     def __init_subclass__(cls, **kwargs):
-        """A graph is differentiated under the float split it was built under: ``forward`` records the thread's
-        ``ops.float_split`` override on ctx, ``backward`` (run by the autograd engine's own thread) re-opens it."""
+        """A graph is differentiated under the thread-local switches it was built under: ``forward`` records the thread's
+        ``ops.float_split`` / ``_fused.detect_scope`` overrides on ctx, ``backward`` (run by the autograd engine's own thread)
+        re-opens them."""
         super().__init_subclass__(**kwargs)
         fwd, bwd = cls.__dict__.get("forward"), cls.__dict__.get("backward")
         if isinstance(fwd, staticmethod) and isinstance(bwd, staticmethod) and not getattr(fwd.__func__, "_qt_wrapped", False):
             f0, b0 = fwd.__func__, bwd.__func__
 
             def forward(ctx, *a, **k):
-                ctx._qt_split = ops.float_split_override()
+                from . import _fused
+                ctx._qt_split, ctx._qt_detect = ops.float_split_override(), _fused.detect_mode_override()
                 return f0(ctx, *a, **k)
 
             def backward(ctx, *g):
-                mode = getattr(ctx, "_qt_split", None)
-                if mode is None:
+                split, detect = getattr(ctx, "_qt_split", None), getattr(ctx, "_qt_detect", None)
+                if split is None and detect is None:
                     return b0(ctx, *g)
-                with ops.float_split(mode):
+                from . import _fused
+                with ops.float_split(split), _fused.detect_scope(detect):
                     return b0(ctx, *g)
             forward._qt_wrapped = backward._qt_wrapped = True
             forward.__doc__, backward.__doc__ = f0.__doc__, b0.__doc__

@@ -170,9 +170,7 @@ class GraphedTrainStep:
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)          # static gradient buffers: the captured backward accumulates into them
-        prev = _fused.DETECT_MODE
-        _fused.DETECT_MODE = "remember"
-        try:
+        with _fused.detect_scope("remember"):          # thread-local; the Functions carry it into their backward
             with torch.cuda.stream(self._stream):
                 for _ in range(max(1, warmup)):       # verdicts asked (and remembered), allocations and weight caches settle
                     self._one()
@@ -180,8 +178,6 @@ class GraphedTrainStep:
                 with torch.cuda.graph(self._graph, stream=self._stream):
                     self._loss = self._one()
             torch.cuda.synchronize(example_input.device)
-        finally:
-            _fused.DETECT_MODE = prev
 
     def _one(self):
         self.model.zero_grad(set_to_none=False)

@@ -182,3 +182,28 @@ def test_auto_graphed_training_check_ignores_the_layers_own_children():
     m.blocks[5].conv1.train()
     assert _any_training(m)
     assert not _any_training(m.eval()) and _any_training(m.train())
+
+
+def test_detect_scope_and_float_split_are_thread_local():
+    """the switches a capturing / exact-split thread opens are invisible to the thread beside it."""
+    import threading
+    from pytorch_quantize_impls_amd import ops
+    from pytorch_quantize_impls_amd.functions import _fused
+    seen = {}
+
+    def other():
+        seen["detect"], seen["split"] = _fused.detect_mode(), ops.current_float_split()
+
+    with _fused.detect_scope("remember"), ops.float_split("bf16x3"):
+        assert _fused.detect_mode() == "remember" and ops.current_float_split() == "bf16x3"
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        with _fused.detect_scope(None), ops.float_split(None):          # None = leave as is
+            assert _fused.detect_mode() == "remember" and ops.current_float_split() == "bf16x3"
+    assert seen == {"detect": _fused.DETECT_MODE, "split": ops.FLOAT_SPLIT}
+    assert _fused.detect_mode() == _fused.DETECT_MODE and _fused.detect_mode_override() is None
+    import pytest
+    with pytest.raises(ValueError):
+        with _fused.detect_scope("sometimes"):
+            pass
