@@ -221,9 +221,11 @@ class _FusedDorefaBlock(nn.Module):
         self.sc_conv, self.sc_bn = (blk.shortcut[0], blk.shortcut[1]) if blk.shortcut is not None else (None, None)
 
     def forward(self, act):
-        res = act if self.sc_conv is None else self.sc_conv(act)
         if self.fuse_conv:
-            return self.c2(self.c1(act), residual=res, residual_bn=self.sc_bn)
+            if self.sc_conv is None:
+                return self.c2(self.c1(act), residual=act)
+            return self.c2(self.c1(act), residual_conv=(self.sc_conv, act), residual_bn=self.sc_bn)   # shortcut conv + BN: one launch
+        res = act if self.sc_conv is None else self.sc_conv(act)
         return self.q2(self.conv2(self.q1(self.conv1(act))), residual=res, residual_bn=self.sc_bn)
 
 
@@ -239,8 +241,7 @@ class FusedDorefaResNet18(nn.Module):
         self.blocks = nn.Sequential(*[_FusedDorefaBlock(b, a_bits, fuse_conv, halo, fold) for b in model.blocks])
 
     def forward(self, x):
-        out = self.blocks(self.q0(self.stem(x))).float()
-        out = torch.nn.functional.avg_pool2d(out, 4)
+        out = self.blocks(self.q0(self.stem(x))).avg_pool2d(4)      # codes -> fp32 image -> avg_pool2d in one pass
         return self.linear(out.reshape(out.size(0), -1))
 
 

@@ -331,6 +331,26 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
                               int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
                               int32_t* overflow, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream);
 
+/* qt_affine_dorefa_codes_i8 over the N*H*W pixel rows of a conv output, written INTO a halo plane
+ * [N][H + 2*out_halo_h][W + 2*out_halo_w][ldc_bytes] whose border the same launch zeroes: the padding of the conv that consumes
+ * the activation is then physical (replaces the pass + qt_pad_pixel_plane pair behind the fp32 stem conv of
+ * models/samples/ResNet_Dorefa.py; no fp32 image output). */
+int qt_affine_dorefa_codes_halo_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                                   const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                                   const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                                   int64_t ldc_bytes, int64_t N, int64_t H, int64_t W, int64_t C, int bit_width,
+                                   int32_t* overflow, const float* bn_stats, const float* res_bn_stats, int64_t out_halo_h,
+                                   int64_t out_halo_w, qt_stream_t stream);
+
+/* The fp32 image of a code plane, y = fl(inv_n * code) — what nnDorefaQuant (functions/dorefa_connect.py:24-25) hands to the
+ * first NON-quantised consumer of a fused DoReFa chain (the avg_pool2d + Linear head of models/samples/ResNet_Dorefa.py).
+ * in [N][H + 2*halo_h][W + 2*halo_w][ld_bytes] -> y [N*Ho*Wo][ldy] fp32 (NHWC rows), C channels per pixel.
+ * *overflow != 0 (may be NULL): the chain left int8 somewhere, every output is NaN (decided on the device, no host sync).
+ * pool_k > 1: avg_pool2d(pool_k) (kernel = stride, no padding, floor mode) applied to the image in the same pass, Ho = H / pool_k:
+ * window values added in (row, column) order in fp32, then divided by pool_k^2 — bit-identical to ATen's kernel on this device. */
+int qt_codes_to_f32(const int8_t* codes, int64_t ld_bytes, int64_t N, int64_t H, int64_t W, int64_t halo_h, int64_t halo_w,
+                    int64_t C, float inv_n, const int32_t* overflow, int64_t pool_k, float* y, int64_t ldy, qt_stream_t stream);
+
 /* MaxPool2d(pool_k, pool_s) (no padding, floor mode) on an NHWC int8 DoReFa code plane: the reference pools after the
  * quantiser (models/samples/AlexNet_Dorefa.py:38-41) and fl(inv_n * code) is monotone in the code, so the max over
  * the codes is bit-identical to pooling the fp32 image and re-deriving the codes.
@@ -833,6 +853,18 @@ int qt_conv2d_implicit_halo(int elem, const uint32_t* P, int64_t N, int64_t H, i
                             int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldw,
                             const float* bias, float scale, const float* scale_dev, float* Y, int64_t ldy,
                             int64_t Cout, qt_stream_t stream);
+
+/* qt_conv2d_implicit_halo followed by eval-mode BatchNorm in the DEVICE's arithmetic, in the conv's epilogue:
+ *   y = fma(fl(fl(v - mean[c]) * rs[c]), bn_weight[c], bn_bias[c]),  v = the value qt_conv2d_implicit_halo stores, bn_stats = [mean | rs]
+ * (the expression of qt_bn_eval_device_f32).  The shortcut branch DorefaConv2d(1x1, stride 2) -> BatchNorm2d of
+ * models/samples/ResNet_Dorefa.py in one launch: its fp32 result joins the main branch's code epilogue as a plain residual.
+ * elem == 1 (int8 codes) only; Cout % 4 == 0, ldy % 4 == 0, 16-byte aligned Y / BatchNorm vectors. */
+int qt_conv2d_implicit_halo_bn(int elem, const uint32_t* P, int64_t N, int64_t H, int64_t W, int64_t Cw,
+                               int64_t halo_h, int64_t halo_w, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                               int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldw,
+                               const float* bias, float scale, const float* scale_dev, const float* bn_weight,
+                               const float* bn_bias, const float* bn_stats, float* Y, int64_t ldy, int64_t Cout,
+                               qt_stream_t stream);
 
 /* MaxPool2d(pool_k, pool_s, no padding, floor mode) evaluated on threshold bits: out = AND over the
  * window where alpha >= 0, OR where alpha < 0 (max-pooling commutes with the monotone map x*alpha+beta;

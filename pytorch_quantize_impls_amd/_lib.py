@@ -103,6 +103,10 @@ SIGNATURES = {
     "qt_bn_eval_device_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_affine_dorefa_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
                                            _c_int, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    "qt_affine_dorefa_codes_halo_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_f32,
+                                                _c_int, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p,
+                                                _c_i64, _c_i64, _c_p]),
+    "qt_codes_to_f32": (_c_int, [_c_p] + [_c_i64] * 7 + [_c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_p]),
     "qt_weight_codes_i8": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
     "qt_i8_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                             _c_i64, _c_i64, _c_p]),
@@ -141,6 +145,8 @@ SIGNATURES = {
                                  + [_c_i64] * 6 + [_c_p, _c_p, _c_p]),
     "qt_conv2d_implicit_halo": (_c_int, [_c_int, _c_p] + [_c_i64] * 14 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64,
                                                                           _c_i64, _c_p]),
+    "qt_conv2d_implicit_halo_bn": (_c_int, [_c_int, _c_p] + [_c_i64] * 14 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p, _c_p,
+                                                                             _c_p, _c_i64, _c_i64, _c_p]),
     "qt_conv2d_implicit_nib": (_c_int, [_c_int, _c_p] + [_c_i64] * 12 + [_c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_p,
                                                                         _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_conv3x3_direct_nib": (_c_int, [_c_int, _c_p] + [_c_i64] * 4 + [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64,

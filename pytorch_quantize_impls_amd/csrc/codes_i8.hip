@@ -148,15 +148,65 @@ __device__ __forceinline__ uint32_t affine_codes_word(const float (&v)[4], const
 // grid-stride walk: the per-channel constants are loaded once, the row index advances by a constant (no 64-bit division per
 // element — 180 VALU instructions per dword and 1.2 TB/s before, profiles/r5_c4_pmc.md), and two rows are in flight per
 // iteration.  Otherwise: the general walk (slot recomputed per element).
+// Output rows of a halo plane: row m = (img, h, w) of the [N][H][W] pixel matrix lands on pixel (img, h + hy, w + hx) of a
+// [N][H + 2hy][W + 2hx] plane whose border the launch's surplus blocks write as zeros (the consuming conv's padding, physical).
+struct HaloMap {
+    int hw = 0, W = 0, H = 0, hy = 0, hx = 0, sh_hw = -1, sh_w = -1, main_blocks = 0, border_blocks = 0;
+    int64_t N = 0;
+};
+__device__ __forceinline__ int64_t halo_row(const HaloMap& hm, int64_t row) {
+    if (!(hm.hy | hm.hx)) return row;
+    const unsigned m = (unsigned)row;
+    unsigned img, h, w;
+    if (hm.sh_w >= 0) {
+        img = m >> hm.sh_hw;
+        const unsigned rem = m & (unsigned)(hm.hw - 1);
+        h = rem >> hm.sh_w;
+        w = rem & (unsigned)(hm.W - 1);
+    } else {
+        img = m / (unsigned)hm.hw;
+        const unsigned rem = m - img * (unsigned)hm.hw;
+        h = rem / (unsigned)hm.W;
+        w = rem - h * (unsigned)hm.W;
+    }
+    return ((int64_t)img * (hm.H + 2 * hm.hy) + h + hm.hy) * (hm.W + 2 * hm.hx) + w + hm.hx;
+}
+// border pixels of the plane, 16-byte chunks, by the FIRST hm.border_blocks blocks of the launch (they start with the main blocks, not
+// as its tail).  Only border pixels are enumerated, in 32-bit arithmetic: per image hy rows on top, hy rows below, 2 hx columns beside
+// each of the H image rows.
+__device__ __forceinline__ void halo_zero_border(const HaloMap& hm, int8_t* __restrict__ codes, int64_t ldc) {
+    const unsigned Hp = hm.H + 2 * hm.hy, Wp = hm.W + 2 * hm.hx, cpp = (unsigned)(ldc / 16);
+    const unsigned top = hm.hy * Wp, side = 2u * hm.hx * hm.H, per_img = 2u * top + side;
+    const unsigned total = (unsigned)hm.N * per_img * cpp;                       // < 2^32: host check
+    const unsigned nthr = (unsigned)hm.border_blocks * blockDim.x;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += nthr) {
+        const unsigned b = t / cpp, c = t - b * cpp;
+        const unsigned img = b / per_img, r = b - img * per_img;
+        unsigned h, w;
+        if (r < top) { h = r / Wp; w = r - h * Wp; }
+        else if (r < top + side) {
+            const unsigned q = r - top, row = q / (2u * hm.hx), k = q - row * 2u * hm.hx;
+            h = hm.hy + row;
+            w = k < (unsigned)hm.hx ? k : hm.W + k;
+        } else { const unsigned q = r - top - side; h = hm.hy + hm.H + q / Wp; w = q % Wp; }
+        *reinterpret_cast<uint4*>(codes + ((int64_t)(img * Hp + h) * Wp + w) * ldc + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 template <bool FIXED>
 __global__ __launch_bounds__(256) void affine_codes_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ rf, int64_t ldr, const float* __restrict__ ralpha, const float* __restrict__ rbeta,
     const int8_t* __restrict__ rc, int64_t ldrc, float rscale, int relu, int8_t* __restrict__ codes, int64_t ldc,
     float* __restrict__ yf, int64_t ldy, int64_t rows, int64_t C, float n, float inv_n,
-    int32_t* __restrict__ overflow, int vec, const float* __restrict__ bn_stats, const float* __restrict__ rbn_stats) {
+    int32_t* __restrict__ overflow, int vec, const float* __restrict__ bn_stats, const float* __restrict__ rbn_stats, HaloMap hm) {
     const int64_t slots_per_row = ldc / 4;
     int bad = 0;
+    if ((int)blockIdx.x < hm.border_blocks) {        // (uniform for the block)
+        halo_zero_border(hm, codes, ldc);
+        return;
+    }
+    const unsigned block = blockIdx.x - hm.border_blocks;
     const bool devbn = bn_stats != nullptr, has_rf = rf != nullptr, has_ralpha = ralpha != nullptr, rdevbn = rbn_stats != nullptr,
                has_rc = rc != nullptr;
     auto load4 = [&](int64_t row, int64_t k0, bool full, float (&v)[4], float (&r)[4], uint32_t& rword) {
@@ -180,7 +230,7 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
         rword = has_rc ? *reinterpret_cast<const uint32_t*>(rc + row * ldrc + k0) : 0u;   // plane rows are 16-byte padded
     };
     auto store4 = [&](int64_t row, int64_t k0, uint32_t word, const float (&q4)[4]) {
-        *reinterpret_cast<uint32_t*>(codes + row * ldc + k0) = word;
+        *reinterpret_cast<uint32_t*>(codes + halo_row(hm, row) * ldc + k0) = word;
         if (yf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -188,8 +238,8 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
         }
     };
     if constexpr (FIXED) {
-        const unsigned spr = (unsigned)slots_per_row, nthreads = gridDim.x * blockDim.x;
-        const unsigned s0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned spr = (unsigned)slots_per_row, nthreads = (unsigned)hm.main_blocks * blockDim.x;
+        const unsigned s0 = block * blockDim.x + threadIdx.x;
         const unsigned slot = s0 % spr;
         const int64_t drow = nthreads / spr, k0 = (int64_t)slot * 4;
         const bool full = k0 + 3 < C;
@@ -215,7 +265,7 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
         }
     } else {
         const int64_t total = rows * slots_per_row;
-        for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t s = (int64_t)block * blockDim.x + threadIdx.x; s < total; s += (int64_t)hm.main_blocks * blockDim.x) {
             const int64_t row = s / slots_per_row, slot = s - row * slots_per_row;
             const int64_t k0 = slot * 4;
             const int nvalid = (int)(C - k0 < 0 ? 0 : (C - k0 > 4 ? 4 : C - k0));
@@ -230,6 +280,51 @@ __global__ __launch_bounds__(256) void affine_codes_kernel(
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, __any(bad & 2) ? 3 : 1);
 }
 
+
+// Code plane -> the fp32 image nnDorefaQuant would have returned, fl(inv_n * q), as an NHWC matrix [N * Ho * Wo][ldy]; a raised int8
+// range flag of the chain turns every value into NaN (there is no fp32 image to fall back to: packed.CodeActivation.float).
+// pool_k > 1: followed by avg_pool2d(pool_k) (kernel = stride, no padding, floor mode): the window's values are added in (row, column)
+// order in fp32 and divided by the window size — the order of ATen's avg_pool2d kernels, so the result is theirs bit for bit.
+// in [N][H + 2hy][W + 2hx][ld bytes]; one thread = 4 channels of one output pixel.  (Was: five ATen kernels + the pooling.)
+__global__ __launch_bounds__(256) void codes_to_f32_kernel(const int8_t* __restrict__ codes, int64_t ld, int N, int H, int W, int hy,
+                                                           int hx, int C, float inv_n, const int32_t* __restrict__ overflow, int pk,
+                                                           float* __restrict__ y, int64_t ldy, int vec) {
+    const int Ho = H / pk, Wo = W / pk, quads = (C + 3) / 4;
+    const int64_t total = (int64_t)N * Ho * Wo * quads;
+    const bool nan_all = overflow != nullptr && *overflow != 0;
+    const float div = (float)(pk * pk);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / quads;
+        const int c0 = (int)(t - pix * quads) * 4;
+        const int wo = (int)(pix % Wo);
+        const int64_t r = pix / Wo;
+        const int ho = (int)(r % Ho), n = (int)(r / Ho);
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < pk; ++i)
+            for (int j = 0; j < pk; ++j) {
+                const int64_t src = ((int64_t)n * (H + 2 * hy) + ho * pk + i + hy) * (W + 2 * hx) + wo * pk + j + hx;
+                const uint32_t word = *reinterpret_cast<const uint32_t*>(codes + src * ld + c0);   // rows are padded to 4 bytes
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = __fmul_rn((float)(int8_t)(word >> (8 * e)), inv_n);
+                    a[e] = pk == 1 ? v : __fadd_rn(a[e], v);
+                }
+            }
+        if (pk > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = __fdiv_rn(a[e], div);
+        }
+        if (nan_all) a[0] = a[1] = a[2] = a[3] = __builtin_nanf("");
+        float* dst = y + pix * ldy + c0;
+        if (vec && c0 + 3 < C) {
+            *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < C) dst[e] = a[e];
+        }
+    }
+}
 
 // The conv weight [Cout][Cin][kh][kw] as the int8 operand of the code-plane convs in one pass: row co, tap (i, j), channel ci
 // hold safeSign / ternary of w[co][ci][i][j]; taps are cb bytes apart (Cin rounded to 16), the row is zero-padded to ldc bytes.
@@ -276,11 +371,12 @@ int qt_bn_eval_device_f32(const float* x, int64_t ldx, const float* weight, cons
     return qt_check_launch();
 }
 
-int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
-                              const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
-                              const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
-                              int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
-                              int32_t* overflow, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream) {
+static int affine_codes_impl(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                             const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                             const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                             int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
+                             int32_t* overflow, const float* bn_stats, const float* res_bn_stats, int64_t N, int64_t H, int64_t W,
+                             int64_t hy, int64_t hx, qt_stream_t stream) {
     if (rows < 0 || C < 0 || ldx < C || bit_width < 2 || bit_width > 8 || relu < 0 || relu > 2) return QT_ERR_INVALID_ARG;
     if (rows == 0) return QT_OK;
     if (!codes || !overflow || !alpha || !beta || (!x && C > 0) || (y_f32 && ldy < C)) return QT_ERR_INVALID_ARG;
@@ -301,11 +397,59 @@ int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, c
     const int64_t unit = spr / g;                              // blocks per whole number of rows
     const bool fixed = unit <= grid && spr <= (1 << 20) && rows * spr < (1ll << 32);
     if (fixed) grid = (int)(grid / unit * unit);
+    HaloMap hm;
+    hm.main_blocks = grid;
+    if (hy | hx) {
+        hm.N = N; hm.H = (int)H; hm.W = (int)W; hm.hw = (int)(H * W); hm.hy = (int)hy; hm.hx = (int)hx;
+        auto lg = [](int64_t v) { int s_ = 0; while ((1ll << s_) < v) ++s_; return (1ll << s_) == v ? s_ : -1; };
+        hm.sh_hw = lg(H * W);
+        hm.sh_w = hm.sh_hw >= 0 ? lg(W) : -1;
+        hm.border_blocks = 32;                                 // border-zeroing blocks, in front
+        grid += hm.border_blocks;
+    }
 #define QT_AFFINE(F) hipLaunchKernelGGL((affine_codes_kernel<F>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, beta, \
                        res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes, ldc_bytes,                  \
-                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec, bn_stats, res_bn_stats)
+                       y_f32, ldy, rows, C, n, 1.0f / n, overflow, vec, bn_stats, res_bn_stats, hm)
     if (fixed) QT_AFFINE(true); else QT_AFFINE(false);
 #undef QT_AFFINE
+    return qt_check_launch();
+}
+
+int qt_affine_dorefa_codes_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                              const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                              const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                              int64_t ldc_bytes, float* y_f32, int64_t ldy, int64_t rows, int64_t C, int bit_width,
+                              int32_t* overflow, const float* bn_stats, const float* res_bn_stats, qt_stream_t stream) {
+    return affine_codes_impl(x, ldx, alpha, beta, res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes,
+                             ldc_bytes, y_f32, ldy, rows, C, bit_width, overflow, bn_stats, res_bn_stats, 0, 0, 0, 0, 0, stream);
+}
+
+int qt_affine_dorefa_codes_halo_i8(const float* x, int64_t ldx, const float* alpha, const float* beta,
+                                   const float* res_f32, int64_t ldr, const float* res_alpha, const float* res_beta,
+                                   const int8_t* res_codes, int64_t ldrc_bytes, float res_scale, int relu, int8_t* codes,
+                                   int64_t ldc_bytes, int64_t N, int64_t H, int64_t W, int64_t C, int bit_width,
+                                   int32_t* overflow, const float* bn_stats, const float* res_bn_stats, int64_t out_halo_h,
+                                   int64_t out_halo_w, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || out_halo_h < 0 || out_halo_w < 0 || out_halo_h > 64 || out_halo_w > 64) return QT_ERR_INVALID_ARG;
+    if (N * H * W >= (1ll << 31) || N * (H + 2 * out_halo_h) * (W + 2 * out_halo_w) * (ldc_bytes / 16 + 1) >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    return affine_codes_impl(x, ldx, alpha, beta, res_f32, ldr, res_alpha, res_beta, res_codes, ldrc_bytes, res_scale, relu, codes,
+                             ldc_bytes, nullptr, 0, N * H * W, C, bit_width, overflow, bn_stats, res_bn_stats, N, H, W, out_halo_h,
+                             out_halo_w, stream);
+}
+
+int qt_codes_to_f32(const int8_t* codes, int64_t ld_bytes, int64_t N, int64_t H, int64_t W, int64_t halo_h, int64_t halo_w,
+                    int64_t C, float inv_n, const int32_t* overflow, int64_t pool_k, float* y, int64_t ldy, qt_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || halo_h < 0 || halo_w < 0 || pool_k < 1 || pool_k > H || pool_k > W || ldy < C)
+        return QT_ERR_INVALID_ARG;
+    if (N == 0) return QT_OK;
+    if (!codes || !y) return QT_ERR_INVALID_ARG;
+    if (ld_bytes < C || (ld_bytes & 3) || ((uintptr_t)codes & 3)) return QT_ERR_ALIGNMENT;
+    const int64_t Ho = H / pool_k, Wo = W / pool_k;
+    if (N * (H + 2 * halo_h) * (W + 2 * halo_w) >= (1ll << 31) || N * Ho * Wo * ((C + 3) / 4) >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
+    const int vec = qt_aligned16(y) && (ldy % 4 == 0);
+    const int grid = qt_stream_grid((N * Ho * Wo * ((C + 3) / 4) + 255) / 256);
+    hipLaunchKernelGGL(codes_to_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, codes, ld_bytes, (int)N, (int)H, (int)W,
+                       (int)halo_h, (int)halo_w, (int)C, inv_n, overflow, (int)pool_k, y, ldy, vec);
     return qt_check_launch();
 }
 

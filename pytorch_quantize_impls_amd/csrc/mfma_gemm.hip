@@ -495,6 +495,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
 #define QT_CONV_STAMPS(E)
     if (g_conv_force == 3) return QT_ERR_UNSUPPORTED;
 #endif
+    // ring of 3 / 4 stage buffers on the small-map tiles (ConvV128x128D / ConvV128x64D); QT_NO_CONV_DEEP_RING=1: the double-buffered
+    // configurations of round 4 (A/B runs and the bit-identity test; read per call like the direct kernel's switches)
+    const bool deep_ring = !getenv("QT_NO_CONV_DEEP_RING");
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
@@ -503,16 +506,25 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
             if (g_conv_force == 0 && kwords * 4 >= 2048 && !(ldwp & 127) && !epi.d2s_cout &&                  \
                 (M <= 4096 || (((M + 255) / 256) * ((Cout + tn - 1) / tn) < 256 &&                              \
                                (M / 64) * Cout * kwords * 4 <= (256ll << 20)))) {                               \
-                if (M > 4096 && ((M + 127) / 128) * ((Cout + 127) / 128) >= 200)                               \
+                if (M > 4096 && ((M + 127) / 128) * ((Cout + 127) / 128) >= 200) {                             \
+                    if (deep_ring) return launch_cfg<ConvV128x128D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                     return launch_cfg<ConvV128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
-                if (((M + 127) / 128) * ((Cout + 63) / 64) >= 200)   /* 512 ch @ 4x4: 128x64 tiles, 256-byte stages */ \
+                }                                                                                               \
+                if (((M + 127) / 128) * ((Cout + 63) / 64) >= 200) { /* 512 ch @ 4x4: 128x64 tiles, 256-byte stages */ \
+                    if (deep_ring) return launch_cfg<ConvV128x64D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                     return launch_cfg<ConvV128x64<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                }                                                                                               \
                 return launch_cfg<ConvVSkinny<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             }                                                                                                   \
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
             /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
             if (g_conv_force == 0 && tn == 256 && kwords * 4 <= 1024)                                           \
                 return launch_cfg<ConvV128x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            /* a few big tiles on a small map (128 -> 256 stride 2 @ 16x16, K = 1152 B: 64 tiles of 256x256): 128x128 tiles */ \
+            /* with the deep ring give every CU one                                                                        */ \
+            if (g_conv_force == 0 && deep_ring && !epi.d2s_cout && ((M + 255) / 256) * ((Cout + tn - 1) / tn) <= 128 &&    \
+                ((M + 127) / 128) * ((Cout + 127) / 128) >= 200 && ((M + 127) / 128) * ((Cout + 127) / 128) <= 512)        \
+                return launch_cfg<ConvV128x128D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (g_conv_force != 1) {                                                                            \
                 if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
                     return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
@@ -686,6 +698,25 @@ int qt_conv2d_implicit_halo(int elem, const uint32_t* P, int64_t Nimg, int64_t H
                             int64_t Cout, qt_stream_t stream) {
     return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
                               scale_dev, Y, ldy, Cout, stream, EpiArgs{}, halo_h, halo_w);
+}
+
+int qt_conv2d_implicit_halo_bn(int elem, const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, int64_t Cw,
+                               int64_t halo_h, int64_t halo_w, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                               int64_t ph, int64_t pw, int64_t dh, int64_t dw, const uint32_t* Wmat, int64_t ldwp,
+                               const float* bias, float scale, const float* scale_dev, const float* bn_weight,
+                               const float* bn_bias, const float* bn_stats, float* Y, int64_t ldy, int64_t Cout,
+                               qt_stream_t stream) {
+    if (!bn_weight || !bn_bias || !bn_stats || ldy < Cout) return QT_ERR_INVALID_ARG;
+    if (elem != 1) return QT_ERR_UNSUPPORTED;               // instantiated for the int8 (DoReFa) configurations
+    if ((Cout & 3) || (ldy & 3) || !qt_aligned16(Y) || !qt_aligned16(bn_weight) || !qt_aligned16(bn_bias) || !qt_aligned16(bn_stats))
+        return QT_ERR_ALIGNMENT;
+    EpiArgs epi;
+    epi.alpha = bn_weight;
+    epi.beta = bn_bias;
+    epi.bn_stats = bn_stats;
+    epi.mode = 4;
+    return conv_implicit_impl(elem, P, Nimg, H, W, Cw, kh, kw, sh, sw, ph, pw, dh, dw, Wmat, ldwp, bias, scale,
+                              scale_dev, Y, ldy, Cout, stream, epi, halo_h, halo_w);
 }
 
 int qt_bits_to_nib(const uint32_t* sign_plane, const uint32_t* mask_plane, int64_t ldb,

@@ -235,7 +235,10 @@ struct GemmCfg {
     static constexpr int TM = WM * TMW * 32, TN = WN * TNW * 32;  // workgroup tile
     static constexpr int X_STAGE = TM * STAGE_BYTES, W_STAGE = TN * STAGE_BYTES;
     static constexpr int BUF = X_STAGE + W_STAGE;
-    static constexpr int NBUF = PIPE_ == 2 ? 4 : 2;  // stage buffers: double-buffered, or a ring of 4 (ping-pong)
+    // stage buffers: double-buffered (PIPE 0 / 1), a ring of 4 (ping-pong, PIPE 2), or a ring of PIPE_ = 3 / 4 buffers walked by the
+    // PIPE 1 loop with PIPE_ - 1 stages of DMA in flight (short-K tiles one per CU: a stage's L2 round trip, ~1 us under load, is 4-5x its
+    // matrix time, so a double-buffered loop runs at one round trip per stage)
+    static constexpr int NBUF = PIPE_ == 2 ? 4 : (PIPE_ >= 3 ? PIPE_ : 2);
     static constexpr int LDS_FIXED = NBUF * BUF + 64;   // stage buffers + the waves' SIMD ids (ping-pong)
     static constexpr int LDS_BYTES = LDS_FIXED;         // VALID conv: + the tap table (launch_cfg adds nstages * CHUNKS * 4)
     static_assert(PIPE_ != 2 || (SB_ == 64 && NWAVES == 8), "ping-pong: 64-byte stages, two waves per SIMD");
@@ -661,17 +664,22 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                 dbg_wall[2] = wall_clock64();
             }
         } else {
-        if (nstages > 0) {
-                if constexpr (C::CONV) conv_stage(0);
+            // ring of NB stage buffers, AH = NB - 1 stages of DMA in flight (NB = 2: the double-buffered loop)
+            constexpr int NB = C::NBUF, AH = NB - 1;
     #pragma unroll
-                for (int j = 0; j < NP; ++j) issue_piece(j, 0, 0, std::false_type{});
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int s = 0; s < AH; ++s)
+                if (s < nstages) {
+                    if constexpr (C::CONV) conv_stage(s);
+    #pragma unroll
+                    for (int j = 0; j < NP; ++j) issue_piece(j, s, s, std::false_type{});
+                }
+            if (nstages >= AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AH - 1) * NP) : "memory");   // stage 0 has landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
     
-            auto stage_body = [&](int s, auto more_tag) {
+            auto stage_body = [&](int s, int buf, auto more_tag) {      // buf = s % NB; stage s + AH goes into the buffer stage s - 1 left
                 constexpr bool more = decltype(more_tag)::value;
-                const int buf = s & 1;
+                const int nbuf = buf == 0 ? NB - 1 : buf - 1;
                 const unsigned char* xs = smem + buf * BUF;
                 const unsigned char* ws = xs + C::X_STAGE;
                 uint4 xfA[C::TMW], wfA[C::TNW], xfB[C::TMW], wfB[C::TNW];
@@ -682,14 +690,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     for (int b = 0; b < C::TNW; ++b) wfA[b] = wfB[b] = make_uint4(0xa2a2a2a2u, 0x2a2a2a2au, lane, s);
                 }
                 if constexpr (C::ABL != 4) read_frags(xs, ws, 0, xfA, wfA);
-                if constexpr (C::CONV && more) conv_stage(s + 1);
+                if constexpr (C::CONV && more) conv_stage(s + AH);
     #pragma unroll
                 for (int kk = 0; kk < KK; kk += 2) {
                     // DMA pieces are spread over the k-steps; fragments of step kk+1 are requested before
                     // the MFMAs of step kk so LDS latency hides under the matrix pipe.
                     if constexpr (more && C::ABL != 2) {
     #pragma unroll
-                        for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1, std::false_type{});
+                        for (int j = kk * NP / KK; j < (kk + 1) * NP / KK; ++j) issue_piece(j, s + AH, nbuf, std::false_type{});
                     }
                     if constexpr (C::ABL != 4) read_frags(xs, ws, kk + 1, xfB, wfB);
                     __builtin_amdgcn_sched_barrier(0);
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (more && C::ABL != 2) {
     #pragma unroll
-                        for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + 1, buf ^ 1, std::false_type{});
+                        for (int j = (kk + 1) * NP / KK; j < (kk + 2) * NP / KK; ++j) issue_piece(j, s + AH, nbuf, std::false_type{});
                     }
                     if constexpr (C::ABL != 4) {
                         if (kk + 2 < KK) read_frags(xs, ws, kk + 2, xfA, wfA);
@@ -708,11 +716,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     else asm volatile("" ::"v"(xfB[0].x), "v"(wfB[0].x), "v"(xfB[C::TMW - 1].w), "v"(wfB[C::TNW - 1].w));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+                // this wave's pieces of stage s + 1 have landed (the younger stages stay in flight)
+                if constexpr (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AH - 1) * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                                   // ... and everyone's are visible
             };
-            for (int s = 0; s + 1 < nstages; ++s) stage_body(s, std::true_type{});
-            if (nstages > 0) stage_body(nstages - 1, std::false_type{});
+            int s = 0, buf = 0;
+            for (; s + AH < nstages; ++s, buf = buf + 1 == NB ? 0 : buf + 1) stage_body(s, buf, std::true_type{});
+            for (; s < nstages; ++s, buf = buf + 1 == NB ? 0 : buf + 1) stage_body(s, buf, std::false_type{});
         }
     } else {
         // ---- generic main loop (builtin DMA, 64-bit addresses, any row stride % 4 words) ------------
@@ -788,6 +799,52 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
     // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
     const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    if constexpr (DEVBN) if (epi.mode == 4) {
+        // fp32 output through eval-mode BatchNorm in the DEVICE's arithmetic (the conv -> BatchNorm shortcut branch of a DoReFa ResNet
+        // block): y = fma(fl(fl(v - mean) * rs), weight, bias) on the value v the plain epilogue would have stored — the expression of
+        // bn_eval_device_kernel, applied before the store instead of in a second pass over the fp32 tensor.  Host: wide stores only.
+        float* T = reinterpret_cast<float*>(smem) + wave * 1024;
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int nb = n0 + (wave_n * C::TNW + b) * 32;
+            const float bv = (bias && nb + lrow < N) ? bias[nb + lrow] : 0.0f;
+            const int n = nb + (lane & 7) * 4;
+            float4 mean = make_float4(0, 0, 0, 0), rs = mean, bw = mean, bb = mean;
+            if (n < N) {                      // N % 4 == 0: the lane's four channels exist together
+                mean = *reinterpret_cast<const float4*>(epi.bn_stats + n);
+                rs = *reinterpret_cast<const float4*>(epi.bn_stats + N + n);
+                bw = *reinterpret_cast<const float4*>(epi.alpha + n);
+                bb = *reinterpret_cast<const float4*>(epi.beta + n);
+            }
+#pragma unroll
+            for (int a = 0; a < C::TMW; ++a) {
+                const int mb = m0 + (wave_m * C::TMW + a) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = E::out(acc[a][b][r], scale, bv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3);
+                    const float4 v = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
+                    const int m = mb + row;
+                    if (m < M && n < N) {
+                        float4 o;
+                        o.x = __builtin_fmaf((v.x - mean.x) * rs.x, bw.x, bb.x);
+                        o.y = __builtin_fmaf((v.y - mean.y) * rs.y, bw.y, bb.y);
+                        o.z = __builtin_fmaf((v.z - mean.z) * rs.z, bw.z, bb.z);
+                        o.w = __builtin_fmaf((v.w - mean.w) * rs.w, bw.w, bb.w);
+                        *reinterpret_cast<float4*>(Y + (int64_t)m * ldy + n) = o;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
     if constexpr (E::CODE_EPI && C::CONV) if (epi.mode == 2) {
         // int8 codes: the 32x32 tile is transposed through the wave-private LDS patch as in the fp32 store below,
         // so a lane holds 4 consecutive channels of one output row: per-channel affine, residual, ReLU, rint ->
@@ -831,12 +888,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
             // small-N launches are VALU-issue bound in their epilogue (profiles/r5_c4_pmc.md).  Same roundings, same codes.
             // (whole ROW tiles too: a bounds branch per row group puts every group in its own basic block, and the waitcnt pass then
             //  drains the previous group's code store before each group's first use of a residual word — profiles/r5_c4_direct_conv.md)
-            const bool fast = !bias && !epi.res_f32 && epi.relu != 2 && (N & 3) == 0 && n0 + C::TN <= N && m0 + C::TM <= M;
+            const bool fast = !bias && (!epi.res_f32 || (rwide && !epi.res_codes)) && epi.relu != 2 && (N & 3) == 0 && n0 + C::TN <= N && m0 + C::TM <= M;
             if (fast) {
                 int badf = 0;
                 const float levels = epi.levels, rscale = epi.rscale;
-                auto body = [&](auto rc_tag, auto relu_tag) {
-                    constexpr bool RC = decltype(rc_tag)::value, RELU = decltype(relu_tag)::value;
+                auto body = [&](auto rc_tag, auto relu_tag, auto rf_tag) {
+                    constexpr bool RC = decltype(rc_tag)::value, RELU = decltype(relu_tag)::value, RF = decltype(rf_tag)::value;
 #pragma unroll
                     for (int b = 0; b < C::TNW; ++b) {
                         const int nb = n0 + (wave_n * C::TNW + b) * 32;
@@ -861,6 +918,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
 #pragma unroll
                         for (int a = 0; a < C::TMW; ++a) {
                             const int mb = m0 + (wave_m * C::TMW + a) * 32;
+                            // fp32 residual (the conv -> BatchNorm shortcut branch, already normalised): this row group's four float4,
+                            // requested before the transpose below
+                            float4 rf4[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                rf4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                if constexpr (RF)
+                                    rf4[i] = *reinterpret_cast<const float4*>(epi.res_f32 + (int64_t)(mb + i * 8 + (lane >> 3)) * epi.ldr + n);
+                            }
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
                                 T[((r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = (float)acc[a][b][r] * scale;
@@ -873,11 +939,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                                 const float4 v4 = *reinterpret_cast<const float4*>(T + row * 32 + (lane & 7) * 4);
                                 {
                                     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                                    const float u[4] = {rf4[i].x, rf4[i].y, rf4[i].z, rf4[i].w};
                                     const uint32_t rword = rwd[a][i];
                                     uint32_t word = 0;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
                                         float t = __builtin_fmaf((v[e] - mean[e]) * rs[e], al[e], be[e]);
+                                        if constexpr (RF) t = t + u[e];
                                         if constexpr (RC) t = t + rscale * (float)(int8_t)(rword >> (8 * e));
                                         if constexpr (RELU) t = t < 0.0f ? 0.0f : t;
                                         const float qf = rintf(levels * t);
@@ -898,11 +966,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
                     }
                 };
                 if (epi.res_codes) {
-                    if (epi.relu == 1) body(std::true_type{}, std::true_type{});
-                    else body(std::true_type{}, std::false_type{});
+                    if (epi.relu == 1) body(std::true_type{}, std::true_type{}, std::false_type{});
+                    else body(std::true_type{}, std::false_type{}, std::false_type{});
+                } else if (epi.res_f32) {
+                    if (epi.relu == 1) body(std::false_type{}, std::true_type{}, std::true_type{});
+                    else body(std::false_type{}, std::false_type{}, std::true_type{});
                 } else {
-                    if (epi.relu == 1) body(std::false_type{}, std::true_type{});
-                    else body(std::false_type{}, std::false_type{});
+                    if (epi.relu == 1) body(std::false_type{}, std::true_type{}, std::false_type{});
+                    else body(std::false_type{}, std::false_type{}, std::false_type{});
                 }
                 if (__any(badf) && lane == 0) atomicOr(epi.overflow, 1);
                 return;
@@ -1183,7 +1254,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
                           (elem_rows<typename C::E>::value ? (epi.ntaps + 1) * C::TM * 4 : 0);   // ROWS: + the per-row factor table
     if (lds_bytes > 160 * 1024) return QT_ERR_UNSUPPORTED;
     if constexpr (C::E::CODE_EPI && C::CONV) {
-        if (epi.mode == 2 && epi.bn_stats) {
+        if ((epi.mode == 2 || epi.mode == 4) && epi.bn_stats) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
                 return QT_ERR_LAUNCH;
@@ -1258,6 +1329,10 @@ template <class E> using ConvVSkinny = GemmCfg<E, 2, 2, 1, 1, 1, 0, 512, 2>;
 template <class E> using ConvV128x128 = GemmCfg<E, 2, 4, 2, 1, 1, 0, 128, 2>;
 // ... and 128x64 tiles (256-byte stages, the skinny GEMM's shape) where THOSE fill the chip (M = 4096 pixels x 512 channels)
 template <class E> using ConvV128x64 = GemmCfg<E, 4, 2, 1, 1, 1, 0, 256, 2>;
+// ... the same two tiles with a DEEPER DMA ring (4 x 32 KiB / 3 x 48 KiB of stage buffers, 3 / 2 stages in flight): one workgroup per
+// CU and 18 stages whose matrix time (~0.2 us) is a fraction of the L2 round trip — the double-buffered loop ran at ~0.8 us per stage
+template <class E> using ConvV128x128D = GemmCfg<E, 2, 4, 2, 1, 4, 0, 128, 2>;
+template <class E> using ConvV128x64D = GemmCfg<E, 4, 2, 1, 1, 3, 0, 256, 2>;
 #ifdef QT_PROFILING_VARIANTS
 template <class E> using ConvVPP192Stamps = GemmCfg<E, 4, 2, 3, 3, 2, 5, 64, 2>;   // profiling builds only
 #endif

@@ -259,8 +259,8 @@ class FusedBnDorefaQuant(torch.nn.Module):
             raise ValueError("code planes exist for 2 <= bit_width <= 8")
         self.fold = fold or DEFAULT_FOLD
         self.bn, self.bit_width, self.relu = bn, int(bit_width), ops.relu_mode(relu)
-        # out_halo: zero border for the consuming conv's padding (see FusedDorefaConvBnQuant); made here by one
-        # qt_pad_pixel_plane pass over the code plane
+        # out_halo: zero border for the consuming conv's padding (see FusedDorefaConvBnQuant): the pass writes into the halo plane
+        # and zeroes its border itself (qt_affine_dorefa_codes_halo_i8)
         self.out_halo = (int(out_halo),) * 2 if isinstance(out_halo, int) else tuple(int(v) for v in out_halo)
         self._folded = None
         self._folded_res = None
@@ -301,18 +301,13 @@ class FusedBnDorefaQuant(torch.nn.Module):
                 rlike = (tuple(residual.shape), residual.dim() == 4 and residual.is_contiguous(memory_format=torch.channels_last)) \
                     if self.fold == "device" else None
                 res_affine = _code_fold_for(self, "_folded_res", residual_bn, self.fold, rlike)
+        halo = x.dim() == 4 and any(self.out_halo)
         codes, _ = ops.affine_dorefa_codes(x2, alpha, beta, self.bit_width, self.relu, res_f32, res_affine, res_codes,
                                            overflow=flag,
                                            ld_bytes=ops.code_ld_bytes(x2.shape[1], 16) if x.dim() == 4 else None,
-                                           bn_stats=stats)
-        if x.dim() == 4 and any(self.out_halo):
-            N, C, H, W = x.shape
-            hy, hx = self.out_halo
-            codes = ops.CodePlanes(codes=ops.pad_pixel_plane(codes.codes, N, H, W, (hy, hx)),
-                                   rows=N * (H + 2 * hy) * (W + 2 * hx), K=codes.K, inv_n=codes.inv_n,
-                                   bit_width=codes.bit_width, overflow=codes.overflow)
-            return packed.CodeActivation(codes, x.shape, halo=self.out_halo)
-        return packed.CodeActivation(codes, x.shape)
+                                           bn_stats=stats, halo_nhw=(N, H, W) if halo else None,
+                                           out_halo=self.out_halo if halo else (0, 0))
+        return packed.CodeActivation(codes, x.shape, halo=self.out_halo if halo else (0, 0))
 
 
 class FusedDorefaConvBnQuant(torch.nn.Module):
@@ -321,7 +316,10 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
     activation in HBM.  Same arithmetic as ``FusedBnDorefaQuant`` applied to the conv's fp32 output (the epilogue
     forms exactly the value the conv would have stored), so the two are bit-identical.
 
-    forward(act, residual=None, residual_bn=None): residual over the conv's OUTPUT pixels, as FusedBnDorefaQuant."""
+    forward(act, residual=None, residual_bn=None, residual_conv=None): residual over the conv's OUTPUT pixels, as
+    FusedBnDorefaQuant.  ``residual_conv`` = (DorefaConv2d, CodeActivation) instead of ``residual``: the shortcut branch
+    conv -> ``residual_bn`` evaluated here, in ONE launch when the conv is a 1-bit DorefaConv2d and the fold is "device"
+    (qt_conv2d_implicit_halo_bn: BatchNorm in the conv's epilogue), else as conv, then BatchNorm."""
 
     def __init__(self, conv, bn, bit_width: int, relu=True, out_halo=0, fold=None):
         super().__init__()
@@ -337,12 +335,34 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
     def refold(self):
         self._folded = self._folded_res = None
 
-    def forward(self, act, residual=None, residual_bn=None):
+    def _shortcut(self, sc_conv, sc_act, residual_bn):
+        """The conv -> BatchNorm shortcut branch: (fp32 [M, C] matrix already normalised, None) or (conv output, its BatchNorm)."""
+        if (residual_bn is not None and self.fold == "device" and isinstance(sc_act, packed.CodeActivation)
+                and getattr(sc_conv, "bit_width", None) == 1 and sc_conv.groups == 1 and sc_conv.padding_mode == "zeros"
+                and not isinstance(sc_conv.padding, str) and not sc_conv.training and sc_conv.out_channels % 4 == 0):
+            N_, C_, H_, W_ = sc_act.shape
+            kh, kw = sc_conv.kernel_size
+            if sc_act.codes.K == C_ == sc_conv.in_channels and 127 * kh * kw * sc_act.codes.codes.shape[1] < (1 << 24):
+                Ho_, Wo_ = ops.conv_out_hw(H_, W_, kh, kw, sc_conv.stride, sc_conv.padding, sc_conv.dilation)
+                rw, rb, rstats = _code_fold_for(self, "_folded_res", residual_bn, "device", ((N_, sc_conv.out_channels, Ho_, Wo_), True))
+                wc = sc_conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(sc_conv.weight.detach()), key="conv_i8")
+                E = sc_conv._eval_planes(lambda w2: w2.abs().amax(), key="E")
+                y2 = ops.conv2d_codes(sc_act.codes, sc_act.shape, wc, (kh, kw), sc_act.codes.inv_n, sc_conv.bias, sc_conv.stride,
+                                      sc_conv.padding, sc_conv.dilation, scale_dev=E, epi=ops.BnEpilogue(rw, rb, rstats),
+                                      in_halo=sc_act.halo)
+                return y2, None
+        return sc_conv(sc_act), residual_bn
+
+    def forward(self, act, residual=None, residual_bn=None, residual_conv=None):
         conv = self.conv
         if conv.training or self.bn.training:
             raise RuntimeError("FusedDorefaConvBnQuant is an inference form: call .eval() first")
         if not isinstance(act, packed.CodeActivation):
             raise TypeError("FusedDorefaConvBnQuant consumes a CodeActivation (FusedBnDorefaQuant output)")
+        if residual_conv is not None:
+            if residual is not None:
+                raise ValueError("pass the shortcut either as its value (residual) or as its conv (residual_conv)")
+            residual, residual_bn = self._shortcut(residual_conv[0], residual_conv[1], residual_bn)
         # the tensor the module graph hands to F.batch_norm is this conv's fp32 output: channels-last for a code-plane input
         N_, _, H_, W_ = act.shape
         Ho_, Wo_ = ops.conv_out_hw(H_, W_, conv.kernel_size[0], conv.kernel_size[1], conv.stride, conv.padding, conv.dilation)
@@ -355,6 +375,8 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
         elif residual is not None:
             r2 = residual.permute(0, 2, 3, 1) if residual.dim() == 4 else residual
             epi.res_f32 = (r2 if r2.is_contiguous() else r2.contiguous()).view(-1, r2.shape[-1])
+            if epi.res_f32.shape != (N_ * Ho_ * Wo_, conv.out_channels):
+                raise ValueError(f"residual {tuple(residual.shape)} does not cover this conv's output")
             if residual_bn is not None and self.fold == "device":
                 # device arithmetic: the shortcut's BatchNorm runs as its own elementwise pass in the same (verified) expression;
                 # the conv epilogue then adds a plain fp32 residual and carries no second set of per-channel registers

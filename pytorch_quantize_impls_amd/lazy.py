@@ -263,7 +263,7 @@ def _force_codes(self, halo=None):
     try:
         with torch.no_grad():
             blk = _code_block(self.layer, self.bn, self.quant, self.relu, halo if self.pool2 is None else (0, 0))
-            res = res_bn = None
+            res = res_bn = res_conv = None
             if self.add is not None:
                 other = self.add
                 if isinstance(other, LazyActivation):
@@ -271,7 +271,14 @@ def _force_codes(self, halo=None):
                     if o.quant is not None:                       # identity shortcut: the block's own (quantised) input
                         res = o.force_any()
                     else:                                         # conv + BatchNorm shortcut: fp32 conv output, BN folded
-                        res, res_bn = o.parent.materialise(), _bn_view(blk, o.bn)
+                        root = o.parent
+                        if (root.parent is None and root.value is None and isinstance(root.input, packed.CodeActivation)
+                                and o.bn is not None and o.pool is None and o.relu is False and o.add is None):
+                            # ... the un-materialised conv of the branch on a code plane: conv + BatchNorm in one launch
+                            root.check_unmodified()
+                            res_conv, res_bn = (root.layer, root.input), _bn_view(blk, o.bn)
+                        else:
+                            res, res_bn = root.materialise(), _bn_view(blk, o.bn)
                 else:
                     res = other
                     # an fp32 residual that carries the int8 codes of the quantiser that produced it (the identity shortcut of the
@@ -287,9 +294,9 @@ def _force_codes(self, halo=None):
                             and tag.rows == int(other.shape[0]) * int(other.shape[2]) * int(other.shape[3])):
                         res = packed.CodeActivation(tag, tuple(int(v) for v in other.shape))
                         STATS["residual_as_codes"] += 1
-                if res is None:
+                if res is None and res_conv is None:
                     raise ValueError("residual cannot join the fused chain")
-            act = blk(self.input, residual=res, residual_bn=res_bn)
+            act = blk(self.input, residual=res, residual_bn=res_bn, residual_conv=res_conv)
             if self.pool2 is not None:
                 act = fused.CodeMaxPool(torch.nn.MaxPool2d(self.pool2[0], self.pool2[1]), out_halo=halo)(act)
     except ValueError:
@@ -795,8 +802,30 @@ def _h_flatten(input, start_dim=0, end_dim=-1):
     return _as_flat(input, ok)
 
 
+def _h_avg_pool2d(input, kernel_size, stride=None, padding=0, ceil_mode=False, count_include_pad=True, divisor_override=None):
+    """F.avg_pool2d(k) (kernel = stride, no padding) of a QUANTISED DoReFa chain — the head of a DoReFa ResNet — reads the chain's
+    int8 codes and pools their fp32 image in the same pass (packed.CodeActivation.avg_pool2d: ATen's order, bit-identical to
+    pooling the materialised image); the result is a computed value (constant node)."""
+    if not isinstance(input, LazyActivation) or ceil_mode or divisor_override is not None:
+        return NotImplemented
+    n = input._qt
+    k = _square(kernel_size)
+    s = _square(stride) if stride not in (None, [], ()) else k
+    if (k is None or s != k or _square(padding) != 0 or len(n.shape) != 4 or n.kind != "dorefa" or n.quant is None
+            or n.pool2 is not None or n.value is not None or n.shape[2] % k or n.shape[3] % k):
+        return NotImplemented
+    n.check_unmodified()
+    with torch.no_grad():
+        codes = n.force_any()
+    if codes is None:
+        return NotImplemented
+    STATS["avg_pool_on_codes"] += 1
+    return codes.avg_pool2d(k)
+
+
 _HANDLERS = {
     F.max_pool2d: _h_max_pool2d,
+    F.avg_pool2d: _h_avg_pool2d,
     F.batch_norm: _h_batch_norm,
     F.hardtanh: _h_hardtanh,
     F.dropout: _h_dropout,

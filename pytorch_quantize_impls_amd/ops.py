@@ -67,6 +67,15 @@ class CodeEpilogue:
     res_halo: tuple = (0, 0)        # halo of the residual code plane
 
 
+@dataclass
+class BnEpilogue:
+    """fp32 conv output through eval-mode BatchNorm in the device's arithmetic, inside the conv's epilogue
+    (qt_conv2d_implicit_halo_bn): ``weight`` / ``bias`` / ``stats`` = [mean | rs] as layers.fused.device_bn_fold supplies them."""
+    weight: torch.Tensor
+    bias: torch.Tensor
+    stats: torch.Tensor
+
+
 def integer_thresholds(bias: Optional[torch.Tensor], alpha: torch.Tensor, beta: torch.Tensor, kmax: int) -> torch.Tensor:
     """Per-channel integer thresholds T of the threshold epilogue for EXACT INTEGER accumulators (|acc| <= kmax):
 
@@ -169,6 +178,15 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
                       I(ohx), I(rhy), I(rhx), _p(stats), _p(rstats), _stream(dev))
         inv_n = inv_levels(epi.bit_width)
         return CodePlanes(codes=codes, rows=Mo, K=Cout, inv_n=inv_n, bit_width=int(epi.bit_width), overflow=flag)
+    if isinstance(epi, BnEpilogue):
+        if elem != 1 or Cout % 4:
+            return None
+        y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv2d_implicit_halo_bn", int(elem), _p(pixels_words), I(N), I(H), I(W), I(Cw), I(hy), I(hx), I(kh), I(kw),
+                      I(sh), I(sw), I(ph), I(pw), I(dh), I(dw), *head[14:], _p(_check_bias(epi.weight, Cout, dev)),
+                      _p(_check_bias(epi.bias, Cout, dev)), _p(_require(epi.stats, "bn_stats")), _p(y), I(Cout), I(Cout), _stream(dev))
+        return y
     if isinstance(epi, NibEpilogue):
         if hy or hx:
             raise ValueError("input halos are passed as a physically padded image for nibble planes")
@@ -902,13 +920,15 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
                         res_f32: Optional[torch.Tensor] = None, res_affine=None,
                         res_codes: Optional[CodePlanes] = None, want_f32: bool = False,
                         overflow: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None,
-                        bn_stats: Optional[torch.Tensor] = None):
+                        bn_stats: Optional[torch.Tensor] = None, halo_nhw=None, out_halo=(0, 0)):
     """Fused eval BatchNorm (folded alpha, beta) [+ residual] [-> ReLU] -> k-bit DoReFa quantiser over a
     [rows, C] fp32 matrix (a conv output viewed as pixels x channels): returns (CodePlanes, fp32 image or None).
     ``res_f32``: fp32 [rows, C] residual, optionally with its own folded BatchNorm ``res_affine`` = (alpha, beta);
     ``res_codes``: residual held as DoReFa codes (value inv_n * code).  ``overflow``: device int32 flag to OR into
     (a fresh one is made when None).  ``bn_stats`` = [mean | rs]: the device's BatchNorm arithmetic with alpha / beta =
-    weight / bias (qt_affine_dorefa_codes_i8); a 3-tuple ``res_affine`` = (weight, bias, stats) likewise for the residual."""
+    weight / bias (qt_affine_dorefa_codes_i8); a 3-tuple ``res_affine`` = (weight, bias, stats) likewise for the residual.
+    ``halo_nhw`` = (N, H, W) with ``out_halo`` = (hy, hx): the rows are the pixels of N images and the codes are written into a
+    [N*(H+2hy)*(W+2hx), ld] plane with a zero border (qt_affine_dorefa_codes_halo_i8; no fp32 image)."""
     _require(x2, "input")
     if x2.dim() != 2 or x2.dtype != torch.float32 or (x2.shape[1] > 1 and x2.stride(1) != 1):
         raise ValueError("affine_dorefa_codes takes a [rows, C] fp32 matrix with unit channel stride")
@@ -941,17 +961,50 @@ def affine_dorefa_codes(x2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tenso
             raise ValueError("residual codes must be a [rows, C] code plane like the input")
         rscale, ldrc = float(res_codes.inv_n), int(res_codes.codes.shape[1])
     ld = code_ld_bytes(C) if ld_bytes is None else int(ld_bytes)
-    codes = torch.empty((rows, ld), dtype=torch.int8, device=dev)
-    y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_f32 else None
     flag = overflow if overflow is not None else torch.zeros((1,), dtype=torch.int32, device=dev)
     I = int
+    inv_n = inv_levels(bit_width)
+    hy, hx = (int(v) for v in out_halo)
+    if halo_nhw is not None and (hy or hx):
+        N, H, W = (int(v) for v in halo_nhw)
+        if N * H * W != rows or want_f32:
+            raise ValueError("halo output: rows must be the N*H*W pixels of the images, and there is no fp32 image")
+        prow = N * (H + 2 * hy) * (W + 2 * hx)
+        codes = torch.empty((prow, ld), dtype=torch.int8, device=dev)
+        with _on(dev):
+            _lib.call("qt_affine_dorefa_codes_halo_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
+                      _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
+                      float(rscale), relu_mode(relu), _p(codes), I(ld), I(N), I(H), I(W), I(C), int(int(bit_width)), _p(flag),
+                      _p(bn_stats), _p(rstats), I(hy), I(hx), _stream(dev))
+        return CodePlanes(codes=codes, rows=prow, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), None
+    codes = torch.empty((rows, ld), dtype=torch.int8, device=dev)
+    y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_f32 else None
     with _on(dev):
         _lib.call("qt_affine_dorefa_codes_i8", _p(x2), I(x2.stride(0) if rows > 1 else max(C, 1)), _p(alpha), _p(beta),
                   _p(res_f32), I(ldr), _p(ra), _p(rb), _p(res_codes.codes if res_codes is not None else None), I(ldrc),
                   float(rscale), relu_mode(relu), _p(codes), I(ld), _p(y), I(C), I(rows), I(C),
                   int(int(bit_width)), _p(flag), _p(bn_stats), _p(rstats), _stream(dev))
-    inv_n = inv_levels(bit_width)
     return CodePlanes(codes=codes, rows=rows, K=C, inv_n=inv_n, bit_width=int(bit_width), overflow=flag), y
+
+
+def codes_to_f32(codes: CodePlanes, N: int, H: int, W: int, halo=(0, 0), pool_k: int = 1, flagged: bool = True) -> torch.Tensor:
+    """The fp32 image fl(inv_n * code) of a code plane [N*(H+2hy)*(W+2hx), ld] as an [N, Ho, Wo, C] NHWC tensor, optionally through
+    avg_pool2d(pool_k) in the same pass (qt_codes_to_f32); ``flagged``: a raised int8 range flag of the chain makes every value NaN."""
+    hy, hx = (int(v) for v in halo)
+    if codes.rows != N * (H + 2 * hy) * (W + 2 * hx):
+        raise ValueError(f"code plane holds {codes.rows} pixels, ({N}, {H}, {W}) with halo {(hy, hx)} needs {N * (H + 2 * hy) * (W + 2 * hx)}")
+    pk = int(pool_k)
+    if pk < 1 or pk > H or pk > W:
+        raise ValueError("pool_k must lie in [1, min(H, W)]")
+    C, dev = int(codes.K), codes.codes.device
+    Ho, Wo = H // pk, W // pk
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=dev)
+    flag = codes.overflow if (flagged and codes.overflow is not None) else None
+    I = int
+    with _on(dev):
+        _lib.call("qt_codes_to_f32", _p(codes.codes), I(codes.codes.stride(0)), I(N), I(H), I(W), I(hy), I(hx), I(C), float(codes.inv_n),
+                  _p(flag), I(pk), _p(y), I(C), _stream(dev))
+    return y
 
 
 def bn_eval_device(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, bn_stats: torch.Tensor) -> torch.Tensor:
@@ -1098,6 +1151,16 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
+    if isinstance(epi, BnEpilogue):
+        # conv -> BatchNorm(eval, device arithmetic) -> fp32: one launch where the implicit kernel takes the shape, else two passes
+        y = None
+        if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31) and not (PAD_PIXEL_PLANES and (ph or pw) and not (hy or hx)):
+            y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
+                               ldA, bias, scale, scale_dev, Cout, epi=epi, in_halo=(hy, hx))
+        if y is None:
+            y = bn_eval_device(conv2d_codes(pixels, in_shape, wplanes, kernel_hw, scale, bias, stride, padding, dilation, scale_dev,
+                                            max_abs_code, None, in_halo), epi.weight, epi.bias, epi.stats)
+        return y
     if hy or hx:
         y = None
         if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):

@@ -188,15 +188,20 @@ class CodeActivation:
         ResNet-18).  ``check=True`` (or ``check()``) synchronises and raises instead."""
         if check:
             self.check()
-        C = self.codes.K
-        if len(self.shape) == 4:
-            N, C_, H, W = self.shape
-            hy, hx = self.halo
-            q = self.codes.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W, :C]
-            y = (q.to(torch.float32) * self.codes.inv_n).permute(0, 3, 1, 2)
-        else:
-            y = (self.codes.codes[:, :C].to(torch.float32) * self.codes.inv_n).view(self.shape)
         from . import ops
-        if self.codes.overflow is not None and not ops.ASSUME_CODES_FIT:
-            y = torch.where(self.codes.overflow.reshape(()) != 0, torch.full((), float("nan"), device=y.device), y)
-        return y
+        flagged = not ops.ASSUME_CODES_FIT
+        if len(self.shape) == 4:
+            N, _, H, W = self.shape
+            return ops.codes_to_f32(self.codes, N, H, W, self.halo, 1, flagged).permute(0, 3, 1, 2)
+        return ops.codes_to_f32(self.codes, self.shape[0], 1, 1, (0, 0), 1, flagged).view(self.shape)
+
+    def avg_pool2d(self, kernel_size: int, check: bool = False) -> torch.Tensor:
+        """F.avg_pool2d(self.float(), kernel_size) (kernel = stride, no padding, floor mode) in the same pass over the codes: the
+        head of models/samples/ResNet_Dorefa.py (avg_pool2d(out, 4) -> Linear).  Bit-identical to pooling the fp32 image with ATen."""
+        if len(self.shape) != 4:
+            raise ValueError("avg_pool2d takes an (N, C, H, W) activation")
+        if check:
+            self.check()
+        from . import ops
+        N, _, H, W = self.shape
+        return ops.codes_to_f32(self.codes, N, H, W, self.halo, int(kernel_size), not ops.ASSUME_CODES_FIT).permute(0, 3, 1, 2)

@@ -1806,7 +1806,8 @@ def test_fused_dorefa_resnet_matches_module_graph(dev):
     assert "qt_dorefa_codes_i8" not in used
     # conv-epilogue form: 16 code-epilogue convs, 3 fp32 shortcut convs, only the stem quantiser as its own pass
     assert used_c.get("qt_conv2d_implicit_codes") == 16 and used_c.get("qt_conv2d_implicit_halo") == 3, used_c
-    assert used_c.get("qt_affine_dorefa_codes_i8") == 1
+    assert used_c.get("qt_affine_dorefa_codes_halo_i8") == 1 and "qt_pad_pixel_plane" not in used_c     # ... straight into the halo plane
+    assert used_c.get("qt_codes_to_f32") == 1                                                            # the head: image + avg_pool2d, one pass
     assert torch.equal(got_c, got)
     with torch.no_grad():
         assert torch.equal(bench_models.FusedDorefaResNet18(m, fuse_conv=True, halo=0)(x), got)

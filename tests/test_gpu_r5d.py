@@ -1,0 +1,187 @@
+"""Round-5 GPU tests, part d: launches taken out of the C4 (DoReFa ResNet-18) forward and the deeper DMA ring of its late stages.
+
+  * qt_codes_to_f32: the fp32 image of a code plane (any halo, ragged channel counts, raised range flag -> NaN), and with
+    avg_pool2d in the same pass bit-identical to ATen's pooling of that image;
+  * qt_affine_dorefa_codes_halo_i8: the BatchNorm + ReLU + quantiser pass writing straight into the consumer's halo plane equals the
+    plain pass followed by qt_pad_pixel_plane, byte for byte;
+  * qt_conv2d_implicit_halo_bn: the 1x1 shortcut conv with BatchNorm in its epilogue equals conv, then qt_bn_eval_device_f32;
+  * the ring of 3 / 4 stage buffers on the 256- / 512-channel small-map convs produces the codes of the double-buffered loop;
+  * the whole C4 net, fused form and un-modified module graph, still equals its module-by-module execution bit for bit."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bench_models  # noqa: E402
+from pytorch_quantize_impls_amd import _lib, lazy, ops, packed  # noqa: E402
+from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedBnDorefaQuant, FusedDorefaConvBnQuant  # noqa: E402
+from pytorch_quantize_impls_amd.layers import fused as fused_layers  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _plane(dev, N, C, H, W, halo, seed=0, bits=4):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    hy, hx = halo
+    ld = ops.code_ld_bytes(C, 16)
+    q = torch.zeros((N, H + 2 * hy, W + 2 * hx, ld), dtype=torch.int8)
+    q[:, hy:hy + H, hx:hx + W, :C] = torch.randint(-20, 128, (N, H, W, C), generator=g, dtype=torch.int32).to(torch.int8)
+    flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    planes = ops.CodePlanes(codes=q.view(-1, ld).to(dev), rows=N * (H + 2 * hy) * (W + 2 * hx), K=C, inv_n=ops.inv_levels(bits),
+                            bit_width=bits, overflow=flag)
+    return packed.CodeActivation(planes, (N, C, H, W), halo=halo), q[:, hy:hy + H, hx:hx + W, :C]
+
+
+@pytest.mark.parametrize("N,C,H,W,halo", [(3, 64, 8, 8, (1, 1)), (2, 20, 5, 7, (0, 0)), (2, 7, 4, 4, (2, 1)), (5, 512, 4, 4, (1, 1))])
+def test_codes_to_f32_is_the_quantisers_image(dev, N, C, H, W, halo):
+    act, q = _plane(dev, N, C, H, W, halo, seed=C)
+    want = (q.to(torch.float32).to(dev) * act.codes.inv_n).permute(0, 3, 1, 2)         # fl(inv_n * q), the reference's image
+    before = _lib.call_counts.get("qt_codes_to_f32", 0)
+    y = act.float()
+    assert _lib.call_counts.get("qt_codes_to_f32", 0) == before + 1
+    assert y.shape == (N, C, H, W) and torch.equal(y, want)
+    act.codes.overflow.fill_(1)                                                         # the chain left int8 somewhere
+    assert bool(torch.isnan(act.float()).all())
+    with pytest.raises(RuntimeError):
+        act.float(check=True)
+
+
+@pytest.mark.parametrize("N,C,H,W,halo,k", [(256, 512, 4, 4, (1, 1), 4), (3, 64, 8, 8, (1, 1), 2), (2, 20, 6, 9, (0, 0), 3), (2, 36, 7, 7, (0, 0), 7),
+                                            (4, 128, 8, 8, (0, 0), 4)])
+def test_avg_pool_on_codes_equals_atens_pooling_of_the_image(dev, N, C, H, W, halo, k):
+    act, _ = _plane(dev, N, C, H, W, halo, seed=7 * C + k)
+    img = act.float()
+    want_cl = torch.nn.functional.avg_pool2d(img, k)                                    # channels_last image (what the head sees)
+    want_nchw = torch.nn.functional.avg_pool2d(img.contiguous(), k)                     # ... and the NCHW kernel
+    got = act.avg_pool2d(k)
+    assert got.shape == want_cl.shape
+    assert torch.equal(got, want_cl) and torch.equal(got, want_nchw)
+
+
+@pytest.mark.parametrize("N,C,H,W,halo", [(4, 64, 32, 32, (1, 1)), (3, 24, 5, 7, (1, 2)), (2, 128, 16, 16, (1, 1))])
+def test_affine_codes_into_a_halo_plane_equals_pass_plus_padding(dev, N, C, H, W, halo):
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, device=dev) * 0.6).contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(C).to(dev).eval()
+    bench_models.randomize_bn(bn, seed=2)
+    with torch.no_grad():
+        plain = FusedBnDorefaQuant(bn, 4, fold="device")(x)
+        padded = ops.pad_pixel_plane(plain.codes.codes, N, H, W, halo)
+        before = _lib.call_counts.get("qt_affine_dorefa_codes_halo_i8", 0)
+        got = FusedBnDorefaQuant(bn, 4, out_halo=halo, fold="device")(x)
+    assert _lib.call_counts.get("qt_affine_dorefa_codes_halo_i8", 0) == before + 1
+    assert got.halo == tuple(halo) and torch.equal(got.codes.codes, padded)
+    assert int(got.codes.overflow.item()) == int(plain.codes.overflow.item())
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 128, 32), (128, 256, 16), (256, 512, 8)])
+def test_shortcut_conv_with_batchnorm_in_its_epilogue(dev, cin, cout, hw):
+    torch.manual_seed(cin)
+    N = 8
+    act, _ = _plane(dev, N, cin, hw, hw, (1, 1), seed=cin)
+    act.codes.codes.clamp_(min=0, max=15)
+    sc = DorefaConv2d(cin, cout, 1, stride=2, bias=False, bit_width=1).to(dev).eval()
+    main = DorefaConv2d(cin, cout, 3, stride=2, padding=1, bias=False, bit_width=1).to(dev).eval()
+    bn_main, bn_sc = torch.nn.BatchNorm2d(cout).to(dev).eval(), torch.nn.BatchNorm2d(cout).to(dev).eval()
+    bench_models.randomize_bn(bn_main, seed=3)
+    bench_models.randomize_bn(bn_sc, seed=4)
+    for b in (bn_main, bn_sc):
+        b.running_var.mul_(4.0)
+    blk = FusedDorefaConvBnQuant(main, bn_main, 4, out_halo=1, fold="device")
+    with torch.no_grad():
+        two = blk(act, residual=sc(act), residual_bn=bn_sc)                              # conv, then qt_bn_eval_device_f32
+        before = _lib.call_counts.get("qt_conv2d_implicit_halo_bn", 0), _lib.call_counts.get("qt_bn_eval_device_f32", 0)
+        one = blk(act, residual_conv=(sc, act), residual_bn=bn_sc)
+    assert _lib.call_counts.get("qt_conv2d_implicit_halo_bn", 0) == before[0] + 1
+    assert _lib.call_counts.get("qt_bn_eval_device_f32", 0) == before[1]
+    assert torch.equal(one.codes.codes, two.codes.codes)
+    # ... and the branch value itself against the library's eval-mode BatchNorm of the conv output
+    with torch.no_grad():
+        y2, none = blk._shortcut(sc, act, bn_sc)
+        want = torch.nn.functional.batch_norm(sc(act), bn_sc.running_mean, bn_sc.running_var, bn_sc.weight, bn_sc.bias, False, 0.0, bn_sc.eps)
+    assert none is None
+    assert torch.equal(y2.view(N, hw // 2, hw // 2, cout).permute(0, 3, 1, 2), want)
+
+
+_RING_AB = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+import bench_models
+from pytorch_quantize_impls_amd import _lib, ops, packed
+from pytorch_quantize_impls_amd.layers import DorefaConv2d, FusedDorefaConvBnQuant
+dev = torch.device("cuda:0")
+h = hashlib.sha256()
+for cin, hw, stride in ((256, 8, 1), (512, 4, 1), (256, 8, 2), (128, 16, 2)):
+    cout = cin * stride
+    torch.manual_seed(cin + stride)
+    N = 256
+    ld = ops.code_ld_bytes(cin, 16)
+    q = torch.zeros((N, hw + 2, hw + 2, ld), dtype=torch.int8)
+    q[:, 1:-1, 1:-1, :cin] = torch.randint(0, 16, (N, hw, hw, cin)).to(torch.int8)
+    planes = ops.CodePlanes(codes=q.view(-1, ld).to(dev), rows=N * (hw + 2) ** 2, K=cin, inv_n=ops.inv_levels(4), bit_width=4,
+                            overflow=torch.zeros((1,), dtype=torch.int32, device=dev))
+    act = packed.CodeActivation(planes, (N, cin, hw, hw), halo=(1, 1))
+    conv = DorefaConv2d(cin, cout, 3, stride=stride, padding=1, bias=False, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    bench_models.randomize_bn(bn, seed=1)
+    bn.running_var.mul_(4.0)
+    with torch.no_grad():
+        out = FusedDorefaConvBnQuant(conv, bn, 4, out_halo=1, fold="device")(act, residual=act if stride == 1 else None)
+    torch.cuda.synchronize()
+    h.update(out.codes.codes.cpu().numpy().tobytes())
+    h.update(bytes([int(out.codes.overflow.item())]))
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_deep_dma_ring_produces_the_double_buffered_codes(dev):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for ring in ("0", "1"):
+        env = dict(os.environ)
+        env.pop("QT_NO_CONV_DEEP_RING", None)
+        if ring == "0":
+            env["QT_NO_CONV_DEEP_RING"] = "1"
+        out = subprocess.run([sys.executable, "-c", _RING_AB % root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
+
+
+def test_c4_forms_equal_the_module_by_module_graph_and_count_their_launches(dev):
+    torch.manual_seed(4)
+    m4 = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m4, seed=3)
+    for m in m4.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.mul_(4.0)
+    m4 = m4.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn((32, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
+    f4 = bench_models.FusedDorefaResNet18(m4, fold="device")
+    with torch.no_grad():
+        with lazy.eager():
+            ye = m4(x)
+        c0 = dict(_lib.call_counts)
+        yf = f4(x)
+        c1 = dict(_lib.call_counts)
+        lazy.STATS.clear()
+        ym = m4(x)
+        c2 = dict(_lib.call_counts)
+
+    def delta(a, b, name):
+        return b.get(name, 0) - a.get(name, 0)
+    assert torch.equal(yf, ye) and torch.equal(ym, ye)
+    for a, b in ((c0, c1), (c1, c2)):
+        assert delta(a, b, "qt_conv2d_implicit_halo_bn") == 3          # the three conv + BatchNorm shortcut branches, one launch each
+        assert delta(a, b, "qt_bn_eval_device_f32") == 0
+        assert delta(a, b, "qt_codes_to_f32") == 1                     # the head: codes -> image -> avg_pool2d in one pass
+        assert delta(a, b, "qt_pad_pixel_plane") == 0
+    assert lazy.STATS["avg_pool_on_codes"] == 1
