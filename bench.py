@@ -997,7 +997,7 @@ def bench_extras(args, dev, dist, world, rank, x, w):
         with torch.no_grad():
             same_a4 = bool(torch.equal(a4(x4), deferred4())) and bool(torch.equal(a4(x4), deferred4()))
         el_a = timed(lambda: a4(x4), 2 * iters)
-        # ... and the opt-in fused form the same way (its eager time is host-bound as well: ~60 launches)
+        # ... and the opt-in fused form the same way (its eager time is host-bound as well: 26 launches)
         fused_graph = {}
         try:
             gf4 = utils.graphed(f4, x4)
@@ -1032,7 +1032,8 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "fused": _net_line("c4", Bc, world, 2 * iters, el_f, st4, 5000.0, "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                {"argmax_agreement_with_unfused": agree, "same_logits_as_module_by_module": same_fused}),
             **fused_graph,
-            "note": "launch / latency bound at 32 x 32 maps (SURVEY 8d): ~60 launches of 5-40 us each"}
+            "note": "32 x 32 maps (SURVEY 8d): the fused form is 26 launches of 5-25 us inside the hipGraph, ~4.5 us of each is the fixed "
+                    "cost of a launch boundary (profiles/r5_c4_direct_conv.md, tools/probes/c4_graph_seq.sh)"}
     # ---- C5: ternary VGG-16, 3 x 224 x 224 (2048 over 8 GPUs = 256 per GPU)
     if args.c5_batch > 0:
         Bv = args.c5_batch

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/c4s
-REPLAYS=${REPLAYS:-40} rocprofv3 --kernel-trace -d /tmp/c4s -o p --output-format csv -- python $R/tools/probes/c4_graph_kernels.py > /tmp/c4s.log 2>&1
+REPLAYS=${REPLAYS:-40} rocprofv3 --kernel-trace -d /tmp/c4s -o p --output-format csv -- python $R/tools/probes/${SCRIPT:-c4_graph_kernels.py} > /tmp/c4s.log 2>&1
 python - <<'PY'
 import csv, glob, os
 def short(n):
