@@ -26,11 +26,12 @@ namespace {
 __global__ __launch_bounds__(1024) void tap_tables_kernel(const float* __restrict__ work, int nblk, float rows, const float* __restrict__ alpha_in,
                                                           int T, float* __restrict__ alpha, float* __restrict__ tables) {
     __shared__ float a[1024];
+    __shared__ float stage[TAP_FINAL_STAGE];
     const int t = threadIdx.x;
+    float s = 0.0f;
+    if (!alpha_in) s = tap_alpha_final(work, nblk, T, t, rows, stage);        // (block-cooperative: every thread calls it)
     if (t < T) {
-        float s;
         if (alpha_in) s = alpha_in[t];
-        else s = tap_alpha_final(work, nblk, T, t, rows);
         a[t] = s;
         if (alpha) alpha[t] = s;
     }

@@ -29,11 +29,24 @@ __global__ __launch_bounds__(1024) void tap_abs_partial_kernel(const float* __re
     }
 }
 
-// the closing step of the order above: blocks in ascending order, one division
-__device__ __forceinline__ float tap_alpha_final(const float* __restrict__ work, int nblk, int T, int t, float rows) {
+// the closing step of the order above: blocks in ascending order, one division.  Called by ALL threads of a 1024-thread block
+// (thread t < T returns column t's alpha, the others 0): the nblk x T partials are staged through LDS in chunks of whole block
+// rows — every thread's loads independent and coalesced — and column t is then added up from LDS in ascending block order, the
+// order (and so the bits) of the plain loop  for b: s += work[b * T + t]  this replaces: that loop was a chain of nblk dependent
+// global loads, 67 us for the 512 blocks of AlexNet's conv2 weight (tools/probes/qi_kt.sh), every forward of a training step.
+constexpr int TAP_FINAL_STAGE = 8192;     // floats of LDS staging (32 KiB)
+__device__ __forceinline__ float tap_alpha_final(const float* __restrict__ work, int nblk, int T, int t, float rows, float* stage) {
     float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += work[(int64_t)b * T + t];
-    return s / rows;
+    const int per = TAP_FINAL_STAGE / T > 0 ? TAP_FINAL_STAGE / T : 1;      // block rows per chunk (T <= 1024 <= TAP_FINAL_STAGE)
+    for (int b0 = 0; b0 < nblk; b0 += per) {
+        const int nb = min(per, nblk - b0), n = nb * T;
+        for (int i = t; i < n; i += 1024) stage[i] = work[(int64_t)b0 * T + i];
+        __syncthreads();
+        if (t < T)
+            for (int b = 0; b < nb; ++b) s += stage[b * T + t];
+        __syncthreads();
+    }
+    return t < T ? s / rows : 0.0f;
 }
 
 // number of row blocks (= workspace rows of C floats) and the rows per block of the order above

@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void col_abs_final_kernel(const float* __restr
 // closing step of xnor_alpha.h's order for FEW columns (XNORConv2d weights): the alpha bits of qt_xnor_tap_prep_f32
 __global__ __launch_bounds__(1024) void tap_alpha_final_kernel(const float* __restrict__ work, int nblk, float rows, int T,
                                                                float* __restrict__ alpha) {
+    __shared__ float stage[TAP_FINAL_STAGE];
     const int t = threadIdx.x;
-    if (t < T) alpha[t] = tap_alpha_final(work, nblk, T, t, rows);
+    const float s = tap_alpha_final(work, nblk, T, t, rows, stage);           // (block-cooperative: every thread calls it)
+    if (t < T) alpha[t] = s;
 }
 
 __device__ __forceinline__ float torch_sign(float x) {
