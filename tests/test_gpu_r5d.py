@@ -185,3 +185,49 @@ def test_c4_forms_equal_the_module_by_module_graph_and_count_their_launches(dev)
         assert delta(a, b, "qt_codes_to_f32") == 1                     # the head: codes -> image -> avg_pool2d in one pass
         assert delta(a, b, "qt_pad_pixel_plane") == 0
     assert lazy.STATS["avg_pool_on_codes"] == 1
+
+
+@pytest.mark.parametrize("cin,cout,hw,stride,k,batch", [
+    (64, 256, 16, 1, 1, 128),      # ONE 64-byte stage on the ring of four (fewer stages than buffers)
+    (128, 256, 16, 1, 1, 128),     # one 128-byte stage
+    (192, 256, 16, 1, 1, 128),     # two stages, the second half empty
+    (64, 256, 16, 1, 3, 128),      # 4.5 stages: exactly the ring depth + a tail
+    (128, 256, 32, 2, 3, 128),     # wide stride-2 conv on a small map (the 128 x 128 deep-ring rule)
+    (256, 256, 8, 1, 3, 256),      # 18 stages (stage 3 of the ResNet)
+    (512, 512, 4, 1, 3, 199),      # ragged M: 3184 rows of 128 x 64 tiles, ring of three
+    (144, 256, 16, 2, 3, 250),     # 1296-byte rows: the wide stride-2 rule with a partial last stage and ragged M
+])
+def test_deep_ring_short_and_ragged_k_loops(dev, cin, cout, hw, stride, k, batch):
+    """Whatever configuration the rules pick with and without the ring (the switch is read per call, so ONE process): short K loops
+    (these stay on the double-buffered small-K tiles), partial last stages, row tiles past M on the ring configurations."""
+    torch.manual_seed(cin + cout + k)
+    pad = k // 2
+    act, _ = _plane(dev, batch, cin, hw, hw, (1, 1), seed=cin + k)
+    act.codes.codes.clamp_(min=0, max=15)
+    conv = DorefaConv2d(cin, cout, k, stride=stride, padding=pad, bias=False, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    bench_models.randomize_bn(bn, seed=5)
+    bn.running_var.mul_(4.0)
+    blk = FusedDorefaConvBnQuant(conv, bn, 4, out_halo=1, fold="device")
+    old = os.environ.pop("QT_NO_CONV_DEEP_RING", None)
+    try:
+        with torch.no_grad():
+            ring = blk(act)
+            os.environ["QT_NO_CONV_DEEP_RING"] = "1"
+            plain = blk(act)
+    finally:
+        os.environ.pop("QT_NO_CONV_DEEP_RING", None)
+        if old is not None:
+            os.environ["QT_NO_CONV_DEEP_RING"] = old
+    torch.cuda.synchronize()
+    assert torch.equal(ring.codes.codes, plain.codes.codes)
+    assert int(ring.codes.overflow.item()) == 0
+    # ... and against the integer conv evaluated by the library on the code values (exact in fp32 for these sizes), pushed through the
+    # same BatchNorm / ReLU / quantiser modules
+    with torch.no_grad():
+        xq = act.float()
+        want = torch.nn.functional.conv2d(xq, conv.weight.sign() * conv.weight.abs().amax(), None, stride, pad)
+        ref = FusedBnDorefaQuant(bn, 4, fold="device")(want.contiguous(memory_format=torch.channels_last))
+    got = ring.without_halo().codes.codes[:, :cout]
+    flips = (got != ref.codes.codes[:, :cout])
+    assert float(flips.float().mean()) < 1e-3                      # the library's fp32 conv rounds differently: ties only
