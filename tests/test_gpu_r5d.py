@@ -231,3 +231,29 @@ def test_deep_ring_short_and_ragged_k_loops(dev, cin, cout, hw, stride, k, batch
     got = ring.without_halo().codes.codes[:, :cout]
     flips = (got != ref.codes.codes[:, :cout])
     assert float(flips.float().mean()) < 1e-3                      # the library's fp32 conv rounds differently: ties only
+
+
+@pytest.mark.parametrize("halo,k,pad,stride", [((1, 1), 1, 0, 2), ((1, 1), 3, 1, 1), ((0, 0), 3, 1, 1), ((0, 0), 1, 0, 1), ((2, 2), 3, 1, 2)])
+def test_conv_with_batchnorm_epilogue_every_route(dev, halo, k, pad, stride):
+    """ops.conv2d_codes(epi=BnEpilogue): one launch on halo planes / un-padded convs, conv + qt_bn_eval_device_f32 where the plane
+    is padded first — the same bits either way."""
+    torch.manual_seed(k + pad + stride)
+    N, cin, cout, hw = 4, 32, 48, 12
+    act, _ = _plane(dev, N, cin, hw, hw, halo, seed=3)
+    act.codes.codes.clamp_(min=0, max=15)
+    conv = DorefaConv2d(cin, cout, k, stride=stride, padding=pad, bias=True, bit_width=1).to(dev).eval()
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    bench_models.randomize_bn(bn, seed=6)
+    Ho, Wo = ops.conv_out_hw(hw, hw, k, k, stride, pad, 1)
+    with torch.no_grad():
+        w, b, stats = fused_layers.device_bn_fold(bn, (N, cout, Ho, Wo), True)
+        wc = ops.pack_conv_weight_codes(conv.weight.detach())
+        E = conv.weight.abs().amax()
+        args = (act.codes, act.shape, wc, (k, k), act.codes.inv_n, conv.bias, stride, pad, 1)
+        plain = ops.conv2d_codes(*args, scale_dev=E, in_halo=halo)
+        want = ops.bn_eval_device(plain, w, b, stats)
+        got = ops.conv2d_codes(*args, scale_dev=E, epi=ops.BnEpilogue(w, b, stats), in_halo=halo)
+        lib = torch.nn.functional.batch_norm(plain.view(N, Ho, Wo, cout).permute(0, 3, 1, 2), bn.running_mean, bn.running_var, bn.weight,
+                                             bn.bias, False, 0.0, bn.eps)
+    assert torch.equal(got, want)
+    assert torch.equal(got.view(N, Ho, Wo, cout).permute(0, 3, 1, 2), lib)
