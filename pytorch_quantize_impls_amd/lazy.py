@@ -275,7 +275,7 @@ def _force_codes(self, halo=None):
                         if (root.parent is None and root.value is None and isinstance(root.input, packed.CodeActivation)
                                 and o.bn is not None and o.pool is None and o.relu is False and o.add is None):
                             # ... the un-materialised conv of the branch on a code plane: conv + BatchNorm in one launch
-                            root.check_unmodified()
+                            o.check_unmodified()                       # the branch's BatchNorm tensors and, through the parent, its conv's
                             res_conv, res_bn = (root.layer, root.input), _bn_view(blk, o.bn)
                         else:
                             res, res_bn = root.materialise(), _bn_view(blk, o.bn)

@@ -257,3 +257,28 @@ def test_conv_with_batchnorm_epilogue_every_route(dev, halo, k, pad, stride):
                                              bn.bias, False, 0.0, bn.eps)
     assert torch.equal(got, want)
     assert torch.equal(got.view(N, Ho, Wo, cout).permute(0, 3, 1, 2), lib)
+
+
+def test_shortcut_batchnorm_written_before_the_chain_is_used_is_caught(dev):
+    """The one-launch shortcut branch reads its BatchNorm when the chain is USED: an in-place write in between is reported like any
+    other producer of a deferred activation (version counters of the branch's BatchNorm node, not only of its conv)."""
+    from pytorch_quantize_impls_amd.functions import nnDorefaQuant
+    torch.manual_seed(2)
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    blk = m.blocks[2]                                               # 64 -> 128, stride 2: conv + BatchNorm shortcut
+    x = torch.randn(4, 64, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        q = nnDorefaQuant(4)(torch.relu(x))
+        y = blk(q)
+        assert isinstance(y, lazy.LazyActivation)
+        ref = y + 0
+        y2 = blk(q)
+        blk.shortcut[1].running_mean.add_(0.25)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y2 + 0
+        y3 = blk(q)                                                 # recorded after the write: the new statistics
+        with lazy.eager():
+            want = blk(q)
+        assert torch.equal(y3 + 0, want) and not torch.equal(want, ref)
