@@ -14,7 +14,11 @@ from .. import lazy
 
 class GraphedModule(torch.nn.Module):
     """``GraphedModule(module, example_input)(x)``: copies x into the captured input buffer, replays the graph and
-    returns the captured output tensor (overwritten by the next call: clone it to keep it)."""
+    returns the captured output tensor (overwritten by the next call: clone it to keep it).
+
+    ``static_input`` is that buffer: a caller that produces its batches there (the target of its host-to-device copy, or of the
+    previous pipeline stage) passes it back — ``g(g.static_input)`` — and the replay starts without the device-to-device copy
+    (154 MB / 53 us for a 256 x 3 x 224 x 224 batch)."""
 
     def __init__(self, module: torch.nn.Module, example_input: torch.Tensor, warmup: int = 3):
         super().__init__()
@@ -39,9 +43,15 @@ class GraphedModule(torch.nn.Module):
         if x.shape != self._static_in.shape or x.dtype != self._static_in.dtype:
             raise ValueError(f"captured for input {tuple(self._static_in.shape)} {self._static_in.dtype}, "
                              f"got {tuple(x.shape)} {x.dtype}")
-        self._static_in.copy_(x)
+        if x is not self._static_in:
+            self._static_in.copy_(x)
         self._graph.replay()
         return self._static_out
+
+    @property
+    def static_input(self) -> torch.Tensor:
+        """The captured input buffer (write the next batch here and call ``self(self.static_input)``: no copy)."""
+        return self._static_in
 
 
 def graphed(module: torch.nn.Module, example_input: torch.Tensor, warmup: int = 3) -> GraphedModule:

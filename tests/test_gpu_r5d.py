@@ -282,3 +282,21 @@ def test_shortcut_batchnorm_written_before_the_chain_is_used_is_caught(dev):
         with lazy.eager():
             want = blk(q)
         assert torch.equal(y3 + 0, want) and not torch.equal(want, ref)
+
+
+def test_graphed_module_replays_from_its_static_input_without_a_copy(dev):
+    from pytorch_quantize_impls_amd import utils
+    torch.manual_seed(9)
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    m = m.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn((8, 3, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn_like(x)
+    with torch.no_grad():
+        g = utils.graphed(m, x)
+        y1 = g(x).clone()
+        g.static_input.copy_(x2)                       # the caller fills the captured buffer itself ...
+        y2 = g(g.static_input).clone()                 # ... and replays without the device-to-device copy
+        assert torch.equal(y2, g(x2)) and not torch.equal(y1, y2)
+        with lazy.eager():
+            assert torch.equal(y1, m(x))
