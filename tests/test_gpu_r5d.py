@@ -179,11 +179,14 @@ def test_c4_forms_equal_the_module_by_module_graph_and_count_their_launches(dev)
     def delta(a, b, name):
         return b.get(name, 0) - a.get(name, 0)
     assert torch.equal(yf, ye) and torch.equal(ym, ye)
-    for a, b in ((c0, c1), (c1, c2)):
+    for a, b, pads in ((c0, c1, 0), (c1, c2, 1)):
         assert delta(a, b, "qt_conv2d_implicit_halo_bn") == 3          # the three conv + BatchNorm shortcut branches, one launch each
         assert delta(a, b, "qt_bn_eval_device_f32") == 0
         assert delta(a, b, "qt_codes_to_f32") == 1                     # the head: codes -> image -> avg_pool2d in one pass
-        assert delta(a, b, "qt_pad_pixel_plane") == 0
+        # fused form: the stem quantiser writes the halo plane itself; module graph: the chain's first conv reads the code TAG of the
+        # stem's nnDorefaQuant result (no halo) and pads it once to run the direct kernel like every later conv
+        assert delta(a, b, "qt_pad_pixel_plane") == pads
+        assert delta(a, b, "qt_conv2d_implicit_codes") == 16
     assert lazy.STATS["avg_pool_on_codes"] == 1
 
 
