@@ -5,5 +5,13 @@ from . import functions, layers, ops, packed, utils
 from .device import device
 from ._lib import QtLibraryError, QtStatusError
 
-# family aliases, as QuantTorch/{BinaryNet,TernerNet,DorefaNet,XnorNet}.py
-__all__ = ["functions", "layers", "ops", "packed", "utils", "device", "QtLibraryError", "QtStatusError"]
+# family aliases, as QuantTorch/{BinaryNet,TernerNet,DorefaNet,XnorNet,LogLinNet}.py (imported lazily: `import pkg.BinaryNet`)
+__all__ = ["functions", "layers", "ops", "packed", "utils", "device", "QtLibraryError", "QtStatusError",
+           "BinaryNet", "TernerNet", "DorefaNet", "XnorNet", "LogLinNet"]
+
+
+def __getattr__(name):
+    if name in ("BinaryNet", "TernerNet", "DorefaNet", "XnorNet", "LogLinNet"):
+        import importlib
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
