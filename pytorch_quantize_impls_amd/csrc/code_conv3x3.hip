@@ -387,7 +387,19 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     const int64_t tiles_m = (rows_total + RT - 1) / RT, tiles_n = Cout / 64;
     const int64_t patch_rows = RT <= H ? RT + 2 : (RT / H) * Hp;
     const int64_t patch_bytes = (patch_rows * Wp * CB + 255) / 256 * 256;
-    const char* fm0 = getenv("QT_C3_MODE");
+    // tool-only switches (occupancy / order / loader-mode experiments) are read ONCE per process: no environment walk on the
+    // launch-bound module-graph path and no race with a concurrent setenv; the one A/B switch tests flip inside a
+    // process, QT_NO_CODE_CONV3X3 above, stays per call as include/qt_hip.h documents
+    struct C3Env { const char* mode; bool plain_order; int per_cu; };
+    static const C3Env env = [] {
+        C3Env e;
+        e.mode = getenv("QT_C3_MODE");
+        e.plain_order = getenv("QT_C3_PLAIN_ORDER") != nullptr;
+        const char* pc = getenv("QT_C3_PER_CU");
+        e.per_cu = pc ? atoi(pc) : 0;
+        return e;
+    }();
+    const char* fm0 = env.mode;
 #ifdef QT_PROFILING_VARIANTS
     const bool single = fm0 && atoi(fm0) == 5;                                  // profiling builds: the single-buffer variant
 #else
@@ -411,23 +423,23 @@ int qt_code_conv3x3_try(const uint32_t* P, int64_t Nimg, int64_t H, int64_t W, i
     a.res_codes = res_codes; a.ldrc = (int)ldrc_bytes; a.rhy = (int)rhy; a.rhx = (int)rhx;
     a.Q = codes; a.ldq = (int)ldc_bytes; a.ohy = (int)ohy; a.ohx = (int)ohx;
     a.overflow = overflow;
-    a.no_xcd_order = getenv("QT_C3_PLAIN_ORDER") ? 1 : 0;
+    a.no_xcd_order = env.plain_order ? 1 : 0;
     // persistent grid: as many workgroups as stay resident (LDS-bound), a multiple of the column tiles
     int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds));
-    if (const char* pc = getenv("QT_C3_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(pc)));     // tools: occupancy experiments
+    if (env.per_cu > 0) per_cu = std::max(1, std::min(per_cu, env.per_cu));     // tools: occupancy experiments
     int64_t grid = std::min<int64_t>(tiles_m * tiles_n, 256ll * per_cu);
     grid = std::max<int64_t>(tiles_n, grid / tiles_n * tiles_n);
     hipStream_t st = (hipStream_t)stream;
     // MODE 0: the compute waves issue the next patch's DMA themselves; MODE 2: a fifth (loader) wave does.  Measured per launch
     // (tools/probes/c3_modes.sh, batch 256): 64 -> 64 @ 32 x 32: 22.8 / 29.4 us, 128 -> 128 @ 16 x 16: 23.8 / 22.4 us
     // (implicit-GEMM kernel: 29.0 / 24.2 us).  QT_C3_MODE overrides (tools only; 1 / 3 / 4 exist in profiling builds).
-    const char* fm = getenv("QT_C3_MODE");
+    const char* fm = env.mode;
     const int forced = fm ? atoi(fm) : -1;
     const int mode = forced >= 0 ? forced : (CB == 64 ? 0 : 2);
 #define QT_C3(CBV, MD)                                                                                                              \
     do {                                                                                                                            \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(code_conv3x3_kernel<CBV, MD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds) != hipSuccess)                                                                            \
+        static QtLdsOnce once;                                                                                                      \
+        if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(code_conv3x3_kernel<CBV, MD>), (int)lds) != QT_OK)               \
             return QT_ERR_LAUNCH;                                                                                                   \
         hipLaunchKernelGGL((code_conv3x3_kernel<CBV, MD>), dim3((unsigned)grid), dim3(MD == 2 ? 320 : 256), (size_t)lds, st, a,    \
                            (int)patch_bytes);                                                                                       \

@@ -582,8 +582,9 @@ int first_direct_impl(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, std::max<int64_t>(1, 512 / ny)), ny);
 #define QT_FIRST_LAUNCH(REALW, BITS, MAXP)                                                                                          \
     do {                                                                                                                      \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_direct_kernel<REALW, BITS, MAXP>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QT_ERR_LAUNCH;          \
+        static QtLdsOnce once;                                                                                                \
+        if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(conv_first_direct_kernel<REALW, BITS, MAXP>), lds) != QT_OK) \
+            return QT_ERR_LAUNCH;                                                                                             \
         hipLaunchKernelGGL((conv_first_direct_kernel<REALW, BITS, MAXP>), grid, dim3(256), lds, (hipStream_t)stream, a);            \
     } while (0)
     if (wlo) { if (alpha) QT_FIRST_LAUNCH(true, true, 18); else QT_FIRST_LAUNCH(true, false, 18); }

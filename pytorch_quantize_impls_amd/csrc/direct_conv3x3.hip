@@ -408,9 +408,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
 template <int CPP, int TNW, int WN, int OCC, int EL = 0>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
     const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16 + (EL == 1 ? 4 * WN * 4096 : 0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return QT_ERR_LAUNCH;
+    static QtLdsOnce once;
+    if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL>), lds) != QT_OK) return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const long long cap = 256ll * wg_per_cu;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);

@@ -1247,7 +1247,7 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     if (gx * gy > (1ll << 30)) return QT_ERR_UNSUPPORTED;
     unsigned grid = (unsigned)((gx * gy + 7) / 8 * 8);
     if (C::CONV && (epi.mode == 2 || epi.mode == 3) && (epi.ohy | epi.ohx)) grid += 64;   // border-zeroing workgroups
-    // > 64 KiB of dynamic LDS needs the opt-in attribute (per device; cheap, so set every call)
+    // > 64 KiB of dynamic LDS needs the opt-in attribute (per kernel and device: qt_ensure_dyn_lds raises it once)
     // VALID conv: + the tap table, one 4-byte offset per (stage, chunk)
     const int lds_bytes = C::LDS_BYTES + (C::VALID ? ((cg.kbytes + C::STAGE_BYTES - 1) / C::STAGE_BYTES) * C::CHUNKS * 4 : 0) +
                           (C::E::TAPS ? (epi.ntaps + 1 + 3) / 4 * 16 : 0) +      // E::TAPS: + the per-tap factor table
@@ -1255,17 +1255,15 @@ int launch_cfg(const uint32_t* Xn, int64_t ldxp, const uint32_t* Wn, int64_t ldw
     if (lds_bytes > 160 * 1024) return QT_ERR_UNSUPPORTED;
     if constexpr (C::E::CODE_EPI && C::CONV) {
         if ((epi.mode == 2 || epi.mode == 4) && epi.bn_stats) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-                return QT_ERR_LAUNCH;
+            static QtLdsOnce once_bn;
+            if (qt_ensure_dyn_lds(once_bn, reinterpret_cast<const void*>(mfma_gemm_kernel<C, true>), lds_bytes) != QT_OK) return QT_ERR_LAUNCH;
             hipLaunchKernelGGL((mfma_gemm_kernel<C, true>), dim3(grid, 1), dim3(C::NTHREADS), lds_bytes, (hipStream_t)stream, Xn,
                                ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy, (int)M, (int)N, (int)K, cg, epi);
             return qt_check_launch();
         }
     }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_gemm_kernel<C>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-        return QT_ERR_LAUNCH;
+    static QtLdsOnce once;
+    if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(mfma_gemm_kernel<C>), lds_bytes) != QT_OK) return QT_ERR_LAUNCH;
     const unsigned nz = (!C::CONV && cg.z_nslice > 0) ? (unsigned)(cg.z_nslice * cg.H) : 1u;   // GEMM batch: cg.H = taps
     hipLaunchKernelGGL(mfma_gemm_kernel<C>, dim3(grid, nz), dim3(C::NTHREADS),
                        lds_bytes, (hipStream_t)stream, Xn, ldxp, Wn, ldwp, bias, scale, scale_dev, Y, ldy,

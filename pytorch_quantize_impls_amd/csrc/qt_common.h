@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/qt_hip.h"
 
 #define QT_VERSION_INT 100 /* 0.1.0 */
@@ -9,6 +10,20 @@
 static inline int qt_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : QT_ERR_LAUNCH;
+}
+
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per (kernel, device).
+// `once` is a function-local static of the launching template instantiation: the attribute call (a runtime lock + lookup) leaves
+// the per-launch path after the first launch on a device (host overhead of the launch-bound module-graph path).
+struct QtLdsOnce { std::atomic<int> have[16]; };
+static inline int qt_ensure_dyn_lds(QtLdsOnce& once, const void* fn, int bytes) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return QT_ERR_LAUNCH;
+    const bool tracked = dev >= 0 && dev < 16;
+    if (tracked && bytes <= once.have[dev].load(std::memory_order_acquire)) return QT_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return QT_ERR_LAUNCH;
+    if (tracked) once.have[dev].store(bytes, std::memory_order_release);     // only a LARGER request calls again
+    return QT_OK;
 }
 
 static inline bool qt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

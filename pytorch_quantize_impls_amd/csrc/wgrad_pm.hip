@@ -828,8 +828,8 @@ int pm_launch(const PmArgs& a, int nslice, hipStream_t stream) {
     using C = PmCfg<TM, TN, KH, KW, NP>;
     void (*kernel)(PmArgs) = wgrad_pm_kernel<TM, TN, KH, KW, NP>;
     if constexpr (FULL) kernel = wgrad_pm_full_kernel<TM, TN, KH, KW, NP>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
-        return QT_ERR_LAUNCH;
+    static QtLdsOnce once;                       // per instantiation (TM, TN, KH, KW, NP, FULL)
+    if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(kernel), C::LDS) != QT_OK) return QT_ERR_LAUNCH;
     PmArgs b = a;
     b.tiles_co = a.Cpo / TM;
     b.tiles_ci = a.Cpi / TN;

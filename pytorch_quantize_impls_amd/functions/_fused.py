@@ -131,16 +131,18 @@ def detect_scope(mode: Optional[str]):
 
 _VERDICTS = {}     # id(weight tensor) -> (weak reference to it, {(question, shape): bool}); tensors compare element-wise, so
 #                    they cannot key a WeakKeyDictionary
+_VERDICTS_LOCK = threading.RLock()   # serving threads share the store; the weak-reference callback may fire inside any of them
 #: "sync": decisions that needed a host sync; "cached": decisions taken from a remembered verdict (tests assert on it)
 DETECT_STATS: Counter = Counter()
 
 
 def reset_detection(weight: Optional[torch.Tensor] = None) -> None:
     """Forget the remembered verdicts (of one weight, or all)."""
-    if weight is None:
-        _VERDICTS.clear()
-    else:
-        _VERDICTS.pop(id(weight), None)
+    with _VERDICTS_LOCK:
+        if weight is None:
+            _VERDICTS.clear()
+        else:
+            _VERDICTS.pop(id(weight), None)
 
 
 def _verdict(weight, tag, resolve):
@@ -152,17 +154,29 @@ def _verdict(weight, tag, resolve):
         DETECT_STATS["sync"] += 1
         return bool(resolve()), False
     key = id(weight)
-    slot = _VERDICTS.get(key)
-    if slot is None or slot[0]() is not weight:
-        slot = (weakref.ref(weight, lambda _r, k=key: _VERDICTS.pop(k, None)), {})
-        _VERDICTS[key] = slot
-    d = slot[1]
-    if tag in d and (d[tag] is False or mode == "remember"):
-        DETECT_STATS["cached"] += 1
-        return d[tag], True
-    d[tag] = bool(resolve())
-    DETECT_STATS["sync"] += 1
-    return d[tag], False
+    with _VERDICTS_LOCK:
+        slot = _VERDICTS.get(key)
+        if slot is None or slot[0]() is not weight:
+            slot = (weakref.ref(weight, _drop_verdicts(key)), {})
+            _VERDICTS[key] = slot
+        d = slot[1]
+        if tag in d and (d[tag] is False or mode == "remember"):
+            DETECT_STATS["cached"] += 1
+            return d[tag], True
+    answer = bool(resolve())                   # (the device check / host sync runs outside the lock)
+    with _VERDICTS_LOCK:
+        d[tag] = answer
+        DETECT_STATS["sync"] += 1
+    return answer, False
+
+
+def _drop_verdicts(key):
+    def drop(_ref):
+        with _VERDICTS_LOCK:
+            slot = _VERDICTS.get(key)
+            if slot is not None and slot[0] is _ref:          # a new tensor may have taken the id meanwhile: keep its slot
+                _VERDICTS.pop(key, None)
+    return drop
 
 
 def verdict_is_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]) -> bool:
@@ -171,8 +185,9 @@ def verdict_is_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]) -> bool:
     armed the device flag that poisons its output, so the backward may contract the same +-1 image."""
     if weight is None:
         return False
-    slot = _VERDICTS.get(id(weight))
-    return bool(slot is not None and slot[0]() is weight and slot[1].get(("pm1", tuple(input.shape[1:]))) is True)
+    with _VERDICTS_LOCK:
+        slot = _VERDICTS.get(id(weight))
+        return bool(slot is not None and slot[0]() is weight and slot[1].get(("pm1", tuple(input.shape[1:]))) is True)
 
 
 _LAST = threading.local()      # .pm1 = (data_ptr, shape, answer) of the detection that ran last in this thread

@@ -187,8 +187,8 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
                         y2 = ops.conv2d_real_taps(input, weight, taps.fwd, bias, stride, padding, dilation)
                     if y2 is not None:
                         ctx.taps = taps                                   # grad_input: the flipped taps, like the +-1 route
-                        if need_image:
-                            ctx.save_for_backward(input, weight, taps.alpha.view(1, 1, kh, kw), bias)
+                        # always saved: a trainable bias alone still runs backward (the image slot is None then)
+                        ctx.save_for_backward(input if need_image else None, weight, taps.alpha.view(1, 1, kh, kw), bias)
                         N_, _, H, W = raw.shape
                         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
                         return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)

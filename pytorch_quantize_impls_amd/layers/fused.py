@@ -335,14 +335,24 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
     def refold(self):
         self._folded = self._folded_res = None
 
-    def _shortcut(self, sc_conv, sc_act, residual_bn):
-        """The conv -> BatchNorm shortcut branch: (fp32 [M, C] matrix already normalised, None) or (conv output, its BatchNorm)."""
-        if (residual_bn is not None and self.fold == "device" and isinstance(sc_act, packed.CodeActivation)
+    def shortcut_in_one_launch(self, sc_conv, sc_act, residual_bn) -> bool:
+        """Does the conv -> BatchNorm shortcut branch run as ONE launch (BatchNorm in the conv's epilogue)?  lazy._force_codes asks
+        before it hands the un-materialised branch over: where the answer is no it materialises the branch's root itself (which
+        caches the value for the branch's other consumers) instead of letting the fallback below re-enter the deferred forward."""
+        if not (residual_bn is not None and self.fold == "device" and isinstance(sc_act, packed.CodeActivation)
                 and getattr(sc_conv, "bit_width", None) == 1 and sc_conv.groups == 1 and sc_conv.padding_mode == "zeros"
                 and not isinstance(sc_conv.padding, str) and not sc_conv.training and sc_conv.out_channels % 4 == 0):
+            return False
+        kh, kw = sc_conv.kernel_size
+        return (sc_act.codes.K == sc_act.shape[1] == sc_conv.in_channels
+                and 127 * kh * kw * sc_act.codes.codes.shape[1] < (1 << 24))
+
+    def _shortcut(self, sc_conv, sc_act, residual_bn):
+        """The conv -> BatchNorm shortcut branch: (fp32 [M, C] matrix already normalised, None) or (conv output, its BatchNorm)."""
+        if self.shortcut_in_one_launch(sc_conv, sc_act, residual_bn):
             N_, C_, H_, W_ = sc_act.shape
             kh, kw = sc_conv.kernel_size
-            if sc_act.codes.K == C_ == sc_conv.in_channels and 127 * kh * kw * sc_act.codes.codes.shape[1] < (1 << 24):
+            if True:
                 Ho_, Wo_ = ops.conv_out_hw(H_, W_, kh, kw, sc_conv.stride, sc_conv.padding, sc_conv.dilation)
                 rw, rb, rstats = _code_fold_for(self, "_folded_res", residual_bn, "device", ((N_, sc_conv.out_channels, Ho_, Wo_), True))
                 wc = sc_conv._eval_planes(lambda _w2: ops.pack_conv_weight_codes(sc_conv.weight.detach()), key="conv_i8")
@@ -351,7 +361,8 @@ class FusedDorefaConvBnQuant(torch.nn.Module):
                                       sc_conv.padding, sc_conv.dilation, scale_dev=E, epi=ops.BnEpilogue(rw, rb, rstats),
                                       in_halo=sc_act.halo)
                 return y2, None
-        return sc_conv(sc_act), residual_bn
+        with lazy.eager():                            # (explicit callers: the branch conv's ordinary eval path, never a deferred node)
+            return sc_conv(sc_act), residual_bn
 
     def forward(self, act, residual=None, residual_bn=None, residual_conv=None):
         conv = self.conv

@@ -273,7 +273,8 @@ def _force_codes(self, halo=None):
                     else:                                         # conv + BatchNorm shortcut: fp32 conv output, BN folded
                         root = o.parent
                         if (root.parent is None and root.value is None and isinstance(root.input, packed.CodeActivation)
-                                and o.bn is not None and o.pool is None and o.relu is False and o.add is None):
+                                and o.bn is not None and o.pool is None and o.relu is False and o.add is None
+                                and blk.shortcut_in_one_launch(root.layer, root.input, _bn_view(blk, o.bn))):
                             # ... the un-materialised conv of the branch on a code plane: conv + BatchNorm in one launch
                             o.check_unmodified()                       # the branch's BatchNorm tensors and, through the parent, its conv's
                             res_conv, res_bn = (root.layer, root.input), _bn_view(blk, o.bn)

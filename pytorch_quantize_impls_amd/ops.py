@@ -1174,7 +1174,10 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
                             bit_width=pixels.bit_width, overflow=pixels.overflow)
     if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
         if (isinstance(epi, CodeEpilogue) and (kh, kw, sh, sw, ph, pw, dh, dw) == (3, 3, 1, 1, 1, 1, 1, 1) and Cw * 4 in (64, 128)
-                and Cout % 64 == 0 and bias is None and epi.res_f32 is None):
+                and Cout % 64 == 0 and bias is None and epi.res_f32 is None
+                and H & (H - 1) == 0 and W & (W - 1) == 0 and W <= 128 and (N * H * W) % 128 == 0):
+            # (the geometry test mirrors qt_code_conv3x3_try's own: where the direct kernel would decline — 56 x 56 / 28 x 28 maps,
+            # odd batches — the pad pass below would be paid for nothing over the bounds-checked un-padded form: ADVICE r5)
             # a chain's FIRST conv (its input is the code tag of an nnDorefaQuant result: no halo yet) in the shape class of the direct
             # 3 x 3 kernel: one pass makes the zero border physical (7 us at 256 x 64 x 32 x 32) and the conv runs on the halo plane
             # like every later one (38.9 -> 22 us there; the bounds-checked implicit form is what it replaces).  Exact either way.

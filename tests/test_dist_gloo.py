@@ -292,3 +292,8 @@ def test_bench_self_launches_without_a_launcher():
     d = lines[0]["dist"]
     assert d["world_size_seen_by_the_process_group"] == 2 and d["ranks"] == [0, 1] and d["distinct_processes"] == 2
     assert d["max_over_ranks"] == 2.0 and lines[0]["n_gpus"] == 2
+    # the line checks itself (process group size == --gpus, one device per rank) and the compact line carries the
+    # C3 AND C5 per-rank times (C5's 8 x 256 split is BASELINE config 5) — assembled by the code path the measured run uses
+    assert d["self_check"] == {"world_size_matches_gpus": True, "distinct_devices": True, "ok": True}
+    per = lines[0]["compact_line_per_rank"]
+    assert per["c3"] == [1.0, 2.0] and per["c5"] == [1.0, 2.0]
