@@ -42,6 +42,7 @@ class LinearDorefa(EvalSwapMixin, torch.nn.Linear, QLayer):
         return ((c - r).abs() <= 1e-3).all() & (r.abs() <= n).all() & (torch.remainder(r + n, 2) == 0).all()
 
     def forward(self, input):
+        lazy.note_inference_call(self, input)
         return lazy_train.wrap(self, self._forward_impl(lazy.resolve(input)))
 
     def _forward_impl(self, input):

@@ -49,6 +49,7 @@ class LinearQuant(_WeightInit, EvalSwapMixin, torch.nn.Linear, QLayer):
         self.weight_op = log_lin_connect.nnQuant(dtype=dtype, fsr=fsr, bit_width=bit_width, with_sign=True, lin_back=True)
 
     def forward(self, input):
+        lazy.note_inference_call(self, input)
         input = lazy.resolve(input)
         wq = self.weight_op.forward(self.weight)
         if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and _exact_in_bf16(self.qdtype, self.bit_width)
@@ -80,6 +81,7 @@ class QuantConv2d(_WeightInit, EvalSwapMixin, torch.nn.Conv2d, QLayer):
         self.weight_op = log_lin_connect.nnQuant(dtype=dtype, fsr=fsr, bit_width=bit_width, with_sign=True, lin_back=True)
 
     def forward(self, input):
+        lazy.note_inference_call(self, input)
         input = lazy.resolve(input)
         wq = self.weight_op.forward(self.weight) if self.training else self.weight
         if (input.is_cuda and input.dtype == torch.float32 and input.numel() > 0 and input.dim() == 4

@@ -75,6 +75,25 @@ def enabled() -> bool:
     return ENABLED and not getattr(_tls, "eager_depth", 0)
 
 
+_implicit = None
+
+
+def note_inference_call(layer, input) -> None:
+    """Tell utils/implicit.py that an eval-mode, no-autograd forward of a quantised layer on a device runs (the trigger of the
+    implicit hipGraphs: after the second such call the ROOT module of the call stack is wrapped).  Costs two attribute reads in
+    training mode."""
+    global _implicit
+    if layer.training or torch.is_grad_enabled():
+        return
+    w = layer.weight
+    if not w.is_cuda:
+        return
+    if _implicit is None:
+        from .utils import implicit as _mod
+        _implicit = _mod
+    _implicit.note(layer)
+
+
 @contextlib.contextmanager
 def eager():
     """Run the enclosed forwards module by module (no deferred activations); per thread, re-entrant."""
@@ -895,6 +914,7 @@ def _conv_can_defer(layer, input) -> bool:
 def conv_forward(layer, input, kind: str):
     """forward() of BinConv2d / TerConv2d: consumes a deferred activation as packed planes and, when it may, defers
     itself; everything else goes to the layer's ordinary path (``_forward_impl``)."""
+    note_inference_call(layer, input)
     if isinstance(input, LazyActivation):
         act = None
         n = input._qt
@@ -930,6 +950,7 @@ def _dorefa_can_defer(layer, input) -> bool:
 def dorefa_conv_forward(layer, input):
     """forward() of DorefaConv2d: a 1-bit-weight conv in eval mode whose input carries int8 codes (the tag nnDorefaQuant
     leaves on its result, a CodeActivation, or a deferred quantised chain) defers itself."""
+    note_inference_call(layer, input)
     if isinstance(input, LazyActivation):
         n = input._qt
         act = None
@@ -995,6 +1016,7 @@ def linear_forward(layer, input, kind: str):
     """forward() of LinearBin / LinearTer / LinearXNOR: a flattened, binarised deferred activation arrives as row planes in
     (h, w, c) order and meets the weight with its columns permuted to that order (cached per weight version).  In eval mode without
     autograd the result goes out as a "dense" deferred activation (DEFER_DENSE)."""
+    note_inference_call(layer, input)
     if isinstance(input, LazyActivation):
         n = input._qt
         if (n.signed and n.flat and not layer.training and _no_autograd(layer) and layer.weight.is_cuda

@@ -20,11 +20,14 @@ class GraphedModule(torch.nn.Module):
     previous pipeline stage) passes it back — ``g(g.static_input)`` — and the replay starts without the device-to-device copy
     (154 MB / 53 us for a 256 x 3 x 224 x 224 batch)."""
 
-    def __init__(self, module: torch.nn.Module, example_input: torch.Tensor, warmup: int = 3):
+    def __init__(self, module: torch.nn.Module, example_input: torch.Tensor, warmup: int = 3, call=None):
         super().__init__()
         if not example_input.is_cuda:
             raise TypeError("graph capture needs a device input")
         self.module = module
+        if call is not None:                        # (implicit graphs, utils/implicit.py: the root's ORIGINAL forward — calling the
+            object.__setattr__(self, "_call", call)  #  module itself would re-enter the wrapper installed on it)
+            module = call
         self._static_in = example_input.clone()
         self._stream = torch.cuda.Stream(device=example_input.device)
         self._graph = torch.cuda.CUDAGraph()
@@ -36,6 +39,9 @@ class GraphedModule(torch.nn.Module):
                 out = module(self._static_in)
                 # a module that ends in a quantised conv chain returns a deferred activation (lazy.py): its kernels
                 # have to be part of the graph, so it is turned into its value inside the captured region
+                #: the forward's own result was (or contained) a deferred activation: a root that hands such a result to a consumer
+                #: outside itself is not wrapped implicitly (utils/implicit.py) — the consumer would lose the fused hand-over
+                self.lazy_output = _contains_lazy(out)
                 self._static_out = tree_map_only(lazy.LazyActivation, lambda t: t.value(), out)
         torch.cuda.synchronize(example_input.device)
 
@@ -52,6 +58,16 @@ class GraphedModule(torch.nn.Module):
     def static_input(self) -> torch.Tensor:
         """The captured input buffer (write the next batch here and call ``self(self.static_input)``: no copy)."""
         return self._static_in
+
+
+def _contains_lazy(out) -> bool:
+    if isinstance(out, lazy.LazyActivation):
+        return True
+    if isinstance(out, (tuple, list)):
+        return any(_contains_lazy(o) for o in out)
+    if isinstance(out, dict):
+        return any(_contains_lazy(o) for o in out.values())
+    return False
 
 
 def graphed(module: torch.nn.Module, example_input: torch.Tensor, warmup: int = 3) -> GraphedModule:
@@ -71,9 +87,17 @@ class AutoGraphed(torch.nn.Module):
     a question) is remembered as such and stays eager.  The returned tensor is a copy of the captured output unless
     ``clone_output=False`` (then it is overwritten by the next call with the same signature)."""
 
-    def __init__(self, module: torch.nn.Module, capture_after: int = 1, max_graphs: int = 8, clone_output: bool = True):
+    def __init__(self, module: torch.nn.Module, capture_after: int = 1, max_graphs: int = 8, clone_output: bool = True, call=None,
+                 keep_if_faster: float = 0.0):
         super().__init__()
         self.module = module
+        # ``call``: what runs the eager forward (default: the module itself); ``keep_if_faster`` = f > 0: at capture time the replay
+        # and the eager forward are both timed (the capture synchronises anyway) and the graph is only kept when it needs less than
+        # f x the eager time — a device-bound forward gains nothing from a replay and its private memory pool is given back
+        object.__setattr__(self, "_call", call if call is not None else module)
+        self.keep_if_faster = float(keep_if_faster)
+        self.not_faster = 0
+        self.refuse_lazy_outputs = False
         self.capture_after, self.max_graphs, self.clone_output = int(capture_after), int(max_graphs), bool(clone_output)
         self._graphs, self._seen, self._state = {}, {}, None
         self.replays = self.eager_calls = 0
@@ -101,7 +125,7 @@ class AutoGraphed(torch.nn.Module):
               and not _any_training(self.module) and not torch.cuda.is_current_stream_capturing())
         if not ok:
             self.eager_calls += 1
-            return self.module(x)
+            return self._call(x)
         sig = self._state_sig()
         if sig != self._state:                          # weights / running statistics were written: the captured kernels
             self._graphs.clear()                        # baked the old packed planes in
@@ -114,9 +138,15 @@ class AutoGraphed(torch.nn.Module):
             self._seen[key] = n
             if n <= self.capture_after or len(self._graphs) >= self.max_graphs:
                 self.eager_calls += 1
-                return self.module(x)
+                return self._call(x)
             try:
-                g = GraphedModule(self.module, x, warmup=1)
+                g = GraphedModule(self.module, x, warmup=1, call=None if self._call is self.module else self._call)
+                if self.refuse_lazy_outputs and g.lazy_output:
+                    g = None
+                    self.capture_failures["deferred output"] = self.capture_failures.get("deferred output", 0) + 1
+                elif self.keep_if_faster > 0.0 and not self._replay_pays(g, x):
+                    g = None
+                    self.not_faster += 1
             except Exception as exc:                    # e.g. a host synchronisation inside the forward: stay eager for this signature,
                 torch.cuda.synchronize(x.device)        # and say so (capture_failures; bench.py prints it)
                 if self.strict:
@@ -128,10 +158,32 @@ class AutoGraphed(torch.nn.Module):
             self._state = self._state_sig()             # the warm-up forwards may have built caches, never written parameters
         if g is None:
             self.eager_calls += 1
-            return self.module(x)
+            return self._call(x)
         self.replays += 1
         out = g(x)
         return tree_map_only(torch.Tensor, torch.clone, out) if self.clone_output else out
+
+
+def _replay_pays(self, g, x, n: int = 3) -> bool:
+    """Wall time of n replays against n eager forwards, each bracketed by a device synchronise (capture time only)."""
+    import time
+    dev = x.device
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        t_replay = timed(lambda: g(x))
+        t_eager = timed(lambda: tree_map_only(lazy.LazyActivation, lambda t: t.value(), self._call(x)))
+    return t_replay < self.keep_if_faster * t_eager
+
+
+AutoGraphed._replay_pays = _replay_pays
 
 
 def _any_training(module: torch.nn.Module) -> bool:

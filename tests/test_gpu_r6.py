@@ -54,3 +54,133 @@ def test_alexnet_conv_layers_reproduce_the_reference_digest_at_batch_256(dev, na
     a = np.ascontiguousarray(y.detach().float().contiguous().cpu().numpy(), dtype=np.float32)
     assert a.shape == (B, Cout, H, H)
     assert hashlib.sha256(a.tobytes()).hexdigest() == c["sha256_f32_nchw"], (float(a.astype(np.float64).sum()), c["sum"])
+
+
+# ---- implicit hipGraphs (utils/implicit.py): the un-modified eval-mode model replays by itself after the second identical call --------
+
+def _c4_model(dev, seed=4):
+    import bench_models
+    torch.manual_seed(seed)
+    m = bench_models.DorefaResNet18(w_bits=1, a_bits=4)
+    bench_models.randomize_bn(m, seed=3)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_var.mul_(4.0)
+    return m.to(dev).to(memory_format=torch.channels_last).eval()
+
+
+def test_implicit_graph_replays_the_unmodified_c4_model_after_the_second_call(dev):
+    """No wrapper: model(x) under no_grad, three times — calls 1 and 2 are eager, the root then carries an instance-level forward and
+    call 3 onwards are hipGraph replays with the eager logits bit for bit; weight updates, a new input shape, training mode and
+    autograd all do what the eager model does."""
+    from pytorch_quantize_impls_amd import utils
+    with utils.implicit_graphs(True):
+        m = _c4_model(dev)
+        x = torch.randn(32, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad(), utils.implicit_graphs(False):
+            want = m(x).clone()
+        assert "forward" not in m.__dict__
+        with torch.no_grad():
+            y1 = m(x)
+            assert "forward" not in m.__dict__
+            y2 = m(x)
+            assert utils.implicit_graph_stats(m)["wrapped"], utils.implicit_graph_stats(m)
+            y3 = m(x)
+            y4 = m(x)
+        st = utils.implicit_graph_stats(m)
+        assert st["replays"] >= 2 and st["value_mismatch"] == 0 and not st["capture_failures"], st
+        for y in (y1, y2, y3, y4):
+            assert torch.equal(y, want)
+        assert y3.data_ptr() != y4.data_ptr()                                 # results are copies, not the captured buffer
+        # another input, same signature: the replay follows the data
+        x2 = torch.randn_like(x)
+        with torch.no_grad():
+            got2 = m(x2)
+            with utils.implicit_graphs(False):
+                want2 = m(x2)
+        assert torch.equal(got2, want2) and not torch.equal(got2, want)
+        # a weight update drops the graphs (version counters); the next calls are eager on the new weights, then captured again
+        with torch.no_grad():
+            m.blocks[0].conv1.weight.mul_(-1.0)
+            before = utils.implicit_graph_stats(m)["replays"]
+            got3 = m(x)
+            with utils.implicit_graphs(False):
+                want3 = m(x)
+            assert torch.equal(got3, want3) and not torch.equal(got3, want)
+            for _ in range(3):
+                assert torch.equal(m(x), want3)
+        assert utils.implicit_graph_stats(m)["replays"] > before
+        # a new shape is a new signature; training mode / autograd are never replayed
+        xs = x[:8].contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            with utils.implicit_graphs(False):
+                want_s = m(xs)
+            for _ in range(3):
+                assert torch.equal(m(xs), want_s)
+        r = utils.implicit_graph_stats(m)["replays"]
+        y = m(x)                                                             # autograd on: eager, with a graph to differentiate
+        assert y.requires_grad and utils.implicit_graph_stats(m)["replays"] == r
+        m.train()
+        with torch.no_grad():
+            m(x)
+        assert utils.implicit_graph_stats(m)["replays"] == r
+        # module by module on request
+        m.eval()
+        from pytorch_quantize_impls_amd import lazy, _lib
+        with torch.no_grad(), lazy.eager():
+            c0 = _lib.call_counts["qt_conv2d_implicit"]
+            m(x)
+            assert _lib.call_counts["qt_conv2d_implicit"] > c0 and utils.implicit_graph_stats(m)["replays"] == r
+
+
+def test_implicit_graph_leaves_instrumented_and_opted_out_models_alone(dev):
+    import copy
+    from pytorch_quantize_impls_amd import utils
+    with utils.implicit_graphs(True):
+        m = _c4_model(dev)
+        x = torch.randn(8, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+        seen = []
+        h = m.blocks[3].register_forward_hook(lambda mod, i, o: seen.append(1))
+        with torch.no_grad():
+            for _ in range(4):
+                m(x)
+        assert len(seen) == 4 and "forward" not in m.__dict__              # the hook saw every call
+        h.remove()
+        with torch.no_grad():
+            for _ in range(6):
+                y = m(x)
+        assert utils.implicit_graph_stats(m)["wrapped"] and utils.implicit_graph_stats(m)["replays"] >= 1
+        # a deep copy carries an empty wrapper bound to the COPY: its own weights decide its result
+        m2 = copy.deepcopy(m)
+        with torch.no_grad():
+            m2.linear.weight.mul_(2.0)
+            m2.linear.bias.zero_()
+            m.linear.bias.zero_()
+            a, b = m(x), m2(x)
+        assert torch.allclose(b, 2.0 * a)
+        utils.implicit_graphs_off(m)
+        assert "forward" not in m.__dict__
+        with torch.no_grad():
+            for _ in range(4):
+                m(x)
+        assert "forward" not in m.__dict__ and utils.implicit_graph_stats(m)["opted_out"]
+
+
+def test_implicit_graph_keeps_a_device_bound_forward_eager(dev):
+    """BinaryNet-AlexNet at batch 256 is device-bound (0.8 ms of kernels in 16 launches): the replay is timed against the eager
+    forward at capture time and not kept."""
+    import bench_models
+    from pytorch_quantize_impls_amd import utils
+    with utils.implicit_graphs(True):
+        torch.manual_seed(1)
+        m = bench_models.AlexNetBin()
+        bench_models.randomize_bn(m)
+        m = m.to(dev).to(memory_format=torch.channels_last).eval()
+        x = torch.randn(256, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            ys = [m(x) for _ in range(5)]
+        st = utils.implicit_graph_stats(m)
+        assert st["wrapped"] and st["value_mismatch"] == 0, st
+        assert all(torch.equal(ys[0], y) for y in ys)
+        # either verdict is legitimate on a given box; what must hold: a kept graph was measurably faster, a dropped one costs nothing
+        assert st["graphs"] + st["not_faster"] >= 1, st
