@@ -505,7 +505,8 @@ def compact_line(result, detail_paths=()):
         c4 = ex.get("c4_dorefa_resnet18_w1a4", {})
         if c4:
             e["c4"] = {leg: _pick(c4[leg], "images_per_s", "ms_per_forward") | _pick(c4[leg].get("roofline", {}), "frac_of_matrix_peak")
-                       for leg in ("module_graph", "module_graph_hipgraph", "fused", "fused_hipgraph") if isinstance(c4.get(leg), dict)}
+                       for leg in ("module_graph", "module_graph_eager", "module_graph_hipgraph", "fused", "fused_hipgraph") if isinstance(c4.get(leg), dict)}
+            e["c4"]["module_graph"]["implicit_hipgraph_replays"] = c4.get("module_graph", {}).get("implicit_hipgraph", {}).get("replays")
         c5 = ex.get("c5_ternary_vgg16", {})
         if c5:
             e["c5"] = {leg: _pick(c5[leg], "images_per_s", "ms_per_forward") | _pick(c5[leg].get("roofline", {}), "frac_of_matrix_peak")
@@ -1125,7 +1126,15 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             agree_d = float((deferred4().argmax(1) == ye4.argmax(1)).float().mean())
             same_default = bool(torch.equal(m4(x4), ye4))
         el_u = timed(eager4)
+        # the un-modified model, called the way a user calls it: since round 6 such a model replays its forward as a hipGraph by
+        # itself from the third identical call on (utils/implicit.py, opt-out); "module_graph_eager" = the same with that switched off
+        from pytorch_quantize_impls_amd import utils
+        with utils.implicit_graphs(False):
+            el_d_eager = timed(deferred4, 2 * iters)
         el_d = timed(deferred4, 2 * iters)
+        implicit4 = utils.implicit_graph_stats(m4)
+        with torch.no_grad():
+            same_implicit = bool(torch.equal(deferred4(), ye4))
         el_f = timed(lambda: f4(x4), 2 * iters)
         # the deferred forward is ~1.7 ms of Python for < 1 ms of GPU work: replayed as a hipGraph (utils.graphed captures
         # the un-modified module; same kernels, no host work)
@@ -1157,9 +1166,13 @@ def bench_extras(args, dev, dist, world, rank, x, w):
             "module_graph": _net_line("c4", Bc, world, 2 * iters, el_d, st4, 5000.0,
                                       "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                       {"argmax_agreement_with_unfused": agree_d,
-                                       "same_logits_as_module_by_module": same_default,
+                                       "same_logits_as_module_by_module": same_default and same_implicit,
+                                       "implicit_hipgraph": implicit4,
                                        "bn_arithmetic": "this device's eval-mode F.batch_norm, emulated and verified "
                                                         "(layers.fused.device_bn_fold)"}),
+            "module_graph_eager": _net_line("c4", Bc, world, 2 * iters, el_d_eager, st4, 5000.0,
+                                            "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
+                                            {"what": "utils.implicit_graphs(False): every forward dispatched from Python (rounds 1-5's module_graph)"}),
             "module_graph_hipgraph": _net_line("c4", Bc, world, 2 * iters, el_g, st4, 5000.0,
                                                "int8 MFMA ~5 POP/s dense (guide); u-bench 4.54",
                                                {"same_logits_as_module_graph": same_g}),

@@ -150,8 +150,10 @@ class _ImplicitForward:
         try:
             x = args[0]
             eng = self.engine
-            before = eng.replays
+            before, state_before = eng.replays, eng._state
             out = eng(x)
+            if eng._state is not state_before:
+                self._checked.clear()                               # graphs were dropped and / or a new one captured: check again
             if eng.replays != before:
                 key = (tuple(x.shape), x.dtype, tuple(x.stride()), x.device)
                 if key not in self._checked:
@@ -162,8 +164,6 @@ class _ImplicitForward:
                         self.value_mismatch += 1
                         eng._graphs[key] = None                     # this signature stays eager
                         return ref
-            elif not eng._graphs:
-                self._checked.clear()                               # the graphs were dropped (a parameter was written)
             return out
         finally:
             self.busy.release()
