@@ -95,6 +95,13 @@ int qt_ste_mask_f32(const float* gout, const float* x, float* gin, int64_t n, fl
  * fp16 plane, a remembered +-1 verdict that no longer holds) into a bias or a gradient without a host synchronisation — a broken
  * assumption yields NaN, never a plausible wrong number. */
 int qt_poison_f32(const float* x, const int32_t* flag, int32_t mask, float* out, int64_t n, qt_stream_t stream);
+/* The base-256 digits of a k-bit DoReFa image whose un-clamped codes left int8 (functions/dorefa_connect.py:11-25): q = rint(x *
+ * levels), hi = floor(q / 256), lo = q - 256 hi over n values in storage order; *flag |= bit when |hi| >= 256 (a digit no longer
+ * exact in bf16).  And the recombination of the two weight-gradient passes: out = (g_hi * 256 + g_lo) * inv, NaN when *flag & mask
+ * (flag may be NULL).  Round 6: one launch each instead of 6 + 5 + 4 torch launches per strided shortcut conv and step. */
+int qt_code_digits_f32(const float* x, int64_t n, float levels, float* hi, float* lo, int32_t* flag, int32_t bit, qt_stream_t stream);
+int qt_digit_combine_f32(const float* g_hi, const float* g_lo, const int32_t* flag, int32_t mask, float inv, float* out, int64_t n,
+                         qt_stream_t stream);
 
 /* DoReFa k-bit quantiser: k==1 -> safeSign; k==32 -> copy; else
  * y = fl(fl(1/n) * rint(n*x)), n = 2^k - 1, round-half-even, NO clamp.
@@ -551,6 +558,19 @@ int qt_f16x2_absmax_scale_ch_f32(const float* g, int64_t stride_n, int64_t strid
                                  int64_t C, int64_t H, int64_t W, int64_t Cp, uint32_t* work, float* scale2c, qt_stream_t stream);
 int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream);
 int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* work, float* scale2, qt_stream_t stream);
+/* qt_f16x2_absmax_scale_f32 + qt_f16x2_pack_f32(mode 0) of a DENSE [rows, K] fp32 matrix in TWO launches instead of three (round 6,
+ * the training step's launch diet — functions/binary_connect.py:104-112's backward GEMMs split their gradient operand here): the
+ * pack's workgroups fold the partial maxima themselves.  scale3 = [s, 1 / s, s * (*mul_dev)] (mul_dev NULL: s): the third slot
+ * is the scale_dev of the consuming qt_f16_gemm / qt_conv2d_implicit* when the contraction carries another device scalar (DoReFa's
+ * E = mean|W|, functions/dorefa_connect.py:100) — s is a power of two, so the product is exact.  work as above. */
+/* E = mean|x| of n dense fp32 values as a device scalar, ONE launch (DoReFa's 1-bit weight scale, functions/dorefa_connect.py:100;
+ * torch: abs + mean [+ fill]).  Deterministic: partial sums are added in index order by the last workgroup to arrive.  `work`:
+ * qt_abs_mean_work_words() uint32, 8-byte aligned, ZERO on first use — the kernel leaves it zero again, so one buffer serves every
+ * later call that is ordered behind this one on the same stream (calls on different streams need different buffers). */
+int64_t qt_abs_mean_work_words(void);
+int qt_abs_mean_f32(const float* x, int64_t n, uint32_t* work, float* out, qt_stream_t stream);
+int qt_f16x2_absmax_pack_f32(const float* x, int64_t rows, int64_t K, uint32_t* work, const float* mul_dev, float* scale3, uint16_t* out,
+                             int64_t ld_bytes, qt_stream_t stream);
 int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes, int64_t rows,
                       int64_t K, int mode, qt_stream_t stream);
 int qt_f16x2_s2d_pack_f32(const float* x, int64_t sN, int64_t sC, int64_t sH, int64_t sW, const float* scale2, uint16_t* out,
@@ -609,7 +629,8 @@ int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p_or_x, cons
  *                                  else g; dgamma = sum g_t xhat, dbeta = sum g_t, gx = gamma invstd (g_t - dbeta / R -
  *                                  xhat dgamma / R), gres (optional) = g_t.  partial: qt_train_chain_partial_floats(R, C) floats. */
 int qt_bn_train_stats_f32(const float* x, int64_t R, int64_t C, float eps, float momentum, float* running_mean,
-                          float* running_var, float* stats2, float* partial, qt_stream_t stream);
+                          float* running_var, float* stats2, float* partial, int32_t* zero_flag /* NULL, or a word set to 0: the range
+                          flag of the quantiser pass that follows (no fill launch) */, qt_stream_t stream);
 int qt_bn_act_train_backward_f32(const float* g, const float* x, const float* res, int64_t R, int64_t C, const float* gamma,
                                  const float* beta, const float* stats2, int relu, float* partial, float* dgamma, float* dbeta,
                                  float* gx, float* gres, qt_stream_t stream);

@@ -120,6 +120,11 @@ SIGNATURES = {
     "qt_f16x2_scale_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p]),
     "qt_f16x2_absmax_work_words": (_c_i64, []),
     "qt_f16x2_absmax_scale_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "qt_code_digits_f32": (_c_int, [_c_p, _c_i64, _c_f32, _c_p, _c_p, _c_p, _c_int, _c_p]),
+    "qt_digit_combine_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_f32, _c_p, _c_i64, _c_p]),
+    "qt_abs_mean_work_words": (_c_i64, []),
+    "qt_abs_mean_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "qt_f16x2_absmax_pack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "qt_f16x2_absmax_ch_work_words": (_c_i64, [_c_i64]),
     "qt_f16x2_absmax_scale_ch_f32": (_c_int, [_c_p] + [_c_i64] * 9 + [_c_p, _c_p, _c_p]),
     "qt_f16x2_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_p]),
@@ -130,7 +135,7 @@ SIGNATURES = {
                                    + [_c_p]),
     "qt_f16_gemm": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_f32, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "qt_train_chain_partial_floats": (_c_i64, [_c_i64, _c_i64]),
-    "qt_bn_train_stats_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_f32, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "qt_bn_train_stats_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_f32, _c_f32, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "qt_bn_act_train_backward_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_int] + [_c_p] * 6),
     "qt_pool_bn_sign_train_f32": (_c_int, [_c_p] + [_c_i64] * 6 + [_c_p, _c_p, _c_f32, _c_f32, _c_f32, _c_f32] + [_c_p] * 9),
     "qt_pool_bn_sign_train_backward_f32": (_c_int, [_c_p, _c_p, _c_p] + [_c_i64] * 6 + [_c_p] * 4 + [_c_f32] * 3 + [_c_p] * 6),

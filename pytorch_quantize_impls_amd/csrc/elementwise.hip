@@ -145,9 +145,52 @@ __global__ __launch_bounds__(256) void poison_kernel(const float* __restrict__ x
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = bad ? __builtin_nanf("") : (x ? x[i] : 0.0f);
 }
+// Base-256 digits of the integer codes of a k-bit DoReFa image x = q / n whose codes left int8 (functions/dorefa_connect.py:11-25 has
+// no clamp): q = rint(x * levels), hi = floor(q / 256), lo = q - 256 hi, both exact in bf16 while |q| < 2^16 — beyond that *flag |= bit.
+// One pass instead of six torch launches (+ five for the range test) in front of the two digit passes of the weight gradient.
+__global__ __launch_bounds__(256) void code_digits_kernel(const float* __restrict__ x, int64_t n, float levels, float* __restrict__ hi,
+                                                          float* __restrict__ lo, int32_t* __restrict__ flag, int32_t bit) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float q = rintf(x[i] * levels);
+        const float h = floorf(q * (1.0f / 256.0f));
+        hi[i] = h;
+        lo[i] = q - h * 256.0f;
+        bad |= !(fabsf(h) < 256.0f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+
+// out = fl(fl(fl(g_hi * 256) + g_lo) * inv), NaN when (*flag & mask) != 0: the two digit passes put together
+__global__ __launch_bounds__(256) void digit_combine_kernel(const float* __restrict__ ghi, const float* __restrict__ glo,
+                                                            const int32_t* __restrict__ flag, int32_t mask, float inv,
+                                                            float* __restrict__ out, int64_t n) {
+    const bool bad = flag && (*flag & mask) != 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = (ghi[i] * 256.0f + glo[i]) * inv;
+        out[i] = bad ? __builtin_nanf("") : v;
+    }
+}
 }  // namespace
 
 extern "C" {
+
+int qt_code_digits_f32(const float* x, int64_t n, float levels, float* hi, float* lo, int32_t* flag, int32_t bit, qt_stream_t stream) {
+    if (n < 0 || !flag || (n > 0 && (!x || !hi || !lo))) return QT_ERR_INVALID_ARG;
+    if (n == 0) return QT_OK;
+    hipLaunchKernelGGL(code_digits_kernel, dim3(qt_stream_grid((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, levels, hi, lo,
+                       flag, bit);
+    return qt_check_launch();
+}
+
+int qt_digit_combine_f32(const float* ghi, const float* glo, const int32_t* flag, int32_t mask, float inv, float* out, int64_t n,
+                         qt_stream_t stream) {
+    if (n < 0 || (n > 0 && (!ghi || !glo || !out))) return QT_ERR_INVALID_ARG;
+    if (n == 0) return QT_OK;
+    hipLaunchKernelGGL(digit_combine_kernel, dim3(qt_stream_grid((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ghi, glo, flag, mask,
+                       inv, out, n);
+    return qt_check_launch();
+}
 
 int qt_binarize_f32(const float* x, float* y, int64_t n, qt_stream_t stream) {
     return launch_unary(x, y, n, stream, OpBinarize{});

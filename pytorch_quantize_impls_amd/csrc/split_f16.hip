@@ -250,6 +250,43 @@ __global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ x, 
     }
 }
 
+// The activation split with the scale's fold inside (round 6: training-step launch diet).  Every workgroup folds the <= 2048
+// partial maxima of absmax_part_kernel itself (8 KB from L2, the same value in every workgroup: max is order-free) instead of a
+// one-workgroup launch in front of it; workgroup 0 leaves scale3 = [s, 1 / s, s * (*mul_dev or 1)] behind for the consumer — the
+// third slot is the GEMM's device scale when the contraction is multiplied by another device scalar anyway (DoReFa's E = mean|W|:
+// s is a power of two, so s * E is E with another exponent — exact), which used to be a torch launch of its own.
+__global__ __launch_bounds__(256) void pair_fold_kernel(const float* __restrict__ x, int64_t ldx, const unsigned* __restrict__ part,
+                                                        int nparts, const float* __restrict__ mul_dev, float* __restrict__ scale3,
+                                                        uint32_t* __restrict__ out, int64_t ld_words, int64_t rows, int64_t K) {
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = max(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float pair[2];
+    write_scale(__uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3]))), pair);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale3[0] = pair[0];
+        scale3[1] = pair[1];
+        scale3[2] = mul_dev ? pair[0] * *mul_dev : pair[0];
+    }
+    const float inv = pair[1];
+    const int64_t quads = ld_words / 4;
+    const int64_t total = rows * quads;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / quads, q = t - row * quads;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t k = q * 4 + e;
+            if (k < K) w[e] = split2(x[row * ldx + k] * inv);
+        }
+        reinterpret_cast<uint4*>(out + row * ld_words)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Space-to-depth gather + split (see split_bf16.hip: s2d_triple_kernel / s2d_triple_rows_kernel for the geometry):
 // pixel (n, Y, X) of the output plane holds, for e = (c*s + dy)*s + dx, the pair of x[n, c, s*Y + dy - ph, s*X + dx - pw] / scale.
 __global__ __launch_bounds__(256) void s2d_pair_kernel(const float* __restrict__ x, int64_t sN, int64_t sC, int64_t sH,
@@ -411,6 +448,21 @@ extern "C" int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* wo
     const int grid = qt_stream_grid(((n >> 2) + 255) / 256 + 1, 2048);
     hipLaunchKernelGGL(absmax_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, work);
     hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, work, grid, scale2);
+    return qt_check_launch();
+}
+
+extern "C" int qt_f16x2_absmax_pack_f32(const float* x, int64_t rows, int64_t K, uint32_t* work, const float* mul_dev, float* scale3,
+                                        uint16_t* out, int64_t ld_bytes, qt_stream_t stream) {
+    if (rows < 0 || K < 0 || !work || !scale3) return QT_ERR_INVALID_ARG;
+    if (rows > 0 && K > 0 && (!x || !out)) return QT_ERR_INVALID_ARG;
+    if (!qt_aligned16(x) || ld_bytes < 4 * K || (ld_bytes & 15) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
+    const int64_t n = rows * K;
+    const int gridp = qt_stream_grid(((n >> 2) + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(gridp), dim3(256), 0, (hipStream_t)stream, x, n, work);
+    const int64_t ld_words = ld_bytes / 4;
+    const int grid = qt_stream_grid((rows * (ld_words / 4) + 255) / 256 + 1);
+    hipLaunchKernelGGL(pair_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, K, work, gridp, mul_dev, scale3,
+                       reinterpret_cast<uint32_t*>(out), ld_words, rows, K);
     return qt_check_launch();
 }
 

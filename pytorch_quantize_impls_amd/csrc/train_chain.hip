@@ -148,9 +148,12 @@ __global__ __launch_bounds__(1024) void fold2_kernel(const float* __restrict__ p
 // var partials -> invstd, running statistics
 __global__ __launch_bounds__(1024) void finalize_kernel(const float* __restrict__ part, int nblk, int C, double R, float eps,
                                                         float momentum, const float* __restrict__ mean, float* __restrict__ invstd,
-                                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        int32_t* __restrict__ zero_flag) {
     __shared__ double sh[TC_FY][64];
     const int c = blockIdx.x * 64 + threadIdx.x;
+    // (the chain's int8 range flag starts at zero here: the quantiser pass behind this launch ORs into it — no fill launch)
+    if (zero_flag && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *zero_flag = 0;
     const double s = fold_partials(part, nblk, C, c, sh);
     if (threadIdx.y != 0 || c >= C) return;
     const float var = (float)(s / R);
@@ -385,7 +388,7 @@ extern "C" int qt_pool_bn_sign_train_f32(const float* x, int64_t N, int64_t H, i
     hipLaunchKernelGGL(fold_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, 1.0 / (double)R, mean);
     hipLaunchKernelGGL(sqdev_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, pp, mean, partial, R, (int)C, rpb);
     hipLaunchKernelGGL(finalize_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, (double)R, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+                       running_mean, running_var, (int32_t*)nullptr);
     hipLaunchKernelGGL(norm_sign_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, pp, mean, invstd, gamma, beta, ht_lo, ht_hi, sgn, R,
                        (int)C, rpb);
     return qt_check_launch();
@@ -426,7 +429,7 @@ extern "C" int qt_pool_bn_sign_train_backward_f32(const float* g, const float* p
 // two passes, partials folded in double) and the running-statistics update of nn.BatchNorm2d.train().  stats2 = [mean | invstd]
 // (the layout the code epilogue's bn_stats takes).
 extern "C" int qt_bn_train_stats_f32(const float* x, int64_t R, int64_t C, float eps, float momentum, float* running_mean,
-                                     float* running_var, float* stats2, float* partial, qt_stream_t stream) {
+                                     float* running_var, float* stats2, float* partial, int32_t* zero_flag, qt_stream_t stream) {
     if (R <= 0 || C <= 0 || !x || !stats2 || !partial) return QT_ERR_INVALID_ARG;
     if (R * C >= (1ll << 40) || C > (1 << 24)) return QT_ERR_UNSUPPORTED;
     if ((C & 3) || !qt_aligned16(x)) return QT_ERR_ALIGNMENT;
@@ -441,7 +444,7 @@ extern "C" int qt_bn_train_stats_f32(const float* x, int64_t R, int64_t C, float
     hipLaunchKernelGGL(fold_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, 1.0 / (double)R, mean);
     hipLaunchKernelGGL(sqdev_kernel, dim3(nblk), dim3(TC_TX, TC_TY), 0, st, x, mean, partial, R, (int)C, rpb);
     hipLaunchKernelGGL(finalize_kernel, dim3(cg), dim3(64, TC_FY), 0, st, partial, nblk, (int)C, (double)R, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+                       running_mean, running_var, zero_flag);
     return qt_check_launch();
 }
 

@@ -81,11 +81,31 @@ __device__ __forceinline__ void pm_item(int item, int c8, int Wq, bool channel_f
     }
 }
 
+// The rows past the packed ones (the K-slice rounding of the gradient planes, the look-ahead rows of the activation plane) are
+// zeroed by PM_TAIL_BLOCKS workgroups appended to the pack launch (round 6: they used to be a launch of their own per plane).
+constexpr int PM_TAIL_BLOCKS = 32;
+struct PmTail {
+    uint16_t* base;        // first tail element of plane 0
+    long long plane;       // elements between the planes' tails
+    long long n16;         // 16-byte items per tail
+    int planes, rows;      // blocks [rows, rows + PM_TAIL_BLOCKS) of the grid do the zeroing
+};
+__device__ __forceinline__ bool pm_tail_zero(const PmTail& t) {
+    if ((int)blockIdx.x < t.rows) return false;
+    const long long b = (long long)blockIdx.x - t.rows;
+    for (int pl = 0; pl < t.planes; ++pl) {
+        uint4* p = reinterpret_cast<uint4*>(t.base + pl * t.plane);
+        for (long long i = b * 256 + threadIdx.x; i < t.n16; i += (long long)PM_TAIL_BLOCKS * 256) p[i] = make_uint4(0, 0, 0, 0);
+    }
+    return true;
+}
+
 // G3[t][q][Cp]: exact bf16 split of g at position q = (y * N + n) * Wq + x (zero where x >= Wo and for channels >= Cout)
 template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restrict__ g, int64_t sn, int64_t sc, int64_t sh_,
                                                            int64_t sw, int N, int Cout, int Wo, int Wq, int Cp, int64_t Qa,
-                                                           uint16_t* __restrict__ G3, const float* __restrict__ scale2) {
+                                                           uint16_t* __restrict__ G3, const float* __restrict__ scale2, PmTail tail) {
+    if (pm_tail_zero(tail)) return;
     const float* inv = NP == 2 ? scale2 + Cp : nullptr;               // 1 / s[c], per channel (split_f16.hip)
     const int c8 = Cp >> 3, items = Wq * c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
@@ -133,7 +153,9 @@ __global__ __launch_bounds__(256) void pm_pack_grad_kernel(const float* __restri
 template <int NP>
 __global__ __launch_bounds__(256) void pm_pack_grad_bias_kernel(const float* __restrict__ g, int64_t sn, int64_t sh_, int64_t sw, int N,
                                                                 int Cout, int Wo, int Wq, int Cp, int64_t Qa, uint16_t* __restrict__ G3,
-                                                                float* __restrict__ bias_part, const float* __restrict__ scale2) {
+                                                                float* __restrict__ bias_part, const float* __restrict__ scale2,
+                                                                PmTail tail) {
+    if (pm_tail_zero(tail)) return;                          // (uniform per workgroup: taken before any barrier)
     __shared__ float red[2048];                              // [xpar][Cp] partial sums, xpar * Cp <= 256 * 8
     const int c8 = Cp >> 3, xpar = 256 / c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
@@ -213,7 +235,8 @@ __global__ __launch_bounds__(256) void pm_bias_reduce_kernel(const float* __rest
 template <bool F16>
 __global__ __launch_bounds__(256) void pm_pack_act_kernel(const float* __restrict__ xin, int64_t sn, int64_t sc, int64_t sh_,
                                                           int64_t sw, int N, int Cin, int H, int W, int ph, int pw, int Wq,
-                                                          int Cp, float x_scale, uint16_t* __restrict__ XP) {
+                                                          int Cp, float x_scale, uint16_t* __restrict__ XP, PmTail tail) {
+    if (pm_tail_zero(tail)) return;
     const int c8 = Cp >> 3, items = Wq * c8;
     const int y = blockIdx.x / N, n = blockIdx.x - y * N;
     const int yy = y - ph;
@@ -789,37 +812,49 @@ __global__ __launch_bounds__(512) void wgrad_pm_full_kernel(PmArgs a) {
     }
 }
 
-// one work item = one (co, ci) with all its taps: sums the K slices (reads coalesced along ci), applies the scales and the STE
-// mask, writes / accumulates the T consecutive values dW[co][ci][0..T) (one (co, ci, tap) per thread scattered 4-byte writes
-// 4 T bytes apart: 37 us for a 512 x 512 x 9 layer, twice what the bytes need)
+// One workgroup = one (co, 64-wide ci chunk, tap): its four waves take every fourth K slice (reads coalesced along ci, four
+// independent loads in flight per lane), meet in LDS in a fixed order, then the scales and the STE mask are applied and
+// dW[co][ci][tap] is written / accumulated.  (Round 6: the first form gave one THREAD a (co, ci) with all taps and let it walk the
+// slices alone — 64 x 64 channels were 16 workgroups chasing 256 x 9 dependent loads each: 37 us whatever the layer, as much as the
+// gradient kernel itself on the 32 x 32 maps.)  The sum of a (co, ci, tap) is the same expression for every launch geometry.
 template <int T, int KW>
 __global__ __launch_bounds__(256) void pm_reduce_kernel(const float* __restrict__ part, int nslice, int Cpo, int Cpi,
                                                         int Cout, int Cin, const float* __restrict__ weight, float thr,
                                                         float out_scale, const float* __restrict__ row_scale, int accumulate,
                                                         float* __restrict__ dW, int64_t so, int64_t si, int64_t sh, int64_t sw) {
-    const int64_t total = (int64_t)Cout * Cin;
+    __shared__ float fold[4][64];
+    const int nchunk = (Cin + 63) >> 6;
+    const int64_t total = (int64_t)Cout * nchunk * T;
     const int64_t tap_elems = (int64_t)Cpo * Cpi, slice_elems = (int64_t)T * tap_elems;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(t % Cin), co = (int)(t / Cin);
-        const float* p = part + (int64_t)co * Cpi + ci;
-        float acc[T];
-#pragma unroll
-        for (int tap = 0; tap < T; ++tap) acc[tap] = 0.0f;
-        for (int sl = 0; sl < nslice; ++sl) {
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap) acc[tap] += p[sl * slice_elems + tap * tap_elems];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
+        const int tap = (int)(b % T);
+        const int64_t r = b / T;
+        const int chunk = (int)(r % nchunk), co = (int)(r / nchunk);
+        const int ci = chunk * 64 + lane;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        if (ci < Cin) {
+            const float* p = part + (int64_t)tap * tap_elems + (int64_t)co * Cpi + ci;
+            int sl = g;
+            for (; sl + 12 < nslice; sl += 16) {
+                a0 += p[(int64_t)sl * slice_elems];
+                a1 += p[(int64_t)(sl + 4) * slice_elems];
+                a2 += p[(int64_t)(sl + 8) * slice_elems];
+                a3 += p[(int64_t)(sl + 12) * slice_elems];
+            }
+            for (; sl < nslice; sl += 4) a0 += p[(int64_t)sl * slice_elems];
         }
-        const float rs = row_scale ? row_scale[co] : 1.0f;          // the two-plane gradient's per-channel power of two
-        // dW and the weight share ONE set of element strides (contiguous, or channels-last like the parameter of a channels_last model)
-        const int64_t base = co * so + ci * si;
-#pragma unroll
-        for (int tap = 0; tap < T; ++tap) {
-            const int64_t o = base + (tap / KW) * sh + (tap % KW) * sw;
-            float v = acc[tap] * out_scale;
-            if (row_scale) v *= rs;
+        fold[g][lane] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && ci < Cin) {
+            float v = ((fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane])) * out_scale;
+            if (row_scale) v *= row_scale[co];                      // the two-plane gradient's per-channel power of two
+            // dW and the weight share ONE set of element strides (contiguous, or channels-last like the parameter of a channels_last model)
+            const int64_t o = co * so + ci * si + (tap / KW) * sh + (tap % KW) * sw;
             if (weight && !(fabsf(weight[o]) <= thr)) v = 0.0f;
             dW[o] = accumulate ? dW[o] + v : v;
         }
+        __syncthreads();
     }
 }
 
@@ -851,27 +886,25 @@ static int pm_pack_grad_impl(int np, const float* g, int64_t stride_n, int64_t s
     if (Wq < Wo || Cp < Cout || (Cp & 63) || Qa < Ho * N * Wq || (Qa & 31) || !qt_aligned16(G)) return QT_ERR_ALIGNMENT;
     if (Ho * N >= (1ll << 31) || Wq * Cp >= (1ll << 28) || (bias_part && Cp > 2048)) return QT_ERR_UNSUPPORTED;
     if (bias_part && stride_c != 1) return QT_ERR_INVALID_ARG;
-    const dim3 grid((unsigned)(Ho * N));
+    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
+    PmTail tz{G + Ho * N * Wq * Cp, (long long)(Qa * Cp), (long long)tail, np, (int)(Ho * N)};
+    const dim3 grid((unsigned)(Ho * N + (tail > 0 ? PM_TAIL_BLOCKS : 0)));
     hipStream_t st = (hipStream_t)stream;
     if (bias_part) {
         if (np == 2)
             hipLaunchKernelGGL(pm_pack_grad_bias_kernel<2>, grid, dim3(256), 0, st, g, stride_n, stride_h, stride_w, (int)N, (int)Cout,
-                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2);
+                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2, tz);
         else
             hipLaunchKernelGGL(pm_pack_grad_bias_kernel<3>, grid, dim3(256), 0, st, g, stride_n, stride_h, stride_w, (int)N, (int)Cout,
-                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2);
+                               (int)Wo, (int)Wq, (int)Cp, Qa, G, bias_part, scale2, tz);
     } else {
         if (np == 2)
             hipLaunchKernelGGL(pm_pack_grad_kernel<2>, grid, dim3(256), 0, st, g, stride_n, stride_c, stride_h, stride_w, (int)N,
-                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2);
+                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2, tz);
         else
             hipLaunchKernelGGL(pm_pack_grad_kernel<3>, grid, dim3(256), 0, st, g, stride_n, stride_c, stride_h, stride_w, (int)N,
-                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2);
+                               (int)Cout, (int)Wo, (int)Wq, (int)Cp, Qa, G, scale2, tz);
     }
-    const int64_t tail = (Qa - Ho * N * Wq) * Cp * 2 / 16;
-    for (int t = 0; t < np && tail > 0; ++t)
-        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<uint4*>(G + ((int64_t)t * Qa + Ho * N * Wq) * Cp), tail);
     return qt_check_launch();
 }
 
@@ -920,16 +953,15 @@ static int pm_pack_act_impl(bool f16, const float* x, int64_t stride_n, int64_t 
     const int64_t rows = (H + 2 * ph) * N;
     if (Wq < W + 2 * pw || Cp < Cin || (Cp & 31) || Qx < rows * Wq || !qt_aligned16(XP)) return QT_ERR_ALIGNMENT;
     if (rows >= (1ll << 31) || Wq * Cp >= (1ll << 28)) return QT_ERR_UNSUPPORTED;
-    if (f16)
-        hipLaunchKernelGGL(pm_pack_act_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
-                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
-    else
-        hipLaunchKernelGGL(pm_pack_act_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
-                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP);
     const int64_t tail = (Qx - rows * Wq) * Cp * 2 / 16;
-    if (tail > 0)
-        hipLaunchKernelGGL(pm_zero_kernel, dim3(qt_stream_grid((tail + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<uint4*>(XP + rows * Wq * Cp), tail);
+    PmTail tz{XP + rows * Wq * Cp, 0ll, (long long)tail, 1, (int)rows};
+    const dim3 grid((unsigned)(rows + (tail > 0 ? PM_TAIL_BLOCKS : 0)));
+    if (f16)
+        hipLaunchKernelGGL(pm_pack_act_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
+                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP, tz);
+    else
+        hipLaunchKernelGGL(pm_pack_act_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, stride_n, stride_c,
+                           stride_h, stride_w, (int)N, (int)Cin, (int)H, (int)W, (int)ph, (int)pw, (int)Wq, (int)Cp, x_scale, XP, tz);
     return qt_check_launch();
 }
 
@@ -1026,7 +1058,7 @@ int qt_wgrad_pm_reduce_f32(const float* part, int64_t nslice, int64_t taps, int6
                            float* dW, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, qt_stream_t stream) {
     if (!part || !dW || nslice <= 0 || taps <= 0 || Cout <= 0 || Cin <= 0 || Cpo < Cout || Cpi < Cin) return QT_ERR_INVALID_ARG;
     if (taps != 9 && taps != 25) return QT_ERR_UNSUPPORTED;       // the kernels this reduce serves: 3 x 3 and 5 x 5
-    const dim3 grid(qt_stream_grid((Cout * Cin + 255) / 256));
+    const dim3 grid(qt_stream_grid(Cout * ((Cin + 63) / 64) * taps, 256 * 8));
     if (taps == 9)
         hipLaunchKernelGGL((pm_reduce_kernel<9, 3>), grid, dim3(256), 0, (hipStream_t)stream, part, (int)nslice, (int)Cpo, (int)Cpi,
                            (int)Cout, (int)Cin, weight, ste_threshold, out_scale, row_scale, accumulate, dW, stride_o, stride_i, stride_h,

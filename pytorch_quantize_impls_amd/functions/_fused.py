@@ -894,7 +894,7 @@ def _dorefa_w1_scale(weight: torch.Tensor, prequantized: bool) -> torch.Tensor:
     """E of the 1-bit DoReFa weight sign(W)*E as a device scalar.  Training: E = mean|W|
     (functions/dorefa_connect.py:100).  Eval: the weight already holds sign(W)*E, so |w| == E for
     every entry and amax recovers it exactly."""
-    return weight.detach().abs().amax() if prequantized else weight.detach().abs().mean()
+    return weight.detach().abs().amax() if prequantized else ops.abs_mean(weight)
 
 
 def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_codes=None, scale=None,
@@ -1137,7 +1137,7 @@ class DorefaW1LinearFn(QtFunction):
         big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
             sgn = quantize_weight_f32(weight, "binary")
-            E = weight.abs().mean()
+            E = ops.abs_mean(weight)
             if big:
                 grad_input = (ops.float_linear(g2.contiguous(), sgn.t().contiguous(), "sign") * E).view(input.shape)
             else:
@@ -1182,7 +1182,7 @@ class DorefaW1Conv2dFn(QtFunction):
         mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
                 and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
         if ctx.needs_input_grad[0]:
-            E = ctx.E if ctx.E is not None else weight.abs().mean()
+            E = ctx.E if ctx.E is not None else ops.abs_mean(weight)
             if mfma:     # g * (sign(W) E) = E * (g * sign(W)): the exact-split conv on the flipped +-1 weight, scaled after
                 grad_input = ops.conv2d_grad_input_q(input.shape, weight, go, stride, padding, dilation, kind="binary",
                                                      out_scale_dev=E)
@@ -1195,7 +1195,7 @@ class DorefaW1Conv2dFn(QtFunction):
             if mfma and ctx.x_levels is not None and ctx.x_levels <= 255:
                 # UNscaled and un-masked, as upstream (_ignore_factor_op, identity STE): functions/dorefa_connect.py:66-79
                 grad_weight = dorefa_conv_grad_weight(input, go, weight.shape[2:], stride, padding, dilation, ctx.x_levels,
-                                                      ctx.codes_fit, ctx.code_flag)
+                                                      ctx.codes_fit, ctx.code_flag, layout_like=weight)
             if grad_weight is None:
                 note_library_path(go, "conv grad_weight outside the matrix-core route")
                 grad_weight = torch.nn.grad.conv2d_weight(input, weight.shape, go, stride=stride, padding=padding,
@@ -1221,7 +1221,8 @@ def _act_levels(t: torch.Tensor, layout):
     return None
 
 
-def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels: float, codes_fit: bool, code_flag=None):
+def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels: float, codes_fit: bool, code_flag=None,
+                            layout_like=None):
     """grad wrt the (quantised) weight of a DoReFa conv whose activation is a k-bit image q / n (n = ``x_levels``): the
     integer codes q are exact in bf16 while |q| <= 256, so the contraction runs on the weight-gradient routes (pixel-major,
     K-major, strided) with the split gradient.  ``codes_fit`` False — the un-clamped quantiser left the int8 range
@@ -1229,16 +1230,18 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
       * pixel-major routes with the two-plane gradient: their activation plane is fp16, where |q| <= 2048 is still exact — one
         pass as before; ``code_flag`` (the quantiser's device flag, bit 1 = a code beyond +-2047) poisons the result with NaN
         instead of a host sync for a case that does not occur (an activation beyond 136 at 4 bits);
-      * otherwise q = 256 hi + lo with both digits exact in bf16, two passes, 256 GW(hi) + GW(lo), NaN from |q| >= 2^16.
-    No route for the shape: None, the caller uses the library."""
+      * otherwise q = 256 hi + lo with both digits exact in bf16 (ops.code_digits: one launch), two passes,
+        (256 GW(hi) + GW(lo)) / n (ops.digit_combine: one launch), NaN from |q| >= 2^16 through the device flag.
+    ``layout_like``: the parameter — the result takes its memory format where the route can write it (no re-layout copy when
+    autograd accumulates it).  No route for the shape: None, the caller uses the library."""
     def run(xt, levels):
         gw = None
         if ops.wgrad_pm_applicable(xt.shape, go.shape, ksz, stride, dilation):
-            gw = ops.conv2d_grad_weight_pm(xt, go, ksz, padding, x_levels=levels)
+            gw = ops.conv2d_grad_weight_pm(xt, go, ksz, padding, x_levels=levels, layout_like=layout_like)
         if gw is None and ops.wgrad_gemm_applicable(xt.shape, go.shape, ksz, stride, dilation):
             gw = ops.conv2d_grad_weight_gemm(xt, go, ksz, padding, x_levels=levels)
         if gw is None and ops.wgrad_strided_applicable(xt.shape, go.shape, ksz, stride, padding, dilation):
-            gw = ops.conv2d_grad_weight_strided(xt, go, ksz, stride, padding, x_levels=levels)
+            gw = ops.conv2d_grad_weight_strided(xt, go, ksz, stride, padding, x_levels=levels, layout_like=layout_like)
         return gw
 
     if codes_fit:
@@ -1246,24 +1249,26 @@ def dorefa_conv_grad_weight(input, go, ksz, stride, padding, dilation, x_levels:
     if code_flag is not None and ops.split_terms() == 2:
         gw = None
         if ops.wgrad_pm_applicable(input.shape, go.shape, ksz, stride, dilation):
-            gw = ops.conv2d_grad_weight_pm(input, go, ksz, padding, x_levels=x_levels, terms=2)
+            gw = ops.conv2d_grad_weight_pm(input, go, ksz, padding, x_levels=x_levels, terms=2, layout_like=layout_like)
         elif int(ksz[0]) > 1 and ops.wgrad_strided_applicable(input.shape, go.shape, ksz, stride, padding, dilation):
-            gw = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=x_levels)     # the pixel-major kernel too
+            gw = ops.conv2d_grad_weight_strided(input, go, ksz, stride, padding, x_levels=x_levels,
+                                                layout_like=layout_like)     # the pixel-major kernel too
         if gw is not None:
-            return ops.poison(gw, code_flag, 2) if code_flag.dtype == torch.int32 else \
-                gw + torch.where((code_flag.reshape(()) & 2) != 0, float("nan"), 0.0)
-    q = torch.round(input.detach() * float(x_levels))
-    hi = torch.floor(q * (1.0 / 256.0))
-    lo = q - hi * 256.0
+            if code_flag.dtype != torch.int32:
+                return gw + torch.where((code_flag.reshape(()) & 2) != 0, float("nan"), 0.0)
+            if ops._storage_dense(gw) and not gw.is_contiguous():
+                # keep the parameter's (channels-last) layout through the poison pass: it works in storage order
+                st = gw.permute(0, 2, 3, 1)
+                return ops.poison(st, code_flag, 2).permute(0, 3, 1, 2)
+            return ops.poison(gw, code_flag, 2)
+    hi, lo, dflag = ops.code_digits(input, float(x_levels), code_flag)
     g_hi = run(hi, 1.0)
     if g_hi is None:
         return None
     g_lo = run(lo, 1.0)
-    inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
-    # |q| >= 2^16 (an activation beyond 4369 at 4 bits): the high digit is not exact in bf16 any more — poison the result on
-    # the device (NaN, like the chain's int8 flag) instead of paying a host sync per layer for a case that does not occur
-    bad = torch.where(hi.abs().amax() >= 256.0, float("nan"), 0.0)
-    return (g_hi * 256.0 + g_lo) * inv + bad
+    # |q| >= 2^16 (an activation beyond 4369 at 4 bits): the high digit is not exact in bf16 any more — the result is poisoned on
+    # the device (NaN, like the chain's int8 flag) instead of a host sync per layer for a case that does not occur
+    return ops.digit_combine(g_hi, g_lo, ops._inv_f32(float(x_levels)), dflag)
 
 
 class DorefaWkConv2dFn(QtFunction):

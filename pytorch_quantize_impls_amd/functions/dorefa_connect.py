@@ -57,8 +57,8 @@ def _make_quant_function(bit_width):
             return _quantize(input, bit_width=bit_width)
 
         @staticmethod
-        def backward(ctx, grad_ouput):  # identity STE (dorefa_connect.py:43-44, 61-62)
-            return grad_ouput.clone()
+        def backward(ctx, grad_ouput):  # identity STE (dorefa_connect.py:43-44, 61-62); upstream's clone() is a copy nobody needs
+            return grad_ouput
 
     return _Quant
 
@@ -82,7 +82,8 @@ class _ignore_factor_op(QtFunction):
 
     @staticmethod
     def backward(ctx, grad_ouput):
-        var_grad = grad_ouput.clone() if ctx.needs_input_grad[0] else None
+        # identity STE: the gradient itself (a clone was one 67 MB copy per quantiser and step; autograd never writes into it)
+        var_grad = grad_ouput if ctx.needs_input_grad[0] else None
         return var_grad, None
 
 
@@ -95,7 +96,7 @@ class _QuantWeight(torch.nn.Module):
     def forward(self, x):
         if self.bit_width == 1:
             # sign(W) * mean|W| with the scalar detached (dorefa_connect.py:99-102)
-            E = torch.mean(torch.abs(x)).detach()
+            E = ops.abs_mean(x)
             return _ignore_factor_op.apply(self.quant_op(x), E)
         if self.bit_width == 32:
             return x
@@ -121,7 +122,7 @@ def QuantDense(bit_width=3):
         def forward(ctx, input, weight, bias=None):
             max_abs = torch.max(torch.abs(torch.tanh(weight)))
             if bit_width == 1:
-                weight_q = safeSign(weight) * torch.mean(torch.abs(weight)).detach()
+                weight_q = safeSign(weight) * ops.abs_mean(weight)
             elif bit_width == 32:
                 weight_q = weight
             else:
@@ -157,7 +158,7 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
         def forward(ctx, input, weight, bias=None):
             max_weight = torch.max(torch.abs(weight))
             if bit_width == 1:
-                weight_q = safeSign(weight) * torch.mean(torch.abs(weight)).detach()
+                weight_q = safeSign(weight) * ops.abs_mean(weight)
             elif bit_width == 32:
                 weight_q = weight
             else:
@@ -178,7 +179,7 @@ def QuantConv2d(stride=1, padding=1, dilation=1, groups=1, bit_width=3):
                                                         out_scale=_fused._inv_levels(bit_width))
                 elif bit_width == 1:        # sign(W) * E
                     grad_input = _fused.conv_grad_input(input.size(), weight, grad_output, stride, padding, dilation, groups,
-                                                        kind="binary", out_scale_dev=torch.mean(torch.abs(weight)).detach())
+                                                        kind="binary", out_scale_dev=ops.abs_mean(weight))
                 else:
                     grad_input = _fused.conv_grad_input(input.size(), weight_q, grad_output, stride, padding, dilation, groups,
                                                         kind=None)

@@ -749,7 +749,9 @@ class _TrainBnActQuantFn(QtFunction):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu, bits):
-        xs, stats2 = ops.bn_train_stats(x, running_mean, running_var, eps, momentum)
+        # (the quantiser's int8 range flag is zeroed by the statistics' last launch instead of a torch.zeros fill)
+        flag = torch.empty((1,), dtype=torch.int32, device=x.device) if bits else None
+        xs, stats2 = ops.bn_train_stats(x, running_mean, running_var, eps, momentum, zero_flag=flag)
         C = int(x.shape[1])
         x2 = xs.view(-1, C)
         dev = x.device
@@ -761,7 +763,8 @@ class _TrainBnActQuantFn(QtFunction):
         four = x.dim() == 4
         if bits:
             cp, y = ops.affine_dorefa_codes(x2, g_, b_, bits, relu=bool(relu), res_f32=rs.view(-1, C) if rs is not None else None,
-                                            want_f32=True, ld_bytes=ops.code_ld_bytes(C, 16) if four else None, bn_stats=stats2)
+                                            want_f32=True, ld_bytes=ops.code_ld_bytes(C, 16) if four else None, bn_stats=stats2,
+                                            overflow=flag)
         else:
             y = ops.bn_eval_device(x2, g_, b_, stats2)
         ctx.saved_chain = (xs, rs, stats2)

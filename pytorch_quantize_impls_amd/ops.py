@@ -1785,10 +1785,24 @@ class TriplePlanes:
     K: int
     terms: int = 3
     scale: Optional[torch.Tensor] = None
+    #: (device scalar m, one-element view holding scale[0] * m) when the pack was asked to fold a consumer's device scale in
+    #: (``_triple_pack(mul_dev=)``): the consumer passes the view as its scale_dev instead of launching scale[0:1] * m
+    scale_mul: Optional[tuple] = None
 
     @property
     def ld_words(self) -> int:
         return int(self.data.shape[1]) // 2
+
+    def scale_dev_with(self, mul: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """One-element device tensor scale[0] * mul (mul None: scale[0:1]; no scale: mul)."""
+        if mul is None:
+            return self.scale[0:1] if self.scale is not None else None
+        m = mul.detach().reshape(1)
+        if self.scale is None:
+            return m
+        if self.scale_mul is not None and self.scale_mul[0] is mul:
+            return self.scale_mul[1]
+        return self.scale[0:1] * m                                     # (the split's scale is a power of two: exact)
 
     @property
     def device(self):
@@ -1798,6 +1812,35 @@ class TriplePlanes:
     def elem(self) -> int:
         """Element code of the conv / GEMM entry points: 2 = bf16 triples, 3 = fp16 pairs."""
         return 2 if self.terms == 3 else 3
+
+
+_ABS_MEAN_WORK = {}      # (device index, stream handle) -> zero-initialised ticket / partial buffer (the kernel leaves it zero)
+
+
+def abs_mean(x: torch.Tensor) -> torch.Tensor:
+    """mean|x| as a 0-dim tensor: ``torch.mean(torch.abs(x))`` (functions/dorefa_connect.py:100, DoReFa's E).  Dense fp32 device
+    tensors: one launch (qt_abs_mean_f32: double-precision, order-fixed fold) instead of torch's abs + mean (+ fill); every
+    device-side E of the package comes from here, so training mode, the eval swap and the backward see the same bits."""
+    x = x.detach()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and _storage_dense(x) and x.data_ptr() % 16 == 0):
+        return torch.mean(torch.abs(x))
+    dev = x.device
+    st = _stream(dev)
+    key = (dev.index, int(st) if st is not None else 0)
+    work = _ABS_MEAN_WORK.get(key)
+    if work is None:
+        if len(_ABS_MEAN_WORK) > 64:
+            _ABS_MEAN_WORK.clear()
+        words = int(_lib.load().qt_abs_mean_work_words())
+        with _on(dev):
+            work = torch.zeros((words + 2,), dtype=torch.int32, device=dev)
+        if work.data_ptr() % 8:
+            work = work[1:]
+        _ABS_MEAN_WORK[key] = work
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.call("qt_abs_mean_f32", _p(x), int(x.numel()), _p(work), _p(out), st)
+    return out
 
 
 def pow2_scale(x: torch.Tensor) -> torch.Tensor:
@@ -1819,7 +1862,7 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 
 
 def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_bytes: Optional[int],
-                 terms: Optional[int] = None, scale: Optional[torch.Tensor] = None) -> TriplePlanes:
+                 terms: Optional[int] = None, scale: Optional[torch.Tensor] = None, mul_dev: Optional[torch.Tensor] = None) -> TriplePlanes:
     _require(x, "input")
     x2 = _as_rows(x)
     rows, K = int(x2.shape[0]), int(x2.shape[1])
@@ -1827,6 +1870,17 @@ def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_b
     ld = triple_ld_bytes(K, terms=terms) if ld_bytes is None else int(ld_bytes)
     out = torch.empty((rows, ld // 2), dtype=torch.int16, device=x.device)
     if terms == 2:
+        if (mode == 0 and scale is None and rows > 0 and K > 0 and x2.is_contiguous() and x2.data_ptr() % 16 == 0
+                and (mul_dev is None or (mul_dev.is_cuda and mul_dev.dtype == torch.float32 and mul_dev.numel() == 1))):
+            # max|x| partials + (fold, scale, split) in two launches; the consumer's other device scalar rides in scale3[2]
+            ws = torch.empty((2048 + 4,), dtype=torch.int32, device=x.device)      # qt_f16x2_absmax_work_words() + the three scales
+            scale3 = ws[2048:2051].view(torch.float32)
+            md = mul_dev.detach() if mul_dev is not None else None
+            with _on(x.device):
+                _lib.call("qt_f16x2_absmax_pack_f32", _p(x2), int(rows), int(K), _p(ws), _p(md), _p(scale3), _p(out), int(ld),
+                          _stream(x.device))
+            return TriplePlanes(data=out, rows=rows, K=K, terms=2, scale=scale3[0:2],
+                                scale_mul=(mul_dev, scale3[2:3]) if mul_dev is not None else None)
         if mode == 0 and scale is None:
             scale = pow2_scale(x2)
         with _on(x.device):
@@ -1845,10 +1899,11 @@ def _triple_pack(x: torch.Tensor, mode: int, alpha: Optional[torch.Tensor], ld_b
 
 
 def split_bf16x3(x: torch.Tensor, alpha: Optional[torch.Tensor] = None, ld_bytes: Optional[int] = None,
-                 terms: Optional[int] = None) -> TriplePlanes:
+                 terms: Optional[int] = None, mul_dev: Optional[torch.Tensor] = None) -> TriplePlanes:
     """Split of an fp32 activation (optionally of x * alpha[k]) for the matrix cores: exact hi / mid / lo bf16 triples, or
-    (terms = 2 / FLOAT_SPLIT = "f16x2") scaled fp16 pairs."""
-    return _triple_pack(x, 0, alpha, ld_bytes, terms)
+    (terms = 2 / FLOAT_SPLIT = "f16x2") scaled fp16 pairs.  ``mul_dev``: a one-element device tensor the consumer multiplies its
+    contraction by (TriplePlanes.scale_dev_with(mul_dev) is then free)."""
+    return _triple_pack(x, 0, alpha, ld_bytes, terms, mul_dev=mul_dev)
 
 
 def weight_bf16x3(w2d: torch.Tensor, kind: str, ld_bytes: Optional[int] = None, terms: Optional[int] = None) -> TriplePlanes:
@@ -2059,7 +2114,7 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
         nhwc = x.permute(0, 2, 3, 1)
         if not nhwc.is_contiguous():
             nhwc = nhwc.contiguous()
-        px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb, terms=terms)
+        px = split_bf16x3(nhwc.view(N * H * W, C), ld_bytes=Cb, terms=terms, mul_dev=out_scale_dev)
     else:
         px = pixels
         x = pixels.data
@@ -2075,10 +2130,9 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     M = N * Ho * Wo
     dev = x.device
     bias = _check_bias(bias, Cout, dev)
-    sdev = px.scale[0:1] if px.scale is not None else None
     if out_scale_dev is not None:
-        osd = _require(out_scale_dev.detach(), "out_scale_dev").reshape(1)
-        sdev = osd if sdev is None else sdev * osd                     # (the split's scale is a power of two: exact)
+        _require(out_scale_dev.detach(), "out_scale_dev")
+    sdev = px.scale_dev_with(out_scale_dev)
     if CONV_IMPLICIT:
         y = _conv_implicit(px.elem, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
                            float(out_scale), sdev, Cout, epi=epi)
@@ -2191,11 +2245,43 @@ def poison(x: Optional[torch.Tensor], flag: torch.Tensor, mask: int = -1, n: Opt
     return out
 
 
+CODE_DIGIT_FLAG_BIT = 8       # bit of a chain's range flag: "a base-256 digit of a code is no longer exact in bf16" (|q| >= 2^16)
+
+
+def code_digits(x: torch.Tensor, levels: float, flag: Optional[torch.Tensor] = None):
+    """(hi, lo, flag) with q = rint(x * levels) = 256 hi + lo, hi = floor(q / 256) — fp32 tensors laid out like x (dense storage,
+    any dimension order); ``flag`` (int32 [1], created zeroed when None) gets CODE_DIGIT_FLAG_BIT when |hi| >= 256."""
+    x = _require(x.detach(), "input")
+    if not _storage_dense(x):
+        x = x.contiguous()
+    hi, lo = torch.empty_like(x), torch.empty_like(x)
+    if flag is None or flag.dtype != torch.int32:
+        flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    with _on(x.device):
+        _lib.call("qt_code_digits_f32", _p(x), int(x.numel()), float(levels), _p(hi), _p(lo), _p(flag), int(CODE_DIGIT_FLAG_BIT),
+                  _stream(x.device))
+    return hi, lo, flag
+
+
+def digit_combine(g_hi: torch.Tensor, g_lo: torch.Tensor, inv: float, flag: Optional[torch.Tensor], mask: int = CODE_DIGIT_FLAG_BIT):
+    """(g_hi * 256 + g_lo) * inv in fp32, NaN when ``flag & mask`` (one launch); the operands share one dense layout."""
+    _require(g_hi, "g_hi")
+    _require(g_lo, "g_lo")
+    if g_hi.shape != g_lo.shape or g_hi.stride() != g_lo.stride() or not _storage_dense(g_hi):
+        g_hi, g_lo = g_hi.contiguous(), g_lo.contiguous()
+    out = torch.empty_like(g_hi)
+    with _on(g_hi.device):
+        _lib.call("qt_digit_combine_f32", _p(g_hi), _p(g_lo), _p(flag), int(mask), float(inv), _p(out), int(g_hi.numel()),
+                  _stream(g_hi.device))
+    return out
+
+
 # ---- training-mode chain BatchNorm(batch stats) [+ residual] [-> ReLU] [-> nnDorefaQuant] (csrc/train_chain.hip, codes_i8.hip) -----
 
-def bn_train_stats(x: torch.Tensor, running_mean, running_var, eps: float, momentum: float):
+def bn_train_stats(x: torch.Tensor, running_mean, running_var, eps: float, momentum: float, zero_flag: Optional[torch.Tensor] = None):
     """Batch statistics of a device fp32 [N, C, H, W] / [N, C] tensor: returns (NHWC view of x, stats2 = [mean | invstd]); the
-    running statistics (None: skipped) are updated in place like nn.BatchNorm2d.train() does."""
+    running statistics (None: skipped) are updated in place like nn.BatchNorm2d.train() does.  ``zero_flag``: an int32 [1] tensor the
+    last launch sets to 0 (the range flag of the quantiser pass that follows: saves its fill launch)."""
     _require(x, "input")
     xs, N, H, W, C = _rows_view(x.detach())
     R = N * H * W
@@ -2204,7 +2290,7 @@ def bn_train_stats(x: torch.Tensor, running_mean, running_var, eps: float, momen
     partial = torch.empty((int(_lib.load().qt_train_chain_partial_floats(R, C)),), dtype=torch.float32, device=dev)
     with _on(dev):
         _lib.call("qt_bn_train_stats_f32", _p(xs), R, C, float(eps), float(momentum), _p(running_mean), _p(running_var),
-                  _p(stats2), _p(partial), _stream(dev))
+                  _p(stats2), _p(partial), _p(zero_flag), _stream(dev))
     return xs, stats2
 
 
@@ -2317,6 +2403,33 @@ def conv2d_grad_input_taps(input_shape, weight: torch.Tensor, grad_output: torch
     return y2.view(N, H, W, C).permute(0, 3, 1, 2)
 
 
+@functools.lru_cache(maxsize=64)
+def _inv_f32(levels: float) -> float:
+    """fl(1 / levels) in fp32 arithmetic (1 for levels == 1): the factor the reduce kernels apply for a k-bit activation q / n."""
+    if levels == 1.0:
+        return 1.0
+    return float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(levels), dtype=torch.float32))
+
+
+_TAP_GATHER = {}
+
+
+def _tap_gather_index(dev, s: int, kh: int, kw: int, p: int):
+    """Device index tensors (a_h, a_w, u_h + 1, u_w + 1), each [kh, kw]: tap (i, j) of a stride-s conv inside the space-to-depth
+    weight gradient [.., s, s, 3, 3] (conv2d_grad_weight_strided); built once per (device, geometry)."""
+    key = (dev, s, kh, kw, p)
+    idx = _TAP_GATHER.get(key)
+    if idx is None:
+        ua_h = [((i - p) // s, (i - p) % s) for i in range(kh)]                  # floor division: t = s u + a, 0 <= a < s
+        ua_w = [((j - p) // s, (j - p) % s) for j in range(kw)]
+        ah = torch.tensor([[a for _ in range(kw)] for (_, a) in ua_h], dtype=torch.long)
+        aw = torch.tensor([[a for (_, a) in ua_w] for _ in range(kh)], dtype=torch.long)
+        uh = torch.tensor([[u + 1 for _ in range(kw)] for (u, _) in ua_h], dtype=torch.long)
+        uw = torch.tensor([[u + 1 for (u, _) in ua_w] for _ in range(kh)], dtype=torch.long)
+        idx = _TAP_GATHER[key] = tuple(t.to(dev) for t in (ah, aw, uh, uw))
+    return idx
+
+
 def wgrad_strided_applicable(x_shape, g_shape, kernel_hw, stride, padding, dilation) -> bool:
     """Strided convs whose weight gradient runs on this backend's kernels (``conv2d_grad_weight_strided``): square stride
     s > 1, un-dilated, and either 1x1 / padding 0 or a kernel whose taps fall on offsets {-1, 0, +1} of the space-to-depth
@@ -2338,7 +2451,8 @@ def wgrad_strided_applicable(x_shape, g_shape, kernel_hw, stride, padding, dilat
 
 
 def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kernel_hw, stride, padding,
-                               x_levels: float = 1.0, bias_grad: Optional[list] = None):
+                               x_levels: float = 1.0, bias_grad: Optional[list] = None,
+                               layout_like: Optional[torch.Tensor] = None):
     """grad wrt the weight of a STRIDED conv2d(x, Q(W)) for an activation that is exact in bf16 (+-1 / 0, or a k-bit DoReFa
     image q / n with ``x_levels`` = n); un-masked (the caller applies the quantiser's STE).  See ``wgrad_strided_applicable``.
 
@@ -2355,7 +2469,7 @@ def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kerne
     p = _pairs(padding)[0]
     N, Cin, H, W = (int(v) for v in x.shape)
     _, Cout, Ho, Wo = (int(v) for v in grad_output.shape)
-    inv = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    inv = _inv_f32(x_levels)
     if kh == 1:
         xs = x.detach()[:, :, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s]
         # the sub-sampled activation (a strided VIEW: the packers take strides) against the gradient is a stride-1 1x1 weight
@@ -2377,12 +2491,13 @@ def conv2d_grad_weight_strided(x: torch.Tensor, grad_output: torch.Tensor, kerne
     if dWp is None:
         return None
     dWp = dWp.view(Cout, Cin, s, s, 3, 3)
-    ua = [((i - p) // s, (i - p) % s) for i in range(kh)]                        # floor division: t = s u + a, 0 <= a < s
-    dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
-    for i, (ui, ai) in enumerate(ua):
-        for j, (uj, aj) in enumerate(ua):
-            dW[:, :, i, j] = dWp[:, :, ai, aj, ui + 1, uj + 1]
-    return dW
+    ah, aw, uh, uw = _tap_gather_index(x.device, s, kh, kw, p)
+    # ONE gather for the k^2 taps (it was one strided copy per tap); for a channels-last parameter the result is produced in that
+    # layout (AccumulateGrad takes it as it is)
+    if layout_like is not None and layout_like.dim() == 4 and layout_like.is_contiguous(memory_format=torch.channels_last) \
+            and not layout_like.is_contiguous():
+        return dWp.permute(0, 2, 3, 4, 5, 1)[:, ah, aw, uh, uw].permute(0, 3, 1, 2)     # [Cout, kh, kw, Cin] memory
+    return dWp[:, :, ah, aw, uh, uw]
 
 
 #: largest output map (Ho * Wo) for which the weight gradient takes the matrix-core route (see conv2d_grad_weight_pm1)
@@ -2520,7 +2635,7 @@ def conv2d_grad_weight_gemm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kern
     dev = x_pm1.device
     g = grad_output.detach()
     x = x_pm1.detach()
-    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    out_scale = _inv_f32(x_levels)
     dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
     A = torch.empty((M, lda), dtype=torch.int16, device=dev)
     B = torch.empty((kw, Cin, ldb), dtype=torch.int16, device=dev)
@@ -2595,7 +2710,7 @@ def _wgrad_pm_plan(nc: int, Cout: int, Cin: int, H: int, W: int, Ho: int, kh: in
 
 
 def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_threshold: float, out_scale: float, workgroups: int,
-                  bias_grad: Optional[list] = None, terms: int = 3):
+                  bias_grad: Optional[list] = None, terms: int = 3, layout_like: Optional[torch.Tensor] = None):
     """Pixel-major weight gradient for the position geometry ``geom`` = (N, Cin, H, W, kh, kw, ph, pw) of a stride-1 conv;
     ``pack_act(n0, cnt, Wq, Cpi, Qx, XP, stream, f16)`` writes the activation plane of images [n0, n0 + cnt) (bf16, or fp16 when
     ``f16``).  Returns [Cout, Cin, kh, kw] fp32 or None when the planes do not fit the byte budget.  ``bias_grad``: a list that
@@ -2640,7 +2755,15 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
         w = _require(weight.detach(), "weight")
         if tuple(w.shape) != (Cout, Cin, kh, kw) or not (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)):
             w = w.contiguous()
-    dW = torch.empty_like(w) if w is not None else torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
+    if w is not None:
+        dW = torch.empty_like(w)
+    elif (layout_like is not None and tuple(layout_like.shape) == (Cout, Cin, kh, kw) and layout_like.dtype == torch.float32
+          and (layout_like.is_contiguous() or layout_like.is_contiguous(memory_format=torch.channels_last))):
+        # un-masked gradient (DoReFa: upstream's _ignore_factor_op) in the PARAMETER's layout: autograd's AccumulateGrad takes a
+        # gradient whose strides match the parameter's as it is, anything else is re-laid-out by a copy kernel per layer and step
+        dW = torch.empty_like(layout_like)
+    else:
+        dW = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=dev)
     dws = tuple(int(v) for v in dW.stride())
     G3 = torch.empty(((2 if two else 3) * qa_m * Cpo,), dtype=torch.int16, device=dev)
     XP = torch.empty((qx_m * Cpi,), dtype=torch.int16, device=dev)
@@ -2682,7 +2805,7 @@ def _wgrad_pm_run(grad_output: torch.Tensor, geom, pack_act, weight, ste_thresho
 def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel_hw, padding,
                           weight: Optional[torch.Tensor] = None, ste_threshold: float = STE_THRESHOLD,
                           x_levels: float = 1.0, workgroups: int = 0, bias_grad: Optional[list] = None,
-                          terms: Optional[int] = None):
+                          terms: Optional[int] = None, layout_like: Optional[torch.Tensor] = None):
     """Same contract as ``conv2d_grad_weight_gemm`` on the pixel-major kernel (csrc/wgrad_pm.hip): the operands stay
     [position][channel] (what channels-last tensors already are), one workgroup accumulates every tap of its tile, so
     the gradient planes are read once instead of once per tap.  Returns None outside (3, 3) / (5, 5) stride-1 convs.
@@ -2698,7 +2821,7 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
             or (kh, kw) not in ((3, 3), (5, 5))):
         return None
     x = x_pm1.detach()
-    out_scale = 1.0 if x_levels == 1.0 else float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(x_levels), dtype=torch.float32))
+    out_scale = _inv_f32(x_levels)
     I = int
 
     def pack_act(n0, cnt, Wq, Cpi, qx, XP, st, f16=False):
@@ -2708,7 +2831,7 @@ def conv2d_grad_weight_pm(x_pm1: torch.Tensor, grad_output: torch.Tensor, kernel
                   _p(XP), st)
 
     return _wgrad_pm_run(grad_output, (N, Cin, H, W, kh, kw, ph, pw), pack_act, weight, ste_threshold, out_scale, workgroups,
-                         bias_grad, terms=split_terms(terms))
+                         bias_grad, terms=split_terms(terms), layout_like=layout_like)
 
 
 def wgrad_s2d_applicable(x_shape, kernel_hw, stride, dilation, any_channels: bool = False) -> bool:

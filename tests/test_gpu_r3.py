@@ -259,7 +259,9 @@ def test_f16x2_split_meets_its_stated_bound(dev):
         before = dict(_lib.call_counts)
         with ops.float_split("f16x2"):
             tp = ops.split_bf16x3(torch.from_numpy(x).to(dev))
-        assert tp.terms == 2 and tp.elem == 3 and _lib.call_counts["qt_f16x2_pack_f32"] > before.get("qt_f16x2_pack_f32", 0)
+        # (round 6: a dense activation is split by qt_f16x2_absmax_pack_f32 — max|x| partials + fold-and-split, two launches)
+        assert tp.terms == 2 and tp.elem == 3 and any(_lib.call_counts[k] > before.get(k, 0)
+                                                      for k in ("qt_f16x2_pack_f32", "qt_f16x2_absmax_pack_f32"))
         terms, s = _decode_pairs(tp, K)
         amax = float(np.abs(x).max())
         assert s[0] * s[1] == 1.0 and np.log2(s[0]) == np.floor(np.log2(s[0])) and 2.0 ** 14 <= amax / s[0] < 2.0 ** 15
