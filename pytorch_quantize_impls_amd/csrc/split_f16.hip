@@ -432,6 +432,50 @@ __global__ __launch_bounds__(256) void conv_weight_pair_kernel(const float* __re
     }
 }
 
+// The transposed 1 x 1 case with unit stride along Cin (a Linear weight [N, K] whose plane of Q(W)^T is wanted: the operand of
+// grad_x = g . Q(W), functions/binary_connect.py:104-112): the generic kernel above would read one float per 4 K-byte row stride —
+// every lane its own cache line.  Here a 64 x 64 tile goes through LDS: coalesced reads along K, coalesced pair writes along N.
+__global__ __launch_bounds__(256) void weight_pair_transpose_kernel(const float* __restrict__ w, int64_t so, int N, int K, int mode,
+                                                                    uint32_t* __restrict__ out, int64_t ld_words) {
+    __shared__ float tile[64][65];
+    const int tn = (N + 63) / 64, tk = (K + 63) / 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;                 // 64 x 4
+    for (int64_t t = blockIdx.x; t < (int64_t)tn * tk; t += gridDim.x) {
+        const int n0 = (int)(t % tn) * 64, k0 = (int)(t / tn) * 64;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = n0 + ly + 4 * j, k = k0 + lx;
+            tile[ly + 4 * j][lx] = (n < N && k < K) ? w[(int64_t)n * so + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + ly + 4 * j, n = n0 + lx;
+            if (k < K && n < N) {
+                const float x = tile[lx][ly + 4 * j];
+                float q;
+                if (mode == 1) q = qt_safe_sign(x);
+                else if (mode == 2) q = qt_ternarize(x);
+                else if (mode == 3) q = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+                else q = x;
+                const uint32_t b = f16_bits(q);
+                out[(int64_t)k * ld_words + n] = b | (b << 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the words of a row beyond `chans` (row padding to the 128-byte stride) of the plane written by the kernel above
+__global__ __launch_bounds__(256) void pair_row_pad_kernel(uint32_t* __restrict__ out, int64_t ld_words, int chans, int64_t rows) {
+    const int pad = (int)(ld_words - chans);
+    const int64_t total = rows * pad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / pad;
+        out[r * ld_words + chans + (int)(t - r * pad)] = 0u;
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_f16x2_scale_f32(const float* mn, const float* mx, float* scale2, qt_stream_t stream) {
@@ -590,6 +634,16 @@ extern "C" int qt_f16x2_pack_conv_weight_f32(const float* w, int64_t stride_o, i
     if (ld_bytes < kh * kw * cb || (ld_bytes & 127) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
     if (Cout * Cin * kh * kw >= (1ll << 31) || rows * ld_bytes >= (1ll << 33)) return QT_ERR_UNSUPPORTED;
     const int64_t ld_words = ld_bytes / 4;
+    if (transpose_flip && kh == 1 && kw == 1 && stride_i == 1 && Cout * Cin >= (1 << 16)) {
+        // (1 x 1, transposed, unit stride along Cin: the LDS-tiled transpose; the row padding, if any, by a second small launch)
+        const int64_t tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+        hipLaunchKernelGGL(weight_pair_transpose_kernel, dim3(qt_stream_grid(tiles, 256 * 8)), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+                           (int)Cout, (int)Cin, mode, reinterpret_cast<uint32_t*>(out), ld_words);
+        if (ld_words > Cout)
+            hipLaunchKernelGGL(pair_row_pad_kernel, dim3(qt_stream_grid((rows * (ld_words - Cout) + 255) / 256)), dim3(256), 0,
+                               (hipStream_t)stream, reinterpret_cast<uint32_t*>(out), ld_words, (int)Cout, rows);
+        return qt_check_launch();
+    }
     hipLaunchKernelGGL(conv_weight_pair_kernel, dim3(qt_stream_grid((rows * ld_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_i, stride_h, stride_w, (int)Cout, (int)Cin, (int)kh, (int)kw, mode, transpose_flip,
                        reinterpret_cast<uint32_t*>(out), ld_words, (int)(cb / 4));

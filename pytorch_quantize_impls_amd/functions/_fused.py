@@ -1505,6 +1505,10 @@ BWD_MFMA_MIN_MACS = 0          # (round 4: every size on the own routes; 1 << 27
 BWD_CONV_MFMA = True
 
 
+#: grad_x of LinearBin / LinearTer packs Q(W)^T in one kernel from W (A/B switch for tools/)
+LINEAR_GRAD_X_ONE_PACK = True
+
+
 def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor, terms=None) -> torch.Tensor:
     """a [M, J] (real) @ b_pm1 [J, K] (entries in {-1, 0, +1}) -> [M, K] fp32.  ``terms``: split of a (ops.float_linear)."""
     M, J = a.shape
@@ -1547,8 +1551,18 @@ class QuantLinearFn(QtFunction):
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
-            grad_input = pm1_matmul(g2, wq).view(input.shape)
+            Nf, Kf = int(weight.shape[0]), int(weight[0].numel())
+            if (LINEAR_GRAD_X_ONE_PACK and weight_q is None and ctx.kind in ("binary", "ternary") and g2.is_cuda and g2.dtype == torch.float32
+                    and weight.dtype == torch.float32 and ops.split_terms() == 2 and Nf % 4 == 0 and g2.numel() > 0 and weight.numel() > 0):
+                # g . Q(W): the operand Q(W)^T comes from ONE kernel that reads W where it lies (quantiser + transpose + fp16 pairs:
+                # qt_f16x2_pack_conv_weight_f32 on the [N, K, 1, 1] view) instead of quantise, transpose-copy and pack (three passes,
+                # 280 us for AlexNet's 9216 x 4096 layer)
+                wt = ops.pack_conv_weight_bf16x3(weight.detach().reshape(Nf, Kf, 1, 1), ctx.kind, terms=2, transpose_flip=True)
+                shape_t = torch.empty((Kf, Nf), dtype=torch.float32, device="meta")
+                grad_input = ops.float_linear(g2.contiguous(), shape_t, ctx.kind, weight_triples=wt, terms=2).view(input.shape)
+            else:
+                wq = weight_q if weight_q is not None else quantize_weight_f32(weight, ctx.kind)
+                grad_input = pm1_matmul(g2, wq).view(input.shape)
         if ctx.needs_input_grad[1]:
             x2 = input.reshape(-1, input.shape[-1])
             # (rows of g2^T are output features: the exact three-term split, not the per-tensor-scaled two-term one)

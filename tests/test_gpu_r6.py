@@ -184,3 +184,96 @@ def test_implicit_graph_keeps_a_device_bound_forward_eager(dev):
         assert all(torch.equal(ys[0], y) for y in ys)
         # either verdict is legitimate on a given box; what must hold: a kept graph was measurably faster, a dropped one costs nothing
         assert st["graphs"] + st["not_faster"] >= 1, st
+
+
+# ---- round-6 launch diet of the training step: the fused kernels against the launches they replace ----------------------------------
+
+def test_abs_mean_one_launch_is_the_mean_of_abs_and_leaves_its_ticket_zero(dev):
+    """qt_abs_mean_f32 (E = mean|W| of DoReFa's 1-bit weights, functions/dorefa_connect.py:100): fp64 reference to 2^-22 relative,
+    identical bits on repeated calls (order-fixed fold), any dense layout, sizes around the block boundaries; the work buffer is
+    zero again after every call."""
+    from pytorch_quantize_impls_amd import ops, _lib
+    torch.manual_seed(0)
+    for n in (1, 3, 4, 5, 255, 1024, 4097, 64 * 64 * 9, 512 * 512 * 9 + 3):
+        x = torch.randn(n, device=dev) * 3.0
+        c0 = _lib.call_counts["qt_abs_mean_f32"]
+        a, b = ops.abs_mean(x), ops.abs_mean(x)
+        assert _lib.call_counts["qt_abs_mean_f32"] == c0 + 2
+        ref = x.double().abs().mean()
+        assert a.dim() == 0 and torch.equal(a, b)
+        assert abs(float(a) - float(ref)) <= 2.0 ** -22 * float(ref), (n, float(a), float(ref))
+    w = torch.randn(64, 32, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    assert abs(float(ops.abs_mean(w)) - float(w.double().abs().mean())) <= 1e-7
+    for work in ops._ABS_MEAN_WORK.values():
+        assert int(work[0]) == 0
+    # a CPU tensor takes torch's expression
+    xc = torch.randn(100)
+    assert torch.equal(ops.abs_mean(xc), xc.abs().mean())
+
+
+def test_fused_absmax_split_equals_the_three_launch_form(dev):
+    """qt_f16x2_absmax_pack_f32 (partials + fold-and-split) writes the plane and the scale of qt_f16x2_absmax_scale_f32 +
+    qt_f16x2_pack_f32 bit for bit, and scale3[2] = s * E for the consumer."""
+    from pytorch_quantize_impls_amd import ops, _lib
+    torch.manual_seed(1)
+    for rows, K in ((1, 4), (7, 36), (513, 200), (4096, 576)):
+        x = torch.randn(rows, K, device=dev) * (10.0 ** float(torch.randint(-6, 6, (1,))))
+        E = torch.rand((), device=dev) + 0.5
+        with ops.float_split("f16x2"):
+            c0 = _lib.call_counts["qt_f16x2_absmax_pack_f32"]
+            new = ops.split_bf16x3(x, mul_dev=E)
+            assert _lib.call_counts["qt_f16x2_absmax_pack_f32"] == c0 + 1
+            scale = ops.pow2_scale(x)
+            old = ops._triple_pack(x, 0, None, None, 2, scale=scale)
+        assert torch.equal(new.scale, old.scale) and torch.equal(new.data, old.data)
+        assert torch.equal(new.scale_dev_with(E), old.scale[0:1] * E) and new.scale_dev_with(E).data_ptr() == new.scale_mul[1].data_ptr()
+        assert torch.equal(new.scale_dev_with(None), old.scale[0:1])
+        other = torch.ones((), device=dev) * 3
+        assert torch.equal(new.scale_dev_with(other), old.scale[0:1] * 3)            # another scalar: the multiply is launched
+
+
+def test_code_digits_and_their_recombination(dev):
+    from pytorch_quantize_impls_amd import ops
+    torch.manual_seed(2)
+    x = (torch.randint(0, 3000, (4, 64, 8, 8), device=dev).float() / 15.0).contiguous(memory_format=torch.channels_last)
+    hi, lo, flag = ops.code_digits(x, 15.0)
+    q = torch.round(x * 15.0)
+    assert hi.stride() == x.stride() and torch.equal(hi, torch.floor(q / 256.0)) and torch.equal(lo, q - hi * 256.0)
+    assert int(flag) == 0
+    a, b = torch.randn(64, 64, device=dev), torch.randn(64, 64, device=dev)
+    inv = ops._inv_f32(15.0)
+    assert torch.equal(ops.digit_combine(a, b, inv, flag), (a * 256.0 + b) * inv)
+    big = torch.full((8,), 2.0 ** 16 / 15.0 * 1.01, device=dev)
+    _, _, f2 = ops.code_digits(big, 15.0)
+    assert int(f2) & ops.CODE_DIGIT_FLAG_BIT
+    assert torch.isnan(ops.digit_combine(a, b, inv, f2)).all()
+
+
+def test_linear_grad_input_operand_from_one_pack_kernel(dev):
+    """grad_x = g . Q(W) of LinearBin / LinearTer: the LDS-tiled transposing pack (qt_f16x2_pack_conv_weight_f32, 1 x 1 transposed) gives
+    the plane of quantise -> transpose -> pack, and the layer's gradient is unchanged bit for bit."""
+    from pytorch_quantize_impls_amd import ops
+    from pytorch_quantize_impls_amd.functions import _fused
+    from pytorch_quantize_impls_amd.layers import LinearBin, LinearTer
+    torch.manual_seed(3)
+    for N, K in ((256, 512), (300, 260), (4096, 1024)):
+        w = torch.randn(N, K, device=dev)
+        for kind in ("binary", "ternary"):
+            one = ops.pack_conv_weight_bf16x3(w.reshape(N, K, 1, 1), kind, terms=2, transpose_flip=True)
+            ref = ops.weight_bf16x3(_fused.quantize_weight_f32(w, kind).t().contiguous(), "raw", terms=2)
+            n4 = (N + 3) // 4 * 4
+            assert torch.equal(one.data[:, :2 * N], ref.data[:, :2 * N]) and not one.data[:, 2 * N:].any() and one.rows == K
+    for cls in (LinearBin, LinearTer):
+        layer = cls(1024, 512).to(dev).train()
+        x = torch.randn(64, 1024, device=dev).sign().requires_grad_(True)
+        g = torch.randn(64, 512, device=dev)
+        grads = []
+        for flag in (True, False):
+            _fused.LINEAR_GRAD_X_ONE_PACK = flag
+            try:
+                x.grad = None
+                layer(x).backward(g)
+                grads.append(x.grad.clone())
+            finally:
+                _fused.LINEAR_GRAD_X_ONE_PACK = True
+        assert torch.equal(grads[0], grads[1])
