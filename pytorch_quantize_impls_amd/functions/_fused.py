@@ -39,6 +39,41 @@ DETECT_BINARY_INPUT = True
 LIBRARY_PATHS: Counter = Counter()
 
 
+# ---- route switches: module attributes = process-wide DEFAULTS; ``with _fused.scope(GEMM_IMPL="valu"):`` = per-thread overrides ----
+# (same mechanism as ops.scope; the autograd Functions re-open the forward's scope around their backward: functions.common.QtFunction)
+_SCOPED = ("GEMM_IMPL", "DETECT_BINARY_INPUT", "FLOAT_PATH", "PAD_PLANES", "XNOR_LINEAR_DIGITS", "BWD_CONV_MFMA", "LINEAR_GRAD_X_ONE_PACK",
+           "BWD_MFMA_MIN_MACS")
+_scope_tls = threading.local()
+
+
+def _cfg(name: str):
+    ov = getattr(_scope_tls, "ov", None)
+    if ov is not None and name in ov:
+        return ov[name]
+    return globals()[name]
+
+
+def scope_overrides():
+    return getattr(_scope_tls, "ov", None)
+
+
+@contextlib.contextmanager
+def scope(_overrides=None, **kw):
+    """Thread-local overrides of this module's route switches (names: ``_SCOPED``); nests; ``scope(None)`` is a no-op."""
+    if _overrides:
+        kw = {**_overrides, **kw}
+    bad = [k for k in kw if k not in _SCOPED]
+    if bad:
+        raise KeyError(f"not a scoped switch of functions._fused: {bad} (known: {_SCOPED})")
+    prev = getattr(_scope_tls, "ov", None)
+    if kw:
+        _scope_tls.ov = {**(prev or {}), **kw}
+    try:
+        yield
+    finally:
+        _scope_tls.ov = prev
+
+
 def note_library_path(input, reason: str) -> None:
     if getattr(input, "is_cuda", False):
         LIBRARY_PATHS[reason] += 1
@@ -216,7 +251,7 @@ def detect_pm1(input: torch.Tensor, weight: Optional[torch.Tensor]):
 
 def codes_route(codes, weight: Optional[torch.Tensor]):
     """(use the int8 code planes?, device flag or None) for DoReFa activation codes whose range flag is on the device."""
-    if ops.ASSUME_CODES_FIT or codes.overflow is None:
+    if ops._cfg("ASSUME_CODES_FIT") or codes.overflow is None:
         return True, None
     ok, cached = _verdict(weight, ("codes", int(codes.K)), codes.usable)
     if ok and cached:
@@ -250,7 +285,7 @@ def activation_planes(input: torch.Tensor, binary_input: Optional[bool], impl: s
         return None, None
     flag = None
     if binary_input is None and tagged is None:
-        if not DETECT_BINARY_INPUT:
+        if not _cfg("DETECT_BINARY_INPUT"):
             return None, None
         ok, flag = detect_pm1(input, weight)
         if not ok:
@@ -274,10 +309,10 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
     K = input.shape[-1]
     N = weight.shape[0]
     M = input.numel() // max(K, 1)
-    impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
+    impl = ops.select_gemm_impl(_cfg("GEMM_IMPL"), M, N, K)
     if (impl == "mfma" and weight_planes is None and input.dtype == torch.float32 and input.numel() > 0
             and binary_input is not False and packed.lookup(input, packed.ROWS_LAST) is None):
-        ok, flag = (True, None) if binary_input else (detect_pm1(input, weight) if DETECT_BINARY_INPUT else (False, None))
+        ok, flag = (True, None) if binary_input else (detect_pm1(input, weight) if _cfg("DETECT_BINARY_INPUT") else (False, None))
         if ok:
             # neither operand is packed yet (un-tagged +-1 activation, training-mode weight): one launch packs both
             wq = weight_q if weight_q is not None else weight
@@ -293,7 +328,7 @@ def quant_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: Option
         y = ops.packed_gemm(xp, wp, poison_bias(bias, flag, N, input.device), impl=impl)
         return y.view(*input.shape[:-1], N)
 
-    if FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+    if _cfg("FLOAT_PATH") == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
         # the quantisers are idempotent, so an explicit quantised image (eval / stochastic) goes through
         # the same weight packer
         return ops.float_linear(input, weight_q if weight_q is not None else weight, kind, bias,
@@ -318,7 +353,7 @@ def _pixel_planes(input: torch.Tensor, binary_input: Optional[bool], weight: Opt
         return None, None
     flag = None
     if binary_input is None and tagged is None:
-        if not DETECT_BINARY_INPUT:
+        if not _cfg("DETECT_BINARY_INPUT"):
             return None, None
         ok, flag = detect_pm1(input, weight)
         if not ok:
@@ -358,7 +393,7 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
             if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
                 y = y.contiguous()                                         # caller works in NCHW storage
             return y
-    if packable and FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+    if packable and _cfg("FLOAT_PATH") == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
         # real-valued activation (first layer): exact bf16 triples + implicit-GEMM conv on the bf16
         # matrix cores; the quantisers are idempotent so an explicit quantised image is packed the same way
         N, C, H, W = input.shape
@@ -474,7 +509,7 @@ def packed_linear(layer, act, kind: str, hwc=None) -> torch.Tensor:
     M, K = act.planes.rows, act.planes.K
     if K != layer.weight.shape[1]:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
-    impl = ops.select_gemm_impl(GEMM_IMPL, M, N, K)
+    impl = ops.select_gemm_impl(_cfg("GEMM_IMPL"), M, N, K)
     if hwc is None:
         wp = layer._eval_planes(lambda w2: pack_weight(w2, kind, impl), key=impl)
     else:
@@ -510,7 +545,7 @@ def packed_conv2d(layer, act, kind: str, epi=None):
             return y2, (N, int(layer.weight.shape[0]), H, W)
         y2 = ops.conv2d_nib(act.nib, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,
                             layer.dilation, epi=epi)
-    elif PAD_PLANES and (ph or pw):
+    elif _cfg("PAD_PLANES") and (ph or pw):
         # zero padding made physical while the bits are expanded: the conv runs un-padded (no per-tap checks)
         px = ops.bits_to_nib_pad(act.planes, N, H, W, (ph, pw), ld=ops.pixel_ld_nib(C))
         y2 = ops.conv2d_nib(px, (N, C, H + 2 * ph, W + 2 * pw), wp, (kh, kw), layer.bias, layer.stride, 0,
@@ -566,7 +601,7 @@ def packed_xnor_linear(layer, act, hwc=None) -> torch.Tensor:
     if K != layer.weight.shape[1]:
         raise ValueError(f"packed activation has {K} features, layer expects {layer.weight.shape[1]}")
 
-    dg = xnor_linear_digits(layer) if XNOR_LINEAR_DIGITS else None
+    dg = xnor_linear_digits(layer) if _cfg("XNOR_LINEAR_DIGITS") else None
     if dg is not None and 3 * act.planes.rows * int(dg[0].codes.shape[1]) >= (1 << 31):
         dg = None                                               # the stacked digit planes pass the GEMM's 32-bit operand offsets
     if dg is not None:
@@ -649,8 +684,8 @@ class QuantConv2dFn(QtFunction):
         stride, padding, dilation, groups = ctx.conv_args
         grad_input = grad_weight = grad_bias = None
         go = _dense(grad_output)
-        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
-                and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
+        mfma = (_cfg("BWD_CONV_MFMA") and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight[0].numel() >= _cfg("BWD_MFMA_MIN_MACS"))
         if ctx.needs_input_grad[0]:
             if mfma:     # real gradient x +-1 / 0 weight: the forward's exact-split conv on flipped weights (the deterministic
                 #          quantiser runs inside the operand pack; a stochastic draw was saved)
@@ -751,7 +786,7 @@ def known_pm1(input: torch.Tensor, weight: Optional[torch.Tensor], layout) -> bo
         return False
     if packed.lookup(input, layout) is not None:
         return True
-    return bool(DETECT_BINARY_INPUT and detect_pm1(input, weight)[0])
+    return bool(_cfg("DETECT_BINARY_INPUT") and detect_pm1(input, weight)[0])
 
 
 def real_matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -790,7 +825,7 @@ def conv_grad_input(input_shape, weight_q, grad_output, stride, padding, dilatio
     "ternary": +-1 / 0; "raw": small integers or multiples of 1/2, the caller scales) on ops.conv2d_grad_input_q; anything else
     (groups, dilation, a real-valued image) on the library, counted."""
     go = _dense(grad_output)
-    if (BWD_CONV_MFMA and kind is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
+    if (_cfg("BWD_CONV_MFMA") and kind is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
             and not isinstance(padding, str) and go.numel() > 0):
         gx = ops.conv2d_grad_input_q(input_shape, weight_q, go, stride, padding, dilation, kind=kind, out_scale=out_scale,
                                      out_scale_dev=out_scale_dev)
@@ -809,7 +844,7 @@ def conv_grad_weight(input, weight_shape, grad_output, stride, padding, dilation
     """UN-masked grad wrt the weight of conv2d(x, .): +-1 activations on the weight-gradient routes, a real-valued image with few
     channels (first layers) through the space-to-depth form; anything else on the library, counted."""
     go = _dense(grad_output)
-    if (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+    if (_cfg("BWD_CONV_MFMA") and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
             and go.numel() > 0 and input.dtype == torch.float32):
         gw = None
         if x_is_pm1:
@@ -922,7 +957,7 @@ def dorefa_w1_linear_forward(input, weight, bias, prequantized: bool, weight_cod
             if route is not None:
                 route.append("codes")
             return y.view(*input.shape[:-1], N)
-    if FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+    if _cfg("FLOAT_PATH") == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
         # no usable int8 codes: exact bf16 split of the activation x sign(W) on the bf16 matrix cores, E and bias after
         y = ops.float_linear(input.detach(), weight.detach(), "binary") * E
         if bias is not None:
@@ -987,7 +1022,7 @@ def dorefa_w1_conv_forward(input, weight, bias, conv_args, prequantized: bool, w
             if route is not None:
                 route.append("codes")
             return y2.view(N_, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)   # channels_last like the input
-    if (FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0 and groups == 1
+    if (_cfg("FLOAT_PATH") == "bf16x3" and input.dtype == torch.float32 and input.dim() == 4 and input.numel() > 0 and groups == 1
             and padding_mode == "zeros" and not isinstance(padding, str)):
         # no int8 codes (an un-quantised input, or the un-clamped quantiser left the int8 range): the activation is a real
         # number for the matrix cores — exact bf16 split x sign(W), E and the bias applied to the result
@@ -1134,7 +1169,7 @@ class DorefaW1LinearFn(QtFunction):
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         x2 = input.reshape(-1, input.shape[-1])
         grad_input = grad_weight = grad_bias = None
-        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
+        big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0 and g2.shape[0] * g2.shape[1] * x2.shape[1] >= _cfg("BWD_MFMA_MIN_MACS"))
         if ctx.needs_input_grad[0]:
             sgn = quantize_weight_f32(weight, "binary")
             E = ops.abs_mean(weight)
@@ -1179,8 +1214,8 @@ class DorefaW1Conv2dFn(QtFunction):
         stride, padding, dilation, groups = ctx.conv_args
         go = _dense(grad_output)
         grad_input = grad_weight = grad_bias = None
-        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
-                and go.numel() * weight[0].numel() >= BWD_MFMA_MIN_MACS)
+        mfma = (_cfg("BWD_CONV_MFMA") and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight[0].numel() >= _cfg("BWD_MFMA_MIN_MACS"))
         if ctx.needs_input_grad[0]:
             E = ctx.E if ctx.E is not None else ops.abs_mean(weight)
             if mfma:     # g * (sign(W) E) = E * (g * sign(W)): the exact-split conv on the flipped +-1 weight, scaled after
@@ -1296,7 +1331,7 @@ class DorefaWkConv2dFn(QtFunction):
             wc = ops.pack_conv_weight_dorefa_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_conv_forward(input, weight_q, bias, conv_args, bit_width, wc)
         ctx.codes_fit = y is not None            # the int8 route ran: every |code| <= 127
-        if y is None and ok and FLOAT_PATH == "bf16x3":
+        if y is None and ok and _cfg("FLOAT_PATH") == "bf16x3":
             y = dorefa_levels_conv_forward(input, weight_q, bias, conv_args, bit_width)
         if y is None:
             note_library_path(input, "k-bit DoReFa conv outside the level routes")
@@ -1310,8 +1345,8 @@ class DorefaWkConv2dFn(QtFunction):
         go = _dense(grad_output)
         k = ctx.bit_width
         grad_input = grad_weight = grad_bias = None
-        mfma = (BWD_CONV_MFMA and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
-                and go.numel() * weight_q[0].numel() >= BWD_MFMA_MIN_MACS)
+        mfma = (_cfg("BWD_CONV_MFMA") and go.is_cuda and go.dtype == torch.float32 and groups == 1 and not isinstance(padding, str)
+                and go.numel() * weight_q[0].numel() >= _cfg("BWD_MFMA_MIN_MACS"))
         if ctx.needs_input_grad[0]:
             if mfma:
                 grad_input = ops.conv2d_grad_input_q(input.shape, _weight_levels(weight_q, k), go, stride, padding, dilation,
@@ -1347,7 +1382,7 @@ class DorefaWkLinearFn(QtFunction):
             wc = ops.dorefa_weight_codes(weight_q.detach(), bit_width)
             y = dorefa_wk_linear_forward(input, weight_q, bias, bit_width, wc)
         ctx.codes_fit = y is not None
-        if y is None and FLOAT_PATH == "bf16x3":
+        if y is None and _cfg("FLOAT_PATH") == "bf16x3":
             y = dorefa_levels_linear_forward(input, weight_q, bias, bit_width)
         if y is None:
             note_library_path(input, "k-bit DoReFa linear outside the level routes")
@@ -1362,7 +1397,7 @@ class DorefaWkLinearFn(QtFunction):
         x2 = input.reshape(-1, input.shape[-1])
         grad_input = grad_weight = grad_bias = None
         big = (g2.is_cuda and g2.dtype == torch.float32 and g2.numel() > 0
-               and g2.shape[0] * g2.shape[1] * x2.shape[1] >= BWD_MFMA_MIN_MACS)
+               and g2.shape[0] * g2.shape[1] * x2.shape[1] >= _cfg("BWD_MFMA_MIN_MACS"))
         if ctx.needs_input_grad[0]:
             if big:        # real gradient x integer levels
                 lv = _weight_levels(weight_q, k)
@@ -1470,7 +1505,7 @@ def grouped_quant_conv(layer, input, kind: str, quant_op):
     # a +-1 tag of the whole activation (BinaryConnect's sign planes) holds for every channel slice
     known_pm1 = True if (layer.binary_input or packed.lookup(input, packed.NHWC) is not None) else layer.binary_input
     flag = None
-    if (known_pm1 is None and DETECT_BINARY_INPUT and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+    if (known_pm1 is None and _cfg("DETECT_BINARY_INPUT") and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
             and input.numel() > 0):
         # un-tagged activation, no hint: ONE detection on the whole activation, remembered under the layer's own weight (the
         # per-group weight views are fresh tensors on every call: verdicts keyed on them die with them — a host sync per group
@@ -1513,7 +1548,7 @@ def pm1_matmul(a: torch.Tensor, b_pm1: torch.Tensor, terms=None) -> torch.Tensor
     """a [M, J] (real) @ b_pm1 [J, K] (entries in {-1, 0, +1}) -> [M, K] fp32.  ``terms``: split of a (ops.float_linear)."""
     M, J = a.shape
     K = b_pm1.shape[1]
-    if a.is_cuda and a.dtype == torch.float32 and M * J * K >= BWD_MFMA_MIN_MACS and a.numel() > 0 and b_pm1.numel() > 0:
+    if a.is_cuda and a.dtype == torch.float32 and M * J * K >= _cfg("BWD_MFMA_MIN_MACS") and a.numel() > 0 and b_pm1.numel() > 0:
         return ops.float_linear(a.contiguous(), b_pm1.t().contiguous(), "sign", terms=terms)
     return lib_mm(a, b_pm1, "backward GEMM below BWD_MFMA_MIN_MACS / non-fp32")
 
@@ -1552,7 +1587,7 @@ class QuantLinearFn(QtFunction):
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
             Nf, Kf = int(weight.shape[0]), int(weight[0].numel())
-            if (LINEAR_GRAD_X_ONE_PACK and weight_q is None and ctx.kind in ("binary", "ternary") and g2.is_cuda and g2.dtype == torch.float32
+            if (_cfg("LINEAR_GRAD_X_ONE_PACK") and weight_q is None and ctx.kind in ("binary", "ternary") and g2.is_cuda and g2.dtype == torch.float32
                     and weight.dtype == torch.float32 and ops.split_terms() == 2 and Nf % 4 == 0 and g2.numel() > 0 and weight.numel() > 0):
                 # g . Q(W): the operand Q(W)^T comes from ONE kernel that reads W where it lies (quantiser + transpose + fp16 pairs:
                 # qt_f16x2_pack_conv_weight_f32 on the [N, K, 1, 1] view) instead of quantise, transpose-copy and pack (three passes,

@@ -26,8 +26,10 @@ class QtFunction(torch.autograd.Function):
 
     def __init_subclass__(cls, **kwargs):
         """A graph is differentiated under the thread-local switches it was built under: ``forward`` records the thread's
-        ``ops.float_split`` / ``_fused.detect_scope`` overrides on ctx, ``backward`` (run by the autograd engine's own thread)
-        re-opens them."""
+        ``ops.float_split`` / ``_fused.detect_scope`` / ``ops.scope`` / ``_fused.scope`` overrides on ctx, ``backward`` (run by the
+        autograd engine's own thread, which sees no thread-local state of the caller) re-opens them.  Consequence: a
+        scope opened ONLY around ``loss.backward()`` does not reach the backward kernels of a graph built outside it — open it around
+        the forward, or set the module-level default (``ops.FLOAT_SPLIT``, ``_fused.DETECT_MODE``, ...), which every thread reads."""
         super().__init_subclass__(**kwargs)
         fwd, bwd = cls.__dict__.get("forward"), cls.__dict__.get("backward")
         if isinstance(fwd, staticmethod) and isinstance(bwd, staticmethod) and not getattr(fwd.__func__, "_qt_wrapped", False):
@@ -36,14 +38,16 @@ class QtFunction(torch.autograd.Function):
             def forward(ctx, *a, **k):
                 from . import _fused
                 ctx._qt_split, ctx._qt_detect = ops.float_split_override(), _fused.detect_mode_override()
+                ctx._qt_scopes = (ops.scope_overrides(), _fused.scope_overrides())
                 return f0(ctx, *a, **k)
 
             def backward(ctx, *g):
                 split, detect = getattr(ctx, "_qt_split", None), getattr(ctx, "_qt_detect", None)
-                if split is None and detect is None:
+                so, sf = getattr(ctx, "_qt_scopes", (None, None))
+                if split is None and detect is None and not so and not sf:
                     return b0(ctx, *g)
                 from . import _fused
-                with ops.float_split(split), _fused.detect_scope(detect):
+                with ops.float_split(split), _fused.detect_scope(detect), ops.scope(so), _fused.scope(sf):
                     return b0(ctx, *g)
             forward._qt_wrapped = backward._qt_wrapped = True
             forward.__doc__, backward.__doc__ = f0.__doc__, b0.__doc__

@@ -101,7 +101,7 @@ def XNORDense(dim=[0, 1]):
                         # bits (the operands of the eval-mode / packed path: one arithmetic for every execution of a layer)
                         wt, ap = _fused.xnor_linear_operands(weight=weight)
                         return ops.bf16_gemm(ops.bits_alpha_pairs(planes, ap), wt, bias.detach() if bias is not None else None)
-                    if not ctx.x_is_pm1 and _fused.DETECT_BINARY_INPUT:
+                    if not ctx.x_is_pm1 and _fused._cfg("DETECT_BINARY_INPUT"):
                         ctx.x_is_pm1 = bool(_fused.detect_pm1(input, weight)[0])
                 return ops.float_linear(input, weight.detach(), "sign", bias, alpha=mean.view(-1))
             weight_q, mean = xnor_weight(weight, DIM)
@@ -223,7 +223,7 @@ def XNORConv2d(dim=[0, 1], quant_input=False, stride=1, padding=1, dilation=1, g
             input, weight, mean, bias = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             go = _fused._dense(grad_output)
-            mfma = (_fused.BWD_CONV_MFMA and ctx.taps is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
+            mfma = (_fused._cfg("BWD_CONV_MFMA") and ctx.taps is not None and go.is_cuda and go.dtype == torch.float32 and groups == 1
                     and not isinstance(padding, str))
             if ctx.needs_input_grad[0]:
                 if mfma:

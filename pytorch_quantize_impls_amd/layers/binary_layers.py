@@ -85,10 +85,10 @@ def _eval_linear(layer, input, kind):
         _fused.note_library_path(input, "eval-mode weight off the quantiser's grid")
         return torch.nn.functional.linear(input, layer.weight, layer.bias)
     K, N = input.shape[-1], layer.weight.shape[0]
-    impl = _fused.ops.select_gemm_impl(_fused.GEMM_IMPL, input.numel() // max(K, 1), N, K)
+    impl = _fused.ops.select_gemm_impl(_fused._cfg("GEMM_IMPL"), input.numel() // max(K, 1), N, K)
     xp, flag = _fused.activation_planes(input, layer.binary_input, impl, layer.weight)
     if xp is None:
-        if _fused.FLOAT_PATH == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
+        if _fused._cfg("FLOAT_PATH") == "bf16x3" and input.dtype == torch.float32 and input.numel() > 0:
             wt = layer._eval_planes(lambda w2: _fused.ops.weight_bf16x3(w2, kind), key="bf16x3")
             return _fused.ops.float_linear(input, layer.weight, kind, layer.bias, weight_triples=wt)
         _fused.note_library_path(input, "eval-mode linear on a real-valued activation with the float route switched off")

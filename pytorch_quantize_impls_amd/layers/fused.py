@@ -919,7 +919,7 @@ def link_nib_planes(mods) -> None:
     for a, b in zip(mods, mods[1:]):
         if isinstance(a, (FusedConvPoolBnSign, PackedMaxPool)):
             a.out_nib_halo = None
-            if (_fused.PAD_PLANES and isinstance(b, FusedConvPoolBnSign) and not getattr(a, "flatten_hwc", False)):
+            if (_fused._cfg("PAD_PLANES") and isinstance(b, FusedConvPoolBnSign) and not getattr(a, "flatten_hwc", False)):
                 a.out_nib_halo = tuple(int(v) for v in ops._pairs(b.conv.padding))
 
 

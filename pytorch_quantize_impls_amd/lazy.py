@@ -920,7 +920,7 @@ def conv_forward(layer, input, kind: str):
         n = input._qt
         if n.signed and not n.flat and _conv_can_defer(layer, _ShapeOnly(n.shape)):
             from .functions import _fused
-            act = n.force(tuple(int(v) for v in ops._pairs(layer.padding)) if _fused.PAD_PLANES else None)
+            act = n.force(tuple(int(v) for v in ops._pairs(layer.padding)) if _fused._cfg("PAD_PLANES") else None)
         input = act if act is not None else n.materialise()
     if enabled() and _conv_can_defer(layer, input):
         N, C, H, W = (int(v) for v in input.shape)

@@ -26,6 +26,43 @@ IM2COL_MAX_BYTES = 1 << 30
 #: nothing is materialised).  False: explicit packed-domain im2col + GEMM (kept for A/B and as a fallback).
 CONV_IMPLICIT = True
 
+# ---- route switches: process-wide DEFAULTS (the module attributes: tools and tests may set them) + per-thread overrides ------------
+# ``with ops.scope(FIRST_DIRECT=False):`` changes what THIS thread's calls read and nothing else (two serving threads of one
+# process can hold different routes: SURVEY 8e "one process, one stream per device"); library code reads every switch through
+# ``_cfg``.  The autograd Functions of the package record the scope their forward ran under and re-open it around their backward
+# (functions.common.QtFunction), like ``float_split``.
+_SCOPED = ("FIRST_DIRECT", "CONV_IMPLICIT", "POPC_VARIANT", "CONV_VARIANT", "ASSUME_CODES_FIT", "PAD_PIXEL_PLANES")
+_scope_tls = threading.local()
+
+
+def _cfg(name: str):
+    ov = getattr(_scope_tls, "ov", None)
+    if ov is not None and name in ov:
+        return ov[name]
+    return globals()[name]
+
+
+def scope_overrides():
+    """The overrides an enclosing ``with scope(...)`` of this thread set (a dict), or None."""
+    return getattr(_scope_tls, "ov", None)
+
+
+@contextlib.contextmanager
+def scope(_overrides=None, **kw):
+    """Thread-local overrides of the route switches (names: ``_SCOPED``); nests; ``scope(None)`` is a no-op."""
+    if _overrides:
+        kw = {**_overrides, **kw}
+    bad = [k for k in kw if k not in _SCOPED]
+    if bad:
+        raise KeyError(f"not a scoped switch of ops: {bad} (known: {_SCOPED})")
+    prev = getattr(_scope_tls, "ov", None)
+    if kw:
+        _scope_tls.ov = {**(prev or {}), **kw}
+    try:
+        yield
+    finally:
+        _scope_tls.ov = prev
+
 
 @functools.lru_cache(maxsize=None)
 def inv_levels(bit_width: int) -> float:
@@ -226,8 +263,8 @@ def _conv_implicit(elem: int, pixels_words: torch.Tensor, N, H, W, Cw, kh, kw, g
         return BitPlanes(sign=plane, rows=M, K=Cout)
     y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
     with _on(dev):
-        if CONV_VARIANT:
-            _lib.call("qt_conv2d_implicit_variant", int(CONV_VARIANT), *head, _p(y), I(Cout), I(Cout), _stream(dev))
+        if _cfg("CONV_VARIANT"):
+            _lib.call("qt_conv2d_implicit_variant", int(_cfg("CONV_VARIANT")), *head, _p(y), I(Cout), I(Cout), _stream(dev))
         else:
             _lib.call("qt_conv2d_implicit", *head, _p(y), I(Cout), I(Cout), _stream(dev))
     return y
@@ -666,7 +703,7 @@ def xnor_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     with _on(dev):
         args = (_p(x.sign), int(x.ld), _p(w.sign), int(w.ld), _p(bias), _p(out), int(out.stride(0) if M > 1 else max(N, 1)),
                 int(M), int(N), int(K), _stream(dev))
-        v = POPC_VARIANT if variant is None else int(variant)
+        v = _cfg("POPC_VARIANT") if variant is None else int(variant)
         if v:
             _lib.call("qt_xnor_gemm_variant", int(v), *args)
         else:
@@ -689,8 +726,8 @@ def tern_gemm(x: BitPlanes, w: BitPlanes, bias: Optional[torch.Tensor] = None,
     with _on(dev):
         args = (_p(x.sign), int(x.ld), _p(w.mask), _p(w.sign), int(w.ld), _p(bias), _p(out),
                 int(out.stride(0) if M > 1 else max(N, 1)), int(M), int(N), int(K), _stream(dev))
-        if POPC_VARIANT:
-            _lib.call("qt_tern_gemm_variant", int(POPC_VARIANT), *args)
+        if _cfg("POPC_VARIANT"):
+            _lib.call("qt_tern_gemm_variant", int(_cfg("POPC_VARIANT")), *args)
         else:
             _lib.call("qt_tern_gemm", *args)
     return out
@@ -879,7 +916,7 @@ class CodePlanes:
         leaves the packed path).  Resolving the device flag synchronises once per tensor — unless the caller
         vouches for the range (ASSUME_CODES_FIT, e.g. activations clipped to [0, 1] as in the DoReFa paper:
         |q| <= 2^k - 1 <= 127 for k <= 7), which also makes such a forward hipGraph-capturable."""
-        if ASSUME_CODES_FIT:
+        if _cfg("ASSUME_CODES_FIT"):
             return True
         if self._usable is None:
             self._usable = self.overflow is None or int(self.overflow.item()) == 0
@@ -1154,7 +1191,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
     if isinstance(epi, BnEpilogue):
         # conv -> BatchNorm(eval, device arithmetic) -> fp32: one launch where the implicit kernel takes the shape, else two passes
         y = None
-        if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31) and not (PAD_PIXEL_PLANES and (ph or pw) and not (hy or hx)):
+        if _cfg("CONV_IMPLICIT") and max_abs_code * kh * kw * Cw * 4 < (1 << 31) and not (_cfg("PAD_PIXEL_PLANES") and (ph or pw) and not (hy or hx)):
             y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
                                ldA, bias, scale, scale_dev, Cout, epi=epi, in_halo=(hy, hx))
         if y is None:
@@ -1163,7 +1200,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
         return y
     if hy or hx:
         y = None
-        if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
+        if _cfg("CONV_IMPLICIT") and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
             y = _conv_implicit(1, pixels.codes, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wplanes.codes,
                                ldA, bias, scale, scale_dev, Cout, epi=epi, in_halo=(hy, hx))
         if y is not None:
@@ -1172,7 +1209,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
         inner = pixels.codes.view(N, H + 2 * hy, W + 2 * hx, -1)[:, hy:hy + H, hx:hx + W].contiguous()
         pixels = CodePlanes(codes=inner.view(N * H * W, -1), rows=N * H * W, K=pixels.K, inv_n=pixels.inv_n,
                             bit_width=pixels.bit_width, overflow=pixels.overflow)
-    if CONV_IMPLICIT and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
+    if _cfg("CONV_IMPLICIT") and max_abs_code * kh * kw * Cw * 4 < (1 << 31):
         if (isinstance(epi, CodeEpilogue) and (kh, kw, sh, sw, ph, pw, dh, dw) == (3, 3, 1, 1, 1, 1, 1, 1) and Cw * 4 in (64, 128)
                 and Cout % 64 == 0 and bias is None and epi.res_f32 is None
                 and H & (H - 1) == 0 and W & (W - 1) == 0 and W <= 128 and (N * H * W) % 128 == 0):
@@ -1187,7 +1224,7 @@ def conv2d_codes(pixels: CodePlanes, in_shape, wplanes: CodePlanes, kernel_hw, s
             if y is not None:
                 return y
         pc_, H_, W_, pad_ = pixels.codes, H, W, (ph, pw)
-        if PAD_PIXEL_PLANES and (ph or pw):
+        if _cfg("PAD_PIXEL_PLANES") and (ph or pw):
             pc_, H_, W_, pad_ = pad_pixel_plane(pixels.codes, N, H, W, (ph, pw)), H + 2 * ph, W + 2 * pw, (0, 0)
         y = _conv_implicit(1, pc_, N, H_, W_, Cw, kh, kw, ((sh, sw), pad_, (dh, dw)), wplanes.codes,
                            ldA, bias, scale, scale_dev, Cout, epi=epi)
@@ -1426,9 +1463,9 @@ def conv2d_nib(pixels: NibPlanes, in_shape, wplanes: NibPlanes, kernel_hw, bias=
     M = N * Ho * Wo
     dev = pixels.device
     bias = _check_bias(bias, Cout, dev)
-    if CONV_IMPLICIT:
+    if _cfg("CONV_IMPLICIT"):
         pw_, H_, W_, pad_ = pixels.words, H, W, (ph, pw)
-        if PAD_PIXEL_PLANES and (ph or pw):
+        if _cfg("PAD_PIXEL_PLANES") and (ph or pw):
             pw_, H_, W_, pad_ = pad_pixel_plane(pixels.words, N, H, W, (ph, pw)), H + 2 * ph, W + 2 * pw, (0, 0)
         y = _conv_implicit(0, pw_, N, H_, W_, Cw, kh, kw, ((sh, sw), pad_, (dh, dw)), wplanes.words,
                            ldA, bias, 1.0, None, Cout, epi=epi)
@@ -1747,7 +1784,8 @@ def float_split(mode: Optional[str]):
     two serving threads (one process, one stream per device: SURVEY 8e) can hold different modes at the same time without seeing
     each other's.  The backward of an autograd graph runs on the engine's own thread, which cannot see the forward thread's
     override — so every autograd.Function of the package records the override at forward time and re-opens it around its backward
-    (functions.common.QtFunction), i.e. a graph is differentiated under the mode it was built under.  Library code never opens a
+    (functions.common.QtFunction), i.e. a graph is differentiated under the mode it was built under — a scope opened only around
+    ``loss.backward()`` is NOT seen by a graph that was built outside it (set ``ops.FLOAT_SPLIT`` for that).  Library code never opens a
     scope: layers that need the exact route pass ``terms=3`` to float_linear / float_conv2d explicitly (Lin / Log layers)."""
     if mode is not None and mode not in ("f16x2", "bf16x3"):
         raise ValueError(f"FLOAT_SPLIT must be 'f16x2' or 'bf16x3', got {mode!r}")
@@ -2133,7 +2171,7 @@ def float_conv2d(x: Optional[torch.Tensor], weight: torch.Tensor, kind: str, bia
     if out_scale_dev is not None:
         _require(out_scale_dev.detach(), "out_scale_dev")
     sdev = px.scale_dev_with(out_scale_dev)
-    if CONV_IMPLICIT:
+    if _cfg("CONV_IMPLICIT"):
         y = _conv_implicit(px.elem, px.data, N, H, W, Cw, kh, kw, ((sh, sw), (ph, pw), (dh, dw)), wt.data, ldA, bias,
                            float(out_scale), sdev, Cout, epi=epi)
         if y is not None:
@@ -2940,7 +2978,7 @@ def first_direct_cp(C: int, S: int) -> int:
 def first_direct_applicable(C: int, kernel_hw, stride, padding, dilation) -> bool:
     (sh, sw), (dh, dw) = _pairs(stride), _pairs(dilation)
     kh, kw = (int(v) for v in kernel_hw)
-    if not (FIRST_DIRECT and sh == sw and sh >= 2 and (dh, dw) == (1, 1) and not isinstance(padding, str) and kh >= sh and kw >= sw):
+    if not (_cfg("FIRST_DIRECT") and sh == sw and sh >= 2 and (dh, dw) == (1, 1) and not isinstance(padding, str) and kh >= sh and kw >= sw):
         return False
     cp = first_direct_cp(C, sh)
     return int(C) <= 4 and cp <= 8 and kw * cp <= 256 and kh <= 64

@@ -175,7 +175,7 @@ class CodeActivation:
 
     def check(self):
         from . import ops
-        if not ops.ASSUME_CODES_FIT and self.codes.overflow is not None and int(self.codes.overflow.item()) != 0:
+        if not ops._cfg("ASSUME_CODES_FIT") and self.codes.overflow is not None and int(self.codes.overflow.item()) != 0:
             raise RuntimeError("a DoReFa activation code exceeded int8 (|q| > 127 or NaN) inside the fused code-plane "
                                "path: run this model module by module (the fp32 route keeps unclamped activations)")
         return self
@@ -189,7 +189,7 @@ class CodeActivation:
         if check:
             self.check()
         from . import ops
-        flagged = not ops.ASSUME_CODES_FIT
+        flagged = not ops._cfg("ASSUME_CODES_FIT")
         if len(self.shape) == 4:
             N, _, H, W = self.shape
             return ops.codes_to_f32(self.codes, N, H, W, self.halo, 1, flagged).permute(0, 3, 1, 2)
@@ -204,4 +204,4 @@ class CodeActivation:
             self.check()
         from . import ops
         N, _, H, W = self.shape
-        return ops.codes_to_f32(self.codes, N, H, W, self.halo, int(kernel_size), not ops.ASSUME_CODES_FIT).permute(0, 3, 1, 2)
+        return ops.codes_to_f32(self.codes, N, H, W, self.halo, int(kernel_size), not ops._cfg("ASSUME_CODES_FIT")).permute(0, 3, 1, 2)

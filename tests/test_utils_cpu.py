@@ -207,3 +207,34 @@ def test_detect_scope_and_float_split_are_thread_local():
     with pytest.raises(ValueError):
         with _fused.detect_scope("sometimes"):
             pass
+
+
+def test_route_switch_scopes_are_thread_local_and_validated():
+    """ops.scope / functions._fused.scope: per-thread overrides of the module-level route switches; the module
+    attributes stay the process-wide defaults; an unknown name is an error; a second thread does not see the first one's scope."""
+    import threading
+    from pytorch_quantize_impls_amd import ops
+    from pytorch_quantize_impls_amd.functions import _fused
+    assert ops._cfg("FIRST_DIRECT") is True and _fused._cfg("GEMM_IMPL") == "auto"
+    seen = {}
+    with ops.scope(FIRST_DIRECT=False, POPC_VARIANT=3), _fused.scope(GEMM_IMPL="valu"):
+        assert ops._cfg("FIRST_DIRECT") is False and ops._cfg("POPC_VARIANT") == 3 and _fused._cfg("GEMM_IMPL") == "valu"
+        with ops.scope(FIRST_DIRECT=True):
+            assert ops._cfg("FIRST_DIRECT") is True and ops._cfg("POPC_VARIANT") == 3          # nests
+        assert ops._cfg("FIRST_DIRECT") is False
+        t = threading.Thread(target=lambda: seen.update(a=ops._cfg("FIRST_DIRECT"), b=_fused._cfg("GEMM_IMPL")))
+        t.start()
+        t.join()
+        assert ops.FIRST_DIRECT is True and _fused.GEMM_IMPL == "auto"                          # the defaults were not touched
+    assert seen == {"a": True, "b": "auto"}
+    assert ops._cfg("FIRST_DIRECT") is True and ops.scope_overrides() is None
+    import pytest as _pt
+    with _pt.raises(KeyError):
+        with ops.scope(NOT_A_SWITCH=1):
+            pass
+    prev = ops.FIRST_DIRECT
+    try:
+        ops.FIRST_DIRECT = False                                                                 # the process-wide default still works
+        assert ops._cfg("FIRST_DIRECT") is False
+    finally:
+        ops.FIRST_DIRECT = prev
