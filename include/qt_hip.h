@@ -569,6 +569,19 @@ int qt_f16x2_absmax_scale_f32(const float* x, int64_t n, uint32_t* work, float* 
  * later call that is ordered behind this one on the same stream (calls on different streams need different buffers). */
 int64_t qt_abs_mean_work_words(void);
 int qt_abs_mean_f32(const float* x, int64_t n, uint32_t* work, float* out, qt_stream_t stream);
+/* Stride-1 3 x 3 / padding-1 FIRST LAYER on a real-valued fp32 image (<= 4 channels, any strides) with 64 output channels, one pass
+ * over the image (csrc/conv_first3x3.hip; VGG-16's conv1_1 as TerConv2d / BinConv2d: layers/terner_layers.py:89-92,
+ * binary_layers.py:103-106 — the reference's F.conv2d(x, Q(W), b, 1, 1)).  The 34 x 34-pixel patch of a 32 x 32 output tile is split
+ * into two fp16 terms with the tile's own power-of-two scale (|x - s (hi + lo)| <= max(2^-22 |x|, 2^-39 tilemax)); weights +-1 / 0.
+ *   wfrag : qt_conv3x3_first_pack_weight_f32 of the QUANTISED weight [Cout <= 64, C, 3, 3] (element strides), 6144 bytes.
+ *   mode 0: out = fp32 [N*H*W, ldo] (+ bias);  mode 1: threshold bits [N*H*W, 4 words], bit c = ((conv + bias) * alpha[c] < -beta[c]);
+ *   mode 2: the same predicate as the fp4 nibble plane [N*(H+2)*(W+2), 8 words] (-1 = 0xA, +1 = 0x2) with its 1-pixel zero halo —
+ *   the operand of the next 3 x 3 conv.  All three come from ONE accumulation order.  Cout != 64: QT_ERR_UNSUPPORTED. */
+int qt_conv3x3_first_pack_weight_f32(const float* wq, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w, int64_t C,
+                                     int64_t Cout, uint32_t* wfrag, qt_stream_t stream);
+int qt_conv3x3_first_f32(const float* x, int64_t stride_n, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t N, int64_t C,
+                         int64_t H, int64_t W, const uint32_t* wfrag, int64_t Cout, const float* bias, const float* alpha,
+                         const float* beta, void* out, int64_t ldo, int mode, qt_stream_t stream);
 int qt_f16x2_absmax_pack_f32(const float* x, int64_t rows, int64_t K, uint32_t* work, const float* mul_dev, float* scale3, uint16_t* out,
                              int64_t ld_bytes, qt_stream_t stream);
 int qt_f16x2_pack_f32(const float* x, int64_t ldx, const float* scale2, uint16_t* out, int64_t ld_bytes, int64_t rows,

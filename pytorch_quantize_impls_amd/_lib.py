@@ -120,6 +120,8 @@ SIGNATURES = {
     "qt_f16x2_scale_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p]),
     "qt_f16x2_absmax_work_words": (_c_i64, []),
     "qt_f16x2_absmax_scale_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "qt_conv3x3_first_pack_weight_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+    "qt_conv3x3_first_f32": (_c_int, [_c_p] + [_c_i64] * 8 + [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_int, _c_p]),
     "qt_code_digits_f32": (_c_int, [_c_p, _c_i64, _c_f32, _c_p, _c_p, _c_p, _c_int, _c_p]),
     "qt_digit_combine_f32": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_f32, _c_p, _c_i64, _c_p]),
     "qt_abs_mean_work_words": (_c_i64, []),

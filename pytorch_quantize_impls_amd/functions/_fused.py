@@ -399,6 +399,28 @@ def quant_conv2d_forward(input, weight, bias, stride, padding, dilation, groups,
         N, C, H, W = input.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         Ho, Wo = ops.conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+        if kind in ("binary", "ternary") and ops.first3x3_applicable(C, int(weight.shape[0]), (kh, kw), stride, padding, dilation) and \
+                (epi is None or isinstance(epi, (tuple, ops.NibEpilogue))):
+            # stride-1 3 x 3 first layer, 64 output channels (VGG-16's conv1_1): the one-pass kernel reads the fp32 image where it lies
+            # (per-tile fp16 split in LDS) and serves all three epilogues from one accumulation — fp32 here for the module-by-module
+            # execution, threshold bits / the next conv's nibble halo plane for the fused chain: same bits at ties by construction
+            fw = weight_triples_fn("first3x3") if weight_triples_fn is not None else None
+            if fw is None:
+                wq = weight_q if weight_q is not None else quantize_weight_f32(weight, kind)
+                fw = ops.pack_first3x3_weight(wq)
+            nib_epi = epi if isinstance(epi, ops.NibEpilogue) else None
+            e3 = epi if (epi is None or (nib_epi is not None and tuple(nib_epi.out_halo) == (1, 1) and not nib_epi.d2s_cout)) else \
+                ((nib_epi.alpha, nib_epi.beta) if nib_epi is not None else epi[:2])
+            y2 = ops.conv_first3x3(input, fw, int(weight.shape[0]), bias, epi=e3)
+            if y2 is not None:
+                if epi is not None:
+                    if nib_epi is not None and isinstance(y2, ops.BitPlanes):
+                        y2 = ops.bits_to_nib_pad(y2, N, Ho, Wo, nib_epi.out_halo, ld=ops.pixel_ld_nib(y2.K))
+                    return y2, (N, int(weight.shape[0]), Ho, Wo)
+                y = y2.view(N, Ho, Wo, weight.shape[0]).permute(0, 3, 1, 2)
+                if input.is_contiguous() and not input.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous()
+                return y
         if ops.first_direct_applicable(C, (kh, kw), stride, padding, dilation):
             # (both epilogues on ONE route: the threshold bits of the fused / deferred chain must come from the very accumulators
             # the fp32 output of the module-by-module execution shows, or the two executions differ at ties.  The kernel's fp32

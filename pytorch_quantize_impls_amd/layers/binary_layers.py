@@ -134,6 +134,8 @@ class BinConv2d(EvalSwapMixin, torch.nn.Conv2d, QLayer):
         weight for real-valued inputs: 'plain' -> TriplePlanes; 's2d' -> (transformed weight shape, TriplePlanes) for the
         space-to-depth form."""
         ops = _fused.ops
+        if form == "first3x3":         # MFMA row fragments of the one-pass 3 x 3 first-layer kernel (ops.pack_first3x3_weight)
+            return self._eval_planes(lambda _w2: ops.pack_first3x3_weight(self.weight.detach()), key="first3x3")
         if form == "first_direct":     # fragment-ordered fp16 weight of the direct first-layer kernel (ops.pack_first_layer_weight)
             return self._eval_planes(lambda _w2: ops.pack_first_layer_weight(self.weight.detach(), self.stride[0]), key="first_direct")
         terms = ops.split_terms(terms)

@@ -532,6 +532,20 @@ class FusedConvPoolBnSign(torch.nn.Module):
                 wp = conv._eval_planes(lambda _w2: ops.pack_conv_weight_nib(conv.weight.detach(), self.kind), key="conv_nib")
             if planes is not None:
                 pass
+            elif (self.kind in ("binary", "ternary") and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
+                    and conv.groups == 1 and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+                    and ops.first3x3_applicable(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                                                conv.dilation)):
+                # VGG-style first layer (3 -> 64, 3 x 3): one pass from the fp32 image to threshold bits / the next conv's nibble
+                # plane (csrc/conv_first3x3.hip) — the same kernel, hence the same accumulators, as the module-by-module fp32 result
+                N, C, H, W = (int(v) for v in x.shape)
+                e2 = ops.NibEpilogue(epi[0], epi[1], (1, 1)) if (nib_out and not pooled and tuple(self.out_nib_halo) == (1, 1)) else (epi[0], epi[1])
+                planes = ops.conv_first3x3(x, conv._conv_triples("first3x3"), conv.out_channels, conv.bias, epi=e2)
+                shape = (N, conv.out_channels, H, W)
+                if isinstance(planes, ops.NibPlanes):
+                    return packed.PackedActivation(None, shape, nib=planes, halo=(1, 1))
+                if planes is not None and nib_out and not pooled:
+                    planes = ops.bits_to_nib_pad(planes, N, H, W, self.out_nib_halo, ld=ops.pixel_ld_nib(planes.K))
             elif (DIRECT_FIRST_LAYER and x.dim() == 4 and x.dtype == torch.float32 and conv.binary_input is False
                     and (not nib_out or pooled or tuple(self.out_nib_halo) == (1, 1))
                     and ops.direct_first_layer_applicable(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride,

@@ -31,7 +31,7 @@ CONV_IMPLICIT = True
 # process can hold different routes: SURVEY 8e "one process, one stream per device"); library code reads every switch through
 # ``_cfg``.  The autograd Functions of the package record the scope their forward ran under and re-open it around their backward
 # (functions.common.QtFunction), like ``float_split``.
-_SCOPED = ("FIRST_DIRECT", "CONV_IMPLICIT", "POPC_VARIANT", "CONV_VARIANT", "ASSUME_CODES_FIT", "PAD_PIXEL_PLANES")
+_SCOPED = ("FIRST_DIRECT", "CONV_IMPLICIT", "POPC_VARIANT", "CONV_VARIANT", "ASSUME_CODES_FIT", "PAD_PIXEL_PLANES", "FIRST_3X3")
 _scope_tls = threading.local()
 
 
@@ -3042,6 +3042,61 @@ def conv_first_direct(x: torch.Tensor, fw: FirstLayerWeights, bias=None, stride=
     with _on(dev):
         _lib.call("qt_conv_first_direct_f32", *head, _p(y), int(fw.Cout), _stream(dev))
     return y
+
+
+#: stride-1 3 x 3 / padding-1 first layers with <= 4 real-valued input channels and 64 output channels (VGG-16's conv1_1) run on
+#: the one-pass kernel of csrc/conv_first3x3.hip (fp32 image in, fp32 / threshold bits / the next conv's nibble halo plane out)
+FIRST_3X3 = True
+
+
+def first3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation) -> bool:
+    return (_cfg("FIRST_3X3") and tuple(int(v) for v in kernel_hw) == (3, 3) and _pairs(stride) == (1, 1) and _pairs(padding) == (1, 1)
+            and _pairs(dilation) == (1, 1) and 1 <= int(C) <= 4 and int(Cout) == 64)
+
+
+def pack_first3x3_weight(wq: torch.Tensor) -> torch.Tensor:
+    """[64, C <= 4, 3, 3] QUANTISED weight image (fp32, values exact in fp16: +-1 / 0) -> the MFMA row fragments of
+    qt_conv3x3_first_f32 (int32 [1536]); cached by eval-mode layers."""
+    wq = _require(wq.detach(), "weight")
+    Cout, C, kh, kw = (int(v) for v in wq.shape)
+    if (kh, kw) != (3, 3) or not 1 <= C <= 4 or Cout > 64:
+        raise ValueError("pack_first3x3_weight takes a [<= 64, <= 4, 3, 3] weight")
+    frag = torch.empty((3 * 2 * 64 * 4,), dtype=torch.int32, device=wq.device)
+    with _on(wq.device):
+        _lib.call("qt_conv3x3_first_pack_weight_f32", _p(wq), *(int(v) for v in wq.stride()), C, Cout, _p(frag), _stream(wq.device))
+    return frag
+
+
+def conv_first3x3(x: torch.Tensor, wfrag: torch.Tensor, Cout: int, bias=None, epi=None):
+    """conv2d(x, Q(W), b, stride 1, padding 1) of a real-valued [N, C <= 4, H, W] fp32 image (any storage order) with a 3 x 3 kernel
+    and 64 output channels in one pass.  ``epi`` None: the NHWC result [N*H*W, 64] fp32; (alpha, beta): BitPlanes of the
+    BatchNorm-threshold bits; NibEpilogue (halo (1, 1)): the next conv's nibble halo plane.  None outside the kernel's limits."""
+    _require(x, "input")
+    N, C, H, W = (int(v) for v in x.shape)
+    if N == 0 or N * (H + 2) >= (1 << 31) or int(Cout) != 64:
+        return None
+    dev = x.device
+    bias = _check_bias(bias, Cout, dev)
+    head = (_p(x), *(int(v) for v in x.stride()), N, C, H, W, _p(wfrag), int(Cout), _p(bias))
+    if epi is None:
+        y = torch.empty((N * H * W, Cout), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv3x3_first_f32", *head, None, None, _p(y), int(Cout), 0, _stream(dev))
+        return y
+    nib = isinstance(epi, NibEpilogue)
+    if nib and (tuple(epi.out_halo) != (1, 1) or epi.d2s_cout):
+        return None
+    alpha, beta = (epi.alpha, epi.beta) if nib else epi[:2]
+    alpha, beta = _check_bias(alpha, Cout, dev), _check_bias(beta, Cout, dev)
+    if nib:
+        out = torch.empty((N * (H + 2) * (W + 2), 8), dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.call("qt_conv3x3_first_f32", *head, _p(alpha), _p(beta), _p(out), 8, 2, _stream(dev))
+        return NibPlanes(words=out, rows=int(out.shape[0]), K=Cout)
+    out = torch.empty((N * H * W, 4), dtype=torch.int32, device=dev)
+    with _on(dev):
+        _lib.call("qt_conv3x3_first_f32", *head, _p(alpha), _p(beta), _p(out), 4, 1, _stream(dev))
+    return BitPlanes(sign=out, rows=N * H * W, K=Cout)
 
 
 def s2d_applicable(C: int, kh: int, kw: int, stride, dilation, padding=0) -> bool:

@@ -277,3 +277,76 @@ def test_linear_grad_input_operand_from_one_pack_kernel(dev):
             finally:
                 _fused.LINEAR_GRAD_X_ONE_PACK = True
         assert torch.equal(grads[0], grads[1])
+
+
+# ---- the one-pass 3 x 3 first-layer kernel (csrc/conv_first3x3.hip: VGG-16's conv1_1) -----------------------------------------------
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 32, 32), (3, 3, 45, 70), (1, 1, 7, 5), (2, 4, 64, 33), (4, 3, 224, 224)])
+@pytest.mark.parametrize("cl", [True, False])
+def test_first3x3_kernel_all_three_epilogues(dev, N, C, H, W, cl):
+    """fp32 result within 1e-5 of the fp64 conv (normalised; two fp16 terms per tile), and the threshold bits / the nibble halo plane
+    are EXACTLY the float predicate ((y_kernel + 0) * alpha < -beta on the kernel's own fp32 result) for slopes of both signs,
+    zero and NaN — one accumulation serves all three; the halo of the nibble plane is zero; any image layout."""
+    from pytorch_quantize_impls_amd import ops
+    torch.manual_seed(N * 1000 + C * 100 + H + W)
+    x = torch.randn(N, C, H, W, device=dev) * 2.5
+    x[0, 0, : min(H, 6), : min(W, 6)] *= 300.0                                        # tiles with very different scales
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-1, 2, (64, C, 3, 3), device=dev).float()
+    bias = torch.randn(64, device=dev)
+    frag = ops.pack_first3x3_weight(wq)
+    y = ops.conv_first3x3(x, frag, 64, bias)
+    assert y is not None and tuple(y.shape) == (N * H * W, 64)
+    ref = torch.nn.functional.conv2d(x.double(), wq.double(), bias.double(), 1, 1).permute(0, 2, 3, 1).reshape(N * H * W, 64)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-5, err
+    alpha = torch.randn(64, device=dev)
+    alpha[3], alpha[10], alpha[20] = 0.0, float("nan"), -0.0
+    beta = torch.randn(64, device=dev) * 3
+    beta[3], beta[4] = -1.0, float("inf")
+    y0 = ops.conv_first3x3(x, frag, 64, None)                                         # the accumulation without the bias
+    want = ((y0 + bias) * alpha < -beta)                                              # [N*H*W, 64] bool: the epilogue's float predicate
+    bits = ops.conv_first3x3(x, frag, 64, bias, epi=(alpha, beta))
+    got = ((bits.sign.view(N * H * W, 4)[:, :2].unsqueeze(-1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1).bool().reshape(N * H * W, 64)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert not bits.sign.view(N * H * W, 4)[:, 2:].any()
+    nib = ops.conv_first3x3(x, frag, 64, bias, epi=ops.NibEpilogue(alpha, beta, (1, 1)))
+    plane = nib.words.view(N, H + 2, W + 2, 8)
+    inner = plane[:, 1:-1, 1:-1, :].reshape(N * H * W, 8)
+    nibbles = ((inner.unsqueeze(-1) >> (4 * torch.arange(8, device=dev, dtype=torch.int32))) & 0xF).reshape(N * H * W, 64)
+    assert torch.equal(nibbles == 0xA, want) and torch.equal(nibbles == 0x2, ~want)
+    border = plane.clone()
+    border[:, 1:-1, 1:-1, :] = 0
+    assert not border.any()
+
+
+def test_vgg_first_layer_module_and_fused_routes_share_the_first3x3_kernel(dev):
+    """TerConv2d(3, 64, 3, padding=1) on a real-valued image: the module-by-module fp32 result, the deferred chain and the explicit
+    fused block all run qt_conv3x3_first_f32; the chain's signs are the signs BatchNorm of the fp32 result has."""
+    from pytorch_quantize_impls_amd import _lib, lazy
+    from pytorch_quantize_impls_amd.functions import BinaryConnect
+    from pytorch_quantize_impls_amd.layers import TerConv2d
+    torch.manual_seed(9)
+    conv = TerConv2d(3, 64, 3, padding=1).to(dev)
+    conv.weight.data.uniform_(-1.2, 1.2)
+    conv.binary_input = False
+    conv2 = TerConv2d(64, 64, 3, padding=1).to(dev)
+    conv2.weight.data.uniform_(-1.2, 1.2)
+    bn = torch.nn.BatchNorm2d(64).to(dev)
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2.0)
+    bn.weight.data.normal_()
+    bn.bias.data.normal_()
+    seq = torch.nn.Sequential(conv, bn, torch.nn.Hardtanh(), BinaryConnect(), conv2).eval()
+    x = torch.randn(3, 3, 40, 56, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        c0 = _lib.call_counts["qt_conv3x3_first_f32"]
+        with lazy.eager():
+            want = seq(x)
+        assert _lib.call_counts["qt_conv3x3_first_f32"] == c0 + 1
+        got = seq(x)
+        if isinstance(got, lazy.LazyActivation):
+            got = got.value()
+        assert _lib.call_counts["qt_conv3x3_first_f32"] == c0 + 2
+    assert torch.equal(got, want)
