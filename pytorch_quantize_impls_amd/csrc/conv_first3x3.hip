@@ -22,6 +22,8 @@
 // bits): 0 = fp32 NHWC (+ bias); 1 = BatchNorm-threshold bits; 2 = the next conv's fp4 nibble plane with a 1-pixel zero halo.
 // The threshold of a channel is found once per workgroup by bisection over the ordered fp32 values with the float epilogue's own
 // arithmetic ((u + bias) * alpha < -beta: exactly the predicate of qt_conv2d_implicit_bits / conv_first_direct).
+#include <cstdlib>
+#include <type_traits>
 #include "qt_common.h"
 
 namespace {
@@ -60,12 +62,16 @@ __device__ __forceinline__ v16f f3_mfma(const uint4& a, const uint4& b, v16f c) 
 // channel of accumulator register r of channel tile T in lane half h (see the header: rows are assigned so that this is 32 h + 16 T + r)
 __device__ __forceinline__ int f3_channel(int h, int T, int r) { return 32 * h + 16 * T + r; }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
+// NC = channels a patch pixel keeps in registers: 3 (C <= 3: VGG) or 4
+// OCC = workgroups per CU the register budget is sized for: 2 = the patch of the next tile in flight across the MFMA rows and two
+// accumulator sets (intra-wave overlap), 4 = neither (128 registers: four waves per SIMD hide the latencies instead)
+template <int MODE, int NC, int OCC>
+__global__ __launch_bounds__(256, OCC) void first3x3_kernel(F3Args a) {
     __shared__ __attribute__((aligned(16))) _Float16 plane[2][F3_PLANE];     // hi | lo
     __shared__ float red[8];
     __shared__ float thr_s[64];
     __shared__ unsigned flip_s[64];
+    __shared__ __attribute__((aligned(16))) float tht_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
 
@@ -123,42 +129,66 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
             }
             wA[ky][T] = f;
         }
-    float thr[2][16];
-    float bia[2][16];
+    [[maybe_unused]] float bia[2][16];
+    if (MODE == 0) {
 #pragma unroll
-    for (int T = 0; T < 2; ++T)
+        for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            thr[T][r] = MODE != 0 ? thr_s[f3_channel(h, T, r)] : 0.0f;
-            bia[T][r] = (MODE == 0 && a.bias) ? a.bias[f3_channel(h, T, r)] : 0.0f;
-        }
+            for (int r = 0; r < 16; ++r) bia[T][r] = a.bias ? a.bias[f3_channel(h, T, r)] : 0.0f;
+    }
 
+    // smallest non-zero and largest finite |theta| over the 64 channels (the same in every lane: `fast` below is workgroup-uniform)
+    [[maybe_unused]] float tsafe_lo = 3.402823466e38f, tsafe_hi = 0.0f;
+    if (MODE != 0) {
+        for (int c = 0; c < 64; ++c) {
+            const float t = fabsf(thr_s[c]);
+            if (t > 0.0f && t < tsafe_lo) tsafe_lo = t;                 // (inf counts: inf / s stays inf)
+            if (t <= 3.402823466e38f && t > tsafe_hi) tsafe_hi = t;
+        }
+    }
     const int tpi = a.tiles_y * a.tiles_x;
     const int ntiles = a.N * tpi;
     // per-lane constants of the fragment reads: byte offset of this lane's run within a patch row
     const int boff = (j + 2 * h) * 8;
+    // the patch in flight: requested for tile t + 1 before the MFMA rows of tile t start (the loads' HBM latency sits under them)
+    float v[F3_PPT][NC];
+    // 32-bit element offsets within an image (the launcher checked that an image spans < 2^31 elements)
+    const int sc1 = (int)a.sc, sc2 = 2 * (int)a.sc;
+    [[maybe_unused]] const int sc3 = 3 * (int)a.sc;
+    auto issue_patch = [&](int tile_) __attribute__((always_inline)) {
+        const int img_ = tile_ / tpi, trem_ = tile_ - img_ * tpi;
+        const int ty_ = trem_ / a.tiles_x, tx_ = trem_ - ty_ * a.tiles_x;
+        const int yb = ty_ * F3_T, xb = tx_ * F3_T;
+        const float* xi = a.x + (int64_t)img_ * a.sn + ((int64_t)yb * a.sh + (int64_t)xb * a.sw);      // uniform
+#pragma unroll
+        for (int i = 0; i < F3_PPT; ++i) {
+            const int pi = tid + 256 * i, pr_ = pi / F3_P, pp_ = pi - pr_ * F3_P;
+            const int iy = yb - 1 + pr_, ix = xb - 1 + pp_;
+            const bool ok = (i < F3_PPT - 1 || pi < F3_NPIX) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const float* p = xi + (ok ? (pr_ - 1) * (int)a.sh + (pp_ - 1) * (int)a.sw : 0);
+            // (a pixel outside the image reads the tile's own origin pixel — inside the image — and is zeroed)
+            const float f0 = p[0], f1 = a.C > 1 ? p[sc1] : 0.0f, f2 = a.C > 2 ? p[sc2] : 0.0f;
+            v[i][0] = ok ? f0 : 0.0f;
+            v[i][1] = ok ? f1 : 0.0f;
+            v[i][2] = ok ? f2 : 0.0f;
+            if constexpr (NC == 4) {
+                const float f3 = a.C > 3 ? p[sc3] : 0.0f;
+                v[i][3] = ok ? f3 : 0.0f;
+            }
+        }
+    };
+    if (OCC == 2 && (int)blockIdx.x < ntiles) issue_patch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (OCC != 2) issue_patch(tile);
         const int img = tile / tpi, trem = tile - img * tpi;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * F3_T, x0 = tx * F3_T;
-        // ---- patch: image -> registers, max|x| ---------------------------------------------------------------------------------------
-        float v[F3_PPT][4];
+        // ---- patch: max|x| of the registers ----------------------------------------------------------------------------------------
         unsigned mx = 0;
-        const float* xi = a.x + (int64_t)img * a.sn;
 #pragma unroll
-        for (int i = 0; i < F3_PPT; ++i) {
-            const int pi = tid + 256 * i;
-            const int pr = pi / F3_P, pp = pi - pr * F3_P;
-            const int iy = y0 - 1 + pr, ix = x0 - 1 + pp;
-            const bool ok = pi < F3_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const float* p = xi + (ok ? (int64_t)iy * a.sh + (int64_t)ix * a.sw : 0);
+        for (int i = 0; i < F3_PPT; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float f = (ok && c < a.C) ? p[(int64_t)c * a.sc] : 0.0f;
-                v[i][c] = f;
-                mx = max(mx, __float_as_uint(f) & 0x7fffffffu);
-            }
-        }
+            for (int c = 0; c < NC; ++c) mx = max(mx, __float_as_uint(v[i][c]) & 0x7fffffffu);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
         __syncthreads();                               // every wave is past the previous tile's fragment reads (and red[] reads)
@@ -178,12 +208,12 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
 #pragma unroll
         for (int i = 0; i < F3_PPT; ++i) {
             const int pi = tid + 256 * i;
-            if (pi < F3_NPIX) {
+            if (i < F3_PPT - 1 || pi < F3_NPIX) {
                 const int pr = pi / F3_P, pp = pi - pr * F3_P;
                 h4 hi4, lo4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float t = v[i][c] * inv;
+                    const float t = (c < NC ? v[i][c < NC ? c : 0] : 0.0f) * inv;
                     const _Float16 hh = (_Float16)t;
                     hi4[c] = hh;
                     lo4[c] = (_Float16)(t - (float)hh);
@@ -192,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
                 *reinterpret_cast<h4*>(&plane[1][pr * F3_PITCH + pp * 4]) = lo4;
             }
         }
-        __syncthreads();
 
         // ---- this wave's 8 output rows -----------------------------------------------------------------------------------------------
         const unsigned char* ph = reinterpret_cast<const unsigned char*>(&plane[0][0]) + boff;
@@ -206,14 +235,27 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
             bh = make_uint4(h0.x, h0.y, h ? 0u : h1.x, h ? 0u : h1.y);
             bl = make_uint4(l0.x, l0.y, h ? 0u : l1.x, h ? 0u : l1.y);
         };
+        // u = acc * s against theta  <=>  acc against theta / s — one multiply per CHANNEL and tile instead of one per value — as long
+        // as theta / s is exact: no finite theta may overflow, no non-zero theta may fall into the subnormals (tsafe_lo / tsafe_hi: the
+        // lane's smallest non-zero and largest finite |theta|).  Wave-uniform; the slow form multiplies every accumulator.
+        // (the per-tile thresholds go through LDS — 64 floats, read back as broadcast ds_read_b128 in the epilogue — instead of 32
+        //  more registers per lane: with the two accumulator sets the kernel is at the 256-register limit of two waves per SIMD)
+        [[maybe_unused]] bool fast = false;
+        if (MODE != 0) {
+            fast = !(tsafe_lo * inv < 1.17549435e-38f) && tsafe_hi * inv <= 3.402823466e38f;
+            if (tid < 64) tht_s[tid] = fast ? thr_s[tid] * inv : thr_s[tid];
+        }
+        __syncthreads();
+        if (OCC == 2 && tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x);
+        const float* tht = &tht_s[32 * h];
         const int r0 = wave * 8;
         uint4 bh[3], bl[3];
         load_b(r0, bh[0], bl[0]);
         load_b(r0 + 1, bh[1], bl[1]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            load_b(r0 + i + 2, bh[(i + 2) % 3], bl[(i + 2) % 3]);
-            v16f acc[2];
+        // the MFMAs of row i + 1 are issued BEFORE the epilogue of row i (two accumulator sets): the matrix pipe works on the next
+        // row while this wave's VALU packs the current one — with one set the wave alternated 12 MFMAs / ~100 VALU, each waiting
+        // for the other
+        auto mfma_row = [&](int i, v16f (&acc)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 v16f z;
@@ -229,6 +271,23 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int T = 0; T < 2; ++T) acc[T] = f3_mfma(wA[ky][T], bl[(i + ky) % 3], acc[T]);
+        };
+        v16f accs[OCC == 2 ? 2 : 1][2];
+        load_b(r0 + 2, bh[2], bl[2]);
+        if (OCC == 2) mfma_row(0, accs[0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OCC == 2) {
+                if (i < 7) {
+                    load_b(r0 + i + 3, bh[(i + 3) % 3], bl[(i + 3) % 3]);  // (slot of patch row r0 + i: row i's MFMAs are issued)
+                    mfma_row(i + 1, accs[(i + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (i > 0) load_b(r0 + i + 2, bh[(i + 2) % 3], bl[(i + 2) % 3]);
+                mfma_row(i, accs[0]);
+            }
+            v16f (&acc)[2] = accs[OCC == 2 ? (i & 1) : 0];
             const int y = y0 + r0 + i, x = x0 + j;
             const bool inside = y < a.H && x < a.W;
             if (MODE == 0) {
@@ -248,17 +307,21 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
                 }
             } else if (MODE == 2) {
                 uint32_t w[4];
+                auto pack = [&](auto fc) __attribute__((always_inline)) {
+                    constexpr bool FAST = decltype(fc)::value;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t ww = 0;
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t ww = 0;
 #pragma unroll
-                    for (int n = 7; n >= 0; --n) {
-                        const int T = q >> 1, r = 8 * (q & 1) + n;
-                        const float u = acc[T][r] * sc;                   // exact (power of two)
-                        ww = (ww << 4) | (u < thr[T][r] ? 0xAu : 0x2u);   // fp4 -1 : +1
+                        for (int n = 7; n >= 0; --n) {
+                            const int T = q >> 1, r = 8 * (q & 1) + n;
+                            const float u = FAST ? acc[T][r] : acc[T][r] * sc;      // (acc * s is exact: a power of two)
+                            ww = (ww << 4) | (u < tht[16 * T + r] ? 0xAu : 0x2u);         // fp4 -1 : +1
+                        }
+                        w[q] = ww;
                     }
-                    w[q] = ww;
-                }
+                };
+                if (fast) pack(std::true_type{}); else pack(std::false_type{});
                 if (inside) {
                     uint32_t* o = reinterpret_cast<uint32_t*>(a.out) +
                                   ((int64_t)(img * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.ldo + 4 * h;
@@ -266,12 +329,16 @@ __global__ __launch_bounds__(256, 2) void first3x3_kernel(F3Args a) {
                 }
             } else {
                 uint32_t ww = 0;
+                auto pack = [&](auto fc) __attribute__((always_inline)) {
+                    constexpr bool FAST = decltype(fc)::value;
 #pragma unroll
-                for (int b = 31; b >= 0; --b) {
-                    const int T = b >> 4, r = b & 15;
-                    const float u = acc[T][r] * sc;
-                    ww = (ww << 1) | (u < thr[T][r] ? 1u : 0u);
-                }
+                    for (int b = 31; b >= 0; --b) {
+                        const int T = b >> 4, r = b & 15;
+                        const float u = FAST ? acc[T][r] : acc[T][r] * sc;
+                        ww = (ww << 1) | (u < tht[16 * T + r] ? 1u : 0u);
+                    }
+                };
+                if (fast) pack(std::true_type{}); else pack(std::false_type{});
                 const uint32_t other = (uint32_t)__shfl_xor((int)ww, 32);
                 if (inside && h == 0) {
                     uint32_t* o = reinterpret_cast<uint32_t*>(a.out) + ((int64_t)(img * a.H + y) * a.W + x) * a.ldo;
@@ -355,6 +422,10 @@ int qt_conv3x3_first_f32(const float* x, int64_t stride_n, int64_t stride_c, int
     if (mode != 0 && (!alpha || !beta)) return QT_ERR_INVALID_ARG;
     if (!qt_aligned16(wfrag) || !qt_aligned16(out)) return QT_ERR_ALIGNMENT;
     if (mode == 0 ? (ldo < 64 || (ldo & 3)) : (mode == 1 ? ldo != 4 : ldo != 8)) return QT_ERR_ALIGNMENT;
+    {
+        auto mag = [](int64_t v) { return v < 0 ? -v : v; };
+        if ((H + 2) * mag(stride_h) + (W + 2) * mag(stride_w) + 4 * mag(stride_c) >= (1ll << 31)) return QT_ERR_UNSUPPORTED;   // 32-bit offsets
+    }
     if (N * (H + 2) >= (1ll << 31) || W + 2 >= (1ll << 30) || N * (H + 2) * (W + 2) * ldo >= (1ll << 40)) return QT_ERR_UNSUPPORTED;
     F3Args a;
     a.x = x; a.sn = stride_n; a.sc = stride_c; a.sh = stride_h; a.sw = stride_w;
@@ -367,9 +438,24 @@ int qt_conv3x3_first_f32(const float* x, int64_t stride_n, int64_t stride_c, int
     if (ntiles >= (1ll << 31)) return QT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));      // persistent: two workgroups per CU
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL(first3x3_kernel<0>, grid, dim3(256), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL(first3x3_kernel<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(first3x3_kernel<2>, grid, dim3(256), 0, st, a);
+    // three workgroups per CU without the register-hungry pipelining beat two with it: 174 vs 212 us inside the C5 graph, batch 256
+    // (tools/probes/c5_graph_kernels.py).  QT_F3_OCC=2 (tools only, read once): the pipelined form.
+    static const int occ = [] { const char* e = getenv("QT_F3_OCC"); return e ? atoi(e) : 3; }();
+    const dim3 grid4((unsigned)(ntiles < 768 ? ntiles : 768));
+#define QT_F3(M)                                                                                         \
+    do {                                                                                                 \
+        if (occ == 3) {                                                                                  \
+            if (C <= 3) hipLaunchKernelGGL((first3x3_kernel<M, 3, 3>), grid4, dim3(256), 0, st, a);    \
+            else hipLaunchKernelGGL((first3x3_kernel<M, 4, 3>), grid4, dim3(256), 0, st, a);           \
+        } else {                                                                                         \
+            if (C <= 3) hipLaunchKernelGGL((first3x3_kernel<M, 3, 2>), grid, dim3(256), 0, st, a);     \
+            else hipLaunchKernelGGL((first3x3_kernel<M, 4, 2>), grid, dim3(256), 0, st, a);            \
+        }                                                                                                \
+    } while (0)
+    if (mode == 0) QT_F3(0);
+    else if (mode == 1) QT_F3(1);
+    else QT_F3(2);
+#undef QT_F3
     return qt_check_launch();
 }
 
