@@ -3050,8 +3050,9 @@ FIRST_3X3 = True
 
 
 def first3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation) -> bool:
-    return (_cfg("FIRST_3X3") and tuple(int(v) for v in kernel_hw) == (3, 3) and _pairs(stride) == (1, 1) and _pairs(padding) == (1, 1)
-            and _pairs(dilation) == (1, 1) and 1 <= int(C) <= 4 and int(Cout) == 64)
+    # (two fp16 terms per tile: only under the default two-term split — ops.float_split("bf16x3") asks for the exact route)
+    return (_cfg("FIRST_3X3") and split_terms(None) == 2 and tuple(int(v) for v in kernel_hw) == (3, 3) and _pairs(stride) == (1, 1)
+            and _pairs(padding) == (1, 1) and _pairs(dilation) == (1, 1) and 1 <= int(C) <= 4 and int(Cout) == 64)
 
 
 def pack_first3x3_weight(wq: torch.Tensor) -> torch.Tensor:

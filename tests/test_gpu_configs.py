@@ -249,7 +249,8 @@ def test_c5_ternary_vgg16_fused_matches_unfused(dev):
         # ... and conv1 (real input, fp16 pair planes), conv2 (-> bits) and conv3 (-> nibbles) take the direct 3x3 kernel
         # (conv4, 128 -> 128 with a bit-plane output, is as fast on the implicit GEMM)
         assert used.get("qt_conv2d_implicit_bits") == 4 and used.get("qt_conv2d_implicit_nib") == 6, used
-        assert used.get("qt_conv3x3_direct_nib") == 2 and used.get("qt_conv3x3_direct_pairs") == 1, used   # (conv1: fp16 pair pixels)
+        # (conv1, real input 3 -> 64: since round 6 the one-pass kernel qt_conv3x3_first_f32 — fp32 image in, nibble halo plane out)
+        assert used.get("qt_conv3x3_direct_nib") == 2 and used.get("qt_conv3x3_first_f32") == 1 and "qt_conv3x3_direct_pairs" not in used, used
         assert used.get("qt_pool_bits_nib") == 4 and used.get("qt_pool_bits") == 1, used
         assert "qt_bits_to_nib_pad" not in used, used               # no bit plane is expanded in a second pass
         with lazy.eager():

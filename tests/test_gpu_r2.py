@@ -301,9 +301,11 @@ def test_direct_first_layer_vs_oracle_chain(dev, oracle):
     alpha, beta = (n(t) for t in fold_batchnorm(bn))
     wq = oracle.ternarize(w)
     # both splits of the image: fp16 pair pixels (the default since round 4: two taps per MFMA) and the exact bf16 triples
-    for mode, entry in (("f16x2", "qt_conv3x3_direct_pairs"), ("bf16x3", "qt_conv3x3_direct_nib")):
+    # (round 6: under the two-term split a 3 -> 64 first layer takes the one-pass kernel qt_conv3x3_first_f32; the pair-plane
+    #  direct kernel it replaced is pinned by switching the new route off)
+    for mode, entry in (("f16x2", "qt_conv3x3_first_f32"), ("f16x2-pairs", "qt_conv3x3_direct_pairs"), ("bf16x3", "qt_conv3x3_direct_nib")):
         blk = FusedConvPoolBnSign(conv, bn)
-        with torch.no_grad(), ops.float_split(mode), used(entry):
+        with torch.no_grad(), ops.float_split(mode.split("-")[0]), ops.scope(FIRST_3X3=(mode != "f16x2-pairs")), used(entry):
             act = blk(g(x, dev).contiguous(memory_format=torch.channels_last))
         got = _decode(act).numpy()
         for img in (0, N - 1):
@@ -413,7 +415,8 @@ def test_c5_fused_vgg16_layerwise_at_224(dev):
                 h_cpu, h_gpu = y_cpu, blk(h_gpu)
         assert ci == len(cmods) and flips <= 4, flips
     used_ = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
-    assert used_.get("qt_conv3x3_direct_nib", 0) + used_.get("qt_conv3x3_direct_pairs", 0) >= 3, used_    # conv1 (real input), conv2, conv3 take the direct kernel
+    # conv1 (real input): the one-pass first-layer kernel; conv2, conv3: the direct 3 x 3 kernel on nibble halo planes
+    assert used_.get("qt_conv3x3_first_f32", 0) >= 1 and used_.get("qt_conv3x3_direct_nib", 0) >= 2, used_
 
 
 def test_c3_fused_alexnet_layerwise(dev):
