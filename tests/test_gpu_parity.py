@@ -912,9 +912,11 @@ def test_fused_first_layer_conv_bits_match_fp32_route(dev):
             ref = FusedPoolBnSign(bn, mp)(conv(x))
         # strided first layers: the direct kernel (round 4), both epilogues; stride 1: the implicit GEMM on bf16 triples
         ran = {k_: _lib.call_counts[k_] - before.get(k_, 0) for k_ in ("qt_conv2d_implicit_bits", "qt_conv_first_direct_bits_f32",
-                                                                      "qt_conv2d_implicit", "qt_conv_first_direct_f32")}
+                                                                      "qt_conv2d_implicit", "qt_conv_first_direct_f32",
+                                                                      "qt_conv3x3_first_f32")}
+        # (3 -> 64, 3 x 3, stride 1: the one-pass first-layer kernel of round 6, threshold-bit and fp32 epilogue of ONE accumulation)
         assert (ran["qt_conv_first_direct_bits_f32"] == 1 and ran["qt_conv_first_direct_f32"] == 1) if st > 1 else \
-            (ran["qt_conv2d_implicit_bits"] == 1 and ran["qt_conv2d_implicit"] == 1), ran
+            ran["qt_conv3x3_first_f32"] == 2, ran
         assert act.shape == ref.shape and torch.equal(act.planes.sign, ref.planes.sign)
 
 

@@ -315,6 +315,8 @@ def test_real_input_conv_both_splits_vs_fp64(dev, N, Cin, Cout, H, k, s, p, cl, 
     with torch.no_grad(), lazy.eager(), ops.float_split(mode):
         y = conv(x)
     pk = "qt_f16x2" if mode == "f16x2" else "qt_bf16x3"
+    if mode == "f16x2" and (Cin, Cout, k, s, p) == (3, 64, 3, 1, 1):
+        pk = "qt_conv3x3_first_f32"        # round 6: the one-pass first-layer kernel splits its patch in LDS (no pack entry point)
     assert any(k2.startswith(pk) and v > before.get(k2, 0) for k2, v in _lib.call_counts.items()), mode
     ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), s, p)
     assert norm_err(n(y), n(ref)) <= (2e-6 if mode == "f16x2" else TOL), norm_err(n(y), n(ref))
