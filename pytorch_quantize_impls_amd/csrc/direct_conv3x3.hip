@@ -85,7 +85,7 @@ struct D3Args {
     const float* beta;
     uint32_t* out;
     long long total;          // N * Hp * Wp positions
-    int H, W, Hp, Wp, Cout, ldw, ldo, out_bits;
+    int H, W, Hp, Wp, Cout, ldw, ldo, out_bits, buf_ok;
     unsigned long long magic_plane, magic_wp;   // ceil(2^64 / (Hp*Wp)), ceil(2^64 / Wp): exact 32-bit quotients
     // EL == 1 (int8 code planes, DoReFa code epilogue as qt_conv2d_implicit_codes; out = int8 halo plane, ldo in BYTES)
     float scale, rscale, levels;
@@ -102,7 +102,7 @@ constexpr int D3_TM = 256, D3_RUN = D3_TM + 2;
 template <int CPP, int TNW, int WN, int OCC, int EL>
 __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     constexpr int NT = 256 * WN;
-    constexpr bool I8 = EL == 1, BF16 = EL == 2, F16 = EL == 3;
+    constexpr bool I8 = EL == 1, BF16 = EL == 2, F16 = EL == 3, FP4 = EL == 0;
     static_assert(!F16 || CPP == 1, "fp16 pair pixels are one 16-byte chunk");
     using acc_t = typename std::conditional<I8, d3_v16i, d3_v16f>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -115,11 +115,71 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     // conflict-free ds_read_b128 of 8 consecutive pixels: spread their chunk over the 128-byte bank line
     auto swz = [](int px) { return (px * CPP / 8) & (CPP - 1); };
 
+    // ---- +-1 / 0 activations (FP4): the accumulators are exact integers, so the threshold test needs no compare at all (round 6).
+    // bit = (u < theta) with u an integer  <=>  u - (ceil(theta) - 1/2) < 0: the accumulators START at -(ceil(theta) - 1/2) (exact: every
+    // partial sum is a half-integer below 2^23, or |theta| is so large that no rounding can change the sign) and the bit is the SIGN BIT of
+    // the result.  The weights are the MFMA's ROW operand here (rows assigned to channels so that lane half h, register r = channel
+    // 16 h + r of a 32-channel block): a lane holds 16 channels of ONE position and collects their sign bits with one v_alignbit per value —
+    // the ballot + two v_writelane per accumulator register of the first form made this kernel VALU-bound (15.6 VALU per MFMA, 265 us of
+    // VALU issue against 128 us of matrix time at VGG conv1_2: profiles/r6_c5_direct_conv.md).  Channels with a negative slope get their
+    // weights negated in LDS (-u < -theta').
+    float* cinit_s = reinterpret_cast<float*>(smem + WBYTES + 3 * D3_RUN * CPP * 16);          // [TNW * WN * 32]
+    unsigned* flip_s = reinterpret_cast<unsigned*>(cinit_s + TNW * WN * 32);
+    if constexpr (FP4) {
+        for (int n = tid; n < TNW * WN * 32; n += NT) {
+            float ci = 1.0e30f;                                           // channel beyond Cout: acc' > 0, bit 0
+            unsigned fl = 0u;
+            if (n < g.Cout) {
+                const float alv = g.alpha[n], nbv = -g.beta[n], bvv = g.bias ? g.bias[n] : 0.0f;
+                auto key2f = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+                auto pred = [&](unsigned k) { const float u = key2f(k); const float v = u + bvv; return v * alv < nbv; };
+                const unsigned klo = 0x007fffffu, khi = 0xff800000u;      // keys of -inf, +inf
+                float th;
+                if (!(alv > 0.0f) && !(alv < 0.0f)) {
+                    th = (alv == 0.0f && 0.0f < nbv) ? __uint_as_float(0x7f800000u) : __uint_as_float(0xff800000u);
+                } else if (alv > 0.0f) {
+                    unsigned lo = klo, hi = khi;
+                    while (lo < hi) {
+                        const unsigned mid = lo + ((hi - lo) >> 1);
+                        if (!pred(mid)) hi = mid; else lo = mid + 1;
+                    }
+                    th = key2f(lo);
+                } else {
+                    fl = 1u;
+                    if (!pred(khi)) {
+                        th = __uint_as_float(0xff800000u);
+                    } else {
+                        unsigned lo = klo, hi = khi;
+                        while (lo < hi) {
+                            const unsigned mid = lo + ((hi - lo) >> 1);
+                            if (pred(mid)) hi = mid; else lo = mid + 1;
+                        }
+                        th = -key2f(lo - 1);
+                    }
+                }
+                // bit <=> u < th (u integer): start value -(ceil(th) - 0.5); th = +inf: always (start -> -huge), -inf / NaN: never
+                if (th >= 3.0e38f) ci = -1.0e30f;                       // always: acc' = acc - 1e30 < 0
+                else if (!(th > -3.0e38f)) ci = 1.0e30f;              // never (th = -inf)
+                else ci = -(ceilf(th) - 0.5f);
+            }
+            cinit_s[n] = ci;
+            flip_s[n] = fl;
+        }
+        __syncthreads();
+    }
     // weights: resident for the whole launch
     for (int e = tid; e < TNW * WN * 32 * 9 * CPP; e += NT) {
         const int row = e / (9 * CPP), c = e - row * (9 * CPP);
+        int src = row;
+        if constexpr (FP4) {                       // LDS row (block, i) = MFMA row i of the block = channel 16 ((i / 4) % 2) + 4 (i / 8) + i % 4
+            const int i = row & 31;
+            src = (row & ~31) + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+        }
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < g.Cout) v = *reinterpret_cast<const uint4*>(g.Wm + (long long)row * g.ldw + c * 16);
+        if (src < g.Cout) v = *reinterpret_cast<const uint4*>(g.Wm + (long long)src * g.ldw + c * 16);
+        if constexpr (FP4) {
+            if (flip_s[src]) { v.x ^= 0x88888888u; v.y ^= 0x88888888u; v.z ^= 0x88888888u; v.w ^= 0x88888888u; }
+        }
         *reinterpret_cast<uint4*>(wl + row * WROW + c * 16) = v;
     }
     if constexpr (F16) {     // the row's 16 pad bytes are tap slot 9 (the odd tap's partner): zero weights
@@ -150,7 +210,9 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     // as -u < -theta' (e_sg flips the sign of u).  Was: add, multiply, compare per accumulator register
     [[maybe_unused]] float e_th[TNW];
     [[maybe_unused]] unsigned e_sg[TNW];
-    if constexpr (!I8) {
+    // FP4: this lane's start values (channel (wave_n TNW + b) 32 + 16 lhalf + r) are re-read from LDS per tile — 16 TNW registers
+    // more pushed the kernel into scratch (470 us instead of 278 at VGG conv1_2)
+    if constexpr (!I8 && !FP4) {
 #pragma unroll
         for (int b = 0; b < TNW; ++b) {
             const float alv = al[b], nbv = nbe[b], bvv = bv[b];
@@ -191,8 +253,33 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     // path): NLD 16-byte loads per thread, issued right after the barrier that publishes the current patch
     constexpr int NLD = (3 * D3_RUN * CPP + NT - 1) / NT;
     uint4 pre[NLD];
+    // the input plane as a BUFFER (planes below 2 GiB: g.buf_ok): a thread's NLD chunk offsets relative to the tile's first run are
+    // tile-invariant registers, the tile's base is a scalar, chunks outside the plane (the runs of the first / last positions) come
+    // back as zeros from the bounds check — the 64-bit clamp-and-multiply address chain of the pointer form was 246 VALU instructions per
+    // tile and thread, almost half of what made this kernel VALU-bound (profiles/r6_c5_direct_conv.md)
+    typedef unsigned d3_u4 __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] unsigned voff[NLD];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.P), 0, g.buf_ok ? (int)(g.total * CPP * 16) : 0, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = tid + k * NT;
+        const int run = e / (D3_RUN * CPP), rem = e - run * (D3_RUN * CPP);
+        voff[k] = e < 3 * D3_RUN * CPP ? (unsigned)((run * g.Wp) * CPP * 16 + rem * 16) : 0x80000000u;
+    }
     auto fetch = [&](long long t) {
         const long long q0n = t * D3_TM;
+        if (g.buf_ok) {
+            // byte offset of position q0n - Wp - 1 (the first chunk of run 0): may be "negative" — 32-bit wrap-around puts exactly the
+            // chunks in front of the plane beyond its extent
+            const unsigned soff = (unsigned)((q0n - g.Wp - 1) * CPP * 16);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const d3_u4 v = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(voff[k] + soff), 0, 0);
+                pre[k] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int e = tid + k * NT;
@@ -229,7 +316,10 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
 #pragma unroll
             for (int b = 0; b < TNW; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (FP4) acc[a][b][r] = cinit_s[(wave_n * TNW + b) * 32 + 16 * lhalf + r];
+                    else acc[a][b][r] = 0;
+                }
         if constexpr (F16) {
 #pragma unroll
             for (int p_ = 0; p_ < 5; ++p_) {
@@ -271,7 +361,7 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                     for (int b = 0; b < TNW; ++b) {
                         if constexpr (I8) acc[a][b] = d3_mfma_i8(xf[a], wf[b], acc[a][b]);
                         else if constexpr (BF16) acc[a][b] = d3_mfma_bf16(xf[a], wf[b], acc[a][b]);
-                        else acc[a][b] = d3_mfma(xf[a], wf[b], acc[a][b]);
+                        else acc[a][b] = d3_mfma(wf[b], xf[a], acc[a][b]);     // FP4: weights = rows (channels), positions = columns
                     }
             }
         }
@@ -369,6 +459,14 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     #pragma unroll
                 for (int b = 0; b < TNW; ++b) {
                     uint32_t myword = 0;
+                    if constexpr (FP4) {
+                        // this lane: position lrow of block a, channels 16 lhalf .. + 15 of column block b: sign bits, channel r -> bit r
+                        uint32_t w16 = 0;
+    #pragma unroll
+                        for (int r = 15; r >= 0; --r) w16 = __builtin_amdgcn_alignbit(w16, __float_as_uint(acc[a][b][r]), 31);
+                        const uint32_t other = (uint32_t)__shfl_xor((int)w16, 32);
+                        myword = lhalf ? ((w16 << 16) | (other & 0xFFFFu)) : ((other << 16) | (w16 & 0xFFFFu));
+                    } else {
     #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned long long mask = __ballot(__uint_as_float(__float_as_uint(acc[a][b][r]) ^ e_sg[b]) < e_th[b]);
@@ -376,6 +474,7 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                         // gfx950 does not interlock a VALU-written SGPR read by the next VALU: see mfma_gemm.hip
                         asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mask), "n"(R));
                         asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mask >> 32)), "n"(R + 4));
+                    }
                     }
                     const int bg = wave_n * TNW + b;                            // column block of the whole tile
                     if (lane < 32 && q < g.total) {
@@ -407,7 +506,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
 
 template <int CPP, int TNW, int WN, int OCC, int EL = 0>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
-    const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16 + (EL == 1 ? 4 * WN * 4096 : 0);
+    const int lds = TNW * WN * 32 * (9 * CPP * 16 + 16) + 3 * D3_RUN * CPP * 16 + (EL == 1 ? 4 * WN * 4096 : 0) +
+                    (EL == 0 ? TNW * WN * 32 * 8 : 0);                    // EL 0: + the start values and flip flags per channel
     static QtLdsOnce once;
     if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL>), lds) != QT_OK) return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
@@ -437,6 +537,7 @@ extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int
     g.bias = bias; g.alpha = alpha; g.beta = beta; g.out = out;
     g.H = (int)H; g.W = (int)W; g.Hp = (int)H + 2; g.Wp = (int)W + 2;
     g.total = N * (int64_t)g.Hp * g.Wp;
+    g.buf_ok = g.total * (int64_t)(Cw * 4) < (1ll << 31) ? 1 : 0;
     g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldo; g.out_bits = out_bits ? 1 : 0;
     g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;     // divisors >= 9: ceil(2^64 / d)
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
@@ -469,6 +570,7 @@ extern "C" int qt_conv3x3_direct_pairs(const uint32_t* P, int64_t N, int64_t H, 
     g.bias = bias; g.alpha = alpha; g.beta = beta; g.out = out;
     g.H = (int)H; g.W = (int)W; g.Hp = (int)H + 2; g.Wp = (int)W + 2;
     g.total = N * (int64_t)g.Hp * g.Wp;
+    g.buf_ok = g.total * (int64_t)16 < (1ll << 31) ? 1 : 0;
     g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldo; g.out_bits = out_bits ? 1 : 0;
     g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
@@ -503,6 +605,7 @@ extern "C" int qt_conv3x3_direct_codes(const uint32_t* P, int64_t N, int64_t H, 
     g.bias = bias; g.alpha = alpha; g.beta = beta; g.out = reinterpret_cast<uint32_t*>(codes);
     g.H = (int)H; g.W = (int)W; g.Hp = (int)H + 2; g.Wp = (int)W + 2;
     g.total = N * (int64_t)g.Hp * g.Wp;
+    g.buf_ok = g.total * (int64_t)(Cw * 4) < (1ll << 31) ? 1 : 0;
     g.Cout = (int)Cout; g.ldw = (int)(ldw * 4); g.ldo = (int)ldc_bytes; g.out_bits = 0;
     g.magic_plane = ~0ull / (unsigned long long)(g.Hp * g.Wp) + 1;
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
