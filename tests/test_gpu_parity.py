@@ -1445,7 +1445,12 @@ def test_first_layer_output_blocked_form_equals_direct_form(dev, monkeypatch, ki
                                                (128, 128, 2, 12, 12, "binary"), (128, 40, 1, 5, 7, "ternary"),
                                                (64, 100, 5, 33, 6, "binary"), (40, 64, 2, 8, 8, "ternary"),
                                                (64, 64, 1, 1, 1, "binary"), (128, 96, 2, 1, 5, "ternary"),
-                                               (64, 7, 3, 2, 1, "binary"), (64, 64, 40, 17, 19, "ternary")])
+                                               (64, 7, 3, 2, 1, "binary"), (64, 64, 40, 17, 19, "ternary"),
+                                               # planes at least 256 wide / high (the lean epilogue's one-compare carries),
+                                               # all four tile shapes of the fp4 kernel
+                                               (64, 64, 1, 3, 300, "binary"), (64, 128, 1, 300, 5, "ternary"),
+                                               (64, 64, 1, 257, 254, "binary"), (128, 64, 2, 2, 254, "ternary"),
+                                               (128, 128, 1, 4, 260, "binary"), (64, 128, 3, 254, 3, "binary")])
 def test_direct_conv3x3_equals_implicit_gemm(dev, monkeypatch, C, Cout, N, H, W, kind):
     """qt_conv3x3_direct_nib (input patch loaded once per tile, taps read from LDS) against the implicit-GEMM kernels:
     threshold bits and the next conv's nibble halo plane, bit for bit (incl. the halo the kernel writes itself)."""
