@@ -88,6 +88,7 @@ struct D3Args {
     long long total;          // N * Hp * Wp positions
     int H, W, Hp, Wp, Cout, ldw, ldo, out_bits, buf_ok;
     int epi32;                // fp4: the lean epilogue applies (whole 32-channel blocks, output plane below 4 GiB, no pad words)
+    unsigned out_bytes;       // of the output plane (epi32)
     unsigned m20_wp, m20_hp;  // ceil(2^20 / Wp), ceil(2^20 / Hp): exact quotients of numbers below 512 (planes narrower / lower than 256)
     unsigned long long magic_plane, magic_wp;   // ceil(2^64 / (Hp*Wp)), ceil(2^64 / Wp): exact 32-bit quotients
     // EL == 1 (int8 code planes, DoReFa code epilogue as qt_conv2d_implicit_codes; out = int8 halo plane, ldo in BYTES)
@@ -103,7 +104,7 @@ constexpr int d3_wrow(int cpp) { return 9 * cpp * 16 + (cpp == 1 ? 32 : 16); }  
 
 // CPP: 16-byte chunks per input pixel (Cin = 32 * CPP); a workgroup = 4 (position) x WN (column) waves, each wave owns
 // 64 positions x TNW 32-column blocks (Cout <= 32 * TNW * WN); OCC: waves per SIMD the register budget is sized for
-template <int CPP, int TNW, int WN, int OCC, int EL>
+template <int CPP, int TNW, int WN, int OCC, int EL, bool LEAN = false>
 __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     constexpr int NT = 256 * WN;
     constexpr bool I8 = EL == 1, BF16 = EL == 2, F16 = EL == 3, FP4 = EL == 0;
@@ -277,6 +278,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
         const int run = e / (D3_RUN * CPP), rem = e - run * (D3_RUN * CPP);
         voff[k] = e < 3 * D3_RUN * CPP ? (unsigned)((run * g.Wp) * CPP * 16 + rem * 16) : 0x80000000u;
     }
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t ors =          // the output plane (lean fp4 epilogue: 32-bit offsets)
+        __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(LEAN ? g.out_bytes : 0u), 0x00020000);
     auto fetch = [&](long long t) {
         const long long q0n = t * D3_TM;
         if (g.buf_ok) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
             if (__any(bad) && lane == 0) atomicOr(g.overflow, 1);
         } else {
             // ---- threshold epilogue (same arithmetic as mfma_gemm.hip: bit = fl((acc + bias) * alpha) < -beta) ----
-            if constexpr (FP4) if (g.epi32) {
+            if constexpr (FP4 && LEAN) {           // (its own instantiation: with both epilogues in one kernel the 3-per-CU tile spilled)
                 // The lean form (round 6, profiles/r6_c5_direct_conv.md): the general form below spends ~10 quarter-rate
                 // instructions (64-bit multiply-adds of the magic divisions and of the row addresses) per 32 positions and output
                 // word — with the matrix work this short that was as much SIMD time as the MFMAs.  Here the tile's first position
@@ -468,17 +471,15 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                 const long long left_ll = g.total - q0;
                 const int lim = left_ll < D3_TM ? (int)left_ll : D3_TM;
                 const bool wide = g.Wp >= 256, tall = g.Hp >= 256;
-                const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                    g.out, 0, (int)(g.out_bits ? (unsigned)((long long)g.total / ((long long)g.Hp * g.Wp) * g.H * g.W * g.ldo * 4)
-                                               : (unsigned)(g.total * g.ldo * 4)), 0x00020000);
     #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int off = wave * 64 + a * 32 + lrow;
                     const int t = x0 + off;
-                    const int k = wide ? (t >= g.Wp ? 1 : 0) : (int)(((unsigned)t * g.m20_wp) >> 20);
-                    const int x = t - k * g.Wp, yt = y0 + k;
-                    const int ky = tall ? (yt >= g.Hp ? 1 : 0) : (int)(((unsigned)yt * g.m20_hp) >> 20);
-                    const int y = yt - ky * g.Hp;
+                    // (24-bit multiplies: full rate; t, yt < 512 there, and k, ky <= 86)
+                    const int k = wide ? (t >= g.Wp ? 1 : 0) : (int)(__umul24((unsigned)t, g.m20_wp) >> 20);
+                    const int x = t - __mul24(k, g.Wp), yt = y0 + k;
+                    const int ky = tall ? (yt >= g.Hp ? 1 : 0) : (int)(__umul24((unsigned)yt, g.m20_hp) >> 20);
+                    const int y = yt - __mul24(ky, g.Hp);
                     const bool in = off < lim;
                     const bool valid = in && (unsigned)(y - 1) < (unsigned)g.H && (unsigned)(x - 1) < (unsigned)g.W;
                     if (g.out_bits) {
@@ -487,8 +488,10 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                         // the low half and block 2p + 1's in the high half; a second one brings a position's words together:
                         // 4 blocks -> 8 bytes per lane (words 0-1 low half, 2-3 high half), 2 blocks -> the low half stores the row
                         if constexpr (WN == 1 && (TNW == 2 || TNW == 4)) {
-                            const unsigned mrow = (unsigned)(mrow0 + off - 2 * k - 2 * g.W * ky);
-                            const unsigned vo = mrow * (unsigned)(g.ldo * 4);
+                            // row = mrow0 + off - 2 k - 2 W ky (a row carry skips 2 halo pixels, an image carry 2 halo rows): the
+                            // tile's part is a scalar product, the lane's part small enough for a 24-bit multiply
+                            const unsigned vo = (unsigned)mrow0 * (unsigned)(g.ldo * 4) +
+                                                (unsigned)__mul24(off - 2 * k - __mul24(2 * g.W, ky), g.ldo * 4);
                             uint32_t word[TNW / 2];
     #pragma unroll
                             for (int b = 0; b < TNW; b += 2) {
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                         // nibble halo plane: a lane owns 16 channels = 8 bytes of its position; nibble = sign << 3 | 2, zeros on the border.
                         // v_alignbit(w, acc, 28) shifts a nibble in whose top bit is the sign; the other three bits are masked at the end
                         const uint32_t msk = valid ? 0x88888888u : 0u, two = valid ? 0x22222222u : 0u;
-                        const unsigned vo = (uq0 + (unsigned)off) * (unsigned)(g.ldo * 4) + (unsigned)(wave_n * TNW * 16 + lhalf * 8);
+                        const unsigned vo = uq0 * (unsigned)(g.ldo * 4) + __umul24((unsigned)off, (unsigned)(g.ldo * 4)) +
+                                            (unsigned)(wave_n * TNW * 16 + lhalf * 8);
     #pragma unroll
                         for (int b = 0; b < TNW; ++b) {
                             uint32_t lo = 0, hi = 0;
@@ -599,16 +603,16 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
     }
 }
 
-template <int CPP, int TNW, int WN, int OCC, int EL = 0>
+template <int CPP, int TNW, int WN, int OCC, int EL = 0, bool LEAN = false>
 int d3_launch(const D3Args& g, int wg_per_cu, hipStream_t stream) {
     const int lds = TNW * WN * 32 * d3_wrow(CPP) + 3 * D3_RUN * CPP * 16 + (EL == 1 ? 4 * WN * 4096 : 0) +
                     (EL == 0 ? TNW * WN * 32 * 8 : 0);                    // EL 0: + the start values and flip flags per channel
     static QtLdsOnce once;
-    if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL>), lds) != QT_OK) return QT_ERR_LAUNCH;
+    if (qt_ensure_dyn_lds(once, reinterpret_cast<const void*>(direct3x3_kernel<CPP, TNW, WN, OCC, EL, LEAN>), lds) != QT_OK) return QT_ERR_LAUNCH;
     const long long ntiles = (g.total + D3_TM - 1) / D3_TM;
     const long long cap = 256ll * wg_per_cu;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC, EL>), dim3(grid), dim3(256 * WN), lds, stream, g);
+    hipLaunchKernelGGL((direct3x3_kernel<CPP, TNW, WN, OCC, EL, LEAN>), dim3(grid), dim3(256 * WN), lds, stream, g);
     return qt_check_launch();
 }
 
@@ -646,12 +650,17 @@ extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int
         const bool whole = Cout == 64 || Cout == 128;      // every column block of the tile shapes below is a real one
         const bool bits_ok = Cw == 8 && (Cout == 128 ? ldo == 4 : (ldo == 4 || ldo == 2));
         g.epi32 = (elem == 0 && !general && whole && out_bytes < (1ll << 32) && (!out_bits || bits_ok)) ? 1 : 0;
+        g.out_bytes = g.epi32 ? (unsigned)out_bytes : 0u;
         g.m20_wp = (unsigned)(((1u << 20) + g.Wp - 1) / g.Wp);
         g.m20_hp = (unsigned)(((1u << 20) + g.Hp - 1) / g.Hp);
     }
     hipStream_t s = (hipStream_t)stream;
     // LDS per workgroup: 44 / 64 KB (64 input channels), 87 / 125 KB (128)
     if (elem == 2) return Cout <= 64 ? d3_launch<2, 2, 1, 3, 2>(g, 3, s) : d3_launch<2, 4, 1, 2, 2>(g, 2, s);
+    if (g.epi32) {
+        if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3, 0, true>(g, 3, s) : d3_launch<2, 4, 1, 2, 0, true>(g, 2, s);
+        return Cout <= 64 ? d3_launch<4, 1, 2, 2, 0, true>(g, 1, s) : d3_launch<4, 2, 2, 2, 0, true>(g, 1, s);
+    }
     if (Cw == 8) return Cout <= 64 ? d3_launch<2, 2, 1, 3>(g, 3, s) : d3_launch<2, 4, 1, 2>(g, 2, s);
     return Cout <= 64 ? d3_launch<4, 1, 2, 2>(g, 1, s) : d3_launch<4, 2, 2, 2>(g, 1, s);
 }
@@ -682,7 +691,7 @@ extern "C" int qt_conv3x3_direct_pairs(const uint32_t* P, int64_t N, int64_t H, 
     g.magic_wp = ~0ull / (unsigned long long)g.Wp + 1;
     g.scale = 1.0f; g.scale_dev = scale_dev; g.rscale = 0.0f; g.levels = 0.0f; g.res_codes = nullptr; g.ldrc = 0; g.relu = 0;
     g.overflow = nullptr;
-    g.epi32 = 0; g.m20_wp = g.m20_hp = 0;
+    g.epi32 = 0; g.out_bytes = 0; g.m20_wp = g.m20_hp = 0;
     hipStream_t s = (hipStream_t)stream;
     return Cout <= 64 ? d3_launch<1, 2, 1, 3, 3>(g, 3, s) : d3_launch<1, 4, 1, 2, 3>(g, 2, s);
 }
@@ -719,6 +728,6 @@ extern "C" int qt_conv3x3_direct_codes(const uint32_t* P, int64_t N, int64_t H, 
     g.scale = scale; g.scale_dev = scale_dev; g.rscale = res_scale; g.levels = (float)((1 << bit_width) - 1);
     g.res_codes = reinterpret_cast<const unsigned char*>(res_codes); g.ldrc = (int)ldrc_bytes; g.relu = relu;
     g.overflow = overflow;
-    g.epi32 = 0; g.m20_wp = g.m20_hp = 0;
+    g.epi32 = 0; g.out_bytes = 0; g.m20_wp = g.m20_hp = 0;
     return d3_launch<4, 1, 2, 2, 1>(g, 1, (hipStream_t)stream);
 }
