@@ -324,6 +324,8 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
         __syncthreads();
         if (tile + 1 < t_end) fetch(tile + 1);
         acc_t acc[2][TNW];
+        constexpr bool CIN = FP4 && LEAN && CPP == 2;       // start values as the C operand of the first tap (no copies into both blocks)
+        if constexpr (!CIN) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -333,6 +335,50 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                     if constexpr (FP4) acc[a][b][r] = cinit_s[(wave_n * TNW + b) * 32 + 16 * lhalf + r];
                     else acc[a][b][r] = 0;
                 }
+        }
+        [[maybe_unused]] auto tap_step = [&](int i, int j, auto first) {
+            if constexpr (CIN) {
+            const int tap = i * 3 + j;
+#pragma unroll
+            for (int kk = 0; kk < CPP / 2; ++kk) {
+                const int c = kk * 2 + lhalf;
+                uint4 xf[2], wf[TNW];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int px = wave * 64 + a * 32 + lrow + j;
+                    xf[a] = *reinterpret_cast<const uint4*>(patch + ((i * D3_RUN + px) * CPP + (c ^ swz(px))) * 16);
+                }
+#pragma unroll
+                for (int b = 0; b < TNW; ++b)
+                    wf[b] = *reinterpret_cast<const uint4*>(wl + ((wave_n * TNW + b) * 32 + lrow) * WROW + (tap * CPP + c) * 16);
+                if constexpr (decltype(first)::value) {
+                    acc_t cin[TNW];
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) cin[b][r] = cinit_s[(wave_n * TNW + b) * 32 + 16 * lhalf + r];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b) acc[a][b] = d3_mfma(wf[b], xf[a], cin[b]);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b) acc[a][b] = d3_mfma(wf[b], xf[a], acc[a][b]);
+                }
+            }
+            }
+        };
+        if constexpr (CIN) {
+            tap_step(0, 0, std::true_type{});
+            tap_step(0, 1, std::false_type{});
+            tap_step(0, 2, std::false_type{});
+#pragma unroll 1
+            for (int i = 1; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tap_step(i, j, std::false_type{});
+        } else
         if constexpr (F16) {
 #pragma unroll
             for (int p_ = 0; p_ < 5; ++p_) {
