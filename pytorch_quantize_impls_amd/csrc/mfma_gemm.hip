@@ -498,6 +498,10 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     // ring of 3 / 4 stage buffers on the small-map tiles (ConvV128x128D / ConvV128x64D); QT_NO_CONV_DEEP_RING=1: the double-buffered
     // configurations of round 4 (A/B runs and the bit-identity test; read per call like the direct kernel's switches)
     const bool deep_ring = !getenv("QT_NO_CONV_DEEP_RING");
+    // weights-as-rows threshold epilogue (sign-bit form): fp4, integer thresholds, whole 32-channel blocks, bit plane or nibble plane
+    // out, no depth-to-space; QT_NO_SWAPT=1: the compare form (A/B runs and the bit-identity test; read per call like the line above)
+    const bool swapt = elem == 0 && epi.alpha && epi.thr && (Cout & 31) == 0 && !epi.d2s_cout && (epi.mode == 0 || epi.mode == 3) &&
+                       !getenv("QT_NO_SWAPT");
 #define QT_CONV(E)                                                                                              \
     do {                                                                                                        \
         const int tn = pick_tile_n(Cout);                                                                       \
@@ -519,7 +523,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
             /* a handful of K stages: a tile is all prologue + epilogue, so 2 co-resident 256x128 workgroups per CU */ \
             /* that overlap each other's beat the 1-per-CU ping-pong tiles (output-blocked first layers: K = 320 B) */ \
             if (g_conv_force == 0 && tn == 256 && kwords * 4 <= 1024)                                           \
-                return launch_cfg<ConvV128x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                return launch_cfg_t<ConvV128x2, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             /* a few big tiles on a small map (128 -> 256 stride 2 @ 16x16, K = 1152 B: 64 tiles of 256x256): 128x128 tiles */ \
             /* with the deep ring give every CU one                                                                        */ \
             if (g_conv_force == 0 && deep_ring && !epi.d2s_cout && ((M + 255) / 256) * ((Cout + tn - 1) / tn) <= 128 &&    \
@@ -527,16 +531,16 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                 return launch_cfg<ConvV128x128D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (g_conv_force != 1) {                                                                            \
                 if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
-                    return launch_cfg<ConvVPP192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
-                if (tn == 256) return launch_cfg<ConvVPP256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                    return launch_cfg_t<ConvVPP192, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                if (tn == 256) return launch_cfg_t<ConvVPP256, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 /* 192-wide tiles whose 384-row form wastes a round (576 -> 1152 @ 13x13): 256x192 ping-pong for long K */ \
                 if (tn == 192 && g_conv_force == 0 && kwords * 4 >= 2048)                                         \
-                    return launch_cfg<ConvVPP256x192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                    return launch_cfg_t<ConvVPP256x192, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             }                                                                                                   \
             if (g_conv_force == 0 && tn == 64 && kwords * 4 <= 1024)                                            \
                 return launch_cfg<ConvV64x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (g_conv_force == 0 && tn == 128 && kwords * 4 <= 1024)                                           \
-                return launch_cfg<ConvV128x2<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                return launch_cfg_t<ConvV128x2, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 256) return launch_cfg<ConvV256<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 192) return launch_cfg<ConvV192<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (tn == 128) return launch_cfg<ConvV128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \

@@ -215,6 +215,19 @@ struct ElemF16Taps : ElemF16 {      // real-valued operand (grad_x of an XNOR co
 struct ElemFp4TapsRows : ElemFp4Taps {
     static constexpr bool ROWS = true;
 };
+// Threshold-epilogue convs on exact-integer fp4 accumulators with the WEIGHTS as the MFMA row operand (round 6): E::mfma swaps its
+// operands and the weight fragment of MFMA row i is read from LDS row 16 ((i / 4) % 2) + 4 (i / 8) + i % 4 of its 32-row block, so
+// accumulator register r of lane (l % 32, l / 32) is (position l % 32, channel 16 (l / 32) + r): a lane owns 16 consecutive channels
+// of ONE output pixel.  The accumulators start at -(T_c - 1/2) (T_c = the integer threshold of EpiArgs::thr), so the threshold bit
+// is the accumulator's sign bit and the epilogue is one v_alignbit per value — no compare, no cross-lane gather, no nibble spread
+// (the v_cmp / v_writelane / spread8 form was 8 VALU instructions per value: 60 % of the kernel's VALU issue, and VALU and MFMA
+// issue add up on a SIMD: profiles/r6_threshold_epilogue.md).
+struct ElemFp4T : ElemFp4 {
+    static constexpr bool SWAPT = true;
+    __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) { return ElemFp4::mfma(b, a, c); }
+};
+template <class E, class = void> struct elem_swapt : std::false_type {};
+template <class E> struct elem_swapt<E, std::void_t<decltype(E::SWAPT)>> : std::bool_constant<E::SWAPT> {};
 template <class E, class = void> struct elem_rows : std::false_type {};
 template <class E> struct elem_rows<E, std::void_t<decltype(E::ROWS)>> : std::bool_constant<E::ROWS> {};
 
@@ -315,12 +328,33 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     }
 
     acc_t acc[C::TMW][C::TNW];
+    constexpr bool SWAPT = elem_swapt<E>::value;
+    if constexpr (SWAPT) {
+        // start values: acc < T (T an integer)  <=>  acc - (T - 1/2) < 0.  Channels past N: never stored
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int nb = n0 + (wave_n * C::TNW + b) * 32 + 16 * lhalf;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 t = make_float4(0, 0, 0, 0);
+                if (nb + r4 * 4 < N) t = *reinterpret_cast<const float4*>(epi.thr + nb + r4 * 4);      // N % 32 == 0 (host)
+                // acc < T <=> acc < ceil(T) for the integer acc; a NaN threshold compares false for every acc: start far above zero
+                auto start = [](float T) { return T == T ? 0.5f - ceilf(T) : 3.0e38f; };
+                const float c[4] = {start(t.x), start(t.y), start(t.z), start(t.w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < C::TMW; ++a) acc[a][b][r4 * 4 + e] = c[e];
+            }
+        }
+    } else {
 #pragma unroll
     for (int a = 0; a < C::TMW; ++a)
 #pragma unroll
         for (int b = 0; b < C::TNW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+    }
 
     unsigned long long dbg_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ABL == 5: cycle stamps of one mid-loop stage
     unsigned long long dbg_wall[5] = {0, 0, 0, 0, 0}, dbg_end = 0, dbg_loop0 = 0;
@@ -339,7 +373,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
         }
 #pragma unroll
         for (int b = 0; b < C::TNW; ++b) {
-            const int row = (wave_n * C::TNW + b) * 32 + lrow;
+            // (SWAPT: MFMA row i = channel 16 ((i / 4) % 2) + 4 (i / 8) + i % 4 of the block; the 16 lanes of every ds_read_b128
+            // group still hit 16 rows distinct mod 16)
+            const int row = (wave_n * C::TNW + b) * 32 + (SWAPT ? 16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3) : lrow);
             wf[b] = *reinterpret_cast<const uint4*>(ws + row * STAGE_BYTES + swz<STAGE_BYTES>(row, c) * 16);
         }
     };
@@ -799,6 +835,75 @@ __global__ __launch_bounds__(C::NTHREADS, C::WAVES_PER_SIMD) void mfma_gemm_kern
     // no DMA is in flight) and leaves as 4 dwordx4 wave-stores of 8 full 128-byte lines each: 4x fewer
     // store instructions.  LDS ops of one wave execute in issue order, so the patch needs no barrier.
     const bool wide = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    if constexpr (SWAPT) {
+        // ---- threshold epilogue, weights-as-rows form: lane (l % 32, l / 32) holds channels 16 (l / 32) .. + 15 of position l % 32 of
+        // every 32 x 32 block; the bit of channel r is the sign bit of register r (flipped where alpha < 0).  Host: epi.alpha and
+        // epi.thr set, N % 32 == 0, no depth-to-space; epi.mode == 3: the next conv's nibble plane, else the bit plane.
+        uint32_t* B = reinterpret_cast<uint32_t*>(Y);
+        // alpha < 0 per channel of block b, as the bit-plane word (uniform) and as this lane's two nibble words | the magnitude bits
+        uint32_t negw[C::TNW], nn[C::TNW][2];
+#pragma unroll
+        for (int b = 0; b < C::TNW; ++b) {
+            const int n = n0 + (wave_n * C::TNW + b) * 32 + lrow;
+            negw[b] = (uint32_t)__ballot(n < N && epi.alpha[n] < 0.0f);
+            const uint32_t my = (negw[b] >> (16 * lhalf)) & 0xFFFFu;
+            nn[b][0] = (spread8(my) << 3) | 0x22222222u;
+            nn[b][1] = (spread8(my >> 8) << 3) | 0x22222222u;
+        }
+#pragma unroll
+        for (int a = 0; a < C::TMW; ++a) {
+            const int m = m0 + (wave_m * C::TMW + a) * 32 + lrow;
+            if (epi.mode == 3) {
+                int orow = m;
+                if (epi.ohy | epi.ohx) {
+                    const unsigned um = (unsigned)m;
+                    unsigned img, ho, wo;
+                    if (cg.sh_w >= 0) {
+                        img = um >> cg.sh_hw;
+                        const unsigned rem = um & (unsigned)(cg.Ho * cg.Wo - 1);
+                        ho = rem >> cg.sh_w;
+                        wo = rem & (unsigned)(cg.Wo - 1);
+                    } else {
+                        img = epi.magic_hw ? (unsigned)__umul64hi((unsigned long long)um, epi.magic_hw) : um;
+                        const unsigned rem = um - img * (unsigned)(cg.Ho * cg.Wo);
+                        ho = epi.magic_w ? (unsigned)__umul64hi((unsigned long long)rem, epi.magic_w) : rem;
+                        wo = rem - ho * (unsigned)cg.Wo;
+                    }
+                    orow = (int)((img * ((unsigned)cg.Ho + 2u * (unsigned)epi.ohy) + ho + (unsigned)epi.ohy) *
+                                     ((unsigned)cg.Wo + 2u * (unsigned)epi.ohx) + wo + (unsigned)epi.ohx);
+                }
+                uint32_t* dst = B + (int64_t)orow * ldy + lhalf * 2;
+#pragma unroll
+                for (int b = 0; b < C::TNW; ++b) {
+                    const int nb = n0 + (wave_n * C::TNW + b) * 32;
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int r = 7; r >= 0; --r) lo = __builtin_amdgcn_alignbit(lo, __float_as_uint(acc[a][b][r]), 28);
+#pragma unroll
+                    for (int r = 15; r >= 8; --r) hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc[a][b][r]), 28);
+                    if (m < M && nb < N)
+                        *reinterpret_cast<uint2*>(dst + (nb >> 3)) = make_uint2((lo & 0x88888888u) ^ nn[b][0], (hi & 0x88888888u) ^ nn[b][1]);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < C::TNW; ++b) {
+                    const int nb = n0 + (wave_n * C::TNW + b) * 32;
+                    uint32_t w16 = 0;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) w16 = __builtin_amdgcn_alignbit(w16, __float_as_uint(acc[a][b][r]), 31);
+                    // both halves' 16 bits into every lane: v_permlane32_swap leaves the low half's value in x, the high half's in y
+                    const auto sw = __builtin_amdgcn_permlane32_swap(w16, w16, false, false);
+                    const uint32_t word = ((sw[1] << 16) | sw[0]) ^ negw[b];
+                    const int wcol = nb >> 5;
+                    if (lane < 32 && m < M && nb < N && wcol < ldy) B[(int64_t)m * ldy + wcol] = word;
+                    // the row's pad words past the last column tile (ldy rounds ceil(N/32) up to 4) are zeroed here
+                    if (b == C::TNW - 1 && wave_n == C::WN - 1 && n0 + C::TN >= N && lane < 32 && m < M)
+                        for (int wc = (N + 31) >> 5; wc < ldy; ++wc) B[(int64_t)m * ldy + wc] = 0u;
+                }
+            }
+        }
+        return;
+    }
     if constexpr (DEVBN) if (epi.mode == 4) {
         // fp32 output through eval-mode BatchNorm in the DEVICE's arithmetic (the conv -> BatchNorm shortcut branch of a DoReFa ResNet
         // block): y = fma(fl(fl(v - mean) * rs), weight, bias) on the value v the plain epilogue would have stored — the expression of
@@ -1425,3 +1530,14 @@ static int conv_prepare(int elem, const uint32_t*& P, int64_t Nimg, int64_t H, i
 }
 
 }  // namespace
+
+// The tile configuration CFG for element E — or, for fp4 convs whose threshold epilogue has integer thresholds (swapt), its
+// weights-as-rows instantiation (ElemFp4T, mfma_gemm_kernel.h).  Only the four configurations the fused AlexNet / VGG-16 chains
+// launch exist in that form; every other one keeps the compare epilogue.
+template <template <class> class CFG, class E, class... A>
+int launch_cfg_t(bool swapt, A&&... a) {
+    if constexpr (std::is_same<E, ElemFp4>::value) {
+        if (swapt) return launch_cfg<CFG<ElemFp4T>>(a...);
+    }
+    return launch_cfg<CFG<E>>(a...);
+}

@@ -350,3 +350,49 @@ def test_vgg_first_layer_module_and_fused_routes_share_the_first3x3_kernel(dev):
             got = got.value()
         assert _lib.call_counts["qt_conv3x3_first_f32"] == c0 + 2
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,N,H,W,kind", [
+    (192, 576, 5, 4, 27, 27, "binary"),      # AlexNet conv2: 384 x 192 ping-pong tile
+    (576, 1152, 3, 8, 13, 13, "binary"),     # conv3: 256 x 192 ping-pong
+    (1152, 768, 3, 8, 13, 13, "ternary"),    # conv4: 256 x 256 ping-pong
+    (768, 256, 3, 3, 13, 13, "binary"),      # conv5
+    (128, 128, 3, 2, 56, 56, "ternary"),     # VGG conv2_2: 256 x 128 tiles, two workgroups per CU
+    (256, 256, 3, 2, 28, 28, "ternary"),     # conv3_2
+    (512, 512, 3, 3, 14, 9, "binary"),       # conv4_2 / conv5 (ragged last row tile)
+    (64, 64, 3, 1, 5, 7, "ternary"),         # one partial tile
+])
+def test_sign_bit_threshold_epilogue_equals_the_compare_form(dev, monkeypatch, Cin, Cout, k, N, H, W, kind):
+    """fp4 convs with integer thresholds: the weights-as-rows kernels (ElemFp4T: start values -(T - 1/2), bit = the accumulator's
+    sign, csrc/mfma_gemm_kernel.h) against the compare form (QT_NO_SWAPT=1) and the float epilogue — bit planes and the next
+    conv's nibble halo planes, bit for bit, with negative / zero slopes and constant predicates among the channels."""
+    from pytorch_quantize_impls_amd import ops
+    pd = k // 2
+    x = t32(synth.pm1(71, (N, Cin, H, W)), dev).contiguous(memory_format=torch.channels_last)
+    bits = ops.sign_pack(x.permute(0, 2, 3, 1).contiguous())[0]
+    px = ops.bits_to_nib_pad(bits, N, H, W, (pd, pd), ld=ops.pixel_ld_nib(Cin))
+    wp = ops.pack_conv_weight_nib(t32(synth.uniform(72, (Cout, Cin, k, k), -1, 1), dev), kind)
+    b = t32(synth.uniform(73, (Cout,), -4, 4), dev)
+    alpha = t32(synth.uniform(74, (Cout,), -0.2, 0.2), dev)
+    beta = t32(synth.uniform(75, (Cout,), -8, 8), dev)
+    alpha[0] = 0.0
+    alpha[1], beta[1] = 0.0, -1.0
+    beta[2], beta[3] = 1e6, -1e6
+    alpha[5], beta[5] = -0.0, 1.0
+    thr = ops.integer_thresholds(b, alpha, beta, Cin * k * k)
+    args = (px, (N, Cin, H + 2 * pd, W + 2 * pd), wp, (k, k), b, 1, 0, 1)
+    want_bits = ops.conv2d_nib(*args, epi=(alpha, beta))
+    want_nib = ops.conv2d_nib(*args, epi=ops.NibEpilogue(alpha, beta, (1, 1)))
+    assert 0.02 < float((want_bits.sign != 0).float().mean())
+    monkeypatch.setenv("QT_NO_SWAPT", "1")
+    cmp_bits = ops.conv2d_nib(*args, epi=(alpha, beta, thr))
+    cmp_nib = ops.conv2d_nib(*args, epi=ops.NibEpilogue(alpha, beta, (1, 1), thr=thr))
+    monkeypatch.delenv("QT_NO_SWAPT")
+    for shape in (want_bits.sign.shape, want_nib.words.shape):          # poison what torch.empty will hand out
+        junk = torch.full(tuple(shape), 0x55555555, dtype=torch.int32, device=dev)
+        del junk
+    got_bits = ops.conv2d_nib(*args, epi=(alpha, beta, thr))
+    got_nib = ops.conv2d_nib(*args, epi=ops.NibEpilogue(alpha, beta, (1, 1), thr=thr))
+    assert torch.equal(cmp_bits.sign, want_bits.sign) and torch.equal(cmp_nib.words, want_nib.words)
+    assert torch.equal(got_bits.sign, want_bits.sign)
+    assert torch.equal(got_nib.words, want_nib.words)
