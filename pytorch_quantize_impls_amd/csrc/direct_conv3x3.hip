@@ -529,11 +529,11 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                     const bool in = off < lim;
                     const bool valid = in && (unsigned)(y - 1) < (unsigned)g.H && (unsigned)(x - 1) < (unsigned)g.W;
                     if (g.out_bits) {
-                        // bit plane, one column tile (WN == 1; the host sends nothing else here): the two lane halves hold bits
+                        // bit plane (one column wave, or two with 64 channels each; the host sends nothing else here): the two lane halves hold bits
                         // 0-15 / 16-31 of every block's word.  One v_permlane32_swap per pair of blocks completes block 2p's word in
                         // the low half and block 2p + 1's in the high half; a second one brings a position's words together:
                         // 4 blocks -> 8 bytes per lane (words 0-1 low half, 2-3 high half), 2 blocks -> the low half stores the row
-                        if constexpr (WN == 1 && (TNW == 2 || TNW == 4)) {
+                        if constexpr ((WN == 1 && (TNW == 2 || TNW == 4)) || (WN == 2 && TNW == 2)) {
                             // row = mrow0 + off - 2 k - 2 W ky (a row carry skips 2 halo pixels, an image carry 2 halo rows): the
                             // tile's part is a scalar product, the lane's part small enough for a 24-bit multiply
                             const unsigned vo = (unsigned)mrow0 * (unsigned)(g.ldo * 4) +
@@ -556,6 +556,10 @@ __global__ __launch_bounds__(256 * WN, OCC) void direct3x3_kernel(D3Args g) {
                                 if (valid) __builtin_amdgcn_raw_buffer_store_b64(v, ors, (int)(vo + (unsigned)(lhalf * 8)), 0, 0);
                             } else {
                                 const auto s2 = __builtin_amdgcn_permlane32_swap(word[0], word[0], false, false);
+                                if constexpr (WN == 2) {            // 128 channels over two column waves: each stores its two words
+                                    const d3_u2 v = {s2[0], s2[1]};
+                                    if (valid && lhalf == 0) __builtin_amdgcn_raw_buffer_store_b64(v, ors, (int)(vo + (unsigned)(wave_n * 8)), 0, 0);
+                                } else
                                 if (valid && lhalf == 0) {
                                     if (g.ldo == 4) {
                                         const d3_u4 v = {s2[0], s2[1], 0u, 0u};
@@ -694,7 +698,7 @@ extern "C" int qt_conv3x3_direct_nib(int elem, const uint32_t* P, int64_t N, int
         static const bool general = [] { const char* e = getenv("QT_D3_EPI"); return e && e[0] == 'g'; }();
         const long long out_bytes = out_bits ? N * H * W * ldo * 4 : g.total * ldo * 4;
         const bool whole = Cout == 64 || Cout == 128;      // every column block of the tile shapes below is a real one
-        const bool bits_ok = Cw == 8 && (Cout == 128 ? ldo == 4 : (ldo == 4 || ldo == 2));
+        const bool bits_ok = Cout == 128 ? ldo == 4 : (Cw == 8 && (ldo == 4 || ldo == 2));
         g.epi32 = (elem == 0 && !general && whole && out_bytes < (1ll << 32) && (!out_bits || bits_ok)) ? 1 : 0;
         g.out_bytes = g.epi32 ? (unsigned)out_bytes : 0u;
         g.m20_wp = (unsigned)(((1u << 20) + g.Wp - 1) / g.Wp);

@@ -31,7 +31,7 @@ CONV_IMPLICIT = True
 # process can hold different routes: SURVEY 8e "one process, one stream per device"); library code reads every switch through
 # ``_cfg``.  The autograd Functions of the package record the scope their forward ran under and re-open it around their backward
 # (functions.common.QtFunction), like ``float_split``.
-_SCOPED = ("FIRST_DIRECT", "CONV_IMPLICIT", "POPC_VARIANT", "CONV_VARIANT", "ASSUME_CODES_FIT", "PAD_PIXEL_PLANES", "FIRST_3X3")
+_SCOPED = ("FIRST_DIRECT", "CONV_IMPLICIT", "POPC_VARIANT", "CONV_VARIANT", "ASSUME_CODES_FIT", "PAD_PIXEL_PLANES", "FIRST_3X3", "DIRECT_BITS_128")
 _scope_tls = threading.local()
 
 
@@ -1318,6 +1318,8 @@ def pad_pixel_plane(words: torch.Tensor, N: int, H: int, W: int, padding) -> tor
 #: (qt_conv3x3_direct_nib: the tile's input patch is loaded once instead of gathered per tap; tools/bench_direct_conv.py,
 #: batch 256: 64->64 at 224^2 620 -> 366 us, 64->128 at 112^2 246 -> 167 us, 128->128 at 112^2 328 -> 281 us)
 DIRECT_CONV3X3 = True
+#: 128 -> 128 channels with a bit-plane epilogue (VGG conv2_2, pooled) on the direct kernel as well
+DIRECT_BITS_128 = True
 
 
 def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dilation, in_halo, epi) -> bool:
@@ -1326,9 +1328,8 @@ def direct_conv3x3_applicable(C: int, Cout: int, kernel_hw, stride, padding, dil
         return False
     if isinstance(epi, NibEpilogue):
         return tuple(epi.out_halo) == (1, 1) and not epi.d2s_cout
-    # bit-plane output with 128 input channels: the implicit GEMM is as fast or faster (VGG conv4 in the network: 207 vs
-    # 240 us), nibble output is where the direct form wins there (275 vs 321 us)
-    return isinstance(epi, tuple) and len(epi) in (2, 3) and pixel_ld_nib(C) == 8
+    # bit-plane output with 128 input channels: only the whole-tile 128 -> 128 shape, which has the lean epilogue (round 6)
+    return isinstance(epi, tuple) and len(epi) in (2, 3) and (pixel_ld_nib(C) == 8 or (_cfg("DIRECT_BITS_128") and Cout == 128))
 
 
 def conv3x3_direct_nib(pixels, N: int, C: int, H: int, W: int, wplanes, bias, epi):

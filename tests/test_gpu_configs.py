@@ -247,11 +247,10 @@ def test_c5_ternary_vgg16_fused_matches_unfused(dev):
         used = {k: v - before.get(k, 0) for k, v in _lib.call_counts.items() if v - before.get(k, 0)}
         # 13 convs: the 5 in front of a pool emit threshold bits, the 8 that feed another conv directly (the real-input
         # first layer included) emit that conv's nibble operand; 4 of the 5 pools do the same (the last feeds the FC)
-        # ... and conv1 (real input, fp16 pair planes), conv2 (-> bits) and conv3 (-> nibbles) take the direct 3x3 kernel
-        # (conv4, 128 -> 128 with a bit-plane output, is as fast on the implicit GEMM)
-        assert used.get("qt_conv2d_implicit_bits") == 4 and used.get("qt_conv2d_implicit_nib") == 6, used
+        # ... and conv2 (-> bits), conv3 (-> nibbles) and, since round 6, conv4 (128 -> 128 -> bits) take the direct 3x3 kernel
+        assert used.get("qt_conv2d_implicit_bits") == 3 and used.get("qt_conv2d_implicit_nib") == 6, used
         # (conv1, real input 3 -> 64: since round 6 the one-pass kernel qt_conv3x3_first_f32 — fp32 image in, nibble halo plane out)
-        assert used.get("qt_conv3x3_direct_nib") == 2 and used.get("qt_conv3x3_first_f32") == 1 and "qt_conv3x3_direct_pairs" not in used, used
+        assert used.get("qt_conv3x3_direct_nib") == 3 and used.get("qt_conv3x3_first_f32") == 1 and "qt_conv3x3_direct_pairs" not in used, used
         assert used.get("qt_pool_bits_nib") == 4 and used.get("qt_pool_bits") == 1, used
         assert "qt_bits_to_nib_pad" not in used, used               # no bit plane is expanded in a second pass
         with lazy.eager():
