@@ -498,6 +498,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
     // ring of 3 / 4 stage buffers on the small-map tiles (ConvV128x128D / ConvV128x64D); QT_NO_CONV_DEEP_RING=1: the double-buffered
     // configurations of round 4 (A/B runs and the bit-identity test; read per call like the direct kernel's switches)
     const bool deep_ring = !getenv("QT_NO_CONV_DEEP_RING");
+    // fewer 256-row tiles than this: 128 x 128 tiles with the deep ring (QT_SMALL_GRID: A/B runs)
+    const long long small_grid = getenv("QT_SMALL_GRID") ? atoll(getenv("QT_SMALL_GRID")) : 128;
+    const long long small_tiles = getenv("QT_SMALL_TILES") ? atoll(getenv("QT_SMALL_TILES")) : 512;
     // weights-as-rows threshold epilogue (sign-bit form): fp4, integer thresholds, whole 32-channel blocks, bit plane or nibble plane
     // out, no depth-to-space; QT_NO_SWAPT=1: the compare form (A/B runs and the bit-identity test; read per call like the line above)
     const bool swapt = elem == 0 && epi.alpha && epi.thr && (Cout & 31) == 0 && !epi.d2s_cout && (epi.mode == 0 || epi.mode == 3) &&
@@ -511,7 +514,7 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                 (M <= 4096 || (((M + 255) / 256) * ((Cout + tn - 1) / tn) < 256 &&                              \
                                (M / 64) * Cout * kwords * 4 <= (256ll << 20)))) {                               \
                 if (M > 4096 && ((M + 127) / 128) * ((Cout + 127) / 128) >= 200) {                             \
-                    if (deep_ring) return launch_cfg<ConvV128x128D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+                    if (deep_ring) return launch_cfg_t<ConvV128x128D, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                     return launch_cfg<ConvV128x128<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
                 }                                                                                               \
                 if (((M + 127) / 128) * ((Cout + 63) / 64) >= 200) { /* 512 ch @ 4x4: 128x64 tiles, 256-byte stages */ \
@@ -526,9 +529,9 @@ static int conv_implicit_impl(int elem, const uint32_t* P, int64_t Nimg, int64_t
                 return launch_cfg_t<ConvV128x2, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             /* a few big tiles on a small map (128 -> 256 stride 2 @ 16x16, K = 1152 B: 64 tiles of 256x256): 128x128 tiles */ \
             /* with the deep ring give every CU one                                                                        */ \
-            if (g_conv_force == 0 && deep_ring && !epi.d2s_cout && ((M + 255) / 256) * ((Cout + tn - 1) / tn) <= 128 &&    \
-                ((M + 127) / 128) * ((Cout + 127) / 128) >= 200 && ((M + 127) / 128) * ((Cout + 127) / 128) <= 512)        \
-                return launch_cfg<ConvV128x128D<E>>(P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
+            if (g_conv_force == 0 && deep_ring && !epi.d2s_cout && ((M + 255) / 256) * ((Cout + tn - 1) / tn) <= small_grid && \
+                ((M + 127) / 128) * ((Cout + 127) / 128) >= 200 && ((M + 127) / 128) * ((Cout + 127) / 128) <= small_tiles) \
+                return launch_cfg_t<ConvV128x128D, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
             if (g_conv_force != 1) {                                                                            \
                 if (tn == 192 && (g_conv_force == 2 || prefer_384_rows(M, Cout)))                               \
                     return launch_cfg_t<ConvVPP192, E>(swapt, P, 0, Wmat, ldwp, bias, scale, scale_dev, Y, ldy, M, Cout, K, stream, cg, epi); \
