@@ -116,8 +116,12 @@ __global__ __launch_bounds__(1024) void sqdev_kernel(const float* __restrict__ p
 constexpr int TC_FY = 16;
 __device__ __forceinline__ double fold_partials(const float* __restrict__ part, int nblk, int C, int c, double (*sh)[64]) {
     double s = 0.0;
-    if (c < C)
+    if (c < C) {
+        // eight loads in flight per thread (same summation order): rolled, the loop was one L2 round trip per partial — 9.5 us for
+        // 512 partials (profiles/r6_train_steps.md)
+#pragma unroll 8
         for (int b = threadIdx.y; b < nblk; b += TC_FY) s += (double)part[(int64_t)b * C + c];
+    }
     sh[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0) {
