@@ -220,8 +220,8 @@ struct ElemFp4TapsRows : ElemFp4Taps {
 // accumulator register r of lane (l % 32, l / 32) is (position l % 32, channel 16 (l / 32) + r): a lane owns 16 consecutive channels
 // of ONE output pixel.  The accumulators start at -(T_c - 1/2) (T_c = the integer threshold of EpiArgs::thr), so the threshold bit
 // is the accumulator's sign bit and the epilogue is one v_alignbit per value — no compare, no cross-lane gather, no nibble spread
-// (the v_cmp / v_writelane / spread8 form was 8 VALU instructions per value: 60 % of the kernel's VALU issue, and VALU and MFMA
-// issue add up on a SIMD: profiles/r6_threshold_epilogue.md).
+// (the v_cmp / v_writelane / spread8 form was 131 VALU instructions per 32 x 32 block against ~25; with one tile per workgroup and one
+// workgroup per CU nothing overlaps a tile's epilogue: profiles/r6_threshold_epilogue.md).
 struct ElemFp4T : ElemFp4 {
     static constexpr bool SWAPT = true;
     __device__ __forceinline__ static acc_t mfma(const uint4& a, const uint4& b, acc_t c) { return ElemFp4::mfma(b, a, c); }
